@@ -1,0 +1,483 @@
+// cvgs_api.cpp -- the C-ABI (include/cvgs_hip.h): validation, host-side lowering of a chain
+// descriptor to kernel arguments, kernel selection, CircularTensor handles.
+// No CPU compute fallback exists: if HIP cannot launch, the call fails loudly.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cvgs_device.h"
+
+using namespace cvgs;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(CVGS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+int depth_bytes(int depth) {
+    switch (depth) {
+    case CVGS_DEPTH_8U: case CVGS_DEPTH_8S: return 1;
+    case CVGS_DEPTH_16U: case CVGS_DEPTH_16S: return 2;
+    case CVGS_DEPTH_32S: case CVGS_DEPTH_32F: return 4;
+    case CVGS_DEPTH_64F: return 8;
+    }
+    return 0;
+}
+
+bool is_resize(int kind) { return kind == CVGS_READ_RESIZE_LINEAR || kind == CVGS_READ_NV12_RESIZE_LINEAR; }
+bool is_nv12(int kind) { return kind == CVGS_READ_NV12 || kind == CVGS_READ_NV12_RESIZE_LINEAR; }
+
+// Host half of fk::Resize::build: the kernel-side scale factors and the aspect-ratio window.
+// IGNORE_AR follows cv::cuda::resize's host code (scale = float(1.0 / (double(dst)/src))).
+// PRESERVE_AR* fits the source inside the target keeping its aspect ratio (scale by height, fall
+// back to width), centred (or left-aligned), extent rounded to nearest (RN_EVEN: down to even).
+void plane_geometry(int sw, int sh, int dw, int dh, int ar, PlaneParams& P) {
+    int tw = dw, th = dh, x0 = 0, y0 = 0;
+    if (ar != CVGS_IGNORE_AR) {
+        float s = (float)dh / (float)sh;
+        tw = (int)std::round(s * (float)sw);
+        if (ar == CVGS_PRESERVE_AR_RN_EVEN) tw -= tw % 2;
+        if (tw > dw) {
+            s = (float)dw / (float)sw;
+            tw = dw;
+            th = (int)std::round(s * (float)sh);
+            if (ar == CVGS_PRESERVE_AR_RN_EVEN) th -= th % 2;
+        }
+        tw = tw < 1 ? 1 : tw;
+        th = th < 1 ? 1 : th;
+        x0 = ar == CVGS_PRESERVE_AR_LEFT ? 0 : (dw - tw) / 2;
+        y0 = (dh - th) / 2;
+    }
+    P.fx = (float)(1.0 / ((double)tw / (double)sw));
+    P.fy = (float)(1.0 / ((double)th / (double)sh));
+    P.x1 = x0;
+    P.y1 = y0;
+    P.x2 = x0 + tw - 1;
+    P.y2 = y0 + th - 1;
+}
+
+struct Lowered {
+    ChainArgs args{};
+    std::vector<PlaneParams> planes;  // host copy (inline or to upload)
+    std::vector<DstPlane> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
+    int out_w = 0, out_h = 0;
+    int final_depth = 0, final_cn = 0;
+};
+
+// Type-state walk over the pointwise stages: what the reference enforces at compile time through
+// IOp input/output types.
+int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, int* out_cn) {
+    for (int k = 0; k < ch->n_ops; ++k) {
+        const cvgs_op& op = ch->ops[k];
+        switch (op.opcode) {
+        case CVGS_OP_NOP: break;
+        case CVGS_OP_CAST:
+            if (op.aux < CVGS_DEPTH_8U || op.aux > CVGS_DEPTH_64F) return fail(CVGS_ERR_INVALID, "CAST: bad destination depth");
+            if (op.aux == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "CAST: 64F is not supported yet");
+            depth = op.aux;
+            break;
+        case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
+            if (depth != CVGS_DEPTH_32F)
+                return fail(CVGS_ERR_UNSUPPORTED, "arithmetic stages are implemented for CV_32F values only");
+            break;
+        case CVGS_OP_REORDER:
+            for (int c = 0; c < cn; ++c)
+                if (((op.aux >> (2 * c)) & 3) >= cn) return fail(CVGS_ERR_INVALID, "REORDER: source channel out of range");
+            break;
+        case CVGS_OP_ADD_ALPHA:
+            if (cn != 3) return fail(CVGS_ERR_INVALID, "ADD_ALPHA needs a 3-channel value");
+            cn = 4;
+            break;
+        case CVGS_OP_DROP_ALPHA:
+            if (cn != 4) return fail(CVGS_ERR_INVALID, "DROP_ALPHA needs a 4-channel value");
+            cn = 3;
+            break;
+        case CVGS_OP_GRAY:
+            if (cn < 3) return fail(CVGS_ERR_INVALID, "GRAY needs a 3- or 4-channel value");
+            if (depth == CVGS_DEPTH_32S) return fail(CVGS_ERR_UNSUPPORTED, "GRAY on CV_32S");
+            cn = 1;
+            break;
+        default: return fail(CVGS_ERR_INVALID, "unknown opcode");
+        }
+    }
+    *out_depth = depth;
+    *out_cn = cn;
+    return CVGS_OK;
+}
+
+int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
+    if (!ch) return fail(CVGS_ERR_INVALID, "null chain");
+    if (ch->struct_size != sizeof(cvgs_chain_desc)) return fail(CVGS_ERR_INVALID, "cvgs_chain_desc size mismatch (ABI)");
+    if (ch->n_ops < 0 || ch->n_ops > CVGS_MAX_OPS) return fail(CVGS_ERR_INVALID, "n_ops out of range");
+    const cvgs_read_desc& rd = ch->read;
+    const cvgs_write_desc& wr = ch->write;
+    if (rd.kind < CVGS_READ_PIXEL || rd.kind > CVGS_READ_NV12_RESIZE_LINEAR) return fail(CVGS_ERR_INVALID, "bad read kind");
+    if (rd.batch < 1 || rd.batch > 65535) return fail(CVGS_ERR_INVALID, "batch must be in [1, 65535]");
+    if (rd.used_planes < 0 || rd.used_planes > rd.batch) return fail(CVGS_ERR_INVALID, "used_planes out of range");
+    if (!rd.src) return fail(CVGS_ERR_INVALID, "read.src is null");
+    const int sdepth = CVGS_TYPE_DEPTH(rd.src_type), scn = CVGS_TYPE_CN(rd.src_type);
+    if (sdepth > CVGS_DEPTH_64F || scn > 4) return fail(CVGS_ERR_INVALID, "bad source type");
+    if (sdepth == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "CV_64F sources are not supported yet");
+    if (is_nv12(rd.kind) && rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
+        return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
+    if (is_resize(rd.kind)) {
+        if (rd.dst_width < 1 || rd.dst_height < 1) return fail(CVGS_ERR_INVALID, "resize target must be positive");
+        if (rd.aspect_ratio < CVGS_PRESERVE_AR || rd.aspect_ratio > CVGS_PRESERVE_AR_LEFT)
+            return fail(CVGS_ERR_INVALID, "bad aspect ratio mode");
+    }
+    const bool table = (rd.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
+
+    // ---- read stage ----
+    ReadArgs& R = L.args.read;
+    R.kind = rd.kind;
+    R.depth = sdepth;
+    R.cn = scn;
+    R.batch = rd.batch;
+    R.used = rd.used_planes;
+    R.is_resize = is_resize(rd.kind);
+    for (int c = 0; c < 4; ++c) R.bg[c] = rd.background[c];
+    R.yuv_range = rd.yuv_range;
+    R.yuv_primaries = rd.yuv_primaries;
+    R.yuv_alpha = rd.yuv_alpha;
+    R.out_cn = is_nv12(rd.kind) ? (rd.yuv_alpha ? 4 : 3) : scn;
+    R.table = nullptr;
+
+    if (table) {
+        R.table = (const PlaneParams*)rd.src;
+        L.out_w = rd.dst_width;
+        L.out_h = rd.dst_height;
+        if (L.out_w < 1 || L.out_h < 1)
+            return fail(CVGS_ERR_INVALID, "device plane tables need dst_width/dst_height (the plane extent)");
+    } else {
+        const cvgs_image2d* src = (const cvgs_image2d*)rd.src;
+        L.planes.assign((size_t)rd.batch, PlaneParams{});
+        for (int z = 0; z < rd.used_planes; ++z) {
+            const cvgs_image2d& im = src[z];
+            if (!im.data || im.width < 1 || im.height < 1) return fail(CVGS_ERR_INVALID, "empty source plane");
+            const int esz = depth_bytes(sdepth) * scn;
+            if (im.step < im.width * esz) return fail(CVGS_ERR_INVALID, "source step smaller than a row");
+            if (is_nv12(rd.kind) && ((im.width & 1) || (im.height & 1)))
+                return fail(CVGS_ERR_INVALID, "NV12 planes need even dimensions");
+            PlaneParams& P = L.planes[(size_t)z];
+            P.data = (const uint8_t*)im.data;
+            P.w = im.width;
+            P.h = im.height;
+            P.step = im.step;
+            if (R.is_resize) plane_geometry(im.width, im.height, rd.dst_width, rd.dst_height, rd.aspect_ratio, P);
+            else if (im.width != src[0].width || im.height != src[0].height)
+                return fail(CVGS_ERR_INVALID, "batched pixel reads need planes of one size");
+        }
+        if (R.is_resize) {
+            L.out_w = rd.dst_width;
+            L.out_h = rd.dst_height;
+        } else if (rd.used_planes > 0) {
+            L.out_w = src[0].width;
+            L.out_h = src[0].height;
+        } else {
+            L.out_w = wr.width;
+            L.out_h = wr.height;
+        }
+    }
+    R.dst_w = L.out_w;
+    R.dst_h = L.out_h;
+
+    // ---- pointwise stages ----
+    ProgArgs& Pg = L.args.prog;
+    int n = 0;
+    for (int k = 0; k < ch->n_ops; ++k) {
+        if (ch->ops[k].opcode == CVGS_OP_NOP) continue;
+        Pg.opcode[n] = ch->ops[k].opcode;
+        Pg.aux[n] = ch->ops[k].aux;
+        for (int c = 0; c < 4; ++c) Pg.operand[n][c] = ch->ops[k].operand[c];
+        ++n;
+    }
+    Pg.n = n;
+    const int d0 = (R.is_resize || is_nv12(rd.kind)) ? CVGS_DEPTH_32F : sdepth;
+    int rc = walk_program(ch, d0, R.out_cn, &L.final_depth, &L.final_cn);
+    if (rc) return rc;
+
+    // ---- write stage ----
+    if (wr.kind < CVGS_WRITE_PIXEL_2D || wr.kind > CVGS_WRITE_PIXEL_2D_BATCH) return fail(CVGS_ERR_INVALID, "bad write kind");
+    if (CVGS_TYPE_DEPTH(wr.dst_type) != L.final_depth || CVGS_TYPE_CN(wr.dst_type) != L.final_cn)
+        return fail(CVGS_ERR_INVALID, "write type does not match the type produced by the last stage");
+    WriteArgs& Wa = L.args.write;
+    Wa.kind = wr.kind;
+    Wa.depth = L.final_depth;
+    Wa.cn = L.final_cn;
+    Wa.width = L.out_w;
+    Wa.height = L.out_h;
+    Wa.step = wr.step;
+    Wa.planes = wr.planes;
+    Wa.data = (uint8_t*)wr.data;
+    Wa.table = nullptr;
+    const bool tensor_kind = wr.kind == CVGS_WRITE_PIXEL_3D || wr.kind == CVGS_WRITE_TENSOR_SPLIT ||
+                             wr.kind == CVGS_WRITE_TENSOR_T_SPLIT;
+    if (tensor_kind || wr.kind == CVGS_WRITE_PIXEL_2D) {
+        if (!circular && !wr.data) return fail(CVGS_ERR_INVALID, "write.data is null");
+        if (!circular && (wr.width != L.out_w || wr.height != L.out_h))
+            return fail(CVGS_ERR_INVALID, "write plane size differs from the size produced by the read stage");
+    }
+    if (tensor_kind && !circular && wr.planes < rd.batch) return fail(CVGS_ERR_INVALID, "tensor has fewer planes than the batch");
+    if (wr.kind == CVGS_WRITE_PIXEL_2D) {
+        if (rd.batch != 1) return fail(CVGS_ERR_INVALID, "PIXEL_2D writes one image: batch must be 1");
+        if (wr.step < L.out_w * depth_bytes(L.final_depth) * L.final_cn) return fail(CVGS_ERR_INVALID, "write step smaller than a row");
+    }
+    if (wr.kind == CVGS_WRITE_SPLIT_2D || wr.kind == CVGS_WRITE_PIXEL_2D_BATCH) {
+        if (!wr.planes2d) return fail(CVGS_ERR_INVALID, "write.planes2d is null");
+        if (wr.kind == CVGS_WRITE_SPLIT_2D && L.final_cn < 2)
+            return fail(CVGS_ERR_INVALID, "split needs 2, 3 or 4 channels"); // cvGPUSpeedupHelpers.cuh:76
+        const int per = wr.kind == CVGS_WRITE_SPLIT_2D ? L.final_cn : 1;
+        const int esz = depth_bytes(L.final_depth) * (wr.kind == CVGS_WRITE_SPLIT_2D ? 1 : L.final_cn);
+        L.dst_planes.resize((size_t)rd.batch * per);
+        for (size_t i = 0; i < L.dst_planes.size(); ++i) {
+            const cvgs_image2d& im = wr.planes2d[i];
+            if (!im.data || im.width != L.out_w || im.height != L.out_h || im.step < im.width * esz)
+                return fail(CVGS_ERR_INVALID, "destination plane missing or of the wrong size");
+            L.dst_planes[i].data = (uint8_t*)im.data;
+            L.dst_planes[i].step = im.step;
+            L.dst_planes[i].pad = 0;
+        }
+    }
+    return CVGS_OK;
+}
+
+// Stream-ordered scratch for descriptor tables that do not fit the kernel-argument block.
+struct AsyncTable {
+    void* dev = nullptr;
+    hipStream_t stream = nullptr;
+    int upload(const void* host, size_t bytes, hipStream_t s) {
+        stream = s;
+        hipError_t e = hipMallocAsync(&dev, bytes, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(descriptor table)");
+        e = hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptor table)");
+        return 0;
+    }
+    ~AsyncTable() {
+        if (dev) (void)hipFreeAsync(dev, stream);
+    }
+};
+
+int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry_run, LaunchInfo* info) {
+    AsyncTable src_tab, dst_tab;
+    const PlaneParams* inline_planes = L.planes.data();
+    int n_inline = (int)L.planes.size();
+    if (!L.args.read.table && n_inline > CVGS_KERNARG_PLANES) {
+        if (!dry_run) {
+            int rc = src_tab.upload(L.planes.data(), L.planes.size() * sizeof(PlaneParams), stream);
+            if (rc) return rc;
+            L.args.read.table = (const PlaneParams*)src_tab.dev;
+        } else {
+            L.args.read.table = (const PlaneParams*)(uintptr_t)16; // any non-null: selects the table variants
+        }
+        inline_planes = nullptr;
+        n_inline = 0;
+    }
+    if (!L.dst_planes.empty()) {
+        if ((int)L.dst_planes.size() <= kInlineDst) {
+            for (size_t i = 0; i < L.dst_planes.size(); ++i) L.args.dst_inline[i] = L.dst_planes[i];
+        } else if (!dry_run) {
+            int rc = dst_tab.upload(L.dst_planes.data(), L.dst_planes.size() * sizeof(DstPlane), stream);
+            if (rc) return rc;
+            L.args.write.table = (const DstPlane*)dst_tab.dev;
+        }
+    }
+    int rc = 0;
+    if (!(ch->flags & CVGS_CHAIN_FORCE_GENERIC)) {
+        rc = launch_k1(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
+        if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
+        if (rc == 1) return CVGS_OK;
+    }
+    rc = launch_generic(L.args, inline_planes, n_inline, stream, dry_run, info);
+    if (rc) return fail(CVGS_ERR_HIP, "generic kernel launch failed");
+    return CVGS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int cvgs_abi_version(void) { return CVGS_ABI_VERSION; }
+const char* cvgs_version_string(void) { return "cvgs-hip 0.1 (gfx950)"; }
+const char* cvgs_last_error(void) { return g_err.c_str(); }
+
+int cvgs_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(CVGS_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int cvgs_validate(const cvgs_chain_desc* chain) {
+    Lowered L;
+    return lower(chain, false, L);
+}
+
+int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream) {
+    Lowered L;
+    int rc = lower(chain, false, L);
+    if (rc) return rc;
+    return dispatch(chain, L, (hipStream_t)stream, false, nullptr);
+}
+
+int cvgs_kernel_name(const cvgs_chain_desc* chain, char* buf, size_t buf_size) {
+    if (!buf || !buf_size) return fail(CVGS_ERR_INVALID, "null buffer");
+    Lowered L;
+    int rc = lower(chain, false, L);
+    if (rc) return rc;
+    LaunchInfo info{"?"};
+    rc = dispatch(chain, L, nullptr, true, &info);
+    if (rc) return rc;
+    std::snprintf(buf, buf_size, "%s", info.kernel);
+    return CVGS_OK;
+}
+
+size_t cvgs_plane_table_bytes(int32_t batch) { return batch > 0 ? (size_t)batch * sizeof(PlaneParams) : 0; }
+
+int cvgs_plane_table_build(const cvgs_read_desc* read, void* host_out) {
+    if (!read || !host_out) return fail(CVGS_ERR_INVALID, "null argument");
+    if (read->flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) return fail(CVGS_ERR_INVALID, "read.src must be a host cvgs_image2d array");
+    cvgs_chain_desc ch;
+    std::memset(&ch, 0, sizeof(ch));
+    ch.struct_size = sizeof(ch);
+    ch.read = *read;
+    // a throw-away write stage so that lower() can be reused for validation of the read stage
+    const int out_cn = is_nv12(read->kind) ? (read->yuv_alpha ? 4 : 3) : CVGS_TYPE_CN(read->src_type);
+    const int out_depth = (is_resize(read->kind) || is_nv12(read->kind)) ? CVGS_DEPTH_32F : CVGS_TYPE_DEPTH(read->src_type);
+    ch.write.kind = CVGS_WRITE_PIXEL_3D;
+    ch.write.dst_type = CVGS_MAKETYPE(out_depth, out_cn);
+    ch.write.data = (void*)(uintptr_t)16;
+    ch.write.planes = read->batch;
+    Lowered L;
+    // extent: unknown to the caller for pixel reads, so take it from the planes
+    if (is_resize(read->kind)) { ch.write.width = read->dst_width; ch.write.height = read->dst_height; }
+    else if (read->src && read->batch > 0) {
+        ch.write.width = ((const cvgs_image2d*)read->src)[0].width;
+        ch.write.height = ((const cvgs_image2d*)read->src)[0].height;
+    }
+    int rc = lower(&ch, false, L);
+    if (rc) return rc;
+    std::memcpy(host_out, L.planes.data(), L.planes.size() * sizeof(PlaneParams));
+    return CVGS_OK;
+}
+
+// ---- CircularTensor ------------------------------------------------------------------------------
+struct cvgs_circular_s {
+    int32_t width, height, elem_type, color_planes, batch, order, cp_mode, device;
+    size_t plane_bytes; // one colour plane of one image
+    size_t image_bytes; // color_planes planes
+    uint8_t* out;       // ordered tensor handed to the user (data())
+    uint8_t* ring;      // history: update k lives in slot k % batch, standard [c][y][x] order
+    int64_t count;
+};
+
+int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
+                         int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode, int32_t device_id) {
+    if (!out) return fail(CVGS_ERR_INVALID, "null handle pointer");
+    if (width < 1 || height < 1 || color_planes < 1 || color_planes > 4 || batch < 1 || batch > 4096)
+        return fail(CVGS_ERR_INVALID, "bad CircularTensor shape");
+    const int esz = depth_bytes(CVGS_TYPE_DEPTH(elem_type)) * CVGS_TYPE_CN(elem_type);
+    if (!esz || CVGS_TYPE_DEPTH(elem_type) == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "element type");
+    if (order != CVGS_NEWEST_FIRST && order != CVGS_OLDEST_FIRST) return fail(CVGS_ERR_INVALID, "bad order");
+    if (cp_mode != CVGS_PLANES_STANDARD && cp_mode != CVGS_PLANES_TRANSPOSED) return fail(CVGS_ERR_INVALID, "bad colour-plane mode");
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    cvgs_circular_s* ct = new cvgs_circular_s{};
+    ct->width = width; ct->height = height; ct->elem_type = elem_type; ct->color_planes = color_planes;
+    ct->batch = batch; ct->order = order; ct->cp_mode = cp_mode; ct->device = device_id;
+    ct->plane_bytes = (size_t)esz * width * height;
+    ct->image_bytes = ct->plane_bytes * color_planes;
+    const size_t total = ct->image_bytes * batch;
+    e = hipMalloc((void**)&ct->out, total);
+    if (e == hipSuccess) e = hipMalloc((void**)&ct->ring, total);
+    if (e == hipSuccess) e = hipMemset(ct->out, 0, total);
+    if (e == hipSuccess) e = hipMemset(ct->ring, 0, total);
+    if (e != hipSuccess) {
+        if (ct->out) (void)hipFree(ct->out);
+        if (ct->ring) (void)hipFree(ct->ring);
+        delete ct;
+        return hip_fail(e, "CircularTensor allocation");
+    }
+    *out = ct;
+    return CVGS_OK;
+}
+
+int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_stream_t stream) {
+    if (!ct || !chain) return fail(CVGS_ERR_INVALID, "null argument");
+    cvgs_chain_desc one = *chain;
+    if (one.read.batch != 1) return fail(CVGS_ERR_INVALID, "CircularTensor::update pushes one frame: batch must be 1");
+    const int wk = one.write.kind;
+    if (wk != CVGS_WRITE_TENSOR_SPLIT && wk != CVGS_WRITE_TENSOR_T_SPLIT && wk != CVGS_WRITE_PIXEL_3D)
+        return fail(CVGS_ERR_INVALID, "CircularTensor needs a TensorSplit / TensorTSplit / TensorWrite stage");
+    // fk::CircularTensor::update static_asserts TensorTSplit for Transposed tensors
+    if ((ct->cp_mode == CVGS_PLANES_TRANSPOSED) != (wk == CVGS_WRITE_TENSOR_T_SPLIT))
+        return fail(CVGS_ERR_INVALID, "Transposed CircularTensors need TensorTSplit (and only they)");
+    const int out_cn = CVGS_TYPE_CN(one.write.dst_type);
+    if (wk == CVGS_WRITE_PIXEL_3D) {
+        if (ct->color_planes != 1 || one.write.dst_type != ct->elem_type)
+            return fail(CVGS_ERR_INVALID, "packed write needs COLOR_PLANES == 1 and the tensor's element type");
+    } else if (out_cn != ct->color_planes || CVGS_MAKETYPE(CVGS_TYPE_DEPTH(one.write.dst_type), 1) != ct->elem_type) {
+        return fail(CVGS_ERR_INVALID, "split write does not match the tensor's planes / element type");
+    }
+    // 1) new frame -> history slot (always standard plane order inside the ring)
+    const int64_t slot = ct->count % ct->batch;
+    one.write.kind = wk == CVGS_WRITE_TENSOR_T_SPLIT ? CVGS_WRITE_TENSOR_SPLIT : wk;
+    one.write.data = ct->ring + (size_t)slot * ct->image_bytes;
+    one.write.width = ct->width;
+    one.write.height = ct->height;
+    one.write.planes = 1;
+    int rc = cvgs_execute(&one, stream);
+    if (rc) return rc;
+    // 2) rebuild the ordered tensor from the history: slot z shows the frame of age z (NewestFirst)
+    //    or BATCH-1-z (OldestFirst); never-written history slots are zero.
+    CopyJob jobs[kMaxCopyJobs];
+    int n = 0;
+    for (int z = 0; z < ct->batch; ++z) {
+        const int64_t age = ct->order == CVGS_NEWEST_FIRST ? z : ct->batch - 1 - z;
+        int64_t src_slot = (ct->count - age) % ct->batch;
+        if (src_slot < 0) src_slot += ct->batch;
+        for (int c = 0; c < ct->color_planes; ++c) {
+            jobs[n].src = ct->ring + (size_t)src_slot * ct->image_bytes + (size_t)c * ct->plane_bytes;
+            jobs[n].dst = ct->cp_mode == CVGS_PLANES_TRANSPOSED
+                              ? ct->out + ((size_t)c * ct->batch + z) * ct->plane_bytes
+                              : ct->out + ((size_t)z * ct->color_planes + c) * ct->plane_bytes;
+            if (++n == kMaxCopyJobs) {
+                rc = launch_plane_copies(jobs, n, ct->plane_bytes, stream);
+                if (rc) return fail(CVGS_ERR_HIP, "CircularTensor copy launch failed");
+                n = 0;
+            }
+        }
+    }
+    if (n) {
+        rc = launch_plane_copies(jobs, n, ct->plane_bytes, stream);
+        if (rc) return fail(CVGS_ERR_HIP, "CircularTensor copy launch failed");
+    }
+    ct->count++;
+    return CVGS_OK;
+}
+
+void* cvgs_circular_data(cvgs_circular_t ct) { return ct ? ct->out : nullptr; }
+size_t cvgs_circular_bytes(cvgs_circular_t ct) { return ct ? ct->image_bytes * (size_t)ct->batch : 0; }
+int64_t cvgs_circular_updates(cvgs_circular_t ct) { return ct ? ct->count : -1; }
+
+int cvgs_circular_destroy(cvgs_circular_t ct) {
+    if (!ct) return fail(CVGS_ERR_INVALID, "null handle");
+    (void)hipFree(ct->out);
+    (void)hipFree(ct->ring);
+    delete ct;
+    return CVGS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,107 @@
+// cvgs_device.h -- structs shared by the host-side lowering (cvgs_api.cpp) and the HIP kernels.
+// Everything here crosses the host->device boundary BY VALUE inside the kernel-argument block,
+// exactly like the reference passes its IOp parameters, so one fused chain is one
+// launch with no side uploads.  Large crop lists use a device-resident plane table instead.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/cvgs_hip.h"
+
+namespace cvgs {
+
+// Per-plane read parameters, precomputed on the host in double precision so that the device never
+// re-derives a scale factor (bit-exactness of fx/fy is part of the parity contract).
+struct PlaneParams {        // 48 bytes
+    const uint8_t* data;    // pixel (0,0) of the crop / image
+    int32_t w, h;           // source extent in pixels (NV12: luma extent)
+    int32_t step;           // bytes between source rows
+    float fx, fy;           // source step per destination pixel (resize kinds)
+    int32_t x1, y1, x2, y2; // inclusive destination window fed from the source (AR modes)
+    int32_t pad;
+};
+static_assert(sizeof(PlaneParams) == 48, "PlaneParams layout");
+
+// Device plane table = PlaneParams[batch]  (cvgs_plane_table_build).
+
+struct DstPlane {           // SPLIT_2D / PIXEL_2D_BATCH targets, 16 bytes
+    uint8_t* data;
+    int32_t step;
+    int32_t pad;
+};
+
+struct ReadArgs {
+    int32_t kind;
+    int32_t depth, cn;      // source pixel type
+    int32_t batch, used;
+    int32_t dst_w, dst_h;   // extent of one output plane
+    int32_t is_resize;
+    float bg[4];
+    int32_t yuv_range, yuv_primaries, yuv_alpha;
+    int32_t out_cn;         // channels produced by the read stage
+    const PlaneParams* table; // device table, or nullptr -> planes inline in the kernel args
+};
+
+struct ProgArgs {
+    int32_t n;
+    int32_t opcode[CVGS_MAX_OPS];
+    int32_t aux[CVGS_MAX_OPS];
+    float operand[CVGS_MAX_OPS][4];
+};
+
+struct WriteArgs {
+    int32_t kind;
+    int32_t depth, cn;      // type of the value written
+    int32_t width, height;  // plane extent
+    int32_t step;           // PIXEL_2D pitch (bytes)
+    int32_t planes;         // tensor N (TensorTSplit stride)
+    int32_t pad;
+    uint8_t* data;
+    const DstPlane* table;  // device table for SPLIT_2D / PIXEL_2D_BATCH beyond the inline ones
+};
+
+static constexpr int kInlineDst = 16; // inline destination planes (e.g. batch 4 x 4 channels)
+
+struct ChainArgs {
+    ReadArgs read;
+    ProgArgs prog;
+    WriteArgs write;
+    DstPlane dst_inline[kInlineDst];
+};
+
+template <int NPLANES>
+struct KernArgs {
+    ChainArgs c;
+    PlaneParams planes[NPLANES];
+};
+// NPLANES == 0: the planes come from the device table; one dummy slot keeps the struct non-empty.
+template <>
+struct KernArgs<0> {
+    ChainArgs c;
+    PlaneParams planes[1];
+};
+static_assert(sizeof(KernArgs<CVGS_KERNARG_PLANES>) <= 4096, "kernel-argument block must fit 4 KB");
+
+// ---- launch entry points implemented in the .hip files -----------------------------------------
+struct LaunchInfo {
+    const char* kernel; // name of the kernel variant chosen
+};
+
+// generic interpreted kernel: any valid chain
+int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream,
+                   bool dry_run, LaunchInfo* info);
+
+// K1 fast path: u8 C3/C4 -> resize linear -> program -> fp32 TensorSplit / TensorTSplit.
+// Returns 1 if it took the chain, 0 if not eligible, <0 on error.
+int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
+              void* stream, bool dry_run, LaunchInfo* info);
+
+// plane-to-plane copies of the CircularTensor update (K9): dst[i] <- src[i], `bytes` each
+struct CopyJob {
+    const uint8_t* src;
+    uint8_t* dst;
+};
+static constexpr int kMaxCopyJobs = 64;
+int launch_plane_copies(const CopyJob* jobs, int n_jobs, size_t bytes, void* stream);
+
+} // namespace cvgs

@@ -1,0 +1,295 @@
+// k_common.hpp -- device-side building blocks shared by every kernel: the work pixel, the
+// pointwise program (interpreted or compile-time), saturating casts, pixel loads and the write
+// stages.  All arithmetic is strict IEEE fp32 in call order: the translation units are built with
+// -ffp-contract=off so that no product/sum is ever fused into an FMA, and HIP's default
+// correctly-rounded fp32 division is kept (the reference builds with fast-math off,
+// cmake/libs/cuda/target_generation.cmake:11-12).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cvgs_device.h"
+
+namespace cvgs {
+
+// The value flowing between stages: up to 4 channels of 32 bits.  8/16-bit integers and fp32 live
+// as floats (exact); 32S values live as raw bits (use as_int / from_int).
+struct Px {
+    float v[4];
+};
+
+__device__ __forceinline__ int as_int(float f) { return __float_as_int(f); }
+__device__ __forceinline__ float from_int(int i) { return __int_as_float(i); }
+
+// ---- fk::SaturateCast -----------------------------------------------------------------------
+// float -> integer depth: round to nearest even, clamp, NaN -> 0 (cv::saturate_cast on the GPU).
+__device__ __forceinline__ float sat_round(float v, float lo, float hi) {
+    float r = rintf(v);          // v_rndne_f32
+    r = (v != v) ? 0.f : r;
+    return fminf(fmaxf(r, lo), hi);
+}
+
+__device__ __forceinline__ int sat_round_s32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return -2147483647 - 1;
+    return (int)rintf(v);
+}
+
+__device__ __forceinline__ void depth_range(int depth, float& lo, float& hi) {
+    switch (depth) {
+    case CVGS_DEPTH_8U: lo = 0.f; hi = 255.f; break;
+    case CVGS_DEPTH_8S: lo = -128.f; hi = 127.f; break;
+    case CVGS_DEPTH_16U: lo = 0.f; hi = 65535.f; break;
+    default: lo = -32768.f; hi = 32767.f; break; // 16S
+    }
+}
+
+__device__ __forceinline__ void cast_px(Px& p, int cn, int src_depth, int dst_depth) {
+    if (src_depth == dst_depth) return;
+    if (dst_depth == CVGS_DEPTH_32F) {
+        if (src_depth == CVGS_DEPTH_32S) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < cn) p.v[c] = (float)as_int(p.v[c]);
+        }
+        return; // 8/16-bit integers are already exact floats
+    }
+    if (dst_depth == CVGS_DEPTH_32S) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < cn) p.v[c] = from_int(src_depth == CVGS_DEPTH_32F ? sat_round_s32(p.v[c]) : (int)p.v[c]);
+        return;
+    }
+    float lo, hi;
+    depth_range(dst_depth, lo, hi);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < cn) {
+            float v = p.v[c];
+            if (src_depth == CVGS_DEPTH_32S) {
+                int iv = as_int(v);
+                iv = iv < (int)lo ? (int)lo : (iv > (int)hi ? (int)hi : iv);
+                p.v[c] = (float)iv;
+            } else if (src_depth == CVGS_DEPTH_32F) {
+                p.v[c] = sat_round(v, lo, hi);
+            } else {
+                p.v[c] = fminf(fmaxf(v, lo), hi);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void reorder_px(Px& p, int aux, int out_cn) {
+    const Px s = p;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < out_cn) {
+            const int k = (aux >> (2 * c)) & 3;
+            p.v[c] = k == 0 ? s.v[0] : (k == 1 ? s.v[1] : (k == 2 ? s.v[2] : s.v[3]));
+        }
+    }
+}
+
+// One pointwise stage.  `opc`, `aux` and the operands are wave-uniform (kernel arguments), so the
+// switch is a scalar branch, never a divergent one.
+__device__ __forceinline__ void apply_op(int opc, int aux, const float* operand, Px& p, int& depth, int& cn) {
+    switch (opc) {
+    case CVGS_OP_CAST:
+        cast_px(p, cn, depth, aux);
+        depth = aux;
+        break;
+    case CVGS_OP_MUL:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = p.v[c] * operand[c];
+        break;
+    case CVGS_OP_ADD:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = p.v[c] + operand[c];
+        break;
+    case CVGS_OP_SUB:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = p.v[c] - operand[c];
+        break;
+    case CVGS_OP_DIV:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = p.v[c] / operand[c];
+        break;
+    case CVGS_OP_REORDER:
+        reorder_px(p, aux, cn);
+        break;
+    case CVGS_OP_ADD_ALPHA:
+        reorder_px(p, aux, 3);
+        p.v[3] = depth == CVGS_DEPTH_32S ? from_int((int)operand[0]) : operand[0];
+        cn = 4;
+        break;
+    case CVGS_OP_DROP_ALPHA:
+        reorder_px(p, aux, 3);
+        cn = 3;
+        break;
+    case CVGS_OP_GRAY: {
+        const int kr = aux & 3, kg = (aux >> 2) & 3, kb = (aux >> 4) & 3;
+        const float r = kr == 0 ? p.v[0] : (kr == 1 ? p.v[1] : (kr == 2 ? p.v[2] : p.v[3]));
+        const float g = kg == 0 ? p.v[0] : (kg == 1 ? p.v[1] : (kg == 2 ? p.v[2] : p.v[3]));
+        const float b = kb == 0 ? p.v[0] : (kb == 1 ? p.v[1] : (kb == 2 ? p.v[2] : p.v[3]));
+        float lum = (r * 0.299f + g * 0.587f) + b * 0.114f;
+        if (depth != CVGS_DEPTH_32F) lum = rintf(lum);
+        p.v[0] = lum;
+        cn = 1;
+        break;
+    }
+    default: break;
+    }
+}
+
+// Interpreted program: any valid op list.
+struct InterpProg {
+    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
+        for (int k = 0; k < prog.n; ++k) apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], p, depth, cn);
+    }
+};
+
+// Compile-time program: the opcode list is a template pack (operands stay run-time), so the chain
+// is straight-line code the compiler can schedule against the loads and stores.
+template <int... OPS>
+struct StaticProg {
+    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
+        int k = 0;
+        ((apply_op(OPS, prog.aux[k], prog.operand[k], p, depth, cn), ++k), ...);
+    }
+};
+
+// ---- fk::PerThreadRead<_2D,T> ------------------------------------------------------------------
+__device__ __forceinline__ void load_px(const uint8_t* row, int depth, int cn, int x, Px& p) {
+    switch (depth) {
+    case CVGS_DEPTH_8U:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = (float)row[x * cn + c];
+        break;
+    case CVGS_DEPTH_8S:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = (float)((const int8_t*)row)[x * cn + c];
+        break;
+    case CVGS_DEPTH_16U:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = (float)((const uint16_t*)row)[x * cn + c];
+        break;
+    case CVGS_DEPTH_16S:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = (float)((const int16_t*)row)[x * cn + c];
+        break;
+    default: // 32S raw bits, 32F
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = ((const float*)row)[x * cn + c];
+        break;
+    }
+}
+
+// a tap as the float the interpolator multiplies (taps are cast to float first)
+__device__ __forceinline__ float tap_f(float v, int depth) {
+    return depth == CVGS_DEPTH_32S ? (float)as_int(v) : v;
+}
+
+// ---- NV12 -> RGB(A) float ----------------------------------------------------------------------
+struct YuvK {
+    float ysub, yscale, rv, gu, gv, bu;
+};
+
+__device__ __forceinline__ YuvK yuv_matrix(int range, int primaries) {
+    YuvK k;
+    if (range == CVGS_YUV_FULL) {
+        k.ysub = 0.f; k.yscale = 1.f;
+        if (primaries == CVGS_BT601) { k.rv = 1.402f; k.gu = -0.344136f; k.gv = -0.714136f; k.bu = 1.772f; }
+        else { k.rv = 1.5748f; k.gu = -0.187324f; k.gv = -0.468124f; k.bu = 1.8556f; }
+    } else {
+        k.ysub = 16.f; k.yscale = 1.164383f;
+        if (primaries == CVGS_BT601) { k.rv = 1.596027f; k.gu = -0.391762f; k.gv = -0.812968f; k.bu = 2.017232f; }
+        else { k.rv = 1.792741f; k.gu = -0.213249f; k.gv = -0.532909f; k.bu = 2.112402f; }
+    }
+    return k;
+}
+
+__device__ __forceinline__ void yuv_to_rgb(float Y, float U, float V, const YuvK& k, Px& p) {
+    const float cb = U - 128.f, cr = V - 128.f;
+    const float yv = (Y - k.ysub) * k.yscale;
+    p.v[0] = yv + k.rv * cr;
+    p.v[1] = (yv + k.gu * cb) + k.gv * cr;
+    p.v[2] = yv + k.bu * cb;
+    p.v[3] = 255.f;
+}
+
+__device__ __forceinline__ void nv12_px(const PlaneParams& P, int x, int y, const YuvK& k, Px& p) {
+    const float Y = (float)P.data[(size_t)y * P.step + x];
+    const uint8_t* uv = P.data + (size_t)(P.h + (y >> 1)) * P.step + 2 * (x >> 1);
+    yuv_to_rgb(Y, (float)uv[0], (float)uv[1], k, p);
+}
+
+// ---- write stages ------------------------------------------------------------------------------
+__device__ __forceinline__ void store_elem(uint8_t* base, size_t idx, int depth, float v) {
+    switch (depth) {
+    case CVGS_DEPTH_8U: base[idx] = (uint8_t)v; break;
+    case CVGS_DEPTH_8S: ((int8_t*)base)[idx] = (int8_t)v; break;
+    case CVGS_DEPTH_16U: ((uint16_t*)base)[idx] = (uint16_t)v; break;
+    case CVGS_DEPTH_16S: ((int16_t*)base)[idx] = (int16_t)v; break;
+    default: ((float*)base)[idx] = v; break; // 32S raw bits, 32F
+    }
+}
+
+__device__ __forceinline__ void write_px(const WriteArgs& w, const DstPlane* dst_planes, int x, int y, int z,
+                                         const Px& p, int depth, int cn) {
+    const size_t W = (size_t)w.width, H = (size_t)w.height;
+    switch (w.kind) {
+    case CVGS_WRITE_PIXEL_2D: {
+        uint8_t* row = w.data + (size_t)y * (size_t)w.step;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) store_elem(row, (size_t)x * cn + c, depth, p.v[c]);
+        break;
+    }
+    case CVGS_WRITE_PIXEL_2D_BATCH: {
+        const DstPlane d = dst_planes[z];
+        uint8_t* row = d.data + (size_t)y * (size_t)d.step;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) store_elem(row, (size_t)x * cn + c, depth, p.v[c]);
+        break;
+    }
+    case CVGS_WRITE_PIXEL_3D: {
+        const size_t pix = ((size_t)z * H + y) * W + x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) store_elem(w.data, pix * cn + c, depth, p.v[c]);
+        break;
+    }
+    case CVGS_WRITE_TENSOR_SPLIT:
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < cn) store_elem(w.data, (((size_t)z * cn + c) * H + y) * W + x, depth, p.v[c]);
+        break;
+    case CVGS_WRITE_TENSOR_T_SPLIT:
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < cn) store_elem(w.data, (((size_t)c * w.planes + z) * H + y) * W + x, depth, p.v[c]);
+        break;
+    case CVGS_WRITE_SPLIT_2D:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < cn) {
+                const DstPlane d = dst_planes[(size_t)z * cn + c];
+                store_elem(d.data + (size_t)y * (size_t)d.step, (size_t)x, depth, p.v[c]);
+            }
+        }
+        break;
+    default: break;
+    }
+}
+
+// XCD-aware remap of a linear workgroup id: the dispatcher places workgroup b on XCD b % 8
+// (MI355X_MICROARCH, "Workgroup dispatch"), so consecutive LOGICAL tiles (same crop, neighbouring
+// rows, shared source rows) are steered to the same XCD and share its L2.  Speed only.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t total) {
+    constexpr uint32_t kXcd = 8;
+    const uint32_t per = (total + kXcd - 1) / kXcd;
+    const uint32_t logical = (bid % kXcd) * per + bid / kXcd;
+    return logical;
+}
+
+} // namespace cvgs

@@ -1,0 +1,455 @@
+"""Host-side mirror of the reference's cvGS:: operator interface for the hot path, in Python.
+
+The reference interface is a C++ template facade (include/cvGPUSpeedup.cuh in the reference); its
+C++ mirror for drop-in use lives in cvgpuspeedup_amd/include/cvGPUSpeedup.h.  This module spells the
+same builders (resize / convertTo / multiply / subtract / divide / add / cvtColor / split / splitT /
+write / executeOperations / CircularTensor) for the Python test and benchmark harnesses: every
+builder returns a small IOp object, executeOperations() lowers the list to ONE cvgs_chain_desc and
+calls cvgs_execute() -> one HIP kernel.  Nothing here computes pixels.
+"""
+import ctypes as C
+
+from . import capi
+from .capi import (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S, DEPTH_32F, DEPTH_64F, make_type,
+                   type_cn, type_depth)
+
+# ---- OpenCV type codes / enums (numeric values of OpenCV 4.x) ---------------------------------------
+for _d, _n in ((DEPTH_8U, "8U"), (DEPTH_8S, "8S"), (DEPTH_16U, "16U"), (DEPTH_16S, "16S"), (DEPTH_32S, "32S"),
+               (DEPTH_32F, "32F"), (DEPTH_64F, "64F")):
+    globals()["CV_" + _n] = _d
+    for _c in (1, 2, 3, 4):
+        globals()["CV_%sC%d" % (_n, _c)] = make_type(_d, _c)
+
+INTER_LINEAR = 1
+COLOR_BGR2BGRA = COLOR_RGB2RGBA = 0
+COLOR_BGRA2BGR = COLOR_RGBA2RGB = 1
+COLOR_BGR2RGBA = COLOR_RGB2BGRA = 2
+COLOR_RGBA2BGR = COLOR_BGRA2RGB = 3
+COLOR_BGR2RGB = COLOR_RGB2BGR = 4
+COLOR_BGRA2RGBA = COLOR_RGBA2BGRA = 5
+COLOR_BGR2GRAY = 6
+COLOR_RGB2GRAY = 7
+COLOR_BGRA2GRAY = 10
+COLOR_RGBA2GRAY = 11
+# reference include/cv2cuda_types.cuh:77-86
+SUPPORTED_COLOR_CONVERSIONS = (0, 1, 2, 3, 4, 5, 6, 7, 10, 11)
+SUPPORTED_INTERPOLATIONS = (INTER_LINEAR,)
+
+PRESERVE_AR, IGNORE_AR, PRESERVE_AR_RN_EVEN, PRESERVE_AR_LEFT = 0, 1, 2, 3  # cvGS::AspectRatio
+NewestFirst, OldestFirst = capi.NEWEST_FIRST, capi.OLDEST_FIRST                # fk::CircularTensorOrder
+Standard, Transposed = capi.PLANES_STANDARD, capi.PLANES_TRANSPOSED            # fk::ColorPlanes
+
+_DEPTH_BYTES = {DEPTH_8U: 1, DEPTH_8S: 1, DEPTH_16U: 2, DEPTH_16S: 2, DEPTH_32S: 4, DEPTH_32F: 4, DEPTH_64F: 8}
+
+
+def elem_size(cv_type):
+    return _DEPTH_BYTES[type_depth(cv_type)] * type_cn(cv_type)
+
+
+# ---- cv::cuda::GpuMat stand-in ------------------------------------------------------------------------
+class GpuMat:
+    """A typed, pitched 2D view of (device or host) memory: data/rows/cols/step/type like cv::cuda::GpuMat.
+
+    `owner` keeps the backing storage (torch tensor, numpy array) alive; a crop is a view that shares it
+    (reference: GpuMat::operator()(Rect), tests/batchresize/test_batchresize_x_split3D.cu:284)."""
+
+    def __init__(self, rows, cols, cv_type, data, step=None, owner=None):
+        self.rows, self.cols, self.cv_type = int(rows), int(cols), int(cv_type)
+        self.data = int(data)
+        self.step = int(step) if step is not None else self.cols * elem_size(cv_type)
+        self.owner = owner
+
+    @staticmethod
+    def from_tensor(t, cv_type):
+        """Wrap a torch tensor (H,W[,C]) whose rows are contiguous."""
+        assert t.stride(-1) == 1 or t.dim() == 2
+        return GpuMat(t.shape[0], t.shape[1], cv_type, t.data_ptr(), t.stride(0) * t.element_size(), owner=t)
+
+    @staticmethod
+    def from_array(a, cv_type):
+        """Wrap a numpy array (H,W[,C]) (host memory: for the CPU oracle only)."""
+        return GpuMat(a.shape[0], a.shape[1], cv_type, a.ctypes.data, a.strides[0], owner=a)
+
+    def type(self):
+        return self.cv_type
+
+    def roi(self, x, y, w, h):
+        """cv::Rect2d crop: doubles are truncated like the reference (include/cvGPUSpeedup.cuh:247-249)."""
+        x, y, w, h = int(x), int(y), int(w), int(h)
+        assert 0 <= x and 0 <= y and x + w <= self.cols and y + h <= self.rows, "ROI outside the image"
+        return GpuMat(h, w, self.cv_type, self.data + y * self.step + x * elem_size(self.cv_type), self.step,
+                      owner=self.owner)
+
+    def row(self, i):
+        return GpuMat(1, self.cols, self.cv_type, self.data + i * self.step, self.step, owner=self.owner)
+
+    def image2d(self):
+        return capi.Image2D(self.data, self.cols, self.rows, self.step, 0)
+
+
+def _scalar(vals, n=4):
+    vals = list(vals) if hasattr(vals, "__len__") else [vals]
+    return [float(v) for v in vals] + [0.0] * (n - len(vals))
+
+
+def cvScalar_set(cv_type, value):
+    """cvGS::cvScalar_set<T>(value) (reference include/cvGPUSpeedupHelpers.cuh:23-37)."""
+    return [float(value)] * type_cn(cv_type)
+
+
+# ---- IOps -----------------------------------------------------------------------------------------------
+class ReadIOp:
+    def __init__(self, kind, src_type, mats, used_planes=None, dsize=None, ar=IGNORE_AR, background=None,
+                 yuv=None, table=None, batch=None):
+        self.kind, self.src_type, self.mats = kind, src_type, list(mats) if mats is not None else None
+        self.batch = batch if batch is not None else len(self.mats)
+        self.used_planes = self.batch if used_planes is None else int(used_planes)
+        self.dsize = dsize  # (width, height)
+        self.ar = ar
+        self.background = _scalar(background if background is not None else [0.0] * 4)
+        self.yuv = yuv or (capi.YUV_FULL, capi.BT601, 0)
+        self.table = table  # device pointer of a prepared plane table (or None)
+
+    def out_type(self):
+        if self.kind == capi.READ_PIXEL:
+            return self.src_type
+        if self.kind == capi.READ_RESIZE_LINEAR:
+            return make_type(DEPTH_32F, type_cn(self.src_type))  # reference :227: CV_32F of same channels
+        return make_type(DEPTH_32F, 4 if self.yuv[2] else 3)
+
+
+class PointwiseIOp:
+    """One or more pointwise stages with an input and an output type (fk::Unary / fk::Binary)."""
+
+    def __init__(self, in_type, out_type, ops):
+        self.in_type, self.out_type, self.ops = in_type, out_type, ops  # ops: [(opcode, aux, operand[4])]
+
+
+class WriteIOp:
+    def __init__(self, kind, dst_type, data=0, width=0, height=0, step=0, planes=0, planes2d=None, keep=None):
+        self.kind, self.dst_type, self.data = kind, dst_type, data
+        self.width, self.height, self.step, self.planes, self.planes2d = width, height, step, planes, planes2d
+        self.keep = keep
+
+
+def resize(src_type, interp, mats, dsize, used_planes=None, background=None, ar=IGNORE_AR, fx=0.0, fy=0.0):
+    """cvGS::resize<T, INTER_F, NPtr, AR>(array<GpuMat,N>, dsize, usedPlanes, background) and the single-image
+    cvGS::resize<T, INTER_F>(GpuMat, dsize, fx, fy) (reference include/cvGPUSpeedup.cuh:209-245)."""
+    if interp not in SUPPORTED_INTERPOLATIONS:
+        raise ValueError("Interpolation type not supported yet.")
+    single = isinstance(mats, GpuMat)
+    mats = [mats] if single else list(mats)
+    w, h = int(dsize[0]), int(dsize[1])
+    if single and (w == 0 or h == 0):  # dsize from fx, fy like cv::resize
+        w = int(round(mats[0].cols * fx))
+        h = int(round(mats[0].rows * fy))
+    return ReadIOp(capi.READ_RESIZE_LINEAR, src_type, mats, used_planes, (w, h), ar, background)
+
+
+def read_nv12(mat, dsize=None, color_range=capi.YUV_FULL, primaries=capi.BT709, alpha=True):
+    """fk::ReadYUV<NV12> + fk::ConvertYUVToRGB<NV12, range, primaries, alpha, floatN>, optionally as the
+    BackIOp of fk::Resize<INTER_LINEAR> (reference tests/resize/test_fused_resize.cu:141-143).
+    `mat` is the CV_8UC1 luma view (rows = luma height); the UV plane follows it in memory."""
+    kind = capi.READ_NV12 if dsize is None else capi.READ_NV12_RESIZE_LINEAR
+    return ReadIOp(kind, make_type(DEPTH_8U, 1), [mat], 1, dsize, IGNORE_AR, None,
+                   (color_range, primaries, 1 if alpha else 0))
+
+
+def convertTo(in_type, out_type, alpha=None, beta=None):
+    """cvGS::convertTo<I,O>([alpha[,beta]]) (reference include/cvGPUSpeedup.cuh:74-129): integral outputs go
+    through float: cast -> mul -> (add) -> saturate."""
+    if type_cn(in_type) != type_cn(out_type):
+        raise ValueError("convertTo does not support changing the number of channels")
+    od = type_depth(out_type)
+    if alpha is None:
+        return PointwiseIOp(in_type, out_type, [(capi.OP_CAST, od, None)])
+    integral = od in (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S)
+    mid = DEPTH_32F if integral else od
+    ops = [(capi.OP_CAST, mid, None), (capi.OP_MUL, 0, [float(alpha)] * 4)]
+    if beta is not None:
+        ops.append((capi.OP_ADD, 0, [float(beta)] * 4))
+    if integral:
+        ops.append((capi.OP_CAST, od, None))
+    return PointwiseIOp(in_type, out_type, ops)
+
+
+def _binary(opcode, cv_type, scalar):
+    return PointwiseIOp(cv_type, cv_type, [(opcode, 0, _scalar(scalar))])
+
+
+def multiply(cv_type, scalar):
+    return _binary(capi.OP_MUL, cv_type, scalar)
+
+
+def subtract(cv_type, scalar):
+    return _binary(capi.OP_SUB, cv_type, scalar)
+
+
+def divide(cv_type, scalar):
+    return _binary(capi.OP_DIV, cv_type, scalar)
+
+
+def add(cv_type, scalar):
+    return _binary(capi.OP_ADD, cv_type, scalar)
+
+
+_SWAP3, _ID3 = 2 | (1 << 2) | (0 << 4), 0 | (1 << 2) | (2 << 4)
+
+
+def _alpha_max(depth):
+    return {DEPTH_8U: 255.0, DEPTH_16U: 65535.0, DEPTH_32F: 1.0}[depth]
+
+
+def cvtColor(code, in_type, out_type=None):
+    """cvGS::cvtColor<CODE, I, O=I>() (reference include/cvGPUSpeedup.cuh:151-161)."""
+    out_type = in_type if out_type is None else out_type
+    d = type_depth(in_type)
+    if d not in (DEPTH_8U, DEPTH_16U, DEPTH_32F) or type_depth(out_type) != d:
+        raise ValueError("Wrong CV_TYPE_DEPTH, it has to be CV_8U, or CV_16U or CV_32F")
+    if code not in SUPPORTED_COLOR_CONVERSIONS:
+        raise ValueError("Color conversion type not supported yet.")
+    icn, ocn = type_cn(in_type), type_cn(out_type)
+    if code in (0, 2):
+        want, op = (3, 4), (capi.OP_ADD_ALPHA, _ID3 if code == 0 else _SWAP3, [_alpha_max(d)] * 4)
+    elif code in (1, 3):
+        want, op = (4, 3), (capi.OP_DROP_ALPHA, _ID3 if code == 1 else _SWAP3, None)
+    elif code == 4:
+        want, op = (3, 3), (capi.OP_REORDER, _SWAP3, None)
+    elif code == 5:
+        want, op = (4, 4), (capi.OP_REORDER, _SWAP3 | (3 << 6), None)
+    elif code in (6, 10):
+        want, op = (3 if code == 6 else 4, 1), (capi.OP_GRAY, _SWAP3, None)
+    else:
+        want, op = (3 if code == 7 else 4, 1), (capi.OP_GRAY, _ID3, None)
+    if (icn, ocn) != want:
+        raise ValueError("channel counts do not match the colour conversion code")
+    return PointwiseIOp(in_type, out_type, [op])
+
+
+def split(out_type, output, plane_dims=None):
+    """cvGS::split<O>(GpuMat tensor, Size plane) -> TensorSplit (NCHW), or split<O>(vector<GpuMat>) /
+    (array<vector<GpuMat>,N>) -> SplitWrite (reference include/cvGPUSpeedup.cuh:163-192)."""
+    cn = type_cn(out_type)
+    if isinstance(output, GpuMat):
+        w, h = int(plane_dims[0]), int(plane_dims[1])
+        assert output.cols % (w * h) == 0 and output.cols // (w * h) == cn, \
+            "Each row of the GpuMat should contain as many planes as width / (planeDims.width * planeDims.height)"
+        return WriteIOp(capi.WRITE_TENSOR_SPLIT, out_type, output.data, w, h, 0, output.rows, keep=output)
+    planes = list(output)
+    if planes and isinstance(planes[0], GpuMat):
+        planes = [planes]
+    flat = [m for img in planes for m in img]
+    if cn < 2:
+        raise ValueError("Split operations can only be used with types of 2, 3 or 4 channels.")
+    arr = (capi.Image2D * len(flat))(*[m.image2d() for m in flat])
+    return WriteIOp(capi.WRITE_SPLIT_2D, out_type, 0, flat[0].cols, flat[0].rows, 0, len(planes), planes2d=arr,
+                    keep=flat)
+
+
+def split_tensor(out_type, data_ptr, width, height, planes, keep=None):
+    """cvGS::split<O>(fk::RawPtr<_3D, base>) (reference :194-197)."""
+    return WriteIOp(capi.WRITE_TENSOR_SPLIT, out_type, int(data_ptr), width, height, 0, planes, keep=keep)
+
+
+def splitT(out_type, data_ptr, width, height, planes, keep=None):
+    """cvGS::splitT<O>(fk::RawPtr<T3D, base>) -> TensorTSplit, CNHW (reference :199-202)."""
+    return WriteIOp(capi.WRITE_TENSOR_T_SPLIT, out_type, int(data_ptr), width, height, 0, planes, keep=keep)
+
+
+def write(out_type, output, plane_dims=None):
+    """cvGS::write<O>(GpuMat) -> PerThreadWrite<_2D>; write<O>(GpuMat, Size) -> PerThreadWrite<_3D>
+    (reference include/cvGPUSpeedup.cuh:449-457)."""
+    if plane_dims is None:
+        return WriteIOp(capi.WRITE_PIXEL_2D, out_type, output.data, output.cols, output.rows, output.step, 1,
+                        keep=output)
+    w, h = int(plane_dims[0]), int(plane_dims[1])
+    return WriteIOp(capi.WRITE_PIXEL_3D, out_type, output.data, w, h, 0, output.rows, keep=output)
+
+
+def write_batch(out_type, outputs):
+    """PerThreadWrite<_2D> per batch element (array of GpuMats)."""
+    outs = list(outputs)
+    arr = (capi.Image2D * len(outs))(*[m.image2d() for m in outs])
+    return WriteIOp(capi.WRITE_PIXEL_2D_BATCH, out_type, 0, outs[0].cols, outs[0].rows, 0, len(outs), planes2d=arr,
+                    keep=outs)
+
+
+# ---- lowering ---------------------------------------------------------------------------------------------
+class LoweredChain:
+    """A cvgs_chain_desc plus everything that must stay alive while it is in use."""
+
+    def __init__(self, desc, keep):
+        self.desc, self.keep = desc, keep
+
+
+def lower(iops, flags=0):
+    """Type-check the IOp list like the reference's template machinery does and emit ONE chain descriptor."""
+    iops = list(iops)
+    if len(iops) < 2 or not isinstance(iops[0], ReadIOp) or not isinstance(iops[-1], WriteIOp):
+        raise ValueError("a chain is Read, pointwise..., Write")
+    rd, wr = iops[0], iops[-1]
+    ch = capi.new_chain()
+    ch.flags = flags
+    keep = [rd.mats, wr.keep, wr.planes2d]
+    r = ch.read
+    r.kind, r.src_type, r.batch, r.used_planes = rd.kind, rd.src_type, rd.batch, rd.used_planes
+    if rd.table is not None:
+        r.src = int(rd.table)
+        r.flags = capi.READ_FLAG_TABLE_ON_DEVICE
+    else:
+        arr = (capi.Image2D * rd.batch)()
+        for i, m in enumerate(rd.mats):
+            if m.cv_type != rd.src_type:
+                raise RuntimeError("Input type does not match the input type of the operation.")
+            arr[i] = m.image2d()
+        keep.append(arr)
+        r.src = C.cast(arr, C.c_void_p).value
+    if rd.dsize is not None:
+        r.dst_width, r.dst_height = rd.dsize
+    r.aspect_ratio = rd.ar
+    for i in range(4):
+        r.background[i] = rd.background[i]
+    r.yuv_range, r.yuv_primaries, r.yuv_alpha = rd.yuv
+    cur = rd.out_type()
+    n = 0
+    for iop in iops[1:-1]:
+        if not isinstance(iop, PointwiseIOp):
+            raise ValueError("only pointwise IOps may sit between the read and the write")
+        if iop.in_type != cur:
+            raise TypeError("IOp input type %d does not match the previous output type %d" % (iop.in_type, cur))
+        for opcode, aux, operand in iop.ops:
+            if n >= capi.MAX_OPS:
+                raise ValueError("too many pointwise stages")
+            ch.ops[n].opcode, ch.ops[n].aux = opcode, aux
+            for i in range(4):
+                ch.ops[n].operand[i] = operand[i] if operand is not None else 0.0
+            n += 1
+        cur = iop.out_type
+    ch.n_ops = n
+    if wr.dst_type != cur:
+        raise TypeError("write type %d does not match the chain's output type %d" % (wr.dst_type, cur))
+    w = ch.write
+    w.kind, w.dst_type, w.data = wr.kind, wr.dst_type, wr.data
+    w.width, w.height, w.step, w.planes = wr.width, wr.height, wr.step, wr.planes
+    if wr.planes2d is not None:
+        w.planes2d = C.cast(wr.planes2d, C.c_void_p).value
+    return LoweredChain(ch, keep)
+
+
+def stream_handle(stream):
+    """cv::cuda::StreamAccessor::getStream: accept a raw hipStream_t int, a torch stream, or None."""
+    if stream is None:
+        return 0
+    if isinstance(stream, int):
+        return stream
+    return int(stream.cuda_stream)
+
+
+def executeOperations(stream, *iops, flags=0):
+    """cvGS::executeOperations(stream, iops...) (reference include/cvGPUSpeedup.cuh:464-473): one kernel,
+    asynchronous on `stream`, never synchronises."""
+    lib = capi.load_library()
+    lowered = lower(iops, flags)
+    capi.check(lib.cvgs_execute(C.byref(lowered.desc), stream_handle(stream)))
+    return lowered
+
+
+def executeOperations_io(input_mat, output_mat, stream, *iops, flags=0):
+    """executeOperations(GpuMat in, [GpuMat out,] stream, iops...) (reference :475-503): a PerThreadRead is
+    prepended and, if `output_mat` is given, a PerThreadWrite appended."""
+    first = iops[0]
+    in_type = first.in_type if isinstance(first, PointwiseIOp) else first.dst_type
+    chain = [ReadIOp(capi.READ_PIXEL, in_type, [input_mat], 1)] + list(iops)
+    if output_mat is not None:
+        last = iops[-1]
+        chain.append(write(last.out_type, output_mat))
+    return executeOperations(stream, *chain, flags=flags)
+
+
+def executeOperations_batch(inputs, stream, *iops, active_batch=None, default_value=None, output=None,
+                            output_plane=None, flags=0):
+    """executeOperations(array<GpuMat,N> in, [activeBatch, default,] [GpuMat out, Size plane,] stream, iops...)
+    (reference :506-583)."""
+    inputs = list(inputs)
+    first = iops[0]
+    in_type = first.in_type if isinstance(first, PointwiseIOp) else first.dst_type
+    chain = [ReadIOp(capi.READ_PIXEL, in_type, inputs, active_batch, None, IGNORE_AR, default_value)] + list(iops)
+    if output is not None:
+        chain.append(write(iops[-1].out_type, output, output_plane))
+    return executeOperations(stream, *chain, flags=flags)
+
+
+def kernel_name(*iops, flags=0):
+    lib = capi.load_library()
+    lowered = lower(iops, flags)
+    buf = C.create_string_buffer(128)
+    capi.check(lib.cvgs_kernel_name(C.byref(lowered.desc), buf, 128))
+    return buf.value.decode()
+
+
+def build_plane_table(read_iop):
+    """Host bytes of the device plane table for a read stage (cvgs_plane_table_build)."""
+    lib = capi.load_library()
+    lowered = lower([read_iop, WriteIOp(capi.WRITE_PIXEL_3D, read_iop.out_type(), 16, 1, 1, 0, read_iop.batch)])
+    n = lib.cvgs_plane_table_bytes(read_iop.batch)
+    buf = (C.c_uint8 * n)()
+    capi.check(lib.cvgs_plane_table_build(C.byref(lowered.desc.read), buf))
+    return bytes(buf)
+
+
+class CircularTensor:
+    """cvGS::CircularTensor<I, O, COLOR_PLANES, BATCH, ORDER, CP_MODE> (reference include/cvGPUSpeedup.cuh:600-627)."""
+
+    def __init__(self, in_type, out_elem_type, color_planes, batch, order, cp_mode=Standard, width=0, height=0,
+                 device_id=0):
+        self.in_type, self.elem_type, self.color_planes, self.batch = in_type, out_elem_type, color_planes, batch
+        self.order, self.cp_mode = order, cp_mode
+        self.handle = C.c_void_p(0)
+        self.lib = capi.load_library()
+        if width and height:
+            self.Alloc(width, height, device_id)
+
+    def Alloc(self, width, height, device_id=0):
+        self.width, self.height = width, height
+        capi.check(self.lib.cvgs_circular_create(C.byref(self.handle), width, height, self.elem_type,
+                                                 self.color_planes, self.batch, self.order, self.cp_mode, device_id))
+
+    def update(self, stream, *iops, flags=0):
+        """update(stream, GpuMat input, iops..., write) or update(stream, readIOp, iops..., write)."""
+        iops = list(iops)
+        if isinstance(iops[0], GpuMat):
+            iops[0] = ReadIOp(capi.READ_PIXEL, self.in_type, [iops[0]], 1)
+        lowered = lower(iops, flags)
+        capi.check(self.lib.cvgs_circular_update(self.handle, C.byref(lowered.desc), stream_handle(stream)))
+        return lowered
+
+    def write_split(self, out_type):
+        """fk::Write<fk::TensorSplit<O>>{tensor.ptr()} for this tensor."""
+        return WriteIOp(capi.WRITE_TENSOR_SPLIT, out_type, 0, self.width, self.height, 0, self.batch)
+
+    def write_splitT(self, out_type):
+        return WriteIOp(capi.WRITE_TENSOR_T_SPLIT, out_type, 0, self.width, self.height, 0, self.batch)
+
+    def write_packed(self, out_type):
+        """fk::Write<fk::TensorWrite<O>>{tensor.ptr()} (COLOR_PLANES == 1)."""
+        return WriteIOp(capi.WRITE_PIXEL_3D, out_type, 0, self.width, self.height, 0, self.batch)
+
+    def data(self):
+        return self.lib.cvgs_circular_data(self.handle)
+
+    def nbytes(self):
+        return self.lib.cvgs_circular_bytes(self.handle)
+
+    def updates(self):
+        return self.lib.cvgs_circular_updates(self.handle)
+
+    def release(self):
+        if self.handle:
+            self.lib.cvgs_circular_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

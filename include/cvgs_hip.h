@@ -1,0 +1,265 @@
+/*
+ * cvgs_hip.h -- C-ABI of the MI355X-native fused image-preprocessing engine.
+ *
+ * This is the drop-in boundary for the hot path
+ *     crop -> resize(bilinear) -> convertTo/normalize -> cvtColor -> split -> (Circular)Tensor
+ * of Libraries-Openly-Fused/cvGPUSpeedup.  The reference has no FFI layer of its own: its
+ * host/device boundary is the single call
+ *     fk::executeOperations<TF>(cu_stream, iops...)          (reference include/cvGPUSpeedup.cuh:467)
+ * into the (un-vendored) FusedKernelLibrary, with every operation parameter passed by value as a
+ * kernel argument.  The entry points below are what a binding for that call would bind: the C++
+ * facade (cvgpuspeedup_amd/include/cvGPUSpeedup.h, same cvGS:: names as the reference) pattern-
+ * matches the compile-time operation list and lowers it to ONE cvgs_chain_desc, and
+ * cvgs_execute() launches ONE hand-written HIP kernel (gfx950) for it.
+ *
+ * Plain C: pointers, sizes and POD structs only.  Every call is asynchronous on the given HIP
+ * stream, never synchronises, never allocates device memory (except cvgs_circular_create and
+ * cvgs_comm_*), and is thread-safe (CircularTensor handles excepted: they carry a ring index, as
+ * in the reference, include/cvGPUSpeedup.cuh:600-627).
+ *
+ * Return value: 0 (CVGS_OK) or a negative cvgs_status; cvgs_last_error() gives a thread-local
+ * human-readable message.
+ */
+#ifndef CVGS_HIP_H
+#define CVGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVGS_ABI_VERSION 1
+#define CVGS_MAX_OPS 12        /* pointwise stages between the read and the write            */
+#define CVGS_MAX_CHANNELS 4
+#define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
+
+typedef void* cvgs_stream_t; /* hipStream_t (0 = the null stream) */
+
+typedef enum cvgs_status {
+    CVGS_OK = 0,
+    CVGS_ERR_INVALID = -1,     /* malformed descriptor (the reference static_asserts / asserts) */
+    CVGS_ERR_UNSUPPORTED = -2, /* well-formed but not implemented on this build                 */
+    CVGS_ERR_HIP = -3,         /* a HIP runtime call failed (reference: gpuErrchk)              */
+    CVGS_ERR_NO_DEVICE = -4,
+    CVGS_ERR_RCCL = -5
+} cvgs_status;
+
+/* Element types use OpenCV's numeric encoding so that the cv2cuda shims (reference
+ * include/cv2cuda_types.cuh:34-61) need no translation table:
+ *   type = depth + ((channels-1) << 3),  depth: 8U=0 8S=1 16U=2 16S=3 32S=4 32F=5 64F=6          */
+#define CVGS_DEPTH_8U 0
+#define CVGS_DEPTH_8S 1
+#define CVGS_DEPTH_16U 2
+#define CVGS_DEPTH_16S 3
+#define CVGS_DEPTH_32S 4
+#define CVGS_DEPTH_32F 5
+#define CVGS_DEPTH_64F 6
+#define CVGS_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
+#define CVGS_TYPE_DEPTH(t) ((t) & 7)
+#define CVGS_TYPE_CN(t) ((((t) >> 3) & 63) + 1)
+
+/* A pitched 2D image view: replaces fk::RawPtr<fk::_2D,T> / fk::Ptr2D<T> as produced by
+ * gpuMat2RawPtr2D / gpuMat2Ptr2D (reference include/cvGPUSpeedup.cuh:34-44).  A crop is a view:
+ * data = frame + y*step + x*elemSize, same step (reference GpuMat::operator()(Rect),
+ * tests/batchresize/test_batchresize_x_split3D.cu:284; cvGS::crop, include/cvGPUSpeedup.cuh:247). */
+typedef struct cvgs_image2d {
+    const void* data; /* device pointer to pixel (0,0)            */
+    int32_t width;    /* pixels                                   */
+    int32_t height;   /* rows (NV12: luma rows; UV plane follows) */
+    int32_t step;     /* bytes between rows                       */
+    int32_t reserved;
+} cvgs_image2d;
+
+/* ---- read stage (first IOp of the chain) ------------------------------------------------- */
+typedef enum cvgs_read_kind {
+    /* fk::PerThreadRead<_2D,T>, batched by fk::BatchRead<N,...> (cvGPUSpeedup.cuh:475-583)   */
+    CVGS_READ_PIXEL = 0,
+    /* fk::Resize<INTER_LINEAR,AR,fk::Read<PerThreadRead<_2D,T>>> wrapped in
+     * fk::BatchRead<N,CONDITIONAL_WITH_DEFAULT> (cvGPUSpeedup.cuh:204-245)                    */
+    CVGS_READ_RESIZE_LINEAR = 1,
+    /* fk::ReadYUV<NV12> + fk::ConvertYUVToRGB<NV12,range,primaries,alpha,floatN>
+     * (reference tests/resize/test_fused_resize.cu:50-51)                                     */
+    CVGS_READ_NV12 = 2,
+    /* the same pair fused as the BackIOp of fk::Resize<INTER_LINEAR>
+     * (reference tests/resize/test_fused_resize.cu:141-143)                                   */
+    CVGS_READ_NV12_RESIZE_LINEAR = 3
+} cvgs_read_kind;
+
+/* same numeric values as cvGS::AspectRatio (reference include/cvGPUSpeedup.cuh:32) */
+typedef enum cvgs_aspect_ratio {
+    CVGS_PRESERVE_AR = 0,
+    CVGS_IGNORE_AR = 1,
+    CVGS_PRESERVE_AR_RN_EVEN = 2,
+    CVGS_PRESERVE_AR_LEFT = 3
+} cvgs_aspect_ratio;
+
+typedef enum cvgs_yuv_range { CVGS_YUV_FULL = 0, CVGS_YUV_LIMITED = 1 } cvgs_yuv_range;
+typedef enum cvgs_yuv_primaries { CVGS_BT601 = 0, CVGS_BT709 = 1 } cvgs_yuv_primaries;
+
+#define CVGS_READ_FLAG_TABLE_ON_DEVICE 1u /* `src` is a device table made by cvgs_plane_table_build */
+
+typedef struct cvgs_read_desc {
+    int32_t kind;         /* cvgs_read_kind                                                   */
+    int32_t src_type;     /* CV type of the source pixels (NV12: CVGS_MAKETYPE(8U,1))         */
+    int32_t batch;        /* planes = grid z (std::array<GpuMat,N>::size())                   */
+    int32_t used_planes;  /* planes >= used_planes produce `background` (usedPlanes/activeBatch) */
+    const void* src;      /* host: cvgs_image2d[batch]; or device table (flag above)          */
+    int32_t dst_width;    /* resize target; PIXEL/NV12 reads: ignored (= source size)         */
+    int32_t dst_height;
+    int32_t aspect_ratio; /* cvgs_aspect_ratio                                                */
+    uint32_t flags;
+    float background[4];  /* default value, already in the float type of the read's output    */
+    int32_t yuv_range;    /* NV12 kinds only                                                  */
+    int32_t yuv_primaries;
+    int32_t yuv_alpha;    /* 1: 4-channel output with alpha = 255                             */
+    int32_t reserved;
+} cvgs_read_desc;
+
+/* ---- pointwise stages (Unary / Binary IOps) ---------------------------------------------- */
+typedef enum cvgs_opcode {
+    CVGS_OP_NOP = 0,
+    /* fk::SaturateCast<I,O> (cvGS::convertTo, cvGPUSpeedup.cuh:74-129). aux = destination depth. */
+    CVGS_OP_CAST = 1,
+    /* fk::Binary<fk::Mul/Add/Sub/Div<T>> (cvGS::multiply/add/subtract/divide,
+     * cvGPUSpeedup.cuh:131-149); operand[c] = static_cast<float>(cv::Scalar[c])
+     * (cvGPUSpeedupHelpers.cuh:38-54).  IEEE fp32, applied in call order, never merged.       */
+    CVGS_OP_MUL = 2,
+    CVGS_OP_ADD = 3,
+    CVGS_OP_SUB = 4,
+    CVGS_OP_DIV = 5,
+    /* fk::VectorReorder / the channel-permuting fk::ColorConversion codes
+     * (cvGS::cvtColor, cvGPUSpeedup.cuh:151-161).  aux = packed source indices,
+     * 2 bits per output channel: out[c] = in[(aux >> 2c) & 3]; channel count unchanged.       */
+    CVGS_OP_REORDER = 6,
+    /* RGB->RGBA style: out[0..2] = in[(aux>>2c)&3], out[3] = operand[0] (type max). 3 -> 4 ch. */
+    CVGS_OP_ADD_ALPHA = 7,
+    /* RGBA->RGB style: out[c] = in[(aux>>2c)&3] for c < 3. 4 -> 3 channels.                    */
+    CVGS_OP_DROP_ALPHA = 8,
+    /* *2GRAY: 0.299 R + 0.587 G + 0.114 B, R = in[aux & 3], B = in[(aux>>4)&3]; integer depths
+     * round to nearest even.  3|4 -> 1 channel.                                                */
+    CVGS_OP_GRAY = 9
+} cvgs_opcode;
+
+typedef struct cvgs_op {
+    int32_t opcode;
+    int32_t aux;
+    float operand[4];
+} cvgs_op;
+
+/* ---- write stage (last IOp of the chain) -------------------------------------------------- */
+typedef enum cvgs_write_kind {
+    /* fk::PerThreadWrite<_2D,T>: packed pixels into ONE pitched image (cvGS::write(GpuMat),
+     * cvGPUSpeedup.cuh:449-452; executeOperations(in,out,...) :489-503).                      */
+    CVGS_WRITE_PIXEL_2D = 0,
+    /* fk::PerThreadWrite<_3D,T>: packed pixels, dense [plane][y][x] (cvGS::write(GpuMat,Size)
+     * :454-457, write(fk::Tensor) :459-462).                                                  */
+    CVGS_WRITE_PIXEL_3D = 1,
+    /* fk::TensorSplit<T>: dense NCHW  out[z][c][y][x]  (cvGS::split(GpuMat,Size) :185-197)     */
+    CVGS_WRITE_TENSOR_SPLIT = 2,
+    /* fk::TensorTSplit<T>: dense CNHW out[c][z][y][x]  (cvGS::splitT :199-202)                 */
+    CVGS_WRITE_TENSOR_T_SPLIT = 3,
+    /* fk::SplitWrite<_2D,T>: C independent pitched planes per batch element
+     * (cvGS::split(vector<GpuMat>) / (array<vector<GpuMat>,N>) :163-183)                       */
+    CVGS_WRITE_SPLIT_2D = 4,
+    /* fk::PerThreadWrite<_2D,T> per batch element: array of pitched images                     */
+    CVGS_WRITE_PIXEL_2D_BATCH = 5
+} cvgs_write_kind;
+
+typedef struct cvgs_write_desc {
+    int32_t kind;     /* cvgs_write_kind                                                       */
+    int32_t dst_type; /* CV type of the value being written (depth + channels)                 */
+    void* data;       /* tensor kinds and PIXEL_2D: device pointer                             */
+    int32_t width;    /* plane width  (pixels)                                                 */
+    int32_t height;   /* plane height (rows)                                                   */
+    int32_t step;     /* PIXEL_2D: row pitch in bytes; tensor kinds: ignored (dense)           */
+    int32_t planes;   /* tensor kinds: number of images N in the tensor (>= read.batch)        */
+    /* SPLIT_2D: host array cvgs_image2d[batch*channels], index z*channels+c.
+     * PIXEL_2D_BATCH: host array cvgs_image2d[batch].                                         */
+    const cvgs_image2d* planes2d;
+} cvgs_write_desc;
+
+/* ---- the fused chain = one kernel launch --------------------------------------------------- */
+typedef struct cvgs_chain_desc {
+    uint32_t struct_size; /* sizeof(cvgs_chain_desc), for ABI checking */
+    uint32_t flags;       /* cvgs_chain_flags                          */
+    cvgs_read_desc read;
+    int32_t n_ops;
+    int32_t reserved;
+    cvgs_op ops[CVGS_MAX_OPS];
+    cvgs_write_desc write;
+} cvgs_chain_desc;
+
+typedef enum cvgs_chain_flags {
+    CVGS_CHAIN_DEFAULT = 0,
+    /* force the interpreted generic kernel even when a specialised kernel matches (testing)   */
+    CVGS_CHAIN_FORCE_GENERIC = 1,
+    /* ENABLE_THREAD_FUSION=false of the reference (cvGPUSpeedup.cuh:464): results identical,
+     * only disables the multi-pixel-per-thread fast paths                                      */
+    CVGS_CHAIN_NO_THREAD_FUSION = 2,
+    /* select a specific K1 variant (benchmark A/B only) */
+    CVGS_CHAIN_K1_DIRECT = 4,
+    CVGS_CHAIN_K1_LDS = 8
+} cvgs_chain_flags;
+
+/* Library / device ------------------------------------------------------------------------- */
+int cvgs_abi_version(void);
+const char* cvgs_version_string(void);
+const char* cvgs_last_error(void);
+/* number of visible HIP devices, or a negative status */
+int cvgs_device_count(void);
+
+/* Replaces fk::executeOperations<TF>(stream, iops...) (reference include/cvGPUSpeedup.cuh:467,
+ * 480,495,513,524,552,566): validates the chain and enqueues exactly one kernel on `stream`.   */
+int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
+
+/* Validation only (what the reference checks with static_assert / assert / runtime_error).    */
+int cvgs_validate(const cvgs_chain_desc* chain);
+
+/* Name of the kernel cvgs_execute would launch for this chain ("k1_u8c3_direct", "generic", ...)
+ * written into buf (NUL terminated).  Introspection for tests and profiles.                    */
+int cvgs_kernel_name(const cvgs_chain_desc* chain, char* buf, size_t buf_size);
+
+/* Plane tables: for batches larger than CVGS_KERNARG_PLANES, or when the caller keeps the crop
+ * list resident in HBM, the per-plane read parameters live in a device buffer instead of the
+ * kernel arguments (the reference is limited to ~50 planes by the 4 KB kernel-parameter block,
+ * tests/batchresize/test_batchresize_aspectratio_x_split3D.cu:21-23).  `read->src` must be a
+ * host cvgs_image2d[batch]; the function writes cvgs_plane_table_bytes(batch) bytes of
+ * position-independent table into host_out, which the caller copies to the device and passes
+ * back as read.src with CVGS_READ_FLAG_TABLE_ON_DEVICE.                                         */
+size_t cvgs_plane_table_bytes(int32_t batch);
+int cvgs_plane_table_build(const cvgs_read_desc* read, void* host_out);
+
+/* ---- CircularTensor ------------------------------------------------------------------------
+ * Replaces fk::CircularTensor<T,COLOR_PLANES,BATCH,ORDER,CP_MODE> as wrapped by
+ * cvGS::CircularTensor (reference include/cvGPUSpeedup.cuh:600-627).                            */
+typedef struct cvgs_circular_s* cvgs_circular_t;
+
+typedef enum cvgs_circular_order { CVGS_NEWEST_FIRST = 0, CVGS_OLDEST_FIRST = 1 } cvgs_circular_order;
+typedef enum cvgs_color_planes_mode { CVGS_PLANES_STANDARD = 0, CVGS_PLANES_TRANSPOSED = 1 } cvgs_color_planes_mode;
+
+/* elem_type: CV type of ONE tensor element (CV_32FC1 for split tensors, CV_32FC4 for packed).
+ * Allocates the output tensor and the internal ring on `device_id` (ctor/Alloc, :605-610).     */
+int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
+                         int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode,
+                         int32_t device_id);
+/* update(stream, [GpuMat,] iops..., write) (:612-622): `chain` carries the read stage (batch 1),
+ * the pointwise stages and the write KIND (TENSOR_SPLIT / TENSOR_T_SPLIT / PIXEL_3D); the write
+ * target is the handle's own tensor (write.data is ignored).  One kernel launch.               */
+int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_stream_t stream);
+/* data() (:624-626): device pointer of the ordered output tensor; stable for the handle's life. */
+void* cvgs_circular_data(cvgs_circular_t ct);
+size_t cvgs_circular_bytes(cvgs_circular_t ct);
+/* number of updates so far (the reference keeps this host-side ring index private)             */
+int64_t cvgs_circular_updates(cvgs_circular_t ct);
+int cvgs_circular_destroy(cvgs_circular_t ct);
+
+/* ---- profiling ranges (reference tests/nvtx.h PUSH_RANGE/POP_RANGE) -------------------------- */
+void cvgs_range_push(const char* name);
+void cvgs_range_pop(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVGS_HIP_H */

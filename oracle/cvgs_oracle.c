@@ -1,0 +1,568 @@
+/*
+ * cvgs_oracle.c -- scalar, strict-IEEE CPU restatement of the cvGPUSpeedup hot path.
+ * TEST INFRASTRUCTURE ONLY (see cvgs_oracle.h).  Build: oracle/Makefile (gcc -O2 -ffp-contract=off).
+ *
+ * Citations are to /root/reference (v0.21.0).  "[FKL]" marks semantics that live in the
+ * un-vendored FusedKernelLibrary 0.1.8 and are restated from its published algorithm and from the
+ * OpenCV-CUDA operation the reference's tests compare it with.
+ */
+#include "cvgs_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* work pixel: the value flowing between IOps.  32S values live in i[], everything else in f[] */
+/* (8/16-bit integers are exact in fp32).                                                      */
+typedef struct opx {
+    float f[4];
+    int32_t i[4];
+    int depth;
+    int cn;
+} opx;
+
+static int g_threads = 1;
+
+void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int oracle_get_threads(void) { return g_threads; }
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static int depth_bytes(int depth) {
+    switch (depth) {
+    case CVGS_DEPTH_8U: case CVGS_DEPTH_8S: return 1;
+    case CVGS_DEPTH_16U: case CVGS_DEPTH_16S: return 2;
+    case CVGS_DEPTH_32S: case CVGS_DEPTH_32F: return 4;
+    case CVGS_DEPTH_64F: return 8;
+    }
+    return 0;
+}
+
+/* fk::PerThreadRead<_2D,T>::exec: *(T*)((char*)data + y*pitch + x*sizeof(T))   [FKL]
+ * (the reference builds it from a GpuMat at include/cvGPUSpeedup.cuh:40-44,613-615). */
+static void load_pixel(const cvgs_image2d* im, int type, int x, int y, opx* p) {
+    const int depth = CVGS_TYPE_DEPTH(type), cn = CVGS_TYPE_CN(type);
+    const uint8_t* row = (const uint8_t*)im->data + (size_t)y * (size_t)im->step;
+    p->depth = depth;
+    p->cn = cn;
+    for (int c = 0; c < cn; ++c) {
+        const size_t e = (size_t)x * cn + c;
+        switch (depth) {
+        case CVGS_DEPTH_8U: p->f[c] = (float)row[e]; break;
+        case CVGS_DEPTH_8S: p->f[c] = (float)((const int8_t*)row)[e]; break;
+        case CVGS_DEPTH_16U: p->f[c] = (float)((const uint16_t*)row)[e]; break;
+        case CVGS_DEPTH_16S: p->f[c] = (float)((const int16_t*)row)[e]; break;
+        case CVGS_DEPTH_32S: p->i[c] = ((const int32_t*)row)[e]; break;
+        case CVGS_DEPTH_32F: p->f[c] = ((const float*)row)[e]; break;
+        default: p->f[c] = 0.f;
+        }
+    }
+}
+
+static float tap_as_float(const opx* p, int c) {
+    return p->depth == CVGS_DEPTH_32S ? (float)p->i[c] : p->f[c];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Resize geometry.
+ * IGNORE_AR: OpenCV-CUDA's host code passes static_cast<float>(1.0 / fx) with
+ * fx = (double)dsize.width / src.cols to its kernel, and fk::Resize::build does the same [FKL]
+ * (facade call site: reference include/cvGPUSpeedup.cuh:204-216,234-243).
+ * PRESERVE_AR: scale by height; if the scaled width overflows scale by width; centre; the
+ * OpenCV side of the reference test spells the same geometry at
+ * tests/batchresize/test_batchresize_aspectratio_x_split3D.cu:86-95,129-133.  The target extent
+ * is rounded to nearest (fk compute_target_size [FKL]); the reference test truncates instead and
+ * the two agree on its only tested case (30x120 -> 32x128).  RN_EVEN rounds the free extent down
+ * to an even number, LEFT pins the window to x = 0 [FKL, unpinned]. */
+void oracle_resize_geometry(int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h,
+                            int32_t aspect_ratio, oracle_resize_geom* g) {
+    if (aspect_ratio == CVGS_IGNORE_AR) {
+        const double cfx = (double)dst_w / (double)src_w;
+        const double cfy = (double)dst_h / (double)src_h;
+        g->fx = (float)(1.0 / cfx);
+        g->fy = (float)(1.0 / cfy);
+        g->x1 = 0;
+        g->y1 = 0;
+        g->x2 = dst_w - 1;
+        g->y2 = dst_h - 1;
+        return;
+    }
+    float scale = (float)dst_h / (float)src_h;
+    int th = dst_h;
+    int tw = (int)roundf(scale * (float)src_w);
+    if (aspect_ratio == CVGS_PRESERVE_AR_RN_EVEN) tw -= tw % 2;
+    if (tw > dst_w) {
+        scale = (float)dst_w / (float)src_w;
+        tw = dst_w;
+        th = (int)roundf(scale * (float)src_h);
+        if (aspect_ratio == CVGS_PRESERVE_AR_RN_EVEN) th -= th % 2;
+    }
+    if (tw < 1) tw = 1;
+    if (th < 1) th = 1;
+    const int x1 = aspect_ratio == CVGS_PRESERVE_AR_LEFT ? 0 : (dst_w - tw) / 2;
+    const int y1 = (dst_h - th) / 2;
+    const double cfx = (double)tw / (double)src_w;
+    const double cfy = (double)th / (double)src_h;
+    g->fx = (float)(1.0 / cfx);
+    g->fy = (float)(1.0 / cfy);
+    g->x1 = x1;
+    g->y1 = y1;
+    g->x2 = x1 + tw - 1;
+    g->y2 = y1 + th - 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* NV12 -> RGB(A) float.  fk::ReadYUV<NV12>: Y at data[y][x], interleaved UV plane right below the
+ * luma rows: (U,V) = data[H + y/2][2*(x/2) + {0,1}] (allocation H + H/2 rows, reference
+ * tests/resize/test_fused_resize.cu:39-40,112-113).  fk::ConvertYUVToRGB<NV12,range,primaries,
+ * alpha,floatN> (:50-51,141-142): 3x3 YCbCr->RGB matrix of the named standard [FKL, unpinned:
+ * the reference test asserts nothing about the values]. */
+typedef struct yuv_coeffs {
+    float ysub, yscale, rv, gu, gv, bu;
+} yuv_coeffs;
+
+static yuv_coeffs yuv_matrix(int range, int primaries) {
+    yuv_coeffs k;
+    if (range == CVGS_YUV_FULL) {
+        k.ysub = 0.f;
+        k.yscale = 1.f;
+        if (primaries == CVGS_BT601) { k.rv = 1.402f; k.gu = -0.344136f; k.gv = -0.714136f; k.bu = 1.772f; }
+        else { k.rv = 1.5748f; k.gu = -0.187324f; k.gv = -0.468124f; k.bu = 1.8556f; }
+    } else {
+        k.ysub = 16.f;
+        k.yscale = 1.164383f;
+        if (primaries == CVGS_BT601) { k.rv = 1.596027f; k.gu = -0.391762f; k.gv = -0.812968f; k.bu = 2.017232f; }
+        else { k.rv = 1.792741f; k.gu = -0.213249f; k.gv = -0.532909f; k.bu = 2.112402f; }
+    }
+    return k;
+}
+
+static void nv12_pixel(const cvgs_image2d* im, int x, int y, const cvgs_read_desc* rd, opx* p) {
+    const uint8_t* base = (const uint8_t*)im->data;
+    const float Y = (float)base[(size_t)y * im->step + x];
+    const uint8_t* uv = base + (size_t)(im->height + y / 2) * im->step + 2 * (x / 2);
+    const float cb = (float)uv[0] - 128.f;
+    const float cr = (float)uv[1] - 128.f;
+    const yuv_coeffs k = yuv_matrix(rd->yuv_range, rd->yuv_primaries);
+    const float yv = (Y - k.ysub) * k.yscale;
+    p->f[0] = yv + k.rv * cr;
+    p->f[1] = (yv + k.gu * cb) + k.gv * cr;
+    p->f[2] = yv + k.bu * cb;
+    p->f[3] = 255.f;
+    p->depth = CVGS_DEPTH_32F;
+    p->cn = rd->yuv_alpha ? 4 : 3;
+}
+
+/* source pixel fetch used by the interpolator: the Resize BackIOp */
+static void back_read(const cvgs_read_desc* rd, const cvgs_image2d* im, int x, int y, opx* p) {
+    if (rd->kind == CVGS_READ_NV12 || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR) nv12_pixel(im, x, y, rd, p);
+    else load_pixel(im, rd->src_type, x, y, p);
+}
+
+/* fk::Interpolate<INTER_LINEAR> [FKL], identical to OpenCV-CUDA's resize_linear kernel which the
+ * reference tests compare against (cv::cuda::resize(..., INTER_LINEAR),
+ * tests/batchresize/test_batchresize_x_split3D.cu:297): no half-pixel offset, floor, +1 clamped
+ * to the LAST source column/row, weights from the unclamped x2/y2, taps cast to float first, the
+ * four products summed in the order 00,10,01,11 in fp32. */
+static void interpolate_linear(const cvgs_read_desc* rd, const cvgs_image2d* im, float src_x,
+                               float src_y, opx* out) {
+    const int x1 = (int)floorf(src_x);
+    const int y1 = (int)floorf(src_y);
+    const int x2 = x1 + 1;
+    const int y2 = y1 + 1;
+    const int x2r = x2 < im->width - 1 ? x2 : im->width - 1;
+    const int y2r = y2 < im->height - 1 ? y2 : im->height - 1;
+    opx p00, p10, p01, p11;
+    back_read(rd, im, x1, y1, &p00);
+    back_read(rd, im, x2r, y1, &p10);
+    back_read(rd, im, x1, y2r, &p01);
+    back_read(rd, im, x2r, y2r, &p11);
+    const float w00 = ((float)x2 - src_x) * ((float)y2 - src_y);
+    const float w10 = (src_x - (float)x1) * ((float)y2 - src_y);
+    const float w01 = ((float)x2 - src_x) * (src_y - (float)y1);
+    const float w11 = (src_x - (float)x1) * (src_y - (float)y1);
+    out->depth = CVGS_DEPTH_32F;
+    out->cn = p00.cn;
+    for (int c = 0; c < p00.cn; ++c) {
+        float acc = tap_as_float(&p00, c) * w00;
+        acc = acc + tap_as_float(&p10, c) * w10;
+        acc = acc + tap_as_float(&p01, c) * w01;
+        acc = acc + tap_as_float(&p11, c) * w11;
+        out->f[c] = acc;
+    }
+}
+
+static void background_pixel(const cvgs_read_desc* rd, int depth, int cn, opx* p) {
+    p->depth = depth;
+    p->cn = cn;
+    for (int c = 0; c < cn; ++c) {
+        p->f[c] = rd->background[c];
+        p->i[c] = (int32_t)rd->background[c];
+    }
+}
+
+/* The read stage for output element (x,y) of plane z.
+ * fk::BatchRead<N,CONDITIONAL_WITH_DEFAULT>: z >= usedPlanes -> default value [FKL]
+ * (reference include/cvGPUSpeedup.cuh:240-243,506-516).
+ * fk::Resize<LINEAR,AR>: inside the AR window interpolate at ((x-x1)*fx,(y-y1)*fy), outside ->
+ * background [FKL] (:238-244). */
+static void read_stage(const cvgs_read_desc* rd, const oracle_resize_geom* geoms, int x, int y, int z,
+                       opx* p) {
+    const cvgs_image2d* im = (const cvgs_image2d*)rd->src + z;
+    const int is_resize = rd->kind == CVGS_READ_RESIZE_LINEAR || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR;
+    int out_depth, out_cn;
+    if (rd->kind == CVGS_READ_PIXEL) {
+        out_depth = CVGS_TYPE_DEPTH(rd->src_type);
+        out_cn = CVGS_TYPE_CN(rd->src_type);
+    } else if (rd->kind == CVGS_READ_RESIZE_LINEAR) {
+        out_depth = CVGS_DEPTH_32F;
+        out_cn = CVGS_TYPE_CN(rd->src_type);
+    } else {
+        out_depth = CVGS_DEPTH_32F;
+        out_cn = rd->yuv_alpha ? 4 : 3;
+    }
+    if (z >= rd->used_planes) {
+        background_pixel(rd, out_depth, out_cn, p);
+        return;
+    }
+    if (!is_resize) {
+        back_read(rd, im, x, y, p);
+        return;
+    }
+    const oracle_resize_geom* g = geoms + z;
+    if (x >= g->x1 && x <= g->x2 && y >= g->y1 && y <= g->y2) {
+        const float src_x = (float)(x - g->x1) * g->fx;
+        const float src_y = (float)(y - g->y1) * g->fy;
+        interpolate_linear(rd, im, src_x, src_y, p);
+    } else {
+        background_pixel(rd, out_depth, out_cn, p);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fk::SaturateCast<I,O> [FKL] == cv::saturate_cast on the CUDA side: float -> integer rounds to
+ * nearest EVEN then clamps (KAT 20*0.5+0.5=10.5 -> 10, 15.5 -> 16: reference
+ * tests/single_operation/test_convertTo.cu:69-73), NaN -> 0; integer -> narrower integer clamps;
+ * anything -> float is a plain conversion. */
+static void int_range(int depth, int64_t* lo, int64_t* hi) {
+    switch (depth) {
+    case CVGS_DEPTH_8U: *lo = 0; *hi = 255; break;
+    case CVGS_DEPTH_8S: *lo = -128; *hi = 127; break;
+    case CVGS_DEPTH_16U: *lo = 0; *hi = 65535; break;
+    case CVGS_DEPTH_16S: *lo = -32768; *hi = 32767; break;
+    default: *lo = INT32_MIN; *hi = INT32_MAX; break;
+    }
+}
+
+static void op_cast(opx* p, int dst_depth) {
+    const int src_depth = p->depth;
+    if (src_depth == dst_depth) return;
+    int64_t lo, hi;
+    int_range(dst_depth, &lo, &hi);
+    for (int c = 0; c < p->cn; ++c) {
+        if (dst_depth == CVGS_DEPTH_32F) {
+            p->f[c] = src_depth == CVGS_DEPTH_32S ? (float)p->i[c] : p->f[c];
+            continue;
+        }
+        int64_t iv;
+        if (src_depth == CVGS_DEPTH_32F) {
+            const float v = p->f[c];
+            if (v != v) iv = 0;
+            else if (v >= 2147483648.0f) iv = INT32_MAX;
+            else if (v <= -2147483648.0f) iv = INT32_MIN;
+            else iv = (int64_t)nearbyintf(v); /* default rounding mode: nearest even */
+        } else if (src_depth == CVGS_DEPTH_32S) {
+            iv = p->i[c];
+        } else {
+            iv = (int64_t)p->f[c];
+        }
+        if (iv < lo) iv = lo;
+        if (iv > hi) iv = hi;
+        if (dst_depth == CVGS_DEPTH_32S) p->i[c] = (int32_t)iv;
+        else p->f[c] = (float)iv;
+    }
+    p->depth = dst_depth;
+}
+
+static void op_reorder(opx* p, int aux, int out_cn) {
+    opx s = *p;
+    for (int c = 0; c < out_cn; ++c) {
+        const int k = (aux >> (2 * c)) & 3;
+        p->f[c] = s.f[k];
+        p->i[c] = s.i[k];
+    }
+    p->cn = out_cn;
+}
+
+/* One Unary/Binary IOp.  fk::Mul/Add/Sub/Div<floatN>: per-channel IEEE fp32, true division (the
+ * reference builds with fast-math OFF, cmake/libs/cuda/target_generation.cmake:11-12); operands
+ * were narrowed double->float by cvScalar2CUDAV (include/cvGPUSpeedupHelpers.cuh:38-54). */
+static int apply_op(const cvgs_op* op, opx* p) {
+    switch (op->opcode) {
+    case CVGS_OP_NOP: return 0;
+    case CVGS_OP_CAST: op_cast(p, op->aux); return 0;
+    case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
+        if (p->depth != CVGS_DEPTH_32F) return CVGS_ERR_UNSUPPORTED;
+        for (int c = 0; c < p->cn; ++c) {
+            const float a = p->f[c], b = op->operand[c];
+            p->f[c] = op->opcode == CVGS_OP_MUL ? a * b
+                    : op->opcode == CVGS_OP_ADD ? a + b
+                    : op->opcode == CVGS_OP_SUB ? a - b
+                                                : a / b;
+        }
+        return 0;
+    /* fk::ColorConversion channel permutations (codes listed at reference
+     * include/cv2cuda_types.cuh:77-85); RGB2BGR = swap 0<->2, RGBA2BGRA keeps 3. */
+    case CVGS_OP_REORDER: op_reorder(p, op->aux, p->cn); return 0;
+    case CVGS_OP_ADD_ALPHA:
+        op_reorder(p, op->aux, 3);
+        p->f[3] = op->operand[0];
+        p->i[3] = (int32_t)op->operand[0];
+        p->cn = 4;
+        return 0;
+    case CVGS_OP_DROP_ALPHA: op_reorder(p, op->aux, 3); return 0;
+    /* *2GRAY: CCIR 601 luma, KATs RGB(10,100,200) -> 84, BGR -> 120
+     * (reference tests/color/test_cvtColor.cu:36,115-123). */
+    case CVGS_OP_GRAY: {
+        if (p->depth == CVGS_DEPTH_32S) return CVGS_ERR_UNSUPPORTED;
+        const float r = p->f[op->aux & 3], g = p->f[(op->aux >> 2) & 3], b = p->f[(op->aux >> 4) & 3];
+        float lum = (r * 0.299f + g * 0.587f) + b * 0.114f;
+        if (p->depth != CVGS_DEPTH_32F) lum = nearbyintf(lum);
+        p->f[0] = lum;
+        p->cn = 1;
+        return 0;
+    }
+    }
+    return CVGS_ERR_INVALID;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+static void store_elem(void* base, size_t elem_index, int depth, const opx* p, int c) {
+    switch (depth) {
+    case CVGS_DEPTH_8U: ((uint8_t*)base)[elem_index] = (uint8_t)p->f[c]; break;
+    case CVGS_DEPTH_8S: ((int8_t*)base)[elem_index] = (int8_t)p->f[c]; break;
+    case CVGS_DEPTH_16U: ((uint16_t*)base)[elem_index] = (uint16_t)p->f[c]; break;
+    case CVGS_DEPTH_16S: ((int16_t*)base)[elem_index] = (int16_t)p->f[c]; break;
+    case CVGS_DEPTH_32S: ((int32_t*)base)[elem_index] = p->i[c]; break;
+    case CVGS_DEPTH_32F: ((float*)base)[elem_index] = p->f[c]; break;
+    }
+}
+
+/* The write stage.
+ * TensorSplit:  out[z][c][y][x], dense NCHW (gpuMat2Tensor, reference include/cvGPUSpeedup.cuh:67-71,
+ *               185-192; layout checked by tests/batchresize/test_batchresize_x_split3D.cu:337-345).
+ * TensorTSplit: out[c][z][y][x] (:199-202; tests/batchread/test_circularbatchread_x_write3D.cu:324-337).
+ * PerThreadWrite<_3D>: packed pixels [z][y][x] (:454-462).  PerThreadWrite<_2D>: one pitched image.
+ * SplitWrite<_2D>: C pitched planes per batch element (:163-183). */
+static void write_stage(const cvgs_write_desc* wr, int x, int y, int z, const opx* p) {
+    const int depth = p->depth, cn = p->cn;
+    const size_t W = (size_t)wr->width, H = (size_t)wr->height;
+    switch (wr->kind) {
+    case CVGS_WRITE_PIXEL_2D: {
+        uint8_t* row = (uint8_t*)wr->data + (size_t)y * (size_t)wr->step;
+        for (int c = 0; c < cn; ++c) store_elem(row, (size_t)x * cn + c, depth, p, c);
+        break;
+    }
+    case CVGS_WRITE_PIXEL_2D_BATCH: {
+        const cvgs_image2d* im = wr->planes2d + z;
+        uint8_t* row = (uint8_t*)im->data + (size_t)y * (size_t)im->step;
+        for (int c = 0; c < cn; ++c) store_elem(row, (size_t)x * cn + c, depth, p, c);
+        break;
+    }
+    case CVGS_WRITE_PIXEL_3D: {
+        const size_t pix = ((size_t)z * H + y) * W + x;
+        for (int c = 0; c < cn; ++c) store_elem(wr->data, pix * cn + c, depth, p, c);
+        break;
+    }
+    case CVGS_WRITE_TENSOR_SPLIT:
+        for (int c = 0; c < cn; ++c)
+            store_elem(wr->data, (((size_t)z * cn + c) * H + y) * W + x, depth, p, c);
+        break;
+    case CVGS_WRITE_TENSOR_T_SPLIT:
+        for (int c = 0; c < cn; ++c)
+            store_elem(wr->data, (((size_t)c * wr->planes + z) * H + y) * W + x, depth, p, c);
+        break;
+    case CVGS_WRITE_SPLIT_2D:
+        for (int c = 0; c < cn; ++c) {
+            const cvgs_image2d* im = wr->planes2d + (size_t)z * cn + c;
+            uint8_t* row = (uint8_t*)im->data + (size_t)y * (size_t)im->step;
+            store_elem(row, (size_t)x, depth, p, c);
+        }
+        break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+static int chain_extent(const cvgs_chain_desc* ch, int* w, int* h) {
+    const cvgs_read_desc* rd = &ch->read;
+    if (rd->batch < 1 || !rd->src) return CVGS_ERR_INVALID;
+    if (rd->kind == CVGS_READ_RESIZE_LINEAR || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR) {
+        *w = rd->dst_width;
+        *h = rd->dst_height;
+    } else {
+        const cvgs_image2d* im = (const cvgs_image2d*)rd->src;
+        *w = im->width;
+        *h = im->height;
+    }
+    return (*w > 0 && *h > 0) ? 0 : CVGS_ERR_INVALID;
+}
+
+/* cvGS::executeOperations(stream, iops...) -> fk::executeOperations (reference
+ * include/cvGPUSpeedup.cuh:464-468): thread (x,y,z) = one output element of plane z:
+ * Read -> Unary/Binary... -> Write, the output of IOp k feeding IOp k+1. */
+int oracle_execute(const cvgs_chain_desc* ch) {
+    if (!ch || ch->struct_size != sizeof(cvgs_chain_desc)) return CVGS_ERR_INVALID;
+    if (ch->n_ops < 0 || ch->n_ops > CVGS_MAX_OPS) return CVGS_ERR_INVALID;
+    if (ch->read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) return CVGS_ERR_UNSUPPORTED;
+    if (CVGS_TYPE_DEPTH(ch->read.src_type) == CVGS_DEPTH_64F ||
+        CVGS_TYPE_DEPTH(ch->write.dst_type) == CVGS_DEPTH_64F)
+        return CVGS_ERR_UNSUPPORTED;
+    int W, H;
+    int rc = chain_extent(ch, &W, &H);
+    if (rc) return rc;
+    const cvgs_read_desc* rd = &ch->read;
+    const int N = rd->batch;
+    oracle_resize_geom* geoms = (oracle_resize_geom*)calloc((size_t)N, sizeof(*geoms));
+    if (!geoms) return CVGS_ERR_INVALID;
+    if (rd->kind == CVGS_READ_RESIZE_LINEAR || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR) {
+        const int used = rd->used_planes < N ? rd->used_planes : N;
+        for (int z = 0; z < used; ++z) {
+            const cvgs_image2d* im = (const cvgs_image2d*)rd->src + z;
+            oracle_resize_geometry(im->width, im->height, rd->dst_width, rd->dst_height,
+                                   rd->aspect_ratio, geoms + z);
+        }
+    }
+    int err = 0;
+    const long total_rows = (long)N * H;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (long zr = 0; zr < total_rows; ++zr) {
+        const int z = (int)(zr / H), y = (int)(zr % H);
+        for (int x = 0; x < W; ++x) {
+            opx p;
+            memset(&p, 0, sizeof(p));
+            read_stage(rd, geoms, x, y, z, &p);
+            int e = 0;
+            for (int k = 0; k < ch->n_ops && !e; ++k) e = apply_op(&ch->ops[k], &p);
+            if (e) {
+                err = e;
+                continue;
+            }
+            if (p.depth != CVGS_TYPE_DEPTH(ch->write.dst_type) || p.cn != CVGS_TYPE_CN(ch->write.dst_type)) {
+                err = CVGS_ERR_INVALID;
+                continue;
+            }
+            write_stage(&ch->write, x, y, z, &p);
+        }
+    }
+    free(geoms);
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* distinct tapped source pixels of one K1 plane = ux * uy (taps are separable). */
+static int64_t distinct_taps(int src, int n_out, float f) {
+    int64_t count = 0;
+    int last = -1;
+    for (int d = 0; d < n_out; ++d) {
+        const float s = (float)d * f;
+        const int a = (int)floorf(s);
+        const int b = a + 1 < src - 1 ? a + 1 : src - 1;
+        if (a > last) { ++count; last = a; }
+        if (b > last) { ++count; last = b; }
+    }
+    return count;
+}
+
+int64_t oracle_resize_tapped_bytes(int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h,
+                                   int32_t aspect_ratio, int32_t bytes_per_pixel) {
+    oracle_resize_geom g;
+    oracle_resize_geometry(src_w, src_h, dst_w, dst_h, aspect_ratio, &g);
+    const int64_t ux = distinct_taps(src_w, g.x2 - g.x1 + 1, g.fx);
+    const int64_t uy = distinct_taps(src_h, g.y2 - g.y1 + 1, g.fy);
+    return ux * uy * bytes_per_pixel;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cvGS::CircularTensor (reference include/cvGPUSpeedup.cuh:600-627) -> fk::CircularTensor [FKL].
+ * Observable contract, pinned by tests/batchread/test_circularbatchread_x_write3D.cu:263-279
+ * (NewestFirst: after 100 updates with value i+1, slot z == 100 - z) and :382-395 (OldestFirst:
+ * slot z == 100 - (BATCH-1-z)): every update the new frame = ops(input) becomes slot 0
+ * (NewestFirst) or BATCH-1 (OldestFirst), every older frame moves one slot, the whole tensor at
+ * data() is rewritten from an INTERNAL history (writes the caller makes into data() never
+ * propagate).  History slots never written read as 0 (the reference leaves them uninitialised). */
+struct oracle_circular_s {
+    int32_t width, height, elem_type, color_planes, batch, order, cp_mode;
+    size_t image_bytes; /* one image: color_planes * H * W elements */
+    uint8_t* out;       /* the tensor at data()                     */
+    uint8_t* hist;      /* batch images, update k at slot k % batch */
+    uint8_t* tmp;       /* one image in standard [c][y][x] order    */
+    int64_t count;
+};
+
+int oracle_circular_create(oracle_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
+                           int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode) {
+    if (!out || width < 1 || height < 1 || color_planes < 1 || batch < 1) return CVGS_ERR_INVALID;
+    const int esz = depth_bytes(CVGS_TYPE_DEPTH(elem_type)) * CVGS_TYPE_CN(elem_type);
+    if (!esz) return CVGS_ERR_INVALID;
+    struct oracle_circular_s* ct = (struct oracle_circular_s*)calloc(1, sizeof(*ct));
+    ct->width = width; ct->height = height; ct->elem_type = elem_type;
+    ct->color_planes = color_planes; ct->batch = batch; ct->order = order; ct->cp_mode = cp_mode;
+    ct->image_bytes = (size_t)esz * width * height * color_planes;
+    ct->out = (uint8_t*)calloc((size_t)batch, ct->image_bytes);
+    ct->hist = (uint8_t*)calloc((size_t)batch, ct->image_bytes);
+    ct->tmp = (uint8_t*)calloc(1, ct->image_bytes);
+    *out = ct;
+    return 0;
+}
+
+int oracle_circular_update(oracle_circular_t ct, const cvgs_chain_desc* chain) {
+    if (!ct || !chain) return CVGS_ERR_INVALID;
+    /* 1. new frame = chain applied to the input, as a single standard-order image */
+    cvgs_chain_desc one = *chain;
+    one.read.batch = 1;
+    one.read.used_planes = 1;
+    one.write.data = ct->tmp;
+    one.write.width = ct->width;
+    one.write.height = ct->height;
+    one.write.planes = 1;
+    if (one.write.kind == CVGS_WRITE_TENSOR_T_SPLIT) one.write.kind = CVGS_WRITE_TENSOR_SPLIT;
+    int rc = oracle_execute(&one);
+    if (rc) return rc;
+    memcpy(ct->hist + (size_t)(ct->count % ct->batch) * ct->image_bytes, ct->tmp, ct->image_bytes);
+    /* 2. rebuild the ordered tensor from the history */
+    const size_t plane_bytes = ct->image_bytes / (size_t)ct->color_planes;
+    for (int z = 0; z < ct->batch; ++z) {
+        const int64_t age = ct->order == CVGS_NEWEST_FIRST ? z : ct->batch - 1 - z;
+        const int64_t src_update = ct->count - age;
+        for (int c = 0; c < ct->color_planes; ++c) {
+            uint8_t* dst = ct->cp_mode == CVGS_PLANES_TRANSPOSED
+                               ? ct->out + ((size_t)c * ct->batch + z) * plane_bytes
+                               : ct->out + ((size_t)z * ct->color_planes + c) * plane_bytes;
+            if (src_update < 0) memset(dst, 0, plane_bytes);
+            else memcpy(dst, ct->hist + (size_t)(src_update % ct->batch) * ct->image_bytes + (size_t)c * plane_bytes,
+                        plane_bytes);
+        }
+    }
+    ct->count++;
+    return 0;
+}
+
+void* oracle_circular_data(oracle_circular_t ct) { return ct ? ct->out : NULL; }
+size_t oracle_circular_bytes(oracle_circular_t ct) { return ct ? ct->image_bytes * (size_t)ct->batch : 0; }
+
+int oracle_circular_destroy(oracle_circular_t ct) {
+    if (!ct) return CVGS_ERR_INVALID;
+    free(ct->out); free(ct->hist); free(ct->tmp); free(ct);
+    return 0;
+}

@@ -1,0 +1,66 @@
+/*
+ * cvgs_oracle.h -- CPU restatement of the reference's hot-path arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the timed CPU baseline.  The product (cvgpuspeedup_amd/) never links or calls it.
+ *
+ * The oracle interprets the same POD chain descriptor as the product's C-ABI
+ * (include/cvgs_hip.h) but with every pointer being a HOST pointer, in plain scalar C compiled
+ * with -O2 -ffp-contract=off (strict IEEE fp32, no FMA, SSE2 so no x87 excess precision).
+ *
+ * Provenance of the arithmetic: the reference's device code lives in the
+ * un-vendored submodule FusedKernelLibrary 0.1.8 (reference .gitmodules:1-3, cmake/libs/fkl.cmake:1-8)
+ * and its comparison side is OpenCV-CUDA 4.8-4.11; neither is present in /root/reference, so the
+ * reference itself is UNBUILDABLE here (needs nvcc + OpenCV-CUDA + FKL) and there is no oracle/_ref.
+ * Every function below restates the published algorithm and cites the reference call site it is
+ * anchored on.  Pinning: tests/test_oracle_kat.py checks this oracle against every known-answer
+ * vector the reference's own tests hold for the path.  The bilinear tap
+ * geometry on NON-constant images, the NV12 coefficients and PRESERVE_AR_RN_EVEN/LEFT are not
+ * constrained by any reference test: for those rows parity is "unpinned" (spec-based).
+ */
+#ifndef CVGS_ORACLE_H
+#define CVGS_ORACLE_H
+
+#include "../include/cvgs_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Resize geometry for one plane: the kernel-side scale factors and the aspect-ratio window. */
+typedef struct oracle_resize_geom {
+    float fx, fy;           /* source step per destination pixel                         */
+    int32_t x1, y1, x2, y2; /* inclusive destination window that receives source pixels  */
+} oracle_resize_geom;
+
+void oracle_resize_geometry(int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h,
+                            int32_t aspect_ratio, oracle_resize_geom* out);
+
+/* Run a whole chain on host memory. All pointers in `chain` are host pointers. Returns 0 or a
+ * negative cvgs_status. */
+int oracle_execute(const cvgs_chain_desc* chain);
+
+/* Threads used by oracle_execute (OpenMP over planes x rows). 1 = scalar port. */
+void oracle_set_threads(int n);
+int oracle_get_threads(void);
+int oracle_max_threads(void);
+
+/* CircularTensor restated as "shift by one slot, then write the new frame" on a host tensor. */
+typedef struct oracle_circular_s* oracle_circular_t;
+int oracle_circular_create(oracle_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
+                           int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode);
+int oracle_circular_update(oracle_circular_t ct, const cvgs_chain_desc* chain);
+void* oracle_circular_data(oracle_circular_t ct);
+size_t oracle_circular_bytes(oracle_circular_t ct);
+int oracle_circular_destroy(oracle_circular_t ct);
+
+/* Algorithmic read bytes of a K1 plane: 3 * ux * uy distinct tapped source
+ * pixels times bytes per pixel. */
+int64_t oracle_resize_tapped_bytes(int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h,
+                                   int32_t aspect_ratio, int32_t bytes_per_pixel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,121 @@
+"""K1 parity on the GPU: N crops -> bilinear resize -> cvtColor/mul/sub/div -> planar fp32 tensor, through the
+C-ABI, bit-exact against the CPU oracle.  Mirrors reference tests/batchresize/test_batchresize_x_split3D.cu and
+test_batchresize_aspectratio_x_split3D.cu, but on NON-constant images (the reference only uses constant colours)."""
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import cvgs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(oracle, frame_np, crops, batch_out, dst=(64, 128), cn=3, flags=0, **kw):
+    import torch
+    dev = torch.device("cuda:0")
+    src_type = cvgs.make_type(cvgs.CV_8U, cn)
+    frame_t = torch.from_numpy(frame_np).to(dev)
+    out_t = torch.full((batch_out, cn * dst[0] * dst[1]), -777.0, dtype=torch.float32, device=dev)
+    g_src = cvgs.GpuMat.from_tensor(frame_t, src_type)
+    g_out = cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1)
+    ops = H.k1_chain(g_src, crops, g_out, dst, cn, **kw)
+    name = cvgs.kernel_name(*ops, flags=flags)
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=flags)
+    torch.cuda.synchronize()
+    gpu = out_t.cpu().numpy()
+
+    ref = np.full((batch_out, cn * dst[0] * dst[1]), -777.0, dtype=np.float32)
+    h_src = cvgs.GpuMat.from_array(frame_np, src_type)
+    h_out = cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1)
+    oracle.execute(cvgs.lower(H.k1_chain(h_src, crops, h_out, dst, cn, **kw)))
+    return gpu, ref, name
+
+
+@pytest.mark.parametrize("batch", [10, 50])
+def test_k1_reference_fixed_crops(oracle, batch):
+    """cfg #2(a): 4K frame, 60x120 crops at (i,i) -> 64x128, kernel-argument descriptors."""
+    frame = H.random_u8((2160, 3840, 3))
+    gpu, ref, name = run_both(oracle, frame, H.fixed_crops(batch), batch)
+    assert name.startswith("k1_u8c3_direct_reorder_mul_sub_div"), name
+    H.assert_bit_exact(gpu, ref, "K1 fixed crops")
+
+
+def test_k1_variable_crops(oracle):
+    """cfg #2(b): 50 variable-size crops (down- and up-scaling in both axes)."""
+    frame = H.random_u8((2160, 3840, 3))
+    crops = H.random_crops(50, 3840, 2160)
+    gpu, ref, _ = run_both(oracle, frame, crops, 50)
+    H.assert_bit_exact(gpu, ref, "K1 variable crops")
+
+
+def test_k1_generic_kernel_agrees(oracle):
+    """The interpreted kernel and the specialised kernel give identical bits."""
+    frame = H.random_u8((1080, 1920, 3), seed=7)
+    crops = H.random_crops(12, 1920, 1080, seed=9)
+    gpu_fast, ref, n1 = run_both(oracle, frame, crops, 12)
+    gpu_gen, _, n2 = run_both(oracle, frame, crops, 12, flags=cvgs.capi.CHAIN_FORCE_GENERIC)
+    assert n1 != n2 and n2.startswith("generic")
+    H.assert_bit_exact(gpu_gen, ref, "generic kernel")
+    H.assert_bit_exact(gpu_fast, gpu_gen, "fast vs generic")
+
+
+def test_k1_four_channels(oracle):
+    """K1-C4: uchar4 -> RGBA2BGRA -> float4 (reference :315-319)."""
+    frame = H.random_u8((720, 1280, 4), seed=11)
+    crops = H.random_crops(20, 1280, 720, seed=12, wmax=300, hmax=600)
+    gpu, ref, name = run_both(oracle, frame, crops, 20, cn=4)
+    assert name.startswith("k1_u8c4")
+    H.assert_bit_exact(gpu, ref, "K1 u8c4")
+
+
+@pytest.mark.parametrize("ar", [cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_RN_EVEN, cvgs.PRESERVE_AR_LEFT])
+def test_k1_aspect_ratio(oracle, ar):
+    """K1-AR: padding with the background value pushed through the chain (reference
+    test_batchresize_aspectratio_x_split3D.cu:151-157), incl. the tested 30x120 crop."""
+    frame = H.random_u8((1080, 1920, 3), seed=21)
+    crops = [(i, i, 30, 120) for i in range(8)] + H.random_crops(16, 1920, 1080, seed=22)
+    gpu, ref, _ = run_both(oracle, frame, crops, 24, ar=ar, background=[128.0] * 3)
+    H.assert_bit_exact(gpu, ref, "K1 AR mode %d" % ar)
+
+
+def test_k1_used_planes_default_value(oracle):
+    """usedPlanes < N: the remaining planes carry the default value pushed through the chain."""
+    frame = H.random_u8((480, 640, 3), seed=31)
+    crops = H.random_crops(10, 640, 480, seed=32, wmax=200, hmax=300)
+    gpu, ref, _ = run_both(oracle, frame, crops, 10, used=6, background=[7.0, 8.0, 9.0])
+    H.assert_bit_exact(gpu, ref, "K1 usedPlanes")
+    t = gpu.reshape(10, 3, 128, 64)
+    assert np.all(t[6:, 0] == t[6, 0, 0, 0])
+
+
+def test_k1_edge_geometries(oracle):
+    """1- and 2-pixel-wide crops (byte-gather path), crops touching the last row/column of the frame, a target
+    that is not a multiple of the 64-lane tile."""
+    frame = H.random_u8((96, 160, 3), seed=41)
+    crops = [(0, 0, 1, 1), (159, 95, 1, 1), (158, 0, 2, 96), (0, 94, 160, 2), (100, 50, 60, 46), (0, 0, 160, 96),
+             (157, 93, 3, 3)]
+    for dst in [(64, 128), (100, 37), (7, 5)]:
+        gpu, ref, _ = run_both(oracle, frame, crops, len(crops), dst=dst)
+        H.assert_bit_exact(gpu, ref, "K1 edges dst=%s" % (dst,))
+
+
+def test_k1_device_plane_table(oracle):
+    """Large batches: descriptors in a device-resident plane table instead of kernel arguments."""
+    import torch
+    frame = H.random_u8((1080, 1920, 3), seed=51)
+    crops = H.random_crops(300, 1920, 1080, seed=52, wmax=256, hmax=256)
+    # library-managed upload (batch > CVGS_KERNARG_PLANES)
+    gpu, ref, name = run_both(oracle, frame, crops, 300)
+    H.assert_bit_exact(gpu, ref, "K1 batch 300 (auto table)")
+    # caller-managed resident table
+    dev = torch.device("cuda:0")
+    frame_t = torch.from_numpy(frame).to(dev)
+    g_src = cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3)
+    out_t = torch.zeros((300, 3 * 64 * 128), dtype=torch.float32, device=dev)
+    g_out = cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1)
+    ops = H.k1_chain(g_src, crops, g_out)
+    table = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
+    ops2 = H.k1_chain(g_src, crops, g_out, table=table.data_ptr())
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops2)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "K1 batch 300 (resident table)")

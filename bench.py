@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of BASELINE.json, measured on MI355X.
+
+Metric: Mpixels/s of the fused crop+resize+normalize+split kernel (K1), 50 variable-size crops of a 4K
+frame -> [50,3,128,64] fp32 NCHW (BASELINE.md cfg #2b), plus the fraction of the HBM roofline the kernel
+reaches and the CPU restatement timed beside it.
+
+A "step" = one pass of the hot path over one batch = ONE cvgs_execute() = one K1 launch over the 50 crops
+of one frame.  Steps cycle over enough distinct resident frames / outputs to exceed 2x the 256 MB Infinity
+Cache, so reads and writes really go to HBM.  Inputs (frames, crop descriptors) are resident in HBM before
+the timed region; the K timed steps are replayed from HIP graphs so the host's launch rate is not what is
+measured (eager numbers are reported next to it under "extra").
+
+N > 1 (one process per GPU, torch.distributed/RCCL): each rank owns its own frames and crop lists (weak
+scaling), runs K1 into its slice of the [N*50,3,128,64] tensor and all-gathers the slices over xGMI every
+step (BASELINE.json north_star).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from cvgpuspeedup_amd import workloads as W  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+CROPS = 50
+INFINITY_CACHE = 256 << 20
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=4096)
+    p.add_argument("--warmup", type=int, default=256)
+    p.add_argument("--crops", type=int, default=CROPS, help="crops per launch (headline: 50)")
+    p.add_argument("--frames", type=int, default=0, help="distinct resident frames (0 = enough to defeat the cache)")
+    p.add_argument("--table", action="store_true", help="descriptors in a resident device table, not kernel args")
+    p.add_argument("--eager", action="store_true", help="time eager launches instead of graph replay")
+    p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    return p.parse_args()
+
+
+class Workload:
+    """F resident 4K frames, F crop lists, F output tensors, F pre-lowered chains."""
+
+    def __init__(self, dev, n_frames, crops_per_launch, rank, world, use_table, frame_wh=W.FRAME_4K,
+                 out_all=None):
+        self.dev = dev
+        fw, fh = frame_wh
+        self.frames, self.outs, self.chains, self.crops, self.tables = [], [], [], [], []
+        self.lib = capi.load_library()
+        self.n = crops_per_launch
+        plane = 3 * W.DST[0] * W.DST[1]
+        for f in range(n_frames):
+            seed = W.SEED + 1000 * rank + f
+            frame = W.random_u8_torch((fh, fw, 3), seed, dev)
+            crops = W.random_crops(crops_per_launch, fw, fh, seed=seed + 500000)
+            if out_all is not None:  # in-place all-gather layout: this rank's slice of the full tensor
+                out = out_all[f][rank * crops_per_launch:(rank + 1) * crops_per_launch]
+            else:
+                out = torch.zeros((crops_per_launch, plane), dtype=torch.float32, device=dev)
+            g_src = cvgs.GpuMat.from_tensor(frame, cvgs.CV_8UC3)
+            g_out = cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)
+            ops = W.k1_chain(g_src, crops, g_out)
+            if use_table:
+                tab = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
+                self.tables.append(tab)
+                ops = W.k1_chain(g_src, crops, g_out, table=tab.data_ptr())
+            self.frames.append(frame)
+            self.outs.append(out)
+            self.crops.append(crops)
+            self.chains.append(cvgs.lower(ops))
+        self.kernel = cvgs.kernel_name(*ops)
+
+    def launch(self, i, stream):
+        ch = self.chains[i % len(self.chains)]
+        rc = self.lib.cvgs_execute(C.byref(ch.desc), stream)
+        if rc:
+            capi.check(rc)
+
+
+def make_graphs(wl, steps, chunk=256):
+    """Capture the K steps as HIP graphs (chunks of <= 256 launches): returns [(graph, n_launches, repeats)]."""
+    plan = []
+    full, rem = divmod(steps, chunk)
+    base = 0
+    for n, reps in ((chunk, full), (rem, 1)):
+        if n == 0 or reps == 0:
+            continue
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            s = torch.cuda.current_stream().cuda_stream
+            for i in range(n):
+                wl.launch(base + i, s)
+        plan.append((g, n, reps))
+        base += n
+    return plan
+
+
+def run_steps(wl, steps, eager, plan=None):
+    if eager:
+        s = torch.cuda.current_stream().cuda_stream
+        for i in range(steps):
+            wl.launch(i, s)
+    else:
+        for g, _, reps in plan:
+            for _ in range(reps):
+                g.replay()
+
+
+def timed(fn, dist_barrier):
+    """barrier + synchronize on both sides; returns (wall seconds, device seconds by HIP events)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dist_barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    dist_barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(wl, seconds):
+    """The CPU restatement (oracle, kind 'port') timed on this box's host cores on a bounded sample of the same
+    workload: frame 0's 50-crop batch, repeated for ~`seconds`.  Also checks the GPU output of that batch."""
+    from oracle import oracle_binding as ob
+    lib = ob.load_oracle()
+    cores = lib.oracle_max_threads()
+    lib.oracle_set_threads(cores)
+    frame = wl.frames[0].cpu().numpy()
+    ref = np.zeros((wl.n, 3 * W.DST[0] * W.DST[1]), np.float32)
+    chain = cvgs.lower(W.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), wl.crops[0],
+                                  cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1)))
+    ob.execute(chain)  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        ob.execute(chain)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or reps >= 100000:
+            break
+    px = wl.n * W.DST[0] * W.DST[1] * reps
+    s = torch.cuda.current_stream().cuda_stream
+    wl.launch(0, s)
+    torch.cuda.synchronize()
+    gpu = wl.outs[0].cpu().numpy()
+    checked = bool((gpu.view(np.uint32) == ref.view(np.uint32)).all())
+    return {"value": round(px / dt / 1e6, 2), "unit": "Mpix/s", "cores": int(cores), "kind": "port",
+            "sample": "%d x the 50-crop batch of frame 0 (oracle/libcvgs_oracle.so, OpenMP %d threads, %.1f s)" % (
+                reps, cores, dt),
+            "gpu_matches_oracle_bit_exact": checked}
+
+
+def algorithmic_bytes(wl):
+    from oracle import oracle_binding as ob  # tap census only, part of the measurement leg
+    per_launch = [W.k1_algorithmic_bytes(c, tapped_bytes_fn=ob.tapped_bytes) for c in wl.crops]
+    return float(np.mean(per_launch))
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    n = a.crops
+    plane = 3 * W.DST[0] * W.DST[1]
+    per_frame_bytes = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + n * plane * 4 * world
+    n_frames = a.frames or max(8, (2 * INFINITY_CACHE + per_frame_bytes - 1) // per_frame_bytes + 1)
+
+    out_all = None
+    if world > 1:
+        out_all = [torch.zeros((world * n, plane), dtype=torch.float32, device=dev) for _ in range(n_frames)]
+    wl = Workload(dev, n_frames, n, rank, world, a.table, out_all=out_all)
+
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+
+    if world == 1:
+        step_fn_graph = None
+        plan = None if a.eager else make_graphs(wl, a.steps)
+        warm = None if a.eager else make_graphs(wl, a.warmup) if a.warmup else []
+        run_steps(wl, a.warmup, a.eager, warm)
+        wall, dev_s = timed(lambda: run_steps(wl, a.steps, a.eager, plan), barrier)
+        gather_note = None
+    else:
+        # K1 into this rank's slice, then the in-place all-gather of the step's tensor (RCCL over xGMI)
+        s = torch.cuda.current_stream().cuda_stream
+
+        def step(i):
+            wl.launch(i, s)
+            full = out_all[i % n_frames]
+            dist.all_gather_into_tensor(full, full[rank * n:(rank + 1) * n])
+
+        for i in range(a.warmup):
+            step(i)
+        wall, dev_s = timed(lambda: [step(i) for i in range(a.steps)], barrier)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        gather_note = "in-place all_gather_into_tensor of %d x %d B per step" % (world, n * plane * 4)
+
+    px_per_step = n * W.DST[0] * W.DST[1] * world
+    value = px_per_step * a.steps / wall / 1e6
+    result = {
+        "metric": "Mpixels/s fused crop+resize+norm+split, 50x->64x128 NCHW",
+        "value": round(value, 1),
+        "unit": "Mpix/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 6),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "cfg2b: %d variable-size crops (w~U[32,512], h~U[64,1024]) of a 4K u8c3 frame -> "
+                               "[%d,3,128,64] fp32 per launch; %d resident frames cycled (working set %.0f MB)" % (
+                                   n, n, n_frames, n_frames * per_frame_bytes / 1e6),
+                   "chain": "resize(bilinear) -> RGB2BGR -> x0.3 -> -(1,4,3.2) -> /(3.2,0.6,11.8) -> TensorSplit",
+                   "crops_per_launch": n, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
+                   "descriptors": "device table" if a.table else "kernel arguments",
+                   "submission": "eager" if a.eager else "hipGraph replay (256-launch graphs)",
+                   "parallelism": "1 process per GPU, crop lists sharded, %s" % (gather_note or "no collective")},
+    }
+
+    if rank == 0:
+        alg = algorithmic_bytes(wl)
+        if world == 1:
+            k_s = dev_s / a.steps  # HIP events on the launch stream over the timed region / K launches
+        else:
+            # time K1 alone with event pairs on the launch stream (the timed region interleaves the gathers)
+            e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+            s = torch.cuda.current_stream().cuda_stream
+            for i, (e0, e1) in enumerate(e):
+                e0.record()
+                wl.launch(i, s)
+                e1.record()
+            torch.cuda.synchronize()
+            k_s = float(np.mean([e0.elapsed_time(e1) for e0, e1 in e])) * 1e-3
+        achieved = alg / k_s / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                              "kernel": wl.kernel, "kernel_us": round(k_s * 1e6, 3),
+                              "algorithmic_bytes_per_launch": int(alg)}
+    if world > 1:
+        barrier()
+    if rank == 0 and world == 1 and not a.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+    if rank == 0 and world == 1 and not a.no_extra:
+        result["extra"] = extra_sweeps(dev, a)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extra_sweeps(dev, a):
+    """Secondary measurements (not the headline): eager submission and larger crop lists per launch, where the
+    kernel leaves the launch-latency regime (SURVEY.md 'hard parts': cfg #2 moves only ~6-10 MB per launch)."""
+    out = {}
+    try:
+        for crops in (50, 200, 800, 3200):
+            per_frame = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + crops * 3 * 64 * 128 * 4
+            nf = max(4, min(24, (2 * INFINITY_CACHE) // per_frame + 1))
+            wl = Workload(dev, nf, crops, 0, 1, use_table=True)
+            steps = max(32, 4096 * 50 // crops)
+            steps -= steps % 1
+            plan = make_graphs(wl, steps)
+            run_steps(wl, min(steps, 64), True)
+            wall, dev_s = timed(lambda: run_steps(wl, steps, False, plan), lambda: None)
+            alg = algorithmic_bytes(wl)
+            out["crops_per_launch_%d" % crops] = {
+                "Mpix_per_s": round(crops * 8192 * steps / wall / 1e6, 1), "kernel_us": round(dev_s / steps * 1e6, 3),
+                "GB_per_s": round(alg / (dev_s / steps) / 1e9, 1), "frac": round(alg / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel": wl.kernel}
+            del wl, plan
+            torch.cuda.empty_cache()
+        wl = Workload(dev, 24, 50, 0, 1, use_table=False)
+        run_steps(wl, 256, True)
+        wall, dev_s = timed(lambda: run_steps(wl, 2048, True), lambda: None)
+        out["eager_50"] = {"Mpix_per_s": round(50 * 8192 * 2048 / wall / 1e6, 1), "us_per_step": round(wall / 2048 * 1e6, 3),
+                           "note": "python ctypes + cvgs_execute + hipLaunchKernel per step (host-bound)"}
+    except Exception as ex:  # extras must never break the headline line
+        out["error"] = repr(ex)
+    return out
+
+
+if __name__ == "__main__":
+    main()

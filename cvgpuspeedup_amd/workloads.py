@@ -1,0 +1,123 @@
+"""Synthetic workloads of BASELINE.md section 2, restated as concrete inputs.
+
+Deterministic generator: splitmix64, seed 0xC0FFEE (identical bytes on any box, numpy on the host or
+torch on the device).  No pixel arithmetic of the hot path happens here."""
+import numpy as np
+
+from . import cvgs
+
+SEED = 0xC0FFEE
+
+FRAME_1080P = (1920, 1080)
+FRAME_4K = (3840, 2160)
+FRAME_6K = (6144, 3456)
+DST = (64, 128)  # crop target, width x height (reference tests/batchresize/test_batchresize_x_split3D.cu:265)
+
+# the per-channel tables of the reference's K1 tests (test_batchresize_x_split3D.cu:56-67,241-252)
+K1_ALPHA = 0.3
+K1_SUB = {1: [1.0], 2: [1.0, 4.0], 3: [1.0, 4.0, 3.2], 4: [1.0, 4.0, 3.2, 0.5]}
+K1_DIV = {1: [3.2], 2: [3.2, 0.6], 3: [3.2, 0.6, 11.8], 4: [3.2, 0.6, 11.8, 33.0]}
+
+
+def splitmix64_array(seed, n):
+    """n successive splitmix64 outputs as uint64 (vectorised numpy)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _to_i64(v):
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def splitmix64_torch(seed, n, device):
+    """The same stream generated on `device` with wrapping int64 arithmetic (bit-identical to numpy)."""
+    import torch
+    idx = torch.arange(1, n + 1, dtype=torch.int64, device=device)
+    z = idx * _to_i64(0x9E3779B97F4A7C15) + _to_i64(seed)
+
+    def lsr(v, k):  # logical shift right on int64
+        return (v >> k) & ((1 << (64 - k)) - 1)
+
+    z = (z ^ lsr(z, 30)) * _to_i64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _to_i64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    return z
+
+
+def random_u8(shape, seed=SEED):
+    n = int(np.prod(shape))
+    words = splitmix64_array(seed, (n + 7) // 8)
+    return words.view(np.uint8)[:n].reshape(shape).copy()
+
+
+def random_u8_torch(shape, seed, device):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    words = splitmix64_torch(seed, (n + 7) // 8, device)
+    return words.view(__import__("torch").uint8)[:n].reshape(shape).contiguous()
+
+
+def random_u16(shape, seed=SEED):
+    n = int(np.prod(shape))
+    words = splitmix64_array(seed, (n + 3) // 4)
+    return words.view(np.uint16)[:n].reshape(shape).copy()
+
+
+def random_crops(n, frame_w, frame_h, seed=SEED + 1, wmin=32, wmax=512, hmin=64, hmax=1024):
+    """BASELINE.md cfg #2(b): w~U[32,512], h~U[64,1024], position uniform inside the frame -> (x,y,w,h)."""
+    r = splitmix64_array(seed, 4 * n)
+    crops = []
+    for i in range(n):
+        w = int(wmin + int(r[4 * i]) % (wmax - wmin + 1))
+        h = int(hmin + int(r[4 * i + 1]) % (hmax - hmin + 1))
+        w, h = min(w, frame_w), min(h, frame_h)
+        x = int(r[4 * i + 2]) % (frame_w - w + 1)
+        y = int(r[4 * i + 3]) % (frame_h - h + 1)
+        crops.append((x, y, w, h))
+    return crops
+
+
+def fixed_crops(n, w=60, h=120):
+    """reference tests/batchresize/test_batchresize_x_split3D.cu:254-263: 60x120 at (i,i)."""
+    return [(i, i, w, h) for i in range(n)]
+
+
+def k1_chain(src_mat, crops, out_mat, dst=DST, cn=3, used=None, ar=cvgs.IGNORE_AR, background=None, swap=True,
+             src_depth=cvgs.CV_8U, table=None):
+    """The K1 chain exactly as the reference test spells it (test_batchresize_x_split3D.cu:311-319):
+    resize -> cvtColor(RGB2BGR) -> multiply(0.3) -> subtract -> divide -> split(tensor)."""
+    src_type = cvgs.make_type(src_depth, cn)
+    f_type = cvgs.make_type(cvgs.CV_32F, cn)
+    mats = [src_mat.roi(*c) for c in crops]
+    rd = cvgs.resize(src_type, cvgs.INTER_LINEAR, mats, dst, len(crops) if used is None else used, background, ar)
+    if table is not None:
+        rd.table = table
+    ops = [rd]
+    if swap and cn == 3:
+        ops.append(cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f_type))
+    elif swap and cn == 4:
+        ops.append(cvgs.cvtColor(cvgs.COLOR_RGBA2BGRA, f_type))
+    ops += [cvgs.multiply(f_type, [K1_ALPHA] * cn), cvgs.subtract(f_type, K1_SUB[cn]),
+            cvgs.divide(f_type, K1_DIV[cn]), cvgs.split(f_type, out_mat, dst)]
+    return ops
+
+
+def k1_algorithmic_bytes(crops, dst=DST, cn=3, src_elem=1, tapped_bytes_fn=None, desc_bytes=48):
+    """per crop, write = cn*4*dstW*dstH, read = distinct tapped source pixels * bytes per pixel,
+    plus the per-crop descriptor.  `tapped_bytes_fn(sw, sh, dw, dh, ar, bpp)` supplies the tap census."""
+    write = cn * 4 * dst[0] * dst[1]
+    total = 0
+    for (_, _, w, h) in crops:
+        if tapped_bytes_fn is not None:
+            read = tapped_bytes_fn(w, h, dst[0], dst[1], cvgs.IGNORE_AR, cn * src_elem)
+        else:
+            read = min(w, 2 * dst[0]) * min(h, 2 * dst[1]) * cn * src_elem  # upper bound
+        total += write + read + desc_bytes
+    return total

@@ -1,0 +1,145 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol include/cvgs_hip.h declares,
+validates chains like the reference's static_asserts/asserts do, and selects the expected kernels (dry run)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "cvgs_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvgs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = header_functions()
+    assert len(names) >= 15
+    declared_in_binding = {s[0] for s in capi.SYMBOLS}
+    for n in names:
+        assert hasattr(lib, n), "libcvgs_hip.so does not export %s" % n
+        assert n in declared_in_binding, "capi.SYMBOLS lacks %s" % n
+    assert lib.cvgs_abi_version() == 1
+    assert b"gfx950" in lib.cvgs_version_string()
+
+
+def test_struct_layout_matches_c(lib):
+    # sizes the C side asserts through struct_size; a mismatch makes every call fail with ERR_INVALID
+    ch = capi.new_chain()
+    assert lib.cvgs_validate(C.byref(ch)) == capi.ERR_INVALID  # empty chain, but NOT a size mismatch
+    assert b"size mismatch" not in lib.cvgs_last_error()
+    ch.struct_size = 8
+    assert lib.cvgs_validate(C.byref(ch)) == capi.ERR_INVALID
+    assert b"size mismatch" in lib.cvgs_last_error()
+
+
+def _k1(n=4, **kw):
+    frame = np.zeros((480, 640, 3), np.uint8)
+    out = np.zeros((n, 3 * 64 * 128), np.float32)
+    return H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), H.random_crops(n, 640, 480, wmax=100, hmax=200),
+                      cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), **kw), (frame, out)
+
+
+def test_kernel_selection(lib):
+    ops, keep = _k1()
+    assert cvgs.kernel_name(*ops) == "k1_u8c3_direct_reorder_mul_sub_div"
+    assert cvgs.kernel_name(*ops, flags=capi.CHAIN_FORCE_GENERIC).startswith("generic_inline")
+    ops2, keep2 = _k1(swap=False)
+    assert cvgs.kernel_name(*ops2) == "k1_u8c3_direct_mul_sub_div"
+    # a program the fast path does not special-case runs interpreted inside the K1 kernel
+    ops3 = ops[:2] + [cvgs.add(cvgs.CV_32FC3, [1, 2, 3])] + ops[2:]
+    assert cvgs.kernel_name(*ops3) == "k1_u8c3_direct_interp"
+    big, keep3 = _k1(n=100)
+    assert cvgs.kernel_name(*big).startswith("k1_u8c3")
+
+
+def test_validation_errors(lib):
+    ops, keep = _k1()
+    good = cvgs.lower(ops)
+    assert lib.cvgs_validate(C.byref(good.desc)) == 0
+
+    def bad(mut, code=capi.ERR_INVALID):
+        ch = cvgs.lower(ops)
+        mut(ch.desc)
+        assert lib.cvgs_validate(C.byref(ch.desc)) == code, lib.cvgs_last_error()
+        with pytest.raises(capi.CvgsError):
+            capi.check(lib.cvgs_validate(C.byref(ch.desc)))
+
+    bad(lambda d: setattr(d.read, "batch", 0))
+    bad(lambda d: setattr(d.read, "used_planes", 99))
+    bad(lambda d: setattr(d.read, "dst_width", 0))
+    bad(lambda d: setattr(d.read, "aspect_ratio", 7))
+    bad(lambda d: setattr(d.write, "width", 63))        # plane size mismatch (reference: assert on split shape)
+    bad(lambda d: setattr(d.write, "planes", 2))        # tensor smaller than the batch
+    bad(lambda d: setattr(d.write, "dst_type", cvgs.CV_32FC4))  # type produced != type written
+    bad(lambda d: setattr(d.write, "data", None))
+    bad(lambda d: setattr(d, "n_ops", 99))
+    bad(lambda d: setattr(d.ops[0], "opcode", 77))
+    bad(lambda d: setattr(d.read, "src_type", cvgs.CV_64FC3), capi.ERR_UNSUPPORTED)
+    # arithmetic on a non-float value: not implemented (the reference spells these on CV_32F types only)
+    frame = np.zeros((8, 8, 3), np.uint8)
+    outm = np.zeros((8, 8, 3), np.uint8)
+    rd = cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)], 1)
+    ch = cvgs.lower([rd, cvgs.multiply(cvgs.CV_8UC3, [2, 2, 2]), cvgs.write(cvgs.CV_8UC3, cvgs.GpuMat.from_array(outm, cvgs.CV_8UC3))])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_UNSUPPORTED
+
+
+def test_builder_type_checks():
+    """The checks the reference does with static_assert (include/cvGPUSpeedup.cuh:76,153-156,211)."""
+    with pytest.raises(ValueError):
+        cvgs.convertTo(cvgs.CV_8UC1, cvgs.CV_32FC2)
+    with pytest.raises(ValueError):
+        cvgs.cvtColor(cvgs.COLOR_RGB2BGR, cvgs.CV_32SC3)
+    with pytest.raises(ValueError):
+        cvgs.cvtColor(8, cvgs.CV_8UC1, cvgs.CV_8UC3)  # COLOR_GRAY2BGR: not in SupportedColorConversions
+    with pytest.raises(ValueError):
+        cvgs.resize(cvgs.CV_8UC3, 0, [], (64, 128))   # INTER_NEAREST: not in SupportedInterpolations
+    ops, keep = _k1()
+    with pytest.raises(TypeError):                     # IOp input type must equal the previous output type
+        cvgs.lower([ops[0], cvgs.multiply(cvgs.CV_8UC3, [1, 1, 1])] + ops[2:])
+
+
+def test_plane_table_build(lib, oracle):
+    ops, keep = _k1(n=5)
+    raw = cvgs.build_plane_table(ops[0])
+    assert len(raw) == lib.cvgs_plane_table_bytes(5) == 5 * 48
+    tab = np.frombuffer(raw, dtype=np.dtype([("data", "<u8"), ("w", "<i4"), ("h", "<i4"), ("step", "<i4"), ("fx", "<f4"),
+                                             ("fy", "<f4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"),
+                                             ("pad", "<i4")]))
+    for i, m in enumerate(ops[0].mats):
+        g = oracle.resize_geometry(m.cols, m.rows, 64, 128, cvgs.IGNORE_AR)
+        assert tab["data"][i] == m.data and tab["w"][i] == m.cols and tab["h"][i] == m.rows
+        assert tab["fx"][i] == np.float32(g.fx) and tab["fy"][i] == np.float32(g.fy)
+        assert (tab["x1"][i], tab["y1"][i], tab["x2"][i], tab["y2"][i]) == (0, 0, 63, 127)
+
+
+@pytest.mark.parametrize("ar", [cvgs.IGNORE_AR, cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_RN_EVEN, cvgs.PRESERVE_AR_LEFT])
+def test_host_geometry_matches_oracle(lib, oracle, ar):
+    """The product's host-side geometry (plane tables) and the oracle's restatement agree bit for bit."""
+    rng = np.random.default_rng(3)
+    frame = np.zeros((1100, 1300, 3), np.uint8)
+    m = cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)
+    sizes = [(int(rng.integers(1, 1300)), int(rng.integers(1, 1100))) for _ in range(40)] + [(30, 120), (60, 120), (1, 1)]
+    for dst in [(64, 128), (128, 64), (33, 77)]:
+        rd = cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [m.roi(0, 0, w, h) for w, h in sizes], dst, len(sizes), None, ar)
+        raw = np.frombuffer(cvgs.build_plane_table(rd), dtype=np.uint8).reshape(len(sizes), 48)
+        for i, (w, h) in enumerate(sizes):
+            g = oracle.resize_geometry(w, h, dst[0], dst[1], ar)
+            fx, fy = raw[i, 20:28].view(np.float32)
+            win = tuple(raw[i, 28:44].view(np.int32))
+            assert (fx, fy) == (np.float32(g.fx), np.float32(g.fy)), (w, h, dst)
+            assert win == (g.x1, g.y1, g.x2, g.y2), (w, h, dst, win)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        capi.load_library()

@@ -1,0 +1,211 @@
+"""GPU parity for every chain shape of the hot path, through the C-ABI:
+ * every reference known-answer vector (tests/golden/reference_kats.json) directly on the GPU,
+ * the same chains on NON-constant seeded inputs, bit-exact against the CPU oracle (integer and fp32 alike:
+   both sides are strict IEEE, no FMA),
+ * write kinds (TensorSplit / TensorTSplit / packed 3D / pitched 2D / SplitWrite), default-value planes."""
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+from tests import kat_runner as K
+
+pytestmark = pytest.mark.gpu
+
+CASES = [c for c in K.load_cases() if "kind" not in c]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_gpu_matches_reference_kat(case):
+    out = K.run_chain_case(case, "gpu")
+    K.check_chain_case(case, out)
+
+
+def _random_src(shape, depth_name, seed):
+    h, w, c = shape
+    if depth_name in ("8U", "8S"):
+        return H.random_u8(shape, seed).view(K.NP_DEPTH[depth_name])
+    if depth_name in ("16U", "16S"):
+        return H.random_u16(shape, seed).view(K.NP_DEPTH[depth_name])
+    if depth_name == "32S":
+        return (H.random_u16(shape, seed).astype(np.int32) - 30000) * 7
+    return (H.random_u16(shape, seed).astype(np.float32) / 64.0 - 300.0).astype(np.float32)
+
+
+def _both(build, out_shape, out_dtype, flags=0):
+    """build(mem_kind, wrap_in, wrap_out) -> iops; runs on the oracle and on the GPU, returns both outputs."""
+    import torch
+    from oracle import oracle_binding as ob
+    dev = torch.device("cuda:0")
+    res = {}
+    for backend in ("oracle", "gpu"):
+        keep = []
+
+        def wrap(a, cvt):
+            if backend == "gpu":
+                t = torch.from_numpy(a).to(dev)
+                keep.append(t)
+                return cvgs.GpuMat.from_tensor(t, cvt)
+            keep.append(a)
+            return cvgs.GpuMat.from_array(a, cvt)
+
+        out = np.full(out_shape, 0, out_dtype)
+        outs = []
+
+        def wrap_out(a, cvt):
+            m = wrap(a, cvt)
+            outs.append((keep[-1], a))
+            return m
+
+        iops = build(wrap, wrap_out, out)
+        if backend == "gpu":
+            cvgs.executeOperations(torch.cuda.current_stream(), *iops, flags=flags)
+            torch.cuda.synchronize()
+            res[backend] = [t.cpu().numpy() for t, _ in outs]
+        else:
+            ob.execute(cvgs.lower(iops, flags))
+            res[backend] = [a for _, a in outs]
+    return res["gpu"], res["oracle"]
+
+
+SRC_TYPES = [("8U", 1), ("8U", 2), ("8U", 3), ("8U", 4), ("8S", 3), ("16U", 1), ("16U", 3), ("16U", 4), ("16S", 3),
+             ("16S", 4), ("32S", 3), ("32F", 1), ("32F", 3), ("32F", 4)]
+
+
+@pytest.mark.parametrize("depth,cn", SRC_TYPES)
+def test_batch_resize_all_source_types(depth, cn):
+    """K1 on every source depth/channel count the reference sweeps (and more), non-constant input."""
+    src = _random_src((300, 400, cn), depth, 100 + cn)
+    stype, ftype = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    crops = H.random_crops(9, 400, 300, seed=77 + cn, wmin=1, wmax=300, hmin=1, hmax=250)
+    dst = (64, 128)
+
+    def build(wrap, wrap_out, out):
+        frame = wrap(src, stype)
+        rd = cvgs.resize(stype, cvgs.INTER_LINEAR, [frame.roi(*c) for c in crops], dst, 9)
+        ops = [rd, cvgs.multiply(ftype, [0.3] * cn), cvgs.subtract(ftype, H.K1_SUB[cn]), cvgs.divide(ftype, H.K1_DIV[cn])]
+        return ops + [cvgs.split(ftype, wrap_out(out, cvgs.CV_32FC1), dst)]
+
+    gpu, ref = _both(build, (9, cn * 64 * 128), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "batch resize %sC%d" % (depth, cn))
+
+
+@pytest.mark.parametrize("depth,cn", [("8U", 3), ("8S", 4), ("16U", 2), ("16S", 3), ("32S", 3), ("32F", 4)])
+def test_pointwise_chain_random(depth, cn):
+    """K6 (read -> convertTo -> sub -> mul -> div -> add -> write) on random pixels, pitched input and output."""
+    src = _random_src((70, 90, cn), depth, 5)
+    stype, ftype = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+
+    def build(wrap, wrap_out, out):
+        full = wrap(src, stype)
+        inp = full.roi(3, 2, 80, 60)  # pitched view
+        o = wrap_out(out, ftype)
+        return [cvgs.ReadIOp(capi.READ_PIXEL, stype, [inp], 1), cvgs.convertTo(stype, ftype),
+                cvgs.subtract(ftype, [0.3] * cn), cvgs.multiply(ftype, H.K1_SUB[cn]), cvgs.divide(ftype, H.K1_DIV[cn]),
+                cvgs.add(ftype, H.K1_DIV[cn]), cvgs.write(ftype, o)]
+
+    gpu, ref = _both(build, (60, 80, cn), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "pointwise %sC%d" % (depth, cn))
+
+
+@pytest.mark.parametrize("dst_depth", ["8U", "8S", "16U", "16S", "32S"])
+def test_saturate_cast_rounding(dst_depth):
+    """fk::SaturateCast float -> integer: nearest-even, clamped, NaN -> 0; via convertTo(alpha, beta)."""
+    vals = np.array([-1e10, -70000.5, -32768.5, -129.5, -128.5, -2.5, -1.5, -0.5, 0.0, 0.5, 1.5, 2.5, 10.5, 15.5, 126.5,
+                     127.5, 254.5, 255.5, 256.5, 32767.5, 65534.5, 65535.5, 1e10, np.nan, np.inf, -np.inf],
+                    np.float32)
+    src = np.tile(vals, (4, 1))[:, :, None].copy()
+    otype = cvgs.make_type(K.CV_DEPTH[dst_depth], 1)
+
+    def build(wrap, wrap_out, out):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_32FC1, [wrap(src, cvgs.CV_32FC1)], 1),
+                cvgs.convertTo(cvgs.CV_32FC1, otype), cvgs.write(otype, wrap_out(out, otype))]
+
+    gpu, ref = _both(build, (4, len(vals), 1), K.NP_DEPTH[dst_depth])
+    H.assert_bit_exact(gpu[0], ref[0], "saturate cast -> %s" % dst_depth)
+    if dst_depth == "8U":
+        assert list(ref[0][0, :, 0][[9, 10, 11, 12, 13, 17, 23]]) == [0, 2, 2, 10, 16, 255, 0]
+
+
+@pytest.mark.parametrize("code,it,ot", [("RGB2BGR", "8UC3", "8UC3"), ("RGBA2BGRA", "16UC4", "16UC4"),
+                                         ("RGB2GRAY", "8UC3", "8UC1"), ("BGRA2GRAY", "16UC4", "16UC1"),
+                                         ("RGB2GRAY", "32FC3", "32FC1")])
+def test_cvtcolor_random(code, it, ot):
+    d, cn, itype = K.parse_type(it)
+    od, ocn, otype = K.parse_type(ot)
+    src = _random_src((50, 61, cn), d, 9)
+
+    def build(wrap, wrap_out, out):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, itype, [wrap(src, itype)], 1), cvgs.cvtColor(K.CODES[code], itype, otype),
+                cvgs.write(otype, wrap_out(out, otype))]
+
+    gpu, ref = _both(build, (50, 61, ocn), K.NP_DEPTH[od])
+    H.assert_bit_exact(gpu[0], ref[0], "cvtColor %s" % code)
+
+
+def test_add_drop_alpha():
+    src = _random_src((20, 33, 3), "8U", 3)
+
+    def build(wrap, wrap_out, out):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [wrap(src, cvgs.CV_8UC3)], 1),
+                cvgs.cvtColor(cvgs.COLOR_RGB2BGRA, cvgs.CV_8UC3, cvgs.CV_8UC4),
+                cvgs.cvtColor(cvgs.COLOR_BGRA2RGBA, cvgs.CV_8UC4), cvgs.write(cvgs.CV_8UC4, wrap_out(out, cvgs.CV_8UC4))]
+
+    gpu, ref = _both(build, (20, 33, 4), np.uint8)
+    H.assert_bit_exact(gpu[0], ref[0], "add alpha")
+    assert (gpu[0][..., 3] == 255).all() and (gpu[0][..., :3] == src).all()
+
+
+@pytest.mark.parametrize("kind", ["tensor_t_split", "write3d", "split_planes_batch", "write2d_batch"])
+def test_write_kinds(kind):
+    """TensorTSplit (CNHW), PerThreadWrite<_3D>, SplitWrite and batched 2D writes of a resized batch."""
+    src = _random_src((200, 300, 3), "8U", 17)
+    crops = H.random_crops(20, 300, 200, seed=3, wmin=5, wmax=200, hmin=5, hmax=150)
+    dst, n, cn = (48, 40), 20, 3
+    f = cvgs.CV_32FC3
+
+    def build(wrap, wrap_out, out):
+        frame = wrap(src, cvgs.CV_8UC3)
+        ops = [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [frame.roi(*c) for c in crops], dst, n),
+               cvgs.multiply(f, [0.5, 0.25, 2.0])]
+        if kind == "tensor_t_split":
+            o = wrap_out(out, cvgs.CV_32FC1)
+            return ops + [cvgs.splitT(f, o.data, dst[0], dst[1], n, keep=o)]
+        if kind == "write3d":
+            return ops + [cvgs.write(f, wrap_out(out, f), dst)]
+        if kind == "split_planes_batch":
+            planes = [[wrap_out(np.zeros((dst[1], dst[0], 1), np.float32), cvgs.CV_32FC1) for _ in range(cn)] for _ in range(n)]
+            return ops + [cvgs.split(f, planes)]
+        outs = [wrap_out(np.zeros((dst[1], dst[0], 3), np.float32), f) for _ in range(n)]
+        return ops + [cvgs.write_batch(f, outs)]
+
+    shape = {"tensor_t_split": (cn * n, dst[0] * dst[1]), "write3d": (n, dst[0] * dst[1], 3)}.get(kind, (1, 1))
+    gpu, ref = _both(build, shape, np.float32)
+    assert len(gpu) == len(ref) and len(gpu) >= 1
+    for g, r in zip(gpu, ref):
+        H.assert_bit_exact(g, r, kind)
+    if kind == "tensor_t_split":  # CNHW: channel-major
+        nchw_gpu, _ = _both(lambda w, wo, o: build_nchw(w, wo, o, src, crops, dst, n), (n, cn * dst[0] * dst[1]), np.float32)
+        a = gpu[0].reshape(cn, n, dst[1], dst[0])
+        b = nchw_gpu[0].reshape(n, cn, dst[1], dst[0]).transpose(1, 0, 2, 3)
+        H.assert_bit_exact(a, np.ascontiguousarray(b), "CNHW vs NCHW")
+
+
+def build_nchw(wrap, wrap_out, out, src, crops, dst, n):
+    frame = wrap(src, cvgs.CV_8UC3)
+    return [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [frame.roi(*c) for c in crops], dst, n),
+            cvgs.multiply(cvgs.CV_32FC3, [0.5, 0.25, 2.0]), cvgs.split(cvgs.CV_32FC3, wrap_out(out, cvgs.CV_32FC1), dst)]
+
+
+def test_batch_pixel_read_default_value():
+    """executeOperations(array<GpuMat,N>, activeBatch, defaultValue, ...) (reference :506-516)."""
+    srcs = [_random_src((30, 40, 3), "8U", 50 + i) for i in range(6)]
+
+    def build(wrap, wrap_out, out):
+        mats = [wrap(s, cvgs.CV_8UC3) for s in srcs]
+        rd = cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, mats, 4, None, cvgs.IGNORE_AR, [9.0, 8.0, 7.0])
+        return [rd, cvgs.convertTo(cvgs.CV_8UC3, cvgs.CV_32FC3, 0.5), cvgs.write(cvgs.CV_32FC3, wrap_out(out, cvgs.CV_32FC3), (40, 30))]
+
+    gpu, ref = _both(build, (6, 40 * 30, 3), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "activeBatch/default")
+    assert (gpu[0][4:] == np.array([4.5, 4.0, 3.5], np.float32)).all()

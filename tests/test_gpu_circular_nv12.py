@@ -1,0 +1,175 @@
+"""GPU parity for the CircularTensor (K9/K10) and the NV12 read-back chain (K4), through the C-ABI."""
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+from tests import kat_runner as K
+
+pytestmark = pytest.mark.gpu
+
+CIRC = [c for c in K.load_cases() if c.get("kind") == "circular"]
+
+
+def _write_iop(ct, name, ftype):
+    return {"tensor_split": ct.write_split, "tensor_t_split": ct.write_splitT, "tensor_write": ct.write_packed}[name](ftype)
+
+
+@pytest.mark.parametrize("case", CIRC, ids=[c["name"] for c in CIRC])
+def test_circular_tensor_reference_kat(case):
+    """After 100 updates with value i+1 slot z holds 100 - age(z) (reference
+    tests/batchread/test_circularbatchread_x_write3D.cu:263-279,324-337,382-395,440-457)."""
+    import torch
+    dev = torch.device("cuda:0")
+    _, icn, itype = K.parse_type(case["in_type"])
+    ed, ecn, etype = K.parse_type(case["elem_type"])
+    order = cvgs.NewestFirst if case["order"] == "NewestFirst" else cvgs.OldestFirst
+    mode = cvgs.Transposed if case["mode"] == "Transposed" else cvgs.Standard
+    W, H_, B, CP = case["width"], case["height"], case["batch"], case["color_planes"]
+    ftype = cvgs.make_type(cvgs.CV_32F, icn)
+    ct = cvgs.CircularTensor(itype, etype, CP, B, order, mode, W, H_)
+    frame = torch.zeros((H_, W, icn), dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream()
+    for i in range(case["iters"]):
+        frame.fill_(i + 1)
+        ct.update(s, cvgs.GpuMat.from_tensor(frame, itype), cvgs.convertTo(itype, ftype), _write_iop(ct, case["write"], ftype))
+    torch.cuda.synchronize()
+    assert ct.updates() == case["iters"]
+    n = ct.nbytes() // 4
+    import ctypes as C
+    host = np.empty(n, np.float32)
+    out_t = torch.empty(n, dtype=torch.float32, device=dev)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(out_t.data_ptr()), C.c_void_p(ct.data()), C.c_size_t(n * 4), 3) == 0  # D2D
+    host = out_t.cpu().numpy()
+    exp = np.asarray(case["expected_slot"], np.float32)
+    if case["write"] == "tensor_t_split":
+        assert (host.reshape(CP, B, H_, W) == exp[None, :, None, None]).all()
+    elif case["write"] == "tensor_split":
+        assert (host.reshape(B, CP, H_, W) == exp[:, None, None, None]).all()
+    else:
+        assert (host.reshape(B, H_, W, ecn) == exp[:, None, None, None]).all()
+    ct.release()
+
+
+def _read_device(ptr, nbytes):
+    import ctypes as C
+    import torch
+    t = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(nbytes), 3) == 0
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("order,mode", [(cvgs.NewestFirst, cvgs.Standard), (cvgs.OldestFirst, cvgs.Standard),
+                                        (cvgs.NewestFirst, cvgs.Transposed), (cvgs.OldestFirst, cvgs.Transposed)])
+def test_circular_tensor_resize_normalize_vs_oracle(oracle, order, mode):
+    """cfg #4 shape in small: every update pushes a NEW random frame through resize + normalize (the
+    update(stream, readIOp, ops..., write) form, reference include/cvGPUSpeedup.cuh:619-622); the whole tensor is
+    compared with the oracle after every update, including the not-yet-filled slots."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H_, B = 96, 54, 5
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, B, order, mode, W, H_)
+    oc = oracle.OracleCircular(W, H_, cvgs.CV_32FC1, 3, B, order, mode)
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    for i in range(2 * B + 3):
+        frame = H.random_u8((216, 384, 3), seed=1000 + i)
+        frame_t = torch.from_numpy(frame).to(dev)
+        pw = [cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3])]
+        wr_g = ct.write_splitT(f) if mode == cvgs.Transposed else ct.write_split(f)
+        ct.update(s, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), (W, H_)),
+                  *pw, wr_g)
+        kind = capi.WRITE_TENSOR_T_SPLIT if mode == cvgs.Transposed else capi.WRITE_TENSOR_SPLIT
+        oc.update(cvgs.lower([cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), (W, H_)),
+                              *pw, cvgs.WriteIOp(kind, f, 16, W, H_, 0, B)]))
+        torch.cuda.synchronize()
+        got = _read_device(ct.data(), ct.nbytes()).view(np.float32)
+        H.assert_bit_exact(got, oc.array(np.float32), "circular update %d" % i)
+    ct.release()
+
+
+def test_circular_batch_read_rotation():
+    """fk::CircularBatchRead<Ascendent>: out[z] = in[(z + first) % BATCH] (reference :24-87)."""
+    import torch
+    dev = torch.device("cuda:0")
+    case = [c for c in K.load_cases() if c["name"] == "circular_batch_read"][0]
+    B, first, W, H_ = case["batch"], case["first"], case["width"], case["height"]
+    planes = [torch.full((H_, W, 3), i, dtype=torch.uint8, device=dev) for i in range(B)]
+    mats = [cvgs.GpuMat.from_tensor(p, cvgs.CV_8UC3) for p in planes]
+    out = torch.zeros((B, W * H_, 3), dtype=torch.uint8, device=dev)
+    cvgs.executeOperations(torch.cuda.current_stream(),
+                           cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [mats[(z + first) % B] for z in range(B)], B),
+                           cvgs.write(cvgs.CV_8UC3, cvgs.GpuMat.from_tensor(out, cvgs.CV_8UC3), (W, H_)))
+    torch.cuda.synchronize()
+    exp = np.asarray(case["expected_plane"], np.uint8)
+    assert (out.cpu().numpy().reshape(B, H_, W, 3) == exp[:, None, None, None]).all()
+
+
+def _nv12(w, h, seed):
+    return H.random_u8((h + h // 2, w, 1), seed)
+
+
+@pytest.mark.parametrize("rng,prim,alpha", [(capi.YUV_FULL, capi.BT709, True), (capi.YUV_FULL, capi.BT601, True),
+                                             (capi.YUV_LIMITED, capi.BT709, False), (capi.YUV_LIMITED, capi.BT601, False)])
+def test_nv12_resize_chain(oracle, rng, prim, alpha):
+    """K4: Resize<LINEAR>(ReadYUV<NV12> + ConvertYUVToRGB) -> SaturateCast -> VectorReorder<2,1,0,3> -> write
+    (reference tests/resize/test_fused_resize.cu:141-147) and the float/normalize/split variant of cfg #3."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h, dst = 640, 360, (213, 120)
+    buf = _nv12(w, h, 77)
+    cn = 4 if alpha else 3
+    f, u = cvgs.make_type(cvgs.CV_32F, cn), cvgs.make_type(cvgs.CV_8U, cn)
+
+    def chains(wrap, out8, outf):
+        luma = wrap(buf)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, luma.data, luma.step, owner=luma.owner)
+        code = cvgs.COLOR_RGBA2BGRA if alpha else cvgs.COLOR_RGB2BGR
+        a = [cvgs.read_nv12(luma, dst, rng, prim, alpha), cvgs.convertTo(f, u), cvgs.cvtColor(code, u), cvgs.write(u, out8)]
+        b = [cvgs.read_nv12(luma, dst, rng, prim, alpha), cvgs.cvtColor(code, f), cvgs.multiply(f, [0.3] * cn),
+             cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn]), cvgs.split(f, outf, dst)]
+        return a, b
+
+    t_buf = torch.from_numpy(buf).to(dev)
+    g8 = torch.zeros((dst[1], dst[0], cn), dtype=torch.uint8, device=dev)
+    gf = torch.zeros((1, cn * dst[0] * dst[1]), dtype=torch.float32, device=dev)
+    a, b = chains(lambda x: cvgs.GpuMat.from_tensor(t_buf, cvgs.CV_8UC1), cvgs.GpuMat.from_tensor(g8, u),
+                     cvgs.GpuMat.from_tensor(gf, cvgs.CV_32FC1))
+    s = torch.cuda.current_stream()
+    cvgs.executeOperations(s, *a)
+    cvgs.executeOperations(s, *b)
+    torch.cuda.synchronize()
+    r8 = np.zeros((dst[1], dst[0], cn), np.uint8)
+    rf = np.zeros((1, cn * dst[0] * dst[1]), np.float32)
+    a, b = chains(lambda x: cvgs.GpuMat.from_array(buf, cvgs.CV_8UC1), cvgs.GpuMat.from_array(r8, u),
+                     cvgs.GpuMat.from_array(rf, cvgs.CV_32FC1))
+    oracle.execute(cvgs.lower(a))
+    oracle.execute(cvgs.lower(b))
+    H.assert_bit_exact(g8.cpu().numpy(), r8, "NV12 resize -> u8")
+    H.assert_bit_exact(gf.cpu().numpy(), rf, "NV12 resize -> normalize -> split")
+
+
+def test_nv12_full_resolution_convert(oracle):
+    """ReadYUV<NV12> -> ConvertYUVToRGB -> SaturateCast -> write at full resolution (reference :50-53)."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h = 256, 128
+    buf = _nv12(w, h, 99)
+    f, u = cvgs.CV_32FC4, cvgs.CV_8UC4
+    t_buf = torch.from_numpy(buf).to(dev)
+    g = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+    gm = cvgs.GpuMat.from_tensor(t_buf, cvgs.CV_8UC1)
+    cvgs.executeOperations(torch.cuda.current_stream(),
+                           cvgs.read_nv12(cvgs.GpuMat(h, w, cvgs.CV_8UC1, gm.data, gm.step, owner=t_buf), None,
+                                          capi.YUV_FULL, capi.BT601, True),
+                           cvgs.convertTo(f, u), cvgs.write(u, cvgs.GpuMat.from_tensor(g, u)))
+    torch.cuda.synchronize()
+    r = np.zeros((h, w, 4), np.uint8)
+    hm = cvgs.GpuMat.from_array(buf, cvgs.CV_8UC1)
+    oracle.execute(cvgs.lower([cvgs.read_nv12(cvgs.GpuMat(h, w, cvgs.CV_8UC1, hm.data, hm.step, owner=buf), None,
+                                              capi.YUV_FULL, capi.BT601, True),
+                               cvgs.convertTo(f, u), cvgs.write(u, cvgs.GpuMat.from_array(r, u))]))
+    H.assert_bit_exact(g.cpu().numpy(), r, "NV12 full-res")
+    assert (r[..., 3] == 255).all()

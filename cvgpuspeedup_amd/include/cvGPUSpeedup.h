@@ -1,0 +1,290 @@
+// cvGPUSpeedup.h -- the cvGS:: facade for the hot path, source-compatible with the reference's
+// include/cvGPUSpeedup.cuh call shapes, on the MI355X engine.
+//
+//   cvGS::executeOperations(stream, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, N>(crops, size, used),
+//                           cvGS::cvtColor<cv::COLOR_RGB2BGR, CV_32FC3>(), cvGS::multiply<CV_32FC3>(a),
+//                           cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d),
+//                           cvGS::split<CV_32FC3>(tensor, size));
+//
+// Each builder returns a typed IOp value (fk_compat.h); executeOperations checks the type chain at compile time,
+// lowers the list to ONE cvgs_chain_desc and calls cvgs_execute() (include/cvgs_hip.h) -> ONE HIP kernel.  All
+// calls are asynchronous on the given stream and never synchronise; device memory stays caller-owned.
+// Not provided (outside the hot path): cvGS::warp, fk::StaticLoop.
+#pragma once
+
+#include <array>
+#include <cassert>
+#include <vector>
+
+#include "cvGPUSpeedupHelpers.h"
+
+namespace cvGS {
+
+enum AspectRatio { PRESERVE_AR = 0, IGNORE_AR = 1, PRESERVE_AR_RN_EVEN = 2, PRESERVE_AR_LEFT = 3 };
+
+// ---- GpuMat -> fk pointer adapters ------------------------------------------------------------------------
+template <typename T>
+inline fk::Ptr2D<T> gpuMat2Ptr2D(const cv::cuda::GpuMat& m) {
+    return fk::Ptr2D<T>(reinterpret_cast<T*>(m.data), (uint)m.cols, (uint)m.rows, (uint)m.step);
+}
+template <typename T>
+inline fk::RawPtr<fk::_2D, T> gpuMat2RawPtr2D(const cv::cuda::GpuMat& m) {
+    fk::RawPtr<fk::_2D, T> p;
+    p.data = reinterpret_cast<T*>(m.data);
+    p.dims = {(uint)m.cols, (uint)m.rows, (uint)m.step};
+    return p;
+}
+template <typename T, size_t N>
+inline std::array<fk::RawPtr<fk::_2D, T>, N> gpuMat2RawPtr2D_arr(const std::array<cv::cuda::GpuMat, N>& src, int used = (int)N) {
+    std::array<fk::RawPtr<fk::_2D, T>, N> out{};
+    for (int i = 0; i < used && i < (int)N; ++i) out[(size_t)i] = gpuMat2RawPtr2D<T>(src[(size_t)i]);
+    return out;
+}
+template <typename T>
+inline fk::Tensor<T> gpuMat2Tensor(const cv::cuda::GpuMat& m, const cv::Size& plane, int colorPlanes) {
+    return fk::Tensor<T>(reinterpret_cast<T*>(m.data), (uint)plane.width, (uint)plane.height, (uint)m.rows, (uint)colorPlanes);
+}
+
+// ---- pointwise builders ------------------------------------------------------------------------------------
+template <int I, int O>
+inline auto convertTo() {
+    static_assert(CV_MAT_CN(I) == CV_MAT_CN(O), "convertTo does not support changing the number of channels, neither in cvGS nor in OpenCV. Please, use cvGS::cvtColor instead.");
+    return fk::Unary<fk::SaturateCast<CUDA_T(I), CUDA_T(O)>>{};
+}
+
+namespace internal {
+// integral outputs go through float: cast -> mul -> (add) -> saturate; float outputs: cast -> mul -> (add)
+template <int I, int O>
+inline auto convertToScaled(float alpha, const float* beta) {
+    static_assert(CV_MAT_CN(I) == CV_MAT_CN(O), "convertTo does not support changing the number of channels, neither in cvGS nor in OpenCV. Please, use cvGS::cvtColor instead.");
+    constexpr bool integral = CV_MAT_DEPTH(O) <= CV_32S;
+    constexpr int mid = integral ? CV_32F : CV_MAT_DEPTH(O);
+    fk::PointwiseSeq<CUDA_T(I), CUDA_T(O)> seq;
+    fk::ChainBuilder b;
+    b.op(CVGS_OP_CAST, mid);
+    const float a[4] = {alpha, alpha, alpha, alpha};
+    b.op(CVGS_OP_MUL, 0, a);
+    if (beta) {
+        const float bb[4] = {*beta, *beta, *beta, *beta};
+        b.op(CVGS_OP_ADD, 0, bb);
+    }
+    if (integral) b.op(CVGS_OP_CAST, CV_MAT_DEPTH(O));
+    seq.ops.assign(b.d.ops, b.d.ops + b.d.n_ops);
+    return seq;
+}
+} // namespace internal
+
+template <int I, int O> inline auto convertTo(float alpha) { return internal::convertToScaled<I, O>(alpha, nullptr); }
+template <int I, int O> inline auto convertTo(float alpha, float beta) { return internal::convertToScaled<I, O>(alpha, &beta); }
+
+template <int I> inline auto multiply(const cv::Scalar& s) { return fk::Binary<fk::Mul<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
+template <int I> inline auto subtract(const cv::Scalar& s) { return fk::Binary<fk::Sub<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
+template <int I> inline auto divide(const cv::Scalar& s) { return fk::Binary<fk::Div<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
+template <int I> inline auto add(const cv::Scalar& s) { return fk::Binary<fk::Add<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
+
+template <cv::ColorConversionCodes CODE, int I, int O = I>
+inline auto cvtColor() {
+    static_assert((CV_MAT_DEPTH(I) == CV_8U || CV_MAT_DEPTH(I) == CV_16U || CV_MAT_DEPTH(I) == CV_32F) &&
+                  (CV_MAT_DEPTH(O) == CV_8U || CV_MAT_DEPTH(O) == CV_16U || CV_MAT_DEPTH(O) == CV_32F),
+                  "Wrong CV_TYPE_DEPTH, it has to be CV_8U, or CV_16U or CV_32F");
+    static_assert(isSupportedColorConversion<CODE>, "Color conversion type not supported yet.");
+    return fk::Unary<fk::ColorConversion<(fk::ColorConversionCodes)CODE, CUDA_T(I), CUDA_T(O)>>{};
+}
+
+// ---- write builders ------------------------------------------------------------------------------------------
+template <int O>
+inline auto split(const std::vector<cv::cuda::GpuMat>& output) {
+    std::vector<fk::Ptr2D<BASE_CUDA_T(O)>> planes;
+    for (const auto& m : output) planes.push_back(gpuMat2Ptr2D<BASE_CUDA_T(O)>(m));
+    return fk::SplitWrite<fk::_2D, CUDA_T(O)>::build(planes);
+}
+template <int O, size_t N>
+inline auto split(const std::array<std::vector<cv::cuda::GpuMat>, N>& output) {
+    std::array<std::vector<fk::Ptr2D<BASE_CUDA_T(O)>>, N> planes{};
+    for (size_t i = 0; i < N; ++i)
+        for (const auto& m : output[i]) planes[i].push_back(gpuMat2Ptr2D<BASE_CUDA_T(O)>(m));
+    return fk::SplitWrite<fk::_2D, CUDA_T(O)>::build(planes);
+}
+// NCHW tensor living in a GpuMat with one image per row
+template <int O>
+inline auto split(const cv::cuda::GpuMat& output, const cv::Size& plane) {
+    assert(output.cols % (plane.width * plane.height) == 0 && output.cols / (plane.width * plane.height) == CV_MAT_CN(O) &&
+           "Each row of the GpuMat should contain as many planes as width / (planeDims.width * planeDims.height)");
+    return fk::Write<fk::TensorSplit<CUDA_T(O)>>{gpuMat2Tensor<BASE_CUDA_T(O)>(output, plane, CV_MAT_CN(O)).ptr()};
+}
+template <int O>
+inline auto split(const fk::RawPtr<fk::_3D, typename fk::VectorTraits<CUDA_T(O)>::base>& output) {
+    return fk::Write<fk::TensorSplit<CUDA_T(O)>>{output};
+}
+template <int O>
+inline auto splitT(const fk::RawPtr<fk::T3D, typename fk::VectorTraits<CUDA_T(O)>::base>& output) {
+    return fk::Write<fk::TensorTSplit<CUDA_T(O)>>{output};
+}
+template <int O>
+inline auto write(const cv::cuda::GpuMat& output) {
+    return fk::Write<fk::PerThreadWrite<fk::_2D, CUDA_T(O)>>{gpuMat2RawPtr2D<CUDA_T(O)>(output)};
+}
+template <int O>
+inline auto write(const cv::cuda::GpuMat& output, const cv::Size& plane) {
+    return fk::Write<fk::PerThreadWrite<fk::_3D, CUDA_T(O)>>{gpuMat2Tensor<CUDA_T(O)>(output, plane, 1).ptr()};
+}
+template <typename T>
+inline auto write(const fk::Tensor<T>& output) {
+    return fk::Write<fk::PerThreadWrite<fk::_3D, T>>{output.ptr()};
+}
+
+// ---- read builders ---------------------------------------------------------------------------------------------
+// single image: resize<T, INTER>(GpuMat, dsize, fx, fy); the output type is CV_32F of the same channels
+template <int T, int INTER_F>
+inline auto resize(const cv::cuda::GpuMat& input, const cv::Size& dsize, double fx, double fy) {
+    static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");
+    return fk::Resize<(fk::InterpolationType)INTER_F>::build(gpuMat2RawPtr2D<CUDA_T(T)>(input), fk::Size(dsize.width, dsize.height), fx, fy);
+}
+
+// batch: N crops -> dsize, planes >= usedPlanes (and the AR padding) take backgroundValue
+template <int T, int INTER_F, int NPtr, AspectRatio AR_ = IGNORE_AR>
+inline auto resize(const std::array<cv::cuda::GpuMat, NPtr>& input, const cv::Size& dsize, const int& usedPlanes,
+                   const cv::Scalar& backgroundValue_ = cvScalar_set<CV_MAKETYPE(CV_32F, CV_MAT_CN(T))>(0)) {
+    static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");
+    fk::BatchResizeRead<CUDA_T(T)> rd;
+    rd.planes.resize((size_t)NPtr, cvgs_image2d{nullptr, 0, 0, 0, 0});
+    for (int i = 0; i < usedPlanes && i < NPtr; ++i) rd.planes[(size_t)i] = fk::image2d(gpuMat2RawPtr2D<CUDA_T(T)>(input[(size_t)i]));
+    rd.used = usedPlanes;
+    rd.dsize = fk::Size(dsize.width, dsize.height);
+    rd.ar = (int)AR_;
+    for (int c = 0; c < CV_MAT_CN(T); ++c) rd.background[c] = static_cast<float>(backgroundValue_[c]);
+    return rd;
+}
+
+// crop == an ROI view (zero cost): same pointer arithmetic as GpuMat::operator()(Rect); Rect2d doubles truncate
+inline cv::cuda::GpuMat crop(const cv::cuda::GpuMat& input, const cv::Rect2d& rect) { return input(cv::Rect(rect)); }
+template <size_t BATCH>
+inline std::array<cv::cuda::GpuMat, BATCH> crop(const cv::cuda::GpuMat& input, const std::array<cv::Rect2d, BATCH>& rects) {
+    std::array<cv::cuda::GpuMat, BATCH> out;
+    for (size_t i = 0; i < BATCH; ++i) out[i] = input(cv::Rect(rects[i]));
+    return out;
+}
+
+// ---- executeOperations ---------------------------------------------------------------------------------------------
+template <bool ENABLE_THREAD_FUSION, typename... IOpTypes>
+inline void executeOperations(const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    fk::executeOperations<ENABLE_THREAD_FUSION>(cv::cuda::StreamAccessor::getStream(stream), iops...);
+}
+template <typename... IOpTypes>
+inline void executeOperations(const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<true>(stream, iops...);
+}
+
+namespace internal {
+template <typename First, typename... Rest> struct first_of { using type = First; };
+template <typename... T> using first_input_t = typename first_of<T...>::type::InputType;
+template <typename... T> struct last_of;
+template <typename T> struct last_of<T> { using type = T; };
+template <typename T, typename... R> struct last_of<T, R...> : last_of<R...> {};
+template <typename... T> using last_output_t = typename last_of<T...>::type::OutputType;
+
+template <typename T, size_t N>
+inline fk::BatchPixelRead<T> batchRead(const std::array<cv::cuda::GpuMat, N>& in, size_t active, const cv::Scalar& def) {
+    fk::BatchPixelRead<T> rd;
+    rd.planes.resize(N, cvgs_image2d{nullptr, 0, 0, 0, 0});
+    for (size_t i = 0; i < active && i < N; ++i) rd.planes[i] = fk::image2d(gpuMat2RawPtr2D<T>(in[i]));
+    rd.used = (int)active;
+    const T d = cvScalar2CUDAV_t<T>::get(def); // narrowed to the INPUT type, as the reference does
+    fk::vec_to_floats(d, rd.background);
+    return rd;
+}
+} // namespace internal
+
+// input GpuMat given: a per-pixel read of it is prepended
+template <bool TF, typename... IOpTypes>
+inline void executeOperations(const cv::cuda::GpuMat& input, const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    using In = internal::first_input_t<IOpTypes...>;
+    const fk::Read<fk::PerThreadRead<fk::_2D, In>> read{gpuMat2RawPtr2D<In>(input)};
+    fk::executeOperations<TF>(cv::cuda::StreamAccessor::getStream(stream), read, iops...);
+}
+template <typename... IOpTypes>
+inline void executeOperations(const cv::cuda::GpuMat& input, const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<true>(input, stream, iops...);
+}
+// input and output GpuMat given: read prepended, per-pixel write appended
+template <bool TF, typename... IOpTypes>
+inline void executeOperations(const cv::cuda::GpuMat& input, cv::cuda::GpuMat& output, cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    using In = internal::first_input_t<IOpTypes...>;
+    using Out = internal::last_output_t<IOpTypes...>;
+    const fk::Read<fk::PerThreadRead<fk::_2D, In>> read{gpuMat2RawPtr2D<In>(input)};
+    const fk::Write<fk::PerThreadWrite<fk::_2D, Out>> wr{gpuMat2RawPtr2D<Out>(output)};
+    fk::executeOperations<TF>(cv::cuda::StreamAccessor::getStream(stream), read, iops..., wr);
+}
+template <typename... IOpTypes>
+inline void executeOperations(const cv::cuda::GpuMat& input, cv::cuda::GpuMat& output, cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<true>(input, output, stream, iops...);
+}
+// batch reads
+template <bool TF, size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const size_t& activeBatch, const cv::Scalar& defaultValue,
+                              const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    using In = internal::first_input_t<IOpTypes...>;
+    fk::executeOperations<TF>(cv::cuda::StreamAccessor::getStream(stream), internal::batchRead<In>(input, activeBatch, defaultValue), iops...);
+}
+template <bool TF, size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    using In = internal::first_input_t<IOpTypes...>;
+    fk::executeOperations<TF>(cv::cuda::StreamAccessor::getStream(stream), internal::batchRead<In>(input, Batch, cv::Scalar()), iops...);
+}
+template <size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const size_t& activeBatch, const cv::Scalar& defaultValue,
+                              const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<true>(input, activeBatch, defaultValue, stream, iops...);
+}
+template <size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<true>(input, stream, iops...);
+}
+// batch reads with a tensor output (one packed image per row of `output`)
+template <bool TF, size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const size_t& activeBatch, const cv::Scalar& defaultValue,
+                              const cv::cuda::GpuMat& output, const cv::Size& outputPlane, const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    using In = internal::first_input_t<IOpTypes...>;
+    using Out = internal::last_output_t<IOpTypes...>;
+    const fk::Write<fk::PerThreadWrite<fk::_3D, Out>> wr{gpuMat2Tensor<Out>(output, outputPlane, 1).ptr()};
+    fk::executeOperations<TF>(cv::cuda::StreamAccessor::getStream(stream), internal::batchRead<In>(input, activeBatch, defaultValue), iops..., wr);
+}
+template <bool TF, size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const cv::cuda::GpuMat& output, const cv::Size& outputPlane,
+                              const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<TF>(input, Batch, cv::Scalar(), output, outputPlane, stream, iops...);
+}
+template <size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const size_t& activeBatch, const cv::Scalar& defaultValue,
+                              const cv::cuda::GpuMat& output, const cv::Size& outputPlane, const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<true>(input, activeBatch, defaultValue, output, outputPlane, stream, iops...);
+}
+template <size_t Batch, typename... IOpTypes>
+inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, const cv::cuda::GpuMat& output, const cv::Size& outputPlane,
+                              const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+    executeOperations<true>(input, output, outputPlane, stream, iops...);
+}
+
+// ---- CircularTensor --------------------------------------------------------------------------------------------------
+template <int I, int O, int COLOR_PLANES, int BATCH, fk::CircularTensorOrder CT_ORDER, fk::ColorPlanes CP_MODE = fk::ColorPlanes::Standard>
+class CircularTensor : public fk::CircularTensor<CUDA_T(O), COLOR_PLANES, BATCH, CT_ORDER, CP_MODE> {
+    using Base = fk::CircularTensor<CUDA_T(O), COLOR_PLANES, BATCH, CT_ORDER, CP_MODE>;
+public:
+    CircularTensor() = default;
+    CircularTensor(const uint& width_, const uint& height_, const int& deviceID_ = 0) : Base(width_, height_, deviceID_) {}
+
+    // new frame read per pixel from a GpuMat of type I
+    template <typename... IOpTypes>
+    void update(const cv::cuda::Stream& stream, const cv::cuda::GpuMat& input, const IOpTypes&... iops) {
+        const fk::Read<fk::PerThreadRead<fk::_2D, CUDA_T(I)>> read{gpuMat2RawPtr2D<CUDA_T(I)>(input)};
+        Base::update(cv::cuda::StreamAccessor::getStream(stream), read, iops...);
+    }
+    // first IOp is already a read (e.g. cvGS::resize(...)): "push with resize+normalize"
+    template <typename... IOpTypes>
+    void update(const cv::cuda::Stream& stream, const IOpTypes&... iops) {
+        Base::update(cv::cuda::StreamAccessor::getStream(stream), iops...);
+    }
+    CUDA_T(O)* data() { return this->ptr_a.data; }
+};
+
+} // namespace cvGS

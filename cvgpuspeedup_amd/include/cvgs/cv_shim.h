@@ -1,0 +1,299 @@
+// cv_shim.h -- the slice of OpenCV's core/cuda API the cvGS facade and its tests touch, implemented on the
+// HIP runtime so the facade builds where OpenCV does not exist (this image).  Same names, same numeric
+// constants as OpenCV 4.x, so code written against <opencv2/core/cuda.hpp> compiles unchanged for the hot path.
+// Define CVGS_USE_OPENCV to use a real OpenCV instead (the facade only needs the names below).
+//
+// Covered: cv::Scalar, Size, Point2d, Rect2d, Rect, Mat (host, dense), cuda::GpuMat (refcounted, pitched,
+// ROI views, upload/download/setTo/convertTo-free), cuda::Stream + StreamAccessor, CV_* type macros,
+// INTER_LINEAR, ColorConversionCodes.  Everything here is host-side plumbing; no pixel arithmetic of the hot
+// path lives in this file (setTo fills on the host and uploads: test scaffolding, like the reference's
+// GpuMat(rows, cols, type, Scalar) constructor use).
+#pragma once
+
+#ifdef CVGS_USE_OPENCV
+#include <opencv2/core.hpp>
+#include <opencv2/core/cuda.hpp>
+#include <opencv2/core/cuda_stream_accessor.hpp>
+#include <opencv2/imgproc.hpp>
+#else
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+typedef unsigned char uchar;
+typedef signed char schar;
+typedef unsigned short ushort;
+typedef unsigned int uint;
+
+#define CV_CN_SHIFT 3
+#define CV_DEPTH_MAX (1 << CV_CN_SHIFT)
+#define CV_8U 0
+#define CV_8S 1
+#define CV_16U 2
+#define CV_16S 3
+#define CV_32S 4
+#define CV_32F 5
+#define CV_64F 6
+#define CV_MAT_DEPTH_MASK (CV_DEPTH_MAX - 1)
+#define CV_MAT_DEPTH(flags) ((flags) & CV_MAT_DEPTH_MASK)
+#define CV_MAKETYPE(depth, cn) (CV_MAT_DEPTH(depth) + (((cn) - 1) << CV_CN_SHIFT))
+#define CV_MAKE_TYPE CV_MAKETYPE
+#define CV_MAT_CN(flags) ((((flags) >> CV_CN_SHIFT) & 63) + 1)
+#define CVGS_DECL_TYPES(D)                                                                                      \
+    constexpr int CV_##D##C1 = CV_MAKETYPE(CV_##D, 1), CV_##D##C2 = CV_MAKETYPE(CV_##D, 2),                    \
+                  CV_##D##C3 = CV_MAKETYPE(CV_##D, 3), CV_##D##C4 = CV_MAKETYPE(CV_##D, 4);
+CVGS_DECL_TYPES(8U) CVGS_DECL_TYPES(8S) CVGS_DECL_TYPES(16U) CVGS_DECL_TYPES(16S) CVGS_DECL_TYPES(32S)
+CVGS_DECL_TYPES(32F) CVGS_DECL_TYPES(64F)
+#undef CVGS_DECL_TYPES
+
+namespace cv {
+
+enum InterpolationFlags { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2, INTER_AREA = 3 };
+
+enum ColorConversionCodes {
+    COLOR_BGR2BGRA = 0, COLOR_RGB2RGBA = COLOR_BGR2BGRA,
+    COLOR_BGRA2BGR = 1, COLOR_RGBA2RGB = COLOR_BGRA2BGR,
+    COLOR_BGR2RGBA = 2, COLOR_RGB2BGRA = COLOR_BGR2RGBA,
+    COLOR_RGBA2BGR = 3, COLOR_BGRA2RGB = COLOR_RGBA2BGR,
+    COLOR_BGR2RGB = 4, COLOR_RGB2BGR = COLOR_BGR2RGB,
+    COLOR_BGRA2RGBA = 5, COLOR_RGBA2BGRA = COLOR_BGRA2RGBA,
+    COLOR_BGR2GRAY = 6, COLOR_RGB2GRAY = 7, COLOR_GRAY2BGR = 8, COLOR_GRAY2RGB = COLOR_GRAY2BGR,
+    COLOR_GRAY2BGRA = 9, COLOR_GRAY2RGBA = COLOR_GRAY2BGRA, COLOR_BGRA2GRAY = 10, COLOR_RGBA2GRAY = 11
+};
+
+struct Scalar {
+    double val[4];
+    Scalar() : val{0, 0, 0, 0} {}
+    Scalar(double v0) : val{v0, 0, 0, 0} {}
+    Scalar(double v0, double v1, double v2 = 0, double v3 = 0) : val{v0, v1, v2, v3} {}
+    double& operator[](int i) { return val[i]; }
+    const double& operator[](int i) const { return val[i]; }
+    bool operator==(const Scalar& o) const { return !std::memcmp(val, o.val, sizeof(val)); }
+    static Scalar all(double v) { return Scalar(v, v, v, v); }
+};
+
+struct Size {
+    int width = 0, height = 0;
+    Size() = default;
+    Size(int w, int h) : width(w), height(h) {}
+    bool operator==(const Size& o) const { return width == o.width && height == o.height; }
+};
+
+struct Point2d {
+    double x = 0, y = 0;
+    Point2d() = default;
+    Point2d(double x_, double y_) : x(x_), y(y_) {}
+};
+
+struct Rect2d {
+    double x = 0, y = 0, width = 0, height = 0;
+    Rect2d() = default;
+    Rect2d(double x_, double y_, double w, double h) : x(x_), y(y_), width(w), height(h) {}
+    Rect2d(const Point2d& a, const Point2d& b)
+        : x(std::fmin(a.x, b.x)), y(std::fmin(a.y, b.y)), width(std::fabs(b.x - a.x)), height(std::fabs(b.y - a.y)) {}
+};
+
+struct Rect {
+    int x = 0, y = 0, width = 0, height = 0;
+    Rect() = default;
+    Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
+    Rect(const Rect2d& r) : x((int)r.x), y((int)r.y), width((int)r.width), height((int)r.height) {}
+};
+
+inline size_t cvgs_elem_size(int type) {
+    static const int bytes[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+    return (size_t)bytes[CV_MAT_DEPTH(type)] * CV_MAT_CN(type);
+}
+
+inline void cvgs_hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Host matrix: dense rows, owns its storage (or wraps user memory).
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    uchar* data = nullptr;
+    size_t step = 0;
+    Mat() = default;
+    Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(Size s, int type) { create(s.height, s.width, type); }
+    Mat(int r, int c, int type, const Scalar& v) { create(r, c, type); setTo(v); }
+    Mat(Size s, int type, const Scalar& v) { create(s.height, s.width, type); setTo(v); }
+    Mat(int r, int c, int type, void* user, size_t step_ = 0)
+        : rows(r), cols(c), data((uchar*)user), step(step_ ? step_ : c * cvgs_elem_size(type)), type_(type) {}
+    void create(int r, int c, int type) {
+        rows = r; cols = c; type_ = type; step = c * cvgs_elem_size(type);
+        store_ = std::make_shared<std::vector<uchar>>((size_t)r * step);
+        data = store_->data();
+    }
+    int type() const { return type_; }
+    int depth() const { return CV_MAT_DEPTH(type_); }
+    int channels() const { return CV_MAT_CN(type_); }
+    size_t elemSize() const { return cvgs_elem_size(type_); }
+    bool empty() const { return !data; }
+    Size size() const { return Size(cols, rows); }
+    template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }
+    template <typename T> const T* ptr(int y = 0) const { return (const T*)(data + (size_t)y * step); }
+    template <typename T> T& at(int y, int x) { return ptr<T>(y)[x]; }
+    template <typename T> const T& at(int y, int x) const { return ptr<T>(y)[x]; }
+    Mat row(int y) const { Mat m = *this; m.rows = 1; m.data = data + (size_t)y * step; return m; }
+    // saturating per-channel fill, like cv::Mat::setTo / the Scalar constructors
+    void setTo(const Scalar& v) {
+        const int cn = channels(), d = depth();
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x)
+                for (int c = 0; c < cn; ++c) store(y, x * cn + c, d, v[c]);
+    }
+
+private:
+    static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+    void store(int y, int e, int d, double v) {
+        uchar* row = data + (size_t)y * step;
+        switch (d) {
+        case CV_8U: row[e] = (uchar)std::nearbyint(clampd(v, 0, 255)); break;
+        case CV_8S: ((schar*)row)[e] = (schar)std::nearbyint(clampd(v, -128, 127)); break;
+        case CV_16U: ((ushort*)row)[e] = (ushort)std::nearbyint(clampd(v, 0, 65535)); break;
+        case CV_16S: ((short*)row)[e] = (short)std::nearbyint(clampd(v, -32768, 32767)); break;
+        case CV_32S: ((int*)row)[e] = (int)std::nearbyint(clampd(v, -2147483648.0, 2147483647.0)); break;
+        case CV_32F: ((float*)row)[e] = (float)v; break;
+        default: ((double*)row)[e] = v; break;
+        }
+    }
+    int type_ = 0;
+    std::shared_ptr<std::vector<uchar>> store_;
+};
+
+namespace cuda {
+
+class Stream {
+public:
+    Stream() : impl_(std::make_shared<Impl>(true)) {}
+    static Stream& Null() { static Stream s{nullptr, 0}; return s; }
+    void waitForCompletion() const { cvgs_hip_check(hipStreamSynchronize(impl_->s), "hipStreamSynchronize"); }
+    hipStream_t raw() const { return impl_->s; }
+    static Stream wrap(hipStream_t s) { return Stream(s, 0); }
+
+private:
+    struct Impl {
+        hipStream_t s = nullptr;
+        bool own = false;
+        explicit Impl(bool create) : own(create) { if (create) cvgs_hip_check(hipStreamCreate(&s), "hipStreamCreate"); }
+        Impl(hipStream_t user) : s(user), own(false) {}
+        ~Impl() { if (own && s) (void)hipStreamDestroy(s); }
+    };
+    Stream(hipStream_t s, int) : impl_(std::make_shared<Impl>(s)) {}
+    std::shared_ptr<Impl> impl_;
+};
+
+struct StreamAccessor {
+    static hipStream_t getStream(const Stream& s) { return s.raw(); }
+    static Stream wrapStream(hipStream_t s) { return Stream::wrap(s); }
+};
+
+// Device matrix: pitched allocation shared between views (ROI / row), like cv::cuda::GpuMat.
+class GpuMat {
+public:
+    int flags = 0, rows = 0, cols = 0;
+    size_t step = 0;
+    uchar* data = nullptr;
+
+    GpuMat() = default;
+    GpuMat(int r, int c, int type) { create(r, c, type); }
+    GpuMat(Size s, int type) { create(s.height, s.width, type); }
+    GpuMat(int r, int c, int type, const Scalar& v) { create(r, c, type); setTo(v); }
+    GpuMat(Size s, int type, const Scalar& v) { create(s.height, s.width, type); setTo(v); }
+    // user-allocated memory (device, or host memory when the descriptor is handed to a CPU checker)
+    GpuMat(int r, int c, int type, void* user, size_t step_ = 0)
+        : flags(type), rows(r), cols(c), step(step_ ? step_ : c * cvgs_elem_size(type)), data((uchar*)user) {}
+    GpuMat(Size s, int type, void* user, size_t step_ = 0) : GpuMat(s.height, s.width, type, user, step_) {}
+    explicit GpuMat(const Mat& m) { upload(m); }
+
+    void create(int r, int c, int type) {
+        if (data && r == rows && c == cols && type == flags && store_) return;
+        flags = type; rows = r; cols = c;
+        size_t pitch = 0;
+        void* p = nullptr;
+        // pitched like cudaMallocPitch: rows start on 512-byte boundaries unless the matrix is one row
+        cvgs_hip_check(hipMallocPitch(&p, &pitch, (size_t)c * cvgs_elem_size(type), (size_t)r), "hipMallocPitch");
+        store_ = std::shared_ptr<void>(p, [](void* q) { (void)hipFree(q); });
+        data = (uchar*)p;
+        step = r == 1 ? (size_t)c * cvgs_elem_size(type) : pitch;
+    }
+    void create(Size s, int type) { create(s.height, s.width, type); }
+    void release() { store_.reset(); data = nullptr; rows = cols = 0; step = 0; }
+
+    int type() const { return flags; }
+    int depth() const { return CV_MAT_DEPTH(flags); }
+    int channels() const { return CV_MAT_CN(flags); }
+    size_t elemSize() const { return cvgs_elem_size(flags); }
+    bool empty() const { return !data; }
+    Size size() const { return Size(cols, rows); }
+
+    GpuMat operator()(const Rect& r) const {
+        if (r.x < 0 || r.y < 0 || r.width < 0 || r.height < 0 || r.x + r.width > cols || r.y + r.height > rows)
+            throw std::runtime_error("GpuMat ROI outside the matrix");
+        GpuMat m = *this;
+        m.data = data + (size_t)r.y * step + (size_t)r.x * elemSize();
+        m.cols = r.width;
+        m.rows = r.height;
+        return m;
+    }
+    GpuMat operator()(const Rect2d& r) const { return (*this)(Rect(r)); }
+    GpuMat row(int y) const { return (*this)(Rect(0, y, cols, 1)); }
+    GpuMat reshape(int cn, int new_rows) const {
+        GpuMat m = *this;
+        const size_t total = (size_t)rows * cols * channels();
+        m.flags = CV_MAKETYPE(depth(), cn);
+        m.rows = new_rows;
+        m.cols = (int)(total / ((size_t)new_rows * cn));
+        m.step = (size_t)m.cols * m.elemSize();
+        return m;
+    }
+
+    void upload(const Mat& m) {
+        create(m.rows, m.cols, m.type());
+        cvgs_hip_check(hipMemcpy2D(data, step, m.data, m.step, (size_t)cols * elemSize(), rows, hipMemcpyHostToDevice),
+                       "hipMemcpy2D(upload)");
+    }
+    void upload(const Mat& m, const Stream& s) {
+        create(m.rows, m.cols, m.type());
+        cvgs_hip_check(hipMemcpy2DAsync(data, step, m.data, m.step, (size_t)cols * elemSize(), rows, hipMemcpyHostToDevice,
+                                        s.raw()), "hipMemcpy2DAsync(upload)");
+    }
+    void download(Mat& m) const {
+        if (m.rows != rows || m.cols != cols || m.type() != type() || m.empty()) m.create(rows, cols, type());
+        cvgs_hip_check(hipMemcpy2D(m.data, m.step, data, step, (size_t)cols * elemSize(), rows, hipMemcpyDeviceToHost),
+                       "hipMemcpy2D(download)");
+    }
+    void download(Mat& m, const Stream& s) const {
+        if (m.rows != rows || m.cols != cols || m.type() != type() || m.empty()) m.create(rows, cols, type());
+        cvgs_hip_check(hipMemcpy2DAsync(m.data, m.step, data, step, (size_t)cols * elemSize(), rows, hipMemcpyDeviceToHost,
+                                        s.raw()), "hipMemcpy2DAsync(download)");
+    }
+    GpuMat& setTo(const Scalar& v) {
+        Mat h(rows, cols, type(), v);
+        cvgs_hip_check(hipMemcpy2D(data, step, h.data, h.step, (size_t)cols * elemSize(), rows, hipMemcpyHostToDevice),
+                       "hipMemcpy2D(setTo)");
+        return *this;
+    }
+    GpuMat& setTo(const Scalar& v, const Stream& s) {
+        s.waitForCompletion();
+        return setTo(v);
+    }
+
+private:
+    std::shared_ptr<void> store_;
+};
+
+} // namespace cuda
+} // namespace cv
+
+#endif // CVGS_USE_OPENCV

@@ -1,0 +1,543 @@
+// fk_compat.h -- the small slice of the fk:: (FusedKernelLibrary) vocabulary that the reference's hot-path
+// call sites spell directly: RawPtr / Ptr2D / Tensor / TensorT, the Read / Unary / Binary /
+// Write instantiable-operation wrappers, the operation tags of the hot chains, fk::executeOperations and
+// fk::CircularTensor.  Nothing here computes pixels: every IOp only knows how to append itself to ONE
+// cvgs_chain_desc (include/cvgs_hip.h); executeOperations() type-checks the list at compile time (the output
+// type of IOp k must be the input type of IOp k+1, as in the reference) and hands the descriptor to the
+// HIP library through the C-ABI -> one kernel launch.
+#pragma once
+
+#include <array>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../../../include/cvgs_hip.h"
+#include "../cv2cuda_types.h"
+
+namespace fk {
+
+// ---- small vocabulary types ---------------------------------------------------------------------------
+template <typename T> constexpr int cn = cvGS::vector_traits<T>::cn;
+template <typename T> using VBase = typename cvGS::vector_traits<T>::base;
+template <typename T> struct VectorTraits { using base = VBase<T>; };
+template <typename B, int N> using VectorType_t = typename cvGS::detail::vec_of<B, N>::type;
+
+template <typename V> inline V make_set(VBase<V> v) {
+    V r{};
+    if constexpr (cn<V> == 1) r = v;
+    else {
+        r.x = v; r.y = v;
+        if constexpr (cn<V> >= 3) r.z = v;
+        if constexpr (cn<V> >= 4) r.w = v;
+    }
+    return r;
+}
+template <typename V, typename... A> inline V make_(A... a) { return V{static_cast<VBase<V>>(a)...}; }
+
+template <typename V> inline void vec_to_floats(const V& v, float out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0.f;
+    if constexpr (cn<V> == 1) out[0] = (float)v;
+    else {
+        out[0] = (float)v.x; out[1] = (float)v.y;
+        if constexpr (cn<V> >= 3) out[2] = (float)v.z;
+        if constexpr (cn<V> >= 4) out[3] = (float)v.w;
+    }
+}
+
+struct Size {
+    int width = 0, height = 0;
+    constexpr Size() = default;
+    constexpr Size(int w, int h) : width(w), height(h) {}
+};
+struct Rect {
+    uint x = 0, y = 0;
+    int width = 0, height = 0;
+    constexpr Rect() = default;
+    constexpr Rect(uint x_, uint y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
+};
+
+enum ND { _2D = 2, _3D = 3, T3D = 4 };
+enum InterpolationType { INTER_LINEAR = 1 };
+enum AspectRatio { PRESERVE_AR = 0, IGNORE_AR = 1, PRESERVE_AR_RN_EVEN = 2, PRESERVE_AR_LEFT = 3 };
+enum class CircularTensorOrder { NewestFirst = 0, OldestFirst = 1 };
+enum class ColorPlanes { Standard = 0, Transposed = 1 };
+enum PixelFormat { NV12 = 0 };
+enum ColorRange { Full = 0, Limited = 1 };
+enum ColorPrimitives { bt601 = 0, bt709 = 1 };
+enum ColorConversionCodes {
+    COLOR_BGR2BGRA = 0, COLOR_RGB2RGBA = 0, COLOR_BGRA2BGR = 1, COLOR_RGBA2RGB = 1, COLOR_BGR2RGBA = 2,
+    COLOR_RGB2BGRA = 2, COLOR_RGBA2BGR = 3, COLOR_BGRA2RGB = 3, COLOR_BGR2RGB = 4, COLOR_RGB2BGR = 4,
+    COLOR_BGRA2RGBA = 5, COLOR_RGBA2BGRA = 5, COLOR_BGR2GRAY = 6, COLOR_RGB2GRAY = 7, COLOR_BGRA2GRAY = 10,
+    COLOR_RGBA2GRAY = 11
+};
+
+struct Dims2D { uint width = 0, height = 0, pitch = 0; };
+struct Dims3D { uint width = 0, height = 0, planes = 0, color_planes = 1, pitch = 0, plane_pitch = 0; };
+
+template <ND D, typename T> struct RawPtr;
+template <typename T> struct RawPtr<_2D, T> { T* data = nullptr; Dims2D dims; using type = T; };
+template <typename T> struct RawPtr<_3D, T> { T* data = nullptr; Dims3D dims; using type = T; };
+template <typename T> struct RawPtr<T3D, T> { T* data = nullptr; Dims3D dims; using type = T; };
+
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Pitched device image, refcounted (fk::Ptr2D).
+template <typename T> class Ptr2D {
+public:
+    Ptr2D() = default;
+    Ptr2D(uint w, uint h) {
+        void* p = nullptr; size_t pitch = 0;
+        hip_check(hipMallocPitch(&p, &pitch, (size_t)w * sizeof(T), h), "hipMallocPitch");
+        store_ = std::shared_ptr<void>(p, [](void* q) { (void)hipFree(q); });
+        raw_.data = (T*)p; raw_.dims = {w, h, (uint)pitch};
+    }
+    Ptr2D(T* data, uint w, uint h, uint pitch) { raw_.data = data; raw_.dims = {w, h, pitch}; }
+    RawPtr<_2D, T> ptr() const { return raw_; }
+    Dims2D dims() const { return raw_.dims; }
+    operator RawPtr<_2D, T>() const { return raw_; }
+private:
+    RawPtr<_2D, T> raw_;
+    std::shared_ptr<void> store_;
+};
+
+// Dense device tensor [planes][color_planes][H][W] (fk::Tensor) or [color_planes][planes][H][W] (fk::TensorT).
+template <ND D, typename T> class TensorBase {
+public:
+    TensorBase() = default;
+    TensorBase(T* data, uint w, uint h, uint planes, uint color_planes = 1) { set(data, w, h, planes, color_planes); }
+    TensorBase(uint w, uint h, uint planes, uint color_planes = 1) { allocTensor(w, h, planes, color_planes); }
+    void allocTensor(uint w, uint h, uint planes, uint color_planes = 1) {
+        void* p = nullptr;
+        hip_check(hipMalloc(&p, (size_t)w * h * planes * color_planes * sizeof(T)), "hipMalloc(tensor)");
+        store_ = std::shared_ptr<void>(p, [](void* q) { (void)hipFree(q); });
+        set((T*)p, w, h, planes, color_planes);
+    }
+    RawPtr<D, T> ptr() const { return raw_; }
+    Dims3D dims() const { return raw_.dims; }
+    size_t sizeInBytes() const { return (size_t)raw_.dims.plane_pitch * raw_.dims.planes * raw_.dims.color_planes; }
+    operator RawPtr<D, T>() const { return raw_; }
+protected:
+    void set(T* data, uint w, uint h, uint planes, uint cp) {
+        raw_.data = data;
+        raw_.dims = {w, h, planes, cp, (uint)(w * sizeof(T)), (uint)(w * sizeof(T) * h)};
+    }
+    RawPtr<D, T> raw_;
+    std::shared_ptr<void> store_;
+};
+template <typename T> using Tensor = TensorBase<_3D, T>;
+template <typename T> using TensorT = TensorBase<T3D, T>;
+
+// ---- chain builder ----------------------------------------------------------------------------------------
+struct ChainBuilder {
+    cvgs_chain_desc d;
+    std::vector<cvgs_image2d> src, dst;
+    ChainBuilder() { std::memset(&d, 0, sizeof(d)); d.struct_size = sizeof(d); }
+    void op(int opcode, int aux, const float* operand = nullptr) {
+        if (d.n_ops >= CVGS_MAX_OPS) throw std::runtime_error("cvGS: too many pointwise operations in one chain");
+        cvgs_op& o = d.ops[d.n_ops++];
+        o.opcode = opcode; o.aux = aux;
+        for (int i = 0; i < 4; ++i) o.operand[i] = operand ? operand[i] : 0.f;
+    }
+    void finish() {
+        if (!src.empty() && !(d.read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE)) d.read.src = src.data();
+        if (!dst.empty()) d.write.planes2d = dst.data();
+    }
+};
+
+template <typename T> inline cvgs_image2d image2d(const RawPtr<_2D, T>& p) {
+    return cvgs_image2d{p.data, (int32_t)p.dims.width, (int32_t)p.dims.height, (int32_t)p.dims.pitch, 0};
+}
+
+enum class Stage { Read, Pointwise, Write };
+
+// ---- instantiable-operation wrappers ---------------------------------------------------------------------------
+template <typename Op> struct Read {
+    typename Op::ParamsType params;
+    using Operation = Op;
+    using OutputType = typename Op::OutputType;
+    static constexpr Stage stage = Stage::Read;
+    void lower(ChainBuilder& b) const { Op::lower(params, b); }
+};
+template <typename Op> using ReadInstantiableOperation = Read<Op>;
+
+template <typename Op> struct Unary {
+    using Operation = Op;
+    using InputType = typename Op::InputType;
+    using OutputType = typename Op::OutputType;
+    static constexpr Stage stage = Stage::Pointwise;
+    void lower(ChainBuilder& b) const { Op::lower(b); }
+};
+
+template <typename Op> struct Binary {
+    typename Op::ParamsType params;
+    using Operation = Op;
+    using InputType = typename Op::InputType;
+    using OutputType = typename Op::OutputType;
+    static constexpr Stage stage = Stage::Pointwise;
+    void lower(ChainBuilder& b) const { Op::lower(params, b); }
+};
+
+template <typename Op> struct Write {
+    typename Op::ParamsType params;
+    using Operation = Op;
+    using InputType = typename Op::InputType;
+    static constexpr Stage stage = Stage::Write;
+    void lower(ChainBuilder& b) const { Op::lower(params, b); }
+};
+template <typename Op> using WriteInstantiableOperation = Write<Op>;
+
+// A run of pointwise stages with known end types (what cvGS::convertTo(alpha[,beta]) returns).
+template <typename I, typename O> struct PointwiseSeq {
+    using InputType = I;
+    using OutputType = O;
+    static constexpr Stage stage = Stage::Pointwise;
+    std::vector<cvgs_op> ops;
+    void lower(ChainBuilder& b) const { for (const auto& o : ops) b.op(o.opcode, o.aux, o.operand); }
+    template <typename Next> auto then(const Next& n) const {
+        static_assert(std::is_same_v<O, typename Next::InputType>, "then(): types do not chain");
+        PointwiseSeq<I, typename Next::OutputType> r;
+        ChainBuilder tmp;
+        lower(tmp); n.lower(tmp);
+        r.ops.assign(tmp.d.ops, tmp.d.ops + tmp.d.n_ops);
+        return r;
+    }
+};
+
+// ---- operation tags ------------------------------------------------------------------------------------------------
+template <ND D, typename T> struct PerThreadRead;
+template <typename T> struct PerThreadRead<_2D, T> {
+    using ParamsType = RawPtr<_2D, T>;
+    using OutputType = T;
+    static void lower(const ParamsType& p, ChainBuilder& b) {
+        b.d.read.kind = CVGS_READ_PIXEL;
+        b.d.read.src_type = cvGS::cv_type_of<T>;
+        b.d.read.batch = 1; b.d.read.used_planes = 1;
+        b.src.assign(1, image2d(p));
+    }
+};
+
+template <ND D, typename T> struct PerThreadWrite;
+template <typename T> struct PerThreadWrite<_2D, T> {
+    using ParamsType = RawPtr<_2D, T>;
+    using InputType = T;
+    static void lower(const ParamsType& p, ChainBuilder& b) {
+        cvgs_write_desc& w = b.d.write;
+        w.kind = CVGS_WRITE_PIXEL_2D; w.dst_type = cvGS::cv_type_of<T>; w.data = p.data;
+        w.width = p.dims.width; w.height = p.dims.height; w.step = p.dims.pitch; w.planes = 1;
+    }
+};
+template <typename T> struct PerThreadWrite<_3D, T> {
+    using ParamsType = RawPtr<_3D, T>;
+    using InputType = T;
+    static void lower(const ParamsType& p, ChainBuilder& b) {
+        cvgs_write_desc& w = b.d.write;
+        w.kind = CVGS_WRITE_PIXEL_3D; w.dst_type = cvGS::cv_type_of<T>; w.data = p.data;
+        w.width = p.dims.width; w.height = p.dims.height; w.planes = p.dims.planes;
+    }
+};
+template <typename T> using TensorWrite = PerThreadWrite<_3D, T>;
+
+template <typename T> struct TensorSplit {
+    using ParamsType = RawPtr<_3D, VBase<T>>;
+    using InputType = T;
+    static void lower(const ParamsType& p, ChainBuilder& b) {
+        cvgs_write_desc& w = b.d.write;
+        w.kind = CVGS_WRITE_TENSOR_SPLIT; w.dst_type = cvGS::cv_type_of<T>; w.data = p.data;
+        w.width = p.dims.width; w.height = p.dims.height; w.planes = p.dims.planes;
+    }
+};
+template <typename T> struct TensorTSplit {
+    using ParamsType = RawPtr<T3D, VBase<T>>;
+    using InputType = T;
+    static void lower(const ParamsType& p, ChainBuilder& b) {
+        cvgs_write_desc& w = b.d.write;
+        w.kind = CVGS_WRITE_TENSOR_T_SPLIT; w.dst_type = cvGS::cv_type_of<T>; w.data = p.data;
+        w.width = p.dims.width; w.height = p.dims.height; w.planes = p.dims.planes;
+    }
+};
+
+// SplitWrite<_2D,T>: C pitched planes per batch element
+template <ND D, typename T> struct SplitWrite {
+    struct ParamsType { std::vector<RawPtr<_2D, VBase<T>>> planes; int batch = 1; };
+    using InputType = T;
+    static void lower(const ParamsType& p, ChainBuilder& b) {
+        cvgs_write_desc& w = b.d.write;
+        w.kind = CVGS_WRITE_SPLIT_2D; w.dst_type = cvGS::cv_type_of<T>;
+        b.dst.clear();
+        for (const auto& pl : p.planes) b.dst.push_back(image2d(pl));
+        if (!p.planes.empty()) { w.width = p.planes[0].dims.width; w.height = p.planes[0].dims.height; }
+        w.planes = p.batch;
+    }
+    static Write<SplitWrite> build(const std::vector<Ptr2D<VBase<T>>>& out) {
+        static_assert(cn<T> >= 2, "Split operations can only be used with types of 2, 3 or 4 channels.");
+        Write<SplitWrite> w;
+        for (const auto& o : out) w.params.planes.push_back(o.ptr());
+        return w;
+    }
+    template <size_t N> static Write<SplitWrite> build(const std::array<std::vector<Ptr2D<VBase<T>>>, N>& out) {
+        static_assert(cn<T> >= 2, "Split operations can only be used with types of 2, 3 or 4 channels.");
+        Write<SplitWrite> w;
+        w.params.batch = (int)N;
+        for (const auto& img : out) for (const auto& o : img) w.params.planes.push_back(o.ptr());
+        return w;
+    }
+};
+
+template <typename I, typename O> struct SaturateCast {
+    using InputType = I;
+    using OutputType = O;
+    static_assert(cn<I> == cn<O>, "SaturateCast cannot change the number of channels");
+    static void lower(ChainBuilder& b) { b.op(CVGS_OP_CAST, cvGS::base_depth<VBase<O>>::value); }
+};
+
+#define CVGS_FK_BINARY(NAME, OPC)                                                           \
+    template <typename T> struct NAME {                                                     \
+        using InputType = T; using OutputType = T; using ParamsType = T;                    \
+        static void lower(const T& v, ChainBuilder& b) { float f[4]; vec_to_floats(v, f); b.op(OPC, 0, f); } \
+    };
+CVGS_FK_BINARY(Mul, CVGS_OP_MUL)
+CVGS_FK_BINARY(Add, CVGS_OP_ADD)
+CVGS_FK_BINARY(Sub, CVGS_OP_SUB)
+CVGS_FK_BINARY(Div, CVGS_OP_DIV)
+#undef CVGS_FK_BINARY
+
+template <typename T, int... IDX> struct VectorReorder {
+    using InputType = T; using OutputType = T;
+    static_assert(sizeof...(IDX) == cn<T>, "VectorReorder needs one index per channel");
+    static void lower(ChainBuilder& b) {
+        int aux = 0, k = 0;
+        ((aux |= (IDX & 3) << (2 * k++)), ...);
+        b.op(CVGS_OP_REORDER, aux);
+    }
+};
+
+namespace detail {
+constexpr int kSwap3 = 2 | (1 << 2) | (0 << 4), kId3 = 0 | (1 << 2) | (2 << 4);
+template <typename B> constexpr float alpha_max() {
+    if constexpr (std::is_same_v<B, uchar>) return 255.f;
+    else if constexpr (std::is_same_v<B, ushort>) return 65535.f;
+    else return 1.f;
+}
+} // namespace detail
+
+template <ColorConversionCodes CODE, typename I, typename O = I> struct ColorConversion {
+    using InputType = I; using OutputType = O;
+    static void lower(ChainBuilder& b) {
+        constexpr int c = (int)CODE;
+        const float a[4] = {detail::alpha_max<VBase<I>>(), 0, 0, 0};
+        if constexpr (c == 0 || c == 2) {
+            static_assert(cn<I> == 3 && cn<O> == 4, "colour code needs 3 -> 4 channels");
+            b.op(CVGS_OP_ADD_ALPHA, c == 0 ? detail::kId3 : detail::kSwap3, a);
+        } else if constexpr (c == 1 || c == 3) {
+            static_assert(cn<I> == 4 && cn<O> == 3, "colour code needs 4 -> 3 channels");
+            b.op(CVGS_OP_DROP_ALPHA, c == 1 ? detail::kId3 : detail::kSwap3);
+        } else if constexpr (c == 4) {
+            static_assert(cn<I> == 3 && cn<O> == 3, "colour code needs 3 -> 3 channels");
+            b.op(CVGS_OP_REORDER, detail::kSwap3);
+        } else if constexpr (c == 5) {
+            static_assert(cn<I> == 4 && cn<O> == 4, "colour code needs 4 -> 4 channels");
+            b.op(CVGS_OP_REORDER, detail::kSwap3 | (3 << 6));
+        } else {
+            static_assert(c == 6 || c == 7 || c == 10 || c == 11, "Color conversion type not supported yet.");
+            static_assert(cn<O> == 1 && cn<I> == ((c == 6 || c == 7) ? 3 : 4), "gray conversion channel counts");
+            b.op(CVGS_OP_GRAY, (c == 6 || c == 10) ? detail::kSwap3 : detail::kId3);
+        }
+    }
+};
+
+// ---- NV12 read-back ------------------------------------------------------------------------------------------------
+template <PixelFormat PF> struct ReadYUV {
+    using ParamsType = RawPtr<_2D, uchar>; // luma view; the interleaved UV plane follows it (height/2 rows)
+    using OutputType = uchar3;             // (Y, U, V) -- only meaningful fused with ConvertYUVToRGB
+    static void lower(const ParamsType&, ChainBuilder&) {
+        throw std::runtime_error("ReadYUV must be fused with ConvertYUVToRGB (fk::fuse) on this engine");
+    }
+};
+template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O = std::conditional_t<ALPHA, uchar4, uchar3>>
+struct ConvertYUVToRGB {
+    using InputType = uchar3;
+    using OutputType = O;
+};
+
+// fuse(Read<ReadYUV>, Unary<ConvertYUVToRGB>) -> one read IOp producing RGB(A)
+template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O> struct YuvRead {
+    RawPtr<_2D, uchar> params;
+    using OutputType = O;
+    static constexpr Stage stage = Stage::Read;
+    static constexpr bool float_out = std::is_same_v<VBase<O>, float>;
+    void lower_read(ChainBuilder& b, int kind) const {
+        cvgs_read_desc& r = b.d.read;
+        r.kind = kind; r.src_type = CV_8UC1; r.batch = 1; r.used_planes = 1;
+        r.yuv_range = (int)CR; r.yuv_primaries = (int)CP; r.yuv_alpha = ALPHA ? 1 : 0;
+        b.src.assign(1, image2d(params));
+    }
+    void lower(ChainBuilder& b) const {
+        lower_read(b, CVGS_READ_NV12);
+        if constexpr (!float_out) b.op(CVGS_OP_CAST, cvGS::base_depth<VBase<O>>::value);
+    }
+};
+template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O>
+inline auto fuse(const Read<ReadYUV<PF>>& r, const Unary<ConvertYUVToRGB<PF, CR, CP, ALPHA, O>>&) {
+    return YuvRead<PF, CR, CP, ALPHA, O>{r.params};
+}
+
+// ---- Resize ------------------------------------------------------------------------------------------------
+template <typename T> struct ResizeRead {          // single image, pixel source
+    RawPtr<_2D, T> src;
+    Size dsize;
+    using OutputType = VectorType_t<float, cn<T>>;
+    static constexpr Stage stage = Stage::Read;
+    void lower(ChainBuilder& b) const {
+        cvgs_read_desc& r = b.d.read;
+        r.kind = CVGS_READ_RESIZE_LINEAR; r.src_type = cvGS::cv_type_of<T>; r.batch = 1; r.used_planes = 1;
+        r.dst_width = dsize.width; r.dst_height = dsize.height; r.aspect_ratio = CVGS_IGNORE_AR;
+        b.src.assign(1, image2d(src));
+    }
+};
+template <typename Yuv> struct ResizeYuvRead {     // single image, NV12 read-back source
+    Yuv back;
+    Size dsize;
+    using OutputType = VectorType_t<float, cn<typename Yuv::OutputType>>;
+    static constexpr Stage stage = Stage::Read;
+    static_assert(Yuv::float_out, "Resize over an NV12 read-back interpolates in float: use ConvertYUVToRGB<..., floatN>");
+    void lower(ChainBuilder& b) const {
+        back.lower_read(b, CVGS_READ_NV12_RESIZE_LINEAR);
+        b.d.read.dst_width = dsize.width; b.d.read.dst_height = dsize.height; b.d.read.aspect_ratio = CVGS_IGNORE_AR;
+    }
+};
+
+// N pitched sources -> resize -> default value for unused planes (BatchRead<N, CONDITIONAL_WITH_DEFAULT>)
+template <typename T> struct BatchResizeRead {
+    std::vector<cvgs_image2d> planes;
+    int used = 0;
+    Size dsize;
+    int ar = CVGS_IGNORE_AR;
+    float background[4] = {0, 0, 0, 0};
+    using OutputType = VectorType_t<float, cn<T>>;
+    static constexpr Stage stage = Stage::Read;
+    void lower(ChainBuilder& b) const {
+        cvgs_read_desc& r = b.d.read;
+        r.kind = CVGS_READ_RESIZE_LINEAR; r.src_type = cvGS::cv_type_of<T>;
+        r.batch = (int)planes.size(); r.used_planes = used;
+        r.dst_width = dsize.width; r.dst_height = dsize.height; r.aspect_ratio = ar;
+        for (int i = 0; i < 4; ++i) r.background[i] = background[i];
+        b.src = planes;
+    }
+};
+
+// N pitched sources read per pixel (the batch executeOperations overloads)
+template <typename T> struct BatchPixelRead {
+    std::vector<cvgs_image2d> planes;
+    int used = 0;
+    float background[4] = {0, 0, 0, 0};
+    using OutputType = T;
+    static constexpr Stage stage = Stage::Read;
+    void lower(ChainBuilder& b) const {
+        cvgs_read_desc& r = b.d.read;
+        r.kind = CVGS_READ_PIXEL; r.src_type = cvGS::cv_type_of<T>;
+        r.batch = (int)planes.size(); r.used_planes = used;
+        for (int i = 0; i < 4; ++i) r.background[i] = background[i];
+        b.src = planes;
+    }
+};
+
+template <InterpolationType IT, AspectRatio AR = IGNORE_AR> struct Resize {
+    static_assert(IT == INTER_LINEAR, "Interpolation type not supported yet.");
+    template <typename T> static auto build(const RawPtr<_2D, T>& in, const Size& dsize, double fx = 0., double fy = 0.) {
+        Size d = dsize;
+        if (d.width == 0 || d.height == 0) {
+            d.width = (int)std::nearbyint(in.dims.width * fx);
+            d.height = (int)std::nearbyint(in.dims.height * fy);
+        }
+        return ResizeRead<T>{in, d};
+    }
+    template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O>
+    static auto build(const YuvRead<PF, CR, CP, ALPHA, O>& back, const Size& dsize) {
+        return ResizeYuvRead<YuvRead<PF, CR, CP, ALPHA, O>>{back, dsize};
+    }
+};
+
+// ---- execution ------------------------------------------------------------------------------------------------
+namespace detail {
+template <typename A, typename B> constexpr bool chains = std::is_same_v<typename A::OutputType, typename B::InputType>;
+
+template <typename Tuple, size_t... I> constexpr bool types_chain(std::index_sequence<I...>) {
+    return (chains<std::tuple_element_t<I, Tuple>, std::tuple_element_t<I + 1, Tuple>> && ...);
+}
+template <typename Tuple, size_t... I> constexpr bool middle_pointwise(std::index_sequence<I...>) {
+    return ((std::tuple_element_t<I + 1, Tuple>::stage == Stage::Pointwise) && ...);
+}
+inline void check_status(int rc) {
+    if (rc != CVGS_OK) throw std::runtime_error(std::string("cvGS: ") + cvgs_last_error());
+}
+} // namespace detail
+
+// Lower a full IOp list (Read, pointwise..., Write) into a chain descriptor.  `b` must outlive the use of b.d.
+template <typename... IOps> inline void lowerChain(ChainBuilder& b, const IOps&... iops) {
+    using Tuple = std::tuple<IOps...>;
+    constexpr size_t N = sizeof...(IOps);
+    static_assert(N >= 2, "a chain needs at least a read and a write operation");
+    static_assert(std::tuple_element_t<0, Tuple>::stage == Stage::Read, "the first operation must be a Read/ReadBack");
+    static_assert(std::tuple_element_t<N - 1, Tuple>::stage == Stage::Write, "the last operation must be a Write");
+    static_assert(detail::middle_pointwise<Tuple>(std::make_index_sequence<N - 2>{}),
+                  "only Unary/Binary operations may sit between the read and the write");
+    static_assert(detail::types_chain<Tuple>(std::make_index_sequence<N - 1>{}),
+                  "the output type of each operation must be the input type of the next one");
+    (iops.lower(b), ...);
+    b.finish();
+}
+
+// fk::executeOperations<TF>(stream, iops...): ONE kernel, asynchronous on `stream`.
+template <bool THREAD_FUSION = true, typename... IOps>
+inline void executeOperations(hipStream_t stream, const IOps&... iops) {
+    ChainBuilder b;
+    lowerChain(b, iops...);
+    if (!THREAD_FUSION) b.d.flags |= CVGS_CHAIN_NO_THREAD_FUSION;
+    detail::check_status(cvgs_execute(&b.d, stream));
+}
+
+// ---- CircularTensor ------------------------------------------------------------------------------------------------
+template <typename T, int COLOR_PLANES, int BATCH, CircularTensorOrder ORDER, ColorPlanes MODE = ColorPlanes::Standard>
+class CircularTensor {
+    static constexpr ND kND = MODE == ColorPlanes::Transposed ? T3D : _3D;
+public:
+    CircularTensor() = default;
+    CircularTensor(uint w, uint h, int device = 0) { Alloc(w, h, device); }
+    CircularTensor(const CircularTensor&) = delete;
+    CircularTensor& operator=(const CircularTensor&) = delete;
+    ~CircularTensor() { if (handle_) (void)cvgs_circular_destroy(handle_); }
+
+    void Alloc(uint w, uint h, int device = 0) {
+        detail::check_status(cvgs_circular_create(&handle_, (int)w, (int)h, cvGS::cv_type_of<T>, COLOR_PLANES, BATCH,
+                                                  (int)ORDER, (int)MODE, device));
+        ptr_a.data = (T*)cvgs_circular_data(handle_);
+        ptr_a.dims = {w, h, (uint)BATCH, (uint)COLOR_PLANES, (uint)(w * sizeof(T)), (uint)(w * sizeof(T) * h)};
+    }
+    // update(stream, readIOp, ops..., writeIOp): the new frame = ops(read) becomes slot 0 (NewestFirst) or
+    // BATCH-1 (OldestFirst), every older frame moves one slot, the tensor at ptr()/data() is rewritten.
+    template <typename... IOps> void update(hipStream_t stream, const IOps&... iops) {
+        ChainBuilder b;
+        lowerChain(b, iops...);
+        constexpr bool tsplit_needed = MODE == ColorPlanes::Transposed;
+        if (tsplit_needed != (b.d.write.kind == CVGS_WRITE_TENSOR_T_SPLIT))
+            throw std::runtime_error("Need to use TensorTSplit as write function exactly when CP_MODE = Transposed");
+        detail::check_status(cvgs_circular_update(handle_, &b.d, stream));
+    }
+    RawPtr<kND, T> ptr() const { return ptr_a; }
+    Dims3D dims() const { return ptr_a.dims; }
+    size_t sizeInBytes() const { return cvgs_circular_bytes(handle_); }
+
+protected:
+    RawPtr<kND, T> ptr_a;
+    cvgs_circular_t handle_ = nullptr;
+};
+
+} // namespace fk

@@ -1,0 +1,137 @@
+// test_batchresize.cpp -- mirrors reference tests/batchresize/test_batchresize_x_split3D.cu and
+// test_batchresize_aspectratio_x_split3D.cu on the cvGS facade: N crops of a 4K frame -> resize -> cvtColor ->
+// multiply -> subtract -> divide -> split into an NCHW tensor, ONE fused kernel.
+//  (1) the reference's constant-colour known answers (tolerance 1e-4, as the reference),
+//  (2) the same chain on a NON-constant frame, bit-exact against the CPU oracle,
+//  (3) facade result == hand-built C-ABI descriptor result (the reference's cvGS == fk check,
+//      benchmarks/benchmark_CPUandGPU_cvGS_vs_fk.cu:191-192).
+#include "common.h"
+
+struct Params { cv::Scalar init, alpha, sub, div; };
+static const double kAlpha = 0.3;
+static const Params kParams[4] = {
+    {{2}, {kAlpha}, {1.f}, {3.2f}},
+    {{2, 37}, {kAlpha, kAlpha}, {1.f, 4.f}, {3.2f, 0.6f}},
+    {{5, 5, 5}, {kAlpha, kAlpha, kAlpha}, {1.f, 4.f, 3.2f}, {3.2f, 0.6f, 11.8f}},
+    {{2, 37, 128, 20}, {kAlpha, kAlpha, kAlpha, kAlpha}, {1.f, 4.f, 3.2f, 0.5f}, {3.2f, 0.6f, 11.8f, 33.f}}};
+
+template <int TI, int TO, int BATCH, cvGS::AspectRatio AR>
+static auto build_chain(const std::array<cv::cuda::GpuMat, BATCH>& crops, const cv::cuda::GpuMat& tensor, const cv::Size& up,
+                        const Params& p) {
+    const auto rd = cvGS::resize<TI, cv::INTER_LINEAR, BATCH, AR>(crops, up, BATCH, cvGS::cvScalar_set<TO>(128.f));
+    if constexpr (CV_MAT_CN(TI) == 3)
+        return std::make_tuple(rd, cvGS::cvtColor<cv::COLOR_RGB2BGR, TO>(), cvGS::multiply<TO>(p.alpha), cvGS::subtract<TO>(p.sub),
+                               cvGS::divide<TO>(p.div), cvGS::split<TO>(tensor, up));
+    else
+        return std::make_tuple(rd, cvGS::cvtColor<cv::COLOR_RGBA2BGRA, TO>(), cvGS::multiply<TO>(p.alpha), cvGS::subtract<TO>(p.sub),
+                               cvGS::divide<TO>(p.div), cvGS::split<TO>(tensor, up));
+}
+
+template <int TI, int TO, int BATCH, cvGS::AspectRatio AR>
+static void test_constant(cv::cuda::Stream& stream, int cropW) {
+    constexpr int CN = CV_MAT_CN(TO);
+    const Params& p = kParams[CN - 1];
+    const cv::Size up(64, 128);
+    cv::cuda::GpuMat d_input(2160, 3840, TI, p.init);
+    std::array<cv::cuda::GpuMat, BATCH> crops;
+    for (int i = 0; i < BATCH; ++i) crops[i] = d_input(cv::Rect2d(cv::Point2d(i, i), cv::Point2d(i + cropW, i + 120)));
+    cv::cuda::GpuMat d_tensor(BATCH, up.width * up.height * CN, CV_32F);
+    d_tensor.step = (size_t)up.width * up.height * CN * sizeof(float);
+
+    std::apply([&](const auto&... iops) { cvGS::executeOperations(stream, iops...); }, build_chain<TI, TO, BATCH, AR>(crops, d_tensor, up, p));
+    stream.waitForCompletion();
+
+    const auto h = fetch(d_tensor.data, (size_t)BATCH * CN * up.width * up.height * sizeof(float));
+    const float* t = (const float*)h.data();
+    // expected constants: channel swap (0 <-> 2), x alpha, - sub, / div; outside the AR window the background 128
+    int x1 = 0, x2 = 63;
+    if (AR != cvGS::IGNORE_AR) { x1 = 16; x2 = 47; } // 30x120 -> 32x128 centred
+    bool ok = true;
+    for (int z = 0; z < BATCH && ok; ++z)
+        for (int c = 0; c < CN && ok; ++c) {
+            const int sc = (c == 0) ? 2 : (c == 2 ? 0 : c);
+            const double in = ((double)p.init[sc] * (float)kAlpha - (float)p.sub[c]) / (float)p.div[c];
+            const double out = (128.0 * (float)kAlpha - (float)p.sub[c]) / (float)p.div[c];
+            for (int y = 0; y < 128 && ok; ++y)
+                for (int x = 0; x < 64 && ok; ++x) {
+                    const float v = t[(((size_t)z * CN + c) * 128 + y) * 64 + x];
+                    const double e = (x >= x1 && x <= x2) ? in : out;
+                    if (std::fabs(v - e) > 1e-4) {
+                        std::cout << "    z=" << z << " c=" << c << " y=" << y << " x=" << x << ": " << v << " vs " << e << std::endl;
+                        ok = false;
+                    }
+                }
+        }
+    CHECK(ok, "constant-colour known answer, type " << TI << " batch " << BATCH);
+}
+
+template <int TI, int TO, int BATCH, cvGS::AspectRatio AR>
+static void test_random_vs_oracle(cv::cuda::Stream& stream) {
+    constexpr int CN = CV_MAT_CN(TO);
+    const Params& p = kParams[CN - 1];
+    const cv::Size up(64, 128);
+    cv::Mat h_frame(1080, 1920, TI);
+    fill_random(h_frame, 0xC0FFEEull + TI);
+    cv::cuda::GpuMat d_frame(h_frame);
+    cv::cuda::GpuMat hv_frame = host_view(h_frame);
+    std::array<cv::cuda::GpuMat, BATCH> crops, h_crops;
+    for (int i = 0; i < BATCH; ++i) {
+        const int w = 8 + (i * 37) % 500, hgt = 16 + (i * 53) % 900, x = (i * 91) % (1920 - w), y = (i * 67) % (1080 - hgt);
+        crops[i] = d_frame(cv::Rect(x, y, w, hgt));
+        h_crops[i] = hv_frame(cv::Rect(x, y, w, hgt));
+    }
+    const size_t n = (size_t)BATCH * CN * up.width * up.height;
+    cv::cuda::GpuMat d_tensor(BATCH, up.width * up.height * CN, CV_32F);
+    d_tensor.step = (size_t)up.width * up.height * CN * sizeof(float);
+    cv::Mat h_ref(BATCH, up.width * up.height * CN, CV_32F);
+    cv::cuda::GpuMat hv_ref = host_view(h_ref);
+
+    std::apply([&](const auto&... iops) { cvGS::executeOperations(stream, iops...); }, build_chain<TI, TO, BATCH, AR>(crops, d_tensor, up, p));
+    std::apply([&](const auto&... iops) { run_oracle(iops...); }, build_chain<TI, TO, BATCH, AR>(h_crops, hv_ref, up, p));
+    stream.waitForCompletion();
+    const auto h = fetch(d_tensor.data, n * sizeof(float));
+    CHECK(bit_equal(h.data(), h_ref.data, n * sizeof(float)), "non-constant frame, bit-exact vs oracle, type " << TI << " AR " << AR);
+
+    // facade == hand-built C-ABI descriptor
+    cvgs_chain_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.struct_size = sizeof(d);
+    std::vector<cvgs_image2d> planes(BATCH);
+    for (int i = 0; i < BATCH; ++i) planes[i] = cvgs_image2d{crops[i].data, crops[i].cols, crops[i].rows, (int32_t)crops[i].step, 0};
+    d.read.kind = CVGS_READ_RESIZE_LINEAR; d.read.src_type = TI; d.read.batch = BATCH; d.read.used_planes = BATCH;
+    d.read.src = planes.data(); d.read.dst_width = 64; d.read.dst_height = 128; d.read.aspect_ratio = (int)AR;
+    for (int c = 0; c < CN; ++c) d.read.background[c] = 128.f;
+    d.n_ops = 4;
+    d.ops[0].opcode = CVGS_OP_REORDER; d.ops[0].aux = CN == 3 ? (2 | (1 << 2)) : (2 | (1 << 2) | (3 << 6));
+    d.ops[1].opcode = CVGS_OP_MUL; d.ops[2].opcode = CVGS_OP_SUB; d.ops[3].opcode = CVGS_OP_DIV;
+    for (int c = 0; c < CN; ++c) { d.ops[1].operand[c] = (float)p.alpha[c]; d.ops[2].operand[c] = (float)p.sub[c]; d.ops[3].operand[c] = (float)p.div[c]; }
+    cv::cuda::GpuMat d_raw(BATCH, up.width * up.height * CN, CV_32F);
+    d.write.kind = CVGS_WRITE_TENSOR_SPLIT; d.write.dst_type = TO; d.write.data = d_raw.data; d.write.width = 64; d.write.height = 128; d.write.planes = BATCH;
+    CHECK(cvgs_execute(&d, stream.raw()) == CVGS_OK, "raw C-ABI launch: " << cvgs_last_error());
+    stream.waitForCompletion();
+    const auto hr = fetch(d_raw.data, n * sizeof(float));
+    CHECK(bit_equal(h.data(), hr.data(), n * sizeof(float)), "facade == raw C-ABI descriptor");
+}
+
+template <int TI, int TO>
+static void sweep(cv::cuda::Stream& stream) {
+    test_constant<TI, TO, 10, cvGS::IGNORE_AR>(stream, 60);
+    test_constant<TI, TO, 30, cvGS::IGNORE_AR>(stream, 60);
+    test_constant<TI, TO, 50, cvGS::IGNORE_AR>(stream, 60);
+    test_constant<TI, TO, 20, cvGS::PRESERVE_AR>(stream, 30);
+    test_constant<TI, TO, 50, cvGS::PRESERVE_AR>(stream, 30);
+    test_random_vs_oracle<TI, TO, 50, cvGS::IGNORE_AR>(stream);
+    test_random_vs_oracle<TI, TO, 24, cvGS::PRESERVE_AR>(stream);
+}
+
+int main() {
+    cv::cuda::Stream stream;
+    // the type list of the reference's LAUNCH_TESTS (test_batchresize_x_split3D.cu:427-432)
+    sweep<CV_8UC3, CV_32FC3>(stream);
+    sweep<CV_8UC4, CV_32FC4>(stream);
+    sweep<CV_16UC3, CV_32FC3>(stream);
+    sweep<CV_16UC4, CV_32FC4>(stream);
+    sweep<CV_16SC3, CV_32FC3>(stream);
+    sweep<CV_16SC4, CV_32FC4>(stream);
+    return report("test_batchresize_x_split3D + aspectratio");
+}

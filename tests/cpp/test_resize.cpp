@@ -1,0 +1,127 @@
+// test_resize.cpp -- mirrors reference tests/resize/test_resize_x_split.cu (K2), test_resize_write.cu (K3) and
+// test_fused_resize.cu (K4, NV12 read-back fused into the resize) on the cvGS facade.
+#include "common.h"
+
+struct Params { cv::Scalar init, alpha, sub, div; };
+static const double kAlpha = 0.3;
+static const Params kParams[4] = {
+    {{2}, {kAlpha}, {1.f}, {3.2f}},
+    {{2, 37}, {kAlpha, kAlpha}, {1.f, 4.f}, {3.2f, 0.6f}},
+    {{2, 37, 128}, {kAlpha, kAlpha, kAlpha}, {1.f, 4.f, 3.2f}, {3.2f, 0.6f, 11.8f}},
+    {{2, 37, 128, 20}, {kAlpha, kAlpha, kAlpha, kAlpha}, {1.f, 4.f, 3.2f, 0.5f}, {3.2f, 0.6f, 11.8f, 33.f}}};
+
+// K2: resize(ROI) -> multiply -> subtract -> divide -> split into C separate GpuMats
+template <int TI, int TO>
+static void test_resize_split_one(cv::cuda::Stream& stream) {
+    constexpr int CN = CV_MAT_CN(TO);
+    const Params& p = kParams[CN - 1];
+    const cv::Size up(64, 128);
+    const cv::Rect2d crop(cv::Point2d(200, 200), cv::Point2d(260, 320));
+    cv::cuda::GpuMat d_input(2160, 3840, TI, p.init);
+    std::vector<cv::cuda::GpuMat> d_out(CN);
+    for (auto& m : d_out) m.create(up, CV_MAT_DEPTH(TO));
+    cvGS::executeOperations(stream, cvGS::resize<TI, cv::INTER_LINEAR>(d_input(crop), up, 0., 0.), cvGS::multiply<TO>(p.alpha),
+                            cvGS::subtract<TO>(p.sub), cvGS::divide<TO>(p.div), cvGS::split<TO>(d_out));
+    stream.waitForCompletion();
+    for (int c = 0; c < CN; ++c) {
+        cv::Mat h;
+        d_out[c].download(h);
+        const double e = ((double)p.init[c] * (float)kAlpha - (float)p.sub[c]) / (float)p.div[c];
+        bool ok = true;
+        for (int y = 0; y < h.rows && ok; ++y) ok = all_close<float>(h.ptr<float>(y), (size_t)h.cols, e);
+        CHECK(ok, "K2 known answer, type " << TI << " channel " << c);
+    }
+    // non-constant frame vs oracle
+    cv::Mat h_frame(700, 900, TI);
+    fill_random(h_frame, 77 + TI);
+    cv::cuda::GpuMat d_frame(h_frame), hv = host_view(h_frame);
+    std::vector<cv::Mat> h_ref(CN);
+    std::vector<cv::cuda::GpuMat> hv_ref(CN);
+    for (int c = 0; c < CN; ++c) { h_ref[c].create(up.height, up.width, CV_MAT_DEPTH(TO)); hv_ref[c] = host_view(h_ref[c]); }
+    const cv::Rect roi(13, 7, 333, 555);
+    cvGS::executeOperations(stream, cvGS::resize<TI, cv::INTER_LINEAR>(d_frame(roi), up, 0., 0.), cvGS::multiply<TO>(p.alpha),
+                            cvGS::subtract<TO>(p.sub), cvGS::divide<TO>(p.div), cvGS::split<TO>(d_out));
+    run_oracle(cvGS::resize<TI, cv::INTER_LINEAR>(hv(roi), up, 0., 0.), cvGS::multiply<TO>(p.alpha), cvGS::subtract<TO>(p.sub),
+               cvGS::divide<TO>(p.div), cvGS::split<TO>(hv_ref));
+    stream.waitForCompletion();
+    for (int c = 0; c < CN; ++c) {
+        cv::Mat h;
+        d_out[c].download(h);
+        bool same = true;
+        for (int y = 0; y < h.rows; ++y) same = same && bit_equal(h.ptr<float>(y), h_ref[c].ptr<float>(y), (size_t)h.cols * 4);
+        CHECK(same, "K2 non-constant vs oracle, type " << TI << " channel " << c);
+    }
+}
+
+// K3: resize up / down -> convertTo<32F -> I> (saturate) -> write; a constant image stays that constant
+template <int I>
+static void test_resize_write(cv::cuda::Stream& stream) {
+    constexpr int CN = CV_MAT_CN(I);
+    constexpr int F = CV_MAKETYPE(CV_32F, CN);
+    const cv::Scalar init = kParams[CN - 1].init;
+    cv::cuda::GpuMat d_input(2160, 3840, I, init);
+    for (const cv::Size sz : {cv::Size(3870, 2260), cv::Size(300, 500)}) {
+        cv::cuda::GpuMat d_out(sz, I);
+        cvGS::executeOperations(stream, cvGS::resize<I, cv::INTER_LINEAR>(d_input, sz, 0., 0.), cvGS::convertTo<F, I>(), cvGS::write<I>(d_out));
+        stream.waitForCompletion();
+        cv::Mat h;
+        d_out.download(h);
+        cv::Mat e(sz, I, init);
+        bool same = true;
+        for (int y = 0; y < h.rows; ++y) same = same && bit_equal(h.ptr<uchar>(y), e.ptr<uchar>(y), (size_t)h.cols * h.elemSize());
+        CHECK(same, "K3 resize+saturate of a constant image, type " << I << " to " << sz.width << "x" << sz.height);
+    }
+}
+
+// K4: Resize<LINEAR>(fuse(ReadYUV<NV12>, ConvertYUVToRGB<NV12,Full,bt709,true,float4>)) -> SaturateCast -> VectorReorder -> write
+static void test_fused_nv12_resize(cv::cuda::Stream& stream) {
+    const uint W = 1920, H = 1080;
+    const fk::Size down(640, 360);
+    cv::Mat h_nv12(H + H / 2, W, CV_8UC1);
+    fill_random(h_nv12, 4242);
+    cv::cuda::GpuMat d_nv12(h_nv12);
+    auto run = [&](uchar* base, uint pitch, uchar4* out, uint out_pitch, bool gpu) {
+        const fk::RawPtr<fk::_2D, uchar> src{base, {W, H, pitch}};
+        const auto readBack = fk::fuse(fk::Read<fk::ReadYUV<fk::NV12>>{src},
+                                       fk::Unary<fk::ConvertYUVToRGB<fk::NV12, fk::Full, fk::bt709, true, float4>>{});
+        const auto readOp = fk::Resize<fk::INTER_LINEAR>::build(readBack, down);
+        const fk::RawPtr<fk::_2D, uchar4> dst{out, {(uint)down.width, (uint)down.height, out_pitch}};
+        const auto convertOp = fk::Unary<fk::SaturateCast<float4, uchar4>>{};
+        const auto colorConvert = fk::Unary<fk::VectorReorder<uchar4, 2, 1, 0, 3>>{};
+        const auto writeOp = fk::Write<fk::PerThreadWrite<fk::_2D, uchar4>>{dst};
+        if (gpu) fk::executeOperations(stream.raw(), readOp, convertOp, colorConvert, writeOp);
+        else run_oracle(readOp, convertOp, colorConvert, writeOp);
+    };
+    cv::cuda::GpuMat d_out(down.height, down.width, CV_8UC4);
+    cv::Mat h_ref(down.height, down.width, CV_8UC4);
+    run(d_nv12.data, (uint)d_nv12.step, (uchar4*)d_out.data, (uint)d_out.step, true);
+    run(h_nv12.data, (uint)h_nv12.step, (uchar4*)h_ref.data, (uint)h_ref.step, false);
+    stream.waitForCompletion();
+    cv::Mat h;
+    d_out.download(h);
+    bool same = true;
+    for (int y = 0; y < h.rows; ++y) same = same && bit_equal(h.ptr<uchar>(y), h_ref.ptr<uchar>(y), (size_t)h.cols * 4);
+    CHECK(same, "K4 NV12 -> BGRA resize, bit-exact vs oracle");
+}
+
+int main() {
+    cv::cuda::Stream stream;
+    test_resize_split_one<CV_8UC3, CV_32FC3>(stream);
+    test_resize_split_one<CV_8UC4, CV_32FC4>(stream);
+    test_resize_split_one<CV_16UC3, CV_32FC3>(stream);
+    test_resize_split_one<CV_16UC4, CV_32FC4>(stream);
+    test_resize_split_one<CV_16SC3, CV_32FC3>(stream);
+    test_resize_split_one<CV_16SC4, CV_32FC4>(stream);
+    test_resize_write<CV_8UC1>(stream);
+    test_resize_write<CV_8UC3>(stream);
+    test_resize_write<CV_8UC4>(stream);
+    test_resize_write<CV_16UC1>(stream);
+    test_resize_write<CV_16UC3>(stream);
+    test_resize_write<CV_16UC4>(stream);
+    test_resize_write<CV_16SC1>(stream);
+    test_resize_write<CV_16SC3>(stream);
+    test_resize_write<CV_16SC4>(stream);
+    test_resize_write<CV_32FC1>(stream);
+    test_fused_nv12_resize(stream);
+    return report("test_resize_x_split + test_resize_write + test_fused_resize");
+}

@@ -56,7 +56,7 @@ class Workload:
     """F resident 4K frames, F crop lists, F output tensors, F pre-lowered chains."""
 
     def __init__(self, dev, n_frames, crops_per_launch, rank, world, use_table, frame_wh=W.FRAME_4K,
-                 out_all=None):
+                 out_all=None, flags=0, share=None):
         self.dev = dev
         fw, fh = frame_wh
         self.frames, self.outs, self.chains, self.crops, self.tables = [], [], [], [], []
@@ -65,7 +65,7 @@ class Workload:
         plane = 3 * W.DST[0] * W.DST[1]
         for f in range(n_frames):
             seed = W.SEED + 1000 * rank + f
-            frame = W.random_u8_torch((fh, fw, 3), seed, dev)
+            frame = share.frames[f] if share is not None else W.random_u8_torch((fh, fw, 3), seed, dev)
             crops = W.random_crops(crops_per_launch, fw, fh, seed=seed + 500000)
             if out_all is not None:  # in-place all-gather layout: this rank's slice of the full tensor
                 out = out_all[f][rank * crops_per_launch:(rank + 1) * crops_per_launch]
@@ -81,8 +81,8 @@ class Workload:
             self.frames.append(frame)
             self.outs.append(out)
             self.crops.append(crops)
-            self.chains.append(cvgs.lower(ops))
-        self.kernel = cvgs.kernel_name(*ops)
+            self.chains.append(cvgs.lower(ops, flags))
+        self.kernel = cvgs.kernel_name(*ops, flags=flags)
 
     def launch(self, i, stream):
         ch = self.chains[i % len(self.chains)]

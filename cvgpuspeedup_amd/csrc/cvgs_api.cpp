@@ -222,6 +222,14 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     Wa.planes = wr.planes;
     Wa.data = (uint8_t*)wr.data;
     Wa.table = nullptr;
+    {
+        const int64_t plane = (int64_t)L.out_w * L.out_h;
+        if (wr.kind == CVGS_WRITE_TENSOR_SPLIT) { Wa.img_stride = plane * L.final_cn; Wa.ch_stride = plane; }
+        else if (wr.kind == CVGS_WRITE_TENSOR_T_SPLIT) { Wa.img_stride = plane; Wa.ch_stride = plane * wr.planes; }
+        else { Wa.img_stride = plane; Wa.ch_stride = 0; }
+        Wa.data2 = nullptr;
+        Wa.img_stride2 = Wa.ch_stride2 = 0;
+    }
     const bool tensor_kind = wr.kind == CVGS_WRITE_PIXEL_3D || wr.kind == CVGS_WRITE_TENSOR_SPLIT ||
                              wr.kind == CVGS_WRITE_TENSOR_T_SPLIT;
     if (tensor_kind || wr.kind == CVGS_WRITE_PIXEL_2D) {
@@ -295,6 +303,16 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         }
     }
     int rc = 0;
+    const int exp_variant = (int)((ch->flags >> 8) & 0xff);
+    if (exp_variant && k1_exp_name(exp_variant) && L.args.read.kind == CVGS_READ_RESIZE_LINEAR && L.args.read.depth == CVGS_DEPTH_8U &&
+        L.args.read.cn == 3 && L.args.prog.n == 4 && L.args.write.depth == CVGS_DEPTH_32F &&
+        (L.args.write.kind == CVGS_WRITE_TENSOR_SPLIT || L.args.write.kind == CVGS_WRITE_TENSOR_T_SPLIT)) {
+        if (info) info->kernel = k1_exp_name(exp_variant);
+        if (dry_run) return CVGS_OK;
+        rc = launch_k1_exp(exp_variant, L.args, inline_planes, n_inline, stream);
+        if (rc < 0) return fail(CVGS_ERR_HIP, "experimental K1 launch failed");
+        return CVGS_OK;
+    }
     if (!(ch->flags & CVGS_CHAIN_FORCE_GENERIC)) {
         rc = launch_k1(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
@@ -431,20 +449,47 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     } else if (out_cn != ct->color_planes || CVGS_MAKETYPE(CVGS_TYPE_DEPTH(one.write.dst_type), 1) != ct->elem_type) {
         return fail(CVGS_ERR_INVALID, "split write does not match the tensor's planes / element type");
     }
-    // 1) new frame -> history slot (always standard plane order inside the ring)
+    // 1) ONE pass over the new frame writes it twice: into the history ring (slot = update index mod BATCH, always
+    //    standard plane order) and into its slot of the ordered tensor (slot 0 NewestFirst / BATCH-1 OldestFirst).
     const int64_t slot = ct->count % ct->batch;
-    one.write.kind = wk == CVGS_WRITE_TENSOR_T_SPLIT ? CVGS_WRITE_TENSOR_SPLIT : wk;
-    one.write.data = ct->ring + (size_t)slot * ct->image_bytes;
+    const int z_new = ct->order == CVGS_NEWEST_FIRST ? 0 : ct->batch - 1;
+    Lowered L;
+    one.write.data = ct->ring; // placeholder so that validation sees a non-null target
     one.write.width = ct->width;
     one.write.height = ct->height;
-    one.write.planes = 1;
-    int rc = cvgs_execute(&one, stream);
+    one.write.planes = ct->batch;
+    int rc = lower(&one, true, L);
     if (rc) return rc;
-    // 2) rebuild the ordered tensor from the history: slot z shows the frame of age z (NewestFirst)
-    //    or BATCH-1-z (OldestFirst); never-written history slots are zero.
+    {
+        WriteArgs& Wa = L.args.write;
+        const int esz = depth_bytes(CVGS_TYPE_DEPTH(one.write.dst_type));
+        const int64_t plane = (int64_t)ct->width * ct->height; // elements of one colour plane (packed: pixels)
+        Wa.kind = wk == CVGS_WRITE_TENSOR_T_SPLIT ? CVGS_WRITE_TENSOR_SPLIT : wk;
+        Wa.planes = 1;
+        // primary: the ordered tensor
+        if (wk == CVGS_WRITE_TENSOR_T_SPLIT) {
+            Wa.data = ct->out + (size_t)z_new * ct->plane_bytes;
+            Wa.img_stride = plane;
+            Wa.ch_stride = plane * ct->batch;
+        } else {
+            Wa.data = ct->out + (size_t)z_new * ct->image_bytes;
+            Wa.img_stride = wk == CVGS_WRITE_PIXEL_3D ? plane : plane * ct->color_planes;
+            Wa.ch_stride = wk == CVGS_WRITE_PIXEL_3D ? 0 : plane;
+        }
+        // secondary: the ring slot, standard order
+        Wa.data2 = ct->ring + (size_t)slot * ct->image_bytes;
+        Wa.img_stride2 = wk == CVGS_WRITE_PIXEL_3D ? plane : plane * ct->color_planes;
+        Wa.ch_stride2 = wk == CVGS_WRITE_PIXEL_3D ? 0 : plane;
+        (void)esz;
+    }
+    rc = dispatch(&one, L, (hipStream_t)stream, false, nullptr);
+    if (rc) return rc;
+    // 2) every OLDER frame: history ring -> its new slot of the ordered tensor.  Slot z shows the frame of age z
+    //    (NewestFirst) or BATCH-1-z (OldestFirst); never-written history slots are zero.
     CopyJob jobs[kMaxCopyJobs];
     int n = 0;
     for (int z = 0; z < ct->batch; ++z) {
+        if (z == z_new) continue;
         const int64_t age = ct->order == CVGS_NEWEST_FIRST ? z : ct->batch - 1 - z;
         int64_t src_slot = (ct->count - age) % ct->batch;
         if (src_slot < 0) src_slot += ct->batch;

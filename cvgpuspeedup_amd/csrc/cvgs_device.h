@@ -58,6 +58,11 @@ struct WriteArgs {
     int32_t pad;
     uint8_t* data;
     const DstPlane* table;  // device table for SPLIT_2D / PIXEL_2D_BATCH beyond the inline ones
+    // Tensor kinds: element strides of the primary target, and an optional SECOND target that receives the same
+    // values (CircularTensor: the new frame goes to the history ring and to the ordered tensor in one pass).
+    int64_t img_stride, ch_stride;
+    uint8_t* data2;
+    int64_t img_stride2, ch_stride2;
 };
 
 static constexpr int kInlineDst = 16; // inline destination planes (e.g. batch 4 x 4 channels)
@@ -95,6 +100,10 @@ int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_i
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
 int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
               void* stream, bool dry_run, LaunchInfo* info);
+
+// experimental K1 variants (k_k1_exp.hip), selected by bits 8..15 of the chain flags; A/B benchmarking only
+int launch_k1_exp(int variant, const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream);
+const char* k1_exp_name(int variant);
 
 // plane-to-plane copies of the CircularTensor update (K9): dst[i] <- src[i], `bytes` each
 struct CopyJob {

@@ -238,7 +238,7 @@ __device__ __forceinline__ void store_elem(uint8_t* base, size_t idx, int depth,
 
 __device__ __forceinline__ void write_px(const WriteArgs& w, const DstPlane* dst_planes, int x, int y, int z,
                                          const Px& p, int depth, int cn) {
-    const size_t W = (size_t)w.width, H = (size_t)w.height;
+    const size_t W = (size_t)w.width;
     switch (w.kind) {
     case CVGS_WRITE_PIXEL_2D: {
         uint8_t* row = w.data + (size_t)y * (size_t)w.step;
@@ -254,20 +254,27 @@ __device__ __forceinline__ void write_px(const WriteArgs& w, const DstPlane* dst
         break;
     }
     case CVGS_WRITE_PIXEL_3D: {
-        const size_t pix = ((size_t)z * H + y) * W + x;
+        const size_t pix = (size_t)z * w.img_stride + (size_t)y * W + x;
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (c < cn) store_elem(w.data, pix * cn + c, depth, p.v[c]);
+        if (w.data2) {
+            const size_t pix2 = (size_t)z * w.img_stride2 + (size_t)y * W + x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < cn) store_elem(w.data2, pix2 * cn + c, depth, p.v[c]);
+        }
         break;
     }
     case CVGS_WRITE_TENSOR_SPLIT:
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < cn) store_elem(w.data, (((size_t)z * cn + c) * H + y) * W + x, depth, p.v[c]);
-        break;
     case CVGS_WRITE_TENSOR_T_SPLIT:
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (c < cn) store_elem(w.data, (((size_t)c * w.planes + z) * H + y) * W + x, depth, p.v[c]);
+            if (c < cn) store_elem(w.data, (size_t)z * w.img_stride + (size_t)c * w.ch_stride + (size_t)y * W + x, depth, p.v[c]);
+        if (w.data2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < cn)
+                    store_elem(w.data2, (size_t)z * w.img_stride2 + (size_t)c * w.ch_stride2 + (size_t)y * W + x, depth, p.v[c]);
+        }
         break;
     case CVGS_WRITE_SPLIT_2D:
 #pragma unroll

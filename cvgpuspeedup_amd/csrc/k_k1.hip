@@ -5,16 +5,22 @@
 //     -> ColorConversion -> Mul -> Sub -> Div -> Write<TensorSplit<float3>>
 // launched at reference tests/batchresize/test_batchresize_x_split3D.cu:311-314.
 //
-// CDNA4 mapping (this path is bandwidth/latency bound: no MFMA, no LDS round trip needed):
-//  * lane = output column, wave = RPW consecutive output rows of one crop.  Everything that depends
-//    only on the column (x1, the two x weights, the byte window) is computed once per lane and
-//    reused for every row; everything that depends only on the row (y1, y weights, the two source
-//    row pointers) is wave-uniform and lives in SGPRs.
-//  * each lane fetches BOTH horizontal taps of a source row with ONE unaligned 8-byte load (a
-//    u8c3 pixel pair is 6 bytes, a u8c4 pair 8): 2 loads per output pixel instead of 12-16 byte
-//    loads.  The window is clamped to the crop row, so no byte outside the ROI is ever read.
-//  * the three/four planar stores of a wave are full 256-byte rows.
-//  * workgroup ids are remapped so the tiles of one crop run on one XCD and share its L2.
+// CDNA4 mapping.  Measured (profiles/, tools/k1_ab.py): a 50-crop launch is latency bound (an EMPTY 1600-workgroup
+// launch already costs 1.76 us of the ~5 us), a 3200-crop launch is HBM bound (mixed read/write traffic at ~4.9 TB/s
+// real); the VALU work hides under both.  Hence:
+//  * lane = output column, wave = RPW consecutive output rows of one crop, blockIdx.y = crop (no integer division).
+//    Column geometry (x1, the two x weights, the byte window) is computed once per lane and reused for every row;
+//    row geometry is wave-uniform (SGPRs).
+//  * every kernel-argument field and the crop's PlaneParams are fetched in ONE batch of scalar loads before the
+//    first branch, so a wave pays one scalar-memory round trip, not one per early-exit test.
+//  * each lane fetches BOTH horizontal taps of a source row with ONE unaligned 8-byte global load (a u8c3 pixel
+//    pair is 6 bytes, u8c4 8 bytes) from a uniform row base + 32-bit lane offset: 2 loads per output pixel.  The
+//    window is clamped into the crop row, so no byte outside the ROI is ever read; rows narrower than 8 bytes
+//    gather their bytes one by one.
+//  * planar stores are full 256-byte rows per wave and non-temporal: the output is written once and never re-read
+//    by this kernel, so it should not wait in L2 for the end-of-kernel write-back.
+//  * small launches use 1 row per wave (maximum parallelism, shortest critical path), large ones 4 (amortises the
+//    column geometry).
 #include <initializer_list>
 #include <type_traits>
 
@@ -22,97 +28,136 @@
 
 namespace cvgs {
 
-// the two chains the reference's tests spell, as compile-time programs; anything else is interpreted
-using ProgReorderMulSubDiv = StaticProg<CVGS_OP_REORDER, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
-using ProgMulSubDiv = StaticProg<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
+// Compile-time programs for the chains the reference's tests spell.  kOpSwapRB is an internal opcode: REORDER whose
+// permutation is the RGB<->BGR swap (aux 2,1,0[,3]) resolved at compile time instead of per-pixel selects.
+constexpr int kOpSwapRB = 100;
+
+template <int... OPS>
+struct K1Prog {
+    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
+        int k = 0;
+        ((step<OPS>(prog, k, p, depth, cn), ++k), ...);
+    }
+    template <int OP>
+    static __device__ __forceinline__ void step(const ProgArgs& prog, int k, Px& p, int& depth, int& cn) {
+        if constexpr (OP == kOpSwapRB) {
+            const float t = p.v[0];
+            p.v[0] = p.v[2];
+            p.v[2] = t;
+        } else {
+            apply_op(OP, prog.aux[k], prog.operand[k], p, depth, cn);
+        }
+    }
+};
+using ProgSwapMulSubDiv = K1Prog<kOpSwapRB, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
+using ProgMulSubDiv = K1Prog<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 
 struct K1Geom {
-    uint32_t col_tiles;       // ceil(dst_w / 64)
-    uint32_t tiles_per_plane; // col_tiles * row_tiles
-    uint32_t total_tiles;     // tiles_per_plane * batch
-    uint32_t padded_tiles;    // total rounded up to a multiple of 8 (XCD remap is a bijection on it)
-    int64_t img_stride;       // output elements between images
-    int64_t ch_stride;        // output elements between channel planes
+    uint32_t col_tiles;  // ceil(dst_w / 64)
+    int32_t dst_w, dst_h;
+    int32_t used;        // planes >= used carry the background value
+    int32_t out_w;       // output row length in elements
+    int32_t pad;
+    int64_t img_stride;  // output elements between images
+    int64_t ch_stride;   // output elements between channel planes
+    float* out;
+    float* out2;         // optional second target (CircularTensor ring + tensor), own strides
+    int64_t img_stride2, ch_stride2;
 };
 
-__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8); // gfx950 global loads need no alignment: one global_load_dwordx2
-    return v;
-}
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) u64_unaligned* gptr_u64;
+typedef const __attribute__((address_space(1))) uint8_t* gptr_u8;
 
-// crops narrower than 8 bytes per row (1-2 pixels): gather the pair byte by byte, never past the row
-__device__ __forceinline__ uint64_t load_pair_bytes(const uint8_t* row, int o, int n, int row_bytes) {
-    uint64_t v = 0;
-    for (int k = 0; k < n; ++k)
-        if (o + k < row_bytes) v |= (uint64_t)row[o + k] << (8 * k);
-    return v;
+// crop rows narrower than 8 bytes (1-2 pixels): byte gather with clamped, always-valid addresses
+template <int CN>
+__device__ __forceinline__ uint64_t gather_pair(gptr_u8 row, int o, int row_bytes) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * CN; ++k) {
+        const uint32_t b = row[min(o + k, row_bytes - 1)];
+        if (k < 4) lo |= b << (8 * k);
+        else hi |= b << (8 * (k - 4));
+    }
+    return ((uint64_t)hi << 32) | lo;
 }
 
 template <int CN>
 __device__ __forceinline__ void unpack_pair(uint64_t v, bool edge, float* a, float* b) {
     const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    // second pixel of the pair as one 32-bit word; at the right edge (x2 clamped onto x1) it IS the first pixel
+    const uint32_t second = CN == 3 ? (uint32_t)(v >> 24) : hi;
+    const uint32_t s = edge ? lo : second;
     a[0] = (float)(lo & 0xffu);
     a[1] = (float)((lo >> 8) & 0xffu);
     a[2] = (float)((lo >> 16) & 0xffu);
-    if constexpr (CN == 3) {
-        b[0] = (float)(lo >> 24);
-        b[1] = (float)(hi & 0xffu);
-        b[2] = (float)((hi >> 8) & 0xffu);
-    } else {
+    b[0] = (float)(s & 0xffu);
+    b[1] = (float)((s >> 8) & 0xffu);
+    b[2] = (float)((s >> 16) & 0xffu);
+    if constexpr (CN == 4) {
         a[3] = (float)(lo >> 24);
-        b[0] = (float)(hi & 0xffu);
-        b[1] = (float)((hi >> 8) & 0xffu);
-        b[2] = (float)((hi >> 16) & 0xffu);
-        b[3] = (float)(hi >> 24);
+        b[3] = (float)(s >> 24);
     }
-#pragma unroll
-    for (int c = 0; c < CN; ++c) b[c] = edge ? a[c] : b[c];
 }
 
+__device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+
 template <int CN, int NPL, int RPW, class Prog>
-__global__ __launch_bounds__(256) void k1_direct(const KernArgs<NPL> a, const K1Geom g) {
+__global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, const K1Geom g) {
     const ChainArgs& c = a.c;
-    const ReadArgs& r = c.read;
-    const uint32_t bid = xcd_remap(blockIdx.x, g.padded_tiles);
-    if (bid >= g.total_tiles) return;
-    const int z = (int)(bid / g.tiles_per_plane);
-    const uint32_t t = bid - (uint32_t)z * g.tiles_per_plane;
-    const int col_tile = (int)(t % g.col_tiles);
-    const int row_tile = (int)(t / g.col_tiles);
+    const int z = (int)blockIdx.y;
+    // ---- one batch of scalar loads: geometry, the crop's parameters, the program operands come in together ----
+    const int dst_w = g.dst_w, dst_h = g.dst_h, used = g.used, W = g.out_w;
+    const uint32_t col_tiles = g.col_tiles;
+    const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
+    float* const out_base = g.out;
+    PlaneParams P;
+    if constexpr (NPL == 0) P = c.read.table[z < used ? z : 0];
+    else P = a.planes[z];
+    asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(used), "s"(W), "s"(col_tiles), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.x1),
+                 "s"(P.y1), "s"(P.x2), "s"(P.y2));
+
+    int col_tile = 0, row_tile = (int)blockIdx.x;
+    if (col_tiles > 1) {
+        col_tile = (int)(blockIdx.x % col_tiles);
+        row_tile = (int)(blockIdx.x / col_tiles);
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const int x = col_tile * 64 + lane;
     const int row0 = (row_tile * 4 + wave) * RPW;
-    if (row0 >= r.dst_h) return;
-    const bool x_ok = x < r.dst_w;
+    if (row0 >= dst_h || x >= dst_w) return;
+    float* const out = out_base + (int64_t)z * img_stride;
+    float* const out2 = g.out2 ? g.out2 + (int64_t)z * g.img_stride2 : nullptr; // wave-uniform
 
-    float* const out = (float*)c.write.data + (int64_t)z * g.img_stride + x;
-    const int W = c.write.width;
+    // does the source cover the whole target?  (always, except AR padding and planes >= usedPlanes)
+    const bool whole = z < used && ((P.x1 | P.y1 | (P.x2 ^ (dst_w - 1)) | (P.y2 ^ (dst_h - 1))) == 0);
 
-    // background value pushed through the whole chain: planes >= usedPlanes and AR padding
     Px bgp;
-    int bdepth = CVGS_DEPTH_32F, bcn = CN;
+    bgp.v[0] = bgp.v[1] = bgp.v[2] = bgp.v[3] = 0.f;
+    int out_cn = CN;
+    if (!whole) {
+        // background value pushed through the whole chain: planes >= usedPlanes and AR padding
+        int bdepth = CVGS_DEPTH_32F, bcn = CN;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bgp.v[k] = r.bg[k];
-    Prog::run(c.prog, bgp, bdepth, bcn);
-
-    if (z >= r.used) {
+        for (int k = 0; k < 4; ++k) bgp.v[k] = c.read.bg[k];
+        Prog::run(c.prog, bgp, bdepth, bcn);
+        out_cn = bcn;
+        if (z >= used) {
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const int y = row0 + j;
-            if (y < r.dst_h && x_ok) {
+            for (int j = 0; j < RPW; ++j) {
+                const int y = row0 + j;
+                if (y < dst_h)
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < bcn) out[(int64_t)k * g.ch_stride + (int64_t)y * W] = bgp.v[k];
+                    for (int k = 0; k < 4; ++k)
+                        if (k < bcn) {
+                            st_nt(out + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
+                            if (out2) st_nt(out2 + (int64_t)k * g.ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
+                        }
             }
+            return;
         }
-        return;
     }
-
-    PlaneParams P;
-    if constexpr (NPL == 0) P = r.table[z];
-    else P = a.planes[z];
 
     // ---- per-lane column geometry (reused for every row) ----
     const bool in_x = x >= P.x1 && x <= P.x2;
@@ -126,15 +171,16 @@ __global__ __launch_bounds__(256) void k1_direct(const KernArgs<NPL> a, const K1
     const int row_bytes = P.w * CN;
     const int o = x1 * CN;
     const bool tiny = row_bytes < 8; // wave-uniform
-    const int ol = tiny ? o : min(o, row_bytes - 8);
-    const int sh = (o - ol) * 8;
+    const uint32_t ol = (uint32_t)(tiny ? o : min(o, row_bytes - 8));
+    const int sh = (o - (int)ol) * 8;
+    const gptr_u8 src = (gptr_u8)P.data;
 
     uint64_t va[RPW], vb[RPW];
     float wya[RPW], wyb[RPW];
     bool in_y[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-        const int y = min(row0 + j, r.dst_h - 1);
+        const int y = min(row0 + j, dst_h - 1);
         in_y[j] = y >= P.y1 && y <= P.y2;
         const int yr = in_y[j] ? y - P.y1 : 0;
         const float sy = (float)yr * P.fy;
@@ -143,67 +189,56 @@ __global__ __launch_bounds__(256) void k1_direct(const KernArgs<NPL> a, const K1
         const int y2r = min(y2, P.h - 1);
         wya[j] = (float)y2 - sy;
         wyb[j] = sy - (float)y1;
-        const uint8_t* ra = P.data + (size_t)y1 * (size_t)P.step;
-        const uint8_t* rb = P.data + (size_t)y2r * (size_t)P.step;
+        const gptr_u8 ra = src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step;
+        const gptr_u8 rb = src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step;
         if (!tiny) {
-            va[j] = load_u64_unaligned(ra + ol);
-            vb[j] = load_u64_unaligned(rb + ol);
+            va[j] = *(gptr_u64)(ra + ol);
+            vb[j] = *(gptr_u64)(rb + ol);
         } else {
-            va[j] = load_pair_bytes(ra, o, 2 * CN, row_bytes);
-            vb[j] = load_pair_bytes(rb, o, 2 * CN, row_bytes);
+            va[j] = gather_pair<CN>(ra, o, row_bytes);
+            vb[j] = gather_pair<CN>(rb, o, row_bytes);
         }
     }
 
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int y = row0 + j;
-        float p00[4], p10[4], p01[4], p11[4];
-        unpack_pair<CN>(va[j] >> sh, edge, p00, p10);
-        unpack_pair<CN>(vb[j] >> sh, edge, p01, p11);
-        const float w00 = wxa * wya[j];
-        const float w10 = wxb * wya[j];
-        const float w01 = wxa * wyb[j];
-        const float w11 = wxb * wyb[j];
-        Px p;
-        p.v[3] = 0.f;
+        if (y < dst_h) { // wave-uniform
+            float p00[4], p10[4], p01[4], p11[4];
+            unpack_pair<CN>(va[j] >> sh, edge, p00, p10);
+            unpack_pair<CN>(vb[j] >> sh, edge, p01, p11);
+            const float w00 = wxa * wya[j];
+            const float w10 = wxb * wya[j];
+            const float w01 = wxa * wyb[j];
+            const float w11 = wxb * wyb[j];
+            Px p;
+            p.v[3] = 0.f;
 #pragma unroll
-        for (int k = 0; k < CN; ++k) {
-            float acc = p00[k] * w00;
-            acc = acc + p10[k] * w10;
-            acc = acc + p01[k] * w01;
-            acc = acc + p11[k] * w11;
-            p.v[k] = acc;
-        }
-        int depth = CVGS_DEPTH_32F, cn = CN;
-        Prog::run(c.prog, p, depth, cn);
-        const bool inside = in_x && in_y[j];
-        if (y < r.dst_h && x_ok) {
+            for (int k = 0; k < CN; ++k) {
+                float acc = p00[k] * w00;
+                acc = acc + p10[k] * w10;
+                acc = acc + p01[k] * w01;
+                acc = acc + p11[k] * w11;
+                p.v[k] = acc;
+            }
+            int depth = CVGS_DEPTH_32F, cn = CN;
+            Prog::run(c.prog, p, depth, cn);
+            out_cn = cn;
+            float* const orow = out + (int64_t)y * W; // wave-uniform
+            const bool take = whole || (in_x && in_y[j]);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k < cn) out[(int64_t)k * g.ch_stride + (int64_t)y * W] = inside ? p.v[k] : bgp.v[k];
+                if (k < cn) {
+                    const float v = take ? p.v[k] : bgp.v[k];
+                    st_nt(orow + (int64_t)k * ch_stride + x, v);
+                    if (out2) st_nt(out2 + (int64_t)y * W + (int64_t)k * g.ch_stride2 + x, v);
+                }
         }
     }
+    (void)out_cn;
 }
 
 // ------------------------------------------------------------------------------------------------
-static K1Geom make_geom(const ChainArgs& c, int rows_per_wg, int out_cn) {
-    K1Geom g;
-    g.col_tiles = (uint32_t)((c.read.dst_w + 63) / 64);
-    const uint32_t row_tiles = (uint32_t)((c.read.dst_h + rows_per_wg - 1) / rows_per_wg);
-    g.tiles_per_plane = g.col_tiles * row_tiles;
-    g.total_tiles = g.tiles_per_plane * (uint32_t)c.read.batch;
-    g.padded_tiles = (g.total_tiles + 7u) / 8u * 8u;
-    const int64_t plane = (int64_t)c.write.width * c.write.height;
-    if (c.write.kind == CVGS_WRITE_TENSOR_SPLIT) {
-        g.img_stride = plane * out_cn;
-        g.ch_stride = plane;
-    } else {
-        g.img_stride = plane;
-        g.ch_stride = plane * c.write.planes;
-    }
-    return g;
-}
-
 template <int CN, int NPL, int RPW, class Prog>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn,
                            hipStream_t stream) {
@@ -215,8 +250,24 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     } else {
         a.planes[0] = PlaneParams{};
     }
-    const K1Geom g = make_geom(c, 4 * RPW, out_cn);
-    hipLaunchKernelGGL((k1_direct<CN, NPL, RPW, Prog>), dim3(g.padded_tiles), dim3(256), 0, stream, a, g);
+    K1Geom g;
+    const int rows_per_wg = 4 * RPW;
+    g.col_tiles = (uint32_t)((c.read.dst_w + 63) / 64);
+    const uint32_t row_tiles = (uint32_t)((c.read.dst_h + rows_per_wg - 1) / rows_per_wg);
+    g.dst_w = c.read.dst_w;
+    g.dst_h = c.read.dst_h;
+    g.used = c.read.used;
+    g.out_w = c.write.width;
+    g.pad = 0;
+    (void)out_cn;
+    g.img_stride = c.write.img_stride;
+    g.ch_stride = c.write.ch_stride;
+    g.out = (float*)c.write.data;
+    g.out2 = (float*)c.write.data2;
+    g.img_stride2 = c.write.img_stride2;
+    g.ch_stride2 = c.write.ch_stride2;
+    const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch);
+    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog>), grid, dim3(256), 0, stream, a, g);
     return hipGetLastError();
 }
 
@@ -239,12 +290,14 @@ static hipError_t launch_npl(bool table, int rpw, const ChainArgs& c, const Plan
     return launch_rpw<CN, CVGS_KERNARG_PLANES, Prog>(rpw, c, ip, ni, out_cn, s);
 }
 
-static bool prog_is(const ProgArgs& p, std::initializer_list<int> ops) {
-    if (p.n != (int)ops.size()) return false;
-    int k = 0;
-    for (int o : ops)
-        if (p.opcode[k++] != o) return false;
-    return true;
+// program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
+static int classify_program(const ProgArgs& p, int cn) {
+    const int swap = cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
+    if (p.n == 4 && p.opcode[0] == CVGS_OP_REORDER && p.aux[0] == swap && p.opcode[1] == CVGS_OP_MUL &&
+        p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV)
+        return 0;
+    if (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) return 1;
+    return 2;
 }
 
 int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
@@ -254,24 +307,21 @@ int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline
     if (r.kind != CVGS_READ_RESIZE_LINEAR || r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4)) return 0;
     if (c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return 0;
     if (c.write.depth != CVGS_DEPTH_32F) return 0;
+    if (r.batch > 65535) return 0;
     for (int k = 0; k < c.prog.n; ++k) // value must stay fp32 through the program
         if (c.prog.opcode[k] == CVGS_OP_CAST) return 0;
 
     // rows per wave: small launches are latency bound -> maximum parallelism (1 row per wave);
-    // large ones amortise the column geometry and the hoisted division set-up over more rows.
+    // large ones amortise the column geometry over more rows (measured: tools/k1_ab.py).
     const int64_t wave_rows = (int64_t)r.batch * r.dst_h * ((r.dst_w + 63) / 64);
-    const int rpw = wave_rows <= 8192 ? 1 : (wave_rows <= 32768 ? 2 : 4);
+    const int rpw = wave_rows <= 16384 ? 1 : (wave_rows <= 65536 ? 2 : 4);
 
     const bool table = r.table != nullptr;
-    int prog_id = 2;
-    if (prog_is(c.prog, {CVGS_OP_REORDER, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV})) prog_id = 0;
-    else if (prog_is(c.prog, {CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV})) prog_id = 1;
+    const int prog_id = classify_program(c.prog, r.cn);
 
     if (info) {
-        static const char* names[2][3] = {{"k1_u8c3_direct_reorder_mul_sub_div", "k1_u8c3_direct_mul_sub_div",
-                                           "k1_u8c3_direct_interp"},
-                                          {"k1_u8c4_direct_reorder_mul_sub_div", "k1_u8c4_direct_mul_sub_div",
-                                           "k1_u8c4_direct_interp"}};
+        static const char* names[2][3] = {{"k1_u8c3_swap_mul_sub_div", "k1_u8c3_mul_sub_div", "k1_u8c3_interp"},
+                                          {"k1_u8c4_swap_mul_sub_div", "k1_u8c4_mul_sub_div", "k1_u8c4_interp"}};
         info->kernel = names[r.cn == 4][prog_id];
     }
     if (dry_run) return 1;
@@ -281,11 +331,11 @@ int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline
     const int out_cn = c.write.cn;
     hipError_t e;
     if (r.cn == 3) {
-        if (prog_id == 0) e = launch_npl<3, ProgReorderMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
+        if (prog_id == 0) e = launch_npl<3, ProgSwapMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
         else if (prog_id == 1) e = launch_npl<3, ProgMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
         else e = launch_npl<3, InterpProg>(table, rpw, c, inline_planes, n_inline, out_cn, s);
     } else {
-        if (prog_id == 0) e = launch_npl<4, ProgReorderMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
+        if (prog_id == 0) e = launch_npl<4, ProgSwapMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
         else if (prog_id == 1) e = launch_npl<4, ProgMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
         else e = launch_npl<4, InterpProg>(table, rpw, c, inline_planes, n_inline, out_cn, s);
     }

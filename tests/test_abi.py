@@ -49,13 +49,13 @@ def _k1(n=4, **kw):
 
 def test_kernel_selection(lib):
     ops, keep = _k1()
-    assert cvgs.kernel_name(*ops) == "k1_u8c3_direct_reorder_mul_sub_div"
+    assert cvgs.kernel_name(*ops) == "k1_u8c3_swap_mul_sub_div"
     assert cvgs.kernel_name(*ops, flags=capi.CHAIN_FORCE_GENERIC).startswith("generic_inline")
     ops2, keep2 = _k1(swap=False)
-    assert cvgs.kernel_name(*ops2) == "k1_u8c3_direct_mul_sub_div"
+    assert cvgs.kernel_name(*ops2) == "k1_u8c3_mul_sub_div"
     # a program the fast path does not special-case runs interpreted inside the K1 kernel
     ops3 = ops[:2] + [cvgs.add(cvgs.CV_32FC3, [1, 2, 3])] + ops[2:]
-    assert cvgs.kernel_name(*ops3) == "k1_u8c3_direct_interp"
+    assert cvgs.kernel_name(*ops3) == "k1_u8c3_interp"
     big, keep3 = _k1(n=100)
     assert cvgs.kernel_name(*big).startswith("k1_u8c3")
 

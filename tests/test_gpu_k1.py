@@ -36,7 +36,7 @@ def test_k1_reference_fixed_crops(oracle, batch):
     """cfg #2(a): 4K frame, 60x120 crops at (i,i) -> 64x128, kernel-argument descriptors."""
     frame = H.random_u8((2160, 3840, 3))
     gpu, ref, name = run_both(oracle, frame, H.fixed_crops(batch), batch)
-    assert name.startswith("k1_u8c3_direct_reorder_mul_sub_div"), name
+    assert name.startswith("k1_u8c3_swap_mul_sub_div"), name
     H.assert_bit_exact(gpu, ref, "K1 fixed crops")
 
 

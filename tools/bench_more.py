@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Secondary benchmarks of BASELINE.md: cfg #3 (NV12 6K -> BGR float -> 1280x720 -> normalize -> split, one kernel)
+and cfg #4 (CircularTensor depth 16 of 1080p fp32 x3: push a frame with [resize+]normalize, shift 15 slots).
+Prints one JSON object per config: time per launch/update (HIP events), algorithmic bytes, GB/s, fraction of 8 TB/s."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from cvgpuspeedup_amd import workloads as W  # noqa: E402
+
+PEAK = 8000.0
+
+
+def events_time(fn, iters, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def cfg4(dev, iters, resize_from_4k=False):
+    Wd, Hd, B = 1920, 1080, 16
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard, Wd, Hd)
+    f = cvgs.CV_32FC3
+    src_wh = W.FRAME_4K if resize_from_4k else (Wd, Hd)
+    frames = [W.random_u8_torch((src_wh[1], src_wh[0], 3), 300 + i, dev) for i in range(8)]
+    s = torch.cuda.current_stream()
+    pw = [cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3])]
+    state = {"i": 0}
+
+    def update():
+        fr = frames[state["i"] % len(frames)]
+        state["i"] += 1
+        m = cvgs.GpuMat.from_tensor(fr, cvgs.CV_8UC3)
+        if resize_from_4k:
+            ct.update(s, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, m, (Wd, Hd)), *pw, ct.write_split(f))
+        else:
+            ct.update(s, m, cvgs.convertTo(cvgs.CV_8UC3, f), *pw, ct.write_split(f))
+
+    t = events_time(update, iters)
+    plane = Wd * Hd * 3 * 4
+    # read = src_frame_bytes + (B-1)*P, write = B*P + P(ring); 4K->1080p taps every source pixel
+    src = src_wh[0] * src_wh[1] * 3
+    alg = src + (B - 1) * plane + B * plane + plane
+    ct.release()
+    return {"config": "cfg4 CircularTensor depth 16, 1080p fp32 x3, push %s" % (
+                "4K->1080p resize+normalize" if resize_from_4k else "1080p convert+normalize"),
+            "us_per_update": round(t * 1e6, 2), "algorithmic_bytes": alg, "GB_per_s": round(alg / t / 1e9, 1),
+            "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4), "updates_per_s": round(1 / t, 1)}
+
+
+def cfg3(dev, iters):
+    w, h = W.FRAME_6K
+    dst = (1280, 720)
+    bufs = [W.random_u8_torch((h + h // 2, w), 500 + i, dev) for i in range(6)]
+    outs = [torch.zeros((1, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev) for _ in range(6)]
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    chains, ops = [], None
+    for b, o in zip(bufs, outs):
+        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, b.data_ptr(), w, owner=b)
+        ops = [cvgs.read_nv12(luma, dst, capi.YUV_FULL, capi.BT709, False), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
+               cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3]),
+               cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), dst)]
+        chains.append(cvgs.lower(ops))
+    lib = capi.load_library()
+    state = {"i": 0}
+
+    def launch():
+        ch = chains[state["i"] % len(chains)]
+        state["i"] += 1
+        capi.check(lib.cvgs_execute(C.byref(ch.desc), s.cuda_stream))
+
+    t = events_time(launch, iters)
+    write = dst[0] * dst[1] * 3 * 4
+    # scale 4.8: every output pixel taps 4 distinct luma bytes and up to 4 distinct UV pairs (SURVEY.md 8d bound)
+    read = dst[0] * dst[1] * 4 + dst[0] * dst[1] * 2 * 4
+    alg = write + read
+    return {"config": "cfg3 NV12 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, one kernel",
+            "kernel": cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
+            "GB_per_s": round(alg / t / 1e9, 1), "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4),
+            "output_Mpix_per_s": round(dst[0] * dst[1] / t / 1e6, 1), "source_Mpix_per_s": round(w * h / t / 1e6, 1)}
+
+
+def run_all(dev, iters=100, only=""):
+    res = []
+    if only in ("", "cfg4"):
+        res.append(cfg4(dev, iters, False))
+        res.append(cfg4(dev, iters, True))
+    if only in ("", "cfg3"):
+        res.append(cfg3(dev, iters))
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.cuda.set_stream(torch.cuda.Stream())
+    for r in run_all(dev, a.iters, a.only):
+        print(json.dumps(r))

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Known-byte-count launches for calibrating rocprofv3 FETCH_SIZE / WRITE_SIZE on OUR access pattern
+(MI355X_MICROARCH.md, HBM section: FETCH_SIZE halves wide 16 B/lane streams on gfx950; other widths must be
+calibrated before an absolute is trusted).
+
+Launch A (K1 pattern: 8 B/lane unaligned taps, 4 B/lane planar nt stores): identity-scale K1 over FOUR whole 4K
+frames -> every source byte is tapped exactly once per output row pair, so the HBM read volume is the frames'
+bytes (4 x 24,883,200 B, + <= 1/16 for the row each 16-row tile shares with its neighbour), the write volume
+4 x 99,532,800 B.
+Launch B (K9 pattern: 16 B/lane streaming copy): the CircularTensor plane copy of 16 planes of 24,883,200 B.
+
+Run under:  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python tools/calibrate_pmc.py
+            rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python tools/calibrate_pmc.py
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from cvgpuspeedup_amd import cvgs  # noqa: E402
+from cvgpuspeedup_amd import workloads as W  # noqa: E402
+
+dev = torch.device("cuda:0")
+fw, fh = W.FRAME_4K
+N = 4
+frames = [W.random_u8_torch((fh, fw, 3), 99 + i, dev) for i in range(N)]
+out = torch.zeros((N, 3 * fw * fh), dtype=torch.float32, device=dev)
+mats = [cvgs.GpuMat.from_tensor(f, cvgs.CV_8UC3) for f in frames]
+f3 = cvgs.CV_32FC3
+ops = [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, mats, (fw, fh), N), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f3),
+       cvgs.multiply(f3, [W.K1_ALPHA] * 3), cvgs.subtract(f3, W.K1_SUB[3]), cvgs.divide(f3, W.K1_DIV[3]),
+       cvgs.split(f3, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (fw, fh))]
+s = torch.cuda.current_stream()
+for _ in range(6):
+    cvgs.executeOperations(s, *ops)
+torch.cuda.synchronize()
+print("A: K1 identity over %d frames: read >= %d B (frames), write %d B per launch; kernel %s" % (
+    N, N * fw * fh * 3, N * fw * fh * 12, cvgs.kernel_name(*ops)))
+
+ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, 16, cvgs.NewestFirst, cvgs.Standard, 1920, 1080)
+frame = W.random_u8_torch((1080, 1920, 3), 7, dev)
+for _ in range(6):
+    ct.update(s, cvgs.GpuMat.from_tensor(frame, cvgs.CV_8UC3), cvgs.convertTo(cvgs.CV_8UC3, f3), ct.write_split(f3))
+torch.cuda.synchronize()
+plane = 1920 * 1080 * 4
+print("B: K9 update: copy kernel moves 48 planes of %d B: read %d B, write %d B per launch" % (plane, 48 * plane, 48 * plane))

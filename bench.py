@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from cvgpuspeedup_amd import capi, cvgs, sharding  # noqa: E402
 from cvgpuspeedup_amd import workloads as W  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (testing)")
     return p.parse_args()
 
 
@@ -177,15 +178,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    if world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
@@ -198,36 +203,52 @@ def main():
     n_frames = a.frames or max(8, (2 * INFINITY_CACHE + per_frame_bytes - 1) // per_frame_bytes + 1)
 
     out_all = None
-    if world > 1:
+    if use_dist:
+        # the full [world*n, C*H*W] tensor of every in-flight step; rank r's K1 writes rows [r*n, (r+1)*n)
         out_all = [torch.zeros((world * n, plane), dtype=torch.float32, device=dev) for _ in range(n_frames)]
     wl = Workload(dev, n_frames, n, rank, world, a.table, out_all=out_all)
 
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
 
-    if world == 1:
-        step_fn_graph = None
+    if not use_dist:
         plan = None if a.eager else make_graphs(wl, a.steps)
-        warm = None if a.eager else make_graphs(wl, a.warmup) if a.warmup else []
+        warm = None if a.eager else (make_graphs(wl, a.warmup) if a.warmup else [])
         run_steps(wl, a.warmup, a.eager, warm)
         wall, dev_s = timed(lambda: run_steps(wl, a.steps, a.eager, plan), barrier)
         gather_note = None
     else:
-        # K1 into this rank's slice, then the in-place all-gather of the step's tensor (RCCL over xGMI)
+        # Per step: K1 into this rank's slice of the step's tensor, then the in-place all-gather (RCCL over xGMI)
+        # that assembles it on every rank.  The collective runs asynchronously on RCCL's stream, so the K1 of the
+        # following steps overlaps it; a buffer is only rewritten after the gather that last used it has completed.
         s = torch.cuda.current_stream().cuda_stream
+        works = [None] * n_frames
 
         def step(i):
+            j = i % n_frames
+            if works[j] is not None:
+                works[j].wait()  # current stream waits for the collective that read buffer j
             wl.launch(i, s)
-            full = out_all[i % n_frames]
-            dist.all_gather_into_tensor(full, full[rank * n:(rank + 1) * n])
+            works[j] = sharding_gather(out_all[j], world * n, dist)
+
+        def sharding_gather(full, items, d):
+            lo, hi = sharding.shard_bounds(items, world, rank)
+            return d.all_gather_into_tensor(full, full[lo:hi], async_op=True)
+
+        def drain():
+            for w in works:
+                if w is not None:
+                    w.wait()
 
         for i in range(a.warmup):
             step(i)
-        wall, dev_s = timed(lambda: [step(i) for i in range(a.steps)], barrier)
+        drain()
+        wall, dev_s = timed(lambda: ([step(i) for i in range(a.steps)], drain()), barrier)
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-        gather_note = "in-place all_gather_into_tensor of %d x %d B per step" % (world, n * plane * 4)
+        gather_note = "in-place all_gather_into_tensor of %d x %d B per step, overlapped with the next steps' K1" % (
+            world, n * plane * 4)
 
     px_per_step = n * W.DST[0] * W.DST[1] * world
     value = px_per_step * a.steps / wall / 1e6
@@ -250,30 +271,35 @@ def main():
                    "chain": "resize(bilinear) -> RGB2BGR -> x0.3 -> -(1,4,3.2) -> /(3.2,0.6,11.8) -> TensorSplit",
                    "crops_per_launch": n, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
                    "descriptors": "device table" if a.table else "kernel arguments",
-                   "submission": "eager" if a.eager else "hipGraph replay (256-launch graphs)",
+                   "submission": ("eager, one K1 launch + one all-gather per step" if use_dist else
+                                  ("eager" if a.eager else "hipGraph replay (256-launch graphs)")),
                    "parallelism": "1 process per GPU, crop lists sharded, %s" % (gather_note or "no collective")},
     }
 
     if rank == 0:
         alg = algorithmic_bytes(wl)
-        if world == 1:
+        if not use_dist:
             k_s = dev_s / a.steps  # HIP events on the launch stream over the timed region / K launches
         else:
-            # time K1 alone with event pairs on the launch stream (the timed region interleaves the gathers)
-            e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+            # K1 alone, serialized on the launch stream (the timed region interleaves the gathers): 256 launches
+            # between one pair of HIP events, same method as the single-GPU leg
             s = torch.cuda.current_stream().cuda_stream
-            for i, (e0, e1) in enumerate(e):
-                e0.record()
+            for i in range(32):
                 wl.launch(i, s)
-                e1.record()
             torch.cuda.synchronize()
-            k_s = float(np.mean([e0.elapsed_time(e1) for e0, e1 in e])) * 1e-3
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(256):
+                wl.launch(i, s)
+            e1.record()
+            torch.cuda.synchronize()
+            k_s = e0.elapsed_time(e1) * 1e-3 / 256
         achieved = alg / k_s / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                               "kernel": wl.kernel, "kernel_us": round(k_s * 1e6, 3),
                               "algorithmic_bytes_per_launch": int(alg)}
-    if world > 1:
+    if use_dist:
         barrier()
     if rank == 0 and world == 1 and not a.no_cpu:
         result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)

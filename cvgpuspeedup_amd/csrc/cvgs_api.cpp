@@ -317,6 +317,11 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         rc = launch_k1(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
         if (rc == 1) return CVGS_OK;
+        int min_w = 1 << 30;
+        for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
+        rc = launch_nv12(L.args, inline_planes, n_inline, min_w, stream, dry_run, info);
+        if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
+        if (rc == 1) return CVGS_OK;
     }
     rc = launch_generic(L.args, inline_planes, n_inline, stream, dry_run, info);
     if (rc) return fail(CVGS_ERR_HIP, "generic kernel launch failed");

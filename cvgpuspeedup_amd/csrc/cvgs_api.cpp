@@ -322,6 +322,9 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         rc = launch_nv12(L.args, inline_planes, n_inline, min_w, stream, dry_run, info);
         if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
         if (rc == 1) return CVGS_OK;
+        rc = launch_pointwise(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
+        if (rc < 0) return fail(CVGS_ERR_HIP, "pointwise kernel launch failed");
+        if (rc == 1) return CVGS_OK;
     }
     rc = launch_generic(L.args, inline_planes, n_inline, stream, dry_run, info);
     if (rc) return fail(CVGS_ERR_HIP, "generic kernel launch failed");

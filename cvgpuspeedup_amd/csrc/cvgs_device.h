@@ -105,6 +105,10 @@ int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline
 int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, void* stream,
                 bool dry_run, LaunchInfo* info);
 
+// Thread-fused pointwise chains on u8 sources (4 pixels per thread) -> fp32 planar / packed.
+int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
+                     bool dry_run, LaunchInfo* info);
+
 // experimental K1 variants (k_k1_exp.hip), selected by bits 8..15 of the chain flags; A/B benchmarking only
 int launch_k1_exp(int variant, const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream);
 const char* k1_exp_name(int variant);

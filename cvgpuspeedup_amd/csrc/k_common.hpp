@@ -148,6 +148,20 @@ struct InterpProg {
     static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
         for (int k = 0; k < prog.n; ++k) apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], p, depth, cn);
     }
+    // four pixels at once: the opcode loop stays outermost so the pixel array is only indexed by constants
+    static __device__ __forceinline__ void run4(const ProgArgs& prog, Px (&px)[4], int& depth, int& cn) {
+        for (int k = 0; k < prog.n; ++k) {
+            int d = depth, c = cn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d = depth;
+                c = cn;
+                apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], px[i], d, c);
+            }
+            depth = d;
+            cn = c;
+        }
+    }
 };
 
 // Compile-time program: the opcode list is a template pack (operands stay run-time), so the chain
@@ -157,6 +171,17 @@ struct StaticProg {
     static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
         int k = 0;
         ((apply_op(OPS, prog.aux[k], prog.operand[k], p, depth, cn), ++k), ...);
+    }
+    static __device__ __forceinline__ void run4(const ProgArgs& prog, Px (&px)[4], int& depth, int& cn) {
+        int d = depth, c = cn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d = depth;
+            c = cn;
+            run(prog, px[i], d, c);
+        }
+        depth = d;
+        cn = c;
     }
 };
 

@@ -209,3 +209,44 @@ def test_batch_pixel_read_default_value():
     gpu, ref = _both(build, (6, 40 * 30, 3), np.float32)
     H.assert_bit_exact(gpu[0], ref[0], "activeBatch/default")
     assert (gpu[0][4:] == np.array([4.5, 4.0, 3.5], np.float32)).all()
+
+
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+@pytest.mark.parametrize("write_kind", ["write2d", "write3d", "split", "splitT"])
+def test_thread_fused_pointwise_kernel(cn, write_kind):
+    """The 4-pixels-per-thread kernel (u8 -> fp32): odd widths (tail lanes), pitched views, batches with default-value
+    planes, packed and planar outputs -- bit-exact vs the oracle AND vs the interpreted kernel."""
+    w, h, n = 77, 19, (1 if write_kind == "write2d" else 5)
+    srcs = [_random_src((h + 3, w + 9, cn), "8U", 900 + 10 * cn + i) for i in range(n)]
+    stype, ftype = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+
+    def build(wrap, wrap_out, out):
+        mats = [wrap(s, stype).roi(5, 2, w, h) for s in srcs]
+        used = n if n == 1 else n - 2
+        rd = cvgs.ReadIOp(capi.READ_PIXEL, stype, mats, used, None, cvgs.IGNORE_AR, [9.0, 8.0, 7.0, 6.0][:cn])
+        ops = [rd, cvgs.convertTo(stype, ftype, 0.5), cvgs.subtract(ftype, H.K1_SUB[cn]), cvgs.divide(ftype, H.K1_DIV[cn])]
+        if write_kind == "write2d":
+            return ops + [cvgs.write(ftype, wrap_out(out, ftype))]
+        if write_kind == "write3d":
+            return ops + [cvgs.write(ftype, wrap_out(out, ftype), (w, h))]
+        o = wrap_out(out, cvgs.CV_32FC1)
+        if write_kind == "split":
+            return ops + [cvgs.split(ftype, o, (w, h))]
+        return ops + [cvgs.splitT(ftype, o.data, w, h, n, keep=o)]
+
+    shape = {"write2d": (h, w, cn), "write3d": (n, w * h, cn), "split": (n, cn * w * h), "splitT": (cn * n, w * h)}[write_kind]
+    gpu, ref = _both(build, shape, np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "thread-fused pointwise c%d %s" % (cn, write_kind))
+    gen, _ = _both(build, shape, np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gpu[0], gen[0], "fused vs interpreted")
+
+
+def test_thread_fused_kernel_is_selected():
+    frame = np.zeros((16, 32, 3), np.uint8)
+    out = np.zeros((16, 32, 3), np.float32)
+    f = cvgs.CV_32FC3
+    ops = [cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)], 1),
+           cvgs.convertTo(cvgs.CV_8UC3, f, 1.0), cvgs.subtract(f, [1, 2, 3]), cvgs.divide(f, [1, 2, 3]),
+           cvgs.write(f, cvgs.GpuMat.from_array(out, f))]
+    assert cvgs.kernel_name(*ops) == "pointwise4_u8_cast_mul_sub_div"
+    assert cvgs.kernel_name(*ops, flags=capi.CHAIN_NO_THREAD_FUSION).startswith("generic")

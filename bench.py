@@ -296,7 +296,7 @@ def main():
             k_s = e0.elapsed_time(e1) * 1e-3 / 256
         achieved = alg / k_s / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, a.table),
                               "kernel": wl.kernel, "kernel_us": round(k_s * 1e6, 3),
                               "algorithmic_bytes_per_launch": int(alg)}
     if use_dist:
@@ -310,6 +310,46 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(crops, table):
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    separate --pmc runs, corrected as calibrated in profiles/r01_b_pmc_hbm.txt).  Counters cannot be read from inside
+    this process, so the value is the one measured for exactly this workload/kernel; null for any other configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_headline.json")
+    if crops != CROPS or table or not os.path.exists(path):
+        return None
+    try:
+        j = json.load(open(path))
+        return int(j["fetch_size_kb"] * 1024 * j["fetch_correction"] + j["write_size_kb"] * 1024)
+    except Exception:
+        return None
+
+
+def multi_stream(dev, n_streams=4, per_stream=64, rounds=16):
+    """Independent batches submitted on several streams (one HIP graph with parallel branches): consecutive launches
+    of ONE stream are serialised by the queue's barrier bit, so a single stream pays the full launch/drain latency per
+    batch; independent streams overlap it.  Throughput only -- per-kernel durations stretch when kernels overlap."""
+    wl = Workload(dev, 24, CROPS, 0, 1, use_table=False)
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    for i in range(64):
+        wl.launch(i, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap = torch.cuda.current_stream()
+        for k, st in enumerate(streams):
+            st.wait_stream(cap)
+            with torch.cuda.stream(st):
+                for i in range(per_stream):
+                    wl.launch(k * per_stream + i, st.cuda_stream)
+        for st in streams:
+            cap.wait_stream(st)
+    g.replay()
+    wall, dev_s = timed(lambda: [g.replay() for _ in range(rounds)], lambda: None)
+    launches = n_streams * per_stream * rounds
+    return {"streams": n_streams, "us_per_batch": round(dev_s / launches * 1e6, 3),
+            "Mpix_per_s": round(CROPS * 8192 * launches / wall / 1e6, 1)}
 
 
 def extra_sweeps(dev, a):
@@ -338,6 +378,13 @@ def extra_sweeps(dev, a):
         wall, dev_s = timed(lambda: run_steps(wl, 2048, True), lambda: None)
         out["eager_50"] = {"Mpix_per_s": round(50 * 8192 * 2048 / wall / 1e6, 1), "us_per_step": round(wall / 2048 * 1e6, 3),
                            "note": "python ctypes + cvgs_execute + hipLaunchKernel per step (host-bound)"}
+        del wl
+        torch.cuda.empty_cache()
+        out["multi_stream_50"] = multi_stream(dev)
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_more
+        out["other_configs"] = bench_more.run_all(dev, iters=50)
     except Exception as ex:  # extras must never break the headline line
         out["error"] = repr(ex)
     return out

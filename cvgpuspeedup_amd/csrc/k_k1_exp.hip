@@ -346,6 +346,131 @@ static hipError_t v2launch(const ChainArgs& c, const PlaneParams* ip, int ni, hi
     return hipGetLastError();
 }
 
+// ---- LDS-staged variant (the north star's suggestion), for the A/B record --------------------------------------
+// Each wave stages the byte span of its source rows into its own LDS slots with coalesced dword loads
+// (lane i loads dword i, i+64, ...), then every lane reads its 2x2 taps from LDS.  No cross-wave sharing, so no
+// barrier; wave-local use of the LDS as a gather buffer.  Experimental limits: crops up to 512 px wide, and the
+// staged span is rounded out to whole dwords (may touch <= 3 bytes beyond the crop row inside the frame).
+constexpr int kLdsSlot = 1552; // 512 * 3 + 16
+
+template <int RPW, int STORE, int NPL>
+__global__ __launch_bounds__(256) void k1_lds(const KernArgs<NPL> a, const XGeom g) {
+    constexpr int CN = 3;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ChainArgs& c = a.c;
+    const ReadArgs& r = c.read;
+    const int z = (int)blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int x = lane;
+    const int row0 = ((int)blockIdx.x * 4 + wave) * RPW;
+    PlaneParams P;
+    if constexpr (NPL == 0) P = r.table[z];
+    else P = a.planes[z];
+    if (row0 >= r.dst_h) return;
+    const int W = c.write.width;
+    float* const out = (float*)c.write.data + (int64_t)z * g.img_stride;
+
+    const float sx = (float)x * P.fx;
+    const int x1 = (int)floorf(sx);
+    const int x2 = x1 + 1;
+    const float wxa = (float)x2 - sx, wxb = sx - (float)x1;
+    const bool edge = x2 > P.w - 1;
+    const int x2r = edge ? x1 : x2;
+    const gptr_u8 src = (gptr_u8)P.data;
+    // span of the row this wave needs: columns [0, last tap] (lane 0 taps column 0)
+    const int last_col = min((int)floorf((float)(min(r.dst_w, 64) - 1) * P.fx) + 1, P.w - 1);
+    const int span_bytes = (last_col + 1) * CN;
+    uint8_t* const my = smem + (size_t)wave * (2 * RPW) * kLdsSlot;
+
+    float wya[RPW], wyb[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int y = min(row0 + j, r.dst_h - 1);
+        const float sy = (float)y * P.fy;
+        const int y1 = (int)floorf(sy);
+        const int y2r = min(y1 + 1, P.h - 1);
+        wya[j] = (float)(y1 + 1) - sy;
+        wyb[j] = sy - (float)y1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const gptr_u8 row = src + (size_t)__builtin_amdgcn_readfirstlane(t ? y2r : y1) * (size_t)P.step;
+            const uint32_t mis = (uint32_t)((uintptr_t)row & 3u);   // stage from the dword that contains byte 0
+            const __attribute__((address_space(1))) uint32_t* g32 = (const __attribute__((address_space(1))) uint32_t*)(row - mis);
+            uint32_t* l32 = (uint32_t*)(my + (size_t)(2 * j + t) * kLdsSlot);
+            const int n_dw = (int)(mis + span_bytes + 3) >> 2;
+            for (int i = lane; i < n_dw; i += 64) l32[i] = g32[i];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int y = row0 + j;
+        if (y < r.dst_h) {
+            float p00[3], p10[3], p01[3], p11[3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int yy = (int)floorf((float)min(y, r.dst_h - 1) * P.fy);
+                const int ysel = t ? min(yy + 1, P.h - 1) : yy;
+                const gptr_u8 row = src + (size_t)__builtin_amdgcn_readfirstlane(ysel) * (size_t)P.step;
+                const uint32_t mis = (uint32_t)((uintptr_t)row & 3u);
+                const uint8_t* l = my + (size_t)(2 * j + t) * kLdsSlot + mis;
+                float* pa = t ? p01 : p00;
+                float* pb = t ? p11 : p10;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pa[k] = (float)l[x1 * CN + k];
+                    pb[k] = (float)l[x2r * CN + k];
+                }
+            }
+            const float w00 = wxa * wya[j], w10 = wxb * wya[j], w01 = wxa * wyb[j], w11 = wxb * wyb[j];
+            Px p;
+            p.v[3] = 0.f;
+#pragma unroll
+            for (int k = 0; k < CN; ++k) {
+                float acc = p00[k] * w00;
+                acc = acc + p10[k] * w10;
+                acc = acc + p01[k] * w01;
+                acc = acc + p11[k] * w11;
+                p.v[k] = acc;
+            }
+            int depth = CVGS_DEPTH_32F, cn = CN;
+            ProgRMSD::run(c.prog, p, depth, cn);
+            float* const orow = out + (int64_t)y * W;
+#pragma unroll
+            for (int k = 0; k < CN; ++k) st<STORE>(orow + (int64_t)k * g.ch_stride + x, p.v[k]);
+        }
+    }
+}
+
+template <int RPW, int STORE>
+static hipError_t ldslaunch(const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+    XGeom g;
+    const int rows_per_wg = 4 * RPW;
+    g.col_tiles = 1;
+    const uint32_t row_tiles = (uint32_t)((c.read.dst_h + rows_per_wg - 1) / rows_per_wg);
+    g.tiles_per_plane = row_tiles;
+    g.total_tiles = row_tiles * (uint32_t)c.read.batch;
+    g.padded_tiles = g.total_tiles;
+    g.img_stride = c.write.img_stride;
+    g.ch_stride = c.write.ch_stride;
+    const dim3 grid(row_tiles, c.read.batch);
+    const size_t shmem = (size_t)4 * 2 * RPW * kLdsSlot;
+    if (c.read.table) {
+        KernArgs<0> a;
+        a.c = c;
+        a.planes[0] = PlaneParams{};
+        hipLaunchKernelGGL((k1_lds<RPW, STORE, 0>), grid, dim3(256), shmem, s, a, g);
+    } else {
+        KernArgs<CVGS_KERNARG_PLANES> a;
+        a.c = c;
+        for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
+        hipLaunchKernelGGL((k1_lds<RPW, STORE, CVGS_KERNARG_PLANES>), grid, dim3(256), shmem, s, a, g);
+    }
+    return hipGetLastError();
+}
+
 const char* k1_exp_name(int v) {
     static const char* names[] = {"", "t256_r1", "t256_r2", "t256_r4", "t128_r1", "t64_r1", "t64_r2", "t64_r4",
                                   "t256_r1_nt", "t256_r1_sc1", "t256_r2_nt", "t256_r1_noremap", "t256_r1_NOLOAD",
@@ -354,7 +479,7 @@ const char* k1_exp_name(int v) {
                                   "v2_t256_r1", "v2_t256_r1_nt", "v2_t256_r2_nt", "v2_t256_r4_nt", "v2_t64_r1_nt", "v2_t256_r4",
                                   "v2_t128_r1_nt", "v2_t256_r8_nt", "v2_t512_r1_nt", "v2_t1024_r1_nt", "t64_r1_EMPTY", "t1024_r1_EMPTY",
                                   "v2_t512_r2_nt", "v2_t1024_r2_nt", "v2_t256_r1_nt_NODIV", "v2_t256_r4_nt_NODIV", "v2_t256_r1_nt_NOARITH",
-                                  "v2_t256_r4_nt_NOARITH", "t256_r4_EMPTY", "t256_r4_COMPUTE", "t256_r4_NOLOAD", "t256_r4_NOSTORE"};
+                                  "v2_t256_r4_nt_NOARITH", "t256_r4_EMPTY", "t256_r4_COMPUTE", "t256_r4_NOLOAD", "t256_r4_NOSTORE", "lds_r1_nt", "lds_r2_nt", "lds_r4_nt"};
     return (v > 0 && v < (int)(sizeof(names) / sizeof(names[0]))) ? names[v] : nullptr;
 }
 
@@ -405,6 +530,9 @@ int launch_k1_exp(int variant, const ChainArgs& c, const PlaneParams* ip, int ni
     case 41: e = xlaunch<256, 4, ST_PLAIN, true, MODE_COMPUTE>(c, ip, ni, s); break;
     case 42: e = xlaunch<256, 4, ST_PLAIN, true, MODE_NOLOAD>(c, ip, ni, s); break;
     case 43: e = xlaunch<256, 4, ST_PLAIN, true, MODE_NOSTORE>(c, ip, ni, s); break;
+    case 44: e = ldslaunch<1, ST_NT>(c, ip, ni, s); break;
+    case 45: e = ldslaunch<2, ST_NT>(c, ip, ni, s); break;
+    case 46: e = ldslaunch<4, ST_NT>(c, ip, ni, s); break;
     default: return -1;
     }
     return e == hipSuccess ? 1 : -(int)e - 1000;

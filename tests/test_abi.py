@@ -143,3 +143,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         capi.load_library()
+
+
+def test_rccl_library_exports_every_declared_symbol():
+    from cvgpuspeedup_amd import rccl
+    src = open(os.path.join(ROOT, "include", "cvgs_rccl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(cvgs_[a-z0-9_]+)\s*\(", src)))
+    lib = rccl.load_library()
+    bound = {s[0] for s in rccl.SYMBOLS}
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in bound, n

@@ -67,7 +67,7 @@ class ReadDesc(C.Structure):
 
 
 class Op(C.Structure):
-    _fields_ = [("opcode", C.c_int32), ("aux", C.c_int32), ("operand", C.c_float * 4)]
+    _fields_ = [("opcode", C.c_int32), ("aux", C.c_int32), ("operand", C.c_float * 4), ("operand_d", C.c_double * 4)]
 
 
 class WriteDesc(C.Structure):

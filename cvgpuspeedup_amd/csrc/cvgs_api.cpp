@@ -70,6 +70,8 @@ void plane_geometry(int sw, int sh, int dw, int dh, int ar, PlaneParams& P) {
 
 struct Lowered {
     ChainArgs args{};
+    Prog64Args p64{};
+    bool uses_64f = false;
     std::vector<PlaneParams> planes;  // host copy (inline or to upload)
     std::vector<DstPlane> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
     int out_w = 0, out_h = 0;
@@ -85,12 +87,11 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
         case CVGS_OP_NOP: break;
         case CVGS_OP_CAST:
             if (op.aux < CVGS_DEPTH_8U || op.aux > CVGS_DEPTH_64F) return fail(CVGS_ERR_INVALID, "CAST: bad destination depth");
-            if (op.aux == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "CAST: 64F is not supported yet");
             depth = op.aux;
             break;
         case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
-            if (depth != CVGS_DEPTH_32F)
-                return fail(CVGS_ERR_UNSUPPORTED, "arithmetic stages are implemented for CV_32F values only");
+            if (depth != CVGS_DEPTH_32F && depth != CVGS_DEPTH_64F)
+                return fail(CVGS_ERR_UNSUPPORTED, "arithmetic stages are implemented for CV_32F / CV_64F values only");
             break;
         case CVGS_OP_REORDER:
             for (int c = 0; c < cn; ++c)
@@ -106,7 +107,7 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
             break;
         case CVGS_OP_GRAY:
             if (cn < 3) return fail(CVGS_ERR_INVALID, "GRAY needs a 3- or 4-channel value");
-            if (depth == CVGS_DEPTH_32S) return fail(CVGS_ERR_UNSUPPORTED, "GRAY on CV_32S");
+            if (depth == CVGS_DEPTH_32S || depth == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "GRAY on CV_32S / CV_64F");
             cn = 1;
             break;
         default: return fail(CVGS_ERR_INVALID, "unknown opcode");
@@ -129,7 +130,8 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (!rd.src) return fail(CVGS_ERR_INVALID, "read.src is null");
     const int sdepth = CVGS_TYPE_DEPTH(rd.src_type), scn = CVGS_TYPE_CN(rd.src_type);
     if (sdepth > CVGS_DEPTH_64F || scn > 4) return fail(CVGS_ERR_INVALID, "bad source type");
-    if (sdepth == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "CV_64F sources are not supported yet");
+    if (sdepth == CVGS_DEPTH_64F && rd.kind != CVGS_READ_PIXEL)
+        return fail(CVGS_ERR_UNSUPPORTED, "CV_64F sources are supported for per-pixel reads only");
     if (is_nv12(rd.kind) && rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
         return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
     if (is_resize(rd.kind)) {
@@ -200,13 +202,18 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         if (ch->ops[k].opcode == CVGS_OP_NOP) continue;
         Pg.opcode[n] = ch->ops[k].opcode;
         Pg.aux[n] = ch->ops[k].aux;
-        for (int c = 0; c < 4; ++c) Pg.operand[n][c] = ch->ops[k].operand[c];
+        for (int c = 0; c < 4; ++c) {
+            Pg.operand[n][c] = ch->ops[k].operand[c];
+            L.p64.operand[n][c] = ch->ops[k].operand_d[c];
+        }
+        if (ch->ops[k].opcode == CVGS_OP_CAST && ch->ops[k].aux == CVGS_DEPTH_64F) L.uses_64f = true;
         ++n;
     }
     Pg.n = n;
     const int d0 = (R.is_resize || is_nv12(rd.kind)) ? CVGS_DEPTH_32F : sdepth;
     int rc = walk_program(ch, d0, R.out_cn, &L.final_depth, &L.final_cn);
     if (rc) return rc;
+    if (sdepth == CVGS_DEPTH_64F || L.final_depth == CVGS_DEPTH_64F) L.uses_64f = true;
 
     // ---- write stage ----
     if (wr.kind < CVGS_WRITE_PIXEL_2D || wr.kind > CVGS_WRITE_PIXEL_2D_BATCH) return fail(CVGS_ERR_INVALID, "bad write kind");
@@ -282,7 +289,8 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
     AsyncTable src_tab, dst_tab;
     const PlaneParams* inline_planes = L.planes.data();
     int n_inline = (int)L.planes.size();
-    if (!L.args.read.table && n_inline > CVGS_KERNARG_PLANES) {
+    const int inline_cap = L.uses_64f ? kInline64 : CVGS_KERNARG_PLANES;
+    if (!L.args.read.table && n_inline > inline_cap) {
         if (!dry_run) {
             int rc = src_tab.upload(L.planes.data(), L.planes.size() * sizeof(PlaneParams), stream);
             if (rc) return rc;
@@ -303,6 +311,11 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         }
     }
     int rc = 0;
+    if (L.uses_64f) {
+        rc = launch_generic64(L.args, L.p64, inline_planes, n_inline, stream, dry_run, info);
+        if (rc) return fail(CVGS_ERR_HIP, "generic64 kernel launch failed");
+        return CVGS_OK;
+    }
     const int exp_variant = (int)((ch->flags >> 8) & 0xff);
     if (exp_variant && k1_exp_name(exp_variant) && L.args.read.kind == CVGS_READ_RESIZE_LINEAR && L.args.read.depth == CVGS_DEPTH_8U &&
         L.args.read.cn == 3 && L.args.prog.n == 4 && L.args.write.depth == CVGS_DEPTH_32F &&

@@ -87,6 +87,24 @@ struct KernArgs<0> {
 };
 static_assert(sizeof(KernArgs<CVGS_KERNARG_PLANES>) <= 4096, "kernel-argument block must fit 4 KB");
 
+// CV_64F chains: the double operands travel next to the float ones, with a small inline plane block.
+struct Prog64Args {
+    double operand[CVGS_MAX_OPS][4];
+};
+template <int NPLANES>
+struct KernArgs64 {
+    ChainArgs c;
+    Prog64Args p64;
+    PlaneParams planes[NPLANES];
+};
+template <>
+struct KernArgs64<0> {
+    ChainArgs c;
+    Prog64Args p64;
+    PlaneParams planes[1];
+};
+static constexpr int kInline64 = 8;
+
 // ---- launch entry points implemented in the .hip files -----------------------------------------
 struct LaunchInfo {
     const char* kernel; // name of the kernel variant chosen
@@ -100,6 +118,10 @@ int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_i
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
 int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
               void* stream, bool dry_run, LaunchInfo* info);
+
+// interpreted kernel for chains that touch CV_64F
+int launch_generic64(const ChainArgs& c, const Prog64Args& p64, const PlaneParams* inline_planes, int n_inline, void* stream,
+                     bool dry_run, LaunchInfo* info);
 
 // K4 fast path: NV12 read-back fused into the bilinear resize -> program -> planar fp32 tensor or packed pixels.
 int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, void* stream,

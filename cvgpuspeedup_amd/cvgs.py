@@ -8,6 +8,7 @@ builder returns a small IOp object, executeOperations() lowers the list to ONE c
 calls cvgs_execute() -> one HIP kernel.  Nothing here computes pixels.
 """
 import ctypes as C
+import struct
 
 from . import capi
 from .capi import (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S, DEPTH_32F, DEPTH_64F, make_type,
@@ -164,10 +165,11 @@ def convertTo(in_type, out_type, alpha=None, beta=None):
     if alpha is None:
         return PointwiseIOp(in_type, out_type, [(capi.OP_CAST, od, None)])
     integral = od in (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S)
-    mid = DEPTH_32F if integral else od
-    ops = [(capi.OP_CAST, mid, None), (capi.OP_MUL, 0, [float(alpha)] * 4)]
+    mid = DEPTH_32F if integral else od  # float for integral outputs, the output type (32F / 64F) otherwise
+    f32 = lambda v: struct.unpack("f", struct.pack("f", float(v)))[0]  # the reference's parameters are `float`
+    ops = [(capi.OP_CAST, mid, None), (capi.OP_MUL, 0, [f32(alpha)] * 4)]
     if beta is not None:
-        ops.append((capi.OP_ADD, 0, [float(beta)] * 4))
+        ops.append((capi.OP_ADD, 0, [f32(beta)] * 4))
     if integral:
         ops.append((capi.OP_CAST, od, None))
     return PointwiseIOp(in_type, out_type, ops)
@@ -323,6 +325,7 @@ def lower(iops, flags=0):
             ch.ops[n].opcode, ch.ops[n].aux = opcode, aux
             for i in range(4):
                 ch.ops[n].operand[i] = operand[i] if operand is not None else 0.0
+                ch.ops[n].operand_d[i] = operand[i] if operand is not None else 0.0
             n += 1
         cur = iop.out_type
     ch.n_ops = n

@@ -63,7 +63,7 @@ inline auto convertToScaled(float alpha, const float* beta) {
     fk::ChainBuilder b;
     b.op(CVGS_OP_CAST, mid);
     const float a[4] = {alpha, alpha, alpha, alpha};
-    b.op(CVGS_OP_MUL, 0, a);
+    b.op(CVGS_OP_MUL, 0, a); // operand_d follows as (double)alpha: fk::make_set<FloatType>(alpha) on CV_64F outputs
     if (beta) {
         const float bb[4] = {*beta, *beta, *beta, *beta};
         b.op(CVGS_OP_ADD, 0, bb);

@@ -40,6 +40,16 @@ template <typename V> inline V make_set(VBase<V> v) {
 }
 template <typename V, typename... A> inline V make_(A... a) { return V{static_cast<VBase<V>>(a)...}; }
 
+template <typename V> inline void vec_to_doubles(const V& v, double out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    if constexpr (cn<V> == 1) out[0] = (double)v;
+    else {
+        out[0] = (double)v.x; out[1] = (double)v.y;
+        if constexpr (cn<V> >= 3) out[2] = (double)v.z;
+        if constexpr (cn<V> >= 4) out[3] = (double)v.w;
+    }
+}
+
 template <typename V> inline void vec_to_floats(const V& v, float out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0.f;
     if constexpr (cn<V> == 1) out[0] = (float)v;
@@ -140,11 +150,14 @@ struct ChainBuilder {
     cvgs_chain_desc d;
     std::vector<cvgs_image2d> src, dst;
     ChainBuilder() { std::memset(&d, 0, sizeof(d)); d.struct_size = sizeof(d); }
-    void op(int opcode, int aux, const float* operand = nullptr) {
+    void op(int opcode, int aux, const float* operand = nullptr, const double* operand_d = nullptr) {
         if (d.n_ops >= CVGS_MAX_OPS) throw std::runtime_error("cvGS: too many pointwise operations in one chain");
         cvgs_op& o = d.ops[d.n_ops++];
         o.opcode = opcode; o.aux = aux;
-        for (int i = 0; i < 4; ++i) o.operand[i] = operand ? operand[i] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            o.operand[i] = operand ? operand[i] : 0.f;
+            o.operand_d[i] = operand_d ? operand_d[i] : (operand ? (double)operand[i] : 0.0);
+        }
     }
     void finish() {
         if (!src.empty() && !(d.read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE)) d.read.src = src.data();
@@ -200,7 +213,7 @@ template <typename I, typename O> struct PointwiseSeq {
     using OutputType = O;
     static constexpr Stage stage = Stage::Pointwise;
     std::vector<cvgs_op> ops;
-    void lower(ChainBuilder& b) const { for (const auto& o : ops) b.op(o.opcode, o.aux, o.operand); }
+    void lower(ChainBuilder& b) const { for (const auto& o : ops) b.op(o.opcode, o.aux, o.operand, o.operand_d); }
     template <typename Next> auto then(const Next& n) const {
         static_assert(std::is_same_v<O, typename Next::InputType>, "then(): types do not chain");
         PointwiseSeq<I, typename Next::OutputType> r;
@@ -301,7 +314,7 @@ template <typename I, typename O> struct SaturateCast {
 #define CVGS_FK_BINARY(NAME, OPC)                                                           \
     template <typename T> struct NAME {                                                     \
         using InputType = T; using OutputType = T; using ParamsType = T;                    \
-        static void lower(const T& v, ChainBuilder& b) { float f[4]; vec_to_floats(v, f); b.op(OPC, 0, f); } \
+        static void lower(const T& v, ChainBuilder& b) { float f[4]; double d[4]; vec_to_floats(v, f); vec_to_doubles(v, d); b.op(OPC, 0, f, d); } \
     };
 CVGS_FK_BINARY(Mul, CVGS_OP_MUL)
 CVGS_FK_BINARY(Add, CVGS_OP_ADD)

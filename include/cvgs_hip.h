@@ -124,7 +124,8 @@ typedef enum cvgs_opcode {
     CVGS_OP_CAST = 1,
     /* fk::Binary<fk::Mul/Add/Sub/Div<T>> (cvGS::multiply/add/subtract/divide,
      * cvGPUSpeedup.cuh:131-149); operand[c] = static_cast<float>(cv::Scalar[c])
-     * (cvGPUSpeedupHelpers.cuh:38-54).  IEEE fp32, applied in call order, never merged.       */
+     * (cvGPUSpeedupHelpers.cuh:38-54), operand_d[c] = the cv::Scalar value itself for CV_64F
+     * types.  IEEE fp32 (fp64 on CV_64F values), applied in call order, never merged.          */
     CVGS_OP_MUL = 2,
     CVGS_OP_ADD = 3,
     CVGS_OP_SUB = 4,
@@ -145,7 +146,8 @@ typedef enum cvgs_opcode {
 typedef struct cvgs_op {
     int32_t opcode;
     int32_t aux;
-    float operand[4];
+    float operand[4];    /* operand narrowed to float: used while the value is CV_32F (or an integer depth)   */
+    double operand_d[4]; /* the same operand in double: used by arithmetic stages on CV_64F values           */
 } cvgs_op;
 
 /* ---- write stage (last IOp of the chain) -------------------------------------------------- */

@@ -21,6 +21,7 @@
 typedef struct opx {
     float f[4];
     int32_t i[4];
+    double d[4]; /* CV_64F values */
     int depth;
     int cn;
 } opx;
@@ -63,12 +64,14 @@ static void load_pixel(const cvgs_image2d* im, int type, int x, int y, opx* p) {
         case CVGS_DEPTH_16S: p->f[c] = (float)((const int16_t*)row)[e]; break;
         case CVGS_DEPTH_32S: p->i[c] = ((const int32_t*)row)[e]; break;
         case CVGS_DEPTH_32F: p->f[c] = ((const float*)row)[e]; break;
+        case CVGS_DEPTH_64F: p->d[c] = ((const double*)row)[e]; break;
         default: p->f[c] = 0.f;
         }
     }
 }
 
 static float tap_as_float(const opx* p, int c) {
+    if (p->depth == CVGS_DEPTH_64F) return (float)p->d[c];
     return p->depth == CVGS_DEPTH_32S ? (float)p->i[c] : p->f[c];
 }
 
@@ -207,6 +210,7 @@ static void background_pixel(const cvgs_read_desc* rd, int depth, int cn, opx* p
     for (int c = 0; c < cn; ++c) {
         p->f[c] = rd->background[c];
         p->i[c] = (int32_t)rd->background[c];
+        p->d[c] = (double)rd->background[c];
     }
 }
 
@@ -269,17 +273,21 @@ static void op_cast(opx* p, int dst_depth) {
     int64_t lo, hi;
     int_range(dst_depth, &lo, &hi);
     for (int c = 0; c < p->cn; ++c) {
+        if (dst_depth == CVGS_DEPTH_64F) { /* every narrower type converts exactly */
+            p->d[c] = src_depth == CVGS_DEPTH_32S ? (double)p->i[c] : (double)p->f[c];
+            continue;
+        }
         if (dst_depth == CVGS_DEPTH_32F) {
-            p->f[c] = src_depth == CVGS_DEPTH_32S ? (float)p->i[c] : p->f[c];
+            p->f[c] = src_depth == CVGS_DEPTH_32S ? (float)p->i[c] : src_depth == CVGS_DEPTH_64F ? (float)p->d[c] : p->f[c];
             continue;
         }
         int64_t iv;
-        if (src_depth == CVGS_DEPTH_32F) {
-            const float v = p->f[c];
+        if (src_depth == CVGS_DEPTH_32F || src_depth == CVGS_DEPTH_64F) {
+            const double v = src_depth == CVGS_DEPTH_64F ? p->d[c] : (double)p->f[c];
             if (v != v) iv = 0;
-            else if (v >= 2147483648.0f) iv = INT32_MAX;
-            else if (v <= -2147483648.0f) iv = INT32_MIN;
-            else iv = (int64_t)nearbyintf(v); /* default rounding mode: nearest even */
+            else if (v >= 2147483648.0) iv = INT32_MAX;
+            else if (v <= -2147483649.0) iv = INT32_MIN;
+            else iv = (int64_t)nearbyint(v); /* default rounding mode: nearest even (exact for float inputs too) */
         } else if (src_depth == CVGS_DEPTH_32S) {
             iv = p->i[c];
         } else {
@@ -299,6 +307,7 @@ static void op_reorder(opx* p, int aux, int out_cn) {
         const int k = (aux >> (2 * c)) & 3;
         p->f[c] = s.f[k];
         p->i[c] = s.i[k];
+        p->d[c] = s.d[k];
     }
     p->cn = out_cn;
 }
@@ -311,6 +320,14 @@ static int apply_op(const cvgs_op* op, opx* p) {
     case CVGS_OP_NOP: return 0;
     case CVGS_OP_CAST: op_cast(p, op->aux); return 0;
     case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
+        if (p->depth == CVGS_DEPTH_64F) { /* fk::Mul/Add/Sub/Div<doubleN>: IEEE fp64 with the double operand */
+            for (int c = 0; c < p->cn; ++c) {
+                const double a = p->d[c], b = op->operand_d[c];
+                p->d[c] = op->opcode == CVGS_OP_MUL ? a * b : op->opcode == CVGS_OP_ADD ? a + b
+                        : op->opcode == CVGS_OP_SUB ? a - b : a / b;
+            }
+            return 0;
+        }
         if (p->depth != CVGS_DEPTH_32F) return CVGS_ERR_UNSUPPORTED;
         for (int c = 0; c < p->cn; ++c) {
             const float a = p->f[c], b = op->operand[c];
@@ -327,13 +344,14 @@ static int apply_op(const cvgs_op* op, opx* p) {
         op_reorder(p, op->aux, 3);
         p->f[3] = op->operand[0];
         p->i[3] = (int32_t)op->operand[0];
+        p->d[3] = (double)op->operand[0];
         p->cn = 4;
         return 0;
     case CVGS_OP_DROP_ALPHA: op_reorder(p, op->aux, 3); return 0;
     /* *2GRAY: CCIR 601 luma, KATs RGB(10,100,200) -> 84, BGR -> 120
      * (reference tests/color/test_cvtColor.cu:36,115-123). */
     case CVGS_OP_GRAY: {
-        if (p->depth == CVGS_DEPTH_32S) return CVGS_ERR_UNSUPPORTED;
+        if (p->depth == CVGS_DEPTH_32S || p->depth == CVGS_DEPTH_64F) return CVGS_ERR_UNSUPPORTED;
         const float r = p->f[op->aux & 3], g = p->f[(op->aux >> 2) & 3], b = p->f[(op->aux >> 4) & 3];
         float lum = (r * 0.299f + g * 0.587f) + b * 0.114f;
         if (p->depth != CVGS_DEPTH_32F) lum = nearbyintf(lum);
@@ -354,6 +372,7 @@ static void store_elem(void* base, size_t elem_index, int depth, const opx* p, i
     case CVGS_DEPTH_16S: ((int16_t*)base)[elem_index] = (int16_t)p->f[c]; break;
     case CVGS_DEPTH_32S: ((int32_t*)base)[elem_index] = p->i[c]; break;
     case CVGS_DEPTH_32F: ((float*)base)[elem_index] = p->f[c]; break;
+    case CVGS_DEPTH_64F: ((double*)base)[elem_index] = p->d[c]; break;
     }
 }
 
@@ -423,9 +442,6 @@ int oracle_execute(const cvgs_chain_desc* ch) {
     if (!ch || ch->struct_size != sizeof(cvgs_chain_desc)) return CVGS_ERR_INVALID;
     if (ch->n_ops < 0 || ch->n_ops > CVGS_MAX_OPS) return CVGS_ERR_INVALID;
     if (ch->read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) return CVGS_ERR_UNSUPPORTED;
-    if (CVGS_TYPE_DEPTH(ch->read.src_type) == CVGS_DEPTH_64F ||
-        CVGS_TYPE_DEPTH(ch->write.dst_type) == CVGS_DEPTH_64F)
-        return CVGS_ERR_UNSUPPORTED;
     int W, H;
     int rc = chain_extent(ch, &W, &H);
     if (rc) return rc;

@@ -129,6 +129,32 @@ for d, c in K5_PAIRS:
         "expected": chain_const(sat(K5_INIT[c], d), [("mul", [1.0] * c), ("sub", K5_SUB[c]), ("div", DIV[c])]),
         "source": "tests/batchread/test_batchread_x_write3D.cu:45-58,60-96,202-224"})
 
+# K5 on CV_64F outputs (test_batchread_x_write3D.cu:208-209,222-224): arithmetic in double
+for d, c, o in (("32F", 1, "64F"), ("64F", 1, "64F"), ("32F", 2, "64F"), ("32F", 3, "64F"), ("32F", 4, "64F")):
+    cases.append({
+        "name": "k5_%sC%d_to_%s" % (d, c, o), "src_type": "%sC%d" % (d, c), "frame": [60, 120], "init": K5_INIT[c],
+        "read": {"kind": "pixel_batch", "batch": 50},
+        "ops": [["convertTo_alpha", "%sC%d" % (o, c), 1.0], ["subtract", K5_SUB[c]], ["divide", DIV[c]]],
+        "write": "write3d", "out_type": "%sC%d" % (o, c), "tol": 1e-4, "no_thread_fusion": True,
+        "expected": chain_const(K5_INIT[c], [("mul", [1.0] * c), ("sub", K5_SUB[c]), ("div", DIV[c])]),
+        "source": "tests/batchread/test_batchread_x_write3D.cu:45-58,60-96,208-209,222-224"})
+
+# K6 / K7 on CV_32F -> CV_64F (test_read_x_write.cu:139-141, test_read_x_split.cu LAUNCH list)
+for c in (2, 3, 4):
+    sub = [0.3] * c
+    cases.append({
+        "name": "k6_32FC%d_to_64F" % c, "src_type": "32FC%d" % c, "frame": [3840, 2160], "init": K2_INIT[c],
+        "read": {"kind": "pixel_single"},
+        "ops": [["convertTo", "64FC%d" % c], ["subtract", sub], ["multiply", SUB[c]], ["divide", DIV[c]], ["add", DIV[c]]],
+        "write": "write2d", "out_type": "64FC%d" % c, "tol": 1e-4,
+        "expected": chain_const(K2_INIT[c], [("sub", sub), ("mul", SUB[c]), ("div", DIV[c]), ("add", DIV[c])]),
+        "source": "tests/read/test_read_x_write.cu:31-73,139-141"})
+    cases.append({
+        "name": "k7_32FC%d_to_64F" % c, "src_type": "32FC%d" % c, "frame": [3840, 2160], "init": K2_INIT[c],
+        "read": {"kind": "pixel_single"}, "ops": [["convertTo", "64FC%d" % c]], "write": "split_planes",
+        "out_type": "64FC%d" % c, "tol": 1e-4, "expected": [float(v) for v in K2_INIT[c]],
+        "source": "tests/read/test_read_x_split.cu:30-59"})
+
 # K6: read -> convertTo -> sub(0.3) -> mul -> div -> add(= the divide scalar) -> write 2D, 4K image
 for d, c in K5_PAIRS:
     sub = [0.3] * c

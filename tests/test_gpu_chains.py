@@ -250,3 +250,32 @@ def test_thread_fused_kernel_is_selected():
            cvgs.write(f, cvgs.GpuMat.from_array(out, f))]
     assert cvgs.kernel_name(*ops) == "pointwise4_u8_cast_mul_sub_div"
     assert cvgs.kernel_name(*ops, flags=capi.CHAIN_NO_THREAD_FUSION).startswith("generic")
+
+
+@pytest.mark.parametrize("src,cn", [("32F", 3), ("8U", 4), ("32S", 2), ("64F", 1), ("64F", 3)])
+def test_double_precision_chains(src, cn):
+    """CV_64F values: convertTo<I, CV_64F>(alpha, beta) then double arithmetic with non-float-representable scalars,
+    written as CV_64F and (after a second cast) as CV_32F / CV_16S.  Bit-exact vs the oracle."""
+    if src == "64F":
+        a = (H.random_u16((40, 50, cn), 77).astype(np.float64) / 7.0 - 3000.0)
+    else:
+        a = _random_src((40, 50, cn), src, 77)
+    stype = cvgs.make_type(K.CV_DEPTH[src], cn)
+    d, f, s16 = cvgs.make_type(cvgs.CV_64F, cn), cvgs.make_type(cvgs.CV_32F, cn), cvgs.make_type(cvgs.CV_16S, cn)
+    third = [1.0 / 3.0, 0.1, 2.0 / 7.0, 1e-3][:cn]
+
+    def build_for(out_kind):
+        def build(wrap, wrap_out, out):
+            rd = cvgs.ReadIOp(capi.READ_PIXEL, stype, [wrap(a, stype)], 1)
+            ops = [rd, cvgs.convertTo(stype, d, 0.3, 0.7), cvgs.subtract(d, third), cvgs.divide(d, [3.2, 0.6, 11.8, 33.0][:cn]),
+                   cvgs.multiply(d, third)]
+            if out_kind == "64F":
+                return ops + [cvgs.write(d, wrap_out(out, d))]
+            if out_kind == "32F":
+                return ops + [cvgs.convertTo(d, f), cvgs.add(f, [0.1] * cn), cvgs.write(f, wrap_out(out, f))]
+            return ops + [cvgs.convertTo(d, s16), cvgs.write(s16, wrap_out(out, s16))]
+        return build
+
+    for kind, dt in (("64F", np.float64), ("32F", np.float32), ("16S", np.int16)):
+        gpu, ref = _both(build_for(kind), (40, 50, cn), dt)
+        H.assert_bit_exact(gpu[0], ref[0], "64F chain %sC%d -> %s" % (src, cn, kind))

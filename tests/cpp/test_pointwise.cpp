@@ -31,9 +31,12 @@ static void test_read_x_write(cv::cuda::Stream& stream) {
         case CV_32S: v0 = src.ptr<int>()[c]; break;
         default: v0 = src.ptr<float>()[c]; break;
         }
-        const double e = ((v0 - (float)p.sub[c]) * (float)p.mul[c]) / (float)p.div[c] + (float)p.div[c];
+        using OB = BASE_CUDA_T(OC); // float or double output
+        const double e = CV_MAT_DEPTH(OC) == CV_64F
+                             ? ((v0 - p.sub[c]) * p.mul[c]) / p.div[c] + p.div[c]
+                             : ((v0 - (float)p.sub[c]) * (float)p.mul[c]) / (float)p.div[c] + (float)p.div[c];
         for (int y = 0; y < H && ok; y += 97)
-            for (int x = 0; x < W && ok; x += 13) ok = close_enough<float>(h.ptr<float>(y)[x * CN + c], (float)e);
+            for (int x = 0; x < W && ok; x += 13) ok = close_enough<OB>(h.ptr<OB>(y)[x * CN + c], (OB)e);
     }
     CHECK(ok, "K6 read x write, types " << I << " -> " << OC);
 }
@@ -150,6 +153,7 @@ int main() {
     RW(CV_8UC2, CV_32FC2) RW(CV_8UC3, CV_32FC3) RW(CV_8UC4, CV_32FC4) RW(CV_8SC2, CV_32FC2) RW(CV_8SC3, CV_32FC3) RW(CV_8SC4, CV_32FC4)
     RW(CV_16UC2, CV_32FC2) RW(CV_16UC3, CV_32FC3) RW(CV_16UC4, CV_32FC4) RW(CV_16SC2, CV_32FC2) RW(CV_16SC3, CV_32FC3) RW(CV_16SC4, CV_32FC4)
     RW(CV_32SC2, CV_32FC2) RW(CV_32SC3, CV_32FC3) RW(CV_32SC4, CV_32FC4)
+    RW(CV_32FC2, CV_64FC2) RW(CV_32FC3, CV_64FC3) RW(CV_32FC4, CV_64FC4) // double-precision outputs (reference :139-141)
 #undef RW
     test_read_convert_split<CV_8UC2, CV_32FC2>(stream);
     test_read_convert_split<CV_8UC3, CV_32FC3>(stream);

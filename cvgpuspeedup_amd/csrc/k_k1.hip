@@ -114,8 +114,16 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
     PlaneParams P;
     if constexpr (NPL == 0) P = c.read.table[z < used ? z : 0];
     else P = a.planes[z];
+    float* const out2_base = g.out2;
+    const int64_t img_stride2 = g.img_stride2, ch_stride2 = g.ch_stride2;
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
+                 op2 = *(const f32x4s*)c.prog.operand[2], op3 = *(const f32x4s*)c.prog.operand[3];
+    // naming every value in one asm statement makes the compiler issue ALL these scalar loads back to back and wait
+    // once; otherwise each early-exit test gets its own load + wait (3-4 serial scalar-memory round trips per wave)
     asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(used), "s"(W), "s"(col_tiles), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.x1),
-                 "s"(P.y1), "s"(P.x2), "s"(P.y2));
+                 "s"(P.y1), "s"(P.x2), "s"(P.y2), "s"(P.fx), "s"(P.fy), "s"(P.data), "s"(img_stride), "s"(ch_stride),
+                 "s"(out_base), "s"(out2_base), "s"(img_stride2), "s"(ch_stride2), "s"(op0), "s"(op1), "s"(op2), "s"(op3));
 
     int col_tile = 0, row_tile = (int)blockIdx.x;
     if (col_tiles > 1) {
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
     const int row0 = (row_tile * 4 + wave) * RPW;
     if (row0 >= dst_h || x >= dst_w) return;
     float* const out = out_base + (int64_t)z * img_stride;
-    float* const out2 = g.out2 ? g.out2 + (int64_t)z * g.img_stride2 : nullptr; // wave-uniform
+    float* const out2 = out2_base ? out2_base + (int64_t)z * img_stride2 : nullptr; // wave-uniform
 
     // does the source cover the whole target?  (always, except AR padding and planes >= usedPlanes)
     const bool whole = z < used && ((P.x1 | P.y1 | (P.x2 ^ (dst_w - 1)) | (P.y2 ^ (dst_h - 1))) == 0);
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
                     for (int k = 0; k < 4; ++k)
                         if (k < bcn) {
                             st_nt(out + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
-                            if (out2) st_nt(out2 + (int64_t)k * g.ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
+                            if (out2) st_nt(out2 + (int64_t)k * ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
                         }
             }
             return;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
                 if (k < cn) {
                     const float v = take ? p.v[k] : bgp.v[k];
                     st_nt(orow + (int64_t)k * ch_stride + x, v);
-                    if (out2) st_nt(out2 + (int64_t)y * W + (int64_t)k * g.ch_stride2 + x, v);
+                    if (out2) st_nt(out2 + (int64_t)y * W + (int64_t)k * ch_stride2 + x, v);
                 }
         }
     }

@@ -47,7 +47,7 @@ READ_FLAG_TABLE_ON_DEVICE = 1
 (WRITE_PIXEL_2D, WRITE_PIXEL_3D, WRITE_TENSOR_SPLIT, WRITE_TENSOR_T_SPLIT, WRITE_SPLIT_2D,
  WRITE_PIXEL_2D_BATCH) = range(6)
 # chain flags
-CHAIN_DEFAULT, CHAIN_FORCE_GENERIC, CHAIN_NO_THREAD_FUSION, CHAIN_K1_DIRECT, CHAIN_K1_LDS = 0, 1, 2, 4, 8
+CHAIN_DEFAULT, CHAIN_FORCE_GENERIC, CHAIN_NO_THREAD_FUSION = 0, 1, 2
 # circular tensor
 NEWEST_FIRST, OLDEST_FIRST = 0, 1
 PLANES_STANDARD, PLANES_TRANSPOSED = 0, 1

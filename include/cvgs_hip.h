@@ -199,10 +199,8 @@ typedef enum cvgs_chain_flags {
     CVGS_CHAIN_FORCE_GENERIC = 1,
     /* ENABLE_THREAD_FUSION=false of the reference (cvGPUSpeedup.cuh:464): results identical,
      * only disables the multi-pixel-per-thread fast paths                                      */
-    CVGS_CHAIN_NO_THREAD_FUSION = 2,
-    /* select a specific K1 variant (benchmark A/B only) */
-    CVGS_CHAIN_K1_DIRECT = 4,
-    CVGS_CHAIN_K1_LDS = 8
+    CVGS_CHAIN_NO_THREAD_FUSION = 2
+    /* bits 8..15: id of an experimental K1 kernel variant (tools/k1_ab.py A/B runs only; 0 = normal dispatch) */
 } cvgs_chain_flags;
 
 /* Library / device ------------------------------------------------------------------------- */

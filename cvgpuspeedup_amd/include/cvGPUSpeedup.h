@@ -156,6 +156,29 @@ inline auto resize(const std::array<cv::cuda::GpuMat, NPtr>& input, const cv::Si
     return rd;
 }
 
+// ---- NV12 sources (NEW: the reference has no cvGS:: wrapper for its fk::ReadYUV path) --------------
+// cvtColorNV12<cv::COLOR_YUV2BGR_NV12 | RGB | BGRA | RGBA>(nv12): reads a decoder surface (CV_8UC1 GpuMat with
+// H luma rows followed by H/2 interleaved UV rows, i.e. rows = H*3/2) as float BGR/RGB[A] pixels -- the first IOp of
+// a chain.  resize<INTER>(thatIOp, dsize) fuses it as the read-back of the bilinear resize (one kernel).
+template <cv::ColorConversionCodes CODE, fk::ColorRange CR = fk::Full, fk::ColorPrimitives CP = fk::bt709>
+inline auto cvtColorNV12(const cv::cuda::GpuMat& nv12) {
+    static_assert(CODE == cv::COLOR_YUV2RGB_NV12 || CODE == cv::COLOR_YUV2BGR_NV12 || CODE == cv::COLOR_YUV2RGBA_NV12 ||
+                  CODE == cv::COLOR_YUV2BGRA_NV12, "Color conversion type not supported yet.");
+    if (nv12.type() != CV_8UC1 || nv12.rows % 3 != 0) throw std::runtime_error("cvtColorNV12 needs a CV_8UC1 surface with rows = H * 3 / 2");
+    constexpr bool alpha = CODE == cv::COLOR_YUV2RGBA_NV12 || CODE == cv::COLOR_YUV2BGRA_NV12;
+    constexpr bool swap = CODE == cv::COLOR_YUV2BGR_NV12 || CODE == cv::COLOR_YUV2BGRA_NV12;
+    using O = std::conditional_t<alpha, float4, float3>;
+    fk::RawPtr<fk::_2D, uchar> luma;
+    luma.data = nv12.data;
+    luma.dims = {(uint)nv12.cols, (uint)(nv12.rows / 3 * 2), (uint)nv12.step};
+    return fk::YuvRead<fk::NV12, CR, CP, alpha, O, swap>{luma};
+}
+template <int INTER_F, fk::PixelFormat PF, fk::ColorRange CR, fk::ColorPrimitives CP, bool ALPHA, typename O, bool SW>
+inline auto resize(const fk::YuvRead<PF, CR, CP, ALPHA, O, SW>& nv12Read, const cv::Size& dsize) {
+    static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");
+    return fk::Resize<(fk::InterpolationType)INTER_F>::build(nv12Read, fk::Size(dsize.width, dsize.height));
+}
+
 // crop == an ROI view (zero cost): same pointer arithmetic as GpuMat::operator()(Rect); Rect2d doubles truncate
 inline cv::cuda::GpuMat crop(const cv::cuda::GpuMat& input, const cv::Rect2d& rect) { return input(cv::Rect(rect)); }
 template <size_t BATCH>

@@ -381,11 +381,15 @@ struct ConvertYUVToRGB {
 };
 
 // fuse(Read<ReadYUV>, Unary<ConvertYUVToRGB>) -> one read IOp producing RGB(A)
-template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O> struct YuvRead {
+template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O, bool SWAP_RB = false> struct YuvRead {
     RawPtr<_2D, uchar> params;
     using OutputType = O;
     static constexpr Stage stage = Stage::Read;
     static constexpr bool float_out = std::is_same_v<VBase<O>, float>;
+    static constexpr bool swap_rb = SWAP_RB; // deliver B,G,R[,A] instead of R,G,B[,A]
+    static void lower_swap(ChainBuilder& b) {
+        if constexpr (SWAP_RB) b.op(CVGS_OP_REORDER, ALPHA ? (detail::kSwap3 | (3 << 6)) : detail::kSwap3);
+    }
     void lower_read(ChainBuilder& b, int kind) const {
         cvgs_read_desc& r = b.d.read;
         r.kind = kind; r.src_type = CV_8UC1; r.batch = 1; r.used_planes = 1;
@@ -394,6 +398,7 @@ template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typenam
     }
     void lower(ChainBuilder& b) const {
         lower_read(b, CVGS_READ_NV12);
+        lower_swap(b);
         if constexpr (!float_out) b.op(CVGS_OP_CAST, cvGS::base_depth<VBase<O>>::value);
     }
 };
@@ -424,6 +429,7 @@ template <typename Yuv> struct ResizeYuvRead {     // single image, NV12 read-ba
     void lower(ChainBuilder& b) const {
         back.lower_read(b, CVGS_READ_NV12_RESIZE_LINEAR);
         b.d.read.dst_width = dsize.width; b.d.read.dst_height = dsize.height; b.d.read.aspect_ratio = CVGS_IGNORE_AR;
+        Yuv::lower_swap(b); // a channel permutation commutes with the per-channel interpolation
     }
 };
 
@@ -472,9 +478,9 @@ template <InterpolationType IT, AspectRatio AR = IGNORE_AR> struct Resize {
         }
         return ResizeRead<T>{in, d};
     }
-    template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O>
-    static auto build(const YuvRead<PF, CR, CP, ALPHA, O>& back, const Size& dsize) {
-        return ResizeYuvRead<YuvRead<PF, CR, CP, ALPHA, O>>{back, dsize};
+    template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O, bool SW>
+    static auto build(const YuvRead<PF, CR, CP, ALPHA, O, SW>& back, const Size& dsize) {
+        return ResizeYuvRead<YuvRead<PF, CR, CP, ALPHA, O, SW>>{back, dsize};
     }
 };
 

@@ -109,8 +109,30 @@ static void test_fused_nv12_resize(cv::cuda::Stream& stream) {
     CHECK(same, "K4 NV12 -> BGRA resize, bit-exact vs oracle");
 }
 
+// cfg #3 through the facade: cvtColorNV12 -> resize -> normalize -> split, ONE kernel
+static void test_nv12_facade_cfg3(cv::cuda::Stream& stream) {
+    const int W = 1280, H = 720;
+    const cv::Size down(426, 240);
+    cv::Mat h_nv12(H + H / 2, W, CV_8UC1);
+    fill_random(h_nv12, 777);
+    cv::cuda::GpuMat d_nv12(h_nv12), hv_nv12 = host_view(h_nv12);
+    cv::cuda::GpuMat d_out(1, down.width * down.height * 3, CV_32F);
+    cv::Mat h_ref(1, down.width * down.height * 3, CV_32F);
+    cv::cuda::GpuMat hv_ref = host_view(h_ref);
+    const cv::Scalar a(0.3, 0.3, 0.3), s(1.f, 4.f, 3.2f), d(3.2f, 0.6f, 11.8f);
+    cvGS::executeOperations(stream, cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12>(d_nv12), down),
+                            cvGS::multiply<CV_32FC3>(a), cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d),
+                            cvGS::split<CV_32FC3>(d_out, down));
+    run_oracle(cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12>(hv_nv12), down), cvGS::multiply<CV_32FC3>(a),
+               cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(hv_ref, down));
+    stream.waitForCompletion();
+    const auto h = fetch(d_out.data, (size_t)down.width * down.height * 3 * 4);
+    CHECK(bit_equal(h.data(), h_ref.data, h.size()), "cfg3 through cvGS::cvtColorNV12 + resize, bit-exact vs oracle");
+}
+
 int main() {
     cv::cuda::Stream stream;
+    test_nv12_facade_cfg3(stream);
     test_resize_split_one<CV_8UC3, CV_32FC3>(stream);
     test_resize_split_one<CV_8UC4, CV_32FC4>(stream);
     test_resize_split_one<CV_16UC3, CV_32FC3>(stream);

@@ -68,42 +68,108 @@ struct K1Geom {
 typedef uint64_t u64_unaligned __attribute__((aligned(1)));
 typedef const __attribute__((address_space(1))) u64_unaligned* gptr_u64;
 typedef const __attribute__((address_space(1))) uint8_t* gptr_u8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) u32x4_unaligned* gptr_u32x4;
 
-// crop rows narrower than 8 bytes (1-2 pixels): byte gather with clamped, always-valid addresses
-template <int CN>
-__device__ __forceinline__ uint64_t gather_pair(gptr_u8 row, int o, int row_bytes) {
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * CN; ++k) {
-        const uint32_t b = row[min(o + k, row_bytes - 1)];
-        if (k < 4) lo |= b << (8 * k);
-        else hi |= b << (8 * (k - 4));
+// Source element kinds of the fast path (the reference sweeps K1 over 8U, 16U and 16S sources,
+// tests/batchresize/test_batchresize_x_split3D.cu:427-432).
+enum { SRC_U8 = 0, SRC_U16 = 1, SRC_S16 = 2 };
+template <int SRC> constexpr int elem_bytes = SRC == SRC_U8 ? 1 : 2;
+
+// The tap window of one lane and one source row: both horizontal taps (a pixel pair: 2*CN elements) arrive in ONE
+// unaligned load -- 8 bytes for u8 pixels (6 or 8 used), 16 bytes for 16-bit pixels (12 or 16 used).
+template <int EB> struct Win;
+template <> struct Win<1> { uint64_t lo; };
+template <> struct Win<2> { uint64_t lo, hi; };
+
+template <int EB>
+__device__ __forceinline__ Win<EB> load_win(gptr_u8 p) {
+    Win<EB> w;
+    if constexpr (EB == 1) {
+        w.lo = *(gptr_u64)p;
+    } else {
+        const u32x4 v = *(gptr_u32x4)p;
+        w.lo = ((uint64_t)v.y << 32) | v.x;
+        w.hi = ((uint64_t)v.w << 32) | v.z;
     }
-    return ((uint64_t)hi << 32) | lo;
+    return w;
 }
 
-template <int CN>
-__device__ __forceinline__ void unpack_pair(uint64_t v, bool edge, float* a, float* b) {
-    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    // second pixel of the pair as one 32-bit word; at the right edge (x2 clamped onto x1) it IS the first pixel
-    const uint32_t second = CN == 3 ? (uint32_t)(v >> 24) : hi;
-    const uint32_t s = edge ? lo : second;
-    a[0] = (float)(lo & 0xffu);
-    a[1] = (float)((lo >> 8) & 0xffu);
-    a[2] = (float)((lo >> 16) & 0xffu);
-    b[0] = (float)(s & 0xffu);
-    b[1] = (float)((s >> 8) & 0xffu);
-    b[2] = (float)((s >> 16) & 0xffu);
-    if constexpr (CN == 4) {
-        a[3] = (float)(lo >> 24);
-        b[3] = (float)(s >> 24);
+// rows narrower than the window (1-2 pixels): gather byte by byte with clamped, always-valid addresses
+template <int CN, int EB>
+__device__ __forceinline__ Win<EB> gather_win(gptr_u8 row, int o, int row_bytes) {
+    uint64_t part[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 2 * CN * EB; ++k) {
+        const uint64_t b = row[min(o + k, row_bytes - 1)];
+        part[k >> 3] |= b << (8 * (k & 7));
+    }
+    Win<EB> w;
+    w.lo = part[0];
+    if constexpr (EB == 2) w.hi = part[1];
+    return w;
+}
+
+// window >> sh bits (sh is a multiple of the pixel size; non-zero only for the last columns of a row)
+template <int EB>
+__device__ __forceinline__ Win<EB> shift_win(Win<EB> w, int sh) {
+    if constexpr (EB == 1) {
+        w.lo >>= sh;
+    } else {
+        if (sh >= 64) {
+            w.lo = w.hi >> (sh - 64);
+            w.hi = 0;
+        } else if (sh > 0) {
+            w.lo = (w.lo >> sh) | (w.hi << (64 - sh));
+            w.hi >>= sh;
+        }
+    }
+    return w;
+}
+
+template <int SRC>
+__device__ __forceinline__ float elem_to_float(uint32_t bits) {
+    if constexpr (SRC == SRC_S16) return (float)(int16_t)(uint16_t)bits;
+    else return (float)bits;
+}
+
+// pixel pair -> floats; at the right edge (x2 clamped onto x1) the second pixel IS the first one
+template <int CN, int SRC>
+__device__ __forceinline__ void unpack_pair(const Win<elem_bytes<SRC>>& w, bool edge, float* a, float* b) {
+    if constexpr (SRC == SRC_U8) {
+        const uint32_t lo = (uint32_t)w.lo, hi = (uint32_t)(w.lo >> 32);
+        const uint32_t second = CN == 3 ? (uint32_t)(w.lo >> 24) : hi;
+        const uint32_t s = edge ? lo : second;
+        a[0] = (float)(lo & 0xffu);
+        a[1] = (float)((lo >> 8) & 0xffu);
+        a[2] = (float)((lo >> 16) & 0xffu);
+        b[0] = (float)(s & 0xffu);
+        b[1] = (float)((s >> 8) & 0xffu);
+        b[2] = (float)((s >> 16) & 0xffu);
+        if constexpr (CN == 4) {
+            a[3] = (float)(lo >> 24);
+            b[3] = (float)(s >> 24);
+        }
+    } else {
+        // 16-bit elements e0..e(2CN-1): e0..e3 in lo, e4.. in hi
+        const uint64_t first = w.lo;                                                  // pixel 0: e0..e(CN-1)
+        const uint64_t second = CN == 3 ? ((w.lo >> 48) | (w.hi << 16)) : w.hi;       // pixel 1: e(CN)..e(2CN-1)
+        const uint64_t s = edge ? first : second;
+#pragma unroll
+        for (int k = 0; k < CN; ++k) {
+            a[k] = elem_to_float<SRC>((uint32_t)(first >> (16 * k)) & 0xffffu);
+            b[k] = elem_to_float<SRC>((uint32_t)(s >> (16 * k)) & 0xffffu);
+        }
     }
 }
 
 __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 
-template <int CN, int NPL, int RPW, class Prog>
+template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8>
 __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, const K1Geom g) {
+    constexpr int EB = elem_bytes<SRC>;
+    constexpr int WINB = 8 * EB; // bytes per tap window
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.y;
     // ---- one batch of scalar loads: geometry, the crop's parameters, the program operands come in together ----
@@ -176,14 +242,14 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
     const float wxa = (float)x2 - sx;
     const float wxb = sx - (float)x1;
     const bool edge = x2 > P.w - 1;
-    const int row_bytes = P.w * CN;
-    const int o = x1 * CN;
-    const bool tiny = row_bytes < 8; // wave-uniform
-    const uint32_t ol = (uint32_t)(tiny ? o : min(o, row_bytes - 8));
+    const int row_bytes = P.w * CN * EB;
+    const int o = x1 * CN * EB;
+    const bool tiny = row_bytes < WINB; // wave-uniform
+    const uint32_t ol = (uint32_t)(tiny ? o : min(o, row_bytes - WINB));
     const int sh = (o - (int)ol) * 8;
     const gptr_u8 src = (gptr_u8)P.data;
 
-    uint64_t va[RPW], vb[RPW];
+    Win<EB> va[RPW], vb[RPW];
     float wya[RPW], wyb[RPW];
     bool in_y[RPW];
 #pragma unroll
@@ -200,11 +266,11 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
         const gptr_u8 ra = src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step;
         const gptr_u8 rb = src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step;
         if (!tiny) {
-            va[j] = *(gptr_u64)(ra + ol);
-            vb[j] = *(gptr_u64)(rb + ol);
+            va[j] = load_win<EB>(ra + ol);
+            vb[j] = load_win<EB>(rb + ol);
         } else {
-            va[j] = gather_pair<CN>(ra, o, row_bytes);
-            vb[j] = gather_pair<CN>(rb, o, row_bytes);
+            va[j] = gather_win<CN, EB>(ra, o, row_bytes);
+            vb[j] = gather_win<CN, EB>(rb, o, row_bytes);
         }
     }
 
@@ -213,8 +279,8 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
         const int y = row0 + j;
         if (y < dst_h) { // wave-uniform
             float p00[4], p10[4], p01[4], p11[4];
-            unpack_pair<CN>(va[j] >> sh, edge, p00, p10);
-            unpack_pair<CN>(vb[j] >> sh, edge, p01, p11);
+            unpack_pair<CN, SRC>(shift_win<EB>(va[j], sh), edge, p00, p10);
+            unpack_pair<CN, SRC>(shift_win<EB>(vb[j], sh), edge, p01, p11);
             const float w00 = wxa * wya[j];
             const float w10 = wxb * wya[j];
             const float w01 = wxa * wyb[j];
@@ -247,7 +313,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CN, int NPL, int RPW, class Prog>
+template <int CN, int NPL, int RPW, class Prog, int SRC>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn,
                            hipStream_t stream) {
     KernArgs<NPL> a;
@@ -275,27 +341,38 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     g.img_stride2 = c.write.img_stride2;
     g.ch_stride2 = c.write.ch_stride2;
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch);
-    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog>), grid, dim3(256), 0, stream, a, g);
+    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC>), grid, dim3(256), 0, stream, a, g);
     return hipGetLastError();
 }
 
-template <int CN, int NPL, class Prog>
+template <int CN, int NPL, class Prog, int SRC>
 static hipError_t launch_rpw(int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s) {
     // the interpreted program keeps its opcode loop rolled; more than one row per wave only bloats it
-    if constexpr (std::is_same_v<Prog, InterpProg>) return launch_t<CN, NPL, 1, Prog>(c, ip, ni, out_cn, s);
-    else
+    if constexpr (std::is_same_v<Prog, InterpProg>) return launch_t<CN, NPL, 1, Prog, SRC>(c, ip, ni, out_cn, s);
+    else if constexpr (SRC != SRC_U8) { // 16-bit sources: two row counts are enough
+        if (rpw == 1) return launch_t<CN, NPL, 1, Prog, SRC>(c, ip, ni, out_cn, s);
+        return launch_t<CN, NPL, 4, Prog, SRC>(c, ip, ni, out_cn, s);
+    } else
     switch (rpw) {
-    case 1: return launch_t<CN, NPL, 1, Prog>(c, ip, ni, out_cn, s);
-    case 2: return launch_t<CN, NPL, 2, Prog>(c, ip, ni, out_cn, s);
-    default: return launch_t<CN, NPL, 4, Prog>(c, ip, ni, out_cn, s);
+    case 1: return launch_t<CN, NPL, 1, Prog, SRC>(c, ip, ni, out_cn, s);
+    case 2: return launch_t<CN, NPL, 2, Prog, SRC>(c, ip, ni, out_cn, s);
+    default: return launch_t<CN, NPL, 4, Prog, SRC>(c, ip, ni, out_cn, s);
     }
 }
 
-template <int CN, class Prog>
+template <int CN, class Prog, int SRC>
 static hipError_t launch_npl(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
                              hipStream_t s) {
-    if (table) return launch_rpw<CN, 0, Prog>(rpw, c, ip, ni, out_cn, s);
-    return launch_rpw<CN, CVGS_KERNARG_PLANES, Prog>(rpw, c, ip, ni, out_cn, s);
+    if (table) return launch_rpw<CN, 0, Prog, SRC>(rpw, c, ip, ni, out_cn, s);
+    return launch_rpw<CN, CVGS_KERNARG_PLANES, Prog, SRC>(rpw, c, ip, ni, out_cn, s);
+}
+
+template <int CN, int SRC>
+static hipError_t launch_prog(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
+                              hipStream_t s) {
+    if (prog_id == 0) return launch_npl<CN, ProgSwapMulSubDiv, SRC>(table, rpw, c, ip, ni, out_cn, s);
+    if (prog_id == 1) return launch_npl<CN, ProgMulSubDiv, SRC>(table, rpw, c, ip, ni, out_cn, s);
+    return launch_npl<CN, InterpProg, SRC>(table, rpw, c, ip, ni, out_cn, s);
 }
 
 // program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
@@ -311,8 +388,9 @@ static int classify_program(const ProgArgs& p, int cn) {
 int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
               void* stream, bool dry_run, LaunchInfo* info) {
     const ReadArgs& r = c.read;
-    // eligibility: u8 C3/C4 resize read, fp32 planar tensor write
-    if (r.kind != CVGS_READ_RESIZE_LINEAR || r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4)) return 0;
+    // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write
+    if (r.kind != CVGS_READ_RESIZE_LINEAR || (r.cn != 3 && r.cn != 4)) return 0;
+    if (r.depth != CVGS_DEPTH_8U && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S) return 0;
     if (c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return 0;
     if (c.write.depth != CVGS_DEPTH_32F) return 0;
     if (r.batch > 65535) return 0;
@@ -327,10 +405,16 @@ int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline
     const bool table = r.table != nullptr;
     const int prog_id = classify_program(c.prog, r.cn);
 
+    const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : SRC_S16);
     if (info) {
-        static const char* names[2][3] = {{"k1_u8c3_swap_mul_sub_div", "k1_u8c3_mul_sub_div", "k1_u8c3_interp"},
-                                          {"k1_u8c4_swap_mul_sub_div", "k1_u8c4_mul_sub_div", "k1_u8c4_interp"}};
-        info->kernel = names[r.cn == 4][prog_id];
+        static const char* names[3][2][3] = {
+            {{"k1_u8c3_swap_mul_sub_div", "k1_u8c3_mul_sub_div", "k1_u8c3_interp"},
+             {"k1_u8c4_swap_mul_sub_div", "k1_u8c4_mul_sub_div", "k1_u8c4_interp"}},
+            {{"k1_u16c3_swap_mul_sub_div", "k1_u16c3_mul_sub_div", "k1_u16c3_interp"},
+             {"k1_u16c4_swap_mul_sub_div", "k1_u16c4_mul_sub_div", "k1_u16c4_interp"}},
+            {{"k1_s16c3_swap_mul_sub_div", "k1_s16c3_mul_sub_div", "k1_s16c3_interp"},
+             {"k1_s16c4_swap_mul_sub_div", "k1_s16c4_mul_sub_div", "k1_s16c4_interp"}}};
+        info->kernel = names[src][r.cn == 4][prog_id];
     }
     if (dry_run) return 1;
     (void)chain_flags;
@@ -339,13 +423,13 @@ int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline
     const int out_cn = c.write.cn;
     hipError_t e;
     if (r.cn == 3) {
-        if (prog_id == 0) e = launch_npl<3, ProgSwapMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
-        else if (prog_id == 1) e = launch_npl<3, ProgMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
-        else e = launch_npl<3, InterpProg>(table, rpw, c, inline_planes, n_inline, out_cn, s);
+        e = src == SRC_U8    ? launch_prog<3, SRC_U8>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
+            : src == SRC_U16 ? launch_prog<3, SRC_U16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
+                             : launch_prog<3, SRC_S16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
     } else {
-        if (prog_id == 0) e = launch_npl<4, ProgSwapMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
-        else if (prog_id == 1) e = launch_npl<4, ProgMulSubDiv>(table, rpw, c, inline_planes, n_inline, out_cn, s);
-        else e = launch_npl<4, InterpProg>(table, rpw, c, inline_planes, n_inline, out_cn, s);
+        e = src == SRC_U8    ? launch_prog<4, SRC_U8>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
+            : src == SRC_U16 ? launch_prog<4, SRC_U16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
+                             : launch_prog<4, SRC_S16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
     }
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }

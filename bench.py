@@ -249,6 +249,16 @@ def main():
         wall = float(t.item())
         gather_note = "in-place all_gather_into_tensor of %d x %d B per step, overlapped with the next steps' K1" % (
             world, n * plane * 4)
+        # the same K steps WITHOUT the collective (every rank keeps its shard): what the sharded K1 alone scales to.
+        # Reported under "extra" only; `value` above includes the all-gather the north star asks for.
+        s2 = torch.cuda.current_stream().cuda_stream
+        for i in range(min(a.warmup, 64)):
+            wl.launch(i, s2)
+        wall_c, _ = timed(lambda: [wl.launch(i, s2) for i in range(a.steps)], barrier)
+        tc = torch.tensor([wall_c], dtype=torch.float64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        compute_only = {"value": round(n * W.DST[0] * W.DST[1] * world * a.steps / float(tc.item()) / 1e6, 1), "unit": "Mpix/s",
+                        "note": "same K steps, K1 only, no all-gather (eager launches; each rank keeps its shard)"}
 
     px_per_step = n * W.DST[0] * W.DST[1] * world
     value = px_per_step * a.steps / wall / 1e6
@@ -301,10 +311,13 @@ def main():
                               "algorithmic_bytes_per_launch": int(alg)}
     if use_dist:
         barrier()
+        if rank == 0:
+            result.setdefault("extra", {})["without_allgather"] = compute_only
+            result["extra"]["per_step_gather_bytes_received_per_gpu"] = (world - 1) * n * plane * 4
     if rank == 0 and world == 1 and not a.no_cpu:
         result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
     if rank == 0 and world == 1 and not a.no_extra:
-        result["extra"] = extra_sweeps(dev, a)
+        result.setdefault("extra", {}).update(extra_sweeps(dev, a))
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

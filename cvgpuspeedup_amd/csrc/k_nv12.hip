@@ -54,8 +54,17 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     PlaneParams P;
     if constexpr (NPL == 0) P = c.read.table[z];
     else P = a.planes[z];
-    const YuvK yk = yuv_matrix(c.read.yuv_range, c.read.yuv_primaries);
-    asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(W), "s"(CN), "s"(P.w), "s"(P.h), "s"(P.step));
+    const int yuv_range = c.read.yuv_range, yuv_prim = c.read.yuv_primaries, packed = g.packed;
+    const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
+    uint8_t* const out_base = g.out;
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
+                 op2 = *(const f32x4s*)c.prog.operand[2], op3 = *(const f32x4s*)c.prog.operand[3];
+    // one batch of scalar loads, one wait (see k_k1.hip)
+    asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(W), "s"(CN), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.fx), "s"(P.fy), "s"(P.data),
+                 "s"(yuv_range), "s"(yuv_prim), "s"(packed), "s"(img_stride), "s"(ch_stride), "s"(out_base), "s"(op0), "s"(op1),
+                 "s"(op2), "s"(op3));
+    const YuvK yk = yuv_matrix(yuv_range, yuv_prim);
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
@@ -118,13 +127,13 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     int depth = CVGS_DEPTH_32F, cn = CN;
     Prog::run(c.prog, p, depth, cn);
 
-    if (g.packed) {
+    if (packed) {
         write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
     } else {
-        float* const orow = (float*)g.out + (int64_t)z * g.img_stride + (int64_t)y * W;
+        float* const orow = (float*)out_base + (int64_t)z * img_stride + (int64_t)y * W;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k < cn) __builtin_nontemporal_store(p.v[k], orow + (int64_t)k * g.ch_stride + x);
+            if (k < cn) __builtin_nontemporal_store(p.v[k], orow + (int64_t)k * ch_stride + x);
     }
 }
 

@@ -42,6 +42,14 @@ def test_facade_rejects_type_mismatch_at_compile_time(tmp_path):
 
 
 @pytest.mark.gpu
+def test_readme_example_runs():
+    """examples/readme_example.cpp: the reference README's 50-detection example on the facade."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(ROOT, "examples", "bin", "readme_example")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("prog", PROGRAMS)
 def test_facade_program_passes(prog):
     exe = os.path.join(CPP, "bin", prog)

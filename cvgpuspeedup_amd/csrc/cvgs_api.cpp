@@ -274,6 +274,13 @@ struct AsyncTable {
     hipStream_t stream = nullptr;
     int upload(const void* host, size_t bytes, hipStream_t s) {
         stream = s;
+        // Under stream capture the copy node would keep a pointer to host memory that dies when this call returns:
+        // refuse loudly instead of replaying garbage.  (Captured launches must use kernel-argument descriptors,
+        // i.e. <= CVGS_KERNARG_PLANES planes, or a caller-owned device table from cvgs_plane_table_build.)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(CVGS_ERR_UNSUPPORTED,
+                        "descriptor table upload during stream capture: pass a device plane table (cvgs_plane_table_build)");
         hipError_t e = hipMallocAsync(&dev, bytes, s);
         if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(descriptor table)");
         e = hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);

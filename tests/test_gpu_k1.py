@@ -119,3 +119,50 @@ def test_k1_device_plane_table(oracle):
     cvgs.executeOperations(torch.cuda.current_stream(), *ops2)
     torch.cuda.synchronize()
     H.assert_bit_exact(out_t.cpu().numpy(), ref, "K1 batch 300 (resident table)")
+
+
+def test_k1_no_used_planes(oracle):
+    """usedPlanes == 0 ("empty" crop list): every plane is the default value pushed through the chain."""
+    frame = H.random_u8((64, 64, 3), seed=61)
+    gpu, ref, _ = run_both(oracle, frame, [(0, 0, 8, 8)] * 4, 4, used=0, background=[10.0, 20.0, 30.0])
+    H.assert_bit_exact(gpu, ref, "usedPlanes == 0")
+    t = gpu.reshape(4, 3, 128, 64)
+    assert (t[:, 0] == t[0, 0, 0, 0]).all() and (t[:, 2] == t[0, 2, 0, 0]).all()
+
+
+def test_k1_large_batch_and_large_crops(oracle):
+    """2000 crops in one launch (device table), including whole-frame crops (strong downscale, scale > 21)."""
+    frame = H.random_u8((1080, 1920, 3), seed=71)
+    crops = H.random_crops(1996, 1920, 1080, seed=72, wmax=1920, hmax=1080) + [(0, 0, 1920, 1080), (0, 0, 1920, 1), (0, 0, 1, 1080),
+                                                                                 (1919, 1079, 1, 1)]
+    gpu, ref, _ = run_both(oracle, frame, crops, 2000)
+    H.assert_bit_exact(gpu, ref, "2000 crops")
+
+
+def test_k1_stream_capture_guard():
+    """Batches that need a library-managed descriptor upload cannot be captured into a HIP graph (the copy would
+    reference dead host memory): the call must fail loudly; the same batch with a resident plane table captures fine."""
+    import torch
+    dev = torch.device("cuda:0")
+    frame_t = torch.from_numpy(H.random_u8((480, 640, 3), seed=81)).to(dev)
+    crops = H.random_crops(100, 640, 480, seed=82, wmax=200, hmax=200)
+    out_t = torch.zeros((100, 3 * 64 * 128), dtype=torch.float32, device=dev)
+    g_src, g_out = cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1)
+    ops = H.k1_chain(g_src, crops, g_out)
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)  # eager: fine
+    torch.cuda.synchronize()
+    eager = out_t.clone()
+    table = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
+    ops_t = H.k1_chain(g_src, crops, g_out, table=table.data_ptr())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            with pytest.raises(cvgs.capi.CvgsError):
+                cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+            cvgs.executeOperations(torch.cuda.current_stream(), *ops_t)
+    out_t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_t, eager)

@@ -370,6 +370,19 @@ def extra_sweeps(dev, a):
     kernel leaves the launch-latency regime (SURVEY.md 'hard parts': cfg #2 moves only ~6-10 MB per launch)."""
     out = {}
     try:
+        # the 50-crop batch on 1080p and 6K source frames (the headline uses 4K); crop sizes are clipped to the frame
+        for name, wh in (("frame_1080p_50", W.FRAME_1080P), ("frame_6k_50", W.FRAME_6K)):
+            per_frame = wh[0] * wh[1] * 3 + 50 * 3 * 64 * 128 * 4
+            nf = max(4, min(48, (2 * INFINITY_CACHE) // per_frame + 1))
+            wl = Workload(dev, nf, 50, 0, 1, use_table=False, frame_wh=wh)
+            plan = make_graphs(wl, 2048)
+            run_steps(wl, 64, True)
+            wall, dev_s = timed(lambda: run_steps(wl, 2048, False, plan), lambda: None)
+            alg = algorithmic_bytes(wl)
+            out[name] = {"Mpix_per_s": round(50 * 8192 * 2048 / wall / 1e6, 1), "kernel_us": round(dev_s / 2048 * 1e6, 3),
+                         "GB_per_s": round(alg / (dev_s / 2048) / 1e9, 1), "frac": round(alg / (dev_s / 2048) / 1e9 / HBM_PEAK_GBS, 4)}
+            del wl, plan
+            torch.cuda.empty_cache()
         for crops in (50, 200, 800, 3200):
             per_frame = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + crops * 3 * 64 * 128 * 4
             nf = max(4, min(24, (2 * INFINITY_CACHE) // per_frame + 1))

@@ -57,7 +57,7 @@ class Workload:
     """F resident 4K frames, F crop lists, F output tensors, F pre-lowered chains."""
 
     def __init__(self, dev, n_frames, crops_per_launch, rank, world, use_table, frame_wh=W.FRAME_4K,
-                 out_all=None, flags=0, share=None):
+                 out_all=None, flags=0, share=None, half=False):
         self.dev = dev
         fw, fh = frame_wh
         self.frames, self.outs, self.chains, self.crops, self.tables = [], [], [], [], []
@@ -71,14 +71,14 @@ class Workload:
             if out_all is not None:  # in-place all-gather layout: this rank's slice of the full tensor
                 out = out_all[f][rank * crops_per_launch:(rank + 1) * crops_per_launch]
             else:
-                out = torch.zeros((crops_per_launch, plane), dtype=torch.float32, device=dev)
+                out = torch.zeros((crops_per_launch, plane), dtype=torch.float16 if half else torch.float32, device=dev)
             g_src = cvgs.GpuMat.from_tensor(frame, cvgs.CV_8UC3)
-            g_out = cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)
-            ops = W.k1_chain(g_src, crops, g_out)
+            g_out = cvgs.GpuMat.from_tensor(out, cvgs.CV_16FC1 if half else cvgs.CV_32FC1)
+            ops = W.k1_chain(g_src, crops, g_out, half=half)
             if use_table:
                 tab = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
                 self.tables.append(tab)
-                ops = W.k1_chain(g_src, crops, g_out, table=tab.data_ptr())
+                ops = W.k1_chain(g_src, crops, g_out, table=tab.data_ptr(), half=half)
             self.frames.append(frame)
             self.outs.append(out)
             self.crops.append(crops)
@@ -167,9 +167,9 @@ def cpu_baseline(wl, seconds):
             "gpu_matches_oracle_bit_exact": checked}
 
 
-def algorithmic_bytes(wl):
-    from oracle import oracle_binding as ob  # tap census only, part of the measurement leg
-    per_launch = [W.k1_algorithmic_bytes(c, tapped_bytes_fn=ob.tapped_bytes) for c in wl.crops]
+def algorithmic_bytes(wl, out_elem=4):
+    """SURVEY.md 8d figure per launch (tap census in cvgpuspeedup_amd/workloads.py; tests cross-check it with the oracle's)."""
+    per_launch = [W.k1_algorithmic_bytes(c, out_elem=out_elem) for c in wl.crops]
     return float(np.mean(per_launch))
 
 
@@ -394,6 +394,22 @@ def extra_sweeps(dev, a):
             wall, dev_s = timed(lambda: run_steps(wl, steps, False, plan), lambda: None)
             alg = algorithmic_bytes(wl)
             out["crops_per_launch_%d" % crops] = {
+                "Mpix_per_s": round(crops * 8192 * steps / wall / 1e6, 1), "kernel_us": round(dev_s / steps * 1e6, 3),
+                "GB_per_s": round(alg / (dev_s / steps) / 1e9, 1), "frac": round(alg / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel": wl.kernel}
+            del wl, plan
+            torch.cuda.empty_cache()
+        # half-precision hand-off option: same chain + convertTo<CV_32FC3, CV_16FC3>, fp16 NCHW tensor
+        for crops in (50, 3200):
+            per_frame = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + crops * 3 * 64 * 128 * 2
+            nf = max(4, min(24, (2 * INFINITY_CACHE) // per_frame + 1))
+            wl = Workload(dev, nf, crops, 0, 1, use_table=crops > 64, half=True)
+            steps = max(32, 4096 * 50 // crops)
+            plan = make_graphs(wl, steps)
+            run_steps(wl, min(steps, 64), True)
+            wall, dev_s = timed(lambda: run_steps(wl, steps, False, plan), lambda: None)
+            alg = algorithmic_bytes(wl, out_elem=2)
+            out["fp16_output_%d" % crops] = {
                 "Mpix_per_s": round(crops * 8192 * steps / wall / 1e6, 1), "kernel_us": round(dev_s / steps * 1e6, 3),
                 "GB_per_s": round(alg / (dev_s / steps) / 1e9, 1), "frac": round(alg / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel": wl.kernel}

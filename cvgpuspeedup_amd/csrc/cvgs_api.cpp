@@ -29,7 +29,7 @@ int hip_fail(hipError_t e, const char* what) {
 int depth_bytes(int depth) {
     switch (depth) {
     case CVGS_DEPTH_8U: case CVGS_DEPTH_8S: return 1;
-    case CVGS_DEPTH_16U: case CVGS_DEPTH_16S: return 2;
+    case CVGS_DEPTH_16U: case CVGS_DEPTH_16S: case CVGS_DEPTH_16F: return 2;
     case CVGS_DEPTH_32S: case CVGS_DEPTH_32F: return 4;
     case CVGS_DEPTH_64F: return 8;
     }
@@ -86,7 +86,7 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
         switch (op.opcode) {
         case CVGS_OP_NOP: break;
         case CVGS_OP_CAST:
-            if (op.aux < CVGS_DEPTH_8U || op.aux > CVGS_DEPTH_64F) return fail(CVGS_ERR_INVALID, "CAST: bad destination depth");
+            if (op.aux < CVGS_DEPTH_8U || op.aux > CVGS_DEPTH_16F) return fail(CVGS_ERR_INVALID, "CAST: bad destination depth");
             depth = op.aux;
             break;
         case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
@@ -107,7 +107,8 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
             break;
         case CVGS_OP_GRAY:
             if (cn < 3) return fail(CVGS_ERR_INVALID, "GRAY needs a 3- or 4-channel value");
-            if (depth == CVGS_DEPTH_32S || depth == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "GRAY on CV_32S / CV_64F");
+            if (depth == CVGS_DEPTH_32S || depth == CVGS_DEPTH_64F || depth == CVGS_DEPTH_16F)
+                return fail(CVGS_ERR_UNSUPPORTED, "GRAY on CV_32S / CV_64F / CV_16F");
             cn = 1;
             break;
         default: return fail(CVGS_ERR_INVALID, "unknown opcode");
@@ -129,9 +130,9 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (rd.used_planes < 0 || rd.used_planes > rd.batch) return fail(CVGS_ERR_INVALID, "used_planes out of range");
     if (!rd.src) return fail(CVGS_ERR_INVALID, "read.src is null");
     const int sdepth = CVGS_TYPE_DEPTH(rd.src_type), scn = CVGS_TYPE_CN(rd.src_type);
-    if (sdepth > CVGS_DEPTH_64F || scn > 4) return fail(CVGS_ERR_INVALID, "bad source type");
-    if (sdepth == CVGS_DEPTH_64F && rd.kind != CVGS_READ_PIXEL)
-        return fail(CVGS_ERR_UNSUPPORTED, "CV_64F sources are supported for per-pixel reads only");
+    if (scn > 4) return fail(CVGS_ERR_INVALID, "bad source type");
+    if ((sdepth == CVGS_DEPTH_64F || sdepth == CVGS_DEPTH_16F) && rd.kind != CVGS_READ_PIXEL)
+        return fail(CVGS_ERR_UNSUPPORTED, "CV_64F / CV_16F sources are supported for per-pixel reads only");
     if (is_nv12(rd.kind) && rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
         return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
     if (is_resize(rd.kind)) {
@@ -197,6 +198,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
 
     // ---- pointwise stages ----
     ProgArgs& Pg = L.args.prog;
+    bool uses_16f = sdepth == CVGS_DEPTH_16F;
     int n = 0;
     for (int k = 0; k < ch->n_ops; ++k) {
         if (ch->ops[k].opcode == CVGS_OP_NOP) continue;
@@ -207,6 +209,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             L.p64.operand[n][c] = ch->ops[k].operand_d[c];
         }
         if (ch->ops[k].opcode == CVGS_OP_CAST && ch->ops[k].aux == CVGS_DEPTH_64F) L.uses_64f = true;
+        if (ch->ops[k].opcode == CVGS_OP_CAST && ch->ops[k].aux == CVGS_DEPTH_16F) uses_16f = true;
         ++n;
     }
     Pg.n = n;
@@ -214,6 +217,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     int rc = walk_program(ch, d0, R.out_cn, &L.final_depth, &L.final_cn);
     if (rc) return rc;
     if (sdepth == CVGS_DEPTH_64F || L.final_depth == CVGS_DEPTH_64F) L.uses_64f = true;
+    if (L.uses_64f && uses_16f) return fail(CVGS_ERR_UNSUPPORTED, "chains mixing CV_64F and CV_16F");
 
     // ---- write stage ----
     if (wr.kind < CVGS_WRITE_PIXEL_2D || wr.kind > CVGS_WRITE_PIXEL_2D_BATCH) return fail(CVGS_ERR_INVALID, "bad write kind");

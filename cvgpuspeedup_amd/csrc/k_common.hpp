@@ -46,8 +46,20 @@ __device__ __forceinline__ void depth_range(int depth, float& lo, float& hi) {
     }
 }
 
+// fp32 -> binary16 -> fp32: round to nearest even, overflow to +-inf (v_cvt_f16_f32); a CV_16F value lives in the
+// work pixel as the float it converts to exactly
+__device__ __forceinline__ float round_half(float v) { return (float)(_Float16)v; }
+
 __device__ __forceinline__ void cast_px(Px& p, int cn, int src_depth, int dst_depth) {
     if (src_depth == dst_depth) return;
+    if (src_depth == CVGS_DEPTH_16F) src_depth = CVGS_DEPTH_32F; // already an exact float
+    if (src_depth == dst_depth) return;
+    if (dst_depth == CVGS_DEPTH_16F) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < cn) p.v[c] = round_half(src_depth == CVGS_DEPTH_32S ? (float)as_int(p.v[c]) : p.v[c]);
+        return;
+    }
     if (dst_depth == CVGS_DEPTH_32F) {
         if (src_depth == CVGS_DEPTH_32S) {
 #pragma unroll
@@ -204,6 +216,10 @@ __device__ __forceinline__ void load_px(const uint8_t* row, int depth, int cn, i
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = (float)((const int16_t*)row)[x * cn + c];
         break;
+    case CVGS_DEPTH_16F:
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = (float)((const _Float16*)row)[x * cn + c];
+        break;
     default: // 32S raw bits, 32F
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (c < cn) p.v[c] = ((const float*)row)[x * cn + c];
@@ -257,6 +273,7 @@ __device__ __forceinline__ void store_elem(uint8_t* base, size_t idx, int depth,
     case CVGS_DEPTH_8S: ((int8_t*)base)[idx] = (int8_t)v; break;
     case CVGS_DEPTH_16U: ((uint16_t*)base)[idx] = (uint16_t)v; break;
     case CVGS_DEPTH_16S: ((int16_t*)base)[idx] = (int16_t)v; break;
+    case CVGS_DEPTH_16F: ((_Float16*)base)[idx] = (_Float16)v; break;
     default: ((float*)base)[idx] = v; break; // 32S raw bits, 32F
     }
 }

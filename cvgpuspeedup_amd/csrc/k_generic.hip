@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void k_generic(const KernArgs<NPL> a) {
     if (z >= r.used) {
         // fk::BatchRead<N,CONDITIONAL_WITH_DEFAULT>: default value, then the whole chain
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p.v[k] = depth == CVGS_DEPTH_32S ? from_int((int)r.bg[k]) : r.bg[k];
+        for (int k = 0; k < 4; ++k)
+            p.v[k] = depth == CVGS_DEPTH_32S ? from_int((int)r.bg[k]) : (depth == CVGS_DEPTH_16F ? round_half(r.bg[k]) : r.bg[k]);
     } else {
         PlaneParams P;
         if constexpr (NPL == 0) P = r.table[z];

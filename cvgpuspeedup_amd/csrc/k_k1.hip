@@ -1,5 +1,6 @@
 // k_k1.hip -- K1, the north-star kernel: N crops (u8 C3/C4 pitched views of a frame) ->
-// bilinear resize -> pointwise program -> planar fp32 tensor (NCHW TensorSplit / CNHW TensorTSplit).
+// bilinear resize -> pointwise program -> planar fp32 (or, as the half-precision hand-off option, fp16) tensor
+// (NCHW TensorSplit / CNHW TensorTSplit).
 // Replaces the FKL instantiation
 //   BatchRead<N,CONDITIONAL_WITH_DEFAULT>[Resize<LINEAR,AR,Read<PerThreadRead<_2D,uchar3>>>]
 //     -> ColorConversion -> Mul -> Sub -> Div -> Write<TensorSplit<float3>>
@@ -60,8 +61,8 @@ struct K1Geom {
     int32_t pad;
     int64_t img_stride;  // output elements between images
     int64_t ch_stride;   // output elements between channel planes
-    float* out;
-    float* out2;         // optional second target (CircularTensor ring + tensor), own strides
+    void* out;           // float* or _Float16* (template parameter OT)
+    void* out2;          // optional second target (CircularTensor ring + tensor), own strides
     int64_t img_stride2, ch_stride2;
 };
 
@@ -165,8 +166,10 @@ __device__ __forceinline__ void unpack_pair(const Win<elem_bytes<SRC>>& w, bool 
 }
 
 __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+// fp16 output: the chain's trailing CAST(CV_16F) is this one round-to-nearest-even conversion
+__device__ __forceinline__ void st_nt(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
 
-template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8>
+template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float>
 __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, const K1Geom g) {
     constexpr int EB = elem_bytes<SRC>;
     constexpr int WINB = 8 * EB; // bytes per tap window
@@ -176,11 +179,11 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
     const int dst_w = g.dst_w, dst_h = g.dst_h, used = g.used, W = g.out_w;
     const uint32_t col_tiles = g.col_tiles;
     const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
-    float* const out_base = g.out;
+    OT* const out_base = (OT*)g.out;
     PlaneParams P;
     if constexpr (NPL == 0) P = c.read.table[z < used ? z : 0];
     else P = a.planes[z];
-    float* const out2_base = g.out2;
+    OT* const out2_base = (OT*)g.out2;
     const int64_t img_stride2 = g.img_stride2, ch_stride2 = g.ch_stride2;
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
@@ -201,8 +204,8 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
     const int x = col_tile * 64 + lane;
     const int row0 = (row_tile * 4 + wave) * RPW;
     if (row0 >= dst_h || x >= dst_w) return;
-    float* const out = out_base + (int64_t)z * img_stride;
-    float* const out2 = out2_base ? out2_base + (int64_t)z * img_stride2 : nullptr; // wave-uniform
+    OT* const out = out_base + (int64_t)z * img_stride;
+    OT* const out2 = out2_base ? out2_base + (int64_t)z * img_stride2 : nullptr; // wave-uniform
 
     // does the source cover the whole target?  (always, except AR padding and planes >= usedPlanes)
     const bool whole = z < used && ((P.x1 | P.y1 | (P.x2 ^ (dst_w - 1)) | (P.y2 ^ (dst_h - 1))) == 0);
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
             int depth = CVGS_DEPTH_32F, cn = CN;
             Prog::run(c.prog, p, depth, cn);
             out_cn = cn;
-            float* const orow = out + (int64_t)y * W; // wave-uniform
+            OT* const orow = out + (int64_t)y * W; // wave-uniform
             const bool take = whole || (in_x && in_y[j]);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CN, int NPL, int RPW, class Prog, int SRC>
+template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn,
                            hipStream_t stream) {
     KernArgs<NPL> a;
@@ -336,43 +339,43 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     (void)out_cn;
     g.img_stride = c.write.img_stride;
     g.ch_stride = c.write.ch_stride;
-    g.out = (float*)c.write.data;
-    g.out2 = (float*)c.write.data2;
+    g.out = c.write.data;
+    g.out2 = c.write.data2;
     g.img_stride2 = c.write.img_stride2;
     g.ch_stride2 = c.write.ch_stride2;
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch);
-    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC>), grid, dim3(256), 0, stream, a, g);
+    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT>), grid, dim3(256), 0, stream, a, g);
     return hipGetLastError();
 }
 
-template <int CN, int NPL, class Prog, int SRC>
+template <int CN, int NPL, class Prog, int SRC, typename OT>
 static hipError_t launch_rpw(int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s) {
     // the interpreted program keeps its opcode loop rolled; more than one row per wave only bloats it
-    if constexpr (std::is_same_v<Prog, InterpProg>) return launch_t<CN, NPL, 1, Prog, SRC>(c, ip, ni, out_cn, s);
+    if constexpr (std::is_same_v<Prog, InterpProg>) return launch_t<CN, NPL, 1, Prog, SRC, OT>(c, ip, ni, out_cn, s);
     else if constexpr (SRC != SRC_U8) { // 16-bit sources: two row counts are enough
-        if (rpw == 1) return launch_t<CN, NPL, 1, Prog, SRC>(c, ip, ni, out_cn, s);
-        return launch_t<CN, NPL, 4, Prog, SRC>(c, ip, ni, out_cn, s);
+        if (rpw == 1) return launch_t<CN, NPL, 1, Prog, SRC, OT>(c, ip, ni, out_cn, s);
+        return launch_t<CN, NPL, 4, Prog, SRC, OT>(c, ip, ni, out_cn, s);
     } else
     switch (rpw) {
-    case 1: return launch_t<CN, NPL, 1, Prog, SRC>(c, ip, ni, out_cn, s);
-    case 2: return launch_t<CN, NPL, 2, Prog, SRC>(c, ip, ni, out_cn, s);
-    default: return launch_t<CN, NPL, 4, Prog, SRC>(c, ip, ni, out_cn, s);
+    case 1: return launch_t<CN, NPL, 1, Prog, SRC, OT>(c, ip, ni, out_cn, s);
+    case 2: return launch_t<CN, NPL, 2, Prog, SRC, OT>(c, ip, ni, out_cn, s);
+    default: return launch_t<CN, NPL, 4, Prog, SRC, OT>(c, ip, ni, out_cn, s);
     }
 }
 
-template <int CN, class Prog, int SRC>
+template <int CN, class Prog, int SRC, typename OT>
 static hipError_t launch_npl(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
                              hipStream_t s) {
-    if (table) return launch_rpw<CN, 0, Prog, SRC>(rpw, c, ip, ni, out_cn, s);
-    return launch_rpw<CN, CVGS_KERNARG_PLANES, Prog, SRC>(rpw, c, ip, ni, out_cn, s);
+    if (table) return launch_rpw<CN, 0, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
+    return launch_rpw<CN, CVGS_KERNARG_PLANES, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
 }
 
-template <int CN, int SRC>
+template <int CN, int SRC, typename OT = float>
 static hipError_t launch_prog(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
                               hipStream_t s) {
-    if (prog_id == 0) return launch_npl<CN, ProgSwapMulSubDiv, SRC>(table, rpw, c, ip, ni, out_cn, s);
-    if (prog_id == 1) return launch_npl<CN, ProgMulSubDiv, SRC>(table, rpw, c, ip, ni, out_cn, s);
-    return launch_npl<CN, InterpProg, SRC>(table, rpw, c, ip, ni, out_cn, s);
+    if (prog_id == 0) return launch_npl<CN, ProgSwapMulSubDiv, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
+    if (prog_id == 1) return launch_npl<CN, ProgMulSubDiv, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
+    return launch_npl<CN, InterpProg, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
 }
 
 // program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
@@ -385,17 +388,30 @@ static int classify_program(const ProgArgs& p, int cn) {
     return 2;
 }
 
-int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
+int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
               void* stream, bool dry_run, LaunchInfo* info) {
-    const ReadArgs& r = c.read;
-    // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write
+    const ReadArgs& r = c_in.read;
+    // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write -- or, for 8U sources, an fp16 planar
+    // tensor whose conversion is the chain's LAST stage (the half-precision hand-off option)
     if (r.kind != CVGS_READ_RESIZE_LINEAR || (r.cn != 3 && r.cn != 4)) return 0;
     if (r.depth != CVGS_DEPTH_8U && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S) return 0;
-    if (c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return 0;
-    if (c.write.depth != CVGS_DEPTH_32F) return 0;
+    if (c_in.write.kind != CVGS_WRITE_TENSOR_SPLIT && c_in.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return 0;
     if (r.batch > 65535) return 0;
-    for (int k = 0; k < c.prog.n; ++k) // value must stay fp32 through the program
-        if (c.prog.opcode[k] == CVGS_OP_CAST) return 0;
+    const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
+    if (!f16 && c_in.write.depth != CVGS_DEPTH_32F) return 0;
+    int n_prog = c_in.prog.n;
+    if (f16) {
+        if (r.depth != CVGS_DEPTH_8U || n_prog < 1 || c_in.prog.opcode[n_prog - 1] != CVGS_OP_CAST) return 0;
+        --n_prog; // the trailing CAST(CV_16F) happens in the store
+    }
+    for (int k = 0; k < n_prog; ++k) // value must stay fp32 through the program
+        if (c_in.prog.opcode[k] == CVGS_OP_CAST) return 0;
+    ChainArgs c_cut;
+    if (f16) {
+        c_cut = c_in;
+        c_cut.prog.n = n_prog;
+    }
+    const ChainArgs& c = f16 ? c_cut : c_in;
 
     // rows per wave: small launches are latency bound -> maximum parallelism (1 row per wave);
     // large ones amortise the column geometry over more rows (measured: tools/k1_ab.py).
@@ -414,7 +430,9 @@ int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline
              {"k1_u16c4_swap_mul_sub_div", "k1_u16c4_mul_sub_div", "k1_u16c4_interp"}},
             {{"k1_s16c3_swap_mul_sub_div", "k1_s16c3_mul_sub_div", "k1_s16c3_interp"},
              {"k1_s16c4_swap_mul_sub_div", "k1_s16c4_mul_sub_div", "k1_s16c4_interp"}}};
-        info->kernel = names[src][r.cn == 4][prog_id];
+        static const char* names16[2][3] = {{"k1_u8c3_swap_mul_sub_div_f16", "k1_u8c3_mul_sub_div_f16", "k1_u8c3_interp_f16"},
+                                            {"k1_u8c4_swap_mul_sub_div_f16", "k1_u8c4_mul_sub_div_f16", "k1_u8c4_interp_f16"}};
+        info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
     }
     if (dry_run) return 1;
     (void)chain_flags;
@@ -422,7 +440,10 @@ int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline
     hipStream_t s = (hipStream_t)stream;
     const int out_cn = c.write.cn;
     hipError_t e;
-    if (r.cn == 3) {
+    if (f16) {
+        e = r.cn == 3 ? launch_prog<3, SRC_U8, _Float16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
+                      : launch_prog<4, SRC_U8, _Float16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
+    } else if (r.cn == 3) {
         e = src == SRC_U8    ? launch_prog<3, SRC_U8>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
             : src == SRC_U16 ? launch_prog<3, SRC_U16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
                              : launch_prog<3, SRC_S16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);

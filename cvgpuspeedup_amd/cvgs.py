@@ -11,12 +11,12 @@ import ctypes as C
 import struct
 
 from . import capi
-from .capi import (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S, DEPTH_32F, DEPTH_64F, make_type,
+from .capi import (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S, DEPTH_32F, DEPTH_64F, DEPTH_16F, make_type,
                    type_cn, type_depth)
 
 # ---- OpenCV type codes / enums (numeric values of OpenCV 4.x) ---------------------------------------
 for _d, _n in ((DEPTH_8U, "8U"), (DEPTH_8S, "8S"), (DEPTH_16U, "16U"), (DEPTH_16S, "16S"), (DEPTH_32S, "32S"),
-               (DEPTH_32F, "32F"), (DEPTH_64F, "64F")):
+               (DEPTH_32F, "32F"), (DEPTH_64F, "64F"), (DEPTH_16F, "16F")):
     globals()["CV_" + _n] = _d
     for _c in (1, 2, 3, 4):
         globals()["CV_%sC%d" % (_n, _c)] = make_type(_d, _c)
@@ -40,7 +40,8 @@ PRESERVE_AR, IGNORE_AR, PRESERVE_AR_RN_EVEN, PRESERVE_AR_LEFT = 0, 1, 2, 3  # cv
 NewestFirst, OldestFirst = capi.NEWEST_FIRST, capi.OLDEST_FIRST                # fk::CircularTensorOrder
 Standard, Transposed = capi.PLANES_STANDARD, capi.PLANES_TRANSPOSED            # fk::ColorPlanes
 
-_DEPTH_BYTES = {DEPTH_8U: 1, DEPTH_8S: 1, DEPTH_16U: 2, DEPTH_16S: 2, DEPTH_32S: 4, DEPTH_32F: 4, DEPTH_64F: 8}
+_DEPTH_BYTES = {DEPTH_8U: 1, DEPTH_8S: 1, DEPTH_16U: 2, DEPTH_16S: 2, DEPTH_32S: 4, DEPTH_32F: 4, DEPTH_64F: 8,
+                DEPTH_16F: 2}
 
 
 def elem_size(cv_type):
@@ -164,7 +165,8 @@ def convertTo(in_type, out_type, alpha=None, beta=None):
     od = type_depth(out_type)
     if alpha is None:
         return PointwiseIOp(in_type, out_type, [(capi.OP_CAST, od, None)])
-    integral = od in (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S)
+    # CV_16F (this engine's half hand-off type) is storage only: computed in float, rounded once at the end
+    integral = od in (DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S, DEPTH_16F)
     mid = DEPTH_32F if integral else od  # float for integral outputs, the output type (32F / 64F) otherwise
     f32 = lambda v: struct.unpack("f", struct.pack("f", float(v)))[0]  # the reference's parameters are `float`
     ops = [(capi.OP_CAST, mid, None), (capi.OP_MUL, 0, [f32(alpha)] * 4)]

@@ -20,6 +20,7 @@ template <> struct depth_base<CV_16S> { using type = short; };
 template <> struct depth_base<CV_32S> { using type = int; };
 template <> struct depth_base<CV_32F> { using type = float; };
 template <> struct depth_base<CV_64F> { using type = double; };
+template <> struct depth_base<CV_16F> { using type = _Float16; }; // engine extension: half-precision hand-off
 
 // scalar for one channel, HIP_vector_type<base, N> otherwise (uchar3, float4, ...)
 template <typename B, int CN> struct vec_of { using type = HIP_vector_type<B, CN>; };
@@ -28,7 +29,7 @@ template <typename B> struct vec_of<B, 1> { using type = B; };
 
 template <int CV_TYPE>
 struct cv2cuda_t {
-    static_assert(CV_MAT_CN(CV_TYPE) >= 1 && CV_MAT_CN(CV_TYPE) <= 4 && CV_MAT_DEPTH(CV_TYPE) <= CV_64F,
+    static_assert(CV_MAT_CN(CV_TYPE) >= 1 && CV_MAT_CN(CV_TYPE) <= 4 && CV_MAT_DEPTH(CV_TYPE) <= CV_16F,
                   "unsupported OpenCV type code");
     using base = typename detail::depth_base<CV_MAT_DEPTH(CV_TYPE)>::type;
     using type = typename detail::vec_of<base, CV_MAT_CN(CV_TYPE)>::type;
@@ -54,6 +55,7 @@ template <> struct base_depth<int> { static constexpr int value = CV_32S; };
 template <> struct base_depth<uint> { static constexpr int value = CV_32S; };
 template <> struct base_depth<float> { static constexpr int value = CV_32F; };
 template <> struct base_depth<double> { static constexpr int value = CV_64F; };
+template <> struct base_depth<_Float16> { static constexpr int value = CV_16F; };
 
 template <typename T>
 constexpr int cv_type_of = CV_MAKETYPE(base_depth<typename vector_traits<T>::base>::value, vector_traits<T>::cn);

@@ -57,7 +57,7 @@ namespace internal {
 template <int I, int O>
 inline auto convertToScaled(float alpha, const float* beta) {
     static_assert(CV_MAT_CN(I) == CV_MAT_CN(O), "convertTo does not support changing the number of channels, neither in cvGS nor in OpenCV. Please, use cvGS::cvtColor instead.");
-    constexpr bool integral = CV_MAT_DEPTH(O) <= CV_32S;
+    constexpr bool integral = CV_MAT_DEPTH(O) <= CV_32S || CV_MAT_DEPTH(O) == CV_16F; // CV_16F: storage only, rounded once
     constexpr int mid = integral ? CV_32F : CV_MAT_DEPTH(O);
     fk::PointwiseSeq<CUDA_T(I), CUDA_T(O)> seq;
     fk::ChainBuilder b;

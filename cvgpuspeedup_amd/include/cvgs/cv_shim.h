@@ -41,6 +41,7 @@ typedef unsigned int uint;
 #define CV_32S 4
 #define CV_32F 5
 #define CV_64F 6
+#define CV_16F 7 /* half-precision hand-off type (engine extension; OpenCV 4's numeric value) */
 #define CV_MAT_DEPTH_MASK (CV_DEPTH_MAX - 1)
 #define CV_MAT_DEPTH(flags) ((flags) & CV_MAT_DEPTH_MASK)
 #define CV_MAKETYPE(depth, cn) (CV_MAT_DEPTH(depth) + (((cn) - 1) << CV_CN_SHIFT))
@@ -50,7 +51,7 @@ typedef unsigned int uint;
     constexpr int CV_##D##C1 = CV_MAKETYPE(CV_##D, 1), CV_##D##C2 = CV_MAKETYPE(CV_##D, 2),                    \
                   CV_##D##C3 = CV_MAKETYPE(CV_##D, 3), CV_##D##C4 = CV_MAKETYPE(CV_##D, 4);
 CVGS_DECL_TYPES(8U) CVGS_DECL_TYPES(8S) CVGS_DECL_TYPES(16U) CVGS_DECL_TYPES(16S) CVGS_DECL_TYPES(32S)
-CVGS_DECL_TYPES(32F) CVGS_DECL_TYPES(64F)
+CVGS_DECL_TYPES(32F) CVGS_DECL_TYPES(64F) CVGS_DECL_TYPES(16F)
 #undef CVGS_DECL_TYPES
 
 namespace cv {
@@ -165,6 +166,7 @@ private:
         case CV_16S: ((short*)row)[e] = (short)std::nearbyint(clampd(v, -32768, 32767)); break;
         case CV_32S: ((int*)row)[e] = (int)std::nearbyint(clampd(v, -2147483648.0, 2147483647.0)); break;
         case CV_32F: ((float*)row)[e] = (float)v; break;
+        case CV_16F: ((_Float16*)row)[e] = (_Float16)v; break;
         default: ((double*)row)[e] = v; break;
         }
     }

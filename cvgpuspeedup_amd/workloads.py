@@ -90,7 +90,7 @@ def fixed_crops(n, w=60, h=120):
 
 
 def k1_chain(src_mat, crops, out_mat, dst=DST, cn=3, used=None, ar=cvgs.IGNORE_AR, background=None, swap=True,
-             src_depth=cvgs.CV_8U, table=None):
+             src_depth=cvgs.CV_8U, table=None, half=False):
     """The K1 chain exactly as the reference test spells it (test_batchresize_x_split3D.cu:311-319):
     resize -> cvtColor(RGB2BGR) -> multiply(0.3) -> subtract -> divide -> split(tensor)."""
     src_type = cvgs.make_type(src_depth, cn)
@@ -104,20 +104,39 @@ def k1_chain(src_mat, crops, out_mat, dst=DST, cn=3, used=None, ar=cvgs.IGNORE_A
         ops.append(cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f_type))
     elif swap and cn == 4:
         ops.append(cvgs.cvtColor(cvgs.COLOR_RGBA2BGRA, f_type))
-    ops += [cvgs.multiply(f_type, [K1_ALPHA] * cn), cvgs.subtract(f_type, K1_SUB[cn]),
-            cvgs.divide(f_type, K1_DIV[cn]), cvgs.split(f_type, out_mat, dst)]
+    ops += [cvgs.multiply(f_type, [K1_ALPHA] * cn), cvgs.subtract(f_type, K1_SUB[cn]), cvgs.divide(f_type, K1_DIV[cn])]
+    if half:  # the half-precision hand-off option: one extra convertTo, fp16 NCHW tensor
+        h_type = cvgs.make_type(cvgs.CV_16F, cn)
+        ops += [cvgs.convertTo(f_type, h_type), cvgs.split(h_type, out_mat, dst)]
+    else:
+        ops.append(cvgs.split(f_type, out_mat, dst))
     return ops
 
 
-def k1_algorithmic_bytes(crops, dst=DST, cn=3, src_elem=1, tapped_bytes_fn=None, desc_bytes=48):
-    """per crop, write = cn*4*dstW*dstH, read = distinct tapped source pixels * bytes per pixel,
-    plus the per-crop descriptor.  `tapped_bytes_fn(sw, sh, dw, dh, ar, bpp)` supplies the tap census."""
-    write = cn * 4 * dst[0] * dst[1]
+def _distinct_taps(src, n_out):
+    """Distinct source indices a stretch resize (IGNORE_AR) taps along one axis: for every output index d both
+    floor(d*f) and min(floor(d*f)+1, src-1), f = float32(1 / (n_out / src)) -- the kernel's own coordinate rule."""
+    f = np.float32(1.0 / (float(n_out) / float(src)))
+    a = np.floor(np.arange(n_out, dtype=np.float32) * f).astype(np.int64)
+    b = np.minimum(a + 1, src - 1)
+    return int(np.unique(np.concatenate([a, b])).size)
+
+
+def tapped_bytes(src_w, src_h, dst_w, dst_h, bytes_per_pixel):
+    """SURVEY.md 8d tap census of one K1 crop: taps are separable, so distinct pixels = ux * uy."""
+    return _distinct_taps(src_w, dst_w) * _distinct_taps(src_h, dst_h) * bytes_per_pixel
+
+
+def k1_algorithmic_bytes(crops, dst=DST, cn=3, src_elem=1, tapped_bytes_fn=None, desc_bytes=48, out_elem=4):
+    """per crop, write = cn*out_elem*dstW*dstH, read = distinct tapped source pixels * bytes per
+    pixel, plus the per-crop descriptor.  `tapped_bytes_fn(sw, sh, dw, dh, ar, bpp)` overrides the tap census
+    (tests pass the oracle's to cross-check this module's)."""
+    write = cn * out_elem * dst[0] * dst[1]
     total = 0
     for (_, _, w, h) in crops:
         if tapped_bytes_fn is not None:
             read = tapped_bytes_fn(w, h, dst[0], dst[1], cvgs.IGNORE_AR, cn * src_elem)
         else:
-            read = min(w, 2 * dst[0]) * min(h, 2 * dst[1]) * cn * src_elem  # upper bound
+            read = tapped_bytes(w, h, dst[0], dst[1], cn * src_elem)
         total += write + read + desc_bytes
     return total

@@ -48,7 +48,10 @@ typedef enum cvgs_status {
 
 /* Element types use OpenCV's numeric encoding so that the cv2cuda shims (reference
  * include/cv2cuda_types.cuh:34-61) need no translation table:
- *   type = depth + ((channels-1) << 3),  depth: 8U=0 8S=1 16U=2 16S=3 32S=4 32F=5 64F=6          */
+ *   type = depth + ((channels-1) << 3),  depth: 8U=0 8S=1 16U=2 16S=3 32S=4 32F=5 64F=6 16F=7
+ * CV_16F (IEEE binary16) is this engine's half-precision hand-off option (the reference has no
+ * half type): a storage format only -- per-pixel read source, CAST target (round-to-nearest-even, overflow to
+ * +-inf, like cv::saturate_cast<cv::float16_t>) and write type; arithmetic stages need a CAST to CV_32F first.  */
 #define CVGS_DEPTH_8U 0
 #define CVGS_DEPTH_8S 1
 #define CVGS_DEPTH_16U 2
@@ -56,6 +59,7 @@ typedef enum cvgs_status {
 #define CVGS_DEPTH_32S 4
 #define CVGS_DEPTH_32F 5
 #define CVGS_DEPTH_64F 6
+#define CVGS_DEPTH_16F 7
 #define CVGS_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
 #define CVGS_TYPE_DEPTH(t) ((t) & 7)
 #define CVGS_TYPE_CN(t) ((((t) >> 3) & 63) + 1)

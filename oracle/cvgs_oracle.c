@@ -41,12 +41,57 @@ int oracle_max_threads(void) {
 static int depth_bytes(int depth) {
     switch (depth) {
     case CVGS_DEPTH_8U: case CVGS_DEPTH_8S: return 1;
-    case CVGS_DEPTH_16U: case CVGS_DEPTH_16S: return 2;
+    case CVGS_DEPTH_16U: case CVGS_DEPTH_16S: case CVGS_DEPTH_16F: return 2;
     case CVGS_DEPTH_32S: case CVGS_DEPTH_32F: return 4;
     case CVGS_DEPTH_64F: return 8;
     }
     return 0;
 }
+
+/* CV_16F (IEEE binary16), the half-precision hand-off option of include/cvgs_hip.h -- an extension: the reference
+ * has no half type, so this restates IEEE 754 conversion (round to nearest even, overflow to infinity, subnormals
+ * kept), which is what cv::saturate_cast<cv::float16_t>(float) and the GPU's v_cvt_f16_f32 do.  gcc 11 has no
+ * _Float16 on x86-64, hence the bit-level spelling; tests/test_oracle_independent.py checks it against numpy. */
+static uint16_t half_bits_from_float(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t mag = u & 0x7fffffffu;
+    if (mag >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (mag > 0x7f800000u ? 0x200u | ((mag >> 13) & 0x3ffu) : 0u));
+    if (mag >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); /* >= 65520: rounds to infinity */
+    if (mag < 0x33000001u) return (uint16_t)sign;              /* <= 2^-25: rounds to zero (tie goes to even = 0) */
+    int exp = (int)(mag >> 23) - 127;
+    uint32_t man = (mag & 0x7fffffu) | 0x800000u; /* 24-bit significand */
+    int shift = exp < -14 ? 13 + (-14 - exp) : 13; /* bits dropped; subnormal halves drop more */
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+    uint32_t h;
+    if (exp < -14) h = q;                                   /* subnormal (a carry into 0x400 is the smallest normal) */
+    else h = ((uint32_t)(exp + 15) << 10) + (q - 0x400u);   /* a carry out of the significand bumps the exponent */
+    return (uint16_t)(sign | h);
+}
+
+static float float_from_half_bits(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t u;
+    if (exp == 0x1fu) u = sign | 0x7f800000u | (man << 13);
+    else if (exp) u = sign | ((exp + 112u) << 23) | (man << 13);
+    else if (!man) u = sign;
+    else { /* subnormal: value = man * 2^-24, exact in fp32 */
+        float f = (float)man * 5.9604644775390625e-08f;
+        memcpy(&u, &f, 4);
+        u |= sign;
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+uint16_t oracle_float_to_half(float v) { return half_bits_from_float(v); }
+float oracle_half_to_float(uint16_t h) { return float_from_half_bits(h); }
+static float round_half(float v) { return float_from_half_bits(half_bits_from_float(v)); }
 
 /* fk::PerThreadRead<_2D,T>::exec: *(T*)((char*)data + y*pitch + x*sizeof(T))   [FKL]
  * (the reference builds it from a GpuMat at include/cvGPUSpeedup.cuh:40-44,613-615). */
@@ -65,6 +110,7 @@ static void load_pixel(const cvgs_image2d* im, int type, int x, int y, opx* p) {
         case CVGS_DEPTH_32S: p->i[c] = ((const int32_t*)row)[e]; break;
         case CVGS_DEPTH_32F: p->f[c] = ((const float*)row)[e]; break;
         case CVGS_DEPTH_64F: p->d[c] = ((const double*)row)[e]; break;
+        case CVGS_DEPTH_16F: p->f[c] = float_from_half_bits(((const uint16_t*)row)[e]); break;
         default: p->f[c] = 0.f;
         }
     }
@@ -208,7 +254,7 @@ static void background_pixel(const cvgs_read_desc* rd, int depth, int cn, opx* p
     p->depth = depth;
     p->cn = cn;
     for (int c = 0; c < cn; ++c) {
-        p->f[c] = rd->background[c];
+        p->f[c] = depth == CVGS_DEPTH_16F ? round_half(rd->background[c]) : rd->background[c];
         p->i[c] = (int32_t)rd->background[c];
         p->d[c] = (double)rd->background[c];
     }
@@ -268,11 +314,18 @@ static void int_range(int depth, int64_t* lo, int64_t* hi) {
 }
 
 static void op_cast(opx* p, int dst_depth) {
-    const int src_depth = p->depth;
+    int src_depth = p->depth;
+    if (src_depth == dst_depth) return;
+    if (src_depth == CVGS_DEPTH_16F) src_depth = CVGS_DEPTH_32F; /* a half value is carried as the float it equals */
+    p->depth = dst_depth;
     if (src_depth == dst_depth) return;
     int64_t lo, hi;
     int_range(dst_depth, &lo, &hi);
     for (int c = 0; c < p->cn; ++c) {
+        if (dst_depth == CVGS_DEPTH_16F) {
+            p->f[c] = round_half(src_depth == CVGS_DEPTH_32S ? (float)p->i[c] : src_depth == CVGS_DEPTH_64F ? (float)p->d[c] : p->f[c]);
+            continue;
+        }
         if (dst_depth == CVGS_DEPTH_64F) { /* every narrower type converts exactly */
             p->d[c] = src_depth == CVGS_DEPTH_32S ? (double)p->i[c] : (double)p->f[c];
             continue;
@@ -351,7 +404,7 @@ static int apply_op(const cvgs_op* op, opx* p) {
     /* *2GRAY: CCIR 601 luma, KATs RGB(10,100,200) -> 84, BGR -> 120
      * (reference tests/color/test_cvtColor.cu:36,115-123). */
     case CVGS_OP_GRAY: {
-        if (p->depth == CVGS_DEPTH_32S || p->depth == CVGS_DEPTH_64F) return CVGS_ERR_UNSUPPORTED;
+        if (p->depth == CVGS_DEPTH_32S || p->depth == CVGS_DEPTH_64F || p->depth == CVGS_DEPTH_16F) return CVGS_ERR_UNSUPPORTED;
         const float r = p->f[op->aux & 3], g = p->f[(op->aux >> 2) & 3], b = p->f[(op->aux >> 4) & 3];
         float lum = (r * 0.299f + g * 0.587f) + b * 0.114f;
         if (p->depth != CVGS_DEPTH_32F) lum = nearbyintf(lum);
@@ -373,6 +426,7 @@ static void store_elem(void* base, size_t elem_index, int depth, const opx* p, i
     case CVGS_DEPTH_32S: ((int32_t*)base)[elem_index] = p->i[c]; break;
     case CVGS_DEPTH_32F: ((float*)base)[elem_index] = p->f[c]; break;
     case CVGS_DEPTH_64F: ((double*)base)[elem_index] = p->d[c]; break;
+    case CVGS_DEPTH_16F: ((uint16_t*)base)[elem_index] = half_bits_from_float(p->f[c]); break;
     }
 }
 

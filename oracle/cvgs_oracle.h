@@ -57,6 +57,10 @@ int oracle_circular_destroy(oracle_circular_t ct);
 
 /* Algorithmic read bytes of a K1 plane: 3 * ux * uy distinct tapped source
  * pixels times bytes per pixel. */
+/* CV_16F conversions (round to nearest even; see cvgs_oracle.c) */
+uint16_t oracle_float_to_half(float v);
+float oracle_half_to_float(uint16_t h);
+
 int64_t oracle_resize_tapped_bytes(int32_t src_w, int32_t src_h, int32_t dst_w, int32_t dst_h,
                                    int32_t aspect_ratio, int32_t bytes_per_pixel);
 

@@ -113,6 +113,39 @@ static void test_random_vs_oracle(cv::cuda::Stream& stream) {
     CHECK(bit_equal(h.data(), hr.data(), n * sizeof(float)), "facade == raw C-ABI descriptor");
 }
 
+// half-precision hand-off (engine extension): the same chain + convertTo<CV_32FCn, CV_16FCn> -> fp16 NCHW
+template <int TI, int BATCH>
+static void test_half_handoff(cv::cuda::Stream& stream) {
+    constexpr int CN = CV_MAT_CN(TI);
+    constexpr int TF = CV_MAKETYPE(CV_32F, CN), TH = CV_MAKETYPE(CV_16F, CN);
+    const Params& p = kParams[CN - 1];
+    const cv::Size up(64, 128);
+    cv::Mat h_frame(720, 1280, TI);
+    fill_random(h_frame, 0xC0FFEEull + 1600 + TI);
+    cv::cuda::GpuMat d_frame(h_frame);
+    cv::cuda::GpuMat hv_frame = host_view(h_frame);
+    std::array<cv::cuda::GpuMat, BATCH> crops, h_crops;
+    for (int i = 0; i < BATCH; ++i) {
+        const int w = 4 + (i * 41) % 400, hgt = 9 + (i * 59) % 600, x = (i * 97) % (1280 - w), y = (i * 71) % (720 - hgt);
+        crops[i] = d_frame(cv::Rect(x, y, w, hgt));
+        h_crops[i] = hv_frame(cv::Rect(x, y, w, hgt));
+    }
+    const size_t n = (size_t)BATCH * CN * up.width * up.height;
+    cv::cuda::GpuMat d_tensor(BATCH, up.width * up.height * CN, CV_16F);
+    cv::Mat h_ref(BATCH, up.width * up.height * CN, CV_16F);
+    cv::cuda::GpuMat hv_ref = host_view(h_ref);
+    auto chain = [&](const std::array<cv::cuda::GpuMat, BATCH>& in, const cv::cuda::GpuMat& out) {
+        return std::make_tuple(cvGS::resize<TI, cv::INTER_LINEAR, BATCH, cvGS::IGNORE_AR>(in, up, BATCH, cvGS::cvScalar_set<TF>(0.f)),
+                               cvGS::multiply<TF>(p.alpha), cvGS::subtract<TF>(p.sub), cvGS::divide<TF>(p.div),
+                               cvGS::convertTo<TF, TH>(), cvGS::split<TH>(out, up));
+    };
+    std::apply([&](const auto&... iops) { cvGS::executeOperations(stream, iops...); }, chain(crops, d_tensor));
+    std::apply([&](const auto&... iops) { run_oracle(iops...); }, chain(h_crops, hv_ref));
+    stream.waitForCompletion();
+    const auto h = fetch(d_tensor.data, n * 2);
+    CHECK(bit_equal(h.data(), h_ref.data, n * 2), "fp16 NCHW hand-off, bit-exact vs oracle, type " << TI);
+}
+
 template <int TI, int TO>
 static void sweep(cv::cuda::Stream& stream) {
     test_constant<TI, TO, 10, cvGS::IGNORE_AR>(stream, 60);
@@ -133,5 +166,7 @@ int main() {
     sweep<CV_16UC4, CV_32FC4>(stream);
     sweep<CV_16SC3, CV_32FC3>(stream);
     sweep<CV_16SC4, CV_32FC4>(stream);
+    test_half_handoff<CV_8UC3, 50>(stream);
+    test_half_handoff<CV_8UC4, 17>(stream);
     return report("test_batchresize_x_split3D + aspectratio");
 }

@@ -9,9 +9,9 @@ from cvgpuspeedup_amd import capi, cvgs
 
 KAT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")
 NP_DEPTH = {"8U": np.uint8, "8S": np.int8, "16U": np.uint16, "16S": np.int16, "32S": np.int32, "32F": np.float32,
-            "64F": np.float64}
+            "64F": np.float64, "16F": np.float16}
 CV_DEPTH = {"8U": cvgs.CV_8U, "8S": cvgs.CV_8S, "16U": cvgs.CV_16U, "16S": cvgs.CV_16S, "32S": cvgs.CV_32S,
-            "32F": cvgs.CV_32F, "64F": cvgs.CV_64F}
+            "32F": cvgs.CV_32F, "64F": cvgs.CV_64F, "16F": cvgs.CV_16F}
 CODES = {"RGB2BGR": cvgs.COLOR_RGB2BGR, "BGR2RGB": cvgs.COLOR_BGR2RGB, "RGBA2BGRA": cvgs.COLOR_RGBA2BGRA,
          "BGRA2RGBA": cvgs.COLOR_BGRA2RGBA, "RGB2GRAY": cvgs.COLOR_RGB2GRAY, "RGBA2GRAY": cvgs.COLOR_RGBA2GRAY,
          "BGR2GRAY": cvgs.COLOR_BGR2GRAY, "BGRA2GRAY": cvgs.COLOR_BGRA2GRAY}

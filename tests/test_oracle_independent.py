@@ -69,3 +69,19 @@ def test_preserve_ar_window(oracle):
     assert (got[:, :, 48:] == np.array([128, 64, 32], np.float32)[:, None, None]).all()
     inner = oracle_resize(oracle, img, (32, 128))
     assert (got[:, :, 16:48] == inner).all()
+
+
+def test_tap_census_of_the_bench_matches_the_oracle(oracle):
+    """bench.py prices roofline.achieved on cvgpuspeedup_amd.workloads.tapped_bytes (numpy); the oracle holds an
+    independent C census of the same SURVEY.md 8d quantity -- they must agree on every crop shape."""
+    from cvgpuspeedup_amd import workloads as W
+    rng = np.random.default_rng(3)
+    shapes = [(60, 120), (1, 1), (2, 3), (64, 128), (128, 256), (129, 257), (512, 1024), (31, 1000), (3840, 2160)]
+    shapes += [(int(w), int(h)) for w, h in zip(rng.integers(1, 600, 200), rng.integers(1, 1100, 200))]
+    for w, h in shapes:
+        assert W.tapped_bytes(w, h, 64, 128, 3) == oracle.tapped_bytes(w, h, 64, 128, cvgs.IGNORE_AR, 3), (w, h)
+    assert W.tapped_bytes(60, 120, 64, 128, 3) == 21600  # SURVEY.md 8d: upscaling taps every source pixel
+    crops = W.fixed_crops(50)
+    assert W.k1_algorithmic_bytes(crops, desc_bytes=0) == 5995200  # SURVEY.md 8d, cfg #2 fixed variant
+    crops = W.random_crops(50, 3840, 2160, seed=W.SEED + 500000)
+    assert W.k1_algorithmic_bytes(crops) == W.k1_algorithmic_bytes(crops, tapped_bytes_fn=oracle.tapped_bytes)

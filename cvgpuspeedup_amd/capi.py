@@ -19,6 +19,7 @@ KERNARG_PLANES = 64
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RCCL = 0, -1, -2, -3, -4, -5
 
 # depths / types (OpenCV encoding)
+CIRCULAR_MIRRORED = 1
 DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S, DEPTH_32F, DEPTH_64F, DEPTH_16F = range(8)
 
 
@@ -92,6 +93,7 @@ SYMBOLS = [
     ("cvgs_plane_table_bytes", C.c_size_t, [C.c_int32]),
     ("cvgs_plane_table_build", C.c_int, [C.POINTER(ReadDesc), C.c_void_p]),
     ("cvgs_circular_create", C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int32] * 8),
+    ("cvgs_circular_create_ex", C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int32] * 8 + [C.c_uint32]),
     ("cvgs_circular_update", C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
     ("cvgs_circular_data", C.c_void_p, [C.c_void_p]),
     ("cvgs_circular_bytes", C.c_size_t, [C.c_void_p]),

@@ -431,11 +431,22 @@ struct cvgs_circular_s {
     uint8_t* out;       // ordered tensor handed to the user (data())
     uint8_t* ring;      // history: update k lives in slot k % batch, standard [c][y][x] order
     int64_t count;
+    bool mirrored;      // ring of 2*batch slots, every frame stored twice, data() is a moving window; `out` unused
 };
 
 int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
                          int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode, int32_t device_id) {
+    return cvgs_circular_create_ex(out, width, height, elem_type, color_planes, batch, order, cp_mode, device_id, 0);
+}
+
+int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
+                            int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode, int32_t device_id,
+                            uint32_t flags) {
     if (!out) return fail(CVGS_ERR_INVALID, "null handle pointer");
+    if (flags & ~CVGS_CIRCULAR_MIRRORED) return fail(CVGS_ERR_INVALID, "unknown CircularTensor flags");
+    const bool mirrored = (flags & CVGS_CIRCULAR_MIRRORED) != 0;
+    if (mirrored && cp_mode != CVGS_PLANES_STANDARD)
+        return fail(CVGS_ERR_UNSUPPORTED, "mirrored CircularTensors exist in the Standard plane order only");
     if (width < 1 || height < 1 || color_planes < 1 || color_planes > 4 || batch < 1 || batch > 4096)
         return fail(CVGS_ERR_INVALID, "bad CircularTensor shape");
     const int esz = depth_bytes(CVGS_TYPE_DEPTH(elem_type)) * CVGS_TYPE_CN(elem_type);
@@ -450,10 +461,16 @@ int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, in
     ct->plane_bytes = (size_t)esz * width * height;
     ct->image_bytes = ct->plane_bytes * color_planes;
     const size_t total = ct->image_bytes * batch;
-    e = hipMalloc((void**)&ct->out, total);
-    if (e == hipSuccess) e = hipMalloc((void**)&ct->ring, total);
-    if (e == hipSuccess) e = hipMemset(ct->out, 0, total);
-    if (e == hipSuccess) e = hipMemset(ct->ring, 0, total);
+    ct->mirrored = mirrored;
+    if (mirrored) {
+        e = hipMalloc((void**)&ct->ring, 2 * total);
+        if (e == hipSuccess) e = hipMemset(ct->ring, 0, 2 * total);
+    } else {
+        e = hipMalloc((void**)&ct->out, total);
+        if (e == hipSuccess) e = hipMalloc((void**)&ct->ring, total);
+        if (e == hipSuccess) e = hipMemset(ct->out, 0, total);
+        if (e == hipSuccess) e = hipMemset(ct->ring, 0, total);
+    }
     if (e != hipSuccess) {
         if (ct->out) (void)hipFree(ct->out);
         if (ct->ring) (void)hipFree(ct->ring);
@@ -480,6 +497,30 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
             return fail(CVGS_ERR_INVALID, "packed write needs COLOR_PLANES == 1 and the tensor's element type");
     } else if (out_cn != ct->color_planes || CVGS_MAKETYPE(CVGS_TYPE_DEPTH(one.write.dst_type), 1) != ct->elem_type) {
         return fail(CVGS_ERR_INVALID, "split write does not match the tensor's planes / element type");
+    }
+    if (ct->mirrored) {
+        // ONE pass over the new frame, stored at slot p and at slot p+BATCH of a 2*BATCH ring; nothing is shifted.
+        // OldestFirst: p = k mod B, window starts at p+1.  NewestFirst: p = B-1 - k mod B, window starts at p.
+        Lowered L;
+        one.write.data = ct->ring;
+        one.write.width = ct->width;
+        one.write.height = ct->height;
+        one.write.planes = ct->batch;
+        int rc = lower(&one, true, L);
+        if (rc) return rc;
+        const int64_t km = ct->count % ct->batch;
+        const int64_t p = ct->order == CVGS_NEWEST_FIRST ? ct->batch - 1 - km : km;
+        const int64_t plane = (int64_t)ct->width * ct->height;
+        WriteArgs& Wa = L.args.write;
+        Wa.planes = 1;
+        Wa.data = ct->ring + (size_t)p * ct->image_bytes;
+        Wa.data2 = ct->ring + (size_t)(p + ct->batch) * ct->image_bytes;
+        Wa.img_stride = Wa.img_stride2 = wk == CVGS_WRITE_PIXEL_3D ? plane : plane * ct->color_planes;
+        Wa.ch_stride = Wa.ch_stride2 = wk == CVGS_WRITE_PIXEL_3D ? 0 : plane;
+        rc = dispatch(&one, L, (hipStream_t)stream, false, nullptr);
+        if (rc) return rc;
+        ct->count++;
+        return CVGS_OK;
     }
     // 1) ONE pass over the new frame writes it twice: into the history ring (slot = update index mod BATCH, always
     //    standard plane order) and into its slot of the ordered tensor (slot 0 NewestFirst / BATCH-1 OldestFirst).
@@ -545,13 +586,20 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     return CVGS_OK;
 }
 
-void* cvgs_circular_data(cvgs_circular_t ct) { return ct ? ct->out : nullptr; }
+void* cvgs_circular_data(cvgs_circular_t ct) {
+    if (!ct) return nullptr;
+    if (!ct->mirrored) return ct->out;
+    if (ct->count == 0) return ct->ring; // nothing pushed yet: any window is all zeros
+    const int64_t km = (ct->count - 1) % ct->batch;
+    const int64_t start = ct->order == CVGS_NEWEST_FIRST ? ct->batch - 1 - km : km + 1;
+    return ct->ring + (size_t)start * ct->image_bytes;
+}
 size_t cvgs_circular_bytes(cvgs_circular_t ct) { return ct ? ct->image_bytes * (size_t)ct->batch : 0; }
 int64_t cvgs_circular_updates(cvgs_circular_t ct) { return ct ? ct->count : -1; }
 
 int cvgs_circular_destroy(cvgs_circular_t ct) {
     if (!ct) return fail(CVGS_ERR_INVALID, "null handle");
-    (void)hipFree(ct->out);
+    if (ct->out) (void)hipFree(ct->out);
     (void)hipFree(ct->ring);
     delete ct;
     return CVGS_OK;

@@ -1,6 +1,6 @@
 // k_pointwise.hip -- thread-fused pointwise chains on u8 sources:
-//   PerThreadRead<_2D, uchar{1,2,3,4}> [batched] -> SaturateCast/Mul/Sub/Div/... -> fp32 planar tensor
-//   (TensorSplit / TensorTSplit, optionally mirrored into a second target) or packed fp32 pixels (2D / 3D).
+//   PerThreadRead<_2D, uchar{1,2,3,4}> [batched] -> SaturateCast/Mul/Sub/Div/... -> fp32 (or fp16) planar tensor
+//   (TensorSplit / TensorTSplit, optionally mirrored into a second target) or packed fp32 / fp16 pixels (2D / 3D).
 // The engine's counterpart of the reference's ENABLE_THREAD_FUSION=true fast path (reference
 // include/cvGPUSpeedup.cuh:464-473): each thread owns FOUR x-adjacent pixels, reads them with one
 // wide load (4*CN bytes) and writes 16-byte vectors.  Results are bit-identical to the interpreted kernel; chains it
@@ -15,6 +15,21 @@ typedef const __attribute__((address_space(1))) u32u* gp_u32;
 typedef const __attribute__((address_space(1))) uint8_t* gp_u8;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4u __attribute__((aligned(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16x4 f16x4u __attribute__((aligned(2)));
+
+// four consecutive output elements in one non-temporal vector store (fp16: the chain's trailing CAST(CV_16F) is this
+// round-to-nearest-even conversion)
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    f32x4 q = {a, b, c, d};
+    __builtin_nontemporal_store(q, (f32x4u*)p);
+}
+__device__ __forceinline__ void store4(_Float16* p, float a, float b, float c, float d) {
+    f16x4 q = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    __builtin_nontemporal_store(q, (f16x4u*)p);
+}
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(_Float16* p, float v) { *p = (_Float16)v; }
 
 using ProgCastMulSubDiv = StaticProg<CVGS_OP_CAST, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 using ProgCast = StaticProg<CVGS_OP_CAST>;
@@ -29,7 +44,7 @@ struct PwGeom {
     uint8_t* out2;
 };
 
-template <int CN, int NPL, class Prog>
+template <int CN, int NPL, class Prog, typename OT>
 __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const PwGeom g) {
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.z;
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (!rows[t]) continue;
-            float* o = (float*)rows[t] + (size_t)x0 * cn;
+            OT* o = (OT*)rows[t] + (size_t)x0 * cn;
             if (npx == 4) {
                 float flat[16];
 #pragma unroll
@@ -93,35 +108,31 @@ __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const
                     for (int ch = 0; ch < 4; ++ch)
                         if (ch < CN) flat[i * CN + ch] = px[i].v[ch];
 #pragma unroll
-                for (int v = 0; v < CN; ++v) {
-                    f32x4 q = {flat[4 * v], flat[4 * v + 1], flat[4 * v + 2], flat[4 * v + 3]};
-                    __builtin_nontemporal_store(q, (f32x4u*)(o + 4 * v));
-                }
+                for (int v = 0; v < CN; ++v) store4(o + 4 * v, flat[4 * v], flat[4 * v + 1], flat[4 * v + 2], flat[4 * v + 3]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int ch = 0; ch < 4; ++ch)
-                        if (i < npx && ch < CN) o[i * CN + ch] = px[i].v[ch];
+                        if (i < npx && ch < CN) store1(o + i * CN + ch, px[i].v[ch]);
             }
         }
     } else {
-        float* bases[2] = {(float*)g.out + (int64_t)z * g.img_stride, g.out2 ? (float*)g.out2 + (int64_t)z * g.img_stride2 : nullptr};
+        OT* bases[2] = {(OT*)g.out + (int64_t)z * g.img_stride, g.out2 ? (OT*)g.out2 + (int64_t)z * g.img_stride2 : nullptr};
         const int64_t chs[2] = {g.ch_stride, g.ch_stride2};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (!bases[t]) continue;
-            float* o = bases[t] + (int64_t)y * W + x0;
+            OT* o = bases[t] + (int64_t)y * W + x0;
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 if (ch < cn) {
                     if (npx == 4) {
-                        f32x4 q = {px[0].v[ch], px[1].v[ch], px[2].v[ch], px[3].v[ch]};
-                        __builtin_nontemporal_store(q, (f32x4u*)(o + (int64_t)ch * chs[t]));
+                        store4(o + (int64_t)ch * chs[t], px[0].v[ch], px[1].v[ch], px[2].v[ch], px[3].v[ch]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (i < npx) o[(int64_t)ch * chs[t] + i] = px[i].v[ch];
+                            if (i < npx) store1(o + (int64_t)ch * chs[t] + i, px[i].v[ch]);
                     }
                 }
             }
@@ -129,38 +140,57 @@ __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const
     }
 }
 
-template <int CN, class Prog>
+template <int CN, class Prog, typename OT>
 static hipError_t launch_pw(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
     const dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         a.c = c;
         a.planes[0] = PlaneParams{};
-        hipLaunchKernelGGL((k_pointwise4<CN, 0, Prog>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_pointwise4<CN, 0, Prog, OT>), grid, dim3(256), 0, s, a, g);
     } else {
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k_pointwise4<CN, CVGS_KERNARG_PLANES, Prog>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_pointwise4<CN, CVGS_KERNARG_PLANES, Prog, OT>), grid, dim3(256), 0, s, a, g);
     }
     return hipGetLastError();
 }
 
-template <int CN>
+template <int CN, typename OT>
 static hipError_t launch_pw_prog(int prog_id, const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
-    if (prog_id == 0) return launch_pw<CN, ProgCastMulSubDiv>(c, ip, ni, g, s);
-    if (prog_id == 1) return launch_pw<CN, ProgCast>(c, ip, ni, g, s);
-    return launch_pw<CN, InterpProg>(c, ip, ni, g, s);
+    if (prog_id == 0) return launch_pw<CN, ProgCastMulSubDiv, OT>(c, ip, ni, g, s);
+    if (prog_id == 1) return launch_pw<CN, ProgCast, OT>(c, ip, ni, g, s);
+    return launch_pw<CN, InterpProg, OT>(c, ip, ni, g, s);
+}
+
+template <typename OT>
+static hipError_t launch_pw_cn(int prog_id, const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    switch (c.read.cn) {
+    case 1: return launch_pw_prog<1, OT>(prog_id, c, ip, ni, g, s);
+    case 2: return launch_pw_prog<2, OT>(prog_id, c, ip, ni, g, s);
+    case 3: return launch_pw_prog<3, OT>(prog_id, c, ip, ni, g, s);
+    default: return launch_pw_prog<4, OT>(prog_id, c, ip, ni, g, s);
+    }
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
-int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
+int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
                      bool dry_run, LaunchInfo* info) {
-    const ReadArgs& r = c.read;
-    const WriteArgs& w = c.write;
+    const ReadArgs& r = c_in.read;
+    const WriteArgs& w = c_in.write;
     if (chain_flags & CVGS_CHAIN_NO_THREAD_FUSION) return 0;
     if (r.kind != CVGS_READ_PIXEL || r.depth != CVGS_DEPTH_8U || r.batch > 65535) return 0;
-    if (w.depth != CVGS_DEPTH_32F) return 0;
+    const bool f16 = w.depth == CVGS_DEPTH_16F;
+    if (!f16 && w.depth != CVGS_DEPTH_32F) return 0;
+    // fp16 targets: the chain ends with CAST(CV_16F); that conversion happens in the store
+    ChainArgs c_cut;
+    if (f16) {
+        if (c_in.prog.n < 2 || c_in.prog.opcode[c_in.prog.n - 1] != CVGS_OP_CAST) return 0;
+        c_cut = c_in;
+        c_cut.prog.n -= 1;
+    }
+    const ChainArgs& c = f16 ? c_cut : c_in;
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
     const bool packed = w.kind == CVGS_WRITE_PIXEL_2D || w.kind == CVGS_WRITE_PIXEL_3D;
     if (!planar && !packed) return 0;
@@ -178,8 +208,9 @@ int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n
     if (p.n == 4 && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV) prog_id = 0;
     else if (p.n == 1) prog_id = 1;
     if (info) {
-        static const char* names[3] = {"pointwise4_u8_cast_mul_sub_div", "pointwise4_u8_cast", "pointwise4_u8_interp"};
-        info->kernel = names[prog_id];
+        static const char* names[2][3] = {{"pointwise4_u8_cast_mul_sub_div", "pointwise4_u8_cast", "pointwise4_u8_interp"},
+                                          {"pointwise4_u8_cast_mul_sub_div_f16", "pointwise4_u8_cast_f16", "pointwise4_u8_interp_f16"}};
+        info->kernel = names[f16][prog_id];
     }
     if (dry_run) return 1;
 
@@ -188,7 +219,7 @@ int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n
     g.packed = packed ? 1 : 0;
     g.out = w.data; g.out2 = w.data2; g.pad = 0;
     if (packed) {
-        const int px_bytes = 4 * w.cn;
+        const int px_bytes = (f16 ? 2 : 4) * w.cn;
         g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * px_bytes;
         g.row_pitch2 = w.width * px_bytes;
         g.img_stride = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : (int64_t)w.img_stride * px_bytes; // bytes
@@ -200,13 +231,8 @@ int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n
         g.img_stride2 = w.img_stride2; g.ch_stride2 = w.ch_stride2;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    switch (r.cn) {
-    case 1: e = launch_pw_prog<1>(prog_id, c, inline_planes, n_inline, g, s); break;
-    case 2: e = launch_pw_prog<2>(prog_id, c, inline_planes, n_inline, g, s); break;
-    case 3: e = launch_pw_prog<3>(prog_id, c, inline_planes, n_inline, g, s); break;
-    default: e = launch_pw_prog<4>(prog_id, c, inline_planes, n_inline, g, s); break;
-    }
+    const hipError_t e = f16 ? launch_pw_cn<_Float16>(prog_id, c, inline_planes, n_inline, g, s)
+                             : launch_pw_cn<float>(prog_id, c, inline_planes, n_inline, g, s);
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 

@@ -524,9 +524,13 @@ inline void executeOperations(hipStream_t stream, const IOps&... iops) {
 }
 
 // ---- CircularTensor ------------------------------------------------------------------------------------------------
-template <typename T, int COLOR_PLANES, int BATCH, CircularTensorOrder ORDER, ColorPlanes MODE = ColorPlanes::Standard>
+// MIRRORED (engine extension, default off = the reference's behaviour): the opt-in mirrored-ring layout of
+// cvgs_circular_create_ex -- no shift traffic per update, but ptr()/data() MOVE with every update.
+template <typename T, int COLOR_PLANES, int BATCH, CircularTensorOrder ORDER, ColorPlanes MODE = ColorPlanes::Standard,
+          bool MIRRORED = false>
 class CircularTensor {
     static constexpr ND kND = MODE == ColorPlanes::Transposed ? T3D : _3D;
+    static_assert(!MIRRORED || MODE == ColorPlanes::Standard, "mirrored CircularTensors exist in the Standard plane order only");
 public:
     CircularTensor() = default;
     CircularTensor(uint w, uint h, int device = 0) { Alloc(w, h, device); }
@@ -535,8 +539,8 @@ public:
     ~CircularTensor() { if (handle_) (void)cvgs_circular_destroy(handle_); }
 
     void Alloc(uint w, uint h, int device = 0) {
-        detail::check_status(cvgs_circular_create(&handle_, (int)w, (int)h, cvGS::cv_type_of<T>, COLOR_PLANES, BATCH,
-                                                  (int)ORDER, (int)MODE, device));
+        detail::check_status(cvgs_circular_create_ex(&handle_, (int)w, (int)h, cvGS::cv_type_of<T>, COLOR_PLANES, BATCH,
+                                                     (int)ORDER, (int)MODE, device, MIRRORED ? CVGS_CIRCULAR_MIRRORED : 0u));
         ptr_a.data = (T*)cvgs_circular_data(handle_);
         ptr_a.dims = {w, h, (uint)BATCH, (uint)COLOR_PLANES, (uint)(w * sizeof(T)), (uint)(w * sizeof(T) * h)};
     }
@@ -549,6 +553,7 @@ public:
         if (tsplit_needed != (b.d.write.kind == CVGS_WRITE_TENSOR_T_SPLIT))
             throw std::runtime_error("Need to use TensorTSplit as write function exactly when CP_MODE = Transposed");
         detail::check_status(cvgs_circular_update(handle_, &b.d, stream));
+        if constexpr (MIRRORED) ptr_a.data = (T*)cvgs_circular_data(handle_); // the window moved
     }
     RawPtr<kND, T> ptr() const { return ptr_a; }
     Dims3D dims() const { return ptr_a.dims; }

@@ -248,11 +248,24 @@ typedef enum cvgs_color_planes_mode { CVGS_PLANES_STANDARD = 0, CVGS_PLANES_TRAN
 int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
                          int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode,
                          int32_t device_id);
+/* Opt-in variant ("mirrored ring"): the tensor lives in a ring of 2*BATCH image slots and every
+ * new frame is written to slot p and to slot p+BATCH, so the BATCH most recent frames are ALWAYS contiguous and in
+ * order somewhere in the ring.  An update then costs one fused pass over the new frame (two stores per element) and
+ * NO shift traffic: ~50 MB instead of ~800 MB per update at cfg #4.  The price is the API break the reference
+ * cannot make: cvgs_circular_data() MOVES with every update (call it after each update), and only the Standard
+ * plane order (N,C,H,W) exists.  Tensor contents at data() are identical to the default mode's.                */
+#define CVGS_CIRCULAR_MIRRORED 1u
+int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
+                            int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode,
+                            int32_t device_id, uint32_t flags);
 /* update(stream, [GpuMat,] iops..., write) (:612-622): `chain` carries the read stage (batch 1),
  * the pointwise stages and the write KIND (TENSOR_SPLIT / TENSOR_T_SPLIT / PIXEL_3D); the write
- * target is the handle's own tensor (write.data is ignored).  One kernel launch.               */
+ * target is the handle's own tensor (write.data is ignored).  The new frame is computed ONCE by the fused chain
+ * kernel, which stores it both into its slot of the ordered tensor and into the history ring; one plane-copy
+ * kernel then moves the BATCH-1 older frames from the ring to their new slots (mirrored handles: no copy).      */
 int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_stream_t stream);
-/* data() (:624-626): device pointer of the ordered output tensor; stable for the handle's life. */
+/* data() (:624-626): device pointer of the ordered output tensor; stable for the handle's life
+ * (mirrored handles: the window of the LAST update -- it moves).                                 */
 void* cvgs_circular_data(cvgs_circular_t ct);
 size_t cvgs_circular_bytes(cvgs_circular_t ct);
 /* number of updates so far (the reference keeps this host-side ring index private)             */

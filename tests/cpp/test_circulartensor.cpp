@@ -69,11 +69,13 @@ static void testOldestFirstCircularTensorcvGS_noSplit() {
 
 // cfg #4 in small: every update resizes + normalizes a NEW frame into the tensor; checked against the oracle's
 // CircularTensor restatement after every update.
+// MIRRORED = true: the opt-in mirrored-ring layout must show the SAME tensor at data() (which then moves every update).
+template <fk::CircularTensorOrder ORDER, bool MIRRORED>
 static void testResizeNormalizePush() {
     constexpr uint B = 6, W = 96, H = 54;
-    cvGS::CircularTensor<CV_8UC3, CV_32F, 3, B, fk::CircularTensorOrder::NewestFirst> myTensor(W, H);
+    cvGS::CircularTensor<CV_8UC3, CV_32F, 3, B, ORDER, fk::ColorPlanes::Standard, MIRRORED> myTensor(W, H);
     oracle_circular_t oc = nullptr;
-    CHECK(oracle_circular_create(&oc, W, H, CV_32FC1, 3, B, CVGS_NEWEST_FIRST, CVGS_PLANES_STANDARD) == 0, "oracle circular create");
+    CHECK(oracle_circular_create(&oc, W, H, CV_32FC1, 3, B, (int)ORDER, CVGS_PLANES_STANDARD) == 0, "oracle circular create");
     cv::cuda::Stream cv_stream;
     const cv::Scalar sub(1.f, 4.f, 3.2f), div(3.2f, 0.6f, 11.8f), alpha(0.3, 0.3, 0.3);
     bool ok = true;
@@ -91,7 +93,8 @@ static void testResizeNormalizePush() {
         const auto h = fetch(myTensor.data(), myTensor.sizeInBytes());
         ok = ok && bit_equal(h.data(), oracle_circular_data(oc), h.size());
     }
-    CHECK(ok, "CircularTensor push with resize + normalize, bit-exact vs oracle after every update");
+    CHECK(ok, "CircularTensor push with resize + normalize, bit-exact vs oracle after every update (order " << (int)ORDER
+                  << ", mirrored " << MIRRORED << ")");
     oracle_circular_destroy(oc);
 }
 
@@ -100,6 +103,9 @@ int main() {
     testTransposedCircularTensorcvGS<CV_8UC3, CV_32FC3, fk::CircularTensorOrder::NewestFirst>();
     testTransposedCircularTensorcvGS<CV_8UC3, CV_32FC3, fk::CircularTensorOrder::OldestFirst>();
     testOldestFirstCircularTensorcvGS_noSplit();
-    testResizeNormalizePush();
+    testResizeNormalizePush<fk::CircularTensorOrder::NewestFirst, false>();
+    testResizeNormalizePush<fk::CircularTensorOrder::OldestFirst, false>();
+    testResizeNormalizePush<fk::CircularTensorOrder::NewestFirst, true>();
+    testResizeNormalizePush<fk::CircularTensorOrder::OldestFirst, true>();
     return report("test_circulartensor");
 }

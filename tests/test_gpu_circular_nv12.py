@@ -173,3 +173,42 @@ def test_nv12_full_resolution_convert(oracle):
                                cvgs.convertTo(f, u), cvgs.write(u, cvgs.GpuMat.from_array(r, u))]))
     H.assert_bit_exact(g.cpu().numpy(), r, "NV12 full-res")
     assert (r[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("order", [cvgs.NewestFirst, cvgs.OldestFirst])
+@pytest.mark.parametrize("write", ["split", "packed"])
+def test_mirrored_circular_tensor_matches_default_semantics(oracle, order, write):
+    """The opt-in mirrored-ring CircularTensor (cvgs_circular_create_ex): no shift traffic, data()
+    moves -- but the tensor seen at data() after every update is the one the reference semantics (oracle) give."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H_, B = 72, 40, 5
+    packed = write == "packed"
+    cp, elem = (1, cvgs.CV_32FC3) if packed else (3, cvgs.CV_32FC1)
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, elem, cp, B, order, cvgs.Standard, W, H_, mirrored=True)
+    oc = oracle.OracleCircular(W, H_, elem, cp, B, order, cvgs.Standard)
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    seen = set()
+    zeros = _read_device(ct.data(), ct.nbytes())
+    assert not zeros.any()
+    for i in range(3 * B + 2):
+        frame = H.random_u8((H_, W, 3), seed=4000 + i)
+        frame_t = torch.from_numpy(frame).to(dev)
+        pw = [cvgs.convertTo(cvgs.CV_8UC3, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3])]
+        wr = ct.write_packed(f) if packed else ct.write_split(f)
+        ct.update(s, cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), *pw, wr)
+        kind = capi.WRITE_PIXEL_3D if packed else capi.WRITE_TENSOR_SPLIT
+        oc.update(cvgs.lower([cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)], 1),
+                              *pw, cvgs.WriteIOp(kind, f, 16, W, H_, 0, B)]))
+        torch.cuda.synchronize()
+        seen.add(ct.data())
+        got = _read_device(ct.data(), ct.nbytes()).view(np.float32)
+        H.assert_bit_exact(got, oc.array(np.float32), "mirrored circular update %d" % i)
+    assert len(seen) == B  # the window really moves: B distinct positions
+    ct.release()
+
+
+def test_mirrored_circular_tensor_rejects_transposed():
+    with pytest.raises(capi.CvgsError, match="Standard plane order"):
+        cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, 4, cvgs.NewestFirst, cvgs.Transposed, 16, 16, mirrored=True)

@@ -31,14 +31,18 @@ def events_time(fn, iters, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def cfg4(dev, iters, resize_from_4k=False):
+def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False):
     Wd, Hd, B = 1920, 1080, 16
-    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard, Wd, Hd)
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_16FC1 if half else cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard,
+                             Wd, Hd, mirrored=mirrored)
     f = cvgs.CV_32FC3
+    ft = cvgs.CV_16FC3 if half else f  # type written into the tensor
     src_wh = W.FRAME_4K if resize_from_4k else (Wd, Hd)
     frames = [W.random_u8_torch((src_wh[1], src_wh[0], 3), 300 + i, dev) for i in range(8)]
     s = torch.cuda.current_stream()
     pw = [cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3])]
+    if half:
+        pw.append(cvgs.convertTo(f, ft))
     state = {"i": 0}
 
     def update():
@@ -46,17 +50,19 @@ def cfg4(dev, iters, resize_from_4k=False):
         state["i"] += 1
         m = cvgs.GpuMat.from_tensor(fr, cvgs.CV_8UC3)
         if resize_from_4k:
-            ct.update(s, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, m, (Wd, Hd)), *pw, ct.write_split(f))
+            ct.update(s, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, m, (Wd, Hd)), *pw, ct.write_split(ft))
         else:
-            ct.update(s, m, cvgs.convertTo(cvgs.CV_8UC3, f), *pw, ct.write_split(f))
+            ct.update(s, m, cvgs.convertTo(cvgs.CV_8UC3, f), *pw, ct.write_split(ft))
 
     t = events_time(update, iters)
-    plane = Wd * Hd * 3 * 4
-    # read = src_frame_bytes + (B-1)*P, write = B*P + P(ring); 4K->1080p taps every source pixel
+    plane = Wd * Hd * 3 * (2 if half else 4)
+    # read = src_frame_bytes + (B-1)*P, write = B*P + P(ring); 4K->1080p taps every source pixel.
+    # Mirrored ring (opt-in): read = src frame, write = 2*P, nothing is shifted.
     src = src_wh[0] * src_wh[1] * 3
-    alg = src + (B - 1) * plane + B * plane + plane
+    alg = src + 2 * plane if mirrored else src + (B - 1) * plane + B * plane + plane
     ct.release()
-    return {"config": "cfg4 CircularTensor depth 16, 1080p fp32 x3, push %s" % (
+    return {"config": "cfg4 CircularTensor depth 16, 1080p %s x3%s, push %s" % (
+                "fp16" if half else "fp32", " MIRRORED ring (opt-in, data() moves)" if mirrored else "",
                 "4K->1080p resize+normalize" if resize_from_4k else "1080p convert+normalize"),
             "us_per_update": round(t * 1e6, 2), "algorithmic_bytes": alg, "GB_per_s": round(alg / t / 1e9, 1),
             "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4), "updates_per_s": round(1 / t, 1)}
@@ -100,6 +106,9 @@ def run_all(dev, iters=100, only=""):
     if only in ("", "cfg4"):
         res.append(cfg4(dev, iters, False))
         res.append(cfg4(dev, iters, True))
+        res.append(cfg4(dev, iters, False, half=True))
+        res.append(cfg4(dev, iters, False, mirrored=True))
+        res.append(cfg4(dev, iters, True, mirrored=True))
     if only in ("", "cfg3"):
         res.append(cfg3(dev, iters))
     return res

@@ -36,14 +36,15 @@ def type_cn(t):
 
 
 # read kinds
-READ_PIXEL, READ_RESIZE_LINEAR, READ_NV12, READ_NV12_RESIZE_LINEAR = 0, 1, 2, 3
+READ_PIXEL, READ_RESIZE_LINEAR, READ_NV12, READ_NV12_RESIZE_LINEAR, READ_WARP_AFFINE, READ_WARP_PERSPECTIVE = range(6)
 # aspect ratio (same values as cvGS::AspectRatio)
 PRESERVE_AR, IGNORE_AR, PRESERVE_AR_RN_EVEN, PRESERVE_AR_LEFT = 0, 1, 2, 3
 YUV_FULL, YUV_LIMITED = 0, 1
 BT601, BT709 = 0, 1
 READ_FLAG_TABLE_ON_DEVICE = 1
 # opcodes
-(OP_NOP, OP_CAST, OP_MUL, OP_ADD, OP_SUB, OP_DIV, OP_REORDER, OP_ADD_ALPHA, OP_DROP_ALPHA, OP_GRAY) = range(10)
+(OP_NOP, OP_CAST, OP_MUL, OP_ADD, OP_SUB, OP_DIV, OP_REORDER, OP_ADD_ALPHA, OP_DROP_ALPHA, OP_GRAY,
+ OP_CAST_TRUNC) = range(11)
 # write kinds
 (WRITE_PIXEL_2D, WRITE_PIXEL_3D, WRITE_TENSOR_SPLIT, WRITE_TENSOR_T_SPLIT, WRITE_SPLIT_2D,
  WRITE_PIXEL_2D_BATCH) = range(6)
@@ -64,7 +65,7 @@ class ReadDesc(C.Structure):
                 ("src", C.c_void_p), ("dst_width", C.c_int32), ("dst_height", C.c_int32),
                 ("aspect_ratio", C.c_int32), ("flags", C.c_uint32), ("background", C.c_float * 4),
                 ("yuv_range", C.c_int32), ("yuv_primaries", C.c_int32), ("yuv_alpha", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("warp_matrices", C.POINTER(C.c_float))]
 
 
 class Op(C.Structure):
@@ -140,7 +141,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.cvgs_abi_version() != 1:
+    if lib.cvgs_abi_version() != 2:
         raise ImportError("libcvgs_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -38,6 +38,7 @@ int depth_bytes(int depth) {
 
 bool is_resize(int kind) { return kind == CVGS_READ_RESIZE_LINEAR || kind == CVGS_READ_NV12_RESIZE_LINEAR; }
 bool is_nv12(int kind) { return kind == CVGS_READ_NV12 || kind == CVGS_READ_NV12_RESIZE_LINEAR; }
+bool is_warp(int kind) { return kind == CVGS_READ_WARP_AFFINE || kind == CVGS_READ_WARP_PERSPECTIVE; }
 
 // Host half of fk::Resize::build: the kernel-side scale factors and the aspect-ratio window.
 // IGNORE_AR follows cv::cuda::resize's host code (scale = float(1.0 / (double(dst)/src))).
@@ -73,6 +74,7 @@ struct Lowered {
     Prog64Args p64{};
     bool uses_64f = false;
     std::vector<PlaneParams> planes;  // host copy (inline or to upload)
+    std::vector<WarpPlane> warp_planes; // WARP kinds (instead of `planes`)
     std::vector<DstPlane> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
     int out_w = 0, out_h = 0;
     int final_depth = 0, final_cn = 0;
@@ -87,6 +89,11 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
         case CVGS_OP_NOP: break;
         case CVGS_OP_CAST:
             if (op.aux < CVGS_DEPTH_8U || op.aux > CVGS_DEPTH_16F) return fail(CVGS_ERR_INVALID, "CAST: bad destination depth");
+            depth = op.aux;
+            break;
+        case CVGS_OP_CAST_TRUNC:
+            if (op.aux < CVGS_DEPTH_8U || op.aux > CVGS_DEPTH_16F) return fail(CVGS_ERR_INVALID, "CAST: bad destination depth");
+            if (op.aux == CVGS_DEPTH_64F || depth == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "fk::Cast on CV_64F values");
             depth = op.aux;
             break;
         case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
@@ -125,7 +132,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (ch->n_ops < 0 || ch->n_ops > CVGS_MAX_OPS) return fail(CVGS_ERR_INVALID, "n_ops out of range");
     const cvgs_read_desc& rd = ch->read;
     const cvgs_write_desc& wr = ch->write;
-    if (rd.kind < CVGS_READ_PIXEL || rd.kind > CVGS_READ_NV12_RESIZE_LINEAR) return fail(CVGS_ERR_INVALID, "bad read kind");
+    if (rd.kind < CVGS_READ_PIXEL || rd.kind > CVGS_READ_WARP_PERSPECTIVE) return fail(CVGS_ERR_INVALID, "bad read kind");
     if (rd.batch < 1 || rd.batch > 65535) return fail(CVGS_ERR_INVALID, "batch must be in [1, 65535]");
     if (rd.used_planes < 0 || rd.used_planes > rd.batch) return fail(CVGS_ERR_INVALID, "used_planes out of range");
     if (!rd.src) return fail(CVGS_ERR_INVALID, "read.src is null");
@@ -135,6 +142,11 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         return fail(CVGS_ERR_UNSUPPORTED, "CV_64F / CV_16F sources are supported for per-pixel reads only");
     if (is_nv12(rd.kind) && rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
         return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
+    if (is_warp(rd.kind)) {
+        if (rd.dst_width < 1 || rd.dst_height < 1) return fail(CVGS_ERR_INVALID, "warp target must be positive");
+        if (!rd.warp_matrices) return fail(CVGS_ERR_INVALID, "read.warp_matrices is null");
+        if (rd.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) return fail(CVGS_ERR_UNSUPPORTED, "warp reads take host descriptors");
+    }
     if (is_resize(rd.kind)) {
         if (rd.dst_width < 1 || rd.dst_height < 1) return fail(CVGS_ERR_INVALID, "resize target must be positive");
         if (rd.aspect_ratio < CVGS_PRESERVE_AR || rd.aspect_ratio > CVGS_PRESERVE_AR_LEFT)
@@ -165,8 +177,23 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             return fail(CVGS_ERR_INVALID, "device plane tables need dst_width/dst_height (the plane extent)");
     } else {
         const cvgs_image2d* src = (const cvgs_image2d*)rd.src;
-        L.planes.assign((size_t)rd.batch, PlaneParams{});
-        for (int z = 0; z < rd.used_planes; ++z) {
+        if (is_warp(rd.kind)) {
+            L.warp_planes.assign((size_t)rd.batch, WarpPlane{});
+            for (int z = 0; z < rd.used_planes; ++z) {
+                const cvgs_image2d& im = src[z];
+                if (!im.data || im.width < 1 || im.height < 1) return fail(CVGS_ERR_INVALID, "empty source plane");
+                if (im.step < im.width * depth_bytes(sdepth) * scn) return fail(CVGS_ERR_INVALID, "source step smaller than a row");
+                WarpPlane& P = L.warp_planes[(size_t)z];
+                P.data = (const uint8_t*)im.data;
+                P.w = im.width;
+                P.h = im.height;
+                P.step = im.step;
+                for (int k = 0; k < 9; ++k) P.m[k] = rd.warp_matrices[(size_t)z * 9 + k];
+            }
+        } else {
+            L.planes.assign((size_t)rd.batch, PlaneParams{});
+        }
+        for (int z = 0; z < (is_warp(rd.kind) ? 0 : rd.used_planes); ++z) {
             const cvgs_image2d& im = src[z];
             if (!im.data || im.width < 1 || im.height < 1) return fail(CVGS_ERR_INVALID, "empty source plane");
             const int esz = depth_bytes(sdepth) * scn;
@@ -182,7 +209,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             else if (im.width != src[0].width || im.height != src[0].height)
                 return fail(CVGS_ERR_INVALID, "batched pixel reads need planes of one size");
         }
-        if (R.is_resize) {
+        if (R.is_resize || is_warp(rd.kind)) {
             L.out_w = rd.dst_width;
             L.out_h = rd.dst_height;
         } else if (rd.used_planes > 0) {
@@ -213,11 +240,13 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         ++n;
     }
     Pg.n = n;
-    const int d0 = (R.is_resize || is_nv12(rd.kind)) ? CVGS_DEPTH_32F : sdepth;
+    const int d0 = (R.is_resize || is_nv12(rd.kind) || is_warp(rd.kind)) ? CVGS_DEPTH_32F : sdepth;
     int rc = walk_program(ch, d0, R.out_cn, &L.final_depth, &L.final_cn);
     if (rc) return rc;
     if (sdepth == CVGS_DEPTH_64F || L.final_depth == CVGS_DEPTH_64F) L.uses_64f = true;
     if (L.uses_64f && uses_16f) return fail(CVGS_ERR_UNSUPPORTED, "chains mixing CV_64F and CV_16F");
+    for (int k = 0; k < Pg.n; ++k)
+        if (L.uses_64f && Pg.opcode[k] == CVGS_OP_CAST_TRUNC) return fail(CVGS_ERR_UNSUPPORTED, "fk::Cast in a CV_64F chain");
 
     // ---- write stage ----
     if (wr.kind < CVGS_WRITE_PIXEL_2D || wr.kind > CVGS_WRITE_PIXEL_2D_BATCH) return fail(CVGS_ERR_INVALID, "bad write kind");
@@ -298,6 +327,31 @@ struct AsyncTable {
 
 int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry_run, LaunchInfo* info) {
     AsyncTable src_tab, dst_tab;
+    if (is_warp(L.args.read.kind)) {
+        if (L.uses_64f) return fail(CVGS_ERR_UNSUPPORTED, "warp chains on CV_64F values");
+        if (!L.dst_planes.empty()) {
+            if ((int)L.dst_planes.size() <= kInlineDst) {
+                for (size_t i = 0; i < L.dst_planes.size(); ++i) L.args.dst_inline[i] = L.dst_planes[i];
+            } else if (!dry_run) {
+                int rc = dst_tab.upload(L.dst_planes.data(), L.dst_planes.size() * sizeof(DstPlane), stream);
+                if (rc) return rc;
+                L.args.write.table = (const DstPlane*)dst_tab.dev;
+            }
+        }
+        const WarpPlane* dev = nullptr;
+        const int n = (int)L.warp_planes.size();
+        if (n > kInlineWarp) {
+            if (!dry_run) {
+                int rc = src_tab.upload(L.warp_planes.data(), L.warp_planes.size() * sizeof(WarpPlane), stream);
+                if (rc) return rc;
+                dev = (const WarpPlane*)src_tab.dev;
+            } else {
+                dev = (const WarpPlane*)(uintptr_t)16;
+            }
+        }
+        if (launch_warp(L.args, L.warp_planes.data(), n, dev, stream, dry_run, info)) return fail(CVGS_ERR_HIP, "warp kernel launch failed");
+        return CVGS_OK;
+    }
     const PlaneParams* inline_planes = L.planes.data();
     int n_inline = (int)L.planes.size();
     const int inline_cap = L.uses_64f ? kInline64 : CVGS_KERNARG_PLANES;
@@ -399,6 +453,7 @@ size_t cvgs_plane_table_bytes(int32_t batch) { return batch > 0 ? (size_t)batch 
 int cvgs_plane_table_build(const cvgs_read_desc* read, void* host_out) {
     if (!read || !host_out) return fail(CVGS_ERR_INVALID, "null argument");
     if (read->flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) return fail(CVGS_ERR_INVALID, "read.src must be a host cvgs_image2d array");
+    if (is_warp(read->kind)) return fail(CVGS_ERR_UNSUPPORTED, "plane tables exist for pixel / resize / NV12 reads");
     cvgs_chain_desc ch;
     std::memset(&ch, 0, sizeof(ch));
     ch.struct_size = sizeof(ch);

@@ -50,6 +50,7 @@ __device__ __forceinline__ void depth_range(int depth, float& lo, float& hi) {
 // work pixel as the float it converts to exactly
 __device__ __forceinline__ float round_half(float v) { return (float)(_Float16)v; }
 
+template <bool TRUNC = false>
 __device__ __forceinline__ void cast_px(Px& p, int cn, int src_depth, int dst_depth) {
     if (src_depth == dst_depth) return;
     if (src_depth == CVGS_DEPTH_16F) src_depth = CVGS_DEPTH_32F; // already an exact float
@@ -71,7 +72,7 @@ __device__ __forceinline__ void cast_px(Px& p, int cn, int src_depth, int dst_de
     if (dst_depth == CVGS_DEPTH_32S) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (c < cn) p.v[c] = from_int(src_depth == CVGS_DEPTH_32F ? sat_round_s32(p.v[c]) : (int)p.v[c]);
+            if (c < cn) p.v[c] = from_int(src_depth == CVGS_DEPTH_32F ? sat_round_s32(TRUNC ? truncf(p.v[c]) : p.v[c]) : (int)p.v[c]);
         return;
     }
     float lo, hi;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void cast_px(Px& p, int cn, int src_depth, int dst_de
                 iv = iv < (int)lo ? (int)lo : (iv > (int)hi ? (int)hi : iv);
                 p.v[c] = (float)iv;
             } else if (src_depth == CVGS_DEPTH_32F) {
-                p.v[c] = sat_round(v, lo, hi);
+                p.v[c] = sat_round(TRUNC ? truncf(v) : v, lo, hi); // fk::Cast: toward zero, then the same clamp
             } else {
                 p.v[c] = fminf(fmaxf(v, lo), hi);
             }
@@ -110,6 +111,10 @@ __device__ __forceinline__ void apply_op(int opc, int aux, const float* operand,
     switch (opc) {
     case CVGS_OP_CAST:
         cast_px(p, cn, depth, aux);
+        depth = aux;
+        break;
+    case CVGS_OP_CAST_TRUNC:
+        cast_px<true>(p, cn, depth, aux);
         depth = aux;
         break;
     case CVGS_OP_MUL:

@@ -111,11 +111,12 @@ class ReadIOp:
         self.background = _scalar(background if background is not None else [0.0] * 4)
         self.yuv = yuv or (capi.YUV_FULL, capi.BT601, 0)
         self.table = table  # device pointer of a prepared plane table (or None)
+        self.warp = None    # WARP kinds: batch x 9 floats, the inverse transforms
 
     def out_type(self):
         if self.kind == capi.READ_PIXEL:
             return self.src_type
-        if self.kind == capi.READ_RESIZE_LINEAR:
+        if self.kind in (capi.READ_RESIZE_LINEAR, capi.READ_WARP_AFFINE, capi.READ_WARP_PERSPECTIVE):
             return make_type(DEPTH_32F, type_cn(self.src_type))  # reference :227: CV_32F of same channels
         return make_type(DEPTH_32F, 4 if self.yuv[2] else 3)
 
@@ -146,6 +147,69 @@ def resize(src_type, interp, mats, dsize, used_planes=None, background=None, ar=
         w = int(round(mats[0].cols * fx))
         h = int(round(mats[0].rows * fy))
     return ReadIOp(capi.READ_RESIZE_LINEAR, src_type, mats, used_planes, (w, h), ar, background)
+
+
+WARP_AFFINE, WARP_PERSPECTIVE = 0, 1  # fk::WarpType
+
+
+def invert_affine(m):
+    """cv::invertAffineTransform on a 2x3 double matrix (the formula of OpenCV's imgwarp.cpp)."""
+    (a, b, tx), (c, d, ty) = [[float(v) for v in row] for row in m]
+    det = a * d - b * c
+    det = 1.0 / det if det != 0.0 else 0.0
+    a11, a22, a12, a21 = d * det, a * det, -b * det, -c * det
+    return [[a11, a12, -a11 * tx - a12 * ty], [a21, a22, -a21 * tx - a22 * ty]]
+
+
+def invert_3x3(m):
+    """cv::Mat::inv() of a 3x3 double matrix: OpenCV's closed form (adjugate / determinant); singular -> zeros."""
+    s = [[float(v) for v in row] for row in m]
+    det = (s[0][0] * (s[1][1] * s[2][2] - s[1][2] * s[2][1]) - s[0][1] * (s[1][0] * s[2][2] - s[1][2] * s[2][0]) +
+           s[0][2] * (s[1][0] * s[2][1] - s[1][1] * s[2][0]))
+    if det == 0.0:
+        return [[0.0] * 3 for _ in range(3)]
+    d = 1.0 / det
+    return [[(s[1][1] * s[2][2] - s[1][2] * s[2][1]) * d, (s[0][2] * s[2][1] - s[0][1] * s[2][2]) * d,
+             (s[0][1] * s[1][2] - s[0][2] * s[1][1]) * d],
+            [(s[1][2] * s[2][0] - s[1][0] * s[2][2]) * d, (s[0][0] * s[2][2] - s[0][2] * s[2][0]) * d,
+             (s[0][2] * s[1][0] - s[0][0] * s[1][2]) * d],
+            [(s[1][0] * s[2][1] - s[1][1] * s[2][0]) * d, (s[0][1] * s[2][0] - s[0][0] * s[2][1]) * d,
+             (s[0][0] * s[1][1] - s[0][1] * s[1][0]) * d]]
+
+
+def warp(warp_type, src_type, mats, transforms, dsize, used_planes=None, default_value=None):
+    """cvGS::warp<WT, InputType[, BATCH]>(input(s), transform_matrix(-ces) (forward, CV_64FC1), dstSize
+    [, usedPlanes, defaultValue]) (reference include/cvGPUSpeedup.cuh:288-442): the matrices are inverted on the
+    host in double (cv::invertAffineTransform / cv::Mat::inv) and narrowed to float."""
+    single = isinstance(mats, GpuMat)
+    mats = [mats] if single else list(mats)
+    transforms = [transforms] if single else list(transforms)
+    used = len(mats) if used_planes is None else int(used_planes)
+    flat = []
+    for i in range(len(mats)):
+        if i < used:
+            if mats[i].cv_type != src_type:
+                raise RuntimeError("Input type does not match the input type of the operation.")
+            if warp_type == WARP_AFFINE:
+                inv = invert_affine(transforms[i]) + [[0.0, 0.0, 1.0]]
+            else:
+                inv = invert_3x3(transforms[i])
+            flat += [struct.unpack("f", struct.pack("f", v))[0] for row in inv for v in row]
+        else:
+            flat += [0.0] * 9
+    kind = capi.READ_WARP_AFFINE if warp_type == WARP_AFFINE else capi.READ_WARP_PERSPECTIVE
+    rd = ReadIOp(kind, src_type, mats[:used] + [mats[0]] * (len(mats) - used), used, (int(dsize[0]), int(dsize[1])),
+                 IGNORE_AR, default_value)
+    rd.warp = flat
+    return rd
+
+
+def cast(in_type, out_type):
+    """fk::Cast<I, O>: static_cast per channel (truncating), as the reference's warp tests use it
+    (tests/warping/test_warping_opencv.cu:63)."""
+    if type_cn(in_type) != type_cn(out_type):
+        raise ValueError("Cast cannot change the number of channels")
+    return PointwiseIOp(in_type, out_type, [(capi.OP_CAST_TRUNC, type_depth(out_type), None)])
 
 
 def read_nv12(mat, dsize=None, color_range=capi.YUV_FULL, primaries=capi.BT709, alpha=True):
@@ -314,6 +378,10 @@ def lower(iops, flags=0):
     for i in range(4):
         r.background[i] = rd.background[i]
     r.yuv_range, r.yuv_primaries, r.yuv_alpha = rd.yuv
+    if rd.warp is not None:
+        wm = (C.c_float * len(rd.warp))(*rd.warp)
+        keep.append(wm)
+        r.warp_matrices = C.cast(wm, C.POINTER(C.c_float))
     cur = rd.out_type()
     n = 0
     for iop in iops[1:-1]:

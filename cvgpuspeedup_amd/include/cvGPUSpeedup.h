@@ -9,7 +9,7 @@
 // Each builder returns a typed IOp value (fk_compat.h); executeOperations checks the type chain at compile time,
 // lowers the list to ONE cvgs_chain_desc and calls cvgs_execute() (include/cvgs_hip.h) -> ONE HIP kernel.  All
 // calls are asynchronous on the given stream and never synchronise; device memory stays caller-owned.
-// Not provided (outside the hot path): cvGS::warp, fk::StaticLoop.
+// Not provided (outside the hot path): fk::StaticLoop.
 #pragma once
 
 #include <array>
@@ -177,6 +177,75 @@ template <int INTER_F, fk::PixelFormat PF, fk::ColorRange CR, fk::ColorPrimitive
 inline auto resize(const fk::YuvRead<PF, CR, CP, ALPHA, O, SW>& nv12Read, const cv::Size& dsize) {
     static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");
     return fk::Resize<(fk::InterpolationType)INTER_F>::build(nv12Read, fk::Size(dsize.width, dsize.height));
+}
+
+// ---- warp (reference include/cvGPUSpeedup.cuh:267-442) --------------------------------------------------------------
+// warp<WT, InputType[, BATCH]>(input(s), FORWARD transform(s) as CV_64FC1 cv::Mat, dstSize(s)[, usedPlanes, defaultValue]):
+// the first IOp of a chain; its output is CV_32F of the input's channels.  The matrices are inverted on the host in
+// double (cv::invertAffineTransform / cv::Mat::inv) and narrowed to float, like the reference.
+namespace internal {
+template <fk::WarpType WT>
+inline fk::WarpingParameters<WT> warp_parameters(const cv::Mat& transform_matrix, const cv::Size& dstSize) {
+    if (transform_matrix.type() != CV_64FC1) throw std::runtime_error("Transform matrix type should be CV_64FC1.");
+    fk::WarpingParameters<WT> p;
+    p.dstSize = fk::Size(dstSize.width, dstSize.height);
+    if constexpr (WT == fk::WarpType::Affine) {
+        cv::Mat inverse_transform_matrix;
+        cv::invertAffineTransform(transform_matrix, inverse_transform_matrix);
+        for (int y = 0; y < 2; ++y)
+            for (int x = 0; x < 3; ++x) p.transformMatrix[y][x] = static_cast<float>(inverse_transform_matrix.ptr<double>(y)[x]);
+    } else {
+        const cv::Mat inverse_transform_matrix(transform_matrix.inv());
+        for (int y = 0; y < 3; ++y)
+            for (int x = 0; x < 3; ++x) p.transformMatrix[y][x] = static_cast<float>(inverse_transform_matrix.ptr<double>(y)[x]);
+    }
+    return p;
+}
+} // namespace internal
+
+template <fk::WarpType WT, int InputType = CV_8UC3>
+inline auto warp(const cv::cuda::GpuMat& input, const cv::Mat& transform_matrix, const cv::Size& dstSize) {
+    if (InputType != input.type()) throw std::runtime_error("Input type does not match the input type of the operation.");
+    fk::WarpRead<WT, CUDA_T(InputType)> rd;
+    rd.planes.assign(1, fk::image2d(gpuMat2RawPtr2D<CUDA_T(InputType)>(input)));
+    rd.params.assign(1, internal::warp_parameters<WT>(transform_matrix, dstSize));
+    rd.used = 1;
+    return rd;
+}
+template <fk::WarpType WT, int InputType, size_t BATCH>
+inline auto warp(const std::array<cv::cuda::GpuMat, BATCH>& inputs, const std::array<cv::Mat, BATCH>& transform_matrices,
+                 const std::array<cv::Size, BATCH>& dstSize, const int& usedPlanes, const cv::Scalar& defaultValue) {
+    fk::WarpRead<WT, CUDA_T(InputType)> rd;
+    rd.planes.resize(BATCH, cvgs_image2d{nullptr, 0, 0, 0, 0});
+    rd.params.resize(BATCH);
+    for (size_t i = 0; i < BATCH; ++i) rd.params[i].dstSize = fk::Size(dstSize[0].width, dstSize[0].height);
+    for (int i = 0; i < usedPlanes && i < (int)BATCH; ++i) {
+        if (InputType != inputs[(size_t)i].type()) throw std::runtime_error("Input type does not match the input type of the operation.");
+        rd.planes[(size_t)i] = fk::image2d(gpuMat2RawPtr2D<CUDA_T(InputType)>(inputs[(size_t)i]));
+        rd.params[(size_t)i] = internal::warp_parameters<WT>(transform_matrices[(size_t)i], dstSize[(size_t)i]);
+    }
+    rd.used = usedPlanes;
+    for (int c = 0; c < CV_MAT_CN(InputType); ++c) rd.background[c] = static_cast<float>(defaultValue[c]); // Scalar() = zeros
+    return rd;
+}
+template <fk::WarpType WT, int InputType, size_t BATCH>
+inline auto warp(const std::array<cv::cuda::GpuMat, BATCH>& inputs, const std::array<cv::Mat, BATCH>& transform_matrices,
+                 const std::array<cv::Size, BATCH>& dstSize) {
+    return warp<WT, InputType>(inputs, transform_matrices, dstSize, (int)BATCH, cv::Scalar());
+}
+template <fk::WarpType WT, int InputType, size_t BATCH>
+inline auto warp(const std::array<cv::cuda::GpuMat, BATCH>& inputs, const std::array<cv::Mat, BATCH>& transform_matrices,
+                 const cv::Size& dstSize) {
+    std::array<cv::Size, BATCH> sizes;
+    sizes.fill(dstSize);
+    return warp<WT, InputType>(inputs, transform_matrices, sizes, (int)BATCH, cv::Scalar());
+}
+template <fk::WarpType WT, int InputType, size_t BATCH>
+inline auto warp(const std::array<cv::cuda::GpuMat, BATCH>& inputs, const std::array<cv::Mat, BATCH>& transform_matrices,
+                 const cv::Size& dstSize, const int& usedPlanes, const cv::Scalar& defaultValue) {
+    std::array<cv::Size, BATCH> sizes;
+    sizes.fill(dstSize);
+    return warp<WT, InputType>(inputs, transform_matrices, sizes, usedPlanes, defaultValue);
 }
 
 // crop == an ROI view (zero cost): same pointer arithmetic as GpuMat::operator()(Rect); Rect2d doubles truncate

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -94,6 +95,12 @@ struct Point2d {
     Point2d(double x_, double y_) : x(x_), y(y_) {}
 };
 
+struct Point2f {
+    float x = 0, y = 0;
+    Point2f() = default;
+    Point2f(float x_, float y_) : x(x_), y(y_) {}
+};
+
 struct Rect2d {
     double x = 0, y = 0, width = 0, height = 0;
     Rect2d() = default;
@@ -140,6 +147,22 @@ public:
     int depth() const { return CV_MAT_DEPTH(type_); }
     int channels() const { return CV_MAT_CN(type_); }
     size_t elemSize() const { return cvgs_elem_size(type_); }
+    // cv::Mat::inv() for the one case the warp builders need: a 3x3 CV_64FC1 matrix, OpenCV's closed form
+    // (adjugate / determinant; a singular matrix gives zeros)
+    Mat inv() const {
+        if (rows != 3 || cols != 3 || type_ != CV_MAKETYPE(CV_64F, 1)) throw std::runtime_error("Mat::inv: 3x3 CV_64FC1 only");
+        const double* r0 = ptr<double>(0); const double* r1 = ptr<double>(1); const double* r2 = ptr<double>(2);
+        const double det = r0[0] * (r1[1] * r2[2] - r1[2] * r2[1]) - r0[1] * (r1[0] * r2[2] - r1[2] * r2[0]) +
+                           r0[2] * (r1[0] * r2[1] - r1[1] * r2[0]);
+        Mat out(3, 3, type_);
+        double* o = out.ptr<double>(0);
+        if (det == 0.0) { for (int i = 0; i < 9; ++i) o[i] = 0.0; return out; }
+        const double d = 1.0 / det;
+        o[0] = (r1[1] * r2[2] - r1[2] * r2[1]) * d; o[1] = (r0[2] * r2[1] - r0[1] * r2[2]) * d; o[2] = (r0[1] * r1[2] - r0[2] * r1[1]) * d;
+        o[3] = (r1[2] * r2[0] - r1[0] * r2[2]) * d; o[4] = (r0[0] * r2[2] - r0[2] * r2[0]) * d; o[5] = (r0[2] * r1[0] - r0[0] * r1[2]) * d;
+        o[6] = (r1[0] * r2[1] - r1[1] * r2[0]) * d; o[7] = (r0[1] * r2[0] - r0[0] * r2[1]) * d; o[8] = (r0[0] * r1[1] - r0[1] * r1[0]) * d;
+        return out;
+    }
     bool empty() const { return !data; }
     Size size() const { return Size(cols, rows); }
     template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }
@@ -173,6 +196,94 @@ private:
     int type_ = 0;
     std::shared_ptr<std::vector<uchar>> store_;
 };
+
+// cv::Mat_<T>(rows, cols) << a, b, c, ...  (the comma initialiser the reference's warp test builds its matrices with)
+template <typename T> struct cvgs_depth_of;
+template <> struct cvgs_depth_of<uchar> { static constexpr int value = CV_8U; };
+template <> struct cvgs_depth_of<short> { static constexpr int value = CV_16S; };
+template <> struct cvgs_depth_of<ushort> { static constexpr int value = CV_16U; };
+template <> struct cvgs_depth_of<int> { static constexpr int value = CV_32S; };
+template <> struct cvgs_depth_of<float> { static constexpr int value = CV_32F; };
+template <> struct cvgs_depth_of<double> { static constexpr int value = CV_64F; };
+
+template <typename T> class Mat_;
+template <typename T> class MatCommaInitializer_ {
+public:
+    MatCommaInitializer_(Mat_<T>* m, T first) : m_(m), i_(0) { put(first); }
+    template <typename V> MatCommaInitializer_& operator,(V v) { put((T)v); return *this; }
+    operator Mat() const;
+    operator Mat_<T>() const;
+private:
+    void put(T v);
+    Mat_<T>* m_;
+    size_t i_;
+};
+template <typename T> class Mat_ : public Mat {
+public:
+    Mat_() = default;
+    Mat_(int r, int c) : Mat(r, c, CV_MAKETYPE(cvgs_depth_of<T>::value, 1)) {}
+    template <typename V> MatCommaInitializer_<T> operator<<(V v) { return MatCommaInitializer_<T>(this, (T)v); }
+    T& operator()(int y, int x) { return this->template ptr<T>(y)[x]; }
+};
+template <typename T> void MatCommaInitializer_<T>::put(T v) {
+    if (i_ >= (size_t)m_->rows * m_->cols) throw std::runtime_error("Mat_ comma initialiser: too many values");
+    m_->template ptr<T>((int)(i_ / m_->cols))[i_ % m_->cols] = v;
+    ++i_;
+}
+template <typename T> MatCommaInitializer_<T>::operator Mat() const { return *m_; }
+template <typename T> MatCommaInitializer_<T>::operator Mat_<T>() const { return *m_; }
+
+// cv::invertAffineTransform (2x3, CV_64F or CV_32F), the arithmetic of OpenCV's imgwarp.cpp in double
+inline void invertAffineTransform(const Mat& M, Mat& iM) {
+    if (M.rows != 2 || M.cols != 3 || (M.type() != CV_MAKETYPE(CV_64F, 1) && M.type() != CV_MAKETYPE(CV_32F, 1)))
+        throw std::runtime_error("invertAffineTransform: 2x3 CV_32FC1 / CV_64FC1 only");
+    double m[6];
+    for (int y = 0; y < 2; ++y)
+        for (int x = 0; x < 3; ++x) m[y * 3 + x] = M.type() == CV_MAKETYPE(CV_64F, 1) ? M.ptr<double>(y)[x] : (double)M.ptr<float>(y)[x];
+    double D = m[0] * m[4] - m[1] * m[3];
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    const double A11 = m[4] * D, A22 = m[0] * D, A12 = -m[1] * D, A21 = -m[3] * D;
+    const double b1 = -A11 * m[2] - A12 * m[5], b2 = -A21 * m[2] - A22 * m[5];
+    iM.create(2, 3, M.type());
+    const double o[6] = {A11, A12, b1, A21, A22, b2};
+    for (int y = 0; y < 2; ++y)
+        for (int x = 0; x < 3; ++x) {
+            if (M.type() == CV_MAKETYPE(CV_64F, 1)) iM.ptr<double>(y)[x] = o[y * 3 + x];
+            else iM.ptr<float>(y)[x] = (float)o[y * 3 + x];
+        }
+}
+
+// cv::getPerspectiveTransform: the 3x3 CV_64FC1 homography through four point pairs (h22 = 1), solved by Gaussian
+// elimination with partial pivoting in double
+inline Mat getPerspectiveTransform(const Point2f src[4], const Point2f dst[4]) {
+    double a[8][9];
+    for (int i = 0; i < 4; ++i) {
+        const double x = src[i].x, y = src[i].y, u = dst[i].x, v = dst[i].y;
+        const double r0[9] = {x, y, 1, 0, 0, 0, -x * u, -y * u, u};
+        const double r1[9] = {0, 0, 0, x, y, 1, -x * v, -y * v, v};
+        for (int k = 0; k < 9; ++k) { a[i][k] = r0[k]; a[i + 4][k] = r1[k]; }
+    }
+    for (int c = 0; c < 8; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 8; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) throw std::runtime_error("getPerspectiveTransform: degenerate point set");
+        for (int k = 0; k < 9; ++k) std::swap(a[c][k], a[piv][k]);
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = a[r][c] / a[c][c];
+            for (int k = c; k < 9; ++k) a[r][k] -= f * a[c][k];
+        }
+    }
+    double h[9];
+    for (int r = 7; r >= 0; --r) {
+        double acc = a[r][8];
+        for (int k = r + 1; k < 8; ++k) acc -= a[r][k] * h[k];
+        h[r] = acc / a[r][r];
+    }
+    h[8] = 1.0;
+    Mat out(3, 3, CV_MAKETYPE(CV_64F, 1));
+    for (int i = 0; i < 9; ++i) out.ptr<double>(i / 3)[i % 3] = h[i];
+    return out;
+}
 
 namespace cuda {
 

@@ -64,6 +64,7 @@ struct Size {
     int width = 0, height = 0;
     constexpr Size() = default;
     constexpr Size(int w, int h) : width(w), height(h) {}
+    constexpr bool operator==(const Size& o) const { return width == o.width && height == o.height; }
 };
 struct Rect {
     uint x = 0, y = 0;
@@ -149,6 +150,7 @@ template <typename T> using TensorT = TensorBase<T3D, T>;
 struct ChainBuilder {
     cvgs_chain_desc d;
     std::vector<cvgs_image2d> src, dst;
+    std::vector<float> warp; // WARP reads: batch x 9 floats
     ChainBuilder() { std::memset(&d, 0, sizeof(d)); d.struct_size = sizeof(d); }
     void op(int opcode, int aux, const float* operand = nullptr, const double* operand_d = nullptr) {
         if (d.n_ops >= CVGS_MAX_OPS) throw std::runtime_error("cvGS: too many pointwise operations in one chain");
@@ -162,6 +164,7 @@ struct ChainBuilder {
     void finish() {
         if (!src.empty() && !(d.read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE)) d.read.src = src.data();
         if (!dst.empty()) d.write.planes2d = dst.data();
+        if (!warp.empty()) d.read.warp_matrices = warp.data();
     }
 };
 
@@ -237,6 +240,21 @@ template <typename T> struct PerThreadRead<_2D, T> {
     }
 };
 
+// one pitched image per batch element (PerThreadWrite<_2D,T>::build(std::array<RawPtr<_2D,T>,N>), as the reference's
+// batched warp test writes its results, tests/warping/test_warping_opencv.cu:173-176)
+template <typename T> struct BatchPixelWrite {
+    std::vector<cvgs_image2d> planes;
+    using InputType = T;
+    static constexpr Stage stage = Stage::Write;
+    void lower(ChainBuilder& b) const {
+        cvgs_write_desc& w = b.d.write;
+        w.kind = CVGS_WRITE_PIXEL_2D_BATCH; w.dst_type = cvGS::cv_type_of<T>;
+        b.dst = planes;
+        if (!planes.empty()) { w.width = planes[0].width; w.height = planes[0].height; }
+        w.planes = (int)planes.size();
+    }
+};
+
 template <ND D, typename T> struct PerThreadWrite;
 template <typename T> struct PerThreadWrite<_2D, T> {
     using ParamsType = RawPtr<_2D, T>;
@@ -245,6 +263,11 @@ template <typename T> struct PerThreadWrite<_2D, T> {
         cvgs_write_desc& w = b.d.write;
         w.kind = CVGS_WRITE_PIXEL_2D; w.dst_type = cvGS::cv_type_of<T>; w.data = p.data;
         w.width = p.dims.width; w.height = p.dims.height; w.step = p.dims.pitch; w.planes = 1;
+    }
+    template <size_t N> static BatchPixelWrite<T> build(const std::array<RawPtr<_2D, T>, N>& out) {
+        BatchPixelWrite<T> w;
+        for (const auto& o : out) w.planes.push_back(image2d(o));
+        return w;
     }
 };
 template <typename T> struct PerThreadWrite<_3D, T> {
@@ -309,6 +332,16 @@ template <typename I, typename O> struct SaturateCast {
     using OutputType = O;
     static_assert(cn<I> == cn<O>, "SaturateCast cannot change the number of channels");
     static void lower(ChainBuilder& b) { b.op(CVGS_OP_CAST, cvGS::base_depth<VBase<O>>::value); }
+};
+
+// fk::Cast<I,O>: static_cast per channel (float -> integer truncates), as the reference's warp tests spell it
+// (tests/warping/test_warping_opencv.cu:63)
+template <typename I, typename O> struct Cast {
+    using InputType = I;
+    using OutputType = O;
+    static_assert(cn<I> == cn<O>, "Cast cannot change the number of channels");
+    static void lower(ChainBuilder& b) { b.op(CVGS_OP_CAST_TRUNC, cvGS::base_depth<VBase<O>>::value); }
+    static Unary<Cast> build() { return {}; }
 };
 
 #define CVGS_FK_BINARY(NAME, OPC)                                                           \
@@ -465,6 +498,39 @@ template <typename T> struct BatchPixelRead {
         r.batch = (int)planes.size(); r.used_planes = used;
         for (int i = 0; i < 4; ++i) r.background[i] = background[i];
         b.src = planes;
+    }
+};
+
+// ---- Warping (cvGS::warp) ------------------------------------------------------------------------------------
+enum class WarpType { Affine = 0, Perspective = 1 };
+// the INVERSE (destination -> source) transform narrowed to float, plus the target size (reference
+// include/cvGPUSpeedup.cuh:269-284); affine matrices leave the last row at (0, 0, 1)
+template <WarpType WT> struct WarpingParameters {
+    float transformMatrix[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    Size dstSize;
+};
+// N pitched sources -> warp -> default value for unused planes
+template <WarpType WT, typename T> struct WarpRead {
+    std::vector<cvgs_image2d> planes;
+    std::vector<WarpingParameters<WT>> params;
+    int used = 0;
+    float background[4] = {0, 0, 0, 0};
+    using OutputType = VectorType_t<float, cn<T>>;
+    static constexpr Stage stage = Stage::Read;
+    void lower(ChainBuilder& b) const {
+        cvgs_read_desc& r = b.d.read;
+        r.kind = WT == WarpType::Affine ? CVGS_READ_WARP_AFFINE : CVGS_READ_WARP_PERSPECTIVE;
+        r.src_type = cvGS::cv_type_of<T>;
+        r.batch = (int)planes.size(); r.used_planes = used;
+        if (params.empty()) throw std::runtime_error("cvGS::warp: no transform given");
+        r.dst_width = params[0].dstSize.width; r.dst_height = params[0].dstSize.height;
+        for (int i = 0; i < 4; ++i) r.background[i] = background[i];
+        b.src = planes;
+        b.warp.clear();
+        for (const auto& p : params) {
+            if (!(p.dstSize == params[0].dstSize)) throw std::runtime_error("cvGS::warp: one destination size per launch");
+            for (int y = 0; y < 3; ++y) for (int x = 0; x < 3; ++x) b.warp.push_back(p.transformMatrix[y][x]);
+        }
     }
 };
 

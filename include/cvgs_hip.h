@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CVGS_ABI_VERSION 1
+#define CVGS_ABI_VERSION 2
 #define CVGS_MAX_OPS 12        /* pointwise stages between the read and the write            */
 #define CVGS_MAX_CHANNELS 4
 #define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
@@ -88,7 +88,15 @@ typedef enum cvgs_read_kind {
     CVGS_READ_NV12 = 2,
     /* the same pair fused as the BackIOp of fk::Resize<INTER_LINEAR>
      * (reference tests/resize/test_fused_resize.cu:141-143)                                   */
-    CVGS_READ_NV12_RESIZE_LINEAR = 3
+    CVGS_READ_NV12_RESIZE_LINEAR = 3,
+    /* fk::Warping<fk::WarpType::Affine | Perspective, fk::Read<PerThreadRead<_2D,T>>>, batched like the resize
+     * (cvGS::warp, cvGPUSpeedup.cuh:288-442; tests/warping/test_warping_opencv.cu).  For output pixel (x,y) the
+     * source position is M*(x,y,1) (perspective: divided by its third component) with M = read.warp_matrices[z],
+     * the INVERSE (destination -> source) transform narrowed to float exactly as fk::WarpingParameters holds it
+     * (cvGPUSpeedup.cuh:269-284); inside the source [0,w) x [0,h) the value is the INTER_LINEAR interpolation of
+     * the resize kinds, outside it is 0; the output type is CV_32F of the source's channels.                    */
+    CVGS_READ_WARP_AFFINE = 4,
+    CVGS_READ_WARP_PERSPECTIVE = 5
 } cvgs_read_kind;
 
 /* same numeric values as cvGS::AspectRatio (reference include/cvGPUSpeedup.cuh:32) */
@@ -119,6 +127,7 @@ typedef struct cvgs_read_desc {
     int32_t yuv_primaries;
     int32_t yuv_alpha;    /* 1: 4-channel output with alpha = 255                             */
     int32_t reserved;
+    const float* warp_matrices; /* WARP kinds: host, batch x 9 floats (3x3 row-major; affine ignores row 2) */
 } cvgs_read_desc;
 
 /* ---- pointwise stages (Unary / Binary IOps) ---------------------------------------------- */
@@ -144,7 +153,11 @@ typedef enum cvgs_opcode {
     CVGS_OP_DROP_ALPHA = 8,
     /* *2GRAY: 0.299 R + 0.587 G + 0.114 B, R = in[aux & 3], B = in[(aux>>4)&3]; integer depths
      * round to nearest even.  3|4 -> 1 channel.                                                */
-    CVGS_OP_GRAY = 9
+    CVGS_OP_GRAY = 9,
+    /* fk::Cast<I,O> (the reference's warp tests end with fk::Cast<float3,uchar3>, tests/warping/
+     * test_warping_opencv.cu:63): static_cast per channel -- float -> integer TRUNCATES toward zero (values outside
+     * the destination range, undefined in C++, saturate; NaN -> 0).  aux = destination depth.                  */
+    CVGS_OP_CAST_TRUNC = 10
 } cvgs_opcode;
 
 typedef struct cvgs_op {

@@ -269,11 +269,12 @@ static void read_stage(const cvgs_read_desc* rd, const oracle_resize_geom* geoms
                        opx* p) {
     const cvgs_image2d* im = (const cvgs_image2d*)rd->src + z;
     const int is_resize = rd->kind == CVGS_READ_RESIZE_LINEAR || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR;
+    const int is_warp = rd->kind == CVGS_READ_WARP_AFFINE || rd->kind == CVGS_READ_WARP_PERSPECTIVE;
     int out_depth, out_cn;
     if (rd->kind == CVGS_READ_PIXEL) {
         out_depth = CVGS_TYPE_DEPTH(rd->src_type);
         out_cn = CVGS_TYPE_CN(rd->src_type);
-    } else if (rd->kind == CVGS_READ_RESIZE_LINEAR) {
+    } else if (rd->kind == CVGS_READ_RESIZE_LINEAR || is_warp) {
         out_depth = CVGS_DEPTH_32F;
         out_cn = CVGS_TYPE_CN(rd->src_type);
     } else {
@@ -282,6 +283,30 @@ static void read_stage(const cvgs_read_desc* rd, const oracle_resize_geom* geoms
     }
     if (z >= rd->used_planes) {
         background_pixel(rd, out_depth, out_cn, p);
+        return;
+    }
+    if (is_warp) {
+        /* fk::Warping<WT, BackIOp> [FKL; unpinned beyond the translation case of the reference test, which must equal
+         * cv::cuda::warpAffine(..., INTER_LINEAR, BORDER_CONSTANT 0), tests/warping/test_warping_opencv.cu:80-117]:
+         * source position = M * (x, y, 1) with the inverse transform the facade narrowed to float
+         * (include/cvGPUSpeedup.cuh:269-284), perspective divides by the third row; inside the source the
+         * INTER_LINEAR interpolation of the resize, outside zero. */
+        const float* m = rd->warp_matrices + (size_t)z * 9;
+        const float fx = (float)x, fy = (float)y;
+        float sx = (m[0] * fx + m[1] * fy) + m[2];
+        float sy = (m[3] * fx + m[4] * fy) + m[5];
+        if (rd->kind == CVGS_READ_WARP_PERSPECTIVE) {
+            const float w = (m[6] * fx + m[7] * fy) + m[8];
+            sx = sx / w;
+            sy = sy / w;
+        }
+        if (sx >= 0.f && sx < (float)im->width && sy >= 0.f && sy < (float)im->height) {
+            interpolate_linear(rd, im, sx, sy, p);
+        } else {
+            p->depth = out_depth;
+            p->cn = out_cn;
+            for (int c = 0; c < 4; ++c) { p->f[c] = 0.f; p->i[c] = 0; p->d[c] = 0.0; }
+        }
         return;
     }
     if (!is_resize) {
@@ -313,7 +338,9 @@ static void int_range(int depth, int64_t* lo, int64_t* hi) {
     }
 }
 
-static void op_cast(opx* p, int dst_depth) {
+/* trunc != 0: fk::Cast<I,O> = static_cast per channel (reference tests/warping/test_warping_opencv.cu:63): float ->
+ * integer truncates toward zero; out-of-range values (undefined in C++) saturate, NaN -> 0. */
+static void op_cast_mode(opx* p, int dst_depth, int trunc_mode) {
     int src_depth = p->depth;
     if (src_depth == dst_depth) return;
     if (src_depth == CVGS_DEPTH_16F) src_depth = CVGS_DEPTH_32F; /* a half value is carried as the float it equals */
@@ -340,7 +367,7 @@ static void op_cast(opx* p, int dst_depth) {
             if (v != v) iv = 0;
             else if (v >= 2147483648.0) iv = INT32_MAX;
             else if (v <= -2147483649.0) iv = INT32_MIN;
-            else iv = (int64_t)nearbyint(v); /* default rounding mode: nearest even (exact for float inputs too) */
+            else iv = (int64_t)(trunc_mode ? trunc(v) : nearbyint(v)); /* default rounding mode: nearest even (exact for float inputs too) */
         } else if (src_depth == CVGS_DEPTH_32S) {
             iv = p->i[c];
         } else {
@@ -353,6 +380,8 @@ static void op_cast(opx* p, int dst_depth) {
     }
     p->depth = dst_depth;
 }
+
+static void op_cast(opx* p, int dst_depth) { op_cast_mode(p, dst_depth, 0); }
 
 static void op_reorder(opx* p, int aux, int out_cn) {
     opx s = *p;
@@ -372,6 +401,10 @@ static int apply_op(const cvgs_op* op, opx* p) {
     switch (op->opcode) {
     case CVGS_OP_NOP: return 0;
     case CVGS_OP_CAST: op_cast(p, op->aux); return 0;
+    case CVGS_OP_CAST_TRUNC:
+        if (op->aux == CVGS_DEPTH_64F || p->depth == CVGS_DEPTH_64F) return CVGS_ERR_UNSUPPORTED;
+        op_cast_mode(p, op->aux, 1);
+        return 0;
     case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
         if (p->depth == CVGS_DEPTH_64F) { /* fk::Mul/Add/Sub/Div<doubleN>: IEEE fp64 with the double operand */
             for (int c = 0; c < p->cn; ++c) {
@@ -478,7 +511,9 @@ static void write_stage(const cvgs_write_desc* wr, int x, int y, int z, const op
 static int chain_extent(const cvgs_chain_desc* ch, int* w, int* h) {
     const cvgs_read_desc* rd = &ch->read;
     if (rd->batch < 1 || !rd->src) return CVGS_ERR_INVALID;
-    if (rd->kind == CVGS_READ_RESIZE_LINEAR || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR) {
+    if (rd->kind == CVGS_READ_RESIZE_LINEAR || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR ||
+        rd->kind == CVGS_READ_WARP_AFFINE || rd->kind == CVGS_READ_WARP_PERSPECTIVE) {
+        if ((rd->kind == CVGS_READ_WARP_AFFINE || rd->kind == CVGS_READ_WARP_PERSPECTIVE) && !rd->warp_matrices) return CVGS_ERR_INVALID;
         *w = rd->dst_width;
         *h = rd->dst_height;
     } else {

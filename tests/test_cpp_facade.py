@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
-PROGRAMS = ["test_batchresize", "test_resize", "test_pointwise", "test_circulartensor"]
+PROGRAMS = ["test_batchresize", "test_resize", "test_pointwise", "test_circulartensor", "test_warping"]
 
 
 def _build():

@@ -1,0 +1,129 @@
+"""GPU parity for cvGS::warp through the C-ABI: bit-exact against the CPU oracle (strict fp32 on both
+sides), on the chain shapes of the reference's warp test (tests/warping/test_warping_opencv.cu) and beyond."""
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+from tests import kat_runner as K
+from tests import warp_cases as WC
+from tests.test_gpu_chains import _both, _random_src
+
+pytestmark = pytest.mark.gpu
+
+
+def test_affine_translation_reference_chain():
+    """warp<Affine, CV_8UC3>(img, [1 0 50; 0 1 100], size) -> fk::Cast<float3, uchar3> -> write<CV_8UC3>: must equal
+    cv::cuda::warpAffine exactly in the reference (test_warping_opencv.cu:80-117) = the shifted image."""
+    src = H.random_u8((300, 400, 3), 11)
+
+    def build(wrap, wrap_out, out):
+        return [cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, wrap(src, cvgs.CV_8UC3), [[1, 0, 50], [0, 1, 100]], (400, 300)),
+                cvgs.cast(cvgs.CV_32FC3, cvgs.CV_8UC3), cvgs.write(cvgs.CV_8UC3, wrap_out(out, cvgs.CV_8UC3))]
+
+    gpu, ref = _both(build, (300, 400, 3), np.uint8)
+    exp = np.zeros_like(src)
+    exp[100:, 50:] = src[:200, :350]
+    assert np.array_equal(gpu[0], exp)
+    H.assert_bit_exact(gpu[0], ref[0], "affine translation")
+
+
+@pytest.mark.parametrize("used", [5, 3])
+def test_perspective_batch_reference_chain(used):
+    """testPerspectiveBatch / testPerspectiveBatchNotAll: 5 (or 10, 3 used) warps of one image in ONE launch, each into
+    its own pitched uchar3 GpuMat (PerThreadWrite<_2D> batch)."""
+    n = 5 if used == 5 else 10
+    src = H.random_u8((430, 470, 3), 31)
+    fwd = [WC.get_perspective_transform(*WC.REF_POINT_SETS[i % 5]) for i in range(n)]
+
+    def build(wrap, wrap_out, out):
+        img = wrap(src, cvgs.CV_8UC3)
+        rd = cvgs.warp(cvgs.WARP_PERSPECTIVE, cvgs.CV_8UC3, [img] * n, fwd, (470, 430), used, None)
+        o = wrap_out(out, cvgs.CV_8UC3)
+        outs = [cvgs.GpuMat(430, 470, cvgs.CV_8UC3, o.data + i * 430 * o.step, o.step, owner=o) for i in range(n)]
+        return [rd, cvgs.cast(cvgs.CV_32FC3, cvgs.CV_8UC3), cvgs.write_batch(cvgs.CV_8UC3, outs)]
+
+    gpu, ref = _both(build, (n * 430, 470, 3), np.uint8)
+    H.assert_bit_exact(gpu[0], ref[0], "perspective batch, %d of %d used" % (used, n))
+    planes = ref[0].reshape(n, 430, 470, 3)
+    assert planes[0].std() > 20 and (planes[used:] == 0).all()
+
+
+@pytest.mark.parametrize("depth,cn", [("8U", 1), ("8U", 4), ("16U", 3), ("16S", 2), ("32S", 3), ("32F", 3)])
+@pytest.mark.parametrize("kind", [cvgs.WARP_AFFINE, cvgs.WARP_PERSPECTIVE])
+def test_warp_all_source_types_into_nchw(depth, cn, kind):
+    """rotation + scale (affine) / a keystone (perspective) on every source type, normalized and split into NCHW fp32."""
+    src = _random_src((150, 210, cn), depth, 70 + cn)
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    a = np.deg2rad(17.0)
+    aff = [[1.3 * np.cos(a), -1.3 * np.sin(a), 31.5], [1.3 * np.sin(a), 1.3 * np.cos(a), -12.25]]
+    per = WC.get_perspective_transform([(10, 12), (200, 5), (3, 140), (190, 149)], [(0, 0), (96, 0), (0, 64), (96, 64)])
+    n, dst = 3, (96, 64)
+
+    def build(wrap, wrap_out, out):
+        img = wrap(src, st)
+        ms = [aff if kind == cvgs.WARP_AFFINE else per] * n
+        if kind == cvgs.WARP_AFFINE:
+            ms = [[[r[0], r[1], r[2] + 9 * i] for r in aff] for i in range(n)]
+        rd = cvgs.warp(kind, st, [img] * n, ms, dst, 2, [3.0, 5.0, 7.0, 11.0][:cn])
+        return [rd, cvgs.multiply(f, [0.3] * cn), cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn]),
+                cvgs.split(f, wrap_out(out, cvgs.CV_32FC1), dst) if cn > 1 else cvgs.write(f, wrap_out(out, cvgs.CV_32FC1), dst)]
+
+    gpu, ref = _both(build, (n, cn * dst[0] * dst[1]), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "warp %sC%d kind %d" % (depth, cn, kind))
+    assert ref[0][0].std() > 0
+
+
+def test_warp_many_planes_uses_device_table():
+    """More planes than travel in the kernel arguments (32): the descriptors are uploaded stream-ordered."""
+    import torch
+    src = H.random_u8((90, 120, 3), 8)
+    n = 40
+    ms = [[[1.0, 0.02 * i, 0.5 * i], [-0.01 * i, 1.0, 0.25 * i]] for i in range(n)]
+
+    def build(wrap, wrap_out, out):
+        img = wrap(src, cvgs.CV_8UC3)
+        return [cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, [img] * n, ms, (64, 48)),
+                cvgs.split(cvgs.CV_32FC3, wrap_out(out, cvgs.CV_32FC1), (64, 48))]
+
+    gpu, ref = _both(build, (n, 3 * 64 * 48), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "40-plane warp")
+    t = torch.zeros((90, 120, 3), dtype=torch.uint8, device="cuda:0")
+    o = torch.zeros((n, 3 * 64 * 48), dtype=torch.float32, device="cuda:0")
+    name = cvgs.kernel_name(cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, [cvgs.GpuMat.from_tensor(t, cvgs.CV_8UC3)] * n, ms, (64, 48)),
+                            cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (64, 48)))
+    assert name == "warp_affine_interp"
+
+
+def test_fk_cast_truncation_on_gpu():
+    vals = np.array([-300.7, -1.5, -0.5, 0.0, 0.5, 0.999, 1.5, 2.5, 254.999, 255.5, 300.2, 70000.0, -70000.0, 3e9, -3e9, np.nan,
+                     np.inf, -np.inf], np.float32)
+    src = np.tile(vals, (4, 1))[:, :, None].copy()
+    for depth, dt in ((cvgs.CV_8U, np.uint8), (cvgs.CV_8S, np.int8), (cvgs.CV_16U, np.uint16), (cvgs.CV_16S, np.int16),
+                      (cvgs.CV_32S, np.int32)):
+        t = cvgs.make_type(depth, 1)
+
+        def build(wrap, wrap_out, out):
+            return [cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_32FC1, [wrap(src, cvgs.CV_32FC1)], 1), cvgs.cast(cvgs.CV_32FC1, t),
+                    cvgs.write(t, wrap_out(out, t))]
+
+        gpu, ref = _both(build, src.shape, dt)
+        H.assert_bit_exact(gpu[0], ref[0], "fk::Cast -> depth %d" % depth)
+
+
+def test_warp_descriptor_validation():
+    import torch
+    t = torch.zeros((16, 16, 3), dtype=torch.uint8, device="cuda:0")
+    o = torch.zeros((1, 3 * 64), dtype=torch.float32, device="cuda:0")
+    m = cvgs.GpuMat.from_tensor(t, cvgs.CV_8UC3)
+    rd = cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, m, [[1, 0, 0], [0, 1, 0]], (8, 8))
+    wr = cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (8, 8))
+    s = torch.cuda.current_stream()
+    cvgs.executeOperations(s, rd, wr)
+    rd.warp = None  # descriptor without matrices
+    with pytest.raises(capi.CvgsError, match="warp_matrices"):
+        cvgs.executeOperations(s, rd, wr)
+    with pytest.raises(capi.CvgsError, match="plane tables"):
+        rd2 = cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, m, [[1, 0, 0], [0, 1, 0]], (8, 8))
+        cvgs.build_plane_table(rd2)
+    torch.cuda.synchronize()

@@ -538,6 +538,13 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
 
 int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_stream_t stream) {
     if (!ct || !chain) return fail(CVGS_ERR_INVALID, "null argument");
+    {
+        // the slot arithmetic lives on the host (ring index, like the reference): a captured update would replay into
+        // the SAME slots forever -- refuse loudly instead of producing a silently wrong graph
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(CVGS_ERR_UNSUPPORTED, "CircularTensor::update cannot be captured into a graph (host-side ring index)");
+    }
     cvgs_chain_desc one = *chain;
     if (one.read.batch != 1) return fail(CVGS_ERR_INVALID, "CircularTensor::update pushes one frame: batch must be 1");
     const int wk = one.write.kind;

@@ -134,6 +134,12 @@ inline auto write(const fk::Tensor<T>& output) {
 }
 
 // ---- read builders ---------------------------------------------------------------------------------------------
+// resize<INTER>(dsize): a resize still waiting for its source -- complete it with readIOp.then(...)
+template <int INTER_F>
+inline auto resize(const cv::Size& dsize) {
+    static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");
+    return fk::Resize<(fk::InterpolationType)INTER_F>::build(fk::Size(dsize.width, dsize.height));
+}
 // single image: resize<T, INTER>(GpuMat, dsize, fx, fy); the output type is CV_32F of the same channels
 template <int T, int INTER_F>
 inline auto resize(const cv::cuda::GpuMat& input, const cv::Size& dsize, double fx, double fy) {
@@ -249,6 +255,20 @@ inline auto warp(const std::array<cv::cuda::GpuMat, BATCH>& inputs, const std::a
 }
 
 // crop == an ROI view (zero cost): same pointer arithmetic as GpuMat::operator()(Rect); Rect2d doubles truncate
+// (reference :247-265,444-447: uint x/y, int width/height)
+namespace internal {
+inline fk::Rect fk_rect(const cv::Rect2d& r) { return fk::Rect(static_cast<uint>(r.x), static_cast<uint>(r.y), static_cast<int>(r.width), static_cast<int>(r.height)); }
+} // namespace internal
+inline auto crop(const cv::Rect2d& rect) { return fk::CropSpec{internal::fk_rect(rect)}; }
+template <size_t BATCH>
+inline auto crop(const std::array<cv::Rect2d, BATCH>& rects) {
+    fk::BatchCropSpec<BATCH> spec;
+    for (size_t i = 0; i < BATCH; ++i) spec.rects[i] = internal::fk_rect(rects[i]);
+    return spec;
+}
+template <typename BackIOp> inline auto crop(const BackIOp& backIOp, const cv::Rect2d& rect) { return backIOp.then(crop(rect)); }
+template <typename BackIOp, size_t BATCH>
+inline auto crop(const BackIOp& backIOp, const std::array<cv::Rect2d, BATCH>& rects) { return backIOp.then(crop(rects)); }
 inline cv::cuda::GpuMat crop(const cv::cuda::GpuMat& input, const cv::Rect2d& rect) { return input(cv::Rect(rect)); }
 template <size_t BATCH>
 inline std::array<cv::cuda::GpuMat, BATCH> crop(const cv::cuda::GpuMat& input, const std::array<cv::Rect2d, BATCH>& rects) {

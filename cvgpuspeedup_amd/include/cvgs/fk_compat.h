@@ -174,6 +174,26 @@ template <typename T> inline cvgs_image2d image2d(const RawPtr<_2D, T>& p) {
 
 enum class Stage { Read, Pointwise, Write };
 
+// ---- read-back specifications completed by ReadIOp::then(...) (reference include/cvGPUSpeedup.cuh:204-207,247-265,
+// 444-447: cvGS::resize<INTER>(Size), cvGS::crop(Rect2d | array<Rect2d,N>)) ----------------------------------------
+struct CropSpec { Rect rect; };
+template <size_t N> struct BatchCropSpec { std::array<Rect, N> rects; };
+template <InterpolationType IT> struct IncompleteResize { Size dsize; };
+template <typename T> struct ResizeRead;
+template <typename T> struct BatchResizeRead;
+template <typename T> struct BatchPixelRead;
+template <ND D, typename T> struct PerThreadRead;
+
+template <typename T> inline RawPtr<_2D, T> crop_view(const RawPtr<_2D, T>& p, const Rect& r) {
+    if (r.width < 0 || r.height < 0 || r.x + (uint)r.width > p.dims.width || r.y + (uint)r.height > p.dims.height)
+        throw std::runtime_error("cvGS::crop: rectangle outside the image");
+    RawPtr<_2D, T> v = p;
+    v.data = (T*)((unsigned char*)p.data + (size_t)r.y * p.dims.pitch) + r.x; // fk::Crop: back.exec(thread + rect.xy)
+    v.dims.width = (uint)r.width;
+    v.dims.height = (uint)r.height;
+    return v;
+}
+
 // ---- instantiable-operation wrappers ---------------------------------------------------------------------------
 template <typename Op> struct Read {
     typename Op::ParamsType params;
@@ -181,6 +201,14 @@ template <typename Op> struct Read {
     using OutputType = typename Op::OutputType;
     static constexpr Stage stage = Stage::Read;
     void lower(ChainBuilder& b) const { Op::lower(params, b); }
+    // readIOp.then(crop / crops / resize): a crop is a view of the same memory, a resize turns the read into its back-op
+    auto then(const CropSpec& c) const {
+        Read r = *this;
+        r.params = crop_view(params, c.rect);
+        return r;
+    }
+    template <size_t N> auto then(const BatchCropSpec<N>& c) const;
+    template <InterpolationType IT> auto then(const IncompleteResize<IT>& rs) const;
 };
 template <typename Op> using ReadInstantiableOperation = Read<Op>;
 
@@ -492,6 +520,16 @@ template <typename T> struct BatchPixelRead {
     float background[4] = {0, 0, 0, 0};
     using OutputType = T;
     static constexpr Stage stage = Stage::Read;
+    // crops.then(resize<INTER>(size)): every plane is stretched to dsize (IGNORE_AR), the K1 read
+    template <InterpolationType IT> BatchResizeRead<T> then(const IncompleteResize<IT>& rs) const {
+        static_assert(IT == INTER_LINEAR, "Interpolation type not supported yet.");
+        BatchResizeRead<T> rd;
+        rd.planes = planes;
+        rd.used = used;
+        rd.dsize = rs.dsize;
+        for (int i = 0; i < 4; ++i) rd.background[i] = background[i];
+        return rd;
+    }
     void lower(ChainBuilder& b) const {
         cvgs_read_desc& r = b.d.read;
         r.kind = CVGS_READ_PIXEL; r.src_type = cvGS::cv_type_of<T>;
@@ -534,8 +572,21 @@ template <WarpType WT, typename T> struct WarpRead {
     }
 };
 
+template <typename Op> template <size_t N> inline auto Read<Op>::then(const BatchCropSpec<N>& c) const {
+    using T = typename Op::OutputType;
+    BatchPixelRead<T> rd;
+    for (const Rect& r : c.rects) rd.planes.push_back(image2d(crop_view(params, r)));
+    rd.used = (int)N;
+    return rd;
+}
+template <typename Op> template <InterpolationType IT> inline auto Read<Op>::then(const IncompleteResize<IT>& rs) const {
+    static_assert(IT == INTER_LINEAR, "Interpolation type not supported yet.");
+    return ResizeRead<typename Op::OutputType>{params, rs.dsize};
+}
+
 template <InterpolationType IT, AspectRatio AR = IGNORE_AR> struct Resize {
     static_assert(IT == INTER_LINEAR, "Interpolation type not supported yet.");
+    static IncompleteResize<IT> build(const Size& dsize) { return {dsize}; }
     template <typename T> static auto build(const RawPtr<_2D, T>& in, const Size& dsize, double fx = 0., double fy = 0.) {
         Size d = dsize;
         if (d.width == 0 || d.height == 0) {

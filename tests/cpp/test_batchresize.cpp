@@ -146,6 +146,40 @@ static void test_half_handoff(cv::cuda::Stream& stream) {
     CHECK(bit_equal(h.data(), h_ref.data, n * 2), "fp16 NCHW hand-off, bit-exact vs oracle, type " << TI);
 }
 
+// the read-composition spelling (reference include/cvGPUSpeedup.cuh:204-207,247-265,444-447, never exercised by its
+// tests): read(frame).then(crop(rects)).then(resize<INTER_LINEAR>(size)) must be the same K1 launch as resize(array of ROIs)
+static void test_then_spelling(cv::cuda::Stream& stream) {
+    constexpr int BATCH = 12;
+    const cv::Size up(64, 128);
+    cv::Mat h_frame(720, 1280, CV_8UC3);
+    fill_random(h_frame, 0xC0FFEEull + 4242);
+    cv::cuda::GpuMat d_frame(h_frame);
+    std::array<cv::Rect2d, BATCH> rects;
+    std::array<cv::cuda::GpuMat, BATCH> crops;
+    for (int i = 0; i < BATCH; ++i) {
+        rects[i] = cv::Rect2d(3.7 + i * 31, 2.2 + i * 17, 40.9 + i * 23, 55.5 + i * 29); // doubles truncate
+        crops[i] = d_frame(rects[i]);
+    }
+    const size_t n = (size_t)BATCH * 3 * up.width * up.height;
+    cv::cuda::GpuMat d_a(BATCH, up.width * up.height * 3, CV_32F), d_b(BATCH, up.width * up.height * 3, CV_32F);
+    const cv::Scalar sub(1.f, 4.f, 3.2f);
+    cvGS::executeOperations(stream, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, BATCH>(crops, up, BATCH), cvGS::subtract<CV_32FC3>(sub),
+                            cvGS::split<CV_32FC3>(d_a, up));
+    const fk::Read<fk::PerThreadRead<fk::_2D, uchar3>> read{cvGS::gpuMat2RawPtr2D<uchar3>(d_frame)};
+    cvGS::executeOperations(stream, cvGS::crop(read, rects).then(cvGS::resize<cv::INTER_LINEAR>(up)), cvGS::subtract<CV_32FC3>(sub),
+                            cvGS::split<CV_32FC3>(d_b, up));
+    stream.waitForCompletion();
+    const auto a = fetch(d_a.data, n * sizeof(float)), b = fetch(d_b.data, n * sizeof(float));
+    CHECK(bit_equal(a.data(), b.data(), n * sizeof(float)), "read.then(crop).then(resize) == resize(array of ROIs)");
+    // single crop + single resize
+    cv::cuda::GpuMat d_c(1, up.width * up.height * 3, CV_32F), d_d(1, up.width * up.height * 3, CV_32F);
+    cvGS::executeOperations(stream, cvGS::resize<CV_8UC3, cv::INTER_LINEAR>(crops[5], up, 0., 0.), cvGS::split<CV_32FC3>(d_c, up));
+    cvGS::executeOperations(stream, cvGS::crop(read, rects[5]).then(cvGS::resize<cv::INTER_LINEAR>(up)), cvGS::split<CV_32FC3>(d_d, up));
+    stream.waitForCompletion();
+    const auto c = fetch(d_c.data, n / BATCH * sizeof(float)), d = fetch(d_d.data, n / BATCH * sizeof(float));
+    CHECK(bit_equal(c.data(), d.data(), c.size()), "read.then(crop(rect)).then(resize) == resize(ROI)");
+}
+
 template <int TI, int TO>
 static void sweep(cv::cuda::Stream& stream) {
     test_constant<TI, TO, 10, cvGS::IGNORE_AR>(stream, 60);
@@ -166,6 +200,7 @@ int main() {
     sweep<CV_16UC4, CV_32FC4>(stream);
     sweep<CV_16SC3, CV_32FC3>(stream);
     sweep<CV_16SC4, CV_32FC4>(stream);
+    test_then_spelling(stream);
     test_half_handoff<CV_8UC3, 50>(stream);
     test_half_handoff<CV_8UC4, 17>(stream);
     return report("test_batchresize_x_split3D + aspectratio");

@@ -212,3 +212,26 @@ def test_mirrored_circular_tensor_matches_default_semantics(oracle, order, write
 def test_mirrored_circular_tensor_rejects_transposed():
     with pytest.raises(capi.CvgsError, match="Standard plane order"):
         cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, 4, cvgs.NewestFirst, cvgs.Transposed, 16, 16, mirrored=True)
+
+
+def test_circular_update_refuses_stream_capture():
+    """The ring index is host state (as in the reference): a captured update would replay into the same slots."""
+    import torch
+    dev = torch.device("cuda:0")
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, 3, cvgs.NewestFirst, cvgs.Standard, 32, 16)
+    frame = torch.zeros((16, 32, 3), dtype=torch.uint8, device=dev)
+    f = cvgs.CV_32FC3
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g.capture_begin()
+        try:
+            with pytest.raises(capi.CvgsError, match="cannot be captured"):
+                ct.update(torch.cuda.current_stream(), cvgs.GpuMat.from_tensor(frame, cvgs.CV_8UC3), cvgs.convertTo(cvgs.CV_8UC3, f),
+                          ct.write_split(f))
+            frame.add_(1)  # keep the capture non-empty
+        finally:
+            g.capture_end()
+    torch.cuda.synchronize()
+    assert ct.updates() == 0
+    ct.release()

@@ -11,7 +11,8 @@ from cvgpuspeedup_amd import cvgs
 from tests import helpers as H
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = json.load(open(os.path.join(HERE, "seeded_fixtures.json")))["cases"]
+_FIX = json.load(open(os.path.join(HERE, "seeded_fixtures.json")))
+CASES, WARPS = _FIX["cases"], _FIX["warp_cases"]
 
 
 def _inputs(case):
@@ -35,9 +36,11 @@ def _check(case, out):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_oracle_reproduces_seeded_fixture(case, oracle):
     frame, crops, cn, bg = _inputs(case)
-    out = np.zeros((case["crops"], cn * 64 * 128), np.float32)
+    half = case.get("half", False)
+    out = np.zeros((case["crops"], cn * 64 * 128), np.float16 if half else np.float32)
     oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.make_type(cvgs.CV_8U, cn)), crops,
-                                         cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), cn=cn, ar=case["ar"], background=bg)))
+                                         cvgs.GpuMat.from_array(out, cvgs.CV_16FC1 if half else cvgs.CV_32FC1), cn=cn,
+                                         ar=case["ar"], background=bg, half=half)))
     _check(case, out)
 
 
@@ -48,9 +51,41 @@ def test_gpu_reproduces_seeded_fixture(case):
     frame, crops, cn, bg = _inputs(case)
     dev = torch.device("cuda:0")
     ft = torch.from_numpy(frame).to(dev)
-    ot = torch.zeros((case["crops"], cn * 64 * 128), dtype=torch.float32, device=dev)
+    half = case.get("half", False)
+    ot = torch.zeros((case["crops"], cn * 64 * 128), dtype=torch.float16 if half else torch.float32, device=dev)
     cvgs.executeOperations(torch.cuda.current_stream(),
                            *H.k1_chain(cvgs.GpuMat.from_tensor(ft, cvgs.make_type(cvgs.CV_8U, cn)), crops,
-                                       cvgs.GpuMat.from_tensor(ot, cvgs.CV_32FC1), cn=cn, ar=case["ar"], background=bg))
+                                       cvgs.GpuMat.from_tensor(ot, cvgs.CV_16FC1 if half else cvgs.CV_32FC1), cn=cn,
+                                       ar=case["ar"], background=bg, half=half))
     torch.cuda.synchronize()
     _check(case, ot.cpu().numpy())
+
+
+def _warp_chain(case, img, out_mat):
+    kind = cvgs.WARP_PERSPECTIVE if case["perspective"] else cvgs.WARP_AFFINE
+    n, dst = len(case["matrices"]), tuple(case["dst"])
+    return [cvgs.warp(kind, cvgs.CV_8UC3, [img] * n, case["matrices"], dst), cvgs.split(cvgs.CV_32FC3, out_mat, dst)]
+
+
+@pytest.mark.parametrize("case", WARPS, ids=[c["name"] for c in WARPS])
+def test_oracle_reproduces_warp_fixture(case, oracle):
+    src = H.random_u8((430, 470, 3), case["seed"])
+    n, dst = len(case["matrices"]), case["dst"]
+    out = np.zeros((n, 3 * dst[0] * dst[1]), np.float32)
+    oracle.execute(cvgs.lower(_warp_chain(case, cvgs.GpuMat.from_array(src, cvgs.CV_8UC3), cvgs.GpuMat.from_array(out, cvgs.CV_32FC1))))
+    assert [xxhash.xxh64(out[i].tobytes()).hexdigest() for i in range(n)] == case["image_hashes"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WARPS, ids=[c["name"] for c in WARPS])
+def test_gpu_reproduces_warp_fixture(case):
+    import torch
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(H.random_u8((430, 470, 3), case["seed"])).to(dev)
+    n, dst = len(case["matrices"]), case["dst"]
+    ot = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
+    cvgs.executeOperations(torch.cuda.current_stream(),
+                           *_warp_chain(case, cvgs.GpuMat.from_tensor(src, cvgs.CV_8UC3), cvgs.GpuMat.from_tensor(ot, cvgs.CV_32FC1)))
+    torch.cuda.synchronize()
+    out = ot.cpu().numpy()
+    assert [xxhash.xxh64(out[i].tobytes()).hexdigest() for i in range(n)] == case["image_hashes"]

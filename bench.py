@@ -156,6 +156,17 @@ def cpu_baseline(wl, seconds):
         if dt >= seconds or reps >= 100000:
             break
     px = wl.n * W.DST[0] * W.DST[1] * reps
+    # the same batch on ONE host thread (SURVEY.md 8d asks for both): ~1/4 of the time budget
+    lib.oracle_set_threads(1)
+    reps1, t1 = 0, time.perf_counter()
+    while True:
+        ob.execute(chain)
+        reps1 += 1
+        dt1 = time.perf_counter() - t1
+        if dt1 >= seconds / 4 or reps1 >= 100000:
+            break
+    lib.oracle_set_threads(cores)
+    single = wl.n * W.DST[0] * W.DST[1] * reps1 / dt1 / 1e6
     s = torch.cuda.current_stream().cuda_stream
     wl.launch(0, s)
     torch.cuda.synchronize()
@@ -164,7 +175,7 @@ def cpu_baseline(wl, seconds):
     return {"value": round(px / dt / 1e6, 2), "unit": "Mpix/s", "cores": int(cores), "kind": "port",
             "sample": "%d x the 50-crop batch of frame 0 (oracle/libcvgs_oracle.so, OpenMP %d threads, %.1f s)" % (
                 reps, cores, dt),
-            "gpu_matches_oracle_bit_exact": checked}
+            "single_thread_value": round(single, 2), "gpu_matches_oracle_bit_exact": checked}
 
 
 def algorithmic_bytes(wl, out_elem=4):
@@ -305,10 +316,13 @@ def main():
             torch.cuda.synchronize()
             k_s = e0.elapsed_time(e1) * 1e-3 / 256
         achieved = alg / k_s / 1e9
+        ceiling = copy_ceiling(dev)
         result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, a.table),
                               "kernel": wl.kernel, "kernel_us": round(k_s * 1e6, 3),
-                              "algorithmic_bytes_per_launch": int(alg)}
+                              "algorithmic_bytes_per_launch": int(alg),
+                              # the on-box device-to-device copy ceiling (read + write bytes / time), measured now
+                              "copy_ceiling": ceiling, "frac_of_copy_ceiling": round(achieved / ceiling, 4) if ceiling else None}
     if use_dist:
         barrier()
         if rank == 0:
@@ -323,6 +337,72 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def timing_distribution(wl, singles=200, bursts=100, burst=64):
+    """SURVEY.md 8d timing protocol: hipEvent pairs around (i) single launches and (ii) bursts of 64 back-to-back
+    launches cycling over the resident frames; median / p10 / p90 in microseconds per launch.  Eager submission, so
+    the single-launch figures include the event records and the host's launch path; plus the host's enqueue time per
+    cvgs_execute call (the quantity the reference's 'CPU' benchmark measures, benchmarks/benchmark_CPU_OpenCV_vs_cvGS.cu)."""
+    s = torch.cuda.current_stream().cuda_stream
+
+    def measure(n_launch, reps, base):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for r, (e0, e1) in enumerate(ev):
+            e0.record()
+            for i in range(n_launch):
+                wl.launch(base + r * n_launch + i, s)
+            e1.record()
+        torch.cuda.synchronize()
+        t = np.sort(np.array([e0.elapsed_time(e1) * 1e3 / n_launch for e0, e1 in ev]))
+        return {"median": round(float(np.median(t)), 3), "p10": round(float(t[len(t) // 10]), 3),
+                "p90": round(float(t[(len(t) * 9) // 10]), 3)}
+
+    run_steps(wl, 64, True)
+    torch.cuda.synchronize()
+    out = {"single_launch_us": measure(1, singles, 0), "burst64_us_per_launch": measure(burst, bursts, 7)}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(2048):
+        wl.launch(i, s)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    out["host_enqueue_us_per_call"] = round((t1 - t0) / 2048 * 1e6, 3)
+    return out
+
+
+def copy_ceiling(dev, mib=256, iters=20):
+    """GB/s (read + write bytes / time) of a plain device-to-device copy of `mib` MiB (working set 2x the Infinity Cache)
+    on this box -- the better of the
+    runtime's copy (torch copy_ = hipMemcpy DtoD) and the engine's streaming copy kernel (cvgs_stream_copy): what a
+    perfectly streaming kernel gets out of this HBM, next to the 8 TB/s spec the roofline fraction is quoted on."""
+    try:
+        n = mib << 20
+        a = torch.empty(n, dtype=torch.uint8, device=dev)
+        b = torch.empty(n, dtype=torch.uint8, device=dev)
+        a.zero_()
+        lib = capi.load_library()
+        s = torch.cuda.current_stream().cuda_stream
+
+        def own():
+            capi.check(lib.cvgs_stream_copy(b.data_ptr(), a.data_ptr(), n, s))
+
+        best = 0.0
+        for fn in (lambda: b.copy_(a), own):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, 2.0 * n * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
+        torch.cuda.empty_cache()
+        return round(best, 1)
+    except Exception:
+        return None
 
 
 def pmc_traffic(crops, table):
@@ -420,6 +500,7 @@ def extra_sweeps(dev, a):
         wall, dev_s = timed(lambda: run_steps(wl, 2048, True), lambda: None)
         out["eager_50"] = {"Mpix_per_s": round(50 * 8192 * 2048 / wall / 1e6, 1), "us_per_step": round(wall / 2048 * 1e6, 3),
                            "note": "python ctypes + cvgs_execute + hipLaunchKernel per step (host-bound)"}
+        out["timing_distribution_50"] = timing_distribution(wl)
         del wl
         torch.cuda.empty_cache()
         out["multi_stream_50"] = multi_stream(dev)

@@ -100,6 +100,7 @@ SYMBOLS = [
     ("cvgs_circular_bytes", C.c_size_t, [C.c_void_p]),
     ("cvgs_circular_updates", C.c_int64, [C.c_void_p]),
     ("cvgs_circular_destroy", C.c_int, [C.c_void_p]),
+    ("cvgs_stream_copy", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("cvgs_range_push", None, [C.c_char_p]),
     ("cvgs_range_pop", None, []),
 ]

@@ -667,4 +667,26 @@ int cvgs_circular_destroy(cvgs_circular_t ct) {
     return CVGS_OK;
 }
 
+int cvgs_stream_copy(void* dst, const void* src, size_t bytes, cvgs_stream_t stream) {
+    if (!dst || !src) return fail(CVGS_ERR_INVALID, "null pointer");
+    if (bytes == 0) return CVGS_OK;
+    // split into up to kMaxCopyJobs equal 16-byte-aligned chunks so the launch fills the chip like a K9 shift does
+    const size_t kChunk = (size_t)8 << 20;
+    size_t n_jobs = bytes / kChunk;
+    if (n_jobs > (size_t)kMaxCopyJobs) n_jobs = kMaxCopyJobs;
+    size_t done = 0;
+    if (n_jobs >= 2) {
+        const size_t per = (bytes / n_jobs) & ~(size_t)15;
+        CopyJob jobs[kMaxCopyJobs];
+        for (size_t i = 0; i < n_jobs; ++i) jobs[i] = CopyJob{(const uint8_t*)src + i * per, (uint8_t*)dst + i * per};
+        if (launch_plane_copies(jobs, (int)n_jobs, per, stream)) return fail(CVGS_ERR_HIP, "copy launch failed");
+        done = per * n_jobs;
+    }
+    if (done < bytes) {
+        CopyJob tail{(const uint8_t*)src + done, (uint8_t*)dst + done};
+        if (launch_plane_copies(&tail, 1, bytes - done, stream)) return fail(CVGS_ERR_HIP, "copy launch failed");
+    }
+    return CVGS_OK;
+}
+
 } // extern "C"

@@ -279,3 +279,18 @@ def test_double_precision_chains(src, cn):
     for kind, dt in (("64F", np.float64), ("32F", np.float32), ("16S", np.int16)):
         gpu, ref = _both(build_for(kind), (40, 50, cn), dt)
         H.assert_bit_exact(gpu[0], ref[0], "64F chain %sC%d -> %s" % (src, cn, kind))
+
+
+@pytest.mark.parametrize("off", [16, 3])
+@pytest.mark.parametrize("nbytes", [1, 15, 4096, (8 << 20) + 7, (40 << 20) + 3, 600 << 20])
+def test_stream_copy(nbytes, off):
+    """cvgs_stream_copy: every size class (tail-only, unaligned tail, multi-job), aligned and unaligned pointers."""
+    import torch
+    lib = capi.load_library()
+    g = torch.Generator(device="cuda").manual_seed(nbytes % 1000)
+    src = torch.randint(0, 256, (nbytes + 32,), dtype=torch.uint8, device="cuda", generator=g)
+    dst = torch.zeros(nbytes + 32, dtype=torch.uint8, device="cuda")
+    capi.check(lib.cvgs_stream_copy(dst.data_ptr() + off, src.data_ptr() + off, nbytes, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(dst[off:off + nbytes], src[off:off + nbytes])
+    assert not dst[:off].any() and not dst[off + nbytes:].any()

@@ -3,7 +3,9 @@
 // No CPU compute fallback exists: if HIP cannot launch, the call fails loudly.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -617,32 +619,41 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
         Wa.ch_stride2 = wk == CVGS_WRITE_PIXEL_3D ? 0 : plane;
         (void)esz;
     }
-    rc = dispatch(&one, L, (hipStream_t)stream, false, nullptr);
-    if (rc) return rc;
     // 2) every OLDER frame: history ring -> its new slot of the ordered tensor.  Slot z shows the frame of age z
     //    (NewestFirst) or BATCH-1-z (OldestFirst); never-written history slots are zero.
-    CopyJob jobs[kMaxCopyJobs];
-    int n = 0;
+    std::vector<CopyJob> jobs;
     for (int z = 0; z < ct->batch; ++z) {
         if (z == z_new) continue;
         const int64_t age = ct->order == CVGS_NEWEST_FIRST ? z : ct->batch - 1 - z;
         int64_t src_slot = (ct->count - age) % ct->batch;
         if (src_slot < 0) src_slot += ct->batch;
         for (int c = 0; c < ct->color_planes; ++c) {
-            jobs[n].src = ct->ring + (size_t)src_slot * ct->image_bytes + (size_t)c * ct->plane_bytes;
-            jobs[n].dst = ct->cp_mode == CVGS_PLANES_TRANSPOSED
-                              ? ct->out + ((size_t)c * ct->batch + z) * ct->plane_bytes
-                              : ct->out + ((size_t)z * ct->color_planes + c) * ct->plane_bytes;
-            if (++n == kMaxCopyJobs) {
-                rc = launch_plane_copies(jobs, n, ct->plane_bytes, stream);
-                if (rc) return fail(CVGS_ERR_HIP, "CircularTensor copy launch failed");
-                n = 0;
-            }
+            CopyJob j;
+            j.src = ct->ring + (size_t)src_slot * ct->image_bytes + (size_t)c * ct->plane_bytes;
+            j.dst = ct->cp_mode == CVGS_PLANES_TRANSPOSED ? ct->out + ((size_t)c * ct->batch + z) * ct->plane_bytes
+                                                          : ct->out + ((size_t)z * ct->color_planes + c) * ct->plane_bytes;
+            jobs.push_back(j);
         }
     }
-    if (n) {
-        rc = launch_plane_copies(jobs, n, ct->plane_bytes, stream);
-        if (rc) return fail(CVGS_ERR_HIP, "CircularTensor copy launch failed");
+    // Per-pixel u8 pushes (the form the reference tests) take ONE launch: compute + every copy in the same kernel.
+    // No copy reads the ring slot or writes the tensor slot the compute part fills (ages >= 1 only), so the two parts
+    // are independent inside the launch.
+    static const bool no_fused = getenv("CVGS_NO_FUSED_PUSH") != nullptr; // A/B switch for benchmarks
+    bool done = false;
+    if (!no_fused && !jobs.empty() && (int)jobs.size() <= kMaxCopyJobs && !L.uses_64f && L.planes.size() == 1 && !L.args.read.table &&
+        L.dst_planes.empty()) {
+        rc = launch_circular_push(L.args, L.planes[0], jobs.data(), (int)jobs.size(), ct->plane_bytes, one.flags, stream);
+        if (rc < 0) return fail(CVGS_ERR_HIP, "CircularTensor push launch failed");
+        done = rc == 1;
+    }
+    if (!done) {
+        rc = dispatch(&one, L, (hipStream_t)stream, false, nullptr);
+        if (rc) return rc;
+        for (size_t at = 0; at < jobs.size(); at += kMaxCopyJobs) {
+            const int n = (int)std::min<size_t>(kMaxCopyJobs, jobs.size() - at);
+            rc = launch_plane_copies(jobs.data() + at, n, ct->plane_bytes, stream);
+            if (rc) return fail(CVGS_ERR_HIP, "CircularTensor copy launch failed");
+        }
     }
     ct->count++;
     return CVGS_OK;

@@ -155,5 +155,9 @@ struct CopyJob {
 };
 static constexpr int kMaxCopyJobs = 64;
 int launch_plane_copies(const CopyJob* jobs, int n_jobs, size_t bytes, void* stream);
+// single-launch CircularTensor update (new frame through the thread-fused pointwise chain + all plane copies):
+// returns 1 if it took the update, 0 if the chain / layout is not eligible, <0 on error
+int launch_circular_push(const ChainArgs& c, const PlaneParams& plane, const CopyJob* jobs, int n_jobs, size_t plane_bytes,
+                         uint32_t chain_flags, void* stream);
 
 } // namespace cvgs

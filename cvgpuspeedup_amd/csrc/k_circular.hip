@@ -6,13 +6,104 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "k_common.hpp"
+#include "k_pointwise_body.hpp"
 
 namespace cvgs {
 
 struct CopyArgs {
     CopyJob jobs[kMaxCopyJobs];
 };
+
+// Single-launch CircularTensor update for per-pixel u8 pushes (the form the reference tests,
+// include/cvGPUSpeedup.cuh:612-617: one kernel computes the new plane and shifts the others).  Workgroups
+// [0, pw_blocks) run the thread-fused pointwise chain on the new frame (written to its tensor slot AND its ring slot),
+// the rest stream the BATCH-1 older frames ring -> tensor exactly like k_plane_copy.
+struct PushGeom {
+    uint32_t pw_blocks, col_groups; // compute part: pw_blocks = col_groups * row_groups
+    uint32_t blocks_per_job, n_jobs;
+    size_t n_vec;                   // 16-byte vectors per plane
+};
+
+template <int CN, class Prog, typename OT>
+__global__ __launch_bounds__(256) void k_circular_push(const KernArgs<1> a, const PwGeom g, const CopyArgs jobs, const PushGeom pg) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    if (blockIdx.x < pg.pw_blocks) {
+        const uint32_t by = blockIdx.x / pg.col_groups, bx = blockIdx.x - by * pg.col_groups;
+        pw4_body<CN, Prog, OT>(a.c, a.planes[0], g, (int)bx, (int)by, 0);
+        return;
+    }
+    const uint32_t b = blockIdx.x - pg.pw_blocks;
+    const uint32_t j = b / pg.blocks_per_job, bx = b - j * pg.blocks_per_job;
+    const CopyJob job = jobs.jobs[j];
+    const v4* __restrict__ src = (const v4*)job.src;
+    v4* __restrict__ dst = (v4*)job.dst;
+    const size_t stride = (size_t)pg.blocks_per_job * 256;
+    size_t i = (size_t)bx * 256 + threadIdx.x;
+    constexpr int UNROLL = 8;
+    for (; i + (UNROLL - 1) * stride < pg.n_vec; i += UNROLL * stride) {
+        v4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+    }
+    for (; i < pg.n_vec; i += stride) dst[i] = src[i];
+}
+
+template <int CN, typename OT>
+static hipError_t launch_push_prog(int prog_id, const KernArgs<1>& a, const PwGeom& g, const CopyArgs& jobs, const PushGeom& pg,
+                                   hipStream_t s) {
+    const dim3 grid(pg.pw_blocks + pg.blocks_per_job * pg.n_jobs);
+    if (prog_id == 0) hipLaunchKernelGGL((k_circular_push<CN, ProgCastMulSubDiv, OT>), grid, dim3(256), 0, s, a, g, jobs, pg);
+    else if (prog_id == 1) hipLaunchKernelGGL((k_circular_push<CN, ProgCast, OT>), grid, dim3(256), 0, s, a, g, jobs, pg);
+    else hipLaunchKernelGGL((k_circular_push<CN, InterpProg, OT>), grid, dim3(256), 0, s, a, g, jobs, pg);
+    return hipGetLastError();
+}
+
+// Returns 1 if it took the update (new frame + all copies in ONE launch), 0 if not eligible, <0 on error.
+int launch_circular_push(const ChainArgs& c_in, const PlaneParams& plane, const CopyJob* copy_jobs, int n_jobs, size_t plane_bytes,
+                         uint32_t chain_flags, void* stream) {
+    ChainArgs c;
+    PwGeom g;
+    int prog_id = 0;
+    bool f16 = false;
+    if (!pointwise4_plan(c_in, 1, chain_flags, c, g, prog_id, f16)) return 0;
+    if (n_jobs < 1 || n_jobs > kMaxCopyJobs || plane_bytes % 16) return 0;
+    for (int i = 0; i < n_jobs; ++i)
+        if ((((uintptr_t)copy_jobs[i].src | (uintptr_t)copy_jobs[i].dst) & 15) != 0) return 0;
+    KernArgs<1> a;
+    a.c = c;
+    a.planes[0] = plane;
+    CopyArgs jobs;
+    for (int i = 0; i < kMaxCopyJobs; ++i) jobs.jobs[i] = i < n_jobs ? copy_jobs[i] : CopyJob{nullptr, nullptr};
+    PushGeom pg;
+    pg.col_groups = (uint32_t)((g.w + 255) / 256);
+    pg.pw_blocks = pg.col_groups * (uint32_t)((g.h + 3) / 4);
+    pg.n_jobs = (uint32_t)n_jobs;
+    pg.n_vec = plane_bytes / 16;
+    const size_t want = (pg.n_vec + 256 * 8 - 1) / (256 * 8);
+    const size_t cap = (size_t)(8192 / n_jobs > 1 ? 8192 / n_jobs : 1);
+    pg.blocks_per_job = (uint32_t)(want < cap ? want : cap);
+    if (pg.blocks_per_job < 1) pg.blocks_per_job = 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (f16) {
+        switch (c.read.cn) {
+        case 1: e = launch_push_prog<1, _Float16>(prog_id, a, g, jobs, pg, s); break;
+        case 2: e = launch_push_prog<2, _Float16>(prog_id, a, g, jobs, pg, s); break;
+        case 3: e = launch_push_prog<3, _Float16>(prog_id, a, g, jobs, pg, s); break;
+        default: e = launch_push_prog<4, _Float16>(prog_id, a, g, jobs, pg, s); break;
+        }
+    } else {
+        switch (c.read.cn) {
+        case 1: e = launch_push_prog<1, float>(prog_id, a, g, jobs, pg, s); break;
+        case 2: e = launch_push_prog<2, float>(prog_id, a, g, jobs, pg, s); break;
+        case 3: e = launch_push_prog<3, float>(prog_id, a, g, jobs, pg, s); break;
+        default: e = launch_push_prog<4, float>(prog_id, a, g, jobs, pg, s); break;
+        }
+    }
+    return e == hipSuccess ? 1 : -(int)e - 1000;
+}
 
 template <typename V, int UNROLL, bool NT = true>
 __global__ __launch_bounds__(256) void k_plane_copy(const CopyArgs a, const size_t n_vec) {

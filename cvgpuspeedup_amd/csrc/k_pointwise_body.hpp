@@ -1,0 +1,137 @@
+// k_pointwise_body.hpp -- the thread-fused pointwise body (4 x-adjacent pixels per thread) shared by k_pointwise4
+// (k_pointwise.hip) and by the single-launch CircularTensor push (k_circular.hip).  See k_pointwise.hip.
+#pragma once
+
+#include "k_common.hpp"
+
+namespace cvgs {
+
+typedef uint32_t u32u __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) u32u* gp_u32;
+typedef const __attribute__((address_space(1))) uint8_t* gp_u8;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4u __attribute__((aligned(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16x4 f16x4u __attribute__((aligned(2)));
+
+// four consecutive output elements in one non-temporal vector store (fp16: the chain's trailing CAST(CV_16F) is this
+// round-to-nearest-even conversion)
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    f32x4 q = {a, b, c, d};
+    __builtin_nontemporal_store(q, (f32x4u*)p);
+}
+__device__ __forceinline__ void store4(_Float16* p, float a, float b, float c, float d) {
+    f16x4 q = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    __builtin_nontemporal_store(q, (f16x4u*)p);
+}
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(_Float16* p, float v) { *p = (_Float16)v; }
+
+using ProgCastMulSubDiv = StaticProg<CVGS_OP_CAST, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
+using ProgCast = StaticProg<CVGS_OP_CAST>;
+
+struct PwGeom {
+    int32_t w, h, used, cn;
+    int32_t packed;    // 1: packed pixels (PIXEL_2D / PIXEL_3D), 0: planar
+    int32_t row_pitch; // packed: bytes between output rows
+    int32_t row_pitch2, pad;
+    int64_t img_stride, ch_stride, img_stride2, ch_stride2; // planar: elements; packed: img_stride in BYTES
+    uint8_t* out;
+    uint8_t* out2;
+};
+
+// One thread's work: pixels x0..x0+3 of row y of plane z.  (bx, by) = the 256-pixel column group and the 4-row group.
+template <int CN, class Prog, typename OT>
+__device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& P, const PwGeom& g, int bx, int by, int z) {
+    const int W = g.w, H = g.h, used = g.used;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int x0 = (bx * 64 + lane) * 4;
+    const int y = by * 4 + wave;
+    if (y >= H || x0 >= W) return;
+    const int npx = min(4, W - x0);
+
+    // ---- read 4 pixels ----
+    uint32_t raw[CN]; // 4*CN bytes
+    if (z < used) {
+        const gp_u8 row = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * CN;
+        if (npx == 4) {
+#pragma unroll
+            for (int k = 0; k < CN; ++k) raw[k] = *(gp_u32)(row + 4 * k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CN; ++k) raw[k] = 0;
+#pragma unroll
+            for (int b = 0; b < 4 * CN; ++b)
+                if (b < npx * CN) raw[b >> 2] |= (uint32_t)row[b] << (8 * (b & 3));
+        }
+    }
+    Px px[4];
+    int depth = CVGS_DEPTH_8U, cn = CN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < CN) {
+                const int b = i * CN + ch;
+                px[i].v[ch] = z < used ? (float)((raw[b >> 2] >> (8 * (b & 3))) & 0xffu) : c.read.bg[ch];
+            } else {
+                px[i].v[ch] = 0.f;
+            }
+        }
+    }
+    Prog::run4(c.prog, px, depth, cn);
+
+    // ---- write ----
+    if (g.packed) {
+        // cn floats per pixel, contiguous: 4 pixels = cn float4
+        uint8_t* rows[2] = {g.out + (size_t)z * g.img_stride + (size_t)y * g.row_pitch,
+                            g.out2 ? g.out2 + (size_t)z * g.img_stride2 + (size_t)y * g.row_pitch2 : nullptr};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!rows[t]) continue;
+            OT* o = (OT*)rows[t] + (size_t)x0 * cn;
+            if (npx == 4) {
+                float flat[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch)
+                        if (ch < CN) flat[i * CN + ch] = px[i].v[ch];
+#pragma unroll
+                for (int v = 0; v < CN; ++v) store4(o + 4 * v, flat[4 * v], flat[4 * v + 1], flat[4 * v + 2], flat[4 * v + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch)
+                        if (i < npx && ch < CN) store1(o + i * CN + ch, px[i].v[ch]);
+            }
+        }
+    } else {
+        OT* bases[2] = {(OT*)g.out + (int64_t)z * g.img_stride, g.out2 ? (OT*)g.out2 + (int64_t)z * g.img_stride2 : nullptr};
+        const int64_t chs[2] = {g.ch_stride, g.ch_stride2};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!bases[t]) continue;
+            OT* o = bases[t] + (int64_t)y * W + x0;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                if (ch < cn) {
+                    if (npx == 4) {
+                        store4(o + (int64_t)ch * chs[t], px[0].v[ch], px[1].v[ch], px[2].v[ch], px[3].v[ch]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (i < npx) store1(o + (int64_t)ch * chs[t] + i, px[i].v[ch]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// host side (k_pointwise.hip): eligibility + geometry of the thread-fused path
+bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16);
+
+} // namespace cvgs

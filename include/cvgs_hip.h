@@ -273,9 +273,11 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
                             int32_t device_id, uint32_t flags);
 /* update(stream, [GpuMat,] iops..., write) (:612-622): `chain` carries the read stage (batch 1),
  * the pointwise stages and the write KIND (TENSOR_SPLIT / TENSOR_T_SPLIT / PIXEL_3D); the write
- * target is the handle's own tensor (write.data is ignored).  The new frame is computed ONCE by the fused chain
- * kernel, which stores it both into its slot of the ordered tensor and into the history ring; one plane-copy
- * kernel then moves the BATCH-1 older frames from the ring to their new slots (mirrored handles: no copy).      */
+ * target is the handle's own tensor (write.data is ignored).  The new frame is computed ONCE and stored both into
+ * its slot of the ordered tensor and into the history ring, and the BATCH-1 older frames move from the ring to their
+ * new slots.  Per-pixel u8 pushes (the form the reference tests) do all of it in ONE kernel launch; pushes with a
+ * resize / NV12 / warp read use the chain's own kernel plus one plane-copy kernel (mirrored handles: no copy at all).
+ * Cannot be captured into a HIP graph (the ring index is host state): CVGS_ERR_UNSUPPORTED.                       */
 int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_stream_t stream);
 /* data() (:624-626): device pointer of the ordered output tensor; stable for the handle's life
  * (mirrored handles: the window of the LAST update -- it moves).                                 */

@@ -235,3 +235,27 @@ def test_circular_update_refuses_stream_capture():
     torch.cuda.synchronize()
     assert ct.updates() == 0
     ct.release()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 30])
+@pytest.mark.parametrize("mirrored", [False, True])
+def test_circular_tensor_depth_extremes(oracle, batch, mirrored):
+    """BATCH = 1 (nothing to shift), 2, and 30 (x3 colour planes = 87 plane copies: more than one copy launch holds)."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H_ = 40, 24
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, batch, cvgs.OldestFirst, cvgs.Standard, W, H_, mirrored=mirrored)
+    oc = oracle.OracleCircular(W, H_, cvgs.CV_32FC1, 3, batch, cvgs.OldestFirst, cvgs.Standard)
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    for i in range(batch + 3):
+        frame = H.random_u8((H_, W, 3), seed=9000 + i)
+        frame_t = torch.from_numpy(frame).to(dev)
+        pw = [cvgs.convertTo(cvgs.CV_8UC3, f), cvgs.subtract(f, [0.5] * 3)]
+        ct.update(s, cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), *pw, ct.write_split(f))
+        oc.update(cvgs.lower([cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)], 1),
+                              *pw, cvgs.WriteIOp(capi.WRITE_TENSOR_SPLIT, f, 16, W, H_, 0, batch)]))
+    torch.cuda.synchronize()
+    got = _read_device(ct.data(), ct.nbytes()).view(np.float32)
+    H.assert_bit_exact(got, oc.array(np.float32), "circular depth %d mirrored %s" % (batch, mirrored))
+    ct.release()

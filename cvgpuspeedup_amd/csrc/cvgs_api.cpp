@@ -681,17 +681,23 @@ int cvgs_circular_destroy(cvgs_circular_t ct) {
 int cvgs_stream_copy(void* dst, const void* src, size_t bytes, cvgs_stream_t stream) {
     if (!dst || !src) return fail(CVGS_ERR_INVALID, "null pointer");
     if (bytes == 0) return CVGS_OK;
-    // split into up to kMaxCopyJobs equal 16-byte-aligned chunks so the launch fills the chip like a K9 shift does
+    // Up to kMaxCopyJobs equal chunks so that one launch fills the chip like a K9 shift does.  Chunks are a multiple of
+    // 16 bytes; the last one is anchored at the END of the 16-byte-aligned body and may overlap its neighbour (the
+    // overlap is rewritten with identical bytes), so there is no ragged second launch; < 16 trailing bytes go separately.
+    const size_t body = bytes & ~(size_t)15;
     const size_t kChunk = (size_t)8 << 20;
-    size_t n_jobs = bytes / kChunk;
+    size_t n_jobs = body / kChunk;
     if (n_jobs > (size_t)kMaxCopyJobs) n_jobs = kMaxCopyJobs;
     size_t done = 0;
     if (n_jobs >= 2) {
-        const size_t per = (bytes / n_jobs) & ~(size_t)15;
+        const size_t per = ((body + n_jobs - 1) / n_jobs + 15) & ~(size_t)15;
         CopyJob jobs[kMaxCopyJobs];
-        for (size_t i = 0; i < n_jobs; ++i) jobs[i] = CopyJob{(const uint8_t*)src + i * per, (uint8_t*)dst + i * per};
+        for (size_t i = 0; i < n_jobs; ++i) {
+            const size_t at = i + 1 < n_jobs ? i * per : body - per;
+            jobs[i] = CopyJob{(const uint8_t*)src + at, (uint8_t*)dst + at};
+        }
         if (launch_plane_copies(jobs, (int)n_jobs, per, stream)) return fail(CVGS_ERR_HIP, "copy launch failed");
-        done = per * n_jobs;
+        done = body;
     }
     if (done < bytes) {
         CopyJob tail{(const uint8_t*)src + done, (uint8_t*)dst + done};

@@ -7,7 +7,8 @@ Launch A (K1 pattern: 8 B/lane unaligned taps, 4 B/lane planar nt stores): ident
 frames -> every source byte is tapped exactly once per output row pair, so the HBM read volume is the frames'
 bytes (4 x 24,883,200 B, + <= 1/16 for the row each 16-row tile shares with its neighbour), the write volume
 4 x 99,532,800 B.
-Launch B (K9 pattern: 16 B/lane streaming copy): the CircularTensor plane copy of 16 planes of 24,883,200 B.
+Launch B (K9 pattern: 16 B/lane streaming copy): cvgs_stream_copy (the CircularTensor's plane-copy kernel) over
+373,248,000 B = the 45 planes a depth-16 1080p fp32x3 update shifts.
 
 Run under:  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python tools/calibrate_pmc.py
             rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python tools/calibrate_pmc.py
@@ -39,10 +40,13 @@ torch.cuda.synchronize()
 print("A: K1 identity over %d frames: read >= %d B (frames), write %d B per launch; kernel %s" % (
     N, N * fw * fh * 3, N * fw * fh * 12, cvgs.kernel_name(*ops)))
 
-ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, 16, cvgs.NewestFirst, cvgs.Standard, 1920, 1080)
-frame = W.random_u8_torch((1080, 1920, 3), 7, dev)
+from cvgpuspeedup_amd import capi  # noqa: E402
+
+lib = capi.load_library()
+nbytes = 45 * 1920 * 1080 * 4
+src = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
 for _ in range(6):
-    ct.update(s, cvgs.GpuMat.from_tensor(frame, cvgs.CV_8UC3), cvgs.convertTo(cvgs.CV_8UC3, f3), ct.write_split(f3))
+    capi.check(lib.cvgs_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, s.cuda_stream))
 torch.cuda.synchronize()
-plane = 1920 * 1080 * 4
-print("B: K9 update: copy kernel moves 48 planes of %d B: read %d B, write %d B per launch" % (plane, 48 * plane, 48 * plane))
+print("B: streaming copy (k_plane_copy): read %d B, write %d B per launch" % (nbytes, nbytes))

@@ -43,7 +43,7 @@ with open(os.path.join(P, label + "_k1_bench_kernel_stats.txt"), "w") as f:
     f.write("# bench line of the SAME (profiled) run: value %s Mpix/s, ms_per_step %s, roofline.kernel_us %s, frac %s\n" % (
         bench["value"], bench["ms_per_step"], bench["roofline"]["kernel_us"], bench["roofline"]["frac"]))
     if unprof:
-        f.write("# un-profiled `python bench.py` on the same box right after: value %s Mpix/s, ms_per_step %s, kernel_us %s, frac %s\n" % (
+        f.write("# un-profiled `python bench.py` (separate gpurun call, MI355X box of the same pool): value %s Mpix/s, ms_per_step %s, kernel_us %s, frac %s\n" % (
             unprof["value"], unprof["ms_per_step"], unprof["roofline"]["kernel_us"], unprof["roofline"]["frac"]))
     f.write("# (profiled passes run 10-15 % slower: profiler serialisation + lower clocks, MI355X_MICROARCH.md DVFS note)\n")
     f.write("# rocprofv3's own kernel stats:\n")

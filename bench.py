@@ -508,6 +508,8 @@ def extra_sweeps(dev, a):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_more
         out["other_configs"] = bench_more.run_all(dev, iters=50)
+        import bench_resize  # whole-frame resizes of synthetic 1080p / 4K / 6K frames (K2 / K3 chains of the reference's tests)
+        out["whole_frame_resize"] = bench_resize.run_all(dev, iters=50)
     except Exception as ex:  # extras must never break the headline line
         out["error"] = repr(ex)
     return out

@@ -53,6 +53,11 @@ struct K1Prog {
 using ProgSwapMulSubDiv = K1Prog<kOpSwapRB, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 using ProgMulSubDiv = K1Prog<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 
+// Write stages of the fast path.  Planar is the hot one (TensorSplit / TensorTSplit); the other two serve the
+// single-image chains of the reference's resize tests (tests/resize/test_resize_write.cu: resize -> convertTo<32F,8U> ->
+// write; tests/resize/test_resize_x_split.cu: resize -> mul -> sub -> div -> split(vector<GpuMat>)).
+enum { WM_PLANAR = 0, WM_PACKED = 1, WM_SPLIT2D = 2 };
+
 struct K1Geom {
     uint32_t col_tiles;  // ceil(dst_w / 64)
     int32_t dst_w, dst_h;
@@ -64,6 +69,9 @@ struct K1Geom {
     void* out;           // float* or _Float16* (template parameter OT)
     void* out2;          // optional second target (CircularTensor ring + tensor), own strides
     int64_t img_stride2, ch_stride2;
+    // WM_PACKED: bytes between output rows / images (both targets dense or pitched alike); WM_SPLIT2D: plane table
+    int64_t row_pitch, img_pitch, row_pitch2, img_pitch2;
+    const DstPlane* planes2d;
 };
 
 typedef uint64_t u64_unaligned __attribute__((aligned(1)));
@@ -169,7 +177,75 @@ __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal
 // fp16 output: the chain's trailing CAST(CV_16F) is this one round-to-nearest-even conversion
 __device__ __forceinline__ void st_nt(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
 
-template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float>
+__device__ __forceinline__ void st_plain(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_plain(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
+// u8 targets: the chain's trailing SaturateCast (round to nearest even, clamp, NaN -> 0) is this conversion
+__device__ __forceinline__ void st_plain(uint8_t* p, float v) { __builtin_nontemporal_store((uint8_t)sat_round(v, 0.f, 255.f), p); }
+
+// one packed pixel: a single vector store when the channel count is the compile-time one (the usual case), element
+// stores when the chain changed it (e.g. *2GRAY after the resize)
+template <int CN, typename OT>
+__device__ __forceinline__ void store_packed_px(OT* px, const float* v, int cn) {
+    if (cn == CN) {
+        if constexpr (std::is_same_v<OT, float>) {
+            typedef float vf __attribute__((ext_vector_type(CN)));
+            typedef vf vfu __attribute__((aligned(4)));
+            vf q;
+#pragma unroll
+            for (int k = 0; k < CN; ++k) q[k] = v[k];
+            __builtin_nontemporal_store(q, (vfu*)px); // global_store_dwordx3 / x4
+            return;
+        } else if constexpr (std::is_same_v<OT, _Float16>) {
+            // pairs of halves as one 32-bit store (a 3-element half vector would be stored as 8 bytes)
+            typedef _Float16 vh2 __attribute__((ext_vector_type(2)));
+            typedef vh2 vh2u __attribute__((aligned(2)));
+            vh2 lo = {(_Float16)v[0], (_Float16)v[1]};
+            __builtin_nontemporal_store(lo, (vh2u*)px);
+            if constexpr (CN == 4) {
+                vh2 hi = {(_Float16)v[2], (_Float16)v[3]};
+                __builtin_nontemporal_store(hi, (vh2u*)(px + 2));
+            } else {
+                __builtin_nontemporal_store((_Float16)v[2], px + 2);
+            }
+            return;
+        } else if constexpr (CN == 4) { // u8c4: one dword
+            typedef uint32_t u32a1 __attribute__((aligned(1)));
+            uint32_t q = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q |= (uint32_t)sat_round(v[k], 0.f, 255.f) << (8 * k);
+            __builtin_nontemporal_store(q, (u32a1*)px);
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < cn) st_plain(px + k, v[k]);
+}
+
+// packed pixels / separate pitched planes: one output pixel of row y, column x, plane z
+template <int WM, typename OT, int CN>
+__device__ __forceinline__ void k1_store_other(const K1Geom& g, const ChainArgs& c, int z, int y, int x, const float* v, int cn) {
+    if constexpr (WM == WM_PACKED) {
+        uint8_t* row = (uint8_t*)g.out + (int64_t)z * g.img_pitch + (int64_t)y * g.row_pitch;
+        store_packed_px<CN, OT>((OT*)row + (int64_t)x * cn, v, cn);
+        if (g.out2) {
+            uint8_t* row2 = (uint8_t*)g.out2 + (int64_t)z * g.img_pitch2 + (int64_t)y * g.row_pitch2;
+            store_packed_px<CN, OT>((OT*)row2 + (int64_t)x * cn, v, cn);
+        }
+    } else {
+        const DstPlane* planes = g.planes2d ? g.planes2d : c.dst_inline;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < cn) {
+                const DstPlane d = planes[z * cn + k];
+                static_assert(std::is_same_v<OT, float>, "separate planes are written as fp32");
+                typedef __attribute__((address_space(1))) float* gptr_f32; // global, not flat, stores
+                __builtin_nontemporal_store(v[k], (gptr_f32)(float*)(d.data + (int64_t)y * d.step) + x);
+            }
+    }
+}
+
+template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR>
 __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, const K1Geom g) {
     constexpr int EB = elem_bytes<SRC>;
     constexpr int WINB = 8 * EB; // bytes per tap window
@@ -224,13 +300,18 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const int y = row0 + j;
-                if (y < dst_h)
+                if (y < dst_h) {
+                    if constexpr (WM == WM_PLANAR) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < bcn) {
-                            st_nt(out + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
-                            if (out2) st_nt(out2 + (int64_t)k * ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
-                        }
+                        for (int k = 0; k < 4; ++k)
+                            if (k < bcn) {
+                                st_nt(out + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
+                                if (out2) st_nt(out2 + (int64_t)k * ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
+                            }
+                    } else {
+                        k1_store_other<WM, OT, CN>(g, c, z, y, x, bgp.v, bcn);
+                    }
+                }
             }
             return;
         }
@@ -301,22 +382,29 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
             int depth = CVGS_DEPTH_32F, cn = CN;
             Prog::run(c.prog, p, depth, cn);
             out_cn = cn;
-            OT* const orow = out + (int64_t)y * W; // wave-uniform
             const bool take = whole || (in_x && in_y[j]);
+            if constexpr (WM == WM_PLANAR) {
+                OT* const orow = out + (int64_t)y * W; // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < cn) {
-                    const float v = take ? p.v[k] : bgp.v[k];
-                    st_nt(orow + (int64_t)k * ch_stride + x, v);
-                    if (out2) st_nt(out2 + (int64_t)y * W + (int64_t)k * ch_stride2 + x, v);
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (k < cn) {
+                        const float v = take ? p.v[k] : bgp.v[k];
+                        st_nt(orow + (int64_t)k * ch_stride + x, v);
+                        if (out2) st_nt(out2 + (int64_t)y * W + (int64_t)k * ch_stride2 + x, v);
+                    }
+            } else {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = take ? p.v[k] : bgp.v[k];
+                k1_store_other<WM, OT, CN>(g, c, z, y, x, v, cn);
+            }
         }
     }
     (void)out_cn;
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT>
+template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT, int WM = WM_PLANAR>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn,
                            hipStream_t stream) {
     KernArgs<NPL> a;
@@ -343,9 +431,34 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     g.out2 = c.write.data2;
     g.img_stride2 = c.write.img_stride2;
     g.ch_stride2 = c.write.ch_stride2;
+    // packed targets: byte pitches (PIXEL_2D: the image's step, one image; PIXEL_3D: dense planes)
+    const int64_t px_bytes = (int64_t)sizeof(OT) * c.write.cn;
+    g.row_pitch = c.write.kind == CVGS_WRITE_PIXEL_2D ? c.write.step : c.write.width * px_bytes;
+    g.img_pitch = c.write.kind == CVGS_WRITE_PIXEL_2D ? 0 : c.write.img_stride * px_bytes;
+    g.row_pitch2 = c.write.width * px_bytes;
+    g.img_pitch2 = c.write.img_stride2 * px_bytes;
+    g.planes2d = c.write.table;
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch);
-    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT>), grid, dim3(256), 0, stream, a, g);
+    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM>), grid, dim3(256), 0, stream, a, g);
     return hipGetLastError();
+}
+
+// packed / separate-plane targets: u8 sources; one row per wave, four for whole-frame sizes
+template <int CN, typename OT, int WM, class Prog = InterpProg>
+static hipError_t launch_other(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+    if (rpw >= 4) {
+        if (table) return launch_t<CN, 0, 4, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
+        return launch_t<CN, CVGS_KERNARG_PLANES, 4, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
+    }
+    if (table) return launch_t<CN, 0, 1, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
+    return launch_t<CN, CVGS_KERNARG_PLANES, 1, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
+}
+// separate planes: the reference's K2 chain (mul, sub, div; with or without the R<->B swap) gets its compile-time program
+template <int CN>
+static hipError_t launch_split2d(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+    if (prog_id == 0) return launch_other<CN, float, WM_SPLIT2D, ProgSwapMulSubDiv>(table, rpw, c, ip, ni, s);
+    if (prog_id == 1) return launch_other<CN, float, WM_SPLIT2D, ProgMulSubDiv>(table, rpw, c, ip, ni, s);
+    return launch_other<CN, float, WM_SPLIT2D>(table, rpw, c, ip, ni, s);
 }
 
 template <int CN, int NPL, class Prog, int SRC, typename OT>
@@ -395,23 +508,31 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     // tensor whose conversion is the chain's LAST stage (the half-precision hand-off option)
     if (r.kind != CVGS_READ_RESIZE_LINEAR || (r.cn != 3 && r.cn != 4)) return 0;
     if (r.depth != CVGS_DEPTH_8U && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S) return 0;
-    if (c_in.write.kind != CVGS_WRITE_TENSOR_SPLIT && c_in.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return 0;
+    const int wk = c_in.write.kind;
+    const bool planar = wk == CVGS_WRITE_TENSOR_SPLIT || wk == CVGS_WRITE_TENSOR_T_SPLIT;
+    const bool packed = wk == CVGS_WRITE_PIXEL_2D || wk == CVGS_WRITE_PIXEL_3D;
+    const bool split2d = wk == CVGS_WRITE_SPLIT_2D;
+    if (!planar && !packed && !split2d) return 0;
     if (r.batch > 65535) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
-    if (!f16 && c_in.write.depth != CVGS_DEPTH_32F) return 0;
+    const bool u8out = c_in.write.depth == CVGS_DEPTH_8U;
+    if (!f16 && !u8out && c_in.write.depth != CVGS_DEPTH_32F) return 0;
+    if (u8out && !packed) return 0;
+    if (split2d && c_in.write.depth != CVGS_DEPTH_32F) return 0;
+    if (!planar && r.depth != CVGS_DEPTH_8U) return 0;
     int n_prog = c_in.prog.n;
-    if (f16) {
+    if (f16 || u8out) {
         if (r.depth != CVGS_DEPTH_8U || n_prog < 1 || c_in.prog.opcode[n_prog - 1] != CVGS_OP_CAST) return 0;
-        --n_prog; // the trailing CAST(CV_16F) happens in the store
+        --n_prog; // the trailing CAST(CV_16F / CV_8U) happens in the store
     }
     for (int k = 0; k < n_prog; ++k) // value must stay fp32 through the program
         if (c_in.prog.opcode[k] == CVGS_OP_CAST) return 0;
     ChainArgs c_cut;
-    if (f16) {
+    if (f16 || u8out) {
         c_cut = c_in;
         c_cut.prog.n = n_prog;
     }
-    const ChainArgs& c = f16 ? c_cut : c_in;
+    const ChainArgs& c = (f16 || u8out) ? c_cut : c_in;
 
     // rows per wave: small launches are latency bound -> maximum parallelism (1 row per wave);
     // large ones amortise the column geometry over more rows (measured: tools/k1_ab.py).
@@ -432,7 +553,10 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
              {"k1_s16c4_swap_mul_sub_div", "k1_s16c4_mul_sub_div", "k1_s16c4_interp"}}};
         static const char* names16[2][3] = {{"k1_u8c3_swap_mul_sub_div_f16", "k1_u8c3_mul_sub_div_f16", "k1_u8c3_interp_f16"},
                                             {"k1_u8c4_swap_mul_sub_div_f16", "k1_u8c4_mul_sub_div_f16", "k1_u8c4_interp_f16"}};
-        info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
+        static const char* names_other[2][4] = {{"k1_u8c3_packed_f32", "k1_u8c3_packed_f16", "k1_u8c3_packed_u8", "k1_u8c3_planes2d_f32"},
+                                                {"k1_u8c4_packed_f32", "k1_u8c4_packed_f16", "k1_u8c4_packed_u8", "k1_u8c4_planes2d_f32"}};
+        if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
+        else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
     }
     if (dry_run) return 1;
     (void)chain_flags;
@@ -440,7 +564,16 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     hipStream_t s = (hipStream_t)stream;
     const int out_cn = c.write.cn;
     hipError_t e;
-    if (f16) {
+    if (!planar) {
+        if (split2d) e = r.cn == 3 ? launch_split2d<3>(prog_id, table, rpw, c, inline_planes, n_inline, s)
+                                   : launch_split2d<4>(prog_id, table, rpw, c, inline_planes, n_inline, s);
+        else if (u8out) e = r.cn == 3 ? launch_other<3, uint8_t, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)
+                                      : launch_other<4, uint8_t, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s);
+        else if (f16) e = r.cn == 3 ? launch_other<3, _Float16, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)
+                                    : launch_other<4, _Float16, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s);
+        else e = r.cn == 3 ? launch_other<3, float, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)
+                           : launch_other<4, float, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s);
+    } else if (f16) {
         e = r.cn == 3 ? launch_prog<3, SRC_U8, _Float16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
                       : launch_prog<4, SRC_U8, _Float16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
     } else if (r.cn == 3) {

@@ -1,0 +1,110 @@
+"""The K1 kernel's other write stages (packed pixels, separate pitched planes), used by the reference's single-image
+resize chains: tests/resize/test_resize_write.cu (resize -> convertTo<32F, 8U> -> write) and test_resize_x_split.cu
+(resize -> multiply -> subtract -> divide -> split(vector<GpuMat>)).  Non-constant images, bit-exact vs the oracle, and
+identical to the interpreted kernel."""
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+from tests.test_gpu_chains import _both
+
+pytestmark = pytest.mark.gpu
+
+
+def _name(build):
+    """kernel the engine picks for the chain `build` makes (on throw-away device buffers)."""
+    import torch
+    keep = []
+
+    def wrap(a, cvt):
+        t = torch.from_numpy(a).cuda()
+        keep.append(t)
+        return cvgs.GpuMat.from_tensor(t, cvt)
+
+    return cvgs.kernel_name(*build(wrap, wrap, None))
+
+
+@pytest.mark.parametrize("cn", [3, 4])
+@pytest.mark.parametrize("dst", [(640, 360), (1500, 901), (37, 53)])
+def test_resize_to_packed_u8(cn, dst):
+    """K3: whole-frame resize (down, up, tiny) back to packed u8 in a PITCHED image."""
+    src = H.random_u8((540, 961, cn), 300 + cn)
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    pitch_w = dst[0] + 5  # the output is a view of a wider buffer -> pitched rows
+
+    def build(wrap, wrap_out, out):
+        o = wrap_out(np.zeros((dst[1], pitch_w, cn), np.uint8) if out is None else out, u)
+        return [cvgs.resize(u, cvgs.INTER_LINEAR, wrap(src, u), dst), cvgs.convertTo(f, u), cvgs.write(u, o.roi(2, 0, dst[0], dst[1]))]
+
+    gpu, ref = _both(build, (dst[1], pitch_w, cn), np.uint8)
+    H.assert_bit_exact(gpu[0], ref[0], "resize -> packed u8")
+    assert not ref[0][:, :2].any() and not ref[0][:, dst[0] + 2:].any() and ref[0][:, 2:dst[0] + 2].std() > 10
+    assert _name(build) == "k1_u8c%d_packed_u8" % cn
+    gen, _ = _both(build, (dst[1], pitch_w, cn), np.uint8, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gen[0], gpu[0], "interpreted kernel agrees")
+
+
+@pytest.mark.parametrize("cn,half", [(3, False), (4, False), (3, True)])
+def test_batch_resize_to_packed_float(cn, half):
+    """N crops -> packed float pixels, dense [plane][y][x] (write<O>(GpuMat, Size)), unused planes and PRESERVE_AR padding."""
+    src = H.random_u8((400, 600, cn), 310 + cn)
+    crops = H.random_crops(7, 600, 400, seed=3, wmin=3, wmax=400, hmin=3, hmax=300)
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    ot = cvgs.make_type(cvgs.CV_16F, cn) if half else f
+    dst, n, used = (80, 48), 7, 5
+
+    def build(wrap, wrap_out, out):
+        frame = wrap(src, u)
+        o = wrap_out(np.zeros((n, dst[0] * dst[1], cn), np.float16 if half else np.float32) if out is None else out, ot)
+        ops = [cvgs.resize(u, cvgs.INTER_LINEAR, [frame.roi(*c) for c in crops], dst, used, [9.0, 8.0, 7.0, 6.0][:cn], cvgs.PRESERVE_AR),
+               cvgs.multiply(f, [0.25] * cn), cvgs.add(f, [1.5] * cn)]
+        if half:
+            ops.append(cvgs.convertTo(f, ot))
+        return ops + [cvgs.write(ot, o, dst)]
+
+    gpu, ref = _both(build, (n, dst[0] * dst[1], cn), np.float16 if half else np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "batch resize -> packed float")
+    assert _name(build) == "k1_u8c%d_packed_%s" % (cn, "f16" if half else "f32")
+
+
+@pytest.mark.parametrize("cn,batch", [(3, 1), (4, 2), (3, 9)])
+def test_resize_to_separate_planes(cn, batch):
+    """K2: resize -> multiply -> subtract -> divide -> split into C pitched GpuMats per image (batch 9 x 3 = 27 planes:
+    more than the 16 that travel in the kernel arguments -> uploaded table)."""
+    src = H.random_u8((300, 500, cn), 320 + cn)
+    crops = H.random_crops(batch, 500, 300, seed=5 + batch, wmin=8, wmax=300, hmin=8, hmax=250)
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    dst = (100, 60)
+    pitch_w = dst[0] + 3
+
+    def build(wrap, wrap_out, out):
+        frame = wrap(src, u)
+        o = wrap_out(np.zeros((batch * cn * dst[1], pitch_w), np.float32) if out is None else out, cvgs.CV_32FC1)
+        planes = [[cvgs.GpuMat(dst[1], dst[0], cvgs.CV_32FC1, o.data + ((z * cn + c) * dst[1]) * o.step, o.step, owner=o)
+                   for c in range(cn)] for z in range(batch)]
+        if batch > 1:
+            rd = cvgs.resize(u, cvgs.INTER_LINEAR, [frame.roi(*c) for c in crops], dst, batch)
+        else:
+            rd = cvgs.resize(u, cvgs.INTER_LINEAR, frame.roi(*crops[0]), dst)
+        return [rd, cvgs.multiply(f, [0.3] * cn), cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn]),
+                cvgs.split(f, planes if batch > 1 else planes[0])]
+
+    gpu, ref = _both(build, (batch * cn * dst[1], pitch_w), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "resize -> separate planes")
+    assert not ref[0][:, dst[0]:].any()
+    assert _name(build) == "k1_u8c%d_planes2d_f32" % cn
+
+
+def test_gray_output_of_a_resize_is_packed_single_channel():
+    """a channel-count change inside the chain (RGB2GRAY after the resize) reaches the packed store with 1 channel."""
+    src = H.random_u8((200, 300, 3), 9)
+    f3, f1 = cvgs.CV_32FC3, cvgs.CV_32FC1
+
+    def build(wrap, wrap_out, out):
+        o = wrap_out(np.zeros((90, 120, 1), np.float32) if out is None else out, f1)
+        return [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, wrap(src, cvgs.CV_8UC3), (120, 90)), cvgs.cvtColor(cvgs.COLOR_RGB2GRAY, f3, f1),
+                cvgs.write(f1, o)]
+
+    gpu, ref = _both(build, (90, 120, 1), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "resize -> gray packed")

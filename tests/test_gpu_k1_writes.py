@@ -26,7 +26,7 @@ def _name(build):
 
 
 @pytest.mark.parametrize("cn", [3, 4])
-@pytest.mark.parametrize("dst", [(640, 360), (1500, 901), (37, 53)])
+@pytest.mark.parametrize("dst", [(640, 360), (1500, 901), (37, 53), (2003, 2100)])  # the last one: 4 rows per wave, shuffled u8c3 stores
 def test_resize_to_packed_u8(cn, dst):
     """K3: whole-frame resize (down, up, tiny) back to packed u8 in a PITCHED image."""
     src = H.random_u8((540, 961, cn), 300 + cn)

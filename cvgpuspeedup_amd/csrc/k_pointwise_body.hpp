@@ -87,6 +87,38 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
         // cn floats per pixel, contiguous: 4 pixels = cn float4
         uint8_t* rows[2] = {g.out + (size_t)z * g.img_stride + (size_t)y * g.row_pitch,
                             g.out2 ? g.out2 + (size_t)z * g.img_stride2 + (size_t)y * g.row_pitch2 : nullptr};
+        if (bx * 256 + 255 < W) { // wave-uniform: the whole 256-pixel group exists, every lane is alive
+            // Each lane owns 4*CN consecutive output elements (48 / 64 bytes for fp32): stored directly, every 16-byte
+            // store instruction would scatter the wave over a 3-4 KB span.  Transpose through LDS instead: lanes write
+            // their elements, then lane l stores the wave's l-th, (64+l)-th, ... 16-byte chunk -> 1 KB contiguous per
+            // instruction.  Wave-private LDS region, wave-synchronous (no workgroup barrier).
+            constexpr int EPW = 256 * CN;                  // elements per wave
+            constexpr int EPC = 16 / (int)sizeof(OT);      // elements per 16-byte chunk
+            constexpr int CHUNKS = EPW / EPC;
+            __shared__ __attribute__((aligned(16))) OT stage[4][EPW];
+            OT* mine = &stage[wave][lane * 4 * CN];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+                    if (ch < CN) mine[i * CN + ch] = (OT)px[i].v[ch];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef u32x4 u32x4u __attribute__((aligned(2))); // fp16 rows may start on any even address
+            const size_t row_off = (size_t)bx * EPW * sizeof(OT);
+#pragma unroll
+            for (int k = 0; k < (CHUNKS + 63) / 64; ++k) {
+                const int cidx = k * 64 + lane;
+                if (cidx < CHUNKS) {
+                    const u32x4 q = *(const u32x4*)((const uint8_t*)&stage[wave][0] + (size_t)cidx * 16);
+                    __builtin_nontemporal_store(q, (u32x4u*)(rows[0] + row_off + (size_t)cidx * 16));
+                    if (rows[1]) __builtin_nontemporal_store(q, (u32x4u*)(rows[1] + row_off + (size_t)cidx * 16));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (!rows[t]) continue;

@@ -211,12 +211,13 @@ def test_batch_pixel_read_default_value():
     assert (gpu[0][4:] == np.array([4.5, 4.0, 3.5], np.float32)).all()
 
 
+@pytest.mark.parametrize("w", [77, 701])  # 701: two full 256-pixel groups (LDS-transposed packed stores) + a ragged tail
 @pytest.mark.parametrize("cn", [1, 2, 3, 4])
 @pytest.mark.parametrize("write_kind", ["write2d", "write3d", "split", "splitT"])
-def test_thread_fused_pointwise_kernel(cn, write_kind):
+def test_thread_fused_pointwise_kernel(cn, write_kind, w):
     """The 4-pixels-per-thread kernel (u8 -> fp32): odd widths (tail lanes), pitched views, batches with default-value
     planes, packed and planar outputs -- bit-exact vs the oracle AND vs the interpreted kernel."""
-    w, h, n = 77, 19, (1 if write_kind == "write2d" else 5)
+    h, n = 19, (1 if write_kind == "write2d" else 5)
     srcs = [_random_src((h + 3, w + 9, cn), "8U", 900 + 10 * cn + i) for i in range(n)]
     stype, ftype = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
 

@@ -102,6 +102,15 @@ def test_pointwise_to_half(src_depth, cn):
     from tests.test_gpu_chains import _random_src
     a = _random_src((45, 67, cn), src_depth, 21)
     st, ht = cvgs.make_type(K.CV_DEPTH[src_depth], cn), cvgs.make_type(cvgs.CV_16F, cn)
+    if src_depth == "8U":  # wide rows too: full 256-pixel groups go through the LDS-transposed packed store
+        wide = _random_src((9, 555, cn), src_depth, 22)
+
+        def packed_wide(wrap, wrap_out, out):
+            return [cvgs.ReadIOp(capi.READ_PIXEL, st, [wrap(wide, st)], 1), cvgs.convertTo(st, ht, 1.0 / 255.0, -0.25),
+                    cvgs.write(ht, wrap_out(out, ht))]
+
+        gpu, ref = _both(packed_wide, (9, 555, cn), np.float16)
+        H.assert_bit_exact(gpu[0], ref[0], "pointwise -> fp16 packed, wide")
 
     def packed(wrap, wrap_out, out):
         return [cvgs.ReadIOp(capi.READ_PIXEL, st, [wrap(a, st)], 1), cvgs.convertTo(st, ht, 1.0 / 255.0, -0.25),

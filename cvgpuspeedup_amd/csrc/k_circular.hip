@@ -68,6 +68,7 @@ int launch_circular_push(const ChainArgs& c_in, const PlaneParams& plane, const 
     int prog_id = 0;
     bool f16 = false;
     if (!pointwise4_plan(c_in, 1, chain_flags, c, g, prog_id, f16)) return 0;
+    if (prog_id == 3) return 0; // non-u8 sources: chain kernel + copy kernel
     if (n_jobs < 1 || n_jobs > kMaxCopyJobs || plane_bytes % 16) return 0;
     for (int i = 0; i < n_jobs; ++i)
         if ((((uintptr_t)copy_jobs[i].src | (uintptr_t)copy_jobs[i].dst) & 15) != 0) return 0;

@@ -6,11 +6,13 @@
 // wide load (4*CN bytes) and writes 16-byte vectors.  Results are bit-identical to the interpreted kernel; chains it
 // does not cover (other depths, integer outputs, SplitWrite) stay on k_generic.  Used by K5/K6/K7 and by the
 // CircularTensor push of an un-resized frame (cfg #4).
+#include <type_traits>
+
 #include "k_pointwise_body.hpp"
 
 namespace cvgs {
 
-template <int CN, int NPL, class Prog, typename OT>
+template <int CN, int NPL, class Prog, typename OT, int SD = CVGS_DEPTH_8U>
 __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const PwGeom g) {
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.z;
@@ -18,22 +20,22 @@ __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const
     if constexpr (NPL == 0) P = c.read.table[z < g.used ? z : 0];
     else P = a.planes[z];
     asm volatile("" ::"s"(g.w), "s"(g.h), "s"(g.used), "s"(P.step));
-    pw4_body<CN, Prog, OT>(c, P, g, (int)blockIdx.x, (int)blockIdx.y, z);
+    pw4_body<CN, Prog, OT, SD>(c, P, g, (int)blockIdx.x, (int)blockIdx.y, z);
 }
 
-template <int CN, class Prog, typename OT>
+template <int CN, class Prog, typename OT, int SD = CVGS_DEPTH_8U>
 static hipError_t launch_pw(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
     const dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         a.c = c;
         a.planes[0] = PlaneParams{};
-        hipLaunchKernelGGL((k_pointwise4<CN, 0, Prog, OT>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_pointwise4<CN, 0, Prog, OT, SD>), grid, dim3(256), 0, s, a, g);
     } else {
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k_pointwise4<CN, CVGS_KERNARG_PLANES, Prog, OT>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_pointwise4<CN, CVGS_KERNARG_PLANES, Prog, OT, SD>), grid, dim3(256), 0, s, a, g);
     }
     return hipGetLastError();
 }
@@ -43,6 +45,25 @@ static hipError_t launch_pw_prog(int prog_id, const ChainArgs& c, const PlanePar
     if (prog_id == 0) return launch_pw<CN, ProgCastMulSubDiv, OT>(c, ip, ni, g, s);
     if (prog_id == 1) return launch_pw<CN, ProgCast, OT>(c, ip, ni, g, s);
     return launch_pw<CN, InterpProg, OT>(c, ip, ni, g, s);
+}
+
+// other source depths, fp32 output: the normalisation chain ([cast,] mul, sub, div) as a compile-time program, anything
+// else interpreted
+using ProgMulSubDivPw = StaticProg<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
+template <int SD, class Prog>
+static hipError_t launch_pw_depth_prog(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    switch (c.read.cn) {
+    case 1: return launch_pw<1, Prog, float, SD>(c, ip, ni, g, s);
+    case 2: return launch_pw<2, Prog, float, SD>(c, ip, ni, g, s);
+    case 3: return launch_pw<3, Prog, float, SD>(c, ip, ni, g, s);
+    default: return launch_pw<4, Prog, float, SD>(c, ip, ni, g, s);
+    }
+}
+template <int SD>
+static hipError_t launch_pw_depth(bool normalise, const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    using Norm = std::conditional_t<SD == CVGS_DEPTH_32F, ProgMulSubDivPw, ProgCastMulSubDiv>;
+    if (normalise) return launch_pw_depth_prog<SD, Norm>(c, ip, ni, g, s);
+    return launch_pw_depth_prog<SD, InterpProg>(c, ip, ni, g, s);
 }
 
 template <typename OT>
@@ -61,9 +82,14 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     const ReadArgs& r = c_in.read;
     const WriteArgs& w = c_in.write;
     if (chain_flags & CVGS_CHAIN_NO_THREAD_FUSION) return false;
-    if (r.kind != CVGS_READ_PIXEL || r.depth != CVGS_DEPTH_8U || r.batch > 65535) return false;
+    if (r.kind != CVGS_READ_PIXEL || r.batch > 65535) return false;
+    const bool u8src = r.depth == CVGS_DEPTH_8U;
+    if (!u8src && r.depth != CVGS_DEPTH_8S && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S && r.depth != CVGS_DEPTH_32S &&
+        r.depth != CVGS_DEPTH_32F)
+        return false;
     f16 = w.depth == CVGS_DEPTH_16F;
     if (!f16 && w.depth != CVGS_DEPTH_32F) return false;
+    if (f16 && !u8src) return false;
     c = c_in;
     if (f16) { // fp16 targets: the chain ends with CAST(CV_16F); that conversion happens in the store
         if (c_in.prog.n < 2 || c_in.prog.opcode[c_in.prog.n - 1] != CVGS_OP_CAST) return false;
@@ -74,8 +100,10 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     if (!planar && !packed) return false;
     // the program must turn the u8 value into fp32 with its first CAST and never change the channel count
     const ProgArgs& p = c.prog;
-    if (p.n < 1 || p.opcode[0] != CVGS_OP_CAST || p.aux[0] != CVGS_DEPTH_32F) return false;
-    for (int k = 1; k < p.n; ++k)
+    // (a CV_32F source needs no cast; every other depth must become fp32 before anything else happens)
+    const bool starts_with_cast = p.n >= 1 && p.opcode[0] == CVGS_OP_CAST && p.aux[0] == CVGS_DEPTH_32F;
+    if (r.depth != CVGS_DEPTH_32F && !starts_with_cast) return false;
+    for (int k = starts_with_cast ? 1 : 0; k < p.n; ++k)
         if (p.opcode[k] != CVGS_OP_MUL && p.opcode[k] != CVGS_OP_ADD && p.opcode[k] != CVGS_OP_SUB && p.opcode[k] != CVGS_OP_DIV &&
             p.opcode[k] != CVGS_OP_REORDER)
             return false;
@@ -83,7 +111,8 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     if (!r.table && n_inline > CVGS_KERNARG_PLANES) return false;
 
     prog_id = 2;
-    if (p.n == 4 && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV) prog_id = 0;
+    if (!u8src) prog_id = 3; // interpreted program, per-depth kernel
+    else if (p.n == 4 && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV) prog_id = 0;
     else if (p.n == 1) prog_id = 1;
 
     g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn;
@@ -115,12 +144,28 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
     if (info) {
         static const char* names[2][3] = {{"pointwise4_u8_cast_mul_sub_div", "pointwise4_u8_cast", "pointwise4_u8_interp"},
                                           {"pointwise4_u8_cast_mul_sub_div_f16", "pointwise4_u8_cast_f16", "pointwise4_u8_interp_f16"}};
-        info->kernel = names[f16][prog_id];
+        static const char* by_depth[6] = {"", "pointwise4_s8", "pointwise4_u16", "pointwise4_s16", "pointwise4_s32", "pointwise4_f32"};
+        info->kernel = prog_id == 3 ? by_depth[c.read.depth] : names[f16][prog_id];
     }
     if (dry_run) return 1;
     hipStream_t s = (hipStream_t)stream;
-    const hipError_t e = f16 ? launch_pw_cn<_Float16>(prog_id, c, inline_planes, n_inline, g, s)
-                             : launch_pw_cn<float>(prog_id, c, inline_planes, n_inline, g, s);
+    hipError_t e;
+    if (prog_id == 3) {
+        const ProgArgs& p = c.prog;
+        const int o = c.read.depth == CVGS_DEPTH_32F ? 0 : 1; // ops after the leading cast
+        const bool norm = p.n == o + 3 && p.opcode[o] == CVGS_OP_MUL && p.opcode[o + 1] == CVGS_OP_SUB && p.opcode[o + 2] == CVGS_OP_DIV &&
+                          (o == 0 || (p.opcode[0] == CVGS_OP_CAST && p.aux[0] == CVGS_DEPTH_32F));
+        switch (c.read.depth) {
+        case CVGS_DEPTH_8S: e = launch_pw_depth<CVGS_DEPTH_8S>(norm, c, inline_planes, n_inline, g, s); break;
+        case CVGS_DEPTH_16U: e = launch_pw_depth<CVGS_DEPTH_16U>(norm, c, inline_planes, n_inline, g, s); break;
+        case CVGS_DEPTH_16S: e = launch_pw_depth<CVGS_DEPTH_16S>(norm, c, inline_planes, n_inline, g, s); break;
+        case CVGS_DEPTH_32S: e = launch_pw_depth<CVGS_DEPTH_32S>(norm, c, inline_planes, n_inline, g, s); break;
+        default: e = launch_pw_depth<CVGS_DEPTH_32F>(norm, c, inline_planes, n_inline, g, s); break;
+        }
+    } else {
+        e = f16 ? launch_pw_cn<_Float16>(prog_id, c, inline_planes, n_inline, g, s)
+                : launch_pw_cn<float>(prog_id, c, inline_planes, n_inline, g, s);
+    }
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 

@@ -40,8 +40,21 @@ struct PwGeom {
     uint8_t* out2;
 };
 
+// source element -> the work pixel's float (8/16-bit integers exact, CV_32S as raw bits, CV_32F as is: load_px's rule)
+template <int SD>
+__device__ __forceinline__ float elem_value(const uint32_t* raw, int e) {
+    if constexpr (SD == CVGS_DEPTH_8U) return (float)((raw[e >> 2] >> (8 * (e & 3))) & 0xffu);
+    else if constexpr (SD == CVGS_DEPTH_8S) return (float)(int8_t)((raw[e >> 2] >> (8 * (e & 3))) & 0xffu);
+    else if constexpr (SD == CVGS_DEPTH_16U) return (float)((raw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+    else if constexpr (SD == CVGS_DEPTH_16S) return (float)(int16_t)((raw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+    else return __uint_as_float(raw[e]);
+}
+template <int SD> constexpr int src_elem_bytes = (SD == CVGS_DEPTH_8U || SD == CVGS_DEPTH_8S) ? 1 : ((SD == CVGS_DEPTH_16U || SD == CVGS_DEPTH_16S) ? 2 : 4);
+
 // One thread's work: pixels x0..x0+3 of row y of plane z.  (bx, by) = the 256-pixel column group and the 4-row group.
-template <int CN, class Prog, typename OT>
+// SD = source depth (8U is the hot one; the reference sweeps its pointwise chains over 8S/16U/16S/32S/32F as well,
+// tests/batchread/test_batchread_x_write3D.cu:202-227).
+template <int CN, class Prog, typename OT, int SD = CVGS_DEPTH_8U>
 __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& P, const PwGeom& g, int bx, int by, int z) {
     const int W = g.w, H = g.h, used = g.used;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -51,30 +64,33 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
     if (y >= H || x0 >= W) return;
     const int npx = min(4, W - x0);
 
-    // ---- read 4 pixels ----
-    uint32_t raw[CN]; // 4*CN bytes
+    // ---- read 4 pixels: 4*CN elements = NDW dwords, one wide load ----
+    constexpr int EB = src_elem_bytes<SD>;
+    constexpr int NDW = CN * EB;
+    uint32_t raw[NDW];
     if (z < used) {
-        const gp_u8 row = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * CN;
+        const gp_u8 row = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * CN * EB;
         if (npx == 4) {
 #pragma unroll
-            for (int k = 0; k < CN; ++k) raw[k] = *(gp_u32)(row + 4 * k);
+            for (int k = 0; k < NDW; ++k) raw[k] = *(gp_u32)(row + 4 * k);
         } else {
 #pragma unroll
-            for (int k = 0; k < CN; ++k) raw[k] = 0;
+            for (int k = 0; k < NDW; ++k) raw[k] = 0;
 #pragma unroll
-            for (int b = 0; b < 4 * CN; ++b)
-                if (b < npx * CN) raw[b >> 2] |= (uint32_t)row[b] << (8 * (b & 3));
+            for (int b = 0; b < 4 * CN * EB; ++b)
+                if (b < npx * CN * EB) raw[b >> 2] |= (uint32_t)row[b] << (8 * (b & 3));
         }
     }
     Px px[4];
-    int depth = CVGS_DEPTH_8U, cn = CN;
+    int depth = SD, cn = CN;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             if (ch < CN) {
-                const int b = i * CN + ch;
-                px[i].v[ch] = z < used ? (float)((raw[b >> 2] >> (8 * (b & 3))) & 0xffu) : c.read.bg[ch];
+                // default-value planes carry the background in the source type (CV_32S: as an integer)
+                const float bgv = SD == CVGS_DEPTH_32S ? from_int((int)c.read.bg[ch]) : c.read.bg[ch];
+                px[i].v[ch] = z < used ? elem_value<SD>(raw, i * CN + ch) : bgv;
             } else {
                 px[i].v[ch] = 0.f;
             }

@@ -295,3 +295,43 @@ def test_stream_copy(nbytes, off):
     torch.cuda.synchronize()
     assert torch.equal(dst[off:off + nbytes], src[off:off + nbytes])
     assert not dst[:off].any() and not dst[off + nbytes:].any()
+
+
+@pytest.mark.parametrize("depth,cn", [("8S", 1), ("8S", 3), ("16U", 1), ("16U", 3), ("16U", 4), ("16S", 2), ("16S", 3), ("32S", 1),
+                                      ("32S", 3), ("32F", 1), ("32F", 2), ("32F", 3), ("32F", 4)])
+@pytest.mark.parametrize("out", ["packed", "planar"])
+def test_thread_fused_pointwise_other_depths(depth, cn, out):
+    """The reference sweeps its pointwise chains over every source depth (tests/batchread/test_batchread_x_write3D.cu:202-227,
+    tests/read/test_read_x_write.cu:121-144): 4 pixels per thread for 8S/16U/16S/32S/32F sources too -- wide rows (full
+    256-pixel groups + a ragged tail), pitched views, default-value planes; vs the oracle and vs the interpreted kernel."""
+    w, h, n = 523, 11, 3
+    srcs = [_random_src((h + 2, w + 7, cn), depth, 1200 + 10 * cn + i) for i in range(n)]
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+
+    def build(wrap, wrap_out, out_buf):
+        mats = [wrap(s, st).roi(3, 1, w, h) for s in srcs]
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, mats, n - 1, None, cvgs.IGNORE_AR, [9.0, 8.0, 7.0, 6.0][:cn])]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(st, f))
+        ops += [cvgs.multiply(f, [0.3] * cn), cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn])]
+        if out == "packed":
+            return ops + [cvgs.write(f, wrap_out(out_buf, f), (w, h))]
+        o = wrap_out(out_buf, cvgs.CV_32FC1)
+        return ops + [cvgs.split(f, o, (w, h)) if cn > 1 else cvgs.write(f, o, (w, h))]
+
+    shape = (n, w * h, cn) if out == "packed" else (n, cn * w * h)
+    gpu, ref = _both(build, shape, np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "fused pointwise %sC%d %s" % (depth, cn, out))
+    gen, _ = _both(build, shape, np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gpu[0], gen[0], "fused vs interpreted")
+    import torch
+    t = torch.from_numpy(srcs[0]).cuda()
+    o = torch.zeros((1, cn * w * h), dtype=torch.float32, device="cuda")
+    chain = [cvgs.ReadIOp(capi.READ_PIXEL, st, [cvgs.GpuMat.from_tensor(t, st).roi(3, 1, w, h)], 1)]
+    if depth != "32F":
+        chain.append(cvgs.convertTo(st, f))
+    chain += [cvgs.multiply(f, [0.3] * cn), cvgs.write(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1).roi(0, 0, w * h, 1) if False else
+                                                      cvgs.GpuMat.from_tensor(o.view(1, w * h * cn) if cn == 1 else o, cvgs.CV_32FC1), (w, h))] if cn == 1 else \
+             [cvgs.multiply(f, [0.3] * cn), cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (w, h))]
+    want = {"8S": "s8", "16U": "u16", "16S": "s16", "32S": "s32", "32F": "f32"}[depth]
+    assert cvgs.kernel_name(*chain) == "pointwise4_%s" % want

@@ -57,7 +57,7 @@ PLANES_STANDARD, PLANES_TRANSPOSED = 0, 1
 
 class Image2D(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("step", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("uv_offset", C.c_int32)]
 
 
 class ReadDesc(C.Structure):

@@ -207,6 +207,10 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             P.w = im.width;
             P.h = im.height;
             P.step = im.step;
+            if (is_nv12(rd.kind)) {
+                if (im.uv_offset < 0 || (im.uv_offset & 1)) return fail(CVGS_ERR_INVALID, "NV12 uv_offset must be even and non-negative");
+                P.uv_off = im.uv_offset ? im.uv_offset : im.height * im.step;
+            }
             if (R.is_resize) plane_geometry(im.width, im.height, rd.dst_width, rd.dst_height, rd.aspect_ratio, P);
             else if (im.width != src[0].width || im.height != src[0].height)
                 return fail(CVGS_ERR_INVALID, "batched pixel reads need planes of one size");

@@ -18,7 +18,7 @@ struct PlaneParams {        // 48 bytes
     int32_t step;           // bytes between source rows
     float fx, fy;           // source step per destination pixel (resize kinds)
     int32_t x1, y1, x2, y2; // inclusive destination window fed from the source (AR modes)
-    int32_t pad;
+    int32_t uv_off;         // NV12: bytes from `data` to the UV row of luma row 0 (h * step for a whole surface)
 };
 static_assert(sizeof(PlaneParams) == 48, "PlaneParams layout");
 

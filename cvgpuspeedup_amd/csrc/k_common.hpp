@@ -267,7 +267,7 @@ __device__ __forceinline__ void yuv_to_rgb(float Y, float U, float V, const YuvK
 
 __device__ __forceinline__ void nv12_px(const PlaneParams& P, int x, int y, const YuvK& k, Px& p) {
     const float Y = (float)P.data[(size_t)y * P.step + x];
-    const uint8_t* uv = P.data + (size_t)(P.h + (y >> 1)) * P.step + 2 * (x >> 1);
+    const uint8_t* uv = P.data + (size_t)P.uv_off + (size_t)(y >> 1) * P.step + 2 * (x >> 1);
     yuv_to_rgb(Y, (float)uv[0], (float)uv[1], k, p);
 }
 

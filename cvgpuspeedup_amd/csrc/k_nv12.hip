@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
                  op2 = *(const f32x4s*)c.prog.operand[2], op3 = *(const f32x4s*)c.prog.operand[3];
     // one batch of scalar loads, one wait (see k_k1.hip)
-    asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(W), "s"(CN), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.fx), "s"(P.fy), "s"(P.data),
+    asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(W), "s"(CN), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.fx), "s"(P.fy), "s"(P.data), "s"(P.uv_off),
                  "s"(yuv_range), "s"(yuv_prim), "s"(packed), "s"(img_stride), "s"(ch_stride), "s"(out_base), "s"(op0), "s"(op1),
                  "s"(op2), "s"(op3));
     const YuvK yk = yuv_matrix(yuv_range, yuv_prim);
@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     const size_t step = (size_t)P.step;
     const gptr_b ya = base + (size_t)__builtin_amdgcn_readfirstlane(y1) * step;
     const gptr_b yb = base + (size_t)__builtin_amdgcn_readfirstlane(y2r) * step;
-    const gptr_b ua = base + (size_t)__builtin_amdgcn_readfirstlane(P.h + (y1 >> 1)) * step;
-    const gptr_b ub = base + (size_t)__builtin_amdgcn_readfirstlane(P.h + (y2r >> 1)) * step;
+    const gptr_b uvp = base + (size_t)P.uv_off; // crops of a surface carry their own luma -> chroma offset
+    const gptr_b ua = uvp + (size_t)__builtin_amdgcn_readfirstlane(y1 >> 1) * step;
+    const gptr_b ub = uvp + (size_t)__builtin_amdgcn_readfirstlane(y2r >> 1) * step;
     const uint32_t vya = *(gptr_u16)(ya + yo);
     const uint32_t vyb = *(gptr_u16)(yb + yo);
     const uint32_t vua = *(gptr_u32)(ua + uo);
@@ -145,11 +146,16 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
         a.c = c;
         a.planes[0] = PlaneParams{};
         hipLaunchKernelGGL((k4_nv12_resize<0, Prog>), grid, dim3(256), 0, s, a, g);
-    } else {
+    } else if (ni <= 8) {
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
         hipLaunchKernelGGL((k4_nv12_resize<8, Prog>), grid, dim3(256), 0, s, a, g);
+    } else { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
+        KernArgs<CVGS_KERNARG_PLANES> a;
+        a.c = c;
+        for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
+        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog>), grid, dim3(256), 0, s, a, g);
     }
     return hipGetLastError();
 }
@@ -159,8 +165,12 @@ int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inli
                 bool dry_run, LaunchInfo* info) {
     const ReadArgs& r = c.read;
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
-    if (r.table || n_inline > 8 || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
+    if (r.table || n_inline > CVGS_KERNARG_PLANES || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
     if (r.used != r.batch || r.batch > 65535) return 0;
+    for (int i = 0; i < n_inline; ++i) { // aspect-ratio padding is the generic kernel's business
+        const PlaneParams& P = inline_planes[i];
+        if (P.x1 != 0 || P.y1 != 0 || P.x2 != r.dst_w - 1 || P.y2 != r.dst_h - 1) return 0;
+    }
     const WriteArgs& w = c.write;
     const bool planar = (w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT) && w.depth == CVGS_DEPTH_32F;
     const bool packed = w.kind == CVGS_WRITE_PIXEL_2D || w.kind == CVGS_WRITE_PIXEL_3D;

@@ -86,7 +86,20 @@ class GpuMat:
         return GpuMat(1, self.cols, self.cv_type, self.data + i * self.step, self.step, owner=self.owner)
 
     def image2d(self):
-        return capi.Image2D(self.data, self.cols, self.rows, self.step, 0)
+        return capi.Image2D(self.data, self.cols, self.rows, self.step, getattr(self, "uv_offset", 0))
+
+    def nv12_roi(self, x, y, w, h):
+        """Crop of an NV12 luma view (rows = luma height; the UV plane follows it, or sits at self.uv_offset): a view
+        like any other crop, plus the luma -> chroma offset the read stage needs.  x, y, w, h must be even."""
+        x, y, w, h = int(x), int(y), int(w), int(h)
+        if (x | y | w | h) & 1:
+            raise ValueError("NV12 crops need even x, y, width and height")
+        if x < 0 or y < 0 or x + w > self.cols or y + h > self.rows:
+            raise ValueError("ROI outside the matrix")
+        parent_uv = getattr(self, "uv_offset", 0) or self.rows * self.step
+        m = GpuMat(h, w, self.cv_type, self.data + y * self.step + x, self.step, owner=self.owner)
+        m.uv_offset = parent_uv + (y // 2 - y) * self.step
+        return m
 
 
 def _scalar(vals, n=4):
@@ -217,7 +230,8 @@ def read_nv12(mat, dsize=None, color_range=capi.YUV_FULL, primaries=capi.BT709, 
     BackIOp of fk::Resize<INTER_LINEAR> (reference tests/resize/test_fused_resize.cu:141-143).
     `mat` is the CV_8UC1 luma view (rows = luma height); the UV plane follows it in memory."""
     kind = capi.READ_NV12 if dsize is None else capi.READ_NV12_RESIZE_LINEAR
-    return ReadIOp(kind, make_type(DEPTH_8U, 1), [mat], 1, dsize, IGNORE_AR, None,
+    mats = [mat] if isinstance(mat, GpuMat) else list(mat)  # a list = N crops (GpuMat.nv12_roi) of decoder surfaces, one launch
+    return ReadIOp(kind, make_type(DEPTH_8U, 1), mats, len(mats), dsize, IGNORE_AR, None,
                    (color_range, primaries, 1 if alpha else 0))
 
 

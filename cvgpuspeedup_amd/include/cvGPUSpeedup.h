@@ -179,6 +179,21 @@ inline auto cvtColorNV12(const cv::cuda::GpuMat& nv12) {
     luma.dims = {(uint)nv12.cols, (uint)(nv12.rows / 3 * 2), (uint)nv12.step};
     return fk::YuvRead<fk::NV12, CR, CP, alpha, O, swap>{luma};
 }
+// cvtColorNV12<CODE>(nv12, crops): N crops of the surface (even x, y, width, height) as a batch of N planes -- with
+// resize<INTER>(thatIOp, dsize) the decode-side version of the headline path: N detections of a decoder surface ->
+// colour conversion -> bilinear resize -> normalize -> NCHW tensor, ONE kernel, no intermediate BGR frame.
+template <cv::ColorConversionCodes CODE, fk::ColorRange CR = fk::Full, fk::ColorPrimitives CP = fk::bt709, size_t N>
+inline auto cvtColorNV12(const cv::cuda::GpuMat& nv12, const std::array<cv::Rect, N>& crops) {
+    auto rd = cvtColorNV12<CODE, CR, CP>(nv12);
+    const int H = nv12.rows / 3 * 2, step = (int)nv12.step;
+    for (const cv::Rect& r : crops) {
+        if ((r.x | r.y | r.width | r.height) & 1) throw std::runtime_error("NV12 crops need even x, y, width and height");
+        if (r.x < 0 || r.y < 0 || r.width < 2 || r.height < 2 || r.x + r.width > nv12.cols || r.y + r.height > H)
+            throw std::runtime_error("NV12 crop outside the surface");
+        rd.crops.push_back(cvgs_image2d{nv12.data + (size_t)r.y * step + r.x, r.width, r.height, step, (H - r.y + r.y / 2) * step});
+    }
+    return rd;
+}
 template <int INTER_F, fk::PixelFormat PF, fk::ColorRange CR, fk::ColorPrimitives CP, bool ALPHA, typename O, bool SW>
 inline auto resize(const fk::YuvRead<PF, CR, CP, ALPHA, O, SW>& nv12Read, const cv::Size& dsize) {
     static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");

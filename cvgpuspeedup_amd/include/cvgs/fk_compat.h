@@ -444,6 +444,9 @@ struct ConvertYUVToRGB {
 // fuse(Read<ReadYUV>, Unary<ConvertYUVToRGB>) -> one read IOp producing RGB(A)
 template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O, bool SWAP_RB = false> struct YuvRead {
     RawPtr<_2D, uchar> params;
+    // optional: N crops of the surface (even x, y, w, h), each a view with its own luma -> chroma offset; the read is
+    // then a batch of N planes in ONE launch (engine extension: crops straight from a decoder surface)
+    std::vector<cvgs_image2d> crops;
     using OutputType = O;
     static constexpr Stage stage = Stage::Read;
     static constexpr bool float_out = std::is_same_v<VBase<O>, float>;
@@ -453,9 +456,11 @@ template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typenam
     }
     void lower_read(ChainBuilder& b, int kind) const {
         cvgs_read_desc& r = b.d.read;
-        r.kind = kind; r.src_type = CV_8UC1; r.batch = 1; r.used_planes = 1;
+        r.kind = kind; r.src_type = CV_8UC1;
         r.yuv_range = (int)CR; r.yuv_primaries = (int)CP; r.yuv_alpha = ALPHA ? 1 : 0;
-        b.src.assign(1, image2d(params));
+        if (crops.empty()) b.src.assign(1, image2d(params));
+        else b.src = crops;
+        r.batch = r.used_planes = (int)b.src.size();
     }
     void lower(ChainBuilder& b) const {
         lower_read(b, CVGS_READ_NV12);

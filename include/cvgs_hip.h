@@ -73,7 +73,10 @@ typedef struct cvgs_image2d {
     int32_t width;    /* pixels                                   */
     int32_t height;   /* rows (NV12: luma rows; UV plane follows) */
     int32_t step;     /* bytes between rows                       */
-    int32_t reserved;
+    /* NV12 kinds only: bytes from `data` to the interleaved UV row that belongs to luma row 0 of this view.
+     * 0 = height * step (a whole surface: the UV plane directly below the luma plane).  A CROP of a surface at an
+     * even (x, y) is then a view like any other: data = Y + y*step + x, uv_offset = (UV + (y/2)*step + x) - data. */
+    int32_t uv_offset;
 } cvgs_image2d;
 
 /* ---- read stage (first IOp of the chain) ------------------------------------------------- */

@@ -198,7 +198,9 @@ static yuv_coeffs yuv_matrix(int range, int primaries) {
 static void nv12_pixel(const cvgs_image2d* im, int x, int y, const cvgs_read_desc* rd, opx* p) {
     const uint8_t* base = (const uint8_t*)im->data;
     const float Y = (float)base[(size_t)y * im->step + x];
-    const uint8_t* uv = base + (size_t)(im->height + y / 2) * im->step + 2 * (x / 2);
+    /* a crop of a surface carries its own luma -> chroma offset (cvgs_image2d.uv_offset); 0 = the whole surface */
+    const size_t uv_off = im->uv_offset ? (size_t)im->uv_offset : (size_t)im->height * (size_t)im->step;
+    const uint8_t* uv = base + uv_off + (size_t)(y / 2) * im->step + 2 * (x / 2);
     const float cb = (float)uv[0] - 128.f;
     const float cr = (float)uv[1] - 128.f;
     const yuv_coeffs k = yuv_matrix(rd->yuv_range, rd->yuv_primaries);

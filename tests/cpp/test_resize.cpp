@@ -130,9 +130,45 @@ static void test_nv12_facade_cfg3(cv::cuda::Stream& stream) {
     CHECK(bit_equal(h.data(), h_ref.data, h.size()), "cfg3 through cvGS::cvtColorNV12 + resize, bit-exact vs oracle");
 }
 
+// the decode-side headline path: N crops of an NV12 surface -> BGR float -> 64x128 -> normalize -> NCHW, ONE kernel;
+// each crop must equal the single-surface chain run on a copy of that crop (same taps, same arithmetic)
+static void test_nv12_crops_batch(cv::cuda::Stream& stream) {
+    const int W = 1280, H = 720;
+    constexpr size_t N = 12;
+    const cv::Size up(64, 128);
+    cv::Mat h_nv12(H + H / 2, W, CV_8UC1);
+    fill_random(h_nv12, 999);
+    cv::cuda::GpuMat d_nv12(h_nv12), hv_nv12 = host_view(h_nv12);
+    std::array<cv::Rect, N> crops;
+    for (size_t i = 0; i < N; ++i) crops[i] = cv::Rect(2 * (int)(i * 37 % 400), 2 * (int)(i * 23 % 200), 16 + 2 * (int)(i * 41 % 300), 32 + 2 * (int)(i * 29 % 150));
+    const size_t n = N * 3 * up.width * up.height;
+    cv::cuda::GpuMat d_out((int)N, up.width * up.height * 3, CV_32F);
+    cv::Mat h_ref((int)N, up.width * up.height * 3, CV_32F);
+    cv::cuda::GpuMat hv_ref = host_view(h_ref);
+    const cv::Scalar a(0.3, 0.3, 0.3), s(1.f, 4.f, 3.2f), d(3.2f, 0.6f, 11.8f);
+    cvGS::executeOperations(stream, cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12>(d_nv12, crops), up),
+                            cvGS::multiply<CV_32FC3>(a), cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(d_out, up));
+    run_oracle(cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12>(hv_nv12, crops), up), cvGS::multiply<CV_32FC3>(a),
+               cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(hv_ref, up));
+    stream.waitForCompletion();
+    const auto h = fetch(d_out.data, n * 4);
+    CHECK(bit_equal(h.data(), h_ref.data, n * 4), "NV12 crop batch -> NCHW, bit-exact vs oracle");
+    // crop 5, copied into its own small NV12 surface, through the single-surface chain (host oracle): must be identical
+    const cv::Rect r = crops[5];
+    cv::Mat h_small(r.height + r.height / 2, r.width, CV_8UC1);
+    for (int y = 0; y < r.height; ++y) std::memcpy(h_small.ptr<uchar>(y), h_nv12.ptr<uchar>(r.y + y) + r.x, (size_t)r.width);
+    for (int y = 0; y < r.height / 2; ++y) std::memcpy(h_small.ptr<uchar>(r.height + y), h_nv12.ptr<uchar>(H + r.y / 2 + y) + r.x, (size_t)r.width);
+    cv::Mat h_one(1, up.width * up.height * 3, CV_32F);
+    cv::cuda::GpuMat hv_small = host_view(h_small), hv_one = host_view(h_one);
+    run_oracle(cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12>(hv_small), up), cvGS::multiply<CV_32FC3>(a),
+               cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(hv_one, up));
+    CHECK(bit_equal(h_one.data, h_ref.ptr<uchar>(5), (size_t)up.width * up.height * 3 * 4), "a crop view == the same pixels as their own surface");
+}
+
 int main() {
     cv::cuda::Stream stream;
     test_nv12_facade_cfg3(stream);
+    test_nv12_crops_batch(stream);
     test_resize_split_one<CV_8UC3, CV_32FC3>(stream);
     test_resize_split_one<CV_8UC4, CV_32FC4>(stream);
     test_resize_split_one<CV_16UC3, CV_32FC3>(stream);

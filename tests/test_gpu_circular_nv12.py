@@ -259,3 +259,62 @@ def test_circular_tensor_depth_extremes(oracle, batch, mirrored):
     got = _read_device(ct.data(), ct.nbytes()).view(np.float32)
     H.assert_bit_exact(got, oc.array(np.float32), "circular depth %d mirrored %s" % (batch, mirrored))
     ct.release()
+
+
+@pytest.mark.parametrize("n", [6, 50])
+def test_nv12_crop_batch_to_nchw(oracle, n):
+    """The decode-side version of the headline path: N crops (GpuMat.nv12_roi views: even x/y/w/h, own luma -> chroma
+    offset) of ONE NV12 surface -> BGR float -> bilinear 64x128 -> normalize -> NCHW, one launch of the K4 kernel."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h, dst = 1920, 1080, (64, 128)
+    buf = _nv12(w, h, 4321)
+    f = cvgs.CV_32FC3
+    rng = np.random.default_rng(n)
+    rects = []
+    for _ in range(n):
+        cw, ch = 2 * int(rng.integers(8, 250)), 2 * int(rng.integers(8, 400))
+        rects.append((2 * int(rng.integers(0, (w - cw) // 2)), 2 * int(rng.integers(0, (h - ch) // 2)), cw, ch))
+
+    def chain(luma, out):
+        rd = cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], dst, capi.YUV_LIMITED, capi.BT709, False)
+        return [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]),
+                cvgs.divide(f, H.K1_DIV[3]), cvgs.split(f, out, dst)]
+
+    ref = np.zeros((n, 3 * dst[0] * dst[1]), np.float32)
+    m = cvgs.GpuMat.from_array(buf, cvgs.CV_8UC1)
+    luma_h = cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
+    oracle.execute(cvgs.lower(chain(luma_h, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+    t = torch.from_numpy(buf).to(dev)
+    o = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
+    md = cvgs.GpuMat.from_tensor(t, cvgs.CV_8UC1)
+    luma_d = cvgs.GpuMat(h, w, cvgs.CV_8UC1, md.data, md.step, owner=md.owner)
+    ops = chain(luma_d, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1))
+    assert cvgs.kernel_name(*ops) == "k4_nv12_resize_swap_mul_sub_div"
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(o.cpu().numpy(), ref, "NV12 crop batch")
+    assert ref.std() > 1
+    # a crop view reads exactly the pixels a copy of that crop would: crop 0 as its own little surface
+    x, y, cw, ch = rects[0]
+    small = np.concatenate([buf[y:y + ch, x:x + cw], buf[h + y // 2:h + y // 2 + ch // 2, x:x + cw]], axis=0).copy()
+    one = np.zeros((1, 3 * dst[0] * dst[1]), np.float32)
+    ms = cvgs.GpuMat.from_array(small, cvgs.CV_8UC1)
+    ls = cvgs.GpuMat(ch, cw, cvgs.CV_8UC1, ms.data, ms.step, owner=ms.owner)
+    rd = cvgs.read_nv12(ls, dst, capi.YUV_LIMITED, capi.BT709, False)
+    oracle.execute(cvgs.lower([rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]),
+                               cvgs.divide(f, H.K1_DIV[3]), cvgs.split(f, cvgs.GpuMat.from_array(one, cvgs.CV_32FC1), dst)]))
+    H.assert_bit_exact(one[0], ref[0], "crop view == crop copy")
+
+
+def test_nv12_preserve_ar_stays_on_the_generic_kernel():
+    """The K4 fast kernel has no aspect-ratio window: such chains must be routed to the interpreted kernel."""
+    import torch
+    t = torch.zeros((360 + 180, 640), dtype=torch.uint8, device="cuda:0")
+    o = torch.zeros((1, 3 * 64 * 64), dtype=torch.float32, device="cuda:0")
+    md = cvgs.GpuMat.from_tensor(t, cvgs.CV_8UC1)
+    luma = cvgs.GpuMat(360, 640, cvgs.CV_8UC1, md.data, md.step, owner=md.owner)
+    rd = cvgs.read_nv12(luma, (64, 64), capi.YUV_FULL, capi.BT709, False)
+    rd.ar = cvgs.PRESERVE_AR
+    name = cvgs.kernel_name(rd, cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (64, 64)))
+    assert name.startswith("generic"), name

@@ -101,6 +101,50 @@ def cfg3(dev, iters):
             "output_Mpix_per_s": round(dst[0] * dst[1] / t / 1e6, 1), "source_Mpix_per_s": round(w * h / t / 1e6, 1)}
 
 
+def nv12_crops(dev, iters, n=50):
+    """The decode-side version of cfg #2b: n crops (even x/y/w/h, the cfg #2b size distribution) of a 4K NV12 decoder
+    surface -> BGR float -> 64x128 -> normalize -> [n,3,128,64], one launch."""
+    w, h = W.FRAME_4K
+    dst = W.DST
+    f = cvgs.CV_32FC3
+    lib = capi.load_library()
+    s = torch.cuda.current_stream()
+    chains, keep, ops = [], [], None
+    for i in range(16):
+        buf = W.random_u8_torch((h + h // 2, w), 800 + i, dev)
+        out = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, buf.data_ptr(), w, owner=buf)
+        rects = [(x & ~1, y & ~1, max(2, cw & ~1), max(2, ch & ~1)) for (x, y, cw, ch) in W.random_crops(n, w, h, seed=W.SEED + 900 + i)]
+        ops = [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], dst, capi.YUV_LIMITED, capi.BT709, False),
+               cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]),
+               cvgs.divide(f, W.K1_DIV[3]), cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst)]
+        keep += [buf, out]
+        chains.append(cvgs.lower(ops))
+    state = {"i": 0}
+
+    def launch():
+        ch = chains[state["i"] % len(chains)]
+        state["i"] += 1
+        capi.check(lib.cvgs_execute(C.byref(ch.desc), s.cuda_stream))
+
+    # replay from a HIP graph like the headline (the host's launch rate is not the point)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        launch()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            s2 = torch.cuda.current_stream()
+            for _ in range(64):
+                ch = chains[state["i"] % len(chains)]
+                state["i"] += 1
+                capi.check(lib.cvgs_execute(C.byref(ch.desc), s2.cuda_stream))
+        t = events_time(g.replay, max(4, iters // 8)) / 64
+    return {"config": "decode-side cfg2b: %d crops of a 4K NV12 surface -> BGR float -> 64x128 -> normalize -> NCHW, one kernel" % n,
+            "kernel": cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2),
+            "output_Mpix_per_s": round(n * dst[0] * dst[1] / t / 1e6, 1)}
+
+
 def run_all(dev, iters=100, only=""):
     res = []
     if only in ("", "cfg4"):
@@ -111,6 +155,8 @@ def run_all(dev, iters=100, only=""):
         res.append(cfg4(dev, iters, True, mirrored=True))
     if only in ("", "cfg3"):
         res.append(cfg3(dev, iters))
+    if only in ("", "nv12crops"):
+        res.append(nv12_crops(dev, iters))
     return res
 
 

@@ -5,6 +5,7 @@
 #include <cvGPUSpeedup.cuh>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
@@ -48,6 +49,25 @@ int main() {
     float mean = 0.f;
     for (float v : us) mean += v;
     mean /= (float)us.size();
+    // host enqueue time per call: what the reference's "CPU" benchmark measures (benchmarks/benchmark_CPU_OpenCV_vs_cvGS.cu:
+    // the time the host spends building the IOps and launching, not the kernel).  256 back-to-back calls, no sync.
+    constexpr int CALLS = 256; // fewer than the queue holds: the host is never throttled by the device
+    stream.waitForCompletion();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < CALLS; ++it)
+        cvGS::executeOperations(stream,
+                                cvGS::resize<CV_8UC3, cv::INTER_LINEAR, MAX_DETECTIONS>(crops, resDims, activeDetections),
+                                cvGS::multiply<CV_32FC3>(cv::Scalar(alpha, alpha, alpha)),
+                                cvGS::subtract<CV_32FC3>(subtract_val),
+                                cvGS::divide<CV_32FC3>(divide_val),
+                                cvGS::split<CV_32FC3>(output, resDims));
+    const auto t1 = std::chrono::steady_clock::now();
+    stream.waitForCompletion();
+    const auto t2 = std::chrono::steady_clock::now();
+    std::printf("host enqueue: %.2f us per cvGS::executeOperations call (C++: build IOps + lower + cvgs_execute + hipLaunchKernel); "
+                "%.2f us per call including the device drain\n",
+                std::chrono::duration<double, std::micro>(t1 - t0).count() / CALLS,
+                std::chrono::duration<double, std::micro>(t2 - t0).count() / CALLS);
     cv::Mat h_out;
     output.download(h_out);
     // constant frame: every pixel of plane c equals (init[c] * 0.5 - sub[c]) / 255

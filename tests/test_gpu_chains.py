@@ -330,8 +330,8 @@ def test_thread_fused_pointwise_other_depths(depth, cn, out):
     chain = [cvgs.ReadIOp(capi.READ_PIXEL, st, [cvgs.GpuMat.from_tensor(t, st).roi(3, 1, w, h)], 1)]
     if depth != "32F":
         chain.append(cvgs.convertTo(st, f))
-    chain += [cvgs.multiply(f, [0.3] * cn), cvgs.write(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1).roi(0, 0, w * h, 1) if False else
-                                                      cvgs.GpuMat.from_tensor(o.view(1, w * h * cn) if cn == 1 else o, cvgs.CV_32FC1), (w, h))] if cn == 1 else \
-             [cvgs.multiply(f, [0.3] * cn), cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (w, h))]
+    chain.append(cvgs.multiply(f, [0.3] * cn))
+    o_mat = cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1)
+    chain.append(cvgs.split(f, o_mat, (w, h)) if cn > 1 else cvgs.write(f, o_mat, (w, h)))
     want = {"8S": "s8", "16U": "u16", "16S": "s16", "32S": "s32", "32F": "f32"}[depth]
     assert cvgs.kernel_name(*chain) == "pointwise4_%s" % want

@@ -147,23 +147,19 @@ __device__ __forceinline__ float elem_to_float(uint32_t bits) {
 template <int CN, int SRC>
 __device__ __forceinline__ void unpack_pair(const Win<elem_bytes<SRC>>& w, bool edge, float* a, float* b) {
     if constexpr (SRC == SRC_U8) {
-        const uint32_t lo = (uint32_t)w.lo, hi = (uint32_t)(w.lo >> 32);
-        const uint32_t second = CN == 3 ? (uint32_t)(w.lo >> 24) : hi;
+        // pixel 0 = bytes 0..CN-1, pixel 1 = bytes CN..2CN-1 of the 8-byte window
+        const uint32_t lo = (uint32_t)w.lo;
+        const uint32_t second = (uint32_t)(w.lo >> (8 * CN));
         const uint32_t s = edge ? lo : second;
-        a[0] = (float)(lo & 0xffu);
-        a[1] = (float)((lo >> 8) & 0xffu);
-        a[2] = (float)((lo >> 16) & 0xffu);
-        b[0] = (float)(s & 0xffu);
-        b[1] = (float)((s >> 8) & 0xffu);
-        b[2] = (float)((s >> 16) & 0xffu);
-        if constexpr (CN == 4) {
-            a[3] = (float)(lo >> 24);
-            b[3] = (float)(s >> 24);
+#pragma unroll
+        for (int k = 0; k < CN; ++k) {
+            a[k] = (float)((lo >> (8 * k)) & 0xffu);
+            b[k] = (float)((s >> (8 * k)) & 0xffu);
         }
     } else {
         // 16-bit elements e0..e(2CN-1): e0..e3 in lo, e4.. in hi
-        const uint64_t first = w.lo;                                                  // pixel 0: e0..e(CN-1)
-        const uint64_t second = CN == 3 ? ((w.lo >> 48) | (w.hi << 16)) : w.hi;       // pixel 1: e(CN)..e(2CN-1)
+        const uint64_t first = w.lo;                                                             // pixel 0: e0..e(CN-1)
+        const uint64_t second = CN == 4 ? w.hi : ((w.lo >> (16 * CN)) | (w.hi << (64 - 16 * CN))); // pixel 1: e(CN)..e(2CN-1)
         const uint64_t s = edge ? first : second;
 #pragma unroll
         for (int k = 0; k < CN; ++k) {
@@ -186,7 +182,7 @@ __device__ __forceinline__ void st_plain(uint8_t* p, float v) { __builtin_nontem
 // stores when the chain changed it (e.g. *2GRAY after the resize)
 template <int CN, typename OT>
 __device__ __forceinline__ void store_packed_px(OT* px, const float* v, int cn) {
-    if (cn == CN) {
+    if (CN >= 3 && cn == CN) {
         if constexpr (std::is_same_v<OT, float>) {
             typedef float vf __attribute__((ext_vector_type(CN)));
             typedef vf vfu __attribute__((aligned(4)));
@@ -395,7 +391,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
             const float w01 = wxa * wyb[j];
             const float w11 = wxb * wyb[j];
             Px p;
-            p.v[3] = 0.f;
+            p.v[0] = p.v[1] = p.v[2] = p.v[3] = 0.f;
 #pragma unroll
             for (int k = 0; k < CN; ++k) {
                 float acc = p00[k] * w00;
@@ -516,8 +512,34 @@ static hipError_t launch_prog(int prog_id, bool table, int rpw, const ChainArgs&
     return launch_npl<CN, InterpProg, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
 }
 
+// 1- and 2-channel sources (grayscale / two-plane images; the reference's single-image resize tests sweep C1 types,
+// tests/resize/test_resize_write.cu:120-123): planar fp32 for every source kind, packed fp32 / u8 for 8U sources
+template <int CN, int SRC>
+static hipError_t launch_few_planar(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+    const int r = rpw >= 4 ? 4 : 1;
+    if (prog_id == 1) {
+        if (table) return r == 4 ? launch_t<CN, 0, 4, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s) : launch_t<CN, 0, 1, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s);
+        return r == 4 ? launch_t<CN, CVGS_KERNARG_PLANES, 4, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s)
+                      : launch_t<CN, CVGS_KERNARG_PLANES, 1, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s);
+    }
+    if (table) return launch_t<CN, 0, 1, InterpProg, SRC, float>(c, ip, ni, CN, s);
+    return launch_t<CN, CVGS_KERNARG_PLANES, 1, InterpProg, SRC, float>(c, ip, ni, CN, s);
+}
+template <int CN>
+static hipError_t launch_few(int src, bool planar, bool u8out, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip,
+                             int ni, hipStream_t s) {
+    if (planar) {
+        return src == SRC_U8    ? launch_few_planar<CN, SRC_U8>(prog_id, table, rpw, c, ip, ni, s)
+               : src == SRC_U16 ? launch_few_planar<CN, SRC_U16>(prog_id, table, rpw, c, ip, ni, s)
+                                : launch_few_planar<CN, SRC_S16>(prog_id, table, rpw, c, ip, ni, s);
+    }
+    if (u8out) return launch_other<CN, uint8_t, WM_PACKED>(table, rpw, c, ip, ni, s);
+    return launch_other<CN, float, WM_PACKED>(table, rpw, c, ip, ni, s);
+}
+
 // program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
 static int classify_program(const ProgArgs& p, int cn) {
+    if (cn < 3) return (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) ? 1 : 2;
     const int swap = cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
     if (p.n == 4 && p.opcode[0] == CVGS_OP_REORDER && p.aux[0] == swap && p.opcode[1] == CVGS_OP_MUL &&
         p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV)
@@ -531,8 +553,10 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     const ReadArgs& r = c_in.read;
     // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write -- or, for 8U sources, an fp16 planar
     // tensor whose conversion is the chain's LAST stage (the half-precision hand-off option)
-    if (r.kind != CVGS_READ_RESIZE_LINEAR || (r.cn != 3 && r.cn != 4)) return 0;
+    if (r.kind != CVGS_READ_RESIZE_LINEAR || r.cn < 1 || r.cn > 4) return 0;
     if (r.depth != CVGS_DEPTH_8U && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S) return 0;
+    const bool few = r.cn < 3; // 1 / 2 channels: planar fp32, or packed fp32 / u8
+    if (few && (c_in.write.kind == CVGS_WRITE_SPLIT_2D || c_in.write.depth == CVGS_DEPTH_16F)) return 0;
     const int wk = c_in.write.kind;
     const bool planar = wk == CVGS_WRITE_TENSOR_SPLIT || wk == CVGS_WRITE_TENSOR_T_SPLIT;
     const bool packed = wk == CVGS_WRITE_PIXEL_2D || wk == CVGS_WRITE_PIXEL_3D;
@@ -580,7 +604,12 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
                                             {"k1_u8c4_swap_mul_sub_div_f16", "k1_u8c4_mul_sub_div_f16", "k1_u8c4_interp_f16"}};
         static const char* names_other[2][4] = {{"k1_u8c3_packed_f32", "k1_u8c3_packed_f16", "k1_u8c3_packed_u8", "k1_u8c3_planes2d_f32"},
                                                 {"k1_u8c4_packed_f32", "k1_u8c4_packed_f16", "k1_u8c4_packed_u8", "k1_u8c4_planes2d_f32"}};
-        if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
+        static const char* names_few[3][2][2] = {{{"k1_u8c1_mul_sub_div", "k1_u8c1_interp"}, {"k1_u8c2_mul_sub_div", "k1_u8c2_interp"}},
+                                                 {{"k1_u16c1_mul_sub_div", "k1_u16c1_interp"}, {"k1_u16c2_mul_sub_div", "k1_u16c2_interp"}},
+                                                 {{"k1_s16c1_mul_sub_div", "k1_s16c1_interp"}, {"k1_s16c2_mul_sub_div", "k1_s16c2_interp"}}};
+        static const char* names_few_packed[2][2] = {{"k1_u8c1_packed_f32", "k1_u8c1_packed_u8"}, {"k1_u8c2_packed_f32", "k1_u8c2_packed_u8"}};
+        if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : names_few_packed[r.cn - 1][u8out];
+        else if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
         else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
     }
     if (dry_run) return 1;
@@ -589,7 +618,10 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     hipStream_t s = (hipStream_t)stream;
     const int out_cn = c.write.cn;
     hipError_t e;
-    if (!planar) {
+    if (few) {
+        e = r.cn == 1 ? launch_few<1>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s)
+                      : launch_few<2>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s);
+    } else if (!planar) {
         if (split2d) e = r.cn == 3 ? launch_split2d<3>(prog_id, table, rpw, c, inline_planes, n_inline, s)
                                    : launch_split2d<4>(prog_id, table, rpw, c, inline_planes, n_inline, s);
         else if (u8out) e = r.cn == 3 ? launch_other<3, uint8_t, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)

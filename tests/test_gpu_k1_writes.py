@@ -108,3 +108,47 @@ def test_gray_output_of_a_resize_is_packed_single_channel():
 
     gpu, ref = _both(build, (90, 120, 1), np.float32)
     H.assert_bit_exact(gpu[0], ref[0], "resize -> gray packed")
+
+
+@pytest.mark.parametrize("depth,cn,out", [("8U", 1, "u8"), ("8U", 1, "f32"), ("8U", 2, "u8"), ("8U", 2, "f32"), ("8U", 2, "planar"),
+                                          ("16U", 2, "planar"), ("16S", 2, "planar_interp"), ("16U", 1, "planar")])
+def test_resize_one_and_two_channel_sources(depth, cn, out):
+    """Grayscale / two-channel sources on the fast kernel (the reference's single-image resize tests sweep C1 types,
+    tests/resize/test_resize_write.cu:120-123): crops from 1 pixel wide (byte-gathered windows) to wide ones, up- and
+    down-scaling, against the oracle and the interpreted kernel."""
+    from tests import kat_runner as K
+    from tests.test_gpu_chains import _random_src
+    src = _random_src((240, 330, cn), depth, 50 + cn)
+    crops = [(0, 0, 1, 1), (5, 7, 2, 3), (11, 3, 3, 200), (1, 1, 7, 9), (0, 0, 330, 240), (100, 50, 200, 33), (17, 19, 64, 64)]
+    n, dst = len(crops), (48, 40)
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    u = cvgs.make_type(cvgs.CV_8U, cn)
+
+    def build(wrap, wrap_out, out_buf):
+        frame = wrap(src, st)
+        rd = cvgs.resize(st, cvgs.INTER_LINEAR, [frame.roi(*c) for c in crops], dst, n - 1, [3.0, 9.0][:cn])
+        if out == "u8":
+            return [rd, cvgs.multiply(f, [0.9] * cn), cvgs.convertTo(f, u), cvgs.write(u, wrap_out(out_buf, u), dst)]
+        if out == "f32":
+            return [rd, cvgs.add(f, [0.25] * cn), cvgs.write(f, wrap_out(out_buf, f), dst)]
+        norm = [cvgs.multiply(f, [0.3] * cn), cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn])]
+        if out == "planar_interp":
+            norm.append(cvgs.add(f, [1.0] * cn))
+        o = wrap_out(out_buf, cvgs.CV_32FC1)
+        return [rd] + norm + [cvgs.split(f, o, dst) if cn > 1 else cvgs.write(f, o, dst)]
+
+    shape, dt = ((n, dst[0] * dst[1], cn), np.uint8) if out == "u8" else (((n, dst[0] * dst[1], cn), np.float32) if out == "f32" else
+                                                                           ((n, cn * dst[0] * dst[1]), np.float32))
+    gpu, ref = _both(build, shape, dt)
+    H.assert_bit_exact(gpu[0], ref[0], "K1 %sC%d -> %s" % (depth, cn, out))
+    gen, _ = _both(build, shape, dt, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gen[0], gpu[0], "interpreted kernel agrees")
+
+    def named(wrap, wrap_out, _):
+        return build(wrap, wrap_out, np.zeros(shape, dt))
+
+    name = _name(named)
+    if depth == "16U" and cn == 1:
+        assert name.startswith("generic")  # packed == planar for one channel; 16-bit C1 stays on the interpreted kernel
+    else:
+        assert name.startswith("k1_%sc%d" % ({"8U": "u8", "16U": "u16", "16S": "s16"}[depth], cn)), name

@@ -355,7 +355,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
                 dev = (const WarpPlane*)(uintptr_t)16;
             }
         }
-        if (launch_warp(L.args, L.warp_planes.data(), n, dev, stream, dry_run, info)) return fail(CVGS_ERR_HIP, "warp kernel launch failed");
+        if (launch_warp(L.args, L.warp_planes.data(), n, dev, ch->flags, stream, dry_run, info)) return fail(CVGS_ERR_HIP, "warp kernel launch failed");
         return CVGS_OK;
     }
     const PlaneParams* inline_planes = L.planes.data();

@@ -131,18 +131,17 @@ int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inli
 int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
                      bool dry_run, LaunchInfo* info);
 
-// Warp reads (cvGS::warp): per-plane source view + the inverse transform, 64 bytes.
+// Warp reads (cvGS::warp): per-plane source view + the inverse transform, 56 bytes.
 struct WarpPlane {
     const uint8_t* data;
     int32_t w, h, step;
     float m[9];            // row-major 3x3, destination -> source; affine kinds ignore m[6..8]
-    int32_t pad[2];
 };
-static_assert(sizeof(WarpPlane) == 64, "WarpPlane layout");
-static constexpr int kInlineWarp = 32; // planes whose WarpPlane travels in the kernel arguments
+static_assert(sizeof(WarpPlane) == 56, "WarpPlane layout");
+static constexpr int kInlineWarp = 56; // planes whose WarpPlane travels in the kernel arguments (4 KB block)
 // interpreted warp kernel: `planes` = host array of n (inline when n <= kInlineWarp), else `dev_table` (device copy)
-int launch_warp(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* dev_table, void* stream, bool dry_run,
-                LaunchInfo* info);
+int launch_warp(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* dev_table, uint32_t chain_flags, void* stream,
+                bool dry_run, LaunchInfo* info);
 
 // experimental K1 variants (k_k1_exp.hip), selected by bits 8..15 of the chain flags; A/B benchmarking only
 int launch_k1_exp(int variant, const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream);

@@ -25,33 +25,9 @@
 #include <initializer_list>
 #include <type_traits>
 
-#include "k_common.hpp"
+#include "k_taps.hpp"
 
 namespace cvgs {
-
-// Compile-time programs for the chains the reference's tests spell.  kOpSwapRB is an internal opcode: REORDER whose
-// permutation is the RGB<->BGR swap (aux 2,1,0[,3]) resolved at compile time instead of per-pixel selects.
-constexpr int kOpSwapRB = 100;
-
-template <int... OPS>
-struct K1Prog {
-    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
-        int k = 0;
-        ((step<OPS>(prog, k, p, depth, cn), ++k), ...);
-    }
-    template <int OP>
-    static __device__ __forceinline__ void step(const ProgArgs& prog, int k, Px& p, int& depth, int& cn) {
-        if constexpr (OP == kOpSwapRB) {
-            const float t = p.v[0];
-            p.v[0] = p.v[2];
-            p.v[2] = t;
-        } else {
-            apply_op(OP, prog.aux[k], prog.operand[k], p, depth, cn);
-        }
-    }
-};
-using ProgSwapMulSubDiv = K1Prog<kOpSwapRB, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
-using ProgMulSubDiv = K1Prog<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 
 // Write stages of the fast path.  Planar is the hot one (TensorSplit / TensorTSplit); the other two serve the
 // single-image chains of the reference's resize tests (tests/resize/test_resize_write.cu: resize -> convertTo<32F,8U> ->
@@ -73,105 +49,6 @@ struct K1Geom {
     int64_t row_pitch, img_pitch, row_pitch2, img_pitch2;
     const DstPlane* planes2d;
 };
-
-typedef uint64_t u64_unaligned __attribute__((aligned(1)));
-typedef const __attribute__((address_space(1))) u64_unaligned* gptr_u64;
-typedef const __attribute__((address_space(1))) uint8_t* gptr_u8;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
-typedef const __attribute__((address_space(1))) u32x4_unaligned* gptr_u32x4;
-
-// Source element kinds of the fast path (the reference sweeps K1 over 8U, 16U and 16S sources,
-// tests/batchresize/test_batchresize_x_split3D.cu:427-432).
-enum { SRC_U8 = 0, SRC_U16 = 1, SRC_S16 = 2 };
-template <int SRC> constexpr int elem_bytes = SRC == SRC_U8 ? 1 : 2;
-
-// The tap window of one lane and one source row: both horizontal taps (a pixel pair: 2*CN elements) arrive in ONE
-// unaligned load -- 8 bytes for u8 pixels (6 or 8 used), 16 bytes for 16-bit pixels (12 or 16 used).
-template <int EB> struct Win;
-template <> struct Win<1> { uint64_t lo; };
-template <> struct Win<2> { uint64_t lo, hi; };
-
-template <int EB>
-__device__ __forceinline__ Win<EB> load_win(gptr_u8 p) {
-    Win<EB> w;
-    if constexpr (EB == 1) {
-        w.lo = *(gptr_u64)p;
-    } else {
-        const u32x4 v = *(gptr_u32x4)p;
-        w.lo = ((uint64_t)v.y << 32) | v.x;
-        w.hi = ((uint64_t)v.w << 32) | v.z;
-    }
-    return w;
-}
-
-// rows narrower than the window (1-2 pixels): gather byte by byte with clamped, always-valid addresses
-template <int CN, int EB>
-__device__ __forceinline__ Win<EB> gather_win(gptr_u8 row, int o, int row_bytes) {
-    uint64_t part[2] = {0, 0};
-#pragma unroll
-    for (int k = 0; k < 2 * CN * EB; ++k) {
-        const uint64_t b = row[min(o + k, row_bytes - 1)];
-        part[k >> 3] |= b << (8 * (k & 7));
-    }
-    Win<EB> w;
-    w.lo = part[0];
-    if constexpr (EB == 2) w.hi = part[1];
-    return w;
-}
-
-// window >> sh bits (sh is a multiple of the pixel size; non-zero only for the last columns of a row)
-template <int EB>
-__device__ __forceinline__ Win<EB> shift_win(Win<EB> w, int sh) {
-    if constexpr (EB == 1) {
-        w.lo >>= sh;
-    } else {
-        if (sh >= 64) {
-            w.lo = w.hi >> (sh - 64);
-            w.hi = 0;
-        } else if (sh > 0) {
-            w.lo = (w.lo >> sh) | (w.hi << (64 - sh));
-            w.hi >>= sh;
-        }
-    }
-    return w;
-}
-
-template <int SRC>
-__device__ __forceinline__ float elem_to_float(uint32_t bits) {
-    if constexpr (SRC == SRC_S16) return (float)(int16_t)(uint16_t)bits;
-    else return (float)bits;
-}
-
-// pixel pair -> floats; at the right edge (x2 clamped onto x1) the second pixel IS the first one
-template <int CN, int SRC>
-__device__ __forceinline__ void unpack_pair(const Win<elem_bytes<SRC>>& w, bool edge, float* a, float* b) {
-    if constexpr (SRC == SRC_U8) {
-        // pixel 0 = bytes 0..CN-1, pixel 1 = bytes CN..2CN-1 of the 8-byte window
-        const uint32_t lo = (uint32_t)w.lo;
-        const uint32_t second = (uint32_t)(w.lo >> (8 * CN));
-        const uint32_t s = edge ? lo : second;
-#pragma unroll
-        for (int k = 0; k < CN; ++k) {
-            a[k] = (float)((lo >> (8 * k)) & 0xffu);
-            b[k] = (float)((s >> (8 * k)) & 0xffu);
-        }
-    } else {
-        // 16-bit elements e0..e(2CN-1): e0..e3 in lo, e4.. in hi
-        const uint64_t first = w.lo;                                                             // pixel 0: e0..e(CN-1)
-        const uint64_t second = CN == 4 ? w.hi : ((w.lo >> (16 * CN)) | (w.hi << (64 - 16 * CN))); // pixel 1: e(CN)..e(2CN-1)
-        const uint64_t s = edge ? first : second;
-#pragma unroll
-        for (int k = 0; k < CN; ++k) {
-            a[k] = elem_to_float<SRC>((uint32_t)(first >> (16 * k)) & 0xffffu);
-            b[k] = elem_to_float<SRC>((uint32_t)(s >> (16 * k)) & 0xffffu);
-        }
-    }
-}
-
-__device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
-// fp16 output: the chain's trailing CAST(CV_16F) is this one round-to-nearest-even conversion
-__device__ __forceinline__ void st_nt(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
 
 __device__ __forceinline__ void st_plain(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_plain(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }

@@ -4,7 +4,9 @@
 // One thread = one output pixel of plane z: destination (x,y) -> source position through the inverse transform
 // (strict fp32, products and sums in the written order, IEEE division), INTER_LINEAR taps as in the resize, zero
 // outside the source.  Interpreted program and generic write stage: this is not a hot-path kernel.
-#include "k_common.hpp"
+#include <type_traits>
+
+#include "k_taps.hpp"
 
 namespace cvgs {
 
@@ -13,6 +15,7 @@ struct WarpKernArgs {
     ChainArgs c;
     WarpPlane planes[NPL > 0 ? NPL : 1];
 };
+static_assert(sizeof(WarpKernArgs<kInlineWarp>) <= 4096, "kernel-argument block must fit 4 KB");
 
 template <int NPL>
 __global__ __launch_bounds__(256) void k_warp(const WarpKernArgs<NPL> a, const WarpPlane* __restrict__ table) {
@@ -84,13 +87,168 @@ static hipError_t launch_warp_t(const ChainArgs& c, const WarpPlane* planes, int
     return hipGetLastError();
 }
 
-int launch_warp(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* dev_table, void* stream, bool dry_run,
-                LaunchInfo* info) {
+// ---- fast path: u8 C3/C4 sources -> program -> planar fp32 tensor (the batched "align N faces / N detections and
+// hand them to the network" shape).  Same structure as the fast resize kernel: lane = output column, wave = one output
+// row, blockIdx.y = plane; both horizontal taps of a source row arrive in ONE unaligned 8-byte load (two loads per
+// pixel), compile-time pointwise program, non-temporal 256-byte planar rows.  Bit-identical to k_warp.
+struct WarpGeom {
+    uint32_t col_tiles;
+    int32_t dst_w, dst_h, used, out_w, pad;
+    int64_t img_stride, ch_stride;
+    float* out;
+};
+
+template <int CN, int NPL, class Prog, bool PERSP>
+__global__ __launch_bounds__(256) void k_warp_fast(const WarpKernArgs<NPL> a, const WarpPlane* __restrict__ table, const WarpGeom g) {
+    const ChainArgs& c = a.c;
+    const int z = (int)blockIdx.y;
+    const int dst_w = g.dst_w, dst_h = g.dst_h, used = g.used, W = g.out_w;
+    WarpPlane P;
+    if constexpr (NPL == 0) P = table[z < used ? z : 0];
+    else P = a.planes[z];
+    asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(used), "s"(W), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.data), "s"(P.m[0]), "s"(P.m[1]),
+                 "s"(P.m[2]), "s"(P.m[3]), "s"(P.m[4]), "s"(P.m[5]), "s"(P.m[6]), "s"(P.m[7]), "s"(P.m[8]));
+    int col_tile = 0, row_tile = (int)blockIdx.x;
+    if (g.col_tiles > 1) {
+        col_tile = (int)(blockIdx.x % g.col_tiles);
+        row_tile = (int)(blockIdx.x / g.col_tiles);
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int x = col_tile * 64 + lane;
+    const int y = row_tile * 4 + wave;
+    if (y >= dst_h || x >= dst_w) return;
+
+    Px p;
+    p.v[0] = p.v[1] = p.v[2] = p.v[3] = 0.f;
+    if (z >= used) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p.v[k] = c.read.bg[k];
+    } else {
+        const float fx = (float)x, fy = (float)y;
+        float sx = (P.m[0] * fx + P.m[1] * fy) + P.m[2];
+        float sy = (P.m[3] * fx + P.m[4] * fy) + P.m[5];
+        if constexpr (PERSP) {
+            const float w = (P.m[6] * fx + P.m[7] * fy) + P.m[8];
+            sx = sx / w;
+            sy = sy / w;
+        }
+        if (sx >= 0.f && sx < (float)P.w && sy >= 0.f && sy < (float)P.h) {
+            const int x1 = (int)floorf(sx), y1 = (int)floorf(sy);
+            const int x2 = x1 + 1, y2 = y1 + 1;
+            const int y2r = min(y2, P.h - 1);
+            const bool edge = x2 > P.w - 1;
+            const int row_bytes = P.w * CN;
+            const int o = x1 * CN;
+            const bool tiny = row_bytes < 8; // uniform per plane
+            const uint32_t ol = (uint32_t)(tiny ? o : min(o, row_bytes - 8));
+            const int sh = (o - (int)ol) * 8;
+            const gptr_u8 ra = (gptr_u8)P.data + (size_t)y1 * (size_t)P.step;
+            const gptr_u8 rb = (gptr_u8)P.data + (size_t)y2r * (size_t)P.step;
+            Win<1> va, vb;
+            if (!tiny) {
+                va = load_win<1>(ra + ol);
+                vb = load_win<1>(rb + ol);
+            } else {
+                va = gather_win<CN, 1>(ra, o, row_bytes);
+                vb = gather_win<CN, 1>(rb, o, row_bytes);
+            }
+            float p00[4], p10[4], p01[4], p11[4];
+            unpack_pair<CN, SRC_U8>(shift_win<1>(va, sh), edge, p00, p10);
+            unpack_pair<CN, SRC_U8>(shift_win<1>(vb, sh), edge, p01, p11);
+            const float w00 = ((float)x2 - sx) * ((float)y2 - sy);
+            const float w10 = (sx - (float)x1) * ((float)y2 - sy);
+            const float w01 = ((float)x2 - sx) * (sy - (float)y1);
+            const float w11 = (sx - (float)x1) * (sy - (float)y1);
+#pragma unroll
+            for (int k = 0; k < CN; ++k) {
+                float acc = p00[k] * w00;
+                acc = acc + p10[k] * w10;
+                acc = acc + p01[k] * w01;
+                acc = acc + p11[k] * w11;
+                p.v[k] = acc;
+            }
+        }
+    }
+    int depth = CVGS_DEPTH_32F, cn = CN;
+    Prog::run(c.prog, p, depth, cn);
+    float* const orow = g.out + (int64_t)z * g.img_stride + (int64_t)y * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < cn) st_nt(orow + (int64_t)k * g.ch_stride + x, p.v[k]);
+}
+
+template <int CN, class Prog, bool PERSP>
+static hipError_t launch_warp_fast_t(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s) {
+    WarpGeom g;
+    g.col_tiles = (uint32_t)((c.read.dst_w + 63) / 64);
+    g.dst_w = c.read.dst_w; g.dst_h = c.read.dst_h; g.used = c.read.used; g.out_w = c.write.width; g.pad = 0;
+    g.img_stride = c.write.img_stride; g.ch_stride = c.write.ch_stride;
+    g.out = (float*)c.write.data;
+    const dim3 grid(g.col_tiles * (uint32_t)((c.read.dst_h + 3) / 4), (unsigned)c.read.batch);
+    if (table) {
+        WarpKernArgs<0> a;
+        a.c = c;
+        a.planes[0] = WarpPlane{};
+        hipLaunchKernelGGL((k_warp_fast<CN, 0, Prog, PERSP>), grid, dim3(256), 0, s, a, table, g);
+    } else {
+        WarpKernArgs<kInlineWarp> a;
+        a.c = c;
+        for (int i = 0; i < kInlineWarp; ++i) a.planes[i] = i < n ? planes[i] : WarpPlane{};
+        hipLaunchKernelGGL((k_warp_fast<CN, kInlineWarp, Prog, PERSP>), grid, dim3(256), 0, s, a, (const WarpPlane*)nullptr, g);
+    }
+    return hipGetLastError();
+}
+
+template <int CN, bool PERSP>
+static hipError_t launch_warp_fast_prog(int prog_id, const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s) {
+    if (prog_id == 0) return launch_warp_fast_t<CN, ProgSwapMulSubDiv, PERSP>(c, planes, n, table, s);
+    if (prog_id == 1) return launch_warp_fast_t<CN, ProgMulSubDiv, PERSP>(c, planes, n, table, s);
+    return launch_warp_fast_t<CN, InterpProg, PERSP>(c, planes, n, table, s);
+}
+
+// 1 = took it, 0 = not eligible
+static int try_warp_fast(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s, bool dry_run,
+                         LaunchInfo* info, hipError_t* err) {
+    const ReadArgs& r = c.read;
+    if (r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4) || r.batch > 65535) return 0;
+    if ((c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) || c.write.depth != CVGS_DEPTH_32F ||
+        c.write.data2)
+        return 0;
+    for (int k = 0; k < c.prog.n; ++k)
+        if (c.prog.opcode[k] == CVGS_OP_CAST || c.prog.opcode[k] == CVGS_OP_CAST_TRUNC) return 0;
+    const ProgArgs& p = c.prog;
+    const int swap = r.cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
+    int prog_id = 2;
+    if (p.n == 4 && p.opcode[0] == CVGS_OP_REORDER && p.aux[0] == swap && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB &&
+        p.opcode[3] == CVGS_OP_DIV)
+        prog_id = 0;
+    else if (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV)
+        prog_id = 1;
+    const bool persp = r.kind == CVGS_READ_WARP_PERSPECTIVE;
+    if (info) {
+        static const char* names[2][2][3] = {
+            {{"warp_affine_u8c3_swap_mul_sub_div", "warp_affine_u8c3_mul_sub_div", "warp_affine_u8c3_interp"},
+             {"warp_affine_u8c4_swap_mul_sub_div", "warp_affine_u8c4_mul_sub_div", "warp_affine_u8c4_interp"}},
+            {{"warp_perspective_u8c3_swap_mul_sub_div", "warp_perspective_u8c3_mul_sub_div", "warp_perspective_u8c3_interp"},
+             {"warp_perspective_u8c4_swap_mul_sub_div", "warp_perspective_u8c4_mul_sub_div", "warp_perspective_u8c4_interp"}}};
+        info->kernel = names[persp][r.cn == 4][prog_id];
+    }
+    if (dry_run) return 1;
+    if (r.cn == 3) *err = persp ? launch_warp_fast_prog<3, true>(prog_id, c, planes, n, table, s) : launch_warp_fast_prog<3, false>(prog_id, c, planes, n, table, s);
+    else *err = persp ? launch_warp_fast_prog<4, true>(prog_id, c, planes, n, table, s) : launch_warp_fast_prog<4, false>(prog_id, c, planes, n, table, s);
+    return 1;
+}
+
+int launch_warp(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* dev_table, uint32_t chain_flags, void* stream,
+                bool dry_run, LaunchInfo* info) {
     const bool persp = c.read.kind == CVGS_READ_WARP_PERSPECTIVE;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (!(chain_flags & CVGS_CHAIN_FORCE_GENERIC) && try_warp_fast(c, planes, n, dev_table, s, dry_run, info, &e))
+        return e == hipSuccess ? 0 : -(int)e - 1000;
     if (info) info->kernel = persp ? "warp_perspective_interp" : "warp_affine_interp";
     if (dry_run) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
     if (dev_table) e = launch_warp_t<0>(c, nullptr, 0, dev_table, s);
     else if (n <= 4) e = launch_warp_t<4>(c, planes, n, nullptr, s);
     else e = launch_warp_t<kInlineWarp>(c, planes, n, nullptr, s);

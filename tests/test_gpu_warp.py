@@ -75,10 +75,10 @@ def test_warp_all_source_types_into_nchw(depth, cn, kind):
 
 
 def test_warp_many_planes_uses_device_table():
-    """More planes than travel in the kernel arguments (32): the descriptors are uploaded stream-ordered."""
+    """More planes than travel in the kernel arguments (56): the descriptors are uploaded stream-ordered."""
     import torch
     src = H.random_u8((90, 120, 3), 8)
-    n = 40
+    n = 70
     ms = [[[1.0, 0.02 * i, 0.5 * i], [-0.01 * i, 1.0, 0.25 * i]] for i in range(n)]
 
     def build(wrap, wrap_out, out):
@@ -87,12 +87,12 @@ def test_warp_many_planes_uses_device_table():
                 cvgs.split(cvgs.CV_32FC3, wrap_out(out, cvgs.CV_32FC1), (64, 48))]
 
     gpu, ref = _both(build, (n, 3 * 64 * 48), np.float32)
-    H.assert_bit_exact(gpu[0], ref[0], "40-plane warp")
+    H.assert_bit_exact(gpu[0], ref[0], "70-plane warp")
     t = torch.zeros((90, 120, 3), dtype=torch.uint8, device="cuda:0")
     o = torch.zeros((n, 3 * 64 * 48), dtype=torch.float32, device="cuda:0")
     name = cvgs.kernel_name(cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, [cvgs.GpuMat.from_tensor(t, cvgs.CV_8UC3)] * n, ms, (64, 48)),
                             cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (64, 48)))
-    assert name == "warp_affine_interp"
+    assert name == "warp_affine_u8c3_interp"
 
 
 def test_fk_cast_truncation_on_gpu():
@@ -127,3 +127,40 @@ def test_warp_descriptor_validation():
         rd2 = cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, m, [[1, 0, 0], [0, 1, 0]], (8, 8))
         cvgs.build_plane_table(rd2)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cn", [3, 4])
+@pytest.mark.parametrize("kind", [cvgs.WARP_AFFINE, cvgs.WARP_PERSPECTIVE])
+@pytest.mark.parametrize("src_wh", [(470, 430), (2, 5), (1, 1)])
+def test_fast_warp_kernel_agrees_with_interpreted(cn, kind, src_wh):
+    """u8 C3/C4 -> [swap,] mul, sub, div -> NCHW takes the fast warp kernel (one 8-byte load per tap pair); it must give
+    the interpreted kernel's bits, also on sources narrower than the load window."""
+    sw, sh = src_wh
+    src = H.random_u8((sh, sw, cn), 400 + cn + sw)
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    n, dst = 6, (112, 96)
+    rng = np.random.default_rng(cn + sw)
+    if kind == cvgs.WARP_AFFINE:
+        ms = [[[rng.uniform(0.2, 3) * 112 / sw, rng.uniform(-0.3, 0.3), rng.uniform(-20, 20)],
+               [rng.uniform(-0.3, 0.3), rng.uniform(0.2, 3) * 96 / sh, rng.uniform(-20, 20)]] for _ in range(n)]
+    else:
+        ms = [WC.get_perspective_transform([(0, 0), (sw, 0.1 * sh), (0.05 * sw, sh), (sw, sh)],
+                                           [(3 * i, 2), (110 - i, 5 + i), (1, 90), (105, 95 - 2 * i)]).tolist() for i in range(n)]
+    code = cvgs.COLOR_RGB2BGR if cn == 3 else cvgs.COLOR_RGBA2BGRA
+
+    def build(wrap, wrap_out, out):
+        img = wrap(src, u)
+        return [cvgs.warp(kind, u, [img] * n, ms, dst, n - 1, [5.0, 6.0, 7.0, 8.0][:cn]), cvgs.cvtColor(code, f), cvgs.multiply(f, [0.3] * cn),
+                cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn]), cvgs.split(f, wrap_out(out, cvgs.CV_32FC1), dst)]
+
+    gpu, ref = _both(build, (n, cn * dst[0] * dst[1]), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "fast warp vs oracle")
+    gen, _ = _both(build, (n, cn * dst[0] * dst[1]), np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gpu[0], gen[0], "fast warp vs interpreted")
+    import torch
+    t = torch.from_numpy(src).cuda()
+    o = torch.zeros((n, cn * dst[0] * dst[1]), dtype=torch.float32, device="cuda")
+    ops = [cvgs.warp(kind, u, [cvgs.GpuMat.from_tensor(t, u)] * n, ms, dst), cvgs.cvtColor(code, f), cvgs.multiply(f, [0.3] * cn),
+           cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn]), cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), dst)]
+    assert cvgs.kernel_name(*ops) == "warp_%s_u8c%d_swap_mul_sub_div" % ("affine" if kind == cvgs.WARP_AFFINE else "perspective", cn)
+    assert cvgs.kernel_name(*ops, flags=capi.CHAIN_FORCE_GENERIC).endswith("_interp")

@@ -13,9 +13,12 @@
  * cvgs_execute() launches ONE hand-written HIP kernel (gfx950) for it.
  *
  * Plain C: pointers, sizes and POD structs only.  Every call is asynchronous on the given HIP
- * stream, never synchronises, never allocates device memory (except cvgs_circular_create and
- * cvgs_comm_*), and is thread-safe (CircularTensor handles excepted: they carry a ring index, as
- * in the reference, include/cvGPUSpeedup.cuh:600-627).
+ * stream, never synchronises, and is thread-safe (CircularTensor handles excepted: they carry a
+ * ring index, as in the reference, include/cvGPUSpeedup.cuh:600-627).  Device memory is only
+ * allocated by cvgs_circular_create and cvgs_comm_*, plus one case inside cvgs_execute: a batch
+ * with more host descriptors than fit the 4 KB kernel-argument block (64 planes, 56 for warps,
+ * 16 destination planes) gets a stream-ordered scratch table (hipMallocAsync / hipFreeAsync);
+ * that case is refused during stream capture -- pass a resident table (cvgs_plane_table_build).
  *
  * Return value: 0 (CVGS_OK) or a negative cvgs_status; cvgs_last_error() gives a thread-local
  * human-readable message.
@@ -237,7 +240,7 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
 /* Validation only (what the reference checks with static_assert / assert / runtime_error).    */
 int cvgs_validate(const cvgs_chain_desc* chain);
 
-/* Name of the kernel cvgs_execute would launch for this chain ("k1_u8c3_direct", "generic", ...)
+/* Name of the kernel cvgs_execute would launch for this chain ("k1_u8c3_swap_mul_sub_div", "generic_inline8", ...)
  * written into buf (NUL terminated).  Introspection for tests and profiles.                    */
 int cvgs_kernel_name(const cvgs_chain_desc* chain, char* buf, size_t buf_size);
 

@@ -226,6 +226,10 @@ def main():
         plan = None if a.eager else make_graphs(wl, a.steps)
         warm = None if a.eager else (make_graphs(wl, a.warmup) if a.warmup else [])
         run_steps(wl, a.warmup, a.eager, warm)
+        if not a.eager:
+            # instantiate + upload the timed graphs before the clock starts (one untimed replay): the first replay of a
+            # HIP graph pays its one-time setup, which is not part of a step
+            run_steps(wl, a.steps, False, plan)
         wall, dev_s = timed(lambda: run_steps(wl, a.steps, a.eager, plan), barrier)
         gather_note = None
     else:

@@ -46,7 +46,7 @@ struct N12Prog {
 };
 using N12SwapMulSubDiv = N12Prog<kOpSwapRB12, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 
-template <int NPL, class Prog>
+template <int NPL, class Prog, typename OT = float>
 __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, const N12Geom g) {
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.z;
@@ -131,39 +131,52 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     if (packed) {
         write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
     } else {
-        float* const orow = (float*)out_base + (int64_t)z * img_stride + (int64_t)y * W;
+        // OT = _Float16: the chain's trailing CAST(CV_16F) is this round-to-nearest-even conversion
+        OT* const orow = (OT*)out_base + (int64_t)z * img_stride + (int64_t)y * W;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k < cn) __builtin_nontemporal_store(p.v[k], orow + (int64_t)k * ch_stride + x);
+            if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow + (int64_t)k * ch_stride + x);
     }
 }
 
-template <class Prog>
+template <class Prog, typename OT = float>
 static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
     const dim3 grid((g.dst_w + 63) / 64, (g.dst_h + 3) / 4, c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         a.c = c;
         a.planes[0] = PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<0, Prog>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT>), grid, dim3(256), 0, s, a, g);
     } else if (ni <= 8) {
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<8, Prog>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT>), grid, dim3(256), 0, s, a, g);
     } else { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT>), grid, dim3(256), 0, s, a, g);
     }
     return hipGetLastError();
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
-int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, void* stream,
+int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, int min_width, void* stream,
                 bool dry_run, LaunchInfo* info) {
-    const ReadArgs& r = c.read;
+    const ReadArgs& r = c_in.read;
+    // fp16 planar tensors: the trailing CAST(CV_16F) moves into the store
+    const bool planar_kind = c_in.write.kind == CVGS_WRITE_TENSOR_SPLIT || c_in.write.kind == CVGS_WRITE_TENSOR_T_SPLIT;
+    const bool f16 = planar_kind && c_in.write.depth == CVGS_DEPTH_16F && c_in.prog.n >= 1 &&
+                     c_in.prog.opcode[c_in.prog.n - 1] == CVGS_OP_CAST;
+    ChainArgs c_cut;
+    if (f16) {
+        c_cut = c_in;
+        c_cut.prog.n -= 1;
+        for (int k = 0; k < c_cut.prog.n; ++k)
+            if (c_cut.prog.opcode[k] == CVGS_OP_CAST || c_cut.prog.opcode[k] == CVGS_OP_CAST_TRUNC) return 0;
+    }
+    const ChainArgs& c = f16 ? c_cut : c_in;
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
     if (r.table || n_inline > CVGS_KERNARG_PLANES || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
     if (r.used != r.batch || r.batch > 65535) return 0;
@@ -172,7 +185,7 @@ int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inli
         if (P.x1 != 0 || P.y1 != 0 || P.x2 != r.dst_w - 1 || P.y2 != r.dst_h - 1) return 0;
     }
     const WriteArgs& w = c.write;
-    const bool planar = (w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT) && w.depth == CVGS_DEPTH_32F;
+    const bool planar = planar_kind && (w.depth == CVGS_DEPTH_32F || f16);
     const bool packed = w.kind == CVGS_WRITE_PIXEL_2D || w.kind == CVGS_WRITE_PIXEL_3D;
     if (!planar && !packed) return 0;
 
@@ -185,11 +198,15 @@ int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inli
     const ProgArgs& p = c.prog;
     const bool fast_prog = planar && p.n == 4 && p.opcode[0] == CVGS_OP_REORDER && p.aux[0] == swap &&
                            p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV;
-    if (info) info->kernel = fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : "k4_nv12_resize_interp";
+    if (info)
+        info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
+                           : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : "k4_nv12_resize_interp");
     if (dry_run) return 1;
     hipStream_t s = (hipStream_t)stream;
-    const hipError_t e = fast_prog ? launch_n12<N12SwapMulSubDiv>(c, inline_planes, n_inline, g, s)
-                                   : launch_n12<InterpProg>(c, inline_planes, n_inline, g, s);
+    hipError_t e;
+    if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c, inline_planes, n_inline, g, s)
+                           : launch_n12<InterpProg, _Float16>(c, inline_planes, n_inline, g, s);
+    else e = fast_prog ? launch_n12<N12SwapMulSubDiv>(c, inline_planes, n_inline, g, s) : launch_n12<InterpProg>(c, inline_planes, n_inline, g, s);
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 

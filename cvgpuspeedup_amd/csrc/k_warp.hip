@@ -95,10 +95,10 @@ struct WarpGeom {
     uint32_t col_tiles;
     int32_t dst_w, dst_h, used, out_w, pad;
     int64_t img_stride, ch_stride;
-    float* out;
+    void* out; // float* or _Float16* (OT)
 };
 
-template <int CN, int NPL, class Prog, bool PERSP>
+template <int CN, int NPL, class Prog, bool PERSP, typename OT = float>
 __global__ __launch_bounds__(256) void k_warp_fast(const WarpKernArgs<NPL> a, const WarpPlane* __restrict__ table, const WarpGeom g) {
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.y;
@@ -172,49 +172,62 @@ __global__ __launch_bounds__(256) void k_warp_fast(const WarpKernArgs<NPL> a, co
     }
     int depth = CVGS_DEPTH_32F, cn = CN;
     Prog::run(c.prog, p, depth, cn);
-    float* const orow = g.out + (int64_t)z * g.img_stride + (int64_t)y * W;
+    OT* const orow = (OT*)g.out + (int64_t)z * g.img_stride + (int64_t)y * W;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (k < cn) st_nt(orow + (int64_t)k * g.ch_stride + x, p.v[k]);
+        if (k < cn) st_nt(orow + (int64_t)k * g.ch_stride + x, p.v[k]); // OT = _Float16: the chain's trailing CAST(CV_16F)
 }
 
-template <int CN, class Prog, bool PERSP>
+template <int CN, class Prog, bool PERSP, typename OT>
 static hipError_t launch_warp_fast_t(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s) {
     WarpGeom g;
     g.col_tiles = (uint32_t)((c.read.dst_w + 63) / 64);
     g.dst_w = c.read.dst_w; g.dst_h = c.read.dst_h; g.used = c.read.used; g.out_w = c.write.width; g.pad = 0;
     g.img_stride = c.write.img_stride; g.ch_stride = c.write.ch_stride;
-    g.out = (float*)c.write.data;
+    g.out = c.write.data;
     const dim3 grid(g.col_tiles * (uint32_t)((c.read.dst_h + 3) / 4), (unsigned)c.read.batch);
     if (table) {
         WarpKernArgs<0> a;
         a.c = c;
         a.planes[0] = WarpPlane{};
-        hipLaunchKernelGGL((k_warp_fast<CN, 0, Prog, PERSP>), grid, dim3(256), 0, s, a, table, g);
+        hipLaunchKernelGGL((k_warp_fast<CN, 0, Prog, PERSP, OT>), grid, dim3(256), 0, s, a, table, g);
     } else {
         WarpKernArgs<kInlineWarp> a;
         a.c = c;
         for (int i = 0; i < kInlineWarp; ++i) a.planes[i] = i < n ? planes[i] : WarpPlane{};
-        hipLaunchKernelGGL((k_warp_fast<CN, kInlineWarp, Prog, PERSP>), grid, dim3(256), 0, s, a, (const WarpPlane*)nullptr, g);
+        hipLaunchKernelGGL((k_warp_fast<CN, kInlineWarp, Prog, PERSP, OT>), grid, dim3(256), 0, s, a, (const WarpPlane*)nullptr, g);
     }
     return hipGetLastError();
 }
 
+template <int CN, bool PERSP, typename OT>
+static hipError_t launch_warp_fast_ot(int prog_id, const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s) {
+    if (prog_id == 0) return launch_warp_fast_t<CN, ProgSwapMulSubDiv, PERSP, OT>(c, planes, n, table, s);
+    if (prog_id == 1) return launch_warp_fast_t<CN, ProgMulSubDiv, PERSP, OT>(c, planes, n, table, s);
+    return launch_warp_fast_t<CN, InterpProg, PERSP, OT>(c, planes, n, table, s);
+}
 template <int CN, bool PERSP>
-static hipError_t launch_warp_fast_prog(int prog_id, const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s) {
-    if (prog_id == 0) return launch_warp_fast_t<CN, ProgSwapMulSubDiv, PERSP>(c, planes, n, table, s);
-    if (prog_id == 1) return launch_warp_fast_t<CN, ProgMulSubDiv, PERSP>(c, planes, n, table, s);
-    return launch_warp_fast_t<CN, InterpProg, PERSP>(c, planes, n, table, s);
+static hipError_t launch_warp_fast_prog(bool f16, int prog_id, const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table,
+                                        hipStream_t s) {
+    if (f16) return launch_warp_fast_ot<CN, PERSP, _Float16>(prog_id, c, planes, n, table, s);
+    return launch_warp_fast_ot<CN, PERSP, float>(prog_id, c, planes, n, table, s);
 }
 
 // 1 = took it, 0 = not eligible
-static int try_warp_fast(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s, bool dry_run,
+static int try_warp_fast(const ChainArgs& c_in, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s, bool dry_run,
                          LaunchInfo* info, hipError_t* err) {
-    const ReadArgs& r = c.read;
+    const ReadArgs& r = c_in.read;
     if (r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4) || r.batch > 65535) return 0;
-    if ((c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) || c.write.depth != CVGS_DEPTH_32F ||
-        c.write.data2)
-        return 0;
+    if ((c_in.write.kind != CVGS_WRITE_TENSOR_SPLIT && c_in.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) || c_in.write.data2) return 0;
+    const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
+    if (!f16 && c_in.write.depth != CVGS_DEPTH_32F) return 0;
+    ChainArgs c_cut;
+    if (f16) { // fp16 tensors: the trailing CAST(CV_16F) moves into the store
+        if (c_in.prog.n < 1 || c_in.prog.opcode[c_in.prog.n - 1] != CVGS_OP_CAST) return 0;
+        c_cut = c_in;
+        c_cut.prog.n -= 1;
+    }
+    const ChainArgs& c = f16 ? c_cut : c_in;
     for (int k = 0; k < c.prog.n; ++k)
         if (c.prog.opcode[k] == CVGS_OP_CAST || c.prog.opcode[k] == CVGS_OP_CAST_TRUNC) return 0;
     const ProgArgs& p = c.prog;
@@ -232,11 +245,16 @@ static int try_warp_fast(const ChainArgs& c, const WarpPlane* planes, int n, con
              {"warp_affine_u8c4_swap_mul_sub_div", "warp_affine_u8c4_mul_sub_div", "warp_affine_u8c4_interp"}},
             {{"warp_perspective_u8c3_swap_mul_sub_div", "warp_perspective_u8c3_mul_sub_div", "warp_perspective_u8c3_interp"},
              {"warp_perspective_u8c4_swap_mul_sub_div", "warp_perspective_u8c4_mul_sub_div", "warp_perspective_u8c4_interp"}}};
-        info->kernel = names[persp][r.cn == 4][prog_id];
+        static const char* names16[2][2][3] = {
+            {{"warp_affine_u8c3_swap_mul_sub_div_f16", "warp_affine_u8c3_mul_sub_div_f16", "warp_affine_u8c3_interp_f16"},
+             {"warp_affine_u8c4_swap_mul_sub_div_f16", "warp_affine_u8c4_mul_sub_div_f16", "warp_affine_u8c4_interp_f16"}},
+            {{"warp_perspective_u8c3_swap_mul_sub_div_f16", "warp_perspective_u8c3_mul_sub_div_f16", "warp_perspective_u8c3_interp_f16"},
+             {"warp_perspective_u8c4_swap_mul_sub_div_f16", "warp_perspective_u8c4_mul_sub_div_f16", "warp_perspective_u8c4_interp_f16"}}};
+        info->kernel = f16 ? names16[persp][r.cn == 4][prog_id] : names[persp][r.cn == 4][prog_id];
     }
     if (dry_run) return 1;
-    if (r.cn == 3) *err = persp ? launch_warp_fast_prog<3, true>(prog_id, c, planes, n, table, s) : launch_warp_fast_prog<3, false>(prog_id, c, planes, n, table, s);
-    else *err = persp ? launch_warp_fast_prog<4, true>(prog_id, c, planes, n, table, s) : launch_warp_fast_prog<4, false>(prog_id, c, planes, n, table, s);
+    if (r.cn == 3) *err = persp ? launch_warp_fast_prog<3, true>(f16, prog_id, c, planes, n, table, s) : launch_warp_fast_prog<3, false>(f16, prog_id, c, planes, n, table, s);
+    else *err = persp ? launch_warp_fast_prog<4, true>(f16, prog_id, c, planes, n, table, s) : launch_warp_fast_prog<4, false>(f16, prog_id, c, planes, n, table, s);
     return 1;
 }
 

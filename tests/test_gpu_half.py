@@ -169,3 +169,50 @@ def test_half_is_storage_only():
     with pytest.raises(capi.CvgsError, match="mixing"):
         cvgs.executeOperations(s, cvgs.ReadIOp(capi.READ_PIXEL, h, [m], 1), cvgs.convertTo(h, d), cvgs.convertTo(d, h),
                                cvgs.write(h, om))
+
+
+def test_warp_and_nv12_half_tensors(oracle):
+    """The fp16 hand-off on the other two fast read kinds: N warped faces and N crops of an NV12 surface -> fp16 NCHW."""
+    import torch
+    from tests import warp_cases as WC
+    from tests.test_gpu_circular_nv12 import _nv12
+    f, h = cvgs.CV_32FC3, cvgs.CV_16FC3
+    # warp
+    src = H.random_u8((300, 400, 3), 77)
+    n, dst = 5, (112, 112)
+    ms = [[[0.4 + 0.1 * i, 0.05 * i, -10.0 * i], [-0.03 * i, 0.5, 7.0]] for i in range(n)]
+
+    def build(wrap, wrap_out, out):
+        img = wrap(src, cvgs.CV_8UC3)
+        return [cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, [img] * n, ms, dst), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]),
+                cvgs.divide(f, H.K1_DIV[3]), cvgs.convertTo(f, h), cvgs.split(h, wrap_out(out, cvgs.CV_16FC1), dst)]
+
+    gpu, ref = _both(build, (n, 3 * dst[0] * dst[1]), np.float16)
+    H.assert_bit_exact(gpu[0], ref[0], "warp -> fp16 NCHW")
+    t = torch.from_numpy(src).cuda()
+    o = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float16, device="cuda")
+    ops = [cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, [cvgs.GpuMat.from_tensor(t, cvgs.CV_8UC3)] * n, ms, dst), cvgs.multiply(f, [0.3] * 3),
+           cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]), cvgs.convertTo(f, h),
+           cvgs.split(h, cvgs.GpuMat.from_tensor(o, cvgs.CV_16FC1), dst)]
+    assert cvgs.kernel_name(*ops) == "warp_affine_u8c3_mul_sub_div_f16"
+    # NV12 crops
+    w, hh, d2 = 640, 360, (64, 128)
+    buf = _nv12(w, hh, 99)
+    rects = [(0, 0, 640, 360), (10, 20, 100, 200), (300, 100, 64, 128), (2, 2, 8, 8)]
+
+    def chain(luma, out):
+        return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], d2, capi.YUV_FULL, capi.BT601, False), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
+                cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]), cvgs.convertTo(f, h),
+                cvgs.split(h, out, d2)]
+
+    ref = np.zeros((4, 3 * d2[0] * d2[1]), np.float16)
+    m = cvgs.GpuMat.from_array(buf, cvgs.CV_8UC1)
+    oracle.execute(cvgs.lower(chain(cvgs.GpuMat(hh, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner), cvgs.GpuMat.from_array(ref, cvgs.CV_16FC1))))
+    tb = torch.from_numpy(buf).cuda()
+    ob = torch.zeros((4, 3 * d2[0] * d2[1]), dtype=torch.float16, device="cuda")
+    md = cvgs.GpuMat.from_tensor(tb, cvgs.CV_8UC1)
+    ops = chain(cvgs.GpuMat(hh, w, cvgs.CV_8UC1, md.data, md.step, owner=md.owner), cvgs.GpuMat.from_tensor(ob, cvgs.CV_16FC1))
+    assert cvgs.kernel_name(*ops) == "k4_nv12_resize_swap_mul_sub_div_f16"
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(ob.cpu().numpy(), ref, "NV12 crops -> fp16 NCHW")

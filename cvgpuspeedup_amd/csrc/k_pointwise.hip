@@ -76,6 +76,133 @@ static hipError_t launch_pw_cn(int prog_id, const ChainArgs& c, const PlaneParam
     }
 }
 
+// ---- u8 -> u8 chains (colour conversions, brightness / contrast, ...): 4 pixels per thread, any program ----------------
+// The standalone cvGS::cvtColor / convertTo chains of the reference's tests (tests/color/test_cvtColor.cu:55,
+// tests/single_operation/test_convertTo.cu) on packed u8 images: one 4*CN-byte load, the interpreted program on four
+// pixels, one 4*OCN-byte store (consecutive lanes write consecutive chunks).  The channel count may change (OCN).
+template <int CN, int OCN, int NPL>
+__global__ __launch_bounds__(256) void k_pointwise4_u8u8(const KernArgs<NPL> a, const PwGeom g) {
+    const ChainArgs& c = a.c;
+    const int z = (int)blockIdx.z;
+    PlaneParams P;
+    if constexpr (NPL == 0) P = c.read.table[z < g.used ? z : 0];
+    else P = a.planes[z];
+    const int W = g.w, H = g.h, used = g.used;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int x0 = ((int)blockIdx.x * 64 + lane) * 4;
+    const int y = (int)blockIdx.y * 4 + wave;
+    if (y >= H || x0 >= W) return;
+    const int npx = min(4, W - x0);
+    uint32_t raw[CN];
+    if (z < used) {
+        const gp_u8 row = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * CN;
+        if (npx == 4) {
+#pragma unroll
+            for (int k = 0; k < CN; ++k) raw[k] = *(gp_u32)(row + 4 * k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CN; ++k) raw[k] = 0;
+#pragma unroll
+            for (int b = 0; b < 4 * CN; ++b)
+                if (b < npx * CN) raw[b >> 2] |= (uint32_t)row[b] << (8 * (b & 3));
+        }
+    }
+    Px px[4];
+    int depth = CVGS_DEPTH_8U, cn = CN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+            px[i].v[ch] = ch < CN ? (z < used ? elem_value<CVGS_DEPTH_8U>(raw, i * CN + ch) : c.read.bg[ch]) : 0.f;
+    InterpProg::run4(c.prog, px, depth, cn); // ends on CV_8U values with OCN channels (checked on the host)
+
+    uint8_t* orow = g.out + (size_t)z * g.img_stride + (size_t)y * g.row_pitch + (size_t)x0 * OCN;
+    if (npx == 4) {
+        uint32_t q[OCN];
+#pragma unroll
+        for (int d = 0; d < OCN; ++d) {
+            q[d] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * d + i; // output byte e = pixel e / OCN, channel e % OCN
+                q[d] |= ((uint32_t)px[e / OCN].v[e % OCN] & 0xffu) << (8 * i);
+            }
+        }
+        typedef uint32_t vq __attribute__((ext_vector_type(OCN == 3 ? 3 : (OCN == 4 ? 4 : (OCN == 2 ? 2 : 1)))));
+        typedef uint32_t u32a1 __attribute__((aligned(1)));
+        if constexpr (OCN == 1) {
+            __builtin_nontemporal_store(q[0], (u32a1*)orow);
+        } else {
+            typedef vq vqu __attribute__((aligned(1)));
+            vq v;
+#pragma unroll
+            for (int d = 0; d < OCN; ++d) v[d] = q[d];
+            __builtin_nontemporal_store(v, (vqu*)orow);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ch = 0; ch < OCN; ++ch)
+                if (i < npx) orow[i * OCN + ch] = (uint8_t)px[i].v[ch];
+    }
+}
+
+template <int CN, int OCN>
+static hipError_t launch_u8u8(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    const dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, c.read.batch);
+    if (c.read.table) {
+        KernArgs<0> a;
+        a.c = c;
+        a.planes[0] = PlaneParams{};
+        hipLaunchKernelGGL((k_pointwise4_u8u8<CN, OCN, 0>), grid, dim3(256), 0, s, a, g);
+    } else {
+        KernArgs<CVGS_KERNARG_PLANES> a;
+        a.c = c;
+        for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
+        hipLaunchKernelGGL((k_pointwise4_u8u8<CN, OCN, CVGS_KERNARG_PLANES>), grid, dim3(256), 0, s, a, g);
+    }
+    return hipGetLastError();
+}
+template <int CN>
+static hipError_t launch_u8u8_ocn(int ocn, const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    switch (ocn) {
+    case 1: return launch_u8u8<CN, 1>(c, ip, ni, g, s);
+    case 2: return launch_u8u8<CN, 2>(c, ip, ni, g, s);
+    case 3: return launch_u8u8<CN, 3>(c, ip, ni, g, s);
+    default: return launch_u8u8<CN, 4>(c, ip, ni, g, s);
+    }
+}
+
+// Returns 1 if it took the chain, 0 if not eligible, <0 on error.
+static int launch_pointwise_u8u8(const ChainArgs& c, const PlaneParams* ip, int ni, uint32_t chain_flags, hipStream_t s, bool dry_run,
+                                 LaunchInfo* info) {
+    const ReadArgs& r = c.read;
+    const WriteArgs& w = c.write;
+    if (chain_flags & CVGS_CHAIN_NO_THREAD_FUSION) return 0;
+    if (r.kind != CVGS_READ_PIXEL || r.depth != CVGS_DEPTH_8U || w.depth != CVGS_DEPTH_8U || r.batch > 65535) return 0;
+    if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
+    if (w.data2 || (!r.table && ni > CVGS_KERNARG_PLANES)) return 0;
+    if (info) info->kernel = "pointwise4_u8_u8_interp";
+    if (dry_run) return 1;
+    PwGeom g;
+    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.pad = 0;
+    g.out = w.data; g.out2 = nullptr;
+    g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * w.cn;
+    g.row_pitch2 = 0;
+    g.img_stride = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : (int64_t)w.img_stride * w.cn; // bytes
+    g.img_stride2 = g.ch_stride = g.ch_stride2 = 0;
+    hipError_t e;
+    switch (r.cn) {
+    case 1: e = launch_u8u8_ocn<1>(w.cn, c, ip, ni, g, s); break;
+    case 2: e = launch_u8u8_ocn<2>(w.cn, c, ip, ni, g, s); break;
+    case 3: e = launch_u8u8_ocn<3>(w.cn, c, ip, ni, g, s); break;
+    default: e = launch_u8u8_ocn<4>(w.cn, c, ip, ni, g, s); break;
+    }
+    return e == hipSuccess ? 1 : -(int)e - 1000;
+}
+
 // Eligibility + geometry of the thread-fused path, shared with the single-launch CircularTensor push (k_circular.hip).
 // On success `c` is the chain to run (an fp16 target's trailing CAST is folded into the store), `g` the geometry.
 bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16) {
@@ -101,9 +228,13 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     // the program must turn the u8 value into fp32 with its first CAST and never change the channel count
     const ProgArgs& p = c.prog;
     // (a CV_32F source needs no cast; every other depth must become fp32 before anything else happens)
-    const bool starts_with_cast = p.n >= 1 && p.opcode[0] == CVGS_OP_CAST && p.aux[0] == CVGS_DEPTH_32F;
-    if (r.depth != CVGS_DEPTH_32F && !starts_with_cast) return false;
-    for (int k = starts_with_cast ? 1 : 0; k < p.n; ++k)
+    // (channel permutations on the source type may come first: cvtColor<BGR2RGB, CV_8UC3>() then convertTo<..., CV_32FC3>())
+    int first = 0;
+    while (first < p.n && p.opcode[first] == CVGS_OP_REORDER) ++first;
+    const bool has_cast = first < p.n && p.opcode[first] == CVGS_OP_CAST && p.aux[first] == CVGS_DEPTH_32F;
+    const bool starts_with_cast = has_cast && first == 0;
+    if (r.depth != CVGS_DEPTH_32F && !has_cast) return false;
+    for (int k = has_cast ? first + 1 : first; k < p.n; ++k)
         if (p.opcode[k] != CVGS_OP_MUL && p.opcode[k] != CVGS_OP_ADD && p.opcode[k] != CVGS_OP_SUB && p.opcode[k] != CVGS_OP_DIV &&
             p.opcode[k] != CVGS_OP_REORDER)
             return false;
@@ -112,8 +243,8 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
 
     prog_id = 2;
     if (!u8src) prog_id = 3; // interpreted program, per-depth kernel
-    else if (p.n == 4 && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV) prog_id = 0;
-    else if (p.n == 1) prog_id = 1;
+    else if (starts_with_cast && p.n == 4 && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV) prog_id = 0;
+    else if (starts_with_cast && p.n == 1) prog_id = 1;
 
     g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn;
     g.packed = packed ? 1 : 0;
@@ -136,6 +267,10 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
 int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
                      bool dry_run, LaunchInfo* info) {
+    {
+        const int rc = launch_pointwise_u8u8(c_in, inline_planes, n_inline, chain_flags, (hipStream_t)stream, dry_run, info);
+        if (rc) return rc;
+    }
     ChainArgs c;
     PwGeom g;
     int prog_id = 0;

@@ -335,3 +335,68 @@ def test_thread_fused_pointwise_other_depths(depth, cn, out):
     chain.append(cvgs.split(f, o_mat, (w, h)) if cn > 1 else cvgs.write(f, o_mat, (w, h)))
     want = {"8S": "s8", "16U": "u16", "16S": "s16", "32S": "s32", "32F": "f32"}[depth]
     assert cvgs.kernel_name(*chain) == "pointwise4_%s" % want
+
+
+U8_CODES = [("BGR2RGB", 3, 3), ("RGBA2BGRA", 4, 4), ("BGR2BGRA", 3, 4), ("RGB2BGRA", 3, 4), ("BGRA2BGR", 4, 3), ("RGBA2BGR", 4, 3),
+            ("BGR2GRAY", 3, 1), ("RGB2GRAY", 3, 1), ("BGRA2GRAY", 4, 1), ("RGBA2GRAY", 4, 1)]
+
+
+@pytest.mark.parametrize("code,icn,ocn", U8_CODES)
+def test_thread_fused_u8_to_u8_colour_conversions(code, icn, ocn):
+    """Standalone cvGS::cvtColor on packed u8 images (reference tests/color/test_cvtColor.cu): 4 pixels per thread, the
+    channel count may change; wide pitched views with a ragged tail, batch with a default-value plane."""
+    w, h, n = 517, 9, 3
+    srcs = [_random_src((h + 1, w + 6, icn), "8U", 1500 + i) for i in range(n)]
+    it, ot = cvgs.make_type(cvgs.CV_8U, icn), cvgs.make_type(cvgs.CV_8U, ocn)
+    cc = getattr(cvgs, "COLOR_" + code)
+
+    def build(wrap, wrap_out, out):
+        mats = [wrap(s, it).roi(2, 1, w, h) for s in srcs]
+        return [cvgs.ReadIOp(capi.READ_PIXEL, it, mats, n - 1, None, cvgs.IGNORE_AR, [200.0, 100.0, 50.0, 25.0][:icn]),
+                cvgs.cvtColor(cc, it, ot), cvgs.write(ot, wrap_out(out, ot), (w, h))]
+
+    gpu, ref = _both(build, (n, w * h, ocn), np.uint8)
+    H.assert_bit_exact(gpu[0], ref[0], "u8 cvtColor " + code)
+    gen, _ = _both(build, (n, w * h, ocn), np.uint8, flags=capi.CHAIN_NO_THREAD_FUSION)
+    H.assert_bit_exact(gpu[0], gen[0], "fused vs interpreted")
+    import torch
+    t = torch.from_numpy(srcs[0]).cuda()
+    o = torch.zeros((h, w, ocn), dtype=torch.uint8, device="cuda")
+    ops = [cvgs.ReadIOp(capi.READ_PIXEL, it, [cvgs.GpuMat.from_tensor(t, it).roi(2, 1, w, h)], 1), cvgs.cvtColor(cc, it, ot),
+           cvgs.write(ot, cvgs.GpuMat.from_tensor(o, ot))]
+    assert cvgs.kernel_name(*ops) == "pointwise4_u8_u8_interp"
+    assert cvgs.kernel_name(*ops, flags=capi.CHAIN_NO_THREAD_FUSION).startswith("generic")
+
+
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_thread_fused_u8_brightness_contrast(cn):
+    """convertTo<CV_8UCn, CV_8UCn>(alpha, beta): u8 -> float -> x alpha + beta -> saturating round back to u8, one pitched image."""
+    src = _random_src((40, 301, cn), "8U", 77 + cn)
+    t8 = cvgs.make_type(cvgs.CV_8U, cn)
+
+    def build(wrap, wrap_out, out):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, t8, [wrap(src, t8)], 1), cvgs.convertTo(t8, t8, 1.7, -40.5), cvgs.write(t8, wrap_out(out, t8))]
+
+    gpu, ref = _both(build, (40, 301, cn), np.uint8)
+    H.assert_bit_exact(gpu[0], ref[0], "u8 brightness/contrast")
+    assert ref[0].min() == 0 and ref[0].max() == 255  # both saturation ends are exercised
+
+
+def test_colour_swap_on_the_source_type_before_the_cast_stays_thread_fused():
+    """cvtColor<BGR2RGB, CV_8UC3>() BEFORE convertTo<CV_8UC3, CV_32FC3>() (a common spelling): still the 4-pixel kernel."""
+    src = _random_src((33, 600, 3), "8U", 5)
+    u, f = cvgs.CV_8UC3, cvgs.CV_32FC3
+
+    def build(wrap, wrap_out, out):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, u, [wrap(src, u)], 1), cvgs.cvtColor(cvgs.COLOR_BGR2RGB, u), cvgs.convertTo(u, f),
+                cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225]),
+                cvgs.split(f, wrap_out(out, cvgs.CV_32FC1), (600, 33))]
+
+    gpu, ref = _both(build, (1, 3 * 600 * 33), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "swap before cast")
+    import torch
+    t = torch.from_numpy(src).cuda()
+    o = torch.zeros((1, 3 * 600 * 33), dtype=torch.float32, device="cuda")
+    ops = [cvgs.ReadIOp(capi.READ_PIXEL, u, [cvgs.GpuMat.from_tensor(t, u)], 1), cvgs.cvtColor(cvgs.COLOR_BGR2RGB, u), cvgs.convertTo(u, f),
+           cvgs.multiply(f, [1 / 255.0] * 3), cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (600, 33))]
+    assert cvgs.kernel_name(*ops) == "pointwise4_u8_interp"

@@ -22,6 +22,7 @@
 //    by this kernel, so it should not wait in L2 for the end-of-kernel write-back.
 //  * small launches use 1 row per wave (maximum parallelism, shortest critical path), large ones 4 (amortises the
 //    column geometry).
+#include <cstdlib>
 #include <initializer_list>
 #include <type_traits>
 
@@ -463,7 +464,9 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     // rows per wave: small launches are latency bound -> maximum parallelism (1 row per wave);
     // large ones amortise the column geometry over more rows (measured: tools/k1_ab.py).
     const int64_t wave_rows = (int64_t)r.batch * r.dst_h * ((r.dst_w + 63) / 64);
-    const int rpw = wave_rows <= 16384 ? 1 : (wave_rows <= 65536 ? 2 : 4);
+    int rpw = wave_rows <= 16384 ? 1 : (wave_rows <= 65536 ? 2 : 4);
+    static const char* rpw_env = getenv("CVGS_K1_RPW"); // tuning hook (benchmarks only): force 1 / 2 / 4 rows per wave
+    if (rpw_env) rpw = atoi(rpw_env) >= 4 ? 4 : (atoi(rpw_env) == 2 ? 2 : 1);
 
     const bool table = r.table != nullptr;
     const int prog_id = classify_program(c.prog, r.cn);

@@ -25,7 +25,9 @@ __device__ __forceinline__ float from_int(int i) { return __int_as_float(i); }
 // ---- fk::SaturateCast -----------------------------------------------------------------------
 // float -> integer depth: round to nearest even, clamp, NaN -> 0 (cv::saturate_cast on the GPU).
 __device__ __forceinline__ float sat_round(float v, float lo, float hi) {
-    float r = rintf(v);          // v_rndne_f32
+    // v_rndne_f32; integer-typed values live in float registers, and an integer has no -0: rint(-0.3) = -0.0 must become
+    // +0 (it would otherwise survive a later cast back to float; found by tests/test_gpu_fuzz.py)
+    float r = rintf(v) + 0.0f;
     r = (v != v) ? 0.f : r;
     return fminf(fmaxf(r, lo), hi);
 }
@@ -151,7 +153,7 @@ __device__ __forceinline__ void apply_op(int opc, int aux, const float* operand,
         const float g = kg == 0 ? p.v[0] : (kg == 1 ? p.v[1] : (kg == 2 ? p.v[2] : p.v[3]));
         const float b = kb == 0 ? p.v[0] : (kb == 1 ? p.v[1] : (kb == 2 ? p.v[2] : p.v[3]));
         float lum = (r * 0.299f + g * 0.587f) + b * 0.114f;
-        if (depth != CVGS_DEPTH_32F) lum = rintf(lum);
+        if (depth != CVGS_DEPTH_32F) lum = rintf(lum) + 0.0f; // integer result: no -0
         p.v[0] = lum;
         cn = 1;
         break;

@@ -48,7 +48,8 @@ __device__ __forceinline__ void cast64(Px64& p, int cn, int src, int dst) {
     for (int c = 0; c < 4; ++c) {
         if (c < cn) {
             double v = p.v[c];
-            if (from_float) v = (v != v) ? 0.0 : rint(v); // nearest even; NaN -> 0
+            // nearest even; NaN -> 0; '+ 0.0' turns the -0.0 that rint(-0.3) gives into the +0 an integer type holds
+            if (from_float) v = (v != v) ? 0.0 : rint(v) + 0.0;
             p.v[c] = fmin(fmax(v, lo), hi);
         }
     }
@@ -88,7 +89,7 @@ __device__ __forceinline__ void apply_op64(int opc, int aux, const float* of, co
     case CVGS_OP_GRAY: {
         const float r = (float)sel4(p, aux & 3), g = (float)sel4(p, (aux >> 2) & 3), b = (float)sel4(p, (aux >> 4) & 3);
         float lum = (r * 0.299f + g * 0.587f) + b * 0.114f;
-        if (depth != CVGS_DEPTH_32F) lum = rintf(lum);
+        if (depth != CVGS_DEPTH_32F) lum = rintf(lum) + 0.0f; // integer result: no -0
         p.v[0] = (double)lum;
         cn = 1;
         break;

@@ -442,7 +442,7 @@ static int apply_op(const cvgs_op* op, opx* p) {
         if (p->depth == CVGS_DEPTH_32S || p->depth == CVGS_DEPTH_64F || p->depth == CVGS_DEPTH_16F) return CVGS_ERR_UNSUPPORTED;
         const float r = p->f[op->aux & 3], g = p->f[(op->aux >> 2) & 3], b = p->f[(op->aux >> 4) & 3];
         float lum = (r * 0.299f + g * 0.587f) + b * 0.114f;
-        if (p->depth != CVGS_DEPTH_32F) lum = nearbyintf(lum);
+        if (p->depth != CVGS_DEPTH_32F) lum = nearbyintf(lum) + 0.0f; /* integer result: no -0 */
         p->f[0] = lum;
         p->cn = 1;
         return 0;

@@ -1,0 +1,192 @@
+"""Seeded differential fuzzing of the whole C-ABI: random VALID chains (read kind x source type x batch / unused planes x
+geometry x pointwise program x write kind), each run on the CPU oracle and on the GPU and compared bit for bit.  The
+dispatcher picks whatever kernel matches (fast or interpreted); half of the cases are also forced onto the interpreted
+kernels.  Catches disagreements between kernels on chain shapes no hand-written test spells."""
+import os
+
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+from tests import kat_runner as K
+from tests.test_gpu_chains import _both, _random_src
+
+pytestmark = pytest.mark.gpu
+
+NP = {cvgs.CV_8U: np.uint8, cvgs.CV_8S: np.int8, cvgs.CV_16U: np.uint16, cvgs.CV_16S: np.int16, cvgs.CV_32S: np.int32,
+      cvgs.CV_32F: np.float32, cvgs.CV_16F: np.float16}
+NAME = {cvgs.CV_8U: "8U", cvgs.CV_8S: "8S", cvgs.CV_16U: "16U", cvgs.CV_16S: "16S", cvgs.CV_32S: "32S", cvgs.CV_32F: "32F"}
+
+
+def _program(rng, depth, cn):
+    """random type-correct pointwise stages; returns (iops, final_depth, final_cn)"""
+    ops = []
+    T = lambda d, c: cvgs.make_type(d, c)  # noqa: E731
+    for _ in range(int(rng.integers(0, 6))):
+        choice = rng.integers(0, 6)
+        if choice == 0 and depth != cvgs.CV_32F:
+            ops.append(cvgs.convertTo(T(depth, cn), T(cvgs.CV_32F, cn)))
+            depth = cvgs.CV_32F
+        elif choice in (1, 2) and depth == cvgs.CV_32F:
+            fn = [cvgs.multiply, cvgs.add, cvgs.subtract, cvgs.divide][int(rng.integers(0, 4))]
+            vals = [float(np.float32(v)) for v in rng.uniform(0.3, 3.0, cn)]
+            ops.append(fn(T(depth, cn), vals))
+        elif choice == 3 and depth in (cvgs.CV_8U, cvgs.CV_16U, cvgs.CV_32F) and cn in (3, 4):
+            codes = {3: [("BGR2RGB", 3), ("BGR2BGRA", 4), ("RGB2BGRA", 4), ("BGR2GRAY", 1), ("RGB2GRAY", 1)],
+                     4: [("RGBA2BGRA", 4), ("BGRA2BGR", 3), ("RGBA2BGR", 3), ("BGRA2GRAY", 1), ("RGBA2GRAY", 1)]}[cn]
+            code, ocn = codes[int(rng.integers(0, len(codes)))]
+            ops.append(cvgs.cvtColor(getattr(cvgs, "COLOR_" + code), T(depth, cn), T(depth, ocn)))
+            cn = ocn
+        elif choice == 4 and depth == cvgs.CV_32F:
+            nd = [cvgs.CV_8U, cvgs.CV_8S, cvgs.CV_16U, cvgs.CV_16S, cvgs.CV_32S, cvgs.CV_16F][int(rng.integers(0, 6))]
+            if rng.integers(0, 2) and nd != cvgs.CV_16F:
+                ops.append(cvgs.convertTo(T(depth, cn), T(nd, cn), float(np.float32(rng.uniform(0.2, 2.0))), float(np.float32(rng.uniform(-20, 20)))))
+            else:
+                ops.append(cvgs.convertTo(T(depth, cn), T(nd, cn)))
+            depth = nd
+        elif choice == 5 and depth == cvgs.CV_32F:
+            nd = [cvgs.CV_8U, cvgs.CV_16S, cvgs.CV_32S][int(rng.integers(0, 3))]
+            ops.append(cvgs.cast(T(depth, cn), T(nd, cn)))  # fk::Cast: truncation
+            depth = nd
+        if sum(len(o.ops) for o in ops) > 9:
+            break
+    return ops, depth, cn
+
+
+def _case(seed):
+    rng = np.random.default_rng(seed)
+    kind = ["pixel", "resize", "resize", "warp", "nv12"][int(rng.integers(0, 5))]
+    n = int(rng.integers(1, 6))
+    used = n if rng.integers(0, 3) else int(rng.integers(0, n + 1))
+    if kind == "nv12":
+        sdepth, scn = cvgs.CV_8U, 1
+        sw, sh = 2 * int(rng.integers(2, 60)), 2 * int(rng.integers(2, 40))
+        srcs = [H.random_u8((sh + sh // 2, sw, 1), seed * 10 + i) for i in range(n)]
+        used = n
+    else:
+        sdepth = [cvgs.CV_8U, cvgs.CV_8U, cvgs.CV_8S, cvgs.CV_16U, cvgs.CV_16S, cvgs.CV_32S, cvgs.CV_32F][int(rng.integers(0, 7))]
+        scn = int(rng.integers(1, 5))
+        sw, sh = int(rng.integers(1, 300)), int(rng.integers(1, 60))
+        srcs = [_random_src((sh, sw, scn), NAME[sdepth], seed * 10 + i) for i in range(n)]
+    st = cvgs.make_type(sdepth, scn)
+    dw, dh = (sw, sh) if kind == "pixel" else (int(rng.integers(1, 200)), int(rng.integers(1, 70)))
+    alpha = bool(rng.integers(0, 2))
+    ar = [cvgs.IGNORE_AR, cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_LEFT, cvgs.PRESERVE_AR_RN_EVEN][int(rng.integers(0, 4))] if kind == "resize" else cvgs.IGNORE_AR
+    bg = [float(v) for v in rng.integers(0, 100, 4)]
+    if kind == "pixel":
+        d0, c0 = sdepth, scn
+    elif kind == "nv12":
+        d0, c0 = cvgs.CV_32F, (4 if alpha else 3)
+    else:
+        d0, c0 = cvgs.CV_32F, scn
+    prog, fd, fc = _program(rng, d0, c0)
+    ft = cvgs.make_type(fd, fc)
+    nv12_resize = bool(rng.integers(0, 2))
+    if kind == "nv12" and not nv12_resize:
+        dw, dh = sw, sh
+    wkinds = ["write3d", "write2d_batch"]
+    if n == 1:
+        wkinds.append("write2d")
+    if fc >= 2:
+        wkinds += ["split", "splitT", "split2d"]
+    wk = wkinds[int(rng.integers(0, len(wkinds)))]
+    pitch_pad = int(rng.integers(0, 4))
+    mats_persp = None
+    if kind == "warp":
+        persp = bool(rng.integers(0, 2))
+        mats_persp = []
+        for _ in range(n):
+            m = np.eye(3)
+            m[:2, :2] += rng.uniform(-0.4, 0.4, (2, 2))
+            m[:2, :2] *= rng.uniform(0.3, 2.0) * max(dw, 1) / max(sw, 1)
+            m[:2, 2] = rng.uniform(-10, 10, 2)
+            if persp:
+                m[2, :2] = rng.uniform(-0.002, 0.002, 2)
+            mats_persp.append(m if persp else m[:2])
+
+    esz = np.dtype(NP[fd]).itemsize
+    if wk in ("write3d",):
+        shape = (n, dw * dh, fc)
+    elif wk == "write2d":
+        shape = (dh, dw + pitch_pad, fc)
+    elif wk == "write2d_batch":
+        shape = (n * dh, dw + pitch_pad, fc)
+    elif wk == "split":
+        shape = (n, fc * dw * dh)
+    elif wk == "splitT":
+        shape = (fc * n, dw * dh)
+    else:
+        shape = (n * fc * dh, dw + pitch_pad)
+
+    def build(wrap, wrap_out, out):
+        mats = [wrap(s, st) for s in srcs]
+        if kind == "pixel":
+            rd = cvgs.ReadIOp(capi.READ_PIXEL, st, mats, used, None, cvgs.IGNORE_AR, bg[:scn])
+        elif kind == "resize":
+            rd = cvgs.resize(st, cvgs.INTER_LINEAR, mats, (dw, dh), used, bg[:scn], ar)
+        elif kind == "warp":
+            rd = cvgs.warp(cvgs.WARP_PERSPECTIVE if mats_persp[0].shape[0] == 3 else cvgs.WARP_AFFINE, st, mats,
+                           [m.tolist() for m in mats_persp], (dw, dh), max(used, 1) if used == 0 else used, bg[:scn])
+        else:
+            lumas = [cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, m.data, m.step, owner=m.owner) for m in mats]
+            rd = cvgs.read_nv12(lumas if n > 1 else lumas[0], (dw, dh) if nv12_resize else None,
+                                int(rng_choice[0]), int(rng_choice[1]), alpha)
+        o_t = cvgs.make_type(fd, 1) if wk in ("split", "splitT", "split2d") else ft
+        o = wrap_out(out, o_t)
+        if wk == "write3d":
+            wr = cvgs.write(ft, o, (dw, dh))
+        elif wk == "write2d":
+            wr = cvgs.write(ft, o.roi(0, 0, dw, dh))
+        elif wk == "write2d_batch":
+            wr = cvgs.write_batch(ft, [cvgs.GpuMat(dh, dw, ft, o.data + i * dh * o.step, o.step, owner=o) for i in range(n)])
+        elif wk == "split":
+            wr = cvgs.split(ft, o, (dw, dh))
+        elif wk == "splitT":
+            wr = cvgs.splitT(ft, o.data, dw, dh, n, keep=o)
+        else:
+            planes = [[cvgs.GpuMat(dh, dw, o_t, o.data + ((z * fc + c) * dh) * o.step, o.step, owner=o) for c in range(fc)] for z in range(n)]
+            wr = cvgs.split(ft, planes if n > 1 else planes[0])
+        return [rd] + prog + [wr]
+
+    rng_choice = (rng.integers(0, 2), rng.integers(0, 2))
+    return build, shape, NP[fd], "%s n=%d used=%d %sC%d %dx%d->%dx%d ops=%d %s out=%s" % (
+        kind, n, used, NAME[sdepth], scn, sw, sh, dw, dh, sum(len(o.ops) for o in prog), wk, np.dtype(NP[fd]).name)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_N", "600"))))  # CVGS_FUZZ_N=20000 for a long hunt
+def test_random_chain_matches_oracle(seed):
+    build, shape, dt, what = _case(seed)
+    flags = capi.CHAIN_FORCE_GENERIC if seed % 2 else 0
+    try:
+        gpu, ref = _both(build, shape, dt, flags=flags)
+    except (capi.CvgsError, RuntimeError) as ex:
+        # a chain the engine declares unsupported must be refused by BOTH sides the same way (never silently differ)
+        if "unsupported" in str(ex).lower() or "implemented" in str(ex).lower() or "oracle" in str(ex).lower():
+            pytest.skip("refused: %s (%s)" % (ex, what))
+        raise
+    g, r = gpu[0], ref[0]
+    if dt in (np.float32, np.float16):  # NaN payloads may differ; everything else must be the same bits
+        gn, rn = np.isnan(g), np.isnan(r)
+        assert np.array_equal(gn, rn), what
+        g, r = np.where(gn, 0, g), np.where(rn, 0, r)
+    H.assert_bit_exact(g, r, what)
+
+
+def test_integer_values_have_no_negative_zero():
+    """Found by the fuzzer (seed 91): float -> integer type -> float must give +0 for values in (-1, 0), for both the
+    saturating cast (round to nearest even) and fk::Cast (truncation): integers have no -0."""
+    vals = np.array([-0.9, -0.5, -0.3, -0.0, 0.0, 0.3, -1.0, -1.4], np.float32)
+    src = np.tile(vals, (2, 8))[:, :, None].copy()
+    for mk in (lambda a, b: cvgs.convertTo(a, b), lambda a, b: cvgs.cast(a, b)):
+        for depth in (cvgs.CV_8S, cvgs.CV_16S, cvgs.CV_32S, cvgs.CV_8U):
+            t = cvgs.make_type(depth, 1)
+
+            def build(wrap, wrap_out, out):
+                return [cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_32FC1, [wrap(src, cvgs.CV_32FC1)], 1), mk(cvgs.CV_32FC1, t),
+                        cvgs.convertTo(t, cvgs.CV_32FC1), cvgs.write(cvgs.CV_32FC1, wrap_out(out, cvgs.CV_32FC1))]
+
+            for flags in (0, capi.CHAIN_FORCE_GENERIC):
+                gpu, ref = _both(build, src.shape, np.float32, flags=flags)
+                H.assert_bit_exact(gpu[0], ref[0], "no -0 through depth %d" % depth)
+                assert not np.signbit(ref[0][ref[0] == 0]).any()

@@ -190,3 +190,55 @@ def test_integer_values_have_no_negative_zero():
                 gpu, ref = _both(build, src.shape, np.float32, flags=flags)
                 H.assert_bit_exact(gpu[0], ref[0], "no -0 through depth %d" % depth)
                 assert not np.signbit(ref[0][ref[0] == 0]).any()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_CIRCULAR_N", "60"))))
+def test_random_circular_tensor_sequence(oracle, seed):
+    """CircularTensor fuzz: order x plane mode x mirrored ring x depth x element type x write kind x push chain (per-pixel,
+    resize, fp16 / u8 / fp32 elements); the whole tensor is compared with the oracle's after EVERY update."""
+    import torch
+    from tests.test_gpu_circular_nv12 import _read_device
+    rng = np.random.default_rng(10_000 + seed)
+    dev = torch.device("cuda:0")
+    W, H_ = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+    B = int(rng.integers(1, 7))
+    order = [cvgs.NewestFirst, cvgs.OldestFirst][int(rng.integers(0, 2))]
+    cn = int(rng.integers(1, 5))
+    packed = bool(rng.integers(0, 2)) or cn == 1
+    mirrored = bool(rng.integers(0, 2))
+    transposed = (not packed) and (not mirrored) and bool(rng.integers(0, 2))
+    mode = cvgs.Transposed if transposed else cvgs.Standard
+    edepth = [cvgs.CV_32F, cvgs.CV_32F, cvgs.CV_16F, cvgs.CV_8U][int(rng.integers(0, 4))]
+    resize_push = bool(rng.integers(0, 2))
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    et = cvgs.make_type(edepth, cn)
+    elem_type = et if packed else cvgs.make_type(edepth, 1)
+    cp = 1 if packed else cn
+    ct = cvgs.CircularTensor(u, elem_type, cp, B, order, mode, W, H_, mirrored=mirrored)
+    oc = oracle.OracleCircular(W, H_, elem_type, cp, B, order, mode)
+    s = torch.cuda.current_stream()
+    for i in range(B + 2):
+        sw, sh = (int(rng.integers(1, 200)), int(rng.integers(1, 60))) if resize_push else (W, H_)
+        frame = H.random_u8((sh, sw, cn), seed=70_000 + seed * 100 + i)
+        frame_t = torch.from_numpy(frame).to(dev)
+        pw = [] if resize_push else [cvgs.convertTo(u, f)]
+        pw += [cvgs.multiply(f, [0.5] * cn), cvgs.add(f, [3.25] * cn)]
+        if edepth != cvgs.CV_32F:
+            pw.append(cvgs.convertTo(f, et))
+
+        def chain(mat, wr):
+            rd = cvgs.resize(u, cvgs.INTER_LINEAR, mat, (W, H_)) if resize_push else cvgs.ReadIOp(capi.READ_PIXEL, u, [mat], 1)
+            return [rd] + pw + [wr]
+
+        wr_g = ct.write_packed(et) if packed else (ct.write_splitT(et) if transposed else ct.write_split(et))
+        ct.update(s, *chain(cvgs.GpuMat.from_tensor(frame_t, u), wr_g))
+        kind = capi.WRITE_PIXEL_3D if packed else (capi.WRITE_TENSOR_T_SPLIT if transposed else capi.WRITE_TENSOR_SPLIT)
+        oc.update(cvgs.lower(chain(cvgs.GpuMat.from_array(frame, u), cvgs.WriteIOp(kind, et, 16, W, H_, 0, B))))
+        torch.cuda.synchronize()
+        got = _read_device(ct.data(), ct.nbytes())
+        want = oc.array(np.uint8)
+        what = "seed %d update %d: %dx%d B=%d cn=%d %s %s %s elem=%d %s" % (seed, i, W, H_, B, cn, "packed" if packed else "planar",
+                                                                      "T" if transposed else "S", "mirrored" if mirrored else "ring",
+                                                                      edepth, "resize" if resize_push else "pixel")
+        assert np.array_equal(got, want), what
+    ct.release()

@@ -54,23 +54,24 @@ def _program(rng, depth, cn):
     return ops, depth, cn
 
 
-def _case(seed):
+def _case(seed, big=False):
     rng = np.random.default_rng(seed)
+    k = 8 if big else 1  # big: whole-frame sizes (4 rows per wave, full 256-pixel groups, shuffled / LDS-transposed stores)
     kind = ["pixel", "resize", "resize", "warp", "nv12"][int(rng.integers(0, 5))]
-    n = int(rng.integers(1, 6))
+    n = int(rng.integers(1, 4 if big else 6))
     used = n if rng.integers(0, 3) else int(rng.integers(0, n + 1))
     if kind == "nv12":
         sdepth, scn = cvgs.CV_8U, 1
-        sw, sh = 2 * int(rng.integers(2, 60)), 2 * int(rng.integers(2, 40))
+        sw, sh = 2 * int(rng.integers(2, 60 * k)), 2 * int(rng.integers(2, 40 * k))
         srcs = [H.random_u8((sh + sh // 2, sw, 1), seed * 10 + i) for i in range(n)]
         used = n
     else:
         sdepth = [cvgs.CV_8U, cvgs.CV_8U, cvgs.CV_8S, cvgs.CV_16U, cvgs.CV_16S, cvgs.CV_32S, cvgs.CV_32F][int(rng.integers(0, 7))]
         scn = int(rng.integers(1, 5))
-        sw, sh = int(rng.integers(1, 300)), int(rng.integers(1, 60))
+        sw, sh = int(rng.integers(1, 300 * k)), int(rng.integers(1, 60 * k))
         srcs = [_random_src((sh, sw, scn), NAME[sdepth], seed * 10 + i) for i in range(n)]
     st = cvgs.make_type(sdepth, scn)
-    dw, dh = (sw, sh) if kind == "pixel" else (int(rng.integers(1, 200)), int(rng.integers(1, 70)))
+    dw, dh = (sw, sh) if kind == "pixel" else (int(rng.integers(1, 200 * k)), int(rng.integers(1, 150 * k)))
     alpha = bool(rng.integers(0, 2))
     ar = [cvgs.IGNORE_AR, cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_LEFT, cvgs.PRESERVE_AR_RN_EVEN][int(rng.integers(0, 4))] if kind == "resize" else cvgs.IGNORE_AR
     bg = [float(v) for v in rng.integers(0, 100, 4)]
@@ -167,6 +168,18 @@ def test_random_chain_matches_oracle(seed):
         raise
     g, r = gpu[0], ref[0]
     if dt in (np.float32, np.float16):  # NaN payloads may differ; everything else must be the same bits
+        gn, rn = np.isnan(g), np.isnan(r)
+        assert np.array_equal(gn, rn), what
+        g, r = np.where(gn, 0, g), np.where(rn, 0, r)
+    H.assert_bit_exact(g, r, what)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_BIG_N", "40"))))
+def test_random_chain_whole_frame_sizes(seed):
+    build, shape, dt, what = _case(500_000 + seed, big=True)
+    gpu, ref = _both(build, shape, dt)
+    g, r = gpu[0], ref[0]
+    if dt in (np.float32, np.float16):
         gn, rn = np.isnan(g), np.isnan(r)
         assert np.array_equal(gn, rn), what
         g, r = np.where(gn, 0, g), np.where(rn, 0, r)

@@ -95,7 +95,6 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
             break;
         case CVGS_OP_CAST_TRUNC:
             if (op.aux < CVGS_DEPTH_8U || op.aux > CVGS_DEPTH_16F) return fail(CVGS_ERR_INVALID, "CAST: bad destination depth");
-            if (op.aux == CVGS_DEPTH_64F || depth == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "fk::Cast on CV_64F values");
             depth = op.aux;
             break;
         case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
@@ -241,8 +240,9 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             Pg.operand[n][c] = ch->ops[k].operand[c];
             L.p64.operand[n][c] = ch->ops[k].operand_d[c];
         }
-        if (ch->ops[k].opcode == CVGS_OP_CAST && ch->ops[k].aux == CVGS_DEPTH_64F) L.uses_64f = true;
-        if (ch->ops[k].opcode == CVGS_OP_CAST && ch->ops[k].aux == CVGS_DEPTH_16F) uses_16f = true;
+        const bool is_cast = ch->ops[k].opcode == CVGS_OP_CAST || ch->ops[k].opcode == CVGS_OP_CAST_TRUNC;
+        if (is_cast && ch->ops[k].aux == CVGS_DEPTH_64F) L.uses_64f = true;
+        if (is_cast && ch->ops[k].aux == CVGS_DEPTH_16F) uses_16f = true;
         ++n;
     }
     Pg.n = n;
@@ -251,8 +251,6 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (rc) return rc;
     if (sdepth == CVGS_DEPTH_64F || L.final_depth == CVGS_DEPTH_64F) L.uses_64f = true;
     if (L.uses_64f && uses_16f) return fail(CVGS_ERR_UNSUPPORTED, "chains mixing CV_64F and CV_16F");
-    for (int k = 0; k < Pg.n; ++k)
-        if (L.uses_64f && Pg.opcode[k] == CVGS_OP_CAST_TRUNC) return fail(CVGS_ERR_UNSUPPORTED, "fk::Cast in a CV_64F chain");
 
     // ---- write stage ----
     if (wr.kind < CVGS_WRITE_PIXEL_2D || wr.kind > CVGS_WRITE_PIXEL_2D_BATCH) return fail(CVGS_ERR_INVALID, "bad write kind");

@@ -33,6 +33,7 @@ __device__ __forceinline__ void int_range64(int depth, double& lo, double& hi) {
     }
 }
 
+template <bool TRUNC = false>
 __device__ __forceinline__ void cast64(Px64& p, int cn, int src, int dst) {
     if (src == dst || dst == CVGS_DEPTH_64F) return; // widening to double is exact
     if (dst == CVGS_DEPTH_32F) {
@@ -49,7 +50,7 @@ __device__ __forceinline__ void cast64(Px64& p, int cn, int src, int dst) {
         if (c < cn) {
             double v = p.v[c];
             // nearest even; NaN -> 0; '+ 0.0' turns the -0.0 that rint(-0.3) gives into the +0 an integer type holds
-            if (from_float) v = (v != v) ? 0.0 : rint(v) + 0.0;
+            if (from_float) v = (v != v) ? 0.0 : (TRUNC ? trunc(v) : rint(v)) + 0.0; // fk::Cast truncates
             p.v[c] = fmin(fmax(v, lo), hi);
         }
     }
@@ -59,6 +60,10 @@ __device__ __forceinline__ void apply_op64(int opc, int aux, const float* of, co
     switch (opc) {
     case CVGS_OP_CAST:
         cast64(p, cn, depth, aux);
+        depth = aux;
+        break;
+    case CVGS_OP_CAST_TRUNC:
+        cast64<true>(p, cn, depth, aux);
         depth = aux;
         break;
     case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:

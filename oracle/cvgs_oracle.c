@@ -404,7 +404,6 @@ static int apply_op(const cvgs_op* op, opx* p) {
     case CVGS_OP_NOP: return 0;
     case CVGS_OP_CAST: op_cast(p, op->aux); return 0;
     case CVGS_OP_CAST_TRUNC:
-        if (op->aux == CVGS_DEPTH_64F || p->depth == CVGS_DEPTH_64F) return CVGS_ERR_UNSUPPORTED;
         op_cast_mode(p, op->aux, 1);
         return 0;
     case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:

@@ -14,7 +14,7 @@ from tests.test_gpu_chains import _both, _random_src
 
 pytestmark = pytest.mark.gpu
 
-NP = {cvgs.CV_8U: np.uint8, cvgs.CV_8S: np.int8, cvgs.CV_16U: np.uint16, cvgs.CV_16S: np.int16, cvgs.CV_32S: np.int32,
+NP = {cvgs.CV_64F: np.float64, cvgs.CV_8U: np.uint8, cvgs.CV_8S: np.int8, cvgs.CV_16U: np.uint16, cvgs.CV_16S: np.int16, cvgs.CV_32S: np.int32,
       cvgs.CV_32F: np.float32, cvgs.CV_16F: np.float16}
 NAME = {cvgs.CV_8U: "8U", cvgs.CV_8S: "8S", cvgs.CV_16U: "16U", cvgs.CV_16S: "16S", cvgs.CV_32S: "32S", cvgs.CV_32F: "32F"}
 
@@ -24,7 +24,22 @@ def _program(rng, depth, cn):
     ops = []
     T = lambda d, c: cvgs.make_type(d, c)  # noqa: E731
     for _ in range(int(rng.integers(0, 6))):
-        choice = rng.integers(0, 6)
+        if sum(len(o.ops) for o in ops) > 7:  # leave room: a stage lowers to at most 4 ops, the chain holds 12
+            break
+        choice = rng.integers(0, 7)
+        if choice == 6 and depth in (cvgs.CV_32F, cvgs.CV_8U, cvgs.CV_16S, cvgs.CV_32S):  # a detour through double precision
+            ops.append(cvgs.convertTo(T(depth, cn), T(cvgs.CV_64F, cn), 1.0 / 3.0, 0.1))
+            ops.append(cvgs.divide(T(cvgs.CV_64F, cn), [float(v) for v in rng.uniform(0.3, 3.0, cn)]))
+            depth = cvgs.CV_64F
+            if rng.integers(0, 3):
+                ops.append(cvgs.convertTo(T(cvgs.CV_64F, cn), T(cvgs.CV_32F, cn)))
+                depth = cvgs.CV_32F
+            continue
+        if depth == cvgs.CV_64F:
+            nd = [cvgs.CV_32F, cvgs.CV_16S, cvgs.CV_8U][int(rng.integers(0, 3))]
+            ops.append(cvgs.convertTo(T(depth, cn), T(nd, cn)))
+            depth = nd
+            continue
         if choice == 0 and depth != cvgs.CV_32F:
             ops.append(cvgs.convertTo(T(depth, cn), T(cvgs.CV_32F, cn)))
             depth = cvgs.CV_32F
@@ -84,6 +99,12 @@ def _case(seed, big=False):
     prog, fd, fc = _program(rng, d0, c0)
     ft = cvgs.make_type(fd, fc)
     nv12_resize = bool(rng.integers(0, 2))
+    crop_views = None
+    if kind == "nv12" and rng.integers(0, 2):
+        crop_views = []
+        for _ in range(n):
+            cw, ch = 2 * int(rng.integers(1, sw // 2 + 1)), 2 * int(rng.integers(1, sh // 2 + 1))
+            crop_views.append((2 * int(rng.integers(0, (sw - cw) // 2 + 1)), 2 * int(rng.integers(0, (sh - ch) // 2 + 1)), cw, ch))
     if kind == "nv12" and not nv12_resize:
         dw, dh = sw, sh
     wkinds = ["write3d", "write2d_batch"]
@@ -131,6 +152,8 @@ def _case(seed, big=False):
                            [m.tolist() for m in mats_persp], (dw, dh), max(used, 1) if used == 0 else used, bg[:scn])
         else:
             lumas = [cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, m.data, m.step, owner=m.owner) for m in mats]
+            if nv12_resize and n > 1 and crop_views:  # N crop views (own luma -> chroma offsets) of ONE decoder surface
+                lumas = [lumas[0].nv12_roi(*c) for c in crop_views]
             rd = cvgs.read_nv12(lumas if n > 1 else lumas[0], (dw, dh) if nv12_resize else None,
                                 int(rng_choice[0]), int(rng_choice[1]), alpha)
         o_t = cvgs.make_type(fd, 1) if wk in ("split", "splitT", "split2d") else ft
@@ -155,35 +178,31 @@ def _case(seed, big=False):
         kind, n, used, NAME[sdepth], scn, sw, sh, dw, dh, sum(len(o.ops) for o in prog), wk, np.dtype(NP[fd]).name)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_N", "600"))))  # CVGS_FUZZ_N=20000 for a long hunt
-def test_random_chain_matches_oracle(seed):
-    build, shape, dt, what = _case(seed)
-    flags = capi.CHAIN_FORCE_GENERIC if seed % 2 else 0
+def _run(seed, big, flags):
+    build, shape, dt, what = _case(seed, big=big)
     try:
         gpu, ref = _both(build, shape, dt, flags=flags)
     except (capi.CvgsError, RuntimeError) as ex:
-        # a chain the engine declares unsupported must be refused by BOTH sides the same way (never silently differ)
-        if "unsupported" in str(ex).lower() or "implemented" in str(ex).lower() or "oracle" in str(ex).lower():
+        # the combinations the engine declares unsupported (warps / fp16 next to CV_64F values) are refused loudly
+        if any(k in str(ex).lower() for k in ("warp chains on cv_64f", "mixing cv_64f and cv_16f")):
             pytest.skip("refused: %s (%s)" % (ex, what))
         raise
     g, r = gpu[0], ref[0]
-    if dt in (np.float32, np.float16):  # NaN payloads may differ; everything else must be the same bits
+    if dt in (np.float32, np.float16, np.float64):  # NaN payloads may differ; everything else must be the same bits
         gn, rn = np.isnan(g), np.isnan(r)
         assert np.array_equal(gn, rn), what
         g, r = np.where(gn, 0, g), np.where(rn, 0, r)
     H.assert_bit_exact(g, r, what)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_N", "600"))))  # CVGS_FUZZ_N=20000 for a long hunt
+def test_random_chain_matches_oracle(seed):
+    _run(seed, False, [0, capi.CHAIN_FORCE_GENERIC, 0, capi.CHAIN_NO_THREAD_FUSION][seed % 4])
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_BIG_N", "40"))))
 def test_random_chain_whole_frame_sizes(seed):
-    build, shape, dt, what = _case(500_000 + seed, big=True)
-    gpu, ref = _both(build, shape, dt)
-    g, r = gpu[0], ref[0]
-    if dt in (np.float32, np.float16):
-        gn, rn = np.isnan(g), np.isnan(r)
-        assert np.array_equal(gn, rn), what
-        g, r = np.where(gn, 0, g), np.where(rn, 0, r)
-    H.assert_bit_exact(g, r, what)
+    _run(500_000 + seed, True, 0)
 
 
 def test_integer_values_have_no_negative_zero():

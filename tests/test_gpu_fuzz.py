@@ -156,6 +156,12 @@ def _case(seed, big=False):
                 lumas = [lumas[0].nv12_roi(*c) for c in crop_views]
             rd = cvgs.read_nv12(lumas if n > 1 else lumas[0], (dw, dh) if nv12_resize else None,
                                 int(rng_choice[0]), int(rng_choice[1]), alpha)
+        if use_table and kind in ("pixel", "resize") and used == n and type(mats[0].owner).__module__.startswith("torch"):
+            # GPU side only: the crop list as a resident device plane table instead of kernel-argument descriptors
+            import torch
+            tab = torch.frombuffer(bytearray(cvgs.build_plane_table(rd)), dtype=torch.uint8).cuda()
+            rd.table, rd.table_keep = tab.data_ptr(), tab
+            rd.dsize = (dw, dh)  # a table carries no extent: the descriptor must
         o_t = cvgs.make_type(fd, 1) if wk in ("split", "splitT", "split2d") else ft
         o = wrap_out(out, o_t)
         if wk == "write3d":
@@ -174,6 +180,7 @@ def _case(seed, big=False):
         return [rd] + prog + [wr]
 
     rng_choice = (rng.integers(0, 2), rng.integers(0, 2))
+    use_table = bool(rng.integers(0, 3) == 0)
     return build, shape, NP[fd], "%s n=%d used=%d %sC%d %dx%d->%dx%d ops=%d %s out=%s" % (
         kind, n, used, NAME[sdepth], scn, sw, sh, dw, dh, sum(len(o.ops) for o in prog), wk, np.dtype(NP[fd]).name)
 

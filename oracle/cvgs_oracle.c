@@ -576,6 +576,89 @@ int oracle_execute(const cvgs_chain_desc* ch) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* The headline chain as a plain CPU loop nest -- what a hand-written CPU implementation of K1 looks like, for the
+ * timed cpu_baseline of bench.py (the interpreter above pays a descriptor walk per pixel, which is not a fair CPU
+ * baseline).  Same arithmetic, same order, same results as oracle_execute (tests/test_oracle_independent.py checks the
+ * two agree bit for bit); only:  u8 C3 sources, stretch geometry, every plane used,
+ * [REORDER(swap R,B)] MUL SUB DIV, fp32 TensorSplit.  Anything else: CVGS_ERR_UNSUPPORTED. */
+int oracle_k1_fast(const cvgs_chain_desc* ch) { return oracle_k1_fast_repeat(ch, 1); }
+
+/* `reps` passes over the same batch in ONE parallel region (threads split reps x crops x rows), so that the timed
+ * baseline measures the host's throughput and not the start-up of a thread team per 50-crop batch; every pass writes
+ * the same values to the same output. */
+int oracle_k1_fast_repeat(const cvgs_chain_desc* ch, int reps) {
+    if (!ch || ch->struct_size != sizeof(cvgs_chain_desc) || reps < 1) return CVGS_ERR_INVALID;
+    const cvgs_read_desc* rd = &ch->read;
+    const cvgs_write_desc* wr = &ch->write;
+    if (rd->kind != CVGS_READ_RESIZE_LINEAR || rd->src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 3) || rd->aspect_ratio != CVGS_IGNORE_AR ||
+        rd->used_planes != rd->batch || (rd->flags & CVGS_READ_FLAG_TABLE_ON_DEVICE))
+        return CVGS_ERR_UNSUPPORTED;
+    if (wr->kind != CVGS_WRITE_TENSOR_SPLIT || wr->dst_type != CVGS_MAKETYPE(CVGS_DEPTH_32F, 3)) return CVGS_ERR_UNSUPPORTED;
+    int k = 0, swap = 0;
+    if (ch->n_ops == 4 && ch->ops[0].opcode == CVGS_OP_REORDER && ch->ops[0].aux == (2 | (1 << 2) | (0 << 4))) { swap = 1; k = 1; }
+    if (ch->n_ops != k + 3 || ch->ops[k].opcode != CVGS_OP_MUL || ch->ops[k + 1].opcode != CVGS_OP_SUB || ch->ops[k + 2].opcode != CVGS_OP_DIV)
+        return CVGS_ERR_UNSUPPORTED;
+    const float* mul = ch->ops[k].operand; const float* sub = ch->ops[k + 1].operand; const float* dv = ch->ops[k + 2].operand;
+    const int W = rd->dst_width, H = rd->dst_height, N = rd->batch;
+    const size_t plane = (size_t)W * H;
+    float* out = (float*)wr->data;
+    /* per-crop column tables: x1 offset, clamped x2 offset, the two x weights */
+    int* xa = (int*)malloc(sizeof(int) * 2 * (size_t)N * W);
+    float* wx = (float*)malloc(sizeof(float) * 2 * (size_t)N * W);
+    if (!xa || !wx) { free(xa); free(wx); return CVGS_ERR_INVALID; }
+    for (int z = 0; z < N; ++z) {
+        const cvgs_image2d* im = (const cvgs_image2d*)rd->src + z;
+        oracle_resize_geom g;
+        oracle_resize_geometry(im->width, im->height, W, H, CVGS_IGNORE_AR, &g);
+        for (int x = 0; x < W; ++x) {
+            const float sx = (float)x * g.fx;
+            const int x1 = (int)floorf(sx), x2 = x1 + 1;
+            xa[((size_t)z * W + x) * 2] = 3 * x1;
+            xa[((size_t)z * W + x) * 2 + 1] = 3 * (x2 < im->width - 1 ? x2 : im->width - 1);
+            wx[((size_t)z * W + x) * 2] = (float)x2 - sx;
+            wx[((size_t)z * W + x) * 2 + 1] = sx - (float)x1;
+        }
+    }
+    const long rows = (long)N * H * reps;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (long rzr = 0; rzr < rows; ++rzr) {
+        const long zr = rzr % ((long)N * H);
+        const int z = (int)(zr / H), y = (int)(zr % H);
+        const cvgs_image2d* im = (const cvgs_image2d*)rd->src + z;
+        oracle_resize_geom g;
+        oracle_resize_geometry(im->width, im->height, W, H, CVGS_IGNORE_AR, &g);
+        const float sy = (float)y * g.fy;
+        const int y1 = (int)floorf(sy), y2 = y1 + 1;
+        const int y2r = y2 < im->height - 1 ? y2 : im->height - 1;
+        const float wya = (float)y2 - sy, wyb = sy - (float)y1;
+        const uint8_t* ra = (const uint8_t*)im->data + (size_t)y1 * im->step;
+        const uint8_t* rb = (const uint8_t*)im->data + (size_t)y2r * im->step;
+        const int* xz = xa + (size_t)z * W * 2;
+        const float* wz = wx + (size_t)z * W * 2;
+        float* o = out + (size_t)z * 3 * plane + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            const int o1 = xz[2 * x], o2 = xz[2 * x + 1];
+            const float w00 = wz[2 * x] * wya, w10 = wz[2 * x + 1] * wya, w01 = wz[2 * x] * wyb, w11 = wz[2 * x + 1] * wyb;
+            float v[3];
+            for (int c = 0; c < 3; ++c) {
+                float acc = (float)ra[o1 + c] * w00;
+                acc = acc + (float)ra[o2 + c] * w10;
+                acc = acc + (float)rb[o1 + c] * w01;
+                acc = acc + (float)rb[o2 + c] * w11;
+                v[c] = acc;
+            }
+            if (swap) { const float t = v[0]; v[0] = v[2]; v[2] = t; }
+            for (int c = 0; c < 3; ++c) o[(size_t)c * plane + x] = ((v[c] * mul[c]) - sub[c]) / dv[c];
+        }
+    }
+    free(xa);
+    free(wx);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* distinct tapped source pixels of one K1 plane = ux * uy (taps are separable). */
 static int64_t distinct_taps(int src, int n_out, float f) {
     int64_t count = 0;

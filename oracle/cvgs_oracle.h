@@ -41,6 +41,11 @@ void oracle_resize_geometry(int32_t src_w, int32_t src_h, int32_t dst_w, int32_t
  * negative cvgs_status. */
 int oracle_execute(const cvgs_chain_desc* chain);
 
+/* The headline K1 chain (u8 C3 crops -> resize -> [swap] mul sub div -> NCHW fp32) as a plain loop nest: the CPU
+ * baseline bench.py times.  Bit-identical to oracle_execute on the chains it accepts; CVGS_ERR_UNSUPPORTED otherwise. */
+int oracle_k1_fast(const cvgs_chain_desc* chain);
+int oracle_k1_fast_repeat(const cvgs_chain_desc* chain, int reps); /* `reps` passes in one parallel region (throughput timing) */
+
 /* Threads used by oracle_execute (OpenMP over planes x rows). 1 = scalar port. */
 void oracle_set_threads(int n);
 int oracle_get_threads(void);

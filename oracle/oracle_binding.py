@@ -65,6 +65,17 @@ def execute(lowered):
         raise RuntimeError("oracle_execute failed: %d" % rc)
 
 
+def execute_k1_fast(lowered, reps=1):
+    """The headline chain as a plain loop nest (oracle_k1_fast_repeat): bench.py's timed CPU baseline; `reps` passes over
+    the batch inside one parallel region."""
+    lib = load_oracle()
+    lib.oracle_k1_fast_repeat.restype = C.c_int
+    lib.oracle_k1_fast_repeat.argtypes = [C.POINTER(capi.ChainDesc), C.c_int]
+    rc = lib.oracle_k1_fast_repeat(C.byref(lowered.desc), int(reps))
+    if rc != 0:
+        raise RuntimeError("oracle_k1_fast failed: %d" % rc)
+
+
 def resize_geometry(sw, sh, dw, dh, ar):
     g = Geom()
     load_oracle().oracle_resize_geometry(sw, sh, dw, dh, ar, C.byref(g))

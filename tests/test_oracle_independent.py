@@ -85,3 +85,20 @@ def test_tap_census_of_the_bench_matches_the_oracle(oracle):
     assert W.k1_algorithmic_bytes(crops, desc_bytes=0) == 5995200  # SURVEY.md 8d, cfg #2 fixed variant
     crops = W.random_crops(50, 3840, 2160, seed=W.SEED + 500000)
     assert W.k1_algorithmic_bytes(crops) == W.k1_algorithmic_bytes(crops, tapped_bytes_fn=oracle.tapped_bytes)
+
+
+@pytest.mark.parametrize("swap", [True, False])
+def test_k1_loop_nest_equals_the_interpreter(oracle, swap):
+    """oracle_k1_fast (the plain loop nest bench.py times as the CPU baseline) == oracle_execute (the checker), bit for bit,
+    on variable crops incl. 1-pixel ones; chains it does not cover are refused."""
+    frame = H.random_u8((300, 500, 3), 8)
+    crops = H.random_crops(17, 500, 300, seed=4, wmin=1, wmax=400, hmin=1, hmax=280)
+    a = np.zeros((17, 3 * 64 * 128), np.float32)
+    b = np.zeros_like(a)
+    mk = lambda out, **kw: cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops,  # noqa: E731
+                                                 cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), swap=swap, **kw))
+    oracle.execute(mk(a))
+    oracle.execute_k1_fast(mk(b), 3)
+    H.assert_bit_exact(b, a, "loop nest vs interpreter")
+    with pytest.raises(RuntimeError):
+        oracle.execute_k1_fast(mk(b, ar=cvgs.PRESERVE_AR, background=[1.0, 2.0, 3.0]))

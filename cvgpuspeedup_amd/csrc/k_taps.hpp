@@ -3,6 +3,8 @@
 // its unpacking, non-temporal element stores.
 #pragma once
 
+#include <type_traits>
+
 #include "k_common.hpp"
 
 namespace cvgs {
@@ -129,5 +131,50 @@ __device__ __forceinline__ void unpack_pair(const Win<elem_bytes<SRC>>& w, bool 
 __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 // fp16 output: the chain's trailing CAST(CV_16F) is this one round-to-nearest-even conversion
 __device__ __forceinline__ void st_nt(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
+
+__device__ __forceinline__ void st_plain(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_plain(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
+// u8 targets: the chain's trailing SaturateCast (round to nearest even, clamp, NaN -> 0) is this conversion
+__device__ __forceinline__ void st_plain(uint8_t* p, float v) { __builtin_nontemporal_store((uint8_t)sat_round(v, 0.f, 255.f), p); }
+
+// one packed pixel: a single vector store when the channel count is the compile-time one (the usual case), element
+// stores when the chain changed it (e.g. *2GRAY after the resize)
+template <int CN, typename OT>
+__device__ __forceinline__ void store_packed_px(OT* px, const float* v, int cn) {
+    if (CN >= 3 && cn == CN) {
+        if constexpr (std::is_same_v<OT, float>) {
+            typedef float vf __attribute__((ext_vector_type(CN)));
+            typedef vf vfu __attribute__((aligned(4)));
+            vf q;
+#pragma unroll
+            for (int k = 0; k < CN; ++k) q[k] = v[k];
+            __builtin_nontemporal_store(q, (vfu*)px); // global_store_dwordx3 / x4
+            return;
+        } else if constexpr (std::is_same_v<OT, _Float16>) {
+            // pairs of halves as one 32-bit store (a 3-element half vector would be stored as 8 bytes)
+            typedef _Float16 vh2 __attribute__((ext_vector_type(2)));
+            typedef vh2 vh2u __attribute__((aligned(2)));
+            vh2 lo = {(_Float16)v[0], (_Float16)v[1]};
+            __builtin_nontemporal_store(lo, (vh2u*)px);
+            if constexpr (CN == 4) {
+                vh2 hi = {(_Float16)v[2], (_Float16)v[3]};
+                __builtin_nontemporal_store(hi, (vh2u*)(px + 2));
+            } else {
+                __builtin_nontemporal_store((_Float16)v[2], px + 2);
+            }
+            return;
+        } else if constexpr (CN == 4) { // u8c4: one dword
+            typedef uint32_t u32a1 __attribute__((aligned(1)));
+            uint32_t q = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q |= (uint32_t)sat_round(v[k], 0.f, 255.f) << (8 * k);
+            __builtin_nontemporal_store(q, (u32a1*)px);
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < cn) st_plain(px + k, v[k]);
+}
 
 } // namespace cvgs

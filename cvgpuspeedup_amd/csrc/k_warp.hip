@@ -96,9 +96,10 @@ struct WarpGeom {
     int32_t dst_w, dst_h, used, out_w, pad;
     int64_t img_stride, ch_stride;
     void* out; // float* or _Float16* (OT)
+    int64_t row_pitch, img_pitch; // PACKED: bytes between output rows / images
 };
 
-template <int CN, int NPL, class Prog, bool PERSP, typename OT = float>
+template <int CN, int NPL, class Prog, bool PERSP, typename OT = float, bool PACKED = false>
 __global__ __launch_bounds__(256) void k_warp_fast(const WarpKernArgs<NPL> a, const WarpPlane* __restrict__ table, const WarpGeom g) {
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.y;
@@ -172,30 +173,38 @@ __global__ __launch_bounds__(256) void k_warp_fast(const WarpKernArgs<NPL> a, co
     }
     int depth = CVGS_DEPTH_32F, cn = CN;
     Prog::run(c.prog, p, depth, cn);
-    OT* const orow = (OT*)g.out + (int64_t)z * g.img_stride + (int64_t)y * W;
+    if constexpr (PACKED) { // NHWC: one 12 / 16-byte store per pixel, consecutive lanes write consecutive pixels
+        uint8_t* const row = (uint8_t*)g.out + (int64_t)z * g.img_pitch + (int64_t)y * g.row_pitch;
+        store_packed_px<CN, OT>((OT*)row + (int64_t)x * cn, p.v, cn);
+    } else {
+        OT* const orow = (OT*)g.out + (int64_t)z * g.img_stride + (int64_t)y * W;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (k < cn) st_nt(orow + (int64_t)k * g.ch_stride + x, p.v[k]); // OT = _Float16: the chain's trailing CAST(CV_16F)
+        for (int k = 0; k < 4; ++k)
+            if (k < cn) st_nt(orow + (int64_t)k * g.ch_stride + x, p.v[k]); // OT = _Float16: the chain's trailing CAST(CV_16F)
+    }
 }
 
-template <int CN, class Prog, bool PERSP, typename OT>
+template <int CN, class Prog, bool PERSP, typename OT, bool PACKED = false>
 static hipError_t launch_warp_fast_t(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s) {
     WarpGeom g;
     g.col_tiles = (uint32_t)((c.read.dst_w + 63) / 64);
     g.dst_w = c.read.dst_w; g.dst_h = c.read.dst_h; g.used = c.read.used; g.out_w = c.write.width; g.pad = 0;
     g.img_stride = c.write.img_stride; g.ch_stride = c.write.ch_stride;
     g.out = c.write.data;
+    const int64_t px_bytes = (int64_t)sizeof(OT) * c.write.cn;
+    g.row_pitch = c.write.kind == CVGS_WRITE_PIXEL_2D ? c.write.step : c.write.width * px_bytes;
+    g.img_pitch = c.write.kind == CVGS_WRITE_PIXEL_2D ? 0 : c.write.img_stride * px_bytes;
     const dim3 grid(g.col_tiles * (uint32_t)((c.read.dst_h + 3) / 4), (unsigned)c.read.batch);
     if (table) {
         WarpKernArgs<0> a;
         a.c = c;
         a.planes[0] = WarpPlane{};
-        hipLaunchKernelGGL((k_warp_fast<CN, 0, Prog, PERSP, OT>), grid, dim3(256), 0, s, a, table, g);
+        hipLaunchKernelGGL((k_warp_fast<CN, 0, Prog, PERSP, OT, PACKED>), grid, dim3(256), 0, s, a, table, g);
     } else {
         WarpKernArgs<kInlineWarp> a;
         a.c = c;
         for (int i = 0; i < kInlineWarp; ++i) a.planes[i] = i < n ? planes[i] : WarpPlane{};
-        hipLaunchKernelGGL((k_warp_fast<CN, kInlineWarp, Prog, PERSP, OT>), grid, dim3(256), 0, s, a, (const WarpPlane*)nullptr, g);
+        hipLaunchKernelGGL((k_warp_fast<CN, kInlineWarp, Prog, PERSP, OT, PACKED>), grid, dim3(256), 0, s, a, (const WarpPlane*)nullptr, g);
     }
     return hipGetLastError();
 }
@@ -205,6 +214,11 @@ static hipError_t launch_warp_fast_ot(int prog_id, const ChainArgs& c, const War
     if (prog_id == 0) return launch_warp_fast_t<CN, ProgSwapMulSubDiv, PERSP, OT>(c, planes, n, table, s);
     if (prog_id == 1) return launch_warp_fast_t<CN, ProgMulSubDiv, PERSP, OT>(c, planes, n, table, s);
     return launch_warp_fast_t<CN, InterpProg, PERSP, OT>(c, planes, n, table, s);
+}
+// packed fp32 pixels (NHWC): interpreted program
+template <int CN, bool PERSP>
+static hipError_t launch_warp_fast_packed(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table, hipStream_t s) {
+    return launch_warp_fast_t<CN, InterpProg, PERSP, float, true>(c, planes, n, table, s);
 }
 template <int CN, bool PERSP>
 static hipError_t launch_warp_fast_prog(bool f16, int prog_id, const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* table,
@@ -218,9 +232,12 @@ static int try_warp_fast(const ChainArgs& c_in, const WarpPlane* planes, int n, 
                          LaunchInfo* info, hipError_t* err) {
     const ReadArgs& r = c_in.read;
     if (r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4) || r.batch > 65535) return 0;
-    if ((c_in.write.kind != CVGS_WRITE_TENSOR_SPLIT && c_in.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) || c_in.write.data2) return 0;
+    const bool planar = c_in.write.kind == CVGS_WRITE_TENSOR_SPLIT || c_in.write.kind == CVGS_WRITE_TENSOR_T_SPLIT;
+    const bool packed = c_in.write.kind == CVGS_WRITE_PIXEL_2D || c_in.write.kind == CVGS_WRITE_PIXEL_3D;
+    if ((!planar && !packed) || c_in.write.data2) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
     if (!f16 && c_in.write.depth != CVGS_DEPTH_32F) return 0;
+    if (packed && f16) return 0;
     ChainArgs c_cut;
     if (f16) { // fp16 tensors: the trailing CAST(CV_16F) moves into the store
         if (c_in.prog.n < 1 || c_in.prog.opcode[c_in.prog.n - 1] != CVGS_OP_CAST) return 0;
@@ -250,9 +267,16 @@ static int try_warp_fast(const ChainArgs& c_in, const WarpPlane* planes, int n, 
              {"warp_affine_u8c4_swap_mul_sub_div_f16", "warp_affine_u8c4_mul_sub_div_f16", "warp_affine_u8c4_interp_f16"}},
             {{"warp_perspective_u8c3_swap_mul_sub_div_f16", "warp_perspective_u8c3_mul_sub_div_f16", "warp_perspective_u8c3_interp_f16"},
              {"warp_perspective_u8c4_swap_mul_sub_div_f16", "warp_perspective_u8c4_mul_sub_div_f16", "warp_perspective_u8c4_interp_f16"}}};
-        info->kernel = f16 ? names16[persp][r.cn == 4][prog_id] : names[persp][r.cn == 4][prog_id];
+        static const char* names_packed[2][2] = {{"warp_affine_u8c3_packed_f32", "warp_affine_u8c4_packed_f32"},
+                                                 {"warp_perspective_u8c3_packed_f32", "warp_perspective_u8c4_packed_f32"}};
+        info->kernel = packed ? names_packed[persp][r.cn == 4] : (f16 ? names16[persp][r.cn == 4][prog_id] : names[persp][r.cn == 4][prog_id]);
     }
     if (dry_run) return 1;
+    if (packed) {
+        if (r.cn == 3) *err = persp ? launch_warp_fast_packed<3, true>(c, planes, n, table, s) : launch_warp_fast_packed<3, false>(c, planes, n, table, s);
+        else *err = persp ? launch_warp_fast_packed<4, true>(c, planes, n, table, s) : launch_warp_fast_packed<4, false>(c, planes, n, table, s);
+        return 1;
+    }
     if (r.cn == 3) *err = persp ? launch_warp_fast_prog<3, true>(f16, prog_id, c, planes, n, table, s) : launch_warp_fast_prog<3, false>(f16, prog_id, c, planes, n, table, s);
     else *err = persp ? launch_warp_fast_prog<4, true>(f16, prog_id, c, planes, n, table, s) : launch_warp_fast_prog<4, false>(f16, prog_id, c, planes, n, table, s);
     return 1;

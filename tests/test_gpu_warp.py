@@ -164,3 +164,32 @@ def test_fast_warp_kernel_agrees_with_interpreted(cn, kind, src_wh):
            cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn]), cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), dst)]
     assert cvgs.kernel_name(*ops) == "warp_%s_u8c%d_swap_mul_sub_div" % ("affine" if kind == cvgs.WARP_AFFINE else "perspective", cn)
     assert cvgs.kernel_name(*ops, flags=capi.CHAIN_FORCE_GENERIC).endswith("_interp")
+
+
+@pytest.mark.parametrize("cn,gray", [(3, False), (4, False), (3, True)])
+def test_fast_warp_packed_nhwc(cn, gray):
+    """N warps -> packed fp32 pixels (NHWC hand-off), also with a channel-count change (RGB2GRAY) inside the chain."""
+    src = H.random_u8((200, 260, cn), 55 + cn)
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    n, dst = 4, (100, 60)
+    ms = [[[0.6 + 0.1 * i, 0.1, -5.0 * i], [-0.05, 0.7, 3.0 * i]] for i in range(n)]
+    ocn = 1 if gray else cn
+    ot = cvgs.make_type(cvgs.CV_32F, ocn)
+
+    def build(wrap, wrap_out, out):
+        img = wrap(src, u)
+        ops = [cvgs.warp(cvgs.WARP_AFFINE, u, [img] * n, ms, dst, n - 1, [9.0, 8.0, 7.0, 6.0][:cn]), cvgs.multiply(f, [0.5] * cn)]
+        if gray:
+            ops.append(cvgs.cvtColor(cvgs.COLOR_RGB2GRAY, f, ot))
+        return ops + [cvgs.write(ot, wrap_out(out, ot), dst)]
+
+    gpu, ref = _both(build, (n, dst[0] * dst[1], ocn), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "warp -> NHWC")
+    gen, _ = _both(build, (n, dst[0] * dst[1], ocn), np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gpu[0], gen[0], "fast vs interpreted")
+    import torch
+    t = torch.from_numpy(src).cuda()
+    o = torch.zeros((n, dst[0] * dst[1], cn), dtype=torch.float32, device="cuda")
+    name = cvgs.kernel_name(cvgs.warp(cvgs.WARP_AFFINE, u, [cvgs.GpuMat.from_tensor(t, u)] * n, ms, dst),
+                            cvgs.write(f, cvgs.GpuMat.from_tensor(o, f), dst))
+    assert name == "warp_affine_u8c%d_packed_f32" % cn

@@ -296,7 +296,8 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
 /* ---- streaming copy ----------------------------------------------------------------------------
  * dst[0..bytes) <- src[0..bytes) with the CircularTensor's plane-copy kernel (non-temporal 16-byte accesses), asynchronous
  * on `stream`.  No reference equivalent: it is the on-box "streaming kernel" copy ceiling SURVEY.md 8(d) asks the
- * roofline fractions to be quoted against (bench.py), and a utility for callers that re-pack tensors.           */
+ * roofline fractions to be quoted against (bench.py), and a utility for callers that re-pack tensors.  The two
+ * ranges must not overlap.                                                                                      */
 int cvgs_stream_copy(void* dst, const void* src, size_t bytes, cvgs_stream_t stream);
 
 /* ---- profiling ranges (reference tests/nvtx.h PUSH_RANGE/POP_RANGE) -------------------------- */

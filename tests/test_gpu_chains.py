@@ -32,18 +32,29 @@ def _random_src(shape, depth_name, seed):
     return (H.random_u16(shape, seed).astype(np.float32) / 64.0 - 300.0).astype(np.float32)
 
 
+GUARD = 4096  # bytes of canary on both sides of every GPU output buffer
+
+
 def _both(build, out_shape, out_dtype, flags=0):
-    """build(mem_kind, wrap_in, wrap_out) -> iops; runs on the oracle and on the GPU, returns both outputs."""
+    """build(mem_kind, wrap_in, wrap_out) -> iops; runs on the oracle and on the GPU, returns both outputs.  Every GPU
+    output buffer sits between two canary bands that must come back untouched (out-of-bounds stores)."""
     import torch
     from oracle import oracle_binding as ob
     dev = torch.device("cuda:0")
     res = {}
     for backend in ("oracle", "gpu"):
         keep = []
+        guards = []
 
-        def wrap(a, cvt):
+        def wrap(a, cvt, guarded=False):
             if backend == "gpu":
-                t = torch.from_numpy(a).to(dev)
+                if guarded:
+                    big = torch.full((a.nbytes + 2 * GUARD,), 0xA5, dtype=torch.uint8, device=dev)
+                    t = big[GUARD:GUARD + a.nbytes].view(torch.from_numpy(a).dtype).view(a.shape)
+                    t.copy_(torch.from_numpy(a))
+                    guards.append(big)
+                else:
+                    t = torch.from_numpy(a).to(dev)
                 keep.append(t)
                 return cvgs.GpuMat.from_tensor(t, cvt)
             keep.append(a)
@@ -53,7 +64,7 @@ def _both(build, out_shape, out_dtype, flags=0):
         outs = []
 
         def wrap_out(a, cvt):
-            m = wrap(a, cvt)
+            m = wrap(a, cvt, guarded=True)
             outs.append((keep[-1], a))
             return m
 
@@ -62,6 +73,8 @@ def _both(build, out_shape, out_dtype, flags=0):
             cvgs.executeOperations(torch.cuda.current_stream(), *iops, flags=flags)
             torch.cuda.synchronize()
             res[backend] = [t.cpu().numpy() for t, _ in outs]
+            for big in guards:
+                assert bool((big[:GUARD] == 0xA5).all()) and bool((big[-GUARD:] == 0xA5).all()), "store outside the output buffer"
         else:
             ob.execute(cvgs.lower(iops, flags))
             res[backend] = [a for _, a in outs]

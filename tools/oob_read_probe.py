@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Out-of-bounds READ probe: every source image is placed so that its last byte is the last byte of a hipMalloc'ed
+region whose size is a multiple of 2 MiB (so that, unless the driver happens to map another allocation right behind it,
+the next page is not mapped), then the fast kernels run on crops that touch the
+last row / column.  A read past the image faults the process; finishing = no over-read.  (A tool, not a test: a fault
+aborts the interpreter.)"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+MB2 = 2 << 20
+
+
+def at_end(a):
+    """device copy of numpy array `a` ending exactly at the end of a 2 MiB-multiple allocation; returns (ptr, keep)"""
+    size = ((a.nbytes + MB2 - 1) // MB2) * MB2
+    base = C.c_void_p()
+    assert hip.hipMalloc(C.byref(base), size) == 0
+    ptr = base.value + size - a.nbytes
+    assert hip.hipMemcpy(C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+    return ptr
+
+
+def main():
+    torch.cuda.init()
+    s = torch.cuda.current_stream()
+    rng = np.random.default_rng(0)
+    n_run = 0
+    for depth, dt in ((cvgs.CV_8U, np.uint8), (cvgs.CV_16U, np.uint16), (cvgs.CV_32F, np.float32)):
+        for cn in (1, 2, 3, 4):
+            for (w, h) in ((1, 1), (2, 3), (5, 4), (257, 9), (1023, 17)):
+                a = (rng.integers(0, 200, (h, w, cn))).astype(dt)
+                st, f = cvgs.make_type(depth, cn), cvgs.make_type(cvgs.CV_32F, cn)
+                m = cvgs.GpuMat(h, w, st, at_end(a), w * cn * a.itemsize)
+                out = torch.zeros((3, 64 * 48 * cn), dtype=torch.float32, device="cuda")
+                om = cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)
+                crops = [m, m.roi(w - 1, h - 1, 1, 1), m.roi(0, h - 1, w, 1)]
+                # resize (K1 / generic), full image + last pixel + last row
+                cvgs.executeOperations(s, cvgs.resize(st, cvgs.INTER_LINEAR, crops, (64, 48), 3), cvgs.multiply(f, [0.5] * cn),
+                                       cvgs.write(f, cvgs.GpuMat.from_tensor(out.view(3, 64 * 48, cn), f), (64, 48)))
+                # per-pixel (pointwise4 / generic)
+                o2 = torch.zeros((h, w, cn), dtype=torch.float32, device="cuda")
+                ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, [m], 1)] + ([cvgs.convertTo(st, f)] if depth != cvgs.CV_32F else []) + \
+                      [cvgs.multiply(f, [0.5] * cn), cvgs.write(f, cvgs.GpuMat.from_tensor(o2, f))]
+                cvgs.executeOperations(s, *ops)
+                if depth == cvgs.CV_8U and cn >= 3:  # warps (fast + interpreted)
+                    for flags in (0, capi.CHAIN_FORCE_GENERIC):
+                        cvgs.executeOperations(s, cvgs.warp(cvgs.WARP_AFFINE, st, [m, m], [[[1, 0, 0.4], [0, 1, 0.4]], [[0.3, 0, -1], [0, 0.3, -1]]], (64, 48)),
+                                               cvgs.split(f, cvgs.GpuMat.from_tensor(out[:2], cvgs.CV_32FC1), (64, 48)), flags=flags)
+                torch.cuda.synchronize()
+                n_run += 1
+    # NV12 surfaces (even sizes), whole + crops touching the last rows / columns
+    for (w, h) in ((4, 2), (6, 4), (64, 36), (642, 362)):
+        a = rng.integers(0, 255, (h + h // 2, w)).astype(np.uint8)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, at_end(a), w)
+        out = torch.zeros((3, 3 * 64 * 48), dtype=torch.float32, device="cuda")
+        views = [luma, luma.nv12_roi(w - 2, h - 2, 2, 2), luma.nv12_roi(0, h - 2, w, 2)]
+        f = cvgs.CV_32FC3
+        for flags in (0, capi.CHAIN_FORCE_GENERIC):
+            cvgs.executeOperations(s, cvgs.read_nv12(views, (64, 48), capi.YUV_FULL, capi.BT709, False), cvgs.multiply(f, [0.5] * 3),
+                                   cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 48)), flags=flags)
+        torch.cuda.synchronize()
+        n_run += 1
+    print("no read past the end of any source image: %d configurations ran to completion" % n_run)
+
+
+if __name__ == "__main__":
+    main()

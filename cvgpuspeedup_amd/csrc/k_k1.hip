@@ -102,7 +102,7 @@ __device__ __forceinline__ void k1_store_other(const K1Geom& g, const ChainArgs&
 template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR>
 __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, const K1Geom g) {
     constexpr int EB = elem_bytes<SRC>;
-    constexpr int WINB = 8 * EB; // bytes per tap window
+    constexpr int WINB = SRC == SRC_F32 ? 2 * CN * 4 : 8 * EB; // bytes per tap window (fp32: exactly the pixel pair)
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.y;
     // ---- one batch of scalar loads: geometry, the crop's parameters, the program operands come in together ----
@@ -203,7 +203,15 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
         wyb[j] = sy - (float)y1;
         const gptr_u8 ra = src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step;
         const gptr_u8 rb = src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step;
-        if (!tiny) {
+        if constexpr (SRC == SRC_F32) {
+            if (!tiny) {
+                va[j] = load_win_f32<CN>(ra + ol);
+                vb[j] = load_win_f32<CN>(rb + ol);
+            } else {
+                va[j] = gather_win_f32<CN>(ra);
+                vb[j] = gather_win_f32<CN>(rb);
+            }
+        } else if (!tiny) {
             va[j] = load_win<EB>(ra + ol);
             vb[j] = load_win<EB>(rb + ol);
         } else {
@@ -217,8 +225,13 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
         const int y = row0 + j;
         if (y < dst_h) { // wave-uniform
             float p00[4], p10[4], p01[4], p11[4];
-            unpack_pair<CN, SRC>(shift_win<EB>(va[j], sh), edge, p00, p10);
-            unpack_pair<CN, SRC>(shift_win<EB>(vb[j], sh), edge, p01, p11);
+            if constexpr (SRC == SRC_F32) {
+                unpack_pair_f32<CN>(va[j], sh != 0, edge, p00, p10);
+                unpack_pair_f32<CN>(vb[j], sh != 0, edge, p01, p11);
+            } else {
+                unpack_pair<CN, SRC>(shift_win<EB>(va[j], sh), edge, p00, p10);
+                unpack_pair<CN, SRC>(shift_win<EB>(vb[j], sh), edge, p01, p11);
+            }
             const float w00 = wxa * wya[j];
             const float w10 = wxb * wya[j];
             const float w01 = wxa * wyb[j];
@@ -364,7 +377,8 @@ static hipError_t launch_few(int src, bool planar, bool u8out, int prog_id, bool
     if (planar) {
         return src == SRC_U8    ? launch_few_planar<CN, SRC_U8>(prog_id, table, rpw, c, ip, ni, s)
                : src == SRC_U16 ? launch_few_planar<CN, SRC_U16>(prog_id, table, rpw, c, ip, ni, s)
-                                : launch_few_planar<CN, SRC_S16>(prog_id, table, rpw, c, ip, ni, s);
+               : src == SRC_S16 ? launch_few_planar<CN, SRC_S16>(prog_id, table, rpw, c, ip, ni, s)
+                                : launch_few_planar<CN, SRC_F32>(prog_id, table, rpw, c, ip, ni, s);
     }
     if (u8out) return launch_other<CN, uint8_t, WM_PACKED>(table, rpw, c, ip, ni, s);
     return launch_other<CN, float, WM_PACKED>(table, rpw, c, ip, ni, s);
@@ -387,7 +401,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write -- or, for 8U sources, an fp16 planar
     // tensor whose conversion is the chain's LAST stage (the half-precision hand-off option)
     if (r.kind != CVGS_READ_RESIZE_LINEAR || r.cn < 1 || r.cn > 4) return 0;
-    if (r.depth != CVGS_DEPTH_8U && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S) return 0;
+    if (r.depth != CVGS_DEPTH_8U && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S && r.depth != CVGS_DEPTH_32F) return 0;
     const bool few = r.cn < 3; // 1 / 2 channels: planar fp32, or packed fp32 / u8
     if (few && (c_in.write.kind == CVGS_WRITE_SPLIT_2D || c_in.write.depth == CVGS_DEPTH_16F)) return 0;
     const int wk = c_in.write.kind;
@@ -426,22 +440,25 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     const bool table = r.table != nullptr;
     const int prog_id = classify_program(c.prog, r.cn);
 
-    const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : SRC_S16);
+    const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
     if (info) {
-        static const char* names[3][2][3] = {
+        static const char* names[4][2][3] = {
             {{"k1_u8c3_swap_mul_sub_div", "k1_u8c3_mul_sub_div", "k1_u8c3_interp"},
              {"k1_u8c4_swap_mul_sub_div", "k1_u8c4_mul_sub_div", "k1_u8c4_interp"}},
             {{"k1_u16c3_swap_mul_sub_div", "k1_u16c3_mul_sub_div", "k1_u16c3_interp"},
              {"k1_u16c4_swap_mul_sub_div", "k1_u16c4_mul_sub_div", "k1_u16c4_interp"}},
             {{"k1_s16c3_swap_mul_sub_div", "k1_s16c3_mul_sub_div", "k1_s16c3_interp"},
-             {"k1_s16c4_swap_mul_sub_div", "k1_s16c4_mul_sub_div", "k1_s16c4_interp"}}};
+             {"k1_s16c4_swap_mul_sub_div", "k1_s16c4_mul_sub_div", "k1_s16c4_interp"}},
+            {{"k1_f32c3_swap_mul_sub_div", "k1_f32c3_mul_sub_div", "k1_f32c3_interp"},
+             {"k1_f32c4_swap_mul_sub_div", "k1_f32c4_mul_sub_div", "k1_f32c4_interp"}}};
         static const char* names16[2][3] = {{"k1_u8c3_swap_mul_sub_div_f16", "k1_u8c3_mul_sub_div_f16", "k1_u8c3_interp_f16"},
                                             {"k1_u8c4_swap_mul_sub_div_f16", "k1_u8c4_mul_sub_div_f16", "k1_u8c4_interp_f16"}};
         static const char* names_other[2][4] = {{"k1_u8c3_packed_f32", "k1_u8c3_packed_f16", "k1_u8c3_packed_u8", "k1_u8c3_planes2d_f32"},
                                                 {"k1_u8c4_packed_f32", "k1_u8c4_packed_f16", "k1_u8c4_packed_u8", "k1_u8c4_planes2d_f32"}};
-        static const char* names_few[3][2][2] = {{{"k1_u8c1_mul_sub_div", "k1_u8c1_interp"}, {"k1_u8c2_mul_sub_div", "k1_u8c2_interp"}},
+        static const char* names_few[4][2][2] = {{{"k1_u8c1_mul_sub_div", "k1_u8c1_interp"}, {"k1_u8c2_mul_sub_div", "k1_u8c2_interp"}},
                                                  {{"k1_u16c1_mul_sub_div", "k1_u16c1_interp"}, {"k1_u16c2_mul_sub_div", "k1_u16c2_interp"}},
-                                                 {{"k1_s16c1_mul_sub_div", "k1_s16c1_interp"}, {"k1_s16c2_mul_sub_div", "k1_s16c2_interp"}}};
+                                                 {{"k1_s16c1_mul_sub_div", "k1_s16c1_interp"}, {"k1_s16c2_mul_sub_div", "k1_s16c2_interp"}},
+                                                 {{"k1_f32c1_mul_sub_div", "k1_f32c1_interp"}, {"k1_f32c2_mul_sub_div", "k1_f32c2_interp"}}};
         static const char* names_few_packed[2][2] = {{"k1_u8c1_packed_f32", "k1_u8c1_packed_u8"}, {"k1_u8c2_packed_f32", "k1_u8c2_packed_u8"}};
         if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : names_few_packed[r.cn - 1][u8out];
         else if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
@@ -471,11 +488,13 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     } else if (r.cn == 3) {
         e = src == SRC_U8    ? launch_prog<3, SRC_U8>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
             : src == SRC_U16 ? launch_prog<3, SRC_U16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
-                             : launch_prog<3, SRC_S16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
+            : src == SRC_S16 ? launch_prog<3, SRC_S16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
+                             : launch_prog<3, SRC_F32>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
     } else {
         e = src == SRC_U8    ? launch_prog<4, SRC_U8>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
             : src == SRC_U16 ? launch_prog<4, SRC_U16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
-                             : launch_prog<4, SRC_S16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
+            : src == SRC_S16 ? launch_prog<4, SRC_S16>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s)
+                             : launch_prog<4, SRC_F32>(prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
     }
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }

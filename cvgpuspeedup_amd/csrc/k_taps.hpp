@@ -42,14 +42,42 @@ typedef const __attribute__((address_space(1))) u32x4_unaligned* gptr_u32x4;
 
 // Source element kinds of the fast path (the reference sweeps K1 over 8U, 16U and 16S sources,
 // tests/batchresize/test_batchresize_x_split3D.cu:427-432).
-enum { SRC_U8 = 0, SRC_U16 = 1, SRC_S16 = 2 };
-template <int SRC> constexpr int elem_bytes = SRC == SRC_U8 ? 1 : 2;
+enum { SRC_U8 = 0, SRC_U16 = 1, SRC_S16 = 2, SRC_F32 = 3 };
+template <int SRC> constexpr int elem_bytes = SRC == SRC_U8 ? 1 : (SRC == SRC_F32 ? 4 : 2);
 
 // The tap window of one lane and one source row: both horizontal taps (a pixel pair: 2*CN elements) arrive in ONE
 // unaligned load -- 8 bytes for u8 pixels (6 or 8 used), 16 bytes for 16-bit pixels (12 or 16 used).
 template <int EB> struct Win;
 template <> struct Win<1> { uint64_t lo; };
 template <> struct Win<2> { uint64_t lo, hi; };
+// CV_32F pixels: the window is exactly the pixel pair (2*CN floats, 8..32 bytes); no sub-dword shifting is ever needed
+template <> struct Win<4> { float e[8]; };
+typedef float f32_unaligned __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) f32_unaligned* gptr_f32u;
+template <int CN>
+__device__ __forceinline__ Win<4> load_win_f32(gptr_u8 p) {
+    Win<4> w;
+#pragma unroll
+    for (int k = 0; k < 2 * CN; ++k) w.e[k] = *(gptr_f32u)(p + 4 * k);
+    return w;
+}
+// one-pixel-wide rows: both taps are pixel 0
+template <int CN>
+__device__ __forceinline__ Win<4> gather_win_f32(gptr_u8 row) {
+    Win<4> w;
+#pragma unroll
+    for (int k = 0; k < CN; ++k) w.e[k] = w.e[CN + k] = *(gptr_f32u)(row + 4 * k);
+    return w;
+}
+// second_half: the window was clamped back by one pixel (x1 is the row's last pixel), so pixel x1 is the window's 2nd
+template <int CN>
+__device__ __forceinline__ void unpack_pair_f32(const Win<4>& w, bool second_half, bool edge, float* a, float* b) {
+#pragma unroll
+    for (int k = 0; k < CN; ++k) {
+        a[k] = second_half ? w.e[CN + k] : w.e[k];
+        b[k] = edge ? a[k] : w.e[CN + k];
+    }
+}
 
 template <int EB>
 __device__ __forceinline__ Win<EB> load_win(gptr_u8 p) {

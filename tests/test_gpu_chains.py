@@ -413,3 +413,44 @@ def test_colour_swap_on_the_source_type_before_the_cast_stays_thread_fused():
     ops = [cvgs.ReadIOp(capi.READ_PIXEL, u, [cvgs.GpuMat.from_tensor(t, u)], 1), cvgs.cvtColor(cvgs.COLOR_BGR2RGB, u), cvgs.convertTo(u, f),
            cvgs.multiply(f, [1 / 255.0] * 3), cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (600, 33))]
     assert cvgs.kernel_name(*ops) == "pointwise4_u8_interp"
+
+
+def test_cvgs_execute_is_thread_safe(oracle):
+    """The C-ABI claims re-entrancy (no shared mutable state except CircularTensor handles): four host threads launch
+    different chains on their own streams concurrently (ctypes releases the GIL); every result must be right."""
+    import ctypes as C
+    import threading
+    import torch
+    dev = torch.device("cuda:0")
+    lib = capi.load_library()
+    jobs = []
+    for t in range(4):
+        src = H.random_u8((200, 300, 3), 600 + t)
+        crops = H.random_crops(8 + t, 300, 200, seed=t, wmin=4, wmax=200, hmin=4, hmax=150)
+        ref = np.zeros((len(crops), 3 * 64 * 128), np.float32)
+        oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(src, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1),
+                                             swap=bool(t % 2))))
+        st = torch.from_numpy(src).to(dev)
+        outs = [torch.zeros((len(crops), 3 * 64 * 128), dtype=torch.float32, device=dev) for _ in range(50)]
+        chains = [cvgs.lower(H.k1_chain(cvgs.GpuMat.from_tensor(st, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1),
+                                        swap=bool(t % 2))) for o in outs]
+        jobs.append((torch.cuda.Stream(), chains, outs, ref, st))
+    errors = []
+
+    def worker(stream, chains):
+        for _ in range(4):
+            for ch in chains:
+                rc = lib.cvgs_execute(C.byref(ch.desc), stream.cuda_stream)
+                if rc:
+                    errors.append(lib.cvgs_last_error())
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=worker, args=(j[0], j[1])) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:3]
+    for _, _, outs, ref, _ in jobs:
+        for o in outs:
+            H.assert_bit_exact(o.cpu().numpy(), ref, "concurrent launches")

@@ -144,6 +144,16 @@ def timed(fn, dist_barrier):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
+def cpu_quota():
+    """CPUs this container may actually use (cgroup v2 cpu.max), or None if unlimited / unreadable: the thread count of
+    the CPU leg is the host's, but a quota caps what those threads can deliver."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else round(float(quota) / float(period), 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(wl, seconds):
     """The CPU restatement (oracle, kind 'port') timed on this box's host cores on a bounded sample of the same
     workload: frame 0's 50-crop batch, repeated for ~`seconds`.  Timed code = oracle_k1_fast_repeat, the headline chain
@@ -152,6 +162,9 @@ def cpu_baseline(wl, seconds):
     from oracle import oracle_binding as ob
     lib = ob.load_oracle()
     cores = lib.oracle_max_threads()
+    quota = cpu_quota()
+    if quota:  # more runnable threads than the container's CPU quota only get throttled
+        cores = max(1, min(cores, int(quota + 0.999)))
     lib.oracle_set_threads(cores)
     frame = wl.frames[0].cpu().numpy()
     ref = np.zeros((wl.n, 3 * W.DST[0] * W.DST[1]), np.float32)
@@ -192,7 +205,7 @@ def cpu_baseline(wl, seconds):
     return {"value": round(px / dt / 1e6, 2), "unit": "Mpix/s", "cores": int(cores), "kind": "port",
             "sample": "%d x the 50-crop batch of frame 0 (oracle_k1_fast_repeat: plain C loop nest, OpenMP %d threads, %.1f s)" % (
                 reps, cores, dt),
-            "single_thread_value": round(single, 2), "loop_nest_matches_interpreter_bit_exact": agree,
+            "single_thread_value": round(single, 2), "host_threads": int(lib.oracle_max_threads()), "cgroup_cpu_quota": quota, "loop_nest_matches_interpreter_bit_exact": agree,
             "gpu_matches_oracle_bit_exact": checked}
 
 

@@ -8,16 +8,27 @@ reaches and the CPU restatement timed beside it.
 A "step" = one pass of the hot path over one batch = ONE cvgs_execute() = one K1 launch over the 50 crops
 of one frame.  Steps cycle over enough distinct resident frames / outputs to exceed 2x the 256 MB Infinity
 Cache, so reads and writes really go to HBM.  Inputs (frames, crop descriptors) are resident in HBM before
-the timed region; the K timed steps are replayed from HIP graphs so the host's launch rate is not what is
-measured (BASELINE.md section 2; eager numbers are reported next to it under "extra").
+the timed region; the K timed steps are replayed from a HIP graph so the host's launch rate is not what is
+measured (eager numbers are reported next to it under "extra").
 
-N > 1 (one process per GPU, torch.distributed/RCCL): each rank owns its own frames and crop lists (weak
-scaling), runs K1 into its slice of the [N*50,3,128,64] tensor and all-gathers the slices over xGMI every
-step (BASELINE.json north_star).
+Timing protocol (one clock for `value`, `ms_per_step` and `roofline.frac`; mirrors the warm-up + ITERS
+mean/min/max protocol of the reference's tests/testsCommon.cuh:122-195):
+  1. pre-roll: >= 50 ms of K1 launches regardless of --warmup (clock ramp), then the W warm-up steps;
+  2. the K-step graph is replayed R >= 50 times back to back, each replay bracketed by a pair of HIP events ON THE
+     LAUNCH STREAM; the whole sequence sits between barrier + torch.cuda.synchronize() on both sides;
+  3. per-step time = MEDIAN over the R replays of (event time / K) (p10 / p90 / single-launch latency beside it);
+     value = pixels per step / that time, ms_per_step = that time, roofline.frac = algorithmic bytes per launch /
+     that time / 8 TB/s.  The wall clock of the bracketed region is reported too (`wall_ms_per_step`).
+
+N > 1 (one process per GPU, torch.distributed/RCCL) runs BASELINE cfg #5: each rank owns one resident 6K frame stream
+and 64 crops per step (weak scaling), K1 writes the rank's rows of the [N*64,3,128,64] tensor, and the tensor is
+assembled on every GPU either by an in-place RCCL all-gather over xGMI or by the P2P fused write (the kernel stores
+its rows into every peer's tensor through IPC-mapped pointers; one tiny all-reduce per step as the barrier).
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -29,12 +40,15 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from cvgpuspeedup_amd import capi, cvgs, sharding  # noqa: E402
+from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
 from cvgpuspeedup_amd import workloads as W  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 CROPS = 50
+CFG5_CROPS = 64        # BASELINE cfg #5: 64 crops of a 6K frame per GPU
 INFINITY_CACHE = 256 << 20
+PREROLL_S = 0.05       # >= 50 ms of K1 before any timing (clock ramp)
+MIN_REPLAYS = 50
 
 
 def baseline_metric():
@@ -48,12 +62,13 @@ def baseline_metric():
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=4096)
-    p.add_argument("--warmup", type=int, default=256)
+    p.add_argument("--steps", type=int, default=256)
+    p.add_argument("--warmup", type=int, default=64)
     p.add_argument("--crops", type=int, default=CROPS, help="crops per launch (headline: 50)")
     p.add_argument("--frames", type=int, default=0, help="distinct resident frames (0 = enough to defeat the cache)")
+    p.add_argument("--frames-per-launch", type=int, default=1, help="independent 50-crop chains fused per launch (cvgs_execute_many)")
     p.add_argument("--table", action="store_true", help="descriptors in a resident device table, not kernel args")
-    p.add_argument("--eager", action="store_true", help="time eager launches instead of graph replay")
+    p.add_argument("--eager", action="store_true", help="time eager launches instead of graph replay (PMC runs)")
     p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -62,21 +77,23 @@ def parse():
 
 
 class Workload:
-    """F resident 4K frames, F crop lists, F output tensors, F pre-lowered chains."""
+    """F resident frames, F crop lists, F output tensors, F pre-lowered chains; optionally grouped M chains per launch."""
 
     def __init__(self, dev, n_frames, crops_per_launch, rank, world, use_table, frame_wh=W.FRAME_4K,
-                 out_all=None, flags=0, share=None, half=False):
+                 out_all=None, flags=0, share=None, half=False, per_launch=1, mirrors=None):
         self.dev = dev
         fw, fh = frame_wh
+        self.frame_wh = frame_wh
         self.frames, self.outs, self.chains, self.crops, self.tables = [], [], [], [], []
         self.lib = capi.load_library()
         self.n = crops_per_launch
+        self.per_launch = per_launch
         plane = 3 * W.DST[0] * W.DST[1]
         for f in range(n_frames):
             seed = W.SEED + 1000 * rank + f
             frame = share.frames[f] if share is not None else W.random_u8_torch((fh, fw, 3), seed, dev)
             crops = W.random_crops(crops_per_launch, fw, fh, seed=seed + 500000)
-            if out_all is not None:  # in-place all-gather layout: this rank's slice of the full tensor
+            if out_all is not None:  # sharded layout: this rank's rows of the full tensor
                 out = out_all[f][rank * crops_per_launch:(rank + 1) * crops_per_launch]
             else:
                 out = torch.zeros((crops_per_launch, plane), dtype=torch.float16 if half else torch.float32, device=dev)
@@ -87,61 +104,124 @@ class Workload:
                 tab = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
                 self.tables.append(tab)
                 ops = W.k1_chain(g_src, crops, g_out, table=tab.data_ptr(), half=half)
+            if mirrors is not None:  # P2P fused write: the same rows of every peer's tensor
+                ops[-1].mirrored_to([p + rank * crops_per_launch * plane * out.element_size() for p in mirrors[f]])
             self.frames.append(frame)
             self.outs.append(out)
             self.crops.append(crops)
             self.chains.append(cvgs.lower(ops, flags))
         self.kernel = cvgs.kernel_name(*ops, flags=flags)
+        self.groups = []
+        if per_launch > 1:  # cvgs_execute_many: M consecutive chains per launch (device tables: capturable)
+            assert use_table and n_frames % per_launch == 0
+            for g in range(n_frames // per_launch):
+                self.groups.append(cvgs.pack_chains(self.chains[g * per_launch:(g + 1) * per_launch]))
 
     def launch(self, i, stream):
-        ch = self.chains[i % len(self.chains)]
-        rc = self.lib.cvgs_execute(C.byref(ch.desc), stream)
+        if self.per_launch > 1:
+            arr = self.groups[i % len(self.groups)]
+            rc = self.lib.cvgs_execute_many(arr, self.per_launch, stream)
+        else:
+            rc = self.lib.cvgs_execute(C.byref(self.chains[i % len(self.chains)].desc), stream)
         if rc:
             capi.check(rc)
 
+    def pixels_per_launch(self):
+        return self.n * self.per_launch * W.DST[0] * W.DST[1]
 
-def make_graphs(wl, steps, chunk=256):
-    """Capture the K steps as HIP graphs (chunks of <= 256 launches): returns [(graph, n_launches, repeats)]."""
-    plan = []
-    full, rem = divmod(steps, chunk)
-    base = 0
-    for n, reps in ((chunk, full), (rem, 1)):
-        if n == 0 or reps == 0:
-            continue
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            s = torch.cuda.current_stream().cuda_stream
-            for i in range(n):
-                wl.launch(base + i, s)
-        plan.append((g, n, reps))
-        base += n
-    return plan
+    def algorithmic_bytes(self, out_elem=4):
+        """SURVEY.md 8d figure per launch (tap census in cvgpuspeedup_amd/workloads.py; tests cross-check it with the oracle's)."""
+        return float(np.mean([W.k1_algorithmic_bytes(c, out_elem=out_elem) for c in self.crops])) * self.per_launch
+
+    def sector_bound_bytes(self, out_elem=4, sector=64):
+        """Sector-granular floor per launch: writes as they are + distinct 64-byte sectors holding a tapped byte."""
+        fw, fh = self.frame_wh
+        wr = self.n * 3 * out_elem * W.DST[0] * W.DST[1]
+        sample = self.crops[:min(len(self.crops), 8)]
+        rd = float(np.mean([W.k1_sector_read_bytes(c, fw, fh, sector=sector) for c in sample]))
+        return (wr + rd) * self.per_launch
 
 
-def run_steps(wl, steps, eager, plan=None):
-    if eager:
+def capture(wl, n, base=0):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
         s = torch.cuda.current_stream().cuda_stream
-        for i in range(steps):
-            wl.launch(i, s)
-    else:
-        for g, _, reps in plan:
-            for _ in range(reps):
+        for i in range(n):
+            wl.launch(base + i, s)
+    return g
+
+
+def percentile(sorted_vals, q):
+    return float(sorted_vals[min(len(sorted_vals) - 1, int(len(sorted_vals) * q))])
+
+
+def measure(wl, steps, warmup, barrier=lambda: None, eager=False, target_s=0.25, min_replays=MIN_REPLAYS, est_step_s=5e-6):
+    """The timing protocol of the module docstring.  Returns per-step seconds (median / p10 / p90 over the replays),
+    the wall clock of the whole bracketed region, and the number of replays."""
+    s = torch.cuda.current_stream().cuda_stream
+    chunk = min(steps, 256)
+    graphs = None
+    if not eager:
+        # the K steps as graphs of <= 256 launches (graph nodes are cheap to build, very long graphs are not)
+        graphs, base = [], 0
+        while base < steps:
+            n = min(chunk, steps - base)
+            graphs.append(capture(wl, n, base))
+            base += n
+
+    def run_k():
+        if eager:
+            for i in range(steps):
+                wl.launch(i, s)
+        else:
+            for g in graphs:
                 g.replay()
 
-
-def timed(fn, dist_barrier):
-    """barrier + synchronize on both sides; returns (wall seconds, device seconds by HIP events)."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    dist_barrier()
+    # 1. pre-roll (clock ramp) + the W warm-up steps
+    run_k()  # also instantiates / uploads the graphs before any clock starts
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    e0.record()
-    fn()
-    e1.record()
+    while time.perf_counter() - t0 < PREROLL_S:
+        for _ in range(max(1, int(64 / max(1, steps)))):
+            run_k()
+        torch.cuda.synchronize()
+    for i in range(warmup):
+        wl.launch(i, s)
     torch.cuda.synchronize()
-    dist_barrier()
-    t1 = time.perf_counter()
-    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+    est = max(est_step_s, 1e-7)
+    reps = int(min(2000, max(min_replays, math.ceil(target_s / (steps * est)))))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    # 2. R replays of the K-step graph, back to back, each between two HIP events on the launch stream
+    barrier()
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    run_k()  # lead-in: the host gets ahead of the GPU, so no replay waits for its submission
+    for e0, e1 in ev:
+        e0.record()
+        run_k()
+        e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    w1 = time.perf_counter()
+    t = np.sort(np.array([e0.elapsed_time(e1) * 1e-3 / steps for e0, e1 in ev]))
+    return {"step_s": float(np.median(t)), "p10_s": percentile(t, 0.10), "p90_s": percentile(t, 0.90), "min_s": float(t[0]),
+            "wall_s": w1 - w0, "replays": reps, "wall_step_s": (w1 - w0) / ((reps + 1) * steps)}
+
+
+def single_launch_latency(wl, n=200):
+    """One launch between two HIP events, stream idle before it (eager): what ONE 50-crop batch costs end to end on the
+    device, including the launch's own start-up -- the latency figure beside the back-to-back step time."""
+    s = torch.cuda.current_stream().cuda_stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i, (e0, e1) in enumerate(ev):
+        e0.record()
+        wl.launch(i, s)
+        e1.record()
+        if i % 8 == 7:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    t = np.sort(np.array([e0.elapsed_time(e1) * 1e3 for e0, e1 in ev]))
+    return {"median_us": round(float(np.median(t)), 3), "p10_us": round(percentile(t, 0.1), 3), "p90_us": round(percentile(t, 0.9), 3)}
 
 
 def cpu_quota():
@@ -209,10 +289,14 @@ def cpu_baseline(wl, seconds):
             "gpu_matches_oracle_bit_exact": checked}
 
 
-def algorithmic_bytes(wl, out_elem=4):
-    """SURVEY.md 8d figure per launch (tap census in cvgpuspeedup_amd/workloads.py; tests cross-check it with the oracle's)."""
-    per_launch = [W.k1_algorithmic_bytes(c, out_elem=out_elem) for c in wl.crops]
-    return float(np.mean(per_launch))
+def summary(wl, m, out_elem=4):
+    """The figures every sweep line carries, all from the one per-step clock."""
+    alg = wl.algorithmic_bytes(out_elem)
+    t = m["step_s"]
+    return {"Mpix_per_s": round(wl.pixels_per_launch() / t / 1e6, 1), "us_per_launch": round(t * 1e6, 3),
+            "p10_us": round(m["p10_s"] * 1e6, 3), "p90_us": round(m["p90_s"] * 1e6, 3),
+            "GB_per_s": round(alg / t / 1e9, 1), "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_of_sector_bound": round(wl.sector_bound_bytes(out_elem) / t / 1e9 / HBM_PEAK_GBS, 4), "kernel": wl.kernel}
 
 
 def main():
@@ -224,98 +308,33 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    use_dist = world > 1 or a.force_dist
-    if use_dist:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    if world > 1 or a.force_dist:
+        import bench_dist
+        return bench_dist.main(a, dev, rank, world)
 
     n = a.crops
+    M = a.frames_per_launch
     plane = 3 * W.DST[0] * W.DST[1]
-    per_frame_bytes = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + n * plane * 4 * world
+    per_frame_bytes = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + n * plane * 4
     n_frames = a.frames or max(8, (2 * INFINITY_CACHE + per_frame_bytes - 1) // per_frame_bytes + 1)
-
-    out_all = None
-    if use_dist:
-        # the full [world*n, C*H*W] tensor of every in-flight step; rank r's K1 writes rows [r*n, (r+1)*n)
-        out_all = [torch.zeros((world * n, plane), dtype=torch.float32, device=dev) for _ in range(n_frames)]
-    wl = Workload(dev, n_frames, n, rank, world, a.table, out_all=out_all)
+    if M > 1:
+        n_frames = ((n_frames + M - 1) // M) * M
+    wl = Workload(dev, n_frames, n, rank, world, a.table or M > 1, per_launch=M)
 
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
 
-    if not use_dist:
-        plan = None if a.eager else make_graphs(wl, a.steps)
-        warm = None if a.eager else (make_graphs(wl, a.warmup) if a.warmup else [])
-        run_steps(wl, a.warmup, a.eager, warm)
-        if not a.eager:
-            # instantiate + upload the timed graphs before the clock starts (one untimed replay): the first replay of a
-            # HIP graph pays its one-time setup, which is not part of a step
-            run_steps(wl, a.steps, False, plan)
-        wall, dev_s = timed(lambda: run_steps(wl, a.steps, a.eager, plan), barrier)
-        gather_note = None
-    else:
-        # Per step: K1 into this rank's slice of the step's tensor, then the in-place all-gather (RCCL over xGMI)
-        # that assembles it on every rank.  The collective runs asynchronously on RCCL's stream, so the K1 of the
-        # following steps overlaps it; a buffer is only rewritten after the gather that last used it has completed.
-        s = torch.cuda.current_stream().cuda_stream
-        works = [None] * n_frames
-
-        def step(i):
-            j = i % n_frames
-            if works[j] is not None:
-                works[j].wait()  # current stream waits for the collective that read buffer j
-            wl.launch(i, s)
-            works[j] = sharding_gather(out_all[j], world * n, dist)
-
-        def sharding_gather(full, items, d):
-            lo, hi = sharding.shard_bounds(items, world, rank)
-            return d.all_gather_into_tensor(full, full[lo:hi], async_op=True)
-
-        def drain():
-            for w in works:
-                if w is not None:
-                    w.wait()
-
-        for i in range(a.warmup):
-            step(i)
-        drain()
-        wall, dev_s = timed(lambda: ([step(i) for i in range(a.steps)], drain()), barrier)
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        gather_note = "in-place all_gather_into_tensor of %d x %d B per step, overlapped with the next steps' K1" % (
-            world, n * plane * 4)
-        # the same K steps WITHOUT the collective (every rank keeps its shard): what the sharded K1 alone scales to.
-        # Reported under "extra" only; `value` above includes the all-gather the north star asks for.
-        s2 = torch.cuda.current_stream().cuda_stream
-        for i in range(min(a.warmup, 64)):
-            wl.launch(i, s2)
-        wall_c, _ = timed(lambda: [wl.launch(i, s2) for i in range(a.steps)], barrier)
-        tc = torch.tensor([wall_c], dtype=torch.float64, device=dev)
-        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-        compute_only = {"value": round(n * W.DST[0] * W.DST[1] * world * a.steps / float(tc.item()) / 1e6, 1), "unit": "Mpix/s",
-                        "note": "same K steps, K1 only, no all-gather (eager launches; each rank keeps its shard)"}
-
-    px_per_step = n * W.DST[0] * W.DST[1] * world
-    value = px_per_step * a.steps / wall / 1e6
+    m = measure(wl, a.steps, a.warmup, eager=a.eager)
+    step_s = m["step_s"]
+    px_per_step = wl.pixels_per_launch()
     result = {
         "metric": baseline_metric(),
-        "value": round(value, 1),
+        "value": round(px_per_step / step_s / 1e6, 1),
         "unit": "Mpix/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "ms_per_step": round(wall / a.steps * 1e3, 6),
+        "ms_per_step": round(step_s * 1e3, 6),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -325,85 +344,41 @@ def main():
                                "[%d,3,128,64] fp32 per launch; %d resident frames cycled (working set %.0f MB)" % (
                                    n, n, n_frames, n_frames * per_frame_bytes / 1e6),
                    "chain": "resize(bilinear) -> RGB2BGR -> x0.3 -> -(1,4,3.2) -> /(3.2,0.6,11.8) -> TensorSplit",
-                   "crops_per_launch": n, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
-                   "descriptors": "device table" if a.table else "kernel arguments",
-                   "submission": ("eager, one K1 launch + one all-gather per step" if use_dist else
-                                  ("eager" if a.eager else "hipGraph replay (256-launch graphs)")),
-                   "parallelism": "1 process per GPU, crop lists sharded, %s" % (gather_note or "no collective")},
+                   "crops_per_launch": n, "frames_per_launch": M, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
+                   "descriptors": "device table" if (a.table or M > 1) else "kernel arguments",
+                   "submission": "eager" if a.eager else "hipGraph replay (%d-launch graphs)" % min(a.steps, 256),
+                   "regime": "one launch per step, steps serialised on one stream (launch-latency regime: a 50-crop launch "
+                             "moves ~9 MB = 1.1 us at 8 TB/s behind a ~1.8 us launch/drain floor)" if M == 1 else
+                             "%d independent 50-crop chains fused per launch (cvgs_execute_many)" % M,
+                   "parallelism": "1 process per GPU, crop lists sharded, no collective"},
+        "timing": {"protocol": "pre-roll >= %d ms; K-step graph replayed R times back to back, HIP events on the launch stream "
+                               "around each replay; per-step time = median over replays" % int(PREROLL_S * 1e3),
+                   "replays": m["replays"], "step_us_median": round(step_s * 1e6, 4), "step_us_p10": round(m["p10_s"] * 1e6, 4),
+                   "step_us_p90": round(m["p90_s"] * 1e6, 4), "step_us_min": round(m["min_s"] * 1e6, 4),
+                   "wall_ms_per_step": round(m["wall_step_s"] * 1e3, 6),
+                   "wall_note": "wall clock of the whole barrier+synchronize bracketed region / ((R+1) x K): includes R graph "
+                                "submissions and event records"},
     }
 
-    if rank == 0:
-        alg = algorithmic_bytes(wl)
-        if not use_dist:
-            k_s = dev_s / a.steps  # HIP events on the launch stream over the timed region / K launches
-        else:
-            # K1 alone, serialized on the launch stream (the timed region interleaves the gathers): 256 launches
-            # between one pair of HIP events, same method as the single-GPU leg
-            s = torch.cuda.current_stream().cuda_stream
-            for i in range(32):
-                wl.launch(i, s)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(256):
-                wl.launch(i, s)
-            e1.record()
-            torch.cuda.synchronize()
-            k_s = e0.elapsed_time(e1) * 1e-3 / 256
-        achieved = alg / k_s / 1e9
-        ceiling = copy_ceiling(dev)
-        result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, a.table),
-                              "kernel": wl.kernel, "kernel_us": round(k_s * 1e6, 3),
-                              "algorithmic_bytes_per_launch": int(alg),
-                              # the on-box device-to-device copy ceiling (read + write bytes / time), measured now
-                              "copy_ceiling": ceiling, "frac_of_copy_ceiling": round(achieved / ceiling, 4) if ceiling else None}
-    if use_dist:
-        barrier()
-        if rank == 0:
-            result.setdefault("extra", {})["without_allgather"] = compute_only
-            result["extra"]["per_step_gather_bytes_received_per_gpu"] = (world - 1) * n * plane * 4
-    if rank == 0 and world == 1 and not a.no_cpu:
+    alg = wl.algorithmic_bytes()
+    achieved = alg / step_s / 1e9
+    ceiling = copy_ceiling(dev)
+    sector = wl.sector_bound_bytes()
+    result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, a.table, M),
+                          "kernel": wl.kernel, "kernel_us": round(step_s * 1e6, 3),
+                          "algorithmic_bytes_per_launch": int(alg),
+                          # distinct 64-byte sectors holding a tapped byte + the writes: what no kernel can go below
+                          "sector_bound_bytes_per_launch": int(sector),
+                          "frac_of_sector_bound": round(sector / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                          # the on-box device-to-device copy ceiling (read + write bytes / time), measured now
+                          "copy_ceiling": ceiling, "frac_of_copy_ceiling": round(achieved / ceiling, 4) if ceiling else None}
+    result["timing"]["single_launch_latency"] = single_launch_latency(wl)
+    if not a.no_cpu and M == 1:
         result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
-    if rank == 0 and world == 1 and not a.no_extra:
-        result.setdefault("extra", {}).update(extra_sweeps(dev, a))
-    if rank == 0:
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def timing_distribution(wl, singles=200, bursts=100, burst=64):
-    """SURVEY.md 8d timing protocol: hipEvent pairs around (i) single launches and (ii) bursts of 64 back-to-back
-    launches cycling over the resident frames; median / p10 / p90 in microseconds per launch.  Eager submission, so
-    the single-launch figures include the event records and the host's launch path; plus the host's enqueue time per
-    cvgs_execute call (the quantity the reference's 'CPU' benchmark measures, benchmarks/benchmark_CPU_OpenCV_vs_cvGS.cu)."""
-    s = torch.cuda.current_stream().cuda_stream
-
-    def measure(n_launch, reps, base):
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for r, (e0, e1) in enumerate(ev):
-            e0.record()
-            for i in range(n_launch):
-                wl.launch(base + r * n_launch + i, s)
-            e1.record()
-        torch.cuda.synchronize()
-        t = np.sort(np.array([e0.elapsed_time(e1) * 1e3 / n_launch for e0, e1 in ev]))
-        return {"median": round(float(np.median(t)), 3), "p10": round(float(t[len(t) // 10]), 3),
-                "p90": round(float(t[(len(t) * 9) // 10]), 3)}
-
-    run_steps(wl, 64, True)
-    torch.cuda.synchronize()
-    out = {"single_launch_us": measure(1, singles, 0), "burst64_us_per_launch": measure(burst, bursts, 7)}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(2048):
-        wl.launch(i, s)
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    out["host_enqueue_us_per_call"] = round((t1 - t0) / 2048 * 1e6, 3)
-    return out
+    if not a.no_extra:
+        result["extra"] = extra_sweeps(dev, a)
+    print(json.dumps(result))
 
 
 def copy_ceiling(dev, mib=256, iters=20):
@@ -440,12 +415,12 @@ def copy_ceiling(dev, mib=256, iters=20):
         return None
 
 
-def pmc_traffic(crops, table):
+def pmc_traffic(crops, table, per_launch=1):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    separate --pmc runs, corrected as calibrated in profiles/r01_b_pmc_hbm.txt).  Counters cannot be read from inside
+    separate --pmc runs, corrected as calibrated in profiles/).  Counters cannot be read from inside
     this process, so the value is the one measured for exactly this workload/kernel; null for any other configuration."""
     path = os.path.join(ROOT, "profiles", "pmc_headline.json")
-    if crops != CROPS or table or not os.path.exists(path):
+    if crops != CROPS or table or per_launch != 1 or not os.path.exists(path):
         return None
     try:
         j = json.load(open(path))
@@ -474,68 +449,63 @@ def multi_stream(dev, n_streams=4, per_stream=64, rounds=16):
         for st in streams:
             cap.wait_stream(st)
     g.replay()
-    wall, dev_s = timed(lambda: [g.replay() for _ in range(rounds)], lambda: None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
     launches = n_streams * per_stream * rounds
-    return {"streams": n_streams, "us_per_batch": round(dev_s / launches * 1e6, 3),
-            "Mpix_per_s": round(CROPS * 8192 * launches / wall / 1e6, 1)}
+    t = e0.elapsed_time(e1) * 1e-3 / launches
+    return {"streams": n_streams, "us_per_batch": round(t * 1e6, 3), "Mpix_per_s": round(CROPS * 8192 / t / 1e6, 1)}
+
+
+def sweep_line(dev, crops, frame_wh=W.FRAME_4K, per_launch=1, half=False, table=None, steps=None):
+    out_elem = 2 if half else 4
+    per_frame = frame_wh[0] * frame_wh[1] * 3 + crops * 3 * 64 * 128 * out_elem
+    nf = max(4, min(48, (2 * INFINITY_CACHE) // per_frame + 1))
+    if per_launch > 1:
+        nf = max(per_launch, ((nf + per_launch - 1) // per_launch) * per_launch)
+    use_table = table if table is not None else (crops > 64 or per_launch > 1)
+    wl = Workload(dev, nf, crops, 0, 1, use_table, frame_wh=frame_wh, half=half, per_launch=per_launch)
+    steps = steps or max(16, min(256, 256 * 50 // (crops * per_launch)))
+    m = measure(wl, steps, 8, target_s=0.08, min_replays=20, est_step_s=5e-6 * max(1.0, crops * per_launch / 100.0))
+    line = summary(wl, m, out_elem)
+    del wl
+    torch.cuda.empty_cache()
+    return line
 
 
 def extra_sweeps(dev, a):
-    """Secondary measurements (not the headline): eager submission and larger crop lists per launch, where the
-    kernel leaves the launch-latency regime (SURVEY.md 'hard parts': cfg #2 moves only ~6-10 MB per launch)."""
+    """Secondary measurements (not the headline), every line on the same clock as the headline: frames fused per launch
+    (cvgs_execute_many), larger crop lists per launch, other frame sizes, fp16 output, eager submission, several streams."""
     out = {}
     try:
+        # launch batching: M independent 50-crop chains (distinct frames / crop lists / output tensors) in ONE launch
+        for M in (1, 4, 16, 64):
+            out["frames_per_launch_%d" % M] = sweep_line(dev, 50, per_launch=M, table=True)
         # the 50-crop batch on 1080p and 6K source frames (the headline uses 4K); crop sizes are clipped to the frame
-        for name, wh in (("frame_1080p_50", W.FRAME_1080P), ("frame_6k_50", W.FRAME_6K)):
-            per_frame = wh[0] * wh[1] * 3 + 50 * 3 * 64 * 128 * 4
-            nf = max(4, min(48, (2 * INFINITY_CACHE) // per_frame + 1))
-            wl = Workload(dev, nf, 50, 0, 1, use_table=False, frame_wh=wh)
-            plan = make_graphs(wl, 2048)
-            run_steps(wl, 64, True)
-            wall, dev_s = timed(lambda: run_steps(wl, 2048, False, plan), lambda: None)
-            alg = algorithmic_bytes(wl)
-            out[name] = {"Mpix_per_s": round(50 * 8192 * 2048 / wall / 1e6, 1), "kernel_us": round(dev_s / 2048 * 1e6, 3),
-                         "GB_per_s": round(alg / (dev_s / 2048) / 1e9, 1), "frac": round(alg / (dev_s / 2048) / 1e9 / HBM_PEAK_GBS, 4)}
-            del wl, plan
-            torch.cuda.empty_cache()
-        for crops in (50, 200, 800, 3200):
-            per_frame = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + crops * 3 * 64 * 128 * 4
-            nf = max(4, min(24, (2 * INFINITY_CACHE) // per_frame + 1))
-            wl = Workload(dev, nf, crops, 0, 1, use_table=True)
-            steps = max(32, 4096 * 50 // crops)
-            steps -= steps % 1
-            plan = make_graphs(wl, steps)
-            run_steps(wl, min(steps, 64), True)
-            wall, dev_s = timed(lambda: run_steps(wl, steps, False, plan), lambda: None)
-            alg = algorithmic_bytes(wl)
-            out["crops_per_launch_%d" % crops] = {
-                "Mpix_per_s": round(crops * 8192 * steps / wall / 1e6, 1), "kernel_us": round(dev_s / steps * 1e6, 3),
-                "GB_per_s": round(alg / (dev_s / steps) / 1e9, 1), "frac": round(alg / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, 4),
-                "kernel": wl.kernel}
-            del wl, plan
-            torch.cuda.empty_cache()
+        out["frame_1080p_50"] = sweep_line(dev, 50, frame_wh=W.FRAME_1080P)
+        out["frame_6k_50"] = sweep_line(dev, 50, frame_wh=W.FRAME_6K)
+        out["frame_6k_64_cfg5_per_gpu"] = sweep_line(dev, CFG5_CROPS, frame_wh=W.FRAME_6K)
+        for crops in (200, 800, 3200):
+            out["crops_per_launch_%d" % crops] = sweep_line(dev, crops)
         # half-precision hand-off option (SURVEY.md 8(f)3): same chain + convertTo<CV_32FC3, CV_16FC3>, fp16 NCHW tensor
         for crops in (50, 3200):
-            per_frame = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + crops * 3 * 64 * 128 * 2
-            nf = max(4, min(24, (2 * INFINITY_CACHE) // per_frame + 1))
-            wl = Workload(dev, nf, crops, 0, 1, use_table=crops > 64, half=True)
-            steps = max(32, 4096 * 50 // crops)
-            plan = make_graphs(wl, steps)
-            run_steps(wl, min(steps, 64), True)
-            wall, dev_s = timed(lambda: run_steps(wl, steps, False, plan), lambda: None)
-            alg = algorithmic_bytes(wl, out_elem=2)
-            out["fp16_output_%d" % crops] = {
-                "Mpix_per_s": round(crops * 8192 * steps / wall / 1e6, 1), "kernel_us": round(dev_s / steps * 1e6, 3),
-                "GB_per_s": round(alg / (dev_s / steps) / 1e9, 1), "frac": round(alg / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, 4),
-                "kernel": wl.kernel}
-            del wl, plan
-            torch.cuda.empty_cache()
+            out["fp16_output_%d" % crops] = sweep_line(dev, crops, half=True)
         wl = Workload(dev, 24, 50, 0, 1, use_table=False)
-        run_steps(wl, 256, True)
-        wall, dev_s = timed(lambda: run_steps(wl, 2048, True), lambda: None)
-        out["eager_50"] = {"Mpix_per_s": round(50 * 8192 * 2048 / wall / 1e6, 1), "us_per_step": round(wall / 2048 * 1e6, 3),
+        m = measure(wl, 256, 64, eager=True, target_s=0.05, min_replays=20)
+        s = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2048):
+            wl.launch(i, s)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        out["eager_50"] = {"us_per_step": round(m["step_s"] * 1e6, 3), "Mpix_per_s": round(50 * 8192 / m["step_s"] / 1e6, 1),
+                           "host_enqueue_us_per_call": round((t1 - t0) / 2048 * 1e6, 3),
                            "note": "python ctypes + cvgs_execute + hipLaunchKernel per step (host-bound)"}
-        out["timing_distribution_50"] = timing_distribution(wl)
         del wl
         torch.cuda.empty_cache()
         out["multi_stream_50"] = multi_stream(dev)

@@ -14,6 +14,8 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 MAX_OPS = 12
 KERNARG_PLANES = 64
+MAX_MIRRORS = 7
+MAX_CHAINS = 128
 
 # status
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RCCL = 0, -1, -2, -3, -4, -5
@@ -74,7 +76,8 @@ class Op(C.Structure):
 
 class WriteDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dst_type", C.c_int32), ("data", C.c_void_p), ("width", C.c_int32),
-                ("height", C.c_int32), ("step", C.c_int32), ("planes", C.c_int32), ("planes2d", C.c_void_p)]
+                ("height", C.c_int32), ("step", C.c_int32), ("planes", C.c_int32), ("planes2d", C.c_void_p),
+                ("mirrors", C.POINTER(C.c_void_p)), ("n_mirrors", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ChainDesc(C.Structure):
@@ -89,6 +92,7 @@ SYMBOLS = [
     ("cvgs_last_error", C.c_char_p, []),
     ("cvgs_device_count", C.c_int, []),
     ("cvgs_execute", C.c_int, [C.POINTER(ChainDesc), C.c_void_p]),
+    ("cvgs_execute_many", C.c_int, [C.POINTER(ChainDesc), C.c_int32, C.c_void_p]),
     ("cvgs_validate", C.c_int, [C.POINTER(ChainDesc)]),
     ("cvgs_kernel_name", C.c_int, [C.POINTER(ChainDesc), C.c_char_p, C.c_size_t]),
     ("cvgs_plane_table_bytes", C.c_size_t, [C.c_int32]),
@@ -142,7 +146,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.cvgs_abi_version() != 2:
+    if lib.cvgs_abi_version() != 3:
         raise ImportError("libcvgs_hip.so ABI version mismatch")
     _lib = lib
     return lib

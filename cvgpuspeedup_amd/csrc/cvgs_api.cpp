@@ -8,12 +8,22 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
 #include "cvgs_device.h"
 
 using namespace cvgs;
+
+#ifdef CVGS_WITH_EXPERIMENTS
+namespace cvgs {
+// experimental K1 variants (k_k1_exp.hip); A/B benchmarking only, never part of libcvgs_hip.so
+int launch_k1_exp(int variant, const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream);
+const char* k1_exp_name(int variant);
+} // namespace cvgs
+#endif
 
 namespace {
 
@@ -71,13 +81,51 @@ void plane_geometry(int sw, int sh, int dw, int dh, int ar, PlaneParams& P) {
     P.y2 = y0 + th - 1;
 }
 
+// Host descriptors of one call: inline storage for everything that fits the kernel-argument block (so that a call with
+// <= CVGS_KERNARG_PLANES planes never touches the heap), heap beyond that.
+template <typename T, int N>
+class SmallBuf {
+public:
+    SmallBuf() = default;
+    SmallBuf(const SmallBuf&) = delete;
+    SmallBuf& operator=(const SmallBuf&) = delete;
+    ~SmallBuf() { if (heap_) std::free(heap_); }
+    bool assign(size_t n, const T& v) {
+        if (!resize(n)) return false;
+        for (size_t i = 0; i < n; ++i) data()[i] = v;
+        return true;
+    }
+    bool resize(size_t n) {
+        if (n > (size_t)N && n > cap_) {
+            void* h = std::realloc(heap_, n * sizeof(T));
+            if (!h) return false;
+            heap_ = (T*)h;
+            cap_ = n;
+        }
+        if (n > (size_t)N && size_ <= (size_t)N && size_) std::memcpy(heap_, inline_, size_ * sizeof(T));
+        size_ = n;
+        return true;
+    }
+    T* data() { return size_ > (size_t)N ? heap_ : inline_; }
+    const T* data() const { return size_ > (size_t)N ? heap_ : inline_; }
+    T& operator[](size_t i) { return data()[i]; }
+    const T& operator[](size_t i) const { return data()[i]; }
+    size_t size() const { return size_; }
+    bool empty() const { return size_ == 0; }
+private:
+    T inline_[N];
+    T* heap_ = nullptr;
+    size_t cap_ = 0, size_ = 0;
+};
+
 struct Lowered {
     ChainArgs args{};
     Prog64Args p64{};
+    MirrorArgs mirrors{};
     bool uses_64f = false;
-    std::vector<PlaneParams> planes;  // host copy (inline or to upload)
-    std::vector<WarpPlane> warp_planes; // WARP kinds (instead of `planes`)
-    std::vector<DstPlane> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
+    SmallBuf<PlaneParams, CVGS_KERNARG_PLANES> planes;  // host copy (inline or to upload)
+    SmallBuf<WarpPlane, kInlineWarp> warp_planes;       // WARP kinds (instead of `planes`)
+    SmallBuf<DstPlane, CVGS_KERNARG_PLANES> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
     int out_w = 0, out_h = 0;
     int final_depth = 0, final_cn = 0;
 };
@@ -107,6 +155,8 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
             break;
         case CVGS_OP_ADD_ALPHA:
             if (cn != 3) return fail(CVGS_ERR_INVALID, "ADD_ALPHA needs a 3-channel value");
+            for (int c = 0; c < 3; ++c)
+                if (((op.aux >> (2 * c)) & 3) >= cn) return fail(CVGS_ERR_INVALID, "ADD_ALPHA: source channel out of range");
             cn = 4;
             break;
         case CVGS_OP_DROP_ALPHA:
@@ -115,6 +165,8 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
             break;
         case CVGS_OP_GRAY:
             if (cn < 3) return fail(CVGS_ERR_INVALID, "GRAY needs a 3- or 4-channel value");
+            for (int c = 0; c < 3; ++c)
+                if (((op.aux >> (2 * c)) & 3) >= cn) return fail(CVGS_ERR_INVALID, "GRAY: source channel out of range");
             if (depth == CVGS_DEPTH_32S || depth == CVGS_DEPTH_64F || depth == CVGS_DEPTH_16F)
                 return fail(CVGS_ERR_UNSUPPORTED, "GRAY on CV_32S / CV_64F / CV_16F");
             cn = 1;
@@ -131,6 +183,8 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (!ch) return fail(CVGS_ERR_INVALID, "null chain");
     if (ch->struct_size != sizeof(cvgs_chain_desc)) return fail(CVGS_ERR_INVALID, "cvgs_chain_desc size mismatch (ABI)");
     if (ch->n_ops < 0 || ch->n_ops > CVGS_MAX_OPS) return fail(CVGS_ERR_INVALID, "n_ops out of range");
+    if (ch->flags & ~(uint32_t)(CVGS_CHAIN_FORCE_GENERIC | CVGS_CHAIN_NO_THREAD_FUSION))
+        return fail(CVGS_ERR_INVALID, "unknown chain flags");
     const cvgs_read_desc& rd = ch->read;
     const cvgs_write_desc& wr = ch->write;
     if (rd.kind < CVGS_READ_PIXEL || rd.kind > CVGS_READ_WARP_PERSPECTIVE) return fail(CVGS_ERR_INVALID, "bad read kind");
@@ -179,7 +233,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     } else {
         const cvgs_image2d* src = (const cvgs_image2d*)rd.src;
         if (is_warp(rd.kind)) {
-            L.warp_planes.assign((size_t)rd.batch, WarpPlane{});
+            if (!L.warp_planes.assign((size_t)rd.batch, WarpPlane{})) return fail(CVGS_ERR_HIP, "out of host memory");
             for (int z = 0; z < rd.used_planes; ++z) {
                 const cvgs_image2d& im = src[z];
                 if (!im.data || im.width < 1 || im.height < 1) return fail(CVGS_ERR_INVALID, "empty source plane");
@@ -192,7 +246,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
                 for (int k = 0; k < 9; ++k) P.m[k] = rd.warp_matrices[(size_t)z * 9 + k];
             }
         } else {
-            L.planes.assign((size_t)rd.batch, PlaneParams{});
+            if (!L.planes.assign((size_t)rd.batch, PlaneParams{})) return fail(CVGS_ERR_HIP, "out of host memory");
         }
         for (int z = 0; z < (is_warp(rd.kind) ? 0 : rd.used_planes); ++z) {
             const cvgs_image2d& im = src[z];
@@ -282,6 +336,16 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             return fail(CVGS_ERR_INVALID, "write plane size differs from the size produced by the read stage");
     }
     if (tensor_kind && !circular && wr.planes < rd.batch) return fail(CVGS_ERR_INVALID, "tensor has fewer planes than the batch");
+    if (wr.n_mirrors < 0 || wr.n_mirrors > CVGS_MAX_MIRRORS) return fail(CVGS_ERR_INVALID, "n_mirrors out of range");
+    if (wr.n_mirrors > 0) {
+        if (!tensor_kind || circular) return fail(CVGS_ERR_INVALID, "mirrors exist for tensor write kinds only (and not inside a CircularTensor update)");
+        if (!wr.mirrors) return fail(CVGS_ERR_INVALID, "write.mirrors is null");
+        for (int i = 0; i < wr.n_mirrors; ++i) {
+            if (!wr.mirrors[i]) return fail(CVGS_ERR_INVALID, "null mirror tensor");
+            L.mirrors.p[i] = (uint8_t*)wr.mirrors[i];
+        }
+        L.mirrors.n = wr.n_mirrors;
+    }
     if (wr.kind == CVGS_WRITE_PIXEL_2D) {
         if (rd.batch != 1) return fail(CVGS_ERR_INVALID, "PIXEL_2D writes one image: batch must be 1");
         if (wr.step < L.out_w * depth_bytes(L.final_depth) * L.final_cn) return fail(CVGS_ERR_INVALID, "write step smaller than a row");
@@ -292,7 +356,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             return fail(CVGS_ERR_INVALID, "split needs 2, 3 or 4 channels"); // cvGPUSpeedupHelpers.cuh:76
         const int per = wr.kind == CVGS_WRITE_SPLIT_2D ? L.final_cn : 1;
         const int esz = depth_bytes(L.final_depth) * (wr.kind == CVGS_WRITE_SPLIT_2D ? 1 : L.final_cn);
-        L.dst_planes.resize((size_t)rd.batch * per);
+        if (!L.dst_planes.resize((size_t)rd.batch * per)) return fail(CVGS_ERR_HIP, "out of host memory");
         for (size_t i = 0; i < L.dst_planes.size(); ++i) {
             const cvgs_image2d& im = wr.planes2d[i];
             if (!im.data || im.width != L.out_w || im.height != L.out_h || im.step < im.width * esz)
@@ -305,111 +369,335 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     return CVGS_OK;
 }
 
-// Stream-ordered scratch for descriptor tables that do not fit the kernel-argument block.
-struct AsyncTable {
+// ---- descriptor scratch ------------------------------------------------------------------------------------------
+// Tables that do not fit the kernel-argument block (more than 64 planes; the segments of cvgs_execute_many) are staged
+// in a pinned host buffer and copied, stream-ordered, into a device buffer.  Both belong to a slot of a library-owned
+// pool; a slot is reusable once the HIP event recorded behind the kernel that read it has completed, so neither the
+// host staging bytes nor the device table can be recycled while the GPU may still read them, no call frees or
+// synchronises, and a steady-state serving loop allocates nothing.
+struct ScratchSlot {
+    void* host = nullptr;
     void* dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    int device = -1;
+    bool leased = false;  // handed to a call that has not committed yet
+    bool pending = false; // committed: reusable once `ev` completes
+};
+
+class ScratchPool {
+public:
+    int acquire(int device, size_t bytes, int* slot_out) {
+        std::lock_guard<std::mutex> lk(m_);
+        int free_small = -1;
+        for (size_t i = 0; i < slots_.size(); ++i) {
+            ScratchSlot& sl = slots_[i];
+            if (sl.device != device || sl.leased) continue;
+            if (sl.pending) {
+                if (hipEventQuery(sl.ev) != hipSuccess) continue;
+                sl.pending = false;
+            }
+            if (sl.cap >= bytes) {
+                sl.leased = true;
+                *slot_out = (int)i;
+                return 0;
+            }
+            free_small = (int)i;
+        }
+        ScratchSlot fresh;
+        ScratchSlot* sl = &fresh;
+        if (free_small >= 0) { // grow an idle slot instead of adding one
+            sl = &slots_[(size_t)free_small];
+            (void)hipHostFree(sl->host);
+            (void)hipFree(sl->dev);
+            sl->host = sl->dev = nullptr;
+        }
+        size_t cap = 64 << 10;
+        while (cap < bytes) cap <<= 1;
+        hipError_t e = hipHostMalloc(&sl->host, cap, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&sl->dev, cap);
+        if (e == hipSuccess && !sl->ev) e = hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (sl->host) (void)hipHostFree(sl->host);
+            if (sl->dev) (void)hipFree(sl->dev);
+            sl->host = sl->dev = nullptr;
+            sl->cap = 0;
+            return hip_fail(e, "descriptor scratch allocation");
+        }
+        sl->cap = cap;
+        sl->device = device;
+        sl->leased = true;
+        sl->pending = false;
+        if (free_small >= 0) {
+            *slot_out = free_small;
+        } else {
+            slots_.push_back(fresh);
+            *slot_out = (int)slots_.size() - 1;
+        }
+        return 0;
+    }
+    void* host(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].host; }
+    void* dev(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].dev; }
+    // the kernel that reads the slot has been enqueued on `stream`: recycle after it
+    void commit(int slot, hipStream_t stream) {
+        std::lock_guard<std::mutex> lk(m_);
+        ScratchSlot& sl = slots_[(size_t)slot];
+        sl.pending = hipEventRecord(sl.ev, stream) == hipSuccess;
+        if (!sl.pending) (void)hipStreamSynchronize(stream); // cannot track it: make it safe the slow way
+        sl.leased = false;
+    }
+    void abandon(int slot) { // nothing was enqueued
+        std::lock_guard<std::mutex> lk(m_);
+        slots_[(size_t)slot].leased = false;
+    }
+private:
+    std::mutex m_;
+    std::vector<ScratchSlot> slots_;
+};
+
+ScratchPool& scratch_pool() {
+    static ScratchPool* pool = new ScratchPool; // leaked on purpose: HIP may already be gone at static destruction
+    return *pool;
+}
+
+int stream_device(hipStream_t s) {
+    int dev = 0;
+    if (s) {
+        hipDevice_t d;
+        if (hipStreamGetDevice(s, &d) == hipSuccess) return (int)d;
+    }
+    (void)hipGetDevice(&dev);
+    return dev;
+}
+
+// makes `device` current for the scope (CircularTensor handles and scratch slots live on one device)
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+            switched = true;
+        }
+        return 0;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// One stream-ordered upload of host descriptors; committed after the launch that reads it.
+struct Upload {
+    int slot = -1;
     hipStream_t stream = nullptr;
-    int upload(const void* host, size_t bytes, hipStream_t s) {
+    void* dev = nullptr;
+    size_t used = 0;
+    bool flushed = false;
+    int begin(size_t bytes, hipStream_t s) {
         stream = s;
-        // Under stream capture the copy node would keep a pointer to host memory that dies when this call returns:
-        // refuse loudly instead of replaying garbage.  (Captured launches must use kernel-argument descriptors,
-        // i.e. <= CVGS_KERNARG_PLANES planes, or a caller-owned device table from cvgs_plane_table_build.)
+        // Under stream capture the copy node would keep a pointer to staging memory this library recycles: refuse
+        // loudly instead of replaying garbage.  (Captured launches use kernel-argument descriptors, i.e. <=
+        // CVGS_KERNARG_PLANES planes, or caller-owned device tables from cvgs_plane_table_build.)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
             return fail(CVGS_ERR_UNSUPPORTED,
                         "descriptor table upload during stream capture: pass a device plane table (cvgs_plane_table_build)");
-        hipError_t e = hipMallocAsync(&dev, bytes, s);
-        if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(descriptor table)");
-        e = hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptor table)");
+        const int device = stream_device(s);
+        DeviceGuard guard;
+        int rc = guard.enter(device);
+        if (rc) return rc;
+        rc = scratch_pool().acquire(device, bytes, &slot);
+        if (rc) return rc;
+        dev = scratch_pool().dev(slot);
         return 0;
     }
-    ~AsyncTable() {
-        if (dev) (void)hipFreeAsync(dev, stream);
+    // appends `bytes` to the staging buffer; returns the device address they will have (16-byte aligned pieces)
+    void* put(const void* src, size_t bytes) {
+        uint8_t* h = (uint8_t*)scratch_pool().host(slot);
+        std::memcpy(h + used, src, bytes);
+        void* d = (uint8_t*)dev + used;
+        used += (bytes + 15) & ~(size_t)15;
+        return d;
     }
+    int flush() {
+        hipError_t e = hipMemcpyAsync(dev, scratch_pool().host(slot), used, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptor table)");
+        flushed = true;
+        return 0;
+    }
+    void done(bool launched) {
+        if (slot < 0) return;
+        if (launched || flushed) scratch_pool().commit(slot, stream); // an enqueued copy still reads the staging bytes
+        else scratch_pool().abandon(slot);
+        slot = -1;
+    }
+    ~Upload() { done(false); }
 };
 
 int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry_run, LaunchInfo* info) {
-    AsyncTable src_tab, dst_tab;
-    if (is_warp(L.args.read.kind)) {
-        if (L.uses_64f) return fail(CVGS_ERR_UNSUPPORTED, "warp chains on CV_64F values");
-        if (!L.dst_planes.empty()) {
-            if ((int)L.dst_planes.size() <= kInlineDst) {
-                for (size_t i = 0; i < L.dst_planes.size(); ++i) L.args.dst_inline[i] = L.dst_planes[i];
-            } else if (!dry_run) {
-                int rc = dst_tab.upload(L.dst_planes.data(), L.dst_planes.size() * sizeof(DstPlane), stream);
-                if (rc) return rc;
-                L.args.write.table = (const DstPlane*)dst_tab.dev;
-            }
+    Upload up;
+    const bool has_mirrors = L.mirrors.n > 0;
+    // how many bytes of descriptors exceed the kernel-argument block?
+    const bool warp = is_warp(L.args.read.kind);
+    const int inline_cap = L.uses_64f ? kInline64 : CVGS_KERNARG_PLANES;
+    const bool up_src = warp ? (int)L.warp_planes.size() > kInlineWarp : (!L.args.read.table && (int)L.planes.size() > inline_cap);
+    const bool up_dst = (int)L.dst_planes.size() > kInlineDst;
+    if (!dry_run && (up_src || up_dst)) {
+        const size_t bytes = (up_src ? (warp ? L.warp_planes.size() * sizeof(WarpPlane) : L.planes.size() * sizeof(PlaneParams)) : 0) +
+                             (up_dst ? L.dst_planes.size() * sizeof(DstPlane) : 0) + 32;
+        int rc = up.begin(bytes, stream);
+        if (rc) return rc;
+    }
+    if (!L.dst_planes.empty()) {
+        if (!up_dst) {
+            for (size_t i = 0; i < L.dst_planes.size(); ++i) L.args.dst_inline[i] = L.dst_planes[i];
+        } else if (!dry_run) {
+            L.args.write.table = (const DstPlane*)up.put(L.dst_planes.data(), L.dst_planes.size() * sizeof(DstPlane));
+        } else {
+            L.args.write.table = (const DstPlane*)(uintptr_t)16; // any non-null: the same variant as the real launch
         }
+    }
+    if (warp) {
+        if (L.uses_64f) return fail(CVGS_ERR_UNSUPPORTED, "warp chains on CV_64F values");
+        if (has_mirrors) return fail(CVGS_ERR_UNSUPPORTED, "mirrors on warp chains");
         const WarpPlane* dev = nullptr;
         const int n = (int)L.warp_planes.size();
-        if (n > kInlineWarp) {
-            if (!dry_run) {
-                int rc = src_tab.upload(L.warp_planes.data(), L.warp_planes.size() * sizeof(WarpPlane), stream);
-                if (rc) return rc;
-                dev = (const WarpPlane*)src_tab.dev;
-            } else {
-                dev = (const WarpPlane*)(uintptr_t)16;
-            }
+        if (up_src) dev = dry_run ? (const WarpPlane*)(uintptr_t)16 : (const WarpPlane*)up.put(L.warp_planes.data(), L.warp_planes.size() * sizeof(WarpPlane));
+        if (up.slot >= 0) {
+            int rc = up.flush();
+            if (rc) return rc;
         }
         if (launch_warp(L.args, L.warp_planes.data(), n, dev, ch->flags, stream, dry_run, info)) return fail(CVGS_ERR_HIP, "warp kernel launch failed");
+        up.done(true);
         return CVGS_OK;
     }
     const PlaneParams* inline_planes = L.planes.data();
     int n_inline = (int)L.planes.size();
-    const int inline_cap = L.uses_64f ? kInline64 : CVGS_KERNARG_PLANES;
-    if (!L.args.read.table && n_inline > inline_cap) {
-        if (!dry_run) {
-            int rc = src_tab.upload(L.planes.data(), L.planes.size() * sizeof(PlaneParams), stream);
-            if (rc) return rc;
-            L.args.read.table = (const PlaneParams*)src_tab.dev;
-        } else {
-            L.args.read.table = (const PlaneParams*)(uintptr_t)16; // any non-null: selects the table variants
-        }
+    if (up_src) {
+        L.args.read.table = dry_run ? (const PlaneParams*)(uintptr_t)16 // any non-null: selects the table variants
+                                    : (const PlaneParams*)up.put(L.planes.data(), L.planes.size() * sizeof(PlaneParams));
         inline_planes = nullptr;
         n_inline = 0;
     }
-    if (!L.dst_planes.empty()) {
-        if ((int)L.dst_planes.size() <= kInlineDst) {
-            for (size_t i = 0; i < L.dst_planes.size(); ++i) L.args.dst_inline[i] = L.dst_planes[i];
-        } else if (!dry_run) {
-            int rc = dst_tab.upload(L.dst_planes.data(), L.dst_planes.size() * sizeof(DstPlane), stream);
-            if (rc) return rc;
-            L.args.write.table = (const DstPlane*)dst_tab.dev;
-        }
+    if (up.slot >= 0) {
+        int rc = up.flush();
+        if (rc) return rc;
     }
     int rc = 0;
     if (L.uses_64f) {
+        if (has_mirrors) return fail(CVGS_ERR_UNSUPPORTED, "mirrors on CV_64F chains");
         rc = launch_generic64(L.args, L.p64, inline_planes, n_inline, stream, dry_run, info);
         if (rc) return fail(CVGS_ERR_HIP, "generic64 kernel launch failed");
-        return CVGS_OK;
-    }
-    const int exp_variant = (int)((ch->flags >> 8) & 0xff);
-    if (exp_variant && k1_exp_name(exp_variant) && L.args.read.kind == CVGS_READ_RESIZE_LINEAR && L.args.read.depth == CVGS_DEPTH_8U &&
-        L.args.read.cn == 3 && L.args.prog.n == 4 && L.args.write.depth == CVGS_DEPTH_32F &&
-        (L.args.write.kind == CVGS_WRITE_TENSOR_SPLIT || L.args.write.kind == CVGS_WRITE_TENSOR_T_SPLIT)) {
-        if (info) info->kernel = k1_exp_name(exp_variant);
-        if (dry_run) return CVGS_OK;
-        rc = launch_k1_exp(exp_variant, L.args, inline_planes, n_inline, stream);
-        if (rc < 0) return fail(CVGS_ERR_HIP, "experimental K1 launch failed");
+        up.done(true);
         return CVGS_OK;
     }
     if (!(ch->flags & CVGS_CHAIN_FORCE_GENERIC)) {
-        rc = launch_k1(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
+        rc = launch_k1(L.args, inline_planes, n_inline, L.mirrors, nullptr, 0, stream, dry_run, info);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
-        if (rc == 1) return CVGS_OK;
-        int min_w = 1 << 30;
-        for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
-        rc = launch_nv12(L.args, inline_planes, n_inline, min_w, stream, dry_run, info);
-        if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
-        if (rc == 1) return CVGS_OK;
-        rc = launch_pointwise(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
-        if (rc < 0) return fail(CVGS_ERR_HIP, "pointwise kernel launch failed");
-        if (rc == 1) return CVGS_OK;
+        if (rc == 1) { up.done(true); return CVGS_OK; }
+        if (!has_mirrors) { // only K1 and the interpreted kernel write mirrors
+            int min_w = 1 << 30;
+            for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
+            rc = launch_nv12(L.args, inline_planes, n_inline, min_w, stream, dry_run, info);
+            if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
+            if (rc == 1) { up.done(true); return CVGS_OK; }
+            rc = launch_pointwise(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
+            if (rc < 0) return fail(CVGS_ERR_HIP, "pointwise kernel launch failed");
+            if (rc == 1) { up.done(true); return CVGS_OK; }
+        }
     }
-    rc = launch_generic(L.args, inline_planes, n_inline, stream, dry_run, info);
+    rc = launch_generic(L.args, inline_planes, n_inline, L.mirrors, stream, dry_run, info);
     if (rc) return fail(CVGS_ERR_HIP, "generic kernel launch failed");
+    up.done(true);
+    return CVGS_OK;
+}
+
+// ---- cvgs_execute_many ---------------------------------------------------------------------------------------------
+// Can chains a and b share one K1 launch?  Everything except the sources and the target tensor must agree.
+bool same_shape(const cvgs_chain_desc& a, const cvgs_chain_desc& b) {
+    if (a.flags != b.flags || a.n_ops != b.n_ops) return false;
+    const cvgs_read_desc &ra = a.read, &rb = b.read;
+    if (ra.kind != rb.kind || ra.src_type != rb.src_type || ra.dst_width != rb.dst_width || ra.dst_height != rb.dst_height ||
+        ra.aspect_ratio != rb.aspect_ratio || std::memcmp(ra.background, rb.background, sizeof(ra.background)) != 0)
+        return false;
+    for (int k = 0; k < a.n_ops; ++k) {
+        const cvgs_op &x = a.ops[k], &y = b.ops[k];
+        if (x.opcode != y.opcode || x.aux != y.aux || std::memcmp(x.operand, y.operand, sizeof(x.operand)) != 0) return false;
+    }
+    const cvgs_write_desc &wa = a.write, &wb = b.write;
+    return wa.kind == wb.kind && wa.dst_type == wb.dst_type && wa.width == wb.width && wa.height == wb.height &&
+           wa.n_mirrors == 0 && wb.n_mirrors == 0 &&
+           (wa.kind != CVGS_WRITE_TENSOR_T_SPLIT || wa.planes == wb.planes); // CNHW: the channel stride is the tensor's N
+}
+
+int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
+    // try the fused launch: every chain a K1-shaped resize into a planar tensor, all of one shape
+    bool fusable = n >= 2;
+    for (int i = 0; fusable && i < n; ++i) {
+        const cvgs_chain_desc& c = chains[i];
+        fusable = c.read.kind == CVGS_READ_RESIZE_LINEAR && !(c.flags & CVGS_CHAIN_FORCE_GENERIC) &&
+                  (c.write.kind == CVGS_WRITE_TENSOR_SPLIT || c.write.kind == CVGS_WRITE_TENSOR_T_SPLIT) && same_shape(chains[0], c) &&
+                  ((c.read.flags ^ chains[0].read.flags) & CVGS_READ_FLAG_TABLE_ON_DEVICE) == 0;
+    }
+    if (fusable) {
+        const bool tables = (chains[0].read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
+        ManySeg segs[CVGS_MAX_CHAINS];
+        Upload up;
+        size_t total_planes = 0;
+        int max_batch = 0;
+        for (int i = 0; i < n; ++i) {
+            total_planes += (size_t)(chains[i].read.batch > 0 ? chains[i].read.batch : 0);
+            max_batch = std::max(max_batch, (int)chains[i].read.batch);
+        }
+        Lowered L0; // the shared read / program / write arguments come from chain 0
+        int rc = lower(&chains[0], false, L0);
+        if (rc) return rc;
+        {
+            // would K1 take this shape?  (dry run: nothing is enqueued, nothing uploaded)
+            ChainArgs probe = L0.args;
+            probe.read.table = (const PlaneParams*)(uintptr_t)16;
+            const ManySeg one{probe.read.table, probe.write.data, probe.read.batch, probe.read.used};
+            fusable = launch_k1(probe, nullptr, 0, MirrorArgs{}, &one, 1, stream, true, nullptr) == 1;
+        }
+        if (fusable && !tables) {
+            rc = up.begin(total_planes * sizeof(PlaneParams) + 16 * (size_t)n, stream);
+            if (rc) return rc;
+        }
+        for (int i = 0; fusable && i < n; ++i) {
+            Lowered Li;
+            Lowered& L = i == 0 ? L0 : Li;
+            if (i > 0) rc = lower(&chains[i], false, L);
+            if (rc) return rc; // nothing enqueued yet
+            segs[i].batch = L.args.read.batch;
+            segs[i].used = L.args.read.used;
+            segs[i].out = L.args.write.data;
+            segs[i].table = tables ? L.args.read.table
+                                   : (const PlaneParams*)up.put(L.planes.data(), L.planes.size() * sizeof(PlaneParams));
+        }
+        if (fusable) {
+            if (!tables) {
+                rc = up.flush();
+                if (rc) return rc;
+            }
+            ChainArgs c = L0.args;
+            c.read.batch = max_batch;
+            c.read.table = segs[0].table; // non-null: the table variants
+            rc = launch_k1(c, nullptr, 0, MirrorArgs{}, segs, n, stream, false, nullptr);
+            if (rc != 1) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
+            up.done(true);
+            return CVGS_OK;
+        }
+        // not a K1 chain after all (e.g. an integer-typed program): one by one below; nothing was enqueued
+    }
+    for (int i = 0; i < n; ++i) {
+        Lowered L;
+        int rc = lower(&chains[i], false, L);
+        if (rc) return rc;
+        rc = dispatch(&chains[i], L, stream, false, nullptr);
+        if (rc) return rc;
+    }
     return CVGS_OK;
 }
 
@@ -418,7 +706,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
 extern "C" {
 
 int cvgs_abi_version(void) { return CVGS_ABI_VERSION; }
-const char* cvgs_version_string(void) { return "cvgs-hip 0.1 (gfx950)"; }
+const char* cvgs_version_string(void) { return "cvgs-hip 0.2 (gfx950)"; }
 const char* cvgs_last_error(void) { return g_err.c_str(); }
 
 int cvgs_device_count(void) {
@@ -439,6 +727,31 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream) {
     if (rc) return rc;
     return dispatch(chain, L, (hipStream_t)stream, false, nullptr);
 }
+
+int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stream_t stream) {
+    if (!chains || n_chains < 1) return fail(CVGS_ERR_INVALID, "no chains");
+    if (n_chains > CVGS_MAX_CHAINS) return fail(CVGS_ERR_INVALID, "more than CVGS_MAX_CHAINS chains in one call");
+    return execute_many(chains, n_chains, (hipStream_t)stream);
+}
+
+#ifdef CVGS_WITH_EXPERIMENTS
+// libcvgs_exp.so only (tools/k1_ab.py): run an experimental K1 variant of csrc/k_k1_exp.hip on a headline-shaped chain.
+// The product library is built without this block and without k_k1_exp.hip.
+int cvgs_exp_execute(const cvgs_chain_desc* chain, int32_t variant, cvgs_stream_t stream) {
+    Lowered L;
+    int rc = lower(chain, false, L);
+    if (rc) return rc;
+    const ChainArgs& a = L.args;
+    if (!k1_exp_name(variant) || a.read.kind != CVGS_READ_RESIZE_LINEAR || a.read.depth != CVGS_DEPTH_8U || a.read.cn != 3 ||
+        a.prog.n != 4 || a.write.depth != CVGS_DEPTH_32F || a.write.data2 || L.mirrors.n ||
+        (a.write.kind != CVGS_WRITE_TENSOR_SPLIT && a.write.kind != CVGS_WRITE_TENSOR_T_SPLIT))
+        return fail(CVGS_ERR_UNSUPPORTED, "experimental variants take the headline chain only");
+    if (!a.read.table && L.planes.size() > (size_t)CVGS_KERNARG_PLANES) return fail(CVGS_ERR_UNSUPPORTED, "pass a device plane table");
+    rc = launch_k1_exp(variant, a, L.planes.data(), a.read.table ? 0 : (int)L.planes.size(), stream);
+    return rc < 0 ? fail(CVGS_ERR_HIP, "experimental K1 launch failed") : CVGS_OK;
+}
+const char* cvgs_exp_name(int32_t variant) { return k1_exp_name(variant); }
+#endif
 
 int cvgs_kernel_name(const cvgs_chain_desc* chain, char* buf, size_t buf_size) {
     if (!buf || !buf_size) return fail(CVGS_ERR_INVALID, "null buffer");
@@ -512,8 +825,12 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
     if (!esz || CVGS_TYPE_DEPTH(elem_type) == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "element type");
     if (order != CVGS_NEWEST_FIRST && order != CVGS_OLDEST_FIRST) return fail(CVGS_ERR_INVALID, "bad order");
     if (cp_mode != CVGS_PLANES_STANDARD && cp_mode != CVGS_PLANES_TRANSPOSED) return fail(CVGS_ERR_INVALID, "bad colour-plane mode");
-    hipError_t e = hipSetDevice(device_id);
-    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    DeviceGuard guard; // the caller's current device is left as it was
+    {
+        int rc = guard.enter(device_id);
+        if (rc) return rc;
+    }
+    hipError_t e = hipSuccess;
     cvgs_circular_s* ct = new cvgs_circular_s{};
     ct->width = width; ct->height = height; ct->elem_type = elem_type; ct->color_planes = color_planes;
     ct->batch = batch; ct->order = order; ct->cp_mode = cp_mode; ct->device = device_id;
@@ -564,6 +881,13 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     } else if (out_cn != ct->color_planes || CVGS_MAKETYPE(CVGS_TYPE_DEPTH(one.write.dst_type), 1) != ct->elem_type) {
         return fail(CVGS_ERR_INVALID, "split write does not match the tensor's planes / element type");
     }
+    if (one.write.n_mirrors) return fail(CVGS_ERR_INVALID, "mirrors cannot be combined with a CircularTensor update");
+    // the handle's buffers live on ct->device; the caller's current device may be another one
+    DeviceGuard guard;
+    {
+        int rc = guard.enter(ct->device);
+        if (rc) return rc;
+    }
     if (ct->mirrored) {
         // ONE pass over the new frame, stored at slot p and at slot p+BATCH of a 2*BATCH ring; nothing is shifted.
         // OldestFirst: p = k mod B, window starts at p+1.  NewestFirst: p = B-1 - k mod B, window starts at p.
@@ -574,6 +898,8 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
         one.write.planes = ct->batch;
         int rc = lower(&one, true, L);
         if (rc) return rc;
+        if (L.out_w != ct->width || L.out_h != ct->height)
+            return fail(CVGS_ERR_INVALID, "the frame produced by the read stage differs from the CircularTensor's plane size");
         const int64_t km = ct->count % ct->batch;
         const int64_t p = ct->order == CVGS_NEWEST_FIRST ? ct->batch - 1 - km : km;
         const int64_t plane = (int64_t)ct->width * ct->height;
@@ -599,6 +925,9 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     one.write.planes = ct->batch;
     int rc = lower(&one, true, L);
     if (rc) return rc;
+    // the kernels index with the frame's extent and strides derived from the tensor's: they must be the same
+    if (L.out_w != ct->width || L.out_h != ct->height)
+        return fail(CVGS_ERR_INVALID, "the frame produced by the read stage differs from the CircularTensor's plane size");
     {
         WriteArgs& Wa = L.args.write;
         const int esz = depth_bytes(CVGS_TYPE_DEPTH(one.write.dst_type));
@@ -623,7 +952,9 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     }
     // 2) every OLDER frame: history ring -> its new slot of the ordered tensor.  Slot z shows the frame of age z
     //    (NewestFirst) or BATCH-1-z (OldestFirst); never-written history slots are zero.
-    std::vector<CopyJob> jobs;
+    SmallBuf<CopyJob, kMaxCopyJobs> jobs;
+    if (!jobs.resize((size_t)(ct->batch - 1) * ct->color_planes)) return fail(CVGS_ERR_HIP, "out of host memory");
+    size_t n_jobs = 0;
     for (int z = 0; z < ct->batch; ++z) {
         if (z == z_new) continue;
         const int64_t age = ct->order == CVGS_NEWEST_FIRST ? z : ct->batch - 1 - z;
@@ -634,7 +965,7 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
             j.src = ct->ring + (size_t)src_slot * ct->image_bytes + (size_t)c * ct->plane_bytes;
             j.dst = ct->cp_mode == CVGS_PLANES_TRANSPOSED ? ct->out + ((size_t)c * ct->batch + z) * ct->plane_bytes
                                                           : ct->out + ((size_t)z * ct->color_planes + c) * ct->plane_bytes;
-            jobs.push_back(j);
+            jobs[n_jobs++] = j;
         }
     }
     // Per-pixel u8 pushes (the form the reference tests) take ONE launch: compute + every copy in the same kernel.
@@ -642,17 +973,17 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     // are independent inside the launch.
     static const bool no_fused = getenv("CVGS_NO_FUSED_PUSH") != nullptr; // A/B switch for benchmarks
     bool done = false;
-    if (!no_fused && !jobs.empty() && (int)jobs.size() <= kMaxCopyJobs && !L.uses_64f && L.planes.size() == 1 && !L.args.read.table &&
+    if (!no_fused && n_jobs > 0 && (int)n_jobs <= kMaxCopyJobs && !L.uses_64f && L.planes.size() == 1 && !L.args.read.table &&
         L.dst_planes.empty()) {
-        rc = launch_circular_push(L.args, L.planes[0], jobs.data(), (int)jobs.size(), ct->plane_bytes, one.flags, stream);
+        rc = launch_circular_push(L.args, L.planes[0], jobs.data(), (int)n_jobs, ct->plane_bytes, one.flags, stream);
         if (rc < 0) return fail(CVGS_ERR_HIP, "CircularTensor push launch failed");
         done = rc == 1;
     }
     if (!done) {
         rc = dispatch(&one, L, (hipStream_t)stream, false, nullptr);
         if (rc) return rc;
-        for (size_t at = 0; at < jobs.size(); at += kMaxCopyJobs) {
-            const int n = (int)std::min<size_t>(kMaxCopyJobs, jobs.size() - at);
+        for (size_t at = 0; at < n_jobs; at += kMaxCopyJobs) {
+            const int n = (int)std::min<size_t>(kMaxCopyJobs, n_jobs - at);
             rc = launch_plane_copies(jobs.data() + at, n, ct->plane_bytes, stream);
             if (rc) return fail(CVGS_ERR_HIP, "CircularTensor copy launch failed");
         }
@@ -674,6 +1005,8 @@ int64_t cvgs_circular_updates(cvgs_circular_t ct) { return ct ? ct->count : -1; 
 
 int cvgs_circular_destroy(cvgs_circular_t ct) {
     if (!ct) return fail(CVGS_ERR_INVALID, "null handle");
+    DeviceGuard guard;
+    (void)guard.enter(ct->device);
     if (ct->out) (void)hipFree(ct->out);
     (void)hipFree(ct->ring);
     delete ct;

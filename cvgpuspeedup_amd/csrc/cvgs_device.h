@@ -87,6 +87,28 @@ struct KernArgs<0> {
 };
 static_assert(sizeof(KernArgs<CVGS_KERNARG_PLANES>) <= 4096, "kernel-argument block must fit 4 KB");
 
+// Extra write targets (cvgs_write_desc.mirrors): the same values at the same element offsets in up to 7 more tensors
+// (the peers' copies of the sharded [N,C,H,W] tensor).  Travels as its own kernel argument to the kernels that
+// implement it (K1 planar inside K1Geom, the interpreted kernel).
+struct MirrorArgs {          // 64 bytes
+    uint8_t* p[CVGS_MAX_MIRRORS];
+    int32_t n;
+    int32_t pad;
+};
+
+// cvgs_execute_many: one segment per fused chain.  The K1 kernel's table variants ALWAYS read their planes through a
+// segment (a single chain with a device table is one segment), so fusing chains adds no kernel variant.
+struct ManySeg {             // 24 bytes
+    const PlaneParams* table; // device: PlaneParams[batch] of this chain
+    uint8_t* out;             // this chain's output tensor
+    int32_t batch, used;
+};
+struct KernArgsMany {
+    ChainArgs c;
+    ManySeg seg[CVGS_MAX_CHAINS];
+};
+static_assert(sizeof(KernArgsMany) <= 4096 - 256, "segment block + K1Geom must fit the kernel-argument block");
+
 // CV_64F chains: the double operands travel next to the float ones, with a small inline plane block.
 struct Prog64Args {
     double operand[CVGS_MAX_OPS][4];
@@ -111,13 +133,15 @@ struct LaunchInfo {
 };
 
 // generic interpreted kernel: any valid chain
-int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream,
+int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors, void* stream,
                    bool dry_run, LaunchInfo* info);
 
 // K1 fast path: u8 C3/C4 -> resize linear -> program -> fp32 TensorSplit / TensorTSplit.
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
-int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
-              void* stream, bool dry_run, LaunchInfo* info);
+// `segs` (n_segs >= 1): the chains of a cvgs_execute_many launch (their planes live in device tables; c.read.batch is
+// the largest batch); nullptr: one chain described by c / inline_planes.
+int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors,
+              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info);
 
 // interpreted kernel for chains that touch CV_64F
 int launch_generic64(const ChainArgs& c, const Prog64Args& p64, const PlaneParams* inline_planes, int n_inline, void* stream,
@@ -142,10 +166,6 @@ static constexpr int kInlineWarp = 56; // planes whose WarpPlane travels in the 
 // interpreted warp kernel: `planes` = host array of n (inline when n <= kInlineWarp), else `dev_table` (device copy)
 int launch_warp(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* dev_table, uint32_t chain_flags, void* stream,
                 bool dry_run, LaunchInfo* info);
-
-// experimental K1 variants (k_k1_exp.hip), selected by bits 8..15 of the chain flags; A/B benchmarking only
-int launch_k1_exp(int variant, const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream);
-const char* k1_exp_name(int variant);
 
 // plane-to-plane copies of the CircularTensor update (K9): dst[i] <- src[i], `bytes` each
 struct CopyJob {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,53 @@ int cvgs_allgather_inplace(cvgs_comm_t c, void* full, size_t bytes_per_rank, voi
 
 int cvgs_group_start(void) { return check(ncclGroupStart(), "ncclGroupStart"); }
 int cvgs_group_end(void) { return check(ncclGroupEnd(), "ncclGroupEnd"); }
+
+// ---- P2P fused write: making the peers' tensors addressable ------------------------------------------------------------
+static int hip_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return -3; // CVGS_ERR_HIP
+}
+
+int cvgs_ipc_alloc(void** dev_ptr, size_t bytes) {
+    if (!dev_ptr || !bytes) return fail("bad arguments");
+    int rc = hip_check(hipMalloc(dev_ptr, bytes), "hipMalloc");
+    if (rc) return rc;
+    return hip_check(hipMemset(*dev_ptr, 0, bytes), "hipMemset");
+}
+int cvgs_ipc_free(void* dev_ptr) { return hip_check(hipFree(dev_ptr), "hipFree"); }
+
+int cvgs_ipc_export(const void* dev_ptr, void* handle_out) {
+    static_assert(sizeof(hipIpcMemHandle_t) == CVGS_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    if (!dev_ptr || !handle_out) return fail("bad arguments");
+    return hip_check(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle_out, const_cast<void*>(dev_ptr)), "hipIpcGetMemHandle");
+}
+int cvgs_ipc_open(const void* handle, void** dev_ptr) {
+    if (!handle || !dev_ptr) return fail("bad arguments");
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    return hip_check(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+}
+int cvgs_ipc_close(void* dev_ptr) { return hip_check(hipIpcCloseMemHandle(dev_ptr), "hipIpcCloseMemHandle"); }
+
+int cvgs_peer_can_access(int32_t device, int32_t peer) {
+    int can = 0;
+    int rc = hip_check(hipDeviceCanAccessPeer(&can, device, peer), "hipDeviceCanAccessPeer");
+    return rc ? rc : can;
+}
+int cvgs_peer_enable(int32_t device, int32_t peer) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = hip_check(hipSetDevice(device), "hipSetDevice");
+    if (rc) return rc;
+    hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) {
+        (void)hipGetLastError();
+        e = hipSuccess;
+    }
+    (void)hipSetDevice(prev);
+    return hip_check(e, "hipDeviceEnablePeerAccess");
+}
 
 int cvgs_comm_destroy(cvgs_comm_t c) {
     if (!c) return fail("null communicator");

@@ -20,7 +20,7 @@ __device__ __forceinline__ void read_tap(const ReadArgs& r, const PlaneParams& P
 
 // 64 x 4 threads: a wave is one 64-pixel row segment, so planar stores are 256-byte coalesced.
 template <int NPL>
-__global__ __launch_bounds__(256) void k_generic(const KernArgs<NPL> a) {
+__global__ __launch_bounds__(256) void k_generic(const KernArgs<NPL> a, const MirrorArgs mirrors) {
     const ChainArgs& c = a.c;
     const ReadArgs& r = c.read;
     const int x = blockIdx.x * 64 + threadIdx.x;
@@ -80,10 +80,17 @@ __global__ __launch_bounds__(256) void k_generic(const KernArgs<NPL> a) {
 
     const DstPlane* dst = c.write.table ? c.write.table : c.dst_inline;
     write_px(c.write, dst, x, y, z, p, depth, cn);
+    // cvgs_write_desc.mirrors (tensor kinds): the same value at the same offsets of every further tensor
+    for (int m = 0; m < mirrors.n; ++m) {
+        WriteArgs w = c.write;
+        w.data = mirrors.p[m];
+        w.data2 = nullptr;
+        write_px(w, dst, x, y, z, p, depth, cn);
+    }
 }
 
 template <int NPL>
-static int launch_generic_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, hipStream_t stream) {
+static int launch_generic_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors, hipStream_t stream) {
     KernArgs<NPL> a;
     a.c = c;
     if constexpr (NPL > 0) {
@@ -94,19 +101,19 @@ static int launch_generic_t(const ChainArgs& c, const PlaneParams* inline_planes
     }
     const dim3 block(64, 4, 1);
     const dim3 grid((c.read.dst_w + 63) / 64, (c.read.dst_h + 3) / 4, c.read.batch);
-    hipLaunchKernelGGL(k_generic<NPL>, grid, block, 0, stream, a);
+    hipLaunchKernelGGL(k_generic<NPL>, grid, block, 0, stream, a, mirrors);
     return (int)hipGetLastError();
 }
 
-int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream, bool dry_run,
+int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors, void* stream, bool dry_run,
                    LaunchInfo* info) {
     if (info) info->kernel = c.read.table ? "generic_table" : (n_inline <= 8 ? "generic_inline8" : "generic_inline64");
     if (dry_run) return 0;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (c.read.table) e = (hipError_t)launch_generic_t<0>(c, nullptr, 0, s);
-    else if (n_inline <= 8) e = (hipError_t)launch_generic_t<8>(c, inline_planes, n_inline, s);
-    else e = (hipError_t)launch_generic_t<CVGS_KERNARG_PLANES>(c, inline_planes, n_inline, s);
+    if (c.read.table) e = (hipError_t)launch_generic_t<0>(c, nullptr, 0, mirrors, s);
+    else if (n_inline <= 8) e = (hipError_t)launch_generic_t<8>(c, inline_planes, n_inline, mirrors, s);
+    else e = (hipError_t)launch_generic_t<CVGS_KERNARG_PLANES>(c, inline_planes, n_inline, mirrors, s);
     return e == hipSuccess ? 0 : -(int)e - 1000;
 }
 

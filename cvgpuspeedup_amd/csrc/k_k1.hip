@@ -49,7 +49,16 @@ struct K1Geom {
     // WM_PACKED: bytes between output rows / images (both targets dense or pitched alike); WM_SPLIT2D: plane table
     int64_t row_pitch, img_pitch, row_pitch2, img_pitch2;
     const DstPlane* planes2d;
+    // planar only: further tensors that receive the same values at the same offsets (cvgs_write_desc.mirrors: the
+    // peers' copies of a sharded tensor, written through P2P-mapped pointers)
+    uint8_t* mirror[CVGS_MAX_MIRRORS];
+    int32_t n_mirror;
+    int32_t pad2;
 };
+
+// NPL > 0: the planes travel in the kernel arguments.  NPL == 0: they live in device tables, one segment per fused
+// chain (cvgs_execute_many; a single chain with a resident table is one segment), blockIdx.z = segment.
+template <int NPL> using K1Args = std::conditional_t<NPL == 0, KernArgsMany, KernArgs<NPL>>;
 
 // u8c3 packed pixels of a FULL 64-column tile: the wave's 192 output bytes leave as 48 dword stores instead of 192 byte
 // stores.  Lane j < 48 assembles bytes 4j..4j+3 from the pixels of lanes p0 = 4j/3 and p0+1 (wave shuffles).
@@ -100,20 +109,31 @@ __device__ __forceinline__ void k1_store_other(const K1Geom& g, const ChainArgs&
 }
 
 template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR>
-__global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, const K1Geom g) {
+__global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, const K1Geom g) {
     constexpr int EB = elem_bytes<SRC>;
     constexpr int WINB = SRC == SRC_F32 ? 2 * CN * 4 : 8 * EB; // bytes per tap window (fp32: exactly the pixel pair)
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.y;
     // ---- one batch of scalar loads: geometry, the crop's parameters, the program operands come in together ----
-    const int dst_w = g.dst_w, dst_h = g.dst_h, used = g.used, W = g.out_w;
+    const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
     const uint32_t col_tiles = g.col_tiles;
     const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
-    OT* const out_base = (OT*)g.out;
+    int used;
+    OT* out_base;
     PlaneParams P;
-    if constexpr (NPL == 0) P = c.read.table[z < used ? z : 0];
-    else P = a.planes[z];
+    if constexpr (NPL == 0) {
+        const ManySeg sg = a.seg[blockIdx.z];
+        if (z >= sg.batch) return; // a shorter chain of the fused launch
+        used = sg.used;
+        out_base = (OT*)sg.out;
+        P = sg.table[z < used ? z : 0];
+    } else {
+        used = g.used;
+        out_base = (OT*)g.out;
+        P = a.planes[z];
+    }
     OT* const out2_base = (OT*)g.out2;
+    const int n_mirror = g.n_mirror;
     const int64_t img_stride2 = g.img_stride2, ch_stride2 = g.ch_stride2;
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
     // once; otherwise each early-exit test gets its own load + wait (3-4 serial scalar-memory round trips per wave)
     asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(used), "s"(W), "s"(col_tiles), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.x1),
                  "s"(P.y1), "s"(P.x2), "s"(P.y2), "s"(P.fx), "s"(P.fy), "s"(P.data), "s"(img_stride), "s"(ch_stride),
-                 "s"(out_base), "s"(out2_base), "s"(img_stride2), "s"(ch_stride2), "s"(op0), "s"(op1), "s"(op2), "s"(op3));
+                 "s"(out_base), "s"(out2_base), "s"(img_stride2), "s"(ch_stride2), "s"(op0), "s"(op1), "s"(op2), "s"(op3), "s"(n_mirror));
 
     int col_tile = 0, row_tile = (int)blockIdx.x;
     if (col_tiles > 1) {
@@ -161,6 +181,8 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
                             if (k < bcn) {
                                 st_nt(out + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
                                 if (out2) st_nt(out2 + (int64_t)k * ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
+                                for (int m = 0; m < n_mirror; ++m)
+                                    st_nt((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
                             }
                     } else {
                         k1_store_other<WM, OT, CN, (RPW >= 4)>(g, c, z, y, x, bgp.v, bcn);
@@ -258,6 +280,8 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
                         const float v = take ? p.v[k] : bgp.v[k];
                         st_nt(orow + (int64_t)k * ch_stride + x, v);
                         if (out2) st_nt(out2 + (int64_t)y * W + (int64_t)k * ch_stride2 + x, v);
+                        for (int m = 0; m < n_mirror; ++m) // wave-uniform trip count; peers' tensors share the strides
+                            st_nt((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)y * W + (int64_t)k * ch_stride + x, v);
                     }
             } else {
                 float v[4];
@@ -271,16 +295,35 @@ __global__ __launch_bounds__(256) void k1_resize_split(const KernArgs<NPL> a, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// what launch_k1 hands to the instantiation it picks, without threading two more parameters through every selector
+struct LaunchExtra {
+    MirrorArgs mirrors;
+    const ManySeg* segs;
+    int n_segs;
+};
+static LaunchExtra& tls_extra() {
+    static thread_local LaunchExtra x{};
+    return x;
+}
+
 template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT, int WM = WM_PLANAR>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn,
                            hipStream_t stream) {
-    KernArgs<NPL> a;
+    K1Args<NPL> a;
     a.c = c;
+    unsigned grid_z = 1;
     if constexpr (NPL > 0) {
         for (int i = 0; i < n_inline; ++i) a.planes[i] = inline_planes[i];
         for (int i = n_inline; i < NPL; ++i) a.planes[i] = PlaneParams{};
     } else {
-        a.planes[0] = PlaneParams{};
+        const LaunchExtra& x = tls_extra();
+        if (x.segs) {
+            grid_z = (unsigned)x.n_segs;
+            for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < x.n_segs ? x.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
+        } else {
+            a.seg[0] = ManySeg{c.read.table, c.write.data, c.read.batch, c.read.used};
+            for (int i = 1; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = ManySeg{nullptr, nullptr, 0, 0};
+        }
     }
     K1Geom g;
     const int rows_per_wg = 4 * RPW;
@@ -305,7 +348,13 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     g.row_pitch2 = c.write.width * px_bytes;
     g.img_pitch2 = c.write.img_stride2 * px_bytes;
     g.planes2d = c.write.table;
-    const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch);
+    {
+        const LaunchExtra& x = tls_extra();
+        g.n_mirror = WM == WM_PLANAR ? x.mirrors.n : 0;
+        g.pad2 = 0;
+        for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
+    }
+    const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
     hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM>), grid, dim3(256), 0, stream, a, g);
     return hipGetLastError();
 }
@@ -395,8 +444,8 @@ static int classify_program(const ProgArgs& p, int cn) {
     return 2;
 }
 
-int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags,
-              void* stream, bool dry_run, LaunchInfo* info) {
+int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors,
+              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info) {
     const ReadArgs& r = c_in.read;
     // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write -- or, for 8U sources, an fp16 planar
     // tensor whose conversion is the chain's LAST stage (the half-precision hand-off option)
@@ -410,6 +459,8 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     const bool split2d = wk == CVGS_WRITE_SPLIT_2D;
     if (!planar && !packed && !split2d) return 0;
     if (r.batch > 65535) return 0;
+    if ((mirrors.n > 0 || segs) && (!planar || c_in.write.data2)) return 0; // extra targets / fused chains: planar tensors only
+    if (segs && (!r.table || n_segs < 1 || n_segs > CVGS_MAX_CHAINS)) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
     const bool u8out = c_in.write.depth == CVGS_DEPTH_8U;
     if (!f16 && !u8out && c_in.write.depth != CVGS_DEPTH_32F) return 0;
@@ -422,7 +473,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         --n_prog; // the trailing CAST(CV_16F / CV_8U) happens in the store
     }
     for (int k = 0; k < n_prog; ++k) // value must stay fp32 through the program
-        if (c_in.prog.opcode[k] == CVGS_OP_CAST) return 0;
+        if (c_in.prog.opcode[k] == CVGS_OP_CAST || c_in.prog.opcode[k] == CVGS_OP_CAST_TRUNC) return 0;
     ChainArgs c_cut;
     if (f16 || u8out) {
         c_cut = c_in;
@@ -432,7 +483,12 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
 
     // rows per wave: small launches are latency bound -> maximum parallelism (1 row per wave);
     // large ones amortise the column geometry over more rows (measured: tools/k1_ab.py).
-    const int64_t wave_rows = (int64_t)r.batch * r.dst_h * ((r.dst_w + 63) / 64);
+    int64_t planes_total = r.batch;
+    if (segs) {
+        planes_total = 0;
+        for (int i = 0; i < n_segs; ++i) planes_total += segs[i].batch;
+    }
+    const int64_t wave_rows = planes_total * r.dst_h * ((r.dst_w + 63) / 64);
     int rpw = wave_rows <= 16384 ? 1 : (wave_rows <= 65536 ? 2 : 4);
     static const char* rpw_env = getenv("CVGS_K1_RPW"); // tuning hook (benchmarks only): force 1 / 2 / 4 rows per wave
     if (rpw_env) rpw = atoi(rpw_env) >= 4 ? 4 : (atoi(rpw_env) == 2 ? 2 : 1);
@@ -465,7 +521,10 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
     }
     if (dry_run) return 1;
-    (void)chain_flags;
+    LaunchExtra& extra = tls_extra();
+    extra.mirrors = mirrors;
+    extra.segs = segs;
+    extra.n_segs = n_segs;
 
     hipStream_t s = (hipStream_t)stream;
     const int out_cn = c.write.cn;

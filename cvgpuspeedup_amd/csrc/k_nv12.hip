@@ -24,6 +24,9 @@ struct N12Geom {
     uint8_t* out;
     int32_t out_step; // packed 2D writes: bytes per row
     int32_t packed;   // 0: planar fp32 tensor, 1: packed pixels through the generic write stage
+    // optional second planar target with its own strides (CircularTensor push: history ring + ordered tensor)
+    uint8_t* out2;
+    int64_t img_stride2, ch_stride2;
 };
 
 constexpr int kOpSwapRB12 = 100;
@@ -136,6 +139,12 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow + (int64_t)k * ch_stride + x);
+        if (g.out2) { // wave-uniform
+            OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow2 + (int64_t)k * g.ch_stride2 + x);
+        }
     }
 }
 
@@ -193,6 +202,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     g.dst_w = r.dst_w; g.dst_h = r.dst_h; g.out_w = w.width; g.cn = r.out_cn;
     g.img_stride = w.img_stride; g.ch_stride = w.ch_stride;
     g.out = w.data; g.out_step = w.step; g.packed = packed ? 1 : 0;
+    g.out2 = w.data2; g.img_stride2 = w.img_stride2; g.ch_stride2 = w.ch_stride2;
 
     const int swap = r.out_cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
     const ProgArgs& p = c.prog;

@@ -146,6 +146,12 @@ class WriteIOp:
         self.kind, self.dst_type, self.data = kind, dst_type, data
         self.width, self.height, self.step, self.planes, self.planes2d = width, height, step, planes, planes2d
         self.keep = keep
+        self.mirrors = []  # device pointers of further tensors that receive the same values (cvgs_write_desc.mirrors)
+
+    def mirrored_to(self, pointers):
+        """The P2P exchange of the sharded batched-crop path: the same values also go to these tensors (peers' copies)."""
+        self.mirrors = [int(p) for p in pointers]
+        return self
 
 
 def resize(src_type, interp, mats, dsize, used_planes=None, background=None, ar=IGNORE_AR, fx=0.0, fy=0.0):
@@ -420,6 +426,11 @@ def lower(iops, flags=0):
     w.width, w.height, w.step, w.planes = wr.width, wr.height, wr.step, wr.planes
     if wr.planes2d is not None:
         w.planes2d = C.cast(wr.planes2d, C.c_void_p).value
+    if getattr(wr, "mirrors", None):
+        arr = (C.c_void_p * len(wr.mirrors))(*wr.mirrors)
+        keep.append(arr)
+        w.mirrors = C.cast(arr, C.POINTER(C.c_void_p))
+        w.n_mirrors = len(wr.mirrors)
     return LoweredChain(ch, keep)
 
 
@@ -439,6 +450,24 @@ def executeOperations(stream, *iops, flags=0):
     lowered = lower(iops, flags)
     capi.check(lib.cvgs_execute(C.byref(lowered.desc), stream_handle(stream)))
     return lowered
+
+
+def pack_chains(lowered_chains):
+    """A contiguous cvgs_chain_desc[n] for cvgs_execute_many from LoweredChain objects (which must stay alive)."""
+    arr = (capi.ChainDesc * len(lowered_chains))()
+    for i, lc in enumerate(lowered_chains):
+        C.memmove(C.byref(arr[i]), C.byref(lc.desc), C.sizeof(capi.ChainDesc))
+    return arr
+
+
+def executeMany(stream, chains, flags=0):
+    """cvgs_execute_many: `chains` = list of IOp lists (independent chains: own frames, crop lists, output tensors);
+    same-shape K1 chains run as ONE launch, bit-identical to one executeOperations per chain."""
+    lib = capi.load_library()
+    lowered = [lower(iops, flags) for iops in chains]
+    arr = pack_chains(lowered)
+    capi.check(lib.cvgs_execute_many(arr, len(lowered), stream_handle(stream)))
+    return lowered, arr
 
 
 def executeOperations_io(input_mat, output_mat, stream, *iops, flags=0):

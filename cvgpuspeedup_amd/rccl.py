@@ -17,7 +17,15 @@ SYMBOLS = [
     ("cvgs_group_end", C.c_int, []),
     ("cvgs_comm_destroy", C.c_int, [C.c_void_p]),
     ("cvgs_rccl_last_error", C.c_char_p, []),
+    ("cvgs_ipc_alloc", C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    ("cvgs_ipc_free", C.c_int, [C.c_void_p]),
+    ("cvgs_ipc_export", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("cvgs_ipc_open", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("cvgs_ipc_close", C.c_int, [C.c_void_p]),
+    ("cvgs_peer_enable", C.c_int, [C.c_int32, C.c_int32]),
+    ("cvgs_peer_can_access", C.c_int, [C.c_int32, C.c_int32]),
 ]
+IPC_HANDLE_BYTES = 64
 
 _lib = None
 
@@ -69,3 +77,49 @@ class Communicator:
         if self.handle:
             self.lib.cvgs_comm_destroy(self.handle)
             self.handle = C.c_void_p(0)
+
+
+class DeviceBuffer:
+    """A dedicated device allocation (cvgs_ipc_alloc) that torch can view and peers can map: the sharded tensor of the
+    P2P fused-write exchange.  `tensor(dtype, shape)` wraps it without copying (__cuda_array_interface__)."""
+
+    def __init__(self, nbytes):
+        self.lib = load_library()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p(0)
+        check(self.lib.cvgs_ipc_alloc(C.byref(p), self.nbytes))
+        self.ptr = int(p.value)
+
+    def handle(self):
+        buf = (C.c_uint8 * IPC_HANDLE_BYTES)()
+        check(self.lib.cvgs_ipc_export(C.c_void_p(self.ptr), buf))
+        return bytes(buf)
+
+    def tensor(self, offset_bytes, shape, typestr="<f4", itemsize=4):
+        import torch
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (self.ptr + offset_bytes, False),
+                                      "version": 2}
+        v._owner = self
+        return torch.as_tensor(v, device="cuda")
+
+    def free(self):
+        if self.ptr:
+            self.lib.cvgs_ipc_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+def open_peer(handle_bytes):
+    """Map a peer process's DeviceBuffer: returns its device address in this process."""
+    lib = load_library()
+    buf = (C.c_uint8 * IPC_HANDLE_BYTES).from_buffer_copy(handle_bytes)
+    p = C.c_void_p(0)
+    check(lib.cvgs_ipc_open(buf, C.byref(p)))
+    return int(p.value)
+
+
+def close_peer(ptr):
+    load_library().cvgs_ipc_close(C.c_void_p(ptr))

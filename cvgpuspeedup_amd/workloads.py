@@ -140,3 +140,29 @@ def k1_algorithmic_bytes(crops, dst=DST, cn=3, src_elem=1, tapped_bytes_fn=None,
             read = tapped_bytes(w, h, dst[0], dst[1], cn * src_elem)
         total += write + read + desc_bytes
     return total
+
+
+def _tap_indices(src, n_out):
+    """Sorted distinct source indices tapped along one axis (same rule as _distinct_taps)."""
+    f = np.float32(1.0 / (float(n_out) / float(src)))
+    a = np.floor(np.arange(n_out, dtype=np.float32) * f).astype(np.int64)
+    b = np.minimum(a + 1, src - 1)
+    return np.unique(np.concatenate([a, b]))
+
+
+def k1_sector_read_bytes(crops, frame_w, frame_h, dst=DST, px_bytes=3, sector=64, step=None):
+    """The sector-granular READ bound of one K1 launch: bytes of the distinct `sector`-byte aligned pieces of the frame
+    that hold at least one tapped pixel byte (union over the launch's crops -- overlapping crops share sectors).  HBM
+    and the caches move whole sectors, so no kernel can read less than this; the gap between it and the algorithmic
+    (distinct tapped bytes) figure is physics (sparse 3-byte taps at up to 8x downscale), the gap between it and the
+    measured FETCH_SIZE is the kernel's.  The frame is taken as sector-aligned with dense rows (step = w * px_bytes)."""
+    step = step or frame_w * px_bytes
+    mark = np.zeros((frame_h, (step + sector - 1) // sector), dtype=bool)
+    for (x0, y0, w, h) in crops:
+        cols = _tap_indices(w, dst[0]) + x0
+        rows = _tap_indices(h, dst[1]) + y0
+        first = (cols * px_bytes) // sector
+        last = (cols * px_bytes + px_bytes - 1) // sector
+        secs = np.unique(np.concatenate([first, last]))
+        mark[np.ix_(rows, secs)] = True
+    return int(mark.sum()) * sector

@@ -15,10 +15,12 @@
  * Plain C: pointers, sizes and POD structs only.  Every call is asynchronous on the given HIP
  * stream, never synchronises, and is thread-safe (CircularTensor handles excepted: they carry a
  * ring index, as in the reference, include/cvGPUSpeedup.cuh:600-627).  Device memory is only
- * allocated by cvgs_circular_create and cvgs_comm_*, plus one case inside cvgs_execute: a batch
+ * allocated by cvgs_circular_create and cvgs_comm_*, plus one case inside cvgs_execute(_many): a batch
  * with more host descriptors than fit the 4 KB kernel-argument block (64 planes, 56 for warps,
- * 16 destination planes) gets a stream-ordered scratch table (hipMallocAsync / hipFreeAsync);
+ * 16 destination planes) is staged through a library-owned pool of {pinned host, device} scratch
+ * slots (grown on first use, recycled by HIP event, never freed per call) and copied stream-ordered;
  * that case is refused during stream capture -- pass a resident table (cvgs_plane_table_build).
+ * Up to CVGS_KERNARG_PLANES planes a call allocates nothing, on the host or on the device.
  *
  * Return value: 0 (CVGS_OK) or a negative cvgs_status; cvgs_last_error() gives a thread-local
  * human-readable message.
@@ -33,10 +35,12 @@
 extern "C" {
 #endif
 
-#define CVGS_ABI_VERSION 2
+#define CVGS_ABI_VERSION 3
 #define CVGS_MAX_OPS 12        /* pointwise stages between the read and the write            */
 #define CVGS_MAX_CHANNELS 4
 #define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
+#define CVGS_MAX_MIRRORS 7     /* extra tensors one chain can write (the 7 peers of an 8-GPU node)  */
+#define CVGS_MAX_CHAINS 128    /* chains one cvgs_execute_many launch can fuse                     */
 
 typedef void* cvgs_stream_t; /* hipStream_t (0 = the null stream) */
 
@@ -203,6 +207,15 @@ typedef struct cvgs_write_desc {
     /* SPLIT_2D: host array cvgs_image2d[batch*channels], index z*channels+c.
      * PIXEL_2D_BATCH: host array cvgs_image2d[batch].                                         */
     const cvgs_image2d* planes2d;
+    /* Tensor kinds (TENSOR_SPLIT / TENSOR_T_SPLIT / PIXEL_3D) only: n_mirrors (<= CVGS_MAX_MIRRORS) further device
+     * tensors of the same shape that receive the SAME values at the same element offsets as `data`, in the same kernel
+     * (host array of device pointers; NULL / 0 = none).  This is the exchange step of the sharded batched-crop path
+     * (SURVEY.md 8e option 2, BASELINE cfg #5): rank r's kernel stores its rows of the [N,C,H,W] tensor into its own
+     * copy AND into every peer's copy through P2P-mapped pointers (include/cvgs_rccl.h: cvgs_ipc_* /
+     * cvgs_peer_enable), so no separate all-gather moves the data a second time.  No reference counterpart.        */
+    void* const* mirrors;
+    int32_t n_mirrors;
+    int32_t reserved;
 } cvgs_write_desc;
 
 /* ---- the fused chain = one kernel launch --------------------------------------------------- */
@@ -223,7 +236,7 @@ typedef enum cvgs_chain_flags {
     /* ENABLE_THREAD_FUSION=false of the reference (cvGPUSpeedup.cuh:464): results identical,
      * only disables the multi-pixel-per-thread fast paths                                      */
     CVGS_CHAIN_NO_THREAD_FUSION = 2
-    /* bits 8..15: id of an experimental K1 kernel variant (tools/k1_ab.py A/B runs only; 0 = normal dispatch) */
+    /* every other bit must be zero (CVGS_ERR_INVALID) */
 } cvgs_chain_flags;
 
 /* Library / device ------------------------------------------------------------------------- */
@@ -236,6 +249,19 @@ int cvgs_device_count(void);
 /* Replaces fk::executeOperations<TF>(stream, iops...) (reference include/cvGPUSpeedup.cuh:467,
  * 480,495,513,524,552,566): validates the chain and enqueues exactly one kernel on `stream`.   */
 int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
+
+/* n_chains INDEPENDENT chains -- distinct source frames, crop lists and output tensors -- in as few launches as
+ * possible.  A 50-crop chain moves ~9 MB, about 1 us of HBM time behind a ~1.8 us launch/drain floor;
+ * a serving loop with several cameras amortises that floor by submitting its frames together.  Chains whose read is
+ * a bilinear resize of 8U/16U/16S/32F pixels into a planar fp32 / fp16 tensor (the K1 shape), and that agree in
+ * everything except read.src / batch / used_planes and write.data / planes (same source type, target size,
+ * aspect-ratio mode, background, pointwise stages and operands, write kind and type), are fused into ONE launch of the K1
+ * kernel: grid z = chain, grid y = crop.  Results are bit-identical to n_chains separate cvgs_execute calls (same
+ * kernel code; tests/test_gpu_many.py).  Any other set of chains is executed one by one, in order.  Host descriptors
+ * are staged through a pinned pool and copied stream-ordered (not capturable: pass device plane tables, then the call
+ * is capturable); at most CVGS_MAX_CHAINS chains per call.  The reference's closest spelling is the batch sweep of
+ * tests/batchresize/test_batchresize_x_split3D.cu:384-392 (one launch per BATCH value).                          */
+int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stream_t stream);
 
 /* Validation only (what the reference checks with static_assert / assert / runtime_error).    */
 int cvgs_validate(const cvgs_chain_desc* chain);

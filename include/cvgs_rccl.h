@@ -39,6 +39,25 @@ int cvgs_group_end(void);
 int cvgs_comm_destroy(cvgs_comm_t comm);
 const char* cvgs_rccl_last_error(void);
 
+/* ---- P2P fused write (SURVEY.md 8e option 2) ---------------------------------------------------------------------
+ * Instead of a collective that moves every shard a second time, rank r's K1 launch stores its rows of the
+ * [N,C,H,W] tensor into its own copy AND into every peer's copy (cvgs_write_desc.mirrors, include/cvgs_hip.h); one
+ * small barrier per step replaces the all-gather.  These calls make the peers' tensors addressable:
+ *  - one process per GPU (torch.distributed / MPI hosts): allocate the tensor with cvgs_ipc_alloc (a dedicated
+ *    hipMalloc allocation, so that the handle covers exactly it), cvgs_ipc_export its 64-byte handle, ship the handles
+ *    by any means, cvgs_ipc_open every peer's handle (hipIpcOpenMemHandle, lazy peer access) -> device pointers valid
+ *    in THIS process;
+ *  - one process driving several GPUs (cvgs_comm_init_all hosts): cvgs_peer_enable(device, peer) once per ordered
+ *    pair (hipDeviceEnablePeerAccess); peers' hipMalloc pointers are then directly usable as mirrors.               */
+#define CVGS_IPC_HANDLE_BYTES 64
+int cvgs_ipc_alloc(void** dev_ptr, size_t bytes);            /* hipMalloc on the current device, zero-filled */
+int cvgs_ipc_free(void* dev_ptr);
+int cvgs_ipc_export(const void* dev_ptr, void* handle_out);  /* handle_out: CVGS_IPC_HANDLE_BYTES bytes        */
+int cvgs_ipc_open(const void* handle, void** dev_ptr);       /* maps a PEER process's allocation               */
+int cvgs_ipc_close(void* dev_ptr);
+int cvgs_peer_enable(int32_t device, int32_t peer);          /* 0 also when access was already enabled         */
+int cvgs_peer_can_access(int32_t device, int32_t peer);      /* 1 / 0, or a negative status                    */
+
 #ifdef __cplusplus
 }
 #endif

@@ -532,6 +532,9 @@ int oracle_execute(const cvgs_chain_desc* ch) {
     if (!ch || ch->struct_size != sizeof(cvgs_chain_desc)) return CVGS_ERR_INVALID;
     if (ch->n_ops < 0 || ch->n_ops > CVGS_MAX_OPS) return CVGS_ERR_INVALID;
     if (ch->read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) return CVGS_ERR_UNSUPPORTED;
+    if (ch->write.n_mirrors < 0 || ch->write.n_mirrors > CVGS_MAX_MIRRORS || (ch->write.n_mirrors && !ch->write.mirrors)) return CVGS_ERR_INVALID;
+    if (ch->write.n_mirrors && ch->write.kind != CVGS_WRITE_PIXEL_3D && ch->write.kind != CVGS_WRITE_TENSOR_SPLIT &&
+        ch->write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return CVGS_ERR_INVALID;
     int W, H;
     int rc = chain_extent(ch, &W, &H);
     if (rc) return rc;
@@ -569,6 +572,13 @@ int oracle_execute(const cvgs_chain_desc* ch) {
                 continue;
             }
             write_stage(&ch->write, x, y, z, &p);
+            /* cvgs_write_desc.mirrors: the same value at the same offsets of every further tensor (the peers' copies
+             * of a sharded tensor; include/cvgs_hip.h) */
+            for (int m = 0; m < ch->write.n_mirrors; ++m) {
+                cvgs_write_desc w = ch->write;
+                w.data = ch->write.mirrors[m];
+                write_stage(&w, x, y, z, &p);
+            }
         }
     }
     free(geoms);

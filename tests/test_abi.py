@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), "libcvgs_hip.so does not export %s" % n
         assert n in declared_in_binding, "capi.SYMBOLS lacks %s" % n
-    assert lib.cvgs_abi_version() == 2
+    assert lib.cvgs_abi_version() == 3
     assert b"gfx950" in lib.cvgs_version_string()
 
 
@@ -89,6 +89,51 @@ def test_validation_errors(lib):
     rd = cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)], 1)
     ch = cvgs.lower([rd, cvgs.multiply(cvgs.CV_8UC3, [2, 2, 2]), cvgs.write(cvgs.CV_8UC3, cvgs.GpuMat.from_array(outm, cvgs.CV_8UC3))])
     assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_UNSUPPORTED
+
+
+def _oracle_k1(oracle, frame, crops):
+    ref = np.zeros((len(crops), 3 * 64 * 128), np.float32)
+    oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+    return ref
+
+
+def test_mirrors_oracle_and_validation(oracle, lib):
+    """The oracle interprets the same descriptor field; bad mirror lists are refused."""
+    frame = H.random_u8((240, 320, 3), seed=4)
+    crops = H.random_crops(3, 320, 240, seed=5, wmax=100, hmax=100)
+    a = np.zeros((3, 3 * 64 * 128), np.float32)
+    b = np.zeros_like(a)
+    ops = H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_array(a, cvgs.CV_32FC1))
+    ops[-1].mirrored_to([b.ctypes.data])
+    oracle.execute(cvgs.lower(ops))
+    assert a.any() and (a.view(np.uint32) == b.view(np.uint32)).all()
+    ch = cvgs.lower(ops)
+    ch.desc.write.n_mirrors = 8
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_INVALID
+    ch = cvgs.lower(ops)
+    ch.desc.write.mirrors = None
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_INVALID
+    ch = cvgs.lower(ops)
+    ch.desc.flags = 1 << 8  # experimental-variant bits are no longer part of the boundary
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_INVALID
+
+
+def test_colour_op_channel_indices_are_validated(lib):
+    """ADD_ALPHA / DROP_ALPHA / GRAY aux indices must name channels the value has (REORDER already did)."""
+    frame = np.zeros((8, 8, 3), np.uint8)
+    out1 = np.zeros((8, 8), np.uint8)
+    rd = cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)], 1)
+    ch = cvgs.lower([rd, cvgs.cvtColor(cvgs.COLOR_RGB2GRAY, cvgs.CV_8UC3, cvgs.CV_8UC1),
+                     cvgs.write(cvgs.CV_8UC1, cvgs.GpuMat.from_array(out1, cvgs.CV_8UC1))])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == 0
+    ch.desc.ops[0].aux = 3 | (1 << 2) | (2 << 4)  # R taken from channel 3 of a 3-channel value
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_INVALID
+    out4 = np.zeros((8, 8, 4), np.uint8)
+    ch = cvgs.lower([rd, cvgs.cvtColor(cvgs.COLOR_RGB2RGBA, cvgs.CV_8UC3, cvgs.CV_8UC4),
+                     cvgs.write(cvgs.CV_8UC4, cvgs.GpuMat.from_array(out4, cvgs.CV_8UC4))])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == 0
+    ch.desc.ops[0].aux = 0 | (3 << 2) | (2 << 4)
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_INVALID
 
 
 def test_builder_type_checks():

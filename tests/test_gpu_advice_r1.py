@@ -1,0 +1,160 @@
+"""Regression tests for the round-1 review findings, on the GPU through the C-ABI.
+
+* NV12-resize and warp pushes into a CircularTensor (default and mirrored ring) must reach BOTH write targets: the
+  tensor is compared with the oracle over more than BATCH updates (the K4 fast path used to drop the ring slot).
+* a CircularTensor update whose frame size differs from the tensor's plane size is refused (it used to write out of bounds).
+* resize -> fk::Cast (CAST_TRUNC) -> convertTo chains: the fast kernel must not fold a cast it cannot see through.
+* handles created on the device stay usable when the caller's current device is left alone (single-GPU box: device 0)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _read_device(ptr, nbytes):
+    import torch
+    t = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(nbytes), 3) == 0
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("mirrored", [False, True])
+@pytest.mark.parametrize("order", [cvgs.NewestFirst, cvgs.OldestFirst])
+def test_nv12_resize_push_reaches_ring_and_tensor(oracle, order, mirrored):
+    import torch
+    dev = torch.device("cuda:0")
+    W, H_, B = 64, 36, 4
+    sw, sh = 256, 144
+    ct = cvgs.CircularTensor(cvgs.CV_8UC1, cvgs.CV_32FC1, 3, B, order, cvgs.Standard, W, H_, mirrored=mirrored)
+    oc = oracle.OracleCircular(W, H_, cvgs.CV_32FC1, 3, B, order, cvgs.Standard)
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    pw = [cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3])]
+    for i in range(2 * B + 2):
+        surf = H.random_u8((sh + sh // 2, sw, 1), seed=4000 + i)
+        st = torch.from_numpy(surf).to(dev)
+        g = cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, st.data_ptr(), sw, owner=st)
+        rd = cvgs.read_nv12(g, (W, H_), capi.YUV_FULL, capi.BT709, alpha=False)
+        lowered = ct.update(s, rd, *pw, ct.write_split(f))
+        if i == 0:
+            buf = C.create_string_buffer(128)  # the push must really take the K4 fast path (that is what regressed)
+            probe = cvgs.lower([rd, *pw, cvgs.split_tensor(f, 16, W, H_, 1)])
+            capi.check(ct.lib.cvgs_kernel_name(C.byref(probe.desc), buf, 128))
+            assert buf.value.decode().startswith("k4_nv12_resize"), buf.value
+        h = cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, surf.ctypes.data, sw, owner=surf)
+        oc.update(cvgs.lower([cvgs.read_nv12(h, (W, H_), capi.YUV_FULL, capi.BT709, alpha=False), *pw,
+                              cvgs.WriteIOp(capi.WRITE_TENSOR_SPLIT, f, 16, W, H_, 0, B)]))
+        torch.cuda.synchronize()
+        got = _read_device(ct.data(), ct.nbytes()).view(np.float32)
+        H.assert_bit_exact(got, oc.array(np.float32), "NV12 push %d (mirrored=%s)" % (i, mirrored))
+        del lowered
+    ct.release()
+
+
+@pytest.mark.parametrize("mirrored", [False, True])
+def test_warp_push_reaches_ring_and_tensor(oracle, mirrored):
+    import torch
+    dev = torch.device("cuda:0")
+    W, H_, B = 48, 40, 3
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, B, cvgs.OldestFirst, cvgs.Standard, W, H_, mirrored=mirrored)
+    oc = oracle.OracleCircular(W, H_, cvgs.CV_32FC1, 3, B, cvgs.OldestFirst, cvgs.Standard)
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    m = [[0.9, 0.1, 3.0], [-0.05, 1.1, 2.0]]
+    pw = [cvgs.multiply(f, [0.5] * 3)]
+    for i in range(2 * B + 1):
+        frame = H.random_u8((90, 120, 3), seed=5000 + i)
+        ft = torch.from_numpy(frame).to(dev)
+        ct.update(s, cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), m, (W, H_)), *pw, ct.write_split(f))
+        oc.update(cvgs.lower([cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), m, (W, H_)), *pw,
+                              cvgs.WriteIOp(capi.WRITE_TENSOR_SPLIT, f, 16, W, H_, 0, B)]))
+        torch.cuda.synchronize()
+        got = _read_device(ct.data(), ct.nbytes()).view(np.float32)
+        H.assert_bit_exact(got, oc.array(np.float32), "warp push %d (mirrored=%s)" % (i, mirrored))
+    ct.release()
+
+
+@pytest.mark.parametrize("mirrored", [False, True])
+def test_circular_update_refuses_a_frame_of_another_size(mirrored):
+    import torch
+    dev = torch.device("cuda:0")
+    W, H_, B = 32, 24, 3
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard, W, H_, mirrored=mirrored)
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    for (fw, fh) in ((W + 8, H_), (W, H_ + 2), (W // 2, H_ // 2)):
+        frame = torch.zeros((fh, fw, 3), dtype=torch.uint8, device=dev)
+        with pytest.raises(capi.CvgsError) as e:  # per-pixel read: the frame IS the plane
+            ct.update(s, cvgs.GpuMat.from_tensor(frame, cvgs.CV_8UC3), cvgs.convertTo(cvgs.CV_8UC3, f), ct.write_split(f))
+        assert e.value.code == capi.ERR_INVALID
+        big = torch.zeros((100, 100, 3), dtype=torch.uint8, device=dev)
+        with pytest.raises(capi.CvgsError) as e:  # resize to a size that is not the tensor's
+            ct.update(s, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, cvgs.GpuMat.from_tensor(big, cvgs.CV_8UC3), (fw, fh)),
+                      ct.write_split(f))
+        assert e.value.code == capi.ERR_INVALID
+    assert ct.updates() == 0
+    torch.cuda.synchronize()
+    assert not _read_device(ct.data(), ct.nbytes()).any()
+    ct.release()
+
+
+@pytest.mark.parametrize("final", [cvgs.CV_8U, cvgs.CV_16F])
+def test_resize_trunc_cast_then_convert_matches_generic_and_oracle(oracle, final):
+    """resize -> fk::Cast<float3,int3> -> convertTo<int3, uchar3 | half3>: after the CAST_TRUNC the value is an integer
+    (raw bits), so K1 must not fold the trailing cast into its store."""
+    import torch
+    dev = torch.device("cuda:0")
+    frame = H.random_u8((300, 400, 3), seed=77)
+    ft = torch.from_numpy(frame).to(dev)
+    dst = (80, 60)
+    f, i32, o = cvgs.CV_32FC3, cvgs.CV_32SC3, cvgs.make_type(final, 3)
+    np_dt = np.uint8 if final == cvgs.CV_8U else np.float16
+    t_dt = torch.uint8 if final == cvgs.CV_8U else torch.float16
+
+    def chain(src, out):
+        return [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, src, dst), cvgs.cast(f, i32), cvgs.convertTo(i32, o), cvgs.write(o, out)]
+
+    outs = {}
+    for flags in (0, capi.CHAIN_FORCE_GENERIC):
+        ot = torch.zeros((dst[1], dst[0], 3), dtype=t_dt, device=dev)
+        cvgs.executeOperations(torch.cuda.current_stream(), *chain(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), cvgs.GpuMat.from_tensor(ot, o)), flags=flags)
+        torch.cuda.synchronize()
+        outs[flags] = ot.cpu().numpy()
+    ref = np.zeros((dst[1], dst[0], 3), np_dt)
+    oracle.execute(cvgs.lower(chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), cvgs.GpuMat.from_array(ref, o))))
+    assert ref.any()
+    H.assert_bit_exact(outs[capi.CHAIN_FORCE_GENERIC], ref, "generic vs oracle")
+    H.assert_bit_exact(outs[0], ref, "dispatcher's kernel vs oracle")
+
+
+def test_large_batches_recycle_the_descriptor_scratch(oracle, device):
+    """> 64 planes: descriptors go through the pooled {pinned, device} scratch; many back-to-back launches on two streams
+    with DIFFERENT crop lists must each see their own table (a slot may only be recycled after its kernel)."""
+    import torch
+    frame = H.random_u8((720, 1280, 3), seed=31)
+    ft = torch.from_numpy(frame).to(device)
+    g_src = cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    n = 70
+    jobs = []
+    for k in range(12):
+        crops = H.random_crops(n, 1280, 720, seed=900 + k)
+        out = torch.zeros((n, 3 * 64 * 128), dtype=torch.float32, device=device)
+        jobs.append((crops, out))
+    torch.cuda.synchronize()
+    keep = []
+    for k, (crops, out) in enumerate(jobs):
+        st = streams[k % 2]
+        with torch.cuda.stream(st):
+            keep.append(cvgs.executeOperations(st, *H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1))))
+    torch.cuda.synchronize()
+    for k, (crops, out) in enumerate(jobs):
+        ref = np.zeros((n, 3 * 64 * 128), np.float32)
+        oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+        H.assert_bit_exact(out.cpu().numpy(), ref, "job %d" % k)

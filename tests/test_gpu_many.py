@@ -1,0 +1,164 @@
+"""cvgs_execute_many and cvgs_write_desc.mirrors on the GPU, bit-exact against the oracle AND against one
+cvgs_execute per chain.
+
+execute_many: M independent 50-crop chains (distinct frames, crop lists, output tensors) fused into ONE K1 launch
+(grid z = chain) -- the launch-batching answer to the 50-crop latency floor; the reference's closest spelling is the
+batch sweep of tests/batchresize/test_batchresize_x_split3D.cu:384-392.
+mirrors: the exchange step of the sharded batched-crop path (SURVEY.md 8e option 2): the kernel stores its rows into
+its own tensor and into every "peer" tensor; here the peers are further tensors on the same device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(dev, n_chains, crops_per, frame_hw=(1080, 1920), table=False, seed=100, ragged=False, half=False, **kw):
+    import torch
+    fh, fw = frame_hw
+    chains, outs, refs_in, keep = [], [], [], []
+    for m in range(n_chains):
+        n = crops_per if not ragged else max(1, crops_per - 7 * m)
+        frame = H.random_u8((fh, fw, 3), seed=seed + m)
+        crops = H.random_crops(n, fw, fh, seed=seed + 50 + m)
+        ft = torch.from_numpy(frame).to(dev)
+        ot = torch.full((n, 3 * 64 * 128), -777.0, dtype=torch.float16 if half else torch.float32, device=dev)
+        g_src = cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3)
+        g_out = cvgs.GpuMat.from_tensor(ot, cvgs.CV_16FC1 if half else cvgs.CV_32FC1)
+        ops = H.k1_chain(g_src, crops, g_out, half=half, **kw)
+        if table:
+            tab = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
+            keep.append(tab)
+            ops = H.k1_chain(g_src, crops, g_out, table=tab.data_ptr(), half=half, **kw)
+        chains.append(ops)
+        outs.append(ot)
+        refs_in.append((frame, crops))
+        keep.append(ft)
+    return chains, outs, refs_in, keep
+
+
+def _oracle(oracle, frame, crops, half=False, **kw):
+    ref = np.full((len(crops), 3 * 64 * 128), -777.0, dtype=np.float16 if half else np.float32)
+    oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops,
+                                         cvgs.GpuMat.from_array(ref, cvgs.CV_16FC1 if half else cvgs.CV_32FC1), half=half, **kw)))
+    return ref
+
+
+@pytest.mark.parametrize("n_chains,crops_per,table,ragged", [(2, 50, False, False), (4, 50, False, True), (16, 50, False, False),
+                                                              (3, 100, False, False), (4, 30, True, True), (64, 6, False, False)])
+def test_execute_many_matches_separate_and_oracle(oracle, device, n_chains, crops_per, table, ragged):
+    import torch
+    chains, outs, refs_in, keep = _make(device, n_chains, crops_per, table=table, ragged=ragged)
+    lowered, arr = cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    many = [o.cpu().numpy() for o in outs]
+    for o in outs:
+        o.fill_(-777.0)
+    for ops in chains:
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    for m, (frame, crops) in enumerate(refs_in):
+        H.assert_bit_exact(many[m], outs[m].cpu().numpy(), "execute_many vs separate launches, chain %d" % m)
+        H.assert_bit_exact(many[m], _oracle(oracle, frame, crops), "execute_many vs oracle, chain %d" % m)
+
+
+def test_execute_many_fp16_and_aspect_ratio(oracle, device):
+    import torch
+    for kw in ({"half": True}, {"ar": cvgs.PRESERVE_AR, "background": [128.0, 128.0, 128.0, 0.0]}, {"used": 3}):
+        chains, outs, refs_in, keep = _make(device, 5, 9, seed=300, **kw)
+        cvgs.executeMany(torch.cuda.current_stream(), chains)
+        torch.cuda.synchronize()
+        for m, (frame, crops) in enumerate(refs_in):
+            H.assert_bit_exact(outs[m].cpu().numpy(), _oracle(oracle, frame, crops, **kw), "execute_many %r chain %d" % (kw, m))
+
+
+def test_execute_many_is_one_launch_and_capturable_with_tables(device, lib):
+    """With device plane tables the fused launch allocates and copies nothing: it can be captured into a HIP graph."""
+    import torch
+    chains, outs, refs_in, keep = _make(device, 8, 50, table=True, seed=500)
+    lowered = [cvgs.lower(ops) for ops in chains]
+    arr = cvgs.pack_chains(lowered)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        capi.check(lib.cvgs_execute_many(arr, len(lowered), side.cuda_stream))
+        torch.cuda.synchronize()
+        want = [o.cpu().numpy() for o in outs]
+        for o in outs:
+            o.fill_(0.0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            capi.check(lib.cvgs_execute_many(arr, len(lowered), torch.cuda.current_stream().cuda_stream))
+        g.replay()
+        torch.cuda.synchronize()
+    for m in range(len(outs)):
+        H.assert_bit_exact(outs[m].cpu().numpy(), want[m], "captured execute_many, chain %d" % m)
+    # host descriptors need an upload: refused under capture, loudly
+    chains2, outs2, _, keep2 = _make(device, 2, 50, seed=600)
+    low2 = [cvgs.lower(ops) for ops in chains2]
+    arr2 = cvgs.pack_chains(low2)
+    with torch.cuda.stream(side):
+        g2 = torch.cuda.CUDAGraph()
+        rc = 0
+        with torch.cuda.graph(g2):
+            rc = lib.cvgs_execute_many(arr2, 2, torch.cuda.current_stream().cuda_stream)
+        assert rc == capi.ERR_UNSUPPORTED, lib.cvgs_last_error()
+
+
+def test_execute_many_mixed_shapes_falls_back_to_one_by_one(oracle, device):
+    """Chains that do not share a K1 shape (different target sizes / programs) are executed one by one, same results."""
+    import torch
+    frame = H.random_u8((480, 640, 3), seed=9)
+    ft = torch.from_numpy(frame).to(device)
+    crops = H.random_crops(6, 640, 480, seed=3, wmax=200, hmax=300)
+    o1 = torch.zeros((6, 3 * 64 * 128), dtype=torch.float32, device=device)
+    o2 = torch.zeros((6, 3 * 32 * 32), dtype=torch.float32, device=device)
+    g_src = cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3)
+    c1 = H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(o1, cvgs.CV_32FC1))
+    c2 = H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(o2, cvgs.CV_32FC1), dst=(32, 32), swap=False)
+    cvgs.executeMany(torch.cuda.current_stream(), [c1, c2])
+    torch.cuda.synchronize()
+    H.assert_bit_exact(o1.cpu().numpy(), _oracle(oracle, frame, crops), "mixed many, chain 0")
+    ref2 = np.zeros((6, 3 * 32 * 32), np.float32)
+    oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops,
+                                         cvgs.GpuMat.from_array(ref2, cvgs.CV_32FC1), dst=(32, 32), swap=False)))
+    H.assert_bit_exact(o2.cpu().numpy(), ref2, "mixed many, chain 1")
+
+
+def test_execute_many_rejects_bad_input(lib, device):
+    assert lib.cvgs_execute_many(None, 1, None) == capi.ERR_INVALID
+    chains, outs, _, keep = _make(device, 2, 4, seed=700)
+    low = [cvgs.lower(ops) for ops in chains]
+    arr = cvgs.pack_chains(low)
+    assert lib.cvgs_execute_many(arr, 0, None) == capi.ERR_INVALID
+    assert lib.cvgs_execute_many(arr, capi.MAX_CHAINS + 1, None) == capi.ERR_INVALID
+    arr[1].read.batch = 0  # a malformed member: nothing may be enqueued, error reported
+    assert lib.cvgs_execute_many(arr, 2, None) == capi.ERR_INVALID
+
+
+# ---- mirrors ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_mirrors,flags", [(1, 0), (3, 0), (7, 0), (2, capi.CHAIN_FORCE_GENERIC)])
+def test_mirrors_receive_the_same_rows(oracle, device, n_mirrors, flags):
+    """Rank r's K1 writes rows [r*n, (r+1)*n) of ITS copy of the [G*n, C*H*W] tensor and of every peer's copy: here the
+    peers are further tensors on the same device; every copy must hold the oracle's rows, and nothing else is touched."""
+    import torch
+    n, world, rank = 10, 3, 1
+    frame = H.random_u8((720, 1280, 3), seed=21)
+    crops = H.random_crops(n, 1280, 720, seed=22)
+    ft = torch.from_numpy(frame).to(device)
+    tensors = [torch.full((world * n, 3 * 64 * 128), -5.0, dtype=torch.float32, device=device) for _ in range(1 + n_mirrors)]
+    mine = tensors[0][rank * n:(rank + 1) * n]
+    ops = H.k1_chain(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_tensor(mine, cvgs.CV_32FC1))
+    ops[-1].mirrored_to([t[rank * n:(rank + 1) * n].data_ptr() for t in tensors[1:]])
+    name = cvgs.kernel_name(*ops, flags=flags)
+    assert name.startswith("generic" if flags else "k1_u8c3"), name
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=flags)
+    torch.cuda.synchronize()
+    ref = _oracle(oracle, frame, crops)
+    for i, t in enumerate(tensors):
+        got = t.cpu().numpy()
+        H.assert_bit_exact(got[rank * n:(rank + 1) * n], ref, "mirror %d" % i)
+        assert (got[:rank * n] == -5.0).all() and (got[(rank + 1) * n:] == -5.0).all(), "mirror %d: rows of other ranks touched" % i

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Within-process interleaved A/B of K1 kernel variants (cvgpuspeedup_amd/csrc/k_k1_exp.hip).
 
+The experimental variants are NOT part of the product library: they live in cvgpuspeedup_amd/lib/libcvgs_exp.so (the
+product objects + k_k1_exp.hip behind one extra entry point, cvgs_exp_execute), which only this tool loads.
+
   python tools/k1_ab.py --crops 50 --variants 0,1,2,8 --rounds 7 [--table]
 
 variant 0 = the production dispatch; others = experimental ids.  Reports the median / min HIP-event time per launch
@@ -15,8 +18,39 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+import ctypes as C  # noqa: E402
+
 import bench  # noqa: E402
+from cvgpuspeedup_amd import capi  # noqa: E402
 from cvgpuspeedup_amd import workloads as W  # noqa: E402
+
+
+def load_exp():
+    lib = C.CDLL(os.path.join(ROOT, "cvgpuspeedup_amd", "lib", "libcvgs_exp.so"))
+    lib.cvgs_exp_execute.restype = C.c_int
+    lib.cvgs_exp_execute.argtypes = [C.POINTER(capi.ChainDesc), C.c_int32, C.c_void_p]
+    lib.cvgs_exp_name.restype = C.c_char_p
+    lib.cvgs_exp_name.argtypes = [C.c_int32]
+    lib.cvgs_last_error.restype = C.c_char_p
+    return lib
+
+
+class ExpWorkload(bench.Workload):
+    """The headline workload launched through an experimental variant (variant 0 = the product dispatch)."""
+
+    def __init__(self, exp, variant, *a, **kw):
+        super().__init__(*a, **kw)
+        self.exp, self.variant = exp, variant
+        if variant:
+            self.kernel = (exp.cvgs_exp_name(variant) or b"?").decode()
+
+    def launch(self, i, stream):
+        if not self.variant:
+            return super().launch(i, stream)
+        ch = self.chains[i % len(self.chains)]
+        rc = self.exp.cvgs_exp_execute(C.byref(ch.desc), self.variant, stream)
+        if rc:
+            raise RuntimeError("cvgs_exp_execute: %d %s" % (rc, self.exp.cvgs_last_error().decode()))
 
 
 def main():
@@ -36,13 +70,13 @@ def main():
     nf = a.frames or max(4, min(24, (2 * bench.INFINITY_CACHE) // per_frame + 1))
     steps = max(16, a.steps * 50 // a.crops) if a.crops > 50 else a.steps
     torch.cuda.set_stream(torch.cuda.Stream())
-    wls, plans, base = {}, {}, None
+    wls, base = {}, None
+    exp = load_exp()
     for v in variants:
-        wl = bench.Workload(dev, nf, a.crops, 0, 1, a.table, flags=v << 8, share=base)
+        wl = ExpWorkload(exp, v, dev, nf, a.crops, 0, 1, a.table, share=base)
         base = base or wl
         wls[v] = wl
-        plans[v] = None if a.eager else bench.make_graphs(wl, steps)
-    alg = bench.algorithmic_bytes(base)
+    alg = base.algorithmic_bytes()
     # correctness: each variant's frame-0 output vs variant 0
     ref = None
     for v in variants:
@@ -57,9 +91,10 @@ def main():
     times = {v: [] for v in variants}
     for r in range(a.rounds + 1):
         for v in variants:
-            _, dev_s = bench.timed(lambda: bench.run_steps(wls[v], steps, a.eager, plans[v]), lambda: None)
+            m = bench.measure(wls[v], min(steps, 256), 8, eager=a.eager, target_s=0.05, min_replays=10,
+                              est_step_s=5e-6 * max(1.0, a.crops / 100.0))
             if r > 0:
-                times[v].append(dev_s / steps * 1e6)
+                times[v].append(m["step_s"] * 1e6)
     print("crops/launch %d, %d frames, %d steps/round, %d rounds, alg bytes/launch %.0f, %s" % (
         a.crops, nf, steps, a.rounds, alg, "table" if a.table else "kernarg"))
     for v in variants:

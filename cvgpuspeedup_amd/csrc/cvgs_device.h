@@ -47,6 +47,11 @@ struct ProgArgs {
     int32_t opcode[CVGS_MAX_OPS];
     int32_t aux[CVGS_MAX_OPS];
     float operand[CVGS_MAX_OPS][4];
+    // K1's compile-time programs only (set by launch_k1, 0 elsewhere): the DIV stage's divisors are wave-uniform, so
+    // their correctly rounded reciprocals are computed ONCE on the host (rdiv[c] = 1.0f / operand[c], IEEE) and the
+    // kernel divides with two FMA correction steps (k_taps.hpp: div_by_uniform) -- same bits as the IEEE division.
+    int32_t fast_div;
+    float rdiv[4];
 };
 
 struct WriteArgs {

@@ -22,7 +22,9 @@
 //    by this kernel, so it should not wait in L2 for the end-of-kernel write-back.
 //  * small launches use 1 row per wave (maximum parallelism, shortest critical path), large ones 4 (amortises the
 //    column geometry).
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <type_traits>
 
@@ -108,7 +110,18 @@ __device__ __forceinline__ void k1_store_other(const K1Geom& g, const ChainArgs&
     }
 }
 
-template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR>
+// one planar element: the row pointer is wave-uniform and pinned in SGPRs, the lane adds its 32-bit byte offset
+template <typename OT>
+__device__ __forceinline__ void st_row(OT* row_uniform, uint32_t x_bytes, float v) {
+    typedef __attribute__((address_space(1))) char* gchar;
+    typedef __attribute__((address_space(1))) OT* got;
+    const gchar r = (gchar)(got)pin_uniform(row_uniform);
+    if constexpr (std::is_same_v<OT, float>) __builtin_nontemporal_store(v, (got)(r + x_bytes));
+    else __builtin_nontemporal_store((OT)v, (got)(r + x_bytes));
+}
+
+// MIR: the instantiations that also write cvgs_write_desc.mirrors (kept out of the others' code)
+template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR, bool MIR = false>
 __global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, const K1Geom g) {
     constexpr int EB = elem_bytes<SRC>;
     constexpr int WINB = SRC == SRC_F32 ? 2 * CN * 4 : 8 * EB; // bytes per tap window (fp32: exactly the pixel pair)
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, cons
         P = a.planes[z];
     }
     OT* const out2_base = (OT*)g.out2;
-    const int n_mirror = g.n_mirror;
+    const int n_mirror = MIR ? g.n_mirror : 0;
     const int64_t img_stride2 = g.img_stride2, ch_stride2 = g.ch_stride2;
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
@@ -181,8 +194,9 @@ __global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, cons
                             if (k < bcn) {
                                 st_nt(out + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
                                 if (out2) st_nt(out2 + (int64_t)k * ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
-                                for (int m = 0; m < n_mirror; ++m)
-                                    st_nt((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
+                                if constexpr (MIR)
+                                    for (int m = 0; m < n_mirror; ++m)
+                                        st_nt((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
                             }
                     } else {
                         k1_store_other<WM, OT, CN, (RPW >= 4)>(g, c, z, y, x, bgp.v, bcn);
@@ -223,8 +237,8 @@ __global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, cons
         const int y2r = min(y2, P.h - 1);
         wya[j] = (float)y2 - sy;
         wyb[j] = sy - (float)y1;
-        const gptr_u8 ra = src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step;
-        const gptr_u8 rb = src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step;
+        const gptr_u8 ra = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step);
+        const gptr_u8 rb = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step);
         if constexpr (SRC == SRC_F32) {
             if (!tiny) {
                 va[j] = load_win_f32<CN>(ra + ol);
@@ -274,14 +288,21 @@ __global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, cons
             const bool take = whole || (in_x && in_y[j]);
             if constexpr (WM == WM_PLANAR) {
                 OT* const orow = out + (int64_t)y * W; // wave-uniform
+                const uint32_t xb = (uint32_t)x * (uint32_t)sizeof(OT);
+                if (!whole) { // wave-uniform: only aspect-ratio padded planes pay the per-lane select
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < cn) p.v[k] = take ? p.v[k] : bgp.v[k];
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < cn) {
-                        const float v = take ? p.v[k] : bgp.v[k];
-                        st_nt(orow + (int64_t)k * ch_stride + x, v);
-                        if (out2) st_nt(out2 + (int64_t)y * W + (int64_t)k * ch_stride2 + x, v);
-                        for (int m = 0; m < n_mirror; ++m) // wave-uniform trip count; peers' tensors share the strides
-                            st_nt((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)y * W + (int64_t)k * ch_stride + x, v);
+                        const float v = p.v[k];
+                        st_row(orow + (int64_t)k * ch_stride, xb, v);
+                        if (out2) st_row(out2 + (int64_t)y * W + (int64_t)k * ch_stride2, xb, v);
+                        if constexpr (MIR)
+                            for (int m = 0; m < n_mirror; ++m) // wave-uniform trip count; peers' tensors share the strides
+                                st_row((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)y * W + (int64_t)k * ch_stride, xb, v);
                     }
             } else {
                 float v[4];
@@ -306,7 +327,7 @@ static LaunchExtra& tls_extra() {
     return x;
 }
 
-template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT, int WM = WM_PLANAR>
+template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT, int WM = WM_PLANAR, bool MIR = false>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn,
                            hipStream_t stream) {
     K1Args<NPL> a;
@@ -350,12 +371,12 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     g.planes2d = c.write.table;
     {
         const LaunchExtra& x = tls_extra();
-        g.n_mirror = WM == WM_PLANAR ? x.mirrors.n : 0;
+        g.n_mirror = MIR ? x.mirrors.n : 0;
         g.pad2 = 0;
         for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
     }
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
-    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM>), grid, dim3(256), 0, stream, a, g);
+    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(256), 0, stream, a, g);
     return hipGetLastError();
 }
 
@@ -433,6 +454,36 @@ static hipError_t launch_few(int src, bool planar, bool u8out, int prog_id, bool
     return launch_other<CN, float, WM_PACKED>(table, rpw, c, ip, ni, s);
 }
 
+// Can the DIV stage of a [swap] MUL SUB DIV program use div_by_uniform (k_taps.hpp)?  Integer-valued sources only: the
+// interpolated value is finite and bounded by the source depth's range, so bounds on the operands bound the dividend
+// x = v * mul - sub: |x| <= 65535 * 2^20 + 2^20 < 2^37, and a non-zero x is never smaller than 2^-70 (a product of two
+// weights >= 2^-46 times |mul| >= 2^-20, or a difference of two floats one of which is >= 2^-20: >= 2^-44), so every
+// intermediate of the FMA corrections is a normal number and the residuals are exact.  A divisor whose significand is
+// all ones is left to the real division (the one case where RN(1/d) is not good enough for Markstein's theorem), and so
+// is a background value outside [2^-20, 2^20] (it is pushed through the same program).
+static void k1_fast_div_setup(ProgArgs& p, int div_at, int mul_at, int cn, const float* bg) {
+    static const char* off = getenv("CVGS_K1_FASTDIV"); // tuning / test hook: CVGS_K1_FASTDIV=0 keeps the IEEE division
+    if (off && off[0] == '0') return;
+    auto in_range = [](float v, int lo_exp, int hi_exp) {
+        const float a = std::fabs(v);
+        return std::isfinite(v) && a >= std::ldexp(1.0f, lo_exp) && a <= std::ldexp(1.0f, hi_exp);
+    };
+    for (int c = 0; c < cn; ++c) {
+        const float mul = p.operand[mul_at][c], sub = p.operand[mul_at + 1][c], d = p.operand[div_at][c];
+        if (!in_range(mul, -20, 20) || !(sub == 0.0f || in_range(sub, -20, 20)) || !in_range(d, -40, 40)) return;
+        // the background value (aspect-ratio padding, unused planes) runs through the same program
+        if (!(bg[c] == 0.0f || in_range(bg[c], -20, 20))) return;
+        uint32_t bits;
+        std::memcpy(&bits, &d, 4);
+        if ((bits & 0x7fffffu) == 0x7fffffu) return;
+    }
+    for (int c = 0; c < cn; ++c) {
+        volatile float r = 1.0f / p.operand[div_at][c]; // IEEE single division on the host: the correctly rounded reciprocal
+        p.rdiv[c] = r;
+    }
+    p.fast_div = 1;
+}
+
 // program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
 static int classify_program(const ProgArgs& p, int cn) {
     if (cn < 3) return (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) ? 1 : 2;
@@ -460,6 +511,9 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if (!planar && !packed && !split2d) return 0;
     if (r.batch > 65535) return 0;
     if ((mirrors.n > 0 || segs) && (!planar || c_in.write.data2)) return 0; // extra targets / fused chains: planar tensors only
+    // mirrors: u8 C3/C4 -> fp32 planar with the planes in the kernel arguments (cfg #5: 64 crops per GPU); the rest is
+    // the interpreted kernel's business
+    if (mirrors.n > 0 && (r.depth != CVGS_DEPTH_8U || r.cn < 3 || r.table || segs || c_in.write.depth != CVGS_DEPTH_32F)) return 0;
     if (segs && (!r.table || n_segs < 1 || n_segs > CVGS_MAX_CHAINS)) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
     const bool u8out = c_in.write.depth == CVGS_DEPTH_8U;
@@ -474,12 +528,11 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     }
     for (int k = 0; k < n_prog; ++k) // value must stay fp32 through the program
         if (c_in.prog.opcode[k] == CVGS_OP_CAST || c_in.prog.opcode[k] == CVGS_OP_CAST_TRUNC) return 0;
-    ChainArgs c_cut;
-    if (f16 || u8out) {
-        c_cut = c_in;
-        c_cut.prog.n = n_prog;
-    }
-    const ChainArgs& c = (f16 || u8out) ? c_cut : c_in;
+    ChainArgs c_mut = c_in;
+    c_mut.prog.n = n_prog;
+    c_mut.prog.fast_div = 0;
+    for (int k = 0; k < 4; ++k) c_mut.prog.rdiv[k] = 0.f;
+    const ChainArgs& c = c_mut;
 
     // rows per wave: small launches are latency bound -> maximum parallelism (1 row per wave);
     // large ones amortise the column geometry over more rows (measured: tools/k1_ab.py).
@@ -495,6 +548,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
 
     const bool table = r.table != nullptr;
     const int prog_id = classify_program(c.prog, r.cn);
+    if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) k1_fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
     if (info) {
@@ -529,7 +583,15 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     hipStream_t s = (hipStream_t)stream;
     const int out_cn = c.write.cn;
     hipError_t e;
-    if (few) {
+    if (mirrors.n > 0) {
+        // one row per wave (a 64-crop launch is in the latency regime), planes in the kernel arguments
+        auto mir = [&](auto prog_tag) {
+            using Pg = decltype(prog_tag);
+            return r.cn == 3 ? launch_t<3, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s)
+                             : launch_t<4, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
+        };
+        e = prog_id == 0 ? mir(ProgSwapMulSubDiv{}) : (prog_id == 1 ? mir(ProgMulSubDiv{}) : mir(InterpProg{}));
+    } else if (few) {
         e = r.cn == 1 ? launch_few<1>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s)
                       : launch_few<2>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s);
     } else if (!planar) {

@@ -13,6 +13,24 @@ namespace cvgs {
 // permutation is the RGB<->BGR swap (aux 2,1,0[,3]) resolved at compile time instead of per-pixel selects.
 constexpr int kOpSwapRB = 100;
 
+// x / d for a wave-uniform divisor d whose correctly rounded reciprocal r = RN(1/d) came with the kernel arguments:
+//   q0 = RN(x r);  e0 = RN(x - d q0);  q1 = RN(q0 + e0 r);  e1 = x - d q1 (exact);  q = RN(q1 + e1 r) = RN(x / d).
+// q1 is within half an ulp (+ 2^-45 relative) of x/d, so e1 is exactly representable and the last step is Markstein's
+// correction (P. Markstein, "Computation of elementary functions on the IBM RISC System/6000 processor", 1990, Thm 2):
+// with r within half an ulp of 1/d and q1 faithful, RN(q1 + e1 r) IS the correctly rounded quotient -- the same bits the
+// hardware's v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence (10 instructions, half of them on the uniform
+// divisor again for every pixel) and the oracle's IEEE division produce.  Preconditions, checked on the HOST for the
+// operands (launch_k1: k1_fast_div_ok) and by construction for x: everything finite and far from the exponent range's
+// ends, d's significand not all ones; x == 0 is excluded by the caller (the sign of a zero quotient needs the real
+// division).  tests/test_fast_division.py checks the identity against IEEE division for EVERY divisor significand.
+__device__ __forceinline__ float div_by_uniform(float x, float d, float r) {
+    const float q0 = x * r;
+    const float e0 = __builtin_fmaf(-d, q0, x);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-d, q1, x);
+    return __builtin_fmaf(e1, r, q1);
+}
+
 template <int... OPS>
 struct K1Prog {
     static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
@@ -25,6 +43,21 @@ struct K1Prog {
             const float t = p.v[0];
             p.v[0] = p.v[2];
             p.v[2] = t;
+        } else if constexpr (OP == CVGS_OP_DIV) {
+            if (prog.fast_div) { // wave-uniform
+                float mn = fabsf(p.v[0]);
+#pragma unroll
+                for (int c = 1; c < 4; ++c)
+                    if (c < cn) mn = fminf(mn, fabsf(p.v[c]));
+                // a zero dividend (its quotient's sign) goes through the real division: the whole wave takes that path
+                if (__builtin_amdgcn_ballot_w64(mn == 0.0f) == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < cn) p.v[c] = div_by_uniform(p.v[c], prog.operand[k][c], prog.rdiv[c]);
+                    return;
+                }
+            }
+            apply_op(OP, prog.aux[k], prog.operand[k], p, depth, cn);
         } else {
             apply_op(OP, prog.aux[k], prog.operand[k], p, depth, cn);
         }
@@ -154,6 +187,26 @@ __device__ __forceinline__ void unpack_pair(const Win<elem_bytes<SRC>>& w, bool 
             b[k] = elem_to_float<SRC>((uint32_t)(s >> (16 * k)) & 0xffffu);
         }
     }
+}
+
+// A wave-uniform pointer pinned in SGPRs: stores / loads through (pinned base + 32-bit lane offset) then use the
+// scalar-base addressing form (global_store_dword v_off, v_data, s[base:base+1]); without the pin LLVM folds the lane
+// offset into ONE 64-bit vector base and pays a 64-bit VALU add per access for the uniform row / channel strides.
+template <typename T>
+__device__ __forceinline__ T* pin_uniform(T* p) {
+    uint64_t v = (uint64_t)p;
+    asm volatile("" : "+s"(v));
+    return (T*)v;
+}
+__device__ __forceinline__ gptr_u8 pin_uniform(gptr_u8 p) {
+    uint64_t v = (uint64_t)p;
+    asm volatile("" : "+s"(v));
+    return (gptr_u8)v;
+}
+// element `off_bytes / sizeof(T)` of a pinned row: the lane offset stays a zero-extended 32-bit byte offset
+template <typename T>
+__device__ __forceinline__ T* lane_elem(T* row, uint32_t off_bytes) {
+    return (T*)((__attribute__((address_space(1))) char*)(__attribute__((address_space(1))) T*)row + off_bytes);
 }
 
 __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }

@@ -765,3 +765,70 @@ int oracle_circular_destroy(oracle_circular_t ct) {
     free(ct->out); free(ct->hist); free(ct->tmp); free(ct);
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* Checker for div_by_uniform (csrc/k_taps.hpp); see cvgs_oracle.h.  Test infrastructure only. */
+typedef float (*fma_fn)(float, float, float);
+static float fma_soft(float a, float b, float c) { return fmaf(a, b, c); }
+#if defined(__x86_64__)
+__attribute__((target("fma"))) static float fma_hw(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+static inline uint64_t fd_rnd(uint64_t* s) {
+    *s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = *s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline float fd_make(uint32_t sig, int e, uint32_t sign) {
+    const uint32_t b = (sign << 31) | ((uint32_t)(e + 127) << 23) | (sig & 0x7fffffu);
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+int64_t oracle_fastdiv_mismatches(uint32_t sig_begin, uint32_t sig_end, int32_t per_divisor, uint64_t seed, int32_t steps) {
+    fma_fn f = fma_soft;
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("fma")) f = fma_hw;
+#endif
+    int64_t bad = 0;
+    uint64_t s = seed;
+    for (uint32_t sig = sig_begin; sig < sig_end && sig < (1u << 23); ++sig) {
+        if (sig == 0x7fffffu) continue;
+        for (int k = 0; k < per_divisor; ++k) {
+            const uint64_t a = fd_rnd(&s);
+            const float d = fd_make(sig, (int)((a >> 12) % 81) - 40, (uint32_t)(a >> 11) & 1u);
+            volatile float rv = 1.0f / d;
+            const float r = rv;
+            float x;
+            switch (k & 3) {
+            case 0: x = fd_make((uint32_t)(a >> 30) & 7u, (int)((a >> 40) % 107) - 70, (uint32_t)(a >> 63)); break;            /* just above 2^e */
+            case 1: x = fd_make(0x7fffffu - ((uint32_t)(a >> 30) & 7u), (int)((a >> 40) % 107) - 70, (uint32_t)(a >> 63)); break; /* just below */
+            case 2: x = fd_make((uint32_t)(a >> 30), (int)((a >> 40) % 107) - 70, (uint32_t)(a >> 63)); break;
+            default: { /* near ties: x = RN(q d) moved by -8..7 ulp for a random q */
+                const float q = fd_make((uint32_t)(a >> 30), (int)((a >> 54) % 41) - 20, 0);
+                volatile float pv = q * d;
+                float pp = pv;
+                uint32_t b;
+                memcpy(&b, &pp, 4);
+                b += (uint32_t)((int)((a >> 5) & 15) - 8);
+                memcpy(&pp, &b, 4);
+                x = pp;
+            }
+            }
+            if (x == 0.0f || !(fabsf(x) >= 0x1p-70f && fabsf(x) <= 0x1p37f)) continue;
+            volatile float tv = x / d;
+            const float t = tv;
+            const float q0 = x * r;
+            const float e0 = f(-d, q0, x);
+            float q = f(e0, r, q0);
+            if (steps >= 2) {
+                const float e1 = f(-d, q, x);
+                q = f(e1, r, q);
+            }
+            if (memcmp(&q, &t, 4) != 0) ++bad;
+        }
+    }
+    return bad;
+}

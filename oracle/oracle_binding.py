@@ -43,6 +43,8 @@ def load_oracle():
     lib.oracle_set_threads.argtypes = [C.c_int]
     lib.oracle_get_threads.restype = C.c_int
     lib.oracle_max_threads.restype = C.c_int
+    lib.oracle_fastdiv_mismatches.restype = C.c_int64
+    lib.oracle_fastdiv_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, C.c_int32]
     lib.oracle_resize_tapped_bytes.restype = C.c_int64
     lib.oracle_resize_tapped_bytes.argtypes = [C.c_int32] * 6
     lib.oracle_circular_create.restype = C.c_int

@@ -166,3 +166,47 @@ def test_k1_stream_capture_guard():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out_t, eager)
+
+
+# ---- division by a wave-uniform divisor (k_taps.hpp div_by_uniform) ---------------------------------------------------
+def _div_chain(src, crops, out, mul, sub, div, swap=True):
+    f = cvgs.CV_32FC3
+    ops = [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [src.roi(*c) for c in crops], (64, 128), len(crops))]
+    if swap:
+        ops.append(cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f))
+    return ops + [cvgs.multiply(f, mul), cvgs.subtract(f, sub), cvgs.divide(f, div), cvgs.split(f, out, (64, 128))]
+
+
+@pytest.mark.parametrize("name,mul,sub,div", [
+    ("zero dividends, negative zero quotients", [-1.0, -0.5, 2.0], [0.0, 0.0, 0.0], [3.0, 0.7, -11.8]),
+    ("integer mean: x == 0 wherever v == sub", [1.0, 1.0, 1.0], [1.0, 4.0, 6.0], [2.0, 8.0, 1.0]),
+    ("divisor significand all ones -> IEEE division", [0.3, 0.3, 0.3], [1.0, 4.0, 3.2], [float(np.float32(2.0) - np.float32(2.0 ** -23)), 0.6, 11.8]),
+    ("operands outside the guarded range -> IEEE division", [0.3, 0.3, 0.3], [1.0, 4.0, 3.2], [1e30, 0.6, 11.8]),
+    ("tiny multiplier outside the guard", [1e-12, 0.3, 0.3], [0.0, 4.0, 3.2], [3.2, 0.6, 11.8]),
+    ("negative divisors", [0.3, 0.3, 0.3], [1.0, 4.0, 3.2], [-3.2, -0.6, -11.8]),
+    ("hard-to-round divisors", [0.0078125, 1.0, 255.0], [0.5, 127.5, 0.0], [0.229, 58.395, 3.0]),
+])
+@pytest.mark.parametrize("swap", [True, False])
+def test_k1_division_paths_match_the_oracle(oracle, name, mul, sub, div, swap):
+    """Every way the DIV stage can run -- FMA-corrected reciprocal (guarded operands, no zero dividend in the wave),
+    the wave-level fallback for zero dividends, the host guard's refusals -- gives the IEEE quotient's bits."""
+    import torch
+    dev = torch.device("cuda:0")
+    frame = H.random_u8((600, 800, 3), seed=91)
+    frame[100:300, 100:500] = 0          # a black region: zero dividends when sub == 0
+    frame[300:400, :, 0] = 1             # v == sub for the integer-mean case
+    frame[300:400, :, 1] = 4
+    frame[300:400, :, 2] = 6
+    crops = H.random_crops(20, 800, 600, seed=92, wmax=400, hmax=500) + [(100, 100, 64, 128), (90, 290, 200, 150)]
+    ft = torch.from_numpy(frame).to(dev)
+    out = torch.full((len(crops), 3 * 64 * 128), -777.0, dtype=torch.float32, device=dev)
+    ops = _div_chain(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), mul, sub, div, swap)
+    assert cvgs.kernel_name(*ops).startswith("k1_u8c3_swap_mul_sub_div" if swap else "k1_u8c3_mul_sub_div")
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    ref = np.full((len(crops), 3 * 64 * 128), -777.0, np.float32)
+    oracle.execute(cvgs.lower(_div_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1),
+                                         mul, sub, div, swap)))
+    H.assert_bit_exact(out.cpu().numpy(), ref, name)
+    if "zero" in name:
+        assert (ref.view(np.uint32) == 0x80000000).any(), "the case must really produce negative zeros"

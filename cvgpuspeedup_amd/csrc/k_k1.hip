@@ -110,16 +110,6 @@ __device__ __forceinline__ void k1_store_other(const K1Geom& g, const ChainArgs&
     }
 }
 
-// one planar element: the row pointer is wave-uniform and pinned in SGPRs, the lane adds its 32-bit byte offset
-template <typename OT>
-__device__ __forceinline__ void st_row(OT* row_uniform, uint32_t x_bytes, float v) {
-    typedef __attribute__((address_space(1))) char* gchar;
-    typedef __attribute__((address_space(1))) OT* got;
-    const gchar r = (gchar)(got)pin_uniform(row_uniform);
-    if constexpr (std::is_same_v<OT, float>) __builtin_nontemporal_store(v, (got)(r + x_bytes));
-    else __builtin_nontemporal_store((OT)v, (got)(r + x_bytes));
-}
-
 // MIR: the instantiations that also write cvgs_write_desc.mirrors (kept out of the others' code)
 template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR, bool MIR = false>
 __global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, const K1Geom g) {
@@ -454,36 +444,6 @@ static hipError_t launch_few(int src, bool planar, bool u8out, int prog_id, bool
     return launch_other<CN, float, WM_PACKED>(table, rpw, c, ip, ni, s);
 }
 
-// Can the DIV stage of a [swap] MUL SUB DIV program use div_by_uniform (k_taps.hpp)?  Integer-valued sources only: the
-// interpolated value is finite and bounded by the source depth's range, so bounds on the operands bound the dividend
-// x = v * mul - sub: |x| <= 65535 * 2^20 + 2^20 < 2^37, and a non-zero x is never smaller than 2^-70 (a product of two
-// weights >= 2^-46 times |mul| >= 2^-20, or a difference of two floats one of which is >= 2^-20: >= 2^-44), so every
-// intermediate of the FMA corrections is a normal number and the residuals are exact.  A divisor whose significand is
-// all ones is left to the real division (the one case where RN(1/d) is not good enough for Markstein's theorem), and so
-// is a background value outside [2^-20, 2^20] (it is pushed through the same program).
-static void k1_fast_div_setup(ProgArgs& p, int div_at, int mul_at, int cn, const float* bg) {
-    static const char* off = getenv("CVGS_K1_FASTDIV"); // tuning / test hook: CVGS_K1_FASTDIV=0 keeps the IEEE division
-    if (off && off[0] == '0') return;
-    auto in_range = [](float v, int lo_exp, int hi_exp) {
-        const float a = std::fabs(v);
-        return std::isfinite(v) && a >= std::ldexp(1.0f, lo_exp) && a <= std::ldexp(1.0f, hi_exp);
-    };
-    for (int c = 0; c < cn; ++c) {
-        const float mul = p.operand[mul_at][c], sub = p.operand[mul_at + 1][c], d = p.operand[div_at][c];
-        if (!in_range(mul, -20, 20) || !(sub == 0.0f || in_range(sub, -20, 20)) || !in_range(d, -40, 40)) return;
-        // the background value (aspect-ratio padding, unused planes) runs through the same program
-        if (!(bg[c] == 0.0f || in_range(bg[c], -20, 20))) return;
-        uint32_t bits;
-        std::memcpy(&bits, &d, 4);
-        if ((bits & 0x7fffffu) == 0x7fffffu) return;
-    }
-    for (int c = 0; c < cn; ++c) {
-        volatile float r = 1.0f / p.operand[div_at][c]; // IEEE single division on the host: the correctly rounded reciprocal
-        p.rdiv[c] = r;
-    }
-    p.fast_div = 1;
-}
-
 // program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
 static int classify_program(const ProgArgs& p, int cn) {
     if (cn < 3) return (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) ? 1 : 2;
@@ -542,13 +502,17 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         for (int i = 0; i < n_segs; ++i) planes_total += segs[i].batch;
     }
     const int64_t wave_rows = planes_total * r.dst_h * ((r.dst_w + 63) / 64);
-    int rpw = wave_rows <= 16384 ? 1 : (wave_rows <= 65536 ? 2 : 4);
+    // round 2 sweep (profiles/r02_*): planar u8 output -- 1 row per wave up to 16 Ki wave-rows (100 crops of 64x128: 7.7 vs
+    // 7.9 us; 200 crops and a 1080p whole-frame output tie or prefer 2), 2 beyond (4 ties at 3200
+    // crops of ONE frame and loses 3-5 % when the crops come from many frames: 16 x 50 crops 38.3 vs 39.2 us); the packed /
+    // separate-plane modes keep round 1's whole-frame tuning (4 rows from 64 Ki wave-rows)
+    int rpw = wave_rows <= 16384 ? 1 : ((planar && wave_rows > 65536 && r.depth == CVGS_DEPTH_8U) || wave_rows <= 65536 ? 2 : 4);
     static const char* rpw_env = getenv("CVGS_K1_RPW"); // tuning hook (benchmarks only): force 1 / 2 / 4 rows per wave
     if (rpw_env) rpw = atoi(rpw_env) >= 4 ? 4 : (atoi(rpw_env) == 2 ? 2 : 1);
 
     const bool table = r.table != nullptr;
     const int prog_id = classify_program(c.prog, r.cn);
-    if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) k1_fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
+    if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
     if (info) {

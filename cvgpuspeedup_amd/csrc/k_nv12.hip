@@ -8,7 +8,10 @@
 // pixel and source row: ONE unaligned 2-byte load brings both luma taps, ONE unaligned 4-byte load both chroma
 // pairs (4 loads per pixel instead of 12 byte loads); windows are clamped into the row.  Planar stores are
 // full-wave 256-byte rows, non-temporal.
-#include "k_common.hpp"
+#include <cstdlib>
+#include <type_traits>
+
+#include "k_taps.hpp"
 
 namespace cvgs {
 
@@ -16,7 +19,6 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 typedef const __attribute__((address_space(1))) u16_unaligned* gptr_u16;
 typedef const __attribute__((address_space(1))) u32_unaligned* gptr_u32;
-typedef const __attribute__((address_space(1))) uint8_t* gptr_b;
 
 struct N12Geom {
     int32_t dst_w, dst_h, out_w, cn; // cn: 3, or 4 with alpha
@@ -29,31 +31,26 @@ struct N12Geom {
     int64_t img_stride2, ch_stride2;
 };
 
-constexpr int kOpSwapRB12 = 100;
-template <int... OPS>
-struct N12Prog {
-    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
-        int k = 0;
-        ((step<OPS>(prog, k, p, depth, cn), ++k), ...);
-    }
-    template <int OP>
-    static __device__ __forceinline__ void step(const ProgArgs& prog, int k, Px& p, int& depth, int& cn) {
-        if constexpr (OP == kOpSwapRB12) {
-            const float t = p.v[0];
-            p.v[0] = p.v[2];
-            p.v[2] = t;
-        } else {
-            apply_op(OP, prog.aux[k], prog.operand[k], p, depth, cn);
-        }
-    }
-};
-using N12SwapMulSubDiv = N12Prog<kOpSwapRB12, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
+using N12SwapMulSubDiv = ProgSwapMulSubDiv; // the compile-time program of k_taps.hpp (incl. the division by the uniform divisor)
 
-template <int NPL, class Prog, typename OT = float>
+// RPW output rows per wave (the launcher uses 1, see launch_n12); CN output channels (3, or 4 with alpha).
+// one tap: the conversion of k_common.hpp's yuv_to_rgb, with the channel count and the range known at compile time (full
+// range: (Y - 0) * 1 is Y itself, bit for bit, so the two instructions are dropped; the alpha lane only exists for CN 4)
+template <int CN, bool FULL>
+__device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k, float* t) {
+    const float cb = U - 128.f, cr = V - 128.f;
+    const float yv = FULL ? Y : (Y - k.ysub) * k.yscale;
+    t[0] = yv + k.rv * cr;
+    t[1] = (yv + k.gu * cb) + k.gv * cr;
+    t[2] = yv + k.bu * cb;
+    if constexpr (CN == 4) t[3] = 255.f;
+}
+
+template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3>
 __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, const N12Geom g) {
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.z;
-    const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w, CN = g.cn;
+    const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
     PlaneParams P;
     if constexpr (NPL == 0) P = c.read.table[z];
     else P = a.planes[z];
@@ -72,10 +69,10 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const int x = (int)blockIdx.x * 64 + lane;
-    const int y = (int)blockIdx.y * 4 + wave;
-    if (y >= dst_h || x >= dst_w) return;
+    const int row0 = ((int)blockIdx.y * 4 + wave) * RPW;
+    if (row0 >= dst_h || x >= dst_w) return;
 
-    // column geometry
+    // column geometry (once per lane, reused for every row)
     const float sx = (float)x * P.fx;
     const int x1 = (int)floorf(sx);
     const int x2 = x1 + 1;
@@ -88,86 +85,142 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4);
     const int ush = (2 * c1 - (int)uo) * 8;
     const bool same_pair = c2 == c1;
-    // row geometry (wave-uniform)
-    const float sy = (float)y * P.fy;
-    const int y1 = (int)floorf(sy);
-    const int y2 = y1 + 1;
-    const int y2r = min(y2, P.h - 1);
-    const float wya = (float)y2 - sy, wyb = sy - (float)y1;
-
-    const gptr_b base = (gptr_b)P.data;
+    const gptr_u8 base = (gptr_u8)P.data;
     const size_t step = (size_t)P.step;
-    const gptr_b ya = base + (size_t)__builtin_amdgcn_readfirstlane(y1) * step;
-    const gptr_b yb = base + (size_t)__builtin_amdgcn_readfirstlane(y2r) * step;
-    const gptr_b uvp = base + (size_t)P.uv_off; // crops of a surface carry their own luma -> chroma offset
-    const gptr_b ua = uvp + (size_t)__builtin_amdgcn_readfirstlane(y1 >> 1) * step;
-    const gptr_b ub = uvp + (size_t)__builtin_amdgcn_readfirstlane(y2r >> 1) * step;
-    const uint32_t vya = *(gptr_u16)(ya + yo);
-    const uint32_t vyb = *(gptr_u16)(yb + yo);
-    const uint32_t vua = *(gptr_u32)(ua + uo);
-    const uint32_t vub = *(gptr_u32)(ub + uo);
+    const gptr_u8 uvp = base + (size_t)P.uv_off; // crops of a surface carry their own luma -> chroma offset
 
-    const uint32_t ya0 = (vya >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya >> 8) & 0xffu;
-    const uint32_t yb0 = (vyb >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb >> 8) & 0xffu;
-    const uint32_t pa0 = (vua >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (vua >> 16) & 0xffffu;
-    const uint32_t pb0 = (vub >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (vub >> 16) & 0xffffu;
-
-    Px t00, t10, t01, t11;
-    yuv_to_rgb((float)ya0, (float)(pa0 & 0xffu), (float)(pa0 >> 8), yk, t00);
-    yuv_to_rgb((float)ya1, (float)(pa1 & 0xffu), (float)(pa1 >> 8), yk, t10);
-    yuv_to_rgb((float)yb0, (float)(pb0 & 0xffu), (float)(pb0 >> 8), yk, t01);
-    yuv_to_rgb((float)yb1, (float)(pb1 & 0xffu), (float)(pb1 >> 8), yk, t11);
-
-    const float w00 = wxa * wya, w10 = wxb * wya, w01 = wxa * wyb, w11 = wxb * wyb;
-    Px p;
+    uint32_t vya[RPW], vyb[RPW], vua[RPW], vub[RPW];
+    float wya[RPW], wyb[RPW];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float acc = t00.v[k] * w00;
-        acc = acc + t10.v[k] * w10;
-        acc = acc + t01.v[k] * w01;
-        acc = acc + t11.v[k] * w11;
-        p.v[k] = acc;
+    for (int j = 0; j < RPW; ++j) {
+        // row geometry (wave-uniform)
+        const int y = min(row0 + j, dst_h - 1);
+        const float sy = (float)y * P.fy;
+        const int y1 = (int)floorf(sy);
+        const int y2 = y1 + 1;
+        const int y2r = min(y2, P.h - 1);
+        wya[j] = (float)y2 - sy;
+        wyb[j] = sy - (float)y1;
+        const int r1 = __builtin_amdgcn_readfirstlane(y1), r2 = __builtin_amdgcn_readfirstlane(y2r);
+#ifdef CVGS_K4_PLAIN_PTR
+#define K4_PIN(p) (p)
+#else
+#define K4_PIN(p) pin_uniform(p)
+#endif
+        const gptr_u8 ya = K4_PIN(base + (size_t)r1 * step);
+        const gptr_u8 yb = K4_PIN(base + (size_t)r2 * step);
+        const gptr_u8 ua = K4_PIN(uvp + (size_t)(r1 >> 1) * step);
+        vya[j] = *(gptr_u16)(ya + yo);
+        vyb[j] = *(gptr_u16)(yb + yo);
+        vua[j] = *(gptr_u32)(ua + uo);
+        // Every other row pair shares ONE chroma row; skipping its second load behind a wave-uniform branch was measured
+        // and lost (tools/k4_ab.sh: cfg #3 9.15 vs 8.02 us, 50 NV12 crops 5.04 vs 4.52 us): the redundant load hits L1,
+        // the branch delays the loads behind it.
+#ifdef CVGS_K4_UVSKIP
+        if ((r1 >> 1) == (r2 >> 1)) {
+            vub[j] = vua[j];
+        } else
+#endif
+        {
+            const gptr_u8 ub = K4_PIN(uvp + (size_t)(r2 >> 1) * step);
+            vub[j] = *(gptr_u32)(ub + uo);
+        }
     }
-    int depth = CVGS_DEPTH_32F, cn = CN;
-    Prog::run(c.prog, p, depth, cn);
 
-    if (packed) {
-        write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
-    } else {
-        // OT = _Float16: the chain's trailing CAST(CV_16F) is this round-to-nearest-even conversion
-        OT* const orow = (OT*)out_base + (int64_t)z * img_stride + (int64_t)y * W;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow + (int64_t)k * ch_stride + x);
-        if (g.out2) { // wave-uniform
-            OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
+    for (int j = 0; j < RPW; ++j) {
+        const int y = row0 + j;
+        if (y >= dst_h) break; // wave-uniform
+        const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
+        const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
+        const uint32_t pa0 = (vua[j] >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (vua[j] >> 16) & 0xffffu;
+        const uint32_t pb0 = (vub[j] >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (vub[j] >> 16) & 0xffffu;
+
+        float t00[4], t10[4], t01[4], t11[4];
+        if (yuv_range == CVGS_YUV_FULL) { // wave-uniform
+            k4_tap<CN, true>((float)ya0, (float)(pa0 & 0xffu), (float)(pa0 >> 8), yk, t00);
+            k4_tap<CN, true>((float)ya1, (float)(pa1 & 0xffu), (float)(pa1 >> 8), yk, t10);
+            k4_tap<CN, true>((float)yb0, (float)(pb0 & 0xffu), (float)(pb0 >> 8), yk, t01);
+            k4_tap<CN, true>((float)yb1, (float)(pb1 & 0xffu), (float)(pb1 >> 8), yk, t11);
+        } else {
+            k4_tap<CN, false>((float)ya0, (float)(pa0 & 0xffu), (float)(pa0 >> 8), yk, t00);
+            k4_tap<CN, false>((float)ya1, (float)(pa1 & 0xffu), (float)(pa1 >> 8), yk, t10);
+            k4_tap<CN, false>((float)yb0, (float)(pb0 & 0xffu), (float)(pb0 >> 8), yk, t01);
+            k4_tap<CN, false>((float)yb1, (float)(pb1 & 0xffu), (float)(pb1 >> 8), yk, t11);
+        }
+
+        const float w00 = wxa * wya[j], w10 = wxb * wya[j], w01 = wxa * wyb[j], w11 = wxb * wyb[j];
+        Px p;
+        p.v[3] = 0.f;
 #pragma unroll
+        for (int k = 0; k < CN; ++k) {
+            float acc = t00[k] * w00;
+            acc = acc + t10[k] * w10;
+            acc = acc + t01[k] * w01;
+            acc = acc + t11[k] * w11;
+            p.v[k] = acc;
+        }
+        int depth = CVGS_DEPTH_32F, cn = CN;
+        Prog::run(c.prog, p, depth, cn);
+
+        if (packed) {
+            write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
+        } else {
+            // OT = _Float16: the chain's trailing CAST(CV_16F) is this round-to-nearest-even conversion
+            const uint32_t xb = (uint32_t)x * (uint32_t)sizeof(OT);
+            OT* const orow = (OT*)out_base + (int64_t)z * img_stride + (int64_t)y * W;
+#pragma unroll
+#ifdef CVGS_K4_PLAIN_PTR
             for (int k = 0; k < 4; ++k)
-                if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow2 + (int64_t)k * g.ch_stride2 + x);
+                if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow + (int64_t)k * ch_stride + x);
+            if (g.out2) {
+                OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow2 + (int64_t)k * g.ch_stride2 + x);
+            }
+#else
+            for (int k = 0; k < 4; ++k)
+                if (k < cn) st_row(orow + (int64_t)k * ch_stride, xb, p.v[k]);
+            if (g.out2) { // wave-uniform
+                OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cn) st_row(orow2 + (int64_t)k * g.ch_stride2, xb, p.v[k]);
+            }
+#endif
         }
     }
 }
 
-template <class Prog, typename OT = float>
-static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
-    const dim3 grid((g.dst_w + 63) / 64, (g.dst_h + 3) / 4, c.read.batch);
+template <class Prog, typename OT, int RPW, int CN>
+static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
+    const dim3 grid((g.dst_w + 63) / 64, (g.dst_h + 4 * RPW - 1) / (4 * RPW), c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         a.c = c;
         a.planes[0] = PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN>), grid, dim3(256), 0, s, a, g);
     } else if (ni <= 8) {
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN>), grid, dim3(256), 0, s, a, g);
     } else { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN>), grid, dim3(256), 0, s, a, g);
     }
     return hipGetLastError();
+}
+
+template <class Prog, typename OT = float>
+static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
+    // One output row per wave.  Two rows per wave were measured for whole-frame outputs (cfg #3: 14400 one-row waves need two
+    // rounds of the chip's 8192 wave slots) and lost: 8.27 vs 8.08 us, and 5.29 vs 4.52 us on 50 crops -- the launch is
+    // bound by the VALU work per row (~100 instructions x 14 waves per SIMD) plus the launch floor, not by residency.
+    return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3>(c, ip, ni, g, s);
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
@@ -212,11 +265,15 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
         info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
                            : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : "k4_nv12_resize_interp");
     if (dry_run) return 1;
+    ChainArgs c_fd = c;
+    c_fd.prog.fast_div = 0;
+    for (int k = 0; k < 4; ++k) c_fd.prog.rdiv[k] = 0.f;
+    if (fast_prog) fast_div_setup(c_fd.prog, 3, 1, r.out_cn, r.bg);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c, inline_planes, n_inline, g, s)
-                           : launch_n12<InterpProg, _Float16>(c, inline_planes, n_inline, g, s);
-    else e = fast_prog ? launch_n12<N12SwapMulSubDiv>(c, inline_planes, n_inline, g, s) : launch_n12<InterpProg>(c, inline_planes, n_inline, g, s);
+    if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c_fd, inline_planes, n_inline, g, s)
+                           : launch_n12<InterpProg, _Float16>(c_fd, inline_planes, n_inline, g, s);
+    else e = fast_prog ? launch_n12<N12SwapMulSubDiv>(c_fd, inline_planes, n_inline, g, s) : launch_n12<InterpProg>(c_fd, inline_planes, n_inline, g, s);
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 

@@ -3,6 +3,9 @@
 // its unpacking, non-temporal element stores.
 #pragma once
 
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "k_common.hpp"
@@ -29,6 +32,39 @@ __device__ __forceinline__ float div_by_uniform(float x, float d, float r) {
     const float q1 = __builtin_fmaf(e0, r, q0);
     const float e1 = __builtin_fmaf(-d, q1, x);
     return __builtin_fmaf(e1, r, q1);
+}
+
+// HOST side of div_by_uniform: can the DIV stage of a [swap] MUL SUB DIV program use it?  Integer-valued sources only
+// (8U / 16U / 16S pixels, NV12 bytes through the YCbCr matrix): the interpolated value v is finite and bounded
+// (|v| < 2^17), so bounds on the operands bound the dividend x = v * mul - sub: |x| < 2^38, and a non-zero x is never
+// smaller than 2^-90 (v is a sum of products of two weights >= 2^-46 with values that are integers or >= 2^-24 after the
+// matrix; times |mul| >= 2^-20; or a difference of two floats one of which is >= 2^-20), far inside the range where every
+// intermediate of the FMA corrections is a normal number and the residuals are exact: with 2^-20 <= |d| <= 2^20 the
+// quotient stays above 2^-110 and the lowest bit of d*q above 2^-136 (the oracle's checker shows the identity FAILING
+// once quotients may be subnormal, e.g. |x| = 2^-100 with |d| = 2^40).  A divisor whose significand is
+// all ones is left to the real division (the one case where RN(1/d) is not good enough for Markstein's theorem), and so
+// is a background value outside [2^-20, 2^20] (it is pushed through the same program).
+inline void fast_div_setup(ProgArgs& p, int div_at, int mul_at, int cn, const float* bg) {
+    static const char* off = getenv("CVGS_K1_FASTDIV"); // tuning / test hook: CVGS_K1_FASTDIV=0 keeps the IEEE division
+    if (off && off[0] == '0') return;
+    auto in_range = [](float v, int lo_exp, int hi_exp) {
+        const float a = std::fabs(v);
+        return std::isfinite(v) && a >= std::ldexp(1.0f, lo_exp) && a <= std::ldexp(1.0f, hi_exp);
+    };
+    for (int c = 0; c < cn; ++c) {
+        const float mul = p.operand[mul_at][c], sub = p.operand[mul_at + 1][c], d = p.operand[div_at][c];
+        if (!in_range(mul, -20, 20) || !(sub == 0.0f || in_range(sub, -20, 20)) || !in_range(d, -20, 20)) return;
+        // the background value (aspect-ratio padding, unused planes) runs through the same program
+        if (!(bg[c] == 0.0f || in_range(bg[c], -20, 20))) return;
+        uint32_t bits;
+        std::memcpy(&bits, &d, 4);
+        if ((bits & 0x7fffffu) == 0x7fffffu) return;
+    }
+    for (int c = 0; c < cn; ++c) {
+        volatile float r = 1.0f / p.operand[div_at][c]; // IEEE single division on the host: the correctly rounded reciprocal
+        p.rdiv[c] = r;
+    }
+    p.fast_div = 1;
 }
 
 template <int... OPS>
@@ -207,6 +243,16 @@ __device__ __forceinline__ gptr_u8 pin_uniform(gptr_u8 p) {
 template <typename T>
 __device__ __forceinline__ T* lane_elem(T* row, uint32_t off_bytes) {
     return (T*)((__attribute__((address_space(1))) char*)(__attribute__((address_space(1))) T*)row + off_bytes);
+}
+
+// one planar element: the row pointer is wave-uniform and pinned in SGPRs, the lane adds its 32-bit byte offset
+template <typename OT>
+__device__ __forceinline__ void st_row(OT* row_uniform, uint32_t x_bytes, float v) {
+    typedef __attribute__((address_space(1))) char* gchar;
+    typedef __attribute__((address_space(1))) OT* got;
+    const gchar r = (gchar)(got)pin_uniform(row_uniform);
+    if constexpr (std::is_same_v<OT, float>) __builtin_nontemporal_store(v, (got)(r + x_bytes));
+    else __builtin_nontemporal_store((OT)v, (got)(r + x_bytes));
 }
 
 __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }

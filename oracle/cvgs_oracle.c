@@ -798,14 +798,14 @@ int64_t oracle_fastdiv_mismatches(uint32_t sig_begin, uint32_t sig_end, int32_t 
         if (sig == 0x7fffffu) continue;
         for (int k = 0; k < per_divisor; ++k) {
             const uint64_t a = fd_rnd(&s);
-            const float d = fd_make(sig, (int)((a >> 12) % 81) - 40, (uint32_t)(a >> 11) & 1u);
+            const float d = fd_make(sig, (int)((a >> 12) % 41) - 20, (uint32_t)(a >> 11) & 1u);
             volatile float rv = 1.0f / d;
             const float r = rv;
             float x;
             switch (k & 3) {
-            case 0: x = fd_make((uint32_t)(a >> 30) & 7u, (int)((a >> 40) % 107) - 70, (uint32_t)(a >> 63)); break;            /* just above 2^e */
-            case 1: x = fd_make(0x7fffffu - ((uint32_t)(a >> 30) & 7u), (int)((a >> 40) % 107) - 70, (uint32_t)(a >> 63)); break; /* just below */
-            case 2: x = fd_make((uint32_t)(a >> 30), (int)((a >> 40) % 107) - 70, (uint32_t)(a >> 63)); break;
+            case 0: x = fd_make((uint32_t)(a >> 30) & 7u, (int)((a >> 40) % 129) - 90, (uint32_t)(a >> 63)); break;            /* just above 2^e */
+            case 1: x = fd_make(0x7fffffu - ((uint32_t)(a >> 30) & 7u), (int)((a >> 40) % 129) - 90, (uint32_t)(a >> 63)); break; /* just below */
+            case 2: x = fd_make((uint32_t)(a >> 30), (int)((a >> 40) % 129) - 90, (uint32_t)(a >> 63)); break;
             default: { /* near ties: x = RN(q d) moved by -8..7 ulp for a random q */
                 const float q = fd_make((uint32_t)(a >> 30), (int)((a >> 54) % 41) - 20, 0);
                 volatile float pv = q * d;
@@ -817,7 +817,7 @@ int64_t oracle_fastdiv_mismatches(uint32_t sig_begin, uint32_t sig_end, int32_t 
                 x = pp;
             }
             }
-            if (x == 0.0f || !(fabsf(x) >= 0x1p-70f && fabsf(x) <= 0x1p37f)) continue;
+            if (x == 0.0f || !(fabsf(x) >= 0x1p-90f && fabsf(x) <= 0x1p38f)) continue;
             volatile float tv = x / d;
             const float t = tv;
             const float q0 = x * r;

@@ -68,8 +68,9 @@ float oracle_half_to_float(uint16_t h);
 
 /* Checker for the product's division by a wave-uniform divisor (cvgpuspeedup_amd/csrc/k_taps.hpp, div_by_uniform:
  * q0 = x*r, two FMA correction steps, r = RN(1/d)): restates the formula with fmaf and counts the dividends for which
- * it differs from the IEEE quotient x / d.  For every divisor significand in [sig_begin, sig_end) (exponent swept over
- * the product's guarded range) it tries `per_divisor` dividends: powers-of-two neighbours, random significands and
+ * it differs from the IEEE quotient x / d.  For every divisor significand in [sig_begin, sig_end) (exponents swept over
+ * the product's guarded ranges: 2^-20 <= |d| <= 2^20, 2^-90 <= |x| <= 2^38; beyond them the quotient or a residual
+ * can be subnormal and the identity does fail) it tries `per_divisor` dividends: powers-of-two neighbours, random significands and
  * near-tie dividends (x = RN(q d) +- a few ulp).  all-ones significands are skipped like the product's host guard does.
  * `steps` = 2: the product's formula; 1: a single correction step (reported for the record, not used). */
 int64_t oracle_fastdiv_mismatches(uint32_t sig_begin, uint32_t sig_end, int32_t per_divisor, uint64_t seed, int32_t steps);

@@ -318,3 +318,33 @@ def test_nv12_preserve_ar_stays_on_the_generic_kernel():
     rd.ar = cvgs.PRESERVE_AR
     name = cvgs.kernel_name(rd, cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (64, 64)))
     assert name.startswith("generic"), name
+
+
+@pytest.mark.parametrize("range_", [capi.YUV_FULL, capi.YUV_LIMITED])
+@pytest.mark.parametrize("primaries", [capi.BT601, capi.BT709])
+@pytest.mark.parametrize("through_k4", [False, True])
+def test_gpu_yuv_matrix_equals_the_derivation_from_kr_kb(range_, primaries, through_k4):
+    """The product's eight coefficient sets against a float64 derivation from the standards' Kr / Kb (tests/
+    test_independent_pins.py), with probe pixels that isolate each coefficient -- through the interpreted kernel (full-
+    resolution NV12 read) and through the K4 fast kernel (resize to the same size: every tap weight is exactly 1)."""
+    import torch
+    from tests import test_independent_pins as P
+    dev = torch.device("cuda:0")
+    surf = P.nv12_probe_surface(P.derived_matrix(range_, primaries)[0])
+    st = torch.from_numpy(surf).to(dev)
+    f = cvgs.CV_32FC3
+    luma = cvgs.GpuMat(2, 6, cvgs.CV_8UC1, st.data_ptr(), 6, owner=st)
+    if through_k4:
+        out = torch.zeros((1, 3 * 6 * 2), dtype=torch.float32, device=dev)
+        ops = [cvgs.read_nv12(luma, (6, 2), range_, primaries, False), cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (6, 2))]
+        assert cvgs.kernel_name(*ops).startswith("k4_nv12_resize")
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+        torch.cuda.synchronize()
+        rgb = out.cpu().numpy().reshape(3, 2, 6).transpose(1, 2, 0).copy()
+    else:
+        out = torch.zeros((2, 6, 3), dtype=torch.float32, device=dev)
+        cvgs.executeOperations(torch.cuda.current_stream(), cvgs.read_nv12(luma, None, range_, primaries, False),
+                               cvgs.write(f, cvgs.GpuMat.from_tensor(out, f)))
+        torch.cuda.synchronize()
+        rgb = out.cpu().numpy()
+    P.check_probe(rgb, range_, primaries, "gpu k4" if through_k4 else "gpu generic")

@@ -121,3 +121,36 @@ def test_cfg4_circular_tensor_full_size(order):
         if len(singles) > B + 1:
             singles[len(singles) - B - 2] = None
     ct.release()
+
+
+def test_cfg4_full_size_resize_push_matches_the_oracle(oracle):
+    """cfg #4 as BASELINE spells it -- "push new frame with resize+normalize while shifting 15 slots" -- at FULL size:
+    a 4K frame resized to 1080p and normalised into a depth-16 CircularTensor.  After 3 pushes the newest slot is compared
+    bit for bit with the ORACLE's resize + normalize of that frame (2 Mpix x 3, ~2 s of CPU), the two older ones with the
+    oracle's results for their frames, the 13 unfilled slots must be zero."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda:0")
+    Wd, Hd, B = 1920, 1080, 16
+    fw, fh = W.FRAME_4K
+    f = cvgs.CV_32FC3
+    ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard, Wd, Hd)
+    pw = [cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3])]
+    s = torch.cuda.current_stream()
+    plane = Wd * Hd * 3
+    frames = [H.random_u8((fh, fw, 3), seed=7100 + k) for k in range(3)]
+    for fr in frames:
+        ft = torch.from_numpy(fr).to(dev)
+        ct.update(s, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), (Wd, Hd)), *pw, ct.write_split(f))
+        torch.cuda.synchronize()
+    view = torch.empty(B * plane, dtype=torch.float32, device=dev)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(view.data_ptr()), C.c_void_p(ct.data()), C.c_size_t(B * plane * 4), 3) == 0
+    got = view.view(B, plane).cpu().numpy()
+    for age, fr in enumerate(reversed(frames)):
+        ref = np.zeros((1, plane), np.float32)
+        oracle.execute(cvgs.lower([cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, cvgs.GpuMat.from_array(fr, cvgs.CV_8UC3), (Wd, Hd)), *pw,
+                                   cvgs.split(f, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), (Wd, Hd))]))
+        H.assert_bit_exact(got[age], ref[0], "cfg4 resize push, slot of age %d" % age)
+    assert not got[3:].any()
+    ct.release()

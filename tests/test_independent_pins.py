@@ -1,0 +1,123 @@
+"""Pins that do not come from the oracle's author reading the same formula twice.
+
+(a) The eight YCbCr -> RGB coefficient sets are DERIVED here in float64 from the standards' luma weights
+    (BT.601: Kr = 0.299, Kb = 0.114; BT.709: Kr = 0.2126, Kb = 0.0722) and the range scaling (full: Y, C / 255;
+    limited: (Y - 16) * 255/219, C * 255/224) and compared with what the ORACLE produces for probe pixels -- the
+    literals live in oracle/cvgs_oracle.c and csrc/k_common.hpp; tests/test_gpu_circular_nv12.py does the same probe
+    on the GPU.
+(b) The PRESERVE_AR / _RN_EVEN / _LEFT windows are restated in EXACT rational arithmetic (fractions) over a sweep of
+    sizes: fit by height, fall back to width, round half away from zero, even / left variants -- and compared with
+    oracle_resize_geometry.  The product and the oracle evaluate the scale in float32 (FKL's order); the restatement shows
+    where that matters: only when the exact extent is within 1e-4 of a .5 tie."""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+
+STANDARDS = {capi.BT601: (0.299, 0.114), capi.BT709: (0.2126, 0.0722)}
+
+
+def derived_matrix(range_, primaries):
+    """(ysub, yscale, rv, gu, gv, bu) in float64 from Kr / Kb: R = Y' + 2(1-Kr) Cr, B = Y' + 2(1-Kb) Cb,
+    G = Y' - [2 Kb (1-Kb) / Kg] Cb - [2 Kr (1-Kr) / Kg] Cr, Kg = 1 - Kr - Kb."""
+    kr, kb = STANDARDS[primaries]
+    kg = 1.0 - kr - kb
+    rv, bu = 2.0 * (1.0 - kr), 2.0 * (1.0 - kb)
+    gu, gv = -2.0 * kb * (1.0 - kb) / kg, -2.0 * kr * (1.0 - kr) / kg
+    if range_ == capi.YUV_FULL:
+        return 0.0, 1.0, rv, gu, gv, bu
+    cs = 255.0 / 224.0
+    return 16.0, 255.0 / 219.0, rv * cs, gu * cs, gv * cs, bu * cs
+
+
+def nv12_probe_surface(ysub):
+    """6x2 NV12 surface: three chroma pairs that isolate the coefficients.
+    pair 0: (U,V) = (128,129), Y = ysub      -> (R,G,B) = (rv, gv, 0)
+    pair 1: (U,V) = (129,128), Y = ysub      -> (0, gu, bu)
+    pair 2: (U,V) = (128,128), Y = ysub + 1  -> (yscale, yscale, yscale)"""
+    s = np.zeros((3, 6), np.uint8)
+    s[0:2, 0:4] = int(ysub)
+    s[0:2, 4:6] = int(ysub) + 1
+    s[2] = [128, 129, 129, 128, 128, 128]
+    return s
+
+
+def probe_chain(wrap_src, wrap_out, surf, out, range_, primaries):
+    luma = wrap_src(surf)
+    luma = cvgs.GpuMat(2, 6, cvgs.CV_8UC1, luma.data, luma.step, owner=luma.owner)
+    return [cvgs.read_nv12(luma, None, range_, primaries, False), cvgs.write(cvgs.CV_32FC3, wrap_out(out))]
+
+
+def check_probe(rgb, range_, primaries, what):
+    ysub, yscale, rv, gu, gv, bu = derived_matrix(range_, primaries)
+    # the literals carry 6-7 significant digits: 1e-6 absolute is half a unit of their last digit, far below any other
+    # candidate matrix (BT.601 vs BT.709 differ in the second digit)
+    tol = 1.2e-6
+    got = {"rv": rgb[0, 0, 0], "gv": rgb[0, 0, 1], "b0": rgb[0, 0, 2], "r1": rgb[0, 2, 0], "gu": rgb[0, 2, 1], "bu": rgb[0, 2, 2],
+           "ys": rgb[0, 4, 0]}
+    want = {"rv": rv, "gv": gv, "b0": 0.0, "r1": 0.0, "gu": gu, "bu": bu, "ys": yscale}
+    for k in want:
+        assert abs(float(got[k]) - want[k]) <= tol, (what, k, float(got[k]), want[k])
+    assert rgb[0, 4, 0] == rgb[0, 4, 1] == rgb[0, 4, 2]
+    assert (rgb[1] == rgb[0]).all()
+
+
+@pytest.mark.parametrize("range_", [capi.YUV_FULL, capi.YUV_LIMITED])
+@pytest.mark.parametrize("primaries", [capi.BT601, capi.BT709])
+def test_oracle_yuv_matrix_equals_the_derivation_from_kr_kb(oracle, range_, primaries):
+    surf = nv12_probe_surface(derived_matrix(range_, primaries)[0])
+    out = np.zeros((2, 6, 3), np.float32)
+    oracle.execute(cvgs.lower(probe_chain(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_32FC3),
+                                          surf, out, range_, primaries)))
+    check_probe(out, range_, primaries, "oracle")
+
+
+def exact_window(sw, sh, dw, dh, ar):
+    """The aspect-ratio window in exact arithmetic: scale by height, fall back to width when it does not fit, extents
+    rounded half away from zero (RN_EVEN: then down to even), centred (LEFT: x = 0).  Returns (x1, y1, x2, y2, margin)
+    where margin = distance of the rounded quantity from the nearest .5 tie."""
+    def rnd(q):
+        return int(q + Fraction(1, 2)), abs((q - int(q)) - Fraction(1, 2))
+    tw, m = rnd(Fraction(dh * sw, sh))
+    th = dh
+    if ar == cvgs.PRESERVE_AR_RN_EVEN:
+        tw -= tw % 2
+    if tw > dw:
+        tw = dw
+        th, m = rnd(Fraction(dw * sh, sw))
+        if ar == cvgs.PRESERVE_AR_RN_EVEN:
+            th -= th % 2
+    tw, th = max(tw, 1), max(th, 1)
+    x1 = 0 if ar == cvgs.PRESERVE_AR_LEFT else (dw - tw) // 2
+    y1 = (dh - th) // 2
+    return x1, y1, x1 + tw - 1, y1 + th - 1, float(m)
+
+
+@pytest.mark.parametrize("ar", [cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_RN_EVEN, cvgs.PRESERVE_AR_LEFT])
+def test_aspect_ratio_windows_against_exact_arithmetic(oracle, ar):
+    rng = np.random.default_rng(11)
+    sizes = [(int(rng.integers(1, 4097)), int(rng.integers(1, 2161))) for _ in range(3000)]
+    sizes += [(30, 120), (60, 120), (120, 30), (1, 1), (4096, 1), (1, 2160), (64, 128), (128, 64), (1920, 1080), (3840, 2160)]
+    near_ties = 0
+    for dst in [(64, 128), (128, 64), (224, 224), (1280, 720), (33, 77)]:
+        for (sw, sh) in sizes:
+            x1, y1, x2, y2, margin = exact_window(sw, sh, dst[0], dst[1], ar)
+            g = oracle.resize_geometry(sw, sh, dst[0], dst[1], ar)
+            if margin < 1e-4:   # the float32 product may land on the other side of the tie: FKL's evaluation order decides
+                near_ties += 1
+                continue
+            assert (g.x1, g.y1, g.x2, g.y2) == (x1, y1, x2, y2), (sw, sh, dst, (g.x1, g.y1, g.x2, g.y2), (x1, y1, x2, y2))
+            # the scale the kernel steps with is the window extent over the source extent, in double, narrowed once
+            assert np.float32(g.fx) == np.float32(1.0 / ((x2 - x1 + 1) / sw)) and np.float32(g.fy) == np.float32(1.0 / ((y2 - y1 + 1) / sh))
+            # the window lies inside the target and keeps the aspect ratio to within one pixel of the exact fit
+            assert 0 <= x1 <= x2 < dst[0] and 0 <= y1 <= y2 < dst[1]
+    assert near_ties < 0.02 * 5 * len(sizes)
+
+
+def test_reference_aspect_ratio_case(oracle):
+    """reference tests/batchresize/test_batchresize_aspectratio_x_split3D.cu:86-95: 30x120 into 64x128 -> 32x128 at x0 = 16."""
+    assert exact_window(30, 120, 64, 128, cvgs.PRESERVE_AR)[:4] == (16, 0, 47, 127)
+    g = oracle.resize_geometry(30, 120, 64, 128, cvgs.PRESERVE_AR)
+    assert (g.x1, g.y1, g.x2, g.y2) == (16, 0, 47, 127)

@@ -1,0 +1,223 @@
+// k_cvtcolor_u8.hip -- the standalone u8 -> u8 colour conversions of cvGS::cvtColor (reference include/cvGPUSpeedup.cuh:
+// 151-161; tests/color/test_cvtColor.cu:105-123) as compile-time programs: RGB <-> BGR, +-alpha (with or without the
+// swap) are pure BYTE PERMUTATIONS and never leave the integer registers; *2GRAY does its three multiplies per pixel.
+// One thread owns SIXTEEN x-adjacent pixels: CN 16-byte loads, OCN 16-byte non-temporal stores (a 4K BGR -> RGB frame is
+// 24.9 MB in + 24.9 MB out: a streaming copy with a shuffle in the middle).  Bit-identical to the interpreted
+// pointwise4_u8_u8 kernel, which keeps every other u8 -> u8 program, ragged widths and unaligned images.
+#include "k_pointwise_body.hpp"
+
+#ifndef CVGS_CC_LOAD
+#define CVGS_CC_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+#ifndef CVGS_CC_STORE
+#define CVGS_CC_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
+namespace cvgs {
+
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4a* gp_u32x4;
+typedef __attribute__((address_space(1))) u32x4a* gp_u32x4_w;
+typedef const __attribute__((address_space(1))) uint8_t* gp_u8c;
+
+enum { PERM_ID = 0, PERM_SWAP = 1 };
+
+// byte of the thread's 16-pixel input chunk that output byte e comes from; -1: the added alpha
+template <int CN, int OCN, int PERM>
+constexpr int src_byte(int e) {
+    const int px = e / OCN, ch = e % OCN;
+    if (ch == 3 && CN == 3) return -1;
+    const int sc = ch < 3 ? (PERM == PERM_SWAP ? 2 - ch : ch) : 3;
+    return px * CN + sc;
+}
+
+// The wave's 1024 pixels travel through a wave-private LDS region in both directions, so that EVERY global access is a
+// fully coalesced 1 KB instruction (lane l touches bytes 16 l .. 16 l + 15 of the k-th KB) while every lane still owns 16
+// whole pixels in between: 16-byte chunks at a 48-byte lane stride measured 15.6 us on a 4K BGR -> RGB frame, the coalesced
+// form 11 us (profiles/r02_*; the LDS round trips are not what bounds it).  No barrier: a wave's LDS instructions execute in
+// order and no other wave touches its region.  ds_read_b128 at a 48-byte lane stride is conflict-free (16-lane groups
+// hit 16 distinct 16-byte slots), at 64 bytes (4-channel pixels) 4-way -- still far from the limiter.
+template <int CN>
+__device__ __forceinline__ void load_chunk16(const gp_u8c row, int tile_px0, int W, int lane, uint32_t* lds_wave, uint32_t* in) {
+    const int row_bytes = W * CN, tile_b0 = tile_px0 * CN;
+#pragma unroll
+    for (int k = 0; k < CN; ++k) {
+        const int off = tile_b0 + 1024 * k + 16 * lane;
+        u32x4a v = {0, 0, 0, 0};
+        if (off < row_bytes) v = CVGS_CC_LOAD((gp_u32x4)(row + (uint32_t)off));
+        *(u32x4a*)(lds_wave + 256 * k + 4 * lane) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < CN; ++k) {
+        const u32x4a v = *(const u32x4a*)(lds_wave + 4 * CN * lane + 4 * k);
+        in[4 * k] = v.x; in[4 * k + 1] = v.y; in[4 * k + 2] = v.z; in[4 * k + 3] = v.w;
+    }
+}
+
+template <int CN, int OCN, int PERM, int NPL>
+__global__ __launch_bounds__(256) void k_u8_permute16(const KernArgs<NPL> a, const PwGeom g, const uint32_t alpha) {
+    constexpr int MAXC = CN > OCN ? CN : OCN;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][256 * MAXC];
+    const ChainArgs& c = a.c;
+    const int z = (int)blockIdx.z;
+    PlaneParams P;
+    if constexpr (NPL == 0) P = c.read.table[z];
+    else P = a.planes[z];
+    const int W = g.w, H = g.h;
+    asm volatile("" ::"s"(W), "s"(H), "s"(P.step), "s"(P.data), "s"(g.out), "s"(g.row_pitch), "s"(g.img_stride));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int tile_px0 = (int)blockIdx.x * 1024;
+    const int y = (int)blockIdx.y * 4 + wave;
+    if (y >= H) return; // wave-uniform
+    const gp_u8c row = (gp_u8c)P.data + (size_t)y * (size_t)P.step;
+    uint32_t* const lw = lds[wave];
+    uint32_t in[4 * CN];
+    load_chunk16<CN>(row, tile_px0, W, lane, lw, in);
+#pragma unroll
+    for (int k = 0; k < OCN; ++k) {
+        uint32_t q[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = src_byte<CN, OCN, PERM>(16 * k + 4 * d + i);
+                const uint32_t b = s < 0 ? alpha : ((in[s < 0 ? 0 : (s >> 2)] >> (8 * (s & 3))) & 0xffu);
+                w |= b << (8 * i);
+            }
+            q[d] = w;
+        }
+        const u32x4a v = {q[0], q[1], q[2], q[3]};
+        *(u32x4a*)(lw + 4 * OCN * lane + 4 * k) = v;
+    }
+    __attribute__((address_space(1))) uint8_t* orow =
+        (__attribute__((address_space(1))) uint8_t*)g.out + (size_t)z * (size_t)g.img_stride + (size_t)y * (size_t)g.row_pitch;
+    const int out_row_bytes = W * OCN, out_b0 = tile_px0 * OCN;
+#pragma unroll
+    for (int k = 0; k < OCN; ++k) {
+        const int off = out_b0 + 1024 * k + 16 * lane;
+        const u32x4a v = *(const u32x4a*)(lw + 256 * k + 4 * lane);
+        if (off < out_row_bytes) CVGS_CC_STORE(v, (gp_u32x4_w)(orow + (uint32_t)off));
+    }
+}
+
+// *2GRAY: 16 pixels -> 16 bytes; the arithmetic is apply_op's (0.299 R + 0.587 G + 0.114 B in that order, round to nearest
+// even), the channel order comes with `aux`.  Input through the LDS like the permutations; the 16 output bytes of a lane
+// are already lane-contiguous.
+template <int CN, int NPL>
+__global__ __launch_bounds__(256) void k_u8_gray16(const KernArgs<NPL> a, const PwGeom g) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][256 * CN];
+    const ChainArgs& c = a.c;
+    const int z = (int)blockIdx.z;
+    PlaneParams P;
+    if constexpr (NPL == 0) P = c.read.table[z];
+    else P = a.planes[z];
+    const int W = g.w, H = g.h, aux = c.prog.aux[0];
+    asm volatile("" ::"s"(W), "s"(H), "s"(P.step), "s"(P.data), "s"(g.out), "s"(g.row_pitch), "s"(g.img_stride), "s"(aux));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int tile_px0 = (int)blockIdx.x * 1024;
+    const int x0 = tile_px0 + lane * 16;
+    const int y = (int)blockIdx.y * 4 + wave;
+    if (y >= H) return;
+    const gp_u8c row = (gp_u8c)P.data + (size_t)y * (size_t)P.step;
+    uint32_t in[4 * CN];
+    load_chunk16<CN>(row, tile_px0, W, lane, lds[wave], in);
+    if (x0 >= W) return;
+    uint32_t q[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        Px p;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) p.v[ch] = ch < CN ? elem_value<CVGS_DEPTH_8U>(in, i * CN + ch) : 0.f;
+        int depth = CVGS_DEPTH_8U, cn = CN;
+        apply_op(CVGS_OP_GRAY, aux, c.prog.operand[0], p, depth, cn);
+        q[i >> 2] |= ((uint32_t)p.v[0] & 0xffu) << (8 * (i & 3));
+    }
+    __attribute__((address_space(1))) uint8_t* orow =
+        (__attribute__((address_space(1))) uint8_t*)g.out + (size_t)z * (size_t)g.img_stride + (size_t)y * (size_t)g.row_pitch;
+    u32x4a v = {q[0], q[1], q[2], q[3]};
+    CVGS_CC_STORE(v, (gp_u32x4_w)(orow + (uint32_t)x0));
+}
+
+template <int NPL>
+static void fill_args(KernArgs<NPL>& a, const ChainArgs& c, const PlaneParams* ip, int ni) {
+    a.c = c;
+    if constexpr (NPL > 0) {
+        for (int i = 0; i < NPL; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
+    } else {
+        a.planes[0] = PlaneParams{};
+    }
+}
+
+template <int CN, int OCN, int PERM>
+static hipError_t launch_perm(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, uint32_t alpha, hipStream_t s) {
+    const dim3 grid((g.w / 16 + 63) / 64, (g.h + 3) / 4, c.read.batch);
+    if (c.read.table) {
+        KernArgs<0> a;
+        fill_args(a, c, ip, ni);
+        hipLaunchKernelGGL((k_u8_permute16<CN, OCN, PERM, 0>), grid, dim3(256), 0, s, a, g, alpha);
+    } else {
+        KernArgs<CVGS_KERNARG_PLANES> a;
+        fill_args(a, c, ip, ni);
+        hipLaunchKernelGGL((k_u8_permute16<CN, OCN, PERM, CVGS_KERNARG_PLANES>), grid, dim3(256), 0, s, a, g, alpha);
+    }
+    return hipGetLastError();
+}
+template <int CN>
+static hipError_t launch_gray(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    const dim3 grid((g.w / 16 + 63) / 64, (g.h + 3) / 4, c.read.batch);
+    if (c.read.table) {
+        KernArgs<0> a;
+        fill_args(a, c, ip, ni);
+        hipLaunchKernelGGL((k_u8_gray16<CN, 0>), grid, dim3(256), 0, s, a, g);
+    } else {
+        KernArgs<CVGS_KERNARG_PLANES> a;
+        fill_args(a, c, ip, ni);
+        hipLaunchKernelGGL((k_u8_gray16<CN, CVGS_KERNARG_PLANES>), grid, dim3(256), 0, s, a, g);
+    }
+    return hipGetLastError();
+}
+
+// Returns 1 if it took the chain, 0 if not eligible, <0 on error.  `g` is the packed-output geometry of pointwise4_u8_u8.
+int launch_u8_colour16(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, void* stream, bool dry_run, LaunchInfo* info) {
+    const ReadArgs& r = c.read;
+    const ProgArgs& p = c.prog;
+    if (p.n != 1 || r.used != r.batch || (g.w & 15) || r.cn < 3) return 0;
+    const int op = p.opcode[0], aux = p.aux[0];
+    constexpr int kId3 = 0 | (1 << 2) | (2 << 4), kSwap3 = 2 | (1 << 2) | (0 << 4);
+    int perm = -1;
+    bool gray = false;
+    if (op == CVGS_OP_REORDER) {
+        if ((r.cn == 3 && aux == kSwap3) || (r.cn == 4 && aux == (kSwap3 | (3 << 6)))) perm = PERM_SWAP;
+    } else if (op == CVGS_OP_ADD_ALPHA || op == CVGS_OP_DROP_ALPHA) {
+        if ((aux & 63) == kId3) perm = PERM_ID;
+        else if ((aux & 63) == kSwap3) perm = PERM_SWAP;
+    } else if (op == CVGS_OP_GRAY) {
+        gray = true;
+    }
+    if (perm < 0 && !gray) return 0;
+    uint32_t alpha = 0;
+    if (op == CVGS_OP_ADD_ALPHA) { // the interpreted kernel stores (uint8_t)operand[0]: take whole values in range only
+        const float av = p.operand[0][0];
+        if (!(av >= 0.f && av <= 255.f) || av != (float)(int)av) return 0;
+        alpha = (uint32_t)(int)av;
+    }
+    // 16-byte accesses: every source row, the output base, its row pitch and image stride must be 16-byte aligned
+    if (((uintptr_t)g.out & 15) || (g.row_pitch & 15) || (g.img_stride & 15)) return 0;
+    if (r.table) return 0; // resident tables: alignment cannot be checked on the host
+    for (int i = 0; i < ni; ++i)
+        if (((uintptr_t)ip[i].data & 15) || (ip[i].step & 15)) return 0;
+    if (info) info->kernel = gray ? "pointwise16_u8_gray" : "pointwise16_u8_permute";
+    if (dry_run) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (gray) e = r.cn == 3 ? launch_gray<3>(c, ip, ni, g, s) : launch_gray<4>(c, ip, ni, g, s);
+    else if (op == CVGS_OP_REORDER) e = r.cn == 3 ? launch_perm<3, 3, PERM_SWAP>(c, ip, ni, g, 0, s) : launch_perm<4, 4, PERM_SWAP>(c, ip, ni, g, 0, s);
+    else if (op == CVGS_OP_ADD_ALPHA) e = perm == PERM_SWAP ? launch_perm<3, 4, PERM_SWAP>(c, ip, ni, g, alpha, s) : launch_perm<3, 4, PERM_ID>(c, ip, ni, g, alpha, s);
+    else e = perm == PERM_SWAP ? launch_perm<4, 3, PERM_SWAP>(c, ip, ni, g, 0, s) : launch_perm<4, 3, PERM_ID>(c, ip, ni, g, 0, s);
+    return e == hipSuccess ? 1 : -(int)e - 1000;
+}
+
+} // namespace cvgs

@@ -184,8 +184,6 @@ static int launch_pointwise_u8u8(const ChainArgs& c, const PlaneParams* ip, int 
     if (r.kind != CVGS_READ_PIXEL || r.depth != CVGS_DEPTH_8U || w.depth != CVGS_DEPTH_8U || r.batch > 65535) return 0;
     if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
     if (w.data2 || (!r.table && ni > CVGS_KERNARG_PLANES)) return 0;
-    if (info) info->kernel = "pointwise4_u8_u8_interp";
-    if (dry_run) return 1;
     PwGeom g;
     g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.pad = 0;
     g.out = w.data; g.out2 = nullptr;
@@ -193,6 +191,13 @@ static int launch_pointwise_u8u8(const ChainArgs& c, const PlaneParams* ip, int 
     g.row_pitch2 = 0;
     g.img_stride = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : (int64_t)w.img_stride * w.cn; // bytes
     g.img_stride2 = g.ch_stride = g.ch_stride2 = 0;
+    {
+        // the colour conversions themselves (RGB <-> BGR, +-alpha, *2GRAY) as compile-time programs, 16 pixels per thread
+        const int rc = launch_u8_colour16(c, ip, ni, g, s, dry_run, info);
+        if (rc) return rc;
+    }
+    if (info) info->kernel = "pointwise4_u8_u8_interp";
+    if (dry_run) return 1;
     hipError_t e;
     switch (r.cn) {
     case 1: e = launch_u8u8_ocn<1>(w.cn, c, ip, ni, g, s); break;

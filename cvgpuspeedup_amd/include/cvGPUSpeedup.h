@@ -34,6 +34,13 @@ inline fk::RawPtr<fk::_2D, T> gpuMat2RawPtr2D(const cv::cuda::GpuMat& m) {
     p.dims = {(uint)m.cols, (uint)m.rows, (uint)m.step};
     return p;
 }
+// reference include/cvGPUSpeedup.cuh:46-52
+template <typename T, int Batch>
+inline std::array<fk::Ptr2D<T>, Batch> gpuMat2Ptr2D_arr(const std::array<cv::cuda::GpuMat, Batch>& src) {
+    std::array<fk::Ptr2D<T>, Batch> out;
+    for (int i = 0; i < Batch; ++i) out[(size_t)i] = gpuMat2Ptr2D<T>(src[(size_t)i]);
+    return out;
+}
 template <typename T, size_t N>
 inline std::array<fk::RawPtr<fk::_2D, T>, N> gpuMat2RawPtr2D_arr(const std::array<cv::cuda::GpuMat, N>& src, int used = (int)N) {
     std::array<fk::RawPtr<fk::_2D, T>, N> out{};

@@ -104,7 +104,10 @@ typedef enum cvgs_read_kind {
      * source position is M*(x,y,1) (perspective: divided by its third component) with M = read.warp_matrices[z],
      * the INVERSE (destination -> source) transform narrowed to float exactly as fk::WarpingParameters holds it
      * (cvGPUSpeedup.cuh:269-284); inside the source [0,w) x [0,h) the value is the INTER_LINEAR interpolation of
-     * the resize kinds, outside it is 0; the output type is CV_32F of the source's channels.                    */
+     * the resize kinds, outside it is 0; the output type is CV_32F of the source's channels.  ONE destination size
+     * (dst_width x dst_height) per launch: the reference's std::array<cv::Size, BATCH> overloads (:381-401) are accepted
+     * by the facade only when every size is equal (it throws std::runtime_error otherwise) -- a batch of differently
+     * sized warps is one launch per size.                                                                          */
     CVGS_READ_WARP_AFFINE = 4,
     CVGS_READ_WARP_PERSPECTIVE = 5
 } cvgs_read_kind;
@@ -148,7 +151,9 @@ typedef enum cvgs_opcode {
     /* fk::Binary<fk::Mul/Add/Sub/Div<T>> (cvGS::multiply/add/subtract/divide,
      * cvGPUSpeedup.cuh:131-149); operand[c] = static_cast<float>(cv::Scalar[c])
      * (cvGPUSpeedupHelpers.cuh:38-54), operand_d[c] = the cv::Scalar value itself for CV_64F
-     * types.  IEEE fp32 (fp64 on CV_64F values), applied in call order, never merged.          */
+     * types.  IEEE fp32 (fp64 on CV_64F values), applied in call order, never merged.  On integer-typed values:
+     * CVGS_ERR_UNSUPPORTED here, a static_assert in the C++ facade (cvGS::multiply<CV_8UC3> does not compile; the
+     * reference instantiates fk::Mul<uchar3>, whose semantics live in the un-vendored FKL and no reference test uses).   */
     CVGS_OP_MUL = 2,
     CVGS_OP_ADD = 3,
     CVGS_OP_SUB = 4,

@@ -180,6 +180,21 @@ static void test_then_spelling(cv::cuda::Stream& stream) {
     CHECK(bit_equal(c.data(), d.data(), c.size()), "read.then(crop(rect)).then(resize) == resize(ROI)");
 }
 
+// the pointer adapters of reference include/cvGPUSpeedup.cuh:34-65 on an array of crops
+static void test_pointer_adapters() {
+    cv::cuda::GpuMat d_frame(240, 320, CV_8UC3, cv::Scalar(1, 2, 3));
+    std::array<cv::cuda::GpuMat, 3> crops = {d_frame(cv::Rect(0, 0, 10, 20)), d_frame(cv::Rect(5, 7, 100, 50)), d_frame(cv::Rect(300, 200, 20, 40))};
+    const auto owning = cvGS::gpuMat2Ptr2D_arr<uchar3, 3>(crops);
+    const auto raw = cvGS::gpuMat2RawPtr2D_arr<uchar3>(crops);
+    bool ok = true;
+    for (size_t i = 0; i < 3; ++i) {
+        const auto p = owning[i].ptr();
+        ok = ok && p.data == (uchar3*)crops[i].data && p.dims.width == (uint)crops[i].cols && p.dims.height == (uint)crops[i].rows &&
+             p.dims.pitch == (uint)crops[i].step && raw[i].data == p.data && raw[i].dims.pitch == p.dims.pitch;
+    }
+    CHECK(ok, "gpuMat2Ptr2D_arr / gpuMat2RawPtr2D_arr describe the crops (no copy)");
+}
+
 template <int TI, int TO>
 static void sweep(cv::cuda::Stream& stream) {
     test_constant<TI, TO, 10, cvGS::IGNORE_AR>(stream, 60);
@@ -201,6 +216,7 @@ int main() {
     sweep<CV_16SC3, CV_32FC3>(stream);
     sweep<CV_16SC4, CV_32FC4>(stream);
     test_then_spelling(stream);
+    test_pointer_adapters();
     test_half_handoff<CV_8UC3, 50>(stream);
     test_half_handoff<CV_8UC4, 17>(stream);
     return report("test_batchresize_x_split3D + aspectratio");

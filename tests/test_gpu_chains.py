@@ -454,3 +454,67 @@ def test_cvgs_execute_is_thread_safe(oracle):
     for _, _, outs, ref, _ in jobs:
         for o in outs:
             H.assert_bit_exact(o.cpu().numpy(), ref, "concurrent launches")
+
+
+# ---- standalone u8 colour conversions as compile-time programs (k_cvtcolor_u8.hip) ------------------------------------
+_CODES = [("BGR2RGB", cvgs.COLOR_BGR2RGB, 3, 3), ("BGRA2RGBA", cvgs.COLOR_BGRA2RGBA, 4, 4), ("BGR2BGRA", cvgs.COLOR_BGR2BGRA, 3, 4),
+          ("BGR2RGBA", cvgs.COLOR_BGR2RGBA, 3, 4), ("BGRA2BGR", cvgs.COLOR_BGRA2BGR, 4, 3), ("RGBA2BGR", cvgs.COLOR_RGBA2BGR, 4, 3),
+          ("BGR2GRAY", cvgs.COLOR_BGR2GRAY, 3, 1), ("RGB2GRAY", cvgs.COLOR_RGB2GRAY, 3, 1), ("BGRA2GRAY", cvgs.COLOR_BGRA2GRAY, 4, 1),
+          ("RGBA2GRAY", cvgs.COLOR_RGBA2GRAY, 4, 1)]
+
+
+@pytest.mark.parametrize("name,code,icn,ocn", _CODES, ids=[c[0] for c in _CODES])
+@pytest.mark.parametrize("shape", [(37, 640, 1), (5, 4096, 3), (9, 16, 2), (7, 637, 1), (6, 656, 1)])
+def test_u8_colour_conversions_fast_and_interpreted_agree_with_oracle(oracle, name, code, icn, ocn, shape):
+    """The reference's cvtColor codes (tests/color/test_cvtColor.cu:105-123) on NON-constant u8 images: aligned widths take
+    the 16-pixel-per-thread permutation / gray kernels, the ragged width (637) and the 8-byte-aligned pitch (656 * 3 with a
+    crop start) stay on the interpreted kernel; all of them must give the oracle's bytes."""
+    import torch
+    dev = torch.device("cuda:0")
+    h, w, batch = shape
+    it, ot = cvgs.make_type(cvgs.CV_8U, icn), cvgs.make_type(cvgs.CV_8U, ocn)
+    srcs = [H.random_u8((h, w, icn), seed=300 + b) for b in range(batch)]
+    ts = [torch.from_numpy(s).to(dev) for s in srcs]
+
+    def chain(mats, out, flags=0):
+        if batch == 1:
+            return [cvgs.ReadIOp(capi.READ_PIXEL, it, [mats[0]], 1), cvgs.cvtColor(code, it, ot), cvgs.write(ot, out)]
+        return [cvgs.ReadIOp(capi.READ_PIXEL, it, mats, batch), cvgs.cvtColor(code, it, ot), cvgs.write(ot, out, (w, h))]
+
+    if batch == 1:
+        out_t = torch.zeros((h, w, ocn), dtype=torch.uint8, device=dev)
+        ref = np.zeros((h, w, ocn), np.uint8)
+    else:
+        out_t = torch.zeros((batch, h * w, ocn), dtype=torch.uint8, device=dev)
+        ref = np.zeros((batch, h * w, ocn), np.uint8)
+    g_ops = chain([cvgs.GpuMat.from_tensor(t, it) for t in ts], cvgs.GpuMat.from_tensor(out_t, ot))
+    name_k = cvgs.kernel_name(*g_ops)
+    aligned = w % 16 == 0
+    assert name_k.startswith("pointwise16_u8_" if aligned else "pointwise4_u8_u8"), (name_k, shape)
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops)
+    torch.cuda.synchronize()
+    oracle.execute(cvgs.lower(chain([cvgs.GpuMat.from_array(s, it) for s in srcs], cvgs.GpuMat.from_array(ref, ot))))
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "%s %s via %s" % (name, shape, name_k))
+    out_t.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops, flags=capi.CHAIN_NO_THREAD_FUSION)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "%s %s interpreted" % (name, shape))
+
+
+def test_u8_colour_conversion_of_an_unaligned_crop_stays_interpreted(oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    frame = H.random_u8((64, 200, 3), seed=17)
+    ft = torch.from_numpy(frame).to(dev)
+    out_t = torch.zeros((32, 64, 3), dtype=torch.uint8, device=dev)
+    ref = np.zeros((32, 64, 3), np.uint8)
+
+    def chain(m, out):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [m.roi(3, 5, 64, 32)], 1), cvgs.cvtColor(cvgs.COLOR_BGR2RGB, cvgs.CV_8UC3), cvgs.write(cvgs.CV_8UC3, out)]
+
+    g_ops = chain(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_8UC3))
+    assert cvgs.kernel_name(*g_ops).startswith("pointwise4_u8_u8")  # the crop starts 9 bytes into a row: no 16-byte loads
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops)
+    torch.cuda.synchronize()
+    oracle.execute(cvgs.lower(chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), cvgs.GpuMat.from_array(ref, cvgs.CV_8UC3))))
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "unaligned crop")

@@ -42,6 +42,7 @@ READ_PIXEL, READ_RESIZE_LINEAR, READ_NV12, READ_NV12_RESIZE_LINEAR, READ_WARP_AF
 # aspect ratio (same values as cvGS::AspectRatio)
 PRESERVE_AR, IGNORE_AR, PRESERVE_AR_RN_EVEN, PRESERVE_AR_LEFT = 0, 1, 2, 3
 YUV_FULL, YUV_LIMITED = 0, 1
+YUV_NV12, YUV_NV21, YUV_I420, YUV_YV12 = 0, 1, 2, 3
 BT601, BT709 = 0, 1
 READ_FLAG_TABLE_ON_DEVICE = 1
 # opcodes
@@ -67,7 +68,7 @@ class ReadDesc(C.Structure):
                 ("src", C.c_void_p), ("dst_width", C.c_int32), ("dst_height", C.c_int32),
                 ("aspect_ratio", C.c_int32), ("flags", C.c_uint32), ("background", C.c_float * 4),
                 ("yuv_range", C.c_int32), ("yuv_primaries", C.c_int32), ("yuv_alpha", C.c_int32),
-                ("reserved", C.c_int32), ("warp_matrices", C.POINTER(C.c_float))]
+                ("yuv_layout", C.c_int32), ("warp_matrices", C.POINTER(C.c_float))]
 
 
 class Op(C.Structure):

@@ -197,6 +197,8 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         return fail(CVGS_ERR_UNSUPPORTED, "CV_64F / CV_16F sources are supported for per-pixel reads only");
     if (is_nv12(rd.kind) && rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
         return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
+    if (is_nv12(rd.kind) && (rd.yuv_layout < CVGS_YUV_NV12 || rd.yuv_layout > CVGS_YUV_YV12))
+        return fail(CVGS_ERR_INVALID, "bad yuv_layout");
     if (is_warp(rd.kind)) {
         if (rd.dst_width < 1 || rd.dst_height < 1) return fail(CVGS_ERR_INVALID, "warp target must be positive");
         if (!rd.warp_matrices) return fail(CVGS_ERR_INVALID, "read.warp_matrices is null");
@@ -221,6 +223,8 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     R.yuv_range = rd.yuv_range;
     R.yuv_primaries = rd.yuv_primaries;
     R.yuv_alpha = rd.yuv_alpha;
+    R.yuv_layout = is_nv12(rd.kind) ? rd.yuv_layout : 0;
+    R.pad = 0;
     R.out_cn = is_nv12(rd.kind) ? (rd.yuv_alpha ? 4 : 3) : scn;
     R.table = nullptr;
 
@@ -262,6 +266,10 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             P.step = im.step;
             if (is_nv12(rd.kind)) {
                 if (im.uv_offset < 0 || (im.uv_offset & 1)) return fail(CVGS_ERR_INVALID, "NV12 uv_offset must be even and non-negative");
+                if (rd.yuv_layout > CVGS_YUV_NV21) {
+                    if (im.uv_offset) return fail(CVGS_ERR_UNSUPPORTED, "crops of planar-chroma (I420 / YV12) surfaces");
+                    if (im.step & 1) return fail(CVGS_ERR_INVALID, "I420 / YV12 surfaces need an even step (chroma rows are step/2 bytes)");
+                }
                 P.uv_off = im.uv_offset ? im.uv_offset : im.height * im.step;
             }
             if (R.is_resize) plane_geometry(im.width, im.height, rd.dst_width, rd.dst_height, rd.aspect_ratio, P);

@@ -39,6 +39,8 @@ struct ReadArgs {
     float bg[4];
     int32_t yuv_range, yuv_primaries, yuv_alpha;
     int32_t out_cn;         // channels produced by the read stage
+    int32_t yuv_layout;     // cvgs_yuv_layout
+    int32_t pad;
     const PlaneParams* table; // device table, or nullptr -> planes inline in the kernel args
 };
 

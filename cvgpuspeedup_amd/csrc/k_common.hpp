@@ -242,10 +242,12 @@ __device__ __forceinline__ float tap_f(float v, int depth) {
 // ---- NV12 -> RGB(A) float ----------------------------------------------------------------------
 struct YuvK {
     float ysub, yscale, rv, gu, gv, bu;
+    int layout; // cvgs_yuv_layout of the source (set by the caller next to yuv_matrix)
 };
 
 __device__ __forceinline__ YuvK yuv_matrix(int range, int primaries) {
     YuvK k;
+    k.layout = CVGS_YUV_NV12;
     if (range == CVGS_YUV_FULL) {
         k.ysub = 0.f; k.yscale = 1.f;
         if (primaries == CVGS_BT601) { k.rv = 1.402f; k.gu = -0.344136f; k.gv = -0.714136f; k.bu = 1.772f; }
@@ -269,8 +271,19 @@ __device__ __forceinline__ void yuv_to_rgb(float Y, float U, float V, const YuvK
 
 __device__ __forceinline__ void nv12_px(const PlaneParams& P, int x, int y, const YuvK& k, Px& p) {
     const float Y = (float)P.data[(size_t)y * P.step + x];
-    const uint8_t* uv = P.data + (size_t)P.uv_off + (size_t)(y >> 1) * P.step + 2 * (x >> 1);
-    yuv_to_rgb(Y, (float)uv[0], (float)uv[1], k, p);
+    float U, V;
+    if (k.layout <= CVGS_YUV_NV21) { // interleaved chroma: one (U,V) or (V,U) pair per 2x2 luma block
+        const uint8_t* uv = P.data + (size_t)P.uv_off + (size_t)(y >> 1) * P.step + 2 * (x >> 1);
+        U = (float)uv[k.layout == CVGS_YUV_NV21 ? 1 : 0];
+        V = (float)uv[k.layout == CVGS_YUV_NV21 ? 0 : 1];
+    } else {                         // planar chroma: (W/2) x (H/2) planes with rows of step/2 bytes, one after the other
+        const size_t cstep = (size_t)(P.step >> 1);
+        const uint8_t* first = P.data + (size_t)P.uv_off + (size_t)(y >> 1) * cstep + (x >> 1);
+        const uint8_t* second = first + (size_t)(P.h >> 1) * cstep;
+        U = (float)*(k.layout == CVGS_YUV_YV12 ? second : first);
+        V = (float)*(k.layout == CVGS_YUV_YV12 ? first : second);
+    }
+    yuv_to_rgb(Y, U, V, k, p);
 }
 
 // ---- write stages ------------------------------------------------------------------------------

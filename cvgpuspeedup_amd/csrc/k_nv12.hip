@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     if constexpr (NPL == 0) P = c.read.table[z];
     else P = a.planes[z];
     const int yuv_range = c.read.yuv_range, yuv_prim = c.read.yuv_primaries, packed = g.packed;
+    const bool vu = c.read.yuv_layout == CVGS_YUV_NV21; // wave-uniform: the chroma pair is (V,U)
     const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
     uint8_t* const out_base = g.out;
     typedef float f32x4s __attribute__((ext_vector_type(4)));
@@ -133,8 +134,13 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
         if (y >= dst_h) break; // wave-uniform
         const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
         const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
-        const uint32_t pa0 = (vua[j] >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (vua[j] >> 16) & 0xffffu;
-        const uint32_t pb0 = (vub[j] >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (vub[j] >> 16) & 0xffffu;
+        uint32_t ca = vua[j], cb = vub[j];
+        if (vu) { // NV21: swap the bytes of every pair once, then everything below is NV12
+            ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
+            cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
+        }
+        const uint32_t pa0 = (ca >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (ca >> 16) & 0xffffu;
+        const uint32_t pb0 = (cb >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (cb >> 16) & 0xffffu;
 
         float t00[4], t10[4], t01[4], t11[4];
         if (yuv_range == CVGS_YUV_FULL) { // wave-uniform
@@ -240,6 +246,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     }
     const ChainArgs& c = f16 ? c_cut : c_in;
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
+    if (r.yuv_layout > CVGS_YUV_NV21) return 0; // planar chroma (I420 / YV12): the interpreted kernel
     if (r.table || n_inline > CVGS_KERNARG_PLANES || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
     if (r.used != r.batch || r.batch > 65535) return 0;
     for (int i = 0; i < n_inline; ++i) { // aspect-ratio padding is the generic kernel's business

@@ -231,14 +231,16 @@ def cast(in_type, out_type):
     return PointwiseIOp(in_type, out_type, [(capi.OP_CAST_TRUNC, type_depth(out_type), None)])
 
 
-def read_nv12(mat, dsize=None, color_range=capi.YUV_FULL, primaries=capi.BT709, alpha=True):
+def read_nv12(mat, dsize=None, color_range=capi.YUV_FULL, primaries=capi.BT709, alpha=True, layout=capi.YUV_NV12):
     """fk::ReadYUV<NV12> + fk::ConvertYUVToRGB<NV12, range, primaries, alpha, floatN>, optionally as the
     BackIOp of fk::Resize<INTER_LINEAR> (reference tests/resize/test_fused_resize.cu:141-143).
     `mat` is the CV_8UC1 luma view (rows = luma height); the UV plane follows it in memory."""
     kind = capi.READ_NV12 if dsize is None else capi.READ_NV12_RESIZE_LINEAR
     mats = [mat] if isinstance(mat, GpuMat) else list(mat)  # a list = N crops (GpuMat.nv12_roi) of decoder surfaces, one launch
-    return ReadIOp(kind, make_type(DEPTH_8U, 1), mats, len(mats), dsize, IGNORE_AR, None,
-                   (color_range, primaries, 1 if alpha else 0))
+    rd = ReadIOp(kind, make_type(DEPTH_8U, 1), mats, len(mats), dsize, IGNORE_AR, None,
+                 (color_range, primaries, 1 if alpha else 0))
+    rd.yuv_layout = layout  # fk::ReadYUV<PF>: NV12 (the reference's), NV21, I420, YV12
+    return rd
 
 
 def convertTo(in_type, out_type, alpha=None, beta=None):
@@ -398,6 +400,7 @@ def lower(iops, flags=0):
     for i in range(4):
         r.background[i] = rd.background[i]
     r.yuv_range, r.yuv_primaries, r.yuv_alpha = rd.yuv
+    r.yuv_layout = getattr(rd, "yuv_layout", 0)
     if rd.warp is not None:
         wm = (C.c_float * len(rd.warp))(*rd.warp)
         keep.append(wm)

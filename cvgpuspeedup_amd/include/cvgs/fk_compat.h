@@ -78,7 +78,9 @@ enum InterpolationType { INTER_LINEAR = 1 };
 enum AspectRatio { PRESERVE_AR = 0, IGNORE_AR = 1, PRESERVE_AR_RN_EVEN = 2, PRESERVE_AR_LEFT = 3 };
 enum class CircularTensorOrder { NewestFirst = 0, OldestFirst = 1 };
 enum class ColorPlanes { Standard = 0, Transposed = 1 };
-enum PixelFormat { NV12 = 0 };
+// fk::PixelFormat: the reference's tests instantiate NV12 only; NV21 / I420 / YV12 are this engine's further 4:2:0 readers
+// (numeric values = cvgs_yuv_layout)
+enum PixelFormat { NV12 = 0, NV21 = 1, I420 = 2, YV12 = 3 };
 enum ColorRange { Full = 0, Limited = 1 };
 enum ColorPrimitives { bt601 = 0, bt709 = 1 };
 enum ColorConversionCodes {
@@ -460,6 +462,7 @@ template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typenam
         cvgs_read_desc& r = b.d.read;
         r.kind = kind; r.src_type = CV_8UC1;
         r.yuv_range = (int)CR; r.yuv_primaries = (int)CP; r.yuv_alpha = ALPHA ? 1 : 0;
+        r.yuv_layout = (int)PF;
         if (crops.empty()) b.src.assign(1, image2d(params));
         else b.src = crops;
         r.batch = r.used_planes = (int)b.src.size();

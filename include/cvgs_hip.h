@@ -122,6 +122,14 @@ typedef enum cvgs_aspect_ratio {
 
 typedef enum cvgs_yuv_range { CVGS_YUV_FULL = 0, CVGS_YUV_LIMITED = 1 } cvgs_yuv_range;
 typedef enum cvgs_yuv_primaries { CVGS_BT601 = 0, CVGS_BT709 = 1 } cvgs_yuv_primaries;
+/* 4:2:0 layouts of the NV12 read kinds (the reference spells the reader as a template on the pixel format,
+ * fk::ReadYUV<fk::NV12>, tests/resize/test_fused_resize.cu:50; NV12 is the only format its tests instantiate):
+ *   NV12: interleaved chroma plane, U first;  NV21: the same, V first;
+ *   I420: planar chroma, a (W/2) x (H/2) U plane with rows of step/2 bytes directly followed by the V plane; YV12: V plane first.
+ * The chroma of luma row 0 starts uv_offset bytes after `data` (0 = height * step, the whole surface).  Crops
+ * (uv_offset != 0) exist for the interleaved layouts only: a crop of a planar-chroma surface cannot say where its second
+ * chroma plane starts (CVGS_ERR_UNSUPPORTED).                                                                      */
+typedef enum cvgs_yuv_layout { CVGS_YUV_NV12 = 0, CVGS_YUV_NV21 = 1, CVGS_YUV_I420 = 2, CVGS_YUV_YV12 = 3 } cvgs_yuv_layout;
 
 #define CVGS_READ_FLAG_TABLE_ON_DEVICE 1u /* `src` is a device table made by cvgs_plane_table_build */
 
@@ -139,7 +147,7 @@ typedef struct cvgs_read_desc {
     int32_t yuv_range;    /* NV12 kinds only                                                  */
     int32_t yuv_primaries;
     int32_t yuv_alpha;    /* 1: 4-channel output with alpha = 255                             */
-    int32_t reserved;
+    int32_t yuv_layout;   /* cvgs_yuv_layout (0 = NV12)                                       */
     const float* warp_matrices; /* WARP kinds: host, batch x 9 floats (3x3 row-major; affine ignores row 2) */
 } cvgs_read_desc;
 

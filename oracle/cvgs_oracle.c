@@ -200,9 +200,23 @@ static void nv12_pixel(const cvgs_image2d* im, int x, int y, const cvgs_read_des
     const float Y = (float)base[(size_t)y * im->step + x];
     /* a crop of a surface carries its own luma -> chroma offset (cvgs_image2d.uv_offset); 0 = the whole surface */
     const size_t uv_off = im->uv_offset ? (size_t)im->uv_offset : (size_t)im->height * (size_t)im->step;
-    const uint8_t* uv = base + uv_off + (size_t)(y / 2) * im->step + 2 * (x / 2);
-    const float cb = (float)uv[0] - 128.f;
-    const float cr = (float)uv[1] - 128.f;
+    /* 4:2:0 layouts (cvgs_yuv_layout): interleaved (U,V) [NV12] or (V,U) [NV21] pairs, one per 2x2 luma block, in rows of
+     * `step` bytes; or planar chroma [I420: U plane then V plane, YV12: V then U], (W/2) x (H/2) samples in rows of
+     * step/2 bytes.  The reference instantiates fk::ReadYUV<fk::NV12> only (tests/resize/test_fused_resize.cu:50). */
+    uint8_t u8, v8;
+    if (rd->yuv_layout <= CVGS_YUV_NV21) {
+        const uint8_t* uv = base + uv_off + (size_t)(y / 2) * im->step + 2 * (x / 2);
+        u8 = uv[rd->yuv_layout == CVGS_YUV_NV21 ? 1 : 0];
+        v8 = uv[rd->yuv_layout == CVGS_YUV_NV21 ? 0 : 1];
+    } else {
+        const size_t cstep = (size_t)(im->step / 2);
+        const uint8_t* first = base + uv_off + (size_t)(y / 2) * cstep + (size_t)(x / 2);
+        const uint8_t* second = first + (size_t)(im->height / 2) * cstep;
+        u8 = *(rd->yuv_layout == CVGS_YUV_YV12 ? second : first);
+        v8 = *(rd->yuv_layout == CVGS_YUV_YV12 ? first : second);
+    }
+    const float cb = (float)u8 - 128.f;
+    const float cr = (float)v8 - 128.f;
     const yuv_coeffs k = yuv_matrix(rd->yuv_range, rd->yuv_primaries);
     const float yv = (Y - k.ysub) * k.yscale;
     p->f[0] = yv + k.rv * cr;

@@ -99,6 +99,7 @@ def _case(seed, big=False):
     prog, fd, fc = _program(rng, d0, c0)
     ft = cvgs.make_type(fd, fc)
     nv12_resize = bool(rng.integers(0, 2))
+    yuv_layout = int(rng.integers(0, 4))  # NV12 / NV21 / I420 / YV12
     crop_views = None
     if kind == "nv12" and rng.integers(0, 2):
         crop_views = []
@@ -152,10 +153,12 @@ def _case(seed, big=False):
                            [m.tolist() for m in mats_persp], (dw, dh), max(used, 1) if used == 0 else used, bg[:scn])
         else:
             lumas = [cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, m.data, m.step, owner=m.owner) for m in mats]
+            layout = yuv_layout
             if nv12_resize and n > 1 and crop_views:  # N crop views (own luma -> chroma offsets) of ONE decoder surface
                 lumas = [lumas[0].nv12_roi(*c) for c in crop_views]
+                layout = yuv_layout & 1  # crops exist for the interleaved layouts only
             rd = cvgs.read_nv12(lumas if n > 1 else lumas[0], (dw, dh) if nv12_resize else None,
-                                int(rng_choice[0]), int(rng_choice[1]), alpha)
+                                int(rng_choice[0]), int(rng_choice[1]), alpha, layout=layout)
         if use_table and kind in ("pixel", "resize") and used == n and type(mats[0].owner).__module__.startswith("torch"):
             # GPU side only: the crop list as a resident device plane table instead of kernel-argument descriptors
             import torch

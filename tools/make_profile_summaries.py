@@ -1,95 +1,121 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/<tag>/) into the committed summaries
-profiles/<label>_*.txt and refresh profiles/pmc_headline.json.   python tools/make_profile_summaries.py r01c r01_c"""
-import csv
-import io
+"""Turn the text summaries tools/profile_round.sh left under gpurun_out/<tag>/ into the committed files
+profiles/<label>_*.txt and refresh profiles/pmc_headline.json.   python tools/make_profile_summaries.py r02f r02_f"""
 import json
 import os
-import statistics
+import re
 import sys
-from contextlib import redirect_stdout
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-import prof_summary  # noqa: E402
-
 tag, label = sys.argv[1], sys.argv[2]
 R = os.path.join(ROOT, "gpurun_out", tag)
 P = os.path.join(ROOT, "profiles")
 
 
-def cap(fn, *a):
-    buf = io.StringIO()
-    with redirect_stdout(buf):
-        fn(*a)
-    return buf.getvalue()
+def rd(name):
+    path = os.path.join(R, name)
+    return open(path).read() if os.path.exists(path) else "(missing: %s)\n" % name
 
 
-def pmc_mean(path, sub):
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if sub in r["Kernel_Name"]]
-    return statistics.mean(v) if v else float("nan")
-
-
-def cut(text, n=200):
+def cut(text, n=190):
     return "\n".join(l[:n] for l in text.splitlines()) + "\n"
 
 
-bench = json.loads(open(os.path.join(R, "bench_trace.json")).read().strip().splitlines()[-1])
-unprof = None
-if os.path.exists(os.path.join(R, "bench_unprofiled.json")):
-    unprof = json.loads(open(os.path.join(R, "bench_unprofiled.json")).read().strip().splitlines()[-1])
+def jline(name):
+    for l in rd(name).splitlines():
+        if l.startswith("{"):
+            return json.loads(l)
+    return None
+
+
+def pmc_value(name, counter):
+    for l in rd(name).splitlines():
+        m = re.search(r"%s\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)" % counter, l)
+        if m and "cvgs::" in l:
+            return float(m.group(2))
+    return float("nan")
+
+
+def brief(j):
+    return "value %s Mpix/s, ms_per_step %s, roofline.frac %s, frac_of_sector_bound %s, step_us p10/p90 %s/%s" % (
+        j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"].get("frac_of_sector_bound"),
+        j["timing"]["step_us_p10"], j["timing"]["step_us_p90"])
+
+
+b_prof, b_un, b_205, b_m16p, b_m16 = (jline(n) for n in ("bench_trace.json", "bench_unprofiled.json", "bench_unprofiled_20_5.json",
+                                                           "bench_trace_m16.json", "bench_unprofiled_m16.json"))
 with open(os.path.join(P, label + "_k1_bench_kernel_stats.txt"), "w") as f:
     f.write("# %s: rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu --no-extra\n" % label)
-    f.write("# bench line of the SAME (profiled) run: value %s Mpix/s, ms_per_step %s, roofline.kernel_us %s, frac %s\n" % (
-        bench["value"], bench["ms_per_step"], bench["roofline"]["kernel_us"], bench["roofline"]["frac"]))
-    if unprof:
-        f.write("# un-profiled `python bench.py` (separate gpurun call, MI355X box of the same pool): value %s Mpix/s, ms_per_step %s, kernel_us %s, frac %s\n" % (
-            unprof["value"], unprof["ms_per_step"], unprof["roofline"]["kernel_us"], unprof["roofline"]["frac"]))
+    f.write("# bench line of the SAME (profiled) run:   %s\n" % brief(b_prof))
+    f.write("# un-profiled `python bench.py` (same box):  %s\n" % brief(b_un))
+    f.write("# un-profiled driver command (--steps 20 --warmup 5): %s\n" % brief(b_205))
     f.write("# (profiled passes run 10-15 % slower: profiler serialisation + lower clocks, MI355X_MICROARCH.md DVFS note)\n")
-    f.write("# rocprofv3's own kernel stats:\n")
-    f.write(cut("\n".join(open(os.path.join(R, "bench_trace", "t_kernel_stats.csv")).read().splitlines()[:6]), 230))
-    f.write("\n" + cut(cap(prof_summary.kernels, os.path.join(R, "bench_trace", "t_kernel_trace.csv")), 190))
-
+    f.write("# rocprofv3's own kernel stats (first rows):\n")
+    f.write(cut(rd("bench_trace_stats_head.txt"), 230))
+    f.write("\n" + cut(rd("bench_trace_kernels.txt")))
+with open(os.path.join(P, label + "_k1_m16_kernel_stats.txt"), "w") as f:
+    f.write("# %s: 16 independent 50-crop chains per launch (cvgs_execute_many): rocprofv3 --kernel-trace --stats -- python bench.py "
+            "--frames-per-launch 16 --no-cpu --no-extra\n" % label)
+    f.write("# bench line of the profiled run: %s\n# un-profiled:                     %s\n" % (brief(b_m16p), brief(b_m16)))
+    f.write("\n" + cut(rd("bench_trace_m16_kernels.txt")))
 with open(os.path.join(P, label + "_cfg3_cfg4_kernel_stats.txt"), "w") as f:
     f.write("# %s: secondary configs, rocprofv3 --kernel-trace --stats -- python tools/bench_more.py --iters 50\n" % label)
-    f.write(open(os.path.join(R, "more_trace.json")).read())
-    f.write("\n" + cut(cap(prof_summary.kernels, os.path.join(R, "more_trace", "t_kernel_trace.csv")), 190))
+    f.write(rd("more_trace.json"))
+    f.write("\n" + cut(rd("more_trace_kernels.txt")))
+    f.write("\n# u8 -> u8 colour conversions of a 4K frame: rocprofv3 --kernel-trace --stats -- python tools/bench_cvtcolor.py\n")
+    f.write(rd("cvtcolor_trace.json"))
+    f.write("\n" + cut(rd("cvtcolor_trace_kernels.txt")))
+with open(os.path.join(P, label + "_bench_lines.txt"), "w") as f:
+    f.write("# %s: raw bench.py output lines, un-profiled, one MI355X box\n" % label)
+    f.write("## python bench.py --gpus 1 --steps 20 --warmup 5   (the driver's command; with the CPU baseline and every extra sweep)\n")
+    f.write(rd("bench_unprofiled_20_5.json"))
+    f.write("## python bench.py --no-cpu --no-extra\n" + rd("bench_unprofiled.json"))
+    f.write("## python bench.py --frames-per-launch 16 --no-cpu --no-extra\n" + rd("bench_unprofiled_m16.json"))
 
-k1 = {}
+k = {n: (pmc_value("pmc_FETCH_SIZE_%s.txt" % n, "FETCH_SIZE"), pmc_value("pmc_WRITE_SIZE_%s.txt" % n, "WRITE_SIZE")) for n in ("50", "m16", "3200")}
+calA, calB, calC = (pmc_value("calib_FETCH_SIZE_%s.txt" % x, "FETCH_SIZE") for x in "ABC")
+fA, fB, fC = 97200.0 / calA, 364500.0 / calB, 97200.0 / calC
 with open(os.path.join(P, label + "_pmc_hbm.txt"), "w") as f:
-    f.write("# %s: HBM counters (KB), separate --pmc passes, and their calibration on known byte counts (tools/calibrate_pmc.py)\n" % label)
-    for n in (50, 3200):
+    f.write("# %s: HBM counters (KB = 1024 B), separate --pmc passes, and their calibration on known byte counts (tools/calibrate_pmc.py)\n" % label)
+    for n, what in (("50", "K1, 50 crops of one 4K frame per launch (the headline)"), ("m16", "K1, 16 x 50 crops of 16 frames per launch (cvgs_execute_many)"),
+                    ("3200", "K1, 3200 crops of one frame per launch")):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            path = os.path.join(R, "pmc_%s_%d" % (c, n), "p_counter_collection.csv")
-            k1[(n, c)] = pmc_mean(path, "k1_resize_split")
-            f.write("## K1, crops per launch = %d, %s\n" % (n, c))
-            f.write(cut(cap(prof_summary.pmc, path, "k1_resize"), 180))
+            f.write("## %s, %s\n" % (what, c))
+            f.write(cut(rd("pmc_%s_%s.txt" % (c, n)), 180))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f.write("## calibration launches (tools/calibrate_pmc.py), %s\n" % c)
-        f.write(open(os.path.join(R, "calib_%s.txt" % c)).read())
-        f.write(cut(cap(prof_summary.pmc, os.path.join(R, "calib_%s" % c, "p_counter_collection.csv")), 180))
+        for x in "ABC":
+            f.write("## calibration launch %s, %s\n" % (x, c))
+            f.write(cut(rd("calib_%s_%s.txt" % (c, x)), 180))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f.write("## cfg3 / cfg4 kernels (tools/bench_more.py), %s\n" % c)
-        f.write(cut(cap(prof_summary.pmc, os.path.join(R, "more_%s" % c, "p_counter_collection.csv")), 180))
-    cal_k1 = pmc_mean(os.path.join(R, "calib_FETCH_SIZE", "p_counter_collection.csv"), "k1_resize_split")
-    cal_cp = pmc_mean(os.path.join(R, "calib_FETCH_SIZE", "p_counter_collection.csv"), "k_plane_copy")
-    alg50 = bench["roofline"]["algorithmic_bytes_per_launch"]
-    f.write("""# Reading (units KB = 1024 B):
-#  * WRITE_SIZE is exact on every pattern here (K1 identity launch: 398,131,200 B -> 388,800 KB).
-#  * FETCH_SIZE halves 16 B/lane streams: the plane copy reads 373,248,000 B and reports %.0f KB (x%.3f) -- the gfx950
-#    under-report of MI355X_MICROARCH.md; the 12 B/lane pointwise kernel is halved as well.
-#  * K1's 8 B/lane unaligned taps: the identity launch must read >= 99,532,800 B (+ <= 1/16 for rows shared between
-#    16-row tiles) and reports %.0f KB = %.0f B: under-report 1.16x .. 1.24x -> correction x1.2.
-#  * traffic(50 crops)  = %.1f KB x 1.2 + %.1f KB = %.2f MB per launch vs %.2f MB algorithmic
-#    traffic(3200 crops) = %.0f KB x 1.2 + %.0f KB = %.1f MB per launch
-""" % (cal_cp, cal_cp * 1024 / 373248000.0, cal_k1, cal_k1 * 1024, k1[(50, "FETCH_SIZE")], k1[(50, "WRITE_SIZE")],
-       (k1[(50, "FETCH_SIZE")] * 1.2 + k1[(50, "WRITE_SIZE")]) * 1024 / 1e6, alg50 / 1e6, k1[(3200, "FETCH_SIZE")],
-       k1[(3200, "WRITE_SIZE")], (k1[(3200, "FETCH_SIZE")] * 1.2 + k1[(3200, "WRITE_SIZE")]) * 1024 / 1e6))
+        f.write(cut(rd("more_%s_pmc.txt" % c), 180))
+    alg50, sec50 = b_un["roofline"]["algorithmic_bytes_per_launch"], b_un["roofline"]["sector_bound_bytes_per_launch"]
+    algm, secm = b_m16["roofline"]["algorithmic_bytes_per_launch"], b_m16["roofline"]["sector_bound_bytes_per_launch"]
+    f.write("""# Reading:
+#  * WRITE_SIZE is exact on every pattern (A: 398,131,200 B -> 388,800 KB; C: 99,532,800 B -> 97.2-97.7 thousand KB).
+#  * FETCH_SIZE under-reports, by a factor that depends on the access pattern (MI355X_MICROARCH.md, HBM section):
+#      B  16 B/lane streaming copy of 373,248,000 B            reports %.0f KB -> x%.3f
+#      A  K1 identity scale over four 4K frames (dense taps)    reports %.0f KB for >= 97,200 KB -> x%.3f
+#      C  K1 4:1 x 1:1 over the same frames (SPARSE taps, every 64-byte sector still holds a tapped byte)
+#                                                               reports %.0f KB for >= 97,200 KB -> x%.3f
+#    The headline's crops shrink 4.25x on average (w ~ U[32,512] -> 64, h ~ U[64,1024] -> 128): its pattern is C's, with a
+#    minority of dense (up-scaled) crops.  Its reads are therefore bracketed by x%.2f (all dense) and x%.2f (all sparse);
+#    the sector-granular floor (distinct 64-byte sectors holding a tapped byte, cvgpuspeedup_amd/workloads.py) sits inside
+#    the bracket, i.e. the kernel re-fetches little or nothing: the gap to the algorithmic bytes is sector granularity.
+#  * 50 crops:      FETCH %.1f KB -> %.2f .. %.2f MB read, WRITE %.1f KB = %.2f MB;  algorithmic %.2f MB, sector floor %.2f MB per launch
+#    16 x 50 crops: FETCH %.0f KB -> %.1f .. %.1f MB read, WRITE %.0f KB = %.1f MB;  algorithmic %.1f MB, sector floor %.1f MB per launch
+#    3200 crops of ONE frame: FETCH %.0f KB, WRITE %.0f KB (the frame stays in the Infinity Cache; FETCH counts its hits)
+#  * bench.py's roofline.traffic uses the sparse-pattern factor (upper estimate): %.2f MB per 50-crop launch.
+""" % (calB, fB, calA, fA, calC, fC, fA, fC,
+       k["50"][0], k["50"][0] * fA * 1024 / 1e6, k["50"][0] * fC * 1024 / 1e6, k["50"][1], k["50"][1] * 1024 / 1e6, alg50 / 1e6, sec50 / 1e6,
+       k["m16"][0], k["m16"][0] * fA * 1024 / 1e6, k["m16"][0] * fC * 1024 / 1e6, k["m16"][1], k["m16"][1] * 1024 / 1e6, algm / 1e6, secm / 1e6,
+       k["3200"][0], k["3200"][1], (k["50"][0] * fC + k["50"][1]) * 1024 / 1e6))
 
 json.dump({"source": "profiles/%s_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % label,
-           "workload": "cfg2b, 50 crops per launch", "kernel": "k1_resize_split<3,64,1,K1Prog<100,2,4,5>,0>",
-           "fetch_size_kb": round(k1[(50, "FETCH_SIZE")], 2), "write_size_kb": round(k1[(50, "WRITE_SIZE")], 2),
-           "fetch_correction": 1.2,
-           "correction_note": "FETCH_SIZE under-reports K1's 8 B/lane taps by 1.16-1.24x (tools/calibrate_pmc.py); WRITE_SIZE is exact"},
+           "workload": "cfg2b, 50 crops per launch", "kernel": "k1_resize_split<3,64,1,K1Prog<100,2,4,5>,0,float,0,false>",
+           "fetch_size_kb": round(k["50"][0], 2), "write_size_kb": round(k["50"][1], 2),
+           "fetch_correction": round(fC, 3),
+           "correction_note": "FETCH_SIZE under-reports K1's taps: x%.3f on dense (identity-scale) taps, x%.3f on sparse (4:1) taps -- the headline's "
+                              "pattern (tools/calibrate_pmc.py launches A / C); the sparse factor is used (upper estimate); WRITE_SIZE is exact" % (fA, fC)},
           open(os.path.join(P, "pmc_headline.json"), "w"), indent=1)
 print("wrote profiles/%s_*" % label)

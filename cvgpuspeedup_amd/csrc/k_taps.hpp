@@ -230,14 +230,22 @@ __device__ __forceinline__ void unpack_pair(const Win<elem_bytes<SRC>>& w, bool 
 // offset into ONE 64-bit vector base and pays a 64-bit VALU add per access for the uniform row / channel strides.
 template <typename T>
 __device__ __forceinline__ T* pin_uniform(T* p) {
+#ifdef CVGS_NO_PIN
+    return p;
+#else
     uint64_t v = (uint64_t)p;
     asm volatile("" : "+s"(v));
     return (T*)v;
+#endif
 }
 __device__ __forceinline__ gptr_u8 pin_uniform(gptr_u8 p) {
+#ifdef CVGS_NO_PIN
+    return p;
+#else
     uint64_t v = (uint64_t)p;
     asm volatile("" : "+s"(v));
     return (gptr_u8)v;
+#endif
 }
 // element `off_bytes / sizeof(T)` of a pinned row: the lane offset stays a zero-extended 32-bit byte offset
 template <typename T>

@@ -424,4 +424,15 @@ public:
     CUDA_T(O)* data() { return this->ptr_a.data; }
 };
 
+// ---- launch batching (engine extension, see fk::ChainBatch): several independent chains, ONE kernel launch -------------
+class ChainBatch {
+public:
+    template <typename... IOps> void add(const IOps&... iops) { batch_.add(iops...); }
+    void execute(const cv::cuda::Stream& stream) { batch_.execute(cv::cuda::StreamAccessor::getStream(stream)); }
+    void clear() { batch_.clear(); }
+    size_t size() const { return batch_.size(); }
+private:
+    fk::ChainBatch batch_;
+};
+
 } // namespace cvGS

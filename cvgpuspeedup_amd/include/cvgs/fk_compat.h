@@ -650,6 +650,34 @@ inline void executeOperations(hipStream_t stream, const IOps&... iops) {
     detail::check_status(cvgs_execute(&b.d, stream));
 }
 
+// ---- launch batching (engine extension: cvgs_execute_many) -----------------------------------------------------------
+// A 50-crop chain is ~1 us of HBM time behind a ~1.8 us launch floor; a host with several frames in hand (multi-camera
+// serving) records one chain per frame and submits them together: chains of the same K1 shape run as ONE kernel launch,
+// bit-identical to one executeOperations per chain.  The reference's closest spelling is its batch sweep
+// (tests/batchresize/test_batchresize_x_split3D.cu:384-392).
+//     fk::ChainBatch batch;
+//     for (auto& cam : cameras) batch.add(cvGS::resize<...>(cam.crops, size, n), ..., cvGS::split<CV_32FC3>(cam.tensor, size));
+//     batch.execute(stream);          // then batch.clear() and record the next frames
+class ChainBatch {
+public:
+    template <typename... IOps> void add(const IOps&... iops) {
+        if (builders_.size() >= (size_t)CVGS_MAX_CHAINS) throw std::runtime_error("cvGS: more than CVGS_MAX_CHAINS chains in one batch");
+        builders_.emplace_back(new ChainBuilder);
+        lowerChain(*builders_.back(), iops...);
+    }
+    size_t size() const { return builders_.size(); }
+    void clear() { builders_.clear(); }
+    void execute(hipStream_t stream) {
+        if (builders_.empty()) return;
+        descs_.resize(builders_.size());
+        for (size_t i = 0; i < builders_.size(); ++i) descs_[i] = builders_[i]->d; // POD copy; the builders keep the arrays alive
+        detail::check_status(cvgs_execute_many(descs_.data(), (int32_t)descs_.size(), stream));
+    }
+private:
+    std::vector<std::unique_ptr<ChainBuilder>> builders_;
+    std::vector<cvgs_chain_desc> descs_;
+};
+
 // ---- CircularTensor ------------------------------------------------------------------------------------------------
 // MIRRORED (engine extension, default off = the reference's behaviour): the opt-in mirrored-ring layout of
 // cvgs_circular_create_ex -- no shift traffic per update, but ptr()/data() MOVE with every update.

@@ -195,6 +195,41 @@ static void test_pointer_adapters() {
     CHECK(ok, "gpuMat2Ptr2D_arr / gpuMat2RawPtr2D_arr describe the crops (no copy)");
 }
 
+// cvGS::ChainBatch (cvgs_execute_many): four cameras' 50-crop chains in one launch == four executeOperations calls
+static void test_chain_batch(cv::cuda::Stream& stream) {
+    constexpr int CAMS = 4, N = 50;
+    const cv::Size up(64, 128);
+    const cv::Scalar mul(0.3, 0.3, 0.3), sub(1, 4, 3.2), div(3.2, 0.6, 11.8);
+    std::vector<cv::cuda::GpuMat> frames, outs_a, outs_b;
+    std::vector<std::array<cv::cuda::GpuMat, N>> crops(CAMS);
+    for (int c = 0; c < CAMS; ++c) {
+        cv::Mat h(720, 1280, CV_8UC3);
+        fill_random(h, 900 + c);
+        cv::cuda::GpuMat d(720, 1280, CV_8UC3);
+        d.upload(h);
+        frames.push_back(d);
+        for (int i = 0; i < N; ++i) crops[c][i] = frames[c](cv::Rect(3 * i + c, 2 * i, 40 + 7 * i, 60 + 9 * i));
+        outs_a.emplace_back(N, up.width * up.height * 3, CV_32F);
+        outs_b.emplace_back(N, up.width * up.height * 3, CV_32F);
+    }
+    cvGS::ChainBatch batch;
+    for (int c = 0; c < CAMS; ++c) {
+        batch.add(cvGS::resize<CV_8UC3, cv::INTER_LINEAR, N>(crops[c], up, N), cvGS::cvtColor<cv::COLOR_RGB2BGR, CV_32FC3>(),
+                  cvGS::multiply<CV_32FC3>(mul), cvGS::subtract<CV_32FC3>(sub), cvGS::divide<CV_32FC3>(div), cvGS::split<CV_32FC3>(outs_a[c], up));
+        cvGS::executeOperations(stream, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, N>(crops[c], up, N), cvGS::cvtColor<cv::COLOR_RGB2BGR, CV_32FC3>(),
+                                cvGS::multiply<CV_32FC3>(mul), cvGS::subtract<CV_32FC3>(sub), cvGS::divide<CV_32FC3>(div), cvGS::split<CV_32FC3>(outs_b[c], up));
+    }
+    batch.execute(stream);
+    stream.waitForCompletion();
+    bool ok = batch.size() == CAMS;
+    const size_t n = (size_t)N * up.width * up.height * 3 * sizeof(float);
+    for (int c = 0; c < CAMS && ok; ++c) {
+        const auto a = fetch(outs_a[c].data, n), b = fetch(outs_b[c].data, n);
+        ok = bit_equal(a.data(), b.data(), n);
+    }
+    CHECK(ok, "ChainBatch of 4 x 50 crops == 4 executeOperations");
+}
+
 template <int TI, int TO>
 static void sweep(cv::cuda::Stream& stream) {
     test_constant<TI, TO, 10, cvGS::IGNORE_AR>(stream, 60);
@@ -217,6 +252,7 @@ int main() {
     sweep<CV_16SC4, CV_32FC4>(stream);
     test_then_spelling(stream);
     test_pointer_adapters();
+    test_chain_batch(stream);
     test_half_handoff<CV_8UC3, 50>(stream);
     test_half_handoff<CV_8UC4, 17>(stream);
     return report("test_batchresize_x_split3D + aspectratio");

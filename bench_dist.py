@@ -44,7 +44,9 @@ def main(a, dev, rank, world):
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
-    dist.init_process_group("nccl", device_id=dev)
+    import datetime
+    # a rank that dies must not hold the others in a collective for the default 10 minutes
+    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
     n = B.CFG5_CROPS
     plane = 3 * W.DST[0] * W.DST[1]
     fw, fh = W.FRAME_6K
@@ -92,12 +94,22 @@ def main(a, dev, rank, world):
 
     # ---- leg 3: P2P fused write + one tiny all-reduce per step ---------------------------------------------------------
     p2p = {"ok": False}
-    peers = []
+    peers, bases, map_error = [], None, None
+    handles = [None] * world
+    dist.all_gather_object(handles, buf.handle())
+    try:  # purely local: map every peer's allocation into this process
+        bases = []
+        for r in range(world):
+            bases.append(buf.ptr if r == rank else rccl.open_peer(handles[r]))
+            if r != rank:
+                peers.append(bases[-1])
+    except Exception as ex:  # no peer access on this box, IPC refused, ...
+        map_error = repr(ex)
+    mapped = torch.tensor([0 if map_error else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(mapped, op=dist.ReduceOp.MIN)  # every rank takes the same branch below: no collective is entered alone
     try:
-        handles = [None] * world
-        dist.all_gather_object(handles, buf.handle())
-        bases = [buf.ptr if r == rank else rccl.open_peer(handles[r]) for r in range(world)]
-        peers = [b for r, b in enumerate(bases) if r != rank]
+        if int(mapped.item()) != 1:
+            raise RuntimeError(map_error or "a peer could not map the tensors")
         mirrors = [[bases[r] + f * tensor_bytes for r in range(world) if r != rank] for f in range(n_frames)]
         for o in out_all:
             o.zero_()

@@ -397,51 +397,35 @@ class ScratchPool {
 public:
     int acquire(int device, size_t bytes, int* slot_out) {
         std::lock_guard<std::mutex> lk(m_);
-        int free_small = -1;
         for (size_t i = 0; i < slots_.size(); ++i) {
             ScratchSlot& sl = slots_[i];
-            if (sl.device != device || sl.leased) continue;
+            if (sl.device != device || sl.leased || sl.cap < bytes) continue;
             if (sl.pending) {
                 if (hipEventQuery(sl.ev) != hipSuccess) continue;
                 sl.pending = false;
             }
-            if (sl.cap >= bytes) {
-                sl.leased = true;
-                *slot_out = (int)i;
-                return 0;
-            }
-            free_small = (int)i;
+            sl.leased = true;
+            *slot_out = (int)i;
+            return 0;
         }
-        ScratchSlot fresh;
-        ScratchSlot* sl = &fresh;
-        if (free_small >= 0) { // grow an idle slot instead of adding one
-            sl = &slots_[(size_t)free_small];
-            (void)hipHostFree(sl->host);
-            (void)hipFree(sl->dev);
-            sl->host = sl->dev = nullptr;
-        }
+        // nothing free and large enough: add a slot (slots are never freed -- hipFree would synchronise the device; the
+        // pool is bounded by the number of tables in flight at once times the largest table)
+        ScratchSlot sl;
         size_t cap = 64 << 10;
         while (cap < bytes) cap <<= 1;
-        hipError_t e = hipHostMalloc(&sl->host, cap, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc(&sl->dev, cap);
-        if (e == hipSuccess && !sl->ev) e = hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming);
+        hipError_t e = hipHostMalloc(&sl.host, cap, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&sl.dev, cap);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
         if (e != hipSuccess) {
-            if (sl->host) (void)hipHostFree(sl->host);
-            if (sl->dev) (void)hipFree(sl->dev);
-            sl->host = sl->dev = nullptr;
-            sl->cap = 0;
+            if (sl.host) (void)hipHostFree(sl.host);
+            if (sl.dev) (void)hipFree(sl.dev);
             return hip_fail(e, "descriptor scratch allocation");
         }
-        sl->cap = cap;
-        sl->device = device;
-        sl->leased = true;
-        sl->pending = false;
-        if (free_small >= 0) {
-            *slot_out = free_small;
-        } else {
-            slots_.push_back(fresh);
-            *slot_out = (int)slots_.size() - 1;
-        }
+        sl.cap = cap;
+        sl.device = device;
+        sl.leased = true;
+        slots_.push_back(sl);
+        *slot_out = (int)slots_.size() - 1;
         return 0;
     }
     void* host(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].host; }

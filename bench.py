@@ -490,6 +490,28 @@ def extra_sweeps(dev, a):
         # launch batching: M independent 50-crop chains (distinct frames / crop lists / output tensors) in ONE launch
         for M in (1, 4, 16, 64):
             out["frames_per_launch_%d" % M] = sweep_line(dev, 50, per_launch=M, table=True)
+        # the same 16-chain launch as a serving loop submits it: host descriptors (new crop lists every call), eager; every call
+        # lowers 16 x 50 crops, stages 38 KB through the pinned scratch pool and launches once
+        wlh = Workload(dev, 32, 50, 0, 1, use_table=False)
+        arrs = [cvgs.pack_chains(wlh.chains[g * 16:(g + 1) * 16]) for g in range(2)]
+        s0 = torch.cuda.current_stream().cuda_stream
+        for i in range(64):
+            capi.check(wlh.lib.cvgs_execute_many(arrs[i & 1], 16, s0))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(512):
+            capi.check(wlh.lib.cvgs_execute_many(arrs[i & 1], 16, s0))
+        e1.record()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        out["frames_per_launch_16_host_descriptors_eager"] = {
+            "us_per_launch": round(e0.elapsed_time(e1) * 1e3 / 512, 3), "host_enqueue_us_per_call": round((t1 - t0) / 512 * 1e6, 3),
+            "Mpix_per_s": round(16 * 50 * 8192 / (e0.elapsed_time(e1) * 1e-3 / 512) / 1e6, 1),
+            "note": "2 groups of 16 frames (working set inside the Infinity Cache): shows the submission path, not HBM"}
+        del wlh, arrs
+        torch.cuda.empty_cache()
         # the 50-crop batch on 1080p and 6K source frames (the headline uses 4K); crop sizes are clipped to the frame
         out["frame_1080p_50"] = sweep_line(dev, 50, frame_wh=W.FRAME_1080P)
         out["frame_6k_50"] = sweep_line(dev, 50, frame_wh=W.FRAME_6K)

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "cvgs_device.h"
@@ -387,7 +388,8 @@ struct ScratchSlot {
     void* host = nullptr;
     void* dev = nullptr;
     size_t cap = 0;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr;      // recorded behind the kernel that read the slot: the slot is reusable once it completes
+    hipEvent_t copy_ev = nullptr; // recorded behind the host -> device copy on the pool's own copy stream
     int device = -1;
     bool leased = false;  // handed to a call that has not committed yet
     bool pending = false; // committed: reusable once `ev` completes
@@ -416,6 +418,7 @@ public:
         hipError_t e = hipHostMalloc(&sl.host, cap, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc(&sl.dev, cap);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.copy_ev, hipEventDisableTiming);
         if (e != hipSuccess) {
             if (sl.host) (void)hipHostFree(sl.host);
             if (sl.dev) (void)hipFree(sl.dev);
@@ -426,6 +429,25 @@ public:
         sl.leased = true;
         slots_.push_back(sl);
         *slot_out = (int)slots_.size() - 1;
+        return 0;
+    }
+    // The copy runs on the pool's own non-blocking stream (one per device) and the caller's stream only WAITS for it: the
+    // table of call i+1 is uploaded while the kernel of call i still runs, instead of queueing behind it.
+    int copy_to_device(int slot, size_t bytes, hipStream_t user_stream) {
+        std::lock_guard<std::mutex> lk(m_);
+        ScratchSlot& sl = slots_[(size_t)slot];
+        hipStream_t cs = nullptr;
+        for (auto& p : copy_streams_)
+            if (p.first == sl.device) cs = p.second;
+        if (!cs) {
+            hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+            if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(descriptor copies)");
+            copy_streams_.emplace_back(sl.device, cs);
+        }
+        hipError_t e = hipMemcpyAsync(sl.dev, sl.host, bytes, hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipEventRecord(sl.copy_ev, cs);
+        if (e == hipSuccess) e = hipStreamWaitEvent(user_stream, sl.copy_ev, 0);
+        if (e != hipSuccess) return hip_fail(e, "descriptor table upload");
         return 0;
     }
     void* host(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].host; }
@@ -445,6 +467,7 @@ public:
 private:
     std::mutex m_;
     std::vector<ScratchSlot> slots_;
+    std::vector<std::pair<int, hipStream_t>> copy_streams_;
 };
 
 ScratchPool& scratch_pool() {
@@ -514,8 +537,11 @@ struct Upload {
         return d;
     }
     int flush() {
-        hipError_t e = hipMemcpyAsync(dev, scratch_pool().host(slot), used, hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptor table)");
+        DeviceGuard guard;
+        int rc = guard.enter(stream_device(stream));
+        if (rc) return rc;
+        rc = scratch_pool().copy_to_device(slot, used, stream);
+        if (rc) return rc;
         flushed = true;
         return 0;
     }

@@ -71,6 +71,28 @@ def main():
                                    cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 48)), flags=flags)
         torch.cuda.synchronize()
         n_run += 1
+    # u8 colour conversions (16 pixels per thread through the LDS: k_cvtcolor_u8.hip), aligned widths, image at the very end
+    for (w, h, cn, code, ocn) in ((16, 3, 3, cvgs.COLOR_BGR2RGB, 3), (1040, 5, 3, cvgs.COLOR_BGR2BGRA, 4), (2064, 2, 4, cvgs.COLOR_BGRA2BGR, 3),
+                                  (1040, 4, 3, cvgs.COLOR_BGR2GRAY, 1), (4096, 1, 4, cvgs.COLOR_RGBA2GRAY, 1)):
+        a = rng.integers(0, 255, (h, w, cn)).astype(np.uint8)
+        it, ot = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_8U, ocn)
+        m = cvgs.GpuMat(h, w, it, at_end(a), w * cn)
+        o = torch.zeros((h, w, ocn), dtype=torch.uint8, device="cuda")
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, it, [m], 1), cvgs.cvtColor(code, it, ot), cvgs.write(ot, cvgs.GpuMat.from_tensor(o, ot))]
+        assert cvgs.kernel_name(*ops).startswith("pointwise16_u8"), cvgs.kernel_name(*ops)
+        cvgs.executeOperations(s, *ops)
+        torch.cuda.synchronize()
+        n_run += 1
+    # NV21 / planar-chroma surfaces at the very end of an allocation
+    for layout in (capi.YUV_NV21, capi.YUV_I420, capi.YUV_YV12):
+        w, h = 64, 36
+        a = rng.integers(0, 255, (h + h // 2, w)).astype(np.uint8)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, at_end(a), w)
+        out = torch.zeros((1, 3 * 64 * 48), dtype=torch.float32, device="cuda")
+        cvgs.executeOperations(s, cvgs.read_nv12(luma, (64, 48), capi.YUV_FULL, capi.BT709, False, layout=layout),
+                               cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 48)))
+        torch.cuda.synchronize()
+        n_run += 1
     print("no read past the end of any source image: %d configurations ran to completion" % n_run)
 
 

@@ -618,7 +618,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         if (!has_mirrors) { // only K1 and the interpreted kernel write mirrors
             int min_w = 1 << 30;
             for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
-            rc = launch_nv12(L.args, inline_planes, n_inline, min_w, stream, dry_run, info);
+            rc = launch_nv12(L.args, inline_planes, n_inline, min_w, nullptr, 0, stream, dry_run, info);
             if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
             if (rc == 1) { up.done(true); return CVGS_OK; }
             rc = launch_pointwise(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
@@ -638,7 +638,8 @@ bool same_shape(const cvgs_chain_desc& a, const cvgs_chain_desc& b) {
     if (a.flags != b.flags || a.n_ops != b.n_ops) return false;
     const cvgs_read_desc &ra = a.read, &rb = b.read;
     if (ra.kind != rb.kind || ra.src_type != rb.src_type || ra.dst_width != rb.dst_width || ra.dst_height != rb.dst_height ||
-        ra.aspect_ratio != rb.aspect_ratio || std::memcmp(ra.background, rb.background, sizeof(ra.background)) != 0)
+        ra.aspect_ratio != rb.aspect_ratio || std::memcmp(ra.background, rb.background, sizeof(ra.background)) != 0 ||
+        ra.yuv_range != rb.yuv_range || ra.yuv_primaries != rb.yuv_primaries || ra.yuv_alpha != rb.yuv_alpha || ra.yuv_layout != rb.yuv_layout)
         return false;
     for (int k = 0; k < a.n_ops; ++k) {
         const cvgs_op &x = a.ops[k], &y = b.ops[k];
@@ -651,16 +652,18 @@ bool same_shape(const cvgs_chain_desc& a, const cvgs_chain_desc& b) {
 }
 
 int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
-    // try the fused launch: every chain a K1-shaped resize into a planar tensor, all of one shape
+    // try the fused launch: every chain a resize of pixels (K1) or of 4:2:0 surfaces (K4) into a planar tensor, all of one shape
     bool fusable = n >= 2;
     for (int i = 0; fusable && i < n; ++i) {
         const cvgs_chain_desc& c = chains[i];
-        fusable = c.read.kind == CVGS_READ_RESIZE_LINEAR && !(c.flags & CVGS_CHAIN_FORCE_GENERIC) &&
+        fusable = (c.read.kind == CVGS_READ_RESIZE_LINEAR || c.read.kind == CVGS_READ_NV12_RESIZE_LINEAR) &&
+                  !(c.flags & CVGS_CHAIN_FORCE_GENERIC) &&
                   (c.write.kind == CVGS_WRITE_TENSOR_SPLIT || c.write.kind == CVGS_WRITE_TENSOR_T_SPLIT) && same_shape(chains[0], c) &&
                   ((c.read.flags ^ chains[0].read.flags) & CVGS_READ_FLAG_TABLE_ON_DEVICE) == 0;
     }
     if (fusable) {
         const bool tables = (chains[0].read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
+        const bool k4 = chains[0].read.kind == CVGS_READ_NV12_RESIZE_LINEAR;
         ManySeg segs[CVGS_MAX_CHAINS];
         Upload up;
         size_t total_planes = 0;
@@ -673,11 +676,12 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         int rc = lower(&chains[0], false, L0);
         if (rc) return rc;
         {
-            // would K1 take this shape?  (dry run: nothing is enqueued, nothing uploaded)
+            // would the fast kernel take this shape?  (dry run: nothing is enqueued, nothing uploaded)
             ChainArgs probe = L0.args;
             probe.read.table = (const PlaneParams*)(uintptr_t)16;
             const ManySeg one{probe.read.table, probe.write.data, probe.read.batch, probe.read.used};
-            fusable = launch_k1(probe, nullptr, 0, MirrorArgs{}, &one, 1, stream, true, nullptr) == 1;
+            if (k4) fusable = !tables && launch_nv12(probe, nullptr, 0, 1 << 30, &one, 1, stream, true, nullptr) == 1; // K4 checks its planes on the host
+            else fusable = launch_k1(probe, nullptr, 0, MirrorArgs{}, &one, 1, stream, true, nullptr) == 1;
         }
         if (fusable && !tables) {
             rc = up.begin(total_planes * sizeof(PlaneParams) + 16 * (size_t)n, stream);
@@ -688,6 +692,11 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             Lowered& L = i == 0 ? L0 : Li;
             if (i > 0) rc = lower(&chains[i], false, L);
             if (rc) return rc; // nothing enqueued yet
+            if (k4 && (L.args.read.used != L.args.read.batch ||
+                       !k4_planes_eligible(L.planes.data(), (int)L.planes.size(), L.args.read.dst_w, L.args.read.dst_h))) {
+                fusable = false; // e.g. a 2-pixel-wide crop: the one-by-one path sends that chain to the interpreted kernel
+                break;
+            }
             segs[i].batch = L.args.read.batch;
             segs[i].used = L.args.read.used;
             segs[i].out = L.args.write.data;
@@ -702,12 +711,13 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             ChainArgs c = L0.args;
             c.read.batch = max_batch;
             c.read.table = segs[0].table; // non-null: the table variants
-            rc = launch_k1(c, nullptr, 0, MirrorArgs{}, segs, n, stream, false, nullptr);
-            if (rc != 1) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
+            rc = k4 ? launch_nv12(c, nullptr, 0, 1 << 30, segs, n, stream, false, nullptr)
+                    : launch_k1(c, nullptr, 0, MirrorArgs{}, segs, n, stream, false, nullptr);
+            if (rc != 1) return fail(CVGS_ERR_HIP, "fused kernel launch failed");
             up.done(true);
             return CVGS_OK;
         }
-        // not a K1 chain after all (e.g. an integer-typed program): one by one below; nothing was enqueued
+        // not a fast-kernel shape after all (e.g. an integer-typed program): one by one below; nothing was enqueued
     }
     for (int i = 0; i < n; ++i) {
         Lowered L;

@@ -155,8 +155,9 @@ int launch_generic64(const ChainArgs& c, const Prog64Args& p64, const PlaneParam
                      bool dry_run, LaunchInfo* info);
 
 // K4 fast path: NV12 read-back fused into the bilinear resize -> program -> planar fp32 tensor or packed pixels.
-int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, void* stream,
-                bool dry_run, LaunchInfo* info);
+int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, const ManySeg* segs, int n_segs,
+                void* stream, bool dry_run, LaunchInfo* info);
+bool k4_planes_eligible(const PlaneParams* planes, int n, int dst_w, int dst_h);
 
 // Thread-fused pointwise chains on u8 sources (4 pixels per thread) -> fp32 planar / packed.
 int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,

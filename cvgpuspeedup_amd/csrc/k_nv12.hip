@@ -29,7 +29,13 @@ struct N12Geom {
     // optional second planar target with its own strides (CircularTensor push: history ring + ordered tensor)
     uint8_t* out2;
     int64_t img_stride2, ch_stride2;
+    uint32_t col_tiles; // NPL == 0 (fused chains): blockIdx.x = row group * col_tiles + column tile
+    uint32_t pad;
 };
+
+// NPL > 0: the planes travel in the kernel arguments, grid = (column tiles, row groups, planes).  NPL == 0: the chains of a
+// cvgs_execute_many launch, planes in per-chain device tables, grid = (column tiles x row groups, planes, chains).
+template <int NPL> using K4Args = std::conditional_t<NPL == 0, KernArgsMany, KernArgs<NPL>>;
 
 using N12SwapMulSubDiv = ProgSwapMulSubDiv; // the compile-time program of k_taps.hpp (incl. the division by the uniform divisor)
 
@@ -47,17 +53,34 @@ __device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k,
 }
 
 template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3>
-__global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, const N12Geom g) {
+__global__ __launch_bounds__(256) void k4_nv12_resize(const K4Args<NPL> a, const N12Geom g) {
     const ChainArgs& c = a.c;
-    const int z = (int)blockIdx.z;
     const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
     PlaneParams P;
-    if constexpr (NPL == 0) P = c.read.table[z];
-    else P = a.planes[z];
+    int z, col_tile, row_group;
+    uint8_t* out_base;
+    if constexpr (NPL == 0) {
+        z = (int)blockIdx.y;
+        const ManySeg sg = a.seg[blockIdx.z];
+        if (z >= sg.batch) return; // a shorter chain of the fused launch
+        P = sg.table[z];
+        out_base = sg.out;
+        col_tile = 0;
+        row_group = (int)blockIdx.x;
+        if (g.col_tiles > 1) { // the quotient comes out of the VALU: hand it back to the scalar side explicitly
+            col_tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % g.col_tiles));
+            row_group = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / g.col_tiles));
+        }
+    } else {
+        z = (int)blockIdx.z;
+        P = a.planes[z];
+        out_base = g.out;
+        col_tile = (int)blockIdx.x;
+        row_group = (int)blockIdx.y;
+    }
     const int yuv_range = c.read.yuv_range, yuv_prim = c.read.yuv_primaries, packed = g.packed;
     const bool vu = c.read.yuv_layout == CVGS_YUV_NV21; // wave-uniform: the chroma pair is (V,U)
     const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
-    uint8_t* const out_base = g.out;
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
                  op2 = *(const f32x4s*)c.prog.operand[2], op3 = *(const f32x4s*)c.prog.operand[3];
@@ -69,8 +92,8 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
-    const int x = (int)blockIdx.x * 64 + lane;
-    const int row0 = ((int)blockIdx.y * 4 + wave) * RPW;
+    const int x = col_tile * 64 + lane;
+    const int row0 = (row_group * 4 + wave) * RPW;
     if (row0 >= dst_h || x >= dst_w) return;
 
     // column geometry (once per lane, reused for every row)
@@ -199,15 +222,33 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const KernArgs<NPL> a, con
     }
 }
 
+// the chains of a cvgs_execute_many launch (set by launch_nv12 for the instantiation it picks)
+struct N12Many {
+    const ManySeg* segs;
+    int n_segs;
+};
+static N12Many& tls_many() {
+    static thread_local N12Many m{nullptr, 0};
+    return m;
+}
+
 template <class Prog, typename OT, int RPW, int CN>
-static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
-    const dim3 grid((g.dst_w + 63) / 64, (g.dst_h + 4 * RPW - 1) / (4 * RPW), c.read.batch);
-    if (c.read.table) {
-        KernArgs<0> a;
+static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g_in, hipStream_t s) {
+    N12Geom g = g_in;
+    const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + 4 * RPW - 1) / (4 * RPW));
+    g.col_tiles = col_tiles;
+    g.pad = 0;
+    const N12Many& many = tls_many();
+    if (many.segs) {
+        KernArgsMany a;
         a.c = c;
-        a.planes[0] = PlaneParams{};
+        for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
+        const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
         hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN>), grid, dim3(256), 0, s, a, g);
-    } else if (ni <= 8) {
+        return hipGetLastError();
+    }
+    const dim3 grid(col_tiles, row_groups, c.read.batch);
+    if (ni <= 8) {
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
@@ -230,8 +271,20 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
-int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, int min_width, void* stream,
-                bool dry_run, LaunchInfo* info) {
+// Can K4 serve these planes?  Stretch geometry only (aspect-ratio padding is the interpreted kernel's business) and rows wide
+// enough for the 4-byte chroma window.
+bool k4_planes_eligible(const PlaneParams* planes, int n, int dst_w, int dst_h) {
+    for (int i = 0; i < n; ++i) {
+        const PlaneParams& P = planes[i];
+        if (P.w < 4 || P.x1 != 0 || P.y1 != 0 || P.x2 != dst_w - 1 || P.y2 != dst_h - 1) return false;
+    }
+    return true;
+}
+
+// `segs` (n_segs >= 1): the chains of a cvgs_execute_many launch -- their planes live in device tables that the caller
+// has checked with k4_planes_eligible; c_in.read.batch is the largest batch.  nullptr: one chain (inline_planes).
+int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, int min_width, const ManySeg* segs, int n_segs,
+                void* stream, bool dry_run, LaunchInfo* info) {
     const ReadArgs& r = c_in.read;
     // fp16 planar tensors: the trailing CAST(CV_16F) moves into the store
     const bool planar_kind = c_in.write.kind == CVGS_WRITE_TENSOR_SPLIT || c_in.write.kind == CVGS_WRITE_TENSOR_T_SPLIT;
@@ -247,16 +300,19 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     const ChainArgs& c = f16 ? c_cut : c_in;
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
     if (r.yuv_layout > CVGS_YUV_NV21) return 0; // planar chroma (I420 / YV12): the interpreted kernel
-    if (r.table || n_inline > CVGS_KERNARG_PLANES || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
-    if (r.used != r.batch || r.batch > 65535) return 0;
-    for (int i = 0; i < n_inline; ++i) { // aspect-ratio padding is the generic kernel's business
-        const PlaneParams& P = inline_planes[i];
-        if (P.x1 != 0 || P.y1 != 0 || P.x2 != r.dst_w - 1 || P.y2 != r.dst_h - 1) return 0;
+    if (segs) {
+        if (n_segs < 1 || n_segs > CVGS_MAX_CHAINS || c_in.write.data2) return 0;
+    } else {
+        if (r.table || n_inline > CVGS_KERNARG_PLANES || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
+        if (r.used != r.batch) return 0;
+        if (!k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h)) return 0;
     }
+    if (r.batch > 65535) return 0;
     const WriteArgs& w = c.write;
     const bool planar = planar_kind && (w.depth == CVGS_DEPTH_32F || f16);
     const bool packed = w.kind == CVGS_WRITE_PIXEL_2D || w.kind == CVGS_WRITE_PIXEL_3D;
     if (!planar && !packed) return 0;
+    if (segs && !planar) return 0; // fused chains: planar tensors only
 
     N12Geom g;
     g.dst_w = r.dst_w; g.dst_h = r.dst_h; g.out_w = w.width; g.cn = r.out_cn;
@@ -276,6 +332,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     c_fd.prog.fast_div = 0;
     for (int k = 0; k < 4; ++k) c_fd.prog.rdiv[k] = 0.f;
     if (fast_prog) fast_div_setup(c_fd.prog, 3, 1, r.out_cn, r.bg);
+    tls_many() = N12Many{segs, n_segs};
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c_fd, inline_planes, n_inline, g, s)

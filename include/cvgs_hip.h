@@ -266,10 +266,11 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
 /* n_chains INDEPENDENT chains -- distinct source frames, crop lists and output tensors -- in as few launches as
  * possible.  A 50-crop chain moves ~9 MB, about 1 us of HBM time behind a ~1.8 us launch/drain floor;
  * a serving loop with several cameras amortises that floor by submitting its frames together.  Chains whose read is
- * a bilinear resize of 8U/16U/16S/32F pixels into a planar fp32 / fp16 tensor (the K1 shape), and that agree in
+ * a bilinear resize of 8U/16U/16S/32F pixels, or of NV12 / NV21 surfaces or crops of them (host descriptors), into a planar
+ * fp32 / fp16 tensor (the K1 / K4 shapes), and that agree in
  * everything except read.src / batch / used_planes and write.data / planes (same source type, target size,
- * aspect-ratio mode, background, pointwise stages and operands, write kind and type), are fused into ONE launch of the K1
- * kernel: grid z = chain, grid y = crop.  Results are bit-identical to n_chains separate cvgs_execute calls (same
+ * aspect-ratio mode, background, YUV range / primaries / layout, pointwise stages and operands, write kind and type), are
+ * fused into ONE launch of the K1 (or K4) kernel: grid z = chain, grid y = crop.  Results are bit-identical to n_chains separate cvgs_execute calls (same
  * kernel code; tests/test_gpu_many.py).  Any other set of chains is executed one by one, in order.  Host descriptors
  * are staged through a pinned pool and copied stream-ordered (not capturable: pass device plane tables, then the call
  * is capturable); at most CVGS_MAX_CHAINS chains per call.  The reference's closest spelling is the batch sweep of

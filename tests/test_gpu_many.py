@@ -162,3 +162,74 @@ def test_mirrors_receive_the_same_rows(oracle, device, n_mirrors, flags):
         got = t.cpu().numpy()
         H.assert_bit_exact(got[rank * n:(rank + 1) * n], ref, "mirror %d" % i)
         assert (got[:rank * n] == -5.0).all() and (got[(rank + 1) * n:] == -5.0).all(), "mirror %d: rows of other ranks touched" % i
+
+
+# ---- fused NV12 chains (K4) --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21])
+@pytest.mark.parametrize("n_cams,crops_per,ragged", [(4, 12, False), (6, 50, True), (16, 5, False)])
+def test_execute_many_nv12_crop_chains(oracle, device, layout, n_cams, crops_per, ragged):
+    """The decode-side form of the batched-crop path: every camera hands over an NV12 (or NV21) decoder surface and a crop
+    list; cvgs_execute_many turns them into ONE launch of the K4 kernel -- bit-identical to one launch per camera and to
+    the oracle."""
+    import torch
+    w, h = 640, 360
+    f = cvgs.CV_32FC3
+    chains, outs, refs, keep = [], [], [], []
+    for cam in range(n_cams):
+        n = crops_per if not ragged else max(1, crops_per - 5 * cam)
+        surf = H.random_u8((h + h // 2, w), seed=800 + cam)
+        st = torch.from_numpy(surf).to(device)
+        rects = [(x & ~1, y & ~1, max(4, cw & ~1), max(2, ch & ~1)) for (x, y, cw, ch) in H.random_crops(n, w, h, seed=850 + cam, wmin=4, wmax=300, hmin=4, hmax=300)]
+        ot = torch.full((n, 3 * 64 * 128), -3.0, dtype=torch.float32, device=device)
+        ref = np.full((n, 3 * 64 * 128), -3.0, np.float32)
+
+        def chain(wrap_s, wrap_o, out):
+            m = wrap_s(surf)
+            luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
+            return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], (64, 128), capi.YUV_LIMITED, capi.BT709, False, layout=layout),
+                    cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]),
+                    cvgs.split(f, wrap_o(out), (64, 128))]
+
+        chains.append(chain(lambda a: cvgs.GpuMat.from_tensor(st, cvgs.CV_8UC1), lambda o: cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), ot))
+        oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), lambda o: cvgs.GpuMat.from_array(o, cvgs.CV_32FC1), ref)))
+        outs.append(ot)
+        refs.append(ref)
+        keep.append(st)
+    assert cvgs.kernel_name(*chains[0]).startswith("k4_nv12_resize")
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    for cam in range(n_cams):
+        H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "fused NV12 chains, camera %d" % cam)
+        outs[cam].fill_(-3.0)
+    for ops in chains:
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    for cam in range(n_cams):
+        H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "one launch per camera, camera %d" % cam)
+
+
+def test_execute_many_nv12_with_a_narrow_crop_falls_back(oracle, device):
+    """A 2-pixel-wide crop is not K4's (its chroma window needs 4 bytes): the set is executed one by one, same results."""
+    import torch
+    w, h = 64, 32
+    f = cvgs.CV_32FC3
+    surf = H.random_u8((h + h // 2, w), seed=77)
+    st = torch.from_numpy(surf).to(device)
+    outs, refs, chains = [], [], []
+    for rects in ([(0, 0, 16, 8), (2, 2, 2, 4)], [(4, 4, 20, 10), (8, 0, 40, 30)]):
+        ot = torch.zeros((2, 3 * 32 * 16), dtype=torch.float32, device=device)
+        ref = np.zeros((2, 3 * 32 * 16), np.float32)
+
+        def chain(wrap_s, wrap_o, out):
+            m = wrap_s(surf)
+            luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
+            return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], (32, 16), capi.YUV_FULL, capi.BT601, False), cvgs.split(f, wrap_o(out), (32, 16))]
+
+        chains.append(chain(lambda a: cvgs.GpuMat.from_tensor(st, cvgs.CV_8UC1), lambda o: cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), ot))
+        oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), lambda o: cvgs.GpuMat.from_array(o, cvgs.CV_32FC1), ref)))
+        outs.append(ot)
+        refs.append(ref)
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    for i in range(2):
+        H.assert_bit_exact(outs[i].cpu().numpy(), refs[i], "fallback chain %d" % i)

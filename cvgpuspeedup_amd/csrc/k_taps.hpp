@@ -152,7 +152,7 @@ template <int EB>
 __device__ __forceinline__ Win<EB> load_win(gptr_u8 p) {
     Win<EB> w;
     if constexpr (EB == 1) {
-        w.lo = *(gptr_u64)p;
+        w.lo = *(gptr_u64)p; // plain, cached: neighbouring lanes and rows share lines (non-temporal loads measured 8 % slower at 16 x 50 crops, 24 % at 3200)
     } else {
         const u32x4 v = *(gptr_u32x4)p;
         w.lo = ((uint64_t)v.y << 32) | v.x;

@@ -9,7 +9,8 @@
 // CDNA4 mapping.  Measured (profiles/, tools/k1_ab.py): a 50-crop launch is latency bound (an EMPTY 1600-workgroup
 // launch already costs 1.76 us of the ~5 us), a 3200-crop launch is HBM bound (mixed read/write traffic at ~4.9 TB/s
 // real); the VALU work hides under both.  Hence:
-//  * lane = output column, wave = RPW consecutive output rows of one crop, blockIdx.y = crop (no integer division).
+//  * lane = output column, wave = RPW consecutive output rows of one crop, workgroup = kK1Waves such waves, blockIdx.y = crop
+//    (no integer division).
 //    Column geometry (x1, the two x weights, the byte window) is computed once per lane and reused for every row;
 //    row geometry is wave-uniform (SGPRs).
 //  * every kernel-argument field and the crop's PlaneParams are fetched in ONE batch of scalar loads before the
@@ -36,6 +37,14 @@ namespace cvgs {
 // single-image chains of the reference's resize tests (tests/resize/test_resize_write.cu: resize -> convertTo<32F,8U> ->
 // write; tests/resize/test_resize_x_split.cu: resize -> mul -> sub -> div -> split(vector<GpuMat>)).
 enum { WM_PLANAR = 0, WM_PACKED = 1, WM_SPLIT2D = 2 };
+
+// waves per workgroup (each wave owns RPW output rows of 64 columns; waves of a workgroup share nothing, so this only sets
+// the dispatch granularity).  Round-2 A/B (-DCVGS_K1_WPB=1/2/4/8): the 50-crop launch 4.48 / 4.34 / 4.40 / 4.55 us,
+// 16 x 50 crops 38.4 us for 2 and 4, whole-frame resizes within noise -> 2 (128-thread workgroups).
+#ifndef CVGS_K1_WPB
+#define CVGS_K1_WPB 2
+#endif
+constexpr int kK1Waves = CVGS_K1_WPB;
 
 struct K1Geom {
     uint32_t col_tiles;  // ceil(dst_w / 64)
@@ -112,7 +121,7 @@ __device__ __forceinline__ void k1_store_other(const K1Geom& g, const ChainArgs&
 
 // MIR: the instantiations that also write cvgs_write_desc.mirrors (kept out of the others' code)
 template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR, bool MIR = false>
-__global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, const K1Geom g) {
+__global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(const K1Args<NPL> a, const K1Geom g) {
     constexpr int EB = elem_bytes<SRC>;
     constexpr int WINB = SRC == SRC_F32 ? 2 * CN * 4 : 8 * EB; // bytes per tap window (fp32: exactly the pixel pair)
     const ChainArgs& c = a.c;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256) void k1_resize_split(const K1Args<NPL> a, cons
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const int x = col_tile * 64 + lane;
-    const int row0 = (row_tile * 4 + wave) * RPW;
+    const int row0 = (row_tile * kK1Waves + wave) * RPW;
     if (row0 >= dst_h || x >= dst_w) return;
     OT* const out = out_base + (int64_t)z * img_stride;
     OT* const out2 = out2_base ? out2_base + (int64_t)z * img_stride2 : nullptr; // wave-uniform
@@ -337,7 +346,7 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         }
     }
     K1Geom g;
-    const int rows_per_wg = 4 * RPW;
+    const int rows_per_wg = kK1Waves * RPW;
     g.col_tiles = (uint32_t)((c.read.dst_w + 63) / 64);
     const uint32_t row_tiles = (uint32_t)((c.read.dst_h + rows_per_wg - 1) / rows_per_wg);
     g.dst_w = c.read.dst_w;
@@ -366,7 +375,7 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
     }
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
-    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(256), 0, stream, a, g);
+    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, a, g);
     return hipGetLastError();
 }
 

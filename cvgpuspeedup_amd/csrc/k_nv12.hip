@@ -37,6 +37,12 @@ struct N12Geom {
 // cvgs_execute_many launch, planes in per-chain device tables, grid = (column tiles x row groups, planes, chains).
 template <int NPL> using K4Args = std::conditional_t<NPL == 0, KernArgsMany, KernArgs<NPL>>;
 
+// waves per workgroup (see k_k1.hip): an A/B build may override it
+#ifndef CVGS_K4_WPB
+#define CVGS_K4_WPB 4
+#endif
+constexpr int kK4Waves = CVGS_K4_WPB;
+
 using N12SwapMulSubDiv = ProgSwapMulSubDiv; // the compile-time program of k_taps.hpp (incl. the division by the uniform divisor)
 
 // RPW output rows per wave (the launcher uses 1, see launch_n12); CN output channels (3, or 4 with alpha).
@@ -53,7 +59,7 @@ __device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k,
 }
 
 template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3>
-__global__ __launch_bounds__(256) void k4_nv12_resize(const K4Args<NPL> a, const N12Geom g) {
+__global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL> a, const N12Geom g) {
     const ChainArgs& c = a.c;
     const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
     PlaneParams P;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void k4_nv12_resize(const K4Args<NPL> a, const
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const int x = col_tile * 64 + lane;
-    const int row0 = (row_group * 4 + wave) * RPW;
+    const int row0 = (row_group * kK4Waves + wave) * RPW;
     if (row0 >= dst_h || x >= dst_w) return;
 
     // column geometry (once per lane, reused for every row)
@@ -235,7 +241,7 @@ static N12Many& tls_many() {
 template <class Prog, typename OT, int RPW, int CN>
 static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g_in, hipStream_t s) {
     N12Geom g = g_in;
-    const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + 4 * RPW - 1) / (4 * RPW));
+    const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + kK4Waves * RPW - 1) / (kK4Waves * RPW));
     g.col_tiles = col_tiles;
     g.pad = 0;
     const N12Many& many = tls_many();
@@ -244,7 +250,7 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         a.c = c;
         for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
-        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
         return hipGetLastError();
     }
     const dim3 grid(col_tiles, row_groups, c.read.batch);
@@ -252,12 +258,12 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     } else { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     }
     return hipGetLastError();
 }

@@ -293,7 +293,6 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
 
     // ---- pointwise stages ----
     ProgArgs& Pg = L.args.prog;
-    bool uses_16f = sdepth == CVGS_DEPTH_16F;
     int n = 0;
     for (int k = 0; k < ch->n_ops; ++k) {
         if (ch->ops[k].opcode == CVGS_OP_NOP) continue;
@@ -305,7 +304,6 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         }
         const bool is_cast = ch->ops[k].opcode == CVGS_OP_CAST || ch->ops[k].opcode == CVGS_OP_CAST_TRUNC;
         if (is_cast && ch->ops[k].aux == CVGS_DEPTH_64F) L.uses_64f = true;
-        if (is_cast && ch->ops[k].aux == CVGS_DEPTH_16F) uses_16f = true;
         ++n;
     }
     Pg.n = n;
@@ -313,7 +311,6 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     int rc = walk_program(ch, d0, R.out_cn, &L.final_depth, &L.final_cn);
     if (rc) return rc;
     if (sdepth == CVGS_DEPTH_64F || L.final_depth == CVGS_DEPTH_64F) L.uses_64f = true;
-    if (L.uses_64f && uses_16f) return fail(CVGS_ERR_UNSUPPORTED, "chains mixing CV_64F and CV_16F");
 
     // ---- write stage ----
     if (wr.kind < CVGS_WRITE_PIXEL_2D || wr.kind > CVGS_WRITE_PIXEL_2D_BATCH) return fail(CVGS_ERR_INVALID, "bad write kind");
@@ -560,7 +557,8 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
     // how many bytes of descriptors exceed the kernel-argument block?
     const bool warp = is_warp(L.args.read.kind);
     const int inline_cap = L.uses_64f ? kInline64 : CVGS_KERNARG_PLANES;
-    const bool up_src = warp ? (int)L.warp_planes.size() > kInlineWarp : (!L.args.read.table && (int)L.planes.size() > inline_cap);
+    const bool up_src = warp ? (int)L.warp_planes.size() > (L.uses_64f ? kInlineWarp64 : kInlineWarp)
+                             : (!L.args.read.table && (int)L.planes.size() > inline_cap);
     const bool up_dst = (int)L.dst_planes.size() > kInlineDst;
     if (!dry_run && (up_src || up_dst)) {
         const size_t bytes = (up_src ? (warp ? L.warp_planes.size() * sizeof(WarpPlane) : L.planes.size() * sizeof(PlaneParams)) : 0) +
@@ -578,7 +576,6 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         }
     }
     if (warp) {
-        if (L.uses_64f) return fail(CVGS_ERR_UNSUPPORTED, "warp chains on CV_64F values");
         if (has_mirrors) return fail(CVGS_ERR_UNSUPPORTED, "mirrors on warp chains");
         const WarpPlane* dev = nullptr;
         const int n = (int)L.warp_planes.size();
@@ -587,7 +584,11 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
             int rc = up.flush();
             if (rc) return rc;
         }
-        if (launch_warp(L.args, L.warp_planes.data(), n, dev, ch->flags, stream, dry_run, info)) return fail(CVGS_ERR_HIP, "warp kernel launch failed");
+        if (L.uses_64f) {
+            if (launch_warp64(L.args, L.p64, L.warp_planes.data(), n, dev, stream, dry_run, info)) return fail(CVGS_ERR_HIP, "warp kernel launch failed");
+        } else if (launch_warp(L.args, L.warp_planes.data(), n, dev, ch->flags, stream, dry_run, info)) {
+            return fail(CVGS_ERR_HIP, "warp kernel launch failed");
+        }
         up.done(true);
         return CVGS_OK;
     }

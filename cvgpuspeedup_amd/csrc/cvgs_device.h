@@ -175,6 +175,11 @@ static constexpr int kInlineWarp = 56; // planes whose WarpPlane travels in the 
 int launch_warp(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* dev_table, uint32_t chain_flags, void* stream,
                 bool dry_run, LaunchInfo* info);
 
+// warp reads in front of a CV_64F program (k_generic64.hip)
+static constexpr int kInlineWarp64 = 8;
+int launch_warp64(const ChainArgs& c, const Prog64Args& p64, const WarpPlane* planes, int n, const WarpPlane* dev_table, void* stream,
+                  bool dry_run, LaunchInfo* info);
+
 // plane-to-plane copies of the CircularTensor update (K9): dst[i] <- src[i], `bytes` each
 struct CopyJob {
     const uint8_t* src;

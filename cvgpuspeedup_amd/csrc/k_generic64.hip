@@ -35,7 +35,14 @@ __device__ __forceinline__ void int_range64(int depth, double& lo, double& hi) {
 
 template <bool TRUNC = false>
 __device__ __forceinline__ void cast64(Px64& p, int cn, int src, int dst) {
+    if (src == CVGS_DEPTH_16F) src = CVGS_DEPTH_32F; // a half value is carried as the float (double) it equals
     if (src == dst || dst == CVGS_DEPTH_64F) return; // widening to double is exact
+    if (dst == CVGS_DEPTH_16F) { // through float, then round to nearest even once more (the oracle's order: (float)d, then half)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < cn) p.v[c] = (double)round_half((float)p.v[c]);
+        return;
+    }
     if (dst == CVGS_DEPTH_32F) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -115,6 +122,7 @@ __device__ __forceinline__ void load64(const uint8_t* row, int depth, int cn, in
             case CVGS_DEPTH_16S: p.v[c] = (double)((const int16_t*)row)[e]; break;
             case CVGS_DEPTH_32S: p.v[c] = (double)((const int32_t*)row)[e]; break;
             case CVGS_DEPTH_32F: p.v[c] = (double)((const float*)row)[e]; break;
+            case CVGS_DEPTH_16F: p.v[c] = (double)(float)((const _Float16*)row)[e]; break;
             default: p.v[c] = ((const double*)row)[e]; break;
             }
         }
@@ -129,6 +137,7 @@ __device__ __forceinline__ void store64(uint8_t* base, size_t idx, int depth, do
     case CVGS_DEPTH_16S: ((int16_t*)base)[idx] = (int16_t)v; break;
     case CVGS_DEPTH_32S: ((int32_t*)base)[idx] = (int32_t)v; break;
     case CVGS_DEPTH_32F: ((float*)base)[idx] = (float)v; break;
+    case CVGS_DEPTH_16F: ((_Float16*)base)[idx] = (_Float16)(float)v; break;
     default: ((double*)base)[idx] = v; break;
     }
 }
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(256) void k_generic64(const KernArgs64<NPL> a) {
     int cn = r.out_cn;
     if (z >= r.used) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p.v[k] = depth == CVGS_DEPTH_32S ? (double)(int)r.bg[k] : (double)r.bg[k];
+        for (int k = 0; k < 4; ++k)
+            p.v[k] = depth == CVGS_DEPTH_32S ? (double)(int)r.bg[k] : (depth == CVGS_DEPTH_16F ? (double)round_half(r.bg[k]) : (double)r.bg[k]);
     } else {
         PlaneParams P;
         if constexpr (NPL == 0) P = r.table[z];
@@ -278,6 +288,102 @@ int launch_generic64(const ChainArgs& c, const Prog64Args& p64, const PlaneParam
         a.p64 = p64;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < n_inline ? inline_planes[i] : PlaneParams{};
         hipLaunchKernelGGL(k_generic64<8>, grid, block, 0, s, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- warp reads in front of a CV_64F program ---------------------------------------------------------------------------
+// cvGS::warp produces CV_32F values (k_warp.hip holds the read's arithmetic, restated here unchanged); a chain that then
+// detours through CV_64F (convertTo<CV_32FC3, CV_64FC3>, arithmetic on doubles, ...) needs the double work registers of this
+// file.  Not a hot path: one thread per output pixel, interpreted program.
+template <int NPL>
+struct WarpKernArgs64 {
+    ChainArgs c;
+    Prog64Args p64;
+    WarpPlane planes[NPL > 0 ? NPL : 1];
+};
+
+template <int NPL>
+__global__ __launch_bounds__(256) void k_warp64(const WarpKernArgs64<NPL> a, const WarpPlane* __restrict__ table) {
+    const ChainArgs& c = a.c;
+    const ReadArgs& r = c.read;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int z = blockIdx.z;
+    if (x >= r.dst_w || y >= r.dst_h) return;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (z >= r.used) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = r.bg[k];
+    } else {
+        WarpPlane P;
+        if constexpr (NPL == 0) P = table[z];
+        else P = a.planes[z];
+        const float fx = (float)x, fy = (float)y;
+        float sx = (P.m[0] * fx + P.m[1] * fy) + P.m[2];
+        float sy = (P.m[3] * fx + P.m[4] * fy) + P.m[5];
+        if (r.kind == CVGS_READ_WARP_PERSPECTIVE) {
+            const float w = (P.m[6] * fx + P.m[7] * fy) + P.m[8];
+            sx = sx / w;
+            sy = sy / w;
+        }
+        if (sx >= 0.f && sx < (float)P.w && sy >= 0.f && sy < (float)P.h) {
+            const int x1 = (int)floorf(sx), y1 = (int)floorf(sy);
+            const int x2 = x1 + 1, y2 = y1 + 1;
+            const int x2r = min(x2, P.w - 1), y2r = min(y2, P.h - 1);
+            Px p00, p10, p01, p11;
+            const uint8_t* ra = P.data + (size_t)y1 * (size_t)P.step;
+            const uint8_t* rb = P.data + (size_t)y2r * (size_t)P.step;
+            load_px(ra, r.depth, r.cn, x1, p00);
+            load_px(ra, r.depth, r.cn, x2r, p10);
+            load_px(rb, r.depth, r.cn, x1, p01);
+            load_px(rb, r.depth, r.cn, x2r, p11);
+            const float w00 = ((float)x2 - sx) * ((float)y2 - sy);
+            const float w10 = (sx - (float)x1) * ((float)y2 - sy);
+            const float w01 = ((float)x2 - sx) * (sy - (float)y1);
+            const float w11 = (sx - (float)x1) * (sy - (float)y1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < r.cn) {
+                    float acc = tap_f(p00.v[k], r.depth) * w00;
+                    acc = acc + tap_f(p10.v[k], r.depth) * w10;
+                    acc = acc + tap_f(p01.v[k], r.depth) * w01;
+                    acc = acc + tap_f(p11.v[k], r.depth) * w11;
+                    v[k] = acc;
+                }
+            }
+        }
+    }
+    Px64 p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.v[k] = (double)v[k];
+    int depth = CVGS_DEPTH_32F, cn = r.out_cn;
+    for (int k = 0; k < c.prog.n; ++k)
+        apply_op64(c.prog.opcode[k], c.prog.aux[k], c.prog.operand[k], a.p64.operand[k], p, depth, cn);
+    const DstPlane* dst = c.write.table ? c.write.table : c.dst_inline;
+    write64(c.write, dst, x, y, z, p, depth, cn);
+}
+
+// `planes`: host array of n (inline when n <= kInlineWarp64), else `dev_table` (device copy)
+int launch_warp64(const ChainArgs& c, const Prog64Args& p64, const WarpPlane* planes, int n, const WarpPlane* dev_table, void* stream,
+                  bool dry_run, LaunchInfo* info) {
+    if (info) info->kernel = dev_table ? "warp64_table" : "warp64_inline8";
+    if (dry_run) return 0;
+    const dim3 block(64, 4, 1);
+    const dim3 grid((c.read.dst_w + 63) / 64, (c.read.dst_h + 3) / 4, c.read.batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (dev_table) {
+        WarpKernArgs64<0> a;
+        a.c = c;
+        a.p64 = p64;
+        a.planes[0] = WarpPlane{};
+        hipLaunchKernelGGL(k_warp64<0>, grid, block, 0, s, a, dev_table);
+    } else {
+        WarpKernArgs64<kInlineWarp64> a;
+        a.c = c;
+        a.p64 = p64;
+        for (int i = 0; i < kInlineWarp64; ++i) a.planes[i] = i < n ? planes[i] : WarpPlane{};
+        hipLaunchKernelGGL(k_warp64<kInlineWarp64>, grid, block, 0, s, a, (const WarpPlane*)nullptr);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

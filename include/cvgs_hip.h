@@ -58,7 +58,8 @@ typedef enum cvgs_status {
  *   type = depth + ((channels-1) << 3),  depth: 8U=0 8S=1 16U=2 16S=3 32S=4 32F=5 64F=6 16F=7
  * CV_16F (IEEE binary16) is this engine's half-precision hand-off option (the reference has no
  * half type): a storage format only -- per-pixel read source, CAST target (round-to-nearest-even, overflow to
- * +-inf, like cv::saturate_cast<cv::float16_t>) and write type; arithmetic stages need a CAST to CV_32F first.  */
+ * +-inf, like cv::saturate_cast<cv::float16_t>) and write type; arithmetic stages need a CAST to CV_32F (or CV_64F) first;
+ * a CV_64F value becomes CV_16F through float (two roundings, like the double -> float -> half conversion it spells).   */
 #define CVGS_DEPTH_8U 0
 #define CVGS_DEPTH_8S 1
 #define CVGS_DEPTH_16U 2

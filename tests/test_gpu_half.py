@@ -154,7 +154,8 @@ def test_circular_tensor_half(oracle):
 
 
 def test_half_is_storage_only():
-    """Arithmetic on CV_16F values, resizing a CV_16F source and CV_16F next to CV_64F are refused loudly."""
+    """Arithmetic on CV_16F values and resizing a CV_16F source are refused loudly; CV_16F next to CV_64F values is served
+    since round 2 (half -> double -> arithmetic -> half, bit-exact vs the oracle)."""
     import torch
     t = torch.zeros((8, 8, 3), dtype=torch.float16, device="cuda:0")
     o = torch.zeros((8, 8, 3), dtype=torch.float16, device="cuda:0")
@@ -166,9 +167,20 @@ def test_half_is_storage_only():
     with pytest.raises(capi.CvgsError, match="per-pixel reads only"):
         of = torch.zeros((4, 4, 3), dtype=torch.float32, device="cuda:0")
         cvgs.executeOperations(s, cvgs.resize(h, cvgs.INTER_LINEAR, m, (4, 4)), cvgs.write(f, cvgs.GpuMat.from_tensor(of, f)))
-    with pytest.raises(capi.CvgsError, match="mixing"):
-        cvgs.executeOperations(s, cvgs.ReadIOp(capi.READ_PIXEL, h, [m], 1), cvgs.convertTo(h, d), cvgs.convertTo(d, h),
-                               cvgs.write(h, om))
+    from oracle import oracle_binding as ob
+    src = (H.random_u8((8, 8, 3), seed=3).astype(np.float32) / 7.0).astype(np.float16)
+    t.copy_(torch.from_numpy(src))
+
+    def chain(mm, oo):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, h, [mm], 1), cvgs.convertTo(h, d), cvgs.multiply(d, [1.0 / 3.0, 0.1, 7.0]),
+                cvgs.add(d, [1e-3, 2.5, -4.0]), cvgs.convertTo(d, h), cvgs.write(h, oo)]
+
+    cvgs.executeOperations(s, *chain(m, om))
+    torch.cuda.synchronize()
+    ref = np.zeros((8, 8, 3), np.float16)
+    ob.execute(cvgs.lower(chain(cvgs.GpuMat.from_array(src, h), cvgs.GpuMat.from_array(ref, h))))
+    H.assert_bit_exact(o.cpu().numpy(), ref, "half -> double -> half")
+    assert ref.any()
 
 
 def test_warp_and_nv12_half_tensors(oracle):

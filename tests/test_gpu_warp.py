@@ -193,3 +193,28 @@ def test_fast_warp_packed_nhwc(cn, gray):
     name = cvgs.kernel_name(cvgs.warp(cvgs.WARP_AFFINE, u, [cvgs.GpuMat.from_tensor(t, u)] * n, ms, dst),
                             cvgs.write(f, cvgs.GpuMat.from_tensor(o, f), dst))
     assert name == "warp_affine_u8c%d_packed_f32" % cn
+
+
+@pytest.mark.parametrize("kind", [cvgs.WARP_AFFINE, cvgs.WARP_PERSPECTIVE])
+@pytest.mark.parametrize("n", [3, 12])
+def test_warp_into_a_double_precision_chain(kind, n):
+    """cvGS::warp followed by a detour through CV_64F (convertTo<CV_32FC3, CV_64FC3>, arithmetic with scalars that are not
+    float-representable, back to CV_32F): the warp read in front of the double-precision interpreter (k_warp64), with the
+    planes in the kernel arguments (3) and in an uploaded table (12)."""
+    src = _random_src((120, 160, 3), "8U", 23)
+    st, f, d = cvgs.CV_8UC3, cvgs.CV_32FC3, cvgs.CV_64FC3
+    a = np.deg2rad(-9.0)
+    aff = [[1.1 * np.cos(a), -1.1 * np.sin(a), 7.25], [1.1 * np.sin(a), 1.1 * np.cos(a), 3.5]]
+    per = WC.get_perspective_transform([(8, 9), (150, 4), (2, 110), (155, 118)], [(0, 0), (80, 0), (0, 60), (80, 60)])
+    dst = (80, 60)
+
+    def build(wrap, wrap_out, out):
+        img = wrap(src, st)
+        ms = [[[r[0], r[1], r[2] + 2 * i] for r in aff] for i in range(n)] if kind == cvgs.WARP_AFFINE else [per] * n
+        rd = cvgs.warp(kind, st, [img] * n, ms, dst, n - 1, [3.0, 5.0, 7.0])
+        return [rd, cvgs.convertTo(f, d), cvgs.multiply(d, [0.1, 1.0 / 3.0, 0.7]), cvgs.subtract(d, [1e-9, 4.0, 3.2]),
+                cvgs.divide(d, [3.3, 0.6, 11.8]), cvgs.convertTo(d, f), cvgs.split(f, wrap_out(out, cvgs.CV_32FC1), dst)]
+
+    gpu, ref = _both(build, (n, 3 * dst[0] * dst[1]), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "warp -> CV_64F chain, kind %d, %d planes" % (kind, n))
+    assert ref[0][0].std() > 0

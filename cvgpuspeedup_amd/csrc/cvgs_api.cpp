@@ -194,8 +194,9 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (!rd.src) return fail(CVGS_ERR_INVALID, "read.src is null");
     const int sdepth = CVGS_TYPE_DEPTH(rd.src_type), scn = CVGS_TYPE_CN(rd.src_type);
     if (scn > 4) return fail(CVGS_ERR_INVALID, "bad source type");
-    if ((sdepth == CVGS_DEPTH_64F || sdepth == CVGS_DEPTH_16F) && rd.kind != CVGS_READ_PIXEL)
-        return fail(CVGS_ERR_UNSUPPORTED, "CV_64F / CV_16F sources are supported for per-pixel reads only");
+    // CV_64F / CV_16F sources: per-pixel reads and the bilinear resize (taps are cast to float, the output is CV_32F, reference
+    // include/cvGPUSpeedup.cuh:227); CV_16F also as a warp source.  A CV_64F warp source has no kernel.
+    if (sdepth == CVGS_DEPTH_64F && is_warp(rd.kind)) return fail(CVGS_ERR_UNSUPPORTED, "CV_64F sources of warp reads");
     if (is_nv12(rd.kind) && rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
         return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
     if (is_nv12(rd.kind) && (rd.yuv_layout < CVGS_YUV_NV12 || rd.yuv_layout > CVGS_YUV_YV12))

@@ -82,7 +82,12 @@ def test_validation_errors(lib):
     bad(lambda d: setattr(d.write, "data", None))
     bad(lambda d: setattr(d, "n_ops", 99))
     bad(lambda d: setattr(d.ops[0], "opcode", 77))
-    bad(lambda d: setattr(d.read, "src_type", cvgs.CV_64FC3), capi.ERR_UNSUPPORTED)
+    bad(lambda d: setattr(d.read, "src_type", cvgs.CV_64FC3))  # a CV_64F resize source is served since round 2; these u8 rows are too short for it
+    wsrc = np.zeros((16, 16, 3), np.float64)
+    wout = np.zeros((1, 3 * 8 * 8), np.float32)
+    wch = cvgs.lower([cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_64FC3, cvgs.GpuMat.from_array(wsrc, cvgs.CV_64FC3), [[1, 0, 0], [0, 1, 0]], (8, 8)),
+                      cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_array(wout, cvgs.CV_32FC1), (8, 8))])
+    assert lib.cvgs_validate(C.byref(wch.desc)) == capi.ERR_UNSUPPORTED  # no kernel warps CV_64F sources
     # arithmetic on a non-float value: not implemented (the reference spells these on CV_32F types only)
     frame = np.zeros((8, 8, 3), np.uint8)
     outm = np.zeros((8, 8, 3), np.uint8)

@@ -29,6 +29,10 @@ def _random_src(shape, depth_name, seed):
         return H.random_u16(shape, seed).view(K.NP_DEPTH[depth_name])
     if depth_name == "32S":
         return (H.random_u16(shape, seed).astype(np.int32) - 30000) * 7
+    if depth_name == "64F":
+        return H.random_u16(shape, seed).astype(np.float64) / 48.0 - 500.0 + 1e-7 * H.random_u16(shape, seed + 1).astype(np.float64)
+    if depth_name == "16F":
+        return (H.random_u16(shape, seed).astype(np.float32) / 64.0 - 300.0).astype(np.float16)
     return (H.random_u16(shape, seed).astype(np.float32) / 64.0 - 300.0).astype(np.float32)
 
 

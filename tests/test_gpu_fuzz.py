@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 NP = {cvgs.CV_64F: np.float64, cvgs.CV_8U: np.uint8, cvgs.CV_8S: np.int8, cvgs.CV_16U: np.uint16, cvgs.CV_16S: np.int16, cvgs.CV_32S: np.int32,
       cvgs.CV_32F: np.float32, cvgs.CV_16F: np.float16}
-NAME = {cvgs.CV_8U: "8U", cvgs.CV_8S: "8S", cvgs.CV_16U: "16U", cvgs.CV_16S: "16S", cvgs.CV_32S: "32S", cvgs.CV_32F: "32F"}
+NAME = {cvgs.CV_8U: "8U", cvgs.CV_8S: "8S", cvgs.CV_16U: "16U", cvgs.CV_16S: "16S", cvgs.CV_32S: "32S", cvgs.CV_32F: "32F", cvgs.CV_64F: "64F",
+        cvgs.CV_16F: "16F"}
 
 
 def _program(rng, depth, cn):
@@ -81,7 +82,9 @@ def _case(seed, big=False):
         srcs = [H.random_u8((sh + sh // 2, sw, 1), seed * 10 + i) for i in range(n)]
         used = n
     else:
-        sdepth = [cvgs.CV_8U, cvgs.CV_8U, cvgs.CV_8S, cvgs.CV_16U, cvgs.CV_16S, cvgs.CV_32S, cvgs.CV_32F][int(rng.integers(0, 7))]
+        # one case in five draws a CV_64F / CV_16F source (per-pixel and resize reads; CV_16F also warps)
+        pool = [cvgs.CV_8U, cvgs.CV_8U, cvgs.CV_8S, cvgs.CV_16U, cvgs.CV_16S, cvgs.CV_32S, cvgs.CV_32F, cvgs.CV_16F, cvgs.CV_16F if kind == "warp" else cvgs.CV_64F]
+        sdepth = pool[int(rng.integers(0, 7))] if rng.integers(0, 5) else pool[int(rng.integers(7, 9))]
         scn = int(rng.integers(1, 5))
         sw, sh = int(rng.integers(1, 300 * k)), int(rng.integers(1, 60 * k))
         srcs = [_random_src((sh, sw, scn), NAME[sdepth], seed * 10 + i) for i in range(n)]

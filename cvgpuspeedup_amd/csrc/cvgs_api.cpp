@@ -852,7 +852,7 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
     if (width < 1 || height < 1 || color_planes < 1 || color_planes > 4 || batch < 1 || batch > 4096)
         return fail(CVGS_ERR_INVALID, "bad CircularTensor shape");
     const int esz = depth_bytes(CVGS_TYPE_DEPTH(elem_type)) * CVGS_TYPE_CN(elem_type);
-    if (!esz || CVGS_TYPE_DEPTH(elem_type) == CVGS_DEPTH_64F) return fail(CVGS_ERR_UNSUPPORTED, "element type");
+    if (!esz) return fail(CVGS_ERR_INVALID, "element type");
     if (order != CVGS_NEWEST_FIRST && order != CVGS_OLDEST_FIRST) return fail(CVGS_ERR_INVALID, "bad order");
     if (cp_mode != CVGS_PLANES_STANDARD && cp_mode != CVGS_PLANES_TRANSPOSED) return fail(CVGS_ERR_INVALID, "bad colour-plane mode");
     DeviceGuard guard; // the caller's current device is left as it was

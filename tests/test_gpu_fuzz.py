@@ -249,7 +249,7 @@ def test_random_circular_tensor_sequence(oracle, seed):
     mirrored = bool(rng.integers(0, 2))
     transposed = (not packed) and (not mirrored) and bool(rng.integers(0, 2))
     mode = cvgs.Transposed if transposed else cvgs.Standard
-    edepth = [cvgs.CV_32F, cvgs.CV_32F, cvgs.CV_16F, cvgs.CV_8U][int(rng.integers(0, 4))]
+    edepth = [cvgs.CV_32F, cvgs.CV_32F, cvgs.CV_16F, cvgs.CV_8U, cvgs.CV_64F][int(rng.integers(0, 5))]
     resize_push = bool(rng.integers(0, 2))
     u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
     et = cvgs.make_type(edepth, cn)

@@ -68,7 +68,8 @@ class ReadDesc(C.Structure):
                 ("src", C.c_void_p), ("dst_width", C.c_int32), ("dst_height", C.c_int32),
                 ("aspect_ratio", C.c_int32), ("flags", C.c_uint32), ("background", C.c_float * 4),
                 ("yuv_range", C.c_int32), ("yuv_primaries", C.c_int32), ("yuv_alpha", C.c_int32),
-                ("yuv_layout", C.c_int32), ("warp_matrices", C.POINTER(C.c_float))]
+                ("yuv_layout", C.c_int32), ("warp_matrices", C.POINTER(C.c_float)),
+                ("warp_dst_sizes", C.POINTER(C.c_int32))]
 
 
 class Op(C.Structure):

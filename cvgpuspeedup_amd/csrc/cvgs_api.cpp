@@ -128,6 +128,7 @@ struct Lowered {
     SmallBuf<WarpPlane, kInlineWarp> warp_planes;       // WARP kinds (instead of `planes`)
     SmallBuf<DstPlane, CVGS_KERNARG_PLANES> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
     int out_w = 0, out_h = 0;
+    int warp_w = 0, warp_h = 0; // WARP kinds: the largest destination plane
     int final_depth = 0, final_cn = 0;
 };
 
@@ -202,7 +203,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (is_nv12(rd.kind) && (rd.yuv_layout < CVGS_YUV_NV12 || rd.yuv_layout > CVGS_YUV_YV12))
         return fail(CVGS_ERR_INVALID, "bad yuv_layout");
     if (is_warp(rd.kind)) {
-        if (rd.dst_width < 1 || rd.dst_height < 1) return fail(CVGS_ERR_INVALID, "warp target must be positive");
+        if (!rd.warp_dst_sizes && (rd.dst_width < 1 || rd.dst_height < 1)) return fail(CVGS_ERR_INVALID, "warp target must be positive");
         if (!rd.warp_matrices) return fail(CVGS_ERR_INVALID, "read.warp_matrices is null");
         if (rd.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) return fail(CVGS_ERR_UNSUPPORTED, "warp reads take host descriptors");
     }
@@ -240,6 +241,18 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         const cvgs_image2d* src = (const cvgs_image2d*)rd.src;
         if (is_warp(rd.kind)) {
             if (!L.warp_planes.assign((size_t)rd.batch, WarpPlane{})) return fail(CVGS_ERR_HIP, "out of host memory");
+            int max_w = rd.dst_width, max_h = rd.dst_height;
+            if (rd.warp_dst_sizes) max_w = max_h = 0;
+            for (int z = 0; z < rd.batch; ++z) { // every plane has a destination size, also the default-value ones
+                WarpPlane& P = L.warp_planes[(size_t)z];
+                P.dw = rd.warp_dst_sizes ? rd.warp_dst_sizes[2 * z] : rd.dst_width;
+                P.dh = rd.warp_dst_sizes ? rd.warp_dst_sizes[2 * z + 1] : rd.dst_height;
+                if (P.dw < 1 || P.dh < 1) return fail(CVGS_ERR_INVALID, "warp target must be positive");
+                max_w = std::max(max_w, (int)P.dw);
+                max_h = std::max(max_h, (int)P.dh);
+            }
+            L.warp_w = max_w; // the launch covers the largest plane
+            L.warp_h = max_h;
             for (int z = 0; z < rd.used_planes; ++z) {
                 const cvgs_image2d& im = src[z];
                 if (!im.data || im.width < 1 || im.height < 1) return fail(CVGS_ERR_INVALID, "empty source plane");
@@ -278,7 +291,10 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             else if (im.width != src[0].width || im.height != src[0].height)
                 return fail(CVGS_ERR_INVALID, "batched pixel reads need planes of one size");
         }
-        if (R.is_resize || is_warp(rd.kind)) {
+        if (is_warp(rd.kind)) {
+            L.out_w = L.warp_w;
+            L.out_h = L.warp_h;
+        } else if (R.is_resize) {
             L.out_w = rd.dst_width;
             L.out_h = rd.dst_height;
         } else if (rd.used_planes > 0) {
@@ -337,6 +353,11 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     }
     const bool tensor_kind = wr.kind == CVGS_WRITE_PIXEL_3D || wr.kind == CVGS_WRITE_TENSOR_SPLIT ||
                              wr.kind == CVGS_WRITE_TENSOR_T_SPLIT;
+    bool warp_sizes_differ = false;
+    for (size_t z = 0; z < L.warp_planes.size(); ++z)
+        warp_sizes_differ = warp_sizes_differ || L.warp_planes[z].dw != L.out_w || L.warp_planes[z].dh != L.out_h;
+    if (warp_sizes_differ && wr.kind != CVGS_WRITE_SPLIT_2D && wr.kind != CVGS_WRITE_PIXEL_2D_BATCH)
+        return fail(CVGS_ERR_INVALID, "differently sized warps need one destination image per plane (PIXEL_2D_BATCH / SPLIT_2D)");
     if (tensor_kind || wr.kind == CVGS_WRITE_PIXEL_2D) {
         if (!circular && !wr.data) return fail(CVGS_ERR_INVALID, "write.data is null");
         if (!circular && (wr.width != L.out_w || wr.height != L.out_h))
@@ -366,7 +387,10 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         if (!L.dst_planes.resize((size_t)rd.batch * per)) return fail(CVGS_ERR_HIP, "out of host memory");
         for (size_t i = 0; i < L.dst_planes.size(); ++i) {
             const cvgs_image2d& im = wr.planes2d[i];
-            if (!im.data || im.width != L.out_w || im.height != L.out_h || im.step < im.width * esz)
+            const size_t z = i / (size_t)per;
+            const int want_w = L.warp_planes.empty() ? L.out_w : (int)L.warp_planes[z].dw;
+            const int want_h = L.warp_planes.empty() ? L.out_h : (int)L.warp_planes[z].dh;
+            if (!im.data || im.width != want_w || im.height != want_h || im.step < im.width * esz)
                 return fail(CVGS_ERR_INVALID, "destination plane missing or of the wrong size");
             L.dst_planes[i].data = (uint8_t*)im.data;
             L.dst_planes[i].step = im.step;

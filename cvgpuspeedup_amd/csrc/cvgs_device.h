@@ -163,14 +163,15 @@ bool k4_planes_eligible(const PlaneParams* planes, int n, int dst_w, int dst_h);
 int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
                      bool dry_run, LaunchInfo* info);
 
-// Warp reads (cvGS::warp): per-plane source view + the inverse transform, 56 bytes.
+// Warp reads (cvGS::warp): per-plane source view + the inverse transform + the plane's destination size, 64 bytes.
 struct WarpPlane {
     const uint8_t* data;
     int32_t w, h, step;
     float m[9];            // row-major 3x3, destination -> source; affine kinds ignore m[6..8]
+    int32_t dw, dh;        // destination extent of THIS plane (cvgs_read_desc.warp_dst_sizes; else the launch's dst size)
 };
-static_assert(sizeof(WarpPlane) == 56, "WarpPlane layout");
-static constexpr int kInlineWarp = 56; // planes whose WarpPlane travels in the kernel arguments (4 KB block)
+static_assert(sizeof(WarpPlane) == 64, "WarpPlane layout");
+static constexpr int kInlineWarp = 52; // planes whose WarpPlane travels in the kernel arguments (4 KB block)
 // interpreted warp kernel: `planes` = host array of n (inline when n <= kInlineWarp), else `dev_table` (device copy)
 int launch_warp(const ChainArgs& c, const WarpPlane* planes, int n, const WarpPlane* dev_table, uint32_t chain_flags, void* stream,
                 bool dry_run, LaunchInfo* info);

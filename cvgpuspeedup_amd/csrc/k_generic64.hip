@@ -311,14 +311,15 @@ __global__ __launch_bounds__(256) void k_warp64(const WarpKernArgs64<NPL> a, con
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= r.dst_w || y >= r.dst_h) return;
+    WarpPlane P;
+    if constexpr (NPL == 0) P = table[z];
+    else P = a.planes[z];
+    if (x >= P.dw || y >= P.dh) return; // this plane's own destination size
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (z >= r.used) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = r.bg[k];
     } else {
-        WarpPlane P;
-        if constexpr (NPL == 0) P = table[z];
-        else P = a.planes[z];
         const float fx = (float)x, fy = (float)y;
         float sx = (P.m[0] * fx + P.m[1] * fy) + P.m[2];
         float sy = (P.m[3] * fx + P.m[4] * fy) + P.m[5];

@@ -25,6 +25,10 @@ __global__ __launch_bounds__(256) void k_warp(const WarpKernArgs<NPL> a, const W
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int z = blockIdx.z;
     if (x >= r.dst_w || y >= r.dst_h) return;
+    WarpPlane P;
+    if constexpr (NPL == 0) P = table[z];
+    else P = a.planes[z];
+    if (x >= P.dw || y >= P.dh) return; // this plane's own destination size (the launch covers the largest)
 
     Px p;
     p.v[0] = p.v[1] = p.v[2] = p.v[3] = 0.f;
@@ -33,9 +37,6 @@ __global__ __launch_bounds__(256) void k_warp(const WarpKernArgs<NPL> a, const W
 #pragma unroll
         for (int k = 0; k < 4; ++k) p.v[k] = r.bg[k]; // fk::BatchRead default value, then the whole chain
     } else {
-        WarpPlane P;
-        if constexpr (NPL == 0) P = table[z];
-        else P = a.planes[z];
         const float fx = (float)x, fy = (float)y;
         float sx = (P.m[0] * fx + P.m[1] * fy) + P.m[2];
         float sy = (P.m[3] * fx + P.m[4] * fy) + P.m[5];

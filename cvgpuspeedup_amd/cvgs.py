@@ -217,9 +217,17 @@ def warp(warp_type, src_type, mats, transforms, dsize, used_planes=None, default
         else:
             flat += [0.0] * 9
     kind = capi.READ_WARP_AFFINE if warp_type == WARP_AFFINE else capi.READ_WARP_PERSPECTIVE
+    # dsize: one (width, height) for every plane, or a list of them (the std::array<cv::Size, BATCH> overloads, reference :381-401)
+    sizes = None
+    if len(dsize) and hasattr(dsize[0], "__len__"):
+        sizes = [(int(w), int(h)) for (w, h) in dsize]
+        if len(sizes) != len(mats):
+            raise ValueError("one destination size per plane")
+        dsize = (max(w for w, _ in sizes), max(h for _, h in sizes))
     rd = ReadIOp(kind, src_type, mats[:used] + [mats[0]] * (len(mats) - used), used, (int(dsize[0]), int(dsize[1])),
                  IGNORE_AR, default_value)
     rd.warp = flat
+    rd.warp_sizes = sizes
     return rd
 
 
@@ -405,6 +413,10 @@ def lower(iops, flags=0):
         wm = (C.c_float * len(rd.warp))(*rd.warp)
         keep.append(wm)
         r.warp_matrices = C.cast(wm, C.POINTER(C.c_float))
+        if getattr(rd, "warp_sizes", None):
+            ws = (C.c_int32 * (2 * len(rd.warp_sizes)))(*[v for wh in rd.warp_sizes for v in wh])
+            keep.append(ws)
+            r.warp_dst_sizes = C.cast(ws, C.POINTER(C.c_int32))
     cur = rd.out_type()
     n = 0
     for iop in iops[1:-1]:

@@ -246,7 +246,7 @@ inline auto warp(const std::array<cv::cuda::GpuMat, BATCH>& inputs, const std::a
     fk::WarpRead<WT, CUDA_T(InputType)> rd;
     rd.planes.resize(BATCH, cvgs_image2d{nullptr, 0, 0, 0, 0});
     rd.params.resize(BATCH);
-    for (size_t i = 0; i < BATCH; ++i) rd.params[i].dstSize = fk::Size(dstSize[0].width, dstSize[0].height);
+    for (size_t i = 0; i < BATCH; ++i) rd.params[i].dstSize = fk::Size(dstSize[i].width, dstSize[i].height); // also of unused planes
     for (int i = 0; i < usedPlanes && i < (int)BATCH; ++i) {
         if (InputType != inputs[(size_t)i].type()) throw std::runtime_error("Input type does not match the input type of the operation.");
         rd.planes[(size_t)i] = fk::image2d(gpuMat2RawPtr2D<CUDA_T(InputType)>(inputs[(size_t)i]));

@@ -153,6 +153,7 @@ struct ChainBuilder {
     cvgs_chain_desc d;
     std::vector<cvgs_image2d> src, dst;
     std::vector<float> warp; // WARP reads: batch x 9 floats
+    std::vector<int32_t> warp_sizes; // WARP reads with per-plane destination sizes: batch x 2
     ChainBuilder() { std::memset(&d, 0, sizeof(d)); d.struct_size = sizeof(d); }
     void op(int opcode, int aux, const float* operand = nullptr, const double* operand_d = nullptr) {
         if (d.n_ops >= CVGS_MAX_OPS) throw std::runtime_error("cvGS: too many pointwise operations in one chain");
@@ -167,6 +168,7 @@ struct ChainBuilder {
         if (!src.empty() && !(d.read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE)) d.read.src = src.data();
         if (!dst.empty()) d.write.planes2d = dst.data();
         if (!warp.empty()) d.read.warp_matrices = warp.data();
+        if (!warp_sizes.empty()) d.read.warp_dst_sizes = warp_sizes.data();
     }
 };
 
@@ -575,10 +577,16 @@ template <WarpType WT, typename T> struct WarpRead {
         for (int i = 0; i < 4; ++i) r.background[i] = background[i];
         b.src = planes;
         b.warp.clear();
+        b.warp_sizes.clear();
+        bool differ = false;
         for (const auto& p : params) {
-            if (!(p.dstSize == params[0].dstSize)) throw std::runtime_error("cvGS::warp: one destination size per launch");
+            differ = differ || !(p.dstSize == params[0].dstSize);
+            r.dst_width = std::max(r.dst_width, (int32_t)p.dstSize.width);
+            r.dst_height = std::max(r.dst_height, (int32_t)p.dstSize.height);
             for (int y = 0; y < 3; ++y) for (int x = 0; x < 3; ++x) b.warp.push_back(p.transformMatrix[y][x]);
         }
+        if (differ) // per-plane destination sizes (reference include/cvGPUSpeedup.cuh:381-401): needs one output image per plane
+            for (const auto& p : params) { b.warp_sizes.push_back(p.dstSize.width); b.warp_sizes.push_back(p.dstSize.height); }
     }
 };
 

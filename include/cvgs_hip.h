@@ -105,10 +105,10 @@ typedef enum cvgs_read_kind {
      * source position is M*(x,y,1) (perspective: divided by its third component) with M = read.warp_matrices[z],
      * the INVERSE (destination -> source) transform narrowed to float exactly as fk::WarpingParameters holds it
      * (cvGPUSpeedup.cuh:269-284); inside the source [0,w) x [0,h) the value is the INTER_LINEAR interpolation of
-     * the resize kinds, outside it is 0; the output type is CV_32F of the source's channels.  ONE destination size
-     * (dst_width x dst_height) per launch: the reference's std::array<cv::Size, BATCH> overloads (:381-401) are accepted
-     * by the facade only when every size is equal (it throws std::runtime_error otherwise) -- a batch of differently
-     * sized warps is one launch per size.                                                                          */
+     * the resize kinds, outside it is 0; the output type is CV_32F of the source's channels.  Every plane warps into
+     * dst_width x dst_height, unless read.warp_dst_sizes gives each plane its own size (the reference's
+     * std::array<cv::Size, BATCH> overloads, :381-401): then the write stage must hold one destination image per plane
+     * (CVGS_WRITE_PIXEL_2D_BATCH / CVGS_WRITE_SPLIT_2D) of exactly that plane's size; dense tensors need equal sizes.  */
     CVGS_READ_WARP_AFFINE = 4,
     CVGS_READ_WARP_PERSPECTIVE = 5
 } cvgs_read_kind;
@@ -150,6 +150,9 @@ typedef struct cvgs_read_desc {
     int32_t yuv_alpha;    /* 1: 4-channel output with alpha = 255                             */
     int32_t yuv_layout;   /* cvgs_yuv_layout (0 = NV12)                                       */
     const float* warp_matrices; /* WARP kinds: host, batch x 9 floats (3x3 row-major; affine ignores row 2) */
+    /* WARP kinds: host, batch x 2 ints (width, height) = the destination size of every plane (also of planes >= used_planes),
+     * or NULL = dst_width x dst_height for all of them.                                                              */
+    const int32_t* warp_dst_sizes;
 } cvgs_read_desc;
 
 /* ---- pointwise stages (Unary / Binary IOps) ---------------------------------------------- */

@@ -528,9 +528,18 @@ static int chain_extent(const cvgs_chain_desc* ch, int* w, int* h) {
     if (rd->batch < 1 || !rd->src) return CVGS_ERR_INVALID;
     if (rd->kind == CVGS_READ_RESIZE_LINEAR || rd->kind == CVGS_READ_NV12_RESIZE_LINEAR ||
         rd->kind == CVGS_READ_WARP_AFFINE || rd->kind == CVGS_READ_WARP_PERSPECTIVE) {
-        if ((rd->kind == CVGS_READ_WARP_AFFINE || rd->kind == CVGS_READ_WARP_PERSPECTIVE) && !rd->warp_matrices) return CVGS_ERR_INVALID;
+        const int warp = rd->kind == CVGS_READ_WARP_AFFINE || rd->kind == CVGS_READ_WARP_PERSPECTIVE;
+        if (warp && !rd->warp_matrices) return CVGS_ERR_INVALID;
         *w = rd->dst_width;
         *h = rd->dst_height;
+        if (warp && rd->warp_dst_sizes) { /* per-plane destination sizes (reference include/cvGPUSpeedup.cuh:381-401): the loop
+                                            * below covers the largest plane, smaller ones skip the pixels outside theirs */
+            *w = *h = 0;
+            for (int z = 0; z < rd->batch; ++z) {
+                if (rd->warp_dst_sizes[2 * z] > *w) *w = rd->warp_dst_sizes[2 * z];
+                if (rd->warp_dst_sizes[2 * z + 1] > *h) *h = rd->warp_dst_sizes[2 * z + 1];
+            }
+        }
     } else {
         const cvgs_image2d* im = (const cvgs_image2d*)rd->src;
         *w = im->width;
@@ -571,7 +580,10 @@ int oracle_execute(const cvgs_chain_desc* ch) {
 #endif
     for (long zr = 0; zr < total_rows; ++zr) {
         const int z = (int)(zr / H), y = (int)(zr % H);
+        const int warp_sized = (rd->kind == CVGS_READ_WARP_AFFINE || rd->kind == CVGS_READ_WARP_PERSPECTIVE) && rd->warp_dst_sizes;
+        if (warp_sized && y >= rd->warp_dst_sizes[2 * z + 1]) continue;
         for (int x = 0; x < W; ++x) {
+            if (warp_sized && x >= rd->warp_dst_sizes[2 * z]) break;
             opx p;
             memset(&p, 0, sizeof(p));
             read_stage(rd, geoms, x, y, z, &p);

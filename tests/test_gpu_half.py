@@ -154,8 +154,8 @@ def test_circular_tensor_half(oracle):
 
 
 def test_half_is_storage_only():
-    """Arithmetic on CV_16F values and resizing a CV_16F source are refused loudly; CV_16F next to CV_64F values is served
-    since round 2 (half -> double -> arithmetic -> half, bit-exact vs the oracle)."""
+    """Arithmetic on CV_16F values is refused loudly; a CV_16F resize source and CV_16F next to CV_64F values are served
+    since round 2 (bit-exact vs the oracle)."""
     import torch
     t = torch.zeros((8, 8, 3), dtype=torch.float16, device="cuda:0")
     o = torch.zeros((8, 8, 3), dtype=torch.float16, device="cuda:0")
@@ -164,12 +164,15 @@ def test_half_is_storage_only():
     s = torch.cuda.current_stream()
     with pytest.raises(capi.CvgsError, match="arithmetic"):
         cvgs.executeOperations(s, cvgs.ReadIOp(capi.READ_PIXEL, h, [m], 1), cvgs.multiply(h, [2.0] * 3), cvgs.write(h, om))
-    with pytest.raises(capi.CvgsError, match="per-pixel reads only"):
-        of = torch.zeros((4, 4, 3), dtype=torch.float32, device="cuda:0")
-        cvgs.executeOperations(s, cvgs.resize(h, cvgs.INTER_LINEAR, m, (4, 4)), cvgs.write(f, cvgs.GpuMat.from_tensor(of, f)))
     from oracle import oracle_binding as ob
     src = (H.random_u8((8, 8, 3), seed=3).astype(np.float32) / 7.0).astype(np.float16)
     t.copy_(torch.from_numpy(src))
+    of = torch.zeros((5, 6, 3), dtype=torch.float32, device="cuda:0")
+    cvgs.executeOperations(s, cvgs.resize(h, cvgs.INTER_LINEAR, m, (6, 5)), cvgs.write(f, cvgs.GpuMat.from_tensor(of, f)))
+    torch.cuda.synchronize()
+    rf = np.zeros((5, 6, 3), np.float32)
+    ob.execute(cvgs.lower([cvgs.resize(h, cvgs.INTER_LINEAR, cvgs.GpuMat.from_array(src, h), (6, 5)), cvgs.write(f, cvgs.GpuMat.from_array(rf, f))]))
+    H.assert_bit_exact(of.cpu().numpy(), rf, "resize of a CV_16F source")
 
     def chain(mm, oo):
         return [cvgs.ReadIOp(capi.READ_PIXEL, h, [mm], 1), cvgs.convertTo(h, d), cvgs.multiply(d, [1.0 / 3.0, 0.1, 7.0]),

@@ -218,3 +218,76 @@ def test_warp_into_a_double_precision_chain(kind, n):
     gpu, ref = _both(build, (n, 3 * dst[0] * dst[1]), np.float32)
     H.assert_bit_exact(gpu[0], ref[0], "warp -> CV_64F chain, kind %d, %d planes" % (kind, n))
     assert ref[0][0].std() > 0
+
+
+@pytest.mark.parametrize("kind", [cvgs.WARP_AFFINE, cvgs.WARP_PERSPECTIVE])
+@pytest.mark.parametrize("write", ["images", "planes"])
+@pytest.mark.parametrize("double_chain", [False, True])
+def test_batched_warp_with_one_destination_size_per_plane(oracle, kind, write, double_chain):
+    """cvGS::warp<WT, I, BATCH>(inputs, matrices, std::array<cv::Size, BATCH>) (reference include/cvGPUSpeedup.cuh:381-401):
+    every plane warps into its own size; the outputs are one image (or one set of channel planes) per plane.  Planes beyond
+    usedPlanes carry the default value at THEIR size."""
+    import torch
+    dev = torch.device("cuda:0")
+    src = _random_src((90, 130, 3), "8U", 31)
+    st, f, d = cvgs.CV_8UC3, cvgs.CV_32FC3, cvgs.CV_64FC3
+    sizes = [(70, 33), (16, 48), (97, 5), (40, 40)]
+    n, used = len(sizes), 3
+    a = np.deg2rad(11.0)
+    aff = [[0.9 * np.cos(a), -0.9 * np.sin(a), 4.5], [0.9 * np.sin(a), 0.9 * np.cos(a), -2.0]]
+    per = WC.get_perspective_transform([(5, 6), (120, 3), (2, 80), (125, 86)], [(0, 0), (60, 0), (0, 40), (60, 40)])
+    ms = [[[r[0], r[1], r[2] + 3 * i] for r in aff] for i in range(n)] if kind == cvgs.WARP_AFFINE else [per] * n
+    pw = [cvgs.multiply(f, [0.5, 0.25, 2.0])]
+    if double_chain:
+        pw = [cvgs.convertTo(f, d), cvgs.multiply(d, [1.0 / 3.0, 0.1, 0.7]), cvgs.convertTo(d, f)]
+
+    def run(wrap, make_out):
+        img = wrap(src, st)
+        rd = cvgs.warp(kind, st, [img] * n, ms, sizes, used, [3.0, 5.0, 7.0])
+        if write == "images":
+            outs = [make_out((h, w, 3)) for (w, h) in sizes]
+            wr = cvgs.write_batch(f, [o[1] for o in outs])
+        else:
+            outs = [[make_out((h, w)) for _ in range(3)] for (w, h) in sizes]
+            wr = cvgs.split(f, [[p[1] for p in img_planes] for img_planes in outs])
+        return [rd] + pw + [wr], outs
+
+    t_src = torch.from_numpy(src).to(dev)
+
+    def gpu_out(shape):
+        t = torch.full(shape, -9.0, dtype=torch.float32, device=dev)
+        return t, cvgs.GpuMat.from_tensor(t, f if len(shape) == 3 else cvgs.CV_32FC1)
+
+    def cpu_out(shape):
+        a_ = np.full(shape, -9.0, np.float32)
+        return a_, cvgs.GpuMat.from_array(a_, f if len(shape) == 3 else cvgs.CV_32FC1)
+
+    g_ops, g_outs = run(lambda s_, t_: cvgs.GpuMat.from_tensor(t_src, t_), gpu_out)
+    c_ops, c_outs = run(lambda s_, t_: cvgs.GpuMat.from_array(s_, t_), cpu_out)
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops)
+    torch.cuda.synchronize()
+    oracle.execute(cvgs.lower(c_ops))
+    flat_g = [o[0] for o in g_outs] if write == "images" else [p[0] for img_planes in g_outs for p in img_planes]
+    flat_c = [o[0] for o in c_outs] if write == "images" else [p[0] for img_planes in c_outs for p in img_planes]
+    for i, (g, c) in enumerate(zip(flat_g, flat_c)):
+        assert (c != -9.0).all(), "the oracle must fill every pixel of output %d" % i
+        H.assert_bit_exact(g.cpu().numpy(), c, "per-plane sized warp, output %d" % i)
+    # the unused plane holds the default value pushed through the chain, at its own size
+    last = flat_c[-1] if write == "images" else flat_c[-3]
+    assert np.unique(last.reshape(-1, last.shape[-1] if write == "images" else 1), axis=0).shape[0] == 1
+
+
+def test_differently_sized_warps_need_one_image_per_plane(lib):
+    import ctypes as C
+    src = np.zeros((20, 30, 3), np.uint8)
+    out = np.zeros((2, 3 * 16 * 16), np.float32)
+    m = cvgs.GpuMat.from_array(src, cvgs.CV_8UC3)
+    rd = cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_8UC3, [m, m], [[[1, 0, 0], [0, 1, 0]]] * 2, [(16, 16), (8, 16)])
+    ch = cvgs.lower([rd, cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), (16, 16))])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_INVALID and b"one destination image per plane" in lib.cvgs_last_error()
+    outs = [np.zeros((16, 16, 3), np.float32), np.zeros((16, 16, 3), np.float32)]  # second image has the wrong size
+    ch = cvgs.lower([rd, cvgs.write_batch(cvgs.CV_32FC3, [cvgs.GpuMat.from_array(o, cvgs.CV_32FC3) for o in outs])])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_INVALID
+    outs[1] = np.zeros((16, 8, 3), np.float32)
+    ch = cvgs.lower([rd, cvgs.write_batch(cvgs.CV_32FC3, [cvgs.GpuMat.from_array(o, cvgs.CV_32FC3) for o in outs])])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == 0

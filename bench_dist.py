@@ -103,6 +103,10 @@ def main(a, dev, rank, world):
             bases.append(buf.ptr if r == rank else rccl.open_peer(handles[r]))
             if r != rank:
                 peers.append(bases[-1])
+        # probe: a plain store into every peer's allocation (its last float: nothing reads it) before any kernel is pointed at it
+        for b in peers:
+            rccl.view(b + n_frames * tensor_bytes - 4, (1,)).fill_(1.0)
+        torch.cuda.synchronize()
     except Exception as ex:  # no peer access on this box, IPC refused, ...
         map_error = repr(ex)
     mapped = torch.tensor([0 if map_error else 1], dtype=torch.int32, device=dev)

@@ -112,6 +112,17 @@ class DeviceBuffer:
             self.ptr = 0
 
 
+def view(ptr, shape, typestr="<f4"):
+    """A torch tensor over raw device memory (own or a mapped peer's), no copy."""
+    import torch
+
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(v, device="cuda")
+
+
 def open_peer(handle_bytes):
     """Map a peer process's DeviceBuffer: returns its device address in this process."""
     lib = load_library()

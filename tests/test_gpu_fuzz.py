@@ -131,6 +131,10 @@ def _case(seed, big=False):
                 m[2, :2] = rng.uniform(-0.002, 0.002, 2)
             mats_persp.append(m if persp else m[:2])
 
+    # batched warps into one image / set of planes per plane may give every plane its own (smaller) destination size
+    warp_sizes = None
+    if kind == "warp" and wk in ("write2d_batch", "split2d") and n > 1 and rng.integers(0, 2):
+        warp_sizes = [(int(rng.integers(1, dw + 1)), int(rng.integers(1, dh + 1))) for _ in range(n)]
     esz = np.dtype(NP[fd]).itemsize
     if wk in ("write3d",):
         shape = (n, dw * dh, fc)
@@ -153,7 +157,7 @@ def _case(seed, big=False):
             rd = cvgs.resize(st, cvgs.INTER_LINEAR, mats, (dw, dh), used, bg[:scn], ar)
         elif kind == "warp":
             rd = cvgs.warp(cvgs.WARP_PERSPECTIVE if mats_persp[0].shape[0] == 3 else cvgs.WARP_AFFINE, st, mats,
-                           [m.tolist() for m in mats_persp], (dw, dh), max(used, 1) if used == 0 else used, bg[:scn])
+                           [m.tolist() for m in mats_persp], warp_sizes or (dw, dh), max(used, 1) if used == 0 else used, bg[:scn])
         else:
             lumas = [cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, m.data, m.step, owner=m.owner) for m in mats]
             layout = yuv_layout
@@ -175,13 +179,15 @@ def _case(seed, big=False):
         elif wk == "write2d":
             wr = cvgs.write(ft, o.roi(0, 0, dw, dh))
         elif wk == "write2d_batch":
-            wr = cvgs.write_batch(ft, [cvgs.GpuMat(dh, dw, ft, o.data + i * dh * o.step, o.step, owner=o) for i in range(n)])
+            zs = warp_sizes or [(dw, dh)] * n  # smaller planes sit in the top-left corner of their dh x dw slot
+            wr = cvgs.write_batch(ft, [cvgs.GpuMat(zs[i][1], zs[i][0], ft, o.data + i * dh * o.step, o.step, owner=o) for i in range(n)])
         elif wk == "split":
             wr = cvgs.split(ft, o, (dw, dh))
         elif wk == "splitT":
             wr = cvgs.splitT(ft, o.data, dw, dh, n, keep=o)
         else:
-            planes = [[cvgs.GpuMat(dh, dw, o_t, o.data + ((z * fc + c) * dh) * o.step, o.step, owner=o) for c in range(fc)] for z in range(n)]
+            zs = warp_sizes or [(dw, dh)] * n
+            planes = [[cvgs.GpuMat(zs[z][1], zs[z][0], o_t, o.data + ((z * fc + c) * dh) * o.step, o.step, owner=o) for c in range(fc)] for z in range(n)]
             wr = cvgs.split(ft, planes if n > 1 else planes[0])
         return [rd] + prog + [wr]
 

@@ -10,6 +10,7 @@
 #include <array>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -148,12 +149,69 @@ protected:
 template <typename T> using Tensor = TensorBase<_3D, T>;
 template <typename T> using TensorT = TensorBase<T3D, T>;
 
+// ---- small-buffer array for the builders --------------------------------------------------------------------------
+// The chain builders hold plane tables / matrices / op lists of at most a few dozen entries; a std::vector there costs
+// one malloc + free per member per executeOperations call on the host path that feeds a ~2 us kernel.  SmallVec keeps up
+// to N trivially-copyable elements inline (no heap at all for the reference's batches, <= 64 planes) and only spills to
+// the heap beyond that.  It offers the subset of std::vector the IOps use.
+namespace detail {
+template <typename T, size_t N> class SmallVec {
+    static_assert(std::is_trivially_copyable_v<T>, "SmallVec holds plain descriptors only");
+public:
+    SmallVec() = default;
+    SmallVec(const SmallVec& o) { assign(o.begin(), o.end()); }
+    SmallVec(SmallVec&& o) noexcept { take(o); }
+    SmallVec& operator=(const SmallVec& o) { if (this != &o) assign(o.begin(), o.end()); return *this; }
+    SmallVec& operator=(SmallVec&& o) noexcept { if (this != &o) { release(); take(o); } return *this; }
+    ~SmallVec() { release(); }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    T* begin() { return p_; }
+    T* end() { return p_ + n_; }
+    const T* begin() const { return p_; }
+    const T* end() const { return p_ + n_; }
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+    T& back() { return p_[n_ - 1]; }
+    void clear() { n_ = 0; }
+    void reserve(size_t c) {
+        if (c <= cap_) return;
+        size_t nc = cap_ * 2 > c ? cap_ * 2 : c;
+        T* q = static_cast<T*>(::operator new(nc * sizeof(T)));
+        if (n_) std::memcpy(static_cast<void*>(q), p_, n_ * sizeof(T));
+        if (p_ != inline_ptr()) ::operator delete(p_);
+        p_ = q; cap_ = nc;
+    }
+    void push_back(const T& v) { T tmp = v; reserve(n_ + 1); p_[n_++] = tmp; } // v may alias an element
+    void resize(size_t n, const T& v = T{}) { T tmp = v; reserve(n); for (size_t i = n_; i < n; ++i) p_[i] = tmp; n_ = n; }
+    void assign(size_t n, const T& v) { T tmp = v; n_ = 0; reserve(n); for (size_t i = 0; i < n; ++i) p_[i] = tmp; n_ = n; }
+    template <typename It, typename = std::enable_if_t<!std::is_integral_v<It>>> void assign(It first, It last) {
+        n_ = 0;
+        for (; first != last; ++first) push_back(*first);
+    }
+private:
+    T* inline_ptr() { return reinterpret_cast<T*>(inline_); }
+    void release() { if (p_ != inline_ptr()) ::operator delete(p_); p_ = inline_ptr(); n_ = 0; cap_ = N; }
+    void take(SmallVec& o) {
+        if (o.p_ != o.inline_ptr()) { p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = o.inline_ptr(); o.n_ = 0; o.cap_ = N; }
+        else { p_ = inline_ptr(); cap_ = N; n_ = o.n_; if (n_) std::memcpy(static_cast<void*>(p_), o.p_, n_ * sizeof(T)); o.n_ = 0; }
+    }
+    alignas(T) unsigned char inline_[N * sizeof(T)];
+    T* p_ = inline_ptr();
+    size_t n_ = 0, cap_ = N;
+};
+constexpr size_t kInlinePlanes = 64; // the reference's largest batch in its tests and benchmarks is 50..60 crops
+} // namespace detail
+
 // ---- chain builder ----------------------------------------------------------------------------------------
 struct ChainBuilder {
     cvgs_chain_desc d;
-    std::vector<cvgs_image2d> src, dst;
-    std::vector<float> warp; // WARP reads: batch x 9 floats
-    std::vector<int32_t> warp_sizes; // WARP reads with per-plane destination sizes: batch x 2
+    detail::SmallVec<cvgs_image2d, detail::kInlinePlanes> src;
+    detail::SmallVec<cvgs_image2d, 3 * detail::kInlinePlanes> dst; // SplitWrite<_2D>: up to 4 planes per batch element
+    detail::SmallVec<float, 9 * detail::kInlinePlanes> warp; // WARP reads: batch x 9 floats
+    detail::SmallVec<int32_t, 2 * detail::kInlinePlanes> warp_sizes; // WARP reads with per-plane destination sizes: batch x 2
     ChainBuilder() { std::memset(&d, 0, sizeof(d)); d.struct_size = sizeof(d); }
     void op(int opcode, int aux, const float* operand = nullptr, const double* operand_d = nullptr) {
         if (d.n_ops >= CVGS_MAX_OPS) throw std::runtime_error("cvGS: too many pointwise operations in one chain");
@@ -247,7 +305,7 @@ template <typename I, typename O> struct PointwiseSeq {
     using InputType = I;
     using OutputType = O;
     static constexpr Stage stage = Stage::Pointwise;
-    std::vector<cvgs_op> ops;
+    detail::SmallVec<cvgs_op, CVGS_MAX_OPS> ops;
     void lower(ChainBuilder& b) const { for (const auto& o : ops) b.op(o.opcode, o.aux, o.operand, o.operand_d); }
     template <typename Next> auto then(const Next& n) const {
         static_assert(std::is_same_v<O, typename Next::InputType>, "then(): types do not chain");
@@ -275,13 +333,13 @@ template <typename T> struct PerThreadRead<_2D, T> {
 // one pitched image per batch element (PerThreadWrite<_2D,T>::build(std::array<RawPtr<_2D,T>,N>), as the reference's
 // batched warp test writes its results, tests/warping/test_warping_opencv.cu:173-176)
 template <typename T> struct BatchPixelWrite {
-    std::vector<cvgs_image2d> planes;
+    detail::SmallVec<cvgs_image2d, detail::kInlinePlanes> planes;
     using InputType = T;
     static constexpr Stage stage = Stage::Write;
     void lower(ChainBuilder& b) const {
         cvgs_write_desc& w = b.d.write;
         w.kind = CVGS_WRITE_PIXEL_2D_BATCH; w.dst_type = cvGS::cv_type_of<T>;
-        b.dst = planes;
+        b.dst.assign(planes.begin(), planes.end());
         if (!planes.empty()) { w.width = planes[0].width; w.height = planes[0].height; }
         w.planes = (int)planes.size();
     }
@@ -334,7 +392,7 @@ template <typename T> struct TensorTSplit {
 
 // SplitWrite<_2D,T>: C pitched planes per batch element
 template <ND D, typename T> struct SplitWrite {
-    struct ParamsType { std::vector<RawPtr<_2D, VBase<T>>> planes; int batch = 1; };
+    struct ParamsType { detail::SmallVec<RawPtr<_2D, VBase<T>>, 3 * detail::kInlinePlanes> planes; int batch = 1; };
     using InputType = T;
     static void lower(const ParamsType& p, ChainBuilder& b) {
         cvgs_write_desc& w = b.d.write;
@@ -452,7 +510,7 @@ template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typenam
     RawPtr<_2D, uchar> params;
     // optional: N crops of the surface (even x, y, w, h), each a view with its own luma -> chroma offset; the read is
     // then a batch of N planes in ONE launch (engine extension: crops straight from a decoder surface)
-    std::vector<cvgs_image2d> crops;
+    detail::SmallVec<cvgs_image2d, detail::kInlinePlanes> crops;
     using OutputType = O;
     static constexpr Stage stage = Stage::Read;
     static constexpr bool float_out = std::is_same_v<VBase<O>, float>;
@@ -508,7 +566,7 @@ template <typename Yuv> struct ResizeYuvRead {     // single image, NV12 read-ba
 
 // N pitched sources -> resize -> default value for unused planes (BatchRead<N, CONDITIONAL_WITH_DEFAULT>)
 template <typename T> struct BatchResizeRead {
-    std::vector<cvgs_image2d> planes;
+    detail::SmallVec<cvgs_image2d, detail::kInlinePlanes> planes;
     int used = 0;
     Size dsize;
     int ar = CVGS_IGNORE_AR;
@@ -527,7 +585,7 @@ template <typename T> struct BatchResizeRead {
 
 // N pitched sources read per pixel (the batch executeOperations overloads)
 template <typename T> struct BatchPixelRead {
-    std::vector<cvgs_image2d> planes;
+    detail::SmallVec<cvgs_image2d, detail::kInlinePlanes> planes;
     int used = 0;
     float background[4] = {0, 0, 0, 0};
     using OutputType = T;
@@ -561,8 +619,8 @@ template <WarpType WT> struct WarpingParameters {
 };
 // N pitched sources -> warp -> default value for unused planes
 template <WarpType WT, typename T> struct WarpRead {
-    std::vector<cvgs_image2d> planes;
-    std::vector<WarpingParameters<WT>> params;
+    detail::SmallVec<cvgs_image2d, detail::kInlinePlanes> planes;
+    detail::SmallVec<WarpingParameters<WT>, detail::kInlinePlanes> params;
     int used = 0;
     float background[4] = {0, 0, 0, 0};
     using OutputType = VectorType_t<float, cn<T>>;

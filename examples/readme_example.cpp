@@ -28,11 +28,11 @@ int main() {
     const int activeDetections = 50;
 
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
     std::vector<float> us;
     for (int it = -1; it < ITERS; ++it) { // it == -1: warm-up
-        hipEventRecord(e0, stream.raw());
+        (void)hipEventRecord(e0, stream.raw());
         // single kernel (resize already yields CV_32FC3, so the README's convertTo<CV_8UC3,CV_32FC3>() is dropped)
         cvGS::executeOperations(stream,
                                 cvGS::resize<CV_8UC3, cv::INTER_LINEAR, MAX_DETECTIONS>(crops, resDims, activeDetections),
@@ -40,10 +40,10 @@ int main() {
                                 cvGS::subtract<CV_32FC3>(subtract_val),
                                 cvGS::divide<CV_32FC3>(divide_val),
                                 cvGS::split<CV_32FC3>(output, resDims));
-        hipEventRecord(e1, stream.raw());
+        (void)hipEventRecord(e1, stream.raw());
         stream.waitForCompletion();
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         if (it >= 0) us.push_back(ms * 1000.f);
     }
     float mean = 0.f;

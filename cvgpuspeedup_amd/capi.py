@@ -42,8 +42,8 @@ READ_PIXEL, READ_RESIZE_LINEAR, READ_NV12, READ_NV12_RESIZE_LINEAR, READ_WARP_AF
 # aspect ratio (same values as cvGS::AspectRatio)
 PRESERVE_AR, IGNORE_AR, PRESERVE_AR_RN_EVEN, PRESERVE_AR_LEFT = 0, 1, 2, 3
 YUV_FULL, YUV_LIMITED = 0, 1
-YUV_NV12, YUV_NV21, YUV_I420, YUV_YV12 = 0, 1, 2, 3
-BT601, BT709 = 0, 1
+YUV_NV12, YUV_NV21, YUV_I420, YUV_YV12, YUV_P010 = 0, 1, 2, 3, 4
+BT601, BT709, BT2020 = 0, 1, 2
 READ_FLAG_TABLE_ON_DEVICE = 1
 # opcodes
 (OP_NOP, OP_CAST, OP_MUL, OP_ADD, OP_SUB, OP_DIV, OP_REORDER, OP_ADD_ALPHA, OP_DROP_ALPHA, OP_GRAY,

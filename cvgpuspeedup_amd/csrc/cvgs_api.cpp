@@ -198,10 +198,15 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     // CV_64F / CV_16F sources: per-pixel reads and the bilinear resize (taps are cast to float, the output is CV_32F, reference
     // include/cvGPUSpeedup.cuh:227); CV_16F also as a warp source.  A CV_64F warp source has no kernel.
     if (sdepth == CVGS_DEPTH_64F && is_warp(rd.kind)) return fail(CVGS_ERR_UNSUPPORTED, "CV_64F sources of warp reads");
-    if (is_nv12(rd.kind) && rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
-        return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
-    if (is_nv12(rd.kind) && (rd.yuv_layout < CVGS_YUV_NV12 || rd.yuv_layout > CVGS_YUV_YV12))
-        return fail(CVGS_ERR_INVALID, "bad yuv_layout");
+    if (is_nv12(rd.kind)) {
+        if (rd.yuv_layout < CVGS_YUV_NV12 || rd.yuv_layout > CVGS_YUV_P010) return fail(CVGS_ERR_INVALID, "bad yuv_layout");
+        if (rd.yuv_range < CVGS_YUV_FULL || rd.yuv_range > CVGS_YUV_LIMITED) return fail(CVGS_ERR_INVALID, "bad yuv_range");
+        if (rd.yuv_primaries < CVGS_BT601 || rd.yuv_primaries > CVGS_BT2020) return fail(CVGS_ERR_INVALID, "bad yuv_primaries");
+        if (rd.yuv_layout == CVGS_YUV_P010) {
+            if (rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_16U, 1)) return fail(CVGS_ERR_INVALID, "P010 reads need a CV_16UC1 source");
+        } else if (rd.src_type != CVGS_MAKETYPE(CVGS_DEPTH_8U, 1))
+            return fail(CVGS_ERR_INVALID, "NV12 reads need a CV_8UC1 source");
+    }
     if (is_warp(rd.kind)) {
         if (!rd.warp_dst_sizes && (rd.dst_width < 1 || rd.dst_height < 1)) return fail(CVGS_ERR_INVALID, "warp target must be positive");
         if (!rd.warp_matrices) return fail(CVGS_ERR_INVALID, "read.warp_matrices is null");
@@ -281,7 +286,9 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             P.step = im.step;
             if (is_nv12(rd.kind)) {
                 if (im.uv_offset < 0 || (im.uv_offset & 1)) return fail(CVGS_ERR_INVALID, "NV12 uv_offset must be even and non-negative");
-                if (rd.yuv_layout > CVGS_YUV_NV21) {
+                if (rd.yuv_layout == CVGS_YUV_P010 && (((uintptr_t)im.data | (uintptr_t)im.step | (uintptr_t)im.uv_offset) & 1))
+                    return fail(CVGS_ERR_INVALID, "P010 surfaces need 2-byte aligned data, step and uv_offset");
+                if (rd.yuv_layout == CVGS_YUV_I420 || rd.yuv_layout == CVGS_YUV_YV12) {
                     if (im.uv_offset) return fail(CVGS_ERR_UNSUPPORTED, "crops of planar-chroma (I420 / YV12) surfaces");
                     if (im.step & 1) return fail(CVGS_ERR_INVALID, "I420 / YV12 surfaces need an even step (chroma rows are step/2 bytes)");
                 }

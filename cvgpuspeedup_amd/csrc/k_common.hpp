@@ -242,44 +242,65 @@ __device__ __forceinline__ float tap_f(float v, int depth) {
 // ---- NV12 -> RGB(A) float ----------------------------------------------------------------------
 struct YuvK {
     float ysub, yscale, rv, gu, gv, bu;
-    int layout; // cvgs_yuv_layout of the source (set by the caller next to yuv_matrix)
+    float csub, amax; // chroma centre and alpha (= full scale): 128 / 255 for 8-bit samples, 512 / 1023 for P010
+    int layout;       // cvgs_yuv_layout of the source
 };
 
-__device__ __forceinline__ YuvK yuv_matrix(int range, int primaries) {
+// 6-decimal literals of the derivation from the standards' luma weights (BT.601, BT.709, BT.2020 NCL); limited range scales
+// luma by 255/219 and chroma by 255/224 on 8-bit codes, by 1023/876 and 1023/896 on P010's 10-bit codes
+// (tests/test_independent_pins.py re-derives every set in float64; the oracle holds the same literals).
+__device__ __forceinline__ YuvK yuv_matrix(int range, int primaries, int layout = CVGS_YUV_NV12) {
     YuvK k;
-    k.layout = CVGS_YUV_NV12;
+    k.layout = layout;
+    const bool ten = layout == CVGS_YUV_P010;
+    k.csub = ten ? 512.f : 128.f;
+    k.amax = ten ? 1023.f : 255.f;
     if (range == CVGS_YUV_FULL) {
         k.ysub = 0.f; k.yscale = 1.f;
         if (primaries == CVGS_BT601) { k.rv = 1.402f; k.gu = -0.344136f; k.gv = -0.714136f; k.bu = 1.772f; }
-        else { k.rv = 1.5748f; k.gu = -0.187324f; k.gv = -0.468124f; k.bu = 1.8556f; }
-    } else {
+        else if (primaries == CVGS_BT709) { k.rv = 1.5748f; k.gu = -0.187324f; k.gv = -0.468124f; k.bu = 1.8556f; }
+        else { k.rv = 1.4746f; k.gu = -0.164553f; k.gv = -0.571353f; k.bu = 1.8814f; }
+    } else if (!ten) {
         k.ysub = 16.f; k.yscale = 1.164383f;
         if (primaries == CVGS_BT601) { k.rv = 1.596027f; k.gu = -0.391762f; k.gv = -0.812968f; k.bu = 2.017232f; }
-        else { k.rv = 1.792741f; k.gu = -0.213249f; k.gv = -0.532909f; k.bu = 2.112402f; }
+        else if (primaries == CVGS_BT709) { k.rv = 1.792741f; k.gu = -0.213249f; k.gv = -0.532909f; k.bu = 2.112402f; }
+        else { k.rv = 1.678674f; k.gu = -0.187326f; k.gv = -0.650424f; k.bu = 2.141772f; }
+    } else {
+        k.ysub = 64.f; k.yscale = 1.167808f;
+        if (primaries == CVGS_BT601) { k.rv = 1.600721f; k.gu = -0.392915f; k.gv = -0.815359f; k.bu = 2.023165f; }
+        else if (primaries == CVGS_BT709) { k.rv = 1.798014f; k.gu = -0.213876f; k.gv = -0.534477f; k.bu = 2.118615f; }
+        else { k.rv = 1.683611f; k.gu = -0.187877f; k.gv = -0.652337f; k.bu = 2.148072f; }
     }
     return k;
 }
 
 __device__ __forceinline__ void yuv_to_rgb(float Y, float U, float V, const YuvK& k, Px& p) {
-    const float cb = U - 128.f, cr = V - 128.f;
+    const float cb = U - k.csub, cr = V - k.csub;
     const float yv = (Y - k.ysub) * k.yscale;
     p.v[0] = yv + k.rv * cr;
     p.v[1] = (yv + k.gu * cb) + k.gv * cr;
     p.v[2] = yv + k.bu * cb;
-    p.v[3] = 255.f;
+    p.v[3] = k.amax;
 }
 
 __device__ __forceinline__ void nv12_px(const PlaneParams& P, int x, int y, const YuvK& k, Px& p) {
-    const float Y = (float)P.data[(size_t)y * P.step + x];
-    float U, V;
-    if (k.layout <= CVGS_YUV_NV21) { // interleaved chroma: one (U,V) or (V,U) pair per 2x2 luma block
+    float Y, U, V;
+    if (k.layout == CVGS_YUV_P010) { // NV12's geometry, 16-bit samples, 10-bit code in the high bits
+        const uint16_t* yrow = (const uint16_t*)(P.data + (size_t)y * P.step);
+        const uint16_t* uv = (const uint16_t*)(P.data + (size_t)P.uv_off + (size_t)(y >> 1) * P.step) + 2 * (x >> 1);
+        Y = (float)(yrow[x] >> 6);
+        U = (float)(uv[0] >> 6);
+        V = (float)(uv[1] >> 6);
+    } else if (k.layout <= CVGS_YUV_NV21) { // interleaved chroma: one (U,V) or (V,U) pair per 2x2 luma block
         const uint8_t* uv = P.data + (size_t)P.uv_off + (size_t)(y >> 1) * P.step + 2 * (x >> 1);
+        Y = (float)P.data[(size_t)y * P.step + x];
         U = (float)uv[k.layout == CVGS_YUV_NV21 ? 1 : 0];
         V = (float)uv[k.layout == CVGS_YUV_NV21 ? 0 : 1];
     } else {                         // planar chroma: (W/2) x (H/2) planes with rows of step/2 bytes, one after the other
         const size_t cstep = (size_t)(P.step >> 1);
         const uint8_t* first = P.data + (size_t)P.uv_off + (size_t)(y >> 1) * cstep + (x >> 1);
         const uint8_t* second = first + (size_t)(P.h >> 1) * cstep;
+        Y = (float)P.data[(size_t)y * P.step + x];
         U = (float)*(k.layout == CVGS_YUV_YV12 ? second : first);
         V = (float)*(k.layout == CVGS_YUV_YV12 ? first : second);
     }

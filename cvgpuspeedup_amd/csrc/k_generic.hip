@@ -42,8 +42,7 @@ __global__ __launch_bounds__(256) void k_generic(const KernArgs<NPL> a, const Mi
         PlaneParams P;
         if constexpr (NPL == 0) P = r.table[z];
         else P = a.planes[z];
-        YuvK yk = yuv_matrix(r.yuv_range, r.yuv_primaries);
-        yk.layout = r.yuv_layout;
+        YuvK yk = yuv_matrix(r.yuv_range, r.yuv_primaries, r.yuv_layout);
         if (!r.is_resize) {
             if (r.kind == CVGS_READ_NV12) nv12_px(P, x, y, yk, p);
             else load_px(P.data + (size_t)y * (size_t)P.step, r.depth, r.cn, x, p);

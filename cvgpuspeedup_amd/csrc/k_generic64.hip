@@ -215,8 +215,7 @@ __global__ __launch_bounds__(256) void k_generic64(const KernArgs64<NPL> a) {
         PlaneParams P;
         if constexpr (NPL == 0) P = r.table[z];
         else P = a.planes[z];
-        YuvK yk = yuv_matrix(r.yuv_range, r.yuv_primaries);
-        yk.layout = r.yuv_layout;
+        YuvK yk = yuv_matrix(r.yuv_range, r.yuv_primaries, r.yuv_layout);
         if (!r.is_resize) {
             if (r.kind == CVGS_READ_NV12) {
                 Px t;

@@ -19,6 +19,8 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 typedef const __attribute__((address_space(1))) u16_unaligned* gptr_u16;
 typedef const __attribute__((address_space(1))) u32_unaligned* gptr_u32;
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) u64_unaligned* gptr_u64;
 
 struct N12Geom {
     int32_t dst_w, dst_h, out_w, cn; // cn: 3, or 4 with alpha
@@ -50,15 +52,17 @@ using N12SwapMulSubDiv = ProgSwapMulSubDiv; // the compile-time program of k_tap
 // range: (Y - 0) * 1 is Y itself, bit for bit, so the two instructions are dropped; the alpha lane only exists for CN 4)
 template <int CN, bool FULL>
 __device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k, float* t) {
-    const float cb = U - 128.f, cr = V - 128.f;
+    const float cb = U - k.csub, cr = V - k.csub;
     const float yv = FULL ? Y : (Y - k.ysub) * k.yscale;
     t[0] = yv + k.rv * cr;
     t[1] = (yv + k.gu * cb) + k.gv * cr;
     t[2] = yv + k.bu * cb;
-    if constexpr (CN == 4) t[3] = 255.f;
+    if constexpr (CN == 4) t[3] = k.amax;
 }
 
-template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3>
+// S16: P010 -- the same geometry with 16-bit samples (10-bit code = sample >> 6): the two luma taps are ONE 4-byte load, the
+// two chroma pairs ONE 8-byte load.
+template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3, bool S16 = false>
 __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL> a, const N12Geom g) {
     const ChainArgs& c = a.c;
     const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(W), "s"(CN), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.fx), "s"(P.fy), "s"(P.data), "s"(P.uv_off),
                  "s"(yuv_range), "s"(yuv_prim), "s"(packed), "s"(img_stride), "s"(ch_stride), "s"(out_base), "s"(op0), "s"(op1),
                  "s"(op2), "s"(op3));
-    const YuvK yk = yuv_matrix(yuv_range, yuv_prim);
+    const YuvK yk = yuv_matrix(yuv_range, yuv_prim, S16 ? CVGS_YUV_P010 : CVGS_YUV_NV12);
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
@@ -109,17 +113,20 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     const float wxa = (float)x2 - sx, wxb = sx - (float)x1;
     const bool edge = x2 > P.w - 1;
     const int x2r = edge ? x1 : x2;
-    const uint32_t yo = (uint32_t)min(x1, P.w - 2);
-    const int ysh = (x1 - (int)yo) * 8;
+    constexpr int kSB = S16 ? 2 : 1; // bytes per sample
+    const uint32_t yo = (uint32_t)min(x1, P.w - 2) * kSB;
+    const int ysh = (x1 * kSB - (int)yo) * 8;
     const int c1 = x1 >> 1, c2 = x2r >> 1;
-    const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4);
-    const int ush = (2 * c1 - (int)uo) * 8;
+    const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4) * kSB;
+    const int ush = (2 * c1 * kSB - (int)uo) * 8;
     const bool same_pair = c2 == c1;
     const gptr_u8 base = (gptr_u8)P.data;
     const size_t step = (size_t)P.step;
     const gptr_u8 uvp = base + (size_t)P.uv_off; // crops of a surface carry their own luma -> chroma offset
 
-    uint32_t vya[RPW], vyb[RPW], vua[RPW], vub[RPW];
+    using ChromaWin = std::conditional_t<S16, uint64_t, uint32_t>; // two (U,V) pairs
+    uint32_t vya[RPW], vyb[RPW];
+    ChromaWin vua[RPW], vub[RPW];
     float wya[RPW], wyb[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
@@ -140,9 +147,15 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
         const gptr_u8 ya = K4_PIN(base + (size_t)r1 * step);
         const gptr_u8 yb = K4_PIN(base + (size_t)r2 * step);
         const gptr_u8 ua = K4_PIN(uvp + (size_t)(r1 >> 1) * step);
-        vya[j] = *(gptr_u16)(ya + yo);
-        vyb[j] = *(gptr_u16)(yb + yo);
-        vua[j] = *(gptr_u32)(ua + uo);
+        if constexpr (S16) {
+            vya[j] = *(gptr_u32)(ya + yo);
+            vyb[j] = *(gptr_u32)(yb + yo);
+            vua[j] = *(gptr_u64)(ua + uo);
+        } else {
+            vya[j] = *(gptr_u16)(ya + yo);
+            vyb[j] = *(gptr_u16)(yb + yo);
+            vua[j] = *(gptr_u32)(ua + uo);
+        }
         // Every other row pair shares ONE chroma row; skipping its second load behind a wave-uniform branch was measured
         // and lost (tools/k4_ab.sh: cfg #3 9.15 vs 8.02 us, 50 NV12 crops 5.04 vs 4.52 us): the redundant load hits L1,
         // the branch delays the loads behind it.
@@ -153,7 +166,8 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
 #endif
         {
             const gptr_u8 ub = K4_PIN(uvp + (size_t)(r2 >> 1) * step);
-            vub[j] = *(gptr_u32)(ub + uo);
+            if constexpr (S16) vub[j] = *(gptr_u64)(ub + uo);
+            else vub[j] = *(gptr_u32)(ub + uo);
         }
     }
 
@@ -161,27 +175,42 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     for (int j = 0; j < RPW; ++j) {
         const int y = row0 + j;
         if (y >= dst_h) break; // wave-uniform
-        const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
-        const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
-        uint32_t ca = vua[j], cb = vub[j];
-        if (vu) { // NV21: swap the bytes of every pair once, then everything below is NV12
-            ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
-            cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
+        float fy[4], fu[4], fv[4]; // taps 00, 10, 01, 11
+        if constexpr (S16) {
+            const uint32_t ya0 = (vya[j] >> ysh) & 0xffffu, ya1 = edge ? ya0 : vya[j] >> 16;
+            const uint32_t yb0 = (vyb[j] >> ysh) & 0xffffu, yb1 = edge ? yb0 : vyb[j] >> 16;
+            const uint32_t pa0 = (uint32_t)(vua[j] >> ush), pa1 = same_pair ? pa0 : (uint32_t)(vua[j] >> 32);
+            const uint32_t pb0 = (uint32_t)(vub[j] >> ush), pb1 = same_pair ? pb0 : (uint32_t)(vub[j] >> 32);
+            fy[0] = (float)(ya0 >> 6); fy[1] = (float)(ya1 >> 6); fy[2] = (float)(yb0 >> 6); fy[3] = (float)(yb1 >> 6);
+            fu[0] = (float)((pa0 & 0xffffu) >> 6); fu[1] = (float)((pa1 & 0xffffu) >> 6);
+            fu[2] = (float)((pb0 & 0xffffu) >> 6); fu[3] = (float)((pb1 & 0xffffu) >> 6);
+            fv[0] = (float)(pa0 >> 22); fv[1] = (float)(pa1 >> 22); fv[2] = (float)(pb0 >> 22); fv[3] = (float)(pb1 >> 22);
+        } else {
+            const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
+            const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
+            uint32_t ca = vua[j], cb = vub[j];
+            if (vu) { // NV21: swap the bytes of every pair once, then everything below is NV12
+                ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
+                cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
+            }
+            const uint32_t pa0 = (ca >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (ca >> 16) & 0xffffu;
+            const uint32_t pb0 = (cb >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (cb >> 16) & 0xffffu;
+            fy[0] = (float)ya0; fy[1] = (float)ya1; fy[2] = (float)yb0; fy[3] = (float)yb1;
+            fu[0] = (float)(pa0 & 0xffu); fu[1] = (float)(pa1 & 0xffu); fu[2] = (float)(pb0 & 0xffu); fu[3] = (float)(pb1 & 0xffu);
+            fv[0] = (float)(pa0 >> 8); fv[1] = (float)(pa1 >> 8); fv[2] = (float)(pb0 >> 8); fv[3] = (float)(pb1 >> 8);
         }
-        const uint32_t pa0 = (ca >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (ca >> 16) & 0xffffu;
-        const uint32_t pb0 = (cb >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (cb >> 16) & 0xffffu;
 
         float t00[4], t10[4], t01[4], t11[4];
         if (yuv_range == CVGS_YUV_FULL) { // wave-uniform
-            k4_tap<CN, true>((float)ya0, (float)(pa0 & 0xffu), (float)(pa0 >> 8), yk, t00);
-            k4_tap<CN, true>((float)ya1, (float)(pa1 & 0xffu), (float)(pa1 >> 8), yk, t10);
-            k4_tap<CN, true>((float)yb0, (float)(pb0 & 0xffu), (float)(pb0 >> 8), yk, t01);
-            k4_tap<CN, true>((float)yb1, (float)(pb1 & 0xffu), (float)(pb1 >> 8), yk, t11);
+            k4_tap<CN, true>(fy[0], fu[0], fv[0], yk, t00);
+            k4_tap<CN, true>(fy[1], fu[1], fv[1], yk, t10);
+            k4_tap<CN, true>(fy[2], fu[2], fv[2], yk, t01);
+            k4_tap<CN, true>(fy[3], fu[3], fv[3], yk, t11);
         } else {
-            k4_tap<CN, false>((float)ya0, (float)(pa0 & 0xffu), (float)(pa0 >> 8), yk, t00);
-            k4_tap<CN, false>((float)ya1, (float)(pa1 & 0xffu), (float)(pa1 >> 8), yk, t10);
-            k4_tap<CN, false>((float)yb0, (float)(pb0 & 0xffu), (float)(pb0 >> 8), yk, t01);
-            k4_tap<CN, false>((float)yb1, (float)(pb1 & 0xffu), (float)(pb1 >> 8), yk, t11);
+            k4_tap<CN, false>(fy[0], fu[0], fv[0], yk, t00);
+            k4_tap<CN, false>(fy[1], fu[1], fv[1], yk, t10);
+            k4_tap<CN, false>(fy[2], fu[2], fv[2], yk, t01);
+            k4_tap<CN, false>(fy[3], fu[3], fv[3], yk, t11);
         }
 
         const float w00 = wxa * wya[j], w10 = wxb * wya[j], w01 = wxa * wyb[j], w11 = wxb * wyb[j];
@@ -238,7 +267,7 @@ static N12Many& tls_many() {
     return m;
 }
 
-template <class Prog, typename OT, int RPW, int CN>
+template <class Prog, typename OT, int RPW, int CN, bool S16>
 static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g_in, hipStream_t s) {
     N12Geom g = g_in;
     const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + kK4Waves * RPW - 1) / (kK4Waves * RPW));
@@ -250,7 +279,7 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         a.c = c;
         for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
-        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
         return hipGetLastError();
     }
     const dim3 grid(col_tiles, row_groups, c.read.batch);
@@ -258,12 +287,12 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     } else { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     }
     return hipGetLastError();
 }
@@ -273,7 +302,9 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     // One output row per wave.  Two rows per wave were measured for whole-frame outputs (cfg #3: 14400 one-row waves need two
     // rounds of the chip's 8192 wave slots) and lost: 8.27 vs 8.08 us, and 5.29 vs 4.52 us on 50 crops -- the launch is
     // bound by the VALU work per row (~100 instructions x 14 waves per SIMD) plus the launch floor, not by residency.
-    return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3>(c, ip, ni, g, s);
+    if (c.read.yuv_layout == CVGS_YUV_P010)
+        return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, true>(c, ip, ni, g, s);
+    return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false>(c, ip, ni, g, s);
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
@@ -305,7 +336,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     }
     const ChainArgs& c = f16 ? c_cut : c_in;
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
-    if (r.yuv_layout > CVGS_YUV_NV21) return 0; // planar chroma (I420 / YV12): the interpreted kernel
+    if (r.yuv_layout == CVGS_YUV_I420 || r.yuv_layout == CVGS_YUV_YV12) return 0; // planar chroma: the interpreted kernel
     if (segs) {
         if (n_segs < 1 || n_segs > CVGS_MAX_CHAINS || c_in.write.data2) return 0;
     } else {

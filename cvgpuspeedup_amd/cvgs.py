@@ -97,7 +97,7 @@ class GpuMat:
         if x < 0 or y < 0 or x + w > self.cols or y + h > self.rows:
             raise ValueError("ROI outside the matrix")
         parent_uv = getattr(self, "uv_offset", 0) or self.rows * self.step
-        m = GpuMat(h, w, self.cv_type, self.data + y * self.step + x, self.step, owner=self.owner)
+        m = GpuMat(h, w, self.cv_type, self.data + y * self.step + x * elem_size(self.cv_type), self.step, owner=self.owner)
         m.uv_offset = parent_uv + (y // 2 - y) * self.step
         return m
 
@@ -242,12 +242,13 @@ def cast(in_type, out_type):
 def read_nv12(mat, dsize=None, color_range=capi.YUV_FULL, primaries=capi.BT709, alpha=True, layout=capi.YUV_NV12):
     """fk::ReadYUV<NV12> + fk::ConvertYUVToRGB<NV12, range, primaries, alpha, floatN>, optionally as the
     BackIOp of fk::Resize<INTER_LINEAR> (reference tests/resize/test_fused_resize.cu:141-143).
-    `mat` is the CV_8UC1 luma view (rows = luma height); the UV plane follows it in memory."""
+    `mat` is the CV_8UC1 luma view (rows = luma height); the UV plane follows it in memory.  layout = YUV_P010: the luma
+    view is CV_16UC1 (10-bit codes in the high bits of 16-bit samples) and R, G, B come out on the 0..1023 scale."""
     kind = capi.READ_NV12 if dsize is None else capi.READ_NV12_RESIZE_LINEAR
     mats = [mat] if isinstance(mat, GpuMat) else list(mat)  # a list = N crops (GpuMat.nv12_roi) of decoder surfaces, one launch
-    rd = ReadIOp(kind, make_type(DEPTH_8U, 1), mats, len(mats), dsize, IGNORE_AR, None,
+    rd = ReadIOp(kind, make_type(DEPTH_16U if layout == capi.YUV_P010 else DEPTH_8U, 1), mats, len(mats), dsize, IGNORE_AR, None,
                  (color_range, primaries, 1 if alpha else 0))
-    rd.yuv_layout = layout  # fk::ReadYUV<PF>: NV12 (the reference's), NV21, I420, YV12
+    rd.yuv_layout = layout  # fk::ReadYUV<PF>: NV12 (the reference's), NV21, I420, YV12, P010
     return rd
 
 

@@ -173,18 +173,35 @@ inline auto resize(const std::array<cv::cuda::GpuMat, NPtr>& input, const cv::Si
 // cvtColorNV12<cv::COLOR_YUV2BGR_NV12 | RGB | BGRA | RGBA>(nv12): reads a decoder surface (CV_8UC1 GpuMat with
 // H luma rows followed by H/2 interleaved UV rows, i.e. rows = H*3/2) as float BGR/RGB[A] pixels -- the first IOp of
 // a chain.  resize<INTER>(thatIOp, dsize) fuses it as the read-back of the bilinear resize (one kernel).
-template <cv::ColorConversionCodes CODE, fk::ColorRange CR = fk::Full, fk::ColorPrimitives CP = fk::bt709>
-inline auto cvtColorNV12(const cv::cuda::GpuMat& nv12) {
+namespace internal {
+template <fk::PixelFormat PF, cv::ColorConversionCodes CODE, fk::ColorRange CR, fk::ColorPrimitives CP>
+inline auto yuv_surface_read(const cv::cuda::GpuMat& surf, const char* what) {
     static_assert(CODE == cv::COLOR_YUV2RGB_NV12 || CODE == cv::COLOR_YUV2BGR_NV12 || CODE == cv::COLOR_YUV2RGBA_NV12 ||
                   CODE == cv::COLOR_YUV2BGRA_NV12, "Color conversion type not supported yet.");
-    if (nv12.type() != CV_8UC1 || nv12.rows % 3 != 0) throw std::runtime_error("cvtColorNV12 needs a CV_8UC1 surface with rows = H * 3 / 2");
+    if (surf.type() != (PF == fk::P010 ? CV_16UC1 : CV_8UC1) || surf.rows % 3 != 0)
+        throw std::runtime_error(std::string(what) + " needs a single-channel surface (CV_8UC1; CV_16UC1 for P010) with rows = H * 3 / 2");
     constexpr bool alpha = CODE == cv::COLOR_YUV2RGBA_NV12 || CODE == cv::COLOR_YUV2BGRA_NV12;
     constexpr bool swap = CODE == cv::COLOR_YUV2BGR_NV12 || CODE == cv::COLOR_YUV2BGRA_NV12;
     using O = std::conditional_t<alpha, float4, float3>;
-    fk::RawPtr<fk::_2D, uchar> luma;
-    luma.data = nv12.data;
-    luma.dims = {(uint)nv12.cols, (uint)(nv12.rows / 3 * 2), (uint)nv12.step};
-    return fk::YuvRead<fk::NV12, CR, CP, alpha, O, swap>{luma};
+    fk::RawPtr<fk::_2D, fk::YuvSample<PF>> luma;
+    luma.data = (fk::YuvSample<PF>*)surf.data;
+    luma.dims = {(uint)surf.cols, (uint)(surf.rows / 3 * 2), (uint)surf.step};
+    return fk::YuvRead<PF, CR, CP, alpha, O, swap>{luma};
+}
+template <typename Read, size_t N>
+inline void yuv_surface_crops(Read& rd, const cv::cuda::GpuMat& surf, const std::array<cv::Rect, N>& crops) {
+    const int H = surf.rows / 3 * 2, step = (int)surf.step, esz = (int)surf.elemSize();
+    for (const cv::Rect& r : crops) {
+        if ((r.x | r.y | r.width | r.height) & 1) throw std::runtime_error("NV12 crops need even x, y, width and height");
+        if (r.x < 0 || r.y < 0 || r.width < 2 || r.height < 2 || r.x + r.width > surf.cols || r.y + r.height > H)
+            throw std::runtime_error("NV12 crop outside the surface");
+        rd.crops.push_back(cvgs_image2d{surf.data + (size_t)r.y * step + (size_t)r.x * esz, r.width, r.height, step, (H - r.y + r.y / 2) * step});
+    }
+}
+} // namespace internal
+template <cv::ColorConversionCodes CODE, fk::ColorRange CR = fk::Full, fk::ColorPrimitives CP = fk::bt709>
+inline auto cvtColorNV12(const cv::cuda::GpuMat& nv12) {
+    return internal::yuv_surface_read<fk::NV12, CODE, CR, CP>(nv12, "cvtColorNV12");
 }
 // cvtColorNV12<CODE>(nv12, crops): N crops of the surface (even x, y, width, height) as a batch of N planes -- with
 // resize<INTER>(thatIOp, dsize) the decode-side version of the headline path: N detections of a decoder surface ->
@@ -192,13 +209,20 @@ inline auto cvtColorNV12(const cv::cuda::GpuMat& nv12) {
 template <cv::ColorConversionCodes CODE, fk::ColorRange CR = fk::Full, fk::ColorPrimitives CP = fk::bt709, size_t N>
 inline auto cvtColorNV12(const cv::cuda::GpuMat& nv12, const std::array<cv::Rect, N>& crops) {
     auto rd = cvtColorNV12<CODE, CR, CP>(nv12);
-    const int H = nv12.rows / 3 * 2, step = (int)nv12.step;
-    for (const cv::Rect& r : crops) {
-        if ((r.x | r.y | r.width | r.height) & 1) throw std::runtime_error("NV12 crops need even x, y, width and height");
-        if (r.x < 0 || r.y < 0 || r.width < 2 || r.height < 2 || r.x + r.width > nv12.cols || r.y + r.height > H)
-            throw std::runtime_error("NV12 crop outside the surface");
-        rd.crops.push_back(cvgs_image2d{nv12.data + (size_t)r.y * step + r.x, r.width, r.height, step, (H - r.y + r.y / 2) * step});
-    }
+    internal::yuv_surface_crops(rd, nv12, crops);
+    return rd;
+}
+// cvtColorP010<CODE[, range, primaries]>(p010[, crops]): the same for a 10-bit decoder surface (CV_16UC1, rows = H * 3 / 2,
+// 10-bit codes in the high bits of every sample); R, G, B[, A] arrive on the 0..1023 scale (A = 1023).  The codes reuse
+// OpenCV's *_NV12 names for the channel order.
+template <cv::ColorConversionCodes CODE, fk::ColorRange CR = fk::Limited, fk::ColorPrimitives CP = fk::bt2020>
+inline auto cvtColorP010(const cv::cuda::GpuMat& p010) {
+    return internal::yuv_surface_read<fk::P010, CODE, CR, CP>(p010, "cvtColorP010");
+}
+template <cv::ColorConversionCodes CODE, fk::ColorRange CR = fk::Limited, fk::ColorPrimitives CP = fk::bt2020, size_t N>
+inline auto cvtColorP010(const cv::cuda::GpuMat& p010, const std::array<cv::Rect, N>& crops) {
+    auto rd = cvtColorP010<CODE, CR, CP>(p010);
+    internal::yuv_surface_crops(rd, p010, crops);
     return rd;
 }
 template <int INTER_F, fk::PixelFormat PF, fk::ColorRange CR, fk::ColorPrimitives CP, bool ALPHA, typename O, bool SW>

@@ -79,11 +79,12 @@ enum InterpolationType { INTER_LINEAR = 1 };
 enum AspectRatio { PRESERVE_AR = 0, IGNORE_AR = 1, PRESERVE_AR_RN_EVEN = 2, PRESERVE_AR_LEFT = 3 };
 enum class CircularTensorOrder { NewestFirst = 0, OldestFirst = 1 };
 enum class ColorPlanes { Standard = 0, Transposed = 1 };
-// fk::PixelFormat: the reference's tests instantiate NV12 only; NV21 / I420 / YV12 are this engine's further 4:2:0 readers
-// (numeric values = cvgs_yuv_layout)
-enum PixelFormat { NV12 = 0, NV21 = 1, I420 = 2, YV12 = 3 };
+// fk::PixelFormat: the reference's tests instantiate NV12 only; NV21 / I420 / YV12 / P010 (10-bit codes in 16-bit samples, the
+// result on the 0..1023 scale) are this engine's further 4:2:0 readers (numeric values = cvgs_yuv_layout)
+enum PixelFormat { NV12 = 0, NV21 = 1, I420 = 2, YV12 = 3, P010 = 4 };
 enum ColorRange { Full = 0, Limited = 1 };
-enum ColorPrimitives { bt601 = 0, bt709 = 1 };
+enum ColorPrimitives { bt601 = 0, bt709 = 1, bt2020 = 2 };
+template <PixelFormat PF> using YuvSample = std::conditional_t<PF == P010, unsigned short, unsigned char>;
 enum ColorConversionCodes {
     COLOR_BGR2BGRA = 0, COLOR_RGB2RGBA = 0, COLOR_BGRA2BGR = 1, COLOR_RGBA2RGB = 1, COLOR_BGR2RGBA = 2,
     COLOR_RGB2BGRA = 2, COLOR_RGBA2BGR = 3, COLOR_BGRA2RGB = 3, COLOR_BGR2RGB = 4, COLOR_RGB2BGR = 4,
@@ -493,21 +494,21 @@ template <ColorConversionCodes CODE, typename I, typename O = I> struct ColorCon
 
 // ---- NV12 read-back ------------------------------------------------------------------------------------------------
 template <PixelFormat PF> struct ReadYUV {
-    using ParamsType = RawPtr<_2D, uchar>; // luma view; the interleaved UV plane follows it (height/2 rows)
-    using OutputType = uchar3;             // (Y, U, V) -- only meaningful fused with ConvertYUVToRGB
+    using ParamsType = RawPtr<_2D, YuvSample<PF>>; // luma view; the chroma plane(s) follow it (height/2 rows)
+    using OutputType = VectorType_t<YuvSample<PF>, 3>; // (Y, U, V) -- only meaningful fused with ConvertYUVToRGB
     static void lower(const ParamsType&, ChainBuilder&) {
         throw std::runtime_error("ReadYUV must be fused with ConvertYUVToRGB (fk::fuse) on this engine");
     }
 };
-template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O = std::conditional_t<ALPHA, uchar4, uchar3>>
+template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O = VectorType_t<YuvSample<PF>, ALPHA ? 4 : 3>>
 struct ConvertYUVToRGB {
-    using InputType = uchar3;
+    using InputType = VectorType_t<YuvSample<PF>, 3>;
     using OutputType = O;
 };
 
 // fuse(Read<ReadYUV>, Unary<ConvertYUVToRGB>) -> one read IOp producing RGB(A)
 template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O, bool SWAP_RB = false> struct YuvRead {
-    RawPtr<_2D, uchar> params;
+    RawPtr<_2D, YuvSample<PF>> params;
     // optional: N crops of the surface (even x, y, w, h), each a view with its own luma -> chroma offset; the read is
     // then a batch of N planes in ONE launch (engine extension: crops straight from a decoder surface)
     detail::SmallVec<cvgs_image2d, detail::kInlinePlanes> crops;
@@ -520,7 +521,7 @@ template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typenam
     }
     void lower_read(ChainBuilder& b, int kind) const {
         cvgs_read_desc& r = b.d.read;
-        r.kind = kind; r.src_type = CV_8UC1;
+        r.kind = kind; r.src_type = PF == P010 ? CV_16UC1 : CV_8UC1;
         r.yuv_range = (int)CR; r.yuv_primaries = (int)CP; r.yuv_alpha = ALPHA ? 1 : 0;
         r.yuv_layout = (int)PF;
         if (crops.empty()) b.src.assign(1, image2d(params));

@@ -122,15 +122,20 @@ typedef enum cvgs_aspect_ratio {
 } cvgs_aspect_ratio;
 
 typedef enum cvgs_yuv_range { CVGS_YUV_FULL = 0, CVGS_YUV_LIMITED = 1 } cvgs_yuv_range;
-typedef enum cvgs_yuv_primaries { CVGS_BT601 = 0, CVGS_BT709 = 1 } cvgs_yuv_primaries;
+typedef enum cvgs_yuv_primaries { CVGS_BT601 = 0, CVGS_BT709 = 1, CVGS_BT2020 = 2 /* non-constant luminance */ } cvgs_yuv_primaries;
 /* 4:2:0 layouts of the NV12 read kinds (the reference spells the reader as a template on the pixel format,
  * fk::ReadYUV<fk::NV12>, tests/resize/test_fused_resize.cu:50; NV12 is the only format its tests instantiate):
  *   NV12: interleaved chroma plane, U first;  NV21: the same, V first;
  *   I420: planar chroma, a (W/2) x (H/2) U plane with rows of step/2 bytes directly followed by the V plane; YV12: V plane first.
  * The chroma of luma row 0 starts uv_offset bytes after `data` (0 = height * step, the whole surface).  Crops
  * (uv_offset != 0) exist for the interleaved layouts only: a crop of a planar-chroma surface cannot say where its second
- * chroma plane starts (CVGS_ERR_UNSUPPORTED).                                                                      */
-typedef enum cvgs_yuv_layout { CVGS_YUV_NV12 = 0, CVGS_YUV_NV21 = 1, CVGS_YUV_I420 = 2, CVGS_YUV_YV12 = 3 } cvgs_yuv_layout;
+ * chroma plane starts (CVGS_ERR_UNSUPPORTED).
+ *   P010: the 10-bit decoder surface -- NV12's geometry with 16-bit little-endian samples whose 10 significant bits are the
+ *         MOST significant ones (code = sample >> 6); src_type is CV_16UC1, width / height in samples, step and uv_offset in
+ *         BYTES.  The conversion works on the 10-bit codes (chroma centre 512, limited range 64..940 / 64..960) and delivers
+ *         R, G, B on the 10-bit scale, 0..1023 (alpha = 1023): convertTo CV_16U for a 10-bit image, or scale by 1/1023 in
+ *         the chain for a network input.                                                                             */
+typedef enum cvgs_yuv_layout { CVGS_YUV_NV12 = 0, CVGS_YUV_NV21 = 1, CVGS_YUV_I420 = 2, CVGS_YUV_YV12 = 3, CVGS_YUV_P010 = 4 } cvgs_yuv_layout;
 
 #define CVGS_READ_FLAG_TABLE_ON_DEVICE 1u /* `src` is a device table made by cvgs_plane_table_build */
 

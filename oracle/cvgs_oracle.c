@@ -177,52 +177,77 @@ void oracle_resize_geometry(int32_t src_w, int32_t src_h, int32_t dst_w, int32_t
  * the reference test asserts nothing about the values]. */
 typedef struct yuv_coeffs {
     float ysub, yscale, rv, gu, gv, bu;
+    float csub, amax; /* chroma centre and alpha (= full scale): 128 / 255 for 8-bit samples, 512 / 1023 for P010 */
 } yuv_coeffs;
 
-static yuv_coeffs yuv_matrix(int range, int primaries) {
+/* Coefficients written as the 6-decimal literals of the published derivation from the standards' luma weights
+ * (BT.601 Kr 0.299 Kb 0.114, BT.709 Kr 0.2126 Kb 0.0722, BT.2020 non-constant luminance Kr 0.2627 Kb 0.0593):
+ * R = Y' + 2(1-Kr) Cr, B = Y' + 2(1-Kb) Cb, G = Y' - 2Kb(1-Kb)/Kg Cb - 2Kr(1-Kr)/Kg Cr; limited range scales luma by
+ * 255/219 and chroma by 255/224 on 8-bit codes, by 1023/876 and 1023/896 on 10-bit codes.  tests/test_independent_pins.py
+ * re-derives every set in float64. */
+static yuv_coeffs yuv_matrix(int range, int primaries, int ten_bit) {
+    static const float full[3][4] = {{1.402f, -0.344136f, -0.714136f, 1.772f},
+                                     {1.5748f, -0.187324f, -0.468124f, 1.8556f},
+                                     {1.4746f, -0.164553f, -0.571353f, 1.8814f}};
+    static const float lim8[3][4] = {{1.596027f, -0.391762f, -0.812968f, 2.017232f},
+                                     {1.792741f, -0.213249f, -0.532909f, 2.112402f},
+                                     {1.678674f, -0.187326f, -0.650424f, 2.141772f}};
+    static const float lim10[3][4] = {{1.600721f, -0.392915f, -0.815359f, 2.023165f},
+                                      {1.798014f, -0.213876f, -0.534477f, 2.118615f},
+                                      {1.683611f, -0.187877f, -0.652337f, 2.148072f}};
     yuv_coeffs k;
+    const float* m;
     if (range == CVGS_YUV_FULL) {
         k.ysub = 0.f;
         k.yscale = 1.f;
-        if (primaries == CVGS_BT601) { k.rv = 1.402f; k.gu = -0.344136f; k.gv = -0.714136f; k.bu = 1.772f; }
-        else { k.rv = 1.5748f; k.gu = -0.187324f; k.gv = -0.468124f; k.bu = 1.8556f; }
+        m = full[primaries];
     } else {
-        k.ysub = 16.f;
-        k.yscale = 1.164383f;
-        if (primaries == CVGS_BT601) { k.rv = 1.596027f; k.gu = -0.391762f; k.gv = -0.812968f; k.bu = 2.017232f; }
-        else { k.rv = 1.792741f; k.gu = -0.213249f; k.gv = -0.532909f; k.bu = 2.112402f; }
+        k.ysub = ten_bit ? 64.f : 16.f;
+        k.yscale = ten_bit ? 1.167808f : 1.164383f;
+        m = ten_bit ? lim10[primaries] : lim8[primaries];
     }
+    k.rv = m[0]; k.gu = m[1]; k.gv = m[2]; k.bu = m[3];
+    k.csub = ten_bit ? 512.f : 128.f;
+    k.amax = ten_bit ? 1023.f : 255.f;
     return k;
 }
 
 static void nv12_pixel(const cvgs_image2d* im, int x, int y, const cvgs_read_desc* rd, opx* p) {
     const uint8_t* base = (const uint8_t*)im->data;
-    const float Y = (float)base[(size_t)y * im->step + x];
     /* a crop of a surface carries its own luma -> chroma offset (cvgs_image2d.uv_offset); 0 = the whole surface */
     const size_t uv_off = im->uv_offset ? (size_t)im->uv_offset : (size_t)im->height * (size_t)im->step;
     /* 4:2:0 layouts (cvgs_yuv_layout): interleaved (U,V) [NV12] or (V,U) [NV21] pairs, one per 2x2 luma block, in rows of
      * `step` bytes; or planar chroma [I420: U plane then V plane, YV12: V then U], (W/2) x (H/2) samples in rows of
-     * step/2 bytes.  The reference instantiates fk::ReadYUV<fk::NV12> only (tests/resize/test_fused_resize.cu:50). */
-    uint8_t u8, v8;
-    if (rd->yuv_layout <= CVGS_YUV_NV21) {
+     * step/2 bytes; or P010 = NV12 with 16-bit samples carrying a 10-bit code in their high bits.  The reference
+     * instantiates fk::ReadYUV<fk::NV12> only (tests/resize/test_fused_resize.cu:50). */
+    float Y, U, V;
+    if (rd->yuv_layout == CVGS_YUV_P010) {
+        const uint16_t* yrow = (const uint16_t*)(base + (size_t)y * im->step);
+        const uint16_t* uv = (const uint16_t*)(base + uv_off + (size_t)(y / 2) * im->step) + 2 * (x / 2);
+        Y = (float)(yrow[x] >> 6);
+        U = (float)(uv[0] >> 6);
+        V = (float)(uv[1] >> 6);
+    } else if (rd->yuv_layout <= CVGS_YUV_NV21) {
         const uint8_t* uv = base + uv_off + (size_t)(y / 2) * im->step + 2 * (x / 2);
-        u8 = uv[rd->yuv_layout == CVGS_YUV_NV21 ? 1 : 0];
-        v8 = uv[rd->yuv_layout == CVGS_YUV_NV21 ? 0 : 1];
+        Y = (float)base[(size_t)y * im->step + x];
+        U = (float)uv[rd->yuv_layout == CVGS_YUV_NV21 ? 1 : 0];
+        V = (float)uv[rd->yuv_layout == CVGS_YUV_NV21 ? 0 : 1];
     } else {
         const size_t cstep = (size_t)(im->step / 2);
         const uint8_t* first = base + uv_off + (size_t)(y / 2) * cstep + (size_t)(x / 2);
         const uint8_t* second = first + (size_t)(im->height / 2) * cstep;
-        u8 = *(rd->yuv_layout == CVGS_YUV_YV12 ? second : first);
-        v8 = *(rd->yuv_layout == CVGS_YUV_YV12 ? first : second);
+        Y = (float)base[(size_t)y * im->step + x];
+        U = (float)*(rd->yuv_layout == CVGS_YUV_YV12 ? second : first);
+        V = (float)*(rd->yuv_layout == CVGS_YUV_YV12 ? first : second);
     }
-    const float cb = (float)u8 - 128.f;
-    const float cr = (float)v8 - 128.f;
-    const yuv_coeffs k = yuv_matrix(rd->yuv_range, rd->yuv_primaries);
+    const yuv_coeffs k = yuv_matrix(rd->yuv_range, rd->yuv_primaries, rd->yuv_layout == CVGS_YUV_P010);
+    const float cb = U - k.csub;
+    const float cr = V - k.csub;
     const float yv = (Y - k.ysub) * k.yscale;
     p->f[0] = yv + k.rv * cr;
     p->f[1] = (yv + k.gu * cb) + k.gv * cr;
     p->f[2] = yv + k.bu * cb;
-    p->f[3] = 255.f;
+    p->f[3] = k.amax;
     p->depth = CVGS_DEPTH_32F;
     p->cn = rd->yuv_alpha ? 4 : 3;
 }

@@ -165,10 +165,57 @@ static void test_nv12_crops_batch(cv::cuda::Stream& stream) {
     CHECK(bit_equal(h_one.data, h_ref.ptr<uchar>(5), (size_t)up.width * up.height * 3 * 4), "a crop view == the same pixels as their own surface");
 }
 
+// the same decode-side path from a 10-bit (P010) decoder surface, BT.2020 limited range: crops -> RGB on the 0..1023 scale ->
+// 64x128 -> x 1/1023 -> normalize -> NCHW, ONE kernel; plus the fk:: spelling (ReadYUV<P010> fused with ConvertYUVToRGB)
+static void test_p010_crops_batch(cv::cuda::Stream& stream) {
+    const int W = 1280, H = 720;
+    constexpr size_t N = 9;
+    const cv::Size up(64, 128);
+    cv::Mat h_p010(H + H / 2, W, CV_16UC1);
+    fill_random(h_p010, 1234); // random 16-bit samples: 10-bit codes plus garbage in the 6 low bits
+    cv::cuda::GpuMat d_p010(h_p010), hv_p010 = host_view(h_p010);
+    std::array<cv::Rect, N> crops;
+    for (size_t i = 0; i < N; ++i) crops[i] = cv::Rect(2 * (int)(i * 53 % 400), 2 * (int)(i * 31 % 200), 16 + 2 * (int)(i * 43 % 300), 32 + 2 * (int)(i * 19 % 150));
+    const size_t n = N * 3 * up.width * up.height;
+    cv::cuda::GpuMat d_out((int)N, up.width * up.height * 3, CV_32F);
+    cv::Mat h_ref((int)N, up.width * up.height * 3, CV_32F);
+    cv::cuda::GpuMat hv_ref = host_view(h_ref);
+    const double k = 1.0 / 1023.0;
+    const cv::Scalar a(k, k, k), s(0.485, 0.456, 0.406), d(0.229, 0.224, 0.225);
+    cvGS::executeOperations(stream, cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorP010<cv::COLOR_YUV2RGB_NV12>(d_p010, crops), up),
+                            cvGS::multiply<CV_32FC3>(a), cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(d_out, up));
+    run_oracle(cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorP010<cv::COLOR_YUV2RGB_NV12>(hv_p010, crops), up), cvGS::multiply<CV_32FC3>(a),
+               cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(hv_ref, up));
+    stream.waitForCompletion();
+    const auto h = fetch(d_out.data, n * 4);
+    CHECK(bit_equal(h.data(), h_ref.data, n * 4), "P010 crop batch -> NCHW, bit-exact vs oracle");
+
+    // fk spelling, whole surface -> 10-bit RGBA image (ushort4): Resize(fuse(ReadYUV<P010>, ConvertYUVToRGB<P010, ..., float4>)) -> SaturateCast
+    const cv::Size down(320, 180);
+    fk::RawPtr<fk::_2D, ushort> dsrc, hsrc;
+    dsrc.data = (ushort*)d_p010.data; dsrc.dims = {(uint)W, (uint)H, (uint)d_p010.step};
+    hsrc.data = (ushort*)h_p010.data; hsrc.dims = {(uint)W, (uint)H, (uint)h_p010.step};
+    cv::cuda::GpuMat d_img(down.height, down.width, CV_16UC4);
+    cv::Mat h_img_ref(down.height, down.width, CV_16UC4);
+    cv::cuda::GpuMat hv_img = host_view(h_img_ref);
+    using Conv = fk::ConvertYUVToRGB<fk::P010, fk::Limited, fk::bt2020, true, float4>;
+    const auto rd_d = fk::Resize<fk::INTER_LINEAR>::build(fk::fuse(fk::Read<fk::ReadYUV<fk::P010>>{dsrc}, fk::Unary<Conv>{}), fk::Size(down.width, down.height));
+    const auto rd_h = fk::Resize<fk::INTER_LINEAR>::build(fk::fuse(fk::Read<fk::ReadYUV<fk::P010>>{hsrc}, fk::Unary<Conv>{}), fk::Size(down.width, down.height));
+    cvGS::executeOperations(stream, rd_d, cvGS::convertTo<CV_32FC4, CV_16UC4>(), cvGS::write<CV_16UC4>(d_img));
+    run_oracle(rd_h, cvGS::convertTo<CV_32FC4, CV_16UC4>(), cvGS::write<CV_16UC4>(hv_img));
+    stream.waitForCompletion();
+    cv::Mat h_img;
+    d_img.download(h_img);
+    bool same = true;
+    for (int y = 0; y < h_img.rows; ++y) same = same && bit_equal(h_img.ptr<uchar>(y), h_img_ref.ptr<uchar>(y), (size_t)h_img.cols * 8);
+    CHECK(same, "fk::ReadYUV<P010> -> ushort4 image, bit-exact vs oracle");
+}
+
 int main() {
     cv::cuda::Stream stream;
     test_nv12_facade_cfg3(stream);
     test_nv12_crops_batch(stream);
+    test_p010_crops_batch(stream);
     test_resize_split_one<CV_8UC3, CV_32FC3>(stream);
     test_resize_split_one<CV_8UC4, CV_32FC4>(stream);
     test_resize_split_one<CV_16UC3, CV_32FC3>(stream);

@@ -76,10 +76,12 @@ def _case(seed, big=False):
     kind = ["pixel", "resize", "resize", "warp", "nv12"][int(rng.integers(0, 5))]
     n = int(rng.integers(1, 4 if big else 6))
     used = n if rng.integers(0, 3) else int(rng.integers(0, n + 1))
+    yuv_layout = int(rng.integers(0, 5))  # NV12 / NV21 / I420 / YV12 / P010
     if kind == "nv12":
-        sdepth, scn = cvgs.CV_8U, 1
+        sdepth, scn = (cvgs.CV_16U if yuv_layout == capi.YUV_P010 else cvgs.CV_8U), 1
         sw, sh = 2 * int(rng.integers(2, 60 * k)), 2 * int(rng.integers(2, 40 * k))
-        srcs = [H.random_u8((sh + sh // 2, sw, 1), seed * 10 + i) for i in range(n)]
+        # P010: random 16-bit samples, i.e. 10-bit codes with garbage in the 6 low bits (which must be ignored)
+        srcs = [(H.random_u16 if sdepth == cvgs.CV_16U else H.random_u8)((sh + sh // 2, sw, 1), seed * 10 + i) for i in range(n)]
         used = n
     else:
         # one case in five draws a CV_64F / CV_16F source (per-pixel and resize reads; CV_16F also warps)
@@ -102,7 +104,6 @@ def _case(seed, big=False):
     prog, fd, fc = _program(rng, d0, c0)
     ft = cvgs.make_type(fd, fc)
     nv12_resize = bool(rng.integers(0, 2))
-    yuv_layout = int(rng.integers(0, 4))  # NV12 / NV21 / I420 / YV12
     crop_views = None
     if kind == "nv12" and rng.integers(0, 2):
         crop_views = []
@@ -159,11 +160,11 @@ def _case(seed, big=False):
             rd = cvgs.warp(cvgs.WARP_PERSPECTIVE if mats_persp[0].shape[0] == 3 else cvgs.WARP_AFFINE, st, mats,
                            [m.tolist() for m in mats_persp], warp_sizes or (dw, dh), max(used, 1) if used == 0 else used, bg[:scn])
         else:
-            lumas = [cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, m.data, m.step, owner=m.owner) for m in mats]
+            lumas = [cvgs.GpuMat(sh, sw, st, m.data, m.step, owner=m.owner) for m in mats]
             layout = yuv_layout
             if nv12_resize and n > 1 and crop_views:  # N crop views (own luma -> chroma offsets) of ONE decoder surface
                 lumas = [lumas[0].nv12_roi(*c) for c in crop_views]
-                layout = yuv_layout & 1  # crops exist for the interleaved layouts only
+                layout = yuv_layout if yuv_layout == capi.YUV_P010 else yuv_layout & 1  # crops exist for the interleaved layouts only
             rd = cvgs.read_nv12(lumas if n > 1 else lumas[0], (dw, dh) if nv12_resize else None,
                                 int(rng_choice[0]), int(rng_choice[1]), alpha, layout=layout)
         if use_table and kind in ("pixel", "resize") and used == n and type(mats[0].owner).__module__.startswith("torch"):
@@ -191,7 +192,7 @@ def _case(seed, big=False):
             wr = cvgs.split(ft, planes if n > 1 else planes[0])
         return [rd] + prog + [wr]
 
-    rng_choice = (rng.integers(0, 2), rng.integers(0, 2))
+    rng_choice = (rng.integers(0, 2), rng.integers(0, 3))  # range; BT.601 / BT.709 / BT.2020
     use_table = bool(rng.integers(0, 3) == 0)
     return build, shape, NP[fd], "%s n=%d used=%d %sC%d %dx%d->%dx%d ops=%d %s out=%s" % (
         kind, n, used, NAME[sdepth], scn, sw, sh, dw, dh, sum(len(o.ops) for o in prog), wk, np.dtype(NP[fd]).name)

@@ -68,18 +68,22 @@ def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False):
             "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4), "updates_per_s": round(1 / t, 1)}
 
 
-def cfg3(dev, iters):
+def cfg3(dev, iters, p010=False):
+    """p010: the same frame as a 10-bit decoder surface (16-bit samples, BT.2020 limited range, x 1/1023 in the chain)."""
     w, h = W.FRAME_6K
     dst = (1280, 720)
-    bufs = [W.random_u8_torch((h + h // 2, w), 500 + i, dev) for i in range(6)]
+    sb = 2 if p010 else 1
+    bufs = [W.random_u8_torch((h + h // 2, w * sb), 500 + i, dev) for i in range(6)]
     outs = [torch.zeros((1, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev) for _ in range(6)]
     f = cvgs.CV_32FC3
     s = torch.cuda.current_stream()
     chains, ops = [], None
     for b, o in zip(bufs, outs):
-        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, b.data_ptr(), w, owner=b)
-        ops = [cvgs.read_nv12(luma, dst, capi.YUV_FULL, capi.BT709, False), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
-               cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3]),
+        luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1 if p010 else cvgs.CV_8UC1, b.data_ptr(), w * sb, owner=b)
+        rd = (cvgs.read_nv12(luma, dst, capi.YUV_LIMITED, capi.BT2020, False, layout=capi.YUV_P010) if p010 else
+              cvgs.read_nv12(luma, dst, capi.YUV_FULL, capi.BT709, False))
+        ops = [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
+               cvgs.multiply(f, [1 / 1023.0 if p010 else W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3]),
                cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), dst)]
         chains.append(cvgs.lower(ops))
     lib = capi.load_library()
@@ -93,9 +97,9 @@ def cfg3(dev, iters):
     t = events_time(launch, iters)
     write = dst[0] * dst[1] * 3 * 4
     # scale 4.8: every output pixel taps 4 distinct luma bytes and up to 4 distinct UV pairs (SURVEY.md 8d bound)
-    read = dst[0] * dst[1] * 4 + dst[0] * dst[1] * 2 * 4
+    read = (dst[0] * dst[1] * 4 + dst[0] * dst[1] * 2 * 4) * sb
     alg = write + read
-    return {"config": "cfg3 NV12 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, one kernel",
+    return {"config": "cfg3 %s 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, one kernel" % ("P010 (10-bit, BT.2020 limited)" if p010 else "NV12"),
             "kernel": cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
             "GB_per_s": round(alg / t / 1e9, 1), "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4),
             "output_Mpix_per_s": round(dst[0] * dst[1] / t / 1e6, 1), "source_Mpix_per_s": round(w * h / t / 1e6, 1)}
@@ -186,6 +190,7 @@ def run_all(dev, iters=100, only=""):
         res.append(cfg4(dev, iters, True, mirrored=True))
     if only in ("", "cfg3"):
         res.append(cfg3(dev, iters))
+        res.append(cfg3(dev, iters, p010=True))
     if only in ("", "nv12many"):
         res.append(nv12_many(dev, iters))
     if only in ("", "nv12crops"):

@@ -50,6 +50,7 @@ int depth_bytes(int depth) {
 }
 
 bool is_resize(int kind) { return kind == CVGS_READ_RESIZE_LINEAR || kind == CVGS_READ_NV12_RESIZE_LINEAR; }
+constexpr int kMaxDim = CVGS_MAX_DIM; // widest / tallest plane the 32-bit index arithmetic of the kernels is specified for
 bool is_nv12(int kind) { return kind == CVGS_READ_NV12 || kind == CVGS_READ_NV12_RESIZE_LINEAR; }
 bool is_warp(int kind) { return kind == CVGS_READ_WARP_AFFINE || kind == CVGS_READ_WARP_PERSPECTIVE; }
 
@@ -214,6 +215,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     }
     if (is_resize(rd.kind)) {
         if (rd.dst_width < 1 || rd.dst_height < 1) return fail(CVGS_ERR_INVALID, "resize target must be positive");
+        if (rd.dst_width > kMaxDim || rd.dst_height > kMaxDim) return fail(CVGS_ERR_UNSUPPORTED, "resize target wider or taller than 2^24 pixels");
         if (rd.aspect_ratio < CVGS_PRESERVE_AR || rd.aspect_ratio > CVGS_PRESERVE_AR_LEFT)
             return fail(CVGS_ERR_INVALID, "bad aspect ratio mode");
     }
@@ -242,6 +244,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         L.out_h = rd.dst_height;
         if (L.out_w < 1 || L.out_h < 1)
             return fail(CVGS_ERR_INVALID, "device plane tables need dst_width/dst_height (the plane extent)");
+        if (L.out_w > kMaxDim || L.out_h > kMaxDim) return fail(CVGS_ERR_UNSUPPORTED, "plane wider or taller than 2^24 pixels");
     } else {
         const cvgs_image2d* src = (const cvgs_image2d*)rd.src;
         if (is_warp(rd.kind)) {
@@ -253,6 +256,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
                 P.dw = rd.warp_dst_sizes ? rd.warp_dst_sizes[2 * z] : rd.dst_width;
                 P.dh = rd.warp_dst_sizes ? rd.warp_dst_sizes[2 * z + 1] : rd.dst_height;
                 if (P.dw < 1 || P.dh < 1) return fail(CVGS_ERR_INVALID, "warp target must be positive");
+                if (P.dw > kMaxDim || P.dh > kMaxDim) return fail(CVGS_ERR_UNSUPPORTED, "warp target wider or taller than 2^24 pixels");
                 max_w = std::max(max_w, (int)P.dw);
                 max_h = std::max(max_h, (int)P.dh);
             }
@@ -261,6 +265,7 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             for (int z = 0; z < rd.used_planes; ++z) {
                 const cvgs_image2d& im = src[z];
                 if (!im.data || im.width < 1 || im.height < 1) return fail(CVGS_ERR_INVALID, "empty source plane");
+                if (im.width > kMaxDim || im.height > kMaxDim) return fail(CVGS_ERR_UNSUPPORTED, "source plane wider or taller than 2^24 pixels");
                 if (im.step < im.width * depth_bytes(sdepth) * scn) return fail(CVGS_ERR_INVALID, "source step smaller than a row");
                 WarpPlane& P = L.warp_planes[(size_t)z];
                 P.data = (const uint8_t*)im.data;
@@ -275,6 +280,8 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
         for (int z = 0; z < (is_warp(rd.kind) ? 0 : rd.used_planes); ++z) {
             const cvgs_image2d& im = src[z];
             if (!im.data || im.width < 1 || im.height < 1) return fail(CVGS_ERR_INVALID, "empty source plane");
+            // 32-bit index arithmetic in the kernels (byte offsets inside a row, chroma offsets): rows stay below 2^24 pixels
+            if (im.width > kMaxDim || im.height > kMaxDim) return fail(CVGS_ERR_UNSUPPORTED, "source plane wider or taller than 2^24 pixels");
             const int esz = depth_bytes(sdepth) * scn;
             if (im.step < im.width * esz) return fail(CVGS_ERR_INVALID, "source step smaller than a row");
             if (is_nv12(rd.kind) && ((im.width & 1) || (im.height & 1)))
@@ -292,7 +299,9 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
                     if (im.uv_offset) return fail(CVGS_ERR_UNSUPPORTED, "crops of planar-chroma (I420 / YV12) surfaces");
                     if (im.step & 1) return fail(CVGS_ERR_INVALID, "I420 / YV12 surfaces need an even step (chroma rows are step/2 bytes)");
                 }
-                P.uv_off = im.uv_offset ? im.uv_offset : im.height * im.step;
+                const int64_t uv_off = im.uv_offset ? (int64_t)im.uv_offset : (int64_t)im.height * im.step;
+                if (uv_off > INT32_MAX) return fail(CVGS_ERR_UNSUPPORTED, "4:2:0 surfaces whose luma plane exceeds 2 GiB");
+                P.uv_off = (int32_t)uv_off;
             }
             if (R.is_resize) plane_geometry(im.width, im.height, rd.dst_width, rd.dst_height, rd.aspect_ratio, P);
             else if (im.width != src[0].width || im.height != src[0].height)
@@ -312,6 +321,8 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             L.out_h = wr.height;
         }
     }
+    if (L.out_w < 1 || L.out_h < 1) return fail(CVGS_ERR_INVALID, "empty output plane");
+    if (L.out_w > kMaxDim || L.out_h > kMaxDim) return fail(CVGS_ERR_UNSUPPORTED, "plane wider or taller than 2^24 pixels");
     R.dst_w = L.out_w;
     R.dst_h = L.out_h;
 

@@ -41,6 +41,10 @@ extern "C" {
 #define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
 #define CVGS_MAX_MIRRORS 7     /* extra tensors one chain can write (the 7 peers of an 8-GPU node)  */
 #define CVGS_MAX_CHAINS 128    /* chains one cvgs_execute_many launch can fuse                     */
+/* Size limits (CVGS_ERR_UNSUPPORTED beyond them; the kernels index inside a row with 32-bit arithmetic): source planes and
+ * output planes are at most 2^24 pixels wide and tall; the chroma plane of a 4:2:0 surface starts less than 2 GiB after its
+ * luma plane.  Row pitches, plane strides and tensor sizes are 64-bit: a 288 GB tensor is addressable.              */
+#define CVGS_MAX_DIM (1 << 24)
 
 typedef void* cvgs_stream_t; /* hipStream_t (0 = the null stream) */
 

@@ -96,6 +96,35 @@ def test_validation_errors(lib):
     assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_UNSUPPORTED
 
 
+def test_dimension_limits(lib):
+    """The kernels index rows with 32-bit arithmetic: planes above 2^24 pixels per side, and 4:2:0 surfaces whose luma plane
+    exceeds 2 GiB, are refused at validation instead of wrapping around (nothing is dereferenced by cvgs_validate)."""
+    ops, keep = _k1()
+
+    def code(mut):
+        ch = cvgs.lower(ops)
+        mut(ch.desc)
+        return lib.cvgs_validate(C.byref(ch.desc))
+
+    big = (1 << 24) + 1
+    assert code(lambda d: setattr(d.read, "dst_width", big)) == capi.ERR_UNSUPPORTED
+    assert code(lambda d: setattr(d.read, "dst_height", big)) == capi.ERR_UNSUPPORTED
+
+    def wide_source(d):
+        im = C.cast(d.read.src, C.POINTER(capi.Image2D))[0]
+        im.width, im.step = big, 3 * big
+    assert code(wide_source) == capi.ERR_UNSUPPORTED
+    # a P010 surface 40000 x 40000: the chroma plane would start 3.2 GB after the luma plane
+    fake = np.zeros((4, 4), np.uint16)
+    luma = cvgs.GpuMat(40000, 40000, cvgs.CV_16UC1, fake.ctypes.data, 80000, owner=fake)
+    out = np.zeros((1, 3 * 8 * 8), np.float32)
+    ch = cvgs.lower([cvgs.read_nv12(luma, (8, 8), alpha=False, layout=capi.YUV_P010), cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), (8, 8))])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_UNSUPPORTED
+    luma = cvgs.GpuMat(20000, 40000, cvgs.CV_16UC1, fake.ctypes.data, 80000, owner=fake)  # 1.6 GB: fine
+    ch = cvgs.lower([cvgs.read_nv12(luma, (8, 8), alpha=False, layout=capi.YUV_P010), cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), (8, 8))])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == 0
+
+
 def _oracle_k1(oracle, frame, crops):
     ref = np.zeros((len(crops), 3 * 64 * 128), np.float32)
     oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))

@@ -154,3 +154,34 @@ def test_cfg4_full_size_resize_push_matches_the_oracle(oracle):
         H.assert_bit_exact(got[age], ref[0], "cfg4 resize push, slot of age %d" % age)
     assert not got[3:].any()
     ct.release()
+
+
+@pytest.mark.parametrize("flags", [0, capi.CHAIN_FORCE_GENERIC])
+def test_output_tensor_larger_than_4_gib(oracle, flags):
+    """45,000 crops of one 4K frame -> [45000,3,128,64] fp32 = 4.42 GB in ONE launch: plane strides and tensor offsets are
+    64-bit (sized for 288 GB of HBM).  Planes at the start, across the 4 GiB boundary and at the end are compared with the
+    oracle run on those crops alone (a plane depends on its crop only); on the fast kernel and on the interpreted one."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 45000
+    plane = 3 * 64 * 128
+    fw, fh = W.FRAME_4K
+    frame = H.random_u8((fh, fw, 3), seed=99)
+    crops = H.random_crops(n, fw, fh, seed=424242)
+    ft = torch.from_numpy(frame).to(dev)
+    out = torch.empty((n, plane), dtype=torch.float32, device=dev)
+    assert out.numel() * 4 > (1 << 32)
+    out.fill_(-7.0)
+    cvgs.executeOperations(torch.cuda.current_stream(), *H.k1_chain(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)),
+                           flags=flags)
+    torch.cuda.synchronize()
+    boundary = (1 << 32) // (plane * 4)  # the plane that straddles byte offset 2^32
+    for lo in (0, boundary - 8, n - 16):
+        sel = list(range(lo, lo + 16))
+        ref = np.zeros((16, plane), np.float32)
+        oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), [crops[i] for i in sel], cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+        H.assert_bit_exact(out[lo:lo + 16].cpu().numpy(), ref, "planes %d.. of a 4.4 GB tensor (flags %d)" % (lo, flags))
+    # every plane was written (no -7 left anywhere): a per-plane minimum over the whole tensor, computed on the device
+    assert bool((out.view(n, -1) != -7.0).any(dim=1).all())
+    del out
+    torch.cuda.empty_cache()

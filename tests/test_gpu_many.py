@@ -235,3 +235,45 @@ def test_execute_many_nv12_with_a_narrow_crop_falls_back(oracle, device):
     torch.cuda.synchronize()
     for i in range(2):
         H.assert_bit_exact(outs[i].cpu().numpy(), refs[i], "fallback chain %d" % i)
+
+
+def test_descriptor_scratch_is_thread_safe(oracle, device, lib):
+    """Four host threads, each on its own stream with its own frames and crop lists, hammer the two paths that stage
+    descriptors in the library's pooled {pinned, device} scratch -- a 100-crop chain (> 64 planes) and a 3-chain
+    cvgs_execute_many -- 40 times each, back to back (ctypes releases the GIL).  A slot recycled before its kernel ran, or
+    handed to two calls at once, would show up as another thread's table: every output must equal its own oracle result."""
+    import threading
+    import torch
+    jobs, errors = [], []
+    for t in range(4):
+        big, big_out, big_in, keep1 = _make(device, 1, 100, frame_hw=(720, 1280), seed=3000 + 10 * t)
+        many, many_out, many_in, keep2 = _make(device, 3, 20 + t, frame_hw=(720, 1280), seed=3500 + 10 * t)
+        low_big = cvgs.lower(big[0])
+        low_many = [cvgs.lower(ops) for ops in many]
+        arr = cvgs.pack_chains(low_many)
+        jobs.append(dict(stream=torch.cuda.Stream(), low_big=low_big, low_many=low_many, arr=arr, big_out=big_out, many_out=many_out,
+                         big_in=big_in, many_in=many_in, keep=(keep1, keep2)))
+    torch.cuda.synchronize()
+
+    def worker(j):
+        s = j["stream"].cuda_stream
+        for _ in range(40):
+            rc = lib.cvgs_execute(C.byref(j["low_big"].desc), s)
+            if rc:
+                errors.append(lib.cvgs_last_error())
+            rc = lib.cvgs_execute_many(j["arr"], len(j["low_many"]), s)
+            if rc:
+                errors.append(lib.cvgs_last_error())
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:3]
+    for t, j in enumerate(jobs):
+        frame, crops = j["big_in"][0]
+        H.assert_bit_exact(j["big_out"][0].cpu().numpy(), _oracle(oracle, frame, crops), "thread %d, 100-crop chain" % t)
+        for m, (frame, crops) in enumerate(j["many_in"]):
+            H.assert_bit_exact(j["many_out"][m].cpu().numpy(), _oracle(oracle, frame, crops), "thread %d, fused chain %d" % (t, m))

@@ -302,6 +302,11 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     // One output row per wave.  Two rows per wave were measured for whole-frame outputs (cfg #3: 14400 one-row waves need two
     // rounds of the chip's 8192 wave slots) and lost: 8.27 vs 8.08 us, and 5.29 vs 4.52 us on 50 crops -- the launch is
     // bound by the VALU work per row (~100 instructions x 14 waves per SIMD) plus the launch floor, not by residency.
+#ifdef CVGS_K4_AB_RPW
+    static const char* rpw_env = getenv("CVGS_K4_RPW");
+    if (rpw_env && rpw_env[0] == '2' && g.cn == 3 && c.read.yuv_layout != CVGS_YUV_P010) return launch_n12_r<Prog, OT, 2, 3, false>(c, ip, ni, g, s);
+    if (rpw_env && rpw_env[0] == '4' && g.cn == 3 && c.read.yuv_layout != CVGS_YUV_P010) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
+#endif
     if (c.read.yuv_layout == CVGS_YUV_P010)
         return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, true>(c, ip, ni, g, s);
     return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false>(c, ip, ni, g, s);

@@ -150,6 +150,20 @@ def _tap_indices(src, n_out):
     return np.unique(np.concatenate([a, b]))
 
 
+def nv12_sector_read_bytes(src_w, src_h, dst_w, dst_h, sample_bytes=1, sector=64):
+    """The sector-granular READ bound of one whole-surface K4 launch (NV12: sample_bytes 1, P010: 2): distinct
+    `sector`-byte pieces of the luma plane and of the interleaved chroma plane that hold a tapped sample.  Rows are taken as
+    sector-aligned (step = src_w * sample_bytes, a multiple of 64 for decoder surfaces).  Every luma row tapped shares one
+    column pattern, so the count is rows x sectors-per-row for each plane."""
+    cols = _tap_indices(src_w, dst_w)
+    rows = _tap_indices(src_h, dst_h)
+    luma_secs = np.unique(np.concatenate([(cols * sample_bytes) // sector, (cols * sample_bytes + sample_bytes - 1) // sector]))
+    pair = (cols // 2) * 2 * sample_bytes  # byte offset of the (U,V) pair of a luma column
+    chroma_secs = np.unique(np.concatenate([pair // sector, (pair + 2 * sample_bytes - 1) // sector]))
+    chroma_rows = np.unique(rows // 2)
+    return int(len(rows) * len(luma_secs) + len(chroma_rows) * len(chroma_secs)) * sector
+
+
 def k1_sector_read_bytes(crops, frame_w, frame_h, dst=DST, px_bytes=3, sector=64, step=None):
     """The sector-granular READ bound of one K1 launch: bytes of the distinct `sector`-byte aligned pieces of the frame
     that hold at least one tapped pixel byte (union over the launch's crops -- overlapping crops share sectors).  HBM

@@ -73,8 +73,12 @@ def cfg3(dev, iters, p010=False):
     w, h = W.FRAME_6K
     dst = (1280, 720)
     sb = 2 if p010 else 1
-    bufs = [W.random_u8_torch((h + h // 2, w * sb), 500 + i, dev) for i in range(6)]
-    outs = [torch.zeros((1, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev) for _ in range(6)]
+    # enough distinct surfaces that none is still in the 256 MiB Infinity Cache when its turn comes again (as bench.py does
+    # for the headline): >= 2 x 256 MiB of surfaces in rotation
+    surf_bytes = (h + h // 2) * w * sb
+    nbuf = max(6, (2 * 256 * (1 << 20) + surf_bytes - 1) // surf_bytes + 1)
+    bufs = [W.random_u8_torch((h + h // 2, w * sb), 500 + i, dev) for i in range(nbuf)]
+    outs = [torch.zeros((1, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     f = cvgs.CV_32FC3
     s = torch.cuda.current_stream()
     chains, ops = [], None
@@ -99,9 +103,11 @@ def cfg3(dev, iters, p010=False):
     # scale 4.8: every output pixel taps 4 distinct luma bytes and up to 4 distinct UV pairs (SURVEY.md 8d bound)
     read = (dst[0] * dst[1] * 4 + dst[0] * dst[1] * 2 * 4) * sb
     alg = write + read
+    sector = W.nv12_sector_read_bytes(w, h, dst[0], dst[1], sb) + write
     return {"config": "cfg3 %s 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, one kernel" % ("P010 (10-bit, BT.2020 limited)" if p010 else "NV12"),
             "kernel": cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
             "GB_per_s": round(alg / t / 1e9, 1), "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4),
+            "sector_bound_bytes": sector, "frac_of_sector_bound": round(sector / t / 1e9 / PEAK, 4), "surfaces_in_rotation": nbuf,
             "output_Mpix_per_s": round(dst[0] * dst[1] / t / 1e6, 1), "source_Mpix_per_s": round(w * h / t / 1e6, 1)}
 
 
@@ -114,7 +120,7 @@ def nv12_crops(dev, iters, n=50):
     lib = capi.load_library()
     s = torch.cuda.current_stream()
     chains, keep, ops = [], [], None
-    for i in range(16):
+    for i in range(48):  # 48 surfaces x 12.4 MB = 597 MB in rotation: none is still in the 256 MiB Infinity Cache on its next turn
         buf = W.random_u8_torch((h + h // 2, w), 800 + i, dev)
         out = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
         luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, buf.data_ptr(), w, owner=buf)
@@ -139,11 +145,11 @@ def nv12_crops(dev, iters, n=50):
         torch.cuda.synchronize()
         with torch.cuda.graph(g, stream=side):
             s2 = torch.cuda.current_stream()
-            for _ in range(64):
+            for _ in range(96):
                 ch = chains[state["i"] % len(chains)]
                 state["i"] += 1
                 capi.check(lib.cvgs_execute(C.byref(ch.desc), s2.cuda_stream))
-        t = events_time(g.replay, max(4, iters // 8)) / 64
+        t = events_time(g.replay, max(4, iters // 8)) / 96
     return {"config": "decode-side cfg2b: %d crops of a 4K NV12 surface -> BGR float -> 64x128 -> normalize -> NCHW, one kernel" % n,
             "kernel": cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2),
             "output_Mpix_per_s": round(n * dst[0] * dst[1] / t / 1e6, 1)}
@@ -158,7 +164,8 @@ def nv12_many(dev, iters, cams=16, n=50):
     lib = capi.load_library()
     s = torch.cuda.current_stream()
     lowered, keep = [], []
-    for i in range(cams):
+    sets = 3  # 3 x 16 surfaces in rotation (597 MB), so that a launch does not find its surfaces in the Infinity Cache
+    for i in range(cams * sets):
         buf = W.random_u8_torch((h + h // 2, w), 1800 + i, dev)
         out = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
         luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, buf.data_ptr(), w, owner=buf)
@@ -168,11 +175,17 @@ def nv12_many(dev, iters, cams=16, n=50):
                cvgs.divide(f, W.K1_DIV[3]), cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst)]
         keep += [buf, out]
         lowered.append(cvgs.lower(ops))
-    arr = cvgs.pack_chains(lowered)
-    t_many = events_time(lambda: capi.check(lib.cvgs_execute_many(arr, cams, s.cuda_stream)), iters)
+    arrs = [cvgs.pack_chains(lowered[k * cams:(k + 1) * cams]) for k in range(sets)]
+    state = {"i": 0}
+
+    def many():
+        state["i"] += 1
+        capi.check(lib.cvgs_execute_many(arrs[state["i"] % sets], cams, s.cuda_stream))
+    t_many = events_time(many, iters)
 
     def separate():
-        for lc in lowered:
+        state["i"] += 1
+        for lc in lowered[(state["i"] % sets) * cams:(state["i"] % sets + 1) * cams]:
             capi.check(lib.cvgs_execute(C.byref(lc.desc), s.cuda_stream))
     t_sep = events_time(separate, max(4, iters // 4))
     return {"config": "decode-side: %d NV12 4K surfaces x %d crops -> %d NCHW tensors, ONE launch (cvgs_execute_many, host descriptors, eager)" % (cams, n, cams),

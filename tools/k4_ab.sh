@@ -1,18 +1,26 @@
 #!/bin/bash
-# A/B of the K4 (NV12 resize) kernel build variants under build/ab/ (see DESIGN.md, K4): swaps the product library in place
-# on the GPU box, runs cfg #3 and the 50-crop NV12 batch with and without the FMA-corrected division, restores the library.
+# A/B of K4 (NV12 resize) build variants under build/ab/ on the GPU box, with the surfaces rotated so that the Infinity Cache
+# cannot hold them (tools/bench_more.py): swaps the product library in place, runs cfg #3 and the 50-crop NV12 batch, restores
+# the library.  Variants (all built with -DCVGS_K4_AB_RPW, which makes rows-per-wave selectable through CVGS_K4_RPW):
+#   2: production settings (4 waves per workgroup)   3: 2 waves per workgroup   4: 8 waves per workgroup   5: chroma-row skip
 cp cvgpuspeedup_amd/lib/libcvgs_hip.so /tmp/orig.so
-for V in 0 1 2 3; do
-  if [ $V = 0 ]; then cp /tmp/orig.so cvgpuspeedup_amd/lib/libcvgs_hip.so; else cp build/ab/libcvgs_hip_$V.so cvgpuspeedup_amd/lib/libcvgs_hip.so; fi
-  for FD in 1 0; do
-    echo "variant $V fastdiv=$FD"
-    export CVGS_K1_FASTDIV=$FD
-    for W in cfg3 nv12crops; do
-      python tools/bench_more.py --iters 300 --only $W 2>/dev/null | python -c "
+run() {
+  for W in cfg3 nv12crops; do
+    python tools/bench_more.py --iters 300 --only $W 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); print('   ', j['config'][:40], j['us_per_launch'])"
+        j=json.loads(l); print('   ', j['config'][:44], j['us_per_launch'])"
+  done
+}
+for rep in 1 2; do
+  cp /tmp/orig.so cvgpuspeedup_amd/lib/libcvgs_hip.so; echo "product library"; run
+  for V in 2 3 4 5; do
+    cp build/ab/libcvgs_hip_$V.so cvgpuspeedup_amd/lib/libcvgs_hip.so
+    for R in 1 2 4; do
+      [ $V != 2 ] && [ $R = 4 ] && continue
+      echo "variant $V rows_per_wave=$R"
+      CVGS_K4_RPW=$R run
     done
   done
 done

@@ -93,6 +93,20 @@ def main():
                                cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 48)))
         torch.cuda.synchronize()
         n_run += 1
+    # P010 surfaces (16-bit samples: 4-byte luma and 8-byte chroma windows in K4), whole + crops touching the last rows / columns
+    for (w, h) in ((4, 2), (6, 4), (64, 36), (642, 362)):
+        a = rng.integers(0, 65535, (h + h // 2, w)).astype(np.uint16)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1, at_end(a), 2 * w)
+        out = torch.zeros((3, 3 * 64 * 48), dtype=torch.float32, device="cuda")
+        views = [luma, luma.nv12_roi(w - 2, h - 2, 2, 2), luma.nv12_roi(0, h - 2, w, 2)]
+        if w >= 8:
+            views[1] = luma.nv12_roi(w - 4, h - 2, 4, 2)  # the narrowest crop K4 serves
+        f = cvgs.CV_32FC3
+        for flags in (0, capi.CHAIN_FORCE_GENERIC):
+            cvgs.executeOperations(s, cvgs.read_nv12(views, (64, 48), capi.YUV_LIMITED, capi.BT2020, False, layout=capi.YUV_P010), cvgs.multiply(f, [0.5] * 3),
+                                   cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 48)), flags=flags)
+        torch.cuda.synchronize()
+        n_run += 1
     print("no read past the end of any source image: %d configurations ran to completion" % n_run)
 
 

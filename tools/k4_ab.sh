@@ -3,6 +3,12 @@
 # cannot hold them (tools/bench_more.py): swaps the product library in place, runs cfg #3 and the 50-crop NV12 batch, restores
 # the library.  Variants (all built with -DCVGS_K4_AB_RPW, which makes rows-per-wave selectable through CVGS_K4_RPW):
 #   2: production settings (4 waves per workgroup)   3: 2 waves per workgroup   4: 8 waves per workgroup   5: chroma-row skip
+# Build the variants first (here, before gpurun: build/ travels with the snapshot):
+#   cd cvgpuspeedup_amd/csrc; mkdir -p ../../build/ab; OBJS=$(ls ../../build/csrc/*.o | grep -v "k_nv12.hip.o\|exp")
+#   for V in "2:" "3:-DCVGS_K4_WPB=2" "4:-DCVGS_K4_WPB=8" "5:-DCVGS_K4_UVSKIP"; do N=${V%%:*}; F=${V#*:}
+#     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DCVGS_K4_AB_RPW $F -c k_nv12.hip -o ../../build/ab/k_nv12_$N.o
+#     hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/ab/libcvgs_hip_$N.so $OBJS ../../build/ab/k_nv12_$N.o -ldl; done
+# Results: profiles/r02_i_k4_ab_hbm.txt.
 cp cvgpuspeedup_amd/lib/libcvgs_hip.so /tmp/orig.so
 run() {
   for W in cfg3 nv12crops; do

@@ -125,7 +125,7 @@ struct Lowered {
     Prog64Args p64{};
     MirrorArgs mirrors{};
     bool uses_64f = false;
-    SmallBuf<PlaneParams, CVGS_KERNARG_PLANES> planes;  // host copy (inline or to upload)
+    SmallBuf<PlaneParams, kKernargPlanesBig> planes;    // host copy (inline or to upload)
     SmallBuf<WarpPlane, kInlineWarp> warp_planes;       // WARP kinds (instead of `planes`)
     SmallBuf<DstPlane, CVGS_KERNARG_PLANES> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
     int out_w = 0, out_h = 0;
@@ -600,8 +600,14 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
     // how many bytes of descriptors exceed the kernel-argument block?
     const bool warp = is_warp(L.args.read.kind);
     const int inline_cap = L.uses_64f ? kInline64 : CVGS_KERNARG_PLANES;
+    // 65 .. CVGS_KERNARG_PLANES_MAX planes of a chain K1 serves with a planar tensor target: the descriptors still travel in
+    // the kernel arguments (a 16 KB block) -- no staging copy, capturable into a HIP graph
+    bool big_inline = false;
+    if (!warp && !L.uses_64f && !L.args.read.table && !has_mirrors && !(ch->flags & CVGS_CHAIN_FORCE_GENERIC) &&
+        (int)L.planes.size() > CVGS_KERNARG_PLANES && (int)L.planes.size() <= kKernargPlanesBig)
+        big_inline = launch_k1(L.args, L.planes.data(), (int)L.planes.size(), L.mirrors, nullptr, 0, stream, true, nullptr) == 1;
     const bool up_src = warp ? (int)L.warp_planes.size() > (L.uses_64f ? kInlineWarp64 : kInlineWarp)
-                             : (!L.args.read.table && (int)L.planes.size() > inline_cap);
+                             : (!L.args.read.table && (int)L.planes.size() > inline_cap && !big_inline);
     const bool up_dst = (int)L.dst_planes.size() > kInlineDst;
     if (!dry_run && (up_src || up_dst)) {
         const size_t bytes = (up_src ? (warp ? L.warp_planes.size() * sizeof(WarpPlane) : L.planes.size() * sizeof(PlaneParams)) : 0) +
@@ -659,6 +665,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         rc = launch_k1(L.args, inline_planes, n_inline, L.mirrors, nullptr, 0, stream, dry_run, info);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
         if (rc == 1) { up.done(true); return CVGS_OK; }
+        if (big_inline) return fail(CVGS_ERR_HIP, "internal: K1 refused a chain its dry run accepted"); // nobody else takes > 64 inline planes
         if (!has_mirrors) { // only K1 and the interpreted kernel write mirrors
             int min_w = 1 << 30;
             for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;

@@ -93,6 +93,12 @@ struct KernArgs<0> {
     PlaneParams planes[1];
 };
 static_assert(sizeof(KernArgs<CVGS_KERNARG_PLANES>) <= 4096, "kernel-argument block must fit 4 KB");
+// K1's planar-tensor kernels also exist with a LARGE kernel-argument block: the reference's own benchmark sweeps the batch to
+// 300 crops per call (tests/batchresize/test_batchresize_x_split3D.cu:384-392), and a 16 KB argument block costs ~2 us more
+// host enqueue time than a 4 KB one, while staging the descriptors in device memory costs a copy, an event and a stream wait
+// (~18 us per eager call) and cannot be captured into a HIP graph.
+static constexpr int kKernargPlanesBig = CVGS_KERNARG_PLANES_MAX;
+static_assert(sizeof(KernArgs<kKernargPlanesBig>) <= 16384, "large kernel-argument block: 16 KB");
 
 // Extra write targets (cvgs_write_desc.mirrors): the same values at the same element offsets in up to 7 more tensors
 // (the peers' copies of the sharded [N,C,H,W] tensor).  Travels as its own kernel argument to the kernels that

@@ -416,6 +416,7 @@ template <int CN, class Prog, int SRC, typename OT>
 static hipError_t launch_npl(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
                              hipStream_t s) {
     if (table) return launch_rpw<CN, 0, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
+    if (ni > CVGS_KERNARG_PLANES) return launch_rpw<CN, kKernargPlanesBig, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s); // 16 KB argument block
     return launch_rpw<CN, CVGS_KERNARG_PLANES, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
 }
 
@@ -484,6 +485,8 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     // the interpreted kernel's business
     if (mirrors.n > 0 && (r.depth != CVGS_DEPTH_8U || r.cn < 3 || r.table || segs || c_in.write.depth != CVGS_DEPTH_32F)) return 0;
     if (segs && (!r.table || n_segs < 1 || n_segs > CVGS_MAX_CHAINS)) return 0;
+    // more than CVGS_KERNARG_PLANES descriptors in the kernel arguments: the 3- / 4-channel planar-tensor kernels only
+    if (!r.table && n_inline > CVGS_KERNARG_PLANES && (n_inline > kKernargPlanesBig || !planar || few || mirrors.n > 0 || segs)) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
     const bool u8out = c_in.write.depth == CVGS_DEPTH_8U;
     if (!f16 && !u8out && c_in.write.depth != CVGS_DEPTH_32F) return 0;

@@ -16,11 +16,13 @@
  * stream, never synchronises, and is thread-safe (CircularTensor handles excepted: they carry a
  * ring index, as in the reference, include/cvGPUSpeedup.cuh:600-627).  Device memory is only
  * allocated by cvgs_circular_create and cvgs_comm_*, plus one case inside cvgs_execute(_many): a batch
- * with more host descriptors than fit the 4 KB kernel-argument block (64 planes, 56 for warps,
- * 16 destination planes) is staged through a library-owned pool of {pinned host, device} scratch
- * slots (grown on first use, recycled by HIP event, never freed per call) and copied stream-ordered;
- * that case is refused during stream capture -- pass a resident table (cvgs_plane_table_build).
- * Up to CVGS_KERNARG_PLANES planes a call allocates nothing, on the host or on the device.
+ * with more host descriptors than fit the kernel-argument block (64 planes in a 4 KB block; up to
+ * CVGS_KERNARG_PLANES_MAX = 320 planes in a 16 KB block for the batched resize -> planar tensor chain,
+ * the reference's benchmark sweep; 52 for warps, 16 destination planes) is staged through a
+ * library-owned pool of {pinned host, device} scratch slots (grown on first use, recycled by HIP
+ * event, never freed per call) and copied stream-ordered; that case is refused during stream
+ * capture -- pass a resident table (cvgs_plane_table_build).  A call whose descriptors travel in the
+ * kernel arguments allocates nothing, on the host or on the device, and can be captured.
  *
  * Return value: 0 (CVGS_OK) or a negative cvgs_status; cvgs_last_error() gives a thread-local
  * human-readable message.
@@ -39,6 +41,7 @@ extern "C" {
 #define CVGS_MAX_OPS 12        /* pointwise stages between the read and the write            */
 #define CVGS_MAX_CHANNELS 4
 #define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
+#define CVGS_KERNARG_PLANES_MAX 320 /* ... and for the batched resize -> planar tensor chain (K1), in a 16 KB argument block */
 #define CVGS_MAX_MIRRORS 7     /* extra tensors one chain can write (the 7 peers of an 8-GPU node)  */
 #define CVGS_MAX_CHAINS 128    /* chains one cvgs_execute_many launch can fuse                     */
 /* Size limits (CVGS_ERR_UNSUPPORTED beyond them; the kernels index inside a row with 32-bit arithmetic): source planes and

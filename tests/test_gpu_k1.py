@@ -140,32 +140,90 @@ def test_k1_large_batch_and_large_crops(oracle):
 
 
 def test_k1_stream_capture_guard():
-    """Batches that need a library-managed descriptor upload cannot be captured into a HIP graph (the copy would
-    reference dead host memory): the call must fail loudly; the same batch with a resident plane table captures fine."""
+    """Batches that need a library-managed descriptor upload (more than CVGS_KERNARG_PLANES_MAX = 320 planes) cannot be
+    captured into a HIP graph (the copy would reference dead host memory): the call must fail loudly; the same batch with a
+    resident plane table captures fine, and so does a batch of up to 320 planes with host descriptors (they travel in the
+    kernel arguments)."""
     import torch
     dev = torch.device("cuda:0")
     frame_t = torch.from_numpy(H.random_u8((480, 640, 3), seed=81)).to(dev)
-    crops = H.random_crops(100, 640, 480, seed=82, wmax=200, hmax=200)
-    out_t = torch.zeros((100, 3 * 64 * 128), dtype=torch.float32, device=dev)
-    g_src, g_out = cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1)
-    ops = H.k1_chain(g_src, crops, g_out)
-    cvgs.executeOperations(torch.cuda.current_stream(), *ops)  # eager: fine
+    g_src = cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3)
+    for n, host_descriptors_capturable in ((100, True), (320, True), (400, False)):
+        crops = H.random_crops(n, 640, 480, seed=82, wmax=200, hmax=200)
+        out_t = torch.zeros((n, 3 * 64 * 128), dtype=torch.float32, device=dev)
+        g_out = cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1)
+        ops = H.k1_chain(g_src, crops, g_out)
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)  # eager: fine
+        torch.cuda.synchronize()
+        eager = out_t.clone()
+        assert eager.any()
+        table = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
+        ops_t = H.k1_chain(g_src, crops, g_out, table=table.data_ptr())
+        for use_table in (False, True):
+            if not use_table and not host_descriptors_capturable:
+                continue
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    cvgs.executeOperations(torch.cuda.current_stream(), *(ops_t if use_table else ops))
+            out_t.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out_t, eager), (n, use_table)
+        if not host_descriptors_capturable:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    with pytest.raises(cvgs.capi.CvgsError):
+                        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+                    cvgs.executeOperations(torch.cuda.current_stream(), *ops_t)  # keep the capture non-empty
+
+
+@pytest.mark.parametrize("n", [65, 128, 300, 320, 321])
+@pytest.mark.parametrize("variant", ["u8c3", "u8c4", "u16c3", "s16c4", "f16out", "interp", "aspect_unused"])
+def test_k1_large_kernel_argument_batches(oracle, n, variant):
+    """65 .. 320 crops with host descriptors: the planar-tensor K1 kernels take them in a 16 KB kernel-argument block (the
+    reference's benchmark sweeps the batch to 300, tests/batchresize/test_batchresize_x_split3D.cu:384-392); 321 goes
+    through the staged device table.  Every type pair of the reference's sweep, the fp16 hand-off, an interpreted program,
+    aspect-ratio padding with unused planes."""
+    import torch
+    dev = torch.device("cuda:0")
+    cn = 4 if variant in ("u8c4", "s16c4") else 3
+    depth = {"u16c3": cvgs.CV_16U, "s16c4": cvgs.CV_16S}.get(variant, cvgs.CV_8U)
+    np_dt = {cvgs.CV_8U: np.uint8, cvgs.CV_16U: np.uint16, cvgs.CV_16S: np.int16}[depth]
+    raw = H.random_u16((270, 480, cn), seed=300 + n)
+    frame = (raw & 0xff).astype(np.uint8) if depth == cvgs.CV_8U else raw.view(np_dt)
+    crops = H.random_crops(n, 480, 270, seed=77 + n, wmin=2, wmax=200, hmin=2, hmax=200)
+    half = variant == "f16out"
+    kw = dict(cn=cn, src_depth=depth, half=half)
+    if variant == "aspect_unused":
+        kw.update(used=n - 7, ar=cvgs.PRESERVE_AR, background=[3.0, 60.0, 128.0])
+    out_np = np.float16 if half else np.float32
+    out_t = torch.zeros((n, cn * 64 * 128), dtype=torch.float16 if half else torch.float32, device=dev)
+    ref = np.zeros((n, cn * 64 * 128), out_np)
+    o_type = cvgs.CV_16FC1 if half else cvgs.CV_32FC1
+    ft = torch.from_numpy(frame.view(np.int16) if depth == cvgs.CV_16U else frame).to(dev)
+    st = cvgs.make_type(depth, cn)
+
+    def chain(src, out):
+        ops = H.k1_chain(src, crops, out, **kw)
+        if variant == "interp":  # one more stage: not one of the compile-time programs
+            f = cvgs.make_type(cvgs.CV_32F, cn)
+            ops = ops[:-1] + [cvgs.add(f, [0.25] * cn), ops[-1]]
+        return ops
+
+    ops = chain(cvgs.GpuMat.from_tensor(ft, st), cvgs.GpuMat.from_tensor(out_t, o_type))
+    name = cvgs.kernel_name(*ops)
+    assert name.startswith("k1_"), name
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
     torch.cuda.synchronize()
-    eager = out_t.clone()
-    table = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
-    ops_t = H.k1_chain(g_src, crops, g_out, table=table.data_ptr())
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            with pytest.raises(cvgs.capi.CvgsError):
-                cvgs.executeOperations(torch.cuda.current_stream(), *ops)
-            cvgs.executeOperations(torch.cuda.current_stream(), *ops_t)
-    out_t.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(out_t, eager)
+    oracle.execute(cvgs.lower(chain(cvgs.GpuMat.from_array(frame, st), cvgs.GpuMat.from_array(ref, o_type))))
+    assert ref.any()
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "%d crops, %s via %s" % (n, variant, name))
 
 
 # ---- division by a wave-uniform divisor (k_taps.hpp div_by_uniform) ---------------------------------------------------

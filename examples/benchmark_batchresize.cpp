@@ -5,12 +5,15 @@
 // and writes one CSV row per batch: mean / variance / max / min of the per-call time in milliseconds.  This program prints the
 // same table for the cvGS columns (there is no OpenCV-CUDA on this platform to fill the other half).  The per-call time of an
 // event pair around one eager call includes the launch latency -- that is what the reference's CSV holds too; the
-// graph-replayed, back-to-back figure of the same kernel is bench.py's.
+// graph-replayed, back-to-back figure of the same kernel is bench.py's.  The last column is the reference's OTHER benchmark of
+// this chain, benchmarks/benchmark_CPU_OpenCV_vs_cvGS.cu: the HOST time of the cvGS::executeOperations call itself (a
+// steady_clock pair around the call, no synchronisation inside) -- building the IOps, lowering, cvgs_execute, hipLaunchKernel.
 //   make -C examples && ./examples/bin/benchmark_batchresize > benchmark_batchresize_x_split3D.csv
 #include <cvGPUSpeedup.cuh>
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdio>
 #include <utility>
 
@@ -62,9 +65,13 @@ void one_batch(cv::cuda::Stream& stream, hipEvent_t e0, hipEvent_t e1) {
                                     cvGS::multiply<TO>(a), cvGS::subtract<TO>(sub[CN - 1]), cvGS::divide<TO>(div[CN - 1]), cvGS::split<TO>(tensor, up));
     };
     std::array<float, ITERS> ms{};
+    double host_ms = 0.0;
     for (int it = -1; it < ITERS; ++it) { // it == -1: the warm-up iteration (ITERS_W = 1)
         (void)hipEventRecord(e0, stream.raw());
+        const auto h0 = std::chrono::steady_clock::now();
         call();
+        const auto h1 = std::chrono::steady_clock::now();
+        if (it >= 0) host_ms += std::chrono::duration<double, std::milli>(h1 - h0).count();
         (void)hipEventRecord(e1, stream.raw());
         stream.waitForCompletion();
         float t = 0.f;
@@ -72,13 +79,13 @@ void one_batch(cv::cuda::Stream& stream, hipEvent_t e0, hipEvent_t e1) {
         if (it >= 0) ms[(size_t)it] = t;
     }
     const Stats s = summarize(ms);
-    std::printf("%d, %.6f, %.3e, %.6f, %.6f, %.1f\n", BATCH, s.mean, s.variance, s.max, s.min,
-                (double)BATCH * up.width * up.height / (s.mean * 1e-3) / 1e6);
+    std::printf("%d, %.6f, %.3e, %.6f, %.6f, %.1f, %.6f\n", BATCH, s.mean, s.variance, s.max, s.min,
+                (double)BATCH * up.width * up.height / (s.mean * 1e-3) / 1e6, host_ms / ITERS);
 }
 
 template <int TI, int TO, size_t... Is>
 void sweep(cv::cuda::Stream& stream, hipEvent_t e0, hipEvent_t e1, std::index_sequence<Is...>) {
-    std::printf("BATCH (%s), cvGS MeanTime [ms], cvGS TimeVariance, cvGS MaxTime [ms], cvGS MinTime [ms], output Mpix/s at the mean\n", pair_name<TI, TO>());
+    std::printf("BATCH (%s), cvGS MeanTime [ms], cvGS TimeVariance, cvGS MaxTime [ms], cvGS MinTime [ms], output Mpix/s at the mean, cvGS CPU MeanTime [ms]\n", pair_name<TI, TO>());
     (one_batch<TI, TO, FIRST + STEP * (int)Is>(stream, e0, e1), ...);
 }
 } // namespace

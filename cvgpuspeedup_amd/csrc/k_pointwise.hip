@@ -4,7 +4,8 @@
 // The engine's counterpart of the reference's ENABLE_THREAD_FUSION=true fast path (reference
 // include/cvGPUSpeedup.cuh:464-473): each thread owns FOUR x-adjacent pixels, reads them with one
 // wide load (4*CN bytes) and writes 16-byte vectors.  Results are bit-identical to the interpreted kernel; chains it
-// does not cover (other depths, integer outputs, SplitWrite) stay on k_generic.  Used by K5/K6/K7 and by the
+// does not cover (integer outputs, CV_64F) stay on k_generic.  SplitWrite<_2D> targets (separate pitched planes) are the
+// planar stores with one base and pitch per plane.  Used by K5/K6/K7 and by the
 // CircularTensor push of an un-resized frame (cfg #4).
 #include <type_traits>
 
@@ -229,7 +230,8 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     }
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
     const bool packed = w.kind == CVGS_WRITE_PIXEL_2D || w.kind == CVGS_WRITE_PIXEL_3D;
-    if (!planar && !packed) return false;
+    const bool split2d = w.kind == CVGS_WRITE_SPLIT_2D && !w.data2;
+    if (!planar && !packed && !split2d) return false;
     // the program must turn the u8 value into fp32 with its first CAST and never change the channel count
     const ProgArgs& p = c.prog;
     // (a CV_32F source needs no cast; every other depth must become fp32 before anything else happens)
@@ -252,9 +254,13 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     else if (starts_with_cast && p.n == 1) prog_id = 1;
 
     g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn;
-    g.packed = packed ? 1 : 0;
+    g.packed = packed ? 1 : (split2d ? 2 : 0);
     g.out = w.data; g.out2 = w.data2; g.pad = 0;
-    if (packed) {
+    if (split2d) {
+        g.out = g.out2 = nullptr; // the planes are in c.dst_inline / c.write.table
+        g.row_pitch = g.row_pitch2 = 0;
+        g.img_stride = g.ch_stride = g.img_stride2 = g.ch_stride2 = 0;
+    } else if (packed) {
         const int px_bytes = (f16 ? 2 : 4) * w.cn;
         g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * px_bytes;
         g.row_pitch2 = w.width * px_bytes;

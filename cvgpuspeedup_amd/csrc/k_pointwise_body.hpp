@@ -32,7 +32,7 @@ using ProgCast = StaticProg<CVGS_OP_CAST>;
 
 struct PwGeom {
     int32_t w, h, used, cn;
-    int32_t packed;    // 1: packed pixels (PIXEL_2D / PIXEL_3D), 0: planar
+    int32_t packed;    // 1: packed pixels (PIXEL_2D / PIXEL_3D), 0: planar tensor, 2: separate pitched planes (SPLIT_2D)
     int32_t row_pitch; // packed: bytes between output rows
     int32_t row_pitch2, pad;
     int64_t img_stride, ch_stride, img_stride2, ch_stride2; // planar: elements; packed: img_stride in BYTES
@@ -102,7 +102,25 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
     Prog::run4(c.prog, px, depth, cn);
 
     // ---- write ----
-    if (g.packed) {
+    if (g.packed == 2) {
+        // cvGS::split(std::vector<GpuMat>) / SplitWrite<_2D>: cn pitched planes per batch element (the reference's
+        // tests/read/test_read_x_split.cu chain): the planar stores below, each plane with its own base and pitch
+        const DstPlane* planes = c.write.table ? c.write.table : c.dst_inline; // wave-uniform
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < cn) {
+                const DstPlane d = planes[(size_t)z * cn + ch];
+                OT* o = (OT*)(d.data + (size_t)y * (size_t)d.step) + x0;
+                if (npx == 4) {
+                    store4(o, px[0].v[ch], px[1].v[ch], px[2].v[ch], px[3].v[ch]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < npx) store1(o + i, px[i].v[ch]);
+                }
+            }
+        }
+    } else if (g.packed) {
         // cn floats per pixel, contiguous: 4 pixels = cn float4
         uint8_t* rows[2] = {g.out + (size_t)z * g.img_stride + (size_t)y * g.row_pitch,
                             g.out2 ? g.out2 + (size_t)z * g.img_stride2 + (size_t)y * g.row_pitch2 : nullptr};

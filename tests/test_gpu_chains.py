@@ -522,3 +522,38 @@ def test_u8_colour_conversion_of_an_unaligned_crop_stays_interpreted(oracle):
     torch.cuda.synchronize()
     oracle.execute(cvgs.lower(chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), cvgs.GpuMat.from_array(ref, cvgs.CV_8UC3))))
     H.assert_bit_exact(out_t.cpu().numpy(), ref, "unaligned crop")
+
+
+# ---- read -> convertTo -> split(std::vector<GpuMat>): the reference's tests/read/test_read_x_split.cu -------------------
+@pytest.mark.parametrize("depth", ["8U", "8S", "16U", "16S", "32S", "32F"])
+@pytest.mark.parametrize("cn", [2, 3, 4])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_read_convert_split_into_separate_planes(depth, cn, normalize):
+    """cvGS::executeOperations(input, stream, convertTo<I, O>(), split<O>(std::vector<GpuMat>)) over the type pairs the
+    reference sweeps (tests/read/test_read_x_split.cu:112-130; CV_32F sources go to CV_64F there, covered by the CV_64F
+    tests): separate PITCHED planes, widths that are not a multiple of the 4-pixel thread tile, the thread-fused kernel
+    (SplitWrite target) vs the oracle and vs the interpreted kernel."""
+    w, h = 333, 41
+    pad = 5  # plane pitch = (w + pad) floats
+    src = _random_src((h, w, cn), depth, 900 + cn)
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+
+    def build(wrap, wrap_out, out):
+        o = wrap_out(out, cvgs.CV_32FC1)  # (cn * h, w + pad): plane c = rows [c*h, (c+1)*h), columns [0, w)
+        planes = [cvgs.GpuMat(h, w, cvgs.CV_32FC1, o.data + c * h * o.step, o.step, owner=o) for c in range(cn)]
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, [wrap(src, st)], 1)]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(st, f))
+        if normalize:
+            ops += [cvgs.multiply(f, [0.3] * cn), cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn])]
+        elif depth == "32F":
+            ops.append(cvgs.multiply(f, [0.5] * cn))
+        return ops + [cvgs.split(f, planes)]
+
+    fast, ref = _both(build, (cn * h, w + pad), np.float32)
+    interp, _ = _both(build, (cn * h, w + pad), np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    assert ref[0].any() and (ref[0][:, w:] == 0).all()
+    H.assert_bit_exact(fast[0], ref[0], "%sC%d -> planes (dispatcher's kernel) vs oracle" % (depth, cn))
+    H.assert_bit_exact(interp[0], ref[0], "%sC%d -> planes (interpreted kernel) vs oracle" % (depth, cn))
+    ops = build(lambda a, t: cvgs.GpuMat.from_array(a, t), lambda a, t: cvgs.GpuMat.from_array(a, t), np.zeros((cn * h, w + pad), np.float32))
+    assert cvgs.kernel_name(*ops).startswith("pointwise4_"), cvgs.kernel_name(*ops)

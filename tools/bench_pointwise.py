@@ -31,7 +31,7 @@ def events_time(fn, iters, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def case(dev, depth, cn, out, iters=50):
+def case(dev, depth, cn, out, iters=50, convert_only=False):
     w, h = W.FRAME_4K
     st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
     esz = torch.empty(0, dtype=TORCH[depth]).element_size()
@@ -43,8 +43,12 @@ def case(dev, depth, cn, out, iters=50):
         ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, [m], 1)]
         if depth != "32F":
             ops.append(cvgs.convertTo(st, f))
-        ops += [cvgs.multiply(f, [W.K1_ALPHA] * cn), cvgs.subtract(f, W.K1_SUB[cn]), cvgs.divide(f, W.K1_DIV[cn])]
-        if out == "planar":
+        if not convert_only:
+            ops += [cvgs.multiply(f, [W.K1_ALPHA] * cn), cvgs.subtract(f, W.K1_SUB[cn]), cvgs.divide(f, W.K1_DIV[cn])]
+        if out == "planes":  # cvGS::split(std::vector<GpuMat>): separate pitched planes, the reference's tests/read/test_read_x_split.cu
+            o = [torch.zeros((h, w), dtype=torch.float32, device=dev) for _ in range(cn)]
+            ops.append(cvgs.split(f, [cvgs.GpuMat.from_tensor(p, cvgs.CV_32FC1) for p in o]))
+        elif out == "planar":
             o = torch.zeros((1, cn * w * h), dtype=torch.float32, device=dev)
             ops.append(cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (w, h)) if cn > 1 else
                        cvgs.write(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (w, h)))
@@ -64,7 +68,7 @@ def case(dev, depth, cn, out, iters=50):
 
     t = events_time(launch, iters)
     alg = w * h * cn * (esz + 4)
-    return {"case": "4K %sC%d -> fp32 %s (normalize)" % (depth, cn, out), "kernel": cvgs.kernel_name(*ops), "us": round(t * 1e6, 2),
+    return {"case": "4K %sC%d -> fp32 %s (%s)" % (depth, cn, out, "convertTo only" if convert_only else "normalize"), "kernel": cvgs.kernel_name(*ops), "us": round(t * 1e6, 2),
             "GB_per_s": round(alg / t / 1e9, 1), "frac_of_8TBs": round(alg / t / 1e9 / 8000.0, 4)}
 
 
@@ -73,3 +77,7 @@ if __name__ == "__main__":
     for depth, cn in (("8U", 3), ("8U", 4), ("8U", 1), ("16U", 3), ("32F", 3), ("32F", 4), ("16S", 1)):
         for out in ("planar", "packed"):
             print(json.dumps(case(dev, depth, cn, out)))
+    # the reference's single-image tests: read -> convertTo -> split(vector<GpuMat>) (tests/read/test_read_x_split.cu:58-60)
+    for depth, cn in (("8U", 3), ("8U", 4), ("8U", 2), ("16U", 3), ("16S", 4)):
+        print(json.dumps(case(dev, depth, cn, "planes", convert_only=True)))
+        print(json.dumps(case(dev, depth, cn, "planes")))

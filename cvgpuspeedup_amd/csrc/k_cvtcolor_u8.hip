@@ -22,13 +22,15 @@ typedef const __attribute__((address_space(1))) uint8_t* gp_u8c;
 
 enum { PERM_ID = 0, PERM_SWAP = 1 };
 
-// byte of the thread's 16-pixel input chunk that output byte e comes from; -1: the added alpha
-template <int CN, int OCN, int PERM>
+// byte of the thread's 16-pixel input chunk that output byte e comes from; -1 - b: byte b of the added alpha.  ES = bytes
+// per channel: 1 (CV_8U), or 2 (CV_16U: the reference's cvtColor test sweeps both, tests/color/test_cvtColor.cu:105-123) --
+// a channel permutation of 16-bit pixels is a byte permutation of 2 CN-byte pixels.
+template <int CN, int OCN, int PERM, int ES>
 constexpr int src_byte(int e) {
-    const int px = e / OCN, ch = e % OCN;
-    if (ch == 3 && CN == 3) return -1;
+    const int px = e / (OCN * ES), within = e % (OCN * ES), ch = within / ES, b = within % ES;
+    if (ch == 3 && CN == 3) return -1 - b;
     const int sc = ch < 3 ? (PERM == PERM_SWAP ? 2 - ch : ch) : 3;
-    return px * CN + sc;
+    return (px * CN + sc) * ES + b;
 }
 
 // The wave's 1024 pixels travel through a wave-private LDS region in both directions, so that EVERY global access is a
@@ -54,8 +56,9 @@ __device__ __forceinline__ void load_chunk16(const gp_u8c row, int tile_px0, int
     }
 }
 
-template <int CN, int OCN, int PERM, int NPL>
+template <int CN_, int OCN_, int PERM, int NPL, int ES = 1>
 __global__ __launch_bounds__(256) void k_u8_permute16(const KernArgs<NPL> a, const PwGeom g, const uint32_t alpha) {
+    constexpr int CN = CN_ * ES, OCN = OCN_ * ES; // BYTES per pixel in / out from here on
     constexpr int MAXC = CN > OCN ? CN : OCN;
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][256 * MAXC];
     const ChainArgs& c = a.c;
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256) void k_u8_permute16(const KernArgs<NPL> a, con
             uint32_t w = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int s = src_byte<CN, OCN, PERM>(16 * k + 4 * d + i);
-                const uint32_t b = s < 0 ? alpha : ((in[s < 0 ? 0 : (s >> 2)] >> (8 * (s & 3))) & 0xffu);
+                const int s = src_byte<CN_, OCN_, PERM, ES>(16 * k + 4 * d + i);
+                const uint32_t b = s < 0 ? ((alpha >> (8 * (-1 - s))) & 0xffu) : ((in[s < 0 ? 0 : (s >> 2)] >> (8 * (s & 3))) & 0xffu);
                 w |= b << (8 * i);
             }
             q[d] = w;
@@ -105,9 +108,11 @@ __global__ __launch_bounds__(256) void k_u8_permute16(const KernArgs<NPL> a, con
 // *2GRAY: 16 pixels -> 16 bytes; the arithmetic is apply_op's (0.299 R + 0.587 G + 0.114 B in that order, round to nearest
 // even), the channel order comes with `aux`.  Input through the LDS like the permutations; the 16 output bytes of a lane
 // are already lane-contiguous.
-template <int CN, int NPL>
+template <int CN, int NPL, int ES = 1>
 __global__ __launch_bounds__(256) void k_u8_gray16(const KernArgs<NPL> a, const PwGeom g) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4][256 * CN];
+    constexpr int CB = CN * ES; // bytes per source pixel
+    constexpr int SD = ES == 1 ? CVGS_DEPTH_8U : CVGS_DEPTH_16U;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][256 * CB];
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.z;
     PlaneParams P;
@@ -122,23 +127,29 @@ __global__ __launch_bounds__(256) void k_u8_gray16(const KernArgs<NPL> a, const 
     const int y = (int)blockIdx.y * 4 + wave;
     if (y >= H) return;
     const gp_u8c row = (gp_u8c)P.data + (size_t)y * (size_t)P.step;
-    uint32_t in[4 * CN];
-    load_chunk16<CN>(row, tile_px0, W, lane, lds[wave], in);
+    uint32_t in[4 * CB];
+    load_chunk16<CB>(row, tile_px0, W, lane, lds[wave], in);
     if (x0 >= W) return;
-    uint32_t q[4] = {0, 0, 0, 0};
+    uint32_t q[4 * ES];
+#pragma unroll
+    for (int j = 0; j < 4 * ES; ++j) q[j] = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         Px p;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) p.v[ch] = ch < CN ? elem_value<CVGS_DEPTH_8U>(in, i * CN + ch) : 0.f;
-        int depth = CVGS_DEPTH_8U, cn = CN;
+        for (int ch = 0; ch < 4; ++ch) p.v[ch] = ch < CN ? elem_value<SD>(in, i * CN + ch) : 0.f;
+        int depth = SD, cn = CN;
         apply_op(CVGS_OP_GRAY, aux, c.prog.operand[0], p, depth, cn);
-        q[i >> 2] |= ((uint32_t)p.v[0] & 0xffu) << (8 * (i & 3));
+        if constexpr (ES == 1) q[i >> 2] |= ((uint32_t)p.v[0] & 0xffu) << (8 * (i & 3));
+        else q[i >> 1] |= ((uint32_t)p.v[0] & 0xffffu) << (16 * (i & 1));
     }
     __attribute__((address_space(1))) uint8_t* orow =
         (__attribute__((address_space(1))) uint8_t*)g.out + (size_t)z * (size_t)g.img_stride + (size_t)y * (size_t)g.row_pitch;
-    u32x4a v = {q[0], q[1], q[2], q[3]};
-    CVGS_CC_STORE(v, (gp_u32x4_w)(orow + (uint32_t)x0));
+#pragma unroll
+    for (int j = 0; j < ES; ++j) { // 16 pixels = ES lane-contiguous 16-byte chunks
+        u32x4a v = {q[4 * j], q[4 * j + 1], q[4 * j + 2], q[4 * j + 3]};
+        CVGS_CC_STORE(v, (gp_u32x4_w)(orow + (uint32_t)x0 * ES + 16 * j));
+    }
 }
 
 template <int NPL>
@@ -151,31 +162,31 @@ static void fill_args(KernArgs<NPL>& a, const ChainArgs& c, const PlaneParams* i
     }
 }
 
-template <int CN, int OCN, int PERM>
+template <int CN, int OCN, int PERM, int ES = 1>
 static hipError_t launch_perm(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, uint32_t alpha, hipStream_t s) {
     const dim3 grid((g.w / 16 + 63) / 64, (g.h + 3) / 4, c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         fill_args(a, c, ip, ni);
-        hipLaunchKernelGGL((k_u8_permute16<CN, OCN, PERM, 0>), grid, dim3(256), 0, s, a, g, alpha);
+        hipLaunchKernelGGL((k_u8_permute16<CN, OCN, PERM, 0, ES>), grid, dim3(256), 0, s, a, g, alpha);
     } else {
         KernArgs<CVGS_KERNARG_PLANES> a;
         fill_args(a, c, ip, ni);
-        hipLaunchKernelGGL((k_u8_permute16<CN, OCN, PERM, CVGS_KERNARG_PLANES>), grid, dim3(256), 0, s, a, g, alpha);
+        hipLaunchKernelGGL((k_u8_permute16<CN, OCN, PERM, CVGS_KERNARG_PLANES, ES>), grid, dim3(256), 0, s, a, g, alpha);
     }
     return hipGetLastError();
 }
-template <int CN>
+template <int CN, int ES = 1>
 static hipError_t launch_gray(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
     const dim3 grid((g.w / 16 + 63) / 64, (g.h + 3) / 4, c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         fill_args(a, c, ip, ni);
-        hipLaunchKernelGGL((k_u8_gray16<CN, 0>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_u8_gray16<CN, 0, ES>), grid, dim3(256), 0, s, a, g);
     } else {
         KernArgs<CVGS_KERNARG_PLANES> a;
         fill_args(a, c, ip, ni);
-        hipLaunchKernelGGL((k_u8_gray16<CN, CVGS_KERNARG_PLANES>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_u8_gray16<CN, CVGS_KERNARG_PLANES, ES>), grid, dim3(256), 0, s, a, g);
     }
     return hipGetLastError();
 }
@@ -198,10 +209,11 @@ int launch_u8_colour16(const ChainArgs& c, const PlaneParams* ip, int ni, const 
         gray = true;
     }
     if (perm < 0 && !gray) return 0;
+    const bool wide = r.depth == CVGS_DEPTH_16U; // 16-bit channels (the caller passes 8U -> 8U or 16U -> 16U chains only)
     uint32_t alpha = 0;
-    if (op == CVGS_OP_ADD_ALPHA) { // the interpreted kernel stores (uint8_t)operand[0]: take whole values in range only
+    if (op == CVGS_OP_ADD_ALPHA) { // the interpreted kernel stores (uint8_t / uint16_t)operand[0]: take whole values in range only
         const float av = p.operand[0][0];
-        if (!(av >= 0.f && av <= 255.f) || av != (float)(int)av) return 0;
+        if (!(av >= 0.f && av <= (wide ? 65535.f : 255.f)) || av != (float)(int)av) return 0;
         alpha = (uint32_t)(int)av;
     }
     // 16-byte accesses: every source row, the output base, its row pitch and image stride must be 16-byte aligned
@@ -209,10 +221,17 @@ int launch_u8_colour16(const ChainArgs& c, const PlaneParams* ip, int ni, const 
     if (r.table) return 0; // resident tables: alignment cannot be checked on the host
     for (int i = 0; i < ni; ++i)
         if (((uintptr_t)ip[i].data & 15) || (ip[i].step & 15)) return 0;
-    if (info) info->kernel = gray ? "pointwise16_u8_gray" : "pointwise16_u8_permute";
+    if (info) info->kernel = wide ? (gray ? "pointwise16_u16_gray" : "pointwise16_u16_permute") : (gray ? "pointwise16_u8_gray" : "pointwise16_u8_permute");
     if (dry_run) return 1;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
+    if (wide) {
+        if (gray) e = r.cn == 3 ? launch_gray<3, 2>(c, ip, ni, g, s) : launch_gray<4, 2>(c, ip, ni, g, s);
+        else if (op == CVGS_OP_REORDER) e = r.cn == 3 ? launch_perm<3, 3, PERM_SWAP, 2>(c, ip, ni, g, 0, s) : launch_perm<4, 4, PERM_SWAP, 2>(c, ip, ni, g, 0, s);
+        else if (op == CVGS_OP_ADD_ALPHA) e = perm == PERM_SWAP ? launch_perm<3, 4, PERM_SWAP, 2>(c, ip, ni, g, alpha, s) : launch_perm<3, 4, PERM_ID, 2>(c, ip, ni, g, alpha, s);
+        else e = perm == PERM_SWAP ? launch_perm<4, 3, PERM_SWAP, 2>(c, ip, ni, g, 0, s) : launch_perm<4, 3, PERM_ID, 2>(c, ip, ni, g, 0, s);
+        return e == hipSuccess ? 1 : -(int)e - 1000;
+    }
     if (gray) e = r.cn == 3 ? launch_gray<3>(c, ip, ni, g, s) : launch_gray<4>(c, ip, ni, g, s);
     else if (op == CVGS_OP_REORDER) e = r.cn == 3 ? launch_perm<3, 3, PERM_SWAP>(c, ip, ni, g, 0, s) : launch_perm<4, 4, PERM_SWAP>(c, ip, ni, g, 0, s);
     else if (op == CVGS_OP_ADD_ALPHA) e = perm == PERM_SWAP ? launch_perm<3, 4, PERM_SWAP>(c, ip, ni, g, alpha, s) : launch_perm<3, 4, PERM_ID>(c, ip, ni, g, alpha, s);

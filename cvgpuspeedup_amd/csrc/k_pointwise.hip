@@ -45,7 +45,7 @@ template <int CN, typename OT>
 static hipError_t launch_pw_prog(int prog_id, const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
     if (prog_id == 0) return launch_pw<CN, ProgCastMulSubDiv, OT>(c, ip, ni, g, s);
     if (prog_id == 1) return launch_pw<CN, ProgCast, OT>(c, ip, ni, g, s);
-    return launch_pw<CN, InterpProg, OT>(c, ip, ni, g, s);
+    return launch_pw<CN, ArithProg<CN, CVGS_DEPTH_8U>, OT>(c, ip, ni, g, s);
 }
 
 // other source depths, fp32 output: the normalisation chain ([cast,] mul, sub, div) as a compile-time program, anything
@@ -61,10 +61,19 @@ static hipError_t launch_pw_depth_prog(const ChainArgs& c, const PlaneParams* ip
     }
 }
 template <int SD>
+static hipError_t launch_pw_depth_arith(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    switch (c.read.cn) {
+    case 1: return launch_pw<1, ArithProg<1, SD>, float, SD>(c, ip, ni, g, s);
+    case 2: return launch_pw<2, ArithProg<2, SD>, float, SD>(c, ip, ni, g, s);
+    case 3: return launch_pw<3, ArithProg<3, SD>, float, SD>(c, ip, ni, g, s);
+    default: return launch_pw<4, ArithProg<4, SD>, float, SD>(c, ip, ni, g, s);
+    }
+}
+template <int SD>
 static hipError_t launch_pw_depth(bool normalise, const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
     using Norm = std::conditional_t<SD == CVGS_DEPTH_32F, ProgMulSubDivPw, ProgCastMulSubDiv>;
     if (normalise) return launch_pw_depth_prog<SD, Norm>(c, ip, ni, g, s);
-    return launch_pw_depth_prog<SD, InterpProg>(c, ip, ni, g, s);
+    return launch_pw_depth_arith<SD>(c, ip, ni, g, s);
 }
 
 template <typename OT>
@@ -209,6 +218,26 @@ static int launch_pointwise_u8u8(const ChainArgs& c, const PlaneParams* ip, int 
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 
+// CV_16U -> CV_16U colour conversions (the reference's cvtColor test sweeps 16-bit types too): only the compile-time
+// permutation / gray kernels exist for them; every other 16-bit program stays on the interpreted kernel.
+static int launch_pointwise_u16u16(const ChainArgs& c, const PlaneParams* ip, int ni, uint32_t chain_flags, hipStream_t s, bool dry_run,
+                                   LaunchInfo* info) {
+    const ReadArgs& r = c.read;
+    const WriteArgs& w = c.write;
+    if (chain_flags & CVGS_CHAIN_NO_THREAD_FUSION) return 0;
+    if (r.kind != CVGS_READ_PIXEL || r.depth != CVGS_DEPTH_16U || w.depth != CVGS_DEPTH_16U || r.batch > 65535) return 0;
+    if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
+    if (w.data2 || (!r.table && ni > CVGS_KERNARG_PLANES)) return 0;
+    PwGeom g;
+    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.pad = 0;
+    g.out = w.data; g.out2 = nullptr;
+    g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * w.cn * 2;
+    g.row_pitch2 = 0;
+    g.img_stride = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : (int64_t)w.img_stride * w.cn * 2; // bytes
+    g.img_stride2 = g.ch_stride = g.ch_stride2 = 0;
+    return launch_u8_colour16(c, ip, ni, g, s, dry_run, info);
+}
+
 // Eligibility + geometry of the thread-fused path, shared with the single-launch CircularTensor push (k_circular.hip).
 // On success `c` is the chain to run (an fp16 target's trailing CAST is folded into the store), `g` the geometry.
 bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16) {
@@ -280,6 +309,10 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
                      bool dry_run, LaunchInfo* info) {
     {
         const int rc = launch_pointwise_u8u8(c_in, inline_planes, n_inline, chain_flags, (hipStream_t)stream, dry_run, info);
+        if (rc) return rc;
+    }
+    {
+        const int rc = launch_pointwise_u16u16(c_in, inline_planes, n_inline, chain_flags, (hipStream_t)stream, dry_run, info);
         if (rc) return rc;
     }
     ChainArgs c;

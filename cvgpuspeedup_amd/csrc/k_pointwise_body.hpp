@@ -30,6 +30,55 @@ __device__ __forceinline__ void store1(_Float16* p, float v) { *p = (_Float16)v;
 using ProgCastMulSubDiv = StaticProg<CVGS_OP_CAST, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 using ProgCast = StaticProg<CVGS_OP_CAST>;
 
+// The run-time programs k_pointwise4 accepts (pointwise4_plan checks it on the host): channel permutations, ONE cast to
+// CV_32F (none for CV_32F sources), then MUL / ADD / SUB / DIV / REORDER on fp32 values, CN channels throughout.  The
+// general interpreter (InterpProg) re-derives the value's depth and channel count at every stage of every pixel; here both
+// are compile-time facts, so a stage is one wave-uniform branch and 4 x CN arithmetic instructions -- same operations, same
+// order, same bits (the reference's tests/read/test_read_x_write.cu chain, convertTo -> sub -> mul -> div -> add, on a 4K
+// frame: 45 -> 21 us).
+template <int CN, int SD>
+struct ArithProg {
+    static __device__ __forceinline__ void run4(const ProgArgs& prog, Px (&px)[4], int& depth, int& cn) {
+        for (int k = 0; k < prog.n; ++k) {
+            const int op = prog.opcode[k]; // wave-uniform
+            const float o[4] = {prog.operand[k][0], prog.operand[k][1], prog.operand[k][2], prog.operand[k][3]};
+            if (op == CVGS_OP_MUL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < CN; ++ch) px[i].v[ch] = px[i].v[ch] * o[ch];
+            } else if (op == CVGS_OP_ADD) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < CN; ++ch) px[i].v[ch] = px[i].v[ch] + o[ch];
+            } else if (op == CVGS_OP_SUB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < CN; ++ch) px[i].v[ch] = px[i].v[ch] - o[ch];
+            } else if (op == CVGS_OP_DIV) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < CN; ++ch) px[i].v[ch] = px[i].v[ch] / o[ch];
+            } else if (op == CVGS_OP_CAST) { // -> CV_32F: 8- / 16-bit integers are exact floats already, CV_32S travels as raw bits
+                if constexpr (SD == CVGS_DEPTH_32S) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int ch = 0; ch < CN; ++ch) px[i].v[ch] = (float)as_int(px[i].v[ch]);
+                }
+            } else { // CVGS_OP_REORDER
+#pragma unroll
+                for (int i = 0; i < 4; ++i) reorder_px(px[i], prog.aux[k], CN);
+            }
+        }
+        depth = CVGS_DEPTH_32F;
+        cn = CN;
+    }
+};
+
 struct PwGeom {
     int32_t w, h, used, cn;
     int32_t packed;    // 1: packed pixels (PIXEL_2D / PIXEL_3D), 0: planar tensor, 2: separate pitched planes (SPLIT_2D)

@@ -505,6 +505,42 @@ def test_u8_colour_conversions_fast_and_interpreted_agree_with_oracle(oracle, na
     H.assert_bit_exact(out_t.cpu().numpy(), ref, "%s %s interpreted" % (name, shape))
 
 
+@pytest.mark.parametrize("name,code,icn,ocn", _CODES, ids=[c[0] for c in _CODES])
+@pytest.mark.parametrize("shape", [(37, 640, 1), (3, 4096, 2), (9, 16, 2), (7, 637, 1)])
+def test_u16_colour_conversions_fast_and_interpreted_agree_with_oracle(oracle, name, code, icn, ocn, shape):
+    """The same codes on CV_16U images (the reference's cvtColor test sweeps CV_16UC3 / C4 next to CV_8U,
+    tests/color/test_cvtColor.cu:105-123): aligned widths take the 16-pixel-per-thread kernels with 2-byte channels, the
+    ragged width stays on the interpreted kernel; full-range 16-bit values (alpha = 65535, gray of 65535 stays 65535)."""
+    import torch
+    dev = torch.device("cuda:0")
+    h, w, batch = shape
+    it, ot = cvgs.make_type(cvgs.CV_16U, icn), cvgs.make_type(cvgs.CV_16U, ocn)
+    srcs = [H.random_u16((h, w, icn), seed=700 + b) for b in range(batch)]
+    srcs[0][0, :8] = 65535
+    ts = [torch.from_numpy(s.view(np.int16)).to(dev) for s in srcs]
+
+    def chain(mats, out):
+        if batch == 1:
+            return [cvgs.ReadIOp(capi.READ_PIXEL, it, [mats[0]], 1), cvgs.cvtColor(code, it, ot), cvgs.write(ot, out)]
+        return [cvgs.ReadIOp(capi.READ_PIXEL, it, mats, batch), cvgs.cvtColor(code, it, ot), cvgs.write(ot, out, (w, h))]
+
+    shape_o = (h, w, ocn) if batch == 1 else (batch, h * w, ocn)
+    out_t = torch.zeros(shape_o, dtype=torch.int16, device=dev)
+    ref = np.zeros(shape_o, np.uint16)
+    g_ops = chain([cvgs.GpuMat.from_tensor(t, it) for t in ts], cvgs.GpuMat.from_tensor(out_t, ot))
+    name_k = cvgs.kernel_name(*g_ops)
+    assert name_k.startswith("pointwise16_u16_" if w % 16 == 0 else "generic"), (name_k, shape)
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops)
+    torch.cuda.synchronize()
+    oracle.execute(cvgs.lower(chain([cvgs.GpuMat.from_array(s, it) for s in srcs], cvgs.GpuMat.from_array(ref, ot))))
+    assert ref.any()
+    H.assert_bit_exact(out_t.cpu().numpy().view(np.uint16), ref, "%s %s via %s" % (name, shape, name_k))
+    out_t.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops, flags=capi.CHAIN_NO_THREAD_FUSION)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(out_t.cpu().numpy().view(np.uint16), ref, "%s %s interpreted" % (name, shape))
+
+
 def test_u8_colour_conversion_of_an_unaligned_crop_stays_interpreted(oracle):
     import torch
     dev = torch.device("cuda:0")

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""The reference's own test chains at the reference's own sizes, as an audit table: which kernel the dispatcher picks, the
+time per eager call (HIP events over a run of calls on rotating buffers, as bench_more.py), algorithmic bytes and the
+fraction of 8 TB/s.  A row on `generic*` or far below its neighbours is a chain the reference tests that this engine still
+serves slowly.  Chains (reference file:line of the cvGS call):
+  read_x_write      tests/read/test_read_x_write.cu:39-44      4K I -> convertTo -> sub -> mul -> div -> add -> write (packed O)
+  read_x_split      tests/read/test_read_x_split.cu:58-60      4K I -> convertTo -> split(vector<GpuMat>)
+  cvtColor          tests/color/test_cvtColor.cu:55            4K cvtColor<code> (thread fusion off, as the test)
+  batchread_write3D tests/batchread/test_batchread_x_write3D.cu:92-96   50 crops 60x120 -> convertTo(alpha) -> sub -> div -> Tensor (TF off)
+  resize_write      tests/resize/test_resize_write.cu:55-56    4K -> 3870x2260 and -> 300x500, convertTo back to I, write
+  resize_x_split    tests/resize/test_resize_x_split.cu:79-84  crop 60x120 -> 64x128 -> mul, sub, div -> split(planes)
+  warp              tests/warping/test_warping_opencv.cu:63    perspective warp of an image to its own size, fk::Cast, write"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from cvgpuspeedup_amd import workloads as W  # noqa: E402
+
+DEPTH = {"8U": cvgs.CV_8U, "8S": cvgs.CV_8S, "16U": cvgs.CV_16U, "16S": cvgs.CV_16S, "32S": cvgs.CV_32S, "32F": cvgs.CV_32F}
+TORCH = {"8U": torch.uint8, "8S": torch.int8, "16U": torch.int16, "16S": torch.int16, "32S": torch.int32, "32F": torch.float32}
+W4K, H4K = W.FRAME_4K
+dev = torch.device("cuda:0")
+lib = None
+
+
+def rand(h, w, cn, depth):
+    return torch.randint(0, 100, (h, w, cn), device=dev, dtype=torch.int32).to(TORCH[depth])
+
+
+def timed(chains, iters=60):
+    s = torch.cuda.current_stream().cuda_stream
+    st = {"i": 0}
+
+    def launch():
+        capi.check(lib.cvgs_execute(C.byref(chains[st["i"] % len(chains)].desc), s))
+        st["i"] += 1
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def report(name, make, alg_bytes, bytes_per_set, flags=0):
+    """make() -> (iops, keep); enough independent sets that the Infinity Cache cannot hold them"""
+    n = max(3, min(40, (600 << 20) // max(1, bytes_per_set) + 1))
+    chains, keep, ops = [], [], None
+    for _ in range(n):
+        ops, k = make()
+        chains.append(cvgs.lower(ops, flags))
+        keep.append(k)
+    t = timed(chains)
+    print(json.dumps({"test": name, "kernel": cvgs.kernel_name(*ops, flags=flags), "us": round(t * 1e6, 2), "GB_per_s": round(alg_bytes / t / 1e9, 1),
+                      "frac_of_8TBs": round(alg_bytes / t / 8e12, 4)}), flush=True)
+
+
+def read_x_write(depth, cn):
+    st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    esz = torch.empty(0, dtype=TORCH[depth]).element_size()
+
+    def make():
+        src, out = rand(H4K, W4K, cn, depth), torch.zeros((H4K, W4K, cn), dtype=torch.float32, device=dev)
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, [cvgs.GpuMat.from_tensor(src, st)], 1)]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(st, f))
+        ops += [cvgs.subtract(f, [0.3] * cn), cvgs.multiply(f, W.K1_SUB[cn]), cvgs.divide(f, W.K1_DIV[cn]), cvgs.add(f, W.K1_DIV[cn]),
+                cvgs.write(f, cvgs.GpuMat.from_tensor(out, f))]
+        return ops, (src, out)
+    b = W4K * H4K * cn * (esz + 4)
+    report("read_x_write %sC%d -> 32FC%d" % (depth, cn, cn), make, b, b)
+
+
+def read_x_split(depth, cn):
+    st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    esz = torch.empty(0, dtype=TORCH[depth]).element_size()
+
+    def make():
+        src = rand(H4K, W4K, cn, depth)
+        outs = [torch.zeros((H4K, W4K), dtype=torch.float32, device=dev) for _ in range(cn)]
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, [cvgs.GpuMat.from_tensor(src, st)], 1), cvgs.convertTo(st, f),
+               cvgs.split(f, [cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1) for o in outs])]
+        return ops, (src, outs)
+    b = W4K * H4K * cn * (esz + 4)
+    report("read_x_split %sC%d -> 32FC%d planes" % (depth, cn, cn), make, b, b)
+
+
+def cvt_color(name, code, depth, icn, ocn):
+    it, ot = cvgs.make_type(DEPTH[depth], icn), cvgs.make_type(DEPTH[depth], ocn)
+    esz = torch.empty(0, dtype=TORCH[depth]).element_size()
+
+    def make():
+        src, out = rand(H4K, W4K, icn, depth), torch.zeros((H4K, W4K, ocn), dtype=TORCH[depth], device=dev)
+        return [cvgs.ReadIOp(capi.READ_PIXEL, it, [cvgs.GpuMat.from_tensor(src, it)], 1), cvgs.cvtColor(code, it, ot),
+                cvgs.write(ot, cvgs.GpuMat.from_tensor(out, ot))], (src, out)
+    b = W4K * H4K * (icn + ocn) * esz
+    # the test spells executeOperations<false>: thread fusion off is a hint this engine may ignore for u8 (same results)
+    report("cvtColor %s %sC%d -> C%d" % (name, depth, icn, ocn), make, b, b)
+
+
+def batchread_write3d(depth, cn, batch=50):
+    st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    esz = torch.empty(0, dtype=TORCH[depth]).element_size()
+
+    def make():
+        frame = rand(H4K, W4K, cn, depth)
+        m = cvgs.GpuMat.from_tensor(frame, st)
+        crops = [m.roi(i, i, 60, 120) for i in range(batch)]
+        out = torch.zeros((batch, 60 * 120, cn), dtype=torch.float32, device=dev)
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, crops, batch), cvgs.convertTo(st, f, 0.3), cvgs.subtract(f, W.K1_SUB[cn]), cvgs.divide(f, W.K1_DIV[cn]),
+               cvgs.write(f, cvgs.GpuMat.from_tensor(out, f), (60, 120))]
+        return ops, (frame, out)
+    b = batch * 60 * 120 * cn * (esz + 4)
+    report("batchread_x_write3D %sC%d x%d crops" % (depth, cn, batch), make, b, W4K * H4K * cn * esz, flags=capi.CHAIN_NO_THREAD_FUSION)
+
+
+def resize_write(depth, cn, dst):
+    st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    esz = torch.empty(0, dtype=TORCH[depth]).element_size()
+
+    def make():
+        src, out = rand(H4K, W4K, cn, depth), torch.zeros((dst[1], dst[0], cn), dtype=TORCH[depth], device=dev)
+        ops = [cvgs.resize(st, cvgs.INTER_LINEAR, cvgs.GpuMat.from_tensor(src, st), dst)]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(f, st))
+        return ops + [cvgs.write(st, cvgs.GpuMat.from_tensor(out, st))], (src, out)
+    tapped = min(W4K, 2 * dst[0]) * min(H4K, 2 * dst[1])  # distinct source pixels a stretch can tap (upper bound)
+    b = (tapped + dst[0] * dst[1]) * cn * esz
+    report("resize_write %sC%d 4K -> %dx%d" % (depth, cn, dst[0], dst[1]), make, b, W4K * H4K * cn * esz + dst[0] * dst[1] * cn * esz)
+
+
+def resize_x_split(depth, cn):
+    st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+
+    def make():
+        src = rand(H4K, W4K, cn, depth)
+        outs = [torch.zeros((128, 64), dtype=torch.float32, device=dev) for _ in range(cn)]
+        ops = [cvgs.resize(st, cvgs.INTER_LINEAR, cvgs.GpuMat.from_tensor(src, st).roi(200, 200, 60, 120), (64, 128)),
+               cvgs.multiply(f, [0.3] * cn), cvgs.subtract(f, W.K1_SUB[cn]), cvgs.divide(f, W.K1_DIV[cn]),
+               cvgs.split(f, [cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1) for o in outs])]
+        return ops, (src, outs)
+    report("resize_x_split %sC%d crop 60x120 -> 64x128 planes (launch-bound)" % (depth, cn), make, 60 * 120 * cn + 64 * 128 * cn * 4, W4K * H4K * cn)
+
+
+def warp(size=(420, 420)):
+    u3, f3 = cvgs.CV_8UC3, cvgs.CV_32FC3
+    m = [[1.05, 0.03, -50.0], [0.02, 1.1, -60.0], [1e-5, 2e-5, 1.0]]
+
+    def make():
+        src, out = rand(size[1], size[0], 3, "8U"), torch.zeros((size[1], size[0], 3), dtype=torch.uint8, device=dev)
+        return [cvgs.warp(cvgs.WARP_PERSPECTIVE, u3, cvgs.GpuMat.from_tensor(src, u3), m, size), cvgs.cast(f3, u3),
+                cvgs.write(u3, cvgs.GpuMat.from_tensor(out, u3))], (src, out)
+    report("warp perspective 8UC3 %dx%d -> same size, fk::Cast (launch-bound)" % size, make, size[0] * size[1] * 6, size[0] * size[1] * 6)
+
+
+if __name__ == "__main__":
+    lib = capi.load_library()
+    torch.cuda.set_device(0)
+    for depth, cn in (("8U", 1), ("8U", 3), ("8U", 4), ("8S", 3), ("16U", 2), ("16S", 4), ("32S", 3), ("32F", 1), ("32F", 3)):
+        read_x_write(depth, cn)
+    for depth, cn in (("8U", 2), ("8U", 3), ("8S", 4), ("16U", 3), ("32S", 2)):
+        read_x_split(depth, cn)
+    for name, code, depth, icn, ocn in (("BGR2RGB", cvgs.COLOR_BGR2RGB, "8U", 3, 3), ("BGR2BGRA", cvgs.COLOR_BGR2BGRA, "8U", 3, 4),
+                                        ("BGRA2GRAY", cvgs.COLOR_BGRA2GRAY, "8U", 4, 1), ("BGR2RGB", cvgs.COLOR_BGR2RGB, "16U", 3, 3),
+                                        ("RGBA2BGR", cvgs.COLOR_RGBA2BGR, "32F", 4, 3), ("BGR2GRAY", cvgs.COLOR_BGR2GRAY, "32F", 3, 1)):
+        cvt_color(name, code, depth, icn, ocn)
+    for depth, cn in (("8U", 3), ("8U", 4), ("16U", 3), ("16S", 1), ("32S", 2), ("32F", 3)):
+        batchread_write3d(depth, cn)
+    for depth, cn in (("8U", 1), ("8U", 3), ("8U", 4), ("16U", 3), ("16S", 1), ("32F", 1)):
+        resize_write(depth, cn, (3870, 2260))
+        resize_write(depth, cn, (300, 500))
+    for depth, cn in (("8U", 3), ("8U", 4), ("16U", 3), ("16S", 4)):
+        resize_x_split(depth, cn)
+    warp()

@@ -379,15 +379,29 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     return hipGetLastError();
 }
 
-// packed / separate-plane targets: u8 sources; one row per wave, four for whole-frame sizes
-template <int CN, typename OT, int WM, class Prog = InterpProg>
+// packed / separate-plane targets; one row per wave, four for whole-frame sizes
+template <int CN, typename OT, int WM, class Prog = InterpProg, int SRC = SRC_U8>
 static hipError_t launch_other(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
     if (rpw >= 4) {
-        if (table) return launch_t<CN, 0, 4, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
-        return launch_t<CN, CVGS_KERNARG_PLANES, 4, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
+        if (table) return launch_t<CN, 0, 4, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
+        return launch_t<CN, CVGS_KERNARG_PLANES, 4, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
     }
-    if (table) return launch_t<CN, 0, 1, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
-    return launch_t<CN, CVGS_KERNARG_PLANES, 1, Prog, SRC_U8, OT, WM>(c, ip, ni, c.write.cn, s);
+    if (table) return launch_t<CN, 0, 1, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
+    return launch_t<CN, CVGS_KERNARG_PLANES, 1, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
+}
+// 16-bit and CV_32F sources into packed pixels of the SOURCE's own type (the reference's single-image resize tests sweep
+// CV_16U / CV_16S C1, C3, C4 and CV_32FC1: resize -> convertTo<CV_32F, I> -> write<I>, tests/resize/test_resize_write.cu:55-56,
+// 110-123), and 16-bit sources into separate fp32 planes (tests/resize/test_resize_x_split.cu)
+template <int CN>
+static hipError_t launch_same_type_packed(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+    if (src == SRC_U16) return launch_other<CN, uint16_t, WM_PACKED, InterpProg, SRC_U16>(table, rpw, c, ip, ni, s);
+    if (src == SRC_S16) return launch_other<CN, int16_t, WM_PACKED, InterpProg, SRC_S16>(table, rpw, c, ip, ni, s);
+    return launch_other<CN, float, WM_PACKED, InterpProg, SRC_F32>(table, rpw, c, ip, ni, s);
+}
+template <int CN>
+static hipError_t launch_split2d_16(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+    if (src == SRC_U16) return launch_other<CN, float, WM_SPLIT2D, InterpProg, SRC_U16>(table, rpw, c, ip, ni, s);
+    return launch_other<CN, float, WM_SPLIT2D, InterpProg, SRC_S16>(table, rpw, c, ip, ni, s);
 }
 // separate planes: the reference's K2 chain (mul, sub, div; with or without the R<->B swap) gets its compile-time program
 template <int CN>
@@ -489,14 +503,20 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if (!r.table && n_inline > CVGS_KERNARG_PLANES && (n_inline > kKernargPlanesBig || !planar || few || mirrors.n > 0 || segs)) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
     const bool u8out = c_in.write.depth == CVGS_DEPTH_8U;
-    if (!f16 && !u8out && c_in.write.depth != CVGS_DEPTH_32F) return 0;
-    if (u8out && !packed) return 0;
+    const bool i16out = c_in.write.depth == CVGS_DEPTH_16U || c_in.write.depth == CVGS_DEPTH_16S;
+    if (!f16 && !u8out && !i16out && c_in.write.depth != CVGS_DEPTH_32F) return 0;
+    if ((u8out || i16out) && !packed) return 0;
+    if (i16out && r.depth != c_in.write.depth) return 0; // 16U -> 16U, 16S -> 16S
     if (split2d && c_in.write.depth != CVGS_DEPTH_32F) return 0;
-    if (!planar && r.depth != CVGS_DEPTH_8U) return 0;
+    // non-planar targets of non-u8 sources: packed pixels of the source's own type, or (16-bit, 3 / 4 channels) separate fp32 planes
+    const bool same_type_packed = packed && r.depth != CVGS_DEPTH_8U && c_in.write.depth == r.depth && r.cn != 2;
+    const bool planes_16 = split2d && (r.depth == CVGS_DEPTH_16U || r.depth == CVGS_DEPTH_16S) && !few;
+    if (!planar && r.depth != CVGS_DEPTH_8U && !same_type_packed && !planes_16) return 0;
+    if (same_type_packed && (mirrors.n > 0 || segs)) return 0;
     int n_prog = c_in.prog.n;
-    if (f16 || u8out) {
-        if (r.depth != CVGS_DEPTH_8U || n_prog < 1 || c_in.prog.opcode[n_prog - 1] != CVGS_OP_CAST) return 0;
-        --n_prog; // the trailing CAST(CV_16F / CV_8U) happens in the store
+    if (f16 || u8out || i16out) {
+        if (((f16 || u8out) && r.depth != CVGS_DEPTH_8U) || n_prog < 1 || c_in.prog.opcode[n_prog - 1] != CVGS_OP_CAST) return 0;
+        --n_prog; // the trailing CAST(CV_16F / CV_8U / CV_16U / CV_16S) happens in the store
     }
     for (int k = 0; k < n_prog; ++k) // value must stay fp32 through the program
         if (c_in.prog.opcode[k] == CVGS_OP_CAST || c_in.prog.opcode[k] == CVGS_OP_CAST_TRUNC) return 0;
@@ -546,7 +566,14 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
                                                  {{"k1_s16c1_mul_sub_div", "k1_s16c1_interp"}, {"k1_s16c2_mul_sub_div", "k1_s16c2_interp"}},
                                                  {{"k1_f32c1_mul_sub_div", "k1_f32c1_interp"}, {"k1_f32c2_mul_sub_div", "k1_f32c2_interp"}}};
         static const char* names_few_packed[2][2] = {{"k1_u8c1_packed_f32", "k1_u8c1_packed_u8"}, {"k1_u8c2_packed_f32", "k1_u8c2_packed_u8"}};
-        if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : names_few_packed[r.cn - 1][u8out];
+        static const char* names_same[4][4] = {{"", "", "", ""},
+                                               {"k1_u16c1_packed_u16", "", "k1_u16c3_packed_u16", "k1_u16c4_packed_u16"},
+                                               {"k1_s16c1_packed_s16", "", "k1_s16c3_packed_s16", "k1_s16c4_packed_s16"},
+                                               {"k1_f32c1_packed_f32", "", "k1_f32c3_packed_f32", "k1_f32c4_packed_f32"}};
+        static const char* names_planes16[2][2] = {{"k1_u16c3_planes2d_f32", "k1_u16c4_planes2d_f32"}, {"k1_s16c3_planes2d_f32", "k1_s16c4_planes2d_f32"}};
+        if (same_type_packed) info->kernel = names_same[src][r.cn - 1];
+        else if (planes_16) info->kernel = names_planes16[src == SRC_S16][r.cn == 4];
+        else if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : names_few_packed[r.cn - 1][u8out];
         else if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
         else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
     }
@@ -567,6 +594,13 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
                              : launch_t<4, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
         };
         e = prog_id == 0 ? mir(ProgSwapMulSubDiv{}) : (prog_id == 1 ? mir(ProgMulSubDiv{}) : mir(InterpProg{}));
+    } else if (same_type_packed) {
+        e = r.cn == 1 ? launch_same_type_packed<1>(src, table, rpw, c, inline_planes, n_inline, s)
+            : r.cn == 3 ? launch_same_type_packed<3>(src, table, rpw, c, inline_planes, n_inline, s)
+                        : launch_same_type_packed<4>(src, table, rpw, c, inline_planes, n_inline, s);
+    } else if (planes_16) {
+        e = r.cn == 3 ? launch_split2d_16<3>(src, table, rpw, c, inline_planes, n_inline, s)
+                      : launch_split2d_16<4>(src, table, rpw, c, inline_planes, n_inline, s);
     } else if (few) {
         e = r.cn == 1 ? launch_few<1>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s)
                       : launch_few<2>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s);

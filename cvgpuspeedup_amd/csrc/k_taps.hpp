@@ -271,6 +271,9 @@ __device__ __forceinline__ void st_plain(float* p, float v) { __builtin_nontempo
 __device__ __forceinline__ void st_plain(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
 // u8 targets: the chain's trailing SaturateCast (round to nearest even, clamp, NaN -> 0) is this conversion
 __device__ __forceinline__ void st_plain(uint8_t* p, float v) { __builtin_nontemporal_store((uint8_t)sat_round(v, 0.f, 255.f), p); }
+// 16-bit integer targets (the reference's resize -> convertTo<32F, 16U / 16S> -> write chains, tests/resize/test_resize_write.cu)
+__device__ __forceinline__ void st_plain(uint16_t* p, float v) { __builtin_nontemporal_store((uint16_t)sat_round(v, 0.f, 65535.f), p); }
+__device__ __forceinline__ void st_plain(int16_t* p, float v) { __builtin_nontemporal_store((int16_t)sat_round(v, -32768.f, 32767.f), p); }
 
 // one packed pixel: a single vector store when the channel count is the compile-time one (the usual case), element
 // stores when the chain changed it (e.g. *2GRAY after the resize)
@@ -296,6 +299,18 @@ __device__ __forceinline__ void store_packed_px(OT* px, const float* v, int cn) 
                 __builtin_nontemporal_store(hi, (vh2u*)(px + 2));
             } else {
                 __builtin_nontemporal_store((_Float16)v[2], px + 2);
+            }
+            return;
+        } else if constexpr (sizeof(OT) == 2) { // 16-bit integers: pairs of elements as one 32-bit store
+            typedef uint32_t u32a2 __attribute__((aligned(2)));
+            constexpr float lo = std::is_same_v<OT, uint16_t> ? 0.f : -32768.f, hi = std::is_same_v<OT, uint16_t> ? 65535.f : 32767.f;
+            const uint32_t e0 = (uint32_t)(uint16_t)(OT)sat_round(v[0], lo, hi), e1 = (uint32_t)(uint16_t)(OT)sat_round(v[1], lo, hi);
+            __builtin_nontemporal_store(e0 | (e1 << 16), (u32a2*)px);
+            if constexpr (CN == 4) {
+                const uint32_t e2 = (uint32_t)(uint16_t)(OT)sat_round(v[2], lo, hi), e3 = (uint32_t)(uint16_t)(OT)sat_round(v[3], lo, hi);
+                __builtin_nontemporal_store(e2 | (e3 << 16), (u32a2*)(px + 2));
+            } else {
+                st_plain(px + 2, v[2]);
             }
             return;
         } else if constexpr (CN == 4) { // u8c4: one dword

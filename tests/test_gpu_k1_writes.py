@@ -152,3 +152,63 @@ def test_resize_one_and_two_channel_sources(depth, cn, out):
         assert name.startswith("generic")  # packed == planar for one channel; 16-bit C1 stays on the interpreted kernel
     else:
         assert name.startswith("k1_%sc%d" % ({"8U": "u8", "16U": "u16", "16S": "s16"}[depth], cn)), name
+
+
+# ---- the reference's single-image resize tests on 16-bit and CV_32F images (tests/resize/test_resize_write.cu:110-123) ----
+@pytest.mark.parametrize("depth,cn", [("16U", 1), ("16U", 3), ("16U", 4), ("16S", 1), ("16S", 3), ("16S", 4), ("32F", 1), ("32F", 3)])
+@pytest.mark.parametrize("dst", [(640, 360), (1010, 601), (37, 53)])
+def test_resize_write_back_to_the_source_type(depth, cn, dst):
+    """resize -> convertTo<CV_32FCn, I> -> write<I> (CV_32F: resize -> write): up, down and tiny, into a PITCHED image; the
+    K1 kernel with a packed store of the source's own type, vs the oracle and vs the interpreted kernel."""
+    from tests.test_gpu_chains import _random_src
+    from tests import kat_runner as K
+    src = _random_src((270, 481, cn), depth, 330 + cn)
+    if depth == "32F":
+        src = (src * 50.0).astype(np.float32)
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    np_dt = K.NP_DEPTH[depth]
+    pitch_w = dst[0] + 3
+
+    def build(wrap, wrap_out, out):
+        o = wrap_out(np.zeros((dst[1], pitch_w, cn), np_dt) if out is None else out, st)
+        ops = [cvgs.resize(st, cvgs.INTER_LINEAR, wrap(src, st), dst)]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(f, st))
+        return ops + [cvgs.write(st, o.roi(1, 0, dst[0], dst[1]))]
+
+    gpu, ref = _both(build, (dst[1], pitch_w, cn), np_dt)
+    H.assert_bit_exact(gpu[0], ref[0], "resize -> packed %s" % depth)
+    assert not ref[0][:, :1].any() and not ref[0][:, dst[0] + 1:].any() and ref[0][:, 1:dst[0] + 1].astype(np.float64).std() > 10
+    assert _name(build) == "k1_%s%sc%d_packed_%s%s" % (depth[-1].lower(), depth[:-1], cn, depth[-1].lower(), depth[:-1]), _name(build)
+    gen, _ = _both(build, (dst[1], pitch_w, cn), np_dt, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gen[0], gpu[0], "interpreted kernel agrees")
+
+
+@pytest.mark.parametrize("depth", ["16U", "16S"])
+@pytest.mark.parametrize("cn,batch", [(3, 1), (4, 3)])
+def test_resize_16_bit_sources_to_separate_planes(depth, cn, batch):
+    """tests/resize/test_resize_x_split.cu on its CV_16U / CV_16S type pairs: resize -> mul -> sub -> div -> split(planes)."""
+    from tests.test_gpu_chains import _random_src
+    from tests import kat_runner as K
+    src = _random_src((300, 500, cn), depth, 340 + cn)
+    crops = H.random_crops(batch, 500, 300, seed=15 + batch, wmin=8, wmax=300, hmin=8, hmax=250)
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    dst = (64, 128)
+    pitch_w = dst[0] + 2
+
+    def build(wrap, wrap_out, out):
+        frame = wrap(src, st)
+        o = wrap_out(np.zeros((batch * cn * dst[1], pitch_w), np.float32) if out is None else out, cvgs.CV_32FC1)
+        planes = [[cvgs.GpuMat(dst[1], dst[0], cvgs.CV_32FC1, o.data + ((z * cn + c) * dst[1]) * o.step, o.step, owner=o)
+                   for c in range(cn)] for z in range(batch)]
+        rd = (cvgs.resize(st, cvgs.INTER_LINEAR, [frame.roi(*c) for c in crops], dst, batch) if batch > 1 else
+              cvgs.resize(st, cvgs.INTER_LINEAR, frame.roi(*crops[0]), dst))
+        return [rd, cvgs.multiply(f, [0.3] * cn), cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn]),
+                cvgs.split(f, planes if batch > 1 else planes[0])]
+
+    gpu, ref = _both(build, (batch * cn * dst[1], pitch_w), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "16-bit resize -> separate planes")
+    assert ref[0].any() and not ref[0][:, dst[0]:].any()
+    assert _name(build) == "k1_%s16c%d_planes2d_f32" % (depth[-1].lower(), cn), _name(build)
+    gen, _ = _both(build, (batch * cn * dst[1], pitch_w), np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gen[0], gpu[0], "interpreted kernel agrees")

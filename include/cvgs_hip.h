@@ -263,7 +263,9 @@ typedef enum cvgs_chain_flags {
     /* force the interpreted generic kernel even when a specialised kernel matches (testing)   */
     CVGS_CHAIN_FORCE_GENERIC = 1,
     /* ENABLE_THREAD_FUSION=false of the reference (cvGPUSpeedup.cuh:464): results identical,
-     * only disables the multi-pixel-per-thread fast paths                                      */
+     * only disables the multi-pixel-per-thread fast paths.  A tuning / testing knob: the C++
+     * facade does not forward executeOperations<false> (the hint exists in the reference because
+     * its thread-fused path does not cover every type; here it would only pick a slower kernel) */
     CVGS_CHAIN_NO_THREAD_FUSION = 2
     /* every other bit must be zero (CVGS_ERR_INVALID) */
 } cvgs_chain_flags;

@@ -5,8 +5,8 @@ fraction of 8 TB/s.  A row on `generic*` or far below its neighbours is a chain 
 serves slowly.  Chains (reference file:line of the cvGS call):
   read_x_write      tests/read/test_read_x_write.cu:39-44      4K I -> convertTo -> sub -> mul -> div -> add -> write (packed O)
   read_x_split      tests/read/test_read_x_split.cu:58-60      4K I -> convertTo -> split(vector<GpuMat>)
-  cvtColor          tests/color/test_cvtColor.cu:55            4K cvtColor<code> (thread fusion off, as the test)
-  batchread_write3D tests/batchread/test_batchread_x_write3D.cu:92-96   50 crops 60x120 -> convertTo(alpha) -> sub -> div -> Tensor (TF off)
+  cvtColor          tests/color/test_cvtColor.cu:55            4K cvtColor<code> (the test spells executeOperations<false>; the facade does not forward that hint)
+  batchread_write3D tests/batchread/test_batchread_x_write3D.cu:92-96   50 crops 60x120 -> convertTo(alpha) -> sub -> div -> Tensor (ditto)
   resize_write      tests/resize/test_resize_write.cu:55-56    4K -> 3870x2260 and -> 300x500, convertTo back to I, write
   resize_x_split    tests/resize/test_resize_x_split.cu:79-84  crop 60x120 -> 64x128 -> mul, sub, div -> split(planes)
   warp              tests/warping/test_warping_opencv.cu:63    perspective warp of an image to its own size, fk::Cast, write"""
@@ -122,7 +122,7 @@ def batchread_write3d(depth, cn, batch=50):
                cvgs.write(f, cvgs.GpuMat.from_tensor(out, f), (60, 120))]
         return ops, (frame, out)
     b = batch * 60 * 120 * cn * (esz + 4)
-    report("batchread_x_write3D %sC%d x%d crops" % (depth, cn, batch), make, b, W4K * H4K * cn * esz, flags=capi.CHAIN_NO_THREAD_FUSION)
+    report("batchread_x_write3D %sC%d x%d crops" % (depth, cn, batch), make, b, W4K * H4K * cn * esz, flags=0)  # the facade does not forward executeOperations<false>
 
 
 def resize_write(depth, cn, dst):

@@ -419,13 +419,28 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
 }
 
 // ---- descriptor scratch ------------------------------------------------------------------------------------------
-// Tables that do not fit the kernel-argument block (more than 64 planes; the segments of cvgs_execute_many) are staged
-// in a pinned host buffer and copied, stream-ordered, into a device buffer.  Both belong to a slot of a library-owned
-// pool; a slot is reusable once the HIP event recorded behind the kernel that read it has completed, so neither the
-// host staging bytes nor the device table can be recycled while the GPU may still read them, no call frees or
+// Tables that do not fit the kernel-argument block (more than 64 / 320 planes; the segments of cvgs_execute_many) are written
+// into a pinned host buffer that the kernel reads in place (or, in the staged mode, copied stream-ordered into a device
+// buffer).  The buffers belong to a slot of a library-owned pool; a slot is reusable once the HIP event recorded behind the
+// kernel that read it has completed, so the table cannot be recycled while the GPU may still read it, no call frees or
 // synchronises, and a steady-state serving loop allocates nothing.
+// Zero-copy mode (the default; CVGS_SCRATCH_ZEROCOPY=0 restores the staged copy): the kernels read the table straight from the
+// pinned host buffer, which is allocated NON-COHERENT (cached in the GPU's L2 for the duration of a kernel, re-fetched by the
+// next one: every launch starts with a system-scope acquire) -- no copy, no copy event, no stream wait; the slot is still
+// recycled by the event behind the kernel that read it.  Measured (MI355X, eager, host descriptors): 16 x 50 crops through
+// cvgs_execute_many 47.3 -> 43.9 us, one chain of 400 crops 28.0 -> 23.7 us (host enqueue 19.4 -> 14.0 us); 300 back-to-back
+// launches with a different crop list each through recycled slots verified plane by plane against the oracle.
+static bool scratch_zero_copy() {
+    static const bool on = [] {
+        const char* e = getenv("CVGS_SCRATCH_ZEROCOPY");
+        return e ? e[0] != '0' : true;
+    }();
+    return on;
+}
+
 struct ScratchSlot {
     void* host = nullptr;
+    void* host_dev = nullptr; // the device-side address of `host` (zero-copy mode)
     void* dev = nullptr;
     size_t cap = 0;
     hipEvent_t ev = nullptr;      // recorded behind the kernel that read the slot: the slot is reusable once it completes
@@ -455,8 +470,10 @@ public:
         ScratchSlot sl;
         size_t cap = 64 << 10;
         while (cap < bytes) cap <<= 1;
-        hipError_t e = hipHostMalloc(&sl.host, cap, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc(&sl.dev, cap);
+        hipError_t e = hipHostMalloc(&sl.host, cap, scratch_zero_copy() ? (hipHostMallocNonCoherent | hipHostMallocMapped | hipHostMallocPortable)
+                                                                         : hipHostMallocDefault);
+        if (e == hipSuccess && scratch_zero_copy()) e = hipHostGetDevicePointer(&sl.host_dev, sl.host, 0);
+        if (e == hipSuccess && !scratch_zero_copy()) e = hipMalloc(&sl.dev, cap);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.copy_ev, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -491,7 +508,10 @@ public:
         return 0;
     }
     void* host(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].host; }
-    void* dev(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].dev; }
+    void* dev(int slot) {
+        std::lock_guard<std::mutex> lk(m_);
+        return scratch_zero_copy() ? slots_[(size_t)slot].host_dev : slots_[(size_t)slot].dev;
+    }
     // the kernel that reads the slot has been enqueued on `stream`: recycle after it
     void commit(int slot, hipStream_t stream) {
         std::lock_guard<std::mutex> lk(m_);
@@ -580,6 +600,7 @@ struct Upload {
         DeviceGuard guard;
         int rc = guard.enter(stream_device(stream));
         if (rc) return rc;
+        if (scratch_zero_copy()) return 0; // the kernel reads the pinned buffer itself
         rc = scratch_pool().copy_to_device(slot, used, stream);
         if (rc) return rc;
         flushed = true;

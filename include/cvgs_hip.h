@@ -18,10 +18,10 @@
  * allocated by cvgs_circular_create and cvgs_comm_*, plus one case inside cvgs_execute(_many): a batch
  * with more host descriptors than fit the kernel-argument block (64 planes in a 4 KB block; up to
  * CVGS_KERNARG_PLANES_MAX = 320 planes in a 16 KB block for the batched resize -> planar tensor chain,
- * the reference's benchmark sweep; 52 for warps, 16 destination planes) is staged through a
- * library-owned pool of {pinned host, device} scratch slots (grown on first use, recycled by HIP
- * event, never freed per call) and copied stream-ordered; that case is refused during stream
- * capture -- pass a resident table (cvgs_plane_table_build).  A call whose descriptors travel in the
+ * the reference's benchmark sweep; 52 for warps, 16 destination planes) is written into a slot of a
+ * library-owned pool of pinned host buffers (grown on first use, recycled by HIP event, never freed
+ * per call) that the kernel reads in place; that case is refused during stream capture -- pass a
+ * resident table (cvgs_plane_table_build).  A call whose descriptors travel in the
  * kernel arguments allocates nothing, on the host or on the device, and can be captured.
  *
  * Return value: 0 (CVGS_OK) or a negative cvgs_status; cvgs_last_error() gives a thread-local

@@ -690,7 +690,15 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         if (!has_mirrors) { // only K1 and the interpreted kernel write mirrors
             int min_w = 1 << 30;
             for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
-            rc = launch_nv12(L.args, inline_planes, n_inline, min_w, nullptr, 0, stream, dry_run, info);
+            if (up_src && is_nv12(L.args.read.kind) && L.args.read.used == L.args.read.batch &&
+                k4_planes_eligible(L.planes.data(), (int)L.planes.size(), L.args.read.dst_w, L.args.read.dst_h)) {
+                // more than 64 crops of a decoder surface: K4 reads the staged table as ONE segment of its fused-chain form
+                // (the planes are known on the host here, so its per-plane preconditions can be checked)
+                const ManySeg seg{L.args.read.table, L.args.write.data, L.args.read.batch, L.args.read.used};
+                rc = launch_nv12(L.args, nullptr, 0, 4, &seg, 1, stream, dry_run, info);
+            } else {
+                rc = launch_nv12(L.args, inline_planes, n_inline, min_w, nullptr, 0, stream, dry_run, info);
+            }
             if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
             if (rc == 1) { up.done(true); return CVGS_OK; }
             rc = launch_pointwise(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);

@@ -277,3 +277,34 @@ def test_descriptor_scratch_is_thread_safe(oracle, device, lib):
         H.assert_bit_exact(j["big_out"][0].cpu().numpy(), _oracle(oracle, frame, crops), "thread %d, 100-crop chain" % t)
         for m, (frame, crops) in enumerate(j["many_in"]):
             H.assert_bit_exact(j["many_out"][m].cpu().numpy(), _oracle(oracle, frame, crops), "thread %d, fused chain %d" % (t, m))
+
+
+@pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_P010])
+@pytest.mark.parametrize("n", [65, 130, 400])
+def test_more_than_64_crops_of_a_decoder_surface_stay_on_k4(oracle, device, layout, n):
+    """65+ detections of one NV12 / NV21 / P010 surface in one chain: the crop table no longer fits the kernel arguments; K4
+    reads it as one segment of its fused-chain form instead of leaving the chain to the interpreted kernel."""
+    import torch
+    w, h = 1280, 720
+    p010 = layout == capi.YUV_P010
+    s_t = cvgs.CV_16UC1 if p010 else cvgs.CV_8UC1
+    surf = (H.random_u16 if p010 else H.random_u8)((h + h // 2, w), seed=4100 + n)
+    st = torch.from_numpy(surf.view(np.int16) if p010 else surf).to(device)
+    rects = [(x & ~1, y & ~1, max(4, cw & ~1), max(2, ch & ~1)) for (x, y, cw, ch) in H.random_crops(n, w, h, seed=4200 + n, wmin=4, wmax=400, hmin=4, hmax=400)]
+    f = cvgs.CV_32FC3
+    ot = torch.full((n, 3 * 64 * 128), -3.0, dtype=torch.float32, device=device)
+    ref = np.full((n, 3 * 64 * 128), -3.0, np.float32)
+
+    def chain(wrap_s, wrap_o, out):
+        m = wrap_s(surf)
+        luma = cvgs.GpuMat(h, w, s_t, m.data, m.step, owner=m.owner)
+        return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], (64, 128), capi.YUV_LIMITED, capi.BT709, False, layout=layout),
+                cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]),
+                cvgs.split(f, wrap_o(out), (64, 128))]
+
+    ops = chain(lambda a: cvgs.GpuMat.from_tensor(st, s_t), lambda o: cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), ot)
+    assert cvgs.kernel_name(*ops).startswith("k4_nv12_resize"), cvgs.kernel_name(*ops)
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, s_t), lambda o: cvgs.GpuMat.from_array(o, cvgs.CV_32FC1), ref)))
+    H.assert_bit_exact(ot.cpu().numpy(), ref, "%d crops of a layout-%d surface" % (n, layout))

@@ -624,7 +624,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
     // 65 .. CVGS_KERNARG_PLANES_MAX planes of a chain K1 serves with a planar tensor target: the descriptors still travel in
     // the kernel arguments (a 16 KB block) -- no staging copy, capturable into a HIP graph
     bool big_inline = false;
-    if (!warp && !L.uses_64f && !L.args.read.table && !has_mirrors && !(ch->flags & CVGS_CHAIN_FORCE_GENERIC) &&
+    if (!warp && !L.uses_64f && !L.args.read.table && !(ch->flags & CVGS_CHAIN_FORCE_GENERIC) &&
         (int)L.planes.size() > CVGS_KERNARG_PLANES && (int)L.planes.size() <= kKernargPlanesBig)
         big_inline = launch_k1(L.args, L.planes.data(), (int)L.planes.size(), L.mirrors, nullptr, 0, stream, true, nullptr) == 1;
     const bool up_src = warp ? (int)L.warp_planes.size() > (L.uses_64f ? kInlineWarp64 : kInlineWarp)

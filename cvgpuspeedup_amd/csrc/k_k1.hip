@@ -500,7 +500,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if (mirrors.n > 0 && (r.depth != CVGS_DEPTH_8U || r.cn < 3 || r.table || segs || c_in.write.depth != CVGS_DEPTH_32F)) return 0;
     if (segs && (!r.table || n_segs < 1 || n_segs > CVGS_MAX_CHAINS)) return 0;
     // more than CVGS_KERNARG_PLANES descriptors in the kernel arguments: the 3- / 4-channel planar-tensor kernels only
-    if (!r.table && n_inline > CVGS_KERNARG_PLANES && (n_inline > kKernargPlanesBig || !planar || few || mirrors.n > 0 || segs)) return 0;
+    if (!r.table && n_inline > CVGS_KERNARG_PLANES && (n_inline > kKernargPlanesBig || !planar || few || segs)) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
     const bool u8out = c_in.write.depth == CVGS_DEPTH_8U;
     const bool i16out = c_in.write.depth == CVGS_DEPTH_16U || c_in.write.depth == CVGS_DEPTH_16S;
@@ -590,6 +590,9 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         // one row per wave (a 64-crop launch is in the latency regime), planes in the kernel arguments
         auto mir = [&](auto prog_tag) {
             using Pg = decltype(prog_tag);
+            if (n_inline > CVGS_KERNARG_PLANES) // a shard of up to 320 crops per GPU: the 16 KB argument block
+                return r.cn == 3 ? launch_t<3, kKernargPlanesBig, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s)
+                                 : launch_t<4, kKernargPlanesBig, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
             return r.cn == 3 ? launch_t<3, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s)
                              : launch_t<4, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
         };

@@ -140,12 +140,12 @@ def test_execute_many_rejects_bad_input(lib, device):
 
 
 # ---- mirrors ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n_mirrors,flags", [(1, 0), (3, 0), (7, 0), (2, capi.CHAIN_FORCE_GENERIC)])
-def test_mirrors_receive_the_same_rows(oracle, device, n_mirrors, flags):
+@pytest.mark.parametrize("n_mirrors,flags,n", [(1, 0, 10), (3, 0, 10), (7, 0, 10), (2, capi.CHAIN_FORCE_GENERIC, 10), (3, 0, 64), (2, 0, 128), (7, 0, 320)])
+def test_mirrors_receive_the_same_rows(oracle, device, n_mirrors, flags, n):
     """Rank r's K1 writes rows [r*n, (r+1)*n) of ITS copy of the [G*n, C*H*W] tensor and of every peer's copy: here the
     peers are further tensors on the same device; every copy must hold the oracle's rows, and nothing else is touched."""
     import torch
-    n, world, rank = 10, 3, 1
+    world, rank = 3, 1  # n crops per rank: up to 320 travel in K1's kernel arguments (a 512-crop job on 2 GPUs is 256 per rank)
     frame = H.random_u8((720, 1280, 3), seed=21)
     crops = H.random_crops(n, 1280, 720, seed=22)
     ft = torch.from_numpy(frame).to(device)

@@ -626,7 +626,14 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
     bool big_inline = false;
     if (!warp && !L.uses_64f && !L.args.read.table && !(ch->flags & CVGS_CHAIN_FORCE_GENERIC) &&
         (int)L.planes.size() > CVGS_KERNARG_PLANES && (int)L.planes.size() <= kKernargPlanesBig)
+    {
         big_inline = launch_k1(L.args, L.planes.data(), (int)L.planes.size(), L.mirrors, nullptr, 0, stream, true, nullptr) == 1;
+        if (!big_inline && !has_mirrors && is_nv12(L.args.read.kind)) { // K4: crops of a decoder surface into a planar tensor
+            int min_w = 1 << 30;
+            for (size_t i = 0; i < L.planes.size(); ++i) min_w = L.planes[i].w < min_w ? L.planes[i].w : min_w;
+            big_inline = launch_nv12(L.args, L.planes.data(), (int)L.planes.size(), min_w, nullptr, 0, stream, true, nullptr) == 1;
+        }
+    }
     const bool up_src = warp ? (int)L.warp_planes.size() > (L.uses_64f ? kInlineWarp64 : kInlineWarp)
                              : (!L.args.read.table && (int)L.planes.size() > inline_cap && !big_inline);
     const bool up_dst = (int)L.dst_planes.size() > kInlineDst;
@@ -686,7 +693,8 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         rc = launch_k1(L.args, inline_planes, n_inline, L.mirrors, nullptr, 0, stream, dry_run, info);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
         if (rc == 1) { up.done(true); return CVGS_OK; }
-        if (big_inline) return fail(CVGS_ERR_HIP, "internal: K1 refused a chain its dry run accepted"); // nobody else takes > 64 inline planes
+        if (big_inline && (has_mirrors || !is_nv12(L.args.read.kind)))
+            return fail(CVGS_ERR_HIP, "internal: K1 refused a chain its dry run accepted"); // only K1 / K4 take > 64 inline planes
         if (!has_mirrors) { // only K1 and the interpreted kernel write mirrors
             int min_w = 1 << 30;
             for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
@@ -701,6 +709,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
             }
             if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
             if (rc == 1) { up.done(true); return CVGS_OK; }
+            if (big_inline) return fail(CVGS_ERR_HIP, "internal: K4 refused a chain its dry run accepted");
             rc = launch_pointwise(L.args, inline_planes, n_inline, ch->flags, stream, dry_run, info);
             if (rc < 0) return fail(CVGS_ERR_HIP, "pointwise kernel launch failed");
             if (rc == 1) { up.done(true); return CVGS_OK; }

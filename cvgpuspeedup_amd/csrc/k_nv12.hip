@@ -288,11 +288,16 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
         hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
-    } else { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
+    } else if (ni <= CVGS_KERNARG_PLANES) { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
         hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+    } else { // ... up to CVGS_KERNARG_PLANES_MAX in a 16 KB argument block (see cvgs_device.h: cheaper than a table for an eager call)
+        KernArgs<kKernargPlanesBig> a;
+        a.c = c;
+        for (int i = 0; i < kKernargPlanesBig; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
+        hipLaunchKernelGGL((k4_nv12_resize<kKernargPlanesBig, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     }
     return hipGetLastError();
 }
@@ -345,7 +350,8 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     if (segs) {
         if (n_segs < 1 || n_segs > CVGS_MAX_CHAINS || c_in.write.data2) return 0;
     } else {
-        if (r.table || n_inline > CVGS_KERNARG_PLANES || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
+        if (r.table || n_inline > kKernargPlanesBig || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
+        if (n_inline > CVGS_KERNARG_PLANES && !(planar_kind && (c_in.write.depth == CVGS_DEPTH_32F || f16))) return 0; // the large block: tensors only
         if (r.used != r.batch) return 0;
         if (!k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h)) return 0;
     }

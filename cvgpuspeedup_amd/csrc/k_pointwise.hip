@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const
 
 template <int CN, class Prog, typename OT, int SD = CVGS_DEPTH_8U>
 static hipError_t launch_pw(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
-    const dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, c.read.batch);
+    const int px_per_wave_row = 256 >> g.narrow, rows_per_block = 4 << g.narrow;
+    const dim3 grid((g.w + px_per_wave_row - 1) / px_per_wave_row, (g.h + rows_per_block - 1) / rows_per_block, c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         a.c = c;
@@ -195,7 +196,7 @@ static int launch_pointwise_u8u8(const ChainArgs& c, const PlaneParams* ip, int 
     if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
     if (w.data2 || (!r.table && ni > CVGS_KERNARG_PLANES)) return 0;
     PwGeom g;
-    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.pad = 0;
+    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.narrow = 0;
     g.out = w.data; g.out2 = nullptr;
     g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * w.cn;
     g.row_pitch2 = 0;
@@ -229,7 +230,7 @@ static int launch_pointwise_u16u16(const ChainArgs& c, const PlaneParams* ip, in
     if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
     if (w.data2 || (!r.table && ni > CVGS_KERNARG_PLANES)) return 0;
     PwGeom g;
-    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.pad = 0;
+    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.narrow = 0;
     g.out = w.data; g.out2 = nullptr;
     g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * w.cn * 2;
     g.row_pitch2 = 0;
@@ -284,7 +285,7 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
 
     g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn;
     g.packed = packed ? 1 : (split2d ? 2 : 0);
-    g.out = w.data; g.out2 = w.data2; g.pad = 0;
+    g.out = w.data; g.out2 = w.data2; g.narrow = 0;
     if (split2d) {
         g.out = g.out2 = nullptr; // the planes are in c.dst_inline / c.write.table
         g.row_pitch = g.row_pitch2 = 0;
@@ -320,6 +321,7 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
     int prog_id = 0;
     bool f16 = false;
     if (!pointwise4_plan(c_in, n_inline, chain_flags, c, g, prog_id, f16)) return 0;
+    g.narrow = g.w <= 64 ? 2 : (g.w <= 128 ? 1 : 0); // batches of small crops (the reference's 60x120 crops): several rows per wave
     if (info) {
         static const char* names[2][3] = {{"pointwise4_u8_cast_mul_sub_div", "pointwise4_u8_cast", "pointwise4_u8_interp"},
                                           {"pointwise4_u8_cast_mul_sub_div_f16", "pointwise4_u8_cast_f16", "pointwise4_u8_interp_f16"}};

@@ -83,7 +83,9 @@ struct PwGeom {
     int32_t w, h, used, cn;
     int32_t packed;    // 1: packed pixels (PIXEL_2D / PIXEL_3D), 0: planar tensor, 2: separate pitched planes (SPLIT_2D)
     int32_t row_pitch; // packed: bytes between output rows
-    int32_t row_pitch2, pad;
+    int32_t row_pitch2;
+    int32_t narrow;    // log2(rows per wave): 0 = a wave is 64 lanes x 4 pixels of ONE row; 1 / 2 = 32 / 16 lanes per row, 2 / 4 rows per
+                       // wave, for planes at most 128 / 64 pixels wide (a 60-pixel crop would leave 49 of 64 lanes idle)
     int64_t img_stride, ch_stride, img_stride2, ch_stride2; // planar: elements; packed: img_stride in BYTES
     uint8_t* out;
     uint8_t* out2;
@@ -111,8 +113,10 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
     const int W = g.w, H = g.h, used = g.used;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
-    const int x0 = (bx * 64 + lane) * 4;
-    const int y = by * 4 + wave;
+    const int sh = g.narrow; // wave-uniform
+    const int lpr = 64 >> sh; // lanes per row
+    const int x0 = (bx * lpr + (lane & (lpr - 1))) * 4;
+    const int y = ((by * 4 + wave) << sh) + (lane >> (6 - sh));
     if (y >= H || x0 >= W) return;
     const int npx = min(4, W - x0);
 
@@ -173,7 +177,7 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
         // cn floats per pixel, contiguous: 4 pixels = cn float4
         uint8_t* rows[2] = {g.out + (size_t)z * g.img_stride + (size_t)y * g.row_pitch,
                             g.out2 ? g.out2 + (size_t)z * g.img_stride2 + (size_t)y * g.row_pitch2 : nullptr};
-        if (bx * 256 + 255 < W) { // wave-uniform: the whole 256-pixel group exists, every lane is alive
+        if (sh == 0 && bx * 256 + 255 < W) { // wave-uniform: the whole 256-pixel group exists, every lane is alive
             // Each lane owns 4*CN consecutive output elements (48 / 64 bytes for fp32): stored directly, every 16-byte
             // store instruction would scatter the wave over a 3-4 KB span.  Transpose through LDS instead: lanes write
             // their elements, then lane l stores the wave's l-th, (64+l)-th, ... 16-byte chunk -> 1 KB contiguous per

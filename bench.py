@@ -491,7 +491,7 @@ def extra_sweeps(dev, a):
         for M in (1, 4, 16, 64):
             out["frames_per_launch_%d" % M] = sweep_line(dev, 50, per_launch=M, table=True)
         # the same 16-chain launch as a serving loop submits it: host descriptors (new crop lists every call), eager; every call
-        # lowers 16 x 50 crops, stages 38 KB through the pinned scratch pool and launches once
+        # lowers 16 x 50 crops, writes 38 KB of plane tables into a pinned slot the kernel reads in place, and launches once
         wlh = Workload(dev, 32, 50, 0, 1, use_table=False)
         arrs = [cvgs.pack_chains(wlh.chains[g * 16:(g + 1) * 16]) for g in range(2)]
         s0 = torch.cuda.current_stream().cuda_stream

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of K1 with and without the SGPR-pinned row pointers (csrc/k_taps.hpp pin_uniform).  Build the variant first:
-#   cd cvgpuspeedup_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DCVGS_NO_PIN -c k_k1.hip -o ../../build/ab/k1_nopin.o
-#   hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/ab/libcvgs_hip_1.so $(ls ../../build/csrc/*.o | grep -v "k_k1.hip\|exp") ../../build/ab/k1_nopin.o -ldl
+#   cd cvgpuspeedup_amd/csrc && for f in k_k1 k_k1_c3 k_k1_c4; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DCVGS_NO_PIN -c $f.hip -o ../../build/ab/${f}_nopin.o; done
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/ab/libcvgs_hip_1.so $(ls ../../build/csrc/*.o | grep -v "k_k1\|exp") ../../build/ab/k_k1*_nopin.o -ldl
 # Round 2 result: no measurable difference on K1 (headline 4.437 vs 4.434 us, 16 x 50 crops 38.30 vs 38.42 us, whole-frame
 # resizes within noise); the pin is kept because K4 gains from it (cfg #3 8.02 vs 8.45 us, tools/k4_ab.sh).
 cp cvgpuspeedup_amd/lib/libcvgs_hip.so /tmp/o.so

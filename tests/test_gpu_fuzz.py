@@ -70,16 +70,20 @@ def _program(rng, depth, cn):
     return ops, depth, cn
 
 
-def _case(seed, big=False):
+def _case(seed, big=False, tiers=False):
     rng = np.random.default_rng(seed)
     k = 8 if big else 1  # big: whole-frame sizes (4 rows per wave, full 256-pixel groups, shuffled / LDS-transposed stores)
     kind = ["pixel", "resize", "resize", "warp", "nv12"][int(rng.integers(0, 5))]
     n = int(rng.integers(1, 4 if big else 6))
+    if tiers:  # batch sizes around the descriptor thresholds (kernel arguments 52 / 64 / 320 planes, 16 destination planes, tables beyond)
+        n = [16, 17, 52, 53, 64, 65, 130, 320, 321][int(rng.integers(0, 9))]
     used = n if rng.integers(0, 3) else int(rng.integers(0, n + 1))
     yuv_layout = int(rng.integers(0, 5))  # NV12 / NV21 / I420 / YV12 / P010
     if kind == "nv12":
         sdepth, scn = (cvgs.CV_16U if yuv_layout == capi.YUV_P010 else cvgs.CV_8U), 1
         sw, sh = 2 * int(rng.integers(2, 60 * k)), 2 * int(rng.integers(2, 40 * k))
+        if tiers:
+            sw, sh = 2 * int(rng.integers(2, 20)), 2 * int(rng.integers(2, 12))
         # P010: random 16-bit samples, i.e. 10-bit codes with garbage in the 6 low bits (which must be ignored)
         srcs = [(H.random_u16 if sdepth == cvgs.CV_16U else H.random_u8)((sh + sh // 2, sw, 1), seed * 10 + i) for i in range(n)]
         used = n
@@ -89,9 +93,13 @@ def _case(seed, big=False):
         sdepth = pool[int(rng.integers(0, 7))] if rng.integers(0, 5) else pool[int(rng.integers(7, 9))]
         scn = int(rng.integers(1, 5))
         sw, sh = int(rng.integers(1, 300 * k)), int(rng.integers(1, 60 * k))
+        if tiers:
+            sw, sh = int(rng.integers(1, 40)), int(rng.integers(1, 24))
         srcs = [_random_src((sh, sw, scn), NAME[sdepth], seed * 10 + i) for i in range(n)]
     st = cvgs.make_type(sdepth, scn)
     dw, dh = (sw, sh) if kind == "pixel" else (int(rng.integers(1, 200 * k)), int(rng.integers(1, 150 * k)))
+    if tiers and kind != "pixel":
+        dw, dh = int(rng.integers(1, 70)), int(rng.integers(1, 20))
     alpha = bool(rng.integers(0, 2))
     ar = [cvgs.IGNORE_AR, cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_LEFT, cvgs.PRESERVE_AR_RN_EVEN][int(rng.integers(0, 4))] if kind == "resize" else cvgs.IGNORE_AR
     bg = [float(v) for v in rng.integers(0, 100, 4)]
@@ -198,8 +206,8 @@ def _case(seed, big=False):
         kind, n, used, NAME[sdepth], scn, sw, sh, dw, dh, sum(len(o.ops) for o in prog), wk, np.dtype(NP[fd]).name)
 
 
-def _run(seed, big, flags):
-    build, shape, dt, what = _case(seed, big=big)
+def _run(seed, big, flags, tiers=False):
+    build, shape, dt, what = _case(seed, big=big, tiers=tiers)
     # every chain the generator can spell is served (round 2 closed the last two refusals: warps and fp16 next to CV_64F
     # values); a refusal is a failure
     gpu, ref = _both(build, shape, dt, flags=flags)
@@ -219,6 +227,13 @@ def test_random_chain_matches_oracle(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_BIG_N", "40"))))
 def test_random_chain_whole_frame_sizes(seed):
     _run(500_000 + seed, True, 0)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_TIERS_N", "120"))))
+def test_random_chain_around_the_descriptor_thresholds(seed):
+    """the same generator with 16 ... 321 planes per chain (tiny images): kernel-argument descriptors (4 KB / 16 KB blocks),
+    inline / table destination planes, pinned tables read in place."""
+    _run(900_000 + seed, False, [0, capi.CHAIN_FORCE_GENERIC, 0][seed % 3], tiers=True)
 
 
 def test_integer_values_have_no_negative_zero():

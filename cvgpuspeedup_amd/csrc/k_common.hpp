@@ -32,6 +32,26 @@ __device__ __forceinline__ float sat_round(float v, float lo, float hi) {
     return fminf(fmaxf(r, lo), hi);
 }
 
+// The SaturateCast in front of a STORE (the value leaves as bits, it does not continue as a float): single instructions whose
+// hardware semantics ARE round to nearest even + clamp + NaN -> 0.  tools/sat_probe.cpp compares each against sat_round over
+// all 2^32 float bit patterns on the GPU (no mismatch; profiles/r02_n_sat_probe.txt).
+//   u8 : v_cvt_pk_u8_f32 converts AND inserts the byte into `old` (1 instruction instead of 7 + shift/or)
+//   u16: v_rndne_f32, v_cvt_u32_f32 (saturating, NaN -> 0), v_min_u32      s16: v_rndne_f32, v_cvt_i32_f32, v_med3_i32
+__device__ __forceinline__ uint32_t sat_u8_insert(float v, uint32_t byte, uint32_t old) { return __builtin_amdgcn_cvt_pk_u8_f32(v, byte, old); }
+__device__ __forceinline__ uint32_t sat_u16_bits(float v) {
+    uint32_t u;
+    const float r = rintf(v);
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(r));
+    return u < 65535u ? u : 65535u;
+}
+__device__ __forceinline__ uint32_t sat_s16_bits(float v) {
+    int32_t i;
+    const float r = rintf(v);
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(r));
+    i = i < -32768 ? -32768 : (i > 32767 ? 32767 : i);
+    return (uint32_t)i & 0xffffu;
+}
+
 __device__ __forceinline__ int sat_round_s32(float v) {
     if (v != v) return 0;
     if (v >= 2147483648.0f) return 2147483647;

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void k_u8_gray16(const KernArgs<NPL> a, const 
         for (int ch = 0; ch < 4; ++ch) p.v[ch] = ch < CN ? elem_value<SD>(in, i * CN + ch) : 0.f;
         int depth = SD, cn = CN;
         apply_op(CVGS_OP_GRAY, aux, c.prog.operand[0], p, depth, cn);
-        if constexpr (ES == 1) q[i >> 2] |= ((uint32_t)p.v[0] & 0xffu) << (8 * (i & 3));
+        // the luminance is already an integer in [0, 255] / [0, 65535]: the saturating conversions only convert and insert
+        if constexpr (ES == 1) q[i >> 2] = sat_u8_insert(p.v[0], (uint32_t)(i & 3), q[i >> 2]);
         else q[i >> 1] |= ((uint32_t)p.v[0] & 0xffffu) << (16 * (i & 1));
     }
     __attribute__((address_space(1))) uint8_t* orow =

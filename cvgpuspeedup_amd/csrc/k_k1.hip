@@ -173,12 +173,12 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     } else if (!planar) {
         if (split2d) e = r.cn == 3 ? launch_split2d<3>(prog_id, table, rpw, c, inline_planes, n_inline, s)
                                    : launch_split2d<4>(prog_id, table, rpw, c, inline_planes, n_inline, s);
-        else if (u8out) e = r.cn == 3 ? launch_other<3, uint8_t, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)
-                                      : launch_other<4, uint8_t, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s);
+        else if (u8out) e = r.cn == 3 ? launch_other_np<3, uint8_t, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s)
+                                      : launch_other_np<4, uint8_t, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s);
         else if (f16) e = r.cn == 3 ? launch_other<3, _Float16, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)
                                     : launch_other<4, _Float16, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s);
-        else e = r.cn == 3 ? launch_other<3, float, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)
-                           : launch_other<4, float, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s);
+        else e = r.cn == 3 ? launch_other_np<3, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s)
+                           : launch_other_np<4, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s);
     } else if (r.cn == 3) {
         e = k1_launch_planar_c3(src, f16, prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
     } else {

@@ -53,8 +53,7 @@ template <int NPL> using K1Args = std::conditional_t<NPL == 0, KernArgsMany, Ker
 // u8c3 packed pixels of a FULL 64-column tile: the wave's 192 output bytes leave as 48 dword stores instead of 192 byte
 // stores.  Lane j < 48 assembles bytes 4j..4j+3 from the pixels of lanes p0 = 4j/3 and p0+1 (wave shuffles).
 __device__ __forceinline__ void store_u8c3_tile(uint8_t* tile_row, int lane, const float* v) {
-    const uint32_t mine = (uint32_t)sat_round(v[0], 0.f, 255.f) | ((uint32_t)sat_round(v[1], 0.f, 255.f) << 8) |
-                          ((uint32_t)sat_round(v[2], 0.f, 255.f) << 16);
+    const uint32_t mine = sat_u8_insert(v[2], 2, sat_u8_insert(v[1], 1, sat_u8_insert(v[0], 0, 0)));
     const int p0 = (4 * lane) / 3, o = 4 * lane - 3 * p0;
     const uint32_t a = (uint32_t)__shfl((int)mine, min(p0, 63)), b = (uint32_t)__shfl((int)mine, min(p0 + 1, 63));
     const uint64_t s = (uint64_t)a | ((uint64_t)b << 24);
@@ -285,7 +284,11 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(const K1Args<NP
             } else {
                 float v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = take ? p.v[k] : bgp.v[k];
+                for (int k = 0; k < 4; ++k) v[k] = p.v[k];
+                if (!whole) { // wave-uniform, as in the planar mode
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = take ? p.v[k] : bgp.v[k];
+                }
                 k1_store_other<WM, OT, CN, (RPW >= 4)>(g, c, z, y, x, v, cn);
             }
         }
@@ -368,14 +371,21 @@ static hipError_t launch_other(bool table, int rpw, const ChainArgs& c, const Pl
     if (table) return launch_t<CN, 0, 1, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
     return launch_t<CN, CVGS_KERNARG_PLANES, 1, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
 }
+// the same with the program picked at run time: empty (nothing between the resize and the folded cast / the write) or interpreted
+template <int CN, typename OT, int WM, int SRC = SRC_U8>
+static hipError_t launch_other_np(bool none, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+    if (none) return launch_other<CN, OT, WM, ProgNone, SRC>(table, rpw, c, ip, ni, s);
+    return launch_other<CN, OT, WM, InterpProg, SRC>(table, rpw, c, ip, ni, s);
+}
 // 16-bit and CV_32F sources into packed pixels of the SOURCE's own type (the reference's single-image resize tests sweep
 // CV_16U / CV_16S C1, C3, C4 and CV_32FC1: resize -> convertTo<CV_32F, I> -> write<I>, tests/resize/test_resize_write.cu:55-56,
 // 110-123), and 16-bit sources into separate fp32 planes (tests/resize/test_resize_x_split.cu)
 template <int CN>
 static hipError_t launch_same_type_packed(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
-    if (src == SRC_U16) return launch_other<CN, uint16_t, WM_PACKED, InterpProg, SRC_U16>(table, rpw, c, ip, ni, s);
-    if (src == SRC_S16) return launch_other<CN, int16_t, WM_PACKED, InterpProg, SRC_S16>(table, rpw, c, ip, ni, s);
-    return launch_other<CN, float, WM_PACKED, InterpProg, SRC_F32>(table, rpw, c, ip, ni, s);
+    const bool none = c.prog.n == 0;
+    if (src == SRC_U16) return launch_other_np<CN, uint16_t, WM_PACKED, SRC_U16>(none, table, rpw, c, ip, ni, s);
+    if (src == SRC_S16) return launch_other_np<CN, int16_t, WM_PACKED, SRC_S16>(none, table, rpw, c, ip, ni, s);
+    return launch_other_np<CN, float, WM_PACKED, SRC_F32>(none, table, rpw, c, ip, ni, s);
 }
 template <int CN>
 static hipError_t launch_split2d_16(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
@@ -443,8 +453,8 @@ static hipError_t launch_few(int src, bool planar, bool u8out, int prog_id, bool
                : src == SRC_S16 ? launch_few_planar<CN, SRC_S16>(prog_id, table, rpw, c, ip, ni, s)
                                 : launch_few_planar<CN, SRC_F32>(prog_id, table, rpw, c, ip, ni, s);
     }
-    if (u8out) return launch_other<CN, uint8_t, WM_PACKED>(table, rpw, c, ip, ni, s);
-    return launch_other<CN, float, WM_PACKED>(table, rpw, c, ip, ni, s);
+    if (u8out) return launch_other_np<CN, uint8_t, WM_PACKED>(c.prog.n == 0, table, rpw, c, ip, ni, s);
+    return launch_other_np<CN, float, WM_PACKED>(c.prog.n == 0, table, rpw, c, ip, ni, s);
 }
 
 

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_pointwise4_u8u8(const KernArgs<NPL> a, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = 4 * d + i; // output byte e = pixel e / OCN, channel e % OCN
-                q[d] |= ((uint32_t)px[e / OCN].v[e % OCN] & 0xffu) << (8 * i);
+                q[d] = sat_u8_insert(px[e / OCN].v[e % OCN], (uint32_t)i, q[d]); // CV_8U-typed value: convert + insert in one instruction
             }
         }
         typedef uint32_t vq __attribute__((ext_vector_type(OCN == 3 ? 3 : (OCN == 4 ? 4 : (OCN == 2 ? 2 : 1)))));

@@ -70,7 +70,7 @@ inline void fast_div_setup(ProgArgs& p, int div_at, int mul_at, int cn, const fl
 template <int... OPS>
 struct K1Prog {
     static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
-        int k = 0;
+        [[maybe_unused]] int k = 0;
         ((step<OPS>(prog, k, p, depth, cn), ++k), ...);
     }
     template <int OP>
@@ -101,6 +101,10 @@ struct K1Prog {
 };
 using ProgSwapMulSubDiv = K1Prog<kOpSwapRB, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 using ProgMulSubDiv = K1Prog<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
+// the empty program: resize -> [trailing cast folded into the store] -> write, the reference's single-image resize chains
+// (tests/resize/test_resize_write.cu: resize -> convertTo<CV_32F, O> -> write).  Channel count and depth stay compile-time
+// constants, so the whole-frame kernels carry no interpreter at all.
+using ProgNone = K1Prog<>;
 
 typedef uint64_t u64_unaligned __attribute__((aligned(1)));
 typedef const __attribute__((address_space(1))) u64_unaligned* gptr_u64;
@@ -270,10 +274,10 @@ __device__ __forceinline__ void st_nt(_Float16* p, float v) { __builtin_nontempo
 __device__ __forceinline__ void st_plain(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_plain(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }
 // u8 targets: the chain's trailing SaturateCast (round to nearest even, clamp, NaN -> 0) is this conversion
-__device__ __forceinline__ void st_plain(uint8_t* p, float v) { __builtin_nontemporal_store((uint8_t)sat_round(v, 0.f, 255.f), p); }
+__device__ __forceinline__ void st_plain(uint8_t* p, float v) { __builtin_nontemporal_store((uint8_t)sat_u8_insert(v, 0, 0), p); }
 // 16-bit integer targets (the reference's resize -> convertTo<32F, 16U / 16S> -> write chains, tests/resize/test_resize_write.cu)
-__device__ __forceinline__ void st_plain(uint16_t* p, float v) { __builtin_nontemporal_store((uint16_t)sat_round(v, 0.f, 65535.f), p); }
-__device__ __forceinline__ void st_plain(int16_t* p, float v) { __builtin_nontemporal_store((int16_t)sat_round(v, -32768.f, 32767.f), p); }
+__device__ __forceinline__ void st_plain(uint16_t* p, float v) { __builtin_nontemporal_store((uint16_t)sat_u16_bits(v), p); }
+__device__ __forceinline__ void st_plain(int16_t* p, float v) { __builtin_nontemporal_store((int16_t)(uint16_t)sat_s16_bits(v), p); }
 
 // one packed pixel: a single vector store when the channel count is the compile-time one (the usual case), element
 // stores when the chain changed it (e.g. *2GRAY after the resize)
@@ -303,11 +307,11 @@ __device__ __forceinline__ void store_packed_px(OT* px, const float* v, int cn) 
             return;
         } else if constexpr (sizeof(OT) == 2) { // 16-bit integers: pairs of elements as one 32-bit store
             typedef uint32_t u32a2 __attribute__((aligned(2)));
-            constexpr float lo = std::is_same_v<OT, uint16_t> ? 0.f : -32768.f, hi = std::is_same_v<OT, uint16_t> ? 65535.f : 32767.f;
-            const uint32_t e0 = (uint32_t)(uint16_t)(OT)sat_round(v[0], lo, hi), e1 = (uint32_t)(uint16_t)(OT)sat_round(v[1], lo, hi);
+            auto bits = [](float x) { return std::is_same_v<OT, uint16_t> ? sat_u16_bits(x) : sat_s16_bits(x); };
+            const uint32_t e0 = bits(v[0]), e1 = bits(v[1]);
             __builtin_nontemporal_store(e0 | (e1 << 16), (u32a2*)px);
             if constexpr (CN == 4) {
-                const uint32_t e2 = (uint32_t)(uint16_t)(OT)sat_round(v[2], lo, hi), e3 = (uint32_t)(uint16_t)(OT)sat_round(v[3], lo, hi);
+                const uint32_t e2 = bits(v[2]), e3 = bits(v[3]);
                 __builtin_nontemporal_store(e2 | (e3 << 16), (u32a2*)(px + 2));
             } else {
                 st_plain(px + 2, v[2]);
@@ -317,7 +321,7 @@ __device__ __forceinline__ void store_packed_px(OT* px, const float* v, int cn) 
             typedef uint32_t u32a1 __attribute__((aligned(1)));
             uint32_t q = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q |= (uint32_t)sat_round(v[k], 0.f, 255.f) << (8 * k);
+            for (int k = 0; k < 4; ++k) q = sat_u8_insert(v[k], (uint32_t)k, q);
             __builtin_nontemporal_store(q, (u32a1*)px);
             return;
         }

@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void k_u8_permute16(const KernArgs<NPL> a, con
 // *2GRAY: 16 pixels -> 16 bytes; the arithmetic is apply_op's (0.299 R + 0.587 G + 0.114 B in that order, round to nearest
 // even), the channel order comes with `aux`.  Input through the LDS like the permutations; the 16 output bytes of a lane
 // are already lane-contiguous.
-template <int CN, int NPL, int ES = 1>
+// ORD: where R, G, B sit in the source pixel -- 1: channels 0,1,2 (RGB[A]2GRAY), 2: channels 2,1,0 (BGR[A]2GRAY), both resolved
+// at compile time; 0: any other order, selected per pixel from `aux` (apply_op).  The luminance of integer pixels is rounded
+// to nearest even; for the two compile-time orders the store-side conversion (sat_u8_insert / sat_u16_bits: RNE + clamp,
+// k_common.hpp) IS that rounding, so a pixel costs 3 conversions, 3 multiplies, 2 adds and 1 convert-and-insert.
+template <int CN, int NPL, int ES = 1, int ORD = 0>
 __global__ __launch_bounds__(256) void k_u8_gray16(const KernArgs<NPL> a, const PwGeom g) {
     constexpr int CB = CN * ES; // bytes per source pixel
     constexpr int SD = ES == 1 ? CVGS_DEPTH_8U : CVGS_DEPTH_16U;
@@ -138,11 +142,15 @@ __global__ __launch_bounds__(256) void k_u8_gray16(const KernArgs<NPL> a, const 
         Px p;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) p.v[ch] = ch < CN ? elem_value<SD>(in, i * CN + ch) : 0.f;
-        int depth = SD, cn = CN;
-        apply_op(CVGS_OP_GRAY, aux, c.prog.operand[0], p, depth, cn);
-        // the luminance is already an integer in [0, 255] / [0, 65535]: the saturating conversions only convert and insert
+        if constexpr (ORD == 0) {
+            int depth = SD, cn = CN;
+            apply_op(CVGS_OP_GRAY, aux, c.prog.operand[0], p, depth, cn);
+        } else {
+            const float r = ORD == 1 ? p.v[0] : p.v[2], b = ORD == 1 ? p.v[2] : p.v[0];
+            p.v[0] = (r * 0.299f + p.v[1] * 0.587f) + b * 0.114f; // apply_op's expression, rounded by the conversion below
+        }
         if constexpr (ES == 1) q[i >> 2] = sat_u8_insert(p.v[0], (uint32_t)(i & 3), q[i >> 2]);
-        else q[i >> 1] |= ((uint32_t)p.v[0] & 0xffffu) << (16 * (i & 1));
+        else q[i >> 1] |= (ORD == 0 ? ((uint32_t)p.v[0] & 0xffffu) : sat_u16_bits(p.v[0])) << (16 * (i & 1));
     }
     __attribute__((address_space(1))) uint8_t* orow =
         (__attribute__((address_space(1))) uint8_t*)g.out + (size_t)z * (size_t)g.img_stride + (size_t)y * (size_t)g.row_pitch;
@@ -177,19 +185,26 @@ static hipError_t launch_perm(const ChainArgs& c, const PlaneParams* ip, int ni,
     }
     return hipGetLastError();
 }
-template <int CN, int ES = 1>
-static hipError_t launch_gray(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+template <int CN, int ES, int ORD>
+static hipError_t launch_gray_ord(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
     const dim3 grid((g.w / 16 + 63) / 64, (g.h + 3) / 4, c.read.batch);
     if (c.read.table) {
         KernArgs<0> a;
         fill_args(a, c, ip, ni);
-        hipLaunchKernelGGL((k_u8_gray16<CN, 0, ES>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_u8_gray16<CN, 0, ES, ORD>), grid, dim3(256), 0, s, a, g);
     } else {
         KernArgs<CVGS_KERNARG_PLANES> a;
         fill_args(a, c, ip, ni);
-        hipLaunchKernelGGL((k_u8_gray16<CN, CVGS_KERNARG_PLANES, ES>), grid, dim3(256), 0, s, a, g);
+        hipLaunchKernelGGL((k_u8_gray16<CN, CVGS_KERNARG_PLANES, ES, ORD>), grid, dim3(256), 0, s, a, g);
     }
     return hipGetLastError();
+}
+template <int CN, int ES = 1>
+static hipError_t launch_gray(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, hipStream_t s) {
+    const int order = c.prog.aux[0] & 63; // (R, G, B) channel indices, 2 bits each
+    if (order == (0 | (1 << 2) | (2 << 4))) return launch_gray_ord<CN, ES, 1>(c, ip, ni, g, s);
+    if (order == (2 | (1 << 2) | (0 << 4))) return launch_gray_ord<CN, ES, 2>(c, ip, ni, g, s);
+    return launch_gray_ord<CN, ES, 0>(c, ip, ni, g, s);
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.  `g` is the packed-output geometry of pointwise4_u8_u8.

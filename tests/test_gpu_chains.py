@@ -541,6 +541,32 @@ def test_u16_colour_conversions_fast_and_interpreted_agree_with_oracle(oracle, n
     H.assert_bit_exact(out_t.cpu().numpy().view(np.uint16), ref, "%s %s interpreted" % (name, shape))
 
 
+@pytest.mark.parametrize("name,code", [("RGB2GRAY", cvgs.COLOR_RGB2GRAY), ("BGR2GRAY", cvgs.COLOR_BGR2GRAY)])
+def test_u8_gray_every_rgb_triple(oracle, name, code):
+    """EVERY 8-bit (c0, c1, c2) triple through the compile-time-order gray kernel (whose store-side conversion does the
+    rounding: k_cvtcolor_u8.hip) against the oracle's 0.299 R + 0.587 G + 0.114 B, rounded to nearest even: 2^24 pixels as one
+    4096 x 4096 image."""
+    import torch
+    dev = torch.device("cuda:0")
+    it, ot = cvgs.make_type(cvgs.CV_8U, 3), cvgs.make_type(cvgs.CV_8U, 1)
+    idx = np.arange(1 << 24, dtype=np.uint32)
+    src = np.stack([(idx & 255), (idx >> 8) & 255, (idx >> 16) & 255], axis=-1).astype(np.uint8).reshape(4096, 4096, 3)
+    t = torch.from_numpy(src).to(dev)
+    out_t = torch.zeros((4096, 4096, 1), dtype=torch.uint8, device=dev)
+    ref = np.zeros((4096, 4096, 1), np.uint8)
+
+    def chain(mat, out):
+        return [cvgs.ReadIOp(capi.READ_PIXEL, it, [mat], 1), cvgs.cvtColor(code, it, ot), cvgs.write(ot, out)]
+
+    g_ops = chain(cvgs.GpuMat.from_tensor(t, it), cvgs.GpuMat.from_tensor(out_t, ot))
+    assert cvgs.kernel_name(*g_ops) == "pointwise16_u8_gray"
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops)
+    torch.cuda.synchronize()
+    oracle.execute(cvgs.lower(chain(cvgs.GpuMat.from_array(src, it), cvgs.GpuMat.from_array(ref, ot))))
+    assert ref.max() == 255 and ref.min() == 0
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "%s over all 2^24 triples" % name)
+
+
 def test_u8_colour_conversion_of_an_unaligned_crop_stays_interpreted(oracle):
     import torch
     dev = torch.device("cuda:0")

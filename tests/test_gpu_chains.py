@@ -228,7 +228,9 @@ def test_batch_pixel_read_default_value():
     assert (gpu[0][4:] == np.array([4.5, 4.0, 3.5], np.float32)).all()
 
 
-@pytest.mark.parametrize("w", [77, 701])  # 701: two full 256-pixel groups (LDS-transposed packed stores) + a ragged tail
+# 701: two full 256-pixel groups (LDS-transposed packed stores) + a ragged tail; 76 / 704 / 2052: widths the C1 / C2 -> C4
+# widening of k_pointwise4 divides (2052 / 4 = 513: two full groups of the widened image + a tail)
+@pytest.mark.parametrize("w", [77, 701, 76, 704, 2052])
 @pytest.mark.parametrize("cn", [1, 2, 3, 4])
 @pytest.mark.parametrize("write_kind", ["write2d", "write3d", "split", "splitT"])
 def test_thread_fused_pointwise_kernel(cn, write_kind, w):
@@ -317,11 +319,12 @@ def test_stream_copy(nbytes, off):
 @pytest.mark.parametrize("depth,cn", [("8S", 1), ("8S", 3), ("16U", 1), ("16U", 3), ("16U", 4), ("16S", 2), ("16S", 3), ("32S", 1),
                                       ("32S", 3), ("32F", 1), ("32F", 2), ("32F", 3), ("32F", 4)])
 @pytest.mark.parametrize("out", ["packed", "planar"])
-def test_thread_fused_pointwise_other_depths(depth, cn, out):
+@pytest.mark.parametrize("w", [523, 1036])  # 1036: a width the C1 / C2 -> C4 widening divides (259 / 518 wide as C4)
+def test_thread_fused_pointwise_other_depths(depth, cn, out, w):
     """The reference sweeps its pointwise chains over every source depth (tests/batchread/test_batchread_x_write3D.cu:202-227,
     tests/read/test_read_x_write.cu:121-144): 4 pixels per thread for 8S/16U/16S/32S/32F sources too -- wide rows (full
     256-pixel groups + a ragged tail), pitched views, default-value planes; vs the oracle and vs the interpreted kernel."""
-    w, h, n = 523, 11, 3
+    h, n = 11, 3
     srcs = [_random_src((h + 2, w + 7, cn), depth, 1200 + 10 * cn + i) for i in range(n)]
     st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
 

@@ -305,37 +305,11 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     return true;
 }
 
-// 1- and 2-channel images as 4-channel images of a quarter / half the width.  The programs k_pointwise4 accepts are
-// per-channel arithmetic, so F = 4 / cn x-adjacent pixels of a C1 / C2 row ARE one C4 pixel whose operands repeat with
-// period cn, and a packed C1 / C2 output row (or a dense one-channel plane) is byte for byte the packed C4 row of width W / F:
-// same loads, same operations on the same values, same stores -- but a thread moves 16 source elements instead of 4 or 8
-// (the reference sweeps its pointwise tests over C1 .. C4, tests/read/test_read_x_write.cu; a 4K 8UC1 -> 32FC1 chain 12.8 us ->
-// see profiles/).  Not taken: channel permutations (REORDER), widths that F does not divide, separate pitched planes,
-// two-channel planar tensors, resident device tables.
-static void widen_few_channels(ChainArgs& c, PwGeom& g) {
-    const int cn = c.read.cn;
-    if (cn != 1 && cn != 2) return;
-    static const char* off = getenv("CVGS_PW_NO_WIDEN"); // A/B hook for benchmarks
-    if (off) return;
-    const int F = 4 / cn;
-    if (c.read.table || (g.w % F) != 0 || g.packed == 2 || (g.packed == 0 && cn != 1)) return;
-    for (int k = 0; k < c.prog.n; ++k)
-        if (c.prog.opcode[k] == CVGS_OP_REORDER) return;
-    if (g.packed == 0) { // [N][1][H][W] dense planes: the packed layout with one element per pixel
-        const int esz = c.write.depth == CVGS_DEPTH_16F ? 2 : 4;
-        g.row_pitch = g.row_pitch2 = g.w * esz;
-        g.img_stride *= esz; // elements -> bytes
-        g.img_stride2 *= esz;
-        g.ch_stride = g.ch_stride2 = 0;
-        g.packed = 1;
-    }
-    for (int k = 0; k < c.prog.n; ++k)
-        for (int ch = cn; ch < 4; ++ch) c.prog.operand[k][ch] = c.prog.operand[k][ch % cn];
-    for (int ch = cn; ch < 4; ++ch) c.read.bg[ch] = c.read.bg[ch % cn];
-    c.read.cn = c.read.out_cn = c.write.cn = g.cn = 4;
-    g.w /= F;
-}
-
+// Measured and NOT adopted (round 2): running C1 / C2 chains as C4 images of a quarter / half the width (4 / 2 x-adjacent
+// pixels are one C4 pixel with periodic operands; byte-identical output, 1601 GPU tests green) so that a thread moves 16 source
+// elements instead of 4: a 4K 8UC1 -> 32FC1 chain went from 12.8 to 15.0 us, 32FC1 15.2 -> 16.4 us, 50 crops of 16SC1 5.1 -> 7.7 us.
+// A quarter of the waves (8,640: ONE resident round) put every wave in the same phase at the same time -- the load burst and the
+// store burst no longer overlap -- whereas 32,400 small waves in four rounds pipeline them.  More waves, not fatter waves.
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
 int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
                      bool dry_run, LaunchInfo* info) {
@@ -352,7 +326,6 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
     int prog_id = 0;
     bool f16 = false;
     if (!pointwise4_plan(c_in, n_inline, chain_flags, c, g, prog_id, f16)) return 0;
-    widen_few_channels(c, g);
     g.narrow = g.w <= 64 ? 2 : (g.w <= 128 ? 1 : 0); // batches of small crops (the reference's 60x120 crops): several rows per wave
     if (info) {
         static const char* names[2][3] = {{"pointwise4_u8_cast_mul_sub_div", "pointwise4_u8_cast", "pointwise4_u8_interp"},

@@ -102,6 +102,9 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     // crops of ONE frame and loses 3-5 % when the crops come from many frames: 16 x 50 crops 38.3 vs 39.2 us); the packed /
     // separate-plane modes keep round 1's whole-frame tuning (4 rows from 64 Ki wave-rows)
     int rpw = wave_rows <= 16384 ? 1 : ((planar && wave_rows > 65536 && r.depth == CVGS_DEPTH_8U) || wave_rows <= 65536 ? 2 : 4);
+    // separate pitched planes (the K2 chain): 4 rows per wave already from 16 Ki wave-rows (session-5 sweep: 4K -> 1080p into 3 planes
+    // 14.9 -> 13.3 us, 6K -> 720p 8.9 -> 8.5 us; the packed modes tie or lose there)
+    if (split2d && wave_rows > 16384) rpw = 4;
     static const char* rpw_env = getenv("CVGS_K1_RPW"); // tuning hook (benchmarks only): force 1 / 2 / 4 rows per wave
     if (rpw_env) rpw = atoi(rpw_env) >= 4 ? 4 : (atoi(rpw_env) == 2 ? 2 : 1);
 

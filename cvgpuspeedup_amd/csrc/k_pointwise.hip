@@ -241,19 +241,29 @@ static int launch_pointwise_u16u16(const ChainArgs& c, const PlaneParams* ip, in
 
 // Eligibility + geometry of the thread-fused path, shared with the single-launch CircularTensor push (k_circular.hip).
 // On success `c` is the chain to run (an fp16 target's trailing CAST is folded into the store), `g` the geometry.
-bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16) {
+bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16, bool* u8out) {
     const ReadArgs& r = c_in.read;
     const WriteArgs& w = c_in.write;
     if (chain_flags & CVGS_CHAIN_NO_THREAD_FUSION) return false;
-    if (r.kind != CVGS_READ_PIXEL || r.batch > 65535) return false;
-    const bool u8src = r.depth == CVGS_DEPTH_8U;
-    if (!u8src && r.depth != CVGS_DEPTH_8S && r.depth != CVGS_DEPTH_16U && r.depth != CVGS_DEPTH_16S && r.depth != CVGS_DEPTH_32S &&
-        r.depth != CVGS_DEPTH_32F)
+    // 4:2:0 surfaces with interleaved chroma read WITHOUT a resize (the decode-side cvtColor: cvGS::cvtColorNV12 -> ... -> tensor):
+    // the value arrives as CV_32F R, G, B[, A], so the chain is a CV_32F chain with out_cn channels
+    const bool yuv = r.kind == CVGS_READ_NV12 &&
+                     (r.yuv_layout == CVGS_YUV_NV12 || r.yuv_layout == CVGS_YUV_NV21 || r.yuv_layout == CVGS_YUV_P010);
+    if ((r.kind != CVGS_READ_PIXEL && !yuv) || r.batch > 65535) return false;
+    const int sdepth = yuv ? CVGS_DEPTH_32F : r.depth, scn = yuv ? r.out_cn : r.cn;
+    const bool u8src = sdepth == CVGS_DEPTH_8U;
+    if (!u8src && sdepth != CVGS_DEPTH_8S && sdepth != CVGS_DEPTH_16U && sdepth != CVGS_DEPTH_16S && sdepth != CVGS_DEPTH_32S &&
+        sdepth != CVGS_DEPTH_32F)
         return false;
     f16 = w.depth == CVGS_DEPTH_16F;
-    if (!f16 && w.depth != CVGS_DEPTH_32F) return false;
+    // packed u8 pixels behind a 4:2:0 read (NV12 -> BGR image): the chain ends with CAST(CV_8U), which the store performs
+    const bool u8o = yuv && u8out && w.depth == CVGS_DEPTH_8U && (w.kind == CVGS_WRITE_PIXEL_2D || w.kind == CVGS_WRITE_PIXEL_3D) &&
+                     c_in.prog.n >= 1 && c_in.prog.opcode[c_in.prog.n - 1] == CVGS_OP_CAST && c_in.prog.aux[c_in.prog.n - 1] == CVGS_DEPTH_8U;
+    if (u8out) *u8out = u8o;
+    if (!f16 && !u8o && w.depth != CVGS_DEPTH_32F) return false;
     if (f16 && !u8src) return false;
     c = c_in;
+    if (u8o) c.prog.n -= 1;
     if (f16) { // fp16 targets: the chain ends with CAST(CV_16F); that conversion happens in the store
         if (c_in.prog.n < 2 || c_in.prog.opcode[c_in.prog.n - 1] != CVGS_OP_CAST) return false;
         c.prog.n -= 1;
@@ -270,20 +280,25 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     while (first < p.n && p.opcode[first] == CVGS_OP_REORDER) ++first;
     const bool has_cast = first < p.n && p.opcode[first] == CVGS_OP_CAST && p.aux[first] == CVGS_DEPTH_32F;
     const bool starts_with_cast = has_cast && first == 0;
-    if (r.depth != CVGS_DEPTH_32F && !has_cast) return false;
-    for (int k = has_cast ? first + 1 : first; k < p.n; ++k)
+    if (sdepth != CVGS_DEPTH_32F && !has_cast) return false;
+    for (int k = has_cast ? first + 1 : first; k < p.n; ++k) {
+        // a 4:2:0 read's value is CV_32F throughout: convertTo<CV_32FCn, O>(alpha) spells cast(CV_32F) -> mul -> cast(O), and
+        // that first cast is the identity (ArithProg executes nothing for it)
+        if (yuv && p.opcode[k] == CVGS_OP_CAST && p.aux[k] == CVGS_DEPTH_32F) continue;
         if (p.opcode[k] != CVGS_OP_MUL && p.opcode[k] != CVGS_OP_ADD && p.opcode[k] != CVGS_OP_SUB && p.opcode[k] != CVGS_OP_DIV &&
             p.opcode[k] != CVGS_OP_REORDER)
             return false;
-    if (w.cn != r.cn) return false;
+    }
+    if (w.cn != scn) return false;
     if (!r.table && n_inline > CVGS_KERNARG_PLANES) return false;
+    if (yuv && r.table) return false; // resident tables: per-plane preconditions cannot be checked on the host
 
     prog_id = 2;
     if (!u8src) prog_id = 3; // interpreted program, per-depth kernel
     else if (starts_with_cast && p.n == 4 && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV) prog_id = 0;
     else if (starts_with_cast && p.n == 1) prog_id = 1;
 
-    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn;
+    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = scn;
     g.packed = packed ? 1 : (split2d ? 2 : 0);
     g.out = w.data; g.out2 = w.data2; g.narrow = 0;
     if (split2d) {
@@ -291,7 +306,7 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
         g.row_pitch = g.row_pitch2 = 0;
         g.img_stride = g.ch_stride = g.img_stride2 = g.ch_stride2 = 0;
     } else if (packed) {
-        const int px_bytes = (f16 ? 2 : 4) * w.cn;
+        const int px_bytes = (u8o ? 1 : (f16 ? 2 : 4)) * w.cn;
         g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * px_bytes;
         g.row_pitch2 = w.width * px_bytes;
         g.img_stride = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : (int64_t)w.img_stride * px_bytes; // bytes
@@ -325,8 +340,31 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
     PwGeom g;
     int prog_id = 0;
     bool f16 = false;
-    if (!pointwise4_plan(c_in, n_inline, chain_flags, c, g, prog_id, f16)) return 0;
+    bool u8o = false;
+    if (!pointwise4_plan(c_in, n_inline, chain_flags, c, g, prog_id, f16, &u8o)) return 0;
     g.narrow = g.w <= 64 ? 2 : (g.w <= 128 ? 1 : 0); // batches of small crops (the reference's 60x120 crops): several rows per wave
+    const bool yuv = c.read.kind == CVGS_READ_NV12;
+    if (yuv) { // the thread's 4 pixels share 2 chroma pairs: even widths (validated for every 4:2:0 plane) and x0 % 4 == 0
+        if (info) info->kernel = c.read.yuv_layout == CVGS_YUV_P010 ? (u8o ? "pointwise4_p010_u8" : "pointwise4_p010") : (u8o ? "pointwise4_nv12_u8" : "pointwise4_nv12");
+        if (dry_run) return 1;
+        const ProgArgs& p = c.prog;
+        const bool norm = p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV;
+        const bool ten = c.read.yuv_layout == CVGS_YUV_P010;
+        hipStream_t s = (hipStream_t)stream;
+        hipError_t e;
+        auto go = [&](auto cn_tag) {
+            constexpr int CN = decltype(cn_tag)::value;
+            using Arith = ArithProg<CN, CVGS_DEPTH_32F>;
+            if (u8o) return ten ? launch_pw<CN, Arith, uint8_t, SD_P010>(c, inline_planes, n_inline, g, s)
+                                : launch_pw<CN, Arith, uint8_t, SD_NV12>(c, inline_planes, n_inline, g, s);
+            if (ten) return norm ? launch_pw<CN, ProgMulSubDivPw, float, SD_P010>(c, inline_planes, n_inline, g, s)
+                                 : launch_pw<CN, Arith, float, SD_P010>(c, inline_planes, n_inline, g, s);
+            return norm ? launch_pw<CN, ProgMulSubDivPw, float, SD_NV12>(c, inline_planes, n_inline, g, s)
+                        : launch_pw<CN, Arith, float, SD_NV12>(c, inline_planes, n_inline, g, s);
+        };
+        e = g.cn == 3 ? go(std::integral_constant<int, 3>{}) : go(std::integral_constant<int, 4>{});
+        return e == hipSuccess ? 1 : -(int)e - 1000;
+    }
     if (info) {
         static const char* names[2][3] = {{"pointwise4_u8_cast_mul_sub_div", "pointwise4_u8_cast", "pointwise4_u8_interp"},
                                           {"pointwise4_u8_cast_mul_sub_div_f16", "pointwise4_u8_cast_f16", "pointwise4_u8_interp_f16"}};

@@ -2,6 +2,8 @@
 // (k_pointwise.hip) and by the single-launch CircularTensor push (k_circular.hip).  See k_pointwise.hip.
 #pragma once
 
+#include <type_traits>
+
 #include "k_common.hpp"
 
 namespace cvgs {
@@ -26,6 +28,17 @@ __device__ __forceinline__ void store4(_Float16* p, float a, float b, float c, f
 }
 __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store1(_Float16* p, float v) { *p = (_Float16)v; }
+// packed u8 pixels (the 4:2:0 read mode's `-> convertTo<CV_32FCn, CV_8UCn> -> write` chains): the chain's trailing
+// SaturateCast is the store's conversion (k_common.hpp: sat_u8_insert)
+__device__ __forceinline__ void store4(uint8_t* p, float a, float b, float c, float d) {
+    typedef uint32_t u32a1 __attribute__((aligned(1)));
+    __builtin_nontemporal_store(sat_u8_insert(d, 3, sat_u8_insert(c, 2, sat_u8_insert(b, 1, sat_u8_insert(a, 0, 0)))), (u32a1*)p);
+}
+__device__ __forceinline__ void store1(uint8_t* p, float v) { *p = (uint8_t)sat_u8_insert(v, 0, 0); }
+template <typename OT> __device__ __forceinline__ OT cvt_out(float v) {
+    if constexpr (std::is_same_v<OT, uint8_t>) return (uint8_t)sat_u8_insert(v, 0, 0);
+    else return (OT)v;
+}
 
 using ProgCastMulSubDiv = StaticProg<CVGS_OP_CAST, CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 using ProgCast = StaticProg<CVGS_OP_CAST>;
@@ -103,7 +116,15 @@ __device__ __forceinline__ float elem_value(const uint32_t* raw, int e) {
     else if constexpr (SD == CVGS_DEPTH_16S) return (float)(int16_t)((raw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
     else return __uint_as_float(raw[e]);
 }
+// pseudo source depths of pw4_body: 4:2:0 decoder surfaces with interleaved chroma read WITHOUT a resize (CVGS_READ_NV12; NV12 /
+// NV21 8-bit samples, P010 16-bit samples) -- the pixel arrives as CV_32F R, G, B[, A] through k_common.hpp's yuv_to_rgb
+constexpr int SD_NV12 = 64, SD_P010 = 65;
+template <int SD> constexpr bool is_yuv_sd = SD == SD_NV12 || SD == SD_P010;
 template <int SD> constexpr int src_elem_bytes = (SD == CVGS_DEPTH_8U || SD == CVGS_DEPTH_8S) ? 1 : ((SD == CVGS_DEPTH_16U || SD == CVGS_DEPTH_16S) ? 2 : 4);
+
+template <int CN, typename OT>
+__device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, const Px (&px)[4], int cn, int bx, int x0, int y, int z, int npx,
+                                          int wave, int lane, int sh);
 
 // One thread's work: pixels x0..x0+3 of row y of plane z.  (bx, by) = the 256-pixel column group and the 4-row group.
 // SD = source depth (8U is the hot one; the reference sweeps its pointwise chains over 8S/16U/16S/32S/32F as well,
@@ -120,6 +141,60 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
     if (y >= H || x0 >= W) return;
     const int npx = min(4, W - x0);
 
+    if constexpr (is_yuv_sd<SD>) {
+        // ---- 4 pixels of a 4:2:0 surface: 4 luma samples + the 2 chroma pairs they share (x0 is a multiple of 4) ----
+        constexpr int SB = SD == SD_P010 ? 2 : 1; // bytes per sample
+        const YuvK yk = yuv_matrix(c.read.yuv_range, c.read.yuv_primaries, SD == SD_P010 ? CVGS_YUV_P010 : CVGS_YUV_NV12);
+        const bool vu = c.read.yuv_layout == CVGS_YUV_NV21; // wave-uniform: the pair is (V,U)
+        Px px[4];
+        int depth = CVGS_DEPTH_32F, cn = CN;
+        if (z < used) {
+            const gp_u8 yrow = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * SB;
+            const gp_u8 crow = (gp_u8)P.data + (size_t)P.uv_off + (size_t)(y >> 1) * (size_t)P.step + (size_t)x0 * SB;
+            uint32_t yw[SB], cw[SB];
+            if (npx == 4) {
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    yw[k] = *(gp_u32)(yrow + 4 * k);
+                    cw[k] = *(gp_u32)(crow + 4 * k);
+                }
+            } else { // ragged tail (planes are even-sized: 2 pixels = one chroma pair)
+#pragma unroll
+                for (int k = 0; k < SB; ++k) yw[k] = cw[k] = 0;
+#pragma unroll
+                for (int b = 0; b < 4 * SB; ++b)
+                    if (b < npx * SB) {
+                        yw[b >> 2] |= (uint32_t)yrow[b] << (8 * (b & 3));
+                        cw[b >> 2] |= (uint32_t)crow[b] << (8 * (b & 3));
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iu = 2 * (i >> 1); // the pair's first sample
+                float Y, A, B;
+                if constexpr (SD == SD_P010) {
+                    Y = (float)(((yw[i >> 1] >> (16 * (i & 1))) & 0xffffu) >> 6);
+                    A = (float)((cw[iu >> 1] & 0xffffu) >> 6);
+                    B = (float)(cw[iu >> 1] >> 22);
+                } else {
+                    Y = (float)((yw[0] >> (8 * i)) & 0xffu);
+                    A = (float)((cw[0] >> (8 * iu)) & 0xffu);
+                    B = (float)((cw[0] >> (8 * iu + 8)) & 0xffu);
+                }
+                yuv_to_rgb(Y, vu ? B : A, vu ? A : B, yk, px[i]);
+#pragma unroll
+                for (int ch = CN; ch < 4; ++ch) px[i].v[ch] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) px[i].v[ch] = ch < CN ? c.read.bg[ch] : 0.f;
+        }
+        Prog::run4(c.prog, px, depth, cn);
+        pw4_write<CN, OT>(c, g, px, cn, bx, x0, y, z, npx, wave, lane, sh);
+        return;
+    }
     // ---- read 4 pixels: 4*CN elements = NDW dwords, one wide load ----
     constexpr int EB = src_elem_bytes<SD>;
     constexpr int NDW = CN * EB;
@@ -153,8 +228,14 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
         }
     }
     Prog::run4(c.prog, px, depth, cn);
+    pw4_write<CN, OT>(c, g, px, cn, bx, x0, y, z, npx, wave, lane, sh);
+}
 
-    // ---- write ----
+// ---- the write stage of pw4_body: 4 pixels of row y, plane z ----
+template <int CN, typename OT>
+__device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, const Px (&px)[4], int cn, int bx, int x0, int y, int z, int npx,
+                                          int wave, int lane, int sh) {
+    const int W = g.w;
     if (g.packed == 2) {
         // cvGS::split(std::vector<GpuMat>) / SplitWrite<_2D>: cn pitched planes per batch element (the reference's
         // tests/read/test_read_x_split.cu chain): the planar stores below, each plane with its own base and pitch
@@ -191,12 +272,14 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch)
-                    if (ch < CN) mine[i * CN + ch] = (OT)px[i].v[ch];
+                    if (ch < CN) mine[i * CN + ch] = cvt_out<OT>(px[i].v[ch]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef u32x4 u32x4u __attribute__((aligned(2))); // fp16 rows may start on any even address
+            typedef u32x4 u32x4_a2 __attribute__((aligned(2))); // fp16 rows may start on any even address,
+            typedef u32x4 u32x4_a1 __attribute__((aligned(1))); // u8 rows anywhere
+            using u32x4u = std::conditional_t<(sizeof(OT) < 2), u32x4_a1, u32x4_a2>;
             const size_t row_off = (size_t)bx * EPW * sizeof(OT);
 #pragma unroll
             for (int k = 0; k < (CHUNKS + 63) / 64; ++k) {
@@ -254,6 +337,7 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
 }
 
 // host side (k_pointwise.hip): eligibility + geometry of the thread-fused path
-bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16);
+// (u8out: packed u8 pixels behind a 4:2:0 read, accepted only when the caller passes the flag)
+bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16, bool* u8out = nullptr);
 
 } // namespace cvgs

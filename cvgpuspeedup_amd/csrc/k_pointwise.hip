@@ -261,11 +261,11 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
                      c_in.prog.n >= 1 && c_in.prog.opcode[c_in.prog.n - 1] == CVGS_OP_CAST && c_in.prog.aux[c_in.prog.n - 1] == CVGS_DEPTH_8U;
     if (u8out) *u8out = u8o;
     if (!f16 && !u8o && w.depth != CVGS_DEPTH_32F) return false;
-    if (f16 && !u8src) return false;
+    if (f16 && !u8src && !yuv) return false;
     c = c_in;
     if (u8o) c.prog.n -= 1;
     if (f16) { // fp16 targets: the chain ends with CAST(CV_16F); that conversion happens in the store
-        if (c_in.prog.n < 2 || c_in.prog.opcode[c_in.prog.n - 1] != CVGS_OP_CAST) return false;
+        if (c_in.prog.n < (yuv ? 1 : 2) || c_in.prog.opcode[c_in.prog.n - 1] != CVGS_OP_CAST) return false;
         c.prog.n -= 1;
     }
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
@@ -345,7 +345,10 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
     g.narrow = g.w <= 64 ? 2 : (g.w <= 128 ? 1 : 0); // batches of small crops (the reference's 60x120 crops): several rows per wave
     const bool yuv = c.read.kind == CVGS_READ_NV12;
     if (yuv) { // the thread's 4 pixels share 2 chroma pairs: even widths (validated for every 4:2:0 plane) and x0 % 4 == 0
-        if (info) info->kernel = c.read.yuv_layout == CVGS_YUV_P010 ? (u8o ? "pointwise4_p010_u8" : "pointwise4_p010") : (u8o ? "pointwise4_nv12_u8" : "pointwise4_nv12");
+        if (info) {
+            static const char* names[2][3] = {{"pointwise4_nv12", "pointwise4_nv12_u8", "pointwise4_nv12_f16"}, {"pointwise4_p010", "pointwise4_p010_u8", "pointwise4_p010_f16"}};
+            info->kernel = names[c.read.yuv_layout == CVGS_YUV_P010][u8o ? 1 : (f16 ? 2 : 0)];
+        }
         if (dry_run) return 1;
         const ProgArgs& p = c.prog;
         const bool norm = p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV;
@@ -357,6 +360,8 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
             using Arith = ArithProg<CN, CVGS_DEPTH_32F>;
             if (u8o) return ten ? launch_pw<CN, Arith, uint8_t, SD_P010>(c, inline_planes, n_inline, g, s)
                                 : launch_pw<CN, Arith, uint8_t, SD_NV12>(c, inline_planes, n_inline, g, s);
+            if (f16) return ten ? launch_pw<CN, Arith, _Float16, SD_P010>(c, inline_planes, n_inline, g, s)
+                                : launch_pw<CN, Arith, _Float16, SD_NV12>(c, inline_planes, n_inline, g, s);
             if (ten) return norm ? launch_pw<CN, ProgMulSubDivPw, float, SD_P010>(c, inline_planes, n_inline, g, s)
                                  : launch_pw<CN, Arith, float, SD_P010>(c, inline_planes, n_inline, g, s);
             return norm ? launch_pw<CN, ProgMulSubDivPw, float, SD_NV12>(c, inline_planes, n_inline, g, s)

@@ -172,7 +172,46 @@ def test_nv12_to_packed_u8_image(oracle, lname, layout, alpha, prog, batched):
     H.assert_bit_exact(gt.cpu().numpy(), ref, "interpreted")
 
 
-def test_planar_chroma_and_half_outputs_stay_interpreted():
+@pytest.mark.parametrize("lname,layout", LAYOUTS, ids=[x[0] for x in LAYOUTS])
+@pytest.mark.parametrize("out", ["packed", "split"])
+def test_nv12_to_half_precision_tensor(oracle, lname, layout, out):
+    """The half-precision hand-off behind a 4:2:0 read: ... -> normalize -> convertTo<CV_32FC3, CV_16FC3> -> tensor / image."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h = 774, 20
+    f, hf = cvgs.CV_32FC3, cvgs.CV_16FC3
+    st = cvgs.CV_16UC1 if layout == capi.YUV_P010 else cvgs.CV_8UC1
+    surf = _surface(layout, w, h, 8000 + layout)
+    full = 1023.0 if layout == capi.YUV_P010 else 255.0
+
+    def build(wrap, out_mat_of):
+        m = wrap(surf)
+        luma = cvgs.GpuMat(h, w, st, m.data, m.step, owner=m.owner)
+        ops = [cvgs.read_nv12(luma, None, capi.YUV_LIMITED, capi.BT709, False, layout=layout), cvgs.multiply(f, [1 / full] * 3),
+               cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225]), cvgs.convertTo(f, hf)]
+        if out == "packed":
+            return ops + [cvgs.write(hf, out_mat_of(hf))]
+        return ops + [cvgs.split(hf, out_mat_of(cvgs.CV_16FC1), (w, h))]
+
+    shape = (h, w, 3) if out == "packed" else (1, 3 * w * h)
+    ref = np.zeros(shape, np.float16)
+    oracle.execute(cvgs.lower(build(lambda a: cvgs.GpuMat.from_array(a, st), lambda t: cvgs.GpuMat.from_array(ref, t))))
+    ts = torch.from_numpy(surf.view(np.int16) if layout == capi.YUV_P010 else surf).to(dev)
+    gt = torch.zeros(shape, dtype=torch.float16, device=dev)
+    ops = build(lambda a: cvgs.GpuMat.from_tensor(ts, st), lambda t: cvgs.GpuMat.from_tensor(gt, t))
+    name = cvgs.kernel_name(*ops)
+    assert name == ("pointwise4_p010_f16" if layout == capi.YUV_P010 else "pointwise4_nv12_f16"), name
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    assert ref.any()
+    H.assert_bit_exact(gt.cpu().numpy().view(np.uint16), ref.view(np.uint16), "%s %s via %s" % (lname, out, name))
+    gt.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(gt.cpu().numpy().view(np.uint16), ref.view(np.uint16), "interpreted")
+
+
+def test_planar_chroma_stays_interpreted():
     import torch
     dev = torch.device("cuda:0")
     w, h = 64, 32
@@ -182,8 +221,4 @@ def test_planar_chroma_and_half_outputs_stay_interpreted():
     luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
     gt = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
     ops = [cvgs.read_nv12(luma, None, capi.YUV_FULL, capi.BT601, False, layout=capi.YUV_I420), cvgs.write(f, cvgs.GpuMat.from_tensor(gt, f))]
-    assert cvgs.kernel_name(*ops).startswith("generic")
-    gh = torch.zeros((h, w, 3), dtype=torch.float16, device=dev)
-    ops = [cvgs.read_nv12(luma, None, capi.YUV_FULL, capi.BT601, False), cvgs.convertTo(f, cvgs.CV_16FC3),
-           cvgs.write(cvgs.CV_16FC3, cvgs.GpuMat.from_tensor(gh, cvgs.CV_16FC3))]
     assert cvgs.kernel_name(*ops).startswith("generic")

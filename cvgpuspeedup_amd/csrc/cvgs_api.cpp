@@ -630,7 +630,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         big_inline = launch_k1(L.args, L.planes.data(), (int)L.planes.size(), L.mirrors, nullptr, 0, stream, true, nullptr) == 1;
         if (!big_inline && !has_mirrors && is_nv12(L.args.read.kind)) { // K4: crops of a decoder surface into a planar tensor
             int min_w = 1 << 30;
-            for (size_t i = 0; i < L.planes.size(); ++i) min_w = L.planes[i].w < min_w ? L.planes[i].w : min_w;
+            for (size_t i = 0; i < L.planes.size() && (int)i < L.args.read.used; ++i) min_w = L.planes[i].w < min_w ? L.planes[i].w : min_w;
             big_inline = launch_nv12(L.args, L.planes.data(), (int)L.planes.size(), min_w, nullptr, 0, stream, true, nullptr) == 1;
         }
     }
@@ -696,8 +696,8 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         if (big_inline && (has_mirrors || !is_nv12(L.args.read.kind)))
             return fail(CVGS_ERR_HIP, "internal: K1 refused a chain its dry run accepted"); // only K1 / K4 take > 64 inline planes
         if (!has_mirrors) { // only K1 and the interpreted kernel write mirrors
-            int min_w = 1 << 30;
-            for (int i = 0; i < n_inline; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
+            int min_w = 1 << 30; // over the planes that are read (default-value planes carry no source)
+            for (int i = 0; i < n_inline && i < L.args.read.used; ++i) min_w = inline_planes[i].w < min_w ? inline_planes[i].w : min_w;
             if (up_src && is_nv12(L.args.read.kind) && L.args.read.used == L.args.read.batch &&
                 k4_planes_eligible(L.planes.data(), (int)L.planes.size(), L.args.read.dst_w, L.args.read.dst_h)) {
                 // more than 64 crops of a decoder surface: K4 reads the staged table as ONE segment of its fused-chain form

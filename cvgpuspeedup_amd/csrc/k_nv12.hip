@@ -62,18 +62,23 @@ __device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k,
 
 // S16: P010 -- the same geometry with 16-bit samples (10-bit code = sample >> 6): the two luma taps are ONE 4-byte load, the
 // two chroma pairs ONE 8-byte load.
-template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3, bool S16 = false>
+// WIN: the target may hold an aspect-ratio window (letterboxed detector inputs: PRESERVE_AR*) and default-value planes
+// (usedPlanes < BATCH) -- K1's machinery: the background value runs through the program once, pixels outside the window take it.
+// A separate instantiation: K4 is bound by its VALU work per row, and the window's selects cost the stretch-only launches 4-8 %
+// when they are compiled in (tools/k4_ar_ab.sh: cfg #3 8.6 -> 9.0 us, 50 crops 4.92 -> 5.32 us).
+template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3, bool S16 = false, bool WIN = false>
 __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL> a, const N12Geom g) {
     const ChainArgs& c = a.c;
     const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
     PlaneParams P;
-    int z, col_tile, row_group;
+    int z, col_tile, row_group, used;
     uint8_t* out_base;
     if constexpr (NPL == 0) {
         z = (int)blockIdx.y;
         const ManySeg sg = a.seg[blockIdx.z];
         if (z >= sg.batch) return; // a shorter chain of the fused launch
-        P = sg.table[z];
+        used = sg.used;
+        P = sg.table[z < used ? z : 0];
         out_base = sg.out;
         col_tile = 0;
         row_group = (int)blockIdx.x;
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
         }
     } else {
         z = (int)blockIdx.z;
+        used = c.read.used;
         P = a.planes[z];
         out_base = g.out;
         col_tile = (int)blockIdx.x;
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
                  op2 = *(const f32x4s*)c.prog.operand[2], op3 = *(const f32x4s*)c.prog.operand[3];
     // one batch of scalar loads, one wait (see k_k1.hip)
+    if constexpr (WIN) asm volatile("" ::"s"(used), "s"(P.x1), "s"(P.y1), "s"(P.x2), "s"(P.y2));
     asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(W), "s"(CN), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.fx), "s"(P.fy), "s"(P.data), "s"(P.uv_off),
                  "s"(yuv_range), "s"(yuv_prim), "s"(packed), "s"(img_stride), "s"(ch_stride), "s"(out_base), "s"(op0), "s"(op1),
                  "s"(op2), "s"(op3));
@@ -106,8 +113,62 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     const int row0 = (row_group * kK4Waves + wave) * RPW;
     if (row0 >= dst_h || x >= dst_w) return;
 
+    // one output pixel of row y (wave-uniform row pointers; planar: non-temporal rows, packed: the generic write stage)
+    auto store_px = [&](const Px& p, int depth, int cn, int y) {
+    if (packed) {
+        write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
+    } else {
+        // OT = _Float16: the chain's trailing CAST(CV_16F) is this round-to-nearest-even conversion
+        const uint32_t xb = (uint32_t)x * (uint32_t)sizeof(OT);
+        OT* const orow = (OT*)out_base + (int64_t)z * img_stride + (int64_t)y * W;
+#pragma unroll
+#ifdef CVGS_K4_PLAIN_PTR
+        for (int k = 0; k < 4; ++k)
+            if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow + (int64_t)k * ch_stride + x);
+        if (g.out2) {
+            OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow2 + (int64_t)k * g.ch_stride2 + x);
+        }
+#else
+        for (int k = 0; k < 4; ++k)
+            if (k < cn) st_row(orow + (int64_t)k * ch_stride, xb, p.v[k]);
+        if (g.out2) { // wave-uniform
+            OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < cn) st_row(orow2 + (int64_t)k * g.ch_stride2, xb, p.v[k]);
+        }
+#endif
+    }
+    };
+    // does the source cover the whole target?  (always, except aspect-ratio padding -- letterboxed detector inputs -- and planes
+    // >= usedPlanes; wave-uniform.)  Otherwise the background value runs through the program once and replaces the pixels outside.
+    const bool whole = !WIN || (z < used && ((P.x1 | P.y1 | (P.x2 ^ (dst_w - 1)) | (P.y2 ^ (dst_h - 1))) == 0));
+    Px bgp;
+    bgp.v[0] = bgp.v[1] = bgp.v[2] = bgp.v[3] = 0.f;
+    bool in_x = true;
+    int xr = x;
+    if constexpr (WIN) {
+        int bg_cn = CN, bg_depth = CVGS_DEPTH_32F;
+        if (!whole) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bgp.v[k] = k < CN ? c.read.bg[k] : 0.f;
+            Prog::run(c.prog, bgp, bg_depth, bg_cn);
+        }
+        if (z >= used) { // a default-value plane: nothing is read
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+                if (row0 + j < dst_h) store_px(bgp, bg_depth, bg_cn, row0 + j);
+            return;
+        }
+        in_x = x >= P.x1 && x <= P.x2;
+        xr = in_x ? x - P.x1 : 0;
+    }
+
     // column geometry (once per lane, reused for every row)
-    const float sx = (float)x * P.fx;
+    const float sx = (float)xr * P.fx;
     const int x1 = (int)floorf(sx);
     const int x2 = x1 + 1;
     const float wxa = (float)x2 - sx, wxb = sx - (float)x1;
@@ -128,11 +189,14 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     uint32_t vya[RPW], vyb[RPW];
     ChromaWin vua[RPW], vub[RPW];
     float wya[RPW], wyb[RPW];
+    bool in_y[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         // row geometry (wave-uniform)
         const int y = min(row0 + j, dst_h - 1);
-        const float sy = (float)y * P.fy;
+        in_y[j] = !WIN || (y >= P.y1 && y <= P.y2);
+        const int yr = WIN ? (in_y[j] ? y - P.y1 : 0) : y;
+        const float sy = (float)yr * P.fy;
         const int y1 = (int)floorf(sy);
         const int y2 = y1 + 1;
         const int y2r = min(y2, P.h - 1);
@@ -226,34 +290,15 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
         }
         int depth = CVGS_DEPTH_32F, cn = CN;
         Prog::run(c.prog, p, depth, cn);
-
-        if (packed) {
-            write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
-        } else {
-            // OT = _Float16: the chain's trailing CAST(CV_16F) is this round-to-nearest-even conversion
-            const uint32_t xb = (uint32_t)x * (uint32_t)sizeof(OT);
-            OT* const orow = (OT*)out_base + (int64_t)z * img_stride + (int64_t)y * W;
+        if constexpr (WIN) {
+            if (!whole) { // wave-uniform: only padded planes pay the per-lane select
+                const bool take = in_x && in_y[j];
 #pragma unroll
-#ifdef CVGS_K4_PLAIN_PTR
-            for (int k = 0; k < 4; ++k)
-                if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow + (int64_t)k * ch_stride + x);
-            if (g.out2) {
-                OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < cn) __builtin_nontemporal_store((OT)p.v[k], orow2 + (int64_t)k * g.ch_stride2 + x);
+                for (int k = 0; k < 4; ++k) p.v[k] = take ? p.v[k] : bgp.v[k];
             }
-#else
-            for (int k = 0; k < 4; ++k)
-                if (k < cn) st_row(orow + (int64_t)k * ch_stride, xb, p.v[k]);
-            if (g.out2) { // wave-uniform
-                OT* const orow2 = (OT*)g.out2 + (int64_t)z * g.img_stride2 + (int64_t)y * W;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < cn) st_row(orow2 + (int64_t)k * g.ch_stride2, xb, p.v[k]);
-            }
-#endif
         }
+
+        store_px(p, depth, cn, y);
     }
 }
 
@@ -267,7 +312,7 @@ static N12Many& tls_many() {
     return m;
 }
 
-template <class Prog, typename OT, int RPW, int CN, bool S16>
+template <class Prog, typename OT, int RPW, int CN, bool S16, bool WIN = false>
 static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g_in, hipStream_t s) {
     N12Geom g = g_in;
     const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + kK4Waves * RPW - 1) / (kK4Waves * RPW));
@@ -279,7 +324,7 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         a.c = c;
         for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
-        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
         return hipGetLastError();
     }
     const dim3 grid(col_tiles, row_groups, c.read.batch);
@@ -287,23 +332,28 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     } else if (ni <= CVGS_KERNARG_PLANES) { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     } else { // ... up to CVGS_KERNARG_PLANES_MAX in a 16 KB argument block (see cvgs_device.h: cheaper than a table for an eager call)
         KernArgs<kKernargPlanesBig> a;
         a.c = c;
         for (int i = 0; i < kKernargPlanesBig; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<kKernargPlanesBig, Prog, OT, RPW, CN, S16>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<kKernargPlanesBig, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     }
     return hipGetLastError();
 }
 
 template <class Prog, typename OT = float>
-static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
+static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s, bool win = false) {
+    if (win) { // aspect-ratio windows / default-value planes: their own instantiations (see k4_nv12_resize)
+        if (c.read.yuv_layout == CVGS_YUV_P010)
+            return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, true, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, true, true>(c, ip, ni, g, s);
+        return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false, true>(c, ip, ni, g, s);
+    }
     // One output row per wave.  Two rows per wave were measured for whole-frame outputs (cfg #3: 14400 one-row waves need two
     // rounds of the chip's 8192 wave slots) and lost: 8.27 vs 8.08 us, and 5.29 vs 4.52 us on 50 crops -- the launch is
     // bound by the VALU work per row (~100 instructions x 14 waves per SIMD) plus the launch floor, not by residency.
@@ -318,13 +368,18 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
-// Can K4 serve these planes?  Stretch geometry only (aspect-ratio padding is the interpreted kernel's business) and rows wide
-// enough for the 4-byte chroma window.
-bool k4_planes_eligible(const PlaneParams* planes, int n, int dst_w, int dst_h) {
+// Can K4 serve these planes?  Rows wide enough for the 4-byte chroma window; stretch geometry for the callers that cannot pick
+// the windowed instantiation (fused chains, staged tables).
+bool k4_planes_eligible(const PlaneParams* planes, int n, int dst_w, int dst_h) { // stretch geometry: the WIN = false instantiations
     for (int i = 0; i < n; ++i) {
         const PlaneParams& P = planes[i];
         if (P.w < 4 || P.x1 != 0 || P.y1 != 0 || P.x2 != dst_w - 1 || P.y2 != dst_h - 1) return false;
     }
+    return true;
+}
+static bool k4_planes_wide_enough(const PlaneParams* planes, int n) {
+    for (int i = 0; i < n; ++i)
+        if (planes[i].w < 4) return false;
     return true;
 }
 
@@ -352,8 +407,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     } else {
         if (r.table || n_inline > kKernargPlanesBig || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
         if (n_inline > CVGS_KERNARG_PLANES && !(planar_kind && (c_in.write.depth == CVGS_DEPTH_32F || f16))) return 0; // the large block: tensors only
-        if (r.used != r.batch) return 0;
-        if (!k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h)) return 0;
+        if (!k4_planes_wide_enough(inline_planes, r.used < n_inline ? r.used : n_inline)) return 0;
     }
     if (r.batch > 65535) return 0;
     const WriteArgs& w = c.write;
@@ -372,20 +426,27 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     const ProgArgs& p = c.prog;
     const bool fast_prog = planar && p.n == 4 && p.opcode[0] == CVGS_OP_REORDER && p.aux[0] == swap &&
                            p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV;
+    // the same normalisation in the surface's own R, G, B order (cvtColorNV12<COLOR_YUV2RGB_NV12>: no swap)
+    const bool fast_rgb = planar && !f16 && p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV;
     if (info)
         info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
-                           : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : "k4_nv12_resize_interp");
+                           : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : (fast_rgb ? "k4_nv12_resize_mul_sub_div" : "k4_nv12_resize_interp"));
     if (dry_run) return 1;
     ChainArgs c_fd = c;
     c_fd.prog.fast_div = 0;
     for (int k = 0; k < 4; ++k) c_fd.prog.rdiv[k] = 0.f;
     if (fast_prog) fast_div_setup(c_fd.prog, 3, 1, r.out_cn, r.bg);
+    else if (fast_rgb) fast_div_setup(c_fd.prog, 2, 0, r.out_cn, r.bg);
     tls_many() = N12Many{segs, n_segs};
+    // the windowed instantiations: an aspect-ratio window or default-value planes (never for fused chains / staged tables, whose
+    // callers admit stretch geometry only)
+    const bool win = !segs && (r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h));
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c_fd, inline_planes, n_inline, g, s)
-                           : launch_n12<InterpProg, _Float16>(c_fd, inline_planes, n_inline, g, s);
-    else e = fast_prog ? launch_n12<N12SwapMulSubDiv>(c_fd, inline_planes, n_inline, g, s) : launch_n12<InterpProg>(c_fd, inline_planes, n_inline, g, s);
+    if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c_fd, inline_planes, n_inline, g, s, win)
+                           : launch_n12<InterpProg, _Float16>(c_fd, inline_planes, n_inline, g, s, win);
+    else e = fast_prog ? launch_n12<N12SwapMulSubDiv>(c_fd, inline_planes, n_inline, g, s, win)
+                       : (fast_rgb ? launch_n12<ProgMulSubDiv>(c_fd, inline_planes, n_inline, g, s, win) : launch_n12<InterpProg>(c_fd, inline_planes, n_inline, g, s, win));
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 

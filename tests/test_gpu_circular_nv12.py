@@ -307,17 +307,63 @@ def test_nv12_crop_batch_to_nchw(oracle, n):
     H.assert_bit_exact(one[0], ref[0], "crop view == crop copy")
 
 
-def test_nv12_preserve_ar_stays_on_the_generic_kernel():
-    """The K4 fast kernel has no aspect-ratio window: such chains must be routed to the interpreted kernel."""
+@pytest.mark.parametrize("ar", [cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_RN_EVEN, cvgs.PRESERVE_AR_LEFT])
+@pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_P010])
+@pytest.mark.parametrize("shape", [((640, 360), (64, 64)), ((360, 640), (96, 64)), ((1920, 1080), (640, 640)), ((322, 198), (70, 70))])
+@pytest.mark.parametrize("prog", ["rgb_norm", "bgr_norm", "u8"])
+def test_nv12_letterbox_resize_on_k4(oracle, ar, layout, shape, prog):
+    """Aspect-ratio-preserving resizes of decoder surfaces (the letterboxed detector input: the reference's AspectRatio modes,
+    include/cvGPUSpeedup.cuh:32,218-245, applied to the NV12 read-back of tests/resize/test_fused_resize.cu) on the K4 kernel:
+    wide and tall sources, every mode, a default-value plane behind the used ones, RGB- and BGR-order normalisation into a planar
+    tensor and a packed u8 image -- against the oracle and the interpreted kernel."""
     import torch
-    t = torch.zeros((360 + 180, 640), dtype=torch.uint8, device="cuda:0")
-    o = torch.zeros((1, 3 * 64 * 64), dtype=torch.float32, device="cuda:0")
-    md = cvgs.GpuMat.from_tensor(t, cvgs.CV_8UC1)
-    luma = cvgs.GpuMat(360, 640, cvgs.CV_8UC1, md.data, md.step, owner=md.owner)
-    rd = cvgs.read_nv12(luma, (64, 64), capi.YUV_FULL, capi.BT709, False)
-    rd.ar = cvgs.PRESERVE_AR
-    name = cvgs.kernel_name(rd, cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), (64, 64)))
-    assert name.startswith("generic"), name
+    dev = torch.device("cuda:0")
+    (w, h), dst = shape
+    st = cvgs.CV_16UC1 if layout == capi.YUV_P010 else cvgs.CV_8UC1
+    if layout == capi.YUV_P010:
+        surf = (H.random_u16((h * 3 // 2, w), 9100 + w) & 0xffc0).astype(np.uint16)
+    else:
+        surf = H.random_u8((h * 3 // 2, w), 9100 + w)
+    f, u = cvgs.CV_32FC3, cvgs.CV_8UC3
+    full = 1023.0 if layout == capi.YUV_P010 else 255.0
+    n = 1 if prog == "u8" else 3
+
+    def build(wrap, out):
+        m = wrap(surf)
+        luma = cvgs.GpuMat(h, w, st, m.data, m.step, owner=m.owner)
+        mats = [luma] if n == 1 else [luma, luma.nv12_roi(2, 2, w - 4, h - 4 - (h % 4)), luma]
+        rd = cvgs.read_nv12(mats, dst, capi.YUV_LIMITED, capi.BT709, False, layout=layout)
+        rd.ar = ar
+        rd.background = cvgs._scalar([114.0, 100.5, 7.25])
+        if n > 1:
+            rd.used_planes = 2
+        norm = [cvgs.multiply(f, [1 / full] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225])]
+        if prog == "rgb_norm":
+            return [rd] + norm + [cvgs.split(f, out, dst)]
+        if prog == "bgr_norm":
+            return [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f)] + norm + [cvgs.split(f, out, dst)]
+        return [rd, cvgs.convertTo(f, u, 255.0 / full), cvgs.write(u, out)]
+
+    if prog == "u8":
+        shp, dt, tdt, ot = (dst[1], dst[0], 3), np.uint8, torch.uint8, u
+    else:
+        shp, dt, tdt, ot = (n, 3 * dst[0] * dst[1]), np.float32, torch.float32, cvgs.CV_32FC1
+    ref = np.zeros(shp, dt)
+    oracle.execute(cvgs.lower(build(lambda a: cvgs.GpuMat.from_array(a, st), cvgs.GpuMat.from_array(ref, ot))))
+    ts = torch.from_numpy(surf.view(np.int16) if layout == capi.YUV_P010 else surf).to(dev)
+    gt = torch.zeros(shp, dtype=tdt, device=dev)
+    ops = build(lambda a: cvgs.GpuMat.from_tensor(ts, st), cvgs.GpuMat.from_tensor(gt, ot))
+    name = cvgs.kernel_name(*ops)
+    want = {"rgb_norm": "k4_nv12_resize_mul_sub_div", "bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "u8": "k4_nv12_resize_interp"}[prog]
+    assert name == want, name
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    assert ref.any()
+    H.assert_bit_exact(gt.cpu().numpy(), ref, "letterbox ar=%d layout=%d %s %s via %s" % (ar, layout, shape, prog, name))
+    gt.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(gt.cpu().numpy(), ref, "interpreted")
 
 
 @pytest.mark.parametrize("range_", [capi.YUV_FULL, capi.YUV_LIMITED])

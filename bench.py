@@ -542,6 +542,10 @@ def extra_sweeps(dev, a):
         out["other_configs"] = bench_more.run_all(dev, iters=50)
         import bench_resize  # whole-frame resizes of synthetic 1080p / 4K / 6K frames (K2 / K3 chains of the reference's tests)
         out["whole_frame_resize"] = bench_resize.run_all(dev, iters=50)
+        import bench_nv12_full  # decode-side cvtColor without a resize (thread-fused 4:2:0 read mode)
+        import bench_nv12_letterbox  # decoder surface -> 640x640 detector input, stretched / letterboxed (K4)
+        out["nv12_full_resolution"] = bench_nv12_full.run_all(iters=40)
+        out["nv12_detector_input"] = bench_nv12_letterbox.run_all()
     except Exception as ex:  # extras must never break the headline line
         out["error"] = repr(ex)
     return out

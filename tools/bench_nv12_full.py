@@ -70,14 +70,19 @@ def run(name, mode, iters=60):
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / iters
     alg = w * h * (3 if mode == "bgr_ref" else 1.5) + w * h * out_bytes
-    print(json.dumps({"case": name, "kernel": cvgs.kernel_name(*ops), "us": round(t * 1e6, 2), "GB_per_s": round(alg / t / 1e9, 1),
-                      "frac_of_8TBs": round(alg / t / 8e12, 4)}))
+    res = {"case": name, "kernel": cvgs.kernel_name(*ops), "us": round(t * 1e6, 2), "GB_per_s": round(alg / t / 1e9, 1),
+           "frac_of_8TBs": round(alg / t / 8e12, 4)}
     del chains, keep
     torch.cuda.empty_cache()
+    return res
+
+
+def run_all(iters=60):
+    return [run("4K NV12 -> BGR u8 packed", "u8", iters), run("4K NV12 -> BGR fp32 packed", "f32", iters),
+            run("4K NV12 -> normalize -> NCHW fp32", "nchw", iters),
+            run("yardstick: 4K packed BGR u8 -> normalize -> NCHW fp32", "bgr_ref", iters)]
 
 
 if __name__ == "__main__":
-    run("4K NV12 -> BGR u8 packed", "u8")
-    run("4K NV12 -> BGR fp32 packed", "f32")
-    run("4K NV12 -> normalize -> NCHW fp32", "nchw")
-    run("yardstick: 4K packed BGR u8 -> normalize -> NCHW fp32", "bgr_ref")
+    for r in run_all():
+        print(json.dumps(r))

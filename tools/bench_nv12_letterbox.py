@@ -40,9 +40,18 @@ def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0):
         e0.record()
         for _ in range(8): g.replay()
         e1.record(); torch.cuda.synchronize()
-    print(json.dumps({"case":name,"kernel":cvgs.kernel_name(*ops, flags=flags),"us":round(e0.elapsed_time(e1)*1e3/(80*n_rot),2)}))
-run("1080p NV12 -> 640x640 stretch", 1920,1080,(640,640), cvgs.IGNORE_AR)
-run("1080p NV12 -> 640x640 letterbox", 1920,1080,(640,640), cvgs.PRESERVE_AR)
-run("4K NV12 -> 640x640 stretch", 3840,2160,(640,640), cvgs.IGNORE_AR)
-run("4K NV12 -> 640x640 letterbox", 3840,2160,(640,640), cvgs.PRESERVE_AR)
-run("1080p NV12 -> 640x640 letterbox, interpreted kernel (CVGS_CHAIN_FORCE_GENERIC)", 1920,1080,(640,640), cvgs.PRESERVE_AR, flags=capi.CHAIN_FORCE_GENERIC)
+    res = {"case":name,"kernel":cvgs.kernel_name(*ops, flags=flags),"us":round(e0.elapsed_time(e1)*1e3/(80*n_rot),2)}
+    del chains, keep, g
+    torch.cuda.empty_cache()
+    return res
+def run_all():
+    return [run("1080p NV12 -> 640x640 stretch -> RGB normalize -> NCHW", 1920,1080,(640,640), cvgs.IGNORE_AR),
+            run("1080p NV12 -> 640x640 letterbox -> RGB normalize -> NCHW", 1920,1080,(640,640), cvgs.PRESERVE_AR),
+            run("4K NV12 -> 640x640 stretch -> RGB normalize -> NCHW", 3840,2160,(640,640), cvgs.IGNORE_AR),
+            run("4K NV12 -> 640x640 letterbox -> RGB normalize -> NCHW", 3840,2160,(640,640), cvgs.PRESERVE_AR),
+            run("1080p NV12 -> 640x640 letterbox, interpreted kernel (CVGS_CHAIN_FORCE_GENERIC)", 1920,1080,(640,640), cvgs.PRESERVE_AR, flags=capi.CHAIN_FORCE_GENERIC)]
+
+
+if __name__ == "__main__":
+    for r in run_all():
+        print(json.dumps(r))

@@ -58,6 +58,48 @@ def test_nv12_resize_push_reaches_ring_and_tensor(oracle, order, mirrored):
 
 
 @pytest.mark.parametrize("mirrored", [False, True])
+@pytest.mark.parametrize("mode", ["full_resolution", "letterbox"])
+def test_nv12_pointwise_and_letterbox_pushes_reach_ring_and_tensor(oracle, mode, mirrored):
+    """The round-2 additions write both targets too: a decoder surface pushed at full resolution (k_pointwise4's 4:2:0 read mode)
+    and pushed through an aspect-ratio-preserving resize (K4's windowed instantiation), default and mirrored ring, > BATCH updates."""
+    import torch
+    dev = torch.device("cuda:0")
+    B = 3
+    sw, sh = 136, 72
+    W, H_ = (sw, sh) if mode == "full_resolution" else (64, 64)
+    ct = cvgs.CircularTensor(cvgs.CV_8UC1, cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard, W, H_, mirrored=mirrored)
+    oc = oracle.OracleCircular(W, H_, cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard)
+    f = cvgs.CV_32FC3
+    s = torch.cuda.current_stream()
+    pw = [cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225])]
+
+    def read(g):
+        rd = cvgs.read_nv12(g, None if mode == "full_resolution" else (W, H_), capi.YUV_LIMITED, capi.BT709, alpha=False)
+        if mode == "letterbox":
+            rd.ar = cvgs.PRESERVE_AR
+            rd.background = cvgs._scalar([114.0, 114.0, 114.0])
+        return rd
+
+    for i in range(2 * B + 1):
+        surf = H.random_u8((sh + sh // 2, sw, 1), seed=4500 + i)
+        st = torch.from_numpy(surf).to(dev)
+        g = cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, st.data_ptr(), sw, owner=st)
+        rd = read(g)
+        ct.update(s, rd, *pw, ct.write_split(f))
+        if i == 0:
+            buf = C.create_string_buffer(128)
+            probe = cvgs.lower([rd, *pw, cvgs.split_tensor(f, 16, W, H_, 1)])
+            capi.check(ct.lib.cvgs_kernel_name(C.byref(probe.desc), buf, 128))
+            assert buf.value.decode() == ("pointwise4_nv12" if mode == "full_resolution" else "k4_nv12_resize_mul_sub_div"), buf.value
+        h = cvgs.GpuMat(sh, sw, cvgs.CV_8UC1, surf.ctypes.data, sw, owner=surf)
+        oc.update(cvgs.lower([read(h), *pw, cvgs.WriteIOp(capi.WRITE_TENSOR_SPLIT, f, 16, W, H_, 0, B)]))
+        torch.cuda.synchronize()
+        got = _read_device(ct.data(), ct.nbytes()).view(np.float32)
+        H.assert_bit_exact(got, oc.array(np.float32), "%s push %d (mirrored=%s)" % (mode, i, mirrored))
+    ct.release()
+
+
+@pytest.mark.parametrize("mirrored", [False, True])
 def test_warp_push_reaches_ring_and_tensor(oracle, mirrored):
     import torch
     dev = torch.device("cuda:0")

@@ -230,6 +230,15 @@ inline auto resize(const fk::YuvRead<PF, CR, CP, ALPHA, O, SW>& nv12Read, const 
     static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");
     return fk::Resize<(fk::InterpolationType)INTER_F>::build(nv12Read, fk::Size(dsize.width, dsize.height));
 }
+// resize<INTER, AR>(thatIOp, dsize, backgroundValue): the decoder surface letterboxed into dsize (the AspectRatio modes of the
+// batched resize, reference :218-245, on the NV12 read-back); the padding takes backgroundValue (in the IOp's channel order) and
+// runs through the rest of the chain like a pixel.  One K4 launch: surface -> detector input tensor.
+template <int INTER_F, AspectRatio AR, fk::PixelFormat PF, fk::ColorRange CR, fk::ColorPrimitives CP, bool ALPHA, typename O, bool SW>
+inline auto resize(const fk::YuvRead<PF, CR, CP, ALPHA, O, SW>& nv12Read, const cv::Size& dsize, const cv::Scalar& backgroundValue = cv::Scalar()) {
+    static_assert(isSupportedInterpolation<INTER_F>, "Interpolation type not supported yet.");
+    const float bg[4] = {(float)backgroundValue[0], (float)backgroundValue[1], (float)backgroundValue[2], (float)backgroundValue[3]};
+    return fk::Resize<(fk::InterpolationType)INTER_F, (fk::AspectRatio)AR>::build(nv12Read, fk::Size(dsize.width, dsize.height), bg);
+}
 
 // ---- warp (reference include/cvGPUSpeedup.cuh:267-442) --------------------------------------------------------------
 // warp<WT, InputType[, BATCH]>(input(s), FORWARD transform(s) as CV_64FC1 cv::Mat, dstSize(s)[, usedPlanes, defaultValue]):

@@ -555,12 +555,20 @@ template <typename T> struct ResizeRead {          // single image, pixel source
 template <typename Yuv> struct ResizeYuvRead {     // single image, NV12 read-back source
     Yuv back;
     Size dsize;
+    int ar = CVGS_IGNORE_AR;            // cvGS::AspectRatio: PRESERVE_AR* letterboxes the surface into dsize
+    float bg[4] = {0.f, 0.f, 0.f, 0.f}; // the padding value, in the read's output channel order
     using OutputType = VectorType_t<float, cn<typename Yuv::OutputType>>;
     static constexpr Stage stage = Stage::Read;
     static_assert(Yuv::float_out, "Resize over an NV12 read-back interpolates in float: use ConvertYUVToRGB<..., floatN>");
     void lower(ChainBuilder& b) const {
         back.lower_read(b, CVGS_READ_NV12_RESIZE_LINEAR);
-        b.d.read.dst_width = dsize.width; b.d.read.dst_height = dsize.height; b.d.read.aspect_ratio = CVGS_IGNORE_AR;
+        b.d.read.dst_width = dsize.width; b.d.read.dst_height = dsize.height; b.d.read.aspect_ratio = ar;
+        // the background enters BEFORE the R <-> B swap the BGR codes append (it runs through the program like a pixel)
+        constexpr bool kSwap = Yuv::swap_rb;
+        b.d.read.background[0] = kSwap ? bg[2] : bg[0];
+        b.d.read.background[1] = bg[1];
+        b.d.read.background[2] = kSwap ? bg[0] : bg[2];
+        b.d.read.background[3] = bg[3];
         Yuv::lower_swap(b); // a channel permutation commutes with the per-channel interpolation
     }
 };
@@ -673,8 +681,12 @@ template <InterpolationType IT, AspectRatio AR = IGNORE_AR> struct Resize {
         return ResizeRead<T>{in, d};
     }
     template <PixelFormat PF, ColorRange CR, ColorPrimitives CP, bool ALPHA, typename O, bool SW>
-    static auto build(const YuvRead<PF, CR, CP, ALPHA, O, SW>& back, const Size& dsize) {
-        return ResizeYuvRead<YuvRead<PF, CR, CP, ALPHA, O, SW>>{back, dsize};
+    static auto build(const YuvRead<PF, CR, CP, ALPHA, O, SW>& back, const Size& dsize, const float* background = nullptr) {
+        ResizeYuvRead<YuvRead<PF, CR, CP, ALPHA, O, SW>> r{back, dsize};
+        r.ar = (int)AR; // same numeric values as cvgs_aspect_ratio
+        if (background)
+            for (int c = 0; c < 4; ++c) r.bg[c] = background[c];
+        return r;
     }
 };
 

@@ -130,6 +130,36 @@ static void test_nv12_facade_cfg3(cv::cuda::Stream& stream) {
     CHECK(bit_equal(h.data(), h_ref.data, h.size()), "cfg3 through cvGS::cvtColorNV12 + resize, bit-exact vs oracle");
 }
 
+// a decoder surface letterboxed into a detector input: cvtColorNV12<RGB> -> resize<LINEAR, PRESERVE_AR>(640x640 style) -> normalize -> split
+static void test_nv12_facade_letterbox(cv::cuda::Stream& stream) {
+    const int W = 1280, H = 720;
+    const cv::Size box(320, 320);
+    cv::Mat h_nv12(H + H / 2, W, CV_8UC1);
+    fill_random(h_nv12, 778);
+    cv::cuda::GpuMat d_nv12(h_nv12), hv_nv12 = host_view(h_nv12);
+    cv::cuda::GpuMat d_out(1, box.width * box.height * 3, CV_32F);
+    cv::Mat h_ref(1, box.width * box.height * 3, CV_32F);
+    cv::cuda::GpuMat hv_ref = host_view(h_ref);
+    const cv::Scalar a(1 / 255.0, 1 / 255.0, 1 / 255.0), s(0.485, 0.456, 0.406), d(0.229, 0.224, 0.225), pad(114, 100, 7);
+    for (int bgr = 0; bgr < 2; ++bgr) {
+        auto go = [&](auto read_dev, auto read_host) {
+            cvGS::executeOperations(stream, cvGS::resize<cv::INTER_LINEAR, cvGS::PRESERVE_AR>(read_dev, box, pad), cvGS::multiply<CV_32FC3>(a),
+                                    cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(d_out, box));
+            run_oracle(cvGS::resize<cv::INTER_LINEAR, cvGS::PRESERVE_AR>(read_host, box, pad), cvGS::multiply<CV_32FC3>(a),
+                       cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d), cvGS::split<CV_32FC3>(hv_ref, box));
+        };
+        if (bgr) go(cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12, fk::Limited>(d_nv12), cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12, fk::Limited>(hv_nv12));
+        else go(cvGS::cvtColorNV12<cv::COLOR_YUV2RGB_NV12, fk::Limited>(d_nv12), cvGS::cvtColorNV12<cv::COLOR_YUV2RGB_NV12, fk::Limited>(hv_nv12));
+        stream.waitForCompletion();
+        const auto h = fetch(d_out.data, (size_t)box.width * box.height * 3 * 4);
+        CHECK(bit_equal(h.data(), h_ref.data, h.size()), (bgr ? "NV12 letterbox (BGR order), bit-exact vs oracle" : "NV12 letterbox (RGB order), bit-exact vs oracle"));
+        // the padding rows carry the background pushed through the chain; backgroundValue is in the IOp's OUTPUT channel order, so plane 0,
+        // row 0 is pad[0] for the RGB and for the BGR code alike
+        const float want = (float)(((float)pad[0] * (float)a[0] - (float)s[0]) / (float)d[0]);
+        CHECK(std::fabs(((const float*)h_ref.data)[0] - want) < 1e-5f, "letterbox padding = background through the chain");
+    }
+}
+
 // the decode-side headline path: N crops of an NV12 surface -> BGR float -> 64x128 -> normalize -> NCHW, ONE kernel;
 // each crop must equal the single-surface chain run on a copy of that crop (same taps, same arithmetic)
 static void test_nv12_crops_batch(cv::cuda::Stream& stream) {
@@ -214,6 +244,7 @@ static void test_p010_crops_batch(cv::cuda::Stream& stream) {
 int main() {
     cv::cuda::Stream stream;
     test_nv12_facade_cfg3(stream);
+    test_nv12_facade_letterbox(stream);
     test_nv12_crops_batch(stream);
     test_p010_crops_batch(stream);
     test_resize_split_one<CV_8UC3, CV_32FC3>(stream);

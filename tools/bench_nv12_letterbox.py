@@ -7,7 +7,7 @@ import torch
 from cvgpuspeedup_amd import capi, cvgs
 from cvgpuspeedup_amd import workloads as W
 dev = torch.device("cuda:0"); lib = capi.load_library()
-def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0):
+def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0, u8_image=False):
     chains=[]; keep=[]
     f3=cvgs.CV_32FC3
     for i in range(n_rot):
@@ -17,8 +17,12 @@ def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0):
         rd = cvgs.read_nv12(luma, dst, capi.YUV_LIMITED, capi.BT709, False)
         rd.ar = ar
         rd.background = cvgs._scalar([114.0,114.0,114.0])
-        out = torch.zeros((1, 3*dst[0]*dst[1]), dtype=torch.float32, device=dev)
-        ops=[rd, cvgs.multiply(f3,[1/255.0]*3), cvgs.subtract(f3,[0.485,0.456,0.406]), cvgs.divide(f3,[0.229,0.224,0.225]), cvgs.split(f3, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst)]
+        if u8_image:  # -> BGR u8 image (thumbnail / display path): swap, saturating cast, packed pixels
+            out = torch.zeros((dst[1], dst[0], 3), dtype=torch.uint8, device=dev)
+            ops=[rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f3), cvgs.convertTo(f3, cvgs.CV_8UC3), cvgs.write(cvgs.CV_8UC3, cvgs.GpuMat.from_tensor(out, cvgs.CV_8UC3))]
+        else:
+            out = torch.zeros((1, 3*dst[0]*dst[1]), dtype=torch.float32, device=dev)
+            ops=[rd, cvgs.multiply(f3,[1/255.0]*3), cvgs.subtract(f3,[0.485,0.456,0.406]), cvgs.divide(f3,[0.229,0.224,0.225]), cvgs.split(f3, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst)]
         chains.append(cvgs.lower(ops, flags)); keep += [surf,out]
     s=torch.cuda.current_stream().cuda_stream
     st={'i':0}
@@ -49,6 +53,8 @@ def run_all():
             run("1080p NV12 -> 640x640 letterbox -> RGB normalize -> NCHW", 1920,1080,(640,640), cvgs.PRESERVE_AR),
             run("4K NV12 -> 640x640 stretch -> RGB normalize -> NCHW", 3840,2160,(640,640), cvgs.IGNORE_AR),
             run("4K NV12 -> 640x640 letterbox -> RGB normalize -> NCHW", 3840,2160,(640,640), cvgs.PRESERVE_AR),
+            run("4K NV12 -> 1920x1080 BGR u8 image", 3840,2160,(1920,1080), cvgs.IGNORE_AR, u8_image=True),
+            run("1080p NV12 -> 640x360 BGR u8 image", 1920,1080,(640,360), cvgs.IGNORE_AR, u8_image=True),
             run("1080p NV12 -> 640x640 letterbox, interpreted kernel (CVGS_CHAIN_FORCE_GENERIC)", 1920,1080,(640,640), cvgs.PRESERVE_AR, flags=capi.CHAIN_FORCE_GENERIC)]
 
 

@@ -310,7 +310,7 @@ def test_nv12_crop_batch_to_nchw(oracle, n):
 @pytest.mark.parametrize("ar", [cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_RN_EVEN, cvgs.PRESERVE_AR_LEFT])
 @pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_P010])
 @pytest.mark.parametrize("shape", [((640, 360), (64, 64)), ((360, 640), (96, 64)), ((1920, 1080), (640, 640)), ((322, 198), (70, 70))])
-@pytest.mark.parametrize("prog", ["rgb_norm", "bgr_norm", "u8"])
+@pytest.mark.parametrize("prog", ["rgb_norm", "bgr_norm", "u8", "u8_batch"])
 def test_nv12_letterbox_resize_on_k4(oracle, ar, layout, shape, prog):
     """Aspect-ratio-preserving resizes of decoder surfaces (the letterboxed detector input: the reference's AspectRatio modes,
     include/cvGPUSpeedup.cuh:32,218-245, applied to the NV12 read-back of tests/resize/test_fused_resize.cu) on the K4 kernel:
@@ -326,7 +326,7 @@ def test_nv12_letterbox_resize_on_k4(oracle, ar, layout, shape, prog):
         surf = H.random_u8((h * 3 // 2, w), 9100 + w)
     f, u = cvgs.CV_32FC3, cvgs.CV_8UC3
     full = 1023.0 if layout == capi.YUV_P010 else 255.0
-    n = 1 if prog == "u8" else 3
+    n = 1 if prog == "u8" else 3  # "u8_batch": a dense batch of packed u8 images, the last one a default-value plane
 
     def build(wrap, out):
         m = wrap(surf)
@@ -342,9 +342,13 @@ def test_nv12_letterbox_resize_on_k4(oracle, ar, layout, shape, prog):
             return [rd] + norm + [cvgs.split(f, out, dst)]
         if prog == "bgr_norm":
             return [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f)] + norm + [cvgs.split(f, out, dst)]
+        if prog == "u8_batch":
+            return [rd, cvgs.convertTo(f, u, 255.0 / full), cvgs.write(u, out, dst)]
         return [rd, cvgs.convertTo(f, u, 255.0 / full), cvgs.write(u, out)]
 
-    if prog == "u8":
+    if prog == "u8_batch":
+        shp, dt, tdt, ot = (n, dst[0] * dst[1], 3), np.uint8, torch.uint8, u
+    elif prog == "u8":
         shp, dt, tdt, ot = (dst[1], dst[0], 3), np.uint8, torch.uint8, u
     else:
         shp, dt, tdt, ot = (n, 3 * dst[0] * dst[1]), np.float32, torch.float32, cvgs.CV_32FC1
@@ -354,7 +358,8 @@ def test_nv12_letterbox_resize_on_k4(oracle, ar, layout, shape, prog):
     gt = torch.zeros(shp, dtype=tdt, device=dev)
     ops = build(lambda a: cvgs.GpuMat.from_tensor(ts, st), cvgs.GpuMat.from_tensor(gt, ot))
     name = cvgs.kernel_name(*ops)
-    want = {"rgb_norm": "k4_nv12_resize_mul_sub_div", "bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "u8": "k4_nv12_resize_interp"}[prog]
+    want = {"rgb_norm": "k4_nv12_resize_mul_sub_div", "bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "u8": "k4_nv12_resize_interp",
+            "u8_batch": "k4_nv12_resize_interp"}[prog]
     assert name == want, name
     cvgs.executeOperations(torch.cuda.current_stream(), *ops)
     torch.cuda.synchronize()

@@ -247,8 +247,7 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     if (chain_flags & CVGS_CHAIN_NO_THREAD_FUSION) return false;
     // 4:2:0 surfaces with interleaved chroma read WITHOUT a resize (the decode-side cvtColor: cvGS::cvtColorNV12 -> ... -> tensor):
     // the value arrives as CV_32F R, G, B[, A], so the chain is a CV_32F chain with out_cn channels
-    const bool yuv = r.kind == CVGS_READ_NV12 &&
-                     (r.yuv_layout == CVGS_YUV_NV12 || r.yuv_layout == CVGS_YUV_NV21 || r.yuv_layout == CVGS_YUV_P010);
+    const bool yuv = r.kind == CVGS_READ_NV12; // every layout: NV12 / NV21 / P010 (interleaved chroma), I420 / YV12 (planar chroma)
     if ((r.kind != CVGS_READ_PIXEL && !yuv) || r.batch > 65535) return false;
     const int sdepth = yuv ? CVGS_DEPTH_32F : r.depth, scn = yuv ? r.out_cn : r.cn;
     const bool u8src = sdepth == CVGS_DEPTH_8U;
@@ -345,29 +344,30 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
     g.narrow = g.w <= 64 ? 2 : (g.w <= 128 ? 1 : 0); // batches of small crops (the reference's 60x120 crops): several rows per wave
     const bool yuv = c.read.kind == CVGS_READ_NV12;
     if (yuv) { // the thread's 4 pixels share 2 chroma pairs: even widths (validated for every 4:2:0 plane) and x0 % 4 == 0
+        const bool ten = c.read.yuv_layout == CVGS_YUV_P010;
+        const bool planar_chroma = c.read.yuv_layout == CVGS_YUV_I420 || c.read.yuv_layout == CVGS_YUV_YV12;
         if (info) {
-            static const char* names[2][3] = {{"pointwise4_nv12", "pointwise4_nv12_u8", "pointwise4_nv12_f16"}, {"pointwise4_p010", "pointwise4_p010_u8", "pointwise4_p010_f16"}};
-            info->kernel = names[c.read.yuv_layout == CVGS_YUV_P010][u8o ? 1 : (f16 ? 2 : 0)];
+            static const char* names[3][3] = {{"pointwise4_nv12", "pointwise4_nv12_u8", "pointwise4_nv12_f16"},
+                                              {"pointwise4_p010", "pointwise4_p010_u8", "pointwise4_p010_f16"},
+                                              {"pointwise4_i420", "pointwise4_i420_u8", "pointwise4_i420_f16"}};
+            info->kernel = names[ten ? 1 : (planar_chroma ? 2 : 0)][u8o ? 1 : (f16 ? 2 : 0)];
         }
         if (dry_run) return 1;
         const ProgArgs& p = c.prog;
         const bool norm = p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV;
-        const bool ten = c.read.yuv_layout == CVGS_YUV_P010;
         hipStream_t s = (hipStream_t)stream;
         hipError_t e;
-        auto go = [&](auto cn_tag) {
-            constexpr int CN = decltype(cn_tag)::value;
+        auto go = [&](auto cn_tag, auto sd_tag) {
+            constexpr int CN = decltype(cn_tag)::value, SD = decltype(sd_tag)::value;
             using Arith = ArithProg<CN, CVGS_DEPTH_32F>;
-            if (u8o) return ten ? launch_pw<CN, Arith, uint8_t, SD_P010>(c, inline_planes, n_inline, g, s)
-                                : launch_pw<CN, Arith, uint8_t, SD_NV12>(c, inline_planes, n_inline, g, s);
-            if (f16) return ten ? launch_pw<CN, Arith, _Float16, SD_P010>(c, inline_planes, n_inline, g, s)
-                                : launch_pw<CN, Arith, _Float16, SD_NV12>(c, inline_planes, n_inline, g, s);
-            if (ten) return norm ? launch_pw<CN, ProgMulSubDivPw, float, SD_P010>(c, inline_planes, n_inline, g, s)
-                                 : launch_pw<CN, Arith, float, SD_P010>(c, inline_planes, n_inline, g, s);
-            return norm ? launch_pw<CN, ProgMulSubDivPw, float, SD_NV12>(c, inline_planes, n_inline, g, s)
-                        : launch_pw<CN, Arith, float, SD_NV12>(c, inline_planes, n_inline, g, s);
+            if (u8o) return launch_pw<CN, Arith, uint8_t, SD>(c, inline_planes, n_inline, g, s);
+            if (f16) return launch_pw<CN, Arith, _Float16, SD>(c, inline_planes, n_inline, g, s);
+            return norm ? launch_pw<CN, ProgMulSubDivPw, float, SD>(c, inline_planes, n_inline, g, s)
+                        : launch_pw<CN, Arith, float, SD>(c, inline_planes, n_inline, g, s);
         };
-        e = g.cn == 3 ? go(std::integral_constant<int, 3>{}) : go(std::integral_constant<int, 4>{});
+        auto go_cn = [&](auto sd_tag) { return g.cn == 3 ? go(std::integral_constant<int, 3>{}, sd_tag) : go(std::integral_constant<int, 4>{}, sd_tag); };
+        e = ten ? go_cn(std::integral_constant<int, SD_P010>{})
+                : (planar_chroma ? go_cn(std::integral_constant<int, SD_I420>{}) : go_cn(std::integral_constant<int, SD_NV12>{}));
         return e == hipSuccess ? 1 : -(int)e - 1000;
     }
     if (info) {

@@ -118,8 +118,8 @@ __device__ __forceinline__ float elem_value(const uint32_t* raw, int e) {
 }
 // pseudo source depths of pw4_body: 4:2:0 decoder surfaces with interleaved chroma read WITHOUT a resize (CVGS_READ_NV12; NV12 /
 // NV21 8-bit samples, P010 16-bit samples) -- the pixel arrives as CV_32F R, G, B[, A] through k_common.hpp's yuv_to_rgb
-constexpr int SD_NV12 = 64, SD_P010 = 65;
-template <int SD> constexpr bool is_yuv_sd = SD == SD_NV12 || SD == SD_P010;
+constexpr int SD_NV12 = 64, SD_P010 = 65, SD_I420 = 66; // SD_I420: planar chroma (I420 / YV12: two quarter-size planes behind the luma)
+template <int SD> constexpr bool is_yuv_sd = SD == SD_NV12 || SD == SD_P010 || SD == SD_I420;
 template <int SD> constexpr int src_elem_bytes = (SD == CVGS_DEPTH_8U || SD == CVGS_DEPTH_8S) ? 1 : ((SD == CVGS_DEPTH_16U || SD == CVGS_DEPTH_16S) ? 2 : 4);
 
 template <int CN, typename OT>
@@ -145,13 +145,36 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
         // ---- 4 pixels of a 4:2:0 surface: 4 luma samples + the 2 chroma pairs they share (x0 is a multiple of 4) ----
         constexpr int SB = SD == SD_P010 ? 2 : 1; // bytes per sample
         const YuvK yk = yuv_matrix(c.read.yuv_range, c.read.yuv_primaries, SD == SD_P010 ? CVGS_YUV_P010 : CVGS_YUV_NV12);
-        const bool vu = c.read.yuv_layout == CVGS_YUV_NV21; // wave-uniform: the pair is (V,U)
+        const bool vu = c.read.yuv_layout == CVGS_YUV_NV21 || c.read.yuv_layout == CVGS_YUV_YV12; // wave-uniform: V comes first
         Px px[4];
         int depth = CVGS_DEPTH_32F, cn = CN;
         if (z < used) {
             const gp_u8 yrow = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * SB;
-            const gp_u8 crow = (gp_u8)P.data + (size_t)P.uv_off + (size_t)(y >> 1) * (size_t)P.step + (size_t)x0 * SB;
             uint32_t yw[SB], cw[SB];
+            if constexpr (SD == SD_I420) {
+                // planar chroma: (W/2) x (H/2) planes with rows of step/2 bytes, one after the other (nv12_px's addressing); the two
+                // samples of each plane are re-interleaved into NV12's pair format
+                typedef uint16_t u16u __attribute__((aligned(1)));
+                typedef const __attribute__((address_space(1))) u16u* gp_u16;
+                const size_t cstep = (size_t)(P.step >> 1);
+                const gp_u8 first = (gp_u8)P.data + (size_t)P.uv_off + (size_t)(y >> 1) * cstep + (size_t)(x0 >> 1);
+                const gp_u8 second = first + (size_t)(P.h >> 1) * cstep;
+                uint32_t a, b;
+                if (npx == 4) {
+                    yw[0] = *(gp_u32)yrow;
+                    a = *(gp_u16)first;
+                    b = *(gp_u16)second;
+                } else {
+                    yw[0] = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < npx) yw[0] |= (uint32_t)yrow[k] << (8 * k);
+                    a = first[0];
+                    b = second[0];
+                }
+                cw[0] = (a & 0xffu) | ((b & 0xffu) << 8) | ((a & 0xff00u) << 8) | ((b & 0xff00u) << 16);
+            } else {
+            const gp_u8 crow = (gp_u8)P.data + (size_t)P.uv_off + (size_t)(y >> 1) * (size_t)P.step + (size_t)x0 * SB;
             if (npx == 4) {
 #pragma unroll
                 for (int k = 0; k < SB; ++k) {
@@ -167,6 +190,7 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
                         yw[b >> 2] |= (uint32_t)yrow[b] << (8 * (b & 3));
                         cw[b >> 2] |= (uint32_t)crow[b] << (8 * (b & 3));
                     }
+            }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

@@ -96,7 +96,10 @@ def test_nv12_pointwise_whole_surface_and_crops(oracle, lname, layout, alpha, ou
         H.assert_bit_exact(g0.cpu().numpy(), ref0, what + " (interpreted)")
 
 
-@pytest.mark.parametrize("lname,layout", LAYOUTS, ids=[x[0] for x in LAYOUTS])
+ALL_LAYOUTS = LAYOUTS + [("i420", capi.YUV_I420), ("yv12", capi.YUV_YV12)]  # planar chroma: whole surfaces only (no crop views)
+
+
+@pytest.mark.parametrize("lname,layout", ALL_LAYOUTS, ids=[x[0] for x in ALL_LAYOUTS])
 @pytest.mark.parametrize("w,h", [(2, 2), (6, 4), (254, 6), (258, 2), (3840, 8)])
 def test_nv12_pointwise_sizes(oracle, lname, layout, w, h):
     """Whole surfaces of awkward sizes (one thread with 2 pixels, one ragged group, exactly full groups) -> packed fp32 RGB."""
@@ -211,14 +214,60 @@ def test_nv12_to_half_precision_tensor(oracle, lname, layout, out):
     H.assert_bit_exact(gt.cpu().numpy().view(np.uint16), ref.view(np.uint16), "interpreted")
 
 
-def test_planar_chroma_stays_interpreted():
+@pytest.mark.parametrize("lname,layout", [("i420", capi.YUV_I420), ("yv12", capi.YUV_YV12)])
+@pytest.mark.parametrize("out", ["u8", "f16", "split", "planes"])
+@pytest.mark.parametrize("alpha", [False, True])
+def test_planar_chroma_surfaces_on_the_thread_fused_kernel(oracle, lname, layout, out, alpha):
+    """I420 / YV12 (software decoders' yuv420p): two quarter-size chroma planes behind the luma, rows of step / 2 bytes -- a batch of
+    two surfaces and a default-value plane through every output form the kernel serves, pitched surfaces included."""
     import torch
     dev = torch.device("cuda:0")
-    w, h = 64, 32
-    f = cvgs.CV_32FC3
-    ts = torch.zeros((h * 3 // 2, w), dtype=torch.uint8, device=dev)
-    m = cvgs.GpuMat.from_tensor(ts, cvgs.CV_8UC1)
-    luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
-    gt = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
-    ops = [cvgs.read_nv12(luma, None, capi.YUV_FULL, capi.BT601, False, layout=capi.YUV_I420), cvgs.write(f, cvgs.GpuMat.from_tensor(gt, f))]
-    assert cvgs.kernel_name(*ops).startswith("generic")
+    w, h, pitch = 778, 22, 800  # pitched: the chroma planes use rows of pitch / 2 bytes
+    cn = 4 if alpha else 3
+    f = cvgs.make_type(cvgs.CV_32F, cn)
+    surfs = [H.random_u8((h * 3 // 2, pitch), 9500 + i + layout) for i in range(2)]
+    n = 3
+    ot = {"u8": cvgs.make_type(cvgs.CV_8U, cn), "f16": cvgs.make_type(cvgs.CV_16F, cn), "split": f, "planes": f}[out]
+    np_dt = {"u8": np.uint8, "f16": np.float16}.get(out, np.float32)
+    t_dt = {"u8": torch.uint8, "f16": torch.float16}.get(out, torch.float32)
+
+    def build(wrap, wrap_out, outs):
+        mats = []
+        for sf in surfs + surfs[:1]:
+            m = wrap(sf)
+            mats.append(cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, pitch, owner=m.owner))
+        rd = cvgs.read_nv12(mats, None, capi.YUV_LIMITED, capi.BT601, alpha, layout=layout)
+        rd.used_planes = 2
+        rd.background = cvgs._scalar([20.0, 130.5, 250.0, 7.0][:cn])
+        ops = [rd, cvgs.multiply(f, [1.1, 0.9, 1.05, 0.5][:cn]), cvgs.add(f, [-3.0, 2.0, 0.5, 1.0][:cn])]
+        if out in ("u8", "f16"):
+            return ops + [cvgs.convertTo(f, ot), cvgs.write(ot, wrap_out(outs[0], ot), (w, h))]
+        if out == "split":
+            return ops + [cvgs.split(f, wrap_out(outs[0], cvgs.CV_32FC1), (w, h))]
+        return ops + [cvgs.split(f, [[wrap_out(p, cvgs.CV_32FC1) for p in outs[1 + i * cn:1 + (i + 1) * cn]] for i in range(n)])]
+
+    shape = (n, w * h, cn) if out in ("u8", "f16") else ((n, cn * w * h) if out == "split" else (1, 1))
+    ref0 = np.zeros(shape, np_dt)
+    planes_np = [np.zeros((h, w), np.float32) for _ in range(n * cn)]
+    oracle.execute(cvgs.lower(build(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), lambda a, t: cvgs.GpuMat.from_array(a, t), [ref0] + planes_np)))
+    ts = {id(sf): torch.from_numpy(sf).to(dev) for sf in surfs}
+    g0 = torch.zeros(shape, dtype=t_dt, device=dev)
+    planes_t = [torch.zeros((h, w), dtype=torch.float32, device=dev) for _ in range(n * cn)]
+    ops = build(lambda a: cvgs.GpuMat.from_tensor(ts[id(a)], cvgs.CV_8UC1), lambda a, t: cvgs.GpuMat.from_tensor(a, t), [g0] + planes_t)
+    name = cvgs.kernel_name(*ops)
+    assert name == {"u8": "pointwise4_i420_u8", "f16": "pointwise4_i420_f16"}.get(out, "pointwise4_i420"), name
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    what = "%s %s alpha=%s via %s" % (lname, out, alpha, name)
+    if out == "planes":
+        assert any(p.any() for p in planes_np)
+        for i, (a, b) in enumerate(zip(planes_t, planes_np)):
+            H.assert_bit_exact(a.cpu().numpy(), b, what + " plane %d" % i)
+        return
+    assert ref0.any()
+    view = (lambda x: x.view(np.uint16)) if out == "f16" else (lambda x: x)
+    H.assert_bit_exact(view(g0.cpu().numpy()), view(ref0), what)
+    g0.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(view(g0.cpu().numpy()), view(ref0), what + " (interpreted)")

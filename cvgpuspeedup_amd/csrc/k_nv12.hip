@@ -66,7 +66,10 @@ __device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k,
 // (usedPlanes < BATCH) -- K1's machinery: the background value runs through the program once, pixels outside the window take it.
 // A separate instantiation: K4 is bound by its VALU work per row, and the window's selects cost the stretch-only launches 4-8 %
 // when they are compiled in (tools/k4_ar_ab.sh: cfg #3 8.6 -> 9.0 us, 50 crops 4.92 -> 5.32 us).
-template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3, bool S16 = false, bool WIN = false>
+// PL: planar chroma (I420 / YV12, software decoders' yuv420p): two (W/2) x (H/2) planes with rows of step/2 bytes behind the luma
+// plane.  The two chroma taps of a plane are ONE unaligned 2-byte load per source row (6 loads per pixel instead of 4); the
+// (U,V) pairs are then assembled in registers and everything downstream is the NV12 arithmetic, bit for bit.
+template <int NPL, class Prog, typename OT = float, int RPW = 1, int CN = 3, bool S16 = false, bool WIN = false, bool PL = false>
 __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL> a, const N12Geom g) {
     const ChainArgs& c = a.c;
     const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
         row_group = (int)blockIdx.y;
     }
     const int yuv_range = c.read.yuv_range, yuv_prim = c.read.yuv_primaries, packed = g.packed;
-    const bool vu = c.read.yuv_layout == CVGS_YUV_NV21; // wave-uniform: the chroma pair is (V,U)
+    const bool vu = c.read.yuv_layout == CVGS_YUV_NV21 || c.read.yuv_layout == CVGS_YUV_YV12; // wave-uniform: V comes first
     const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const f32x4s op0 = *(const f32x4s*)c.prog.operand[0], op1 = *(const f32x4s*)c.prog.operand[1],
@@ -178,16 +181,20 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     const uint32_t yo = (uint32_t)min(x1, P.w - 2) * kSB;
     const int ysh = (x1 * kSB - (int)yo) * 8;
     const int c1 = x1 >> 1, c2 = x2r >> 1;
-    const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4) * kSB;
-    const int ush = (2 * c1 * kSB - (int)uo) * 8;
+    // interleaved: a window of two pairs, clamped into the row; planar: a window of two samples of one chroma plane
+    const uint32_t uo = PL ? (uint32_t)min(c1, ((P.w - 1) >> 1) - 1) : (uint32_t)min(2 * c1, P.w - 4) * kSB;
+    const int ush = PL ? (c1 - (int)uo) * 8 : (2 * c1 * kSB - (int)uo) * 8;
     const bool same_pair = c2 == c1;
     const gptr_u8 base = (gptr_u8)P.data;
     const size_t step = (size_t)P.step;
     const gptr_u8 uvp = base + (size_t)P.uv_off; // crops of a surface carry their own luma -> chroma offset
+    const size_t cstep = PL ? step >> 1 : step;  // bytes per chroma row
+    const size_t plane2 = (size_t)(P.h >> 1) * cstep; // planar: the second chroma plane follows the first
 
     using ChromaWin = std::conditional_t<S16, uint64_t, uint32_t>; // two (U,V) pairs
     uint32_t vya[RPW], vyb[RPW];
     ChromaWin vua[RPW], vub[RPW];
+    uint32_t vva[RPW], vvb[RPW]; // planar chroma: the windows of the second plane
     float wya[RPW], wyb[RPW];
     bool in_y[RPW];
 #pragma unroll
@@ -210,7 +217,17 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
 #endif
         const gptr_u8 ya = K4_PIN(base + (size_t)r1 * step);
         const gptr_u8 yb = K4_PIN(base + (size_t)r2 * step);
-        const gptr_u8 ua = K4_PIN(uvp + (size_t)(r1 >> 1) * step);
+        const gptr_u8 ua = K4_PIN(uvp + (size_t)(r1 >> 1) * cstep);
+        if constexpr (PL) {
+            const gptr_u8 ub = K4_PIN(uvp + (size_t)(r2 >> 1) * cstep);
+            vya[j] = *(gptr_u16)(ya + yo);
+            vyb[j] = *(gptr_u16)(yb + yo);
+            vua[j] = *(gptr_u16)(ua + uo);
+            vub[j] = *(gptr_u16)(ub + uo);
+            vva[j] = *(gptr_u16)(K4_PIN(ua + plane2) + uo);
+            vvb[j] = *(gptr_u16)(K4_PIN(ub + plane2) + uo);
+            continue;
+        }
         if constexpr (S16) {
             vya[j] = *(gptr_u32)(ya + yo);
             vyb[j] = *(gptr_u32)(yb + yo);
@@ -253,12 +270,18 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
             const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
             const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
             uint32_t ca = vua[j], cb = vub[j];
+            if constexpr (PL) { // spread the two samples of each plane into the (first, second) pairs of an interleaved window
+                const uint32_t fa = (uint32_t)vua[j] >> ush, fb = (uint32_t)vub[j] >> ush, sa = vva[j] >> ush, sb = vvb[j] >> ush;
+                ca = (fa & 0xffu) | ((sa & 0xffu) << 8) | ((fa & 0xff00u) << 8) | ((sa & 0xff00u) << 16);
+                cb = (fb & 0xffu) | ((sb & 0xffu) << 8) | ((fb & 0xff00u) << 8) | ((sb & 0xff00u) << 16);
+            }
             if (vu) { // NV21: swap the bytes of every pair once, then everything below is NV12
                 ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
                 cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
             }
-            const uint32_t pa0 = (ca >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (ca >> 16) & 0xffffu;
-            const uint32_t pb0 = (cb >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (cb >> 16) & 0xffffu;
+            const int psh = PL ? 0 : ush; // planar: the windows were shifted before the spread
+            const uint32_t pa0 = (ca >> psh) & 0xffffu, pa1 = same_pair ? pa0 : (ca >> 16) & 0xffffu;
+            const uint32_t pb0 = (cb >> psh) & 0xffffu, pb1 = same_pair ? pb0 : (cb >> 16) & 0xffffu;
             fy[0] = (float)ya0; fy[1] = (float)ya1; fy[2] = (float)yb0; fy[3] = (float)yb1;
             fu[0] = (float)(pa0 & 0xffu); fu[1] = (float)(pa1 & 0xffu); fu[2] = (float)(pb0 & 0xffu); fu[3] = (float)(pb1 & 0xffu);
             fv[0] = (float)(pa0 >> 8); fv[1] = (float)(pa1 >> 8); fv[2] = (float)(pb0 >> 8); fv[3] = (float)(pb1 >> 8);
@@ -312,7 +335,7 @@ static N12Many& tls_many() {
     return m;
 }
 
-template <class Prog, typename OT, int RPW, int CN, bool S16, bool WIN = false>
+template <class Prog, typename OT, int RPW, int CN, bool S16, bool WIN = false, bool PL = false>
 static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g_in, hipStream_t s) {
     N12Geom g = g_in;
     const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + kK4Waves * RPW - 1) / (kK4Waves * RPW));
@@ -324,7 +347,7 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         a.c = c;
         for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
-        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
         return hipGetLastError();
     }
     const dim3 grid(col_tiles, row_groups, c.read.batch);
@@ -332,24 +355,26 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         KernArgs<8> a;
         a.c = c;
         for (int i = 0; i < 8; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<8, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     } else if (ni <= CVGS_KERNARG_PLANES) { // crop lists of a decoder surface: up to CVGS_KERNARG_PLANES descriptors in the kernel arguments
         KernArgs<CVGS_KERNARG_PLANES> a;
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     } else { // ... up to CVGS_KERNARG_PLANES_MAX in a 16 KB argument block (see cvgs_device.h: cheaper than a table for an eager call)
         KernArgs<kKernargPlanesBig> a;
         a.c = c;
         for (int i = 0; i < kKernargPlanesBig; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
-        hipLaunchKernelGGL((k4_nv12_resize<kKernargPlanesBig, Prog, OT, RPW, CN, S16, WIN>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        hipLaunchKernelGGL((k4_nv12_resize<kKernargPlanesBig, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
     }
     return hipGetLastError();
 }
 
 template <class Prog, typename OT = float>
 static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s, bool win = false) {
+    const bool pl = c.read.yuv_layout == CVGS_YUV_I420 || c.read.yuv_layout == CVGS_YUV_YV12;
     if (win) { // aspect-ratio windows / default-value planes: their own instantiations (see k4_nv12_resize)
+        if (pl) return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false, true, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false, true, true>(c, ip, ni, g, s);
         if (c.read.yuv_layout == CVGS_YUV_P010)
             return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, true, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, true, true>(c, ip, ni, g, s);
         return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false, true>(c, ip, ni, g, s);
@@ -362,6 +387,7 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     if (rpw_env && rpw_env[0] == '2' && g.cn == 3 && c.read.yuv_layout != CVGS_YUV_P010) return launch_n12_r<Prog, OT, 2, 3, false>(c, ip, ni, g, s);
     if (rpw_env && rpw_env[0] == '4' && g.cn == 3 && c.read.yuv_layout != CVGS_YUV_P010) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
 #endif
+    if (pl) return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false, false, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false, false, true>(c, ip, ni, g, s);
     if (c.read.yuv_layout == CVGS_YUV_P010)
         return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, true>(c, ip, ni, g, s);
     return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false>(c, ip, ni, g, s);
@@ -401,7 +427,6 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     }
     const ChainArgs& c = f16 ? c_cut : c_in;
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
-    if (r.yuv_layout == CVGS_YUV_I420 || r.yuv_layout == CVGS_YUV_YV12) return 0; // planar chroma: the interpreted kernel
     if (segs) {
         if (n_segs < 1 || n_segs > CVGS_MAX_CHAINS || c_in.write.data2) return 0;
     } else {

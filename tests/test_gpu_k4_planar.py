@@ -1,0 +1,173 @@
+"""Planar-chroma surfaces (I420 / YV12: software decoders' yuv420p) through the fused NV12 resize kernel K4 -- the pixel-format
+parameter of the reference's reader (fk::ReadYUV<PF>, tests/resize/test_fused_resize.cu:50-51,141-147) on the fast path: stretch
+and letterboxed resizes (include/cvGPUSpeedup.cuh:32,218-245), default-value planes, RGB- / BGR-order normalisation into planar
+fp32 / fp16 tensors, packed u8 images, alpha, every range / primaries pair, CircularTensor pushes.  Each case is compared bit for
+bit with the CPU oracle and with the interpreted kernel; the same picture stored as NV12 must give the same tensor."""
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+PLANAR = [capi.YUV_I420, capi.YUV_YV12]
+
+
+def planar_surface(w, h, seed, layout):
+    """(surface in `layout`, the same picture as NV12)."""
+    y = H.random_u8((h, w), seed)
+    u = H.random_u8((h // 2, w // 2), seed + 1)
+    v = H.random_u8((h // 2, w // 2), seed + 2)
+    s = np.zeros((h + h // 2, w), np.uint8)
+    s[:h] = y
+    first, second = (u, v) if layout == capi.YUV_I420 else (v, u)
+    q = (h // 2) * (w // 2)
+    s[h:].reshape(-1)[:q] = first.reshape(-1)
+    s[h:].reshape(-1)[q:2 * q] = second.reshape(-1)
+    nv = np.zeros_like(s)
+    nv[:h] = y
+    nv[h:, 0::2] = u
+    nv[h:, 1::2] = v
+    return s, nv
+
+
+def luma_of(wrap, surf, w, h):
+    m = wrap(surf)
+    return cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
+
+
+def run_both(oracle, build, surfs, shp, np_dt, ot, want_prefix="k4_nv12_resize", rtol=None):
+    """build(wrap, out) -> ops.  GPU fast path and interpreted path vs the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.float16: torch.float16}[np_dt]
+    ref = np.zeros(shp, np_dt)
+    oracle.execute(cvgs.lower(build(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), cvgs.GpuMat.from_array(ref, ot))))
+    ts = {id(s): torch.from_numpy(s).to(dev) for s in surfs}
+    gt = torch.zeros(shp, dtype=tdt, device=dev)
+    ops = build(lambda a: cvgs.GpuMat.from_tensor(ts[id(a)], cvgs.CV_8UC1), cvgs.GpuMat.from_tensor(gt, ot))
+    name = cvgs.kernel_name(*ops)
+    assert name.startswith(want_prefix), name
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    assert ref.any()
+    H.assert_bit_exact(gt.cpu().numpy(), ref, "fast path %s" % name)
+    gt.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(gt.cpu().numpy(), ref, "interpreted")
+    return ref, name
+
+
+@pytest.mark.parametrize("layout", PLANAR)
+@pytest.mark.parametrize("shape", [((640, 360), (213, 120)), ((640, 360), (64, 128)), ((1920, 1080), (1280, 720)), ((322, 198), (70, 66)),
+                                   ((64, 36), (200, 150)), ((6, 4), (9, 7)), ((4, 4), (64, 3)), ((130, 2), (65, 5))])
+@pytest.mark.parametrize("prog", ["bgr_norm", "rgb_norm", "plain", "u8"])
+def test_planar_stretch(oracle, layout, shape, prog):
+    (w, h), dst = shape
+    surf, nv = planar_surface(w, h, 7000 + w + h, layout)
+    f, u = cvgs.CV_32FC3, cvgs.CV_8UC3
+    norm = [cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225])]
+
+    def mk(lay, s):
+        def build(wrap, out):
+            rd = cvgs.read_nv12(luma_of(wrap, s, w, h), dst, capi.YUV_LIMITED, capi.BT709, False, layout=lay)
+            if prog == "bgr_norm":
+                return [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f)] + norm + [cvgs.split(f, out, dst)]
+            if prog == "rgb_norm":
+                return [rd] + norm + [cvgs.split(f, out, dst)]
+            if prog == "plain":
+                return [rd, cvgs.multiply(f, [0.5, 0.25, 2.0]), cvgs.split(f, out, dst)]
+            return [rd, cvgs.convertTo(f, u), cvgs.write(u, out)]
+        return build
+
+    if prog == "u8":
+        shp, dt, ot = (dst[1], dst[0], 3), np.uint8, u
+    else:
+        shp, dt, ot = (1, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1
+    want = {"bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "rgb_norm": "k4_nv12_resize_mul_sub_div", "plain": "k4_nv12_resize_interp",
+            "u8": "k4_nv12_resize_interp"}[prog]
+    ref, _ = run_both(oracle, mk(layout, surf), [surf], shp, dt, ot, want)
+    # the same picture as NV12 (the reference's own format) gives the same output
+    ref_nv = np.zeros(shp, dt)
+    oracle.execute(cvgs.lower(mk(capi.YUV_NV12, nv)(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), cvgs.GpuMat.from_array(ref_nv, ot))))
+    H.assert_bit_exact(ref, ref_nv, "planar == NV12 picture")
+
+
+@pytest.mark.parametrize("layout", PLANAR)
+@pytest.mark.parametrize("ar", [cvgs.PRESERVE_AR, cvgs.PRESERVE_AR_RN_EVEN, cvgs.PRESERVE_AR_LEFT])
+@pytest.mark.parametrize("shape", [((640, 360), (64, 64)), ((360, 640), (96, 64)), ((1920, 1080), (640, 640)), ((322, 198), (70, 70))])
+@pytest.mark.parametrize("prog", ["rgb_norm", "bgr_norm", "u8_batch"])
+def test_planar_letterbox_and_default_planes(oracle, layout, ar, shape, prog):
+    (w, h), dst = shape
+    s0, _ = planar_surface(w, h, 7100 + w, layout)
+    s1, _ = planar_surface(w, h, 7200 + w, layout)
+    f, u = cvgs.CV_32FC3, cvgs.CV_8UC3
+    n = 3
+
+    def build(wrap, out):
+        mats = [luma_of(wrap, s0, w, h), luma_of(wrap, s1, w, h), luma_of(wrap, s0, w, h)]
+        rd = cvgs.read_nv12(mats, dst, capi.YUV_LIMITED, capi.BT601, False, layout=layout)
+        rd.ar = ar
+        rd.background = cvgs._scalar([114.0, 100.5, 7.25])
+        rd.used_planes = 2
+        norm = [cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225])]
+        if prog == "rgb_norm":
+            return [rd] + norm + [cvgs.split(f, out, dst)]
+        if prog == "bgr_norm":
+            return [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f)] + norm + [cvgs.split(f, out, dst)]
+        return [rd, cvgs.convertTo(f, u), cvgs.write(u, out, dst)]
+
+    if prog == "u8_batch":
+        shp, dt, ot = (n, dst[0] * dst[1], 3), np.uint8, u
+    else:
+        shp, dt, ot = (n, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1
+    run_both(oracle, build, [s0, s1], shp, dt, ot)
+
+
+@pytest.mark.parametrize("layout", PLANAR)
+@pytest.mark.parametrize("range_", [capi.YUV_FULL, capi.YUV_LIMITED])
+@pytest.mark.parametrize("prim", [capi.BT601, capi.BT709, capi.BT2020])
+@pytest.mark.parametrize("alpha", [False, True])
+def test_planar_ranges_primaries_alpha(oracle, layout, range_, prim, alpha):
+    w, h, dst = 322, 198, (101, 77)
+    surf, _ = planar_surface(w, h, 7300, layout)
+    f = cvgs.CV_32FC4 if alpha else cvgs.CV_32FC3
+    cn = 4 if alpha else 3
+
+    def build(wrap, out):
+        rd = cvgs.read_nv12(luma_of(wrap, surf, w, h), dst, range_, prim, alpha, layout=layout)
+        return [rd, cvgs.multiply(f, [0.5, 0.25, 2.0, 1.5][:cn]), cvgs.split(f, out, dst)]
+
+    run_both(oracle, build, [surf], (1, cn * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1)
+
+
+@pytest.mark.parametrize("layout", PLANAR)
+def test_planar_fp16_tensor(oracle, layout):
+    w, h, dst = 640, 360, (224, 224)
+    surf, _ = planar_surface(w, h, 7400, layout)
+    f = cvgs.CV_32FC3
+
+    def build(wrap, out):
+        rd = cvgs.read_nv12(luma_of(wrap, surf, w, h), dst, capi.YUV_LIMITED, capi.BT709, False, layout=layout)
+        return [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]),
+                cvgs.divide(f, [0.229, 0.224, 0.225]), cvgs.convertTo(f, cvgs.CV_16FC3), cvgs.split(cvgs.CV_16FC3, out, dst)]
+
+    run_both(oracle, build, [surf], (1, 3 * dst[0] * dst[1]), np.float16, cvgs.CV_16FC1, "k4_nv12_resize_swap_mul_sub_div_f16")
+
+
+@pytest.mark.parametrize("layout", PLANAR)
+def test_planar_many_planes(oracle, layout):
+    """More planes than the small argument block holds (frames of several software decoders in one launch)."""
+    w, h, dst, n = 96, 64, (40, 24), 70
+    surfs = [planar_surface(w, h, 7500 + i, layout)[0] for i in range(4)]
+    f = cvgs.CV_32FC3
+
+    def build(wrap, out):
+        mats = [luma_of(wrap, surfs[i % 4], w, h) for i in range(n)]
+        rd = cvgs.read_nv12(mats, dst, capi.YUV_LIMITED, capi.BT709, False, layout=layout)
+        return [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]),
+                cvgs.divide(f, [0.229, 0.224, 0.225]), cvgs.split(f, out, dst)]
+
+    run_both(oracle, build, surfs, (n, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1)

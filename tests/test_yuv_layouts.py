@@ -96,7 +96,7 @@ def test_gpu_layouts_match_the_oracle(oracle, layout, dst):
     ops = chain(lambda a: cvgs.GpuMat.from_tensor(st, cvgs.CV_8UC1), surf, w, h, layout, dst, cvgs.GpuMat.from_tensor(gt, ot))
     name = cvgs.kernel_name(*ops)
     if dst is not None:
-        assert name.startswith("k4_nv12_resize" if layout <= capi.YUV_NV21 else "generic"), name
+        assert name.startswith("k4_nv12_resize"), name  # planar chroma too (tests/test_gpu_k4_planar.py)
     cvgs.executeOperations(torch.cuda.current_stream(), *ops)
     torch.cuda.synchronize()
     oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), surf, w, h, layout, dst, cvgs.GpuMat.from_array(ref, ot))))

@@ -7,14 +7,14 @@ import torch
 from cvgpuspeedup_amd import capi, cvgs
 from cvgpuspeedup_amd import workloads as W
 dev = torch.device("cuda:0"); lib = capi.load_library()
-def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0, u8_image=False):
+def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0, u8_image=False, layout=capi.YUV_NV12):
     chains=[]; keep=[]
     f3=cvgs.CV_32FC3
     for i in range(n_rot):
         surf = W.random_u8_torch((h*3//2, w), 100+i, dev)
         m = cvgs.GpuMat.from_tensor(surf, cvgs.CV_8UC1)
         luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
-        rd = cvgs.read_nv12(luma, dst, capi.YUV_LIMITED, capi.BT709, False)
+        rd = cvgs.read_nv12(luma, dst, capi.YUV_LIMITED, capi.BT709, False, layout=layout)
         rd.ar = ar
         rd.background = cvgs._scalar([114.0,114.0,114.0])
         if u8_image:  # -> BGR u8 image (thumbnail / display path): swap, saturating cast, packed pixels
@@ -55,6 +55,14 @@ def run_all():
             run("4K NV12 -> 640x640 letterbox -> RGB normalize -> NCHW", 3840,2160,(640,640), cvgs.PRESERVE_AR),
             run("4K NV12 -> 1920x1080 BGR u8 image", 3840,2160,(1920,1080), cvgs.IGNORE_AR, u8_image=True),
             run("1080p NV12 -> 640x360 BGR u8 image", 1920,1080,(640,360), cvgs.IGNORE_AR, u8_image=True),
+            # planar chroma (software decoders' yuv420p) on the same kernel, and what the interpreted kernel took for it before
+            run("1080p I420 -> 640x640 letterbox -> RGB normalize -> NCHW", 1920,1080,(640,640), cvgs.PRESERVE_AR, layout=capi.YUV_I420),
+            run("4K I420 -> 640x640 letterbox -> RGB normalize -> NCHW", 3840,2160,(640,640), cvgs.PRESERVE_AR, layout=capi.YUV_I420),
+            run("4K YV12 -> 1920x1080 BGR u8 image", 3840,2160,(1920,1080), cvgs.IGNORE_AR, u8_image=True, layout=capi.YUV_YV12),
+            run("6K I420 -> 1280x720 stretch -> RGB normalize -> NCHW", 6144,3160,(1280,720), cvgs.IGNORE_AR, n_rot=18, layout=capi.YUV_I420),
+            run("6K NV12 -> 1280x720 stretch -> RGB normalize -> NCHW", 6144,3160,(1280,720), cvgs.IGNORE_AR, n_rot=18),
+            run("1080p I420 -> 640x640 letterbox, interpreted kernel (CVGS_CHAIN_FORCE_GENERIC)", 1920,1080,(640,640), cvgs.PRESERVE_AR, flags=capi.CHAIN_FORCE_GENERIC, layout=capi.YUV_I420),
+            run("6K I420 -> 1280x720, interpreted kernel (CVGS_CHAIN_FORCE_GENERIC)", 6144,3160,(1280,720), cvgs.IGNORE_AR, n_rot=18, flags=capi.CHAIN_FORCE_GENERIC, layout=capi.YUV_I420),
             run("1080p NV12 -> 640x640 letterbox, interpreted kernel (CVGS_CHAIN_FORCE_GENERIC)", 1920,1080,(640,640), cvgs.PRESERVE_AR, flags=capi.CHAIN_FORCE_GENERIC)]
 
 

@@ -50,19 +50,6 @@ struct K1Geom {
 // chain (cvgs_execute_many; a single chain with a resident table is one segment), blockIdx.z = segment.
 template <int NPL> using K1Args = std::conditional_t<NPL == 0, KernArgsMany, KernArgs<NPL>>;
 
-// u8c3 packed pixels of a FULL 64-column tile: the wave's 192 output bytes leave as 48 dword stores instead of 192 byte
-// stores.  Lane j < 48 assembles bytes 4j..4j+3 from the pixels of lanes p0 = 4j/3 and p0+1 (wave shuffles).
-__device__ __forceinline__ void store_u8c3_tile(uint8_t* tile_row, int lane, const float* v) {
-    const uint32_t mine = sat_u8_insert(v[2], 2, sat_u8_insert(v[1], 1, sat_u8_insert(v[0], 0, 0)));
-    const int p0 = (4 * lane) / 3, o = 4 * lane - 3 * p0;
-    const uint32_t a = (uint32_t)__shfl((int)mine, min(p0, 63)), b = (uint32_t)__shfl((int)mine, min(p0 + 1, 63));
-    const uint64_t s = (uint64_t)a | ((uint64_t)b << 24);
-    if (lane < 48) {
-        typedef uint32_t u32a1 __attribute__((aligned(1)));
-        __builtin_nontemporal_store((uint32_t)(s >> (8 * o)), (u32a1*)(tile_row + 4 * lane));
-    }
-}
-
 // packed pixels / separate pitched planes: one output pixel of row y, column x, plane z
 // WIDE: the throughput regime (4 rows per wave, whole-frame outputs), where the store instruction count matters; small
 // launches are latency bound and keep the shuffle off their critical path (measured: 4K->1080p 10.8 vs 12.1 us with it,

@@ -118,7 +118,21 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
 
     // one output pixel of row y (wave-uniform row pointers; planar: non-temporal rows, packed: the generic write stage)
     auto store_px = [&](const Px& p, int depth, int cn, int y) {
-    if (packed) {
+    if constexpr (std::is_same_v<OT, uint8_t>) {
+        // packed u8 C3 images (thumbnails, display surfaces): the chain's trailing SaturateCast is the store's conversion; a full
+        // 64-column tile leaves as 48 dword stores (k_taps.hpp: store_u8c3_tile), ragged tiles as 3 bytes per lane
+        const WriteArgs& w = c.write;
+        uint8_t* row = w.kind == CVGS_WRITE_PIXEL_2D ? w.data + (size_t)y * (size_t)w.step
+                                                     : w.data + ((size_t)z * w.img_stride + (size_t)y * (size_t)W) * 3;
+        const bool full = col_tile * 64 + 63 < dst_w; // wave-uniform: every lane of the tile is alive
+        if (full) store_u8c3_tile(row + (size_t)(col_tile * 64) * 3, lane, p.v);
+        else store_packed_px<3, uint8_t>(row + (size_t)x * 3, p.v, 3);
+        if (w.kind == CVGS_WRITE_PIXEL_3D && w.data2) { // wave-uniform (CircularTensor-style second target)
+            uint8_t* row2 = w.data2 + ((size_t)z * w.img_stride2 + (size_t)y * (size_t)W) * 3;
+            if (full) store_u8c3_tile(row2 + (size_t)(col_tile * 64) * 3, lane, p.v);
+            else store_packed_px<3, uint8_t>(row2 + (size_t)x * 3, p.v, 3);
+        }
+    } else if (packed) {
         write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
     } else {
         // OT = _Float16: the chain's trailing CAST(CV_16F) is this round-to-nearest-even conversion
@@ -342,7 +356,8 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
     g.col_tiles = col_tiles;
     g.pad = 0;
     const N12Many& many = tls_many();
-    if (many.segs) {
+    constexpr bool kImage = std::is_same_v<OT, uint8_t>; // packed u8 images: never fused chains, never the 16 KB argument block
+    if constexpr (!kImage) if (many.segs) {
         KernArgsMany a;
         a.c = c;
         for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
@@ -361,7 +376,7 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         a.c = c;
         for (int i = 0; i < CVGS_KERNARG_PLANES; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
         hipLaunchKernelGGL((k4_nv12_resize<CVGS_KERNARG_PLANES, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
-    } else { // ... up to CVGS_KERNARG_PLANES_MAX in a 16 KB argument block (see cvgs_device.h: cheaper than a table for an eager call)
+    } else if constexpr (!kImage) { // ... up to CVGS_KERNARG_PLANES_MAX in a 16 KB argument block (see cvgs_device.h: cheaper than a table for an eager call)
         KernArgs<kKernargPlanesBig> a;
         a.c = c;
         for (int i = 0; i < kKernargPlanesBig; ++i) a.planes[i] = i < ni ? ip[i] : PlaneParams{};
@@ -370,27 +385,34 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
     return hipGetLastError();
 }
 
+// the channel count (3, or 4 with alpha) becomes a template argument; packed u8 images are C3 only
+template <class Prog, typename OT, bool S16, bool WIN, bool PL>
+static hipError_t launch_n12_cn(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
+    if constexpr (!std::is_same_v<OT, uint8_t>)
+        if (g.cn == 4) return launch_n12_r<Prog, OT, 1, 4, S16, WIN, PL>(c, ip, ni, g, s);
+    return launch_n12_r<Prog, OT, 1, 3, S16, WIN, PL>(c, ip, ni, g, s);
+}
+
 template <class Prog, typename OT = float>
 static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s, bool win = false) {
     const bool pl = c.read.yuv_layout == CVGS_YUV_I420 || c.read.yuv_layout == CVGS_YUV_YV12;
+    const bool s16 = c.read.yuv_layout == CVGS_YUV_P010;
     if (win) { // aspect-ratio windows / default-value planes: their own instantiations (see k4_nv12_resize)
-        if (pl) return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false, true, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false, true, true>(c, ip, ni, g, s);
-        if (c.read.yuv_layout == CVGS_YUV_P010)
-            return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, true, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, true, true>(c, ip, ni, g, s);
-        return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false, true>(c, ip, ni, g, s);
+        if (pl) return launch_n12_cn<Prog, OT, false, true, true>(c, ip, ni, g, s);
+        if (s16) return launch_n12_cn<Prog, OT, true, true, false>(c, ip, ni, g, s);
+        return launch_n12_cn<Prog, OT, false, true, false>(c, ip, ni, g, s);
     }
     // One output row per wave.  Two rows per wave were measured for whole-frame outputs (cfg #3: 14400 one-row waves need two
     // rounds of the chip's 8192 wave slots) and lost: 8.27 vs 8.08 us, and 5.29 vs 4.52 us on 50 crops -- the launch is
     // bound by the VALU work per row (~100 instructions x 14 waves per SIMD) plus the launch floor, not by residency.
 #ifdef CVGS_K4_AB_RPW
     static const char* rpw_env = getenv("CVGS_K4_RPW");
-    if (rpw_env && rpw_env[0] == '2' && g.cn == 3 && c.read.yuv_layout != CVGS_YUV_P010) return launch_n12_r<Prog, OT, 2, 3, false>(c, ip, ni, g, s);
-    if (rpw_env && rpw_env[0] == '4' && g.cn == 3 && c.read.yuv_layout != CVGS_YUV_P010) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
+    if (rpw_env && rpw_env[0] == '2' && g.cn == 3 && !s16 && !pl) return launch_n12_r<Prog, OT, 2, 3, false>(c, ip, ni, g, s);
+    if (rpw_env && rpw_env[0] == '4' && g.cn == 3 && !s16 && !pl) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
 #endif
-    if (pl) return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false, false, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false, false, true>(c, ip, ni, g, s);
-    if (c.read.yuv_layout == CVGS_YUV_P010)
-        return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, true>(c, ip, ni, g, s);
-    return g.cn == 4 ? launch_n12_r<Prog, OT, 1, 4, false>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 1, 3, false>(c, ip, ni, g, s);
+    if (pl) return launch_n12_cn<Prog, OT, false, false, true>(c, ip, ni, g, s);
+    if (s16) return launch_n12_cn<Prog, OT, true, false, false>(c, ip, ni, g, s);
+    return launch_n12_cn<Prog, OT, false, false, false>(c, ip, ni, g, s);
 }
 
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
@@ -440,6 +462,40 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     const bool packed = w.kind == CVGS_WRITE_PIXEL_2D || w.kind == CVGS_WRITE_PIXEL_3D;
     if (!planar && !packed) return 0;
     if (segs && !planar) return 0; // fused chains: planar tensors only
+
+    // packed u8 C3 images (decoder surface -> thumbnail / display image): resize -> [REORDER / MUL / ADD / SUB / DIV in float] ->
+    // CAST(CV_8U) -> write.  The trailing SaturateCast becomes the store's conversion and the store a coalesced tile.
+    bool u8img = false;
+    int u8_prog = 2; // 0: nothing in front of the cast, 1: the R<->B swap only, 2: interpreted
+    if (packed && !f16 && !segs && w.depth == CVGS_DEPTH_8U && r.out_cn == 3 && n_inline <= CVGS_KERNARG_PLANES && c.prog.n >= 1 &&
+        c.prog.opcode[c.prog.n - 1] == CVGS_OP_CAST && c.prog.aux[c.prog.n - 1] == CVGS_DEPTH_8U) {
+        u8img = true;
+        for (int k = 0; k + 1 < c.prog.n; ++k) {
+            const int op = c.prog.opcode[k];
+            const bool arith = op == CVGS_OP_MUL || op == CVGS_OP_ADD || op == CVGS_OP_SUB || op == CVGS_OP_DIV || op == CVGS_OP_REORDER || op == CVGS_OP_NOP;
+            if (!arith && !(op == CVGS_OP_CAST && c.prog.aux[k] == CVGS_DEPTH_32F)) u8img = false; // the value stays 3 floats up to the cast
+        }
+        const int swap3 = 2 | (1 << 2) | (0 << 4);
+        if (c.prog.n == 1) u8_prog = 0;
+        else if (c.prog.n == 2 && c.prog.opcode[0] == CVGS_OP_REORDER && c.prog.aux[0] == swap3) u8_prog = 1;
+    }
+    if (u8img) {
+        ChainArgs c8 = c;
+        c8.prog.n -= 1;
+        c8.prog.fast_div = 0;
+        N12Geom g8{};
+        g8.dst_w = r.dst_w; g8.dst_h = r.dst_h; g8.out_w = w.width; g8.cn = 3;
+        g8.out = w.data; g8.out_step = w.step; g8.packed = 1;
+        if (info) info->kernel = u8_prog == 0 ? "k4_nv12_resize_u8c3" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c3" : "k4_nv12_resize_interp_u8c3");
+        if (dry_run) return 1;
+        tls_many() = N12Many{nullptr, 0};
+        const bool win8 = r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h);
+        hipStream_t s8 = (hipStream_t)stream;
+        const hipError_t e8 = u8_prog == 0   ? launch_n12<ProgNone, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
+                              : u8_prog == 1 ? launch_n12<K1Prog<kOpSwapRB>, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
+                                             : launch_n12<InterpProg, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8);
+        return e8 == hipSuccess ? 1 : -(int)e8 - 1000;
+    }
 
     N12Geom g;
     g.dst_w = r.dst_w; g.dst_h = r.dst_h; g.out_w = w.width; g.cn = r.out_cn;

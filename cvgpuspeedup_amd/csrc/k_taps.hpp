@@ -279,6 +279,19 @@ __device__ __forceinline__ void st_plain(uint8_t* p, float v) { __builtin_nontem
 __device__ __forceinline__ void st_plain(uint16_t* p, float v) { __builtin_nontemporal_store((uint16_t)sat_u16_bits(v), p); }
 __device__ __forceinline__ void st_plain(int16_t* p, float v) { __builtin_nontemporal_store((int16_t)(uint16_t)sat_s16_bits(v), p); }
 
+// u8c3 packed pixels of a FULL 64-column tile: the wave's 192 output bytes leave as 48 dword stores instead of 192 byte
+// stores.  Lane j < 48 assembles bytes 4j..4j+3 from the pixels of lanes p0 = 4j/3 and p0+1 (wave shuffles).
+__device__ __forceinline__ void store_u8c3_tile(uint8_t* tile_row, int lane, const float* v) {
+    const uint32_t mine = sat_u8_insert(v[2], 2, sat_u8_insert(v[1], 1, sat_u8_insert(v[0], 0, 0)));
+    const int p0 = (4 * lane) / 3, o = 4 * lane - 3 * p0;
+    const uint32_t a = (uint32_t)__shfl((int)mine, min(p0, 63)), b = (uint32_t)__shfl((int)mine, min(p0 + 1, 63));
+    const uint64_t s = (uint64_t)a | ((uint64_t)b << 24);
+    if (lane < 48) {
+        typedef uint32_t u32a1 __attribute__((aligned(1)));
+        __builtin_nontemporal_store((uint32_t)(s >> (8 * o)), (u32a1*)(tile_row + 4 * lane));
+    }
+}
+
 // one packed pixel: a single vector store when the channel count is the compile-time one (the usual case), element
 // stores when the chain changed it (e.g. *2GRAY after the resize)
 template <int CN, typename OT>

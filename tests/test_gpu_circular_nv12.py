@@ -358,8 +358,8 @@ def test_nv12_letterbox_resize_on_k4(oracle, ar, layout, shape, prog):
     gt = torch.zeros(shp, dtype=tdt, device=dev)
     ops = build(lambda a: cvgs.GpuMat.from_tensor(ts, st), cvgs.GpuMat.from_tensor(gt, ot))
     name = cvgs.kernel_name(*ops)
-    want = {"rgb_norm": "k4_nv12_resize_mul_sub_div", "bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "u8": "k4_nv12_resize_interp",
-            "u8_batch": "k4_nv12_resize_interp"}[prog]
+    want = {"rgb_norm": "k4_nv12_resize_mul_sub_div", "bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "u8": "k4_nv12_resize_interp_u8c3",
+            "u8_batch": "k4_nv12_resize_interp_u8c3"}[prog]
     assert name == want, name
     cvgs.executeOperations(torch.cuda.current_stream(), *ops)
     torch.cuda.synchronize()

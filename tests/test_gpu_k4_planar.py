@@ -87,7 +87,7 @@ def test_planar_stretch(oracle, layout, shape, prog):
     else:
         shp, dt, ot = (1, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1
     want = {"bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "rgb_norm": "k4_nv12_resize_mul_sub_div", "plain": "k4_nv12_resize_interp",
-            "u8": "k4_nv12_resize_interp"}[prog]
+            "u8": "k4_nv12_resize_u8c3"}[prog]
     ref, _ = run_both(oracle, mk(layout, surf), [surf], shp, dt, ot, want)
     # the same picture as NV12 (the reference's own format) gives the same output
     ref_nv = np.zeros(shp, dt)
@@ -171,3 +171,46 @@ def test_planar_many_planes(oracle, layout):
                 cvgs.divide(f, [0.229, 0.224, 0.225]), cvgs.split(f, out, dst)]
 
     run_both(oracle, build, surfs, (n, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1)
+
+
+@pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_I420, capi.YUV_YV12])
+@pytest.mark.parametrize("shape", [((640, 360), (213, 120)), ((1920, 1080), (640, 360)), ((322, 198), (64, 66)), ((322, 198), (128, 5)),
+                                   ((64, 36), (200, 150)), ((3840, 2160), (1920, 1080)), ((6, 4), (63, 7))])
+@pytest.mark.parametrize("prog", ["cast", "swap_cast", "scale_cast", "swap_scale_add_cast"])
+@pytest.mark.parametrize("batch", [False, True])
+def test_u8_image_outputs(oracle, layout, shape, prog, batch):
+    """Decoder surface -> packed u8 C3 image(s) (thumbnails, display surfaces): resize -> [swap / scale in float] ->
+    SaturateCast -> write, the reference's resize -> convertTo<CV_32FC3, CV_8UC3> -> write (tests/resize/test_resize_write.cu)
+    behind its NV12 reader: the cast is the store's conversion, full tiles leave as dword stores; values beyond 0..255 saturate."""
+    (w, h), dst = shape
+    if layout in PLANAR:
+        surf = planar_surface(w, h, 7600 + w, layout)[0]
+    else:
+        surf = H.random_u8((h * 3 // 2, w), 7600 + w)
+    f, u = cvgs.CV_32FC3, cvgs.CV_8UC3
+    n = 3 if batch else 1
+
+    def build(wrap, out):
+        luma = luma_of(wrap, surf, w, h)
+        rd = cvgs.read_nv12([luma] * n if batch else luma, dst, capi.YUV_LIMITED, capi.BT709, False, layout=layout)
+        if batch:
+            rd.used_planes = 2
+            rd.background = cvgs._scalar([300.0, -4.0, 17.5])
+        ops = [rd]
+        if prog.startswith("swap"):
+            ops.append(cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f))
+        if prog == "scale_cast":
+            ops.append(cvgs.convertTo(f, u, 1.7))  # saturates the bright pixels
+        elif prog == "swap_scale_add_cast":
+            ops.append(cvgs.convertTo(f, u, 0.75, -20.5))  # and the dark ones
+        else:
+            ops.append(cvgs.convertTo(f, u))
+        return ops + [cvgs.write(u, out, dst) if batch else cvgs.write(u, out)]
+
+    shp = (n, dst[0] * dst[1], 3) if batch else (dst[1], dst[0], 3)
+    want = {"cast": "k4_nv12_resize_u8c3", "swap_cast": "k4_nv12_resize_swap_u8c3", "scale_cast": "k4_nv12_resize_interp_u8c3",
+            "swap_scale_add_cast": "k4_nv12_resize_interp_u8c3"}[prog]
+    ref, name = run_both(oracle, build, [surf], shp, np.uint8, u, want)
+    assert name == want
+    if prog == "scale_cast" and w > 6:
+        assert (ref == 255).any()

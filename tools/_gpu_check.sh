@@ -1,5 +1,6 @@
 set -x
-mkdir -p gpurun_out/r02p
-timeout 900 python -m pytest tests/test_gpu_k4_planar.py tests/test_yuv_layouts.py tests/test_gpu_circular_nv12.py tests/test_p010.py -m gpu -x -q -n 4 > gpurun_out/r02p/k4_u8_tests.txt 2>&1; tail -15 gpurun_out/r02p/k4_u8_tests.txt
-timeout 600 python tools/bench_nv12_letterbox.py > gpurun_out/r02p/k4_u8_bench.txt 2>&1; cat gpurun_out/r02p/k4_u8_bench.txt
-CVGS_FUZZ_N=20000 timeout 600 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q > gpurun_out/r02p/fuzz2.txt 2>&1; tail -3 gpurun_out/r02p/fuzz2.txt
+mkdir -p gpurun_out/r02q
+timeout 900 python -m pytest tests -m gpu -x -q -n 4 > gpurun_out/r02q/gputests.txt 2>&1; tail -2 gpurun_out/r02q/gputests.txt
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r02q/smoke.txt 2>&1; tail -1 gpurun_out/r02q/smoke.txt
+timeout 1500 bash tools/profile_round.sh r02q > gpurun_out/r02q/profile_round.log 2>&1
+cat gpurun_out/r02q/bench_unprofiled_20_5.json | cut -c1-300

@@ -109,6 +109,42 @@ static void test_fused_nv12_resize(cv::cuda::Stream& stream) {
     CHECK(same, "K4 NV12 -> BGRA resize, bit-exact vs oracle");
 }
 
+// a software decoder's planar-chroma surface (yuv420p) -> BGR u8 thumbnail: Resize<LINEAR>(fuse(ReadYUV<PF>, ConvertYUVToRGB<PF,...,float3>))
+// -> VectorReorder -> SaturateCast<float3, uchar3> -> write: the pixel-format parameter of the reference's reader
+// (tests/resize/test_fused_resize.cu:50-51) beyond NV12, on K4's u8 image mode
+template <fk::PixelFormat PF>
+static void test_fused_planar_resize_u8(cv::cuda::Stream& stream, const char* what) {
+    const uint W = 1280, H = 720;
+    const fk::Size down(426, 240); // 6 full 64-column tiles + a ragged one per row
+    cv::Mat h_yuv(H + H / 2, W, CV_8UC1);
+    fill_random(h_yuv, 5150);
+    cv::cuda::GpuMat d_yuv(h_yuv);
+    auto run = [&](uchar* base, uint pitch, uchar3* out, uint out_pitch, bool gpu) {
+        const fk::RawPtr<fk::_2D, uchar> src{base, {W, H, pitch}};
+        const auto readBack = fk::fuse(fk::Read<fk::ReadYUV<PF>>{src}, fk::Unary<fk::ConvertYUVToRGB<PF, fk::Limited, fk::bt601, false, float3>>{});
+        const auto readOp = fk::Resize<fk::INTER_LINEAR>::build(readBack, down);
+        const fk::RawPtr<fk::_2D, uchar3> dst{out, {(uint)down.width, (uint)down.height, out_pitch}};
+        const auto colorConvert = fk::Unary<fk::VectorReorder<float3, 2, 1, 0>>{};
+        const auto convertOp = fk::Unary<fk::SaturateCast<float3, uchar3>>{};
+        const auto writeOp = fk::Write<fk::PerThreadWrite<fk::_2D, uchar3>>{dst};
+        if (gpu) fk::executeOperations(stream.raw(), readOp, colorConvert, convertOp, writeOp);
+        else run_oracle(readOp, colorConvert, convertOp, writeOp);
+    };
+    cv::cuda::GpuMat d_out(down.height, down.width, CV_8UC3);
+    cv::Mat h_ref(down.height, down.width, CV_8UC3);
+    run(d_yuv.data, (uint)d_yuv.step, (uchar3*)d_out.data, (uint)d_out.step, true);
+    run(h_yuv.data, (uint)h_yuv.step, (uchar3*)h_ref.data, (uint)h_ref.step, false);
+    stream.waitForCompletion();
+    cv::Mat h;
+    d_out.download(h);
+    bool same = true, varied = false;
+    for (int y = 0; y < h.rows; ++y) {
+        same = same && bit_equal(h.ptr<uchar>(y), h_ref.ptr<uchar>(y), (size_t)h.cols * 3);
+        varied = varied || h_ref.ptr<uchar>(y)[0] != h_ref.ptr<uchar>(0)[0];
+    }
+    CHECK(same && varied, what);
+}
+
 // cfg #3 through the facade: cvtColorNV12 -> resize -> normalize -> split, ONE kernel
 static void test_nv12_facade_cfg3(cv::cuda::Stream& stream) {
     const int W = 1280, H = 720;
@@ -243,6 +279,9 @@ static void test_p010_crops_batch(cv::cuda::Stream& stream) {
 
 int main() {
     cv::cuda::Stream stream;
+    test_fused_planar_resize_u8<fk::I420>(stream, "K4 I420 -> BGR u8 thumbnail, bit-exact vs oracle");
+    test_fused_planar_resize_u8<fk::YV12>(stream, "K4 YV12 -> BGR u8 thumbnail, bit-exact vs oracle");
+    test_fused_planar_resize_u8<fk::NV21>(stream, "K4 NV21 -> BGR u8 thumbnail, bit-exact vs oracle");
     test_nv12_facade_cfg3(stream);
     test_nv12_facade_letterbox(stream);
     test_nv12_crops_batch(stream);

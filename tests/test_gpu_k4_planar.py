@@ -214,3 +214,43 @@ def test_u8_image_outputs(oracle, layout, shape, prog, batch):
     assert name == want
     if prog == "scale_cast" and w > 6:
         assert (ref == 255).any()
+
+
+@pytest.mark.parametrize("layout", PLANAR)
+@pytest.mark.parametrize("n_cams,frames_per", [(4, 3), (16, 1)])
+def test_execute_many_planar_surfaces(oracle, layout, n_cams, frames_per):
+    """Frames of several software decoders -> one NCHW tensor per camera in ONE launch (cvgs_execute_many over K4 with planar
+    chroma): bit-identical to one launch per camera and to the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h, dst = 320, 180, (64, 128)
+    f = cvgs.CV_32FC3
+    chains, outs, refs, keep = [], [], [], []
+    for cam in range(n_cams):
+        surfs = [planar_surface(w, h, 7700 + 10 * cam + i, layout)[0] for i in range(frames_per)]
+        ts = [torch.from_numpy(s).to(dev) for s in surfs]
+        ot = torch.full((frames_per, 3 * dst[0] * dst[1]), -3.0, dtype=torch.float32, device=dev)
+        ref = np.full((frames_per, 3 * dst[0] * dst[1]), -3.0, np.float32)
+
+        def chain(wrap, out):
+            mats = [luma_of(wrap, i, w, h) for i in range(frames_per)]
+            return [cvgs.read_nv12(mats, dst, capi.YUV_LIMITED, capi.BT709, False, layout=layout), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
+                    cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]), cvgs.split(f, out, dst)]
+
+        chains.append(chain(lambda i: cvgs.GpuMat.from_tensor(ts[i], cvgs.CV_8UC1), cvgs.GpuMat.from_tensor(ot, cvgs.CV_32FC1)))
+        oracle.execute(cvgs.lower(chain(lambda i: cvgs.GpuMat.from_array(surfs[i], cvgs.CV_8UC1), cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+        outs.append(ot)
+        refs.append(ref)
+        keep += ts
+    assert cvgs.kernel_name(*chains[0]).startswith("k4_nv12_resize")
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    for cam in range(n_cams):
+        assert refs[cam].std() > 0.1
+        H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "fused planar chains, camera %d" % cam)
+        outs[cam].fill_(-3.0)
+    for ops in chains:
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    for cam in range(n_cams):
+        H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "one launch per camera, camera %d" % cam)

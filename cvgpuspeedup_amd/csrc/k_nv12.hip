@@ -119,19 +119,23 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     // one output pixel of row y (wave-uniform row pointers; planar: non-temporal rows, packed: the generic write stage)
     auto store_px = [&](const Px& p, int depth, int cn, int y) {
     if constexpr (std::is_same_v<OT, uint8_t>) {
-        // packed u8 C3 images (thumbnails, display surfaces): the chain's trailing SaturateCast is the store's conversion; a full
-        // 64-column tile leaves as 48 dword stores (k_taps.hpp: store_u8c3_tile), ragged tiles as 3 bytes per lane
+        // packed u8 images (thumbnails, display surfaces): the chain's trailing SaturateCast is the store's conversion.  C3: a full
+        // 64-column tile leaves as 48 dword stores (k_taps.hpp: store_u8c3_tile), ragged tiles as 3 bytes per lane; C4 (the
+        // reference's own chain, tests/resize/test_fused_resize.cu:141-147: uchar4): one dword per lane, 256 bytes per wave
         const WriteArgs& w = c.write;
-        uint8_t* row = w.kind == CVGS_WRITE_PIXEL_2D ? w.data + (size_t)y * (size_t)w.step
-                                                     : w.data + ((size_t)z * w.img_stride + (size_t)y * (size_t)W) * 3;
-        const bool full = col_tile * 64 + 63 < dst_w; // wave-uniform: every lane of the tile is alive
-        if (full) store_u8c3_tile(row + (size_t)(col_tile * 64) * 3, lane, p.v);
-        else store_packed_px<3, uint8_t>(row + (size_t)x * 3, p.v, 3);
-        if (w.kind == CVGS_WRITE_PIXEL_3D && w.data2) { // wave-uniform (CircularTensor-style second target)
-            uint8_t* row2 = w.data2 + ((size_t)z * w.img_stride2 + (size_t)y * (size_t)W) * 3;
-            if (full) store_u8c3_tile(row2 + (size_t)(col_tile * 64) * 3, lane, p.v);
-            else store_packed_px<3, uint8_t>(row2 + (size_t)x * 3, p.v, 3);
-        }
+        auto put = [&](uint8_t* row) {
+            if constexpr (CN == 4) {
+                typedef uint32_t u32a1 __attribute__((aligned(1)));
+                const uint32_t q = sat_u8_insert(p.v[3], 3, sat_u8_insert(p.v[2], 2, sat_u8_insert(p.v[1], 1, sat_u8_insert(p.v[0], 0, 0))));
+                __builtin_nontemporal_store(q, (u32a1*)(row + (size_t)x * 4));
+            } else {
+                if (col_tile * 64 + 63 < dst_w) store_u8c3_tile(row + (size_t)(col_tile * 64) * 3, lane, p.v); // wave-uniform: every lane is alive
+                else store_packed_px<3, uint8_t>(row + (size_t)x * 3, p.v, 3);
+            }
+        };
+        put(w.kind == CVGS_WRITE_PIXEL_2D ? w.data + (size_t)y * (size_t)w.step : w.data + ((size_t)z * w.img_stride + (size_t)y * (size_t)W) * CN);
+        if (w.kind == CVGS_WRITE_PIXEL_3D && w.data2) // wave-uniform (a second target with its own image stride)
+            put(w.data2 + ((size_t)z * w.img_stride2 + (size_t)y * (size_t)W) * CN);
     } else if (packed) {
         write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
     } else {
@@ -385,11 +389,10 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
     return hipGetLastError();
 }
 
-// the channel count (3, or 4 with alpha) becomes a template argument; packed u8 images are C3 only
+// the channel count (3, or 4 with alpha) becomes a template argument
 template <class Prog, typename OT, bool S16, bool WIN, bool PL>
 static hipError_t launch_n12_cn(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
-    if constexpr (!std::is_same_v<OT, uint8_t>)
-        if (g.cn == 4) return launch_n12_r<Prog, OT, 1, 4, S16, WIN, PL>(c, ip, ni, g, s);
+    if (g.cn == 4) return launch_n12_r<Prog, OT, 1, 4, S16, WIN, PL>(c, ip, ni, g, s);
     return launch_n12_r<Prog, OT, 1, 3, S16, WIN, PL>(c, ip, ni, g, s);
 }
 
@@ -467,26 +470,37 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     // CAST(CV_8U) -> write.  The trailing SaturateCast becomes the store's conversion and the store a coalesced tile.
     bool u8img = false;
     int u8_prog = 2; // 0: nothing in front of the cast, 1: the R<->B swap only, 2: interpreted
-    if (packed && !f16 && !segs && w.depth == CVGS_DEPTH_8U && r.out_cn == 3 && n_inline <= CVGS_KERNARG_PLANES && c.prog.n >= 1 &&
-        c.prog.opcode[c.prog.n - 1] == CVGS_OP_CAST && c.prog.aux[c.prog.n - 1] == CVGS_DEPTH_8U) {
+    ChainArgs c8 = c;
+    // the reference's spelling casts first and reorders the bytes afterwards (SaturateCast<float4, uchar4> -> VectorReorder<uchar4, 2, 1, 0, 3>);
+    // a pure permutation commutes with the per-channel cast, so the cast moves to the end (bit for bit the same image)
+    if (c8.prog.n >= 2 && c8.prog.opcode[c8.prog.n - 1] == CVGS_OP_REORDER && c8.prog.opcode[c8.prog.n - 2] == CVGS_OP_CAST &&
+        c8.prog.aux[c8.prog.n - 2] == CVGS_DEPTH_8U) {
+        const int a = c8.prog.n - 2, b = c8.prog.n - 1;
+        std::swap(c8.prog.opcode[a], c8.prog.opcode[b]);
+        std::swap(c8.prog.aux[a], c8.prog.aux[b]);
+        for (int k = 0; k < 4; ++k) std::swap(c8.prog.operand[a][k], c8.prog.operand[b][k]);
+    }
+    if (packed && !f16 && !segs && w.depth == CVGS_DEPTH_8U && n_inline <= CVGS_KERNARG_PLANES && c8.prog.n >= 1 &&
+        c8.prog.opcode[c8.prog.n - 1] == CVGS_OP_CAST && c8.prog.aux[c8.prog.n - 1] == CVGS_DEPTH_8U) {
         u8img = true;
-        for (int k = 0; k + 1 < c.prog.n; ++k) {
-            const int op = c.prog.opcode[k];
+        for (int k = 0; k + 1 < c8.prog.n; ++k) {
+            const int op = c8.prog.opcode[k];
             const bool arith = op == CVGS_OP_MUL || op == CVGS_OP_ADD || op == CVGS_OP_SUB || op == CVGS_OP_DIV || op == CVGS_OP_REORDER || op == CVGS_OP_NOP;
-            if (!arith && !(op == CVGS_OP_CAST && c.prog.aux[k] == CVGS_DEPTH_32F)) u8img = false; // the value stays 3 floats up to the cast
+            if (!arith && !(op == CVGS_OP_CAST && c8.prog.aux[k] == CVGS_DEPTH_32F)) u8img = false; // the value stays out_cn floats up to the cast
         }
-        const int swap3 = 2 | (1 << 2) | (0 << 4);
-        if (c.prog.n == 1) u8_prog = 0;
-        else if (c.prog.n == 2 && c.prog.opcode[0] == CVGS_OP_REORDER && c.prog.aux[0] == swap3) u8_prog = 1;
+        const int swap_rb = r.out_cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
+        if (c8.prog.n == 1) u8_prog = 0;
+        else if (c8.prog.n == 2 && c8.prog.opcode[0] == CVGS_OP_REORDER && c8.prog.aux[0] == swap_rb) u8_prog = 1;
     }
     if (u8img) {
-        ChainArgs c8 = c;
         c8.prog.n -= 1;
         c8.prog.fast_div = 0;
         N12Geom g8{};
-        g8.dst_w = r.dst_w; g8.dst_h = r.dst_h; g8.out_w = w.width; g8.cn = 3;
+        g8.dst_w = r.dst_w; g8.dst_h = r.dst_h; g8.out_w = w.width; g8.cn = r.out_cn;
         g8.out = w.data; g8.out_step = w.step; g8.packed = 1;
-        if (info) info->kernel = u8_prog == 0 ? "k4_nv12_resize_u8c3" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c3" : "k4_nv12_resize_interp_u8c3");
+        if (info)
+            info->kernel = r.out_cn == 3 ? (u8_prog == 0 ? "k4_nv12_resize_u8c3" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c3" : "k4_nv12_resize_interp_u8c3"))
+                                         : (u8_prog == 0 ? "k4_nv12_resize_u8c4" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c4" : "k4_nv12_resize_interp_u8c4"));
         if (dry_run) return 1;
         tls_many() = N12Many{nullptr, 0};
         const bool win8 = r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h);

@@ -254,3 +254,31 @@ def test_execute_many_planar_surfaces(oracle, layout, n_cams, frames_per):
     torch.cuda.synchronize()
     for cam in range(n_cams):
         H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "one launch per camera, camera %d" % cam)
+
+
+@pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_I420, capi.YUV_YV12])
+@pytest.mark.parametrize("shape", [((1920, 1080), (640, 360)), ((322, 198), (70, 66)), ((64, 36), (200, 150)), ((6, 4), (63, 7))])
+@pytest.mark.parametrize("spelling", ["cast", "cast_then_reorder", "reorder_then_cast", "scale"])
+@pytest.mark.parametrize("cn", [3, 4])
+def test_u8_image_reference_spelling(oracle, layout, shape, spelling, cn):
+    """The reference's own fused chain (tests/resize/test_fused_resize.cu:141-147): Resize(fuse(ReadYUV, ConvertYUVToRGB<..., alpha, float4>))
+    -> SaturateCast<float4, uchar4> -> VectorReorder<uchar4, 2, 1, 0, 3> -> write.  The reorder behind the cast is a permutation of
+    bytes, so the engine moves the cast to the end and the store does it; uchar4 pixels leave as one dword per lane."""
+    (w, h), dst = shape
+    surf = planar_surface(w, h, 7800 + w, layout)[0] if layout in PLANAR else H.random_u8((h * 3 // 2, w), 7800 + w)
+    f, u = cvgs.make_type(cvgs.DEPTH_32F, cn), cvgs.make_type(cvgs.DEPTH_8U, cn)
+    swap = cvgs.COLOR_RGB2BGR if cn == 3 else cvgs.COLOR_RGBA2BGRA
+
+    def build(wrap, out):
+        rd = cvgs.read_nv12(luma_of(wrap, surf, w, h), dst, capi.YUV_FULL, capi.BT709, cn == 4, layout=layout)
+        mid = {"cast": [cvgs.convertTo(f, u)], "cast_then_reorder": [cvgs.convertTo(f, u), cvgs.cvtColor(swap, u)],
+               "reorder_then_cast": [cvgs.cvtColor(swap, f), cvgs.convertTo(f, u)], "scale": [cvgs.convertTo(f, u, 1.4, -30.0)]}[spelling]
+        return [rd] + mid + [cvgs.write(u, out)]
+
+    tag = "u8c%d" % cn
+    want = {"cast": "k4_nv12_resize_" + tag, "cast_then_reorder": "k4_nv12_resize_swap_" + tag, "reorder_then_cast": "k4_nv12_resize_swap_" + tag,
+            "scale": "k4_nv12_resize_interp_" + tag}[spelling]
+    ref, name = run_both(oracle, build, [surf], (dst[1], dst[0], cn), np.uint8, u, want)
+    assert name == want
+    if cn == 4:
+        assert (ref[..., 3] == 255).all()

@@ -137,7 +137,16 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
         if (w.kind == CVGS_WRITE_PIXEL_3D && w.data2) // wave-uniform (a second target with its own image stride)
             put(w.data2 + ((size_t)z * w.img_stride2 + (size_t)y * (size_t)W) * CN);
     } else if (packed) {
-        write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
+        const WriteArgs& w = c.write;
+        if (depth == CVGS_DEPTH_32F && cn == CN) { // wave-uniform: packed float pixels leave as ONE dwordx3 / x4 store per lane
+            float* const px = w.kind == CVGS_WRITE_PIXEL_2D ? (float*)(w.data + (size_t)y * (size_t)w.step) + (size_t)x * CN
+                                                            : (float*)w.data + ((size_t)z * w.img_stride + (size_t)y * (size_t)W + x) * CN;
+            store_packed_px<CN, float>(px, p.v, CN);
+            if (w.kind == CVGS_WRITE_PIXEL_3D && w.data2)
+                store_packed_px<CN, float>((float*)w.data2 + ((size_t)z * w.img_stride2 + (size_t)y * (size_t)W + x) * CN, p.v, CN);
+        } else {
+            write_px(c.write, c.dst_inline, x, y, z, p, depth, cn);
+        }
     } else {
         // OT = _Float16: the chain's trailing CAST(CV_16F) is this round-to-nearest-even conversion
         const uint32_t xb = (uint32_t)x * (uint32_t)sizeof(OT);

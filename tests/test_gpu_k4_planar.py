@@ -282,3 +282,26 @@ def test_u8_image_reference_spelling(oracle, layout, shape, spelling, cn):
     assert name == want
     if cn == 4:
         assert (ref[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_I420])
+@pytest.mark.parametrize("shape", [((1920, 1080), (640, 360)), ((322, 198), (70, 66)), ((6, 4), (63, 7))])
+@pytest.mark.parametrize("cn", [3, 4])
+@pytest.mark.parametrize("batch", [False, True])
+def test_packed_float_image_outputs(oracle, layout, shape, cn, batch):
+    """Decoder surface -> resize -> scale -> packed CV_32FC3 / C4 image(s): the pixel leaves as one vector store per lane."""
+    (w, h), dst = shape
+    surf = planar_surface(w, h, 7900 + w, layout)[0] if layout in PLANAR else H.random_u8((h * 3 // 2, w), 7900 + w)
+    f = cvgs.make_type(cvgs.DEPTH_32F, cn)
+    n = 3 if batch else 1
+
+    def build(wrap, out):
+        luma = luma_of(wrap, surf, w, h)
+        rd = cvgs.read_nv12([luma] * n if batch else luma, dst, capi.YUV_LIMITED, capi.BT601, cn == 4, layout=layout)
+        if batch:
+            rd.used_planes = 2
+            rd.background = cvgs._scalar([3.0, -4.0, 17.5, 9.0][:cn] + [0.0] * (4 - cn))
+        return [rd, cvgs.multiply(f, [0.5, 0.25, 2.0, 1.5][:cn]), cvgs.write(f, out, dst) if batch else cvgs.write(f, out)]
+
+    shp = (n, dst[0] * dst[1], cn) if batch else (dst[1], dst[0], cn)
+    run_both(oracle, build, [surf], shp, np.float32, f, "k4_nv12_resize_interp")

@@ -7,7 +7,7 @@ import torch
 from cvgpuspeedup_amd import capi, cvgs
 from cvgpuspeedup_amd import workloads as W
 dev = torch.device("cuda:0"); lib = capi.load_library()
-def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0, u8_image=False, layout=capi.YUV_NV12, ref_chain=False):
+def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0, u8_image=False, layout=capi.YUV_NV12, ref_chain=False, f32_image=False):
     chains=[]; keep=[]
     f3=cvgs.CV_32FC3
     for i in range(n_rot):
@@ -21,6 +21,9 @@ def run(name, w, h, dst, ar, n_rot=24, iters=100, flags=0, u8_image=False, layou
             rd = cvgs.read_nv12(luma, dst, capi.YUV_FULL, capi.BT709, True, layout=layout)
             out = torch.zeros((dst[1], dst[0], 4), dtype=torch.uint8, device=dev)
             ops=[rd, cvgs.convertTo(cvgs.CV_32FC4, cvgs.CV_8UC4), cvgs.cvtColor(cvgs.COLOR_RGBA2BGRA, cvgs.CV_8UC4), cvgs.write(cvgs.CV_8UC4, cvgs.GpuMat.from_tensor(out, cvgs.CV_8UC4))]
+        elif f32_image:  # -> packed CV_32FC3 image scaled to 0..1
+            out = torch.zeros((dst[1], dst[0], 3), dtype=torch.float32, device=dev)
+            ops=[rd, cvgs.multiply(f3,[1/255.0]*3), cvgs.write(f3, cvgs.GpuMat.from_tensor(out, f3))]
         elif u8_image:  # -> BGR u8 image (thumbnail / display path): swap, saturating cast, packed pixels
             out = torch.zeros((dst[1], dst[0], 3), dtype=torch.uint8, device=dev)
             ops=[rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f3), cvgs.convertTo(f3, cvgs.CV_8UC3), cvgs.write(cvgs.CV_8UC3, cvgs.GpuMat.from_tensor(out, cvgs.CV_8UC3))]
@@ -62,6 +65,8 @@ def run_all():
             run("reference chain: 1080p NV12 -> 640x360 BGRA u8 (float4 -> SaturateCast -> VectorReorder -> write)", 1920,1080,(640,360), cvgs.IGNORE_AR, ref_chain=True),
             run("reference chain: 4K NV12 -> 1920x1080 BGRA u8", 3840,2160,(1920,1080), cvgs.IGNORE_AR, ref_chain=True),
             run("reference chain, interpreted kernel: 1080p NV12 -> 640x360 BGRA u8", 1920,1080,(640,360), cvgs.IGNORE_AR, ref_chain=True, flags=capi.CHAIN_FORCE_GENERIC),
+            run("4K NV12 -> 1920x1080 packed fp32 RGB image (x 1/255)", 3840,2160,(1920,1080), cvgs.IGNORE_AR, f32_image=True),
+            run("1080p NV12 -> 640x360 packed fp32 RGB image (x 1/255)", 1920,1080,(640,360), cvgs.IGNORE_AR, f32_image=True),
             # planar chroma (software decoders' yuv420p) on the same kernel, and what the interpreted kernel took for it before
             run("1080p I420 -> 640x640 letterbox -> RGB normalize -> NCHW", 1920,1080,(640,640), cvgs.PRESERVE_AR, layout=capi.YUV_I420),
             run("4K I420 -> 640x640 letterbox -> RGB normalize -> NCHW", 3840,2160,(640,640), cvgs.PRESERVE_AR, layout=capi.YUV_I420),

@@ -122,9 +122,25 @@ constexpr int SD_NV12 = 64, SD_P010 = 65, SD_I420 = 66; // SD_I420: planar chrom
 template <int SD> constexpr bool is_yuv_sd = SD == SD_NV12 || SD == SD_P010 || SD == SD_I420;
 template <int SD> constexpr int src_elem_bytes = (SD == CVGS_DEPTH_8U || SD == CVGS_DEPTH_8S) ? 1 : ((SD == CVGS_DEPTH_16U || SD == CVGS_DEPTH_16S) ? 2 : 4);
 
+// The thread's 4 work pixels travel to the write stage BY VALUE.  Round 2 passed `const Px (&)[4]`: after inlining, LLVM kept
+// part of the array in memory (SROA gave up on a <4 x float> load that overlapped two pixels), AMDGPUPromoteAlloca moved
+// those 24 bytes per thread into LDS for CN = 3 (+6 KB per workgroup, and the kernel started reading the dispatch packet
+// for its linear thread id) and into SCRATCH for CN = 4 -- +20..25 us on every launch of these kernels
+// (profiles/r02_k vs r02_o).  tests/test_kernel_resources.py now fails the CPU suite on scratch / promoted allocas.
+struct Px4 {
+    Px p[4];
+};
 template <int CN, typename OT>
-__device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, const Px (&px)[4], int cn, int bx, int x0, int y, int z, int npx,
+__device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, const Px4 px4, int cn, int bx, int x0, int y, int z, int npx,
                                           int wave, int lane, int sh);
+__device__ __forceinline__ Px4 px4_of(const Px (&px)[4]) {
+    Px4 q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) q.p[i].v[ch] = px[i].v[ch];
+    return q;
+}
 
 // One thread's work: pixels x0..x0+3 of row y of plane z.  (bx, by) = the 256-pixel column group and the 4-row group.
 // SD = source depth (8U is the hot one; the reference sweeps its pointwise chains over 8S/16U/16S/32S/32F as well,
@@ -216,7 +232,7 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
                 for (int ch = 0; ch < 4; ++ch) px[i].v[ch] = ch < CN ? c.read.bg[ch] : 0.f;
         }
         Prog::run4(c.prog, px, depth, cn);
-        pw4_write<CN, OT>(c, g, px, cn, bx, x0, y, z, npx, wave, lane, sh);
+        pw4_write<CN, OT>(c, g, px4_of(px), cn, bx, x0, y, z, npx, wave, lane, sh);
         return;
     }
     // ---- read 4 pixels: 4*CN elements = NDW dwords, one wide load ----
@@ -252,14 +268,15 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
         }
     }
     Prog::run4(c.prog, px, depth, cn);
-    pw4_write<CN, OT>(c, g, px, cn, bx, x0, y, z, npx, wave, lane, sh);
+    pw4_write<CN, OT>(c, g, px4_of(px), cn, bx, x0, y, z, npx, wave, lane, sh);
 }
 
 // ---- the write stage of pw4_body: 4 pixels of row y, plane z ----
 template <int CN, typename OT>
-__device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, const Px (&px)[4], int cn, int bx, int x0, int y, int z, int npx,
+__device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, const Px4 px4, int cn, int bx, int x0, int y, int z, int npx,
                                           int wave, int lane, int sh) {
     const int W = g.w;
+    const Px (&px)[4] = px4.p;
     if (g.packed == 2) {
         // cvGS::split(std::vector<GpuMat>) / SplitWrite<_2D>: cn pitched planes per batch element (the reference's
         // tests/read/test_read_x_split.cu chain): the planar stores below, each plane with its own base and pitch

@@ -302,7 +302,15 @@ __device__ __forceinline__ void store_packed_px(OT* px, const float* v, int cn) 
             typedef vf vfu __attribute__((aligned(4)));
             vf q;
 #pragma unroll
-            for (int k = 0; k < CN; ++k) q[k] = v[k];
+            for (int k = 0; k < CN; ++k) {
+                // The empty asm pins each channel in a VGPR before the vector is assembled.  Without it LLVM folds the four reads
+                // into ONE <4 x float> load of the caller's Px; next to the interpreter's integer-typed accesses of the same
+                // slots (CV_32S values travel as raw bits) that whole-array access keeps the pixel in SCRATCH (K4's interpreted
+                // C4 kernels: 32 / 48 bytes per lane; tools/kernel_resources.py).  No instruction is emitted for it.
+                float e = v[k];
+                asm("" : "+v"(e));
+                q[k] = e;
+            }
             __builtin_nontemporal_store(q, (vfu*)px); // global_store_dwordx3 / x4
             return;
         } else if constexpr (std::is_same_v<OT, _Float16>) {

@@ -546,6 +546,14 @@ def extra_sweeps(dev, a):
         import bench_nv12_letterbox  # decoder surface -> 640x640 detector input, stretched / letterboxed (K4)
         out["nv12_full_resolution"] = bench_nv12_full.run_all(iters=40)
         out["nv12_detector_input"] = bench_nv12_letterbox.run_all()
+        # perf gate: the reference's own test chains at its sizes + the configs above against the committed
+        # per-chain ceilings (tools/perf_ceilings.json); "over" lists every chain slower than its ceiling
+        import bench_reference_tests
+        import perf_gate
+        ref_rows = bench_reference_tests.run_all(verbose=False)
+        out["reference_test_chains"] = [{"test": r["test"], "kernel": r["kernel"], "us": r["us"], "frac_of_8TBs": r["frac_of_8TBs"]} for r in ref_rows]
+        v = perf_gate.check(ref_rows + out["other_configs"])
+        out["perf_gate"] = {"pass": v["pass"], "checked": v["checked"], "over": v["over"], "new": v["new"]}
     except Exception as ex:  # extras must never break the headline line
         out["error"] = repr(ex)
     return out

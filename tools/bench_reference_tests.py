@@ -28,6 +28,8 @@ TORCH = {"8U": torch.uint8, "8S": torch.int8, "16U": torch.int16, "16S": torch.i
 W4K, H4K = W.FRAME_4K
 dev = torch.device("cuda:0")
 lib = None
+ROWS = []       # every report() row of this process (tools/perf_gate.py reads it)
+VERBOSE = True
 
 
 def rand(h, w, cn, depth):
@@ -62,8 +64,11 @@ def report(name, make, alg_bytes, bytes_per_set, flags=0):
         chains.append(cvgs.lower(ops, flags))
         keep.append(k)
     t = timed(chains)
-    print(json.dumps({"test": name, "kernel": cvgs.kernel_name(*ops, flags=flags), "us": round(t * 1e6, 2), "GB_per_s": round(alg_bytes / t / 1e9, 1),
-                      "frac_of_8TBs": round(alg_bytes / t / 8e12, 4)}), flush=True)
+    row = {"test": name, "kernel": cvgs.kernel_name(*ops, flags=flags), "us": round(t * 1e6, 2), "GB_per_s": round(alg_bytes / t / 1e9, 1),
+           "frac_of_8TBs": round(alg_bytes / t / 8e12, 4)}
+    ROWS.append(row)
+    if VERBOSE:
+        print(json.dumps(row), flush=True)
 
 
 def read_x_write(depth, cn):
@@ -164,7 +169,11 @@ def warp(size=(420, 420)):
     report("warp perspective 8UC3 %dx%d -> same size, fk::Cast (launch-bound)" % size, make, size[0] * size[1] * 6, size[0] * size[1] * 6)
 
 
-if __name__ == "__main__":
+def run_all(verbose=True):
+    """Every chain of the audit; returns the rows (also printed as JSON lines when verbose)."""
+    global lib, VERBOSE
+    VERBOSE = verbose
+    del ROWS[:]
     lib = capi.load_library()
     torch.cuda.set_device(0)
     for depth, cn in (("8U", 1), ("8U", 3), ("8U", 4), ("8S", 3), ("16U", 2), ("16S", 4), ("32S", 3), ("32F", 1), ("32F", 3)):
@@ -183,3 +192,8 @@ if __name__ == "__main__":
     for depth, cn in (("8U", 3), ("8U", 4), ("16U", 3), ("16S", 4)):
         resize_x_split(depth, cn)
     warp()
+    return list(ROWS)
+
+
+if __name__ == "__main__":
+    run_all()

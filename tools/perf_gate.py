@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""GPU perf gate: ~60 chains against committed per-chain ceilings (tools/perf_ceilings.json, microseconds per launch / update).
+
+Round 2 shipped a 1.4-7x slowdown of one kernel family with every bit-exactness test green.  The static half of
+the answer is tests/test_kernel_resources.py (CPU, metadata of the built kernels); this is the measured half: the reference's
+own test chains at the reference's sizes (tools/bench_reference_tests.py), BASELINE's cfg #3 / #4 and the decode-side batches
+(tools/bench_more.py) and the headline (bench.py's clock) are timed and compared with the ceilings -- the best figure a
+round's profile set recorded + 12 % (boxes of the pool differ by 2-5 %).  Exit code 1 and an "over" list when any chain is
+slower than its ceiling; chains missing from the table are reported as "new" (regenerate with --write on purpose).
+
+  python tools/perf_gate.py                  # run on the GPU box, print a JSON verdict, exit 0 / 1
+  python tools/perf_gate.py --write          # measure and REWRITE the ceilings (measured x 1.12)
+  python tools/perf_gate.py --rows f.jsonl   # gate rows measured elsewhere (JSON lines with test|config and us*)
+bench.py's extras call check() on the rows they measured anyway, so the driver's BENCH line carries the verdict too."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TABLE = os.path.join(ROOT, "tools", "perf_ceilings.json")
+SLACK = 1.12
+
+
+def key_us(row):
+    """(name, microseconds) of a row from bench_reference_tests / bench_more / bench.py"""
+    name = row.get("test") or row.get("config") or row.get("name")
+    for k in ("us", "us_per_update", "us_per_launch", "us_per_step"):
+        if k in row:
+            return name, float(row[k])
+    return name, None
+
+
+def check(rows, table=None):
+    table = table if table is not None else json.load(open(TABLE))
+    over, new, ok = [], [], 0
+    for r in rows:
+        name, us = key_us(r)
+        if name is None or us is None:
+            continue
+        ceil = table.get(name)
+        if ceil is None:
+            new.append(name)
+        elif us > ceil:
+            over.append({"chain": name, "us": us, "ceiling_us": ceil})
+        else:
+            ok += 1
+    return {"checked": ok + len(over), "over": over, "new": new, "pass": not over}
+
+
+def measure_all():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch
+    import bench_more
+    import bench_reference_tests
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    rows = bench_reference_tests.run_all(verbose=False)
+    torch.cuda.empty_cache()
+    torch.cuda.set_stream(torch.cuda.Stream())
+    rows += bench_more.run_all(dev, iters=60)
+    torch.cuda.empty_cache()
+    # the headline on bench.py's own clock
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-extra"], capture_output=True, text=True)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if line:
+        j = json.loads(line[-1])
+        rows.append({"name": "headline cfg2b 50 crops, one launch per step (bench.py clock)", "us_per_step": j["timing"]["step_us_median"]})
+    return rows
+
+
+def main(argv):
+    write = "--write" in argv
+    if "--rows" in argv:
+        rows = [json.loads(l) for l in open(argv[argv.index("--rows") + 1]) if l.startswith("{")]
+    else:
+        rows = measure_all()
+    if write:
+        table = {}
+        for r in rows:
+            name, us = key_us(r)
+            if name and us:
+                table[name] = round(us * SLACK, 2)
+        with open(TABLE, "w") as f:
+            json.dump(table, f, indent=0, sort_keys=True)
+        print("wrote %d ceilings to %s" % (len(table), TABLE))
+        return 0
+    v = check(rows)
+    v["rows"] = [dict(zip(("chain", "us"), key_us(r))) for r in rows]
+    print(json.dumps(v))
+    return 0 if v["pass"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

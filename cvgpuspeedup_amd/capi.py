@@ -107,6 +107,14 @@ SYMBOLS = [
     ("cvgs_circular_updates", C.c_int64, [C.c_void_p]),
     ("cvgs_circular_destroy", C.c_int, [C.c_void_p]),
     ("cvgs_stream_copy", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("cvgs_queue_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_double, C.c_uint32]),
+    ("cvgs_queue_submit", C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(C.c_uint64)]),
+    ("cvgs_queue_submit_many", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(ChainDesc)), C.c_int32, C.POINTER(C.c_uint64)]),
+    ("cvgs_queue_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_double]),
+    ("cvgs_queue_stream_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("cvgs_queue_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("cvgs_queue_profile", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("cvgs_queue_destroy", C.c_int, [C.c_void_p]),
     ("cvgs_range_push", None, [C.c_char_p]),
     ("cvgs_range_pop", None, []),
 ]
@@ -148,7 +156,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.cvgs_abi_version() != 3:
+    if lib.cvgs_abi_version() != 4:
         raise ImportError("libcvgs_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1130,6 +1130,92 @@ int cvgs_circular_destroy(cvgs_circular_t ct) {
     return CVGS_OK;
 }
 
+// ---- device-side descriptor queue ------------------------------------------------------------------------------------
+struct cvgs_queue_s {
+    cvgs::Queue* q;
+    int device;
+};
+
+int cvgs_queue_create(cvgs_queue_t* out, int32_t device, int32_t depth, double idle_us, uint32_t flags) {
+    if (!out) return fail(CVGS_ERR_INVALID, "null queue handle");
+    if (depth < 0 || depth > 256) return fail(CVGS_ERR_INVALID, "queue depth must be in [0, 256]");
+    DeviceGuard guard;
+    if (int rc = guard.enter(device)) return rc;
+    cvgs::Queue* q = nullptr;
+    std::string err;
+    if (cvgs::queue_create(&q, device, depth, flags, idle_us, err)) return fail(CVGS_ERR_HIP, err);
+    *out = new cvgs_queue_s{q, device};
+    return CVGS_OK;
+}
+
+static int queue_submit_one(cvgs_queue_t h, const cvgs_chain_desc* chain, uint64_t* ticket) {
+    Lowered L;
+    int rc = lower(chain, false, L);
+    if (rc) return rc;
+    if (L.uses_64f || L.mirrors.n > 0 || is_warp(L.args.read.kind) || (chain->flags & CVGS_CHAIN_FORCE_GENERIC))
+        return fail(CVGS_ERR_UNSUPPORTED, "queue: not a chain the server takes");
+    std::string err;
+    rc = cvgs::queue_submit(h->q, L.args, L.planes.data(), (int)L.planes.size(), ticket, err);
+    if (rc == 1) return fail(CVGS_ERR_UNSUPPORTED, err);
+    if (rc) return fail(CVGS_ERR_HIP, err);
+    return CVGS_OK;
+}
+
+int cvgs_queue_submit(cvgs_queue_t h, const cvgs_chain_desc* chain, uint64_t* ticket) {
+    if (!h) return fail(CVGS_ERR_INVALID, "null queue");
+    DeviceGuard guard;
+    if (int rc = guard.enter(h->device)) return rc;
+    return queue_submit_one(h, chain, ticket);
+}
+
+int cvgs_queue_submit_many(cvgs_queue_t h, const cvgs_chain_desc* const* chains, int32_t n, uint64_t* last_ticket) {
+    if (!h || !chains || n < 1) return fail(CVGS_ERR_INVALID, "null queue / no chains");
+    DeviceGuard guard;
+    if (int rc = guard.enter(h->device)) return rc;
+    uint64_t t = 0;
+    for (int32_t i = 0; i < n; ++i)
+        if (int rc = queue_submit_one(h, chains[i], &t)) return rc;
+    if (last_ticket) *last_ticket = t;
+    return CVGS_OK;
+}
+
+int cvgs_queue_wait(cvgs_queue_t h, uint64_t ticket, double timeout_s) {
+    if (!h) return fail(CVGS_ERR_INVALID, "null queue");
+    std::string err;
+    const int rc = cvgs::queue_wait(h->q, ticket, timeout_s, err);
+    if (rc == 1) return fail(CVGS_ERR_INVALID, err);
+    if (rc) return fail(CVGS_ERR_HIP, err);
+    return CVGS_OK;
+}
+
+int cvgs_queue_stream_wait(cvgs_queue_t h, uint64_t ticket, cvgs_stream_t stream) {
+    if (!h) return fail(CVGS_ERR_INVALID, "null queue");
+    std::string err;
+    if (cvgs::queue_stream_wait(h->q, ticket, stream, err)) return fail(CVGS_ERR_HIP, err);
+    return CVGS_OK;
+}
+
+int cvgs_queue_stats(cvgs_queue_t h, uint64_t* out8) {
+    if (!h || !out8) return fail(CVGS_ERR_INVALID, "null queue / output");
+    cvgs::queue_stats(h->q, out8);
+    return CVGS_OK;
+}
+
+int cvgs_queue_profile(cvgs_queue_t h, uint64_t* out16) {
+    if (!h || !out16) return fail(CVGS_ERR_INVALID, "null queue / output");
+    cvgs::queue_prof(h->q, out16);
+    return CVGS_OK;
+}
+
+int cvgs_queue_destroy(cvgs_queue_t h) {
+    if (!h) return CVGS_OK;
+    DeviceGuard guard;
+    (void)guard.enter(h->device);
+    cvgs::queue_destroy(h->q);
+    delete h;
+    return CVGS_OK;
+}
+
 int cvgs_stream_copy(void* dst, const void* src, size_t bytes, cvgs_stream_t stream) {
     if (!dst || !src) return fail(CVGS_ERR_INVALID, "null pointer");
     if (bytes == 0) return CVGS_OK;

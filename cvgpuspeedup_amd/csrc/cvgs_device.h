@@ -6,6 +6,8 @@
 
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/cvgs_hip.h"
 
 namespace cvgs {
@@ -198,5 +200,18 @@ int launch_plane_copies(const CopyJob* jobs, int n_jobs, size_t bytes, void* str
 // returns 1 if it took the update, 0 if the chain / layout is not eligible, <0 on error
 int launch_circular_push(const ChainArgs& c, const PlaneParams& plane, const CopyJob* jobs, int n_jobs, size_t plane_bytes,
                          uint32_t chain_flags, void* stream);
+
+
+// ---- device-side descriptor queue (k_queue.hip): K1 batches served by a resident grid, no launch per batch ----------------
+struct Queue;
+int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle_us, std::string& err);
+// 0 = queued (ticket = batch number), 1 = this chain is not one the server takes (use cvgs_execute), < 0 = error
+int queue_submit(Queue* q, const ChainArgs& c, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err);
+int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err);
+int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err);
+void queue_stats(Queue* q, uint64_t* out8);
+void queue_prof(Queue* q, uint64_t* out16); // instrumentation of the last retired server
+void* queue_stream(Queue* q);
+int queue_destroy(Queue* q);
 
 } // namespace cvgs

@@ -31,17 +31,6 @@ namespace cvgs {
 hipError_t k1_launch_planar_c3(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s);
 hipError_t k1_launch_planar_c4(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s);
 
-// program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
-static int classify_program(const ProgArgs& p, int cn) {
-    if (cn < 3) return (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) ? 1 : 2;
-    const int swap = cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
-    if (p.n == 4 && p.opcode[0] == CVGS_OP_REORDER && p.aux[0] == swap && p.opcode[1] == CVGS_OP_MUL &&
-        p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV)
-        return 0;
-    if (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) return 1;
-    return 2;
-}
-
 int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors,
               const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info) {
     const ReadArgs& r = c_in.read;
@@ -109,7 +98,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if (rpw_env) rpw = atoi(rpw_env) >= 4 ? 4 : (atoi(rpw_env) == 2 ? 2 : 1);
 
     const bool table = r.table != nullptr;
-    const int prog_id = classify_program(c.prog, r.cn);
+    const int prog_id = k1_classify_program(c.prog, r.cn);
     if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));

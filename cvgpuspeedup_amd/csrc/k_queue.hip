@@ -1,0 +1,994 @@
+// k_queue.hip -- the device-side descriptor queue: K1 batches WITHOUT one serialised launch per batch.
+//
+// Why (DESIGN.md 4 "the 50-crop floor"): a 50-crop K1 launch moves 9 MB behind a ~1.8 us launch/drain
+// boundary, and all 6400 waves of one launch are in the same phase at the same time -- the load burst, then the store burst.
+// 16 frames fused into one launch run at 2.4 us per frame, one launch per frame at 4.4 us.  The reference's call shape is one
+// executeOperations per frame (include/cvGPUSpeedup.cuh:464-473); keeping that shape while removing the boundary needs a
+// different submission path: a resident "server" grid that takes batch descriptors from a ring and lets batch k+1's loads
+// overlap batch k's stores, because its waves move from batch to batch without any grid-wide barrier.
+//
+// Protocol (hand-offs follow the guide's recipe R1: write-through payload, drained, then ONE flag word; pollers use relaxed
+// loads; nothing depends on dispatch order or XCD placement):
+//   host    cvgs_queue_submit lowers the chain (cvgs_execute's validation and double-precision geometry) and writes the batch's
+//           slot + its index entry STRAIGHT INTO DEVICE MEMORY through the PCIe BAR (write-combined stores, ~0.2 us per slot;
+//           tools/probes/bar_probe.cpp -- probed at create, staged through a copy kernel where the BAR is not mapped), then
+//           the queue's tail word.  The control block / ring / index live in UNCACHED device memory, so no device cache can
+//           hold a stale copy of what the host rewrites.
+//   worker  4 independent waves per workgroup, 4 G in all; worker w owns the tasks T = w (mod 4 G) of a cumulative task
+//           numbering (static: no dequeue atomics); a task = 16 output rows x 64 columns of one crop.  Batches are consecutive
+//           task ranges, so they interleave over the whole chip and batch k+1 starts while batch k's stores drain.  A worker
+//           finds the batch that holds T with ONE wave-wide load of a 64-entry window of the batch index.  After a task it
+//           drains its write-through stores and bumps the batch's arrival counter; the LAST arrival publishes the batch's
+//           completion flag (device word for hipStreamWaitValue64, host word for cvgs_queue_wait).
+//   janitor (workgroup 0, one wave) retires the grid after `idle_us` without work (Dekker hand-shake with the host on words in
+//           HOST memory: PCIe ordering makes the device's state store visible before its re-read of the host's tail), and
+//           trips a watchdog when a batch makes no progress -- the server never outlives its work and cannot hang a box.
+// Stores are sc1 WRITE-THROUGH 16-byte vectors: the lane = column register layout is transposed 4x4 inside lane quads (two
+// DPP rounds) so that a lane owns 4 consecutive columns of ONE row -- a dword-per-lane sc1 store is one fabric write per lane
+// (MI355X_MICROARCH.md "stores of each flavour").  Tap loads are sc1 too: the server outlives kernel boundaries, so its
+// L1 / L2 never see the invalidate a kernel start performs; agent-coherent loads never serve a stale copy of a source buffer
+// the caller has rewritten between two submits (tests/test_gpu_queue.py rewrites one).
+#include <immintrin.h>
+#include <setjmp.h>
+#include <signal.h>
+
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "k_taps.hpp"
+
+namespace cvgs {
+
+constexpr int kQSlotBytes = 4096;   // one batch: 256 B of parameters, planes from byte 512
+constexpr int kQPlanesOff = 512;
+constexpr int kQMaxPlanes = (kQSlotBytes - kQPlanesOff) / (int)sizeof(PlaneParams); // 74
+constexpr int kQMaxRing = 256;
+constexpr int kQRowsPerWave = 4, kQWaves = 4, kQRowsPerTask = 16;
+constexpr int kQSubOff = 256;      // 16 cumulative sub-counter targets (8 bytes each) behind the parameters
+constexpr int kQSubs = 16;         // arrival sub-counters per slot: task T arrives at sub-counter T % 16
+constexpr int kQCtrStride = 16;    // counters are 128 bytes (16 words) apart
+
+// dwords 0..63 of a slot; a worker wave reads them with ONE wave-wide dword load and picks fields with v_readlane
+struct QParams {
+    uint64_t stamp;     // batch number + 1
+    uint64_t task_base; // cumulative index of the batch's first task
+    uint32_t n_tasks, tiles_per_plane, col_tiles, n_planes;
+    uint32_t used, dst_w, dst_h, out_w;
+    uint32_t cn, swap, fast_div, rows_per_task; // rows_per_task: 4 (shallow queue: latency) or 16 (deep queue: throughput)
+    float mul[4], sub[4], div[4], rdiv[4], bg[4];
+    int64_t img_stride, ch_stride; // output elements
+    uint64_t out, out_bytes;
+    uint64_t arrive_target;        // value of the slot's TOP arrival counter when the batch's last sub-counter has filled
+    uint32_t pad[18];
+};
+static_assert(sizeof(QParams) == 256, "QParams is one wave-wide dword load");
+enum { QD_STAMP = 0, QD_TASK_BASE = 2, QD_N_TASKS = 4, QD_TPP = 5, QD_COL_TILES = 6, QD_N_PLANES = 7, QD_USED = 8, QD_DST_W = 9, QD_DST_H = 10,
+       QD_OUT_W = 11, QD_CN = 12, QD_SWAP = 13, QD_FAST_DIV = 14, QD_ROWS_PER_TASK = 15, QD_MUL = 16, QD_SUB = 20, QD_DIV = 24, QD_RDIV = 28, QD_BG = 32,
+       QD_IMG_STRIDE = 36, QD_CH_STRIDE = 38, QD_OUT = 40, QD_OUT_BYTES = 42, QD_ARRIVE_TARGET = 44 };
+
+// The batch index: one 32-byte entry per ring slot, rewritten by the host while workers may be looking: every 8-byte word is
+// written atomically, and `check` ties the four words together (a torn entry is simply not a candidate).
+struct QIndex {
+    uint64_t end_task;  // first task index BEYOND the batch (tasks are numbered cumulatively over batches)
+    uint64_t stamp;     // batch number + 1 (0 = never written)
+    uint32_t n_tasks, tiles_per_plane;
+    uint32_t n_planes, check;
+};
+static_assert(sizeof(QIndex) == 32, "QIndex layout");
+__host__ __device__ inline uint32_t q_index_check(uint64_t end_task, uint64_t stamp, uint32_t n_tasks, uint32_t tpp, uint32_t n_planes) {
+    uint64_t h = end_task * 0x9E3779B97F4A7C15ull ^ (stamp + 0x632BE59BD9B4E019ull) * 0xD6E8FEB86659FD93ull;
+    h ^= ((uint64_t)n_tasks << 32 | tpp) * 0xA24BAED4963EE407ull ^ n_planes;
+    return (uint32_t)(h >> 32) ^ (uint32_t)h;
+}
+
+struct alignas(128) QLine { // one word per 128-byte line
+    uint64_t v;
+    uint64_t pad[15];
+};
+struct QDevCtl {   // UNCACHED device memory; `tail` is written by the host through the BAR (or by the staging kernel)
+    QLine tail;     // batches published
+    QLine stop_gen; // == the launch's generation: every workgroup of that launch returns
+};
+enum { QS_IDLE = 0, QS_RUNNING = 1, QS_EXITING = 2, QS_EXITED = 3 };
+struct QHostCtl {  // pinned host memory: the words of the retirement hand-shake, errors, instrumentation
+    QLine tail;     // host -> janitor: batches submitted (the copy the Dekker hand-shake reads)
+    QLine state;    // QS_*
+    QLine stop_req; // host -> janitor: destroy
+    QLine error;    // device -> host: 1 = stalled (watchdog), 2 = protocol violation
+    QLine stat_rounds, stat_launch_ticks;
+    uint64_t prof[32]; // instrumentation of the last server (100 MHz ticks / counts), see queue_prof
+};
+
+typedef __attribute__((address_space(1))) uint64_t* g_u64;
+typedef __attribute__((address_space(1))) uint32_t* g_u32;
+#define Q_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define Q_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+__device__ __forceinline__ uint64_t q_ld(const uint64_t* p) { return __hip_atomic_load((g_u64)p, Q_AGENT); }
+__device__ __forceinline__ void q_st(uint64_t* p, uint64_t v) { __hip_atomic_store((g_u64)p, v, Q_AGENT); }
+__device__ __forceinline__ uint64_t q_ld_sys(const uint64_t* p) { return __hip_atomic_load((g_u64)p, Q_SYSTEM); }
+__device__ __forceinline__ void q_st_sys(uint64_t* p, uint64_t v) { __hip_atomic_store((g_u64)p, v, Q_SYSTEM); }
+// a wave-uniform value the compiler cannot prove uniform (it came through a vector load): pin it into SGPRs
+__device__ __forceinline__ uint32_t q_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t q_uni(uint64_t v) { return (uint64_t)q_uni((uint32_t)v) | ((uint64_t)q_uni((uint32_t)(v >> 32)) << 32); }
+__device__ __forceinline__ uint64_t q_ldu(const uint64_t* p) { return q_uni(__hip_atomic_load((g_u64)p, Q_AGENT)); }
+__device__ __forceinline__ uint64_t q_ldu_sys(const uint64_t* p) { return q_uni(__hip_atomic_load((g_u64)p, Q_SYSTEM)); }
+typedef uint64_t q_u64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) q_u64x2* g_u64x2;
+__device__ __forceinline__ void q_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t q_lane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ uint64_t q_lane_u64(uint32_t v, int lane) { return (uint64_t)q_lane_u32(v, lane) | ((uint64_t)q_lane_u32(v, lane + 1) << 32); }
+__device__ __forceinline__ float q_lane_f32(uint32_t v, int lane) { return __uint_as_float(q_lane_u32(v, lane)); }
+
+// tap window load flavours: LD 0 plain (cached; A/B upper bound only: may serve a stale line of a rewritten source), 1 sc1
+template <int LD>
+__device__ __forceinline__ Win<1> q_load_win(gptr_u8 p) {
+    Win<1> w;
+    if constexpr (LD == 0) w.lo = *(gptr_u64)p;
+    else w.lo = __hip_atomic_load((g_u64)(__attribute__((address_space(1))) uint8_t*)p, Q_AGENT); // global_load_dwordx2 ... sc1 (unaligned is fine for the hardware)
+    return w;
+}
+
+// 4x4 transpose inside lane quads: in: r[j] = row j at this lane's column; out: o[0..3] = columns 4q..4q+3 of row (lane & 3)
+__device__ __forceinline__ void q_quad_transpose(const float (&r)[4], float (&o)[4], int lane) {
+    const bool odd = lane & 1, hi = lane & 2;
+    auto xor1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); }; // quad_perm:[1,0,3,2]
+    auto xor2 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); }; // quad_perm:[2,3,0,1]
+    // stage 1: 2x2 blocks between lane pairs, on the row pairs (0,1) and (2,3)
+    const float s01 = odd ? r[0] : r[1], s23 = odd ? r[2] : r[3];
+    const float g01 = xor1(s01), g23 = xor1(s23);
+    const float x0 = odd ? g01 : r[0], x1 = odd ? r[1] : g01; // even lanes: row 0 at (own, next) column; odd: row 1 at (previous, own)
+    const float y0 = odd ? g23 : r[2], y1 = odd ? r[3] : g23; // rows 2 / 3 likewise
+    // stage 2: lanes i and i ^ 2 swap the halves they do not keep
+    const float t0 = hi ? x0 : y0, t1 = hi ? x1 : y1;
+    const float u0 = xor2(t0), u1 = xor2(t1);
+    o[0] = hi ? u0 : x0;
+    o[1] = hi ? u1 : x1;
+    o[2] = hi ? y0 : u0;
+    o[3] = hi ? y1 : u1;
+}
+
+struct QTask { // everything a wave needs for its 4 rows, wave-uniform
+    PlaneParams P;
+    float mul[4], sub[4], div[4], rdiv[4], bg[4];
+    int32_t used, dst_w, dst_h, out_w, swap, fast_div;
+    int64_t img_stride, ch_stride;
+    uint8_t* out;
+    uint32_t out_bytes;
+};
+
+// One wave's share of a task: rows row0..row0+3 of plane z, columns col_tile*64 + lane.  K1's arithmetic (k_k1_impl.hpp:
+// same geometry, same tap windows, same fp32 expression order, the same program stages) -- bit-identical results.
+// ST: 0 = nt dword stores, NOT published safely (A/B upper bound only), 1 = sc1 dword stores, 2 = sc1 16-byte transposed stores
+template <int CN, int LD, int ST>
+__device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, int row0, int lane) {
+    const PlaneParams& P = t.P;
+    const int dst_w = t.dst_w, dst_h = t.dst_h, W = t.out_w;
+    const int x = col_tile * 64 + lane;
+    if (row0 >= dst_h) return; // wave-uniform
+    const bool live = x < dst_w;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(t.out, 0, (int)t.out_bytes, 0x00020000);
+    const uint32_t plane_off = (uint32_t)((int64_t)z * t.img_stride * 4); // byte offsets fit 32 bits (checked at submit)
+    const uint32_t ch_bytes = (uint32_t)(t.ch_stride * 4);
+    ProgArgs prog; // registers: only the static program's operands are ever read
+    prog.fast_div = t.fast_div;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        prog.operand[0][c] = t.mul[c];
+        prog.operand[1][c] = t.sub[c];
+        prog.operand[2][c] = t.div[c];
+        prog.rdiv[c] = t.rdiv[c];
+    }
+    auto run_prog = [&](Px& p) {
+        int depth = CVGS_DEPTH_32F, cn = CN;
+        if (t.swap) { // wave-uniform
+            const float s = p.v[0];
+            p.v[0] = p.v[2];
+            p.v[2] = s;
+        }
+        ProgMulSubDiv::run(prog, p, depth, cn);
+    };
+    auto store_rows = [&](const float (&v)[kQRowsPerWave][4]) { // v[j][k]: row j, channel k at this lane's column
+        const bool full = col_tile * 64 + 63 < dst_w; // wave-uniform: every lane of the tile is alive
+        if (ST == 2 && full) {
+            const int i = lane & 3, q = lane >> 2;
+            const bool row_ok = row0 + i < dst_h;
+            const uint32_t off = plane_off + (uint32_t)(((row0 + i) * W + col_tile * 64 + q * 4) * 4);
+#pragma unroll
+            for (int k = 0; k < CN; ++k) {
+                const float r[4] = {v[0][k], v[1][k], v[2][k], v[3][k]};
+                float o[4];
+                q_quad_transpose(r, o, lane);
+                typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+                const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kQRowsPerWave; ++j) {
+                if (row0 + j < dst_h && live) {
+                    const uint32_t off = plane_off + (uint32_t)(((row0 + j) * W + x) * 4);
+#pragma unroll
+                    for (int k = 0; k < CN; ++k)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                }
+            }
+        }
+    };
+
+    const bool whole = z < t.used && ((P.x1 | P.y1 | (P.x2 ^ (dst_w - 1)) | (P.y2 ^ (dst_h - 1))) == 0);
+    Px bgp;
+    bgp.v[0] = bgp.v[1] = bgp.v[2] = bgp.v[3] = 0.f;
+    if (!whole) { // the background value through the whole chain: planes >= usedPlanes and aspect-ratio padding
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bgp.v[k] = t.bg[k];
+        run_prog(bgp);
+        if (z >= t.used) {
+            float v[kQRowsPerWave][4];
+#pragma unroll
+            for (int j = 0; j < kQRowsPerWave; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[j][k] = bgp.v[k];
+            store_rows(v);
+            return;
+        }
+    }
+    // ---- per-lane column geometry ----
+    const int xc = live ? x : dst_w - 1; // dead lanes of a ragged tile compute the last column (never stored)
+    const bool in_x = xc >= P.x1 && xc <= P.x2;
+    const int xr = in_x ? xc - P.x1 : 0;
+    const float sx = (float)xr * P.fx;
+    const int x1 = (int)floorf(sx);
+    const int x2 = x1 + 1;
+    const float wxa = (float)x2 - sx;
+    const float wxb = sx - (float)x1;
+    const bool edge = x2 > P.w - 1;
+    const int row_bytes = P.w * CN;
+    const int o = x1 * CN;
+    const uint32_t ol = (uint32_t)min(o, row_bytes - 8);
+    const int sh = (o - (int)ol) * 8;
+    const gptr_u8 src = (gptr_u8)P.data;
+
+    Win<1> va[kQRowsPerWave], vb[kQRowsPerWave];
+    float wya[kQRowsPerWave], wyb[kQRowsPerWave];
+    bool in_y[kQRowsPerWave];
+#pragma unroll
+    for (int j = 0; j < kQRowsPerWave; ++j) {
+        const int y = min(row0 + j, dst_h - 1);
+        in_y[j] = y >= P.y1 && y <= P.y2;
+        const int yr = in_y[j] ? y - P.y1 : 0;
+        const float sy = (float)yr * P.fy;
+        const int y1 = (int)floorf(sy);
+        const int y2 = y1 + 1;
+        const int y2r = min(y2, P.h - 1);
+        wya[j] = (float)y2 - sy;
+        wyb[j] = sy - (float)y1;
+        const gptr_u8 ra = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step);
+        const gptr_u8 rb = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step);
+        va[j] = q_load_win<LD>(ra + ol); // (rows narrower than the 8-byte window never reach the server: queue_submit refuses them)
+        vb[j] = q_load_win<LD>(rb + ol);
+    }
+    float outv[kQRowsPerWave][4];
+#pragma unroll
+    for (int j = 0; j < kQRowsPerWave; ++j) {
+        float p00[4], p10[4], p01[4], p11[4];
+        unpack_pair<CN, SRC_U8>(shift_win<1>(va[j], sh), edge, p00, p10);
+        unpack_pair<CN, SRC_U8>(shift_win<1>(vb[j], sh), edge, p01, p11);
+        const float w00 = wxa * wya[j];
+        const float w10 = wxb * wya[j];
+        const float w01 = wxa * wyb[j];
+        const float w11 = wxb * wyb[j];
+        Px p;
+        p.v[0] = p.v[1] = p.v[2] = p.v[3] = 0.f;
+#pragma unroll
+        for (int k = 0; k < CN; ++k) {
+            float acc = p00[k] * w00;
+            acc = acc + p10[k] * w10;
+            acc = acc + p01[k] * w01;
+            acc = acc + p11[k] * w11;
+            p.v[k] = acc;
+        }
+        run_prog(p);
+        const bool take = whole || (in_x && in_y[j]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) outv[j][k] = take ? p.v[k] : bgp.v[k];
+    }
+    store_rows(outv);
+}
+
+__device__ __forceinline__ uint64_t q_wave_min(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t q_wave_max(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t q_bcast_u64(uint64_t v, int src_lane) {
+    return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src_lane) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src_lane) << 32);
+}
+
+// worker-side instrumentation costs ~10 SGPRs in a kernel that has none to spare: compiled in with -DCVGS_QUEUE_PROFILE only
+#ifdef CVGS_QUEUE_PROFILE
+#define QPROF(...) __VA_ARGS__
+#else
+#define QPROF(...)
+#endif
+
+
+// ---- workgroup 0's janitor wave: in-order completion count (for retirement / the watchdog only), retirement --------------
+__device__ void k1q_janitor(QDevCtl* dc, QHostCtl* hc, const uint64_t* dflags, uint32_t R, uint64_t gen, uint64_t idle_ticks,
+                            uint64_t stall_ticks, uint64_t done) {
+    const int lane = (int)threadIdx.x;
+    const uint64_t t_launch = wall_clock64();
+    uint64_t t_last = t_launch, rounds = 0;
+    int why = -1; // 0 = idle retirement, 1 = stall, 3 = destroy
+    while (why < 0) {
+        ++rounds;
+        const uint64_t tail = q_ldu_sys(&dc->tail.v);
+        if (q_ldu_sys(&hc->stop_req.v)) {
+            why = 3;
+            break;
+        }
+        if (q_ldu_sys(&hc->error.v)) {
+            why = 2;
+            break;
+        }
+        if (done < tail) {
+            // lane i looks at batch done + i: how many of the oldest in-flight batches have their flag up?
+            const uint64_t bi = done + (uint64_t)lane;
+            const uint64_t f = bi < tail && (uint32_t)lane < R ? q_ld_sys(dflags + kQCtrStride * (bi % R)) : 0;
+            const uint64_t up = __builtin_amdgcn_ballot_w64(f >= bi + 1);
+            const int n = up == ~0ull ? 64 : __builtin_ctzll(~up);
+            if (n > 0) {
+                done += (uint64_t)n;
+                t_last = wall_clock64();
+            } else if (wall_clock64() - t_last > stall_ticks) {
+                why = 1;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        } else if (wall_clock64() - t_last > idle_ticks) {
+            // retire: announce, then look at the host's tail once more (the host publishes its tail, fences, then reads state;
+            // the read below is a PCIe read and cannot pass the posted state write)
+            if (lane == 0) q_st_sys(&hc->state.v, QS_EXITING);
+            q_drain();
+            if (q_ldu_sys(&hc->tail.v) != tail) {
+                if (lane == 0) q_st_sys(&hc->state.v, QS_RUNNING);
+                q_drain();
+                t_last = wall_clock64();
+            } else {
+                why = 0;
+            }
+        } else {
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    if (lane == 0) {
+        q_st_sys(&dc->stop_gen.v, gen);
+        if (why == 1) q_st_sys(&hc->error.v, 1);
+        q_st_sys(&hc->stat_rounds.v, rounds);
+        q_st_sys(&hc->stat_launch_ticks.v, wall_clock64() - t_launch);
+        q_drain();
+        q_st_sys(&hc->state.v, QS_EXITED);
+    }
+}
+
+// ---- the server grid -----------------------------------------------------------------------------------------------
+// Workgroup 0: the janitor.  Workgroups 1..G: four INDEPENDENT worker waves each.  No barrier; a wave's shared writes are its
+// write-through output rows, one returning atomic on its batch's arrival counter, its resume word, and -- the last arrival
+// of a batch -- the batch's two completion flags.
+struct QDevMem { // the server's device-side state, one uncached allocation (host-writable through the BAR)
+    QDevCtl* dc;
+    uint8_t* ring;      // R slots
+    QIndex* index;      // R entries
+    uint64_t* arrive;   // ordinary (cached) device memory: per slot 1 top + 16 sub arrival counters, 128 bytes apart; device atomics only
+    uint64_t* dflags;   // R completion flags, 128 bytes apart (hipStreamWaitValue64 targets)
+    uint64_t* prog;     // 4 G resume words
+};
+
+template <int LD, int ST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
+                                                                                             uint64_t gen, uint64_t done0, uint64_t idle_ticks,
+                                                                                             uint64_t stall_ticks) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t n_workers = G * kQWaves;
+    if (blockIdx.x == 0) {
+        if (wave == 0) k1q_janitor(m.dc, hc, m.dflags, R, gen, idle_ticks, stall_ticks, done0);
+        return;
+    }
+    const uint32_t wid = (blockIdx.x - 1) * kQWaves + (uint32_t)wave;
+    uint64_t T = q_ldu(m.prog + wid); // resume where the previous server's worker stopped
+    uint64_t b = done0;                   // every batch below was complete when this server was launched
+    // the NEXT task's index window, requested before the current task's rows and consumed after them: with a deep queue the
+    // dispatch round trip disappears behind the arithmetic (loads the compiler counts: it waits where they are first used)
+    bool pre_valid = false;
+    uint64_t pre_wb = 0, pre_tail = 0, pre_e[4] = {0, 0, 0, 0};
+    QPROF(uint64_t p_tasks = 0, p_find = 0, p_rows = 0, p_drain = 0, p_idle = 0, p_arrive = 0, p_t4 = 0, p_first = 0, p_last = 0;)
+    for (;;) {
+        QPROF(const uint64_t p_t0 = wall_clock64();)
+        // ---- find the batch that holds task T: the tail + a 64-entry window of the batch index, ONE round trip; then the
+        // batch's parameters and the crop's, ONE more.  A worker only reads the slot of the batch that holds its own unprocessed
+        // task -- that batch cannot complete, so its slot cannot be recycled under the read; index entries say which batch they
+        // describe and carry a check word, so a recycled / half-written / never-written entry is simply not a candidate.
+        uint32_t v, pv;   // the batch's 64 parameter dwords / the crop's 12, one per lane (fields by v_readlane)
+        uint64_t tb, te;  // the batch's task range
+        uint64_t sub_target; // value of my arrival sub-counter once the batch's last task of my residue class has arrived
+        uint64_t tail_seen = ~0ull; // the tail at the last window read that found nothing
+        for (;;) {
+            if (tail_seen != ~0ull) { // idle: poll the 8-byte tail only; the 2 KB window is read again once it has moved
+                if (q_ldu_sys(&m.dc->tail.v) == tail_seen) {
+                    if (q_ldu_sys(&m.dc->stop_gen.v) == gen) {
+                        QPROF(if (wid == 0 && lane == 0) {
+                            q_st_sys(&hc->prof[8], p_tasks);
+                            q_st_sys(&hc->prof[9], p_find);
+                            q_st_sys(&hc->prof[10], p_rows);
+                            q_st_sys(&hc->prof[11], p_drain);
+                            q_st_sys(&hc->prof[12], p_idle);
+                            q_st_sys(&hc->prof[5], p_arrive);
+                            q_st_sys(&hc->prof[4], p_last - p_first);
+                        })
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                    QPROF(p_idle += 1;)
+                    continue;
+                }
+            }
+            uint64_t wb, tail_c; // window base, the tail that came with the window
+            q_u64x2 e0, e1;
+            if (pre_valid) { // the window this wave asked for BEFORE its previous task's rows: it has long landed
+                pre_valid = false;
+                wb = pre_wb;
+                tail_c = pre_tail;
+                e0.x = pre_e[0];
+                e0.y = pre_e[1];
+                e1.x = pre_e[2];
+                e1.y = pre_e[3];
+            } else {
+                wb = b;
+                const uint64_t* ep = (const uint64_t*)(m.index + ((wb + (uint64_t)lane) % R));
+                tail_c = q_ld_sys(&m.dc->tail.v);
+                e0.x = q_ld_sys(ep);
+                e0.y = q_ld_sys(ep + 1);
+                e1.x = q_ld_sys(ep + 2);
+                e1.y = q_ld_sys(ep + 3);
+            }
+            const uint64_t tail_u = q_uni(tail_c);
+            const uint64_t cand = e0.y - 1; // the batch this entry describes
+            const bool valid = e0.y != 0 && cand >= wb && cand < tail_u && cand < wb + R &&
+                               (uint32_t)(e1.y >> 32) == q_index_check(e0.x, e0.y, (uint32_t)e1.x, (uint32_t)(e1.x >> 32), (uint32_t)e1.y);
+            const bool hit = valid && e0.x > T;
+            // (the tail and the window come back in one round trip, in no particular order: the window may predate a batch the
+            // tail already counts.  Only entries actually SEEN move b: a batch that ends at or below T, and all before it, are behind.)
+            const uint64_t passed = q_uni(q_wave_max(valid && e0.x <= T ? cand + 1 : 0));
+            if (passed > b) b = passed;
+            if (__builtin_amdgcn_ballot_w64(hit) == 0) {
+                tail_seen = passed > wb ? ~0ull : tail_u; // progress: look again at once; none: wait for the tail to move
+                if (tail_seen == ~0ull && q_ldu_sys(&m.dc->stop_gen.v) == gen) return;
+                continue;
+            }
+            // the EARLIEST candidate (lanes are not sorted by batch once the window wraps the ring)
+            const uint64_t best = q_uni(q_wave_min(hit ? cand : ~0ull));
+            const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(hit && cand == best));
+            te = q_bcast_u64(e0.x, src);
+            const uint64_t e1x = q_bcast_u64(e1.x, src), e1y = q_bcast_u64(e1.y, src);
+            tb = te - (uint32_t)e1x;
+            if (T < tb) { // T belongs to an earlier batch whose entry this window read predates: read again
+                tail_seen = ~0ull;
+                continue;
+            }
+            const uint32_t tpp = (uint32_t)(e1x >> 32), n_planes = (uint32_t)e1y;
+            const uint32_t z = (uint32_t)(T - tb) / tpp;
+            const uint32_t pz = z < n_planes ? z : n_planes - 1;
+            const uint8_t* slot = m.ring + (size_t)(best % R) * kQSlotBytes;
+            v = __hip_atomic_load((g_u32)((const uint32_t*)slot + lane), Q_SYSTEM);
+            pv = __hip_atomic_load((g_u32)((const uint32_t*)(slot + kQPlanesOff + (size_t)pz * sizeof(PlaneParams)) + (lane < 12 ? lane : 0)), Q_SYSTEM);
+            sub_target = q_ld_sys((const uint64_t*)(slot + kQSubOff) + (T & (kQSubs - 1)));
+            q_drain();
+            sub_target = q_uni(sub_target);
+            if (q_lane_u64(v, QD_STAMP) != best + 1 || q_lane_u64(v, QD_TASK_BASE) != tb) { // a check-word collision: read again
+                tail_seen = ~0ull;
+                continue;
+            }
+            b = best;
+            break;
+        }
+        QPROF(const uint64_t p_t1 = wall_clock64();)
+        {
+            const uint32_t local = (uint32_t)(T - tb);
+            const uint32_t tpp = q_lane_u32(v, QD_TPP), col_tiles = q_lane_u32(v, QD_COL_TILES);
+            const uint32_t z = local / tpp, rt = local - z * tpp;
+            const uint32_t row_tile = rt / col_tiles, col_tile = rt - row_tile * col_tiles;
+            QTask t;
+            t.P.data = (const uint8_t*)q_lane_u64(pv, 0);
+            t.P.w = (int)q_lane_u32(pv, 2);
+            t.P.h = (int)q_lane_u32(pv, 3);
+            t.P.step = (int)q_lane_u32(pv, 4);
+            t.P.fx = q_lane_f32(pv, 5);
+            t.P.fy = q_lane_f32(pv, 6);
+            t.P.x1 = (int)q_lane_u32(pv, 7);
+            t.P.y1 = (int)q_lane_u32(pv, 8);
+            t.P.x2 = (int)q_lane_u32(pv, 9);
+            t.P.y2 = (int)q_lane_u32(pv, 10);
+            t.P.uv_off = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t.mul[c] = q_lane_f32(v, QD_MUL + c);
+                t.sub[c] = q_lane_f32(v, QD_SUB + c);
+                t.div[c] = q_lane_f32(v, QD_DIV + c);
+                t.rdiv[c] = q_lane_f32(v, QD_RDIV + c);
+                t.bg[c] = q_lane_f32(v, QD_BG + c);
+            }
+            t.used = (int)q_lane_u32(v, QD_USED);
+            t.dst_w = (int)q_lane_u32(v, QD_DST_W);
+            t.dst_h = (int)q_lane_u32(v, QD_DST_H);
+            t.out_w = (int)q_lane_u32(v, QD_OUT_W);
+            t.swap = (int)q_lane_u32(v, QD_SWAP);
+            t.fast_div = (int)q_lane_u32(v, QD_FAST_DIV);
+            t.img_stride = (int64_t)q_lane_u64(v, QD_IMG_STRIDE);
+            t.ch_stride = (int64_t)q_lane_u64(v, QD_CH_STRIDE);
+            t.out = (uint8_t*)q_lane_u64(v, QD_OUT);
+            t.out_bytes = (uint32_t)q_lane_u64(v, QD_OUT_BYTES);
+            const bool c3 = q_lane_u32(v, QD_CN) == 3;
+            {
+                pre_wb = b;
+                const uint64_t* ep = (const uint64_t*)(m.index + ((pre_wb + (uint64_t)lane) % R));
+                pre_tail = q_ld_sys(&m.dc->tail.v);
+                pre_e[0] = q_ld_sys(ep);
+                pre_e[1] = q_ld_sys(ep + 1);
+                pre_e[2] = q_ld_sys(ep + 2);
+                pre_e[3] = q_ld_sys(ep + 3);
+                pre_valid = true;
+            }
+            const int rows_per_task = (int)q_lane_u32(v, QD_ROWS_PER_TASK);
+#pragma nounroll
+            for (int grp = 0; grp * kQRowsPerWave < rows_per_task; ++grp) {
+                const int row0 = (int)row_tile * rows_per_task + grp * kQRowsPerWave;
+                if (row0 >= t.dst_h) break;
+                if (c3) k1q_rows<3, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+                else k1q_rows<4, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+            }
+        }
+        // ---- arrive: the write-through stores are visible device-wide once drained; the batch's last arrival raises its flags ----
+        QPROF(const uint64_t p_t2 = wall_clock64();)
+        q_drain();
+        QPROF(const uint64_t p_t3 = wall_clock64();)
+        QPROF(++p_tasks; p_find += p_t1 - p_t0; p_rows += p_t2 - p_t1; p_drain += p_t3 - p_t2; const uint64_t p_t3x = p_t3;)
+        // Two-level arrival (one word takes ~88 returning atomics per microsecond: 400-1600 arrivals on ONE counter would cost
+        // a batch 5-18 us of latency): task T bumps sub-counter T % 16 of its slot; whoever fills a sub-counter bumps the top one.
+        uint64_t* ctr = m.arrive + (size_t)(b % R) * (1 + kQSubs) * kQCtrStride;
+        const uint32_t sub = (uint32_t)T & (kQSubs - 1);
+        T += n_workers;
+        uint64_t before = 0;
+        if (lane == 0) {
+            q_st(m.prog + wid, T);
+            before = __hip_atomic_fetch_add((g_u64)(ctr + (1 + sub) * kQCtrStride), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (q_uni(before) + 1 == sub_target) {
+            if (lane == 0) before = __hip_atomic_fetch_add((g_u64)ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q_uni(before) + 1 == q_lane_u64(v, QD_ARRIVE_TARGET)) {
+                if (lane == 0) {
+                    q_st_sys(m.dflags + kQCtrStride * (b % R), b + 1);
+                    q_st_sys(hflags + (b % R), b + 1);
+                }
+            }
+        }
+        QPROF(p_t4 = wall_clock64(); p_arrive += p_t4 - p_t3x; if (!p_first) p_first = p_t0; p_last = p_t4;)
+        if (T >= te) ++b;
+    }
+}
+
+// staging path (no host-visible BAR): one wave copies n slots + index entries from the pinned host copies, then the tail
+__global__ void k1q_stage(QDevMem m, const uint8_t* host_ring, const QIndex* host_index, uint32_t R, uint64_t first, uint32_t n, uint64_t new_tail) {
+    const int lane = (int)threadIdx.x;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint64_t k = (first + s) % R;
+        const uint64_t* hp = (const uint64_t*)(host_ring + k * kQSlotBytes) + lane * 8;
+        uint64_t* dp = (uint64_t*)(m.ring + k * kQSlotBytes) + lane * 8;
+        for (int i = 0; i < 8; ++i) q_st_sys(dp + i, q_ld_sys(hp + i));
+        if (lane < 4) q_st_sys((uint64_t*)(m.index + k) + lane, q_ld_sys((const uint64_t*)(host_index + k) + lane));
+    }
+    q_drain();
+    if (lane == 0) q_st_sys(&m.dc->tail.v, new_tail);
+}
+
+// ====================================================================================================================
+// host side
+// ====================================================================================================================
+struct Queue {
+    int device = 0;
+    hipStream_t stream = nullptr;       // the server's stream
+    hipStream_t stage_stream = nullptr; // staging path only
+    uint32_t R = 0, G = 0;
+    int ld = 1, st = 2;
+    bool direct = false;                // the host writes device memory through the BAR
+    uint8_t* dev_block = nullptr;       // ONE uncached device allocation (host-written): ctl | ring | index | dflags
+    uint8_t* dev_counters = nullptr;    // ordinary device memory (device-only): arrival counters | resume words
+    QDevMem m{};
+    uint8_t* host_ring = nullptr;       // staging path: pinned copies the staging kernel reads
+    QIndex* host_index = nullptr;
+    QHostCtl* hc = nullptr;             // pinned
+    uint64_t* hflags = nullptr;         // pinned: R completion flags
+    std::vector<uint64_t> arrive_cum;   // per slot, 1 + 16 words: each arrival counter's value once every batch that used the slot has arrived
+    uint64_t next_seq = 0, next_task = 0, done_inorder = 0, gen = 0, launches = 0;
+    uint64_t idle_ticks = 0, stall_ticks = 0;
+    std::mutex mu;
+    uint64_t ns_ring_wait = 0, ns_write = 0, ns_ensure = 0, n_sub = 0; // host-side profile of submit
+    uint64_t n_ring_waits = 0, sum_done_behind_head = 0;               // head-of-line blocking: batches already complete behind an incomplete oldest one
+};
+
+static inline volatile uint64_t& hv(QLine& l) { return *(volatile uint64_t*)&l.v; }
+static inline uint64_t hflag(Queue* q, uint64_t slot) { return *(volatile uint64_t*)(q->hflags + slot); }
+
+static sigjmp_buf g_probe_jmp;
+static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+// Is device memory writable from the host (large BAR)?  One guarded 8-byte store + device-side read-back.
+static bool probe_direct(uint64_t* dev_word) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    struct sigaction sa {}, old_segv {}, old_bus {};
+    sa.sa_handler = probe_fault;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGSEGV, &sa, &old_segv);
+    sigaction(SIGBUS, &sa, &old_bus);
+    bool ok = false;
+    if (sigsetjmp(g_probe_jmp, 1) == 0) {
+        *(volatile uint64_t*)dev_word = 0x5157455545ull;
+        _mm_sfence();
+        ok = true;
+    }
+    sigaction(SIGSEGV, &old_segv, nullptr);
+    sigaction(SIGBUS, &old_bus, nullptr);
+    if (!ok) return false;
+    uint64_t back = 0;
+    if (hipMemcpy(&back, dev_word, 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return back == 0x5157455545ull;
+}
+
+static void advance_done(Queue* q) {
+    while (q->done_inorder < q->next_seq && hflag(q, q->done_inorder % q->R) >= q->done_inorder + 1) ++q->done_inorder;
+}
+
+static hipError_t queue_launch(Queue* q) {
+    ++q->gen;
+    ++q->launches;
+    advance_done(q);
+    hv(q->hc->state) = QS_RUNNING;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    const dim3 grid(q->G + 1), block(256);
+#define Q_LAUNCH(LD_, ST_) hipLaunchKernelGGL((k1q_server<LD_, ST_>), grid, block, 0, q->stream, q->m, q->hc, q->hflags, q->R, q->G, q->gen, q->done_inorder, q->idle_ticks, q->stall_ticks)
+    if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0);
+    else if (q->ld == 0 && q->st == 1) Q_LAUNCH(0, 1);
+    else if (q->ld == 0) Q_LAUNCH(0, 2);
+    else if (q->st == 0) Q_LAUNCH(1, 0);
+    else if (q->st == 1) Q_LAUNCH(1, 1);
+    else Q_LAUNCH(1, 2);
+#undef Q_LAUNCH
+    return hipGetLastError();
+}
+
+// after a batch has been published: make sure a server is (still) there to take it
+static int queue_ensure_running(Queue* q) {
+    std::atomic_thread_fence(std::memory_order_seq_cst); // host.tail store, then state load (the janitor does the mirror image)
+    for (;;) {
+        const uint64_t s = hv(q->hc->state);
+        if (s == QS_RUNNING) return 0;
+        if (s == QS_EXITING) { // the janitor is deciding: it re-reads host.tail and either resumes or exits, within microseconds
+            _mm_pause();
+            continue;
+        }
+        if (hv(q->hc->error)) return -2;
+        return queue_launch(q) == hipSuccess ? 0 : -1;
+    }
+}
+
+int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle_us, std::string& err) {
+    Queue* q = new (std::nothrow) Queue();
+    if (!q) return -1;
+    q->device = device;
+    q->R = depth <= 0 ? 128 : (depth > kQMaxRing ? kQMaxRing : depth);
+    // experiments (tools/queue_ab.py): bits 8..9 = store flavour + 1, bits 12..13 = load flavour + 1, bits 16..27 = workgroups;
+    // bit 0: never write device memory from the host (force the staging path)
+    if ((flags >> 8) & 3) q->st = (int)((flags >> 8) & 3) - 1;
+    if ((flags >> 12) & 3) q->ld = (int)((flags >> 12) & 3) - 1;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { err = "hipGetDeviceProperties"; delete q; return -1; }
+    int per_cu = 0;
+    e = q->st == 2 && q->ld == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2>, 256, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<0, 0>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) { err = "occupancy query failed"; delete q; return -1; }
+    // Every workgroup must be resident (tasks are statically owned).  The occupancy API can overstate by one where the SGPR
+    // file is the binding limit (MI355X_MICROARCH.md "Residency"); at <= 5 workgroups per CU the VGPR file binds and it is exact.
+    int use = per_cu > 8 ? 8 : per_cu;
+    if (use > 5) use -= 1;
+    // Three workgroups per CU already run the headline at the memory system's rate for its access pattern (2.4-2.6 us per 50-crop
+    // batch, the rate of 16-64 frames fused into one launch; tools/queue_ab.py: 767 vs 1023 workgroups tie) and leave more than
+    // half of every SIMD's wave slots to the caller's other kernels while the server is alive.
+    if (use > 3) use = 3;
+    uint32_t G = (uint32_t)(prop.multiProcessorCount * use) - 1;
+    if ((flags >> 16) & 0xfff) G = (flags >> 16) & 0xfff;
+    q->G = G;
+    const double tick_hz = 100e6; // s_memrealtime: constant 100 MHz
+    q->idle_ticks = (uint64_t)((idle_us <= 0 ? 200.0 : idle_us) * 1e-6 * tick_hz);
+    q->stall_ticks = (uint64_t)(0.25 * tick_hz); // a batch that makes no progress for 250 ms is reported, not waited for
+    const size_t R = q->R, NW = (size_t)q->G * kQWaves;
+    const size_t off_ring = 4096, off_index = off_ring + R * kQSlotBytes, off_dflags = off_index + R * sizeof(QIndex), total = off_dflags + R * 128;
+    const size_t ctr_bytes = R * (1 + kQSubs) * kQCtrStride * 8, total_ctr = ctr_bytes + NW * 8;
+    if ((e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipExtMallocWithFlags((void**)&q->dev_block, total, hipDeviceMallocUncached)) != hipSuccess ||
+        (e = hipMalloc((void**)&q->dev_counters, total_ctr)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&q->hc, sizeof(QHostCtl), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&q->hflags, R * 8, hipHostMallocDefault)) != hipSuccess) {
+        err = std::string("queue allocation: ") + hipGetErrorString(e);
+        return -1; // (leaks on this cold path are reclaimed at process exit)
+    }
+    q->m.dc = (QDevCtl*)q->dev_block;
+    q->m.ring = q->dev_block + off_ring;
+    q->m.index = (QIndex*)(q->dev_block + off_index);
+    q->m.dflags = (uint64_t*)(q->dev_block + off_dflags);
+    q->m.arrive = (uint64_t*)q->dev_counters;
+    q->m.prog = (uint64_t*)(q->dev_counters + ctr_bytes);
+    std::memset((void*)q->hc, 0, sizeof(QHostCtl));
+    std::memset((void*)q->hflags, 0, R * 8);
+    q->arrive_cum.assign(R * (1 + kQSubs), 0);
+    std::vector<uint64_t> p0(NW);
+    for (size_t i = 0; i < NW; ++i) p0[i] = i; // worker w's first task is w
+    if ((e = hipMemset(q->dev_block, 0, total)) != hipSuccess || (e = hipMemset(q->dev_counters, 0, total_ctr)) != hipSuccess ||
+        (e = hipMemcpy(q->m.prog, p0.data(), NW * 8, hipMemcpyHostToDevice)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+        err = std::string("queue init: ") + hipGetErrorString(e);
+        return -1;
+    }
+    q->direct = !(flags & 1u) && probe_direct(&q->m.dc->stop_gen.pad[0]);
+    if (!q->direct) {
+        if ((e = hipHostMalloc((void**)&q->host_ring, R * kQSlotBytes, hipHostMallocDefault)) != hipSuccess ||
+            (e = hipHostMalloc((void**)&q->host_index, R * sizeof(QIndex), hipHostMallocDefault)) != hipSuccess) {
+            err = std::string("queue staging buffers: ") + hipGetErrorString(e);
+            return -1;
+        }
+        std::memset(q->host_ring, 0, R * kQSlotBytes);
+        std::memset((void*)q->host_index, 0, R * sizeof(QIndex));
+    }
+    *out = q;
+    return 0;
+}
+
+// Can the server take this chain?  K1's hot shape only: 8U C3 / C4 crops -> bilinear resize -> [swap R,B] mul sub div -> fp32
+// planar tensor (NCHW / CNHW), descriptors inline, one target.  Everything else belongs to cvgs_execute.
+int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err) {
+    const ReadArgs& r = c_in.read;
+    const WriteArgs& w = c_in.write;
+    const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
+    if (r.kind != CVGS_READ_RESIZE_LINEAR || r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4) || !planar || w.depth != CVGS_DEPTH_32F ||
+        w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch) {
+        err = "queue: chain is not a batched 8UC3/8UC4 resize into an fp32 planar tensor with <= 74 inline planes";
+        return 1;
+    }
+    for (int i = 0; i < n_planes && i < r.used; ++i)
+        if (planes[i].w * r.cn < 8) {
+            err = "queue: a crop narrower than the 8-byte tap window (1-2 pixels)";
+            return 1;
+        }
+    ChainArgs c = c_in;
+    c.prog.fast_div = 0;
+    for (int k = 0; k < 4; ++k) c.prog.rdiv[k] = 0.f;
+    const int prog_id = k1_classify_program(c.prog, r.cn);
+    if (prog_id > 1) {
+        err = "queue: the pointwise program must be [RGB<->BGR swap,] mul, sub, div";
+        return 1;
+    }
+    fast_div_setup(c.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
+    const int o = prog_id == 0 ? 1 : 0; // index of the MUL stage
+    // output bytes addressed through ONE 32-bit-offset buffer descriptor
+    const int64_t last = (int64_t)(r.batch - 1) * w.img_stride + (int64_t)(r.cn - 1) * w.ch_stride + (int64_t)r.dst_h * w.width;
+    if (last <= 0 || last * 4 >= (int64_t)1 << 31) {
+        err = "queue: output tensor beyond 2 GB";
+        return 1;
+    }
+    std::lock_guard<std::mutex> lock(q->mu);
+    if (hv(q->hc->error)) {
+        err = "queue: the server reported a stall / protocol error earlier";
+        return -2;
+    }
+    auto ns_since = [](std::chrono::steady_clock::time_point a) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a).count(); };
+    // ring space: batch next_seq reuses the slot of batch next_seq - R, which must be complete
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t k = q->next_seq % q->R;
+    if (q->next_seq >= q->R) {
+        unsigned spins = 0;
+        if (hflag(q, k) < q->next_seq - q->R + 1) {
+            ++q->n_ring_waits;
+            for (uint64_t bb = q->next_seq - q->R + 1; bb < q->next_seq; ++bb) q->sum_done_behind_head += hflag(q, bb % q->R) >= bb + 1;
+        }
+        while (hflag(q, k) < q->next_seq - q->R + 1) {
+            if ((spins & 255) == 0) {
+                const int rc = queue_ensure_running(q);
+                if (rc) { err = "queue: server launch failed / stalled"; return rc; }
+            }
+            _mm_pause();
+            if ((++spins & 0xffff) == 0 && ns_since(t0) > 2000000000ull) { err = "queue: ring full for 2 s"; return -2; }
+        }
+    }
+    q->ns_ring_wait += ns_since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    QParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.stamp = q->next_seq + 1;
+    p.task_base = q->next_task;
+    p.col_tiles = (uint32_t)((r.dst_w + 63) / 64);
+    // task size: a deep queue is a throughput problem (16 rows per task amortise the dispatch), a shallow one a latency problem
+    // (4 rows per task: four times the waves on each batch)
+    advance_done(q);
+    p.rows_per_task = q->next_seq - q->done_inorder >= 2 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave;
+    p.tiles_per_plane = p.col_tiles * (uint32_t)((r.dst_h + (int)p.rows_per_task - 1) / (int)p.rows_per_task);
+    p.n_tasks = p.tiles_per_plane * (uint32_t)r.batch;
+    p.n_planes = (uint32_t)n_planes;
+    p.used = (uint32_t)r.used;
+    p.dst_w = (uint32_t)r.dst_w;
+    p.dst_h = (uint32_t)r.dst_h;
+    p.out_w = (uint32_t)w.width;
+    p.cn = (uint32_t)r.cn;
+    p.swap = prog_id == 0;
+    p.fast_div = (uint32_t)c.prog.fast_div;
+    for (int i = 0; i < 4; ++i) {
+        p.mul[i] = c.prog.operand[o][i];
+        p.sub[i] = c.prog.operand[o + 1][i];
+        p.div[i] = c.prog.operand[o + 2][i];
+        p.rdiv[i] = c.prog.rdiv[i];
+        p.bg[i] = r.bg[i];
+    }
+    p.img_stride = w.img_stride;
+    p.ch_stride = w.ch_stride;
+    p.out = (uint64_t)w.data;
+    p.out_bytes = (uint64_t)last * 4;
+    // cumulative arrival targets of the slot's counters (they are never reset): sub-counter s takes the tasks T = s (mod 16)
+    uint64_t sub_targets[kQSubs];
+    uint64_t* cum = &q->arrive_cum[k * (1 + kQSubs)];
+    uint32_t filled = 0;
+    for (int sres = 0; sres < kQSubs; ++sres) {
+        const uint64_t lo = p.task_base, hi = p.task_base + p.n_tasks; // tasks in [lo, hi) with T % 16 == sres
+        const uint64_t cnt = (hi + (kQSubs - 1 - sres)) / kQSubs - (lo + (kQSubs - 1 - sres)) / kQSubs;
+        cum[1 + sres] += cnt;
+        sub_targets[sres] = cnt ? cum[1 + sres] : 0; // 0: never matched (counters start at 0 and the comparison is against old + 1 >= 1)
+        filled += cnt != 0;
+    }
+    cum[0] += filled;
+    p.arrive_target = cum[0];
+    QIndex ix;
+    ix.end_task = p.task_base + p.n_tasks;
+    ix.stamp = p.stamp;
+    ix.n_tasks = p.n_tasks;
+    ix.tiles_per_plane = p.tiles_per_plane;
+    ix.n_planes = p.n_planes;
+    ix.check = q_index_check(ix.end_task, ix.stamp, ix.n_tasks, ix.tiles_per_plane, ix.n_planes);
+    // 1. the retirement hand-shake, on host memory only (no write-combined store is pending, so the fence is cheap): once
+    //    host.tail is ahead of the device's tail the janitor cannot retire, whatever it sees next
+    if (ticket) *ticket = q->next_seq;
+    q->next_seq += 1;
+    q->next_task += p.n_tasks;
+    hv(q->hc->tail) = q->next_seq;
+    q->ns_write += ns_since(t1);
+    const auto t2 = std::chrono::steady_clock::now();
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    bool need_launch = false;
+    for (;;) {
+        const uint64_t st = hv(q->hc->state);
+        if (st == QS_RUNNING) break;
+        if (st == QS_EXITING) { // the janitor is deciding: it re-reads host.tail and resumes or exits within microseconds
+            _mm_pause();
+            continue;
+        }
+        if (hv(q->hc->error)) { err = "queue: the server reported a stall / protocol error"; return -2; }
+        need_launch = true;
+        break;
+    }
+    q->ns_ensure += ns_since(t2);
+    // 2. the slot, its index entry, then the tail
+    uint8_t* slot = (q->direct ? q->m.ring : q->host_ring) + k * kQSlotBytes;
+    QIndex* ixp = (q->direct ? q->m.index : q->host_index) + k;
+    std::memcpy(slot, &p, sizeof(p));
+    std::memcpy(slot + kQSubOff, sub_targets, sizeof(sub_targets));
+    std::memcpy(slot + kQPlanesOff, planes, (size_t)n_planes * sizeof(PlaneParams));
+    for (int i = 0; i < 4; ++i) ((volatile uint64_t*)ixp)[i] = ((const uint64_t*)&ix)[i]; // four atomic 8-byte stores
+    if (q->direct) {
+        _mm_sfence(); // the write-combined slot / index stores leave before the tail does
+        *(volatile uint64_t*)&q->m.dc->tail.v = q->next_seq;
+        _mm_sfence();
+    } else {
+        hipLaunchKernelGGL(k1q_stage, dim3(1), dim3(64), 0, q->stage_stream, q->m, q->host_ring, q->host_index, q->R, q->next_seq - 1, 1u, q->next_seq);
+        if (hipGetLastError() != hipSuccess) { err = "queue: staging kernel launch failed"; return -1; }
+    }
+    q->n_sub += 1;
+    // 3. a retired server is replaced AFTER the batch is in place
+    if (need_launch && queue_launch(q) != hipSuccess) { err = "queue: server launch failed"; return -1; }
+    return 0;
+}
+
+int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err) {
+    if (ticket >= q->next_seq) { err = "queue: ticket was never issued"; return 1; }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    const uint64_t k = ticket % q->R;
+    while (hflag(q, k) < ticket + 1) { // a later batch in the same slot carries a larger stamp: still "complete"
+        if (hv(q->hc->error)) { err = "queue: the server reported a stall / protocol error"; return -2; }
+        _mm_pause();
+        if ((++spins & 1023) == 0 && timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+            err = "queue: wait timed out";
+            return -3;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
+int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err) {
+    if (ticket >= q->next_seq) { err = "queue: ticket was never issued"; return 1; }
+    const hipError_t e = hipStreamWaitValue64((hipStream_t)stream, q->m.dflags + kQCtrStride * (ticket % q->R), ticket + 1, hipStreamWaitValueGte, ~0ull);
+    if (e != hipSuccess) { err = std::string("hipStreamWaitValue64: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
+
+void queue_prof(Queue* q, uint64_t* out16) {
+    for (int i = 0; i < 16; ++i) out16[i] = *(volatile uint64_t*)&q->hc->prof[i];
+    out16[6] = q->n_ring_waits;
+    out16[7] = q->n_ring_waits ? q->sum_done_behind_head / q->n_ring_waits : 0;
+    out16[13] = q->n_sub ? q->ns_ring_wait / q->n_sub : 0; // host side of submit, ns per call (since create)
+    out16[14] = q->n_sub ? q->ns_write / q->n_sub : 0;
+    out16[15] = q->n_sub ? q->ns_ensure / q->n_sub : 0;
+}
+
+void queue_stats(Queue* q, uint64_t* out8) {
+    std::lock_guard<std::mutex> lock(q->mu);
+    advance_done(q);
+    out8[0] = q->next_seq;
+    out8[1] = q->done_inorder;
+    out8[2] = q->launches;
+    out8[3] = hv(q->hc->stat_rounds);
+    out8[4] = hv(q->hc->stat_launch_ticks); // 100 MHz ticks the last retired server lived
+    out8[5] = q->G;
+    out8[6] = q->R | (q->direct ? 1ull << 32 : 0);
+    out8[7] = hv(q->hc->error);
+}
+
+void* queue_stream(Queue* q) { return (void*)q->stream; }
+
+int queue_destroy(Queue* q) {
+    if (!q) return 0;
+    {
+        std::lock_guard<std::mutex> lock(q->mu);
+        hv(q->hc->stop_req) = 1;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+    }
+    (void)hipStreamSynchronize(q->stage_stream);
+    (void)hipStreamSynchronize(q->stream); // the janitor sees stop_req within one round and retires the grid
+    (void)hipStreamDestroy(q->stream);
+    (void)hipStreamDestroy(q->stage_stream);
+    (void)hipFree(q->dev_block);
+    (void)hipFree(q->dev_counters);
+    (void)hipHostFree((void*)q->hc);
+    (void)hipHostFree((void*)q->hflags);
+    if (q->host_ring) (void)hipHostFree(q->host_ring);
+    if (q->host_index) (void)hipHostFree((void*)q->host_index);
+    delete q;
+    return 0;
+}
+
+} // namespace cvgs

@@ -106,6 +106,18 @@ using ProgMulSubDiv = K1Prog<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 // constants, so the whole-frame kernels carry no interpreter at all.
 using ProgNone = K1Prog<>;
 
+// program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
+inline int k1_classify_program(const ProgArgs& p, int cn) {
+    if (cn < 3) return (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) ? 1 : 2;
+    const int swap = cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
+    if (p.n == 4 && p.opcode[0] == CVGS_OP_REORDER && p.aux[0] == swap && p.opcode[1] == CVGS_OP_MUL &&
+        p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV)
+        return 0;
+    if (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) return 1;
+    return 2;
+}
+
+
 typedef uint64_t u64_unaligned __attribute__((aligned(1)));
 typedef const __attribute__((address_space(1))) u64_unaligned* gptr_u64;
 typedef const __attribute__((address_space(1))) uint8_t* gptr_u8;

@@ -588,3 +588,73 @@ class CircularTensor:
             self.release()
         except Exception:
             pass
+
+
+class Queue:
+    """cvgs_queue_*: a device-side descriptor queue.  `submit(*iops)` has executeOperations' call shape (one call per frame,
+    the same IOps) but no kernel launch per call: a resident server grid takes the batch from a ring, and consecutive batches
+    overlap on the device.  Only K1's hot shape is taken (batched 8UC3 / 8UC4 resize -> [swap,] mul, sub, div -> fp32 planar
+    tensor); capi.CvgsError(CVGS_ERR_UNSUPPORTED) otherwise."""
+
+    def __init__(self, device=0, depth=0, idle_us=0.0, flags=0):
+        self.lib = capi.load_library()
+        self.handle = C.c_void_p()
+        capi.check(self.lib.cvgs_queue_create(C.byref(self.handle), device, depth, float(idle_us), flags))
+        self._keep = {}
+
+    def submit(self, *iops, flags=0):
+        lowered = lower(iops, flags)
+        return self.submit_lowered(lowered)
+
+    def submit_lowered(self, lowered):
+        t = C.c_uint64()
+        capi.check(self.lib.cvgs_queue_submit(self.handle, C.byref(lowered.desc), C.byref(t)))
+        return t.value
+
+    def submit_many(self, ptr_array, n):
+        """ptr_array: (POINTER(ChainDesc) * n) of pre-lowered chains (see chain_pointers); returns the last ticket"""
+        t = C.c_uint64()
+        capi.check(self.lib.cvgs_queue_submit_many(self.handle, ptr_array, n, C.byref(t)))
+        return t.value
+
+    @staticmethod
+    def chain_pointers(lowered_chains):
+        arr = (C.POINTER(capi.ChainDesc) * len(lowered_chains))()
+        for i, lc in enumerate(lowered_chains):
+            arr[i] = C.pointer(lc.desc)
+        return arr
+
+    def wait(self, ticket, timeout_s=10.0):
+        capi.check(self.lib.cvgs_queue_wait(self.handle, ticket, float(timeout_s)))
+
+    def stream_wait(self, ticket, stream):
+        capi.check(self.lib.cvgs_queue_stream_wait(self.handle, ticket, stream_handle(stream)))
+
+    def stats(self):
+        out = (C.c_uint64 * 8)()
+        capi.check(self.lib.cvgs_queue_stats(self.handle, out))
+        keys = ("submitted", "completed", "server_launches", "janitor_rounds", "server_ticks_100MHz", "workgroups", "ring_slots", "error")
+        d = dict(zip(keys, [int(v) for v in out]))
+        d["host_writes_device_memory"] = bool(d["ring_slots"] >> 32)  # slots go through the PCIe BAR (else: staged by a copy kernel)
+        d["ring_slots"] &= 0xffffffff
+        return d
+
+    def profile(self):
+        """instrumentation of the last retired server: ticks are 10 ns"""
+        out = (C.c_uint64 * 16)()
+        capi.check(self.lib.cvgs_queue_profile(self.handle, out))
+        v = [int(x) for x in out]
+        return {"worker0": {"tasks": v[8], "find_us": v[9] / 100.0, "rows_us": v[10] / 100.0, "drain_us": v[11] / 100.0, "arrive_us": v[5] / 100.0, "first_to_last_us": v[4] / 100.0, "idle_polls": v[12]},
+                "host_submit_ns": {"ring_wait": v[13], "slot_write": v[14], "ensure_running": v[15]},
+                "ring_full_waits": v[6], "complete_behind_an_incomplete_head_avg": v[7]}
+
+    def destroy(self):
+        if self.handle:
+            self.lib.cvgs_queue_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CVGS_ABI_VERSION 3
+#define CVGS_ABI_VERSION 4
 #define CVGS_MAX_OPS 12        /* pointwise stages between the read and the write            */
 #define CVGS_MAX_CHANNELS 4
 #define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
@@ -350,6 +350,38 @@ size_t cvgs_circular_bytes(cvgs_circular_t ct);
 /* number of updates so far (the reference keeps this host-side ring index private)             */
 int64_t cvgs_circular_updates(cvgs_circular_t ct);
 int cvgs_circular_destroy(cvgs_circular_t ct);
+
+/* ---- device-side descriptor queue (ABI 4) ---------------------------------------------------------------------
+ * The reference submits one kernel per executeOperations call (include/cvGPUSpeedup.cuh:464-473 -> fk::executeOperations:
+ * one TransformDPP launch).  On MI355X a 50-crop batch is ~1 us of HBM time behind a ~1.8 us launch/drain boundary, and the
+ * waves of ONE launch load, then store, all at the same time.  A queue keeps the call shape -- one submit per
+ * frame, same chain descriptor -- and removes the boundary: a resident server grid takes batches from a ring; its
+ * workgroups walk from batch to batch without a grid-wide barrier, so batch k+1's loads overlap batch k's stores.
+ *   cvgs_queue_create   one queue per device; `depth` ring slots (0 = 64, at most 256); `idle_us`: the server retires
+ *                       itself after this long without work (0 = 200 us) and the next submit starts a new one, so the grid
+ *                       never outlives its work; a batch without progress for 250 ms is reported as CVGS_ERR_HIP, not waited for.
+ *   cvgs_queue_submit   asynchronous; the chain must be K1's hot shape (batched 8UC3 / 8UC4 bilinear resize -> [RGB<->BGR]
+ *                       mul, sub, div -> fp32 NCHW / CNHW tensor, host descriptors, <= 74 planes): anything else returns
+ *                       CVGS_ERR_UNSUPPORTED and belongs to cvgs_execute.  The sources must be complete when submit is
+ *                       called (the server is not ordered behind any stream); results are bit-identical to cvgs_execute.
+ *   cvgs_queue_wait     host waits for a ticket (batches complete in order); cvgs_queue_stream_wait makes a HIP stream
+ *                       wait for it instead (hipStreamWaitValue64 on the queue's completion counter), the consumer's kernels
+ *                       enqueued behind it see the tensor.
+ * One host thread at a time per queue (submits are serialised by a mutex).  No reference counterpart.                  */
+typedef struct cvgs_queue_s* cvgs_queue_t;
+int cvgs_queue_create(cvgs_queue_t* out, int32_t device, int32_t depth, double idle_us, uint32_t flags);
+int cvgs_queue_submit(cvgs_queue_t q, const cvgs_chain_desc* chain, uint64_t* ticket);
+/* n submits in one call (a serving loop's burst); *last_ticket = the ticket of chains[n-1] */
+int cvgs_queue_submit_many(cvgs_queue_t q, const cvgs_chain_desc* const* chains, int32_t n, uint64_t* last_ticket);
+int cvgs_queue_wait(cvgs_queue_t q, uint64_t ticket, double timeout_s);
+int cvgs_queue_stream_wait(cvgs_queue_t q, uint64_t ticket, cvgs_stream_t stream);
+/* out[8]: submitted, completed, server launches, feeder rounds and lifetime (100 MHz ticks) of the last retired server,
+ * worker workgroups, ring slots, error word */
+int cvgs_queue_stats(cvgs_queue_t q, uint64_t* out8);
+/* out[16], of the last RETIRED server, 100 MHz ticks / counts: feeder {rounds with copies, slots, load ticks, copy ticks},
+ * monitor {scans, scan ticks, completions published, -}, worker 0 {tasks, find ticks, rows ticks, drain ticks, idle polls} */
+int cvgs_queue_profile(cvgs_queue_t q, uint64_t* out16);
+int cvgs_queue_destroy(cvgs_queue_t q);
 
 /* ---- streaming copy ----------------------------------------------------------------------------
  * dst[0..bytes) <- src[0..bytes) with the CircularTensor's plane-copy kernel (non-temporal 16-byte accesses), asynchronous

@@ -1,0 +1,165 @@
+"""The device-side descriptor queue (cvgs_queue_*): every batch a resident server grid produces must be bit-identical to the
+CPU oracle -- the same contract as cvgs_execute (tests/test_gpu_k1.py), whose call shape the queue keeps (one submit per frame,
+reference include/cvGPUSpeedup.cuh:464-473).  Covered: variable crops, aspect-ratio padding, unused planes, C4, ragged target
+sizes, many batches in flight (ring wrap-around), a server that retires and is restarted, a source buffer REWRITTEN between
+two submits (the server outlives kernel boundaries, so nothing invalidates its caches for it), a consumer stream waiting on a
+ticket, and chains the server must refuse."""
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def torch_dev():
+    import torch
+    return torch, torch.device("cuda:0")
+
+
+def oracle_out(oracle, frame_np, crops, batch_out, dst, cn, **kw):
+    ref = np.full((batch_out, cn * dst[0] * dst[1]), -777.0, dtype=np.float32)
+    h_src = cvgs.GpuMat.from_array(frame_np, cvgs.make_type(cvgs.CV_8U, cn))
+    oracle.execute(cvgs.lower(H.k1_chain(h_src, crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, cn, **kw)))
+    return ref
+
+
+def gpu_chain(torch, dev, frame_t, crops, batch_out, dst, cn, **kw):
+    out_t = torch.full((batch_out, cn * dst[0] * dst[1]), -777.0, dtype=torch.float32, device=dev)
+    ops = H.k1_chain(cvgs.GpuMat.from_tensor(frame_t, cvgs.make_type(cvgs.CV_8U, cn)), crops, cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), dst, cn, **kw)
+    return out_t, ops
+
+
+@pytest.mark.parametrize("cn,dst,kw", [
+    (3, (64, 128), {}),
+    (3, (64, 128), {"swap": False}),
+    (4, (64, 128), {}),
+    (3, (64, 128), {"ar": cvgs.PRESERVE_AR, "background": [128.0, 128.0, 128.0, 0.0]}),
+    (3, (64, 128), {"used": 5, "background": [7.0, 8.0, 9.0, 0.0]}),
+    (3, (100, 37), {}),      # ragged: 2 column tiles, the second 36 wide; 37 rows = 2 full tasks + 5 rows
+    (4, (30, 50), {"ar": cvgs.PRESERVE_AR_LEFT, "background": [1.0, 2.0, 3.0, 4.0]}),
+    (3, (256, 16), {}),      # 4 column tiles, one task row
+])
+def test_queue_batch_matches_the_oracle(oracle, torch_dev, cn, dst, kw):
+    torch, dev = torch_dev
+    frame = H.random_u8((1080, 1920, cn), seed=3)
+    crops = H.random_crops(9, 1920, 1080, wmax=400, hmax=500, seed=11)
+    q = cvgs.Queue()
+    try:
+        out_t, ops = gpu_chain(torch, dev, torch.from_numpy(frame).to(dev), crops, 9, dst, cn, **kw)
+        torch.cuda.synchronize()
+        q.wait(q.submit(*ops))
+        torch.cuda.synchronize()
+        H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, 9, dst, cn, **kw), "queue batch %s %s" % (dst, kw))
+    finally:
+        q.destroy()
+
+
+def test_queue_many_batches_in_flight_wrap_the_ring(oracle, torch_dev):
+    """200 batches through an 8-slot ring without waiting in between: distinct frames / crop lists / tensors, every one checked."""
+    torch, dev = torch_dev
+    q = cvgs.Queue(depth=8)
+    try:
+        frames = [H.random_u8((720, 1280, 3), seed=100 + i) for i in range(5)]
+        frames_t = [torch.from_numpy(f).to(dev) for f in frames]
+        jobs = []
+        for i in range(200):
+            crops = H.random_crops(1 + i % 50, 1280, 720, wmax=300, hmax=400, seed=1000 + i)
+            out_t, ops = gpu_chain(torch, dev, frames_t[i % 5], crops, len(crops), (64, 128), 3)
+            jobs.append((i, crops, out_t, cvgs.lower(ops)))
+        torch.cuda.synchronize()
+        last = None
+        for _, _, _, lowered in jobs:
+            last = q.submit_lowered(lowered)
+        q.wait(last)
+        torch.cuda.synchronize()
+        st = q.stats()
+        assert st["completed"] == 200 and st["error"] == 0, st
+        for i, crops, out_t, _ in jobs:
+            H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frames[i % 5], crops, len(crops), (64, 128), 3), "batch %d" % i)
+    finally:
+        q.destroy()
+
+
+def test_queue_server_retires_and_restarts(oracle, torch_dev):
+    import time
+    torch, dev = torch_dev
+    q = cvgs.Queue(idle_us=50.0)
+    try:
+        frame = H.random_u8((480, 640, 3), seed=5)
+        frame_t = torch.from_numpy(frame).to(dev)
+        for rnd in range(4):
+            crops = H.random_crops(12, 640, 480, wmax=200, hmax=300, seed=50 + rnd)
+            out_t, ops = gpu_chain(torch, dev, frame_t, crops, 12, (64, 128), 3)
+            torch.cuda.synchronize()
+            q.wait(q.submit(*ops))
+            H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, 12, (64, 128), 3), "round %d" % rnd)
+            time.sleep(0.01)  # far beyond idle_us: the server has retired, the next submit launches a new one
+        st = q.stats()
+        assert st["server_launches"] == 4 and st["error"] == 0, st
+    finally:
+        q.destroy()
+
+
+def test_queue_sees_a_source_buffer_rewritten_between_submits(oracle, torch_dev):
+    """The same frame buffer gets new pixels while the server stays alive: every batch must be computed from the pixels that were
+    in the buffer when it was submitted (ONE server launch serves all six: nothing invalidates its caches between them)."""
+    torch, dev = torch_dev
+    crops = H.random_crops(20, 1280, 720, wmax=300, hmax=400, seed=9)
+    frames = [H.random_u8((720, 1280, 3), seed=200 + rnd) for rnd in range(6)]
+    refs = [oracle_out(oracle, f, crops, 20, (64, 128), 3) for f in frames]
+    staged = [torch.from_numpy(f).to(dev) for f in frames]
+    q = cvgs.Queue(idle_us=200000.0)  # 200 ms: the server survives the host-side work between the submits
+    try:
+        frame_t = torch.zeros((720, 1280, 3), dtype=torch.uint8, device=dev)
+        out_t, ops = gpu_chain(torch, dev, frame_t, crops, 20, (64, 128), 3)
+        lowered = cvgs.lower(ops)
+        got = [torch.empty_like(out_t) for _ in range(6)]  # allocated up front: a hipMalloc inside the loop would wait for the server
+        for rnd in range(6):
+            frame_t.copy_(staged[rnd])
+            torch.cuda.current_stream().synchronize()  # NOT a device-wide synchronize: that one waits for the server to retire
+            q.wait(q.submit_lowered(lowered))
+            got[rnd].copy_(out_t)
+        torch.cuda.current_stream().synchronize()
+        assert q.stats()["error"] == 0, q.stats()
+        for rnd in range(6):
+            H.assert_bit_exact(got[rnd].cpu().numpy(), refs[rnd], "rewrite %d" % rnd)
+    finally:
+        q.destroy()
+
+
+def test_queue_stream_wait_orders_a_consumer_kernel(oracle, torch_dev):
+    torch, dev = torch_dev
+    q = cvgs.Queue()
+    try:
+        frame = H.random_u8((720, 1280, 3), seed=21)
+        crops = H.random_crops(30, 1280, 720, wmax=300, hmax=400, seed=22)
+        out_t, ops = gpu_chain(torch, dev, torch.from_numpy(frame).to(dev), crops, 30, (64, 128), 3)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        t = q.submit(*ops)
+        q.stream_wait(t, s)
+        with torch.cuda.stream(s):
+            copy = out_t.clone()  # a consumer kernel enqueued behind the ticket
+        s.synchronize()
+        H.assert_bit_exact(copy.cpu().numpy(), oracle_out(oracle, frame, crops, 30, (64, 128), 3), "consumer behind stream_wait")
+    finally:
+        q.destroy()
+
+
+def test_queue_refuses_what_the_server_does_not_take(torch_dev):
+    torch, dev = torch_dev
+    q = cvgs.Queue()
+    try:
+        frame_t = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
+        out_t = torch.zeros((2, 3 * 64 * 128), dtype=torch.float16, device=dev)
+        ops = H.k1_chain(cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), H.fixed_crops(2), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_16FC1), half=True)
+        with pytest.raises(capi.CvgsError):
+            q.submit(*ops)
+        # the queue is still usable afterwards
+        out32, ops32 = gpu_chain(torch, dev, frame_t, H.fixed_crops(2), 2, (64, 128), 3)
+        q.wait(q.submit(*ops32))
+    finally:
+        q.destroy()

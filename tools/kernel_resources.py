@@ -7,7 +7,8 @@ pointwise body made LLVM keep 24 / 48 bytes of a per-thread array in memory; AMD
 kernels).  Every launch of those kernels became 20-25 us slower and 2435 bit-exactness tests stayed green.  All three
 symptoms are visible in the code object's metadata, so the CPU test suite (tests/test_kernel_resources.py) now reads it:
 
-  * .private_segment_fixed_size > 0 or .uses_dynamic_stack   -> scratch (spills / unpromoted allocas / calls)
+  * .private_segment_fixed_size > 0 or .uses_dynamic_stack   -> scratch (VGPR spills / unpromoted allocas / calls); SGPRs
+    parked in VGPR lanes (.sgpr_spill_count) stay in registers and are reported, not refused
   * hidden_* / dispatch-ptr user SGPR                        -> a promoted alloca (nothing in this engine asks for the packet)
   * .group_segment_fixed_size, .vgpr_count, .sgpr_count      -> compared with the committed table (tools/kernel_resources.json)
 
@@ -133,7 +134,8 @@ def kernels_of(lib_path):
                 "scratch": k[".private_segment_fixed_size"],
                 "vgpr": k[".vgpr_count"],
                 "sgpr": k[".sgpr_count"],
-                "spill": k.get(".vgpr_spill_count", 0) + k.get(".sgpr_spill_count", 0),
+                "spill": k.get(".vgpr_spill_count", 0),            # VGPRs spilled to scratch MEMORY
+                "sgpr_spill": k.get(".sgpr_spill_count", 0),        # SGPRs parked in VGPR lanes (v_writelane): registers, not memory
                 "dynamic_stack": bool(k.get(".uses_dynamic_stack", False)),
                 "dispatch_ptr": bool(props & 0x2),   # ENABLE_SGPR_DISPATCH_PTR
                 "queue_ptr": bool(props & 0x4),      # ENABLE_SGPR_QUEUE_PTR
@@ -158,7 +160,7 @@ def violations(kernels):
         if k["scratch"] > 0:
             why.append("scratch %d B/lane" % k["scratch"])
         if k["spill"] > 0:
-            why.append("%d spilled registers" % k["spill"])
+            why.append("%d VGPRs spilled to scratch" % k["spill"])
         if k["dynamic_stack"]:
             why.append("dynamic stack (a call that was not inlined)")
         if k["dispatch_ptr"] or k["queue_ptr"]:

@@ -69,6 +69,12 @@ def parse():
     p.add_argument("--frames-per-launch", type=int, default=1, help="independent 50-crop chains fused per launch (cvgs_execute_many)")
     p.add_argument("--table", action="store_true", help="descriptors in a resident device table, not kernel args")
     p.add_argument("--eager", action="store_true", help="time eager launches instead of graph replay (PMC runs)")
+    p.add_argument("--submission", choices=("queue", "graph"), default="queue",
+                   help="headline submission path: the device-side descriptor queue (one cvgs_queue_submit per step) or one "
+                        "graph-replayed cvgs_execute launch per step")
+    p.add_argument("--no-queue-events", action="store_true",
+                   help="queue submission: no HIP events on the server's stream (rocprofv3 --pmc crashes on them); the server's "
+                        "duration then comes from its own 100 MHz clock (cvgs_queue_stats)")
     p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -212,6 +218,90 @@ def measure(wl, steps, warmup, barrier=lambda: None, eager=False, target_s=0.25,
             "wall_s": w1 - w0, "replays": reps, "passes_per_replay": m_rep, "wall_step_s": (w1 - w0) / ((reps + 1) * steps * m_rep)}
 
 
+def measure_queue(wl, steps, warmup, barrier=lambda: None, target_s=0.25, min_replays=MIN_REPLAYS, est_step_s=2.6e-6, events=True):
+    """The same protocol on the device-side descriptor queue: a step = ONE cvgs_queue_submit of one frame's 50-crop chain (the
+    call shape of executeOperations), no kernel launch per step.  A replay = the K steps (repeated m times, m*K >= 256) handed
+    to cvgs_queue_submit_many; replays are pipelined the way a serving loop runs (replay r+1 is submitted, then replay r's
+    last ticket is awaited), the host's wall clock is stamped at every awaited ticket, and the per-step time is the MEDIAN over
+    the replays of (stamp difference / (m*K)) -- an end-to-end figure: host lowering, the BAR write, dispatch, the kernel and
+    the completion flag.  The server grid lives across the whole timed region (ONE launch): its duration between two HIP
+    events on ITS stream / the batches it served is reported beside it and feeds roofline.achieved."""
+    m_rep = 1 if steps >= 256 else -(-256 // steps)
+    n = steps * m_rep
+    q = cvgs.Queue(depth=128, idle_us=2000.0)
+    order = [wl.chains[i % len(wl.chains)] for i in range(n)]
+    ptrs = cvgs.Queue.chain_pointers(order)
+    try:
+        # 1. pre-roll (clock ramp) + the W warm-up steps
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < PREROLL_S:
+            q.wait(q.submit_many(ptrs, n))
+        if warmup:
+            wp = cvgs.Queue.chain_pointers([wl.chains[i % len(wl.chains)] for i in range(warmup)])
+            q.wait(q.submit_many(wp, warmup))
+        torch.cuda.synchronize()  # (waits for the server to retire: the timed region below starts with its launch)
+        reps = int(min(2000, max(min_replays, math.ceil(target_s / (n * est_step_s)))))
+        if events:
+            qs = torch.cuda.ExternalStream(q.stream_handle())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        launches_before = q.stats()["server_launches"]
+        barrier()
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        if events:
+            e0.record(qs)
+        prev = q.submit_many(ptrs, n)  # lead-in: the host gets one replay ahead
+        q.wait(prev)
+        stamps = [time.perf_counter()]
+        prev = q.submit_many(ptrs, n)
+        for _ in range(reps):
+            cur = q.submit_many(ptrs, n)
+            q.wait(prev)
+            stamps.append(time.perf_counter())
+            prev = cur
+        q.wait(prev)
+        if events:
+            e1.record(qs)  # completes when the server retires (idle_us after the last batch)
+        torch.cuda.synchronize()
+        barrier()
+        w1 = time.perf_counter()
+        st = q.stats()
+        t = np.sort(np.diff(np.array(stamps)) / n)
+        batches = (reps + 2) * n
+        # warm single-batch latency: the server is alive, one batch at a time
+        lat = []
+        q.wait(q.submit_many(ptrs, n))
+        for i in range(200):
+            l0 = time.perf_counter()
+            q.wait(q.submit_lowered(wl.chains[i % len(wl.chains)]))
+            lat.append((time.perf_counter() - l0) * 1e6)
+        lat = np.sort(np.array(lat))
+        return {"step_s": float(np.median(t)), "p10_s": percentile(t, 0.10), "p90_s": percentile(t, 0.90), "min_s": float(t[0]),
+                "wall_s": w1 - w0, "replays": reps, "passes_per_replay": m_rep, "wall_step_s": (w1 - w0) / batches,
+                "server_launches_in_timed_region": st["server_launches"] - launches_before,
+                "server_kernel_ms": e0.elapsed_time(e1) if events else st["server_ticks_100MHz"] / 1e5, "batches_served": batches, "idle_tail_ms": 2.0,
+                "server_kernel_clock": "HIP events on the server's stream" if events else "the server's own 100 MHz clock (s_memrealtime)",
+                "queue": {"worker_workgroups": st["workgroups"], "ring_slots": st["ring_slots"],
+                          "host_writes_device_memory": st["host_writes_device_memory"], "error": st["error"]},
+                "latency": {"median_us": round(float(np.median(lat)), 3), "p10_us": round(percentile(lat, 0.1), 3),
+                            "p90_us": round(percentile(lat, 0.9), 3)}}
+    finally:
+        q.destroy()
+
+
+def queue_outputs_match_execute(wl):
+    """Every resident frame's tensor as the queue left it against what ONE cvgs_execute launch writes for the same chain."""
+    s = torch.cuda.current_stream().cuda_stream
+    ok = True
+    for i in range(len(wl.chains)):
+        got = wl.outs[i].clone()
+        wl.outs[i].zero_()
+        wl.launch(i, s)
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(got.view(torch.int32), wl.outs[i].view(torch.int32)))
+    return ok
+
+
 def single_launch_latency(wl, n=200):
     """One launch between two HIP events, stream idle before it (eager): what ONE 50-crop batch costs end to end on the
     device, including the launch's own start-up -- the latency figure beside the back-to-back step time."""
@@ -328,7 +418,13 @@ def main():
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
 
-    m = measure(wl, a.steps, a.warmup, eager=a.eager)
+    use_queue = a.submission == "queue" and M == 1 and not a.eager and not a.table and n <= 74
+    m_graph = None
+    if use_queue:
+        m = measure_queue(wl, a.steps, a.warmup, events=not a.no_queue_events)
+        queue_ok = queue_outputs_match_execute(wl)
+    else:
+        m = measure(wl, a.steps, a.warmup, eager=a.eager)
     step_s = m["step_s"]
     px_per_step = wl.pixels_per_launch()
     result = {
@@ -350,12 +446,18 @@ def main():
                    "chain": "resize(bilinear) -> RGB2BGR -> x0.3 -> -(1,4,3.2) -> /(3.2,0.6,11.8) -> TensorSplit",
                    "crops_per_launch": n, "frames_per_launch": M, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
                    "descriptors": "device table" if (a.table or M > 1) else "kernel arguments",
-                   "submission": "eager" if a.eager else "hipGraph replay (%d-launch graphs)" % (256 if a.steps >= 256 else a.steps * -(-256 // a.steps)),
-                   "regime": "one launch per step, steps serialised on one stream (launch-latency regime: a 50-crop launch "
-                             "moves ~9 MB = 1.1 us at 8 TB/s behind a ~1.8 us launch/drain floor)" if M == 1 else
+                   "submission": ("device-side descriptor queue: one cvgs_queue_submit per step, a resident server grid, no launch per step"
+                                  if use_queue else ("eager" if a.eager else "hipGraph replay (%d-launch graphs)" % (256 if a.steps >= 256 else a.steps * -(-256 // a.steps)))),
+                   "regime": ("one frame (50 crops) per step; consecutive steps overlap on the device (batch k+1 loads while batch k stores)"
+                              if use_queue else
+                              "one launch per step, steps serialised on one stream (launch-latency regime: a 50-crop launch "
+                              "moves ~9 MB = 1.1 us at 8 TB/s behind a ~1.8 us launch/drain floor)") if M == 1 else
                              "%d independent 50-crop chains fused per launch (cvgs_execute_many)" % M,
                    "parallelism": "1 process per GPU, crop lists sharded, no collective"},
-        "timing": {"protocol": "pre-roll >= %d ms; graph of the K steps (repeated m times when K < 256, so that a graph holds >= 256 "
+        "timing": {"protocol": ("pre-roll >= %d ms; the K steps (repeated m times when K < 256) handed to cvgs_queue_submit_many per replay, replays "
+                                "pipelined one ahead, host wall clock stamped at every awaited last ticket; per-step time = median over "
+                                "replays of stamp difference / (m x K) -- end to end, host side included" % int(PREROLL_S * 1e3)) if use_queue else
+                               "pre-roll >= %d ms; graph of the K steps (repeated m times when K < 256, so that a graph holds >= 256 "
                                "launches) replayed R times back to back, HIP events on the launch stream around each replay; "
                                "per-step time = median over replays of event time / (m x K)" % int(PREROLL_S * 1e3),
                    "replays": m["replays"], "passes_over_the_K_steps_per_replay": m["passes_per_replay"], "step_us_median": round(step_s * 1e6, 4), "step_us_p10": round(m["p10_s"] * 1e6, 4),
@@ -366,19 +468,36 @@ def main():
     }
 
     alg = wl.algorithmic_bytes()
-    achieved = alg / step_s / 1e9
+    kernel_us = step_s * 1e6
+    if use_queue:
+        # the dominant kernel is the server grid: ONE launch served every batch of the timed region; its duration between two
+        # HIP events on its own stream (minus the idle tail it waits before retiring) / the batches it served
+        kernel_us = (m["server_kernel_ms"] - m["idle_tail_ms"]) * 1e3 / m["batches_served"]
+        result["timing"]["server_kernel"] = {"launches_in_timed_region": m["server_launches_in_timed_region"], "duration_ms": round(m["server_kernel_ms"], 3),
+                                             "idle_tail_ms": m["idle_tail_ms"], "batches_served": m["batches_served"], "us_per_batch": round(kernel_us, 4), "clock": m["server_kernel_clock"],
+                                             "kernel": "k1q_server<1, 2> (rocprofv3: ONE call per timed region; avg duration / batches_served agrees)"}
+        result["timing"]["batch_latency_server_alive"] = m["latency"]
+        result["queue"] = m["queue"]
+        result["queue"]["every_frame_bit_identical_to_cvgs_execute"] = queue_ok
+    achieved = alg / (kernel_us * 1e-6) / 1e9
     ceiling = copy_ceiling(dev)
     sector = wl.sector_bound_bytes()
     result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, a.table, M),
-                          "kernel": wl.kernel, "kernel_us": round(step_s * 1e6, 3),
+                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, a.table, M, use_queue),
+                          "kernel": "k1q_server (queue) / " + wl.kernel if use_queue else wl.kernel, "kernel_us": round(kernel_us, 3),
+                          "frac_end_to_end": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 4),
                           "algorithmic_bytes_per_launch": int(alg),
                           # distinct 64-byte sectors holding a tapped byte + the writes: what no kernel can go below
                           "sector_bound_bytes_per_launch": int(sector),
-                          "frac_of_sector_bound": round(sector / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "frac_of_sector_bound": round(sector / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                           # the on-box device-to-device copy ceiling (read + write bytes / time), measured now
                           "copy_ceiling": ceiling, "frac_of_copy_ceiling": round(achieved / ceiling, 4) if ceiling else None}
     result["timing"]["single_launch_latency"] = single_launch_latency(wl)
+    if use_queue:  # the same workload with one graph-replayed launch per step: the round-1/2 headline, for comparison
+        mg = measure(wl, a.steps, a.warmup)
+        result["one_launch_per_step"] = {"us_per_step": round(mg["step_s"] * 1e6, 4), "Mpix_per_s": round(px_per_step / mg["step_s"] / 1e6, 1),
+                                         "frac": round(alg / mg["step_s"] / 1e9 / HBM_PEAK_GBS, 4), "kernel": wl.kernel,
+                                         "submission": "hipGraph replay, one cvgs_execute launch per step"}
     if not a.no_cpu and M == 1:
         result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
     if not a.no_extra:
@@ -420,15 +539,15 @@ def copy_ceiling(dev, mib=256, iters=20):
         return None
 
 
-def pmc_traffic(crops, table, per_launch=1):
-    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    separate --pmc runs, corrected as calibrated in profiles/).  Counters cannot be read from inside
-    this process, so the value is the one measured for exactly this workload/kernel; null for any other configuration."""
+def pmc_traffic(crops, table, per_launch=1, queue=False):
+    """HBM bytes per launch (per batch on the queue) of the headline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE +
+    WRITE_SIZE, separate --pmc runs, corrected as calibrated in profiles/).  Counters cannot be read from inside this process, so
+    the value is the one measured for exactly this workload/kernel; null for any other configuration."""
     path = os.path.join(ROOT, "profiles", "pmc_headline.json")
     if crops != CROPS or table or per_launch != 1 or not os.path.exists(path):
         return None
     try:
-        j = json.load(open(path))
+        j = json.load(open(path))["queue" if queue else "launch"]
         return int(j["fetch_size_kb"] * 1024 * j["fetch_correction"] + j["write_size_kb"] * 1024)
     except Exception:
         return None

@@ -113,6 +113,7 @@ SYMBOLS = [
     ("cvgs_queue_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_double]),
     ("cvgs_queue_stream_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("cvgs_queue_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("cvgs_queue_stream", C.c_void_p, [C.c_void_p]),
     ("cvgs_queue_profile", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("cvgs_queue_destroy", C.c_int, [C.c_void_p]),
     ("cvgs_range_push", None, [C.c_char_p]),

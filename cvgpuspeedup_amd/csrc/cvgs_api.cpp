@@ -1201,6 +1201,8 @@ int cvgs_queue_stats(cvgs_queue_t h, uint64_t* out8) {
     return CVGS_OK;
 }
 
+cvgs_stream_t cvgs_queue_stream(cvgs_queue_t h) { return h ? cvgs::queue_stream(h->q) : nullptr; }
+
 int cvgs_queue_profile(cvgs_queue_t h, uint64_t* out16) {
     if (!h || !out16) return fail(CVGS_ERR_INVALID, "null queue / output");
     cvgs::queue_prof(h->q, out16);

@@ -757,7 +757,8 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
         err = std::string("queue init: ") + hipGetErrorString(e);
         return -1;
     }
-    q->direct = !(flags & 1u) && probe_direct(&q->m.dc->stop_gen.pad[0]);
+    static const char* staged_env = getenv("CVGS_QUEUE_STAGED"); // debugging / profilers that remap device memory: force the staging path
+    q->direct = !(flags & 1u) && !(staged_env && staged_env[0] == '1') && probe_direct(&q->m.dc->stop_gen.pad[0]);
     if (!q->direct) {
         if ((e = hipHostMalloc((void**)&q->host_ring, R * kQSlotBytes, hipHostMallocDefault)) != hipSuccess ||
             (e = hipHostMalloc((void**)&q->host_index, R * sizeof(QIndex), hipHostMallocDefault)) != hipSuccess) {

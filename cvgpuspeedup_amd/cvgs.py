@@ -639,6 +639,10 @@ class Queue:
         d["ring_slots"] &= 0xffffffff
         return d
 
+    def stream_handle(self):
+        """hipStream_t of the server grid (HIP events around its launches, profilers)"""
+        return self.lib.cvgs_queue_stream(self.handle)
+
     def profile(self):
         """instrumentation of the last retired server: ticks are 10 ns"""
         out = (C.c_uint64 * 16)()

@@ -468,4 +468,20 @@ private:
     fk::ChainBatch batch_;
 };
 
+// ---- device-side descriptor queue (engine extension, see fk::Queue): executeOperations without a launch per call -------
+class Queue {
+public:
+    explicit Queue(int device = 0, int depth = 0, double idle_us = 0.0) : q_(device, depth, idle_us) {}
+    template <typename... IOps> uint64_t submit(const IOps&... iops) { return q_.submit(iops...); }
+    void wait(uint64_t ticket, double timeout_s = 10.0) { q_.wait(ticket, timeout_s); }
+    void wait(uint64_t ticket, const cv::cuda::Stream& consumer) { q_.wait(ticket, cv::cuda::StreamAccessor::getStream(consumer)); }
+private:
+    fk::Queue q_;
+};
+// cvGS::executeOperations(queue, iops...): the stream form's IOps, a ticket instead of a stream position
+template <typename... IOpTypes>
+inline uint64_t executeOperations(Queue& queue, const IOpTypes&... iops) {
+    return queue.submit(iops...);
+}
+
 } // namespace cvGS

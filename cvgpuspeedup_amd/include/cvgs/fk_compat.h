@@ -763,6 +763,40 @@ private:
     std::vector<cvgs_chain_desc> descs_;
 };
 
+// ---- device-side descriptor queue (engine extension: cvgs_queue_*) ---------------------------------------------------
+// executeOperations' call shape -- one call per frame, the same IOps -- without a kernel launch per call: a resident server
+// grid takes the batch from a ring and consecutive batches overlap on the device (a 50-crop batch every ~2.6 us instead of
+// 4.4 us with one launch each; include/cvgs_hip.h "device-side descriptor queue").  Only K1's hot shape is taken (batched
+// 8UC3 / 8UC4 bilinear resize -> [cvtColor swap] -> multiply -> subtract -> divide -> split into an fp32 tensor, <= 74 crops):
+// anything else throws, exactly as an unsupported chain does elsewhere in the facade; those chains belong to the stream form.
+//     fk::Queue q;                                             // once
+//     auto t = fk::executeOperations(q, resize, cvt, mul, sub, div, split);   // per frame, asynchronous
+//     q.wait(t);   or   q.wait(t, consumerStream);             // host wait, or order a consumer stream behind the ticket
+// The sources must be complete when the call is made (the server is not ordered behind any stream).
+class Queue {
+public:
+    explicit Queue(int device = 0, int depth = 0, double idle_us = 0.0) { detail::check_status(cvgs_queue_create(&q_, device, depth, idle_us, 0u)); }
+    Queue(const Queue&) = delete;
+    Queue& operator=(const Queue&) = delete;
+    ~Queue() { if (q_) (void)cvgs_queue_destroy(q_); }
+    template <typename... IOps> uint64_t submit(const IOps&... iops) {
+        ChainBuilder b;
+        lowerChain(b, iops...);
+        uint64_t ticket = 0;
+        detail::check_status(cvgs_queue_submit(q_, &b.d, &ticket));
+        return ticket;
+    }
+    void wait(uint64_t ticket, double timeout_s = 10.0) { detail::check_status(cvgs_queue_wait(q_, ticket, timeout_s)); }
+    void wait(uint64_t ticket, hipStream_t consumer) { detail::check_status(cvgs_queue_stream_wait(q_, ticket, consumer)); }
+    cvgs_queue_t handle() const { return q_; }
+private:
+    cvgs_queue_t q_ = nullptr;
+};
+template <bool THREAD_FUSION = true, typename... IOps>
+inline uint64_t executeOperations(Queue& queue, const IOps&... iops) {
+    return queue.submit(iops...);
+}
+
 // ---- CircularTensor ------------------------------------------------------------------------------------------------
 // MIRRORED (engine extension, default off = the reference's behaviour): the opt-in mirrored-ring layout of
 // cvgs_circular_create_ex -- no shift traffic per update, but ptr()/data() MOVE with every update.

@@ -378,6 +378,8 @@ int cvgs_queue_stream_wait(cvgs_queue_t q, uint64_t ticket, cvgs_stream_t stream
 /* out[8]: submitted, completed, server launches, feeder rounds and lifetime (100 MHz ticks) of the last retired server,
  * worker workgroups, ring slots, error word */
 int cvgs_queue_stats(cvgs_queue_t q, uint64_t* out8);
+/* the hipStream_t the server grid is launched on (for HIP events / profilers; do not enqueue work behind a live server) */
+cvgs_stream_t cvgs_queue_stream(cvgs_queue_t q);
 /* out[16], of the last RETIRED server, 100 MHz ticks / counts: feeder {rounds with copies, slots, load ticks, copy ticks},
  * monitor {scans, scan ticks, completions published, -}, worker 0 {tasks, find ticks, rows ticks, drain ticks, idle polls} */
 int cvgs_queue_profile(cvgs_queue_t q, uint64_t* out16);

@@ -241,6 +241,59 @@ static void sweep(cv::cuda::Stream& stream) {
     test_random_vs_oracle<TI, TO, 24, cvGS::PRESERVE_AR>(stream);
 }
 
+// engine extension: the device-side descriptor queue -- executeOperations(queue, iops...) must give the bits of the stream form
+template <int TI, int TO, int BATCH>
+static void test_queue_vs_oracle(cv::cuda::Stream& stream) {
+    constexpr int CN = CV_MAT_CN(TO);
+    const Params& p = kParams[CN - 1];
+    const cv::Size up(64, 128);
+    cvGS::Queue queue;
+    const int FRAMES = 6;
+    std::vector<cv::Mat> h_frames;
+    std::vector<cv::cuda::GpuMat> d_frames, d_tensors;
+    std::vector<uint64_t> tickets;
+    std::vector<std::array<cv::Rect, BATCH>> rects(FRAMES);
+    for (int f = 0; f < FRAMES; ++f) {
+        h_frames.emplace_back(720, 1280, TI);
+        fill_random(h_frames.back(), 0xC0FFEEull + 7000 + f);
+        d_frames.emplace_back(h_frames.back());
+        cv::cuda::GpuMat t(BATCH, up.width * up.height * CN, CV_32F);
+        d_tensors.push_back(t);
+        for (int i = 0; i < BATCH; ++i) {
+            const int w = 8 + ((i + f) * 37) % 400, hgt = 16 + ((i + 2 * f) * 53) % 600;
+            rects[f][i] = cv::Rect(((i + f) * 91) % (1280 - w), (i * 67) % (720 - hgt), w, hgt);
+        }
+    }
+    stream.waitForCompletion(); // uploads done: the queue is not ordered behind any stream
+    for (int f = 0; f < FRAMES; ++f) { // six frames in flight, no wait in between
+        std::array<cv::cuda::GpuMat, BATCH> crops;
+        for (int i = 0; i < BATCH; ++i) crops[i] = d_frames[f](rects[f][i]);
+        tickets.push_back(std::apply([&](const auto&... iops) { return cvGS::executeOperations(queue, iops...); },
+                                     build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(crops, d_tensors[f], up, p)));
+    }
+    const size_t n = (size_t)BATCH * CN * up.width * up.height;
+    for (int f = 0; f < FRAMES; ++f) {
+        queue.wait(tickets[f]);
+        cv::cuda::GpuMat hv_frame = host_view(h_frames[f]);
+        std::array<cv::cuda::GpuMat, BATCH> h_crops;
+        for (int i = 0; i < BATCH; ++i) h_crops[i] = hv_frame(rects[f][i]);
+        cv::Mat h_ref(BATCH, up.width * up.height * CN, CV_32F);
+        cv::cuda::GpuMat hv_ref = host_view(h_ref);
+        std::apply([&](const auto&... iops) { run_oracle(iops...); }, build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(h_crops, hv_ref, up, p));
+        const auto h = fetch(d_tensors[f].data, n * sizeof(float));
+        CHECK(bit_equal(h.data(), h_ref.data, n * sizeof(float)), "queue: frame " << f << " bit-exact vs oracle, type " << TI);
+    }
+    // a chain the server does not take throws like any unsupported chain
+    bool threw = false;
+    try {
+        cv::cuda::GpuMat out(up.height, up.width, TO);
+        cvGS::executeOperations(queue, cvGS::resize<TI, cv::INTER_LINEAR>(d_frames[0], up, 0., 0.), cvGS::write<TO>(out));
+    } catch (const std::exception&) {
+        threw = true;
+    }
+    CHECK(threw, "queue refuses a chain that is not the batched resize -> normalize -> split shape");
+}
+
 int main() {
     cv::cuda::Stream stream;
     // the type list of the reference's LAUNCH_TESTS (test_batchresize_x_split3D.cu:427-432)
@@ -255,5 +308,7 @@ int main() {
     test_chain_batch(stream);
     test_half_handoff<CV_8UC3, 50>(stream);
     test_half_handoff<CV_8UC4, 17>(stream);
+    test_queue_vs_oracle<CV_8UC3, CV_32FC3, 50>(stream);
+    test_queue_vs_oracle<CV_8UC4, CV_32FC4, 9>(stream);
     return report("test_batchresize_x_split3D + aspectratio");
 }

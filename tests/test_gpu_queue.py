@@ -163,3 +163,79 @@ def test_queue_refuses_what_the_server_does_not_take(torch_dev):
         q.wait(q.submit(*ops32))
     finally:
         q.destroy()
+
+
+def test_queue_staging_path_without_host_writes_to_device_memory(oracle, torch_dev):
+    """flags bit 0: never write device memory from the host -- slots travel through pinned host copies and a staging kernel
+    (what the queue falls back to where the PCIe BAR does not expose device memory)."""
+    torch, dev = torch_dev
+    q = cvgs.Queue(flags=1)
+    try:
+        assert q.stats()["host_writes_device_memory"] is False
+        frame = H.random_u8((720, 1280, 3), seed=31)
+        frame_t = torch.from_numpy(frame).to(dev)
+        jobs = []
+        for i in range(40):
+            crops = H.random_crops(1 + i % 20, 1280, 720, wmax=300, hmax=400, seed=300 + i)
+            out_t, ops = gpu_chain(torch, dev, frame_t, crops, len(crops), (64, 128), 3)
+            jobs.append((crops, out_t, cvgs.lower(ops)))
+        torch.cuda.synchronize()
+        tickets = [q.submit_lowered(j[2]) for j in jobs]
+        for t in tickets:
+            q.wait(t)
+        for i, (crops, out_t, _) in enumerate(jobs):
+            H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, len(crops), (64, 128), 3), "staged batch %d" % i)
+    finally:
+        q.destroy()
+
+
+def test_queue_tiny_batches_on_a_deep_ring(oracle, torch_dev):
+    """600 batches of 1-3 crops through a 256-slot ring: a worker's consecutive tasks lie hundreds of batches apart, so the
+    64-entry index window has to step through the ring; small targets (one 4-row task per plane) and out-of-order completion."""
+    torch, dev = torch_dev
+    q = cvgs.Queue(depth=256)
+    try:
+        frame = H.random_u8((480, 640, 3), seed=41)
+        frame_t = torch.from_numpy(frame).to(dev)
+        jobs = []
+        for i in range(600):
+            crops = H.random_crops(1 + i % 3, 640, 480, wmax=200, hmax=300, seed=4000 + i)
+            dst = (64, 128) if i % 2 else (48, 20)
+            out_t, ops = gpu_chain(torch, dev, frame_t, crops, len(crops), dst, 3)
+            jobs.append((crops, dst, out_t, cvgs.lower(ops)))
+        torch.cuda.synchronize()
+        last = None
+        for j in jobs:
+            last = q.submit_lowered(j[3])
+        for t in range(last + 1):
+            q.wait(t)
+        st = q.stats()
+        assert st["completed"] == 600 and st["error"] == 0, st
+        for i, (crops, dst, out_t, _) in enumerate(jobs):
+            if i % 7 == 0 or i > 590:
+                H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, len(crops), dst, 3), "tiny batch %d" % i)
+    finally:
+        q.destroy()
+
+
+def test_queue_two_queues_side_by_side(oracle, torch_dev):
+    """Two queues on one device (two server grids share the chip): both produce the oracle's bits."""
+    torch, dev = torch_dev
+    qa, qb = cvgs.Queue(), cvgs.Queue()
+    try:
+        frame = H.random_u8((720, 1280, 3), seed=51)
+        frame_t = torch.from_numpy(frame).to(dev)
+        jobs = []
+        for i in range(30):
+            crops = H.random_crops(10 + i, 1280, 720, wmax=300, hmax=400, seed=500 + i)
+            out_t, ops = gpu_chain(torch, dev, frame_t, crops, len(crops), (64, 128), 3)
+            jobs.append((crops, out_t, cvgs.lower(ops)))
+        torch.cuda.synchronize()
+        tickets = [(qa if i % 2 == 0 else qb).submit_lowered(j[2]) for i, j in enumerate(jobs)]
+        for i, t in enumerate(tickets):
+            (qa if i % 2 == 0 else qb).wait(t)
+        for i, (crops, out_t, _) in enumerate(jobs):
+            H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, len(crops), (64, 128), 3), "queue %s batch %d" % ("ab"[i % 2], i))
+    finally:
+        qa.destroy()
+        qb.destroy()

@@ -5,6 +5,12 @@
                                             (rocpd .db or *_kernel_trace.csv from --kernel-trace)
   prof_summary.py pmc <counter_collection.csv> [kernel-substring]
                                             per-kernel mean of every collected counter
+  prof_summary.py calls <dir-or-file> <kernel-substring>
+                                            every call of the matching kernels with its duration -- for the descriptor queue's
+                                            server grid, where ONE call serves a whole timed region (bench.py prints how many
+                                            batches it served: duration / batches = the per-batch kernel time)
+  prof_summary.py pmccalls <counter_collection.csv> <kernel-substring>
+                                            every call's counter values (same reason)
 """
 import csv
 import glob
@@ -49,6 +55,25 @@ def kernels(path):
                                                              100.0 * sum(v) / total))
 
 
+def calls(path, sub):
+    rows, src = kernel_rows(path)
+    print("# source: %s" % os.path.basename(src))
+    print("%-60s %6s %14s" % ("kernel", "call", "duration_us"))
+    i = 0
+    for n, s0, e0 in sorted(rows, key=lambda r: r[1]):
+        if sub in n:
+            print("%-60s %6d %14.1f" % (short(n, 60), i, (e0 - s0) / 1e3))
+            i += 1
+
+
+def pmccalls(path, sub):
+    print("# source: %s" % os.path.basename(path))
+    print("%-60s %-16s %18s" % ("kernel", "counter", "value"))
+    for r in csv.DictReader(open(path)):
+        if sub in r["Kernel_Name"]:
+            print("%-60s %-16s %18.1f" % (short(r["Kernel_Name"], 60), r["Counter_Name"], float(r["Counter_Value"])))
+
+
 def pmc(path, sub=""):
     by = {}
     for r in csv.DictReader(open(path)):
@@ -64,7 +89,11 @@ def pmc(path, sub=""):
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         raise SystemExit(__doc__)
-    if sys.argv[1] == "kernels":
+    if sys.argv[1] == "calls":
+        calls(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmccalls":
+        pmccalls(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "kernels":
         kernels(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")

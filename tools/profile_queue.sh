@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): the rocprofv3 evidence of the headline on the device-side descriptor queue.
+#   tools/profile_queue.sh r03_c
+# The dominant kernel is the server grid k1q_server: ONE call serves the whole timed region of bench.py, which prints how many
+# batches that call served -- its duration / batches is the per-batch kernel time of roofline.achieved.  PMC passes are separate
+# runs with --kernel-trace only.
+set -u
+TAG=${1:-queue}
+OUT=gpurun_out/$TAG
+RAW=/tmp/prof_$TAG
+mkdir -p $OUT $RAW
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+RP="rocprofv3 --kernel-trace --output-format csv"
+SUM="python tools/prof_summary.py"
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra > $OUT/bench_unprofiled_20_5.json 2>/dev/null
+timeout -k 5 300 $RP --stats -d $RAW/trace -o t -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extra > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+$SUM kernels $RAW/trace/t_kernel_trace.csv > $OUT/bench_trace_kernels.txt 2>&1
+$SUM calls $RAW/trace/t_kernel_trace.csv k1q_server > $OUT/bench_trace_server_calls.txt 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 5 300 $RP --pmc $C -d $RAW/pmc_$C -o p -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extra --no-queue-events > $OUT/bench_pmc_$C.json 2>/dev/null
+  $SUM pmccalls $RAW/pmc_$C/p_counter_collection.csv k1q_server > $OUT/pmc_${C}_server_calls.txt 2>&1
+done
+ls -la $OUT

@@ -22,6 +22,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RCCL = 0, -1, -2, 
 
 # depths / types (OpenCV encoding)
 CIRCULAR_MIRRORED = 1
+CIRCULAR_CAPTURABLE = 2
 DEPTH_8U, DEPTH_8S, DEPTH_16U, DEPTH_16S, DEPTH_32S, DEPTH_32F, DEPTH_64F, DEPTH_16F = range(8)
 
 

@@ -921,6 +921,9 @@ struct cvgs_circular_s {
     uint8_t* ring;      // history: update k lives in slot k % batch, standard [c][y][x] order
     int64_t count;
     bool mirrored;      // ring of 2*batch slots, every frame stored twice, data() is a moving window; `out` unused
+    bool capturable;    // CVGS_CIRCULAR_CAPTURABLE: the count lives in `dcount`, updates go through `stage`
+    uint8_t* stage;     // one image
+    uint64_t* dcount;   // device: updates completed
 };
 
 int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
@@ -932,7 +935,7 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
                             int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode, int32_t device_id,
                             uint32_t flags) {
     if (!out) return fail(CVGS_ERR_INVALID, "null handle pointer");
-    if (flags & ~CVGS_CIRCULAR_MIRRORED) return fail(CVGS_ERR_INVALID, "unknown CircularTensor flags");
+    if (flags & ~(uint32_t)(CVGS_CIRCULAR_MIRRORED | CVGS_CIRCULAR_CAPTURABLE)) return fail(CVGS_ERR_INVALID, "unknown CircularTensor flags");
     const bool mirrored = (flags & CVGS_CIRCULAR_MIRRORED) != 0;
     if (mirrored && cp_mode != CVGS_PLANES_STANDARD)
         return fail(CVGS_ERR_UNSUPPORTED, "mirrored CircularTensors exist in the Standard plane order only");
@@ -964,9 +967,17 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
         if (e == hipSuccess) e = hipMemset(ct->out, 0, total);
         if (e == hipSuccess) e = hipMemset(ct->ring, 0, total);
     }
+    ct->capturable = (flags & CVGS_CIRCULAR_CAPTURABLE) != 0;
+    if (e == hipSuccess && ct->capturable) {
+        e = hipMalloc((void**)&ct->stage, ct->image_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&ct->dcount, 8);
+        if (e == hipSuccess) e = hipMemset(ct->dcount, 0, 8);
+    }
     if (e != hipSuccess) {
         if (ct->out) (void)hipFree(ct->out);
         if (ct->ring) (void)hipFree(ct->ring);
+        if (ct->stage) (void)hipFree(ct->stage);
+        if (ct->dcount) (void)hipFree(ct->dcount);
         delete ct;
         return hip_fail(e, "CircularTensor allocation");
     }
@@ -976,12 +987,13 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
 
 int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_stream_t stream) {
     if (!ct || !chain) return fail(CVGS_ERR_INVALID, "null argument");
-    {
-        // the slot arithmetic lives on the host (ring index, like the reference): a captured update would replay into
-        // the SAME slots forever -- refuse loudly instead of producing a silently wrong graph
+    if (!ct->capturable) {
+        // the slot arithmetic of the default path lives on the host (ring index, like the reference): a captured update would
+        // replay into the SAME slots forever -- refuse loudly instead of producing a silently wrong graph
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            return fail(CVGS_ERR_UNSUPPORTED, "CircularTensor::update cannot be captured into a graph (host-side ring index)");
+            return fail(CVGS_ERR_UNSUPPORTED, "CircularTensor::update cannot be captured into a graph (host-side ring index): create the "
+                                              "handle with CVGS_CIRCULAR_CAPTURABLE");
     }
     cvgs_chain_desc one = *chain;
     if (one.read.batch != 1) return fail(CVGS_ERR_INVALID, "CircularTensor::update pushes one frame: batch must be 1");
@@ -1004,6 +1016,43 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     {
         int rc = guard.enter(ct->device);
         if (rc) return rc;
+    }
+    if (ct->capturable) {
+        // device-indexed update: the chain writes the new frame into the staging image (standard order), the shift kernel
+        // derives every plane job from the device-side count (k_circular.hip: k_circular_dev), a last kernel advances it
+        Lowered L;
+        one.write.data = ct->stage;
+        one.write.width = ct->width;
+        one.write.height = ct->height;
+        one.write.planes = ct->batch;
+        int rc = lower(&one, true, L);
+        if (rc) return rc;
+        if (L.out_w != ct->width || L.out_h != ct->height)
+            return fail(CVGS_ERR_INVALID, "the frame produced by the read stage differs from the CircularTensor's plane size");
+        const int64_t plane = (int64_t)ct->width * ct->height;
+        WriteArgs& Wa = L.args.write;
+        Wa.kind = wk == CVGS_WRITE_TENSOR_T_SPLIT ? CVGS_WRITE_TENSOR_SPLIT : wk;
+        Wa.planes = 1;
+        Wa.data = ct->stage;
+        Wa.data2 = nullptr;
+        Wa.img_stride = wk == CVGS_WRITE_PIXEL_3D ? plane : plane * ct->color_planes;
+        Wa.ch_stride = wk == CVGS_WRITE_PIXEL_3D ? 0 : plane;
+        rc = dispatch(&one, L, (hipStream_t)stream, false, nullptr);
+        if (rc) return rc;
+        CircDev a{};
+        a.out = ct->out;
+        a.ring = ct->ring;
+        a.stage = ct->stage;
+        a.count = ct->dcount;
+        a.plane_bytes = ct->plane_bytes;
+        a.batch = ct->batch;
+        a.color_planes = ct->color_planes;
+        a.order = ct->order;
+        a.transposed = ct->cp_mode == CVGS_PLANES_TRANSPOSED;
+        a.mirrored = ct->mirrored;
+        if (launch_circular_dev(a, stream)) return fail(CVGS_ERR_HIP, "CircularTensor device-indexed shift launch failed");
+        ct->count++; // calls made (captured ones count once); the device-side count is the authority (cvgs_circular_updates)
+        return CVGS_OK;
     }
     if (ct->mirrored) {
         // ONE pass over the new frame, stored at slot p and at slot p+BATCH of a 2*BATCH ring; nothing is shifted.
@@ -1109,16 +1158,27 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
     return CVGS_OK;
 }
 
+// capturable handles: the number of updates that have RUN (graph replays included) is device state
+static int64_t circular_count(cvgs_circular_t ct) {
+    if (!ct->capturable) return ct->count;
+    DeviceGuard guard;
+    if (guard.enter(ct->device)) return ct->count;
+    uint64_t n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, ct->dcount, 8, hipMemcpyDeviceToHost) != hipSuccess) return ct->count;
+    return (int64_t)n;
+}
+
 void* cvgs_circular_data(cvgs_circular_t ct) {
     if (!ct) return nullptr;
     if (!ct->mirrored) return ct->out;
-    if (ct->count == 0) return ct->ring; // nothing pushed yet: any window is all zeros
-    const int64_t km = (ct->count - 1) % ct->batch;
+    const int64_t count = circular_count(ct);
+    if (count == 0) return ct->ring; // nothing pushed yet: any window is all zeros
+    const int64_t km = (count - 1) % ct->batch;
     const int64_t start = ct->order == CVGS_NEWEST_FIRST ? ct->batch - 1 - km : km + 1;
     return ct->ring + (size_t)start * ct->image_bytes;
 }
 size_t cvgs_circular_bytes(cvgs_circular_t ct) { return ct ? ct->image_bytes * (size_t)ct->batch : 0; }
-int64_t cvgs_circular_updates(cvgs_circular_t ct) { return ct ? ct->count : -1; }
+int64_t cvgs_circular_updates(cvgs_circular_t ct) { return ct ? circular_count(ct) : -1; }
 
 int cvgs_circular_destroy(cvgs_circular_t ct) {
     if (!ct) return fail(CVGS_ERR_INVALID, "null handle");
@@ -1126,6 +1186,8 @@ int cvgs_circular_destroy(cvgs_circular_t ct) {
     (void)guard.enter(ct->device);
     if (ct->out) (void)hipFree(ct->out);
     (void)hipFree(ct->ring);
+    if (ct->stage) (void)hipFree(ct->stage);
+    if (ct->dcount) (void)hipFree(ct->dcount);
     delete ct;
     return CVGS_OK;
 }

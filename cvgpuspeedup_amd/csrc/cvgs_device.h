@@ -196,6 +196,16 @@ struct CopyJob {
 };
 static constexpr int kMaxCopyJobs = 64;
 int launch_plane_copies(const CopyJob* jobs, int n_jobs, size_t bytes, void* stream);
+// device-indexed CircularTensor update (capturable): every plane job derived from *count on the device
+struct CircDev {
+    uint8_t* out;         // ordered tensor (unused when mirrored)
+    uint8_t* ring;        // history ring (2 * batch slots when mirrored)
+    const uint8_t* stage; // the new frame, standard [c][y][x] order (or packed pixels, color_planes == 1)
+    const uint64_t* count;
+    size_t plane_bytes;
+    int32_t batch, color_planes, order, transposed, mirrored, pad;
+};
+int launch_circular_dev(const CircDev& a, void* stream);
 // single-launch CircularTensor update (new frame through the thread-fused pointwise chain + all plane copies):
 // returns 1 if it took the update, 0 if the chain / layout is not eligible, <0 on error
 int launch_circular_push(const ChainArgs& c, const PlaneParams& plane, const CopyJob* jobs, int n_jobs, size_t plane_bytes,

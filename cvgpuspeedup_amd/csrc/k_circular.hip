@@ -126,6 +126,79 @@ __global__ __launch_bounds__(256) void k_plane_copy(const CopyArgs a, const size
     for (; i < n_vec; i += stride) dst[i] = src[i];
 }
 
+// ---- device-indexed update (CVGS_CIRCULAR_CAPTURABLE) ----------------------------------------------------------------------
+// The reference's update is an ordinary stream launch (include/cvGPUSpeedup.cuh:612-622), so a serving loop may capture it into a
+// graph.  The default path resolves the ring slot on the HOST (kernel arguments hold the resolved pointers): replaying such a
+// capture would write the same slots for ever.  Here the update count lives in DEVICE memory: the push chain writes the new
+// frame into a fixed staging image, and this kernel -- every plane job derived from *count -- moves it to its tensor slot and
+// its history slot and shifts the older frames; k_circular_bump then advances the count.  Nothing depends on host state, so
+// N captured updates replay as the next N updates.  Costs one extra pass over ONE image (+6 % of cfg #4's traffic).
+template <typename V, int UNROLL>
+__global__ __launch_bounds__(256) void k_circular_dev(const CircDev a, const size_t n_vec) {
+    const int64_t count = (int64_t)*a.count; // updates completed before this one (wave-uniform)
+    const int B = a.batch, CP = a.color_planes;
+    const int job = (int)blockIdx.y;
+    const uint8_t* src;
+    uint8_t* dst;
+    if (a.mirrored) { // 2 * CP jobs: staging plane c -> ring slots p and p + B
+        const int c = job % CP, half = job / CP;
+        const int64_t km = count % B;
+        const int64_t p = a.order == CVGS_NEWEST_FIRST ? B - 1 - km : km;
+        src = a.stage + (size_t)c * a.plane_bytes;
+        dst = a.ring + ((size_t)(p + (half ? B : 0)) * CP + c) * a.plane_bytes;
+    } else if (job >= B * CP) { // CP jobs: staging plane c -> history slot count % B
+        const int c = job - B * CP;
+        src = a.stage + (size_t)c * a.plane_bytes;
+        dst = a.ring + ((size_t)(count % B) * CP + c) * a.plane_bytes;
+    } else { // B * CP jobs: tensor slot z, plane c
+        const int z = job / CP, c = job % CP;
+        const int z_new = a.order == CVGS_NEWEST_FIRST ? 0 : B - 1;
+        if (z == z_new) {
+            src = a.stage + (size_t)c * a.plane_bytes;
+        } else {
+            const int64_t age = a.order == CVGS_NEWEST_FIRST ? z : B - 1 - z;
+            int64_t slot = (count - age) % B;
+            if (slot < 0) slot += B; // never-written history slots hold zeros
+            src = a.ring + ((size_t)slot * CP + c) * a.plane_bytes;
+        }
+        dst = a.transposed ? a.out + ((size_t)c * B + z) * a.plane_bytes : a.out + ((size_t)z * CP + c) * a.plane_bytes;
+    }
+    const V* __restrict__ sp = (const V*)src;
+    V* __restrict__ dp = (V*)dst;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n_vec; i += UNROLL * stride) {
+        V v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(sp + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) __builtin_nontemporal_store(v[u], dp + i + u * stride);
+    }
+    for (; i < n_vec; i += stride) dp[i] = sp[i];
+}
+__global__ void k_circular_bump(uint64_t* count) {
+    if (threadIdx.x == 0) *count += 1;
+}
+
+int launch_circular_dev(const CircDev& a, void* stream) {
+    const int n_jobs = a.mirrored ? 2 * a.color_planes : (a.batch + 1) * a.color_planes;
+    if (n_jobs < 1 || n_jobs > 65535) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    auto blocks_for = [&](size_t n_vec, int unroll) {
+        size_t want = (n_vec + 256 * (size_t)unroll - 1) / (256 * (size_t)unroll);
+        size_t cap = (size_t)(8192 / n_jobs > 1 ? 8192 / n_jobs : 1);
+        size_t b = want < cap ? want : cap;
+        return (unsigned)(b < 1 ? 1 : b);
+    };
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    if (a.plane_bytes % 16 == 0) hipLaunchKernelGGL((k_circular_dev<v4, 8>), dim3(blocks_for(a.plane_bytes / 16, 8), n_jobs), dim3(256), 0, s, a, a.plane_bytes / 16);
+    else if (a.plane_bytes % 4 == 0) hipLaunchKernelGGL((k_circular_dev<uint32_t, 4>), dim3(blocks_for(a.plane_bytes / 4, 4), n_jobs), dim3(256), 0, s, a, a.plane_bytes / 4);
+    else hipLaunchKernelGGL((k_circular_dev<uint8_t, 4>), dim3(blocks_for(a.plane_bytes, 4), n_jobs), dim3(256), 0, s, a, a.plane_bytes);
+    if (hipGetLastError() != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_circular_bump, dim3(1), dim3(64), 0, s, (uint64_t*)a.count);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 typedef float vec4f __attribute__((ext_vector_type(4)));
 
 int launch_plane_copies(const CopyJob* jobs, int n_jobs, size_t bytes, void* stream) {

@@ -533,11 +533,11 @@ class CircularTensor:
     """cvGS::CircularTensor<I, O, COLOR_PLANES, BATCH, ORDER, CP_MODE> (reference include/cvGPUSpeedup.cuh:600-627)."""
 
     def __init__(self, in_type, out_elem_type, color_planes, batch, order, cp_mode=Standard, width=0, height=0,
-                 device_id=0, mirrored=False):
+                 device_id=0, mirrored=False, capturable=False):
         """mirrored=True: the opt-in mirrored-ring variant (cvgs_circular_create_ex, CVGS_CIRCULAR_MIRRORED): no shift
         traffic, but data() moves with every update."""
         self.in_type, self.elem_type, self.color_planes, self.batch = in_type, out_elem_type, color_planes, batch
-        self.order, self.cp_mode, self.mirrored = order, cp_mode, mirrored
+        self.order, self.cp_mode, self.mirrored, self.capturable = order, cp_mode, mirrored, capturable
         self.handle = C.c_void_p(0)
         self.lib = capi.load_library()
         if width and height:
@@ -547,7 +547,7 @@ class CircularTensor:
         self.width, self.height = width, height
         capi.check(self.lib.cvgs_circular_create_ex(C.byref(self.handle), width, height, self.elem_type,
                                                     self.color_planes, self.batch, self.order, self.cp_mode, device_id,
-                                                    capi.CIRCULAR_MIRRORED if self.mirrored else 0))
+                                                    (capi.CIRCULAR_MIRRORED if self.mirrored else 0) | (capi.CIRCULAR_CAPTURABLE if self.capturable else 0)))
 
     def update(self, stream, *iops, flags=0):
         """update(stream, GpuMat input, iops..., write) or update(stream, readIOp, iops..., write)."""

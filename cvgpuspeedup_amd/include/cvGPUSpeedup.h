@@ -434,11 +434,12 @@ inline void executeOperations(const std::array<cv::cuda::GpuMat, Batch>& input, 
 
 // ---- CircularTensor --------------------------------------------------------------------------------------------------
 // MIRRORED = true selects the opt-in mirrored-ring layout (engine extension; see include/cvgs_hip.h): data() then moves
-// with every update instead of being stable, and an update costs one pass over the new frame only.
+// with every update instead of being stable, and an update costs one pass over the new frame only.  CAPTURABLE = true makes
+// update() capturable into a HIP graph (engine extension: the update count lives on the device).
 template <int I, int O, int COLOR_PLANES, int BATCH, fk::CircularTensorOrder CT_ORDER, fk::ColorPlanes CP_MODE = fk::ColorPlanes::Standard,
-          bool MIRRORED = false>
-class CircularTensor : public fk::CircularTensor<CUDA_T(O), COLOR_PLANES, BATCH, CT_ORDER, CP_MODE, MIRRORED> {
-    using Base = fk::CircularTensor<CUDA_T(O), COLOR_PLANES, BATCH, CT_ORDER, CP_MODE, MIRRORED>;
+          bool MIRRORED = false, bool CAPTURABLE = false>
+class CircularTensor : public fk::CircularTensor<CUDA_T(O), COLOR_PLANES, BATCH, CT_ORDER, CP_MODE, MIRRORED, CAPTURABLE> {
+    using Base = fk::CircularTensor<CUDA_T(O), COLOR_PLANES, BATCH, CT_ORDER, CP_MODE, MIRRORED, CAPTURABLE>;
 public:
     CircularTensor() = default;
     CircularTensor(const uint& width_, const uint& height_, const int& deviceID_ = 0) : Base(width_, height_, deviceID_) {}

@@ -800,8 +800,11 @@ inline uint64_t executeOperations(Queue& queue, const IOps&... iops) {
 // ---- CircularTensor ------------------------------------------------------------------------------------------------
 // MIRRORED (engine extension, default off = the reference's behaviour): the opt-in mirrored-ring layout of
 // cvgs_circular_create_ex -- no shift traffic per update, but ptr()/data() MOVE with every update.
+// CAPTURABLE (engine extension, default off): update() may be captured into a HIP graph and replayed (CVGS_CIRCULAR_CAPTURABLE:
+// the update count lives on the device; N captured updates replay as the NEXT N updates).  For MIRRORED + CAPTURABLE tensors
+// ptr() asks the device where the window stands (it synchronises): call it outside captures.
 template <typename T, int COLOR_PLANES, int BATCH, CircularTensorOrder ORDER, ColorPlanes MODE = ColorPlanes::Standard,
-          bool MIRRORED = false>
+          bool MIRRORED = false, bool CAPTURABLE = false>
 class CircularTensor {
     static constexpr ND kND = MODE == ColorPlanes::Transposed ? T3D : _3D;
     static_assert(!MIRRORED || MODE == ColorPlanes::Standard, "mirrored CircularTensors exist in the Standard plane order only");
@@ -814,7 +817,8 @@ public:
 
     void Alloc(uint w, uint h, int device = 0) {
         detail::check_status(cvgs_circular_create_ex(&handle_, (int)w, (int)h, cvGS::cv_type_of<T>, COLOR_PLANES, BATCH,
-                                                     (int)ORDER, (int)MODE, device, MIRRORED ? CVGS_CIRCULAR_MIRRORED : 0u));
+                                                     (int)ORDER, (int)MODE, device,
+                                                     (MIRRORED ? CVGS_CIRCULAR_MIRRORED : 0u) | (CAPTURABLE ? CVGS_CIRCULAR_CAPTURABLE : 0u)));
         ptr_a.data = (T*)cvgs_circular_data(handle_);
         ptr_a.dims = {w, h, (uint)BATCH, (uint)COLOR_PLANES, (uint)(w * sizeof(T)), (uint)(w * sizeof(T) * h)};
     }
@@ -827,9 +831,17 @@ public:
         if (tsplit_needed != (b.d.write.kind == CVGS_WRITE_TENSOR_T_SPLIT))
             throw std::runtime_error("Need to use TensorTSplit as write function exactly when CP_MODE = Transposed");
         detail::check_status(cvgs_circular_update(handle_, &b.d, stream));
-        if constexpr (MIRRORED) ptr_a.data = (T*)cvgs_circular_data(handle_); // the window moved
+        if constexpr (MIRRORED && !CAPTURABLE) ptr_a.data = (T*)cvgs_circular_data(handle_); // the window moved
     }
-    RawPtr<kND, T> ptr() const { return ptr_a; }
+    RawPtr<kND, T> ptr() const {
+        if constexpr (MIRRORED && CAPTURABLE) {
+            RawPtr<kND, T> p = ptr_a;
+            p.data = (T*)cvgs_circular_data(handle_);
+            return p;
+        } else {
+            return ptr_a;
+        }
+    }
     Dims3D dims() const { return ptr_a.dims; }
     size_t sizeInBytes() const { return cvgs_circular_bytes(handle_); }
 

@@ -332,6 +332,12 @@ int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, in
  * cannot make: cvgs_circular_data() MOVES with every update (call it after each update), and only the Standard
  * plane order (N,C,H,W) exists.  Tensor contents at data() are identical to the default mode's.                */
 #define CVGS_CIRCULAR_MIRRORED 1u
+/* CVGS_CIRCULAR_CAPTURABLE: cvgs_circular_update may be captured into a HIP graph (the reference's update is an ordinary stream
+ * launch, include/cvGPUSpeedup.cuh:612-622; a serving loop that replays graphs needs it inside them).  The update count then
+ * lives in device memory and every update -- captured or not -- goes through a staging image and a device-indexed shift
+ * (one extra pass over ONE image); N captured updates replay as the NEXT N updates.  cvgs_circular_updates() and, for mirrored
+ * handles, cvgs_circular_data() read the device-side count and therefore synchronise the device.                        */
+#define CVGS_CIRCULAR_CAPTURABLE 2u
 int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
                             int32_t color_planes, int32_t batch, int32_t order, int32_t cp_mode,
                             int32_t device_id, uint32_t flags);

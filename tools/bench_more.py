@@ -31,10 +31,11 @@ def events_time(fn, iters, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False):
+def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False, graph=False):
+    """graph=True: a capturable handle (CVGS_CIRCULAR_CAPTURABLE), 16 updates captured into ONE HIP graph, the graph replayed"""
     Wd, Hd, B = 1920, 1080, 16
     ct = cvgs.CircularTensor(cvgs.CV_8UC3, cvgs.CV_16FC1 if half else cvgs.CV_32FC1, 3, B, cvgs.NewestFirst, cvgs.Standard,
-                             Wd, Hd, mirrored=mirrored)
+                             Wd, Hd, mirrored=mirrored, capturable=graph)
     f = cvgs.CV_32FC3
     ft = cvgs.CV_16FC3 if half else f  # type written into the tensor
     src_wh = W.FRAME_4K if resize_from_4k else (Wd, Hd)
@@ -45,16 +46,25 @@ def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False):
         pw.append(cvgs.convertTo(f, ft))
     state = {"i": 0}
 
-    def update():
+    def update(stream=None):
         fr = frames[state["i"] % len(frames)]
         state["i"] += 1
         m = cvgs.GpuMat.from_tensor(fr, cvgs.CV_8UC3)
+        st = stream or s
         if resize_from_4k:
-            ct.update(s, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, m, (Wd, Hd)), *pw, ct.write_split(ft))
+            ct.update(st, cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, m, (Wd, Hd)), *pw, ct.write_split(ft))
         else:
-            ct.update(s, m, cvgs.convertTo(cvgs.CV_8UC3, f), *pw, ct.write_split(ft))
+            ct.update(st, m, cvgs.convertTo(cvgs.CV_8UC3, f), *pw, ct.write_split(ft))
 
-    t = events_time(update, iters)
+    if graph:
+        per = 16
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(per):
+                update(torch.cuda.current_stream())
+        t = events_time(g.replay, max(2, iters // per), warm=2) / per
+    else:
+        t = events_time(update, iters)
     plane = Wd * Hd * 3 * (2 if half else 4)
     # read = src_frame_bytes + (B-1)*P, write = B*P + P(ring); 4K->1080p taps every source pixel.
     # Mirrored ring (opt-in): read = src frame, write = 2*P, nothing is shifted.
@@ -62,7 +72,7 @@ def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False):
     alg = src + 2 * plane if mirrored else src + (B - 1) * plane + B * plane + plane
     ct.release()
     return {"config": "cfg4 CircularTensor depth 16, 1080p %s x3%s, push %s" % (
-                "fp16" if half else "fp32", " MIRRORED ring (opt-in, data() moves)" if mirrored else "",
+                "fp16" if half else "fp32", (" MIRRORED ring (opt-in, data() moves)" if mirrored else "") + (" CAPTURABLE handle, 16 updates per replayed HIP graph" if graph else ""),
                 "4K->1080p resize+normalize" if resize_from_4k else "1080p convert+normalize"),
             "us_per_update": round(t * 1e6, 2), "algorithmic_bytes": alg, "GB_per_s": round(alg / t / 1e9, 1),
             "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4), "updates_per_s": round(1 / t, 1)}
@@ -201,6 +211,8 @@ def run_all(dev, iters=100, only=""):
         res.append(cfg4(dev, iters, False, half=True))
         res.append(cfg4(dev, iters, False, mirrored=True))
         res.append(cfg4(dev, iters, True, mirrored=True))
+        res.append(cfg4(dev, iters, False, graph=True))
+        res.append(cfg4(dev, iters, False, mirrored=True, graph=True))
     if only in ("", "cfg3"):
         res.append(cfg3(dev, iters))
         res.append(cfg3(dev, iters, p010=True))

@@ -79,6 +79,7 @@ def parse():
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (testing)")
+    p.add_argument("--exchange-half", action="store_true", help="N > 1: assemble an fp16 tensor (half the bytes per xGMI link)")
     return p.parse_args()
 
 

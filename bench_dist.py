@@ -8,8 +8,12 @@ max over ranks:
   allgather    : K1 + in-place RCCL all-gather of the N slices per step (BASELINE's spelling; the collective runs on
                  RCCL's stream, so the K1 of later steps overlaps it)
   p2p_write    : K1 stores its rows into its own copy AND into every peer's copy through IPC-mapped pointers
-                 (cvgs_write_desc.mirrors; SURVEY.md 8e option 2) + ONE 4-byte all-reduce per step as the barrier
-`value` is the faster of the two legs that deliver the assembled tensor; both are reported."""
+                 (cvgs_write_desc.mirrors; SURVEY.md 8e option 2); "all rows of step k have landed" is a DEVICE-side flag
+                 exchange over the same mappings (cvgs_exchange_signal / cvgs_exchange_wait: two tiny kernels on the launch
+                 stream, no collective and no host round trip per step; round 2 used one RCCL all-reduce per step, 32 us)
+  flags_only   : the flag exchange alone (no K1): what the protocol itself costs per step
+`value` is the faster of the two legs that deliver the assembled tensor; every leg is reported.  --exchange-half assembles an
+fp16 tensor (the half-precision hand-off): half the bytes on every xGMI link."""
 import json
 import os
 import time
@@ -17,8 +21,10 @@ import time
 import numpy as np
 import torch
 
+import ctypes as C
+
 import bench as B
-from cvgpuspeedup_amd import rccl, sharding
+from cvgpuspeedup_amd import capi, rccl, sharding
 from cvgpuspeedup_amd import workloads as W
 
 
@@ -50,21 +56,24 @@ def main(a, dev, rank, world):
     n = B.CFG5_CROPS
     plane = 3 * W.DST[0] * W.DST[1]
     fw, fh = W.FRAME_6K
-    tensor_bytes = world * n * plane * 4
+    half = bool(getattr(a, "exchange_half", False))
+    esz = 2 if half else 4
+    tensor_bytes = world * n * plane * esz
     per_frame_bytes = fw * fh * 3 + tensor_bytes
     n_frames = a.frames or max(6, (2 * B.INFINITY_CACHE + per_frame_bytes - 1) // per_frame_bytes + 1)
     steps, reps = a.steps, 9
 
     # the step's full tensors live in ONE dedicated allocation per rank, so that peers can map it with one IPC handle
-    buf = rccl.DeviceBuffer(n_frames * tensor_bytes)
-    out_all = [buf.tensor(f * tensor_bytes, (world * n, plane)) for f in range(n_frames)]
+    flag_off = n_frames * tensor_bytes          # behind the tensors: one 8-byte arrival word per source rank, 128 bytes apart
+    buf = rccl.DeviceBuffer(flag_off + world * 128 + 256)
+    out_all = [buf.tensor(f * tensor_bytes, (world * n, plane), "<f2" if half else "<f4", esz) for f in range(n_frames)]
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
     s = torch.cuda.current_stream().cuda_stream
     result_extra = {}
 
     # ---- leg 1: compute only (graph replay, the headline's own clock) --------------------------------------------
-    wl = B.Workload(dev, n_frames, n, rank, world, False, frame_wh=W.FRAME_6K, out_all=out_all)
+    wl = B.Workload(dev, n_frames, n, rank, world, False, frame_wh=W.FRAME_6K, out_all=out_all, half=half)
     m = B.measure(wl, steps, a.warmup, barrier=dist.barrier, target_s=0.1, min_replays=20)
     t = torch.tensor([m["step_s"]], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -105,7 +114,7 @@ def main(a, dev, rank, world):
                 peers.append(bases[-1])
         # probe: a plain store into every peer's allocation (its last float: nothing reads it) before any kernel is pointed at it
         for b in peers:
-            rccl.view(b + n_frames * tensor_bytes - 4, (1,)).fill_(1.0)
+            rccl.view(b + flag_off + world * 128 + 128, (1,)).fill_(1.0)
         torch.cuda.synchronize()
     except Exception as ex:  # no peer access on this box, IPC refused, ...
         map_error = repr(ex)
@@ -119,21 +128,34 @@ def main(a, dev, rank, world):
             o.zero_()
         torch.cuda.synchronize()
         dist.barrier()
-        wl2 = B.Workload(dev, n_frames, n, rank, world, False, frame_wh=W.FRAME_6K, out_all=out_all, share=wl, mirrors=mirrors)
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        works2 = [None] * n_frames
+        wl2 = B.Workload(dev, n_frames, n, rank, world, False, frame_wh=W.FRAME_6K, out_all=out_all, share=wl, mirrors=mirrors, half=half)
+        lib = capi.load_library()
+        others = [r for r in range(world) if r != rank]
+        # my arrival word in every peer's flag block / the peers' words in mine
+        sig = (C.c_void_p * max(1, len(others)))(*[bases[r] + flag_off + rank * 128 for r in others])
+        own = (C.c_void_p * max(1, len(others)))(*[buf.ptr + flag_off + r * 128 for r in others])
+        err_words = torch.zeros(2, dtype=torch.int64, device=dev)
+        lag = max(1, min(4, n_frames - 1))  # waits trail the signals: a well-fed stream never blocks on them
+        counter = torch.zeros(1, dtype=torch.int64, device=dev)  # the step number lives on the device: the K steps are ONE replayable graph
 
-        def p2p_steps():
+        def enqueue(with_k1):
+            s = torch.cuda.current_stream().cuda_stream  # the capturing stream
             for i in range(steps):
-                j = i % n_frames
-                if works2[j] is not None:
-                    works2[j].wait()  # every rank finished WRITING the previous use of buffer j before it is rewritten
-                wl2.launch(i, s)
-                works2[j] = dist.all_reduce(flag, async_op=True)  # barrier: all ranks' rows of buffer j have landed
-            for j, w in enumerate(works2):
-                if w is not None:
-                    w.wait()
-                    works2[j] = None
+                if with_k1:
+                    wl2.launch(i, s)
+                # my rows of this step have landed everywhere: advance the device-side step count, publish it to every peer
+                capi.check(lib.cvgs_exchange_step(sig, own, len(others), counter.data_ptr(), lag, 2000.0, err_words.data_ptr(), s))
+            capi.check(lib.cvgs_exchange_wait(own, len(others), 0, counter.data_ptr(), 0, 2000.0, err_words.data_ptr(), s))  # the last steps are complete here
+
+        graphs = {}
+        for with_k1 in (True, False):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enqueue(with_k1)
+            graphs[with_k1] = g
+
+        def p2p_steps(with_k1=True):
+            graphs[with_k1].replay()
 
         p2p_steps()
         torch.cuda.synchronize()
@@ -142,7 +164,11 @@ def main(a, dev, rank, world):
         okt = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         p2p_wall = _median_wall(p2p_steps, reps, dist, dev)
-        p2p = {"ok": bool(okt.item() == 1), "wall": p2p_wall, "kernel": wl2.kernel}
+        flags_wall = _median_wall(lambda: p2p_steps(False), reps, dist, dev)
+        torch.cuda.synchronize()
+        lost = int(err_words[0].item())
+        p2p = {"ok": bool(okt.item() == 1) and lost == 0, "wall": p2p_wall, "flags_wall": flags_wall, "kernel": wl2.kernel,
+               "error": "a flag wait timed out (peer %d)" % int(err_words[1].item()) if lost else None}
     except Exception as ex:  # no peer access on this box, IPC refused, ...: the all-gather leg stands
         p2p = {"ok": False, "error": repr(ex)}
     okall = torch.tensor([1 if p2p.get("ok") else 0], dtype=torch.int32, device=dev)
@@ -151,16 +177,16 @@ def main(a, dev, rank, world):
 
     best_wall, exchange = ag_wall, "RCCL in-place all_gather_into_tensor per step (overlapped with later steps' K1)"
     if p2p_ok and p2p["wall"] < ag_wall:
-        best_wall, exchange = p2p["wall"], "P2P fused write (K1 stores into every peer's tensor) + one 4-byte all-reduce per step"
+        best_wall, exchange = p2p["wall"], "P2P fused write (K1 stores into every peer's tensor) + device-side arrival flags (no collective per step)"
     step_s = best_wall / steps
     if rank == 0:
         alg = wl.algorithmic_bytes()
         result = {
             "metric": B.baseline_metric(), "value": round(px_step / step_s / 1e6, 1), "unit": "Mpix/s", "n_gpus": world,
             "steps": steps, "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 6), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",  # (arithmetic in fp32; --exchange-half only narrows the stored tensor)
             "config": {"workload": "cfg5: %d x (64 variable-size crops of a resident 6K u8c3 frame per GPU) -> [%d,3,128,64] fp32 "
-                                   "assembled on every GPU per step; %d resident frames per GPU" % (world, world * n, n_frames),
+                                   "assembled on every GPU per step; %d resident frames per GPU" % (world, world * n, n_frames) + (" (fp16 tensor: --exchange-half)" if half else ""),
                        "chain": "resize(bilinear) -> RGB2BGR -> x0.3 -> -(1,4,3.2) -> /(3.2,0.6,11.8) -> TensorSplit",
                        "crops_per_launch": n, "frame": "6144x3456 u8c3", "kernel": wl.kernel, "exchange": exchange,
                        "parallelism": "1 process per GPU, crop lists sharded, frames never replicated"},
@@ -172,12 +198,15 @@ def main(a, dev, rank, world):
                 "compute_only": {"Mpix_per_s": round(px_step / compute_step / 1e6, 1), "us_per_step": round(compute_step * 1e6, 3),
                                  "note": "graph-replayed K1, no exchange: every rank keeps its shard"},
                 "allgather": {"Mpix_per_s": round(px_step * steps / ag_wall / 1e6, 1), "us_per_step": round(ag_wall / steps * 1e6, 3),
-                              "bytes_received_per_gpu_per_step": (world - 1) * n * plane * 4},
+                              "bytes_received_per_gpu_per_step": (world - 1) * n * plane * esz},
                 "p2p_write": ({"Mpix_per_s": round(px_step * steps / p2p["wall"] / 1e6, 1), "us_per_step": round(p2p["wall"] / steps * 1e6, 3),
-                               "matches_allgather_bit_exact": True, "kernel": p2p.get("kernel")} if p2p_ok else
+                               "matches_allgather_bit_exact": True, "kernel": p2p.get("kernel"),
+                               "barrier": "device-side arrival flags over the IPC mappings (cvgs_exchange_step: ONE one-wave kernel per step, none with a single rank), waits trail by <= 4 steps",
+                               "flags_only_us_per_step": round(p2p["flags_wall"] / steps * 1e6, 3)} if p2p_ok else
                               {"error": p2p.get("error", "result differs from the all-gather's or a rank failed")}),
                 # every GPU receives world-1 slices, each from a different peer over its own xGMI link (~153 GB/s)
-                "xgmi_floor_us_per_step": round(n * plane * 4 / 153e9 * 1e6, 3) if world > 1 else 0.0,
+                "xgmi_floor_us_per_step": round(n * plane * esz / 153e9 * 1e6, 3) if world > 1 else 0.0,
+                "tensor_element_bytes": esz,
             }}
         result["extra"].update(result_extra)
         print(json.dumps(result))

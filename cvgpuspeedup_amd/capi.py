@@ -108,6 +108,9 @@ SYMBOLS = [
     ("cvgs_circular_updates", C.c_int64, [C.c_void_p]),
     ("cvgs_circular_destroy", C.c_int, [C.c_void_p]),
     ("cvgs_stream_copy", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("cvgs_exchange_signal", C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("cvgs_exchange_wait", C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]),
+    ("cvgs_exchange_step", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]),
     ("cvgs_queue_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_double, C.c_uint32]),
     ("cvgs_queue_submit", C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.POINTER(C.c_uint64)]),
     ("cvgs_queue_submit_many", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(ChainDesc)), C.c_int32, C.POINTER(C.c_uint64)]),

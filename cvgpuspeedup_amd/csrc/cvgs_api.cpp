@@ -1280,6 +1280,34 @@ int cvgs_queue_destroy(cvgs_queue_t h) {
     return CVGS_OK;
 }
 
+int cvgs_exchange_signal(void* const* peer_flag_words, int32_t n, uint64_t value, uint64_t* step_counter, cvgs_stream_t stream) {
+    if (n < 0 || n > CVGS_MAX_EXCHANGE_PEERS || (n > 0 && !peer_flag_words)) return fail(CVGS_ERR_INVALID, "exchange: 0..16 flag words");
+    for (int i = 0; i < n; ++i)
+        if (!peer_flag_words[i] || ((uintptr_t)peer_flag_words[i] & 7)) return fail(CVGS_ERR_INVALID, "exchange: null / unaligned flag word");
+    if (launch_exchange_signal(peer_flag_words, n, value, step_counter, stream)) return fail(CVGS_ERR_HIP, "exchange signal launch failed");
+    return CVGS_OK;
+}
+
+int cvgs_exchange_wait(const void* const* own_flag_words, int32_t n, uint64_t value, const uint64_t* step_counter, uint64_t lag, double timeout_ms,
+                       void* err_words, cvgs_stream_t stream) {
+    if (n < 0 || n > CVGS_MAX_EXCHANGE_PEERS || (n > 0 && !own_flag_words)) return fail(CVGS_ERR_INVALID, "exchange: 0..16 flag words");
+    for (int i = 0; i < n; ++i)
+        if (!own_flag_words[i] || ((uintptr_t)own_flag_words[i] & 7)) return fail(CVGS_ERR_INVALID, "exchange: null / unaligned flag word");
+    if (launch_exchange_wait(own_flag_words, n, value, step_counter, lag, timeout_ms, err_words, stream)) return fail(CVGS_ERR_HIP, "exchange wait launch failed");
+    return CVGS_OK;
+}
+
+int cvgs_exchange_step(void* const* peer_flag_words, const void* const* own_flag_words, int32_t n, uint64_t* step_counter, uint64_t lag,
+                       double timeout_ms, void* err_words, cvgs_stream_t stream) {
+    if (n < 0 || n > CVGS_MAX_EXCHANGE_PEERS || !step_counter || (n > 0 && (!peer_flag_words || !own_flag_words)))
+        return fail(CVGS_ERR_INVALID, "exchange: 0..16 flag words and a step counter");
+    for (int i = 0; i < n; ++i)
+        if (!peer_flag_words[i] || !own_flag_words[i] || (((uintptr_t)peer_flag_words[i] | (uintptr_t)own_flag_words[i]) & 7))
+            return fail(CVGS_ERR_INVALID, "exchange: null / unaligned flag word");
+    if (launch_exchange_step(peer_flag_words, own_flag_words, n, step_counter, lag, timeout_ms, err_words, stream)) return fail(CVGS_ERR_HIP, "exchange step launch failed");
+    return CVGS_OK;
+}
+
 int cvgs_stream_copy(void* dst, const void* src, size_t bytes, cvgs_stream_t stream) {
     if (!dst || !src) return fail(CVGS_ERR_INVALID, "null pointer");
     if (bytes == 0) return CVGS_OK;

@@ -212,6 +212,14 @@ int launch_circular_push(const ChainArgs& c, const PlaneParams& plane, const Cop
                          uint32_t chain_flags, void* stream);
 
 
+// ---- device-side arrival flags of the P2P fused-write exchange (k_exchange.hip) ----------------------------------------------
+#define CVGS_MAX_EXCHANGE_PEERS 16
+int launch_exchange_signal(void* const* peer_flags, int n, uint64_t value, uint64_t* counter, void* stream);
+int launch_exchange_step(void* const* peer_flags, const void* const* own_flags, int n, uint64_t* counter, uint64_t lag, double timeout_ms, void* err_words,
+                         void* stream);
+int launch_exchange_wait(const void* const* flags, int n, uint64_t value, const uint64_t* counter, uint64_t lag, double timeout_ms, void* err_words,
+                         void* stream);
+
 // ---- device-side descriptor queue (k_queue.hip): K1 batches served by a resident grid, no launch per batch ----------------
 struct Queue;
 int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle_us, std::string& err);

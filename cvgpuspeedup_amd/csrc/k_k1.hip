@@ -49,7 +49,8 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if ((mirrors.n > 0 || segs) && (!planar || c_in.write.data2)) return 0; // extra targets / fused chains: planar tensors only
     // mirrors: u8 C3/C4 -> fp32 planar with the planes in the kernel arguments (cfg #5: 64 crops per GPU); the rest is
     // the interpreted kernel's business
-    if (mirrors.n > 0 && (r.depth != CVGS_DEPTH_8U || r.cn < 3 || r.table || segs || c_in.write.depth != CVGS_DEPTH_32F)) return 0;
+    if (mirrors.n > 0 && (r.depth != CVGS_DEPTH_8U || r.cn < 3 || r.table || segs || (c_in.write.depth != CVGS_DEPTH_32F && c_in.write.depth != CVGS_DEPTH_16F)))
+        return 0;
     if (segs && (!r.table || n_segs < 1 || n_segs > CVGS_MAX_CHAINS)) return 0;
     // more than CVGS_KERNARG_PLANES descriptors in the kernel arguments: the 3- / 4-channel planar-tensor kernels only
     if (!r.table && n_inline > CVGS_KERNARG_PLANES && (n_inline > kKernargPlanesBig || !planar || few || segs)) return 0;
@@ -143,14 +144,17 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     hipError_t e;
     if (mirrors.n > 0) {
         // one row per wave (a 64-crop launch is in the latency regime), planes in the kernel arguments
-        auto mir = [&](auto prog_tag) {
+        // fp16 tensors (the half-precision hand-off) halve the bytes every xGMI link has to carry
+        auto mir_t = [&](auto prog_tag, auto ot_tag) {
             using Pg = decltype(prog_tag);
+            using OT = decltype(ot_tag);
             if (n_inline > CVGS_KERNARG_PLANES) // a shard of up to 320 crops per GPU: the 16 KB argument block
-                return r.cn == 3 ? launch_t<3, kKernargPlanesBig, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s)
-                                 : launch_t<4, kKernargPlanesBig, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
-            return r.cn == 3 ? launch_t<3, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s)
-                             : launch_t<4, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, float, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
+                return r.cn == 3 ? launch_t<3, kKernargPlanesBig, 1, Pg, SRC_U8, OT, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s)
+                                 : launch_t<4, kKernargPlanesBig, 1, Pg, SRC_U8, OT, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
+            return r.cn == 3 ? launch_t<3, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, OT, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s)
+                             : launch_t<4, CVGS_KERNARG_PLANES, 1, Pg, SRC_U8, OT, WM_PLANAR, true>(c, inline_planes, n_inline, out_cn, s);
         };
+        auto mir = [&](auto prog_tag) { return f16 ? mir_t(prog_tag, _Float16{}) : mir_t(prog_tag, float{}); };
         e = prog_id == 0 ? mir(ProgSwapMulSubDiv{}) : (prog_id == 1 ? mir(ProgMulSubDiv{}) : mir(InterpProg{}));
     } else if (same_type_packed) {
         e = r.cn == 1 ? launch_same_type_packed<1>(src, table, rpw, c, inline_planes, n_inline, s)

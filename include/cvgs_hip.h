@@ -391,6 +391,32 @@ cvgs_stream_t cvgs_queue_stream(cvgs_queue_t q);
 int cvgs_queue_profile(cvgs_queue_t q, uint64_t* out16);
 int cvgs_queue_destroy(cvgs_queue_t q);
 
+/* ---- device-side arrival flags for the sharded batched-crop path (ABI 4; BASELINE cfg #5, SURVEY.md 8e option 2) ----------
+ * With the P2P fused write (cvgs_write_desc.mirrors) every rank's K1 launch stores its rows of the [N,C,H,W] tensor into every
+ * peer's copy; what remains of the exchange is knowing when all rows of a step have landed.  These two calls keep that on the
+ * device: flags are 8-byte words the ranks place in their IPC-shared allocations (include/cvgs_rccl.h: cvgs_ipc_*), one word per
+ * source rank, at least 128 bytes apart.
+ *   cvgs_exchange_signal  enqueue behind the step's launch: stores `value` (the step number, monotonic) into the n given words --
+ *                         this rank's word in each peer's flag block (pointers valid in THIS process).  The kernel boundary in
+ *                         front of it makes the step's rows visible before the flags.
+ *   cvgs_exchange_wait    the stream waits until each of the n given words (this rank's own flag block: one word per peer)
+ *                         is >= `value`; after `timeout_ms` (0 = 2000) it gives up, stores {1, index of a flag that was behind}
+ *                         into err_words[0..1] (device or pinned memory, may be NULL) and lets the stream continue -- a lost
+ *                         peer is reported, never waited for.  n <= 16.
+ * `step_counter` (device memory, 8 bytes, zero-initialised by the caller; NULL = use `value`): the step number then lives on the
+ * device -- signal advances *step_counter and publishes the new count, wait waits for *step_counter - lag (and for nothing while
+ * the count is <= lag) -- so that a whole sequence of steps can be captured into ONE HIP graph and replayed (a captured constant
+ * would repeat).  With n == 0 and a counter, signal still advances it.
+ * No collective and no host round trip per step.  No reference counterpart (the reference is single-GPU).                 */
+int cvgs_exchange_signal(void* const* peer_flag_words, int32_t n, uint64_t value, uint64_t* step_counter, cvgs_stream_t stream);
+int cvgs_exchange_wait(const void* const* own_flag_words, int32_t n, uint64_t value, const uint64_t* step_counter, uint64_t lag, double timeout_ms,
+                       void* err_words, cvgs_stream_t stream);
+/* signal + lagged wait as ONE launch per step (what a steady loop enqueues behind each K1): advances *step_counter, publishes it
+ * into peer_flag_words[0..n), then waits until own_flag_words[0..n) have reached the count - lag.  n == 0 (one rank): nothing is
+ * enqueued.  About one kernel boundary (~2 us) per step, against >= 20 us of link time per step on 8 GPUs.                      */
+int cvgs_exchange_step(void* const* peer_flag_words, const void* const* own_flag_words, int32_t n, uint64_t* step_counter, uint64_t lag,
+                       double timeout_ms, void* err_words, cvgs_stream_t stream);
+
 /* ---- streaming copy ----------------------------------------------------------------------------
  * dst[0..bytes) <- src[0..bytes) with the CircularTensor's plane-copy kernel (non-temporal 16-byte accesses), asynchronous
  * on `stream`.  No reference equivalent: it is the on-box "streaming kernel" copy ceiling SURVEY.md 8(d) asks the

@@ -220,6 +220,11 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
             return fail(CVGS_ERR_INVALID, "bad aspect ratio mode");
     }
     const bool table = (rd.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
+    // a device plane table carries no layout tag, and the per-plane preconditions of the 16-bit / planar-chroma
+    // layouts (2-byte alignment, even steps, whole surfaces: checked below for HOST descriptors only) cannot be checked on a
+    // table this call cannot read -- a table built for NV12 and executed as I420 would address a second chroma plane that is not there
+    if (table && is_nv12(rd.kind) && rd.yuv_layout != CVGS_YUV_NV12 && rd.yuv_layout != CVGS_YUV_NV21)
+        return fail(CVGS_ERR_UNSUPPORTED, "device plane tables serve the NV12 / NV21 layouts only (P010 / I420 / YV12: host descriptors)");
 
     // ---- read stage ----
     ReadArgs& R = L.args.read;
@@ -749,6 +754,37 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
                   !(c.flags & CVGS_CHAIN_FORCE_GENERIC) &&
                   (c.write.kind == CVGS_WRITE_TENSOR_SPLIT || c.write.kind == CVGS_WRITE_TENSOR_T_SPLIT) && same_shape(chains[0], c) &&
                   ((c.read.flags ^ chains[0].read.flags) & CVGS_READ_FLAG_TABLE_ON_DEVICE) == 0;
+    }
+    // whatever the one-by-one path would serve must not fail because the chains happen to share a shape.
+    //  * host descriptors under stream capture: the fused launch would stage a table (not capturable); one by one, chains of
+    //    <= 64 planes travel in kernel arguments and ARE capturable;
+    //  * a batch beyond the grid's y range;
+    //  * chains that are not independent (one writes where another writes or reads): the fused launch runs them concurrently,
+    //    n sequential cvgs_execute calls would not -- keep the sequential meaning.
+    if (fusable) {
+        const bool tables0 = (chains[0].read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (!tables0 && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) fusable = false;
+        struct Range { const uint8_t* lo; const uint8_t* hi; };
+        Range outs[CVGS_MAX_CHAINS];
+        for (int i = 0; fusable && i < n; ++i) {
+            const cvgs_chain_desc& c = chains[i];
+            if (c.read.batch < 1 || c.read.batch > 65535) fusable = false;
+            const size_t esz = (size_t)depth_bytes(CVGS_TYPE_DEPTH(c.write.dst_type));
+            const size_t bytes = (size_t)c.read.batch * CVGS_TYPE_CN(c.write.dst_type) * (size_t)c.write.width * (size_t)c.write.height * esz;
+            outs[i] = Range{(const uint8_t*)c.write.data, (const uint8_t*)c.write.data + bytes};
+            for (int j = 0; fusable && j < i; ++j)
+                if (outs[i].lo < outs[j].hi && outs[j].lo < outs[i].hi) fusable = false; // two chains write the same bytes
+        }
+        for (int i = 0; fusable && !tables0 && i < n; ++i) { // a source view of one chain inside another chain's output
+            const cvgs_image2d* src = (const cvgs_image2d*)chains[i].read.src;
+            for (int k = 0; fusable && src && k < chains[i].read.batch && k < chains[i].read.used_planes; ++k) {
+                const uint8_t* lo = (const uint8_t*)src[k].data;
+                const uint8_t* hi = lo + (size_t)src[k].step * (size_t)(src[k].height > 0 ? src[k].height : 1);
+                for (int j = 0; fusable && j < n; ++j)
+                    if (lo < outs[j].hi && outs[j].lo < hi) fusable = false;
+            }
+        }
     }
     if (fusable) {
         const bool tables = (chains[0].read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;

@@ -214,6 +214,12 @@ struct ChainBuilder {
     detail::SmallVec<float, 9 * detail::kInlinePlanes> warp; // WARP reads: batch x 9 floats
     detail::SmallVec<int32_t, 2 * detail::kInlinePlanes> warp_sizes; // WARP reads with per-plane destination sizes: batch x 2
     ChainBuilder() { std::memset(&d, 0, sizeof(d)); d.struct_size = sizeof(d); }
+    // finish() points d.read.src / d.write.planes2d / the warp tables at this object's INLINE buffers: a copy or a move would
+    // leave them pointing into the old object.  Builders are used in place (stack) or behind unique_ptr (ChainBatch).
+    ChainBuilder(const ChainBuilder&) = delete;
+    ChainBuilder& operator=(const ChainBuilder&) = delete;
+    ChainBuilder(ChainBuilder&&) = delete;
+    ChainBuilder& operator=(ChainBuilder&&) = delete;
     void op(int opcode, int aux, const float* operand = nullptr, const double* operand_d = nullptr) {
         if (d.n_ops >= CVGS_MAX_OPS) throw std::runtime_error("cvGS: too many pointwise operations in one chain");
         cvgs_op& o = d.ops[d.n_ops++];

@@ -289,9 +289,12 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * everything except read.src / batch / used_planes and write.data / planes (same source type, target size,
  * aspect-ratio mode, background, YUV range / primaries / layout, pointwise stages and operands, write kind and type), are
  * fused into ONE launch of the K1 (or K4) kernel: grid z = chain, grid y = crop.  Results are bit-identical to n_chains separate cvgs_execute calls (same
- * kernel code; tests/test_gpu_many.py).  Any other set of chains is executed one by one, in order.  Host descriptors
- * are staged through a pinned pool and copied stream-ordered (not capturable: pass device plane tables, then the call
- * is capturable); at most CVGS_MAX_CHAINS chains per call.  The reference's closest spelling is the batch sweep of
+ * kernel code; tests/test_gpu_many.py).  Any other set of chains is executed one by one, in order -- and so is a set whose
+ * chains are NOT independent (two chains write overlapping bytes, or a host-described source view of one lies inside another's
+ * output: fused chains run concurrently), a set with a batch beyond 65535, and host descriptors under stream capture.  Host
+ * descriptors of a fused launch are written into a pooled pinned buffer that the kernel reads in place (no copy; the slot is
+ * recycled by a HIP event behind the kernel); pass device plane tables to make the fused call capturable; at most
+ * CVGS_MAX_CHAINS chains per call.  The reference's closest spelling is the batch sweep of
  * tests/batchresize/test_batchresize_x_split3D.cu:384-392 (one launch per BATCH value).                          */
 int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stream_t stream);
 
@@ -310,6 +313,8 @@ int cvgs_kernel_name(const cvgs_chain_desc* chain, char* buf, size_t buf_size);
  * position-independent table into host_out, which the caller copies to the device and passes
  * back as read.src with CVGS_READ_FLAG_TABLE_ON_DEVICE.                                         */
 size_t cvgs_plane_table_bytes(int32_t batch);
+/* A table is bound to the 4:2:0 layout it was built (and validated) with: executing it with another read.yuv_layout is
+ * refused for the layouts whose per-plane preconditions differ (P010, I420, YV12: CVGS_ERR_UNSUPPORTED with device tables). */
 int cvgs_plane_table_build(const cvgs_read_desc* read, void* host_out);
 
 /* ---- CircularTensor ------------------------------------------------------------------------

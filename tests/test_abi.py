@@ -235,3 +235,17 @@ def test_rccl_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
         assert n in bound, n
+
+
+def test_device_plane_tables_are_refused_for_layouts_they_cannot_vouch_for(lib):
+    """a device plane table carries no layout tag; P010 / I420 / YV12 need per-plane checks the call cannot make."""
+    import numpy as np
+    surf = np.zeros((96 * 3 // 2, 128), np.uint8)
+    out = np.zeros((1, 3 * 32 * 32), np.float32)
+    for layout, ok in ((capi.YUV_NV12, True), (capi.YUV_NV21, True), (capi.YUV_P010, False), (capi.YUV_I420, False), (capi.YUV_YV12, False)):
+        rd = cvgs.read_nv12(cvgs.GpuMat.from_array(surf, cvgs.CV_8UC1), (32, 32), layout=capi.YUV_NV12, alpha=False)
+        lowered = cvgs.lower([rd, cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), (32, 32))])
+        lowered.desc.read.flags |= 1  # CVGS_READ_FLAG_TABLE_ON_DEVICE: `src` now names a (pretend) device table
+        lowered.desc.read.yuv_layout = layout
+        rc = lib.cvgs_validate(C.byref(lowered.desc))
+        assert (rc == 0) == ok, (layout, rc, lib.cvgs_last_error())

@@ -200,3 +200,35 @@ def test_large_batches_recycle_the_descriptor_scratch(oracle, device):
         ref = np.zeros((n, 3 * 64 * 128), np.float32)
         oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
         H.assert_bit_exact(out.cpu().numpy(), ref, "job %d" % k)
+
+
+# ---- round-2 advice: the zero-copy descriptor scratch (tables read in place from pinned NON-COHERENT host memory) --------------
+def test_recycled_zero_copy_descriptor_slots_never_serve_a_stale_table(oracle):
+    """beyond 320 planes the crop table is read by the kernel straight from a pooled pinned host buffer whose
+    slots the host rewrites and recycles; that is only correct if a launch never sees the previous table of a recycled slot
+    (every dispatch starts with a system-scope acquire).  160 back-to-back launches on ONE stream, no synchronisation in between,
+    a DIFFERENT 330-crop list each, the same few pool slots recycled over and over: every plane of every launch against the
+    oracle.  (CVGS_SCRATCH_ZEROCOPY=0 selects the staged copy instead.)"""
+    import torch
+    dev = torch.device("cuda:0")
+    frame = H.random_u8((540, 960, 3), seed=77)
+    frame_t = torch.from_numpy(frame).to(dev)
+    g_src = cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3)
+    h_src = cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)
+    n, dst, launches = 330, (16, 8), 160
+    plane = 3 * dst[0] * dst[1]
+    outs = [torch.zeros((n, plane), dtype=torch.float32, device=dev) for _ in range(launches)]
+    lists = [H.random_crops(n, 960, 540, seed=5000 + i, wmin=8, wmax=200, hmin=8, hmax=200) for i in range(launches)]
+    s = torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    names = set()
+    for i in range(launches):
+        ops = H.k1_chain(g_src, lists[i], cvgs.GpuMat.from_tensor(outs[i], cvgs.CV_32FC1), dst, 3)
+        names.add(cvgs.kernel_name(*ops))
+        cvgs.executeOperations(s, *ops)
+    torch.cuda.synchronize()
+    assert names == {"k1_u8c3_swap_mul_sub_div"}, names
+    for i in range(launches):
+        ref = np.zeros((n, plane), np.float32)
+        oracle.execute(cvgs.lower(H.k1_chain(h_src, lists[i], cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, 3)))
+        H.assert_bit_exact(outs[i].cpu().numpy(), ref, "launch %d through a recycled descriptor slot" % i)

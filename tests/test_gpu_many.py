@@ -308,3 +308,35 @@ def test_more_than_64_crops_of_a_decoder_surface_stay_on_k4(oracle, device, layo
     torch.cuda.synchronize()
     oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, s_t), lambda o: cvgs.GpuMat.from_array(o, cvgs.CV_32FC1), ref)))
     H.assert_bit_exact(ot.cpu().numpy(), ref, "%d crops of a layout-%d surface" % (n, layout))
+
+
+# ---- round-2 advice: cvgs_execute_many must keep the meaning of n sequential cvgs_execute calls -------------------------------
+def test_execute_many_with_overlapping_outputs_keeps_the_sequential_meaning(oracle, device):
+    """Two same-shape chains that write the SAME tensor: fused they would race; one by one the second wins."""
+    import torch
+    frame_a, frame_b = H.random_u8((720, 1280, 3), seed=901), H.random_u8((720, 1280, 3), seed=902)
+    crops = H.random_crops(20, 1280, 720, seed=903)
+    ta, tb = torch.from_numpy(frame_a).to(device), torch.from_numpy(frame_b).to(device)
+    out = torch.zeros((20, 3 * 64 * 128), dtype=torch.float32, device=device)
+    g_out = cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)
+    chains = [H.k1_chain(cvgs.GpuMat.from_tensor(ta, cvgs.CV_8UC3), crops, g_out), H.k1_chain(cvgs.GpuMat.from_tensor(tb, cvgs.CV_8UC3), crops, g_out)]
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(out.cpu().numpy(), _oracle(oracle, frame_b, crops), "the later chain's result stands")
+
+
+def test_execute_many_with_host_descriptors_is_capturable_chain_by_chain(oracle, device):
+    """Host descriptors under stream capture: the fused launch would stage a table (not capturable); the call falls back to one
+    launch per chain, whose <= 64 planes travel in kernel arguments."""
+    import torch
+    chains, outs, refs_in, keep = _make(device, 3, 40)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    for o in outs:
+        o.fill_(-777.0)
+    g.replay()
+    torch.cuda.synchronize()
+    for o, (frame, crops) in zip(outs, refs_in):
+        H.assert_bit_exact(o.cpu().numpy(), _oracle(oracle, frame, crops), "captured execute_many, host descriptors")

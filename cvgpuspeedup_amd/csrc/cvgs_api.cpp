@@ -125,6 +125,7 @@ struct Lowered {
     Prog64Args p64{};
     MirrorArgs mirrors{};
     bool uses_64f = false;
+    bool int_arith = false; // an arithmetic stage meets an integer-typed value: interpreted kernels only
     SmallBuf<PlaneParams, kKernargPlanesBig> planes;    // host copy (inline or to upload)
     SmallBuf<WarpPlane, kInlineWarp> warp_planes;       // WARP kinds (instead of `planes`)
     SmallBuf<DstPlane, CVGS_KERNARG_PLANES> dst_planes; // SPLIT_2D / PIXEL_2D_BATCH
@@ -149,8 +150,7 @@ int walk_program(const cvgs_chain_desc* ch, int depth, int cn, int* out_depth, i
             depth = op.aux;
             break;
         case CVGS_OP_MUL: case CVGS_OP_ADD: case CVGS_OP_SUB: case CVGS_OP_DIV:
-            if (depth != CVGS_DEPTH_32F && depth != CVGS_DEPTH_64F)
-                return fail(CVGS_ERR_UNSUPPORTED, "arithmetic stages are implemented for CV_32F / CV_64F values only");
+            if (depth == CVGS_DEPTH_16F) return fail(CVGS_ERR_UNSUPPORTED, "arithmetic stages on CV_16F values (convertTo CV_32F first)");
             break;
         case CVGS_OP_REORDER:
             for (int c = 0; c < cn; ++c)
@@ -198,7 +198,6 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     if (scn > 4) return fail(CVGS_ERR_INVALID, "bad source type");
     // CV_64F / CV_16F sources: per-pixel reads and the bilinear resize (taps are cast to float, the output is CV_32F, reference
     // include/cvGPUSpeedup.cuh:227); CV_16F also as a warp source.  A CV_64F warp source has no kernel.
-    if (sdepth == CVGS_DEPTH_64F && is_warp(rd.kind)) return fail(CVGS_ERR_UNSUPPORTED, "CV_64F sources of warp reads");
     if (is_nv12(rd.kind)) {
         if (rd.yuv_layout < CVGS_YUV_NV12 || rd.yuv_layout > CVGS_YUV_P010) return fail(CVGS_ERR_INVALID, "bad yuv_layout");
         if (rd.yuv_range < CVGS_YUV_FULL || rd.yuv_range > CVGS_YUV_LIMITED) return fail(CVGS_ERR_INVALID, "bad yuv_range");
@@ -350,6 +349,33 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     const int d0 = (R.is_resize || is_nv12(rd.kind) || is_warp(rd.kind)) ? CVGS_DEPTH_32F : sdepth;
     int rc = walk_program(ch, d0, R.out_cn, &L.final_depth, &L.final_cn);
     if (rc) return rc;
+    {
+        // Arithmetic on integer-typed values (cvGS::multiply<CV_8UC3> ...): the kernels take the scalar as an EXACT integer of the
+        // value's own type -- what cvScalar2CUDAV<I> made of it (truncation), saturated.  8/16-bit: as a float; CV_32S: as raw bits.
+        int depth = d0, m = 0;
+        for (int k = 0; k < ch->n_ops; ++k) {
+            const cvgs_op& op = ch->ops[k];
+            if (op.opcode == CVGS_OP_NOP) continue;
+            if (op.opcode == CVGS_OP_CAST || op.opcode == CVGS_OP_CAST_TRUNC) depth = op.aux;
+            const bool arith = op.opcode == CVGS_OP_MUL || op.opcode == CVGS_OP_ADD || op.opcode == CVGS_OP_SUB || op.opcode == CVGS_OP_DIV;
+            if (arith && depth <= CVGS_DEPTH_32S) {
+                L.int_arith = true;
+                static const double lo[5] = {0, -128, 0, -32768, -2147483648.0}, hi[5] = {255, 127, 65535, 32767, 2147483647.0};
+                for (int c = 0; c < 4; ++c) {
+                    double v = op.operand_d[c];
+                    if (op.operand_d[0] == 0 && op.operand_d[1] == 0 && op.operand_d[2] == 0 && op.operand_d[3] == 0) v = op.operand[c]; // callers that fill the floats only
+                    v = v != v ? 0.0 : std::trunc(v);
+                    v = v < lo[depth] ? lo[depth] : (v > hi[depth] ? hi[depth] : v);
+                    const int32_t iv = (int32_t)v;
+                    float f = (float)iv;
+                    if (depth == CVGS_DEPTH_32S) std::memcpy(&f, &iv, 4);
+                    Pg.operand[m][c] = f;
+                    L.p64.operand[m][c] = (double)iv;
+                }
+            }
+            ++m;
+        }
+    }
     if (sdepth == CVGS_DEPTH_64F || L.final_depth == CVGS_DEPTH_64F) L.uses_64f = true;
 
     // ---- write stage ----
@@ -629,7 +655,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
     // 65 .. CVGS_KERNARG_PLANES_MAX planes of a chain K1 serves with a planar tensor target: the descriptors still travel in
     // the kernel arguments (a 16 KB block) -- no staging copy, capturable into a HIP graph
     bool big_inline = false;
-    if (!warp && !L.uses_64f && !L.args.read.table && !(ch->flags & CVGS_CHAIN_FORCE_GENERIC) &&
+    if (!warp && !L.uses_64f && !L.int_arith && !L.args.read.table && !(ch->flags & CVGS_CHAIN_FORCE_GENERIC) &&
         (int)L.planes.size() > CVGS_KERNARG_PLANES && (int)L.planes.size() <= kKernargPlanesBig)
     {
         big_inline = launch_k1(L.args, L.planes.data(), (int)L.planes.size(), L.mirrors, nullptr, 0, stream, true, nullptr) == 1;
@@ -694,7 +720,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         up.done(true);
         return CVGS_OK;
     }
-    if (!(ch->flags & CVGS_CHAIN_FORCE_GENERIC)) {
+    if (!(ch->flags & CVGS_CHAIN_FORCE_GENERIC) && !L.int_arith) { // integer-typed arithmetic: the interpreted kernel's business
         rc = launch_k1(L.args, inline_planes, n_inline, L.mirrors, nullptr, 0, stream, dry_run, info);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
         if (rc == 1) { up.done(true); return CVGS_OK; }
@@ -800,7 +826,8 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         Lowered L0; // the shared read / program / write arguments come from chain 0
         int rc = lower(&chains[0], false, L0);
         if (rc) return rc;
-        {
+        if (L0.int_arith) fusable = false; // integer-typed arithmetic: the interpreted kernel, chain by chain
+        if (fusable) {
             // would the fast kernel take this shape?  (dry run: nothing is enqueued, nothing uploaded)
             ChainArgs probe = L0.args;
             probe.read.table = (const PlaneParams*)(uintptr_t)16;
@@ -1250,7 +1277,7 @@ static int queue_submit_one(cvgs_queue_t h, const cvgs_chain_desc* chain, uint64
     Lowered L;
     int rc = lower(chain, false, L);
     if (rc) return rc;
-    if (L.uses_64f || L.mirrors.n > 0 || is_warp(L.args.read.kind) || (chain->flags & CVGS_CHAIN_FORCE_GENERIC))
+    if (L.uses_64f || L.int_arith || L.mirrors.n > 0 || is_warp(L.args.read.kind) || (chain->flags & CVGS_CHAIN_FORCE_GENERIC))
         return fail(CVGS_ERR_UNSUPPORTED, "queue: not a chain the server takes");
     std::string err;
     rc = cvgs::queue_submit(h->q, L.args, L.planes.data(), (int)L.planes.size(), ticket, err);

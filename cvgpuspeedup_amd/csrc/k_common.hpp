@@ -127,9 +127,53 @@ __device__ __forceinline__ void reorder_px(Px& p, int aux, int out_cn) {
     }
 }
 
+// Arithmetic on INTEGER-typed values (cvGS::multiply / add / subtract / divide<I> with an integer pixel type I, reference
+// include/cvGPUSpeedup.cuh:131-149).  FKL, which defines fk::Mul<uchar3> etc., is not in the reference tree and no reference
+// test uses these instantiations; the semantics chosen here: the scalar was converted to the pixel's own type by
+// the facade (cvScalar2CUDAV<I>: truncation) -- the host hands it over as an exact integer --, the operation runs in 64-bit
+// integer arithmetic (C++ promotion, no intermediate wrap), division truncates toward zero and x / 0 = 0 (cv::divide's
+// convention), and the result is SATURATED back to the type (cv::saturate_cast), so the value stays a valid value of its type.
+__device__ __forceinline__ void int_range(int depth, long long& lo, long long& hi) {
+    switch (depth) {
+    case CVGS_DEPTH_8U: lo = 0; hi = 255; break;
+    case CVGS_DEPTH_8S: lo = -128; hi = 127; break;
+    case CVGS_DEPTH_16U: lo = 0; hi = 65535; break;
+    case CVGS_DEPTH_16S: lo = -32768; hi = 32767; break;
+    default: lo = -2147483648ll; hi = 2147483647ll; break;
+    }
+}
+__device__ __forceinline__ long long int_arith(int opc, long long a, long long b, long long lo, long long hi) {
+    long long r;
+    switch (opc) {
+    case CVGS_OP_MUL: r = a * b; break;
+    case CVGS_OP_ADD: r = a + b; break;
+    case CVGS_OP_SUB: r = a - b; break;
+    default: r = b == 0 ? 0 : a / b; break;
+    }
+    return r < lo ? lo : (r > hi ? hi : r);
+}
+__device__ __forceinline__ bool is_int_depth(int depth) { return depth <= CVGS_DEPTH_32S; }
+
 // One pointwise stage.  `opc`, `aux` and the operands are wave-uniform (kernel arguments), so the
-// switch is a scalar branch, never a divergent one.
+// switch is a scalar branch, never a divergent one.  INTA: the value may be integer-typed when an arithmetic stage meets it
+// (the interpreted kernels only: every fast kernel's host-side plan keeps such chains out).
+template <bool INTA = false>
 __device__ __forceinline__ void apply_op(int opc, int aux, const float* operand, Px& p, int& depth, int& cn) {
+    if constexpr (INTA) {
+        if ((opc == CVGS_OP_MUL || opc == CVGS_OP_ADD || opc == CVGS_OP_SUB || opc == CVGS_OP_DIV) && is_int_depth(depth)) {
+            long long lo, hi;
+            int_range(depth, lo, hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < cn) {
+                    const long long a = depth == CVGS_DEPTH_32S ? (long long)as_int(p.v[c]) : (long long)p.v[c];
+                    const long long b = depth == CVGS_DEPTH_32S ? (long long)as_int(operand[c]) : (long long)operand[c];
+                    const long long r = int_arith(opc, a, b, lo, hi);
+                    p.v[c] = depth == CVGS_DEPTH_32S ? from_int((int)r) : (float)r;
+                }
+            return;
+        }
+    }
     switch (opc) {
     case CVGS_OP_CAST:
         cast_px(p, cn, depth, aux);
@@ -182,7 +226,14 @@ __device__ __forceinline__ void apply_op(int opc, int aux, const float* operand,
     }
 }
 
-// Interpreted program: any valid op list.
+// Interpreted program, integer-typed arithmetic included (k_generic / k_warp's interpreted kernels)
+struct InterpProgInt {
+    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
+        for (int k = 0; k < prog.n; ++k) apply_op<true>(prog.opcode[k], prog.aux[k], prog.operand[k], p, depth, cn);
+    }
+};
+
+// Interpreted program: any valid op list whose arithmetic meets float values.
 struct InterpProg {
     static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
         for (int k = 0; k < prog.n; ++k) apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], p, depth, cn);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_generic(const KernArgs<NPL> a, const Mi
         }
     }
 
-    InterpProg::run(c.prog, p, depth, cn);
+    InterpProgInt::run(c.prog, p, depth, cn);
 
     const DstPlane* dst = c.write.table ? c.write.table : c.dst_inline;
     write_px(c.write, dst, x, y, z, p, depth, cn);

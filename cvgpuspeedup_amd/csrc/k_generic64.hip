@@ -80,6 +80,10 @@ __device__ __forceinline__ void apply_op64(int opc, int aux, const float* of, co
                 if (depth == CVGS_DEPTH_64F) {
                     const double a = p.v[c], b = od[c];
                     p.v[c] = opc == CVGS_OP_MUL ? a * b : opc == CVGS_OP_ADD ? a + b : opc == CVGS_OP_SUB ? a - b : a / b;
+                } else if (is_int_depth(depth)) { // integer-typed value: k_common.hpp int_arith (the operand arrives as an exact integer)
+                    long long lo, hi;
+                    int_range(depth, lo, hi);
+                    p.v[c] = (double)int_arith(opc, (long long)p.v[c], (long long)od[c], lo, hi);
                 } else {
                     const float a = (float)p.v[c], b = of[c];
                     const float r = opc == CVGS_OP_MUL ? a * b : opc == CVGS_OP_ADD ? a + b : opc == CVGS_OP_SUB ? a - b : a / b;
@@ -334,10 +338,22 @@ __global__ __launch_bounds__(256) void k_warp64(const WarpKernArgs64<NPL> a, con
             Px p00, p10, p01, p11;
             const uint8_t* ra = P.data + (size_t)y1 * (size_t)P.step;
             const uint8_t* rb = P.data + (size_t)y2r * (size_t)P.step;
-            load_px(ra, r.depth, r.cn, x1, p00);
-            load_px(ra, r.depth, r.cn, x2r, p10);
-            load_px(rb, r.depth, r.cn, x1, p01);
-            load_px(rb, r.depth, r.cn, x2r, p11);
+            if (r.depth == CVGS_DEPTH_64F) { // CV_64F sources (reference warp<WT, InputType> takes any type, include/cvGPUSpeedup.cuh:285-292):
+                                              // taps are cast to float first, as in the resize (:227)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < r.cn) {
+                        p00.v[k] = (float)((const double*)ra)[x1 * r.cn + k];
+                        p10.v[k] = (float)((const double*)ra)[x2r * r.cn + k];
+                        p01.v[k] = (float)((const double*)rb)[x1 * r.cn + k];
+                        p11.v[k] = (float)((const double*)rb)[x2r * r.cn + k];
+                    }
+            } else {
+                load_px(ra, r.depth, r.cn, x1, p00);
+                load_px(ra, r.depth, r.cn, x2r, p10);
+                load_px(rb, r.depth, r.cn, x1, p01);
+                load_px(rb, r.depth, r.cn, x2r, p11);
+            }
             const float w00 = ((float)x2 - sx) * ((float)y2 - sy);
             const float w10 = (sx - (float)x1) * ((float)y2 - sy);
             const float w01 = ((float)x2 - sx) * (sy - (float)y1);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_warp(const WarpKernArgs<NPL> a, const W
             }
         }
     }
-    InterpProg::run(c.prog, p, depth, cn);
+    InterpProgInt::run(c.prog, p, depth, cn);
     const DstPlane* dst = c.write.table ? c.write.table : c.dst_inline;
     write_px(c.write, dst, x, y, z, p, depth, cn);
 }

@@ -441,10 +441,10 @@ template <typename I, typename O> struct Cast {
     static Unary<Cast> build() { return {}; }
 };
 
+// Integer pixel types T: the scalar arrives as T (cvScalar2CUDAV<I> truncated it), the stage runs in integer arithmetic and
+// saturates back to T (include/cvgs_hip.h CVGS_OP_MUL...; FKL's own definition is not in the reference tree).
 #define CVGS_FK_BINARY(NAME, OPC)                                                           \
     template <typename T> struct NAME {                                                     \
-        static_assert(std::is_floating_point_v<VBase<T>>,                                   \
-                      "cvGS::" #NAME ": arithmetic IOps are implemented for CV_32F / CV_64F pixel types (the only ones the reference's tests spell); convertTo the value to float first"); \
         using InputType = T; using OutputType = T; using ParamsType = T;                    \
         static void lower(const T& v, ChainBuilder& b) { float f[4]; double d[4]; vec_to_floats(v, f); vec_to_doubles(v, d); b.op(OPC, 0, f, d); } \
     };

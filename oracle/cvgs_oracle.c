@@ -454,7 +454,30 @@ static int apply_op(const cvgs_op* op, opx* p) {
             }
             return 0;
         }
-        if (p->depth != CVGS_DEPTH_32F) return CVGS_ERR_UNSUPPORTED;
+        if (p->depth == CVGS_DEPTH_16F) return CVGS_ERR_UNSUPPORTED;
+        if (p->depth != CVGS_DEPTH_32F) {
+            /* Integer-typed values (cvGS::multiply / add / subtract / divide<I>, integer I; reference include/cvGPUSpeedup.cuh:
+             * 131-149 instantiates fk::Mul<uchar3> etc., whose definition lives in the absent FKL and which no reference test
+             * uses).  Semantics fixed by this build: the scalar as the pixel's own type (cvScalar2CUDAV<I>:
+             * truncation, saturated), 64-bit integer arithmetic, division truncating toward zero with x / 0 = 0, result
+             * saturated to the type. */
+            static const double lo[5] = {0, -128, 0, -32768, -2147483648.0}, hi[5] = {255, 127, 65535, 32767, 2147483647.0};
+            const int d = p->depth;
+            for (int c = 0; c < p->cn; ++c) {
+                double sv = op->operand_d[c];
+                if (op->operand_d[0] == 0 && op->operand_d[1] == 0 && op->operand_d[2] == 0 && op->operand_d[3] == 0) sv = op->operand[c];
+                sv = sv != sv ? 0.0 : trunc(sv);
+                sv = sv < lo[d] ? lo[d] : (sv > hi[d] ? hi[d] : sv);
+                const long long b = (long long)sv;
+                const long long a = d == CVGS_DEPTH_32S ? (long long)p->i[c] : (long long)p->f[c];
+                long long r = op->opcode == CVGS_OP_MUL ? a * b : op->opcode == CVGS_OP_ADD ? a + b : op->opcode == CVGS_OP_SUB ? a - b
+                              : (b == 0 ? 0 : a / b);
+                r = r < (long long)lo[d] ? (long long)lo[d] : (r > (long long)hi[d] ? (long long)hi[d] : r);
+                if (d == CVGS_DEPTH_32S) p->i[c] = (int32_t)r;
+                else p->f[c] = (float)r;
+            }
+            return 0;
+        }
         for (int c = 0; c < p->cn; ++c) {
             const float a = p->f[c], b = op->operand[c];
             p->f[c] = op->opcode == CVGS_OP_MUL ? a * b

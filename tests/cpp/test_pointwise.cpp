@@ -146,6 +146,37 @@ static void test_split(cv::cuda::Stream& stream) {
     CHECK(ok, "split / batch split: every element of plane c equals 1 + c");
 }
 
+// arithmetic IOps on INTEGER pixel types (reference include/cvGPUSpeedup.cuh:131-149 defines them for every type; no reference
+// test uses them): known answers of the semantics DESIGN.md 7 fixes -- integer arithmetic, truncating division, saturation
+template <int T>
+static void test_integer_arithmetic(cv::cuda::Stream& stream) {
+    using B = BASE_CUDA_T(T);
+    constexpr int CN = CV_MAT_CN(T);
+    cv::Mat h_in(24, 40, T, cv::Scalar(200, 100, 50, 7));
+    cv::cuda::GpuMat d_in(h_in), d_out(24, 40, T);
+    cvGS::executeOperations(d_in, d_out, stream, cvGS::multiply<T>(cv::Scalar(2, 3, 1, 1)), cvGS::subtract<T>(cv::Scalar(100, 0.9, 60, 0)),
+                            cvGS::divide<T>(cv::Scalar(3, 0, 2, 2)));
+    stream.waitForCompletion();
+    const auto h = fetch(d_out.data, d_out.step * d_out.rows);
+    // per channel, in the type's own range: ch0 (200*2 sat) - 100, / 3; ch1 anything / 0 = 0; ch2 50 - 60 (sat at 0 for unsigned) / 2; ch3 7 / 2 = 3
+    const long long hi = std::is_same_v<B, uchar> ? 255 : (std::is_same_v<B, ushort> ? 65535 : (std::is_same_v<B, short> ? 32767 : 2147483647ll));
+    const long long lo = std::is_unsigned_v<B> ? 0 : -hi - 1;
+    auto sat = [&](long long v) { return v < lo ? lo : (v > hi ? hi : v); };
+    const long long want[4] = {sat(sat(200 * 2) - 100) / 3, 0, sat(50 - 60) / 2, 3};
+    bool ok = true;
+    for (int y = 0; y < 24 && ok; ++y)
+        for (int x = 0; x < 40 && ok; ++x)
+            for (int c = 0; c < CN; ++c) {
+                const B v = ((const B*)(h.data() + (size_t)y * d_out.step))[x * CN + c];
+                if ((long long)v != want[c]) {
+                    std::cout << "    (" << x << "," << y << "," << c << "): " << (long long)v << " vs " << want[c] << std::endl;
+                    ok = false;
+                    break;
+                }
+            }
+    CHECK(ok, "integer-typed multiply / subtract / divide, type " << T);
+}
+
 int main() {
     cv::cuda::Stream stream;
 #define RW(I, O) test_read_x_write<I, O>(stream);
@@ -182,5 +213,10 @@ int main() {
     test_cvtColor<CV_16UC4, CV_16UC1, cv::COLOR_BGRA2GRAY>(stream, {2});
     test_convertTo(stream);
     test_split(stream);
+    test_integer_arithmetic<CV_8UC3>(stream);
+    test_integer_arithmetic<CV_8UC4>(stream);
+    test_integer_arithmetic<CV_16UC3>(stream);
+    test_integer_arithmetic<CV_16SC4>(stream);
+    test_integer_arithmetic<CV_32SC3>(stream);
     return report("test_read_x_write + read_x_split + batchread_x_write3D + cvtColor + convertTo + split");
 }

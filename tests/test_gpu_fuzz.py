@@ -48,6 +48,12 @@ def _program(rng, depth, cn):
             fn = [cvgs.multiply, cvgs.add, cvgs.subtract, cvgs.divide][int(rng.integers(0, 4))]
             vals = [float(np.float32(v)) for v in rng.uniform(0.3, 3.0, cn)]
             ops.append(fn(T(depth, cn), vals))
+        elif choice in (1, 2) and depth in (cvgs.CV_8U, cvgs.CV_8S, cvgs.CV_16U, cvgs.CV_16S, cvgs.CV_32S):
+            # arithmetic on an integer-typed value (cvGS::multiply<CV_8UC3> ...): integer operands incl. zero divisors, negative
+            # and fractional scalars (truncated by the facade's conversion), results that saturate
+            fn = [cvgs.multiply, cvgs.add, cvgs.subtract, cvgs.divide][int(rng.integers(0, 4))]
+            pool = [0.0, 1.0, -1.0, 2.0, 3.0, -3.0, 7.5, -2.25, 100.0, 300.0, -40000.0, 70000.0, 3e9]
+            ops.append(fn(T(depth, cn), [pool[int(rng.integers(0, len(pool)))] for _ in range(cn)]))
         elif choice == 3 and depth in (cvgs.CV_8U, cvgs.CV_16U, cvgs.CV_32F) and cn in (3, 4):
             codes = {3: [("BGR2RGB", 3), ("BGR2BGRA", 4), ("RGB2BGRA", 4), ("BGR2GRAY", 1), ("RGB2GRAY", 1)],
                      4: [("RGBA2BGRA", 4), ("BGRA2BGR", 3), ("RGBA2BGR", 3), ("BGRA2GRAY", 1), ("RGBA2GRAY", 1)]}[cn]

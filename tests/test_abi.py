@@ -87,12 +87,16 @@ def test_validation_errors(lib):
     wout = np.zeros((1, 3 * 8 * 8), np.float32)
     wch = cvgs.lower([cvgs.warp(cvgs.WARP_AFFINE, cvgs.CV_64FC3, cvgs.GpuMat.from_array(wsrc, cvgs.CV_64FC3), [[1, 0, 0], [0, 1, 0]], (8, 8)),
                       cvgs.split(cvgs.CV_32FC3, cvgs.GpuMat.from_array(wout, cvgs.CV_32FC1), (8, 8))])
-    assert lib.cvgs_validate(C.byref(wch.desc)) == capi.ERR_UNSUPPORTED  # no kernel warps CV_64F sources
-    # arithmetic on a non-float value: not implemented (the reference spells these on CV_32F types only)
+    assert lib.cvgs_validate(C.byref(wch.desc)) == 0  # CV_64F warp sources are served since round 3 (k_warp64)
+    # arithmetic on an integer-typed value: served since round 3 (integer arithmetic, saturating); CV_16F values are not
     frame = np.zeros((8, 8, 3), np.uint8)
     outm = np.zeros((8, 8, 3), np.uint8)
     rd = cvgs.ReadIOp(capi.READ_PIXEL, cvgs.CV_8UC3, [cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)], 1)
     ch = cvgs.lower([rd, cvgs.multiply(cvgs.CV_8UC3, [2, 2, 2]), cvgs.write(cvgs.CV_8UC3, cvgs.GpuMat.from_array(outm, cvgs.CV_8UC3))])
+    assert lib.cvgs_validate(C.byref(ch.desc)) == 0
+    outh = np.zeros((8, 8, 3), np.float16)
+    ch = cvgs.lower([rd, cvgs.convertTo(cvgs.CV_8UC3, cvgs.CV_16FC3), cvgs.multiply(cvgs.CV_16FC3, [2, 2, 2]),
+                     cvgs.write(cvgs.CV_16FC3, cvgs.GpuMat.from_array(outh, cvgs.CV_16FC3))])
     assert lib.cvgs_validate(C.byref(ch.desc)) == capi.ERR_UNSUPPORTED
 
 

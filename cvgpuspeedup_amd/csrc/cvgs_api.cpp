@@ -721,7 +721,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         return CVGS_OK;
     }
     if (!(ch->flags & CVGS_CHAIN_FORCE_GENERIC) && !L.int_arith) { // integer-typed arithmetic: the interpreted kernel's business
-        rc = launch_k1(L.args, inline_planes, n_inline, L.mirrors, nullptr, 0, stream, dry_run, info);
+        rc = launch_k1(L.args, inline_planes, n_inline, L.mirrors, nullptr, 0, stream, dry_run, info, ch->flags);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
         if (rc == 1) { up.done(true); return CVGS_OK; }
         if (big_inline && (has_mirrors || !is_nv12(L.args.read.kind)))

@@ -156,7 +156,10 @@ int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_i
 // `segs` (n_segs >= 1): the chains of a cvgs_execute_many launch (their planes live in device tables; c.read.batch is
 // the largest batch); nullptr: one chain described by c / inline_planes.
 int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors,
-              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info);
+              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags = 0);
+// K1's whole-frame form for packed targets, four output pixels per lane (k_k1_x4.hip); 1 launched / 0 not eligible / < 0 error
+int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_planes, void* stream, bool dry_run, bool force);
+static constexpr int64_t kX4MinWaveRows = 12288; // output rows x 64-column tiles x images from which launch_k1 prefers it
 
 // interpreted kernel for chains that touch CV_64F
 int launch_generic64(const ChainArgs& c, const Prog64Args& p64, const PlaneParams* inline_planes, int n_inline, void* stream,

@@ -32,7 +32,7 @@ hipError_t k1_launch_planar_c3(int src, bool f16, int prog_id, bool table, int r
 hipError_t k1_launch_planar_c4(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s);
 
 int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors,
-              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info) {
+              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags) {
     const ReadArgs& r = c_in.read;
     // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write -- or, for 8U sources, an fp16 planar
     // tensor whose conversion is the chain's LAST stage (the half-precision hand-off option)
@@ -103,6 +103,21 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
+    // whole-frame resize -> cast -> packed u8 pixels with nothing in between: four output pixels per lane
+    // (k_k1_x4.hip) once the launch is in the throughput regime.  CVGS_CHAIN_NO_THREAD_FUSION keeps the one-pixel kernel.
+    if (packed && r.depth == CVGS_DEPTH_8U && u8out && n_prog == 0 && !table && !segs &&
+        mirrors.n == 0 && !(chain_flags & CVGS_CHAIN_NO_THREAD_FUSION)) {
+        const char* x4_env = getenv("CVGS_K1_X4"); // tuning / test hook: 0 = never, 1 = whenever eligible
+        const bool force = x4_env && x4_env[0] == '1';
+        if (force || (!x4_env && wave_rows >= kX4MinWaveRows)) {
+            const int rc = launch_k1_packed_x4(c, inline_planes, n_inline, stream, dry_run, force);
+            if (rc != 0) {
+                static const char* names_x4[4] = {"k1_u8c1_packed_u8_x4", "k1_u8c2_packed_u8_x4", "k1_u8c3_packed_u8_x4", "k1_u8c4_packed_u8_x4"};
+                if (info) info->kernel = names_x4[r.cn - 1];
+                return rc;
+            }
+        }
+    }
     if (info) {
         static const char* names[4][2][3] = {
             {{"k1_u8c3_swap_mul_sub_div", "k1_u8c3_mul_sub_div", "k1_u8c3_interp"},

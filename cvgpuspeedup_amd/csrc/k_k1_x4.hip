@@ -1,0 +1,330 @@
+// k_k1_x4.hip -- whole-frame resize into PACKED pixels, four x-adjacent output pixels per lane.
+//
+// The chain: resize<INTER_LINEAR>(8UCn image) -> convertTo<CV_32F, O> -> write<O>(packed image), O = CV_8UCn --
+// the reference's tests/resize/test_resize_write.cu chain (cvGS::resize + cvGS::convertTo + cvGS::write, :110-123) at
+// whole-frame sizes (1080p <-> 4K).  k1_resize_split (lane = ONE output column) is VALU + SALU issue bound there
+// (369 VALU + 218 SALU per 4-row wave on 1080p -> 4K packed u8, 23 us, 0.17 of the HBM roofline): the
+// per-pixel work is dominated by what is NOT the interpolation -- the 64-bit window shift, the edge selects, the wave
+// shuffle that turns 3-byte pixels into dword stores, per-row address arithmetic.
+//
+// This kernel's mapping:
+//  * lane = 4 x-adjacent output pixels, wave = 256 output columns x R consecutive output rows (R is a launch parameter).
+//    The lane's 4 pixels leave as ONE 4*CN-byte store: no shuffle.
+//  * column geometry (x1, weights, window offset) once per lane and pixel, reused for all R rows; the window's byte shift AND
+//    the right-edge duplication (x2 clamped onto x1) are ONE v_perm_b32 selector per dword, computed with the geometry.
+//  * row geometry for all R rows at once: lane j computes row row0 + j, the loop reads it back with v_readlane.
+//  * the unpacked taps of a SOURCE row live in one of two register slots picked by the row's parity; an output row whose
+//    source rows are already in the slots (every second row of a 2x up-scaling) loads and unpacks nothing, and the
+//    interpolation is written once per slot order so that nothing is ever moved between registers.
+//  * the interpolation runs on pixel PAIRS (v_pk_mul_f32 / v_pk_add_f32): same IEEE operations in the same order as the
+//    oracle (p00*w00 + p10*w10 + p01*w01 + p11*w11, left to right, no FMA), two pixels per instruction.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "k_taps.hpp"
+
+namespace cvgs {
+
+constexpr int kX4Planes = 8;   // images per launch (blockIdx.y)
+constexpr int kX4Waves = 4;    // waves per workgroup (independent)
+constexpr int kX4Px = 4;       // output pixels per lane
+
+struct X4Plane { // 32 bytes
+    const uint8_t* data;
+    int32_t w, h, step;
+    float fx, fy;
+    int32_t pad;
+};
+struct X4Args {
+    X4Plane plane[kX4Planes];
+    uint8_t* out;
+    int64_t row_pitch, img_pitch; // bytes
+    int32_t dst_w, dst_h;
+    uint32_t col_tiles;           // ceil(dst_w / 256)
+    int32_t rows_per_wave;        // <= 64
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// the unpacked taps of one source row for the lane's 4 output pixels: [pixel pair][channel] x {pixel 2q, pixel 2q+1}
+template <int CN>
+struct X4Slot {
+    f32x2 t0[2][CN]; // tap x1
+    f32x2 t1[2][CN]; // tap x2 (= x1 at the right edge)
+};
+
+template <int CN>
+struct X4Col {
+    f32x2 wxa[2], wxb[2];
+    uint32_t ol[kX4Px], sel_lo[kX4Px], sel_hi[kX4Px];
+};
+
+// bytes [CN, 2CN) of the window hold the second tap; at the right edge they are re-pointed at the first one
+template <int CN> constexpr uint32_t x4_edge_sub(int dword) {
+    uint32_t v = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int b = dword * 4 + k;
+        if (b >= CN && b < 2 * CN) v |= (uint32_t)CN << (8 * k);
+    }
+    return v;
+}
+
+// the lane's four 8-byte tap windows of one source row, as loaded
+struct X4Raw { uint64_t w[kX4Px]; };
+
+template <int CN>
+__device__ __forceinline__ X4Raw x4_load(const X4Col<CN>& col, gptr_u8 row) {
+    X4Raw r;
+#pragma unroll
+    for (int i = 0; i < kX4Px; ++i) r.w[i] = *(gptr_u64)(row + col.ol[i]);
+    return r;
+}
+
+template <int CN>
+__device__ __forceinline__ void x4_unpack(X4Slot<CN>& s, const X4Col<CN>& col, const X4Raw& r) {
+#pragma unroll
+    for (int i = 0; i < kX4Px; ++i) {
+        const uint32_t wl = (uint32_t)r.w[i], wh = (uint32_t)(r.w[i] >> 32);
+        const uint32_t lo = __builtin_amdgcn_perm(wh, wl, col.sel_lo[i]);
+        [[maybe_unused]] uint32_t hi = 0;
+        if constexpr (2 * CN > 4) hi = __builtin_amdgcn_perm(wh, wl, col.sel_hi[i]);
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            const int b0 = c, b1 = CN + c;
+            const uint32_t e0 = ((b0 < 4 ? lo : hi) >> (8 * (b0 & 3))) & 0xffu;
+            const uint32_t e1 = ((b1 < 4 ? lo : hi) >> (8 * (b1 & 3))) & 0xffu;
+            s.t0[i >> 1][c][i & 1] = (float)e0;
+            s.t1[i >> 1][c][i & 1] = (float)e1;
+        }
+    }
+}
+
+template <int CN, typename OT>
+__device__ __forceinline__ void x4_row(const X4Slot<CN>& A, const X4Slot<CN>& B, const X4Col<CN>& col, float wya, float wyb,
+                                       uint8_t* orow, uint32_t x0, int dst_w, bool wave_full) {
+    float v[kX4Px * CN];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 w00 = col.wxa[q] * wya;
+        const f32x2 w10 = col.wxb[q] * wya;
+        const f32x2 w01 = col.wxa[q] * wyb;
+        const f32x2 w11 = col.wxb[q] * wyb;
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            f32x2 acc = A.t0[q][c] * w00;
+            acc = acc + A.t1[q][c] * w10;
+            acc = acc + B.t0[q][c] * w01;
+            acc = acc + B.t1[q][c] * w11;
+            v[(2 * q) * CN + c] = acc.x;
+            v[(2 * q + 1) * CN + c] = acc.y;
+        }
+    }
+    typedef __attribute__((address_space(1))) uint8_t* gout;
+    static_assert(std::is_same_v<OT, uint8_t>, "packed u8 targets");
+    uint32_t word[CN];
+#pragma unroll
+    for (int k = 0; k < CN; ++k) word[k] = 0;
+#pragma unroll
+    for (int b = 0; b < kX4Px * CN; ++b) word[b >> 2] = sat_u8_insert(v[b], (uint32_t)(b & 3), word[b >> 2]);
+    const gout p = (gout)pin_uniform(orow) + x0 * (uint32_t)CN;
+    auto store_all = [&]() {
+        typedef uint32_t vw __attribute__((ext_vector_type(CN)));
+        typedef __attribute__((address_space(1))) vw* gvw;
+        if constexpr (CN == 1) {
+            __builtin_nontemporal_store(word[0], (__attribute__((address_space(1))) uint32_t*)p);
+        } else {
+            vw q;
+#pragma unroll
+            for (int k = 0; k < CN; ++k) q[k] = word[k];
+            __builtin_nontemporal_store(q, (gvw)p);
+        }
+    };
+    if (wave_full) { // scalar: no lane of this column tile hangs over the row's end
+        store_all();
+    } else if ((int)x0 + kX4Px - 1 < dst_w) {
+        store_all();
+    } else {
+#pragma unroll
+        for (int b = 0; b < kX4Px * CN; ++b)
+            if ((int)x0 + b / CN < dst_w) __builtin_nontemporal_store((uint8_t)(word[b >> 2] >> (8 * (b & 3))), p + b);
+    }
+}
+
+template <int CN, typename OT>
+__global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
+    const int z = (int)blockIdx.y;
+    const X4Plane P = a.plane[z];
+    const int dst_w = a.dst_w, dst_h = a.dst_h, R = a.rows_per_wave;
+    const uint32_t col_tiles = a.col_tiles;
+    uint32_t col_tile = 0, row_blk = blockIdx.x;
+    if (col_tiles > 1) {
+        col_tile = blockIdx.x % col_tiles;
+        row_blk = blockIdx.x / col_tiles;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int row0 = ((int)row_blk * kX4Waves + wave) * R;
+    if (row0 >= dst_h) return;
+    const int nrows = min(R, dst_h - row0);
+    const uint32_t x0 = (col_tile * 64u + (uint32_t)lane) * kX4Px;
+
+    // ---- column geometry: the oracle's expressions per pixel (sx = x * fx in fp32, x1 = floor, the two weights) ----
+    X4Col<CN> col;
+    const int row_bytes = P.w * CN;
+#pragma unroll
+    for (int i = 0; i < kX4Px; ++i) {
+        const int x = min((int)x0 + i, dst_w - 1); // lanes / pixels past the row compute a valid pixel and store nothing
+        const float sx = (float)x * P.fx;
+        const int x1 = (int)floorf(sx);
+        const int x2 = x1 + 1;
+        col.wxa[i >> 1][i & 1] = (float)x2 - sx;
+        col.wxb[i >> 1][i & 1] = sx - (float)x1;
+        const bool edge = x2 > P.w - 1;
+        const int o = x1 * CN;
+        const int ol = min(o, row_bytes - 8);
+        const uint32_t sh = (uint32_t)(o - ol);
+        col.ol[i] = (uint32_t)ol;
+        col.sel_lo[i] = 0x03020100u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(0) : 0u);
+        col.sel_hi[i] = 0x07060504u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(1) : 0u);
+    }
+
+    // ---- row geometry: lane j holds output row row0 + j ----
+    int y1v;
+    float wyav, wybv;
+    {
+        const int y = min(row0 + lane, dst_h - 1);
+        const float sy = (float)y * P.fy;
+        y1v = (int)floorf(sy);
+        wyav = (float)(y1v + 1) - sy;
+        wybv = sy - (float)y1v;
+    }
+
+    const gptr_u8 src = (gptr_u8)P.data;
+    uint8_t* const out = a.out + (int64_t)z * a.img_pitch + (int64_t)row0 * a.row_pitch;
+    X4Slot<CN> S0, S1;
+    auto row_of = [&](int r) { return pin_uniform(src + (size_t)r * (size_t)P.step); };
+    auto y1_of = [&](int j) { return __builtin_amdgcn_readlane(y1v, j); };
+    const bool wave_full = (int)(col_tile + 1) * 64 * kX4Px <= dst_w;
+    auto emit = [&](const X4Slot<CN>& A, const X4Slot<CN>& B, int j) {
+        const float wya = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyav), j));
+        const float wyb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wybv), j));
+        x4_row<CN, OT>(A, B, col, wya, wyb, out + (int64_t)j * a.row_pitch, x0, dst_w, wave_full);
+    };
+    // Source rows s, s+1 sit in (S0, S1) in the first phase and in (S1, S0) in the second: when the next output row starts
+    // one source row further down (every up-scaling; often when 1 < fy < 2) only ONE row is loaded and unpacked, and the
+    // slots never trade registers.  Any other step (fy >= 2, or the next row is further away) restarts with both rows.
+    // y1 never decreases with the output row, so the rows of a phase are the lanes whose y1v == s: their count comes from
+    // one ballot, and the windows of the NEXT phase's new row are requested before this phase's rows are computed.
+    int j = 0;
+    const int h1 = P.h - 1;
+    const bool mine = lane < nrows;
+    auto rows_on = [&](int s) { return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && y1v == s)); };
+#pragma unroll 1
+    while (j < nrows) {
+        int s = y1_of(j);
+        const X4Raw first = x4_load<CN>(col, row_of(s));
+        X4Raw next = x4_load<CN>(col, row_of(min(s + 1, h1)));
+        x4_unpack<CN>(S0, col, first);
+#pragma unroll 1
+        for (;;) {
+            x4_unpack<CN>(S1, col, next);
+            int jn = j + rows_on(s);
+            bool more = jn < nrows && y1_of(jn) == s + 1;
+            if (more) next = x4_load<CN>(col, row_of(min(s + 2, h1)));
+            if (jn - j == 2) { // the 2x up-scaling's phase, without the loop
+                emit(S0, S1, j);
+                emit(S0, S1, j + 1);
+                j = jn;
+            }
+#pragma unroll 1
+            for (; j < jn; ++j) emit(S0, S1, j);
+            if (!more) break;
+            ++s;
+            x4_unpack<CN>(S0, col, next);
+            jn = j + rows_on(s);
+            more = jn < nrows && y1_of(jn) == s + 1;
+            if (more) next = x4_load<CN>(col, row_of(min(s + 2, h1)));
+            if (jn - j == 2) { // the 2x up-scaling's phase, without the loop
+                emit(S1, S0, j);
+                emit(S1, S0, j + 1);
+                j = jn;
+            }
+#pragma unroll 1
+            for (; j < jn; ++j) emit(S1, S0, j);
+            if (!more) break;
+            ++s;
+        }
+    }
+}
+
+// Host side.  Takes the chain when every image of the batch covers its whole target (no aspect-ratio padding, no unused
+// planes), the source rows hold at least one 8-byte window, the target rows are dword aligned and -- unless `force`d
+// (CVGS_K1_X4=1: tests) -- no image is scaled down vertically.
+// Returns 1 launched / 0 not eligible / < 0 error (as launch_k1).
+int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_planes, void* stream, bool dry_run, bool force) {
+    const ReadArgs& r = c.read;
+    const WriteArgs& w = c.write;
+    if (r.depth != CVGS_DEPTH_8U || r.cn < 1 || r.cn > 4 || r.table || w.data2 || w.table) return 0;
+    if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
+    // packed fp32 targets stay with the one-pixel kernel: its per-pixel 12 / 16-byte stores already run the 4K output at
+    // 4.6 TB/s, while a lane that owns 4 pixels writes 48-byte strides (measured: 1080p -> 4K 49 us against 22.8)
+    if (w.depth != CVGS_DEPTH_8U) return 0;
+    if (w.cn != r.cn || r.batch < 1 || r.batch > kX4Planes || r.used != r.batch || n_planes != r.batch) return 0;
+    if (r.dst_w < 4 || r.dst_h < 1) return 0;
+    const int64_t px_bytes = w.cn;
+    const int64_t row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * px_bytes;
+    const int64_t img_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : w.img_stride * px_bytes;
+    const int64_t align = 4;
+    if (((uintptr_t)w.data | (uint64_t)row_pitch | (uint64_t)img_pitch) & (uint64_t)(align - 1)) return 0;
+    X4Args a;
+    for (int i = 0; i < kX4Planes; ++i) {
+        const PlaneParams& p = planes[i < n_planes ? i : 0];
+        if (i < n_planes) {
+            if (p.x1 != 0 || p.y1 != 0 || p.x2 != r.dst_w - 1 || p.y2 != r.dst_h - 1) return 0;
+            if ((int64_t)p.w * r.cn < 8 || p.h < 1) return 0;
+            // the kernel's gain is the source row shared by consecutive output rows: vertical up-scaling (or 1:1).  Down-scaling
+            // launches tie with the one-pixel kernel or lose to it (4K -> 1080p 9.9 - 12 us against 10.3), so they stay there.
+            if (!force && !(p.fy <= 1.0f)) return 0;
+        }
+        a.plane[i] = X4Plane{p.data, p.w, p.h, p.step, p.fx, p.fy, 0};
+    }
+    if (dry_run) return 1;
+    a.out = w.data;
+    a.row_pitch = row_pitch;
+    a.img_pitch = img_pitch;
+    a.dst_w = r.dst_w;
+    a.dst_h = r.dst_h;
+    a.col_tiles = (uint32_t)((r.dst_w + 64 * kX4Px - 1) / (64 * kX4Px));
+    // rows per wave: enough waves to fill the chip (~4 per SIMD) before the column geometry is amortised over more rows
+    // (tools/bench_upscale.py: 4K output 8 rows 10.9 us / 4 rows 11.9; 1440p 4 rows 7.0 / 8 rows 9.5; 720p 2 rows 4.0 / 8 rows 5.6)
+    const int64_t wave_rows = (int64_t)r.dst_h * a.col_tiles * r.batch;
+    int rows_per_wave = (int)((wave_rows + 2048) / 4096);
+    rows_per_wave = rows_per_wave < 2 ? 2 : (rows_per_wave > 8 ? 8 : rows_per_wave);
+    static const char* rows_env = getenv("CVGS_K1_X4_ROWS"); // tuning hook (benchmarks only)
+    if (rows_env && atoi(rows_env) > 0) rows_per_wave = atoi(rows_env);
+    a.rows_per_wave = rows_per_wave > 64 ? 64 : rows_per_wave;
+    const int rows_per_wg = kX4Waves * a.rows_per_wave;
+    const uint32_t row_blks = (uint32_t)((r.dst_h + rows_per_wg - 1) / rows_per_wg);
+    const dim3 grid(a.col_tiles * row_blks, (unsigned)r.batch), block(64 * kX4Waves);
+    hipStream_t s = (hipStream_t)stream;
+    auto go = [&](auto cn_tag, auto ot_tag) {
+        constexpr int CN = decltype(cn_tag)::value;
+        using OT = decltype(ot_tag);
+        hipLaunchKernelGGL((k1_packed_x4<CN, OT>), grid, block, 0, s, a);
+    };
+    auto by_cn = [&](auto ot_tag) {
+        switch (r.cn) {
+        case 1: go(std::integral_constant<int, 1>{}, ot_tag); break;
+        case 2: go(std::integral_constant<int, 2>{}, ot_tag); break;
+        case 3: go(std::integral_constant<int, 3>{}, ot_tag); break;
+        default: go(std::integral_constant<int, 4>{}, ot_tag); break;
+        }
+    };
+    by_cn(uint8_t{});
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : -(int)e - 1000;
+}
+
+} // namespace cvgs

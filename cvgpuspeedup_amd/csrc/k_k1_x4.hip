@@ -30,6 +30,7 @@ namespace cvgs {
 constexpr int kX4Planes = 8;   // images per launch (blockIdx.y)
 constexpr int kX4Waves = 4;    // waves per workgroup (independent)
 constexpr int kX4Px = 4;       // output pixels per lane
+constexpr int kX4Pre = 4;      // source intervals whose rows a wave requests up front (kX4Pre + 1 source rows)
 
 struct X4Plane { // 32 bytes
     const uint8_t* data;
@@ -130,10 +131,14 @@ __device__ __forceinline__ void x4_row(const X4Slot<CN>& A, const X4Slot<CN>& B,
     for (int b = 0; b < kX4Px * CN; ++b) word[b >> 2] = sat_u8_insert(v[b], (uint32_t)(b & 3), word[b >> 2]);
     const gout p = (gout)pin_uniform(orow) + x0 * (uint32_t)CN;
     auto store_all = [&]() {
-        typedef uint32_t vw __attribute__((ext_vector_type(CN)));
+        // byte-aligned types: rows of a 3870-pixel u8c3 image (the reference's tests/resize/test_resize_write.cu size) start on
+        // any byte; the hardware takes the unaligned multi-dword store
+        typedef uint32_t vw_a4 __attribute__((ext_vector_type(CN)));
+        typedef vw_a4 vw __attribute__((aligned(1)));
         typedef __attribute__((address_space(1))) vw* gvw;
+        typedef uint32_t u32a1 __attribute__((aligned(1)));
         if constexpr (CN == 1) {
-            __builtin_nontemporal_store(word[0], (__attribute__((address_space(1))) uint32_t*)p);
+            __builtin_nontemporal_store(word[0], (__attribute__((address_space(1))) u32a1*)p);
         } else {
             vw q;
 #pragma unroll
@@ -212,15 +217,43 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
         const float wyb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wybv), j));
         x4_row<CN, OT>(A, B, col, wya, wyb, out + (int64_t)j * a.row_pitch, x0, dst_w, wave_full);
     };
-    // Source rows s, s+1 sit in (S0, S1) in the first phase and in (S1, S0) in the second: when the next output row starts
-    // one source row further down (every up-scaling; often when 1 < fy < 2) only ONE row is loaded and unpacked, and the
-    // slots never trade registers.  Any other step (fy >= 2, or the next row is further away) restarts with both rows.
-    // y1 never decreases with the output row, so the rows of a phase are the lanes whose y1v == s: their count comes from
-    // one ballot, and the windows of the NEXT phase's new row are requested before this phase's rows are computed.
     int j = 0;
     const int h1 = P.h - 1;
     const bool mine = lane < nrows;
+    // y1 never decreases with the output row, so the rows fed from source rows (s, s+1) are the lanes whose y1v == s: one ballot
     auto rows_on = [&](int s) { return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && y1v == s)); };
+
+    // ---- the wave's first kX4Pre source intervals: ALL their rows are requested before anything is computed ----
+    // The wave then waits for memory ONCE; what follows is arithmetic and stores nobody waits for.  (Fetching each new source
+    // row when its interval starts cost one load + store-acknowledge round trip per interval: 4K -> 3870 x 2260, one new source
+    // row per output row, ran 8 such round trips per wave: 23.7 us.)  Source rows s, s+1 sit in (S0, S1) for the even intervals
+    // and in (S1, S0) for the odd ones: one row is unpacked per interval and the slots never trade registers.
+    {
+        const int s0 = y1_of(0);
+        X4Raw raw[kX4Pre + 1];
+#pragma unroll
+        for (int k = 0; k <= kX4Pre; ++k) raw[k] = x4_load<CN>(col, row_of(min(s0 + k, h1)));
+        x4_unpack<CN>(S0, col, raw[0]);
+#pragma unroll
+        for (int k = 0; k < kX4Pre; ++k) {
+            if (j < nrows) { // wave-uniform
+                const int jn = j + rows_on(s0 + k);
+                if ((k & 1) == 0) {
+                    x4_unpack<CN>(S1, col, raw[k + 1]);
+#pragma unroll 1
+                    for (; j < jn; ++j) emit(S0, S1, j);
+                } else {
+                    x4_unpack<CN>(S0, col, raw[k + 1]);
+#pragma unroll 1
+                    for (; j < jn; ++j) emit(S1, S0, j);
+                }
+            }
+        }
+    }
+
+    // ---- whatever is left (the launcher sizes the wave's rows so that nothing is, for vertical up-scaling): interval by interval.
+    // When the next output row starts one source row further down only ONE row is loaded and unpacked; any other step
+    // (fy >= 2, or the next row is further away) restarts with both rows.
 #pragma unroll 1
     while (j < nrows) {
         int s = y1_of(j);
@@ -233,11 +266,6 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
             int jn = j + rows_on(s);
             bool more = jn < nrows && y1_of(jn) == s + 1;
             if (more) next = x4_load<CN>(col, row_of(min(s + 2, h1)));
-            if (jn - j == 2) { // the 2x up-scaling's phase, without the loop
-                emit(S0, S1, j);
-                emit(S0, S1, j + 1);
-                j = jn;
-            }
 #pragma unroll 1
             for (; j < jn; ++j) emit(S0, S1, j);
             if (!more) break;
@@ -246,11 +274,6 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
             jn = j + rows_on(s);
             more = jn < nrows && y1_of(jn) == s + 1;
             if (more) next = x4_load<CN>(col, row_of(min(s + 2, h1)));
-            if (jn - j == 2) { // the 2x up-scaling's phase, without the loop
-                emit(S1, S0, j);
-                emit(S1, S0, j + 1);
-                j = jn;
-            }
 #pragma unroll 1
             for (; j < jn; ++j) emit(S1, S0, j);
             if (!more) break;
@@ -260,7 +283,7 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
 }
 
 // Host side.  Takes the chain when every image of the batch covers its whole target (no aspect-ratio padding, no unused
-// planes), the source rows hold at least one 8-byte window, the target rows are dword aligned and -- unless `force`d
+// planes), the source rows hold at least one 8-byte window and -- unless `force`d
 // (CVGS_K1_X4=1: tests) -- no image is scaled down vertically.
 // Returns 1 launched / 0 not eligible / < 0 error (as launch_k1).
 int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_planes, void* stream, bool dry_run, bool force) {
@@ -276,8 +299,6 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     const int64_t px_bytes = w.cn;
     const int64_t row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * px_bytes;
     const int64_t img_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : w.img_stride * px_bytes;
-    const int64_t align = 4;
-    if (((uintptr_t)w.data | (uint64_t)row_pitch | (uint64_t)img_pitch) & (uint64_t)(align - 1)) return 0;
     X4Args a;
     for (int i = 0; i < kX4Planes; ++i) {
         const PlaneParams& p = planes[i < n_planes ? i : 0];
@@ -298,10 +319,15 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     a.dst_h = r.dst_h;
     a.col_tiles = (uint32_t)((r.dst_w + 64 * kX4Px - 1) / (64 * kX4Px));
     // rows per wave: enough waves to fill the chip (~4 per SIMD) before the column geometry is amortised over more rows
-    // (tools/bench_upscale.py: 4K output 8 rows 10.9 us / 4 rows 11.9; 1440p 4 rows 7.0 / 8 rows 9.5; 720p 2 rows 4.0 / 8 rows 5.6)
+    // (tools/bench_upscale.py: 4K output 8 rows 10.7 us / 4 rows 14.2; 1440p 4 rows 7.0 / 8 rows 9.5; 720p 2 rows 4.0 / 8 rows 5.6),
+    // and no more rows than the kX4Pre source intervals requested up front feed (4K -> 3870 x 2260, fy 0.956: 4 rows 20.4 us / 8 rows 22.8)
     const int64_t wave_rows = (int64_t)r.dst_h * a.col_tiles * r.batch;
     int rows_per_wave = (int)((wave_rows + 2048) / 4096);
     rows_per_wave = rows_per_wave < 2 ? 2 : (rows_per_wave > 8 ? 8 : rows_per_wave);
+    float fy_max = 0.f;
+    for (int i = 0; i < n_planes; ++i) fy_max = planes[i].fy > fy_max ? planes[i].fy : fy_max;
+    const int rows_fed = fy_max > 0.f ? (int)((float)kX4Pre / fy_max) : 8;
+    if (rows_fed < rows_per_wave) rows_per_wave = rows_fed < 1 ? 1 : rows_fed;
     static const char* rows_env = getenv("CVGS_K1_X4_ROWS"); // tuning hook (benchmarks only)
     if (rows_env && atoi(rows_env) > 0) rows_per_wave = atoi(rows_env);
     a.rows_per_wave = rows_per_wave > 64 ? 64 : rows_per_wave;

@@ -26,9 +26,9 @@ def forced():
         os.environ["CVGS_K1_X4"] = old
 
 
-def _chain(src, cn, dst, to_u8, x_off=4, pad=8):
+def _chain(src, cn, dst, to_u8, x_off=3, pad=6):
     u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
-    pitch_w = (dst[0] + x_off + pad + 3) // 4 * 4  # a view of a wider buffer -> pitched rows; offsets / pitches stay 16-byte multiples
+    pitch_w = dst[0] + x_off + pad  # a view of a wider buffer -> pitched rows that start on any byte
     odt = np.uint8 if to_u8 else np.float32
 
     def build(wrap, wrap_out, out):
@@ -60,6 +60,21 @@ def test_x4_matches_the_oracle(forced, shape, cn, to_u8=True):
     assert _name(build) == "k1_u8c%d_packed_%s_x4" % (cn, "u8" if to_u8 else "f32")
     one, _ = _both(build, oshape, odt, flags=capi.CHAIN_NO_THREAD_FUSION)
     H.assert_bit_exact(one[0], gpu[0], "the one-pixel-per-lane kernel agrees")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_x4_random_shapes(forced, seed):
+    """15 random (source, target, channels) shapes per seed: any mix of up- and down-scaling, ragged widths, 1-row sources."""
+    rng = np.random.default_rng(4200 + seed)
+    for _ in range(15):
+        cn = int(rng.integers(1, 5))
+        sh, sw = int(rng.integers(1, 140)), int(rng.integers((8 + cn - 1) // cn, 320))
+        dst = (int(rng.integers(4, 720)), int(rng.integers(1, 220)))
+        src = H.random_u8((sh, sw, cn), int(rng.integers(1 << 30)))
+        build, oshape, odt = _chain(src, cn, dst, True, x_off=int(rng.integers(0, 9)), pad=int(rng.integers(0, 9)))
+        gpu, ref = _both(build, oshape, odt)
+        H.assert_bit_exact(gpu[0], ref[0], "%dx%dx%d -> %dx%d" % (sw, sh, cn, dst[0], dst[1]))
+        assert _name(build) == "k1_u8c%d_packed_u8_x4" % cn
 
 
 @pytest.mark.parametrize("cn", [3, 4])
@@ -99,15 +114,10 @@ def test_x4_batch_of_images(forced, to_u8=True):
 
 
 def test_x4_leaves_what_it_does_not_cover(forced):
-    """an unaligned target, a program between resize and write, a packed fp32 target: the one-pixel kernel."""
+    """a program between resize and write, a packed fp32 target: the one-pixel kernel."""
     cn = 3
     src = H.random_u8((100, 160, cn), 5)
     u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
-    build, oshape, odt = _chain(src, cn, (320, 200), True, x_off=2)  # 6-byte offset: rows not dword aligned
-    gpu, ref = _both(build, oshape, odt)
-    H.assert_bit_exact(gpu[0], ref[0], "unaligned target")
-    assert _name(build) == "k1_u8c3_packed_u8"
-
     def with_program(wrap, wrap_out, out):
         o = wrap_out(np.zeros((200, 320, cn), np.float32) if out is None else out, f)
         return [cvgs.resize(u, cvgs.INTER_LINEAR, wrap(src, u), (320, 200)), cvgs.multiply(f, [0.5] * cn), cvgs.write(f, o)]
@@ -132,3 +142,15 @@ def test_x4_is_the_default_for_whole_frames():
     assert _name(build) == "k1_u8c3_packed_u8_x4"
     small, oshape, odt = _chain(src, 3, (64, 128), True, x_off=0, pad=0)
     assert _name(small) == "k1_u8c3_packed_u8"
+    down, oshape, odt = _chain(H.random_u8((2160, 3840, 3), 12), 3, (1920, 1080), True, x_off=0, pad=0)
+    assert _name(down) == "k1_u8c3_packed_u8"  # vertical down-scaling: no source row is shared, the one-pixel kernel is as fast
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_x4_reference_resize_write_size(cn):
+    """tests/resize/test_resize_write.cu:55-56 at its own size: 4K -> 3870 x 2260 (rows of 3870 * cn bytes start on any byte)."""
+    src = H.random_u8((2160, 3840, cn), 40 + cn)
+    build, oshape, odt = _chain(src, cn, (3870, 2260), True, x_off=0, pad=0)
+    gpu, ref = _both(build, oshape, odt)
+    H.assert_bit_exact(gpu[0], ref[0], "4K -> 3870x2260 packed u8c%d" % cn)
+    assert _name(build) == "k1_u8c%d_packed_u8_x4" % cn

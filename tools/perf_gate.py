@@ -5,11 +5,11 @@ Round 2 shipped a 1.4-7x slowdown of one kernel family with every bit-exactness 
 the answer is tests/test_kernel_resources.py (CPU, metadata of the built kernels); this is the measured half: the reference's
 own test chains at the reference's sizes (tools/bench_reference_tests.py), BASELINE's cfg #3 / #4 and the decode-side batches
 (tools/bench_more.py) and the headline (bench.py's clock) are timed and compared with the ceilings -- the best figure a
-round's profile set recorded + 12 % (boxes of the pool differ by 2-5 %).  Exit code 1 and an "over" list when any chain is
+round's profile set recorded + 25 % (boxes of the pool differ: the driver's round-2 box ran cfg #3 at 9.6 us against 8.4 here).  Exit code 1 and an "over" list when any chain is
 slower than its ceiling; chains missing from the table are reported as "new" (regenerate with --write on purpose).
 
   python tools/perf_gate.py                  # run on the GPU box, print a JSON verdict, exit 0 / 1
-  python tools/perf_gate.py --write          # measure and REWRITE the ceilings (measured x 1.12)
+  python tools/perf_gate.py --write          # measure and REWRITE the ceilings (measured x 1.25)
   python tools/perf_gate.py --rows f.jsonl   # gate rows measured elsewhere (JSON lines with test|config and us*)
 bench.py's extras call check() on the rows they measured anyway, so the driver's BENCH line carries the verdict too."""
 import json
@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TABLE = os.path.join(ROOT, "tools", "perf_ceilings.json")
-SLACK = 1.12
+SLACK = 1.25
 
 
 def key_us(row):
@@ -59,6 +59,11 @@ def measure_all():
     torch.cuda.empty_cache()
     torch.cuda.set_stream(torch.cuda.Stream())
     rows += bench_more.run_all(dev, iters=60)
+    torch.cuda.empty_cache()
+    import bench_upscale  # whole-frame resizes into packed u8 (K1's four-pixels-per-lane form and its down-scaling sibling)
+    for src, dst in bench_upscale.CASES:
+        r = bench_upscale.case(dev, 3, src, dst, 100)
+        rows.append({"name": "resize packed " + r["case"], "us": r["us"]})
     torch.cuda.empty_cache()
     # the headline on bench.py's own clock
     import subprocess

@@ -9,15 +9,23 @@
 //
 // This kernel's mapping:
 //  * lane = 4 x-adjacent output pixels, wave = 256 output columns x R consecutive output rows (R is a launch parameter).
-//    The lane's 4 pixels leave as ONE 4*CN-byte store: no shuffle.
+//    The lane's 4 pixels leave as ONE 4*CN-byte store (rows may start on any byte): no shuffle.
 //  * column geometry (x1, weights, window offset) once per lane and pixel, reused for all R rows; the window's byte shift AND
 //    the right-edge duplication (x2 clamped onto x1) are ONE v_perm_b32 selector per dword, computed with the geometry.
 //  * row geometry for all R rows at once: lane j computes row row0 + j, the loop reads it back with v_readlane.
-//  * the unpacked taps of a SOURCE row live in one of two register slots picked by the row's parity; an output row whose
-//    source rows are already in the slots (every second row of a 2x up-scaling) loads and unpacks nothing, and the
-//    interpolation is written once per slot order so that nothing is ever moved between registers.
+//  * the unpacked taps of a SOURCE row live in one of two register slots; consecutive source intervals alternate the slots'
+//    roles (the interpolation is written once per order), so an output row whose source rows are already there (every
+//    second row of a 2x up-scaling) loads and unpacks nothing and nothing is ever moved between registers.
+//  * every source row of the wave's first PRE intervals (PRE = 1, 2, 4 by the rows the wave spans) is requested before
+//    anything is computed: one memory wait per wave, then arithmetic and stores nobody waits for.
 //  * the interpolation runs on pixel PAIRS (v_pk_mul_f32 / v_pk_add_f32): same IEEE operations in the same order as the
 //    oracle (p00*w00 + p10*w10 + p01*w01 + p11*w11, left to right, no FMA), two pixels per instruction.
+// Measured (tools/bench_upscale.py, profiles/r03_*): 1080p -> 4K packed u8c3 23.0 -> 10.8 us, u8c4 23.9 -> 11.0, u8c1 17.5 -> 8.3;
+// 720p -> 1440p 13.8 -> 6.8; the reference's 4K -> 3870 x 2260: 8UC3 30.1 -> 19.8, 8UC1 23.6 -> 15.8, 8UC4 25.7 -> 19.4.
+// What bounds it now: issue (tools/probes/pk_rate_probe.cpp: v_pk_mul_f32 / v_pk_add_f32 retire at 5.7 cycles per
+// instruction per SIMD, conversions at 4.4 - 4.8; 3.4 M VALU + 1.4 M SALU instructions per 4K launch = ~7 us of issue at
+// 4 waves per SIMD) -- a launch without its stores runs 10.3 us against 11.3 with them (profiles/r03_d_*).
+// Vertical DOWN-scaling stays with k1_resize_split: no source row is shared, and it ties or wins there (4K -> 1080p 10.3 us).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -30,7 +38,7 @@ namespace cvgs {
 constexpr int kX4Planes = 8;   // images per launch (blockIdx.y)
 constexpr int kX4Waves = 4;    // waves per workgroup (independent)
 constexpr int kX4Px = 4;       // output pixels per lane
-constexpr int kX4Pre = 4;      // source intervals whose rows a wave requests up front (kX4Pre + 1 source rows)
+constexpr int kX4Pre = 4;      // most source intervals whose rows a wave requests up front (PRE + 1 source rows; PRE = 1, 2, 4)
 
 struct X4Plane { // 32 bytes
     const uint8_t* data;
@@ -157,7 +165,7 @@ __device__ __forceinline__ void x4_row(const X4Slot<CN>& A, const X4Slot<CN>& B,
     }
 }
 
-template <int CN, typename OT>
+template <int CN, typename OT, int PRE>
 __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
     const int z = (int)blockIdx.y;
     const X4Plane P = a.plane[z];
@@ -223,19 +231,19 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
     // y1 never decreases with the output row, so the rows fed from source rows (s, s+1) are the lanes whose y1v == s: one ballot
     auto rows_on = [&](int s) { return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && y1v == s)); };
 
-    // ---- the wave's first kX4Pre source intervals: ALL their rows are requested before anything is computed ----
+    // ---- the wave's first PRE source intervals: ALL their rows are requested before anything is computed ----
     // The wave then waits for memory ONCE; what follows is arithmetic and stores nobody waits for.  (Fetching each new source
     // row when its interval starts cost one load + store-acknowledge round trip per interval: 4K -> 3870 x 2260, one new source
     // row per output row, ran 8 such round trips per wave: 23.7 us.)  Source rows s, s+1 sit in (S0, S1) for the even intervals
     // and in (S1, S0) for the odd ones: one row is unpacked per interval and the slots never trade registers.
     {
         const int s0 = y1_of(0);
-        X4Raw raw[kX4Pre + 1];
+        X4Raw raw[PRE + 1];
 #pragma unroll
-        for (int k = 0; k <= kX4Pre; ++k) raw[k] = x4_load<CN>(col, row_of(min(s0 + k, h1)));
+        for (int k = 0; k <= PRE; ++k) raw[k] = x4_load<CN>(col, row_of(min(s0 + k, h1)));
         x4_unpack<CN>(S0, col, raw[0]);
 #pragma unroll
-        for (int k = 0; k < kX4Pre; ++k) {
+        for (int k = 0; k < PRE; ++k) {
             if (j < nrows) { // wave-uniform
                 const int jn = j + rows_on(s0 + k);
                 if ((k & 1) == 0) {
@@ -335,20 +343,21 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     const uint32_t row_blks = (uint32_t)((r.dst_h + rows_per_wg - 1) / rows_per_wg);
     const dim3 grid(a.col_tiles * row_blks, (unsigned)r.batch), block(64 * kX4Waves);
     hipStream_t s = (hipStream_t)stream;
-    auto go = [&](auto cn_tag, auto ot_tag) {
+    // source intervals requested up front: what the wave's rows span (a wave that needs 2 source rows must not fetch 5)
+    const float spanned = (float)a.rows_per_wave * (fy_max > 0.f ? fy_max : 1.f);
+    const int pre = spanned <= 1.0f ? 1 : (spanned <= 2.0f ? 2 : kX4Pre);
+    auto go = [&](auto cn_tag) {
         constexpr int CN = decltype(cn_tag)::value;
-        using OT = decltype(ot_tag);
-        hipLaunchKernelGGL((k1_packed_x4<CN, OT>), grid, block, 0, s, a);
+        if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, uint8_t, 1>), grid, block, 0, s, a);
+        else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, uint8_t, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k1_packed_x4<CN, uint8_t, kX4Pre>), grid, block, 0, s, a);
     };
-    auto by_cn = [&](auto ot_tag) {
-        switch (r.cn) {
-        case 1: go(std::integral_constant<int, 1>{}, ot_tag); break;
-        case 2: go(std::integral_constant<int, 2>{}, ot_tag); break;
-        case 3: go(std::integral_constant<int, 3>{}, ot_tag); break;
-        default: go(std::integral_constant<int, 4>{}, ot_tag); break;
-        }
-    };
-    by_cn(uint8_t{});
+    switch (r.cn) {
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    case 3: go(std::integral_constant<int, 3>{}); break;
+    default: go(std::integral_constant<int, 4>{}); break;
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }

@@ -103,17 +103,22 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
-    // whole-frame resize -> cast -> packed u8 pixels with nothing in between: four output pixels per lane
-    // (k_k1_x4.hip) once the launch is in the throughput regime.  CVGS_CHAIN_NO_THREAD_FUSION keeps the one-pixel kernel.
-    if (packed && r.depth == CVGS_DEPTH_8U && u8out && n_prog == 0 && !table && !segs &&
-        mirrors.n == 0 && !(chain_flags & CVGS_CHAIN_NO_THREAD_FUSION)) {
+    // whole-frame resize -> cast -> packed pixels of the SOURCE's type with nothing in between (the reference's
+    // tests/resize/test_resize_write.cu chain): several output pixels per lane (k_k1_x4.hip) once the launch is in the
+    // throughput regime.  CVGS_CHAIN_NO_THREAD_FUSION keeps the one-pixel kernel.
+    if (packed && c.write.depth == r.depth && (u8out || same_type_packed) && n_prog == 0 && !table && !segs && mirrors.n == 0 &&
+        !(chain_flags & CVGS_CHAIN_NO_THREAD_FUSION)) {
         const char* x4_env = getenv("CVGS_K1_X4"); // tuning / test hook: 0 = never, 1 = whenever eligible
         const bool force = x4_env && x4_env[0] == '1';
         if (force || (!x4_env && wave_rows >= kX4MinWaveRows)) {
             const int rc = launch_k1_packed_x4(c, inline_planes, n_inline, stream, dry_run, force);
             if (rc != 0) {
-                static const char* names_x4[4] = {"k1_u8c1_packed_u8_x4", "k1_u8c2_packed_u8_x4", "k1_u8c3_packed_u8_x4", "k1_u8c4_packed_u8_x4"};
-                if (info) info->kernel = names_x4[r.cn - 1];
+                static const char* names_x4[4][4] = {
+                    {"k1_u8c1_packed_u8_x4", "k1_u8c2_packed_u8_x4", "k1_u8c3_packed_u8_x4", "k1_u8c4_packed_u8_x4"},
+                    {"k1_u16c1_packed_u16_x2", "", "k1_u16c3_packed_u16_x2", "k1_u16c4_packed_u16_x2"},
+                    {"k1_s16c1_packed_s16_x2", "", "k1_s16c3_packed_s16_x2", "k1_s16c4_packed_s16_x2"},
+                    {"k1_f32c1_packed_f32_x4", "", "", ""}};
+                if (info) info->kernel = names_x4[src][r.cn - 1];
                 return rc;
             }
         }

@@ -1,6 +1,7 @@
-// k_k1_x4.hip -- whole-frame resize into PACKED pixels, four x-adjacent output pixels per lane.
+// k_k1_x4.hip -- whole-frame resize into PACKED pixels of the source's own type, several x-adjacent output pixels per lane.
 //
-// The chain: resize<INTER_LINEAR>(8UCn image) -> convertTo<CV_32F, O> -> write<O>(packed image), O = CV_8UCn --
+// The chain: resize<INTER_LINEAR>(image of type I) -> convertTo<CV_32F, I> -> write<I>(packed image), I = CV_8UCn, CV_16UCn,
+// CV_16SCn or CV_32FC1 (the types the reference sweeps) --
 // the reference's tests/resize/test_resize_write.cu chain (cvGS::resize + cvGS::convertTo + cvGS::write, :110-123) at
 // whole-frame sizes (1080p <-> 4K).  k1_resize_split (lane = ONE output column) is VALU + SALU issue bound there
 // (369 VALU + 218 SALU per 4-row wave on 1080p -> 4K packed u8, 23 us, 0.17 of the HBM roofline): the
@@ -8,10 +9,12 @@
 // shuffle that turns 3-byte pixels into dword stores, per-row address arithmetic.
 //
 // This kernel's mapping:
-//  * lane = 4 x-adjacent output pixels, wave = 256 output columns x R consecutive output rows (R is a launch parameter).
-//    The lane's 4 pixels leave as ONE 4*CN-byte store (rows may start on any byte): no shuffle.
-//  * column geometry (x1, weights, window offset) once per lane and pixel, reused for all R rows; the window's byte shift AND
-//    the right-edge duplication (x2 clamped onto x1) are ONE v_perm_b32 selector per dword, computed with the geometry.
+//  * lane = PX x-adjacent output pixels (4 of a u8 or fp32 image, 2 of a 16-bit one: 4*CN bytes of u8 / 16-bit pixels, 16 of
+//    fp32), wave = 64*PX output columns x R consecutive output rows (R is a launch parameter).  The lane's pixels leave as
+//    ONE store (rows may start on any byte): no shuffle.
+//  * column geometry (x1, weights, window offset) once per lane and pixel, reused for all R rows; for u8 the window's byte
+//    shift AND the right-edge duplication (x2 clamped onto x1) are ONE v_perm_b32 selector per dword, computed with the
+//    geometry; 16-bit windows (16 bytes) take k_taps.hpp's shift + select only in the waves that hold a row's last pixels.
 //  * row geometry for all R rows at once: lane j computes row row0 + j, the loop reads it back with v_readlane.
 //  * the unpacked taps of a SOURCE row live in one of two register slots; consecutive source intervals alternate the slots'
 //    roles (the interpolation is written once per order), so an output row whose source rows are already there (every
@@ -37,7 +40,6 @@ namespace cvgs {
 
 constexpr int kX4Planes = 8;   // images per launch (blockIdx.y)
 constexpr int kX4Waves = 4;    // waves per workgroup (independent)
-constexpr int kX4Px = 4;       // output pixels per lane
 constexpr int kX4Pre = 4;      // most source intervals whose rows a wave requests up front (PRE + 1 source rows; PRE = 1, 2, 4)
 
 struct X4Plane { // 32 bytes
@@ -51,26 +53,36 @@ struct X4Args {
     uint8_t* out;
     int64_t row_pitch, img_pitch; // bytes
     int32_t dst_w, dst_h;
-    uint32_t col_tiles;           // ceil(dst_w / 256)
+    uint32_t col_tiles;           // ceil(dst_w / (64 * PX))
     int32_t rows_per_wave;        // <= 64
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// the unpacked taps of one source row for the lane's 4 output pixels: [pixel pair][channel] x {pixel 2q, pixel 2q+1}
-template <int CN>
+// output pixels per lane and bytes per tap window (both horizontal taps of one pixel) by source kind
+template <int SRC> constexpr int x4_px = (SRC == SRC_U16 || SRC == SRC_S16) ? 2 : 4;
+template <int SRC> constexpr int x4_winb = (SRC == SRC_U16 || SRC == SRC_S16) ? 16 : 8;
+template <int SRC> using x4_elem_t = std::conditional_t<SRC == SRC_U8, uint8_t, std::conditional_t<SRC == SRC_U16, uint16_t, std::conditional_t<SRC == SRC_S16, int16_t, float>>>;
+
+// the unpacked taps of one source row for the lane's output pixels: [pixel pair][channel] x {pixel 2q, pixel 2q+1}
+template <int CN, int PX>
 struct X4Slot {
-    f32x2 t0[2][CN]; // tap x1
-    f32x2 t1[2][CN]; // tap x2 (= x1 at the right edge)
+    f32x2 t0[PX / 2][CN]; // tap x1
+    f32x2 t1[PX / 2][CN]; // tap x2 (= x1 at the right edge)
 };
 
-template <int CN>
+template <int CN, int SRC>
 struct X4Col {
-    f32x2 wxa[2], wxb[2];
-    uint32_t ol[kX4Px], sel_lo[kX4Px], sel_hi[kX4Px];
+    static constexpr int PX = x4_px<SRC>;
+    f32x2 wxa[PX / 2], wxb[PX / 2];
+    uint32_t ol[PX];
+    // u8: the v_perm_b32 selectors of the window's two dwords; 16-bit: the window's shift in bits, fp32: "the window was
+    // clamped back by one pixel" (fix_a), and the right-edge flag (fix_b)
+    uint32_t fix_a[PX], fix_b[PX];
+    bool any_fix; // wave-uniform: some pixel of this wave sits at its row's end (16-bit windows only)
 };
 
-// bytes [CN, 2CN) of the window hold the second tap; at the right edge they are re-pointed at the first one
+// bytes [CN, 2CN) of a u8 window hold the second tap; at the right edge they are re-pointed at the first one
 template <int CN> constexpr uint32_t x4_edge_sub(int dword) {
     uint32_t v = 0;
     for (int k = 0; k < 4; ++k) {
@@ -80,42 +92,69 @@ template <int CN> constexpr uint32_t x4_edge_sub(int dword) {
     return v;
 }
 
-// the lane's four 8-byte tap windows of one source row, as loaded
-struct X4Raw { uint64_t w[kX4Px]; };
+// the lane's tap windows of one source row, as loaded
+template <int SRC> struct X4Raw { uint64_t w[x4_px<SRC>]; };
+template <> struct X4Raw<SRC_U16> { u32x4 w[2]; };
+template <> struct X4Raw<SRC_S16> { u32x4 w[2]; };
 
-template <int CN>
-__device__ __forceinline__ X4Raw x4_load(const X4Col<CN>& col, gptr_u8 row) {
-    X4Raw r;
+template <int CN, int SRC>
+__device__ __forceinline__ X4Raw<SRC> x4_load(const X4Col<CN, SRC>& col, gptr_u8 row) {
+    X4Raw<SRC> r;
 #pragma unroll
-    for (int i = 0; i < kX4Px; ++i) r.w[i] = *(gptr_u64)(row + col.ol[i]);
+    for (int i = 0; i < x4_px<SRC>; ++i) {
+        if constexpr (x4_winb<SRC> == 16) r.w[i] = *(gptr_u32x4)(row + col.ol[i]);
+        else r.w[i] = *(gptr_u64)(row + col.ol[i]);
+    }
     return r;
 }
 
-template <int CN>
-__device__ __forceinline__ void x4_unpack(X4Slot<CN>& s, const X4Col<CN>& col, const X4Raw& r) {
+template <int CN, int SRC>
+__device__ __forceinline__ void x4_unpack(X4Slot<CN, x4_px<SRC>>& s, const X4Col<CN, SRC>& col, const X4Raw<SRC>& r) {
 #pragma unroll
-    for (int i = 0; i < kX4Px; ++i) {
-        const uint32_t wl = (uint32_t)r.w[i], wh = (uint32_t)(r.w[i] >> 32);
-        const uint32_t lo = __builtin_amdgcn_perm(wh, wl, col.sel_lo[i]);
-        [[maybe_unused]] uint32_t hi = 0;
-        if constexpr (2 * CN > 4) hi = __builtin_amdgcn_perm(wh, wl, col.sel_hi[i]);
+    for (int i = 0; i < x4_px<SRC>; ++i) {
+        if constexpr (SRC == SRC_U8) {
+            const uint32_t wl = (uint32_t)r.w[i], wh = (uint32_t)(r.w[i] >> 32);
+            const uint32_t lo = __builtin_amdgcn_perm(wh, wl, col.fix_a[i]);
+            [[maybe_unused]] uint32_t hi = 0;
+            if constexpr (2 * CN > 4) hi = __builtin_amdgcn_perm(wh, wl, col.fix_b[i]);
 #pragma unroll
-        for (int c = 0; c < CN; ++c) {
-            const int b0 = c, b1 = CN + c;
-            const uint32_t e0 = ((b0 < 4 ? lo : hi) >> (8 * (b0 & 3))) & 0xffu;
-            const uint32_t e1 = ((b1 < 4 ? lo : hi) >> (8 * (b1 & 3))) & 0xffu;
-            s.t0[i >> 1][c][i & 1] = (float)e0;
-            s.t1[i >> 1][c][i & 1] = (float)e1;
+            for (int c = 0; c < CN; ++c) {
+                const int b0 = c, b1 = CN + c;
+                const uint32_t e0 = ((b0 < 4 ? lo : hi) >> (8 * (b0 & 3))) & 0xffu;
+                const uint32_t e1 = ((b1 < 4 ? lo : hi) >> (8 * (b1 & 3))) & 0xffu;
+                s.t0[i >> 1][c][i & 1] = (float)e0;
+                s.t1[i >> 1][c][i & 1] = (float)e1;
+            }
+        } else if constexpr (SRC == SRC_F32) {
+            static_assert(SRC != SRC_F32 || CN == 1, "fp32 sources: one channel (the window is the pixel pair)");
+            const float a0 = __builtin_bit_cast(float, (uint32_t)r.w[i]), a1 = __builtin_bit_cast(float, (uint32_t)(r.w[i] >> 32));
+            const float first = col.fix_a[i] ? a1 : a0;
+            s.t0[i >> 1][0][i & 1] = first;
+            s.t1[i >> 1][0][i & 1] = col.fix_b[i] ? first : a1;
+        } else {
+            Win<2> w;
+            w.lo = ((uint64_t)r.w[i].y << 32) | r.w[i].x;
+            w.hi = ((uint64_t)r.w[i].w << 32) | r.w[i].z;
+            float a[4], b[4];
+            if (col.any_fix) unpack_pair<CN, SRC>(shift_win<2>(w, (int)col.fix_a[i]), col.fix_b[i] != 0, a, b); // a row's last pixels
+            else unpack_pair<CN, SRC>(w, false, a, b);
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                s.t0[i >> 1][c][i & 1] = a[c];
+                s.t1[i >> 1][c][i & 1] = b[c];
+            }
         }
     }
 }
 
-template <int CN, typename OT>
-__device__ __forceinline__ void x4_row(const X4Slot<CN>& A, const X4Slot<CN>& B, const X4Col<CN>& col, float wya, float wyb,
-                                       uint8_t* orow, uint32_t x0, int dst_w, bool wave_full) {
-    float v[kX4Px * CN];
+template <int CN, int SRC>
+__device__ __forceinline__ void x4_row(const X4Slot<CN, x4_px<SRC>>& A, const X4Slot<CN, x4_px<SRC>>& B, const X4Col<CN, SRC>& col,
+                                       float wya, float wyb, uint8_t* orow, uint32_t x0, int dst_w, bool wave_full) {
+    constexpr int PX = x4_px<SRC>;
+    using OT = x4_elem_t<SRC>;
+    float v[PX * CN];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < PX / 2; ++q) {
         const f32x2 w00 = col.wxa[q] * wya;
         const f32x2 w10 = col.wxb[q] * wya;
         const f32x2 w01 = col.wxa[q] * wyb;
@@ -131,42 +170,64 @@ __device__ __forceinline__ void x4_row(const X4Slot<CN>& A, const X4Slot<CN>& B,
         }
     }
     typedef __attribute__((address_space(1))) uint8_t* gout;
-    static_assert(std::is_same_v<OT, uint8_t>, "packed u8 targets");
-    uint32_t word[CN];
+    // the lane's PX pixels as dwords: the chain's trailing SaturateCast is the conversion (k_common.hpp: sat_u8_insert,
+    // sat_u16_bits, sat_s16_bits -- the instructions tools/sat_probe.cpp checked over all 2^32 inputs); fp32 as it is
+    constexpr int NW = PX * CN * (int)sizeof(OT) / 4;
+    uint32_t word[NW];
+    if constexpr (SRC == SRC_U8) {
 #pragma unroll
-    for (int k = 0; k < CN; ++k) word[k] = 0;
+        for (int k = 0; k < NW; ++k) word[k] = 0;
 #pragma unroll
-    for (int b = 0; b < kX4Px * CN; ++b) word[b >> 2] = sat_u8_insert(v[b], (uint32_t)(b & 3), word[b >> 2]);
-    const gout p = (gout)pin_uniform(orow) + x0 * (uint32_t)CN;
+        for (int b = 0; b < PX * CN; ++b) word[b >> 2] = sat_u8_insert(v[b], (uint32_t)(b & 3), word[b >> 2]);
+    } else if constexpr (SRC == SRC_F32) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) word[k] = __builtin_bit_cast(uint32_t, v[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const uint32_t e0 = SRC == SRC_U16 ? sat_u16_bits(v[2 * k]) : sat_s16_bits(v[2 * k]);
+            const uint32_t e1 = SRC == SRC_U16 ? sat_u16_bits(v[2 * k + 1]) : sat_s16_bits(v[2 * k + 1]);
+            word[k] = e0 | (e1 << 16);
+        }
+    }
+    const gout p = (gout)pin_uniform(orow) + x0 * (uint32_t)(CN * sizeof(OT));
     auto store_all = [&]() {
         // byte-aligned types: rows of a 3870-pixel u8c3 image (the reference's tests/resize/test_resize_write.cu size) start on
         // any byte; the hardware takes the unaligned multi-dword store
-        typedef uint32_t vw_a4 __attribute__((ext_vector_type(CN)));
+        typedef uint32_t vw_a4 __attribute__((ext_vector_type(NW)));
         typedef vw_a4 vw __attribute__((aligned(1)));
         typedef __attribute__((address_space(1))) vw* gvw;
         typedef uint32_t u32a1 __attribute__((aligned(1)));
-        if constexpr (CN == 1) {
+        if constexpr (NW == 1) {
             __builtin_nontemporal_store(word[0], (__attribute__((address_space(1))) u32a1*)p);
         } else {
             vw q;
 #pragma unroll
-            for (int k = 0; k < CN; ++k) q[k] = word[k];
+            for (int k = 0; k < NW; ++k) q[k] = word[k];
             __builtin_nontemporal_store(q, (gvw)p);
         }
     };
     if (wave_full) { // scalar: no lane of this column tile hangs over the row's end
         store_all();
-    } else if ((int)x0 + kX4Px - 1 < dst_w) {
+    } else if ((int)x0 + PX - 1 < dst_w) {
         store_all();
-    } else {
+    } else { // the ragged lane: element by element
+        typedef std::conditional_t<sizeof(OT) == 1, uint8_t, std::conditional_t<sizeof(OT) == 2, uint16_t, uint32_t>> ET;
+        typedef ET ET_a1 __attribute__((aligned(1)));
+        typedef __attribute__((address_space(1))) ET_a1* get;
+        constexpr int EPW = 4 / (int)sizeof(OT); // elements per dword
 #pragma unroll
-        for (int b = 0; b < kX4Px * CN; ++b)
-            if ((int)x0 + b / CN < dst_w) __builtin_nontemporal_store((uint8_t)(word[b >> 2] >> (8 * (b & 3))), p + b);
+        for (int e = 0; e < PX * CN; ++e)
+            if ((int)x0 + e / CN < dst_w)
+                __builtin_nontemporal_store((ET)(word[e / EPW] >> (8 * (int)sizeof(OT) * (e % EPW))), (get)p + e);
     }
 }
 
-template <int CN, typename OT, int PRE>
+template <int CN, int SRC, int PRE>
 __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
+    constexpr int PX = x4_px<SRC>;
+    constexpr int EB = elem_bytes<SRC>;
+    constexpr int WINB = x4_winb<SRC>;
     const int z = (int)blockIdx.y;
     const X4Plane P = a.plane[z];
     const int dst_w = a.dst_w, dst_h = a.dst_h, R = a.rows_per_wave;
@@ -181,13 +242,14 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
     const int row0 = ((int)row_blk * kX4Waves + wave) * R;
     if (row0 >= dst_h) return;
     const int nrows = min(R, dst_h - row0);
-    const uint32_t x0 = (col_tile * 64u + (uint32_t)lane) * kX4Px;
+    const uint32_t x0 = (col_tile * 64u + (uint32_t)lane) * PX;
 
     // ---- column geometry: the oracle's expressions per pixel (sx = x * fx in fp32, x1 = floor, the two weights) ----
-    X4Col<CN> col;
-    const int row_bytes = P.w * CN;
+    X4Col<CN, SRC> col;
+    const int row_bytes = P.w * CN * EB;
+    bool fix = false;
 #pragma unroll
-    for (int i = 0; i < kX4Px; ++i) {
+    for (int i = 0; i < PX; ++i) {
         const int x = min((int)x0 + i, dst_w - 1); // lanes / pixels past the row compute a valid pixel and store nothing
         const float sx = (float)x * P.fx;
         const int x1 = (int)floorf(sx);
@@ -195,13 +257,20 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
         col.wxa[i >> 1][i & 1] = (float)x2 - sx;
         col.wxb[i >> 1][i & 1] = sx - (float)x1;
         const bool edge = x2 > P.w - 1;
-        const int o = x1 * CN;
-        const int ol = min(o, row_bytes - 8);
+        const int o = x1 * CN * EB;
+        const int ol = min(o, row_bytes - WINB);
         const uint32_t sh = (uint32_t)(o - ol);
         col.ol[i] = (uint32_t)ol;
-        col.sel_lo[i] = 0x03020100u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(0) : 0u);
-        col.sel_hi[i] = 0x07060504u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(1) : 0u);
+        if constexpr (SRC == SRC_U8) {
+            col.fix_a[i] = 0x03020100u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(0) : 0u);
+            col.fix_b[i] = 0x07060504u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(1) : 0u);
+        } else {
+            col.fix_a[i] = SRC == SRC_F32 ? (uint32_t)(sh != 0) : sh * 8u;
+            col.fix_b[i] = (uint32_t)edge;
+            fix = fix || sh != 0 || edge;
+        }
     }
+    col.any_fix = __builtin_amdgcn_ballot_w64(fix) != 0;
 
     // ---- row geometry: lane j holds output row row0 + j ----
     int y1v;
@@ -216,14 +285,14 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
 
     const gptr_u8 src = (gptr_u8)P.data;
     uint8_t* const out = a.out + (int64_t)z * a.img_pitch + (int64_t)row0 * a.row_pitch;
-    X4Slot<CN> S0, S1;
+    X4Slot<CN, PX> S0, S1;
     auto row_of = [&](int r) { return pin_uniform(src + (size_t)r * (size_t)P.step); };
     auto y1_of = [&](int j) { return __builtin_amdgcn_readlane(y1v, j); };
-    const bool wave_full = (int)(col_tile + 1) * 64 * kX4Px <= dst_w;
-    auto emit = [&](const X4Slot<CN>& A, const X4Slot<CN>& B, int j) {
+    const bool wave_full = (int)(col_tile + 1) * 64 * PX <= dst_w;
+    auto emit = [&](const X4Slot<CN, PX>& A, const X4Slot<CN, PX>& B, int j) {
         const float wya = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyav), j));
         const float wyb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wybv), j));
-        x4_row<CN, OT>(A, B, col, wya, wyb, out + (int64_t)j * a.row_pitch, x0, dst_w, wave_full);
+        x4_row<CN, SRC>(A, B, col, wya, wyb, out + (int64_t)j * a.row_pitch, x0, dst_w, wave_full);
     };
     int j = 0;
     const int h1 = P.h - 1;
@@ -238,20 +307,20 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
     // and in (S1, S0) for the odd ones: one row is unpacked per interval and the slots never trade registers.
     {
         const int s0 = y1_of(0);
-        X4Raw raw[PRE + 1];
+        X4Raw<SRC> raw[PRE + 1];
 #pragma unroll
-        for (int k = 0; k <= PRE; ++k) raw[k] = x4_load<CN>(col, row_of(min(s0 + k, h1)));
-        x4_unpack<CN>(S0, col, raw[0]);
+        for (int k = 0; k <= PRE; ++k) raw[k] = x4_load<CN, SRC>(col, row_of(min(s0 + k, h1)));
+        x4_unpack<CN, SRC>(S0, col, raw[0]);
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
             if (j < nrows) { // wave-uniform
                 const int jn = j + rows_on(s0 + k);
                 if ((k & 1) == 0) {
-                    x4_unpack<CN>(S1, col, raw[k + 1]);
+                    x4_unpack<CN, SRC>(S1, col, raw[k + 1]);
 #pragma unroll 1
                     for (; j < jn; ++j) emit(S0, S1, j);
                 } else {
-                    x4_unpack<CN>(S0, col, raw[k + 1]);
+                    x4_unpack<CN, SRC>(S0, col, raw[k + 1]);
 #pragma unroll 1
                     for (; j < jn; ++j) emit(S1, S0, j);
                 }
@@ -265,23 +334,23 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
 #pragma unroll 1
     while (j < nrows) {
         int s = y1_of(j);
-        const X4Raw first = x4_load<CN>(col, row_of(s));
-        X4Raw next = x4_load<CN>(col, row_of(min(s + 1, h1)));
-        x4_unpack<CN>(S0, col, first);
+        const X4Raw<SRC> first = x4_load<CN, SRC>(col, row_of(s));
+        X4Raw<SRC> next = x4_load<CN, SRC>(col, row_of(min(s + 1, h1)));
+        x4_unpack<CN, SRC>(S0, col, first);
 #pragma unroll 1
         for (;;) {
-            x4_unpack<CN>(S1, col, next);
+            x4_unpack<CN, SRC>(S1, col, next);
             int jn = j + rows_on(s);
             bool more = jn < nrows && y1_of(jn) == s + 1;
-            if (more) next = x4_load<CN>(col, row_of(min(s + 2, h1)));
+            if (more) next = x4_load<CN, SRC>(col, row_of(min(s + 2, h1)));
 #pragma unroll 1
             for (; j < jn; ++j) emit(S0, S1, j);
             if (!more) break;
             ++s;
-            x4_unpack<CN>(S0, col, next);
+            x4_unpack<CN, SRC>(S0, col, next);
             jn = j + rows_on(s);
             more = jn < nrows && y1_of(jn) == s + 1;
-            if (more) next = x4_load<CN>(col, row_of(min(s + 2, h1)));
+            if (more) next = x4_load<CN, SRC>(col, row_of(min(s + 2, h1)));
 #pragma unroll 1
             for (; j < jn; ++j) emit(S1, S0, j);
             if (!more) break;
@@ -290,21 +359,33 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
     }
 }
 
-// Host side.  Takes the chain when every image of the batch covers its whole target (no aspect-ratio padding, no unused
-// planes), the source rows hold at least one 8-byte window and -- unless `force`d
-// (CVGS_K1_X4=1: tests) -- no image is scaled down vertically.
+// Host side.  Takes the chain when the target holds packed pixels of the SOURCE's type (8U / 16U / 16S with 1, 3 or 4 channels --
+// 8U also 2 --, 32F with one), every image of the batch covers its whole target (no aspect-ratio padding, no unused planes),
+// the source rows hold at least one tap window and -- unless `force`d (CVGS_K1_X4=1: tests) -- no image is scaled down vertically.
 // Returns 1 launched / 0 not eligible / < 0 error (as launch_k1).
 int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_planes, void* stream, bool dry_run, bool force) {
     const ReadArgs& r = c.read;
     const WriteArgs& w = c.write;
-    if (r.depth != CVGS_DEPTH_8U || r.cn < 1 || r.cn > 4 || r.table || w.data2 || w.table) return 0;
+    if (r.cn < 1 || r.cn > 4 || r.table || w.data2 || w.table) return 0;
     if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
-    // packed fp32 targets stay with the one-pixel kernel: its per-pixel 12 / 16-byte stores already run the 4K output at
-    // 4.6 TB/s, while a lane that owns 4 pixels writes 48-byte strides (measured: 1080p -> 4K 49 us against 22.8)
-    if (w.depth != CVGS_DEPTH_8U) return 0;
-    if (w.cn != r.cn || r.batch < 1 || r.batch > kX4Planes || r.used != r.batch || n_planes != r.batch) return 0;
-    if (r.dst_w < 4 || r.dst_h < 1) return 0;
-    const int64_t px_bytes = w.cn;
+    // packed fp32 pixels of a u8 source stay with the one-pixel kernel: its per-pixel 12 / 16-byte stores already run the 4K
+    // output at 4.6 TB/s, while a lane that owns 4 three-channel fp32 pixels writes 48-byte strides (measured: 1080p -> 4K 49 us against 22.8)
+    if (w.depth != r.depth || w.cn != r.cn) return 0;
+    int src;
+    switch (r.depth) {
+    case CVGS_DEPTH_8U: src = SRC_U8; break;
+    case CVGS_DEPTH_16U: src = SRC_U16; break;
+    case CVGS_DEPTH_16S: src = SRC_S16; break;
+    case CVGS_DEPTH_32F: src = SRC_F32; break;
+    default: return 0;
+    }
+    if (src != SRC_U8 && r.cn == 2) return 0;
+    if (src == SRC_F32 && r.cn != 1) return 0;
+    const int px = (src == SRC_U16 || src == SRC_S16) ? 2 : 4;
+    const int eb = src == SRC_U8 ? 1 : (src == SRC_F32 ? 4 : 2), winb = px == 2 ? 16 : 8;
+    if (r.batch < 1 || r.batch > kX4Planes || r.used != r.batch || n_planes != r.batch) return 0;
+    if (r.dst_w < px || r.dst_h < 1) return 0;
+    const int64_t px_bytes = (int64_t)w.cn * eb;
     const int64_t row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * px_bytes;
     const int64_t img_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : w.img_stride * px_bytes;
     X4Args a;
@@ -312,7 +393,7 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
         const PlaneParams& p = planes[i < n_planes ? i : 0];
         if (i < n_planes) {
             if (p.x1 != 0 || p.y1 != 0 || p.x2 != r.dst_w - 1 || p.y2 != r.dst_h - 1) return 0;
-            if ((int64_t)p.w * r.cn < 8 || p.h < 1) return 0;
+            if ((int64_t)p.w * r.cn * eb < winb || p.h < 1) return 0;
             // the kernel's gain is the source row shared by consecutive output rows: vertical up-scaling (or 1:1).  Down-scaling
             // launches tie with the one-pixel kernel or lose to it (4K -> 1080p 9.9 - 12 us against 10.3), so they stay there.
             if (!force && !(p.fy <= 1.0f)) return 0;
@@ -325,7 +406,7 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     a.img_pitch = img_pitch;
     a.dst_w = r.dst_w;
     a.dst_h = r.dst_h;
-    a.col_tiles = (uint32_t)((r.dst_w + 64 * kX4Px - 1) / (64 * kX4Px));
+    a.col_tiles = (uint32_t)((r.dst_w + 64 * px - 1) / (64 * px));
     // rows per wave: enough waves to fill the chip (~4 per SIMD) before the column geometry is amortised over more rows
     // (tools/bench_upscale.py: 4K output 8 rows 10.7 us / 4 rows 14.2; 1440p 4 rows 7.0 / 8 rows 9.5; 720p 2 rows 4.0 / 8 rows 5.6),
     // and no more rows than the kX4Pre source intervals requested up front feed (4K -> 3870 x 2260, fy 0.956: 4 rows 20.4 us / 8 rows 22.8)
@@ -346,18 +427,31 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     // source intervals requested up front: what the wave's rows span (a wave that needs 2 source rows must not fetch 5)
     const float spanned = (float)a.rows_per_wave * (fy_max > 0.f ? fy_max : 1.f);
     const int pre = spanned <= 1.0f ? 1 : (spanned <= 2.0f ? 2 : kX4Pre);
-    auto go = [&](auto cn_tag) {
-        constexpr int CN = decltype(cn_tag)::value;
-        if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, uint8_t, 1>), grid, block, 0, s, a);
-        else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, uint8_t, 2>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k1_packed_x4<CN, uint8_t, kX4Pre>), grid, block, 0, s, a);
+    auto go = [&](auto cn_tag, auto src_tag) {
+        constexpr int CN = decltype(cn_tag)::value, SRC = decltype(src_tag)::value;
+        if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 1>), grid, block, 0, s, a);
+        else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k1_packed_x4<CN, SRC, kX4Pre>), grid, block, 0, s, a);
     };
-    switch (r.cn) {
-    case 1: go(std::integral_constant<int, 1>{}); break;
-    case 2: go(std::integral_constant<int, 2>{}); break;
-    case 3: go(std::integral_constant<int, 3>{}); break;
-    default: go(std::integral_constant<int, 4>{}); break;
-    }
+    auto by_cn = [&](auto src_tag) {
+        constexpr int SRC = decltype(src_tag)::value;
+        if constexpr (SRC == SRC_F32) {
+            go(std::integral_constant<int, 1>{}, src_tag);
+        } else {
+            switch (r.cn) {
+            case 1: go(std::integral_constant<int, 1>{}, src_tag); break;
+            case 2:
+                if constexpr (SRC == SRC_U8) go(std::integral_constant<int, 2>{}, src_tag);
+                break;
+            case 3: go(std::integral_constant<int, 3>{}, src_tag); break;
+            default: go(std::integral_constant<int, 4>{}, src_tag); break;
+            }
+        }
+    };
+    if (src == SRC_U8) by_cn(std::integral_constant<int, SRC_U8>{});
+    else if (src == SRC_U16) by_cn(std::integral_constant<int, SRC_U16>{});
+    else if (src == SRC_S16) by_cn(std::integral_constant<int, SRC_S16>{});
+    else by_cn(std::integral_constant<int, SRC_F32>{});
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }

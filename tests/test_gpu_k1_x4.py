@@ -62,6 +62,65 @@ def test_x4_matches_the_oracle(forced, shape, cn, to_u8=True):
     H.assert_bit_exact(one[0], gpu[0], "the one-pixel-per-lane kernel agrees")
 
 
+TYPED = [("16U", 1), ("16U", 3), ("16U", 4), ("16S", 1), ("16S", 3), ("16S", 4), ("32F", 1)]
+
+
+def _typed_chain(src, depth, cn, dst, x_off=3, pad=6):
+    from tests import kat_runner as K
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    np_dt = K.NP_DEPTH[depth]
+    pitch_w = dst[0] + x_off + pad
+
+    def build(wrap, wrap_out, out):
+        o = wrap_out(np.zeros((dst[1], pitch_w, cn), np_dt) if out is None else out, st)
+        ops = [cvgs.resize(st, cvgs.INTER_LINEAR, wrap(src, st), dst)]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(f, st))
+        return ops + [cvgs.write(st, o.roi(x_off, 0, dst[0], dst[1]))]
+
+    return build, (dst[1], pitch_w, cn), np_dt
+
+
+def _typed_name(depth, cn):
+    t = depth[-1].lower() + depth[:-1]
+    return "k1_%sc%d_packed_%s_x%d" % (t, cn, t, 4 if depth == "32F" else 2)
+
+
+@pytest.mark.parametrize("depth,cn", TYPED)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_x4_16_bit_and_float_images(forced, shape, depth, cn):
+    """the reference's resize_write sweep (tests/resize/test_resize_write.cu:110-123: CV_16U / CV_16S C1, C3, C4 and CV_32FC1):
+    two pixels per lane for 16-bit images (16-byte tap windows), four for CV_32FC1."""
+    from tests.test_gpu_chains import _random_src
+    (sh, sw), dst = shape
+    eb = 4 if depth == "32F" else 2
+    if sw * cn * eb < (8 if depth == "32F" else 16):
+        pytest.skip("rows narrower than one tap window stay with the one-pixel kernel")
+    src = _random_src((sh, sw, cn), depth, 700 + cn + sh)
+    if depth == "32F":
+        src = (src * 50.0).astype(np.float32)
+    build, oshape, odt = _typed_chain(src, depth, cn, dst)
+    gpu, ref = _both(build, oshape, odt)
+    H.assert_bit_exact(gpu[0], ref[0], "resize -> packed %sC%d" % (depth, cn))
+    assert _name(build) == _typed_name(depth, cn), _name(build)
+    one, _ = _both(build, oshape, odt, flags=capi.CHAIN_NO_THREAD_FUSION)
+    H.assert_bit_exact(one[0], gpu[0], "the one-pixel-per-lane kernel agrees")
+
+
+@pytest.mark.parametrize("depth,cn", [("16U", 3), ("16S", 1), ("32F", 1)])
+def test_x4_reference_resize_write_size_typed(depth, cn):
+    """4K -> 3870 x 2260 on the 16-bit / float types of the reference's sweep, no environment hook."""
+    from tests.test_gpu_chains import _random_src
+    assert "CVGS_K1_X4" not in os.environ
+    src = _random_src((2160, 3840, cn), depth, 60 + cn)
+    if depth == "32F":
+        src = (src * 50.0).astype(np.float32)
+    build, oshape, odt = _typed_chain(src, depth, cn, (3870, 2260), x_off=0, pad=0)
+    gpu, ref = _both(build, oshape, odt)
+    H.assert_bit_exact(gpu[0], ref[0], "4K -> 3870x2260 packed %sC%d" % (depth, cn))
+    assert _name(build) == _typed_name(depth, cn)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_x4_random_shapes(forced, seed):
     """15 random (source, target, channels) shapes per seed: any mix of up- and down-scaling, ragged widths, 1-row sources."""

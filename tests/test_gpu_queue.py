@@ -98,7 +98,8 @@ def test_queue_server_retires_and_restarts(oracle, torch_dev):
             H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, 12, (64, 128), 3), "round %d" % rnd)
             time.sleep(0.01)  # far beyond idle_us: the server has retired, the next submit launches a new one
         st = q.stats()
-        assert st["server_launches"] == 4 and st["error"] == 0, st
+        # one launch per round; a host thread descheduled for > idle_us between the launch and its tail write costs one more
+        assert 4 <= st["server_launches"] <= 8 and st["error"] == 0, st
     finally:
         q.destroy()
 

@@ -16,8 +16,11 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra > $OUT/bench_unprofile
 timeout -k 5 300 $RP --stats -d $RAW/trace -o t -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extra > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 $SUM kernels $RAW/trace/t_kernel_trace.csv > $OUT/bench_trace_kernels.txt 2>&1
 $SUM calls $RAW/trace/t_kernel_trace.csv k1q_server > $OUT/bench_trace_server_calls.txt 2>&1
+# HBM counters: rocprofv3 --pmc segfaults inside bench.py on this image (with and without the stream events, staged or direct
+# slots) and works on tools/queue_ab.py, which drives the same server with the same batches: one batch per server call
+# (--retire-between), so every k1q_server row of the counter file is ONE 50-crop batch.
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 300 $RP --pmc $C -d $RAW/pmc_$C -o p -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extra --no-queue-events > $OUT/bench_pmc_$C.json 2>/dev/null
+  timeout -k 5 300 $RP --pmc $C -d $RAW/pmc_$C -o p -- python tools/queue_ab.py --batches 1 --replays 40 --retire-between > $OUT/queue_ab_pmc_$C.txt 2>/dev/null
   $SUM pmccalls $RAW/pmc_$C/p_counter_collection.csv k1q_server > $OUT/pmc_${C}_server_calls.txt 2>&1
 done
 ls -la $OUT

@@ -354,6 +354,19 @@ __device__ __forceinline__ void yuv_to_rgb(float Y, float U, float V, const YuvK
     p.v[3] = k.amax;
 }
 
+// one tap of the fast NV12 resize kernels (K4, k_nv12.hip; the queue's NV12 worker, k_queue.hip): yuv_to_rgb with the channel
+// count and the range known at compile time (full range: (Y - 0) * 1 is Y itself, bit for bit, so the two instructions are
+// dropped; the alpha lane only exists for CN 4)
+template <int CN, bool FULL>
+__device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k, float* t) {
+    const float cb = U - k.csub, cr = V - k.csub;
+    const float yv = FULL ? Y : (Y - k.ysub) * k.yscale;
+    t[0] = yv + k.rv * cr;
+    t[1] = (yv + k.gu * cb) + k.gv * cr;
+    t[2] = yv + k.bu * cb;
+    if constexpr (CN == 4) t[3] = k.amax;
+}
+
 __device__ __forceinline__ void nv12_px(const PlaneParams& P, int x, int y, const YuvK& k, Px& p) {
     float Y, U, V;
     if (k.layout == CVGS_YUV_P010) { // NV12's geometry, 16-bit samples, 10-bit code in the high bits

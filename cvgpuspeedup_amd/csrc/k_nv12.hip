@@ -47,19 +47,8 @@ constexpr int kK4Waves = CVGS_K4_WPB;
 
 using N12SwapMulSubDiv = ProgSwapMulSubDiv; // the compile-time program of k_taps.hpp (incl. the division by the uniform divisor)
 
-// RPW output rows per wave (the launcher uses 1, see launch_n12); CN output channels (3, or 4 with alpha).
-// one tap: the conversion of k_common.hpp's yuv_to_rgb, with the channel count and the range known at compile time (full
-// range: (Y - 0) * 1 is Y itself, bit for bit, so the two instructions are dropped; the alpha lane only exists for CN 4)
-template <int CN, bool FULL>
-__device__ __forceinline__ void k4_tap(float Y, float U, float V, const YuvK& k, float* t) {
-    const float cb = U - k.csub, cr = V - k.csub;
-    const float yv = FULL ? Y : (Y - k.ysub) * k.yscale;
-    t[0] = yv + k.rv * cr;
-    t[1] = (yv + k.gu * cb) + k.gv * cr;
-    t[2] = yv + k.bu * cb;
-    if constexpr (CN == 4) t[3] = k.amax;
-}
-
+// RPW output rows per wave (the launcher uses 1, see launch_n12); CN output channels (3, or 4 with alpha).  One tap's conversion:
+// k4_tap (k_common.hpp), shared with the descriptor queue's NV12 worker (k_queue.hip).
 // S16: P010 -- the same geometry with 16-bit samples (10-bit code = sample >> 6): the two luma taps are ONE 4-byte load, the
 // two chroma pairs ONE 8-byte load.
 // WIN: the target may hold an aspect-ratio window (letterboxed detector inputs: PRESERVE_AR*) and default-value planes

@@ -28,6 +28,10 @@
 // (MI355X_MICROARCH.md "stores of each flavour").  Tap loads are sc1 too: the server outlives kernel boundaries, so its
 // L1 / L2 never see the invalidate a kernel start performs; agent-coherent loads never serve a stale copy of a source buffer
 // the caller has rewritten between two submits (tests/test_gpu_queue.py rewrites one).
+//
+// Two kinds of batches, one server instantiation each (QK_*; a queue's first submit decides): crops of 8UC3 / 8UC4 frames
+// (k1q_rows: K1's arithmetic -- the headline) and crops of NV12 / NV21 decoder surfaces (k4q_rows: K4's arithmetic -- BASELINE
+// cfg #3 and the decode-side 50-crop batch: 8.4 -> 7.4-7.6 us and 4.7 -> 3.5 us per frame, tools/bench_more.py).
 #include <immintrin.h>
 #include <setjmp.h>
 #include <signal.h>
@@ -64,12 +68,18 @@ struct QParams {
     int64_t img_stride, ch_stride; // output elements
     uint64_t out, out_bytes;
     uint64_t arrive_target;        // value of the slot's TOP arrival counter when the batch's last sub-counter has filled
-    uint32_t pad[18];
+    uint32_t kind;                 // QK_*: what the planes are
+    uint32_t yuv_range, yuv_primaries, yuv_vu; // QK_NV12: cvgs_yuv_range / cvgs_yuv_primaries, V-before-U (NV21)
+    uint32_t pad[14];
 };
 static_assert(sizeof(QParams) == 256, "QParams is one wave-wide dword load");
 enum { QD_STAMP = 0, QD_TASK_BASE = 2, QD_N_TASKS = 4, QD_TPP = 5, QD_COL_TILES = 6, QD_N_PLANES = 7, QD_USED = 8, QD_DST_W = 9, QD_DST_H = 10,
        QD_OUT_W = 11, QD_CN = 12, QD_SWAP = 13, QD_FAST_DIV = 14, QD_ROWS_PER_TASK = 15, QD_MUL = 16, QD_SUB = 20, QD_DIV = 24, QD_RDIV = 28, QD_BG = 32,
-       QD_IMG_STRIDE = 36, QD_CH_STRIDE = 38, QD_OUT = 40, QD_OUT_BYTES = 42, QD_ARRIVE_TARGET = 44 };
+       QD_IMG_STRIDE = 36, QD_CH_STRIDE = 38, QD_OUT = 40, QD_OUT_BYTES = 42, QD_ARRIVE_TARGET = 44, QD_KIND = 46, QD_YUV_RANGE = 47,
+       QD_YUV_PRIM = 48, QD_YUV_VU = 49 };
+// What a queue serves -- latched by its first submit; each kind has its own server instantiation (the 8-bit-pixel worker is the
+// tuned headline path and carries nothing of the other's code or registers).
+enum { QK_PIXELS = 0 /* 8UC3 / 8UC4 crops (K1's shape) */, QK_NV12 = 1 /* crops of NV12 / NV21 decoder surfaces (K4's shape) */ };
 
 // The batch index: one 32-byte entry per ring slot, rewritten by the host while workers may be looking: every 8-byte word is
 // written atomically, and `check` ties the four words together (a torn entry is simply not a candidate).
@@ -159,6 +169,7 @@ struct QTask { // everything a wave needs for its 4 rows, wave-uniform
     int64_t img_stride, ch_stride;
     uint8_t* out;
     uint32_t out_bytes;
+    int32_t yuv_range, yuv_primaries, yuv_vu; // QK_NV12 only
 };
 
 // One wave's share of a task: rows row0..row0+3 of plane z, columns col_tile*64 + lane.  K1's arithmetic (k_k1_impl.hpp:
@@ -300,6 +311,184 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
     store_rows(outv);
 }
 
+// The NV12 worker's share of a task: rows row0..row0+3 of plane z, columns col_tile*64 + lane of a crop of an NV12 / NV21 decoder
+// surface.  K4's arithmetic (k_nv12.hip: same geometry, the two luma taps of a row in ONE 2-byte load, the two chroma pairs in ONE
+// 4-byte load, the per-tap YCbCr -> RGB conversion k4_tap, the same fp32 expression order and program stages) -- bit-identical results.
+typedef uint16_t q_u16_unaligned __attribute__((aligned(1)));
+typedef uint32_t q_u32_unaligned __attribute__((aligned(1)));
+template <int LD>
+__device__ __forceinline__ uint32_t q_load_u16(gptr_u8 p) {
+    typedef __attribute__((address_space(1))) uint16_t* g_u16;
+    if constexpr (LD == 0) return *(const __attribute__((address_space(1))) q_u16_unaligned*)p;
+    else return __hip_atomic_load((g_u16)(__attribute__((address_space(1))) uint8_t*)p, Q_AGENT);
+}
+template <int LD>
+__device__ __forceinline__ uint32_t q_load_u32(gptr_u8 p) {
+    if constexpr (LD == 0) return *(const __attribute__((address_space(1))) q_u32_unaligned*)p;
+    else return __hip_atomic_load((g_u32)(__attribute__((address_space(1))) uint8_t*)p, Q_AGENT);
+}
+
+template <int LD, int ST>
+__device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, int row0, int lane) {
+    constexpr int CN = 3;
+    const PlaneParams& P = t.P;
+    const int dst_w = t.dst_w, dst_h = t.dst_h, W = t.out_w;
+    const int x = col_tile * 64 + lane;
+    if (row0 >= dst_h) return; // wave-uniform
+    const bool live = x < dst_w;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(t.out, 0, (int)t.out_bytes, 0x00020000);
+    const uint32_t plane_off = (uint32_t)((int64_t)z * t.img_stride * 4);
+    const uint32_t ch_bytes = (uint32_t)(t.ch_stride * 4);
+    ProgArgs prog;
+    prog.fast_div = t.fast_div;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        prog.operand[0][c] = t.mul[c];
+        prog.operand[1][c] = t.sub[c];
+        prog.operand[2][c] = t.div[c];
+        prog.rdiv[c] = t.rdiv[c];
+    }
+    auto run_prog = [&](Px& p) {
+        int depth = CVGS_DEPTH_32F, cn = CN;
+        if (t.swap) { // wave-uniform
+            const float s = p.v[0];
+            p.v[0] = p.v[2];
+            p.v[2] = s;
+        }
+        ProgMulSubDiv::run(prog, p, depth, cn);
+    };
+    auto store_rows = [&](const float (&v)[kQRowsPerWave][4]) { // as k1q_rows
+        const bool full = col_tile * 64 + 63 < dst_w;
+        if (ST == 2 && full) {
+            const int i = lane & 3, q = lane >> 2;
+            const bool row_ok = row0 + i < dst_h;
+            const uint32_t off = plane_off + (uint32_t)(((row0 + i) * W + col_tile * 64 + q * 4) * 4);
+#pragma unroll
+            for (int k = 0; k < CN; ++k) {
+                const float r[4] = {v[0][k], v[1][k], v[2][k], v[3][k]};
+                float o[4];
+                q_quad_transpose(r, o, lane);
+                typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+                const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kQRowsPerWave; ++j) {
+                if (row0 + j < dst_h && live) {
+                    const uint32_t off = plane_off + (uint32_t)(((row0 + j) * W + x) * 4);
+#pragma unroll
+                    for (int k = 0; k < CN; ++k)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                }
+            }
+        }
+    };
+
+    const bool whole = z < t.used && ((P.x1 | P.y1 | (P.x2 ^ (dst_w - 1)) | (P.y2 ^ (dst_h - 1))) == 0);
+    Px bgp;
+    bgp.v[0] = bgp.v[1] = bgp.v[2] = bgp.v[3] = 0.f;
+    if (!whole) { // the background value through the whole chain: planes >= usedPlanes and letterbox padding
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bgp.v[k] = k < CN ? t.bg[k] : 0.f;
+        run_prog(bgp);
+        if (z >= t.used) {
+            float v[kQRowsPerWave][4];
+#pragma unroll
+            for (int j = 0; j < kQRowsPerWave; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[j][k] = bgp.v[k];
+            store_rows(v);
+            return;
+        }
+    }
+    const YuvK yk = yuv_matrix(t.yuv_range, t.yuv_primaries, CVGS_YUV_NV12);
+    // ---- per-lane column geometry (k4_nv12_resize's) ----
+    const int xc = live ? x : dst_w - 1;
+    const bool in_x = xc >= P.x1 && xc <= P.x2;
+    const int xr = in_x ? xc - P.x1 : 0;
+    const float sx = (float)xr * P.fx;
+    const int x1 = (int)floorf(sx);
+    const int x2 = x1 + 1;
+    const float wxa = (float)x2 - sx, wxb = sx - (float)x1;
+    const bool edge = x2 > P.w - 1;
+    const int x2r = edge ? x1 : x2;
+    const uint32_t yo = (uint32_t)min(x1, P.w - 2);
+    const int ysh = (x1 - (int)yo) * 8;
+    const int c1 = x1 >> 1, c2 = x2r >> 1;
+    const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4);
+    const int ush = (2 * c1 - (int)uo) * 8;
+    const bool same_pair = c2 == c1;
+    const gptr_u8 base = (gptr_u8)P.data;
+    const size_t step = (size_t)P.step;
+    const gptr_u8 uvp = base + (size_t)P.uv_off;
+
+    uint32_t vya[kQRowsPerWave], vyb[kQRowsPerWave], vua[kQRowsPerWave], vub[kQRowsPerWave];
+    float wya[kQRowsPerWave], wyb[kQRowsPerWave];
+    bool in_y[kQRowsPerWave];
+#pragma unroll
+    for (int j = 0; j < kQRowsPerWave; ++j) {
+        const int y = min(row0 + j, dst_h - 1);
+        in_y[j] = y >= P.y1 && y <= P.y2;
+        const int yr = in_y[j] ? y - P.y1 : 0;
+        const float sy = (float)yr * P.fy;
+        const int y1 = (int)floorf(sy);
+        const int y2 = y1 + 1;
+        const int y2r = min(y2, P.h - 1);
+        wya[j] = (float)y2 - sy;
+        wyb[j] = sy - (float)y1;
+        const int r1 = __builtin_amdgcn_readfirstlane(y1), r2 = __builtin_amdgcn_readfirstlane(y2r);
+        vya[j] = q_load_u16<LD>(pin_uniform(base + (size_t)r1 * step) + yo);
+        vyb[j] = q_load_u16<LD>(pin_uniform(base + (size_t)r2 * step) + yo);
+        vua[j] = q_load_u32<LD>(pin_uniform(uvp + (size_t)(r1 >> 1) * step) + uo);
+        vub[j] = q_load_u32<LD>(pin_uniform(uvp + (size_t)(r2 >> 1) * step) + uo);
+    }
+    float outv[kQRowsPerWave][4];
+#pragma unroll
+    for (int j = 0; j < kQRowsPerWave; ++j) {
+        const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
+        const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
+        uint32_t ca = vua[j], cb = vub[j];
+        if (t.yuv_vu) { // NV21: swap the bytes of every pair once, then everything below is NV12 (wave-uniform)
+            ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
+            cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
+        }
+        const uint32_t pa0 = (ca >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (ca >> 16) & 0xffffu;
+        const uint32_t pb0 = (cb >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (cb >> 16) & 0xffffu;
+        const float fy[4] = {(float)ya0, (float)ya1, (float)yb0, (float)yb1};
+        const float fu[4] = {(float)(pa0 & 0xffu), (float)(pa1 & 0xffu), (float)(pb0 & 0xffu), (float)(pb1 & 0xffu)};
+        const float fv[4] = {(float)(pa0 >> 8), (float)(pa1 >> 8), (float)(pb0 >> 8), (float)(pb1 >> 8)};
+        float t00[4], t10[4], t01[4], t11[4];
+        if (t.yuv_range == CVGS_YUV_FULL) { // wave-uniform
+            k4_tap<CN, true>(fy[0], fu[0], fv[0], yk, t00);
+            k4_tap<CN, true>(fy[1], fu[1], fv[1], yk, t10);
+            k4_tap<CN, true>(fy[2], fu[2], fv[2], yk, t01);
+            k4_tap<CN, true>(fy[3], fu[3], fv[3], yk, t11);
+        } else {
+            k4_tap<CN, false>(fy[0], fu[0], fv[0], yk, t00);
+            k4_tap<CN, false>(fy[1], fu[1], fv[1], yk, t10);
+            k4_tap<CN, false>(fy[2], fu[2], fv[2], yk, t01);
+            k4_tap<CN, false>(fy[3], fu[3], fv[3], yk, t11);
+        }
+        const float w00 = wxa * wya[j], w10 = wxb * wya[j], w01 = wxa * wyb[j], w11 = wxb * wyb[j];
+        Px p;
+        p.v[3] = 0.f;
+#pragma unroll
+        for (int k = 0; k < CN; ++k) {
+            float acc = t00[k] * w00;
+            acc = acc + t10[k] * w10;
+            acc = acc + t01[k] * w01;
+            acc = acc + t11[k] * w11;
+            p.v[k] = acc;
+        }
+        run_prog(p);
+        const bool take = whole || (in_x && in_y[j]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) outv[j][k] = take ? p.v[k] : bgp.v[k];
+    }
+    store_rows(outv);
+}
+
 __device__ __forceinline__ uint64_t q_wave_min(uint64_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -402,8 +591,10 @@ struct QDevMem { // the server's device-side state, one uncached allocation (hos
     uint64_t* prog;     // 4 G resume words
 };
 
-template <int LD, int ST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
+// (register budget: 4 waves per SIMD -- 128 VGPRs -- for the pixel worker; the NV12 worker holds 16 tap words and four taps'
+// conversions per row and gets 3 waves per SIMD -- 168 VGPRs -- which is what the default 3 workgroups per CU use anyway)
+template <int LD, int ST, int KIND = QK_PIXELS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_NV12 ? 3 : 4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
                                                                                              uint64_t gen, uint64_t done0, uint64_t idle_ticks,
                                                                                              uint64_t stall_ticks) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -527,7 +718,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             t.P.y1 = (int)q_lane_u32(pv, 8);
             t.P.x2 = (int)q_lane_u32(pv, 9);
             t.P.y2 = (int)q_lane_u32(pv, 10);
-            t.P.uv_off = 0;
+            t.P.uv_off = KIND == QK_NV12 ? (int)q_lane_u32(pv, 11) : 0;
+            if constexpr (KIND == QK_NV12) {
+                t.yuv_range = (int)q_lane_u32(v, QD_YUV_RANGE);
+                t.yuv_primaries = (int)q_lane_u32(v, QD_YUV_PRIM);
+                t.yuv_vu = (int)q_lane_u32(v, QD_YUV_VU);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 t.mul[c] = q_lane_f32(v, QD_MUL + c);
@@ -546,7 +742,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             t.ch_stride = (int64_t)q_lane_u64(v, QD_CH_STRIDE);
             t.out = (uint8_t*)q_lane_u64(v, QD_OUT);
             t.out_bytes = (uint32_t)q_lane_u64(v, QD_OUT_BYTES);
-            const bool c3 = q_lane_u32(v, QD_CN) == 3;
+            [[maybe_unused]] const bool c3 = q_lane_u32(v, QD_CN) == 3;
             {
                 pre_wb = b;
                 const uint64_t* ep = (const uint64_t*)(m.index + ((pre_wb + (uint64_t)lane) % R));
@@ -562,7 +758,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             for (int grp = 0; grp * kQRowsPerWave < rows_per_task; ++grp) {
                 const int row0 = (int)row_tile * rows_per_task + grp * kQRowsPerWave;
                 if (row0 >= t.dst_h) break;
-                if (c3) k1q_rows<3, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+                if constexpr (KIND == QK_NV12) k4q_rows<LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+                else if (c3) k1q_rows<3, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
                 else k1q_rows<4, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
             }
         }
@@ -618,6 +815,8 @@ struct Queue {
     hipStream_t stage_stream = nullptr; // staging path only
     uint32_t R = 0, G = 0;
     int ld = 1, st = 2;
+    int kind = -1;                      // QK_*: latched by the first submit
+    int cus = 0;                        // compute units of the device
     bool direct = false;                // the host writes device memory through the BAR
     uint8_t* dev_block = nullptr;       // ONE uncached device allocation (host-written): ctl | ring | index | dflags
     uint8_t* dev_counters = nullptr;    // ordinary device memory (device-only): arrival counters | resume words
@@ -673,13 +872,16 @@ static hipError_t queue_launch(Queue* q) {
     hv(q->hc->state) = QS_RUNNING;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     const dim3 grid(q->G + 1), block(256);
-#define Q_LAUNCH(LD_, ST_) hipLaunchKernelGGL((k1q_server<LD_, ST_>), grid, block, 0, q->stream, q->m, q->hc, q->hflags, q->R, q->G, q->gen, q->done_inorder, q->idle_ticks, q->stall_ticks)
-    if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0);
-    else if (q->ld == 0 && q->st == 1) Q_LAUNCH(0, 1);
-    else if (q->ld == 0) Q_LAUNCH(0, 2);
-    else if (q->st == 0) Q_LAUNCH(1, 0);
-    else if (q->st == 1) Q_LAUNCH(1, 1);
-    else Q_LAUNCH(1, 2);
+#define Q_LAUNCH(LD_, ST_, K_) hipLaunchKernelGGL((k1q_server<LD_, ST_, K_>), grid, block, 0, q->stream, q->m, q->hc, q->hflags, q->R, q->G, q->gen, q->done_inorder, q->idle_ticks, q->stall_ticks)
+    if (q->kind == QK_NV12) { // the product flavour, and the unsafe upper bound of the A/B tool
+        if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0, QK_NV12);
+        else Q_LAUNCH(1, 2, QK_NV12);
+    } else if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0, QK_PIXELS);
+    else if (q->ld == 0 && q->st == 1) Q_LAUNCH(0, 1, QK_PIXELS);
+    else if (q->ld == 0) Q_LAUNCH(0, 2, QK_PIXELS);
+    else if (q->st == 0) Q_LAUNCH(1, 0, QK_PIXELS);
+    else if (q->st == 1) Q_LAUNCH(1, 1, QK_PIXELS);
+    else Q_LAUNCH(1, 2, QK_PIXELS);
 #undef Q_LAUNCH
     return hipGetLastError();
 }
@@ -724,6 +926,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     // half of every SIMD's wave slots to the caller's other kernels while the server is alive.
     if (use > 3) use = 3;
     uint32_t G = (uint32_t)(prop.multiProcessorCount * use) - 1;
+    q->cus = prop.multiProcessorCount;
     if ((flags >> 16) & 0xfff) G = (flags >> 16) & 0xfff;
     q->G = G;
     const double tick_hz = 100e6; // s_memrealtime: constant 100 MHz
@@ -772,34 +975,40 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     return 0;
 }
 
-// Can the server take this chain?  K1's hot shape only: 8U C3 / C4 crops -> bilinear resize -> [swap R,B] mul sub div -> fp32
-// planar tensor (NCHW / CNHW), descriptors inline, one target.  Everything else belongs to cvgs_execute.
+// Can the server take this chain?  K1's hot shape: 8U C3 / C4 crops -> bilinear resize -> [swap R,B] mul sub div -> fp32 planar
+// tensor (NCHW / CNHW), descriptors inline, one target -- or K4's: the same behind crops of an NV12 / NV21 decoder surface
+// (cvtColorNV12 in front of the resize, 3 channels).  A queue serves ONE of the two (its first submit decides); everything else
+// belongs to cvgs_execute.
 int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err) {
     const ReadArgs& r = c_in.read;
     const WriteArgs& w = c_in.write;
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
-    if (r.kind != CVGS_READ_RESIZE_LINEAR || r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4) || !planar || w.depth != CVGS_DEPTH_32F ||
-        w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch) {
-        err = "queue: chain is not a batched 8UC3/8UC4 resize into an fp32 planar tensor with <= 74 inline planes";
+    const bool nv12 = r.kind == CVGS_READ_NV12_RESIZE_LINEAR;
+    const int kind = nv12 ? QK_NV12 : QK_PIXELS;
+    const int vcn = nv12 ? r.out_cn : r.cn; // channels of the value the program sees
+    if (!planar || w.depth != CVGS_DEPTH_32F || w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch ||
+        (!nv12 && (r.kind != CVGS_READ_RESIZE_LINEAR || r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4))) ||
+        (nv12 && ((r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21) || r.out_cn != 3))) {
+        err = "queue: chain is not a batched 8UC3 / 8UC4 (or NV12 / NV21 -> 3 channels) resize into an fp32 planar tensor with <= 74 inline planes";
         return 1;
     }
     for (int i = 0; i < n_planes && i < r.used; ++i)
-        if (planes[i].w * r.cn < 8) {
-            err = "queue: a crop narrower than the 8-byte tap window (1-2 pixels)";
+        if (nv12 ? planes[i].w < 4 : planes[i].w * r.cn < 8) {
+            err = nv12 ? "queue: a surface crop narrower than 4 pixels" : "queue: a crop narrower than the 8-byte tap window (1-2 pixels)";
             return 1;
         }
     ChainArgs c = c_in;
     c.prog.fast_div = 0;
     for (int k = 0; k < 4; ++k) c.prog.rdiv[k] = 0.f;
-    const int prog_id = k1_classify_program(c.prog, r.cn);
+    const int prog_id = k1_classify_program(c.prog, vcn);
     if (prog_id > 1) {
         err = "queue: the pointwise program must be [RGB<->BGR swap,] mul, sub, div";
         return 1;
     }
-    fast_div_setup(c.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
+    fast_div_setup(c.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, vcn, r.bg);
     const int o = prog_id == 0 ? 1 : 0; // index of the MUL stage
     // output bytes addressed through ONE 32-bit-offset buffer descriptor
-    const int64_t last = (int64_t)(r.batch - 1) * w.img_stride + (int64_t)(r.cn - 1) * w.ch_stride + (int64_t)r.dst_h * w.width;
+    const int64_t last = (int64_t)(r.batch - 1) * w.img_stride + (int64_t)(vcn - 1) * w.ch_stride + (int64_t)r.dst_h * w.width;
     if (last <= 0 || last * 4 >= (int64_t)1 << 31) {
         err = "queue: output tensor beyond 2 GB";
         return 1;
@@ -808,6 +1017,24 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     if (hv(q->hc->error)) {
         err = "queue: the server reported a stall / protocol error earlier";
         return -2;
+    }
+    if (q->kind < 0) {
+        q->kind = kind;
+        if (kind == QK_NV12) { // every workgroup must be resident (tasks are statically owned): the NV12 worker's register budget allows 3 per CU
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_NV12>, 256, 0) != hipSuccess || per_cu < 1) {
+                q->kind = -1;
+                err = "queue: occupancy query failed";
+                return -1;
+            }
+            const uint32_t g_max = (uint32_t)(q->cus * (per_cu > 3 ? 3 : per_cu)) - 1;
+            if (q->G > g_max) q->G = g_max; // (nothing has been launched yet: the first submit decides the kind)
+        }
+    }
+    if (q->kind != kind) {
+        err = q->kind == QK_NV12 ? "queue: this queue serves NV12 / NV21 surface crops (its first submit decided); use another queue for pixel crops"
+                                 : "queue: this queue serves 8UC3 / 8UC4 crops (its first submit decided); use another queue for NV12 surfaces";
+        return 1;
     }
     auto ns_since = [](std::chrono::steady_clock::time_point a) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a).count(); };
     // ring space: batch next_seq reuses the slot of batch next_seq - R, which must be complete
@@ -846,7 +1073,11 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     p.dst_w = (uint32_t)r.dst_w;
     p.dst_h = (uint32_t)r.dst_h;
     p.out_w = (uint32_t)w.width;
-    p.cn = (uint32_t)r.cn;
+    p.cn = (uint32_t)vcn;
+    p.kind = (uint32_t)kind;
+    p.yuv_range = (uint32_t)r.yuv_range;
+    p.yuv_primaries = (uint32_t)r.yuv_primaries;
+    p.yuv_vu = r.yuv_layout == CVGS_YUV_NV21;
     p.swap = prog_id == 0;
     p.fast_div = (uint32_t)c.prog.fast_div;
     for (int i = 0; i < 4; ++i) {

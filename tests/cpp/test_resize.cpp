@@ -164,6 +164,15 @@ static void test_nv12_facade_cfg3(cv::cuda::Stream& stream) {
     stream.waitForCompletion();
     const auto h = fetch(d_out.data, (size_t)down.width * down.height * 3 * 4);
     CHECK(bit_equal(h.data(), h_ref.data, h.size()), "cfg3 through cvGS::cvtColorNV12 + resize, bit-exact vs oracle");
+    // the same frame through the device-side descriptor queue (engine extension): decoder surfaces are its second kind
+    cvGS::Queue queue;
+    cv::cuda::GpuMat d_out_q(1, down.width * down.height * 3, CV_32F);
+    const uint64_t ticket = cvGS::executeOperations(queue, cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorNV12<cv::COLOR_YUV2BGR_NV12>(d_nv12), down),
+                                                    cvGS::multiply<CV_32FC3>(a), cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d),
+                                                    cvGS::split<CV_32FC3>(d_out_q, down));
+    queue.wait(ticket);
+    const auto hq = fetch(d_out_q.data, (size_t)down.width * down.height * 3 * 4);
+    CHECK(bit_equal(hq.data(), h_ref.data, hq.size()), "cfg3 through cvGS::executeOperations(queue, ...), bit-exact vs oracle");
 }
 
 // a decoder surface letterboxed into a detector input: cvtColorNV12<RGB> -> resize<LINEAR, PRESERVE_AR>(640x640 style) -> normalize -> split

@@ -240,3 +240,142 @@ def test_queue_two_queues_side_by_side(oracle, torch_dev):
     finally:
         qa.destroy()
         qb.destroy()
+
+
+# ---- the queue's second kind: crops of NV12 / NV21 decoder surfaces (K4's shape) ----------------------------------------------
+def _nv12_ops(luma_mats, out_mat, dst, range_, prim, layout, swap=True, ar=None, background=None, used=None):
+    f = cvgs.CV_32FC3
+    rd = cvgs.read_nv12(luma_mats, dst, range_, prim, False, layout=layout)
+    if ar is not None:
+        rd.ar = ar
+    if background is not None:
+        rd.background = cvgs._scalar(background)
+    if used is not None:
+        rd.used_planes = used
+    ops = [rd]
+    if swap:
+        ops.append(cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f))
+    return ops + [cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225]),
+                  cvgs.split(f, out_mat, dst)]
+
+
+def _nv12_case(oracle, torch, dev, q, surf, w, h, crops, dst, **kw):
+    """one batch: crops (x, y, w, h; even) of the surface `surf` ((h + h/2) x w bytes) on the queue, on cvgs_execute and on the oracle"""
+    n = len(crops)
+    surf_t = torch.from_numpy(surf).to(dev)
+    outs = {}
+    for name in ("queue", "execute"):
+        out_t = torch.full((n, 3 * dst[0] * dst[1]), -777.0, dtype=torch.float32, device=dev)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, surf_t.data_ptr(), w, owner=surf_t)
+        ops = _nv12_ops([luma.nv12_roi(*c) for c in crops], cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), dst, **kw)
+        torch.cuda.synchronize()
+        if name == "queue":
+            q.wait(q.submit(*ops))
+        else:
+            cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+        torch.cuda.synchronize()
+        outs[name] = out_t.cpu().numpy()
+    ref = np.full((n, 3 * dst[0] * dst[1]), -777.0, dtype=np.float32)
+    luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, surf.ctypes.data, w, owner=surf)
+    oracle.execute(cvgs.lower(_nv12_ops([luma.nv12_roi(*c) for c in crops], cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, **kw)))
+    H.assert_bit_exact(outs["queue"], ref, "NV12 queue batch vs the oracle %s" % (kw,))
+    H.assert_bit_exact(outs["queue"], outs["execute"], "NV12 queue batch vs cvgs_execute")
+
+
+def _even_crops(n, w, h, seed, wmin=8, hmin=8):
+    return [tuple(v & ~1 for v in c) for c in H.random_crops(n, w, h, seed=seed, wmin=wmin + 1, wmax=w // 2, hmin=hmin + 1, hmax=h // 2)]
+
+
+@pytest.mark.parametrize("dst,kw", [
+    ((64, 128), dict(range_=capi.YUV_FULL, prim=capi.BT709, layout=capi.YUV_NV12)),
+    ((64, 128), dict(range_=capi.YUV_LIMITED, prim=capi.BT601, layout=capi.YUV_NV21)),
+    ((64, 128), dict(range_=capi.YUV_LIMITED, prim=capi.BT2020, layout=capi.YUV_NV12, swap=False)),
+    ((100, 37), dict(range_=capi.YUV_FULL, prim=capi.BT601, layout=capi.YUV_NV12)),       # ragged: 2 column tiles, 37 rows
+    ((64, 64), dict(range_=capi.YUV_LIMITED, prim=capi.BT709, layout=capi.YUV_NV12, ar=cvgs.PRESERVE_AR, background=[114.0, 100.5, 7.25])),
+    ((96, 64), dict(range_=capi.YUV_FULL, prim=capi.BT709, layout=capi.YUV_NV21, ar=cvgs.PRESERVE_AR_LEFT, background=[1.0, 2.0, 3.0], used=4)),
+    ((256, 16), dict(range_=capi.YUV_FULL, prim=capi.BT709, layout=capi.YUV_NV12)),
+])
+def test_queue_nv12_batch_matches_the_oracle(oracle, torch_dev, dst, kw):
+    torch, dev = torch_dev
+    w, h = 1280, 720
+    surf = H.random_u8((h + h // 2, w), seed=21)
+    crops = _even_crops(7, w, h, seed=31) + [(0, 0, w, h), (w - 4, h - 2, 4, 2)]  # the whole surface, a 4 x 2 corner
+    q = cvgs.Queue()
+    try:
+        _nv12_case(oracle, torch, dev, q, surf, w, h, crops, dst, **kw)
+    finally:
+        q.destroy()
+
+
+def test_queue_nv12_whole_6k_surface_cfg3(oracle, torch_dev):
+    """BASELINE cfg #3 through the queue: a 6K NV12 surface -> BGR float -> 1280 x 720 -> normalize -> split, frame after frame."""
+    torch, dev = torch_dev
+    w, h = 6144, 3456
+    q = cvgs.Queue()
+    try:
+        for seed in (41, 42):
+            surf = H.random_u8((h + h // 2, w), seed=seed)
+            _nv12_case(oracle, torch, dev, q, surf, w, h, [(0, 0, w, h)], (1280, 720), range_=capi.YUV_FULL, prim=capi.BT709, layout=capi.YUV_NV12)
+        assert q.stats()["error"] == 0
+    finally:
+        q.destroy()
+
+
+def test_queue_nv12_many_batches_in_flight(oracle, torch_dev):
+    torch, dev = torch_dev
+    w, h = 1920, 1080
+    dst = (64, 128)
+    surfs = [H.random_u8((h + h // 2, w), seed=50 + i) for i in range(3)]
+    surf_ts = [torch.from_numpy(s).to(dev) for s in surfs]
+    q = cvgs.Queue(depth=8)
+    try:
+        jobs = []
+        for i in range(40):
+            crops = _even_crops(10, w, h, seed=300 + i)
+            out_t = torch.full((10, 3 * dst[0] * dst[1]), -777.0, dtype=torch.float32, device=dev)
+            st = surf_ts[i % 3]
+            luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, st.data_ptr(), w, owner=st)
+            ops = _nv12_ops([luma.nv12_roi(*c) for c in crops], cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), dst, capi.YUV_LIMITED, capi.BT709, capi.YUV_NV12)
+            jobs.append((i, crops, out_t, q.submit(*ops)))
+        q.wait(jobs[-1][3])
+        for i, crops, out_t, ticket in jobs:
+            q.wait(ticket)
+            ref = np.full((10, 3 * dst[0] * dst[1]), -777.0, dtype=np.float32)
+            s = surfs[i % 3]
+            luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, s.ctypes.data, w, owner=s)
+            oracle.execute(cvgs.lower(_nv12_ops([luma.nv12_roi(*c) for c in crops], cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, capi.YUV_LIMITED, capi.BT709, capi.YUV_NV12)))
+            H.assert_bit_exact(out_t.cpu().numpy(), ref, "NV12 batch %d" % i)
+        st = q.stats()
+        assert st["completed"] == 40 and st["error"] == 0, st
+    finally:
+        q.destroy()
+
+
+def test_queue_serves_one_kind(torch_dev):
+    """a queue's first submit decides what it serves; the other kind and the layouts the worker does not read are refused"""
+    torch, dev = torch_dev
+    w, h = 640, 360
+    surf_t = torch.from_numpy(H.random_u8((h + h // 2, w), seed=5)).to(dev)
+    frame_t = torch.from_numpy(H.random_u8((h, w, 3), seed=6)).to(dev)
+    out_t = torch.zeros((1, 3 * 64 * 128), dtype=torch.float32, device=dev)
+    luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, surf_t.data_ptr(), w, owner=surf_t)
+    nv = _nv12_ops([luma], cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), (64, 128), capi.YUV_FULL, capi.BT709, capi.YUV_NV12)
+    px = H.k1_chain(cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), [(0, 0, w, h)], cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), (64, 128), 3)
+    for first, second in ((nv, px), (px, nv)):
+        q = cvgs.Queue()
+        try:
+            q.wait(q.submit(*first))
+            with pytest.raises(capi.CvgsError):
+                q.submit(*second)
+            q.wait(q.submit(*first))
+            assert q.stats()["error"] == 0
+        finally:
+            q.destroy()
+    q = cvgs.Queue()
+    try:
+        i420 = torch.from_numpy(H.random_u8((h + h // 2, w), seed=7)).to(dev)
+        lu = cvgs.GpuMat(h, w, cvgs.CV_8UC1, i420.data_ptr(), w, owner=i420)
+        with pytest.raises(capi.CvgsError):
+            q.submit(*_nv12_ops([lu], cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), (64, 128), capi.YUV_FULL, capi.BT709, capi.YUV_I420))
+    finally:
+        q.destroy()

@@ -31,6 +31,30 @@ def events_time(fn, iters, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def queue_time(chains, frames_per_replay=384, replays=9):
+    """The same pre-lowered chains, ONE cvgs_queue_submit per frame (no kernel launch per frame; csrc/k_queue.hip): K frames are
+    handed to cvgs_queue_submit_many, the host's wall clock brackets submit + wait of the last ticket; median over the replays
+    (each replay ends with the queue drained: ~25 us of latency tail in K frames' time).  Returns seconds per frame."""
+    import time
+    q = cvgs.Queue(idle_us=2000.0, depth=128, flags=(int(os.environ.get("CVGS_BENCH_QUEUE_G", "0")) & 0xfff) << 16)  # tuning hook: worker workgroups
+    try:
+        seq = [chains[i % len(chains)] for i in range(frames_per_replay)]
+        ptrs = cvgs.Queue.chain_pointers(seq)
+        q.wait(q.submit_many(ptrs, frames_per_replay), 30.0)
+        ts = []
+        for _ in range(replays):
+            t0 = time.perf_counter()
+            q.wait(q.submit_many(ptrs, frames_per_replay), 30.0)
+            ts.append((time.perf_counter() - t0) / frames_per_replay)
+        st = q.stats()
+        if st["error"]:
+            raise RuntimeError("queue error %r" % (st,))
+        ts.sort()
+        return ts[len(ts) // 2]
+    finally:
+        q.destroy()
+
+
 def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False, graph=False):
     """graph=True: a capturable handle (CVGS_CIRCULAR_CAPTURABLE), 16 updates captured into ONE HIP graph, the graph replayed"""
     Wd, Hd, B = 1920, 1080, 16
@@ -78,7 +102,7 @@ def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False, graph=Fal
             "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4), "updates_per_s": round(1 / t, 1)}
 
 
-def cfg3(dev, iters, p010=False):
+def cfg3(dev, iters, p010=False, queue=False):
     """p010: the same frame as a 10-bit decoder surface (16-bit samples, BT.2020 limited range, x 1/1023 in the chain)."""
     w, h = W.FRAME_6K
     dst = (1280, 720)
@@ -109,19 +133,21 @@ def cfg3(dev, iters, p010=False):
         capi.check(lib.cvgs_execute(C.byref(ch.desc), s.cuda_stream))
 
     t = events_time(launch, iters)
+    if queue:  # the same frames through the descriptor queue (NV12 surfaces are its second kind)
+        t = queue_time(chains)
     write = dst[0] * dst[1] * 3 * 4
     # scale 4.8: every output pixel taps 4 distinct luma bytes and up to 4 distinct UV pairs (SURVEY.md 8d bound)
     read = (dst[0] * dst[1] * 4 + dst[0] * dst[1] * 2 * 4) * sb
     alg = write + read
     sector = W.nv12_sector_read_bytes(w, h, dst[0], dst[1], sb) + write
-    return {"config": "cfg3 %s 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, one kernel" % ("P010 (10-bit, BT.2020 limited)" if p010 else "NV12"),
-            "kernel": cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
+    return {"config": "cfg3 %s 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, %s" % ("P010 (10-bit, BT.2020 limited)" if p010 else "NV12", "one cvgs_queue_submit per frame (descriptor queue, no launch per frame)" if queue else "one kernel"),
+            "kernel": "k1q_server<1, 2, NV12> (k4q_rows)" if queue else cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
             "GB_per_s": round(alg / t / 1e9, 1), "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4),
             "sector_bound_bytes": sector, "frac_of_sector_bound": round(sector / t / 1e9 / PEAK, 4), "surfaces_in_rotation": nbuf,
             "output_Mpix_per_s": round(dst[0] * dst[1] / t / 1e6, 1), "source_Mpix_per_s": round(w * h / t / 1e6, 1)}
 
 
-def nv12_crops(dev, iters, n=50):
+def nv12_crops(dev, iters, n=50, queue=False):
     """The decode-side version of cfg #2b: n crops (even x/y/w/h, the cfg #2b size distribution) of a 4K NV12 decoder
     surface -> BGR float -> 64x128 -> normalize -> [n,3,128,64], one launch."""
     w, h = W.FRAME_4K
@@ -141,6 +167,11 @@ def nv12_crops(dev, iters, n=50):
         keep += [buf, out]
         chains.append(cvgs.lower(ops))
     state = {"i": 0}
+    if queue:
+        t = queue_time(chains, frames_per_replay=960)
+        return {"config": "decode-side cfg2b: %d crops of a 4K NV12 surface -> BGR float -> 64x128 -> normalize -> NCHW, one cvgs_queue_submit per frame (descriptor queue)" % n,
+                "kernel": "k1q_server<1, 2, NV12> (k4q_rows)", "us_per_launch": round(t * 1e6, 2),
+                "output_Mpix_per_s": round(n * dst[0] * dst[1] / t / 1e6, 1)}
 
     def launch():
         ch = chains[state["i"] % len(chains)]
@@ -216,10 +247,12 @@ def run_all(dev, iters=100, only=""):
     if only in ("", "cfg3"):
         res.append(cfg3(dev, iters))
         res.append(cfg3(dev, iters, p010=True))
+        res.append(cfg3(dev, iters, queue=True))
     if only in ("", "nv12many"):
         res.append(nv12_many(dev, iters))
     if only in ("", "nv12crops"):
         res.append(nv12_crops(dev, iters))
+        res.append(nv12_crops(dev, iters, queue=True))
     return res
 
 

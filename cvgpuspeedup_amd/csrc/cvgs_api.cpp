@@ -736,7 +736,7 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
                 const ManySeg seg{L.args.read.table, L.args.write.data, L.args.read.batch, L.args.read.used};
                 rc = launch_nv12(L.args, nullptr, 0, 4, &seg, 1, stream, dry_run, info);
             } else {
-                rc = launch_nv12(L.args, inline_planes, n_inline, min_w, nullptr, 0, stream, dry_run, info);
+                rc = launch_nv12(L.args, inline_planes, n_inline, min_w, nullptr, 0, stream, dry_run, info, ch->flags);
             }
             if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
             if (rc == 1) { up.done(true); return CVGS_OK; }

@@ -167,7 +167,10 @@ int launch_generic64(const ChainArgs& c, const Prog64Args& p64, const PlaneParam
 
 // K4 fast path: NV12 read-back fused into the bilinear resize -> program -> planar fp32 tensor or packed pixels.
 int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, const ManySeg* segs, int n_segs,
-                void* stream, bool dry_run, LaunchInfo* info);
+                void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags = 0);
+// K4 at frame size, two output pixels per lane (k_nv12_x2.hip); 1 launched / 0 not eligible / < 0 error
+int launch_nv12_x2(const ChainArgs& c, const PlaneParams* planes, int n_planes, bool prog_swap, void* stream, bool dry_run);
+static constexpr int64_t kK4X2MinWaveRows = 4096; // output rows x 64-column tiles x surfaces from which launch_nv12 prefers it
 bool k4_planes_eligible(const PlaneParams* planes, int n, int dst_w, int dst_h);
 
 // Thread-fused pointwise chains on u8 sources (4 pixels per thread) -> fp32 planar / packed.

@@ -435,7 +435,7 @@ static bool k4_planes_wide_enough(const PlaneParams* planes, int n) {
 // `segs` (n_segs >= 1): the chains of a cvgs_execute_many launch -- their planes live in device tables that the caller
 // has checked with k4_planes_eligible; c_in.read.batch is the largest batch.  nullptr: one chain (inline_planes).
 int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, int min_width, const ManySeg* segs, int n_segs,
-                void* stream, bool dry_run, LaunchInfo* info) {
+                void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags) {
     const ReadArgs& r = c_in.read;
     // fp16 planar tensors: the trailing CAST(CV_16F) moves into the store
     const bool planar_kind = c_in.write.kind == CVGS_WRITE_TENSOR_SPLIT || c_in.write.kind == CVGS_WRITE_TENSOR_T_SPLIT;
@@ -521,15 +521,28 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
                            p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV;
     // the same normalisation in the surface's own R, G, B order (cvtColorNV12<COLOR_YUV2RGB_NV12>: no swap)
     const bool fast_rgb = planar && !f16 && p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV;
-    if (info)
-        info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
-                           : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : (fast_rgb ? "k4_nv12_resize_mul_sub_div" : "k4_nv12_resize_interp"));
-    if (dry_run) return 1;
     ChainArgs c_fd = c;
     c_fd.prog.fast_div = 0;
     for (int k = 0; k < 4; ++k) c_fd.prog.rdiv[k] = 0.f;
     if (fast_prog) fast_div_setup(c_fd.prog, 3, 1, r.out_cn, r.bg);
     else if (fast_rgb) fast_div_setup(c_fd.prog, 2, 0, r.out_cn, r.bg);
+    // whole surfaces stretched into large targets (cfg #3: 6K -> 1280 x 720): two output pixels per lane (k_nv12_x2.hip) once the
+    // launch is paced by instruction issue rather than by its latency; CVGS_CHAIN_NO_THREAD_FUSION keeps the one-pixel kernel
+    if ((fast_prog || fast_rgb) && !f16 && !segs && r.out_cn == 3 && !(chain_flags & CVGS_CHAIN_NO_THREAD_FUSION)) {
+        const char* x2_env = getenv("CVGS_K4_X2"); // tuning / test hook: 0 = never, 1 = whenever eligible
+        const int64_t wave_rows = (int64_t)r.batch * r.dst_h * ((r.dst_w + 63) / 64);
+        if (x2_env ? x2_env[0] == '1' : wave_rows >= kK4X2MinWaveRows) {
+            const int rc = launch_nv12_x2(c_fd, inline_planes, n_inline, fast_prog, stream, dry_run);
+            if (rc != 0) {
+                if (info) info->kernel = fast_prog ? "k4_nv12_x2_swap_mul_sub_div" : "k4_nv12_x2_mul_sub_div";
+                return rc;
+            }
+        }
+    }
+    if (info)
+        info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
+                           : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : (fast_rgb ? "k4_nv12_resize_mul_sub_div" : "k4_nv12_resize_interp"));
+    if (dry_run) return 1;
     tls_many() = N12Many{segs, n_segs};
     // the windowed instantiations: an aspect-ratio window or default-value planes (never for fused chains / staged tables, whose
     // callers admit stretch geometry only)

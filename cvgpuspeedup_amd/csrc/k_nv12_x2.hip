@@ -1,0 +1,274 @@
+// k_nv12_x2.hip -- K4 at frame size: two x-adjacent output pixels per lane.
+//
+// The chain: Resize<INTER_LINEAR>(ReadYUV<NV12> + ConvertYUVToRGB) -> [RGB<->BGR] mul sub div -> planar fp32 tensor -- BASELINE cfg #3
+// (a 6K decoder surface -> 1280 x 720 normalized NCHW; reference tests/resize/test_fused_resize.cu:141-147 fused with the K1 tail).
+// k4_nv12_resize (k_nv12.hip: lane = one output column, wave = one output row) runs cfg #3 in 8.4 us: 14,400 waves of 140 VALU +
+// 90 SALU instructions (profiles/r03_f_cfg3_pmc_sq1.txt), and no memory-side change moves it (cached surfaces: 7.3-7.7 us; the
+// descriptor queue: 6.9-7.3).  This kernel halves the waves and runs the arithmetic that dominates -- four YCbCr -> RGB conversions
+// and the bilinear blend per pixel -- on PIXEL PAIRS (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations in the same order, two
+// pixels per instruction; the multi-pixel resize kernel k_k1_x4.hip does the same for packed images):
+//  * lane = 2 x-adjacent output pixels, wave = 128 output columns; each pixel keeps K4's loads (one unaligned 2-byte load for both
+//    luma taps of a source row, one 4-byte load for both chroma pairs): 8 loads per lane and row;
+//  * large launches walk kN2Rows rows per wave with the NEXT row's tap words requested before the current row is computed, the
+//    stores through one buffer descriptor (a store past the target is dropped by the hardware: no control flow around it, so the
+//    compiler's s_waitcnt counts stay exact and no row ever waits for the previous row's stores); small ones keep one row per wave;
+//  * the scalar side (row geometry, row pointers, program operands) is paid once per 128 columns instead of once per 64;
+//  * planar stores are 8 bytes per lane and channel: 512-byte rows per wave, non-temporal.
+// Measured (tools/bench_more.py, tools/bench_nv12_letterbox.py): cfg #3 8.4 -> 8.0 us, 1080p / 4K surface -> 640 x 640 detector
+// input 4.3 / 4.6 -> 3.9 / 4.4 us.  Less than the instruction counts promised, and the reason is measured too: with its loads
+// AND stores disabled the launch still takes 7.2 us of the 8.0-9.0 (the same box) -- the chain is bound by its arithmetic at the
+// issue rates this chip gives it (tools/probes/pk_rate_probe.cpp: a packed fp32 instruction costs 5.7 cycles, worth 1.2 plain
+// ones, not 2), not by memory: 230 VALU instructions per 128 pixels here against 280 on k4_nv12_resize.
+// Stretch geometry only (every surface covers its whole target), NV12 / NV21 8-bit, three channels, the two compile-time
+// programs; everything else stays on k4_nv12_resize.  Bit-identical to it and to the oracle (tests/test_gpu_k4_x2.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "k_taps.hpp"
+
+namespace cvgs {
+
+constexpr int kN2Planes = 8; // surfaces per launch (blockIdx.z)
+constexpr int kN2Waves = 4;  // waves per workgroup (independent)
+constexpr int kN2Rows = 4;   // rows per wave of the pipelined form (even)
+
+typedef uint16_t n2_u16_unaligned __attribute__((aligned(1)));
+typedef uint32_t n2_u32_unaligned __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) n2_u16_unaligned* n2_gptr_u16;
+typedef const __attribute__((address_space(1))) n2_u32_unaligned* n2_gptr_u32;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct N2Plane { // 32 bytes
+    const uint8_t* data;
+    int32_t w, h, step, uv_off;
+    float fx, fy;
+};
+struct N2Args {
+    N2Plane plane[kN2Planes];
+    float* out;
+    int64_t img_stride, ch_stride; // elements
+    int32_t dst_w, dst_h, out_w;
+    int32_t yuv_range, yuv_primaries, yuv_vu;
+    uint32_t out_bytes;            // RPW > 1: the whole tensor behind one buffer descriptor
+    ProgArgs prog; // [swap,] mul, sub, div with the host's reciprocals (fast_div)
+};
+
+// one tap of the pair: k4_tap's expressions on two pixels at once
+struct N2Rgb { f32x2 r, g, b; };
+template <bool FULL>
+__device__ __forceinline__ N2Rgb n2_tap(f32x2 Y, f32x2 U, f32x2 V, const YuvK& k) {
+    const f32x2 cb = U - k.csub, cr = V - k.csub;
+    const f32x2 yv = FULL ? Y : (Y - k.ysub) * k.yscale;
+    N2Rgb t;
+    t.r = yv + k.rv * cr;
+    t.g = (yv + k.gu * cb) + k.gv * cr;
+    t.b = yv + k.bu * cb;
+    return t;
+}
+
+template <class Prog, int RPW>
+__global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(const N2Args a) {
+    const int z = (int)blockIdx.z;
+    const N2Plane P = a.plane[z];
+    const int dst_w = a.dst_w, dst_h = a.dst_h, W = a.out_w;
+    const int yuv_range = a.yuv_range, vu = a.yuv_vu;
+    const YuvK yk = yuv_matrix(yuv_range, a.yuv_primaries, CVGS_YUV_NV12);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int col_tile = (int)blockIdx.x;
+    const int row0 = ((int)blockIdx.y * kN2Waves + wave) * RPW;
+    const int x0 = (col_tile * 64 + lane) * 2;
+    if (row0 >= dst_h || x0 >= dst_w) return;
+
+    // ---- column geometry of the lane's two pixels (k4_nv12_resize's, per pixel) ----
+    f32x2 wxa, wxb;
+    bool edge[2], same_pair[2];
+    uint32_t yo[2], uo[2];
+    int ysh[2], ush[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int x = min(x0 + i, dst_w - 1); // an odd target's last lane computes its last pixel twice and stores it once
+        const float sx = (float)x * P.fx;
+        const int x1 = (int)floorf(sx);
+        const int x2 = x1 + 1;
+        wxa[i] = (float)x2 - sx;
+        wxb[i] = sx - (float)x1;
+        edge[i] = x2 > P.w - 1;
+        const int x2r = edge[i] ? x1 : x2;
+        yo[i] = (uint32_t)min(x1, P.w - 2);
+        ysh[i] = (x1 - (int)yo[i]) * 8;
+        const int c1 = x1 >> 1, c2 = x2r >> 1;
+        uo[i] = (uint32_t)min(2 * c1, P.w - 4);
+        ush[i] = (2 * c1 - (int)uo[i]) * 8;
+        same_pair[i] = c2 == c1;
+    }
+    const gptr_u8 base = (gptr_u8)P.data;
+    const size_t step = (size_t)P.step;
+    const gptr_u8 uvp = base + (size_t)P.uv_off;
+
+    struct Raw {
+        uint32_t vya[2], vyb[2], vua[2], vub[2];
+        float wya, wyb;
+    };
+    auto load_row = [&](int y_in) { // the tap words of one output row: requests only
+        Raw r;
+        const int y = min(y_in, dst_h - 1);
+        const float sy = (float)y * P.fy;
+        const int y1 = (int)floorf(sy);
+        const int y2 = y1 + 1;
+        const int y2r = min(y2, P.h - 1);
+        r.wya = (float)y2 - sy;
+        r.wyb = sy - (float)y1;
+        const int r1 = __builtin_amdgcn_readfirstlane(y1), r2 = __builtin_amdgcn_readfirstlane(y2r);
+        const gptr_u8 ya = pin_uniform(base + (size_t)r1 * step), yb = pin_uniform(base + (size_t)r2 * step);
+        const gptr_u8 ua = pin_uniform(uvp + (size_t)(r1 >> 1) * step), ub = pin_uniform(uvp + (size_t)(r2 >> 1) * step);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            r.vya[i] = *(n2_gptr_u16)(ya + yo[i]);
+            r.vyb[i] = *(n2_gptr_u16)(yb + yo[i]);
+            r.vua[i] = *(n2_gptr_u32)(ua + uo[i]);
+            r.vub[i] = *(n2_gptr_u32)(ub + uo[i]);
+        }
+        return r;
+    };
+
+    float* const out = a.out + (int64_t)z * a.img_stride;
+    const bool both = x0 + 1 < dst_w;
+    // RPW > 1: the output tensor behind ONE buffer descriptor -- a store whose offset lies beyond it is dropped by the hardware,
+    // so rows past the target and the control flow around them disappear and every row issues the same 8 loads + 3 stores
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    auto finish_row = [&](const Raw& raw, int y) {
+        f32x2 fy[4], fu[4], fv[4]; // taps 00, 10, 01, 11 of the pixel pair
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t ya0 = (raw.vya[i] >> ysh[i]) & 0xffu, ya1 = edge[i] ? ya0 : (raw.vya[i] >> 8) & 0xffu;
+            const uint32_t yb0 = (raw.vyb[i] >> ysh[i]) & 0xffu, yb1 = edge[i] ? yb0 : (raw.vyb[i] >> 8) & 0xffu;
+            uint32_t ca = raw.vua[i], cb = raw.vub[i];
+            if (vu) { // NV21: swap the bytes of every pair once, then everything below is NV12 (wave-uniform)
+                ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
+                cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
+            }
+            const uint32_t pa0 = (ca >> ush[i]) & 0xffffu, pa1 = same_pair[i] ? pa0 : (ca >> 16) & 0xffffu;
+            const uint32_t pb0 = (cb >> ush[i]) & 0xffffu, pb1 = same_pair[i] ? pb0 : (cb >> 16) & 0xffffu;
+            fy[0][i] = (float)ya0; fy[1][i] = (float)ya1; fy[2][i] = (float)yb0; fy[3][i] = (float)yb1;
+            fu[0][i] = (float)(pa0 & 0xffu); fu[1][i] = (float)(pa1 & 0xffu); fu[2][i] = (float)(pb0 & 0xffu); fu[3][i] = (float)(pb1 & 0xffu);
+            fv[0][i] = (float)(pa0 >> 8); fv[1][i] = (float)(pa1 >> 8); fv[2][i] = (float)(pb0 >> 8); fv[3][i] = (float)(pb1 >> 8);
+        }
+        N2Rgb t[4];
+        if (yuv_range == CVGS_YUV_FULL) { // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = n2_tap<true>(fy[k], fu[k], fv[k], yk);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = n2_tap<false>(fy[k], fu[k], fv[k], yk);
+        }
+        const f32x2 w00 = wxa * raw.wya, w10 = wxb * raw.wya, w01 = wxa * raw.wyb, w11 = wxb * raw.wyb;
+        f32x2 acc[3];
+        {
+            f32x2 v = t[0].r * w00; v = v + t[1].r * w10; v = v + t[2].r * w01; v = v + t[3].r * w11; acc[0] = v;
+            v = t[0].g * w00; v = v + t[1].g * w10; v = v + t[2].g * w01; v = v + t[3].g * w11; acc[1] = v;
+            v = t[0].b * w00; v = v + t[1].b * w10; v = v + t[2].b * w01; v = v + t[3].b * w11; acc[2] = v;
+        }
+        // the program, per pixel: the compile-time stages of k_taps.hpp (incl. the division by the uniform divisor)
+        Px p0, p1;
+        p0.v[0] = acc[0].x; p0.v[1] = acc[1].x; p0.v[2] = acc[2].x; p0.v[3] = 0.f;
+        p1.v[0] = acc[0].y; p1.v[1] = acc[1].y; p1.v[2] = acc[2].y; p1.v[3] = 0.f;
+        int depth = CVGS_DEPTH_32F, cn = 3;
+        Prog::run(a.prog, p0, depth, cn);
+        depth = CVGS_DEPTH_32F; cn = 3;
+        Prog::run(a.prog, p1, depth, cn);
+        if constexpr (RPW > 1) {
+            // (even target widths only: the launcher checks) offsets in bytes from the tensor's start fit 32 bits (checked on the host)
+            const uint32_t row_off = (uint32_t)(((int64_t)z * a.img_stride + (int64_t)y * W) * 4);
+            const uint32_t off = y < dst_h ? row_off + (uint32_t)x0 * 4u : 0xfffffff0u;
+            typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const u32x2q q = {__float_as_uint(p0.v[k]), __float_as_uint(p1.v[k])};
+                __builtin_amdgcn_raw_buffer_store_b64(q, rsrc, off, (uint32_t)((int64_t)k * a.ch_stride * 4), 2 /* nt */);
+            }
+        } else {
+            float* const orow = out + (int64_t)y * W; // wave-uniform
+            typedef __attribute__((address_space(1))) char* gchar;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const gchar r = (gchar)(__attribute__((address_space(1))) float*)pin_uniform(orow + (int64_t)k * a.ch_stride);
+                const uint32_t xb = (uint32_t)x0 * 4u;
+                if (both) {
+                    typedef float f2u __attribute__((ext_vector_type(2)));
+                    typedef f2u f2u_a4 __attribute__((aligned(4)));
+                    const f2u q = {p0.v[k], p1.v[k]};
+                    __builtin_nontemporal_store(q, (__attribute__((address_space(1))) f2u_a4*)(r + xb));
+                } else {
+                    __builtin_nontemporal_store(p0.v[k], (__attribute__((address_space(1))) float*)(r + xb));
+                }
+            }
+        }
+    };
+
+    if constexpr (RPW == 1) {
+        finish_row(load_row(row0), row0);
+    } else {
+        // the wave's rows one after the other, the NEXT row's tap words requested before this row is computed: across the chip the
+        // rows' loads and stores interleave in time (a launch of one-row waves reads everything, then writes everything)
+        Raw r0 = load_row(row0), r1;
+#pragma unroll
+        for (int j = 0; j < RPW; j += 2) {
+            r1 = load_row(row0 + j + 1);
+            finish_row(r0, row0 + j);
+            if (j + 2 < RPW) r0 = load_row(row0 + j + 2);
+            finish_row(r1, row0 + j + 1);
+        }
+    }
+}
+
+// Host side: 1 launched / 0 not eligible / < 0 error (as launch_nv12).  `c.prog` holds the chain's program with its trailing
+// stages as launch_nv12 prepared them (fast_div set up); prog_swap says which compile-time program it is.
+int launch_nv12_x2(const ChainArgs& c, const PlaneParams* planes, int n_planes, bool prog_swap, void* stream, bool dry_run) {
+    const ReadArgs& r = c.read;
+    const WriteArgs& w = c.write;
+    if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR || (r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21) || r.out_cn != 3) return 0;
+    if (r.table || w.data2 || w.depth != CVGS_DEPTH_32F || (w.kind != CVGS_WRITE_TENSOR_SPLIT && w.kind != CVGS_WRITE_TENSOR_T_SPLIT)) return 0;
+    if (r.batch < 1 || r.batch > kN2Planes || r.used != r.batch || n_planes != r.batch || r.dst_w < 2) return 0;
+    N2Args a;
+    for (int i = 0; i < kN2Planes; ++i) {
+        const PlaneParams& p = planes[i < n_planes ? i : 0];
+        if (i < n_planes && (p.w < 4 || p.x1 != 0 || p.y1 != 0 || p.x2 != r.dst_w - 1 || p.y2 != r.dst_h - 1)) return 0;
+        a.plane[i] = N2Plane{p.data, p.w, p.h, p.step, p.uv_off, p.fx, p.fy};
+    }
+    if (dry_run) return 1;
+    a.out = (float*)w.data;
+    a.img_stride = w.img_stride;
+    a.ch_stride = w.ch_stride;
+    a.dst_w = r.dst_w;
+    a.dst_h = r.dst_h;
+    a.out_w = w.width;
+    a.yuv_range = r.yuv_range;
+    a.yuv_primaries = r.yuv_primaries;
+    a.yuv_vu = r.yuv_layout == CVGS_YUV_NV21;
+    a.prog = c.prog;
+    // rows per wave: 1 (small / odd-width targets: maximum parallelism, the last lane may store ONE pixel) or kN2Rows, walked with the
+    // next row's loads in flight (even widths, tensors below 4 GB: the stores go through one buffer descriptor)
+    const int64_t total_bytes = ((int64_t)(r.batch - 1) * w.img_stride + 2 * w.ch_stride + (int64_t)r.dst_h * w.width) * 4;
+    static const char* rows_env = getenv("CVGS_K4_X2_ROWS"); // tuning hook (benchmarks only): 1 = one row per wave always
+    const bool pipe = !(rows_env && rows_env[0] == '1') && (r.dst_w & 1) == 0 && total_bytes > 0 && total_bytes < ((int64_t)1 << 32) - 65536 &&
+                      (int64_t)r.batch * r.dst_h * ((r.dst_w + 127) / 128) >= 4096;
+    a.out_bytes = pipe ? (uint32_t)total_bytes : 0u;
+    const int rpw = pipe ? kN2Rows : 1;
+    const unsigned col_tiles = (unsigned)((r.dst_w + 127) / 128), row_groups = (unsigned)((r.dst_h + kN2Waves * rpw - 1) / (kN2Waves * rpw));
+    const dim3 grid(col_tiles, row_groups, (unsigned)r.batch), block(64 * kN2Waves);
+    hipStream_t s = (hipStream_t)stream;
+    if (prog_swap) {
+        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, kN2Rows>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, 1>), grid, block, 0, s, a);
+    } else {
+        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, kN2Rows>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, 1>), grid, block, 0, s, a);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : -(int)e - 1000;
+}
+
+} // namespace cvgs

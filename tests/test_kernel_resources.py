@@ -51,6 +51,7 @@ HOT = (  # mangled-name fragments of the kernels behind BASELINE's configs
     "k1_resize_splitILi3ELi64ELi1ENS_6K1ProgIJLi100ELi2ELi4ELi5EEEELi0EfLi0E",   # cfg #2: the 50-crop headline (1 row per wave)
     "k1_resize_splitILi3ELi64ELi2ENS_6K1ProgIJLi100ELi2ELi4ELi5EEEELi0EfLi0E",   # the same, 2 rows per wave (large batches)
     "k4_nv12_resizeILi64ENS_6K1ProgIJLi100ELi2ELi4ELi5EEEEfLi1ELi3E",            # cfg #3: NV12 -> BGR -> resize -> normalize -> split
+    "k4_nv12_x2INS_6K1ProgIJLi100ELi2ELi4ELi5EEEELi1E",                          # the same at frame size, two pixels per lane
     "k_pointwise4ILi3ELi64ENS_10StaticProgIJLi1ELi2ELi4ELi5EEEEfLi0E",           # K5/K6: the regression's kernel
     "k_circular_pushILi3ENS_10StaticProgIJLi1ELi2ELi4ELi5EEEEfE",                # cfg #4: CircularTensor push
     "k_plane_copyIDv4_fLi8E",                                                    # cfg #4: the shift

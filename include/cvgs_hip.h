@@ -381,7 +381,9 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  *   cvgs_queue_wait     host waits for a ticket (batches complete in order); cvgs_queue_stream_wait makes a HIP stream
  *                       wait for it instead (hipStreamWaitValue64 on the queue's completion counter), the consumer's kernels
  *                       enqueued behind it see the tensor.
- * One host thread at a time per queue (submits are serialised by a mutex).  No reference counterpart.                  */
+ * Submits from several host threads are serialised by a mutex (tickets are handed out in submit order).  cvgs_queue_destroy
+ * completes the batches in flight first (the workers drain the ring before they see the stop word), then retires the server.
+ * No reference counterpart.                                                                                           */
 typedef struct cvgs_queue_s* cvgs_queue_t;
 int cvgs_queue_create(cvgs_queue_t* out, int32_t device, int32_t depth, double idle_us, uint32_t flags);
 int cvgs_queue_submit(cvgs_queue_t q, const cvgs_chain_desc* chain, uint64_t* ticket);

@@ -379,3 +379,39 @@ def test_queue_serves_one_kind(torch_dev):
             q.submit(*_nv12_ops([lu], cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), (64, 128), capi.YUV_FULL, capi.BT709, capi.YUV_I420))
     finally:
         q.destroy()
+
+
+def test_queue_two_host_threads_and_destroy_with_batches_in_flight(oracle, torch_dev):
+    """submits are serialised by the queue's mutex: two host threads feeding ONE queue get every batch right; destroying a queue
+    with batches in flight completes them first (the workers drain the ring before they see the stop word)"""
+    import threading
+    torch, dev = torch_dev
+    frame = H.random_u8((720, 1280, 3), seed=77)
+    frame_t = torch.from_numpy(frame).to(dev)
+    q = cvgs.Queue(depth=16)
+    jobs, errors = [], []
+    lock = threading.Lock()
+
+    def feed(tid):
+        try:
+            for i in range(30):
+                crops = H.random_crops(8, 1280, 720, wmax=300, hmax=400, seed=1000 * tid + i)
+                out_t, ops = gpu_chain(torch, dev, frame_t, crops, 8, (64, 128), 3)
+                ticket = q.submit(*ops)
+                with lock:
+                    jobs.append((crops, out_t, ticket))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=feed, args=(t,)) for t in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(jobs) == 60 and sorted(j[2] for j in jobs) == list(range(60))
+    q.destroy()  # no wait in front of it: up to 16 batches are still in flight
+    torch.cuda.synchronize()
+    for crops, out_t, ticket in jobs:
+        H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, 8, (64, 128), 3), "ticket %d" % ticket)

@@ -4,6 +4,8 @@
 // One thread owns SIXTEEN x-adjacent pixels: CN 16-byte loads, OCN 16-byte non-temporal stores (a 4K BGR -> RGB frame is
 // 24.9 MB in + 24.9 MB out: a streaming copy with a shuffle in the middle).  Bit-identical to the interpreted
 // pointwise4_u8_u8 kernel, which keeps every other u8 -> u8 program, ragged widths and unaligned images.
+#include <cstring>
+
 #include "k_pointwise_body.hpp"
 
 #ifndef CVGS_CC_LOAD
@@ -161,6 +163,61 @@ __global__ __launch_bounds__(256) void k_u8_gray16(const KernArgs<NPL> a, const 
     }
 }
 
+// CV_32F -> CV_32F colour conversions (the reference's cvtColor test sweeps float types too, tests/color/test_cvtColor.cu:105-123):
+// four pixels per thread -- the same 16 CN bytes per lane as sixteen u8 pixels, through the same wave-private LDS region, so every
+// global access is a fully coalesced 1 KB instruction.  MODE 0 / 1: channel permutation (identity / R<->B swap, +- alpha);
+// MODE 2 / 3: *2GRAY with R, G, B at channels 0,1,2 / 2,1,0 (apply_op's expression: (R 0.299 + G 0.587) + B 0.114, no rounding for
+// float pixels); every other order stays on the interpreted kernel.
+template <int CN, int OCN, int MODE, int NPL>
+__global__ __launch_bounds__(256) void k_f32_colour4(const KernArgs<NPL> a, const PwGeom g, const uint32_t alpha_bits) {
+    constexpr int MAXC = CN > OCN ? CN : OCN;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][256 * MAXC];
+    const ChainArgs& c = a.c;
+    const int z = (int)blockIdx.z;
+    PlaneParams P;
+    if constexpr (NPL == 0) P = c.read.table[z];
+    else P = a.planes[z];
+    const int W = g.w, H = g.h;
+    asm volatile("" ::"s"(W), "s"(H), "s"(P.step), "s"(P.data), "s"(g.out), "s"(g.row_pitch), "s"(g.img_stride));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int tile_px0 = (int)blockIdx.x * 256; // 4 pixels per lane
+    const int y = (int)blockIdx.y * 4 + wave;
+    if (y >= H) return; // wave-uniform
+    const gp_u8c row = (gp_u8c)P.data + (size_t)y * (size_t)P.step;
+    uint32_t* const lw = lds[wave];
+    uint32_t in[4 * CN];
+    load_chunk16<CN>(row, tile_px0 * 4, W * 4, lane, lw, in); // (in units of 4-byte "pixels" of CN bytes: the same byte layout)
+    uint32_t out[4 * OCN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (MODE < 2) {
+#pragma unroll
+            for (int ch = 0; ch < OCN; ++ch) {
+                if (ch == 3 && CN == 3) out[i * OCN + ch] = alpha_bits;
+                else out[i * OCN + ch] = in[i * CN + (ch < 3 ? (MODE == 1 ? 2 - ch : ch) : 3)];
+            }
+        } else {
+            const float r = __uint_as_float(in[i * CN + (MODE == 2 ? 0 : 2)]), gg = __uint_as_float(in[i * CN + 1]), b = __uint_as_float(in[i * CN + (MODE == 2 ? 2 : 0)]);
+            out[i] = __float_as_uint((r * 0.299f + gg * 0.587f) + b * 0.114f);
+        }
+    }
+    __attribute__((address_space(1))) uint8_t* orow =
+        (__attribute__((address_space(1))) uint8_t*)g.out + (size_t)z * (size_t)g.img_stride + (size_t)y * (size_t)g.row_pitch;
+    const int out_row_bytes = W * OCN * 4, out_b0 = tile_px0 * OCN * 4;
+#pragma unroll
+    for (int k = 0; k < OCN; ++k) {
+        const u32x4a v = {out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]};
+        *(u32x4a*)(lw + 4 * OCN * lane + 4 * k) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < OCN; ++k) {
+        const int off = out_b0 + 1024 * k + 16 * lane;
+        const u32x4a v = *(const u32x4a*)(lw + 256 * k + 4 * lane);
+        if (off < out_row_bytes) CVGS_CC_STORE(v, (gp_u32x4_w)(orow + (uint32_t)off));
+    }
+}
+
 template <int NPL>
 static void fill_args(KernArgs<NPL>& a, const ChainArgs& c, const PlaneParams* ip, int ni) {
     a.c = c;
@@ -252,6 +309,55 @@ int launch_u8_colour16(const ChainArgs& c, const PlaneParams* ip, int ni, const 
     else if (op == CVGS_OP_REORDER) e = r.cn == 3 ? launch_perm<3, 3, PERM_SWAP>(c, ip, ni, g, 0, s) : launch_perm<4, 4, PERM_SWAP>(c, ip, ni, g, 0, s);
     else if (op == CVGS_OP_ADD_ALPHA) e = perm == PERM_SWAP ? launch_perm<3, 4, PERM_SWAP>(c, ip, ni, g, alpha, s) : launch_perm<3, 4, PERM_ID>(c, ip, ni, g, alpha, s);
     else e = perm == PERM_SWAP ? launch_perm<4, 3, PERM_SWAP>(c, ip, ni, g, 0, s) : launch_perm<4, 3, PERM_ID>(c, ip, ni, g, 0, s);
+    return e == hipSuccess ? 1 : -(int)e - 1000;
+}
+
+template <int CN, int OCN, int MODE>
+static hipError_t launch_f32c(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, uint32_t alpha_bits, hipStream_t s) {
+    const dim3 grid((g.w / 4 + 63) / 64, (g.h + 3) / 4, c.read.batch);
+    KernArgs<CVGS_KERNARG_PLANES> a;
+    fill_args(a, c, ip, ni);
+    hipLaunchKernelGGL((k_f32_colour4<CN, OCN, MODE, CVGS_KERNARG_PLANES>), grid, dim3(256), 0, s, a, g, alpha_bits);
+    return hipGetLastError();
+}
+
+// CV_32F -> CV_32F chains that are ONE colour conversion.  Returns 1 if it took the chain, 0 if not eligible, <0 on error.
+int launch_f32_colour4(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, void* stream, bool dry_run, LaunchInfo* info) {
+    const ReadArgs& r = c.read;
+    const ProgArgs& p = c.prog;
+    if (p.n != 1 || r.used != r.batch || (g.w & 3) || r.cn < 3 || r.table) return 0;
+    const int op = p.opcode[0], aux = p.aux[0];
+    constexpr int kId3 = 0 | (1 << 2) | (2 << 4), kSwap3 = 2 | (1 << 2) | (0 << 4);
+    int mode = -1;
+    if (op == CVGS_OP_REORDER) {
+        if ((r.cn == 3 && aux == kSwap3) || (r.cn == 4 && aux == (kSwap3 | (3 << 6)))) mode = 1;
+    } else if (op == CVGS_OP_ADD_ALPHA || op == CVGS_OP_DROP_ALPHA) {
+        if ((aux & 63) == kId3) mode = 0;
+        else if ((aux & 63) == kSwap3) mode = 1;
+    } else if (op == CVGS_OP_GRAY) {
+        if ((aux & 63) == kId3) mode = 2;
+        else if ((aux & 63) == kSwap3) mode = 3;
+    }
+    if (mode < 0) return 0;
+    uint32_t alpha_bits = 0;
+    if (op == CVGS_OP_ADD_ALPHA) std::memcpy(&alpha_bits, &p.operand[0][0], 4); // the interpreted kernel stores operand[0] as it is
+    if (((uintptr_t)g.out & 15) || (g.row_pitch & 15) || (g.img_stride & 15)) return 0;
+    for (int i = 0; i < ni; ++i)
+        if (((uintptr_t)ip[i].data & 15) || (ip[i].step & 15)) return 0;
+    if (info) info->kernel = mode >= 2 ? "pointwise4_f32_gray" : "pointwise4_f32_permute";
+    if (dry_run) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (mode >= 2) {
+        if (r.cn == 3) e = mode == 2 ? launch_f32c<3, 1, 2>(c, ip, ni, g, 0, s) : launch_f32c<3, 1, 3>(c, ip, ni, g, 0, s);
+        else e = mode == 2 ? launch_f32c<4, 1, 2>(c, ip, ni, g, 0, s) : launch_f32c<4, 1, 3>(c, ip, ni, g, 0, s);
+    } else if (op == CVGS_OP_REORDER) {
+        e = r.cn == 3 ? launch_f32c<3, 3, 1>(c, ip, ni, g, 0, s) : launch_f32c<4, 4, 1>(c, ip, ni, g, 0, s);
+    } else if (op == CVGS_OP_ADD_ALPHA) {
+        e = mode == 1 ? launch_f32c<3, 4, 1>(c, ip, ni, g, alpha_bits, s) : launch_f32c<3, 4, 0>(c, ip, ni, g, alpha_bits, s);
+    } else {
+        e = mode == 1 ? launch_f32c<4, 3, 1>(c, ip, ni, g, 0, s) : launch_f32c<4, 3, 0>(c, ip, ni, g, 0, s);
+    }
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 

@@ -239,6 +239,25 @@ static int launch_pointwise_u16u16(const ChainArgs& c, const PlaneParams* ip, in
     return launch_u8_colour16(c, ip, ni, g, s, dry_run, info);
 }
 
+// CV_32F -> CV_32F colour conversions: the compile-time permutation / gray kernels of k_cvtcolor_u8.hip, four pixels per thread
+static int launch_pointwise_f32f32(const ChainArgs& c, const PlaneParams* ip, int ni, uint32_t chain_flags, hipStream_t s, bool dry_run,
+                                   LaunchInfo* info) {
+    const ReadArgs& r = c.read;
+    const WriteArgs& w = c.write;
+    if (chain_flags & CVGS_CHAIN_NO_THREAD_FUSION) return 0;
+    if (r.kind != CVGS_READ_PIXEL || r.depth != CVGS_DEPTH_32F || w.depth != CVGS_DEPTH_32F || r.batch > 65535) return 0;
+    if (w.kind != CVGS_WRITE_PIXEL_2D && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
+    if (w.data2 || r.table || ni > CVGS_KERNARG_PLANES) return 0;
+    PwGeom g;
+    g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = r.cn; g.packed = 1; g.narrow = 0;
+    g.out = w.data; g.out2 = nullptr;
+    g.row_pitch = w.kind == CVGS_WRITE_PIXEL_2D ? w.step : w.width * w.cn * 4;
+    g.row_pitch2 = 0;
+    g.img_stride = w.kind == CVGS_WRITE_PIXEL_2D ? 0 : (int64_t)w.img_stride * w.cn * 4; // bytes
+    g.img_stride2 = g.ch_stride = g.ch_stride2 = 0;
+    return launch_f32_colour4(c, ip, ni, g, s, dry_run, info);
+}
+
 // Eligibility + geometry of the thread-fused path, shared with the single-launch CircularTensor push (k_circular.hip).
 // On success `c` is the chain to run (an fp16 target's trailing CAST is folded into the store), `g` the geometry.
 bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, ChainArgs& c, PwGeom& g, int& prog_id, bool& f16, bool* u8out) {
@@ -333,6 +352,10 @@ int launch_pointwise(const ChainArgs& c_in, const PlaneParams* inline_planes, in
     }
     {
         const int rc = launch_pointwise_u16u16(c_in, inline_planes, n_inline, chain_flags, (hipStream_t)stream, dry_run, info);
+        if (rc) return rc;
+    }
+    {
+        const int rc = launch_pointwise_f32f32(c_in, inline_planes, n_inline, chain_flags, (hipStream_t)stream, dry_run, info);
         if (rc) return rc;
     }
     ChainArgs c;

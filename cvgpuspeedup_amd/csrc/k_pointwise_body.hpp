@@ -106,6 +106,7 @@ struct PwGeom {
 
 // u8 -> u8 colour conversions as compile-time programs (k_cvtcolor_u8.hip); 1 = took the chain, 0 = not eligible
 int launch_u8_colour16(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, void* stream, bool dry_run, LaunchInfo* info);
+int launch_f32_colour4(const ChainArgs& c, const PlaneParams* ip, int ni, const PwGeom& g, void* stream, bool dry_run, LaunchInfo* info);
 
 // source element -> the work pixel's float (8/16-bit integers exact, CV_32S as raw bits, CV_32F as is: load_px's rule)
 template <int SD>

@@ -544,6 +544,42 @@ def test_u16_colour_conversions_fast_and_interpreted_agree_with_oracle(oracle, n
     H.assert_bit_exact(out_t.cpu().numpy().view(np.uint16), ref, "%s %s interpreted" % (name, shape))
 
 
+@pytest.mark.parametrize("name,code,icn,ocn", _CODES, ids=[c[0] for c in _CODES])
+@pytest.mark.parametrize("shape", [(37, 640, 1), (3, 4096, 2), (9, 4, 2), (7, 637, 1), (5, 260, 1)])
+def test_f32_colour_conversions_fast_and_interpreted_agree_with_oracle(oracle, name, code, icn, ocn, shape):
+    """The same codes on CV_32F images (tests/color/test_cvtColor.cu:105-123 sweeps CV_32FC3 / C4 too): widths that are multiples
+    of 4 take the four-pixels-per-thread kernels (channel permutations move bits: NaNs, infinities and -0 travel unchanged;
+    gray is (R 0.299 + G 0.587) + B 0.114 without rounding), ragged widths stay on the interpreted kernel."""
+    import torch
+    dev = torch.device("cuda:0")
+    h, w, batch = shape
+    it, ot = cvgs.make_type(cvgs.CV_32F, icn), cvgs.make_type(cvgs.CV_32F, ocn)
+    srcs = [(H.random_u16((h, w, icn), seed=900 + b).astype(np.float32) / 64.0 - 300.0).astype(np.float32) for b in range(batch)]
+    srcs[0][0, :4, 0] = [np.inf, -np.inf, -0.0, 3.0e38]
+    ts = [torch.from_numpy(s).to(dev) for s in srcs]
+
+    def chain(mats, out):
+        if batch == 1:
+            return [cvgs.ReadIOp(capi.READ_PIXEL, it, [mats[0]], 1), cvgs.cvtColor(code, it, ot), cvgs.write(ot, out)]
+        return [cvgs.ReadIOp(capi.READ_PIXEL, it, mats, batch), cvgs.cvtColor(code, it, ot), cvgs.write(ot, out, (w, h))]
+
+    shape_o = (h, w, ocn) if batch == 1 else (batch, h * w, ocn)
+    out_t = torch.zeros(shape_o, dtype=torch.float32, device=dev)
+    ref = np.zeros(shape_o, np.float32)
+    g_ops = chain([cvgs.GpuMat.from_tensor(t, it) for t in ts], cvgs.GpuMat.from_tensor(out_t, ot))
+    name_k = cvgs.kernel_name(*g_ops)
+    assert (name_k in ("pointwise4_f32_gray", "pointwise4_f32_permute")) == (w % 4 == 0), (name_k, shape)
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops)
+    torch.cuda.synchronize()
+    oracle.execute(cvgs.lower(chain([cvgs.GpuMat.from_array(s, it) for s in srcs], cvgs.GpuMat.from_array(ref, ot))))
+    assert ref.any()
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "%s %s via %s" % (name, shape, name_k))
+    out_t.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *g_ops, flags=capi.CHAIN_NO_THREAD_FUSION)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(out_t.cpu().numpy(), ref, "%s %s interpreted" % (name, shape))
+
+
 @pytest.mark.parametrize("name,code", [("RGB2GRAY", cvgs.COLOR_RGB2GRAY), ("BGR2GRAY", cvgs.COLOR_BGR2GRAY)])
 def test_u8_gray_every_rgb_triple(oracle, name, code):
     """EVERY 8-bit (c0, c1, c2) triple through the compile-time-order gray kernel (whose store-side conversion does the

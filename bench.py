@@ -641,6 +641,14 @@ def extra_sweeps(dev, a):
         # half-precision hand-off option: same chain + convertTo<CV_32FC3, CV_16FC3>, fp16 NCHW tensor
         for crops in (50, 3200):
             out["fp16_output_%d" % crops] = sweep_line(dev, crops, half=True)
+        # the fp16 tensor through the descriptor queue (one submit per frame, as the headline)
+        per_frame = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + 50 * 3 * 64 * 128 * 2
+        wlq = Workload(dev, max(4, min(48, (2 * INFINITY_CACHE) // per_frame + 1)), 50, 0, 1, False, half=True)
+        mq = measure_queue(wlq, 256, 64, target_s=0.08, min_replays=10, events=False)
+        out["fp16_output_50_queue"] = {"us_per_step": round(mq["step_s"] * 1e6, 3), "Mpix_per_s": round(50 * 8192 / mq["step_s"] / 1e6, 1),
+                                       "every_frame_bit_identical_to_cvgs_execute": queue_outputs_match_execute(wlq), "queue_error": mq["queue"]["error"]}
+        del wlq
+        torch.cuda.empty_cache()
         wl = Workload(dev, 24, 50, 0, 1, use_table=False)
         m = measure(wl, 256, 64, eager=True, target_s=0.05, min_replays=20)
         s = torch.cuda.current_stream().cuda_stream

@@ -70,13 +70,14 @@ struct QParams {
     uint64_t arrive_target;        // value of the slot's TOP arrival counter when the batch's last sub-counter has filled
     uint32_t kind;                 // QK_*: what the planes are
     uint32_t yuv_range, yuv_primaries, yuv_vu; // QK_NV12: cvgs_yuv_range / cvgs_yuv_primaries, V-before-U (NV21)
-    uint32_t pad[14];
+    uint32_t out_half;             // the tensor holds CV_16F elements (the chain's trailing convertTo<CV_32F, CV_16F> is the store's conversion)
+    uint32_t pad[13];
 };
 static_assert(sizeof(QParams) == 256, "QParams is one wave-wide dword load");
 enum { QD_STAMP = 0, QD_TASK_BASE = 2, QD_N_TASKS = 4, QD_TPP = 5, QD_COL_TILES = 6, QD_N_PLANES = 7, QD_USED = 8, QD_DST_W = 9, QD_DST_H = 10,
        QD_OUT_W = 11, QD_CN = 12, QD_SWAP = 13, QD_FAST_DIV = 14, QD_ROWS_PER_TASK = 15, QD_MUL = 16, QD_SUB = 20, QD_DIV = 24, QD_RDIV = 28, QD_BG = 32,
        QD_IMG_STRIDE = 36, QD_CH_STRIDE = 38, QD_OUT = 40, QD_OUT_BYTES = 42, QD_ARRIVE_TARGET = 44, QD_KIND = 46, QD_YUV_RANGE = 47,
-       QD_YUV_PRIM = 48, QD_YUV_VU = 49 };
+       QD_YUV_PRIM = 48, QD_YUV_VU = 49, QD_OUT_HALF = 50 };
 // What a queue serves -- latched by its first submit; each kind has its own server instantiation (the 8-bit-pixel worker is the
 // tuned headline path and carries nothing of the other's code or registers).
 enum { QK_PIXELS = 0 /* 8UC3 / 8UC4 crops (K1's shape) */, QK_NV12 = 1 /* crops of NV12 / NV21 decoder surfaces (K4's shape) */ };
@@ -170,6 +171,7 @@ struct QTask { // everything a wave needs for its 4 rows, wave-uniform
     uint8_t* out;
     uint32_t out_bytes;
     int32_t yuv_range, yuv_primaries, yuv_vu; // QK_NV12 only
+    int32_t out_half;                         // CV_16F tensor: 2-byte elements, round-to-nearest-even in the store
 };
 
 // One wave's share of a task: rows row0..row0+3 of plane z, columns col_tile*64 + lane.  K1's arithmetic (k_k1_impl.hpp:
@@ -183,8 +185,9 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
     if (row0 >= dst_h) return; // wave-uniform
     const bool live = x < dst_w;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(t.out, 0, (int)t.out_bytes, 0x00020000);
-    const uint32_t plane_off = (uint32_t)((int64_t)z * t.img_stride * 4); // byte offsets fit 32 bits (checked at submit)
-    const uint32_t ch_bytes = (uint32_t)(t.ch_stride * 4);
+    const uint32_t esh = t.out_half ? 1u : 2u; // log2 of the element size (wave-uniform)
+    const uint32_t plane_off = (uint32_t)(((int64_t)z * t.img_stride) << esh); // byte offsets fit 32 bits (checked at submit)
+    const uint32_t ch_bytes = (uint32_t)(t.ch_stride << esh);
     ProgArgs prog; // registers: only the static program's operands are ever read
     prog.fast_div = t.fast_div;
 #pragma unroll
@@ -208,24 +211,34 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
         if (ST == 2 && full) {
             const int i = lane & 3, q = lane >> 2;
             const bool row_ok = row0 + i < dst_h;
-            const uint32_t off = plane_off + (uint32_t)(((row0 + i) * W + col_tile * 64 + q * 4) * 4);
+            const uint32_t off = plane_off + ((uint32_t)((row0 + i) * W + col_tile * 64 + q * 4) << esh);
 #pragma unroll
             for (int k = 0; k < CN; ++k) {
                 const float r[4] = {v[0][k], v[1][k], v[2][k], v[3][k]};
                 float o[4];
                 q_quad_transpose(r, o, lane);
-                typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
-                const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-                if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                if (t.out_half) { // wave-uniform: four halves, 8 bytes per lane
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
+                    const h2 lo = {(_Float16)o[0], (_Float16)o[1]}, hi = {(_Float16)o[2], (_Float16)o[3]};
+                    const u32x2q d = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                } else {
+                    typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+                    const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < kQRowsPerWave; ++j) {
                 if (row0 + j < dst_h && live) {
-                    const uint32_t off = plane_off + (uint32_t)(((row0 + j) * W + x) * 4);
+                    const uint32_t off = plane_off + ((uint32_t)((row0 + j) * W + x) << esh);
 #pragma unroll
-                    for (int k = 0; k < CN; ++k)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                    for (int k = 0; k < CN; ++k) {
+                        if (t.out_half) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 : 16);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                    }
                 }
             }
         }
@@ -337,8 +350,9 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     if (row0 >= dst_h) return; // wave-uniform
     const bool live = x < dst_w;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(t.out, 0, (int)t.out_bytes, 0x00020000);
-    const uint32_t plane_off = (uint32_t)((int64_t)z * t.img_stride * 4);
-    const uint32_t ch_bytes = (uint32_t)(t.ch_stride * 4);
+    const uint32_t esh = t.out_half ? 1u : 2u; // log2 of the element size (wave-uniform)
+    const uint32_t plane_off = (uint32_t)(((int64_t)z * t.img_stride) << esh);
+    const uint32_t ch_bytes = (uint32_t)(t.ch_stride << esh);
     ProgArgs prog;
     prog.fast_div = t.fast_div;
 #pragma unroll
@@ -362,24 +376,34 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
         if (ST == 2 && full) {
             const int i = lane & 3, q = lane >> 2;
             const bool row_ok = row0 + i < dst_h;
-            const uint32_t off = plane_off + (uint32_t)(((row0 + i) * W + col_tile * 64 + q * 4) * 4);
+            const uint32_t off = plane_off + ((uint32_t)((row0 + i) * W + col_tile * 64 + q * 4) << esh);
 #pragma unroll
             for (int k = 0; k < CN; ++k) {
                 const float r[4] = {v[0][k], v[1][k], v[2][k], v[3][k]};
                 float o[4];
                 q_quad_transpose(r, o, lane);
-                typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
-                const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-                if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                if (t.out_half) { // wave-uniform: four halves, 8 bytes per lane
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
+                    const h2 lo = {(_Float16)o[0], (_Float16)o[1]}, hi = {(_Float16)o[2], (_Float16)o[3]};
+                    const u32x2q d = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                } else {
+                    typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+                    const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < kQRowsPerWave; ++j) {
                 if (row0 + j < dst_h && live) {
-                    const uint32_t off = plane_off + (uint32_t)(((row0 + j) * W + x) * 4);
+                    const uint32_t off = plane_off + ((uint32_t)((row0 + j) * W + x) << esh);
 #pragma unroll
-                    for (int k = 0; k < CN; ++k)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                    for (int k = 0; k < CN; ++k) {
+                        if (t.out_half) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 : 16);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                    }
                 }
             }
         }
@@ -742,6 +766,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             t.ch_stride = (int64_t)q_lane_u64(v, QD_CH_STRIDE);
             t.out = (uint8_t*)q_lane_u64(v, QD_OUT);
             t.out_bytes = (uint32_t)q_lane_u64(v, QD_OUT_BYTES);
+            t.out_half = (int)q_lane_u32(v, QD_OUT_HALF);
             [[maybe_unused]] const bool c3 = q_lane_u32(v, QD_CN) == 3;
             {
                 pre_wb = b;
@@ -986,10 +1011,11 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     const bool nv12 = r.kind == CVGS_READ_NV12_RESIZE_LINEAR;
     const int kind = nv12 ? QK_NV12 : QK_PIXELS;
     const int vcn = nv12 ? r.out_cn : r.cn; // channels of the value the program sees
-    if (!planar || w.depth != CVGS_DEPTH_32F || w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch ||
+    const bool half = w.depth == CVGS_DEPTH_16F; // the half-precision hand-off: the chain ends with CAST(CV_16F), which the store performs
+    if (!planar || (w.depth != CVGS_DEPTH_32F && !half) || w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch ||
         (!nv12 && (r.kind != CVGS_READ_RESIZE_LINEAR || r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4))) ||
         (nv12 && ((r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21) || r.out_cn != 3))) {
-        err = "queue: chain is not a batched 8UC3 / 8UC4 (or NV12 / NV21 -> 3 channels) resize into an fp32 planar tensor with <= 74 inline planes";
+        err = "queue: chain is not a batched 8UC3 / 8UC4 (or NV12 / NV21 -> 3 channels) resize into an fp32 / fp16 planar tensor with <= 74 inline planes";
         return 1;
     }
     for (int i = 0; i < n_planes && i < r.used; ++i)
@@ -1000,6 +1026,13 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     ChainArgs c = c_in;
     c.prog.fast_div = 0;
     for (int k = 0; k < 4; ++k) c.prog.rdiv[k] = 0.f;
+    if (half) {
+        if (c.prog.n < 1 || c.prog.opcode[c.prog.n - 1] != CVGS_OP_CAST || c.prog.aux[c.prog.n - 1] != CVGS_DEPTH_16F) {
+            err = "queue: an fp16 tensor needs a chain that ends with convertTo<CV_32F, CV_16F>";
+            return 1;
+        }
+        c.prog.n -= 1;
+    }
     const int prog_id = k1_classify_program(c.prog, vcn);
     if (prog_id > 1) {
         err = "queue: the pointwise program must be [RGB<->BGR swap,] mul, sub, div";
@@ -1009,7 +1042,7 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     const int o = prog_id == 0 ? 1 : 0; // index of the MUL stage
     // output bytes addressed through ONE 32-bit-offset buffer descriptor
     const int64_t last = (int64_t)(r.batch - 1) * w.img_stride + (int64_t)(vcn - 1) * w.ch_stride + (int64_t)r.dst_h * w.width;
-    if (last <= 0 || last * 4 >= (int64_t)1 << 31) {
+    if (last <= 0 || last * (half ? 2 : 4) >= (int64_t)1 << 31) {
         err = "queue: output tensor beyond 2 GB";
         return 1;
     }
@@ -1090,7 +1123,8 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     p.img_stride = w.img_stride;
     p.ch_stride = w.ch_stride;
     p.out = (uint64_t)w.data;
-    p.out_bytes = (uint64_t)last * 4;
+    p.out_bytes = (uint64_t)last * (half ? 2 : 4);
+    p.out_half = half ? 1u : 0u;
     // cumulative arrival targets of the slot's counters (they are never reset): sub-counter s takes the tasks T = s (mod 16)
     uint64_t sub_targets[kQSubs];
     uint64_t* cum = &q->arrive_cum[k * (1 + kQSubs)];

@@ -155,10 +155,15 @@ def test_queue_refuses_what_the_server_does_not_take(torch_dev):
     q = cvgs.Queue()
     try:
         frame_t = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
-        out_t = torch.zeros((2, 3 * 64 * 128), dtype=torch.float16, device=dev)
-        ops = H.k1_chain(cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), H.fixed_crops(2), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_16FC1), half=True)
+        out_t = torch.zeros((2, 3 * 64 * 128), dtype=torch.float32, device=dev)
+        ops = H.k1_chain(cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3), H.fixed_crops(2), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1))
+        ops.insert(-1, cvgs.add(cvgs.CV_32FC3, [1.0, 2.0, 3.0]))  # a fourth arithmetic stage: not the server's program
         with pytest.raises(capi.CvgsError):
             q.submit(*ops)
+        frame16 = torch.zeros((480, 640, 3), dtype=torch.int16, device=dev)  # a 16-bit source: cvgs_execute's business
+        ops16 = H.k1_chain(cvgs.GpuMat.from_tensor(frame16, cvgs.CV_16UC3), H.fixed_crops(2), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), src_depth=cvgs.CV_16U)
+        with pytest.raises(capi.CvgsError):
+            q.submit(*ops16)
         # the queue is still usable afterwards
         out32, ops32 = gpu_chain(torch, dev, frame_t, H.fixed_crops(2), 2, (64, 128), 3)
         q.wait(q.submit(*ops32))
@@ -415,3 +420,51 @@ def test_queue_two_host_threads_and_destroy_with_batches_in_flight(oracle, torch
     torch.cuda.synchronize()
     for crops, out_t, ticket in jobs:
         H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, 8, (64, 128), 3), "ticket %d" % ticket)
+
+
+@pytest.mark.parametrize("cn,dst,kw", [(3, (64, 128), {}), (4, (64, 128), {}), (3, (100, 37), {"ar": cvgs.PRESERVE_AR, "background": [9.0, 8.0, 7.0, 0.0]}),
+                                       (3, (64, 128), {"used": 5, "background": [7.0, 8.0, 9.0, 0.0]})])
+def test_queue_fp16_tensor_matches_the_oracle(oracle, torch_dev, cn, dst, kw):
+    """the half-precision hand-off through the queue: the chain ends with convertTo<CV_32FCn, CV_16FCn>, the worker's stores convert"""
+    torch, dev = torch_dev
+    frame = H.random_u8((1080, 1920, cn), seed=13)
+    crops = H.random_crops(9, 1920, 1080, wmax=400, hmax=500, seed=17)
+    frame_t = torch.from_numpy(frame).to(dev)
+    q = cvgs.Queue()
+    try:
+        out_t = torch.full((9, cn * dst[0] * dst[1]), -7.0, dtype=torch.float16, device=dev)
+        ops = H.k1_chain(cvgs.GpuMat.from_tensor(frame_t, cvgs.make_type(cvgs.CV_8U, cn)), crops, cvgs.GpuMat.from_tensor(out_t, cvgs.CV_16FC1), dst, cn, half=True, **kw)
+        torch.cuda.synchronize()
+        q.wait(q.submit(*ops))
+        torch.cuda.synchronize()
+        ref = np.full((9, cn * dst[0] * dst[1]), -7.0, dtype=np.float16)
+        oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.make_type(cvgs.CV_8U, cn)), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_16FC1), dst, cn, half=True, **kw)))
+        H.assert_bit_exact(out_t.cpu().numpy(), ref, "fp16 queue batch %s %s" % (dst, kw))
+    finally:
+        q.destroy()
+
+
+def test_queue_nv12_fp16_tensor(oracle, torch_dev):
+    torch, dev = torch_dev
+    w, h, dst = 1280, 720, (96, 54)
+    surf = H.random_u8((h + h // 2, w), seed=23)
+    crops = _even_crops(6, w, h, seed=33)
+    f, hf = cvgs.CV_32FC3, cvgs.CV_16FC3
+
+    def ops_for(luma, out_mat):
+        return [cvgs.read_nv12([luma.nv12_roi(*c) for c in crops], dst, capi.YUV_LIMITED, capi.BT709, False), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
+                cvgs.multiply(f, [1 / 255.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225]),
+                cvgs.convertTo(f, hf), cvgs.split(hf, out_mat, dst)]
+
+    st = torch.from_numpy(surf).to(dev)
+    out_t = torch.zeros((6, 3 * dst[0] * dst[1]), dtype=torch.float16, device=dev)
+    q = cvgs.Queue()
+    try:
+        torch.cuda.synchronize()
+        q.wait(q.submit(*ops_for(cvgs.GpuMat(h, w, cvgs.CV_8UC1, st.data_ptr(), w, owner=st), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_16FC1))))
+        torch.cuda.synchronize()
+        ref = np.zeros((6, 3 * dst[0] * dst[1]), dtype=np.float16)
+        oracle.execute(cvgs.lower(ops_for(cvgs.GpuMat(h, w, cvgs.CV_8UC1, surf.ctypes.data, w, owner=surf), cvgs.GpuMat.from_array(ref, cvgs.CV_16FC1))))
+        H.assert_bit_exact(out_t.cpu().numpy(), ref, "NV12 fp16 queue batch")
+    finally:
+        q.destroy()

@@ -372,7 +372,7 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  *                       itself after this long without work (0 = 200 us) and the next submit starts a new one, so the grid
  *                       never outlives its work; a batch without progress for 250 ms is reported as CVGS_ERR_HIP, not waited for.
  *   cvgs_queue_submit   asynchronous; the chain must be K1's hot shape (batched 8UC3 / 8UC4 bilinear resize -> [RGB<->BGR]
- *                       mul, sub, div -> fp32 NCHW / CNHW tensor, host descriptors, <= 74 planes) or the same behind crops of
+ *                       mul, sub, div [-> convertTo CV_16F] -> fp32 / fp16 NCHW / CNHW tensor, host descriptors, <= 74 planes) or the same behind crops of
  *                       NV12 / NV21 decoder surfaces (CVGS_READ_NV12_RESIZE_LINEAR, 3 channels; letterboxing and default planes
  *                       included): anything else returns CVGS_ERR_UNSUPPORTED and belongs to cvgs_execute.  A queue serves ONE
  *                       of the two kinds -- its first submit decides, the other kind is then CVGS_ERR_UNSUPPORTED (each kind

@@ -1081,8 +1081,66 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
         if (rc) return rc;
     }
     if (ct->capturable) {
-        // device-indexed update: the chain writes the new frame into the staging image (standard order), the shift kernel
-        // derives every plane job from the device-side count (k_circular.hip: k_circular_dev), a last kernel advances it
+        CircDev dev{};
+        dev.out = ct->out;
+        dev.ring = ct->ring;
+        dev.stage = ct->stage;
+        dev.count = ct->dcount;
+        dev.plane_bytes = ct->plane_bytes;
+        dev.batch = ct->batch;
+        dev.color_planes = ct->color_planes;
+        dev.order = ct->order;
+        dev.transposed = ct->cp_mode == CVGS_PLANES_TRANSPOSED;
+        dev.mirrored = ct->mirrored;
+        // Per-pixel u8 pushes (the form the reference tests): ONE launch whose kernel reads the device-side count and derives the
+        // new frame's ring slot and every copy job itself -- the traffic of an eager update, no staging image
+        static const bool no_fused_dev = getenv("CVGS_NO_FUSED_PUSH") != nullptr;
+        if (!no_fused_dev) {
+            Lowered Lp;
+            cvgs_chain_desc onep = one;
+            onep.write.data = ct->ring;
+            onep.write.width = ct->width;
+            onep.write.height = ct->height;
+            onep.write.planes = ct->batch;
+            int rcp = lower(&onep, true, Lp);
+            if (rcp) return rcp;
+            if (Lp.out_w != ct->width || Lp.out_h != ct->height)
+                return fail(CVGS_ERR_INVALID, "the frame produced by the read stage differs from the CircularTensor's plane size");
+            if (!Lp.uses_64f && Lp.planes.size() == 1 && !Lp.args.read.table && Lp.dst_planes.empty()) {
+                const int64_t plane = (int64_t)ct->width * ct->height;
+                const int z_new = ct->order == CVGS_NEWEST_FIRST ? 0 : ct->batch - 1;
+                WriteArgs& Wa = Lp.args.write;
+                Wa.kind = wk == CVGS_WRITE_TENSOR_T_SPLIT ? CVGS_WRITE_TENSOR_SPLIT : wk;
+                Wa.planes = 1;
+                const int64_t std_img = wk == CVGS_WRITE_PIXEL_3D ? plane : plane * ct->color_planes, std_ch = wk == CVGS_WRITE_PIXEL_3D ? 0 : plane;
+                if (ct->mirrored) { // both targets are ring slots the kernel picks from the count
+                    Wa.data = ct->ring;
+                    Wa.img_stride = std_img;
+                    Wa.ch_stride = std_ch;
+                } else if (wk == CVGS_WRITE_TENSOR_T_SPLIT) {
+                    Wa.data = ct->out + (size_t)z_new * ct->plane_bytes;
+                    Wa.img_stride = plane;
+                    Wa.ch_stride = plane * ct->batch;
+                } else {
+                    Wa.data = ct->out + (size_t)z_new * ct->image_bytes;
+                    Wa.img_stride = std_img;
+                    Wa.ch_stride = std_ch;
+                }
+                Wa.data2 = ct->ring; // the kernel replaces it: ring slot count % BATCH (mirrored: slot p + BATCH)
+                Wa.img_stride2 = std_img;
+                Wa.ch_stride2 = std_ch;
+                const int n_jobs = ct->mirrored ? 0 : (ct->batch - 1) * ct->color_planes;
+                rcp = launch_circular_push(Lp.args, Lp.planes[0], nullptr, n_jobs, ct->plane_bytes, one.flags, stream, &dev);
+                if (rcp < 0) return fail(CVGS_ERR_HIP, "CircularTensor push launch failed");
+                if (rcp == 1) {
+                    if (launch_circular_bump(ct->dcount, stream)) return fail(CVGS_ERR_HIP, "CircularTensor count launch failed");
+                    ct->count++;
+                    return CVGS_OK;
+                }
+            }
+        }
+        // every other push: the chain writes the new frame into the staging image (standard order), the shift kernel derives every
+        // plane job from the device-side count (k_circular.hip: k_circular_dev), a last kernel advances it
         Lowered L;
         one.write.data = ct->stage;
         one.write.width = ct->width;
@@ -1102,18 +1160,7 @@ int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_
         Wa.ch_stride = wk == CVGS_WRITE_PIXEL_3D ? 0 : plane;
         rc = dispatch(&one, L, (hipStream_t)stream, false, nullptr);
         if (rc) return rc;
-        CircDev a{};
-        a.out = ct->out;
-        a.ring = ct->ring;
-        a.stage = ct->stage;
-        a.count = ct->dcount;
-        a.plane_bytes = ct->plane_bytes;
-        a.batch = ct->batch;
-        a.color_planes = ct->color_planes;
-        a.order = ct->order;
-        a.transposed = ct->cp_mode == CVGS_PLANES_TRANSPOSED;
-        a.mirrored = ct->mirrored;
-        if (launch_circular_dev(a, stream)) return fail(CVGS_ERR_HIP, "CircularTensor device-indexed shift launch failed");
+        if (launch_circular_dev(dev, stream)) return fail(CVGS_ERR_HIP, "CircularTensor device-indexed shift launch failed");
         ct->count++; // calls made (captured ones count once); the device-side count is the authority (cvgs_circular_updates)
         return CVGS_OK;
     }

@@ -215,7 +215,8 @@ int launch_circular_dev(const CircDev& a, void* stream);
 // single-launch CircularTensor update (new frame through the thread-fused pointwise chain + all plane copies):
 // returns 1 if it took the update, 0 if the chain / layout is not eligible, <0 on error
 int launch_circular_push(const ChainArgs& c, const PlaneParams& plane, const CopyJob* jobs, int n_jobs, size_t plane_bytes,
-                         uint32_t chain_flags, void* stream);
+                         uint32_t chain_flags, void* stream, const CircDev* dev = nullptr);
+int launch_circular_bump(const uint64_t* count, void* stream);
 
 
 // ---- device-side arrival flags of the P2P fused-write exchange (k_exchange.hip) ----------------------------------------------

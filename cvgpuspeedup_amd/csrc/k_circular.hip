@@ -24,17 +24,48 @@ struct PushGeom {
     size_t n_vec;                   // 16-byte vectors per plane
 };
 
-template <int CN, class Prog, typename OT>
-__global__ __launch_bounds__(256) void k_circular_push(const KernArgs<1> a, const PwGeom g, const CopyArgs jobs, const PushGeom pg) {
+// DEV (capturable handles, CVGS_CIRCULAR_CAPTURABLE): nothing that depends on the update count comes with the kernel arguments --
+// the kernel reads the count and derives the new frame's ring slot (both slots of a mirrored ring) and every copy job itself,
+// so a captured update replays as the NEXT update with the traffic of an eager one (no staging image).
+template <int CN, class Prog, typename OT, bool DEV = false>
+__global__ __launch_bounds__(256) void k_circular_push(const KernArgs<1> a, const PwGeom g, const CopyArgs jobs, const PushGeom pg, const CircDev d) {
     typedef float v4 __attribute__((ext_vector_type(4)));
+    int64_t count = 0;
+    if constexpr (DEV) count = (int64_t)*d.count; // updates completed before this one (wave-uniform)
     if (blockIdx.x < pg.pw_blocks) {
         const uint32_t by = blockIdx.x / pg.col_groups, bx = blockIdx.x - by * pg.col_groups;
-        pw4_body<CN, Prog, OT>(a.c, a.planes[0], g, (int)bx, (int)by, 0);
+        if constexpr (DEV) {
+            PwGeom g2 = g;
+            const size_t image_bytes = d.plane_bytes * (size_t)d.color_planes;
+            const int64_t km = count % d.batch;
+            if (d.mirrored) {
+                const int64_t p = d.order == CVGS_NEWEST_FIRST ? d.batch - 1 - km : km;
+                g2.out = d.ring + (size_t)p * image_bytes;
+                g2.out2 = d.ring + (size_t)(p + d.batch) * image_bytes;
+            } else {
+                g2.out2 = d.ring + (size_t)km * image_bytes; // (g.out: the new frame's tensor slot, the same for every update)
+            }
+            pw4_body<CN, Prog, OT>(a.c, a.planes[0], g2, (int)bx, (int)by, 0);
+        } else {
+            pw4_body<CN, Prog, OT>(a.c, a.planes[0], g, (int)bx, (int)by, 0);
+        }
         return;
     }
     const uint32_t b = blockIdx.x - pg.pw_blocks;
     const uint32_t j = b / pg.blocks_per_job, bx = b - j * pg.blocks_per_job;
-    const CopyJob job = jobs.jobs[j];
+    CopyJob job;
+    if constexpr (DEV) { // job j: plane c of the frame of age >= 1 shown at tensor slot z (k_circular_dev's derivation)
+        const int B = d.batch, CP = d.color_planes;
+        const int c = (int)j % CP, zi = (int)j / CP;
+        const int z = d.order == CVGS_NEWEST_FIRST ? zi + 1 : zi; // every slot but the new frame's (0 / B - 1)
+        const int64_t age = d.order == CVGS_NEWEST_FIRST ? z : B - 1 - z;
+        int64_t slot = (count - age) % B;
+        if (slot < 0) slot += B; // never-written history slots hold zeros
+        job.src = d.ring + ((size_t)slot * CP + c) * d.plane_bytes;
+        job.dst = d.transposed ? d.out + ((size_t)c * B + z) * d.plane_bytes : d.out + ((size_t)z * CP + c) * d.plane_bytes;
+    } else {
+        job = jobs.jobs[j];
+    }
     const v4* __restrict__ src = (const v4*)job.src;
     v4* __restrict__ dst = (v4*)job.dst;
     const size_t stride = (size_t)pg.blocks_per_job * 256;
@@ -52,55 +83,68 @@ __global__ __launch_bounds__(256) void k_circular_push(const KernArgs<1> a, cons
 
 template <int CN, typename OT>
 static hipError_t launch_push_prog(int prog_id, const KernArgs<1>& a, const PwGeom& g, const CopyArgs& jobs, const PushGeom& pg,
-                                   hipStream_t s) {
+                                   const CircDev* dev, hipStream_t s) {
     const dim3 grid(pg.pw_blocks + pg.blocks_per_job * pg.n_jobs);
-    if (prog_id == 0) hipLaunchKernelGGL((k_circular_push<CN, ProgCastMulSubDiv, OT>), grid, dim3(256), 0, s, a, g, jobs, pg);
-    else if (prog_id == 1) hipLaunchKernelGGL((k_circular_push<CN, ProgCast, OT>), grid, dim3(256), 0, s, a, g, jobs, pg);
-    else hipLaunchKernelGGL((k_circular_push<CN, InterpProg, OT>), grid, dim3(256), 0, s, a, g, jobs, pg);
+    if (dev) {
+        if (prog_id == 0) hipLaunchKernelGGL((k_circular_push<CN, ProgCastMulSubDiv, OT, true>), grid, dim3(256), 0, s, a, g, jobs, pg, *dev);
+        else if (prog_id == 1) hipLaunchKernelGGL((k_circular_push<CN, ProgCast, OT, true>), grid, dim3(256), 0, s, a, g, jobs, pg, *dev);
+        else hipLaunchKernelGGL((k_circular_push<CN, InterpProg, OT, true>), grid, dim3(256), 0, s, a, g, jobs, pg, *dev);
+        return hipGetLastError();
+    }
+    const CircDev none{};
+    if (prog_id == 0) hipLaunchKernelGGL((k_circular_push<CN, ProgCastMulSubDiv, OT>), grid, dim3(256), 0, s, a, g, jobs, pg, none);
+    else if (prog_id == 1) hipLaunchKernelGGL((k_circular_push<CN, ProgCast, OT>), grid, dim3(256), 0, s, a, g, jobs, pg, none);
+    else hipLaunchKernelGGL((k_circular_push<CN, InterpProg, OT>), grid, dim3(256), 0, s, a, g, jobs, pg, none);
     return hipGetLastError();
 }
 
 // Returns 1 if it took the update (new frame + all copies in ONE launch), 0 if not eligible, <0 on error.
+// `dev` (capturable handles): the kernel derives the count-dependent destinations and the n_jobs copy jobs itself (copy_jobs unused;
+// n_jobs = (BATCH - 1) * planes, or 0 for a mirrored ring); the caller advances the device-side count behind it.
 int launch_circular_push(const ChainArgs& c_in, const PlaneParams& plane, const CopyJob* copy_jobs, int n_jobs, size_t plane_bytes,
-                         uint32_t chain_flags, void* stream) {
+                         uint32_t chain_flags, void* stream, const CircDev* dev) {
     ChainArgs c;
     PwGeom g;
     int prog_id = 0;
     bool f16 = false;
     if (!pointwise4_plan(c_in, 1, chain_flags, c, g, prog_id, f16)) return 0;
     if (prog_id == 3) return 0; // non-u8 sources: chain kernel + copy kernel
-    if (n_jobs < 1 || n_jobs > kMaxCopyJobs || plane_bytes % 16) return 0;
-    for (int i = 0; i < n_jobs; ++i)
-        if ((((uintptr_t)copy_jobs[i].src | (uintptr_t)copy_jobs[i].dst) & 15) != 0) return 0;
+    if (n_jobs < (dev ? 0 : 1) || n_jobs > kMaxCopyJobs || plane_bytes % 16) return 0;
+    if (dev) {
+        if ((((uintptr_t)dev->out | (uintptr_t)dev->ring) & 15) != 0) return 0;
+    } else {
+        for (int i = 0; i < n_jobs; ++i)
+            if ((((uintptr_t)copy_jobs[i].src | (uintptr_t)copy_jobs[i].dst) & 15) != 0) return 0;
+    }
     KernArgs<1> a;
     a.c = c;
     a.planes[0] = plane;
     CopyArgs jobs;
-    for (int i = 0; i < kMaxCopyJobs; ++i) jobs.jobs[i] = i < n_jobs ? copy_jobs[i] : CopyJob{nullptr, nullptr};
+    for (int i = 0; i < kMaxCopyJobs; ++i) jobs.jobs[i] = (!dev && i < n_jobs) ? copy_jobs[i] : CopyJob{nullptr, nullptr};
     PushGeom pg;
     pg.col_groups = (uint32_t)((g.w + 255) / 256);
     pg.pw_blocks = pg.col_groups * (uint32_t)((g.h + 3) / 4);
     pg.n_jobs = (uint32_t)n_jobs;
     pg.n_vec = plane_bytes / 16;
     const size_t want = (pg.n_vec + 256 * 8 - 1) / (256 * 8);
-    const size_t cap = (size_t)(8192 / n_jobs > 1 ? 8192 / n_jobs : 1);
+    const size_t cap = (size_t)(n_jobs > 0 && 8192 / n_jobs > 1 ? 8192 / n_jobs : 1);
     pg.blocks_per_job = (uint32_t)(want < cap ? want : cap);
     if (pg.blocks_per_job < 1) pg.blocks_per_job = 1;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (f16) {
         switch (c.read.cn) {
-        case 1: e = launch_push_prog<1, _Float16>(prog_id, a, g, jobs, pg, s); break;
-        case 2: e = launch_push_prog<2, _Float16>(prog_id, a, g, jobs, pg, s); break;
-        case 3: e = launch_push_prog<3, _Float16>(prog_id, a, g, jobs, pg, s); break;
-        default: e = launch_push_prog<4, _Float16>(prog_id, a, g, jobs, pg, s); break;
+        case 1: e = launch_push_prog<1, _Float16>(prog_id, a, g, jobs, pg, dev, s); break;
+        case 2: e = launch_push_prog<2, _Float16>(prog_id, a, g, jobs, pg, dev, s); break;
+        case 3: e = launch_push_prog<3, _Float16>(prog_id, a, g, jobs, pg, dev, s); break;
+        default: e = launch_push_prog<4, _Float16>(prog_id, a, g, jobs, pg, dev, s); break;
         }
     } else {
         switch (c.read.cn) {
-        case 1: e = launch_push_prog<1, float>(prog_id, a, g, jobs, pg, s); break;
-        case 2: e = launch_push_prog<2, float>(prog_id, a, g, jobs, pg, s); break;
-        case 3: e = launch_push_prog<3, float>(prog_id, a, g, jobs, pg, s); break;
-        default: e = launch_push_prog<4, float>(prog_id, a, g, jobs, pg, s); break;
+        case 1: e = launch_push_prog<1, float>(prog_id, a, g, jobs, pg, dev, s); break;
+        case 2: e = launch_push_prog<2, float>(prog_id, a, g, jobs, pg, dev, s); break;
+        case 3: e = launch_push_prog<3, float>(prog_id, a, g, jobs, pg, dev, s); break;
+        default: e = launch_push_prog<4, float>(prog_id, a, g, jobs, pg, dev, s); break;
         }
     }
     return e == hipSuccess ? 1 : -(int)e - 1000;
@@ -178,6 +222,11 @@ __global__ __launch_bounds__(256) void k_circular_dev(const CircDev a, const siz
 }
 __global__ void k_circular_bump(uint64_t* count) {
     if (threadIdx.x == 0) *count += 1;
+}
+
+int launch_circular_bump(const uint64_t* count, void* stream) {
+    hipLaunchKernelGGL(k_circular_bump, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint64_t*)count);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_circular_dev(const CircDev& a, void* stream) {

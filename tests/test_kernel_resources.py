@@ -53,7 +53,8 @@ HOT = (  # mangled-name fragments of the kernels behind BASELINE's configs
     "k4_nv12_resizeILi64ENS_6K1ProgIJLi100ELi2ELi4ELi5EEEEfLi1ELi3E",            # cfg #3: NV12 -> BGR -> resize -> normalize -> split
     "k4_nv12_x2INS_6K1ProgIJLi100ELi2ELi4ELi5EEEELi1E",                          # the same at frame size, two pixels per lane
     "k_pointwise4ILi3ELi64ENS_10StaticProgIJLi1ELi2ELi4ELi5EEEEfLi0E",           # K5/K6: the regression's kernel
-    "k_circular_pushILi3ENS_10StaticProgIJLi1ELi2ELi4ELi5EEEEfE",                # cfg #4: CircularTensor push
+    "k_circular_pushILi3ENS_10StaticProgIJLi1ELi2ELi4ELi5EEEEfLb0EE",                # cfg #4: CircularTensor push
+    "k_circular_pushILi3ENS_10StaticProgIJLi1ELi2ELi4ELi5EEEEfLb1EE",  # the same, device-indexed (capturable handles)
     "k_plane_copyIDv4_fLi8E",                                                    # cfg #4: the shift
 )
 

@@ -110,6 +110,7 @@ struct QHostCtl {  // pinned host memory: the words of the retirement hand-shake
     QLine tail;     // host -> janitor: batches submitted (the copy the Dekker hand-shake reads)
     QLine state;    // QS_*
     QLine stop_req; // host -> janitor: destroy
+    QLine yield_req; // host -> janitor: another queue of this device wants to launch its server: retire as soon as nothing is in flight
     QLine error;    // device -> host: 1 = stalled (watchdog), 2 = protocol violation
     QLine stat_rounds, stat_launch_ticks;
     uint64_t prof[32]; // instrumentation of the last server (100 MHz ticks / counts), see queue_prof
@@ -576,8 +577,8 @@ __device__ void k1q_janitor(QDevCtl* dc, QHostCtl* hc, const uint64_t* dflags, u
                 why = 1;
             }
             __builtin_amdgcn_s_sleep(16);
-        } else if (wall_clock64() - t_last > idle_ticks) {
-            // retire: announce, then look at the host's tail once more (the host publishes its tail, fences, then reads state;
+        } else if (wall_clock64() - t_last > idle_ticks || q_ldu_sys(&hc->yield_req.v)) {
+            // retire (idle, or asked to make room for another queue's server): announce, then look at the host's tail once more (the host publishes its tail, fences, then reads state;
             // the read below is a PCIe read and cannot pass the posted state write)
             if (lane == 0) q_st_sys(&hc->state.v, QS_EXITING);
             q_drain();
@@ -695,7 +696,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             const uint64_t passed = q_uni(q_wave_max(valid && e0.x <= T ? cand + 1 : 0));
             if (passed > b) b = passed;
             if (__builtin_amdgcn_ballot_w64(hit) == 0) {
-                tail_seen = passed > wb ? ~0ull : tail_u; // progress: look again at once; none: wait for the tail to move
+                // Nothing for this worker in the window.  Before it goes to sleep on the tail it has just read: was the window as NEW as
+                // that tail?  The two came back from one round trip in no particular order, so the tail may already count a batch whose
+                // index entry the window read predates (the host writes the entry, fences, then the tail, ~100 ns apart).  A worker that
+                // then waits for the tail to move waits forever if that batch is the last one for a while: ONE task of 96 missing, the
+                // watchdog's 250 ms (tools/probes/queue_relaunch_stress.py: every run).  The newest batch the tail counts must have been
+                // seen in the window, or the pair is read again.
+                const bool newest_seen = tail_u <= wb || tail_u > wb + 64 || __builtin_amdgcn_ballot_w64(valid && cand == tail_u - 1) != 0;
+                tail_seen = (passed > wb || !newest_seen) ? ~0ull : tail_u; // progress / a stale window: look again at once; else wait for the tail to move
                 if (tail_seen == ~0ull && q_ldu_sys(&m.dc->stop_gen.v) == gen) return;
                 continue;
             }
@@ -890,7 +898,38 @@ static void advance_done(Queue* q) {
     while (q->done_inorder < q->next_seq && hflag(q, q->done_inorder % q->R) >= q->done_inorder + 1) ++q->done_inorder;
 }
 
+// ONE server grid per device at a time.  A server's tasks are statically owned, so every one of its workgroups must be resident;
+// two queues' grids do not fit the chip together (3 of 4 wave slots per SIMD each): a second server stays partly resident for as
+// long as the first one is fed, and its batches -- whose tasks are spread over ALL its workers -- cannot complete (the watchdog
+// reports them after 250 ms).  So a queue that needs to launch asks the device's current server to retire as soon as it has
+// nothing in flight, and waits for it; the other queue's submits wait for that retirement too (cvgs_queue_submit's yield check).  Alternating submits to two queues
+// therefore cost a server switch each (~20 us); batches submitted in bursts per queue do not.
+static std::mutex g_server_mu;
+static Queue* g_server_owner[64]; // by device: the queue whose server may be alive
+
 static hipError_t queue_launch(Queue* q) {
+    std::lock_guard<std::mutex> owner_lock(g_server_mu);
+    Queue* const o = g_server_owner[q->device & 63];
+    if (o && o != q) {
+        const uint64_t st = hv(o->hc->state);
+        if (st == QS_RUNNING || st == QS_EXITING) {
+            hv(o->hc->yield_req) = 1;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            for (;;) {
+                const uint64_t s2 = hv(o->hc->state);
+                if (s2 != QS_RUNNING && s2 != QS_EXITING) break;
+                _mm_pause();
+                if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                    hv(o->hc->yield_req) = 0;
+                    return hipErrorLaunchTimeOut; // the other queue's server never drained
+                }
+            }
+            hv(o->hc->yield_req) = 0;
+        }
+    }
+    g_server_owner[q->device & 63] = q;
     ++q->gen;
     ++q->launches;
     advance_done(q);
@@ -1051,6 +1090,16 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
         err = "queue: the server reported a stall / protocol error earlier";
         return -2;
     }
+    if (hv(q->hc->yield_req)) { // another queue of this device waits to launch its server: this one drains and retires first
+        const auto ty = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (hv(q->hc->yield_req)) {
+            const uint64_t st = hv(q->hc->state);
+            if (st != QS_RUNNING && st != QS_EXITING) break;
+            _mm_pause();
+            if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - ty > std::chrono::seconds(5)) break;
+        }
+    }
     if (q->kind < 0) {
         q->kind = kind;
         if (kind == QK_NV12) { // every workgroup must be resident (tasks are statically owned): the NV12 worker's register budget allows 3 per CU
@@ -1167,6 +1216,11 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
         break;
     }
     q->ns_ensure += ns_since(t2);
+    // A retired grid's workers leave within a microsecond of their janitor -- but one that sees the tail move before it looks at the
+    // stop word would take a task of the batch published below, and so would the worker of the NEXT grid that resumes at the same
+    // task number: two arrivals for one task, an arrival counter that skips its target, a batch that never completes (the watchdog's
+    // 250 ms).  Nothing new is published until the old grid is gone.
+    if (need_launch) (void)hipStreamSynchronize(q->stream);
     // 2. the slot, its index entry, then the tail
     uint8_t* slot = (q->direct ? q->m.ring : q->host_ring) + k * kQSlotBytes;
     QIndex* ixp = (q->direct ? q->m.index : q->host_index) + k;
@@ -1188,13 +1242,46 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     return 0;
 }
 
+// debugging aid (CVGS_QUEUE_DEBUG=1): what the device-side state of the oldest incomplete batch looks like when the server reports a stall
+static void queue_debug_dump(Queue* q) {
+    static const bool on = getenv("CVGS_QUEUE_DEBUG") != nullptr;
+    if (!on) return;
+    advance_done(q);
+    const uint64_t b = q->done_inorder, k = b % q->R;
+    fprintf(stderr, "[cvgs queue] stall: next_seq %llu done_inorder %llu gen %llu launches %llu state %llu dev tail %llu host tail %llu\n",
+            (unsigned long long)q->next_seq, (unsigned long long)b, (unsigned long long)q->gen, (unsigned long long)q->launches,
+            (unsigned long long)hv(q->hc->state), (unsigned long long)*(volatile uint64_t*)&q->m.dc->tail.v, (unsigned long long)hv(q->hc->tail));
+    const QParams* p = (const QParams*)(q->m.ring + k * kQSlotBytes);
+    const QIndex* ix = q->m.index + k;
+    fprintf(stderr, "  slot %llu: stamp %llu task_base %llu n_tasks %u arrive_target %llu | index end_task %llu stamp %llu\n", (unsigned long long)k,
+            (unsigned long long)p->stamp, (unsigned long long)p->task_base, p->n_tasks, (unsigned long long)p->arrive_target,
+            (unsigned long long)ix->end_task, (unsigned long long)ix->stamp);
+    uint64_t ctr[1 + kQSubs] = {0};
+    for (int i = 0; i <= kQSubs; ++i) (void)hipMemcpyAsync(&ctr[i], q->m.arrive + (k * (1 + kQSubs) + i) * kQCtrStride, 8, hipMemcpyDeviceToHost, q->stage_stream);
+    (void)hipStreamSynchronize(q->stage_stream);
+    const uint64_t* sub = (const uint64_t*)((const uint8_t*)p + kQSubOff);
+    fprintf(stderr, "  top counter %llu (target %llu); sub counters / targets:", (unsigned long long)ctr[0], (unsigned long long)p->arrive_target);
+    for (int i = 0; i < kQSubs; ++i) fprintf(stderr, " %llu/%llu", (unsigned long long)ctr[1 + i], (unsigned long long)sub[i]);
+    fprintf(stderr, "\n");
+    const size_t NW = (size_t)q->G * kQWaves;
+    std::vector<uint64_t> prog(NW);
+    (void)hipMemcpyAsync(prog.data(), q->m.prog, NW * 8, hipMemcpyDeviceToHost, q->stage_stream);
+    (void)hipStreamSynchronize(q->stage_stream);
+    size_t behind = 0;
+    uint64_t first = ~0ull;
+    for (size_t i = 0; i < NW; ++i)
+        if (prog[i] < p->task_base + p->n_tasks) { ++behind; if (prog[i] < first) first = prog[i]; }
+    fprintf(stderr, "  workers whose next task lies inside / before the batch: %zu of %zu (smallest next task %llu; batch tasks [%llu, %llu))\n", behind, NW,
+            (unsigned long long)first, (unsigned long long)p->task_base, (unsigned long long)(p->task_base + p->n_tasks));
+}
+
 int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err) {
     if (ticket >= q->next_seq) { err = "queue: ticket was never issued"; return 1; }
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     const uint64_t k = ticket % q->R;
     while (hflag(q, k) < ticket + 1) { // a later batch in the same slot carries a larger stamp: still "complete"
-        if (hv(q->hc->error)) { err = "queue: the server reported a stall / protocol error"; return -2; }
+        if (hv(q->hc->error)) { queue_debug_dump(q); err = "queue: the server reported a stall / protocol error"; return -2; }
         _mm_pause();
         if ((++spins & 1023) == 0 && timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
             err = "queue: wait timed out";
@@ -1245,6 +1332,10 @@ int queue_destroy(Queue* q) {
     }
     (void)hipStreamSynchronize(q->stage_stream);
     (void)hipStreamSynchronize(q->stream); // the janitor sees stop_req within one round and retires the grid
+    {
+        std::lock_guard<std::mutex> owner_lock(g_server_mu);
+        if (g_server_owner[q->device & 63] == q) g_server_owner[q->device & 63] = nullptr;
+    }
     (void)hipStreamDestroy(q->stream);
     (void)hipStreamDestroy(q->stage_stream);
     (void)hipFree(q->dev_block);

@@ -468,3 +468,69 @@ def test_queue_nv12_fp16_tensor(oracle, torch_dev):
         H.assert_bit_exact(out_t.cpu().numpy(), ref, "NV12 fp16 queue batch")
     finally:
         q.destroy()
+
+
+def test_queue_two_queues_never_wait_for_each_others_slots(oracle, torch_dev):
+    """A server's workgroups must all be resident, two servers do not fit the chip together, and two PARTLY resident servers can
+    wait for each other forever (a retirement and a relaunch racing for the freed slots: the watchdog's 250 ms, once in ~10 runs of
+    the test above).  One server per device at a time: a queue that needs to launch asks the current server to retire first.
+    Provoked here: short idle times, sleeps around them, a pixel queue and an NV12 queue alternating, then two threads."""
+    import threading
+    import time
+    torch, dev = torch_dev
+    frame = H.random_u8((720, 1280, 3), seed=61)
+    frame_t = torch.from_numpy(frame).to(dev)
+    w, h = 1280, 720
+    surf = H.random_u8((h + h // 2, w), seed=62)
+    surf_t = torch.from_numpy(surf).to(dev)
+    luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, surf_t.data_ptr(), w, owner=surf_t)
+    crops = H.random_crops(12, 1280, 720, wmax=300, hmax=400, seed=63)
+    ecrops = _even_crops(6, w, h, seed=64)
+    out_a, ops_a = gpu_chain(torch, dev, frame_t, crops, 12, (64, 128), 3)
+    out_b = torch.zeros((6, 3 * 64 * 128), dtype=torch.float32, device=dev)
+    ops_b = _nv12_ops([luma.nv12_roi(*c) for c in ecrops], cvgs.GpuMat.from_tensor(out_b, cvgs.CV_32FC1), (64, 128), capi.YUV_FULL, capi.BT709, capi.YUV_NV12)
+    la, lb = cvgs.lower(ops_a), cvgs.lower(ops_b)
+    ref_a = oracle_out(oracle, frame, crops, 12, (64, 128), 3)
+    ref_b = np.zeros((6, 3 * 64 * 128), dtype=np.float32)
+    hl = cvgs.GpuMat(h, w, cvgs.CV_8UC1, surf.ctypes.data, w, owner=surf)
+    oracle.execute(cvgs.lower(_nv12_ops([hl.nv12_roi(*c) for c in ecrops], cvgs.GpuMat.from_array(ref_b, cvgs.CV_32FC1), (64, 128), capi.YUV_FULL, capi.BT709, capi.YUV_NV12)))
+    qa, qb = cvgs.Queue(idle_us=30.0), cvgs.Queue(idle_us=30.0)
+    try:
+        torch.cuda.synchronize()
+        rng = np.random.default_rng(5)
+        ta = tb = None
+        for i in range(400):  # one thread, alternating, with pauses around the idle time: retirements and relaunches interleave
+            ta = qa.submit_lowered(la)
+            if i % 3 == 0:
+                time.sleep(float(rng.uniform(0, 120e-6)))
+            tb = qb.submit_lowered(lb)
+            if i % 5 == 0:
+                time.sleep(float(rng.uniform(0, 120e-6)))
+        qa.wait(ta)
+        qb.wait(tb)
+        errors = []
+
+        def feed(q, lowered, n):
+            try:
+                t = None
+                for i in range(n):
+                    t = q.submit_lowered(lowered)
+                    if i % 16 == 15:
+                        q.wait(t)
+                q.wait(t)
+            except Exception as ex:  # noqa: BLE001
+                errors.append(ex)
+
+        threads = [threading.Thread(target=feed, args=(qa, la, 600)), threading.Thread(target=feed, args=(qb, lb, 600))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert qa.stats()["error"] == 0 and qb.stats()["error"] == 0
+        torch.cuda.synchronize()
+        H.assert_bit_exact(out_a.cpu().numpy(), ref_a, "pixel queue")
+        H.assert_bit_exact(out_b.cpu().numpy(), ref_b, "NV12 queue")
+    finally:
+        qa.destroy()
+        qb.destroy()

@@ -1,5 +1,7 @@
+"""Two queues on one device (a pixel queue and an NV12 queue), each fed by its own host thread, short idle times: server switches
+every few submits.  Every run failed before the round-3 protocol fixes; prints the stalled queue's statistics."""
 import sys, threading, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import numpy as np, torch
 from cvgpuspeedup_amd import capi, cvgs
 from tests import helpers as H

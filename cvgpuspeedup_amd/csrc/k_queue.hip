@@ -17,7 +17,8 @@
 //   worker  4 independent waves per workgroup, 4 G in all; worker w owns the tasks T = w (mod 4 G) of a cumulative task
 //           numbering (static: no dequeue atomics); a task = 16 output rows x 64 columns of one crop.  Batches are consecutive
 //           task ranges, so they interleave over the whole chip and batch k+1 starts while batch k's stores drain.  A worker
-//           finds the batch that holds T with ONE wave-wide load of a 64-entry window of the batch index.  After a task it
+//           finds the batch that holds T with ONE wave-wide load of a 64-entry window of the batch index (read together with the
+//           tail: a worker only goes to sleep on a tail whose newest batch it has SEEN in the window).  After a task it
 //           drains its write-through stores and bumps the batch's arrival counter; the LAST arrival publishes the batch's
 //           completion flag (device word for hipStreamWaitValue64, host word for cvgs_queue_wait).
 //   janitor (workgroup 0, one wave) retires the grid after `idle_us` without work (Dekker hand-shake with the host on words in

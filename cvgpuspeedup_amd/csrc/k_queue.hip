@@ -996,7 +996,14 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     q->G = G;
     const double tick_hz = 100e6; // s_memrealtime: constant 100 MHz
     q->idle_ticks = (uint64_t)((idle_us <= 0 ? 200.0 : idle_us) * 1e-6 * tick_hz);
-    q->stall_ticks = (uint64_t)(0.25 * tick_hz); // a batch that makes no progress for 250 ms is reported, not waited for
+    // a batch that makes no progress for 250 ms is reported, not waited for.  CVGS_QUEUE_STALL_MS moves the limit (a process whose OTHER
+    // kernels can hold the whole chip for longer than that -- the server's workgroups must all be resident -- wants a larger one)
+    double stall_s = 0.25;
+    if (const char* sm = getenv("CVGS_QUEUE_STALL_MS")) {
+        const double v = atof(sm);
+        if (v >= 1.0 && v <= 600000.0) stall_s = v * 1e-3;
+    }
+    q->stall_ticks = (uint64_t)(stall_s * tick_hz);
     const size_t R = q->R, NW = (size_t)q->G * kQWaves;
     const size_t off_ring = 4096, off_index = off_ring + R * kQSlotBytes, off_dflags = off_index + R * sizeof(QIndex), total = off_dflags + R * 128;
     const size_t ctr_bytes = R * (1 + kQSubs) * kQCtrStride * 8, total_ctr = ctr_bytes + NW * 8;

@@ -370,7 +370,9 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  * workgroups walk from batch to batch without a grid-wide barrier, so batch k+1's loads overlap batch k's stores.
  *   cvgs_queue_create   one queue per device; `depth` ring slots (0 = 64, at most 256); `idle_us`: the server retires
  *                       itself after this long without work (0 = 200 us) and the next submit starts a new one, so the grid
- *                       never outlives its work; a batch without progress for 250 ms is reported as CVGS_ERR_HIP, not waited for.
+ *                       never outlives its work; a batch without progress for 250 ms (environment: CVGS_QUEUE_STALL_MS) is reported
+ *                       as CVGS_ERR_HIP, not waited for -- every workgroup of the server must be resident, so other kernels of the
+ *                       process must not hold the whole chip for longer than that.
  *   cvgs_queue_submit   asynchronous; the chain must be K1's hot shape (batched 8UC3 / 8UC4 bilinear resize -> [RGB<->BGR]
  *                       mul, sub, div [-> convertTo CV_16F] -> fp32 / fp16 NCHW / CNHW tensor, host descriptors, <= 74 planes) or the same behind crops of
  *                       NV12 / NV21 decoder surfaces (CVGS_READ_NV12_RESIZE_LINEAR, 3 channels; letterboxing and default planes

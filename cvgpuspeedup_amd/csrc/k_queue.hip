@@ -71,17 +71,19 @@ struct QParams {
     uint64_t arrive_target;        // value of the slot's TOP arrival counter when the batch's last sub-counter has filled
     uint32_t kind;                 // QK_*: what the planes are
     uint32_t yuv_range, yuv_primaries, yuv_vu; // QK_NV12: cvgs_yuv_range / cvgs_yuv_primaries, V-before-U (NV21)
+    uint32_t src_signed;           // QK_PIXELS16: CV_16S pixels (else CV_16U)
     uint32_t out_half;             // the tensor holds CV_16F elements (the chain's trailing convertTo<CV_32F, CV_16F> is the store's conversion)
-    uint32_t pad[13];
+    uint32_t pad[12];
 };
 static_assert(sizeof(QParams) == 256, "QParams is one wave-wide dword load");
 enum { QD_STAMP = 0, QD_TASK_BASE = 2, QD_N_TASKS = 4, QD_TPP = 5, QD_COL_TILES = 6, QD_N_PLANES = 7, QD_USED = 8, QD_DST_W = 9, QD_DST_H = 10,
        QD_OUT_W = 11, QD_CN = 12, QD_SWAP = 13, QD_FAST_DIV = 14, QD_ROWS_PER_TASK = 15, QD_MUL = 16, QD_SUB = 20, QD_DIV = 24, QD_RDIV = 28, QD_BG = 32,
        QD_IMG_STRIDE = 36, QD_CH_STRIDE = 38, QD_OUT = 40, QD_OUT_BYTES = 42, QD_ARRIVE_TARGET = 44, QD_KIND = 46, QD_YUV_RANGE = 47,
-       QD_YUV_PRIM = 48, QD_YUV_VU = 49, QD_OUT_HALF = 50 };
+       QD_YUV_PRIM = 48, QD_YUV_VU = 49, QD_SRC_SIGNED = 50, QD_OUT_HALF = 51 };
 // What a queue serves -- latched by its first submit; each kind has its own server instantiation (the 8-bit-pixel worker is the
 // tuned headline path and carries nothing of the other's code or registers).
-enum { QK_PIXELS = 0 /* 8UC3 / 8UC4 crops (K1's shape) */, QK_NV12 = 1 /* crops of NV12 / NV21 decoder surfaces (K4's shape) */ };
+enum { QK_PIXELS = 0 /* 8UC3 / 8UC4 crops (K1's shape) */, QK_NV12 = 1 /* crops of NV12 / NV21 decoder surfaces (K4's shape) */,
+       QK_PIXELS16 = 2 /* 16UC3 / 16UC4 / 16SC3 / 16SC4 crops: the other source types of the reference's K1 sweep (test_batchresize_x_split3D.cu:427-432) */ };
 
 // The batch index: one 32-byte entry per ring slot, rewritten by the host while workers may be looking: every 8-byte word is
 // written atomically, and `check` ties the four words together (a torn entry is simply not a candidate).
@@ -138,6 +140,20 @@ __device__ __forceinline__ uint64_t q_lane_u64(uint32_t v, int lane) { return (u
 __device__ __forceinline__ float q_lane_f32(uint32_t v, int lane) { return __uint_as_float(q_lane_u32(v, lane)); }
 
 // tap window load flavours: LD 0 plain (cached; A/B upper bound only: may serve a stale line of a rewritten source), 1 sc1
+// 16-bit pixels: the 16-byte window (k_taps.hpp: Win<2>)
+template <int LD>
+__device__ __forceinline__ Win<2> q_load_win16(gptr_u8 p) {
+    Win<2> w;
+    if constexpr (LD == 0) {
+        const u32x4 v = *(gptr_u32x4)p;
+        w.lo = ((uint64_t)v.y << 32) | v.x;
+        w.hi = ((uint64_t)v.w << 32) | v.z;
+    } else { // two sc1 8-byte loads (the atomic builtin has no 16-byte form)
+        w.lo = __hip_atomic_load((g_u64)(__attribute__((address_space(1))) uint8_t*)p, Q_AGENT);
+        w.hi = __hip_atomic_load((g_u64)(__attribute__((address_space(1))) uint8_t*)(p + 8), Q_AGENT);
+    }
+    return w;
+}
 template <int LD>
 __device__ __forceinline__ Win<1> q_load_win(gptr_u8 p) {
     Win<1> w;
@@ -179,8 +195,9 @@ struct QTask { // everything a wave needs for its 4 rows, wave-uniform
 // One wave's share of a task: rows row0..row0+3 of plane z, columns col_tile*64 + lane.  K1's arithmetic (k_k1_impl.hpp:
 // same geometry, same tap windows, same fp32 expression order, the same program stages) -- bit-identical results.
 // ST: 0 = nt dword stores, NOT published safely (A/B upper bound only), 1 = sc1 dword stores, 2 = sc1 16-byte transposed stores
-template <int CN, int LD, int ST>
+template <int CN, int LD, int ST, int SRC = SRC_U8>
 __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, int row0, int lane) {
+    constexpr int EB = elem_bytes<SRC>, WINB = 8 * EB;
     const PlaneParams& P = t.P;
     const int dst_w = t.dst_w, dst_h = t.dst_h, W = t.out_w;
     const int x = col_tile * 64 + lane;
@@ -273,13 +290,13 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
     const float wxa = (float)x2 - sx;
     const float wxb = sx - (float)x1;
     const bool edge = x2 > P.w - 1;
-    const int row_bytes = P.w * CN;
-    const int o = x1 * CN;
-    const uint32_t ol = (uint32_t)min(o, row_bytes - 8);
+    const int row_bytes = P.w * CN * EB;
+    const int o = x1 * CN * EB;
+    const uint32_t ol = (uint32_t)min(o, row_bytes - WINB);
     const int sh = (o - (int)ol) * 8;
     const gptr_u8 src = (gptr_u8)P.data;
 
-    Win<1> va[kQRowsPerWave], vb[kQRowsPerWave];
+    Win<EB> va[kQRowsPerWave], vb[kQRowsPerWave];
     float wya[kQRowsPerWave], wyb[kQRowsPerWave];
     bool in_y[kQRowsPerWave];
 #pragma unroll
@@ -295,15 +312,20 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
         wyb[j] = sy - (float)y1;
         const gptr_u8 ra = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step);
         const gptr_u8 rb = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step);
-        va[j] = q_load_win<LD>(ra + ol); // (rows narrower than the 8-byte window never reach the server: queue_submit refuses them)
-        vb[j] = q_load_win<LD>(rb + ol);
+        if constexpr (EB == 1) { // (rows narrower than the tap window never reach the server: queue_submit refuses them)
+            va[j] = q_load_win<LD>(ra + ol);
+            vb[j] = q_load_win<LD>(rb + ol);
+        } else {
+            va[j] = q_load_win16<LD>(ra + ol);
+            vb[j] = q_load_win16<LD>(rb + ol);
+        }
     }
     float outv[kQRowsPerWave][4];
 #pragma unroll
     for (int j = 0; j < kQRowsPerWave; ++j) {
         float p00[4], p10[4], p01[4], p11[4];
-        unpack_pair<CN, SRC_U8>(shift_win<1>(va[j], sh), edge, p00, p10);
-        unpack_pair<CN, SRC_U8>(shift_win<1>(vb[j], sh), edge, p01, p11);
+        unpack_pair<CN, SRC>(shift_win<EB>(va[j], sh), edge, p00, p10);
+        unpack_pair<CN, SRC>(shift_win<EB>(vb[j], sh), edge, p01, p11);
         const float w00 = wxa * wya[j];
         const float w10 = wxb * wya[j];
         const float w01 = wxa * wyb[j];
@@ -620,7 +642,7 @@ struct QDevMem { // the server's device-side state, one uncached allocation (hos
 // (register budget: 4 waves per SIMD -- 128 VGPRs -- for the pixel worker; the NV12 worker holds 16 tap words and four taps'
 // conversions per row and gets 3 waves per SIMD -- 168 VGPRs -- which is what the default 3 workgroups per CU use anyway)
 template <int LD, int ST, int KIND = QK_PIXELS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_NV12 ? 3 : 4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_PIXELS ? 4 : 3, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
                                                                                              uint64_t gen, uint64_t done0, uint64_t idle_ticks,
                                                                                              uint64_t stall_ticks) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -792,8 +814,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             for (int grp = 0; grp * kQRowsPerWave < rows_per_task; ++grp) {
                 const int row0 = (int)row_tile * rows_per_task + grp * kQRowsPerWave;
                 if (row0 >= t.dst_h) break;
-                if constexpr (KIND == QK_NV12) k4q_rows<LD, ST>(t, (int)z, (int)col_tile, row0, lane);
-                else if (c3) k1q_rows<3, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+                if constexpr (KIND == QK_NV12) {
+                    k4q_rows<LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+                } else if constexpr (KIND == QK_PIXELS16) {
+                    const bool sgn = q_lane_u32(v, QD_SRC_SIGNED) != 0; // wave-uniform
+                    if (c3) {
+                        if (sgn) k1q_rows<3, LD, ST, SRC_S16>(t, (int)z, (int)col_tile, row0, lane);
+                        else k1q_rows<3, LD, ST, SRC_U16>(t, (int)z, (int)col_tile, row0, lane);
+                    } else {
+                        if (sgn) k1q_rows<4, LD, ST, SRC_S16>(t, (int)z, (int)col_tile, row0, lane);
+                        else k1q_rows<4, LD, ST, SRC_U16>(t, (int)z, (int)col_tile, row0, lane);
+                    }
+                } else if (c3) k1q_rows<3, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
                 else k1q_rows<4, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
             }
         }
@@ -941,6 +973,8 @@ static hipError_t queue_launch(Queue* q) {
     if (q->kind == QK_NV12) { // the product flavour, and the unsafe upper bound of the A/B tool
         if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0, QK_NV12);
         else Q_LAUNCH(1, 2, QK_NV12);
+    } else if (q->kind == QK_PIXELS16) {
+        Q_LAUNCH(1, 2, QK_PIXELS16);
     } else if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0, QK_PIXELS);
     else if (q->ld == 0 && q->st == 1) Q_LAUNCH(0, 1, QK_PIXELS);
     else if (q->ld == 0) Q_LAUNCH(0, 2, QK_PIXELS);
@@ -1056,18 +1090,19 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     const WriteArgs& w = c_in.write;
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
     const bool nv12 = r.kind == CVGS_READ_NV12_RESIZE_LINEAR;
-    const int kind = nv12 ? QK_NV12 : QK_PIXELS;
+    const bool wide = !nv12 && (r.depth == CVGS_DEPTH_16U || r.depth == CVGS_DEPTH_16S);
+    const int kind = nv12 ? QK_NV12 : (wide ? QK_PIXELS16 : QK_PIXELS);
     const int vcn = nv12 ? r.out_cn : r.cn; // channels of the value the program sees
     const bool half = w.depth == CVGS_DEPTH_16F; // the half-precision hand-off: the chain ends with CAST(CV_16F), which the store performs
     if (!planar || (w.depth != CVGS_DEPTH_32F && !half) || w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch ||
-        (!nv12 && (r.kind != CVGS_READ_RESIZE_LINEAR || r.depth != CVGS_DEPTH_8U || (r.cn != 3 && r.cn != 4))) ||
+        (!nv12 && (r.kind != CVGS_READ_RESIZE_LINEAR || (r.depth != CVGS_DEPTH_8U && !wide) || (r.cn != 3 && r.cn != 4))) ||
         (nv12 && ((r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21) || r.out_cn != 3))) {
-        err = "queue: chain is not a batched 8UC3 / 8UC4 (or NV12 / NV21 -> 3 channels) resize into an fp32 / fp16 planar tensor with <= 74 inline planes";
+        err = "queue: chain is not a batched 8U / 16U / 16S C3 / C4 (or NV12 / NV21 -> 3 channels) resize into an fp32 / fp16 planar tensor with <= 74 inline planes";
         return 1;
     }
     for (int i = 0; i < n_planes && i < r.used; ++i)
-        if (nv12 ? planes[i].w < 4 : planes[i].w * r.cn < 8) {
-            err = nv12 ? "queue: a surface crop narrower than 4 pixels" : "queue: a crop narrower than the 8-byte tap window (1-2 pixels)";
+        if (nv12 ? planes[i].w < 4 : planes[i].w * r.cn < 8) { // (8 ELEMENTS: the window is 8 bytes of 8-bit, 16 bytes of 16-bit pixels)
+            err = nv12 ? "queue: a surface crop narrower than 4 pixels" : "queue: a crop narrower than the tap window (1-2 pixels)";
             return 1;
         }
     ChainArgs c = c_in;
@@ -1110,9 +1145,11 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     }
     if (q->kind < 0) {
         q->kind = kind;
-        if (kind == QK_NV12) { // every workgroup must be resident (tasks are statically owned): the NV12 worker's register budget allows 3 per CU
+        if (kind != QK_PIXELS) { // every workgroup must be resident (tasks are statically owned): these workers' register budget allows 3 per CU
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_NV12>, 256, 0) != hipSuccess || per_cu < 1) {
+            const hipError_t oe = kind == QK_NV12 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_NV12>, 256, 0)
+                                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_PIXELS16>, 256, 0);
+            if (oe != hipSuccess || per_cu < 1) {
                 q->kind = -1;
                 err = "queue: occupancy query failed";
                 return -1;
@@ -1123,7 +1160,8 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     }
     if (q->kind != kind) {
         err = q->kind == QK_NV12 ? "queue: this queue serves NV12 / NV21 surface crops (its first submit decided); use another queue for pixel crops"
-                                 : "queue: this queue serves 8UC3 / 8UC4 crops (its first submit decided); use another queue for NV12 surfaces";
+              : (q->kind == QK_PIXELS16 ? "queue: this queue serves 16-bit pixel crops (its first submit decided); use another queue for the other kinds"
+                                        : "queue: this queue serves 8UC3 / 8UC4 crops (its first submit decided); use another queue for the other kinds");
         return 1;
     }
     auto ns_since = [](std::chrono::steady_clock::time_point a) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a).count(); };
@@ -1168,6 +1206,7 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     p.yuv_range = (uint32_t)r.yuv_range;
     p.yuv_primaries = (uint32_t)r.yuv_primaries;
     p.yuv_vu = r.yuv_layout == CVGS_YUV_NV21;
+    p.src_signed = r.depth == CVGS_DEPTH_16S;
     p.swap = prog_id == 0;
     p.fast_div = (uint32_t)c.prog.fast_div;
     for (int i = 0; i < 4; ++i) {

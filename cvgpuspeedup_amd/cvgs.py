@@ -593,7 +593,7 @@ class CircularTensor:
 class Queue:
     """cvgs_queue_*: a device-side descriptor queue.  `submit(*iops)` has executeOperations' call shape (one call per frame,
     the same IOps) but no kernel launch per call: a resident server grid takes the batch from a ring, and consecutive batches
-    overlap on the device.  Taken: K1's hot shape (batched 8UC3 / 8UC4 resize -> [swap,] mul, sub, div -> fp32 or fp16 planar tensor) or
+    overlap on the device.  Taken: K1's hot shape (batched 8U / 16U / 16S C3 / C4 resize -> [swap,] mul, sub, div -> fp32 or fp16 planar tensor) or
     the same behind crops of NV12 / NV21 decoder surfaces (read_nv12(..., dsize), 3 channels); a queue serves the kind of its
     first submit.  capi.CvgsError(CVGS_ERR_UNSUPPORTED) otherwise."""
 

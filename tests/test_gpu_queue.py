@@ -160,10 +160,10 @@ def test_queue_refuses_what_the_server_does_not_take(torch_dev):
         ops.insert(-1, cvgs.add(cvgs.CV_32FC3, [1.0, 2.0, 3.0]))  # a fourth arithmetic stage: not the server's program
         with pytest.raises(capi.CvgsError):
             q.submit(*ops)
-        frame16 = torch.zeros((480, 640, 3), dtype=torch.int16, device=dev)  # a 16-bit source: cvgs_execute's business
-        ops16 = H.k1_chain(cvgs.GpuMat.from_tensor(frame16, cvgs.CV_16UC3), H.fixed_crops(2), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), src_depth=cvgs.CV_16U)
+        frame32 = torch.zeros((480, 640, 3), dtype=torch.float32, device=dev)  # a CV_32F source: cvgs_execute's business
+        ops32f = H.k1_chain(cvgs.GpuMat.from_tensor(frame32, cvgs.CV_32FC3), H.fixed_crops(2), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), src_depth=cvgs.CV_32F)
         with pytest.raises(capi.CvgsError):
-            q.submit(*ops16)
+            q.submit(*ops32f)
         # the queue is still usable afterwards
         out32, ops32 = gpu_chain(torch, dev, frame_t, H.fixed_crops(2), 2, (64, 128), 3)
         q.wait(q.submit(*ops32))
@@ -534,3 +534,36 @@ def test_queue_two_queues_never_wait_for_each_others_slots(oracle, torch_dev):
     finally:
         qa.destroy()
         qb.destroy()
+
+
+@pytest.mark.parametrize("depth,cn,dst,kw", [("16U", 3, (64, 128), {}), ("16S", 4, (64, 128), {}), ("16U", 4, (100, 37), {"ar": cvgs.PRESERVE_AR, "background": [9.0, 8.0, 7.0, 6.0]}),
+                                             ("16S", 3, (64, 128), {"used": 5, "background": [7.0, 8.0, 9.0, 0.0], "swap": False})])
+def test_queue_16_bit_pixel_crops_match_the_oracle(oracle, torch_dev, depth, cn, dst, kw):
+    """the queue's third kind: CV_16U / CV_16S C3 / C4 crops -- the other source types of the reference's K1 sweep
+    (tests/batchresize/test_batchresize_x_split3D.cu:427-432); a queue of its own (the first submit decides)"""
+    torch, dev = torch_dev
+    sd = cvgs.CV_16U if depth == "16U" else cvgs.CV_16S
+    frame = H.random_u16((720, 1280, cn), seed=29).view(np.uint16 if depth == "16U" else np.int16)
+    crops = H.random_crops(9, 1280, 720, wmax=400, hmax=500, seed=31) + [(1276, 0, 4, 700)]  # + a crop barely wider than one tap window
+    n = len(crops)
+    frame_t = torch.from_numpy(frame.view(np.int16)).to(dev)
+    q = cvgs.Queue()
+    try:
+        out_t = torch.full((n, cn * dst[0] * dst[1]), -777.0, dtype=torch.float32, device=dev)
+        ops = H.k1_chain(cvgs.GpuMat.from_tensor(frame_t, cvgs.make_type(sd, cn)), crops, cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), dst, cn, src_depth=sd, **kw)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            t = q.submit(*ops)
+        q.wait(t)
+        torch.cuda.synchronize()
+        ref = np.full((n, cn * dst[0] * dst[1]), -777.0, dtype=np.float32)
+        oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.make_type(sd, cn)), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, cn, src_depth=sd, **kw)))
+        H.assert_bit_exact(out_t.cpu().numpy(), ref, "16-bit queue batch %s C%d %s %s" % (depth, cn, dst, kw))
+        # the other kinds are refused on this queue
+        u8 = torch.zeros((64, 64, 3), dtype=torch.uint8, device=dev)
+        o8 = torch.zeros((1, 3 * 64 * 128), dtype=torch.float32, device=dev)
+        with pytest.raises(capi.CvgsError):
+            q.submit(*H.k1_chain(cvgs.GpuMat.from_tensor(u8, cvgs.CV_8UC3), [(0, 0, 64, 64)], cvgs.GpuMat.from_tensor(o8, cvgs.CV_32FC1), (64, 128), 3))
+        assert q.stats()["error"] == 0
+    finally:
+        q.destroy()

@@ -895,7 +895,7 @@ struct Queue {
     uint64_t next_seq = 0, next_task = 0, done_inorder = 0, gen = 0, launches = 0;
     uint64_t idle_ticks = 0, stall_ticks = 0;
     std::mutex mu;
-    uint64_t ns_ring_wait = 0, ns_write = 0, ns_ensure = 0, n_sub = 0; // host-side profile of submit
+    uint64_t ns_ring_wait = 0, n_sub = 0; // host side of submit: time spent waiting for a ring slot
     uint64_t n_ring_waits = 0, sum_done_behind_head = 0;               // head-of-line blocking: batches already complete behind an incomplete oldest one
 };
 
@@ -1081,6 +1081,13 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     return 0;
 }
 
+// `bytes` (a multiple of 16) to a 16-byte aligned destination with non-temporal stores
+static inline void wc_copy16(void* dst, const void* src, size_t bytes) {
+    __m128i* d = (__m128i*)dst;
+    const __m128i* s = (const __m128i*)src;
+    for (size_t i = 0; i < bytes / 16; ++i) _mm_stream_si128(d + i, _mm_loadu_si128(s + i));
+}
+
 // Can the server take this chain?  K1's hot shape: 8U C3 / C4 crops -> bilinear resize -> [swap R,B] mul sub div -> fp32 planar
 // tensor (NCHW / CNHW), descriptors inline, one target -- or K4's: the same behind crops of an NV12 / NV21 decoder surface
 // (cvtColorNV12 in front of the resize, 3 channels).  A queue serves ONE of the two (its first submit decides); everything else
@@ -1166,14 +1173,14 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     }
     auto ns_since = [](std::chrono::steady_clock::time_point a) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a).count(); };
     // ring space: batch next_seq reuses the slot of batch next_seq - R, which must be complete
-    const auto t0 = std::chrono::steady_clock::now();
+    // (the host side of a submit is ~1.2 us, a third of it the write-combined stores below: no clock is read on the way unless the
+    //  ring is full -- tools/probes/submit_host_cost.cpp, submit_cost_probe.cpp)
     const uint64_t k = q->next_seq % q->R;
-    if (q->next_seq >= q->R) {
+    if (q->next_seq >= q->R && hflag(q, k) < q->next_seq - q->R + 1) {
+        const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
-        if (hflag(q, k) < q->next_seq - q->R + 1) {
-            ++q->n_ring_waits;
-            for (uint64_t bb = q->next_seq - q->R + 1; bb < q->next_seq; ++bb) q->sum_done_behind_head += hflag(q, bb % q->R) >= bb + 1;
-        }
+        ++q->n_ring_waits;
+        for (uint64_t bb = q->next_seq - q->R + 1; bb < q->next_seq; ++bb) q->sum_done_behind_head += hflag(q, bb % q->R) >= bb + 1;
         while (hflag(q, k) < q->next_seq - q->R + 1) {
             if ((spins & 255) == 0) {
                 const int rc = queue_ensure_running(q);
@@ -1182,9 +1189,8 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
             _mm_pause();
             if ((++spins & 0xffff) == 0 && ns_since(t0) > 2000000000ull) { err = "queue: ring full for 2 s"; return -2; }
         }
+        q->ns_ring_wait += ns_since(t0);
     }
-    q->ns_ring_wait += ns_since(t0);
-    const auto t1 = std::chrono::steady_clock::now();
     QParams p;
     std::memset(&p, 0, sizeof(p));
     p.stamp = q->next_seq + 1;
@@ -1247,8 +1253,6 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     q->next_seq += 1;
     q->next_task += p.n_tasks;
     hv(q->hc->tail) = q->next_seq;
-    q->ns_write += ns_since(t1);
-    const auto t2 = std::chrono::steady_clock::now();
     std::atomic_thread_fence(std::memory_order_seq_cst);
     bool need_launch = false;
     for (;;) {
@@ -1262,7 +1266,6 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
         need_launch = true;
         break;
     }
-    q->ns_ensure += ns_since(t2);
     // A retired grid's workers leave within a microsecond of their janitor -- but one that sees the tail move before it looks at the
     // stop word would take a task of the batch published below, and so would the worker of the NEXT grid that resumes at the same
     // task number: two arrivals for one task, an arrival counter that skips its target, a batch that never completes (the watchdog's
@@ -1271,9 +1274,16 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     // 2. the slot, its index entry, then the tail
     uint8_t* slot = (q->direct ? q->m.ring : q->host_ring) + k * kQSlotBytes;
     QIndex* ixp = (q->direct ? q->m.index : q->host_index) + k;
-    std::memcpy(slot, &p, sizeof(p));
-    std::memcpy(slot + kQSubOff, sub_targets, sizeof(sub_targets));
-    std::memcpy(slot + kQPlanesOff, planes, (size_t)n_planes * sizeof(PlaneParams));
+    if (q->direct) { // write-combined device memory: every 64-byte line exactly once, front to back (memcpy's overlapping head / tail
+                     // stores flush half-filled combining buffers: 550 vs 380 ns for a 50-crop slot)
+        wc_copy16(slot, &p, sizeof(p));
+        wc_copy16(slot + kQSubOff, sub_targets, sizeof(sub_targets));
+        wc_copy16(slot + kQPlanesOff, planes, (size_t)n_planes * sizeof(PlaneParams));
+    } else {
+        std::memcpy(slot, &p, sizeof(p));
+        std::memcpy(slot + kQSubOff, sub_targets, sizeof(sub_targets));
+        std::memcpy(slot + kQPlanesOff, planes, (size_t)n_planes * sizeof(PlaneParams));
+    }
     for (int i = 0; i < 4; ++i) ((volatile uint64_t*)ixp)[i] = ((const uint64_t*)&ix)[i]; // four atomic 8-byte stores
     if (q->direct) {
         _mm_sfence(); // the write-combined slot / index stores leave before the tail does
@@ -1351,8 +1361,7 @@ void queue_prof(Queue* q, uint64_t* out16) {
     out16[6] = q->n_ring_waits;
     out16[7] = q->n_ring_waits ? q->sum_done_behind_head / q->n_ring_waits : 0;
     out16[13] = q->n_sub ? q->ns_ring_wait / q->n_sub : 0; // host side of submit, ns per call (since create)
-    out16[14] = q->n_sub ? q->ns_write / q->n_sub : 0;
-    out16[15] = q->n_sub ? q->ns_ensure / q->n_sub : 0;
+    out16[14] = out16[15] = 0;
 }
 
 void queue_stats(Queue* q, uint64_t* out8) {

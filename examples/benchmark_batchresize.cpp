@@ -79,13 +79,42 @@ void one_batch(cv::cuda::Stream& stream, hipEvent_t e0, hipEvent_t e1) {
         if (it >= 0) ms[(size_t)it] = t;
     }
     const Stats s = summarize(ms);
-    std::printf("%d, %.6f, %.3e, %.6f, %.6f, %.1f, %.6f\n", BATCH, s.mean, s.variance, s.max, s.min,
+    std::printf("%d, %.6f, %.3e, %.6f, %.6f, %.1f, %.6f", BATCH, s.mean, s.variance, s.max, s.min,
                 (double)BATCH * up.width * up.height / (s.mean * 1e-3) / 1e6, host_ms / ITERS);
+    // engine extension: the same call on the device-side descriptor queue (executeOperations(queue, iops...): no kernel launch per
+    // call).  QITERS calls back to back, one wait at the end: the sustained time per batch and the host time of the call itself.
+    if constexpr (BATCH <= 70) { // a ring slot holds 74 planes
+        constexpr int QITERS = 2000;
+        cvGS::Queue queue;
+        auto qcall = [&] {
+            if constexpr (CN == 3)
+                return cvGS::executeOperations(queue, cvGS::resize<TI, cv::INTER_LINEAR, BATCH>(crops, up, BATCH), cvGS::cvtColor<cv::COLOR_RGB2BGR, TO, TO>(),
+                                               cvGS::multiply<TO>(a), cvGS::subtract<TO>(sub[CN - 1]), cvGS::divide<TO>(div[CN - 1]), cvGS::split<TO>(tensor, up));
+            else
+                return cvGS::executeOperations(queue, cvGS::resize<TI, cv::INTER_LINEAR, BATCH>(crops, up, BATCH), cvGS::cvtColor<cv::COLOR_RGBA2BGRA, TO, TO>(),
+                                               cvGS::multiply<TO>(a), cvGS::subtract<TO>(sub[CN - 1]), cvGS::divide<TO>(div[CN - 1]), cvGS::split<TO>(tensor, up));
+        };
+        stream.waitForCompletion();
+        for (int i = 0; i < 200; ++i) queue.wait(qcall()); // server up, code and descriptors warm
+        double qhost_ms = 0.0;
+        uint64_t last = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < QITERS; ++i) {
+            const auto h0 = std::chrono::steady_clock::now();
+            last = qcall();
+            qhost_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+        }
+        queue.wait(last);
+        const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::printf(", %.6f, %.6f\n", total_ms / QITERS, qhost_ms / QITERS);
+    } else {
+        std::printf(", , \n");
+    }
 }
 
 template <int TI, int TO, size_t... Is>
 void sweep(cv::cuda::Stream& stream, hipEvent_t e0, hipEvent_t e1, std::index_sequence<Is...>) {
-    std::printf("BATCH (%s), cvGS MeanTime [ms], cvGS TimeVariance, cvGS MaxTime [ms], cvGS MinTime [ms], output Mpix/s at the mean, cvGS CPU MeanTime [ms]\n", pair_name<TI, TO>());
+    std::printf("BATCH (%s), cvGS MeanTime [ms], cvGS TimeVariance, cvGS MaxTime [ms], cvGS MinTime [ms], output Mpix/s at the mean, cvGS CPU MeanTime [ms], queue sustained [ms per batch], queue CPU MeanTime [ms]\n", pair_name<TI, TO>());
     (one_batch<TI, TO, FIRST + STEP * (int)Is>(stream, e0, e1), ...);
 }
 } // namespace

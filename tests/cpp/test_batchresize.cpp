@@ -310,5 +310,7 @@ int main() {
     test_half_handoff<CV_8UC4, 17>(stream);
     test_queue_vs_oracle<CV_8UC3, CV_32FC3, 50>(stream);
     test_queue_vs_oracle<CV_8UC4, CV_32FC4, 9>(stream);
+    test_queue_vs_oracle<CV_16UC3, CV_32FC3, 50>(stream); // the 16-bit kind: a queue of its own (one kind per queue)
+    test_queue_vs_oracle<CV_16SC4, CV_32FC4, 11>(stream);
     return report("test_batchresize_x_split3D + aspectratio");
 }

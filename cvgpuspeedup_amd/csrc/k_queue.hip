@@ -893,6 +893,7 @@ struct Queue {
     uint64_t* hflags = nullptr;         // pinned: R completion flags
     std::vector<uint64_t> arrive_cum;   // per slot, 1 + 16 words: each arrival counter's value once every batch that used the slot has arrived
     uint64_t next_seq = 0, next_task = 0, done_inorder = 0, gen = 0, launches = 0;
+    std::atomic<uint64_t> done_hint{0}; // every batch below is complete: what waiters (which do not take the mutex) have seen so far
     uint64_t idle_ticks = 0, stall_ticks = 0;
     std::mutex mu;
     uint64_t ns_ring_wait = 0, n_sub = 0; // host side of submit: time spent waiting for a ring slot
@@ -927,8 +928,14 @@ static bool probe_direct(uint64_t* dev_word) {
     return back == 0x5157455545ull;
 }
 
-static void advance_done(Queue* q) {
+static void advance_done(Queue* q) { // (under q->mu)
+    const uint64_t seen = q->done_hint.load(std::memory_order_relaxed);
+    if (seen > q->done_inorder) q->done_inorder = seen;
     while (q->done_inorder < q->next_seq && hflag(q, q->done_inorder % q->R) >= q->done_inorder + 1) ++q->done_inorder;
+}
+static void raise_done_hint(Queue* q, uint64_t d) {
+    uint64_t cur = q->done_hint.load(std::memory_order_relaxed);
+    while (cur < d && !q->done_hint.compare_exchange_weak(cur, d, std::memory_order_relaxed)) {}
 }
 
 // ONE server grid per device at a time.  A server's tasks are statically owned, so every one of its workgroups must be resident;
@@ -1332,27 +1339,50 @@ static void queue_debug_dump(Queue* q) {
             (unsigned long long)first, (unsigned long long)p->task_base, (unsigned long long)(p->task_base + p->n_tasks));
 }
 
+// Tickets are handed out in submit order, but batches do NOT complete in that order (a batch's tasks are spread over the workers,
+// 400 tasks over 3068 of them: with a full ring ~20 batches are complete behind an incomplete older one).  A wait is for the
+// ticket AND every batch submitted before it -- "wait(last) means all done" is what callers assume.  A slot's flag only ever grows
+// (a later batch in the slot carries a larger stamp and was submitted after the earlier one had completed), so flag >= b + 1
+// says "batch b is complete" however stale b is.
 int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err) {
     if (ticket >= q->next_seq) { err = "queue: ticket was never issued"; return 1; }
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    const uint64_t k = ticket % q->R;
-    while (hflag(q, k) < ticket + 1) { // a later batch in the same slot carries a larger stamp: still "complete"
-        if (hv(q->hc->error)) { queue_debug_dump(q); err = "queue: the server reported a stall / protocol error"; return -2; }
-        _mm_pause();
-        if ((++spins & 1023) == 0 && timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
-            err = "queue: wait timed out";
-            return -3;
+    auto wait_flag = [&](uint64_t b) {
+        while (hflag(q, b % q->R) < b + 1) {
+            if (hv(q->hc->error)) { queue_debug_dump(q); err = "queue: the server reported a stall / protocol error"; return -2; }
+            _mm_pause();
+            if ((++spins & 1023) == 0 && timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                err = "queue: wait timed out";
+                return -3;
+            }
         }
-    }
+        return 0;
+    };
+    // the ticket's own flag first (the usual last one to rise), then whatever older batch is still open
+    if (const int rc = wait_flag(ticket)) return rc;
+    uint64_t b = q->done_hint.load(std::memory_order_relaxed);
+    if (ticket >= q->R && b + q->R <= ticket) b = ticket - q->R + 1; // batch ticket took the slot of batch ticket - R: that one and all before it were complete
+    for (; b < ticket; ++b)
+        if (const int rc = wait_flag(b)) return rc;
     std::atomic_thread_fence(std::memory_order_acquire);
+    raise_done_hint(q, ticket + 1);
     return 0;
 }
 
+// The stream form: one hipStreamWaitValue64 per batch up to the ticket that the host has not yet seen complete (usually one or
+// two: the consumer of frame k is enqueued right after frame k's submit).
 int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err) {
     if (ticket >= q->next_seq) { err = "queue: ticket was never issued"; return 1; }
-    const hipError_t e = hipStreamWaitValue64((hipStream_t)stream, q->m.dflags + kQCtrStride * (ticket % q->R), ticket + 1, hipStreamWaitValueGte, ~0ull);
-    if (e != hipSuccess) { err = std::string("hipStreamWaitValue64: ") + hipGetErrorString(e); return -1; }
+    uint64_t d = q->done_hint.load(std::memory_order_relaxed);
+    if (ticket >= q->R && d + q->R <= ticket) d = ticket - q->R + 1;
+    while (d <= ticket && hflag(q, d % q->R) >= d + 1) ++d;
+    raise_done_hint(q, d < ticket + 1 ? d : ticket + 1);
+    for (uint64_t b = d; b <= ticket; ++b) {
+        if (b != ticket && hflag(q, b % q->R) >= b + 1) continue;
+        const hipError_t e = hipStreamWaitValue64((hipStream_t)stream, q->m.dflags + kQCtrStride * (b % q->R), b + 1, hipStreamWaitValueGte, ~0ull);
+        if (e != hipSuccess) { err = std::string("hipStreamWaitValue64: ") + hipGetErrorString(e); return -1; }
+    }
     return 0;
 }
 

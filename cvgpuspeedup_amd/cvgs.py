@@ -626,9 +626,11 @@ class Queue:
         return arr
 
     def wait(self, ticket, timeout_s=10.0):
+        """the batch of `ticket` and every batch submitted before it are complete on return (batches finish in any order on the device)"""
         capi.check(self.lib.cvgs_queue_wait(self.handle, ticket, float(timeout_s)))
 
     def stream_wait(self, ticket, stream):
+        """`stream` waits (on the device) for the batch of `ticket` and every batch submitted before it"""
         capi.check(self.lib.cvgs_queue_stream_wait(self.handle, ticket, stream_handle(stream)))
 
     def stats(self):

@@ -780,6 +780,7 @@ private:
 //     fk::Queue q;                                             // once
 //     auto t = fk::executeOperations(q, resize, cvt, mul, sub, div, split);   // per frame, asynchronous
 //     q.wait(t);   or   q.wait(t, consumerStream);             // host wait, or order a consumer stream behind the ticket
+// A wait covers the ticket's batch AND every batch submitted before it (the device completes batches in any order).
 // The sources must be complete when the call is made (the server is not ordered behind any stream).
 class Queue {
 public:

@@ -380,9 +380,11 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  *                       of the three kinds (8-bit pixels, 16-bit pixels, NV12 surfaces) -- its first submit decides, the others are then CVGS_ERR_UNSUPPORTED (each kind
  *                       has its own server grid; create a second queue).  The sources must be complete when submit is
  *                       called (the server is not ordered behind any stream); results are bit-identical to cvgs_execute.
- *   cvgs_queue_wait     host waits for a ticket (batches complete in order); cvgs_queue_stream_wait makes a HIP stream
- *                       wait for it instead (hipStreamWaitValue64 on the queue's completion counter), the consumer's kernels
- *                       enqueued behind it see the tensor.
+ *   cvgs_queue_wait     host waits for a ticket AND every batch submitted before it (tickets are handed out in submit order; the
+ *                       server completes batches in any order -- their tasks are spread over its workers -- so the wait looks at every
+ *                       batch up to the ticket that it has not yet seen complete); cvgs_queue_stream_wait makes a HIP stream
+ *                       wait for the same set instead (one hipStreamWaitValue64 per batch still open, on the batches' device-side
+ *                       completion words), the consumer's kernels enqueued behind it see the tensors.
  * Submits from several host threads are serialised by a mutex (tickets are handed out in submit order).  cvgs_queue_destroy
  * completes the batches in flight first (the workers drain the ring before they see the stop word), then retires the server.
  * No reference counterpart.                                                                                           */

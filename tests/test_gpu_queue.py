@@ -567,3 +567,52 @@ def test_queue_16_bit_pixel_crops_match_the_oracle(oracle, torch_dev, depth, cn,
         assert q.stats()["error"] == 0
     finally:
         q.destroy()
+
+
+def test_queue_wait_on_a_ticket_covers_every_earlier_batch(oracle, torch_dev):
+    """Batches finish in any order on the device (the last of 24 60-crop batches are still running when the one-crop batches submitted
+    behind them are done): a wait for the LAST ticket must still mean "everything up to here is complete" -- on the host (the completed count is read
+    right after the wait, no device synchronisation) and on a consumer stream (it copies the BIG batch's tensor)."""
+    torch, dev = torch_dev
+    q = cvgs.Queue()
+    try:
+        frame = H.random_u8((1080, 1920, 3), seed=61)
+        frame_t = torch.from_numpy(frame).to(dev)
+        big_crops = H.random_crops(60, 1920, 1080, wmax=500, hmax=600, seed=62)
+        big_t, big_ops = gpu_chain(torch, dev, frame_t, big_crops, 60, (64, 128), 3)
+        big = cvgs.lower(big_ops)
+        small = []
+        for i in range(8):
+            crops = H.random_crops(1, 1920, 1080, wmax=64, hmax=64, seed=70 + i)
+            out_t, ops = gpu_chain(torch, dev, frame_t, crops, 1, (64, 16), 3)
+            small.append((crops, out_t, cvgs.lower(ops)))
+        want_big = oracle_out(oracle, frame, big_crops, 60, (64, 128), 3)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        submitted = 0
+        for rep in range(40):
+            big_t.fill_(-5.0)
+            torch.cuda.synchronize()
+            for _ in range(24):
+                q.submit_lowered(big)
+            last = None
+            for _, _, lw in small:
+                last = q.submit_lowered(lw)
+            submitted += 32
+            if rep % 2 == 0:
+                q.wait(last)
+                st = q.stats()
+                assert st["completed"] == submitted and st["error"] == 0, (rep, st)
+                got = big_t.cpu().numpy()
+            else:
+                q.stream_wait(last, s)
+                with torch.cuda.stream(s):
+                    copy = big_t.clone()
+                s.synchronize()
+                got = copy.cpu().numpy()
+            H.assert_bit_exact(got, want_big, "the big batch behind the last ticket, rep %d" % rep)
+        q.wait(last)
+        for crops, out_t, _ in small:
+            H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, 1, (64, 16), 3), "one-crop batch")
+    finally:
+        q.destroy()

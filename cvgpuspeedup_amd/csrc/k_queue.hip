@@ -1099,7 +1099,7 @@ static inline void wc_copy16(void* dst, const void* src, size_t bytes) {
 // tensor (NCHW / CNHW), descriptors inline, one target -- or K4's: the same behind crops of an NV12 / NV21 decoder surface
 // (cvtColorNV12 in front of the resize, 3 channels).  A queue serves ONE of the two (its first submit decides); everything else
 // belongs to cvgs_execute.
-int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err) {
+static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err) {
     const ReadArgs& r = c_in.read;
     const WriteArgs& w = c_in.write;
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
@@ -1111,7 +1111,7 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     if (!planar || (w.depth != CVGS_DEPTH_32F && !half) || w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch ||
         (!nv12 && (r.kind != CVGS_READ_RESIZE_LINEAR || (r.depth != CVGS_DEPTH_8U && !wide) || (r.cn != 3 && r.cn != 4))) ||
         (nv12 && ((r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21) || r.out_cn != 3))) {
-        err = "queue: chain is not a batched 8U / 16U / 16S C3 / C4 (or NV12 / NV21 -> 3 channels) resize into an fp32 / fp16 planar tensor with <= 74 inline planes";
+        err = "queue: chain is not a batched 8U / 16U / 16S C3 / C4 (or NV12 / NV21 -> 3 channels) resize into an fp32 / fp16 planar tensor with host plane descriptors";
         return 1;
     }
     for (int i = 0; i < n_planes && i < r.used; ++i)
@@ -1303,6 +1303,29 @@ int queue_submit(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int
     q->n_sub += 1;
     // 3. a retired server is replaced AFTER the batch is in place
     if (need_launch && queue_launch(q) != hipSuccess) { err = "queue: server launch failed"; return -1; }
+    return 0;
+}
+
+// A ring slot holds 74 planes.  A larger batch (the reference's own sweep of this chain goes to 300 crops, tests/batchresize/
+// test_batchresize_x_split3D.cu:384-392) is submitted as consecutive slots, each a batch of its own over its planes' slice of the
+// tensor; the ticket is the last slot's, and a wait for it covers the earlier ones (queue_wait).
+int queue_submit(Queue* q, const ChainArgs& c, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err) {
+    if (n_planes <= kQMaxPlanes || n_planes != c.read.batch || c.read.table) return queue_submit_slot(q, c, planes, n_planes, ticket, err);
+    const bool nv12 = c.read.kind == CVGS_READ_NV12_RESIZE_LINEAR;
+    for (int i = 0; i < n_planes && i < c.read.used; ++i) // what a later slot would be refused for is refused before the first one is published
+        if (nv12 ? planes[i].w < 4 : planes[i].w * c.read.cn < 8) {
+            err = nv12 ? "queue: a surface crop narrower than 4 pixels" : "queue: a crop narrower than the tap window (1-2 pixels)";
+            return 1;
+        }
+    const int64_t elem = c.write.depth == CVGS_DEPTH_16F ? 2 : 4;
+    for (int base = 0; base < n_planes; base += kQMaxPlanes) {
+        const int cnt = n_planes - base < kQMaxPlanes ? n_planes - base : kQMaxPlanes;
+        ChainArgs part = c;
+        part.read.batch = cnt;
+        part.read.used = c.read.used <= base ? 0 : (c.read.used - base < cnt ? c.read.used - base : cnt);
+        part.write.data = c.write.data + (int64_t)base * c.write.img_stride * elem;
+        if (const int rc = queue_submit_slot(q, part, planes + base, cnt, ticket, err)) return rc;
+    }
     return 0;
 }
 

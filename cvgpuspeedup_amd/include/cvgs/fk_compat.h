@@ -773,7 +773,7 @@ private:
 // executeOperations' call shape -- one call per frame, the same IOps -- without a kernel launch per call: a resident server
 // grid takes the batch from a ring and consecutive batches overlap on the device (a 50-crop batch every ~2.6 us instead of
 // 4.4 us with one launch each; include/cvgs_hip.h "device-side descriptor queue").  Taken: K1's hot shape (batched
-// 8UC3 / 8UC4 bilinear resize -> [cvtColor swap] -> multiply -> subtract -> divide [-> convertTo CV_16F] -> split into an fp32 / fp16 tensor, <= 74 crops)
+// 8UC3 / 8UC4 bilinear resize -> [cvtColor swap] -> multiply -> subtract -> divide [-> convertTo CV_16F] -> split into an fp32 / fp16 tensor; any batch size, 74 crops per ring slot)
 // or the same behind crops of NV12 / NV21 decoder surfaces (resize(cvtColorNV12<...>(surface), size) / Resize over ReadYUV);
 // a queue serves the kind of its first call.  Anything else throws, exactly as an unsupported chain does elsewhere in the
 // facade; those chains belong to the stream form.

@@ -616,3 +616,35 @@ def test_queue_wait_on_a_ticket_covers_every_earlier_batch(oracle, torch_dev):
             H.assert_bit_exact(out_t.cpu().numpy(), oracle_out(oracle, frame, crops, 1, (64, 16), 3), "one-crop batch")
     finally:
         q.destroy()
+
+
+@pytest.mark.parametrize("n,cn,kw", [
+    (150, 3, {}),                                                     # three ring slots: 74 + 74 + 2
+    (75, 4, {}),                                                      # a second slot with ONE plane
+    (200, 3, {"used": 120, "background": [7.0, 8.0, 9.0, 0.0]}),      # the used / default-value boundary falls inside the second slot
+    (148, 3, {"ar": cvgs.PRESERVE_AR, "background": [114.0, 114.0, 114.0, 0.0], "swap": False}),
+    (300, 3, {"half": True}),                                         # the reference's largest batch (test_batchresize_x_split3D.cu:384-392), fp16 tensor
+])
+def test_queue_batches_larger_than_a_ring_slot(oracle, torch_dev, n, cn, kw):
+    """A ring slot holds 74 planes; larger batches go out as consecutive slots over slices of the tensor, one ticket."""
+    torch, dev = torch_dev
+    frame = H.random_u8((1080, 1920, cn), seed=90 + n)
+    crops = H.random_crops(n, 1920, 1080, wmax=300, hmax=300, seed=91 + n)
+    half = kw.get("half", False)
+    dst = (64, 32)
+    q = cvgs.Queue()
+    try:
+        ft = torch.from_numpy(frame).to(dev)
+        out_t = torch.full((n, cn * dst[0] * dst[1]), -3.0, dtype=torch.float16 if half else torch.float32, device=dev)
+        ref = np.full((n, cn * dst[0] * dst[1]), -3.0, dtype=np.float16 if half else np.float32)
+        t_out = cvgs.CV_16FC1 if half else cvgs.CV_32FC1
+        ops = H.k1_chain(cvgs.GpuMat.from_tensor(ft, cvgs.make_type(cvgs.CV_8U, cn)), crops, cvgs.GpuMat.from_tensor(out_t, t_out), dst, cn, **kw)
+        oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.make_type(cvgs.CV_8U, cn)), crops, cvgs.GpuMat.from_array(ref, t_out), dst, cn, **kw)))
+        torch.cuda.synchronize()
+        before = q.stats()["submitted"]
+        q.wait(q.submit(*ops))
+        st = q.stats()
+        assert st["submitted"] - before == (n + 73) // 74 and st["completed"] == st["submitted"], st
+        H.assert_bit_exact(out_t.cpu().numpy().view(np.uint16 if half else np.uint32), ref.view(np.uint16 if half else np.uint32), "%d crops over ring slots" % n)
+    finally:
+        q.destroy()

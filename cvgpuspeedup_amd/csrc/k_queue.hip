@@ -53,7 +53,7 @@ constexpr int kQSlotBytes = 4096;   // one batch: 256 B of parameters, planes fr
 constexpr int kQPlanesOff = 512;
 constexpr int kQMaxPlanes = (kQSlotBytes - kQPlanesOff) / (int)sizeof(PlaneParams); // 74
 constexpr int kQMaxRing = 256;
-constexpr int kQRowsPerWave = 4, kQWaves = 4, kQRowsPerTask = 16;
+constexpr int kQRowsPerWave = 4, kQWaves = 4, kQRowsPerTask = 16, kQRowsPerTaskMid = 64, kQRowsPerTaskDeep = 128;
 constexpr int kQSubOff = 256;      // 16 cumulative sub-counter targets (8 bytes each) behind the parameters
 constexpr int kQSubs = 16;         // arrival sub-counters per slot: task T arrives at sub-counter T % 16
 constexpr int kQCtrStride = 16;    // counters are 128 bytes (16 words) apart
@@ -162,23 +162,20 @@ __device__ __forceinline__ Win<1> q_load_win(gptr_u8 p) {
     return w;
 }
 
-// 4x4 transpose inside lane quads: in: r[j] = row j at this lane's column; out: o[0..3] = columns 4q..4q+3 of row (lane & 3)
-__device__ __forceinline__ void q_quad_transpose(const float (&r)[4], float (&o)[4], int lane) {
-    const bool odd = lane & 1, hi = lane & 2;
-    auto xor1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); }; // quad_perm:[1,0,3,2]
-    auto xor2 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); }; // quad_perm:[2,3,0,1]
-    // stage 1: 2x2 blocks between lane pairs, on the row pairs (0,1) and (2,3)
-    const float s01 = odd ? r[0] : r[1], s23 = odd ? r[2] : r[3];
-    const float g01 = xor1(s01), g23 = xor1(s23);
-    const float x0 = odd ? g01 : r[0], x1 = odd ? r[1] : g01; // even lanes: row 0 at (own, next) column; odd: row 1 at (previous, own)
-    const float y0 = odd ? g23 : r[2], y1 = odd ? r[3] : g23; // rows 2 / 3 likewise
-    // stage 2: lanes i and i ^ 2 swap the halves they do not keep
-    const float t0 = hi ? x0 : y0, t1 = hi ? x1 : y1;
-    const float u0 = xor2(t0), u1 = xor2(t1);
-    o[0] = hi ? u0 : x0;
-    o[1] = hi ? u1 : x1;
-    o[2] = hi ? y0 : u0;
-    o[3] = hi ? y1 : u1;
+// The 4 x 64 tile a wave has computed (lane = column, register = row) leaves as 16-byte stores (lane = four consecutive columns of
+// one row).  The transpose goes through a wave-private LDS tile: four conflict-free ds_write_b32 and one ds_read_b128 per channel
+// instead of two DPP rounds of selects (48 VALU instructions per 4 rows of 3 channels: the workers are VALU-bound on small crops,
+// tools/pmc_queue_insts.sh).  Row stride 80 floats: lane (i = lane & 3, q = lane >> 2) reads floats i*80 + 4q .. +3, banks
+// (16 i + 4 q) mod 64 .. +3 -- sixteen lanes cover the 64 banks once.  One wave's LDS operations execute in order, so the tile is
+// reused without a barrier.
+constexpr int kQLdsRow = 80, kQLdsChan = kQRowsPerWave * kQLdsRow, kQLdsWave = 4 * kQLdsChan; // floats
+typedef float q_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void q_lds_put(float* tile, int k, const float (&r)[4], int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[k * kQLdsChan + j * kQLdsRow + lane] = r[j];
+}
+__device__ __forceinline__ q_f32x4 q_lds_get(const float* tile, int k, int lane) {
+    return *(const q_f32x4*)(tile + k * kQLdsChan + (lane & 3) * kQLdsRow + (lane >> 2) * 4);
 }
 
 struct QTask { // everything a wave needs for its 4 rows, wave-uniform
@@ -190,6 +187,7 @@ struct QTask { // everything a wave needs for its 4 rows, wave-uniform
     uint32_t out_bytes;
     int32_t yuv_range, yuv_primaries, yuv_vu; // QK_NV12 only
     int32_t out_half;                         // CV_16F tensor: 2-byte elements, round-to-nearest-even in the store
+    float* tile;                              // this wave's LDS tile (q_lds_put / q_lds_get)
 };
 
 // One wave's share of a task: rows row0..row0+3 of plane z, columns col_tile*64 + lane.  K1's arithmetic (k_k1_impl.hpp:
@@ -234,8 +232,12 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
 #pragma unroll
             for (int k = 0; k < CN; ++k) {
                 const float r[4] = {v[0][k], v[1][k], v[2][k], v[3][k]};
-                float o[4];
-                q_quad_transpose(r, o, lane);
+                q_lds_put(t.tile, k, r, lane);
+            }
+            __builtin_amdgcn_wave_barrier(); // (compiler ordering only: the hardware runs one wave's LDS operations in order)
+#pragma unroll
+            for (int k = 0; k < CN; ++k) {
+                const q_f32x4 o = q_lds_get(t.tile, k, lane);
                 if (t.out_half) { // wave-uniform: four halves, 8 bytes per lane
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
@@ -404,8 +406,12 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
 #pragma unroll
             for (int k = 0; k < CN; ++k) {
                 const float r[4] = {v[0][k], v[1][k], v[2][k], v[3][k]};
-                float o[4];
-                q_quad_transpose(r, o, lane);
+                q_lds_put(t.tile, k, r, lane);
+            }
+            __builtin_amdgcn_wave_barrier(); // (compiler ordering only: the hardware runs one wave's LDS operations in order)
+#pragma unroll
+            for (int k = 0; k < CN; ++k) {
+                const q_f32x4 o = q_lds_get(t.tile, k, lane);
                 if (t.out_half) { // wave-uniform: four halves, 8 bytes per lane
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
@@ -636,7 +642,8 @@ struct QDevMem { // the server's device-side state, one uncached allocation (hos
     QIndex* index;      // R entries
     uint64_t* arrive;   // ordinary (cached) device memory: per slot 1 top + 16 sub arrival counters, 128 bytes apart; device atomics only
     uint64_t* dflags;   // R completion flags, 128 bytes apart (hipStreamWaitValue64 targets)
-    uint64_t* prog;     // 4 G resume words
+    uint64_t* prog;     // 4 G resume words: the ticket (task number) each worker holds
+    uint64_t* ticket;   // 16 ticket counters (one per residue class of the task numbering), 128 bytes apart
 };
 
 // (register budget: 4 waves per SIMD -- 128 VGPRs -- for the pixel worker; the NV12 worker holds 16 tap words and four taps'
@@ -645,6 +652,7 @@ template <int LD, int ST, int KIND = QK_PIXELS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_PIXELS ? 4 : 3, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
                                                                                              uint64_t gen, uint64_t done0, uint64_t idle_ticks,
                                                                                              uint64_t stall_ticks) {
+    __shared__ __attribute__((aligned(16))) float q_tiles[kQWaves * kQLdsWave]; // one transpose tile per wave (20 KB per workgroup)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t n_workers = G * kQWaves;
@@ -653,13 +661,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
         return;
     }
     const uint32_t wid = (blockIdx.x - 1) * kQWaves + (uint32_t)wave;
-    uint64_t T = q_ldu(m.prog + wid); // resume where the previous server's worker stopped
+    uint64_t T = q_ldu(m.prog + wid); // the ticket this worker holds (a resumed server: the one its predecessor held)
+    const uint32_t cls = wid & (kQSubs - 1);                                   // this worker's tickets are T = cls (mod 16)
+    const uint64_t cls_first = (n_workers - cls + kQSubs - 1) / kQSubs;        // tickets cls, cls + 16, ... < 4G were handed out at create
     uint64_t b = done0;                   // every batch below was complete when this server was launched
     // the NEXT task's index window, requested before the current task's rows and consumed after them: with a deep queue the
     // dispatch round trip disappears behind the arithmetic (loads the compiler counts: it waits where they are first used)
     bool pre_valid = false;
     uint64_t pre_wb = 0, pre_tail = 0, pre_e[4] = {0, 0, 0, 0};
-    QPROF(uint64_t p_tasks = 0, p_find = 0, p_rows = 0, p_drain = 0, p_idle = 0, p_arrive = 0, p_t4 = 0, p_first = 0, p_last = 0;)
+    QPROF(uint64_t p_slot = 0, p_iters = 0; uint64_t p_tasks = 0, p_find = 0, p_rows = 0, p_drain = 0, p_idle = 0, p_arrive = 0, p_t4 = 0, p_first = 0, p_last = 0;)
     for (;;) {
         QPROF(const uint64_t p_t0 = wall_clock64();)
         // ---- find the batch that holds task T: the tail + a 64-entry window of the batch index, ONE round trip; then the
@@ -675,6 +685,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
                 if (q_ldu_sys(&m.dc->tail.v) == tail_seen) {
                     if (q_ldu_sys(&m.dc->stop_gen.v) == gen) {
                         QPROF(if (wid == 0 && lane == 0) {
+                            q_st_sys(&hc->prof[0], p_slot);
+                            q_st_sys(&hc->prof[1], p_iters);
                             q_st_sys(&hc->prof[8], p_tasks);
                             q_st_sys(&hc->prof[9], p_find);
                             q_st_sys(&hc->prof[10], p_rows);
@@ -690,6 +702,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
                     continue;
                 }
             }
+            QPROF(++p_iters;)
             uint64_t wb, tail_c; // window base, the tail that came with the window
             q_u64x2 e0, e1;
             if (pre_valid) { // the window this wave asked for BEFORE its previous task's rows: it has long landed
@@ -744,11 +757,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             const uint32_t z = (uint32_t)(T - tb) / tpp;
             const uint32_t pz = z < n_planes ? z : n_planes - 1;
             const uint8_t* slot = m.ring + (size_t)(best % R) * kQSlotBytes;
+            QPROF(const uint64_t p_s0 = wall_clock64();)
             v = __hip_atomic_load((g_u32)((const uint32_t*)slot + lane), Q_SYSTEM);
             pv = __hip_atomic_load((g_u32)((const uint32_t*)(slot + kQPlanesOff + (size_t)pz * sizeof(PlaneParams)) + (lane < 12 ? lane : 0)), Q_SYSTEM);
             sub_target = q_ld_sys((const uint64_t*)(slot + kQSubOff) + (T & (kQSubs - 1)));
             q_drain();
             sub_target = q_uni(sub_target);
+            QPROF(p_slot += wall_clock64() - p_s0;)
             if (q_lane_u64(v, QD_STAMP) != best + 1 || q_lane_u64(v, QD_TASK_BASE) != tb) { // a check-word collision: read again
                 tail_seen = ~0ull;
                 continue;
@@ -763,6 +778,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             const uint32_t z = local / tpp, rt = local - z * tpp;
             const uint32_t row_tile = rt / col_tiles, col_tile = rt - row_tile * col_tiles;
             QTask t;
+            t.tile = q_tiles + wave * kQLdsWave;
             t.P.data = (const uint8_t*)q_lane_u64(pv, 0);
             t.P.w = (int)q_lane_u32(pv, 2);
             t.P.h = (int)q_lane_u32(pv, 3);
@@ -838,12 +854,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
         // a batch 5-18 us of latency): task T bumps sub-counter T % 16 of its slot; whoever fills a sub-counter bumps the top one.
         uint64_t* ctr = m.arrive + (size_t)(b % R) * (1 + kQSubs) * kQCtrStride;
         const uint32_t sub = (uint32_t)T & (kQSubs - 1);
-        T += n_workers;
-        uint64_t before = 0;
+        // The next ticket.  Tasks were statically owned at first (worker w: T = w mod 4G): no atomics, but the grid then runs at the pace
+        // of its SLOWEST worker -- the fast ones run ahead to the end of the ring and poll there (30 % of a worker's time at the
+        // headline with a full 128-slot ring, 43 batches complete behind an incomplete oldest one).  Now a worker draws its next task
+        // number from the counter of its residue class (T = w mod 16, the arrival sub-counters' classes: 16 words share the ~88
+        // atomics per microsecond one word takes): work goes to whoever is free, oldest first.  The class's first 4G / 16 tickets are
+        // the workers' initial ones (worker w starts with T = w).
+        uint64_t before = 0, drawn = 0;
         if (lane == 0) {
-            q_st(m.prog + wid, T);
+            drawn = __hip_atomic_fetch_add((g_u64)(m.ticket + cls * kQCtrStride), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             before = __hip_atomic_fetch_add((g_u64)(ctr + (1 + sub) * kQCtrStride), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        T = (uint64_t)cls + (uint64_t)kQSubs * (cls_first + q_uni(drawn));
+        if (lane == 0) q_st(m.prog + wid, T);
         if (q_uni(before) + 1 == sub_target) {
             if (lane == 0) before = __hip_atomic_fetch_add((g_u64)ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q_uni(before) + 1 == q_lane_u64(v, QD_ARRIVE_TARGET)) {
@@ -1034,6 +1057,10 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     uint32_t G = (uint32_t)(prop.multiProcessorCount * use) - 1;
     q->cus = prop.multiProcessorCount;
     if ((flags >> 16) & 0xfff) G = (flags >> 16) & 0xfff;
+    else if (const char* ge = getenv("CVGS_QUEUE_G")) { // tuning hook: worker workgroups (the flags' bits 16..27 say the same per queue)
+        const int v = atoi(ge);
+        if (v >= 1 && v <= 4095) G = (uint32_t)v;
+    }
     q->G = G;
     const double tick_hz = 100e6; // s_memrealtime: constant 100 MHz
     q->idle_ticks = (uint64_t)((idle_us <= 0 ? 200.0 : idle_us) * 1e-6 * tick_hz);
@@ -1047,7 +1074,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     q->stall_ticks = (uint64_t)(stall_s * tick_hz);
     const size_t R = q->R, NW = (size_t)q->G * kQWaves;
     const size_t off_ring = 4096, off_index = off_ring + R * kQSlotBytes, off_dflags = off_index + R * sizeof(QIndex), total = off_dflags + R * 128;
-    const size_t ctr_bytes = R * (1 + kQSubs) * kQCtrStride * 8, total_ctr = ctr_bytes + NW * 8;
+    const size_t ctr_bytes = R * (1 + kQSubs) * kQCtrStride * 8, prog_bytes = (NW * 8 + 127) & ~(size_t)127, total_ctr = ctr_bytes + prog_bytes + kQSubs * kQCtrStride * 8;
     if ((e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipExtMallocWithFlags((void**)&q->dev_block, total, hipDeviceMallocUncached)) != hipSuccess ||
@@ -1063,6 +1090,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     q->m.dflags = (uint64_t*)(q->dev_block + off_dflags);
     q->m.arrive = (uint64_t*)q->dev_counters;
     q->m.prog = (uint64_t*)(q->dev_counters + ctr_bytes);
+    q->m.ticket = (uint64_t*)(q->dev_counters + ctr_bytes + prog_bytes);
     std::memset((void*)q->hc, 0, sizeof(QHostCtl));
     std::memset((void*)q->hflags, 0, R * 8);
     q->arrive_cum.assign(R * (1 + kQSubs), 0);
@@ -1203,10 +1231,16 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     p.stamp = q->next_seq + 1;
     p.task_base = q->next_task;
     p.col_tiles = (uint32_t)((r.dst_w + 63) / 64);
-    // task size: a deep queue is a throughput problem (16 rows per task amortise the dispatch), a shallow one a latency problem
-    // (4 rows per task: four times the waves on each batch)
+    // task size: a shallow queue is a latency problem (4 rows per task: four times the waves on each batch), a deep one a throughput
+    // problem -- every worker is busy there, a task costs its worker ~4 us of dispatch (ticket, index window, slot, drain, arrival)
+    // beside ~0.8 us per row, and larger tasks keep a wave on one crop's rows: 16 rows per task with 2..7 batches in flight, 64 with
+    // 8..31, 128 with 32 or more (headline 2.49 / 2.25 / 2.21 us per batch; the reference's 60 x 120 crops, 50 per batch: 1.56 / 1.32 /
+    // 1.32).  The price is the tail of a burst: the last batches' tasks run 60 - 110 us.  CVGS_QUEUE_DEEP_ROWS pins the deep size (tuning).
     advance_done(q);
-    p.rows_per_task = q->next_seq - q->done_inorder >= 2 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave;
+    const uint64_t in_flight = q->next_seq - q->done_inorder;
+    static const int deep_env = getenv("CVGS_QUEUE_DEEP_ROWS") ? atoi(getenv("CVGS_QUEUE_DEEP_ROWS")) & ~3 : 0;
+    const uint32_t deep_rows = deep_env >= 4 && deep_env <= 4096 ? (uint32_t)deep_env : (in_flight >= 32 ? (uint32_t)kQRowsPerTaskDeep : (uint32_t)kQRowsPerTaskMid);
+    p.rows_per_task = in_flight >= 8 ? deep_rows : (in_flight >= 2 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
     p.tiles_per_plane = p.col_tiles * (uint32_t)((r.dst_h + (int)p.rows_per_task - 1) / (int)p.rows_per_task);
     p.n_tasks = p.tiles_per_plane * (uint32_t)r.batch;
     p.n_planes = (uint32_t)n_planes;

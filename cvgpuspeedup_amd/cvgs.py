@@ -651,7 +651,7 @@ class Queue:
         out = (C.c_uint64 * 16)()
         capi.check(self.lib.cvgs_queue_profile(self.handle, out))
         v = [int(x) for x in out]
-        return {"worker0": {"tasks": v[8], "find_us": v[9] / 100.0, "rows_us": v[10] / 100.0, "drain_us": v[11] / 100.0, "arrive_us": v[5] / 100.0, "first_to_last_us": v[4] / 100.0, "idle_polls": v[12]},
+        return {"worker0": {"tasks": v[8], "find_us": v[9] / 100.0, "rows_us": v[10] / 100.0, "drain_us": v[11] / 100.0, "arrive_us": v[5] / 100.0, "first_to_last_us": v[4] / 100.0, "idle_polls": v[12], "slot_load_us": v[0] / 100.0, "find_iterations": v[1]},
                 "host_submit_ns": {"ring_wait": v[13]},
                 "ring_full_waits": v[6], "complete_behind_an_incomplete_head_avg": v[7]}
 

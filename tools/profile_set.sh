@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): the whole evidence set of a round into gpurun_out/<tag>/ -- the headline's rocprofv3 trace and HBM
+# counters (tools/profile_queue.sh), the default bench line, the other benches, the perf gate and the GPU test suite's tail.
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/profile_set.sh r03_j'
+# then copy gpurun_out/<tag>/* to profiles/<tag>_* (tools/README.md).
+set -u
+TAG=${1:-set}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu_tail.txt
+bash tools/profile_queue.sh $TAG > /dev/null 2>&1
+python bench.py > $OUT/bench_default.json 2> /dev/null
+python tools/bench_reference_tests.py > $OUT/reference_test_chains.txt 2> /dev/null
+python tools/bench_more.py > $OUT/bench_more.txt 2> /dev/null
+python tools/bench_upscale.py > $OUT/bench_upscale.txt 2> /dev/null
+python tools/bench_upscale.py --cn 4 >> $OUT/bench_upscale.txt 2> /dev/null
+python tools/bench_upscale.py --cn 1 >> $OUT/bench_upscale.txt 2> /dev/null
+python tools/bench_nv12_letterbox.py > $OUT/bench_nv12_letterbox.txt 2> /dev/null
+python tools/perf_gate.py > $OUT/perf_gate.json 2> /dev/null
+./examples/bin/benchmark_batchresize > $OUT/benchmark_batchresize_x_split3D.csv 2> /dev/null
+ls -la $OUT

@@ -190,11 +190,33 @@ struct QTask { // everything a wave needs for its 4 rows, wave-uniform
     float* tile;                              // this wave's LDS tile (q_lds_put / q_lds_get)
 };
 
+// The vertical geometry of 64 consecutive output rows, one row per lane (computed once per 64 rows of a task; the row loop reads its
+// rows' values with v_readlane: 4 instructions per row instead of the 16 of computing wave-uniform values on the vector pipe)
+struct QRowGeo {
+    int y1, y2r;       // source rows of the two taps
+    float wya, wyb;    // their weights
+    uint64_t in_y;     // bit i: row first + i lies inside the destination window (aspect-ratio modes)
+};
+__device__ __forceinline__ QRowGeo q_row_geo(const PlaneParams& P, int dst_h, int first, int lane) {
+    QRowGeo g;
+    const int y = min(first + lane, dst_h - 1);
+    const bool in = y >= P.y1 && y <= P.y2;
+    const int yr = in ? y - P.y1 : 0;
+    const float sy = (float)yr * P.fy;
+    g.y1 = (int)floorf(sy);
+    const int y2 = g.y1 + 1;
+    g.y2r = min(y2, P.h - 1);
+    g.wya = (float)y2 - sy;
+    g.wyb = sy - (float)g.y1;
+    g.in_y = __builtin_amdgcn_ballot_w64(in);
+    return g;
+}
+
 // One wave's share of a task: rows row0..row0+3 of plane z, columns col_tile*64 + lane.  K1's arithmetic (k_k1_impl.hpp:
 // same geometry, same tap windows, same fp32 expression order, the same program stages) -- bit-identical results.
 // ST: 0 = nt dword stores, NOT published safely (A/B upper bound only), 1 = sc1 dword stores, 2 = sc1 16-byte transposed stores
 template <int CN, int LD, int ST, int SRC = SRC_U8>
-__device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, int row0, int lane) {
+__device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, int row0, int lane, const QRowGeo& geo, int gi) { // geo lane gi + j <-> row0 + j
     constexpr int EB = elem_bytes<SRC>, WINB = 8 * EB;
     const PlaneParams& P = t.P;
     const int dst_w = t.dst_w, dst_h = t.dst_h, W = t.out_w;
@@ -205,6 +227,8 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
     const uint32_t esh = t.out_half ? 1u : 2u; // log2 of the element size (wave-uniform)
     const uint32_t plane_off = (uint32_t)(((int64_t)z * t.img_stride) << esh); // byte offsets fit 32 bits (checked at submit)
     const uint32_t ch_bytes = (uint32_t)(t.ch_stride << esh);
+    // channel k of the value goes to plane k -- or, with the chain's R <-> B swap, 2 - k for k = 0, 2 (wave-uniform)
+    const uint32_t ch_off[4] = {t.swap ? 2u * ch_bytes : 0u, ch_bytes, t.swap ? 0u : 2u * ch_bytes, 3u * ch_bytes};
     ProgArgs prog; // registers: only the static program's operands are ever read
     prog.fast_div = t.fast_div;
 #pragma unroll
@@ -216,12 +240,7 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
     }
     auto run_prog = [&](Px& p) {
         int depth = CVGS_DEPTH_32F, cn = CN;
-        if (t.swap) { // wave-uniform
-            const float s = p.v[0];
-            p.v[0] = p.v[2];
-            p.v[2] = s;
-        }
-        ProgMulSubDiv::run(prog, p, depth, cn);
+        ProgMulSubDiv::run(prog, p, depth, cn); // (the R <-> B swap is not executed: QTask carries its operands and planes exchanged)
     };
     auto store_rows = [&](const float (&v)[kQRowsPerWave][4]) { // v[j][k]: row j, channel k at this lane's column
         const bool full = col_tile * 64 + 63 < dst_w; // wave-uniform: every lane of the tile is alive
@@ -243,11 +262,11 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
                     typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
                     const h2 lo = {(_Float16)o[0], (_Float16)o[1]}, hi = {(_Float16)o[2], (_Float16)o[3]};
                     const u32x2q d = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
-                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off + ch_off[k], 0, 16 /* sc1 */);
                 } else {
                     typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
                     const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + ch_off[k], 0, 16 /* sc1 */);
                 }
             }
         } else {
@@ -257,8 +276,8 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
                     const uint32_t off = plane_off + ((uint32_t)((row0 + j) * W + x) << esh);
 #pragma unroll
                     for (int k = 0; k < CN; ++k) {
-                        if (t.out_half) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 : 16);
-                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                        if (t.out_half) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[j][k]), rsrc, off + ch_off[k], 0, ST == 0 ? 2 : 16);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + ch_off[k], 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
                     }
                 }
             }
@@ -303,17 +322,11 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
     bool in_y[kQRowsPerWave];
 #pragma unroll
     for (int j = 0; j < kQRowsPerWave; ++j) {
-        const int y = min(row0 + j, dst_h - 1);
-        in_y[j] = y >= P.y1 && y <= P.y2;
-        const int yr = in_y[j] ? y - P.y1 : 0;
-        const float sy = (float)yr * P.fy;
-        const int y1 = (int)floorf(sy);
-        const int y2 = y1 + 1;
-        const int y2r = min(y2, P.h - 1);
-        wya[j] = (float)y2 - sy;
-        wyb[j] = sy - (float)y1;
-        const gptr_u8 ra = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step);
-        const gptr_u8 rb = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step);
+        in_y[j] = (geo.in_y >> (gi + j)) & 1;
+        wya[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wya), gi + j));
+        wyb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wyb), gi + j));
+        const gptr_u8 ra = pin_uniform(src + (size_t)__builtin_amdgcn_readlane(geo.y1, gi + j) * (size_t)P.step);
+        const gptr_u8 rb = pin_uniform(src + (size_t)__builtin_amdgcn_readlane(geo.y2r, gi + j) * (size_t)P.step);
         if constexpr (EB == 1) { // (rows narrower than the tap window never reach the server: queue_submit refuses them)
             va[j] = q_load_win<LD>(ra + ol);
             vb[j] = q_load_win<LD>(rb + ol);
@@ -379,6 +392,8 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     const uint32_t esh = t.out_half ? 1u : 2u; // log2 of the element size (wave-uniform)
     const uint32_t plane_off = (uint32_t)(((int64_t)z * t.img_stride) << esh);
     const uint32_t ch_bytes = (uint32_t)(t.ch_stride << esh);
+    // channel k of the value goes to plane k -- or, with the chain's R <-> B swap, 2 - k for k = 0, 2 (wave-uniform)
+    const uint32_t ch_off[4] = {t.swap ? 2u * ch_bytes : 0u, ch_bytes, t.swap ? 0u : 2u * ch_bytes, 3u * ch_bytes};
     ProgArgs prog;
     prog.fast_div = t.fast_div;
 #pragma unroll
@@ -390,12 +405,7 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     }
     auto run_prog = [&](Px& p) {
         int depth = CVGS_DEPTH_32F, cn = CN;
-        if (t.swap) { // wave-uniform
-            const float s = p.v[0];
-            p.v[0] = p.v[2];
-            p.v[2] = s;
-        }
-        ProgMulSubDiv::run(prog, p, depth, cn);
+        ProgMulSubDiv::run(prog, p, depth, cn); // (the R <-> B swap is not executed: QTask carries its operands and planes exchanged)
     };
     auto store_rows = [&](const float (&v)[kQRowsPerWave][4]) { // as k1q_rows
         const bool full = col_tile * 64 + 63 < dst_w;
@@ -417,11 +427,11 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
                     typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
                     const h2 lo = {(_Float16)o[0], (_Float16)o[1]}, hi = {(_Float16)o[2], (_Float16)o[3]};
                     const u32x2q d = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
-                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off + ch_off[k], 0, 16 /* sc1 */);
                 } else {
                     typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
                     const u32x4q d = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + (uint32_t)k * ch_bytes, 0, 16 /* sc1 */);
+                    if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off + ch_off[k], 0, 16 /* sc1 */);
                 }
             }
         } else {
@@ -431,8 +441,8 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
                     const uint32_t off = plane_off + ((uint32_t)((row0 + j) * W + x) << esh);
 #pragma unroll
                     for (int k = 0; k < CN; ++k) {
-                        if (t.out_half) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 : 16);
-                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + (uint32_t)k * ch_bytes, 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
+                        if (t.out_half) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[j][k]), rsrc, off + ch_off[k], 0, ST == 0 ? 2 : 16);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j][k]), rsrc, off + ch_off[k], 0, ST == 0 ? 2 /* nt */ : 16 /* sc1 */);
                     }
                 }
             }
@@ -808,6 +818,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             t.dst_h = (int)q_lane_u32(v, QD_DST_H);
             t.out_w = (int)q_lane_u32(v, QD_OUT_W);
             t.swap = (int)q_lane_u32(v, QD_SWAP);
+            if (t.swap) { // swap, then per-channel mul / sub / div == per-channel stages with operands 0 <-> 2 exchanged, channel k stored in plane 2 - k
+                float x;
+                x = t.mul[0]; t.mul[0] = t.mul[2]; t.mul[2] = x;
+                x = t.sub[0]; t.sub[0] = t.sub[2]; t.sub[2] = x;
+                x = t.div[0]; t.div[0] = t.div[2]; t.div[2] = x;
+                x = t.rdiv[0]; t.rdiv[0] = t.rdiv[2]; t.rdiv[2] = x;
+            }
             t.fast_div = (int)q_lane_u32(v, QD_FAST_DIV);
             t.img_stride = (int64_t)q_lane_u64(v, QD_IMG_STRIDE);
             t.ch_stride = (int64_t)q_lane_u64(v, QD_CH_STRIDE);
@@ -826,23 +843,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
                 pre_valid = true;
             }
             const int rows_per_task = (int)q_lane_u32(v, QD_ROWS_PER_TASK);
+            [[maybe_unused]] QRowGeo geo{};
 #pragma nounroll
             for (int grp = 0; grp * kQRowsPerWave < rows_per_task; ++grp) {
                 const int row0 = (int)row_tile * rows_per_task + grp * kQRowsPerWave;
                 if (row0 >= t.dst_h) break;
+                [[maybe_unused]] const int gi = (grp & 15) * kQRowsPerWave;
+                if constexpr (KIND != QK_NV12) {
+                    if (gi == 0) geo = q_row_geo(t.P, t.dst_h, row0, lane); // the next 64 rows' vertical geometry, one row per lane
+                }
                 if constexpr (KIND == QK_NV12) {
                     k4q_rows<LD, ST>(t, (int)z, (int)col_tile, row0, lane);
                 } else if constexpr (KIND == QK_PIXELS16) {
                     const bool sgn = q_lane_u32(v, QD_SRC_SIGNED) != 0; // wave-uniform
                     if (c3) {
-                        if (sgn) k1q_rows<3, LD, ST, SRC_S16>(t, (int)z, (int)col_tile, row0, lane);
-                        else k1q_rows<3, LD, ST, SRC_U16>(t, (int)z, (int)col_tile, row0, lane);
+                        if (sgn) k1q_rows<3, LD, ST, SRC_S16>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
+                        else k1q_rows<3, LD, ST, SRC_U16>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
                     } else {
-                        if (sgn) k1q_rows<4, LD, ST, SRC_S16>(t, (int)z, (int)col_tile, row0, lane);
-                        else k1q_rows<4, LD, ST, SRC_U16>(t, (int)z, (int)col_tile, row0, lane);
+                        if (sgn) k1q_rows<4, LD, ST, SRC_S16>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
+                        else k1q_rows<4, LD, ST, SRC_U16>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
                     }
-                } else if (c3) k1q_rows<3, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
-                else k1q_rows<4, LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+                } else if (c3) k1q_rows<3, LD, ST>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
+                else k1q_rows<4, LD, ST>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
             }
         }
         // ---- arrive: the write-through stores are visible device-wide once drained; the batch's last arrival raises its flags ----

@@ -1083,6 +1083,8 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
         const int v = atoi(ge);
         if (v >= 1 && v <= 4095) G = (uint32_t)v;
     }
+    const uint32_t g_cap = (uint32_t)prop.multiProcessorCount * 4u - 1u; // every workgroup must be resident (each worker holds a ticket): 4 per CU at most
+    if (G > g_cap) G = g_cap;
     q->G = G;
     const double tick_hz = 100e6; // s_memrealtime: constant 100 MHz
     q->idle_ticks = (uint64_t)((idle_us <= 0 ? 200.0 : idle_us) * 1e-6 * tick_hz);

@@ -386,6 +386,8 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  *                       batch up to the ticket that it has not yet seen complete); cvgs_queue_stream_wait makes a HIP stream
  *                       wait for the same set instead (one hipStreamWaitValue64 per batch still open, on the batches' device-side
  *                       completion words), the consumer's kernels enqueued behind it see the tensors.
+ * Tuning hooks (environment): CVGS_QUEUE_G = worker workgroups (default 3 per CU - 1; the flags' bits 16..27 say the same per queue),
+ * CVGS_QUEUE_DEEP_ROWS = rows per task of a deep queue (default 64 / 128 by depth), CVGS_QUEUE_STALL_MS, CVGS_QUEUE_STAGED=1, CVGS_QUEUE_DEBUG=1.
  * Submits from several host threads are serialised by a mutex (tickets are handed out in submit order).  cvgs_queue_destroy
  * completes the batches in flight first (the workers drain the ring before they see the stop word), then retires the server.
  * No reference counterpart.                                                                                           */

@@ -14,9 +14,11 @@
 //           tools/probes/bar_probe.cpp -- probed at create, staged through a copy kernel where the BAR is not mapped), then
 //           the queue's tail word.  The control block / ring / index live in UNCACHED device memory, so no device cache can
 //           hold a stale copy of what the host rewrites.
-//   worker  4 independent waves per workgroup, 4 G in all; worker w owns the tasks T = w (mod 4 G) of a cumulative task
-//           numbering (static: no dequeue atomics); a task = 16 output rows x 64 columns of one crop.  Batches are consecutive
-//           task ranges, so they interleave over the whole chip and batch k+1 starts while batch k's stores drain.  A worker
+//   worker  4 independent waves per workgroup, 4 G in all.  A task = R output rows x 64 columns of one crop in a cumulative task
+//           numbering (R = 4 / 16 / 64 / 128 by queue depth); a worker HOLDS one task number (worker w starts with T = w) and draws its
+//           next one from the ticket counter of its residue class (16 counters, T = w mod 16) when it has finished a task: work
+//           goes to whoever is free, oldest first.  Batches are consecutive task ranges, so they interleave over the whole chip
+//           and batch k+1 starts while batch k's stores drain.  A worker
 //           finds the batch that holds T with ONE wave-wide load of a 64-entry window of the batch index (read together with the
 //           tail: a worker only goes to sleep on a tail whose newest batch it has SEEN in the window).  After a task it
 //           drains its write-through stores and bumps the batch's arrival counter; the LAST arrival publishes the batch's
@@ -24,15 +26,16 @@
 //   janitor (workgroup 0, one wave) retires the grid after `idle_us` without work (Dekker hand-shake with the host on words in
 //           HOST memory: PCIe ordering makes the device's state store visible before its re-read of the host's tail), and
 //           trips a watchdog when a batch makes no progress -- the server never outlives its work and cannot hang a box.
-// Stores are sc1 WRITE-THROUGH 16-byte vectors: the lane = column register layout is transposed 4x4 inside lane quads (two
-// DPP rounds) so that a lane owns 4 consecutive columns of ONE row -- a dword-per-lane sc1 store is one fabric write per lane
+// Stores are sc1 WRITE-THROUGH 16-byte vectors: the lane = column register layout is transposed through a wave-private LDS tile
+// (q_lds_put / q_lds_get) so that a lane owns 4 consecutive columns of ONE row -- a dword-per-lane sc1 store is one fabric write per lane
 // (MI355X_MICROARCH.md "stores of each flavour").  Tap loads are sc1 too: the server outlives kernel boundaries, so its
 // L1 / L2 never see the invalidate a kernel start performs; agent-coherent loads never serve a stale copy of a source buffer
 // the caller has rewritten between two submits (tests/test_gpu_queue.py rewrites one).
 //
-// Two kinds of batches, one server instantiation each (QK_*; a queue's first submit decides): crops of 8UC3 / 8UC4 frames
-// (k1q_rows: K1's arithmetic -- the headline) and crops of NV12 / NV21 decoder surfaces (k4q_rows: K4's arithmetic -- BASELINE
-// cfg #3 and the decode-side 50-crop batch: 8.4 -> 7.4-7.6 us and 4.7 -> 3.5 us per frame, tools/bench_more.py).
+// Three kinds of batches, one server instantiation each (QK_*; a queue's first submit decides): crops of 8UC3 / 8UC4 frames
+// (k1q_rows: K1's arithmetic -- the headline), of 16UC3 / 16UC4 / 16SC3 / 16SC4 frames (the same worker on 16-byte windows) and of
+// NV12 / NV21 decoder surfaces (k4q_rows: K4's arithmetic -- BASELINE cfg #3 and the decode-side 50-crop batch: 8.0 -> 5.8 us and
+// 4.7 -> 2.5 us per frame, tools/bench_more.py).
 #include <immintrin.h>
 #include <setjmp.h>
 #include <signal.h>
@@ -983,7 +986,7 @@ static void raise_done_hint(Queue* q, uint64_t d) {
     while (cur < d && !q->done_hint.compare_exchange_weak(cur, d, std::memory_order_relaxed)) {}
 }
 
-// ONE server grid per device at a time.  A server's tasks are statically owned, so every one of its workgroups must be resident;
+// ONE server grid per device at a time.  Every worker of a server holds a task number (its ticket), so every one of its workgroups must be resident;
 // two queues' grids do not fit the chip together (3 of 4 wave slots per SIMD each): a second server stays partly resident for as
 // long as the first one is fed, and its batches -- whose tasks are spread over ALL its workers -- cannot complete (the watchdog
 // reports them after 250 ms).  So a queue that needs to launch asks the device's current server to retire as soon as it has
@@ -1068,7 +1071,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     e = q->st == 2 && q->ld == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2>, 256, 0)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<0, 0>, 256, 0);
     if (e != hipSuccess || per_cu < 1) { err = "occupancy query failed"; delete q; return -1; }
-    // Every workgroup must be resident (tasks are statically owned).  The occupancy API can overstate by one where the SGPR
+    // Every workgroup must be resident (each worker holds a ticket).  The occupancy API can overstate by one where the SGPR
     // file is the binding limit (MI355X_MICROARCH.md "Residency"); at <= 5 workgroups per CU the VGPR file binds and it is exact.
     int use = per_cu > 8 ? 8 : per_cu;
     if (use > 5) use -= 1;
@@ -1211,7 +1214,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     }
     if (q->kind < 0) {
         q->kind = kind;
-        if (kind != QK_PIXELS) { // every workgroup must be resident (tasks are statically owned): these workers' register budget allows 3 per CU
+        if (kind != QK_PIXELS) { // every workgroup must be resident (each worker holds a ticket): these workers' register budget allows 3 per CU
             int per_cu = 0;
             const hipError_t oe = kind == QK_NV12 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_NV12>, 256, 0)
                                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_PIXELS16>, 256, 0);

@@ -56,7 +56,7 @@ constexpr int kQSlotBytes = 4096;   // one batch: 256 B of parameters, planes fr
 constexpr int kQPlanesOff = 512;
 constexpr int kQMaxPlanes = (kQSlotBytes - kQPlanesOff) / (int)sizeof(PlaneParams); // 74
 constexpr int kQMaxRing = 256;
-constexpr int kQRowsPerWave = 4, kQWaves = 4, kQRowsPerTask = 16, kQRowsPerTaskMid = 64, kQRowsPerTaskDeep = 128;
+constexpr int kQRowsPerWave = 4, kQWaves = 4, kQRowsPerTask = 16, kQRowsPerTaskMid = 32, kQRowsPerTaskDeep = 128;
 constexpr int kQSubOff = 256;      // 16 cumulative sub-counter targets (8 bytes each) behind the parameters
 constexpr int kQSubs = 16;         // arrival sub-counters per slot: task T arrives at sub-counter T % 16
 constexpr int kQCtrStride = 16;    // counters are 128 bytes (16 words) apart
@@ -1260,13 +1260,18 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     p.col_tiles = (uint32_t)((r.dst_w + 63) / 64);
     // task size: a shallow queue is a latency problem (4 rows per task: four times the waves on each batch), a deep one a throughput
     // problem -- every worker is busy there, a task costs its worker ~4 us of dispatch (ticket, index window, slot, drain, arrival)
-    // beside ~0.8 us per row, and larger tasks keep a wave on one crop's rows: 16 rows per task with 2..7 batches in flight, 64 with
-    // 8..31, 128 with 32 or more (headline 2.49 / 2.25 / 2.21 us per batch; the reference's 60 x 120 crops, 50 per batch: 1.56 / 1.32 /
-    // 1.32).  The price is the tail of a burst: the last batches' tasks run 60 - 110 us.  CVGS_QUEUE_DEEP_ROWS pins the deep size (tuning).
+    // beside ~0.8 us per row, and larger tasks keep a wave on one crop's rows (headline with the deep size pinned to 16 / 32 / 64 / 128
+    // rows: 2.49 / 2.38 / 2.25 / 2.21 us per batch).  The price is the tail of a burst -- the last batches' tasks run 60 - 110 us: a burst
+    // of 16 batches takes 71 us with 64-row tasks from 8 batches in flight, 53 us with 16-row tasks (tools/probes/queue_burst_tail.py).
+    // So: 16 rows with 2..7 batches in flight, 32 from 8, and the large size (128 rows; 64 on rings shallower than 128 slots, whose
+    // batches would not hold two tasks per worker) only when the ring is three quarters full, i.e. the stream is sustained.
+    // CVGS_QUEUE_DEEP_ROWS pins the size used from 8 batches in flight (tuning).
     advance_done(q);
     const uint64_t in_flight = q->next_seq - q->done_inorder;
     static const int deep_env = getenv("CVGS_QUEUE_DEEP_ROWS") ? atoi(getenv("CVGS_QUEUE_DEEP_ROWS")) & ~3 : 0;
-    const uint32_t deep_rows = deep_env >= 4 && deep_env <= 4096 ? (uint32_t)deep_env : (in_flight >= 32 ? (uint32_t)kQRowsPerTaskDeep : (uint32_t)kQRowsPerTaskMid);
+    const bool sustained = q->R >= 32 && in_flight * 4 >= q->R * 3;
+    const uint32_t deep_rows = deep_env >= 4 && deep_env <= 4096 ? (uint32_t)deep_env
+                               : (sustained ? (q->R >= 128 ? (uint32_t)kQRowsPerTaskDeep : 64u) : (uint32_t)kQRowsPerTaskMid);
     p.rows_per_task = in_flight >= 8 ? deep_rows : (in_flight >= 2 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
     p.tiles_per_plane = p.col_tiles * (uint32_t)((r.dst_h + (int)p.rows_per_task - 1) / (int)p.rows_per_task);
     p.n_tasks = p.tiles_per_plane * (uint32_t)r.batch;

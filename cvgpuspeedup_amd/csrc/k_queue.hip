@@ -384,7 +384,7 @@ __device__ __forceinline__ uint32_t q_load_u32(gptr_u8 p) {
 }
 
 template <int LD, int ST>
-__device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, int row0, int lane) {
+__device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, int row0, int lane, const QRowGeo& geo, int gi) { // geo lane gi + j <-> row0 + j
     constexpr int CN = 3;
     const PlaneParams& P = t.P;
     const int dst_w = t.dst_w, dst_h = t.dst_h, W = t.out_w;
@@ -481,11 +481,19 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     const bool edge = x2 > P.w - 1;
     const int x2r = edge ? x1 : x2;
     const uint32_t yo = (uint32_t)min(x1, P.w - 2);
-    const int ysh = (x1 - (int)yo) * 8;
     const int c1 = x1 >> 1, c2 = x2r >> 1;
     const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4);
-    const int ush = (2 * c1 - (int)uo) * 8;
     const bool same_pair = c2 == c1;
+    // The four taps' samples as bytes of three dwords -- luma {a0, a1, b0, b1} (row a / b, tap 0 / 1), U and V likewise -- picked by
+    // v_perm_b32 out of the two 2-byte luma loads and the two 4-byte chroma loads; the selectors hold what was a shift, a mask and
+    // a select per sample: the window clamped back at the right edge (edge <=> the 2-byte luma window starts one pixel early and both
+    // taps are its second byte; the last chroma pair <=> the 4-byte window starts one pair early), taps that share a chroma pair,
+    // and NV21's byte order (wave-uniform).  Then one v_cvt_f32_ubyteN per sample.
+    const uint32_t sel_y = edge ? 0x05050101u : 0x05040100u;
+    const uint32_t pr0 = 2 * c1 != (int)uo ? 2u : 0u;   // byte of tap 0's pair inside the chroma window
+    const uint32_t pr1 = same_pair ? pr0 : 2u;          // ... of tap 1's
+    const uint32_t sel_c = pr0 | (pr1 << 8) | ((4u + pr0) << 16) | ((4u + pr1) << 24);
+    const uint32_t sel_u = sel_c + (t.yuv_vu ? 0x01010101u : 0u), sel_v = sel_c + (t.yuv_vu ? 0u : 0x01010101u);
     const gptr_u8 base = (gptr_u8)P.data;
     const size_t step = (size_t)P.step;
     const gptr_u8 uvp = base + (size_t)P.uv_off;
@@ -495,16 +503,10 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     bool in_y[kQRowsPerWave];
 #pragma unroll
     for (int j = 0; j < kQRowsPerWave; ++j) {
-        const int y = min(row0 + j, dst_h - 1);
-        in_y[j] = y >= P.y1 && y <= P.y2;
-        const int yr = in_y[j] ? y - P.y1 : 0;
-        const float sy = (float)yr * P.fy;
-        const int y1 = (int)floorf(sy);
-        const int y2 = y1 + 1;
-        const int y2r = min(y2, P.h - 1);
-        wya[j] = (float)y2 - sy;
-        wyb[j] = sy - (float)y1;
-        const int r1 = __builtin_amdgcn_readfirstlane(y1), r2 = __builtin_amdgcn_readfirstlane(y2r);
+        in_y[j] = (geo.in_y >> (gi + j)) & 1;
+        wya[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wya), gi + j));
+        wyb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wyb), gi + j));
+        const int r1 = __builtin_amdgcn_readlane(geo.y1, gi + j), r2 = __builtin_amdgcn_readlane(geo.y2r, gi + j);
         vya[j] = q_load_u16<LD>(pin_uniform(base + (size_t)r1 * step) + yo);
         vyb[j] = q_load_u16<LD>(pin_uniform(base + (size_t)r2 * step) + yo);
         vua[j] = q_load_u32<LD>(pin_uniform(uvp + (size_t)(r1 >> 1) * step) + uo);
@@ -513,18 +515,11 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     float outv[kQRowsPerWave][4];
 #pragma unroll
     for (int j = 0; j < kQRowsPerWave; ++j) {
-        const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
-        const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
-        uint32_t ca = vua[j], cb = vub[j];
-        if (t.yuv_vu) { // NV21: swap the bytes of every pair once, then everything below is NV12 (wave-uniform)
-            ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
-            cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
-        }
-        const uint32_t pa0 = (ca >> ush) & 0xffffu, pa1 = same_pair ? pa0 : (ca >> 16) & 0xffffu;
-        const uint32_t pb0 = (cb >> ush) & 0xffffu, pb1 = same_pair ? pb0 : (cb >> 16) & 0xffffu;
-        const float fy[4] = {(float)ya0, (float)ya1, (float)yb0, (float)yb1};
-        const float fu[4] = {(float)(pa0 & 0xffu), (float)(pa1 & 0xffu), (float)(pb0 & 0xffu), (float)(pb1 & 0xffu)};
-        const float fv[4] = {(float)(pa0 >> 8), (float)(pa1 >> 8), (float)(pb0 >> 8), (float)(pb1 >> 8)};
+        const uint32_t ly = __builtin_amdgcn_perm(vyb[j], vya[j], sel_y);
+        const uint32_t lu = __builtin_amdgcn_perm(vub[j], vua[j], sel_u), lv = __builtin_amdgcn_perm(vub[j], vua[j], sel_v);
+        const float fy[4] = {(float)(ly & 0xffu), (float)((ly >> 8) & 0xffu), (float)((ly >> 16) & 0xffu), (float)(ly >> 24)};
+        const float fu[4] = {(float)(lu & 0xffu), (float)((lu >> 8) & 0xffu), (float)((lu >> 16) & 0xffu), (float)(lu >> 24)};
+        const float fv[4] = {(float)(lv & 0xffu), (float)((lv >> 8) & 0xffu), (float)((lv >> 16) & 0xffu), (float)(lv >> 24)};
         float t00[4], t10[4], t01[4], t11[4];
         if (t.yuv_range == CVGS_YUV_FULL) { // wave-uniform
             k4_tap<CN, true>(fy[0], fu[0], fv[0], yk, t00);
@@ -846,17 +841,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
                 pre_valid = true;
             }
             const int rows_per_task = (int)q_lane_u32(v, QD_ROWS_PER_TASK);
-            [[maybe_unused]] QRowGeo geo{};
+            QRowGeo geo{};
 #pragma nounroll
             for (int grp = 0; grp * kQRowsPerWave < rows_per_task; ++grp) {
                 const int row0 = (int)row_tile * rows_per_task + grp * kQRowsPerWave;
                 if (row0 >= t.dst_h) break;
-                [[maybe_unused]] const int gi = (grp & 15) * kQRowsPerWave;
-                if constexpr (KIND != QK_NV12) {
-                    if (gi == 0) geo = q_row_geo(t.P, t.dst_h, row0, lane); // the next 64 rows' vertical geometry, one row per lane
-                }
+                const int gi = (grp & 15) * kQRowsPerWave;
+                if (gi == 0) geo = q_row_geo(t.P, t.dst_h, row0, lane); // the next 64 rows' vertical geometry, one row per lane
                 if constexpr (KIND == QK_NV12) {
-                    k4q_rows<LD, ST>(t, (int)z, (int)col_tile, row0, lane);
+                    k4q_rows<LD, ST>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
                 } else if constexpr (KIND == QK_PIXELS16) {
                     const bool sgn = q_lane_u32(v, QD_SRC_SIGNED) != 0; // wave-uniform
                     if (c3) {

@@ -33,19 +33,24 @@ def events_time(fn, iters, warm=5):
 
 def queue_time(chains, frames_per_replay=384, replays=9):
     """The same pre-lowered chains, ONE cvgs_queue_submit per frame (no kernel launch per frame; csrc/k_queue.hip): K frames are
-    handed to cvgs_queue_submit_many, the host's wall clock brackets submit + wait of the last ticket; median over the replays
-    (each replay ends with the queue drained: ~25 us of latency tail in K frames' time).  Returns seconds per frame."""
+    handed to cvgs_queue_submit_many per replay; replays are pipelined one ahead the way a serving loop runs (replay r+1 is
+    submitted, then replay r's last ticket awaited -- bench.py's protocol for the headline), the host's wall clock is stamped at
+    every awaited ticket; median stamp difference / K.  Returns seconds per frame."""
     import time
     q = cvgs.Queue(idle_us=2000.0, depth=128, flags=(int(os.environ.get("CVGS_BENCH_QUEUE_G", "0")) & 0xfff) << 16)  # tuning hook: worker workgroups
     try:
         seq = [chains[i % len(chains)] for i in range(frames_per_replay)]
         ptrs = cvgs.Queue.chain_pointers(seq)
         q.wait(q.submit_many(ptrs, frames_per_replay), 30.0)
-        ts = []
-        for _ in range(replays):
-            t0 = time.perf_counter()
-            q.wait(q.submit_many(ptrs, frames_per_replay), 30.0)
-            ts.append((time.perf_counter() - t0) / frames_per_replay)
+        stamps = []
+        prev = q.submit_many(ptrs, frames_per_replay)
+        for _ in range(replays + 1):
+            cur = q.submit_many(ptrs, frames_per_replay)
+            q.wait(prev, 30.0)
+            stamps.append(time.perf_counter())
+            prev = cur
+        q.wait(prev, 30.0)
+        ts = [(b - a) / frames_per_replay for a, b in zip(stamps, stamps[1:])]
         st = q.stats()
         if st["error"]:
             raise RuntimeError("queue error %r" % (st,))

@@ -196,8 +196,9 @@ struct QTask { // everything a wave needs for its 4 rows, wave-uniform
 // The vertical geometry of 64 consecutive output rows, one row per lane (computed once per 64 rows of a task; the row loop reads its
 // rows' values with v_readlane: 4 instructions per row instead of the 16 of computing wave-uniform values on the vector pipe)
 struct QRowGeo {
-    int y1, y2r;       // source rows of the two taps
-    float wya, wyb;    // their weights
+    uint32_t oa, ob;   // byte offsets of the two tap rows: y1 * step, min(y1 + 1, h - 1) * step (sources stay below 4 GB: queue_submit)
+    uint32_t ca, cb;   // NV12: byte offsets of their chroma rows inside the UV plane, (y >> 1) * step
+    float wya, wyb;    // the taps' weights
     uint64_t in_y;     // bit i: row first + i lies inside the destination window (aspect-ratio modes)
 };
 __device__ __forceinline__ QRowGeo q_row_geo(const PlaneParams& P, int dst_h, int first, int lane) {
@@ -206,11 +207,15 @@ __device__ __forceinline__ QRowGeo q_row_geo(const PlaneParams& P, int dst_h, in
     const bool in = y >= P.y1 && y <= P.y2;
     const int yr = in ? y - P.y1 : 0;
     const float sy = (float)yr * P.fy;
-    g.y1 = (int)floorf(sy);
-    const int y2 = g.y1 + 1;
-    g.y2r = min(y2, P.h - 1);
+    const int y1 = (int)floorf(sy);
+    const int y2 = y1 + 1;
+    const int y2r = min(y2, P.h - 1);
+    g.oa = (uint32_t)y1 * (uint32_t)P.step;
+    g.ob = (uint32_t)y2r * (uint32_t)P.step;
+    g.ca = (uint32_t)(y1 >> 1) * (uint32_t)P.step;
+    g.cb = (uint32_t)(y2r >> 1) * (uint32_t)P.step;
     g.wya = (float)y2 - sy;
-    g.wyb = sy - (float)g.y1;
+    g.wyb = sy - (float)y1;
     g.in_y = __builtin_amdgcn_ballot_w64(in);
     return g;
 }
@@ -328,14 +333,16 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
         in_y[j] = (geo.in_y >> (gi + j)) & 1;
         wya[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wya), gi + j));
         wyb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wyb), gi + j));
-        const gptr_u8 ra = pin_uniform(src + (size_t)__builtin_amdgcn_readlane(geo.y1, gi + j) * (size_t)P.step);
-        const gptr_u8 rb = pin_uniform(src + (size_t)__builtin_amdgcn_readlane(geo.y2r, gi + j) * (size_t)P.step);
+        // (a uniform 64-bit base + a 32-bit lane offset: one v_readlane and one v_add per load instead of a 64-bit scalar multiply-add
+        //  and a 64-bit vector add -- issuing a group's loads took a worker 0.75 us of dependent scalar arithmetic)
+        const uint32_t oa = (uint32_t)__builtin_amdgcn_readlane((int)geo.oa, gi + j) + ol, ob = (uint32_t)__builtin_amdgcn_readlane((int)geo.ob, gi + j) + ol;
+        const gptr_u8 ra = pin_uniform(src) + oa, rb = pin_uniform(src) + ob;
         if constexpr (EB == 1) { // (rows narrower than the tap window never reach the server: queue_submit refuses them)
-            va[j] = q_load_win<LD>(ra + ol);
-            vb[j] = q_load_win<LD>(rb + ol);
+            va[j] = q_load_win<LD>(ra);
+            vb[j] = q_load_win<LD>(rb);
         } else {
-            va[j] = q_load_win16<LD>(ra + ol);
-            vb[j] = q_load_win16<LD>(rb + ol);
+            va[j] = q_load_win16<LD>(ra);
+            vb[j] = q_load_win16<LD>(rb);
         }
     }
     float outv[kQRowsPerWave][4];
@@ -495,7 +502,6 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     const uint32_t sel_c = pr0 | (pr1 << 8) | ((4u + pr0) << 16) | ((4u + pr1) << 24);
     const uint32_t sel_u = sel_c + (t.yuv_vu ? 0x01010101u : 0u), sel_v = sel_c + (t.yuv_vu ? 0u : 0x01010101u);
     const gptr_u8 base = (gptr_u8)P.data;
-    const size_t step = (size_t)P.step;
     const gptr_u8 uvp = base + (size_t)P.uv_off;
 
     uint32_t vya[kQRowsPerWave], vyb[kQRowsPerWave], vua[kQRowsPerWave], vub[kQRowsPerWave];
@@ -506,11 +512,12 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
         in_y[j] = (geo.in_y >> (gi + j)) & 1;
         wya[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wya), gi + j));
         wyb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wyb), gi + j));
-        const int r1 = __builtin_amdgcn_readlane(geo.y1, gi + j), r2 = __builtin_amdgcn_readlane(geo.y2r, gi + j);
-        vya[j] = q_load_u16<LD>(pin_uniform(base + (size_t)r1 * step) + yo);
-        vyb[j] = q_load_u16<LD>(pin_uniform(base + (size_t)r2 * step) + yo);
-        vua[j] = q_load_u32<LD>(pin_uniform(uvp + (size_t)(r1 >> 1) * step) + uo);
-        vub[j] = q_load_u32<LD>(pin_uniform(uvp + (size_t)(r2 >> 1) * step) + uo);
+        const uint32_t oa = (uint32_t)__builtin_amdgcn_readlane((int)geo.oa, gi + j) + yo, ob = (uint32_t)__builtin_amdgcn_readlane((int)geo.ob, gi + j) + yo;
+        const uint32_t ca = (uint32_t)__builtin_amdgcn_readlane((int)geo.ca, gi + j) + uo, cb = (uint32_t)__builtin_amdgcn_readlane((int)geo.cb, gi + j) + uo;
+        vya[j] = q_load_u16<LD>(pin_uniform(base) + oa); // (uniform base + 32-bit lane offset, as k1q_rows)
+        vyb[j] = q_load_u16<LD>(pin_uniform(base) + ob);
+        vua[j] = q_load_u32<LD>(pin_uniform(uvp) + ca);
+        vub[j] = q_load_u32<LD>(pin_uniform(uvp) + cb);
     }
     float outv[kQRowsPerWave][4];
 #pragma unroll
@@ -1162,11 +1169,16 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
         err = "queue: chain is not a batched 8U / 16U / 16S C3 / C4 (or NV12 / NV21 -> 3 channels) resize into an fp32 / fp16 planar tensor with host plane descriptors";
         return 1;
     }
-    for (int i = 0; i < n_planes && i < r.used; ++i)
+    for (int i = 0; i < n_planes && i < r.used; ++i) {
         if (nv12 ? planes[i].w < 4 : planes[i].w * r.cn < 8) { // (8 ELEMENTS: the window is 8 bytes of 8-bit, 16 bytes of 16-bit pixels)
             err = nv12 ? "queue: a surface crop narrower than 4 pixels" : "queue: a crop narrower than the tap window (1-2 pixels)";
             return 1;
         }
+        if ((uint64_t)planes[i].h * (uint64_t)planes[i].step >= (1ull << 32)) { // the workers address a crop's rows with 32-bit byte offsets
+            err = "queue: a source crop spanning 4 GB or more";
+            return 1;
+        }
+    }
     ChainArgs c = c_in;
     c.prog.fast_div = 0;
     for (int k = 0; k < 4; ++k) c.prog.rdiv[k] = 0.f;

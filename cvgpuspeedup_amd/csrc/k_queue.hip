@@ -165,12 +165,14 @@ __device__ __forceinline__ Win<1> q_load_win(gptr_u8 p) {
     return w;
 }
 
-// The 4 x 64 tile a wave has computed (lane = column, register = row) leaves as 16-byte stores (lane = four consecutive columns of
-// one row).  The transpose goes through a wave-private LDS tile: four conflict-free ds_write_b32 and one ds_read_b128 per channel
-// instead of two DPP rounds of selects (48 VALU instructions per 4 rows of 3 channels: the workers are VALU-bound on small crops,
-// tools/pmc_queue_insts.sh).  Row stride 80 floats: lane (i = lane & 3, q = lane >> 2) reads floats i*80 + 4q .. +3, banks
-// (16 i + 4 q) mod 64 .. +3 -- sixteen lanes cover the 64 banks once.  One wave's LDS operations execute in order, so the tile is
-// reused without a barrier.
+// The 4 x 64 tile a wave has computed (lane = column, register = row) leaves as 16-byte stores: lane (i = lane >> 4, q = lane & 15)
+// stores columns 4q .. 4q+3 of row i, so that 16 consecutive lanes cover one row's 256 contiguous bytes and the memory pipeline merges
+// four lanes into one 64-byte request (a first version gave consecutive lanes consecutive ROWS -- the layout of its DPP quad
+// transposes --: 64 partial-line requests per store instead of 16 whole ones, the L2's request rate then bounded write-heavy
+// batches).  The transpose goes through a wave-private LDS tile: four conflict-free ds_write_b32 and one ds_read_b128 per channel
+// instead of two DPP rounds of selects (48 VALU instructions per 4 rows of 3 channels).  A 16-lane phase of the read covers 64
+// consecutive floats of one tile row: all 64 banks once (the row stride only has to keep 16-byte alignment).  One wave's LDS
+// operations execute in order, so the tile is reused without a barrier.
 constexpr int kQLdsRow = 80, kQLdsChan = kQRowsPerWave * kQLdsRow, kQLdsWave = 4 * kQLdsChan; // floats
 typedef float q_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void q_lds_put(float* tile, int k, const float (&r)[4], int lane) {
@@ -178,7 +180,7 @@ __device__ __forceinline__ void q_lds_put(float* tile, int k, const float (&r)[4
     for (int j = 0; j < 4; ++j) tile[k * kQLdsChan + j * kQLdsRow + lane] = r[j];
 }
 __device__ __forceinline__ q_f32x4 q_lds_get(const float* tile, int k, int lane) {
-    return *(const q_f32x4*)(tile + k * kQLdsChan + (lane & 3) * kQLdsRow + (lane >> 2) * 4);
+    return *(const q_f32x4*)(tile + k * kQLdsChan + (lane >> 4) * kQLdsRow + (lane & 15) * 4);
 }
 
 struct QTask { // everything a wave needs for its 4 rows, wave-uniform
@@ -253,7 +255,7 @@ __device__ __forceinline__ void k1q_rows(const QTask& t, int z, int col_tile, in
     auto store_rows = [&](const float (&v)[kQRowsPerWave][4]) { // v[j][k]: row j, channel k at this lane's column
         const bool full = col_tile * 64 + 63 < dst_w; // wave-uniform: every lane of the tile is alive
         if (ST == 2 && full) {
-            const int i = lane & 3, q = lane >> 2;
+            const int i = lane >> 4, q = lane & 15; // 16 consecutive lanes = one row's 256 contiguous bytes: four lanes per 64-byte request
             const bool row_ok = row0 + i < dst_h;
             const uint32_t off = plane_off + ((uint32_t)((row0 + i) * W + col_tile * 64 + q * 4) << esh);
 #pragma unroll
@@ -420,7 +422,7 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     auto store_rows = [&](const float (&v)[kQRowsPerWave][4]) { // as k1q_rows
         const bool full = col_tile * 64 + 63 < dst_w;
         if (ST == 2 && full) {
-            const int i = lane & 3, q = lane >> 2;
+            const int i = lane >> 4, q = lane & 15; // 16 consecutive lanes = one row's 256 contiguous bytes: four lanes per 64-byte request
             const bool row_ok = row0 + i < dst_h;
             const uint32_t off = plane_off + ((uint32_t)((row0 + i) * W + col_tile * 64 + q * 4) << esh);
 #pragma unroll

@@ -84,9 +84,12 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(const N2Args a) {
 
     // ---- column geometry of the lane's two pixels (k4_nv12_resize's, per pixel) ----
     f32x2 wxa, wxb;
-    bool edge[2], same_pair[2];
     uint32_t yo[2], uo[2];
-    int ysh[2], ush[2];
+    // v_perm_b32 selectors that pick a pixel's four tap samples {a0, a1, b0, b1} (row a / b, tap 0 / 1) out of its two 2-byte luma
+    // loads / its two 4-byte chroma loads: what used to be a shift, a mask and a select per sample -- the luma window clamped back at
+    // the right edge (then both taps are its second byte), the chroma window clamped back at the last pair, taps sharing a chroma pair,
+    // NV21's byte order (csrc/k_queue.hip: k4q_rows does the same)
+    uint32_t sel_y[2], sel_u[2], sel_v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int x = min(x0 + i, dst_w - 1); // an odd target's last lane computes its last pixel twice and stores it once
@@ -95,14 +98,17 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(const N2Args a) {
         const int x2 = x1 + 1;
         wxa[i] = (float)x2 - sx;
         wxb[i] = sx - (float)x1;
-        edge[i] = x2 > P.w - 1;
-        const int x2r = edge[i] ? x1 : x2;
+        const bool edge = x2 > P.w - 1;
+        const int x2r = edge ? x1 : x2;
         yo[i] = (uint32_t)min(x1, P.w - 2);
-        ysh[i] = (x1 - (int)yo[i]) * 8;
         const int c1 = x1 >> 1, c2 = x2r >> 1;
         uo[i] = (uint32_t)min(2 * c1, P.w - 4);
-        ush[i] = (2 * c1 - (int)uo[i]) * 8;
-        same_pair[i] = c2 == c1;
+        sel_y[i] = edge ? 0x05050101u : 0x05040100u;
+        const uint32_t pr0 = 2 * c1 != (int)uo[i] ? 2u : 0u; // byte of tap 0's pair inside the chroma window
+        const uint32_t pr1 = c2 == c1 ? pr0 : 2u;            // ... of tap 1's
+        const uint32_t sel_c = pr0 | (pr1 << 8) | ((4u + pr0) << 16) | ((4u + pr1) << 24);
+        sel_u[i] = sel_c + (vu ? 0x01010101u : 0u);
+        sel_v[i] = sel_c + (vu ? 0u : 0x01010101u);
     }
     const gptr_u8 base = (gptr_u8)P.data;
     const size_t step = (size_t)P.step;
@@ -143,18 +149,11 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(const N2Args a) {
         f32x2 fy[4], fu[4], fv[4]; // taps 00, 10, 01, 11 of the pixel pair
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const uint32_t ya0 = (raw.vya[i] >> ysh[i]) & 0xffu, ya1 = edge[i] ? ya0 : (raw.vya[i] >> 8) & 0xffu;
-            const uint32_t yb0 = (raw.vyb[i] >> ysh[i]) & 0xffu, yb1 = edge[i] ? yb0 : (raw.vyb[i] >> 8) & 0xffu;
-            uint32_t ca = raw.vua[i], cb = raw.vub[i];
-            if (vu) { // NV21: swap the bytes of every pair once, then everything below is NV12 (wave-uniform)
-                ca = ((ca & 0x00ff00ffu) << 8) | ((ca >> 8) & 0x00ff00ffu);
-                cb = ((cb & 0x00ff00ffu) << 8) | ((cb >> 8) & 0x00ff00ffu);
-            }
-            const uint32_t pa0 = (ca >> ush[i]) & 0xffffu, pa1 = same_pair[i] ? pa0 : (ca >> 16) & 0xffffu;
-            const uint32_t pb0 = (cb >> ush[i]) & 0xffffu, pb1 = same_pair[i] ? pb0 : (cb >> 16) & 0xffffu;
-            fy[0][i] = (float)ya0; fy[1][i] = (float)ya1; fy[2][i] = (float)yb0; fy[3][i] = (float)yb1;
-            fu[0][i] = (float)(pa0 & 0xffu); fu[1][i] = (float)(pa1 & 0xffu); fu[2][i] = (float)(pb0 & 0xffu); fu[3][i] = (float)(pb1 & 0xffu);
-            fv[0][i] = (float)(pa0 >> 8); fv[1][i] = (float)(pa1 >> 8); fv[2][i] = (float)(pb0 >> 8); fv[3][i] = (float)(pb1 >> 8);
+            const uint32_t ly = __builtin_amdgcn_perm(raw.vyb[i], raw.vya[i], sel_y[i]);
+            const uint32_t lu = __builtin_amdgcn_perm(raw.vub[i], raw.vua[i], sel_u[i]), lv = __builtin_amdgcn_perm(raw.vub[i], raw.vua[i], sel_v[i]);
+            fy[0][i] = (float)(ly & 0xffu); fy[1][i] = (float)((ly >> 8) & 0xffu); fy[2][i] = (float)((ly >> 16) & 0xffu); fy[3][i] = (float)(ly >> 24);
+            fu[0][i] = (float)(lu & 0xffu); fu[1][i] = (float)((lu >> 8) & 0xffu); fu[2][i] = (float)((lu >> 16) & 0xffu); fu[3][i] = (float)(lu >> 24);
+            fv[0][i] = (float)(lv & 0xffu); fv[1][i] = (float)((lv >> 8) & 0xffu); fv[2][i] = (float)((lv >> 16) & 0xffu); fv[3][i] = (float)(lv >> 24);
         }
         N2Rgb t[4];
         if (yuv_range == CVGS_YUV_FULL) { // wave-uniform

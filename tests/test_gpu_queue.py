@@ -164,6 +164,11 @@ def test_queue_refuses_what_the_server_does_not_take(torch_dev):
         ops32f = H.k1_chain(cvgs.GpuMat.from_tensor(frame32, cvgs.CV_32FC3), H.fixed_crops(2), cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), src_depth=cvgs.CV_32F)
         with pytest.raises(capi.CvgsError):
             q.submit(*ops32f)
+        # a source whose rows span 4 GB or more (the workers address rows with 32-bit byte offsets): refused before anything is read
+        huge = cvgs.GpuMat(4, 640, cvgs.CV_8UC3, frame_t.data_ptr(), 1 << 30, owner=frame_t)
+        ops_huge = H.k1_chain(huge, [(0, 0, 640, 4)], cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1))
+        with pytest.raises(capi.CvgsError):
+            q.submit(*ops_huge)
         # the queue is still usable afterwards
         out32, ops32 = gpu_chain(torch, dev, frame_t, H.fixed_crops(2), 2, (64, 128), 3)
         q.wait(q.submit(*ops32))

@@ -663,10 +663,11 @@ struct QDevMem { // the server's device-side state, one uncached allocation (hos
     uint64_t* ticket;   // 16 ticket counters (one per residue class of the task numbering), 128 bytes apart
 };
 
-// (register budget: 4 waves per SIMD -- 128 VGPRs -- for the pixel worker; the NV12 worker holds 16 tap words and four taps'
-// conversions per row and gets 3 waves per SIMD -- 168 VGPRs -- which is what the default 3 workgroups per CU use anyway)
+// (register budget: 4 waves per SIMD -- 128 VGPRs -- for the 8-bit pixel worker (103) and, since its tap samples are picked by v_perm_b32 and
+// its row geometry lives in lanes, for the NV12 worker too (125, no scratch: tests/test_kernel_resources.py); the 16-bit worker holds
+// 16-byte windows and gets 3 waves per SIMD -- 168 VGPRs -- which is what the default 3 workgroups per CU use anyway)
 template <int LD, int ST, int KIND = QK_PIXELS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_PIXELS ? 4 : 3, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_PIXELS16 ? 3 : 4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
                                                                                              uint64_t gen, uint64_t done0, uint64_t idle_ticks,
                                                                                              uint64_t stall_ticks) {
     __shared__ __attribute__((aligned(16))) float q_tiles[kQWaves * kQLdsWave]; // one transpose tile per wave (20 KB per workgroup)
@@ -1230,7 +1231,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
                 err = "queue: occupancy query failed";
                 return -1;
             }
-            const uint32_t g_max = (uint32_t)(q->cus * (per_cu > 3 ? 3 : per_cu)) - 1;
+            const uint32_t g_max = (uint32_t)(q->cus * (per_cu > 4 ? 4 : per_cu)) - 1;
             if (q->G > g_max) q->G = g_max; // (nothing has been launched yet: the first submit decides the kind)
         }
     }

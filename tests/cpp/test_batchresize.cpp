@@ -312,5 +312,6 @@ int main() {
     test_queue_vs_oracle<CV_8UC4, CV_32FC4, 9>(stream);
     test_queue_vs_oracle<CV_16UC3, CV_32FC3, 50>(stream); // the 16-bit kind: a queue of its own (one kind per queue)
     test_queue_vs_oracle<CV_16SC4, CV_32FC4, 11>(stream);
+    test_queue_vs_oracle<CV_8UC3, CV_32FC3, 100>(stream); // more crops than a ring slot holds (74): two slots behind one ticket
     return report("test_batchresize_x_split3D + aspectratio");
 }

@@ -86,7 +86,9 @@ enum { QD_STAMP = 0, QD_TASK_BASE = 2, QD_N_TASKS = 4, QD_TPP = 5, QD_COL_TILES 
 // What a queue serves -- latched by its first submit; each kind has its own server instantiation (the 8-bit-pixel worker is the
 // tuned headline path and carries nothing of the other's code or registers).
 enum { QK_PIXELS = 0 /* 8UC3 / 8UC4 crops (K1's shape) */, QK_NV12 = 1 /* crops of NV12 / NV21 decoder surfaces (K4's shape) */,
-       QK_PIXELS16 = 2 /* 16UC3 / 16UC4 / 16SC3 / 16SC4 crops: the other source types of the reference's K1 sweep (test_batchresize_x_split3D.cu:427-432) */ };
+       QK_PIXELS16 = 2 /* 16UC3 / 16UC4 / 16SC3 / 16SC4 crops: the other source types of the reference's K1 sweep (test_batchresize_x_split3D.cu:427-432) */,
+       QK_P010 = 3 /* crops of P010 decoder surfaces (10-bit, 16-bit samples): K4's S16 shape */ };
+constexpr bool q_kind_yuv(int kind) { return kind == QK_NV12 || kind == QK_P010; }
 
 // The batch index: one 32-byte entry per ring slot, rewritten by the host while workers may be looking: every 8-byte word is
 // written atomically, and `check` ties the four words together (a torn entry is simply not a candidate).
@@ -392,7 +394,9 @@ __device__ __forceinline__ uint32_t q_load_u32(gptr_u8 p) {
     else return __hip_atomic_load((g_u32)(__attribute__((address_space(1))) uint8_t*)p, Q_AGENT);
 }
 
-template <int LD, int ST>
+// S16: P010 surfaces -- NV12's geometry with 16-bit samples (10-bit code = sample >> 6, k_nv12.hip's S16 instantiation): the two luma taps
+// of a row are ONE 4-byte load, its two chroma pairs ONE 8-byte load; the samples are picked with shifts (no byte selectors).
+template <int LD, int ST, bool S16 = false>
 __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, int row0, int lane, const QRowGeo& geo, int gi) { // geo lane gi + j <-> row0 + j
     constexpr int CN = 3;
     const PlaneParams& P = t.P;
@@ -478,7 +482,7 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
             return;
         }
     }
-    const YuvK yk = yuv_matrix(t.yuv_range, t.yuv_primaries, CVGS_YUV_NV12);
+    const YuvK yk = yuv_matrix(t.yuv_range, t.yuv_primaries, S16 ? CVGS_YUV_P010 : CVGS_YUV_NV12);
     // ---- per-lane column geometry (k4_nv12_resize's) ----
     const int xc = live ? x : dst_w - 1;
     const bool in_x = xc >= P.x1 && xc <= P.x2;
@@ -489,24 +493,28 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
     const float wxa = (float)x2 - sx, wxb = sx - (float)x1;
     const bool edge = x2 > P.w - 1;
     const int x2r = edge ? x1 : x2;
-    const uint32_t yo = (uint32_t)min(x1, P.w - 2);
+    constexpr uint32_t kSB = S16 ? 2 : 1; // bytes per sample
+    const uint32_t yo = (uint32_t)min(x1, P.w - 2) * kSB;
     const int c1 = x1 >> 1, c2 = x2r >> 1;
-    const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4);
+    const uint32_t uo = (uint32_t)min(2 * c1, P.w - 4) * kSB;
     const bool same_pair = c2 == c1;
+    [[maybe_unused]] const uint32_t ysh = ((uint32_t)x1 * kSB - yo) * 8, ush = ((uint32_t)(2 * c1) * kSB - uo) * 8; // S16: 0 / 16 and 0 / 32
     // The four taps' samples as bytes of three dwords -- luma {a0, a1, b0, b1} (row a / b, tap 0 / 1), U and V likewise -- picked by
     // v_perm_b32 out of the two 2-byte luma loads and the two 4-byte chroma loads; the selectors hold what was a shift, a mask and
     // a select per sample: the window clamped back at the right edge (edge <=> the 2-byte luma window starts one pixel early and both
     // taps are its second byte; the last chroma pair <=> the 4-byte window starts one pair early), taps that share a chroma pair,
     // and NV21's byte order (wave-uniform).  Then one v_cvt_f32_ubyteN per sample.
     const uint32_t sel_y = edge ? 0x05050101u : 0x05040100u;
-    const uint32_t pr0 = 2 * c1 != (int)uo ? 2u : 0u;   // byte of tap 0's pair inside the chroma window
+    const uint32_t pr0 = (uint32_t)(2 * c1) * kSB != uo ? 2u : 0u;   // byte of tap 0's pair inside the chroma window
     const uint32_t pr1 = same_pair ? pr0 : 2u;          // ... of tap 1's
     const uint32_t sel_c = pr0 | (pr1 << 8) | ((4u + pr0) << 16) | ((4u + pr1) << 24);
     const uint32_t sel_u = sel_c + (t.yuv_vu ? 0x01010101u : 0u), sel_v = sel_c + (t.yuv_vu ? 0u : 0x01010101u);
     const gptr_u8 base = (gptr_u8)P.data;
     const gptr_u8 uvp = base + (size_t)P.uv_off;
 
-    uint32_t vya[kQRowsPerWave], vyb[kQRowsPerWave], vua[kQRowsPerWave], vub[kQRowsPerWave];
+    using ChromaWin = std::conditional_t<S16, uint64_t, uint32_t>; // two (U,V) pairs
+    uint32_t vya[kQRowsPerWave], vyb[kQRowsPerWave];
+    ChromaWin vua[kQRowsPerWave], vub[kQRowsPerWave];
     float wya[kQRowsPerWave], wyb[kQRowsPerWave];
     bool in_y[kQRowsPerWave];
 #pragma unroll
@@ -516,19 +524,38 @@ __device__ __forceinline__ void k4q_rows(const QTask& t, int z, int col_tile, in
         wyb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo.wyb), gi + j));
         const uint32_t oa = (uint32_t)__builtin_amdgcn_readlane((int)geo.oa, gi + j) + yo, ob = (uint32_t)__builtin_amdgcn_readlane((int)geo.ob, gi + j) + yo;
         const uint32_t ca = (uint32_t)__builtin_amdgcn_readlane((int)geo.ca, gi + j) + uo, cb = (uint32_t)__builtin_amdgcn_readlane((int)geo.cb, gi + j) + uo;
-        vya[j] = q_load_u16<LD>(pin_uniform(base) + oa); // (uniform base + 32-bit lane offset, as k1q_rows)
-        vyb[j] = q_load_u16<LD>(pin_uniform(base) + ob);
-        vua[j] = q_load_u32<LD>(pin_uniform(uvp) + ca);
-        vub[j] = q_load_u32<LD>(pin_uniform(uvp) + cb);
+        if constexpr (S16) {
+            vya[j] = q_load_u32<LD>(pin_uniform(base) + oa);
+            vyb[j] = q_load_u32<LD>(pin_uniform(base) + ob);
+            vua[j] = q_load_win<LD>(pin_uniform(uvp) + ca).lo;
+            vub[j] = q_load_win<LD>(pin_uniform(uvp) + cb).lo;
+        } else {
+            vya[j] = q_load_u16<LD>(pin_uniform(base) + oa); // (uniform base + 32-bit lane offset, as k1q_rows)
+            vyb[j] = q_load_u16<LD>(pin_uniform(base) + ob);
+            vua[j] = q_load_u32<LD>(pin_uniform(uvp) + ca);
+            vub[j] = q_load_u32<LD>(pin_uniform(uvp) + cb);
+        }
     }
     float outv[kQRowsPerWave][4];
 #pragma unroll
     for (int j = 0; j < kQRowsPerWave; ++j) {
-        const uint32_t ly = __builtin_amdgcn_perm(vyb[j], vya[j], sel_y);
-        const uint32_t lu = __builtin_amdgcn_perm(vub[j], vua[j], sel_u), lv = __builtin_amdgcn_perm(vub[j], vua[j], sel_v);
-        const float fy[4] = {(float)(ly & 0xffu), (float)((ly >> 8) & 0xffu), (float)((ly >> 16) & 0xffu), (float)(ly >> 24)};
-        const float fu[4] = {(float)(lu & 0xffu), (float)((lu >> 8) & 0xffu), (float)((lu >> 16) & 0xffu), (float)(lu >> 24)};
-        const float fv[4] = {(float)(lv & 0xffu), (float)((lv >> 8) & 0xffu), (float)((lv >> 16) & 0xffu), (float)(lv >> 24)};
+        float fy[4], fu[4], fv[4]; // taps 00, 10, 01, 11
+        if constexpr (S16) { // k4_nv12_resize's S16 picks: the window shifted to tap 0, tap 1 = the next sample / pair unless clamped
+            const uint32_t ya0 = (vya[j] >> ysh) & 0xffffu, ya1 = edge ? ya0 : vya[j] >> 16;
+            const uint32_t yb0 = (vyb[j] >> ysh) & 0xffffu, yb1 = edge ? yb0 : vyb[j] >> 16;
+            const uint32_t pa0 = (uint32_t)(vua[j] >> ush), pa1 = same_pair ? pa0 : (uint32_t)(vua[j] >> 32);
+            const uint32_t pb0 = (uint32_t)(vub[j] >> ush), pb1 = same_pair ? pb0 : (uint32_t)(vub[j] >> 32);
+            fy[0] = (float)(ya0 >> 6); fy[1] = (float)(ya1 >> 6); fy[2] = (float)(yb0 >> 6); fy[3] = (float)(yb1 >> 6);
+            fu[0] = (float)((pa0 & 0xffffu) >> 6); fu[1] = (float)((pa1 & 0xffffu) >> 6);
+            fu[2] = (float)((pb0 & 0xffffu) >> 6); fu[3] = (float)((pb1 & 0xffffu) >> 6);
+            fv[0] = (float)(pa0 >> 22); fv[1] = (float)(pa1 >> 22); fv[2] = (float)(pb0 >> 22); fv[3] = (float)(pb1 >> 22);
+        } else {
+            const uint32_t ly = __builtin_amdgcn_perm(vyb[j], vya[j], sel_y);
+            const uint32_t lu = __builtin_amdgcn_perm(vub[j], vua[j], sel_u), lv = __builtin_amdgcn_perm(vub[j], vua[j], sel_v);
+            fy[0] = (float)(ly & 0xffu); fy[1] = (float)((ly >> 8) & 0xffu); fy[2] = (float)((ly >> 16) & 0xffu); fy[3] = (float)(ly >> 24);
+            fu[0] = (float)(lu & 0xffu); fu[1] = (float)((lu >> 8) & 0xffu); fu[2] = (float)((lu >> 16) & 0xffu); fu[3] = (float)(lu >> 24);
+            fv[0] = (float)(lv & 0xffu); fv[1] = (float)((lv >> 8) & 0xffu); fv[2] = (float)((lv >> 16) & 0xffu); fv[3] = (float)(lv >> 24);
+        }
         float t00[4], t10[4], t01[4], t11[4];
         if (t.yuv_range == CVGS_YUV_FULL) { // wave-uniform
             k4_tap<CN, true>(fy[0], fu[0], fv[0], yk, t00);
@@ -667,7 +694,7 @@ struct QDevMem { // the server's device-side state, one uncached allocation (hos
 // its row geometry lives in lanes, for the NV12 worker too (125, no scratch: tests/test_kernel_resources.py); the 16-bit worker holds
 // 16-byte windows and gets 3 waves per SIMD -- 168 VGPRs -- which is what the default 3 workgroups per CU use anyway)
 template <int LD, int ST, int KIND = QK_PIXELS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_PIXELS16 ? 3 : 4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_PIXELS16 || KIND == QK_P010 ? 3 : 4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
                                                                                              uint64_t gen, uint64_t done0, uint64_t idle_ticks,
                                                                                              uint64_t stall_ticks) {
     __shared__ __attribute__((aligned(16))) float q_tiles[kQWaves * kQLdsWave]; // one transpose tile per wave (20 KB per workgroup)
@@ -807,8 +834,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             t.P.y1 = (int)q_lane_u32(pv, 8);
             t.P.x2 = (int)q_lane_u32(pv, 9);
             t.P.y2 = (int)q_lane_u32(pv, 10);
-            t.P.uv_off = KIND == QK_NV12 ? (int)q_lane_u32(pv, 11) : 0;
-            if constexpr (KIND == QK_NV12) {
+            t.P.uv_off = q_kind_yuv(KIND) ? (int)q_lane_u32(pv, 11) : 0;
+            if constexpr (q_kind_yuv(KIND)) {
                 t.yuv_range = (int)q_lane_u32(v, QD_YUV_RANGE);
                 t.yuv_primaries = (int)q_lane_u32(v, QD_YUV_PRIM);
                 t.yuv_vu = (int)q_lane_u32(v, QD_YUV_VU);
@@ -858,8 +885,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
                 if (row0 >= t.dst_h) break;
                 const int gi = (grp & 15) * kQRowsPerWave;
                 if (gi == 0) geo = q_row_geo(t.P, t.dst_h, row0, lane); // the next 64 rows' vertical geometry, one row per lane
-                if constexpr (KIND == QK_NV12) {
-                    k4q_rows<LD, ST>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
+                if constexpr (q_kind_yuv(KIND)) {
+                    k4q_rows<LD, ST, KIND == QK_P010>(t, (int)z, (int)col_tile, row0, lane, geo, gi);
                 } else if constexpr (KIND == QK_PIXELS16) {
                     const bool sgn = q_lane_u32(v, QD_SRC_SIGNED) != 0; // wave-uniform
                     if (c3) {
@@ -1033,6 +1060,8 @@ static hipError_t queue_launch(Queue* q) {
         else Q_LAUNCH(1, 2, QK_NV12);
     } else if (q->kind == QK_PIXELS16) {
         Q_LAUNCH(1, 2, QK_PIXELS16);
+    } else if (q->kind == QK_P010) {
+        Q_LAUNCH(1, 2, QK_P010);
     } else if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0, QK_PIXELS);
     else if (q->ld == 0 && q->st == 1) Q_LAUNCH(0, 1, QK_PIXELS);
     else if (q->ld == 0) Q_LAUNCH(0, 2, QK_PIXELS);
@@ -1163,13 +1192,14 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
     const bool nv12 = r.kind == CVGS_READ_NV12_RESIZE_LINEAR;
     const bool wide = !nv12 && (r.depth == CVGS_DEPTH_16U || r.depth == CVGS_DEPTH_16S);
-    const int kind = nv12 ? QK_NV12 : (wide ? QK_PIXELS16 : QK_PIXELS);
+    const bool p010 = nv12 && r.yuv_layout == CVGS_YUV_P010;
+    const int kind = p010 ? QK_P010 : (nv12 ? QK_NV12 : (wide ? QK_PIXELS16 : QK_PIXELS));
     const int vcn = nv12 ? r.out_cn : r.cn; // channels of the value the program sees
     const bool half = w.depth == CVGS_DEPTH_16F; // the half-precision hand-off: the chain ends with CAST(CV_16F), which the store performs
     if (!planar || (w.depth != CVGS_DEPTH_32F && !half) || w.data2 || r.table || n_planes < 1 || n_planes > kQMaxPlanes || n_planes != r.batch ||
         (!nv12 && (r.kind != CVGS_READ_RESIZE_LINEAR || (r.depth != CVGS_DEPTH_8U && !wide) || (r.cn != 3 && r.cn != 4))) ||
-        (nv12 && ((r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21) || r.out_cn != 3))) {
-        err = "queue: chain is not a batched 8U / 16U / 16S C3 / C4 (or NV12 / NV21 -> 3 channels) resize into an fp32 / fp16 planar tensor with host plane descriptors";
+        (nv12 && ((r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21 && !p010) || r.out_cn != 3))) {
+        err = "queue: chain is not a batched 8U / 16U / 16S C3 / C4 (or NV12 / NV21 / P010 -> 3 channels) resize into an fp32 / fp16 planar tensor with host plane descriptors";
         return 1;
     }
     for (int i = 0; i < n_planes && i < r.used; ++i) {
@@ -1224,8 +1254,9 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
         q->kind = kind;
         if (kind != QK_PIXELS) { // every workgroup must be resident (each worker holds a ticket): these workers' register budget allows 3 per CU
             int per_cu = 0;
-            const hipError_t oe = kind == QK_NV12 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_NV12>, 256, 0)
-                                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_PIXELS16>, 256, 0);
+            const hipError_t oe = kind == QK_NV12   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_NV12>, 256, 0)
+                                  : kind == QK_P010 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_P010>, 256, 0)
+                                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_PIXELS16>, 256, 0);
             if (oe != hipSuccess || per_cu < 1) {
                 q->kind = -1;
                 err = "queue: occupancy query failed";
@@ -1236,7 +1267,8 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
         }
     }
     if (q->kind != kind) {
-        err = q->kind == QK_NV12 ? "queue: this queue serves NV12 / NV21 surface crops (its first submit decided); use another queue for pixel crops"
+        err = q->kind == QK_P010 ? "queue: this queue serves P010 surface crops (its first submit decided); use another queue for the other kinds"
+              : q->kind == QK_NV12 ? "queue: this queue serves NV12 / NV21 surface crops (its first submit decided); use another queue for pixel crops"
               : (q->kind == QK_PIXELS16 ? "queue: this queue serves 16-bit pixel crops (its first submit decided); use another queue for the other kinds"
                                         : "queue: this queue serves 8UC3 / 8UC4 crops (its first submit decided); use another queue for the other kinds");
         return 1;

@@ -391,6 +391,128 @@ def test_queue_serves_one_kind(torch_dev):
         q.destroy()
 
 
+# ---- the queue's fourth kind: crops of P010 decoder surfaces (10-bit, 16-bit samples: K4's S16 shape) ----------------------------
+def _p010_surface(w, h, seed):
+    """(H * 3 / 2, W) u16: 10-bit codes in the high bits, the six low bits dirty (a decoder may leave anything there)"""
+    return ((H.random_u16((h + h // 2, w), seed) >> 6) << 6 | (H.random_u16((h + h // 2, w), seed + 1) & 63)).astype(np.uint16)
+
+
+def _p010_ops(luma, crops, out_mat, dst, range_, prim, swap=True, ar=None, background=None, used=None, half=False):
+    f, hf = cvgs.CV_32FC3, cvgs.CV_16FC3
+    rd = cvgs.read_nv12([luma.nv12_roi(*c) for c in crops], dst, range_, prim, False, layout=capi.YUV_P010)
+    if ar is not None:
+        rd.ar = ar
+    if background is not None:
+        rd.background = cvgs._scalar(background)
+    if used is not None:
+        rd.used_planes = used
+    ops = [rd] + ([cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f)] if swap else [])
+    ops += [cvgs.multiply(f, [1 / 1023.0] * 3), cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225])]
+    return ops + ([cvgs.convertTo(f, hf), cvgs.split(hf, out_mat, dst)] if half else [cvgs.split(f, out_mat, dst)])
+
+
+def _p010_case(oracle, torch, dev, q, surf, w, h, crops, dst, half=False, **kw):
+    """one batch of crops (x, y, w, h; even) of the P010 surface on the queue, on cvgs_execute and on the oracle"""
+    n = len(crops)
+    surf_t = torch.from_numpy(surf.view(np.int16)).to(dev)
+    tt, nt, mt = (torch.float16, np.float16, cvgs.CV_16FC1) if half else (torch.float32, np.float32, cvgs.CV_32FC1)
+    outs = {}
+    for name in ("queue", "execute"):
+        out_t = torch.full((n, 3 * dst[0] * dst[1]), -777.0, dtype=tt, device=dev)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1, surf_t.data_ptr(), 2 * w, owner=surf_t)
+        ops = _p010_ops(luma, crops, cvgs.GpuMat.from_tensor(out_t, mt), dst, half=half, **kw)
+        torch.cuda.synchronize()
+        if name == "queue":
+            q.wait(q.submit(*ops))
+        else:
+            cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+        torch.cuda.synchronize()
+        outs[name] = out_t.cpu().numpy()
+    ref = np.full((n, 3 * dst[0] * dst[1]), -777.0, dtype=nt)
+    luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1, surf.ctypes.data, 2 * w, owner=surf)
+    oracle.execute(cvgs.lower(_p010_ops(luma, crops, cvgs.GpuMat.from_array(ref, mt), dst, half=half, **kw)))
+    H.assert_bit_exact(outs["queue"], ref, "P010 queue batch vs the oracle %s" % (kw,))
+    H.assert_bit_exact(outs["queue"], outs["execute"], "P010 queue batch vs cvgs_execute")
+
+
+@pytest.mark.parametrize("dst,kw", [
+    ((64, 128), dict(range_=capi.YUV_LIMITED, prim=capi.BT2020)),
+    ((64, 128), dict(range_=capi.YUV_FULL, prim=capi.BT709, swap=False)),
+    ((64, 128), dict(range_=capi.YUV_LIMITED, prim=capi.BT601, half=True)),
+    ((100, 37), dict(range_=capi.YUV_FULL, prim=capi.BT2020)),                              # ragged: 2 column tiles, 37 rows
+    ((64, 64), dict(range_=capi.YUV_LIMITED, prim=capi.BT2020, ar=cvgs.PRESERVE_AR, background=[114.0, 100.5, 7.25])),
+    ((96, 64), dict(range_=capi.YUV_FULL, prim=capi.BT709, ar=cvgs.PRESERVE_AR_LEFT, background=[1.0, 2.0, 3.0], used=4)),
+    ((256, 16), dict(range_=capi.YUV_LIMITED, prim=capi.BT2020)),
+])
+def test_queue_p010_batch_matches_the_oracle(oracle, torch_dev, dst, kw):
+    torch, dev = torch_dev
+    w, h = 1280, 720
+    surf = _p010_surface(w, h, seed=121)
+    crops = _even_crops(7, w, h, seed=131) + [(0, 0, w, h), (w - 4, h - 2, 4, 2)]  # the whole surface, a 4 x 2 corner
+    q = cvgs.Queue()
+    try:
+        _p010_case(oracle, torch, dev, q, surf, w, h, crops, dst, **kw)
+        assert q.stats()["error"] == 0
+    finally:
+        q.destroy()
+
+
+def test_queue_p010_whole_6k_surface(oracle, torch_dev):
+    """BASELINE cfg #3's 10-bit sibling through the queue: a 6K P010 surface (BT.2020 limited) -> BGR float -> 1280 x 720 -> normalize
+    -> split, frame after frame; then an upscaled crop (taps that share samples and chroma pairs)."""
+    torch, dev = torch_dev
+    w, h = 6144, 3456
+    q = cvgs.Queue()
+    try:
+        for seed in (141, 142):
+            surf = _p010_surface(w, h, seed=seed)
+            _p010_case(oracle, torch, dev, q, surf, w, h, [(0, 0, w, h)], (1280, 720), range_=capi.YUV_LIMITED, prim=capi.BT2020)
+        _p010_case(oracle, torch, dev, q, surf, w, h, [(6144 - 40, 3456 - 24, 40, 24), (0, 0, 6, 4)], (200, 120), range_=capi.YUV_LIMITED, prim=capi.BT2020)
+        assert q.stats()["error"] == 0
+    finally:
+        q.destroy()
+
+
+def test_queue_p010_many_batches_in_flight_and_kind_latch(oracle, torch_dev):
+    """40 P010 batches submitted back to back (every task size), each checked; a P010 queue refuses NV12 batches and vice versa"""
+    torch, dev = torch_dev
+    w, h, dst, n = 1920, 1080, (64, 128), 12
+    surf = _p010_surface(w, h, seed=151)
+    surf_t = torch.from_numpy(surf.view(np.int16)).to(dev)
+    luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1, surf_t.data_ptr(), 2 * w, owner=surf_t)
+    hl = cvgs.GpuMat(h, w, cvgs.CV_16UC1, surf.ctypes.data, 2 * w, owner=surf)
+    q = cvgs.Queue()
+    try:
+        outs, lists, tickets = [], [], []
+        torch.cuda.synchronize()
+        for i in range(40):
+            crops = _even_crops(n, w, h, seed=200 + i)
+            out_t = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
+            tickets.append(q.submit(*_p010_ops(luma, crops, cvgs.GpuMat.from_tensor(out_t, cvgs.CV_32FC1), dst, capi.YUV_LIMITED, capi.BT2020)))
+            outs.append(out_t)
+            lists.append(crops)
+        q.wait(tickets[-1])
+        torch.cuda.synchronize()
+        for i in range(40):
+            ref = np.zeros((n, 3 * dst[0] * dst[1]), dtype=np.float32)
+            oracle.execute(cvgs.lower(_p010_ops(hl, lists[i], cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, capi.YUV_LIMITED, capi.BT2020)))
+            H.assert_bit_exact(outs[i].cpu().numpy(), ref, "P010 batch %d" % i)
+        nv = torch.from_numpy(H.random_u8((h + h // 2, w), seed=9)).to(dev)
+        l8 = cvgs.GpuMat(h, w, cvgs.CV_8UC1, nv.data_ptr(), w, owner=nv)
+        with pytest.raises(capi.CvgsError):
+            q.submit(*_nv12_ops([l8], cvgs.GpuMat.from_tensor(outs[0], cvgs.CV_32FC1), dst, capi.YUV_FULL, capi.BT709, capi.YUV_NV12))
+        assert q.stats()["error"] == 0
+    finally:
+        q.destroy()
+    q = cvgs.Queue()
+    try:
+        q.wait(q.submit(*_nv12_ops([l8], cvgs.GpuMat.from_tensor(outs[0], cvgs.CV_32FC1), dst, capi.YUV_FULL, capi.BT709, capi.YUV_NV12)))
+        with pytest.raises(capi.CvgsError):
+            q.submit(*_p010_ops(luma, lists[0], cvgs.GpuMat.from_tensor(outs[1], cvgs.CV_32FC1), dst, capi.YUV_LIMITED, capi.BT2020))
+    finally:
+        q.destroy()
+
+
 def test_queue_two_host_threads_and_destroy_with_batches_in_flight(oracle, torch_dev):
     """submits are serialised by the queue's mutex: two host threads feeding ONE queue get every batch right; destroying a queue
     with batches in flight completes them first (the workers drain the ring before they see the stop word)"""

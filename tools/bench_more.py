@@ -148,7 +148,7 @@ def cfg3(dev, iters, p010=False, queue=False):
         for _ in range(per):
             launch(torch.cuda.current_stream())
     t = events_time(g.replay, max(3, iters // 8), warm=2) / per
-    if queue:  # the same frames through the descriptor queue (NV12 surfaces are its second kind)
+    if queue:  # the same frames through the descriptor queue (NV12 / NV21 surfaces are its second kind, P010 surfaces its fourth)
         t = queue_time(chains)
     write = dst[0] * dst[1] * 3 * 4
     # scale 4.8: every output pixel taps 4 distinct luma bytes and up to 4 distinct UV pairs (SURVEY.md 8d bound)
@@ -156,7 +156,7 @@ def cfg3(dev, iters, p010=False, queue=False):
     alg = write + read
     sector = W.nv12_sector_read_bytes(w, h, dst[0], dst[1], sb) + write
     return {"config": "cfg3 %s 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, %s" % ("P010 (10-bit, BT.2020 limited)" if p010 else "NV12", "one cvgs_queue_submit per frame (descriptor queue, no launch per frame)" if queue else "one kernel per frame (graph-replayed launches)"),
-            "kernel": "k1q_server<1, 2, NV12> (k4q_rows)" if queue else cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
+            "kernel": ("k1q_server<1, 2, P010> (k4q_rows<S16>)" if p010 else "k1q_server<1, 2, NV12> (k4q_rows)") if queue else cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
             "GB_per_s": round(alg / t / 1e9, 1), "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4),
             "sector_bound_bytes": sector, "frac_of_sector_bound": round(sector / t / 1e9 / PEAK, 4), "surfaces_in_rotation": nbuf,
             "output_Mpix_per_s": round(dst[0] * dst[1] / t / 1e6, 1), "source_Mpix_per_s": round(w * h / t / 1e6, 1)}
@@ -263,6 +263,7 @@ def run_all(dev, iters=100, only=""):
         res.append(cfg3(dev, iters))
         res.append(cfg3(dev, iters, p010=True))
         res.append(cfg3(dev, iters, queue=True))
+        res.append(cfg3(dev, iters, p010=True, queue=True))
     if only in ("", "nv12many"):
         res.append(nv12_many(dev, iters))
     if only in ("", "nv12crops"):

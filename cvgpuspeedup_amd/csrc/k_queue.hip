@@ -32,10 +32,10 @@
 // L1 / L2 never see the invalidate a kernel start performs; agent-coherent loads never serve a stale copy of a source buffer
 // the caller has rewritten between two submits (tests/test_gpu_queue.py rewrites one).
 //
-// Three kinds of batches, one server instantiation each (QK_*; a queue's first submit decides): crops of 8UC3 / 8UC4 frames
-// (k1q_rows: K1's arithmetic -- the headline), of 16UC3 / 16UC4 / 16SC3 / 16SC4 frames (the same worker on 16-byte windows) and of
-// NV12 / NV21 decoder surfaces (k4q_rows: K4's arithmetic -- BASELINE cfg #3 and the decode-side 50-crop batch: 8.0 -> 5.8 us and
-// 4.7 -> 2.5 us per frame, tools/bench_more.py).
+// Four kinds of batches, one server instantiation each (QK_*; a queue's first submit decides): crops of 8UC3 / 8UC4 frames
+// (k1q_rows: K1's arithmetic -- the headline), of 16UC3 / 16UC4 / 16SC3 / 16SC4 frames (the same worker on 16-byte windows), of
+// NV12 / NV21 decoder surfaces (k4q_rows: K4's arithmetic -- BASELINE cfg #3 and the decode-side 50-crop batch: 8.0 -> 4.9 us and
+// 4.7 -> 2.2 us per frame, tools/bench_more.py) and of P010 decoder surfaces (k4q_rows<S16>: cfg #3's 10-bit sibling 10.7 -> 6.2 us).
 #include <immintrin.h>
 #include <setjmp.h>
 #include <signal.h>

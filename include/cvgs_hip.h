@@ -376,9 +376,9 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  *   cvgs_queue_submit   asynchronous; the chain must be K1's hot shape (batched 8UC3 / 8UC4 -- or 16UC3 / 16UC4 / 16SC3 / 16SC4 -- bilinear resize -> [RGB<->BGR]
  *                       mul, sub, div [-> convertTo CV_16F] -> fp32 / fp16 NCHW / CNHW tensor, host descriptors; a ring slot holds 74 planes, larger batches take
  *                       consecutive slots behind ONE ticket) or the same behind crops of
- *                       NV12 / NV21 decoder surfaces (CVGS_READ_NV12_RESIZE_LINEAR, 3 channels; letterboxing and default planes
+ *                       NV12 / NV21 / P010 decoder surfaces (CVGS_READ_NV12_RESIZE_LINEAR, 3 channels; letterboxing and default planes
  *                       included): anything else returns CVGS_ERR_UNSUPPORTED and belongs to cvgs_execute.  A queue serves ONE
- *                       of the three kinds (8-bit pixels, 16-bit pixels, NV12 surfaces) -- its first submit decides, the others are then CVGS_ERR_UNSUPPORTED (each kind
+ *                       of the four kinds (8-bit pixels, 16-bit pixels, NV12 / NV21 surfaces, P010 surfaces) -- its first submit decides, the others are then CVGS_ERR_UNSUPPORTED (each kind
  *                       has its own server grid; create a second queue).  The sources must be complete when submit is
  *                       called (the server is not ordered behind any stream); results are bit-identical to cvgs_execute.
  *   cvgs_queue_wait     host waits for a ticket AND every batch submitted before it (tickets are handed out in submit order; the

@@ -264,6 +264,16 @@ static void test_p010_crops_batch(cv::cuda::Stream& stream) {
     stream.waitForCompletion();
     const auto h = fetch(d_out.data, n * 4);
     CHECK(bit_equal(h.data(), h_ref.data, n * 4), "P010 crop batch -> NCHW, bit-exact vs oracle");
+    {   // the same batch through the device-side descriptor queue (engine extension): P010 surfaces are its fourth kind
+        cvGS::Queue queue;
+        cv::cuda::GpuMat d_out_q((int)N, up.width * up.height * 3, CV_32F);
+        const uint64_t ticket = cvGS::executeOperations(queue, cvGS::resize<cv::INTER_LINEAR>(cvGS::cvtColorP010<cv::COLOR_YUV2RGB_NV12>(d_p010, crops), up),
+                                                        cvGS::multiply<CV_32FC3>(a), cvGS::subtract<CV_32FC3>(s), cvGS::divide<CV_32FC3>(d),
+                                                        cvGS::split<CV_32FC3>(d_out_q, up));
+        queue.wait(ticket);
+        const auto hq = fetch(d_out_q.data, n * 4);
+        CHECK(bit_equal(hq.data(), h_ref.data, n * 4), "P010 crop batch through cvGS::executeOperations(queue, ...), bit-exact vs oracle");
+    }
 
     // fk spelling, whole surface -> 10-bit RGBA image (ushort4): Resize(fuse(ReadYUV<P010>, ConvertYUVToRGB<P010, ..., float4>)) -> SaturateCast
     const cv::Size down(320, 180);

@@ -8,7 +8,9 @@
 //                         (system-scope stores over xGMI).  The kernel boundary in front of it is the release: K1's stores to
 //                         the peers are complete and visible before any flag is.
 //   cvgs_exchange_wait    makes the stream wait until every listed flag word has reached a step number (one wave polls with
-//                         system-scope loads; a watchdog gives up after `timeout_ms` and reports instead of hanging the box).
+//                         system-scope loads; a watchdog gives up after `timeout_ms` and reports instead of hanging the box --
+//                         and once err[0] is set every later wait behind the same error words returns at once: a lost peer
+//                         costs ONE timeout, not one per step of a replayed graph).
 // No collective, no host round trip; the waits may lag the signals by a few steps so that they never block a well-fed stream.
 // The reference has no multi-GPU code (include/cvGPUSpeedup.cuh:605-610 is its only device selector).
 #include <hip/hip_runtime.h>
@@ -46,6 +48,7 @@ __global__ void k_exchange_wait(const XPtrs flags, uint64_t value, const uint64_
         if (c <= lag) return; // nothing that old has been signalled yet
         value = c - lag;
     }
+    if (err && __hip_atomic_load((xg_u64)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return; // a peer was lost earlier: fail fast
     const uint64_t t0 = wall_clock64();
     for (;;) {
         const bool behind = i < flags.n && __hip_atomic_load((xg_u64)flags.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < value;
@@ -71,6 +74,7 @@ __global__ void k_exchange_step(const XPtrs peers, const XPtrs flags, uint64_t* 
     if (i == 0) *counter = value;
     if (i < peers.n) __hip_atomic_store((xg_u64)peers.p[i], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (value <= lag) return;
+    if (err && __hip_atomic_load((xg_u64)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return; // a peer was lost earlier: fail fast
     const uint64_t want = value - lag;
     const uint64_t t0 = wall_clock64();
     for (;;) {

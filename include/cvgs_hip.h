@@ -419,7 +419,8 @@ int cvgs_queue_destroy(cvgs_queue_t q);
  *   cvgs_exchange_wait    the stream waits until each of the n given words (this rank's own flag block: one word per peer)
  *                         is >= `value`; after `timeout_ms` (0 = 2000) it gives up, stores {1, index of a flag that was behind}
  *                         into err_words[0..1] (device or pinned memory, may be NULL) and lets the stream continue -- a lost
- *                         peer is reported, never waited for.  n <= 16.
+ *                         peer is reported, never waited for; while err_words[0] is non-zero every later wait / step behind the same
+ *                         error words returns at once (ONE timeout per lost peer, not one per step; clear the words to re-arm).  n <= 16.
  * `step_counter` (device memory, 8 bytes, zero-initialised by the caller; NULL = use `value`): the step number then lives on the
  * device -- signal advances *step_counter and publishes the new count, wait waits for *step_counter - lag (and for nothing while
  * the count is <= lag) -- so that a whole sequence of steps can be captured into ONE HIP graph and replayed (a captured constant

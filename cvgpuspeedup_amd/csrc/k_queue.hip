@@ -52,6 +52,10 @@
 
 namespace cvgs {
 
+// an idle worker's pause between two polls of the tail word, in units of 64 clocks (A/B: tools/probes/queue_idle_sleep_ab.sh)
+#ifndef CVGS_QUEUE_IDLE_SLEEP
+#define CVGS_QUEUE_IDLE_SLEEP 32
+#endif
 constexpr int kQSlotBytes = 4096;   // one batch: 256 B of parameters, planes from byte 512
 constexpr int kQPlanesOff = 512;
 constexpr int kQMaxPlanes = (kQSlotBytes - kQPlanesOff) / (int)sizeof(PlaneParams); // 74
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
                         })
                         return;
                     }
-                    __builtin_amdgcn_s_sleep(32);
+                    __builtin_amdgcn_s_sleep(CVGS_QUEUE_IDLE_SLEEP);
                     QPROF(p_idle += 1;)
                     continue;
                 }

@@ -77,6 +77,7 @@ def parse():
                         "duration then comes from its own 100 MHz clock (cvgs_queue_stats)")
     p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
+    p.add_argument("--print-extra", action="store_true", help="also print the full record (bench_extra.json's content) on stderr")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (testing)")
     p.add_argument("--exchange-half", action="store_true", help="N > 1: assemble an fp16 tensor (half the bytes per xGMI link)")
@@ -399,8 +400,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and a.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+        return self_spawn(a)
+    guard_stdout()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or a.force_dist:
@@ -503,7 +505,156 @@ def main():
         result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
     if not a.no_extra:
         result["extra"] = extra_sweeps(dev, a)
-    print(json.dumps(result))
+    emit(result, a)
+
+
+# ---- the result line ---------------------------------------------------------------------------------------------------
+# The driver parses the LAST stdout line as one JSON object.  Round 3's line had grown to 20.9 KB (17 KB of secondary sweeps
+# glued on under "extra") and was not parsed: the round had no driver-observed headline.  The contract now: stdout carries ONE
+# compact line (< 4 KB) with the headline, `roofline`, `cpu_baseline` and a few scalars; everything else (the full timing block,
+# every sweep, the reference's test chains, the perf gate's table) goes to bench_extra.json beside this file (and to
+# gpurun_out/ when that directory exists), mirroring the reference's protocol of one small CSV row per test
+# (tests/testsCommon.cuh:128-195).  tests/test_bench_line.py holds the formatter to that contract on CPU.
+COMPACT_LIMIT = 4096
+EXTRA_FILE = "bench_extra.json"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(result):
+    """The driver's line: the contract keys + roofline + cpu_baseline + a handful of scalars, guaranteed under COMPACT_LIMIT."""
+    line = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                          "vs_baseline", "dtype", "data"))
+    cfg = result.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "submission", "kernel", "exchange", "parallelism"))
+    for k in ("workload", "submission", "exchange", "parallelism"):
+        if k in line["config"] and isinstance(line["config"][k], str) and len(line["config"][k]) > 260:
+            line["config"][k] = line["config"][k][:257] + "..."
+    line["roofline"] = _pick(result.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us",
+                                                          "algorithmic_bytes_per_launch", "sector_bound_bytes_per_launch",
+                                                          "frac_of_sector_bound", "copy_ceiling", "per_gpu_frac"))
+    if "cpu_baseline" in result:
+        cb = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "single_thread_value", "gpu_matches_oracle_bit_exact"))
+        if isinstance(cb.get("sample"), str) and len(cb["sample"]) > 200:
+            cb["sample"] = cb["sample"][:197] + "..."
+        line["cpu_baseline"] = cb
+    optional = []  # (key, value) in the order they are dropped LAST if the line would be too long
+    if "one_launch_per_step" in result:
+        o = result["one_launch_per_step"]
+        optional.append(("one_launch_per_step", {"us": o.get("us_per_step"), "frac": o.get("frac")}))
+    t = result.get("timing", {})
+    if "batch_latency_server_alive" in t or "single_launch_latency" in t:
+        optional.append(("latency_us", {"queue_batch": t.get("batch_latency_server_alive", {}).get("median_us"),
+                                        "one_launch": t.get("single_launch_latency", {}).get("median_us")}))
+    for k in ("stream_ordered", "coexistence", "n1_same_workload", "legs", "xgmi_probe", "queue_latency_by_depth"):
+        if k in result:
+            optional.append((k, result[k]))
+    if "queue" in result:
+        optional.append(("queue_ok", bool(result["queue"].get("every_frame_bit_identical_to_cvgs_execute")) and not result["queue"].get("error")))
+    pg = result.get("extra", {}).get("perf_gate") if isinstance(result.get("extra"), dict) else None
+    if pg:
+        over = pg.get("over") or []
+        optional.append(("perf_gate", {"pass": pg.get("pass"), "checked": pg.get("checked"), "over": len(over),
+                                       "first_over": [str(o.get("test", o) if isinstance(o, dict) else o)[:60] for o in over[:3]]}))
+    if isinstance(result.get("extra"), dict) and "error" in result["extra"]:
+        optional.append(("extra_error", str(result["extra"]["error"])[:200]))
+    optional.append(("extra_file", EXTRA_FILE))
+    for k, v in optional:
+        line[k] = v
+    text = json.dumps(line)
+    while len(text) >= COMPACT_LIMIT and optional:  # never expected; the contract keys always survive
+        k, _ = optional.pop(0)
+        line.pop(k, None)
+        text = json.dumps(line)
+    return text
+
+
+def guard_stdout():
+    """From here on file descriptor 1 is stderr for everything in this process -- Python prints AND the C runtime's (RCCL prints
+    its version banner from C stdio, whose pipe buffer is flushed at exit: round 3's N > 1 line was followed by five banner lines)
+    -- and the ONE result line goes to a private duplicate of the original stdout.  Ranks other than 0 never write to stdout."""
+    if getattr(sys, "_cvgs_real_stdout", None) is None:  # (on `sys`: bench_dist imports this file a second time as module `bench`)
+        sys.stdout.flush()
+        sys._cvgs_real_stdout = os.dup(1)
+        os.dup2(2, 1)
+
+
+def write_line(text):
+    sys.stdout.flush()
+    sys.stderr.flush()
+    real = getattr(sys, "_cvgs_real_stdout", None)
+    if real is None:
+        sys.stdout.write(text + "\n")
+        sys.stdout.flush()
+    else:
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.write(real, (text + "\n").encode())
+
+
+def emit(result, a=None):
+    """Write the full record to bench_extra.json (+ gpurun_out/), then print the ONE compact line as the last thing on stdout."""
+    full = json.dumps(result, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, EXTRA_FILE), "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    if a is not None and getattr(a, "print_extra", False):
+        sys.stderr.write(json.dumps(result) + "\n")
+        sys.stderr.flush()
+    write_line(compact_line(result))
+
+
+def error_line(a, msg):
+    """A compact, parseable line for a run that cannot take place (fewer GPUs than --gpus, a rank that died)."""
+    return json.dumps({"metric": baseline_metric(), "value": None, "unit": "Mpix/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+                       "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                       "data": "synthetic", "config": {"workload": "cfg5 (not run)"}, "error": str(msg)[:600]})
+
+
+def self_spawn(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks itself (torch.distributed.run, one process per GPU,
+    rendezvous on 127.0.0.1), pass rank 0's result line through as the LAST stdout line, everything else to stderr."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus:
+        write_line(error_line(a, "--gpus %d but this box has %d visible GPU(s)" % (a.gpus, have)))
+        raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    picked = None
+    for ln in reversed(lines):
+        if ln.lstrip().startswith("{"):
+            try:
+                json.loads(ln)
+                picked = ln
+                break
+            except ValueError:
+                pass
+    for ln in lines:
+        if ln is not picked:
+            sys.stderr.write(ln + "\n")
+    if picked is None:
+        write_line(error_line(a, "the ranks exited with code %d without a result line" % p.returncode))
+        raise SystemExit(p.returncode or 3)
+    write_line(picked)
+    if p.returncode:
+        raise SystemExit(p.returncode)
 
 
 def copy_ceiling(dev, mib=256, iters=20):

@@ -123,6 +123,33 @@ def main(a, dev, rank, world):
     try:
         if int(mapped.item()) != 1:
             raise RuntimeError(map_error or "a peer could not map the tensors")
+        # one xGMI link, measured (SURVEY.md 8e quotes ~153 GB/s per link, round 1 quoted 64 GB/s per direction -- neither had been
+        # measured): every rank streams 64 MiB (or what the allocation holds) into its right-hand neighbour's allocation with the
+        # engine's copy kernel, all ranks at once (each link carries one stream per direction), before any tensor is live
+        if world > 1:
+            try:
+                nxt = bases[(rank + 1) % world]
+                nbytes = min(64 << 20, (n_frames * tensor_bytes) & ~0xfff)
+                lib0 = capi.load_library()
+                for _ in range(2):
+                    capi.check(lib0.cvgs_stream_copy(nxt, buf.ptr, nbytes, s))
+                torch.cuda.synchronize()
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(8):
+                    capi.check(lib0.cvgs_stream_copy(nxt, buf.ptr, nbytes, s))
+                e1.record()
+                torch.cuda.synchronize()
+                gbs = torch.tensor([8.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9], dtype=torch.float64, device=dev)
+                lo_t, hi_t = gbs.clone(), gbs.clone()
+                dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+                result_extra["xgmi_probe"] = {"GB_per_s_per_link_one_direction_min": round(float(lo_t.item()), 1), "max": round(float(hi_t.item()), 1),
+                                              "bytes": int(nbytes), "pattern": "rank r -> rank r+1, all ranks at once, cvgs_stream_copy into the IPC mapping"}
+            except Exception as ex:
+                result_extra["xgmi_probe"] = {"error": repr(ex)[:200]}
+            dist.barrier()
         mirrors = [[bases[r] + f * tensor_bytes for r in range(world) if r != rank] for f in range(n_frames)]
         for o in out_all:
             o.zero_()
@@ -179,8 +206,10 @@ def main(a, dev, rank, world):
     if p2p_ok and p2p["wall"] < ag_wall:
         best_wall, exchange = p2p["wall"], "P2P fused write (K1 stores into every peer's tensor) + device-side arrival flags (no collective per step)"
     step_s = best_wall / steps
+    result = None
     if rank == 0:
         alg = wl.algorithmic_bytes()
+        link = (result_extra.get("xgmi_probe") or {}).get("GB_per_s_per_link_one_direction_min")
         result = {
             "metric": B.baseline_metric(), "value": round(px_step / step_s / 1e6, 1), "unit": "Mpix/s", "n_gpus": world,
             "steps": steps, "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 6), "higher_is_better": True,
@@ -193,7 +222,16 @@ def main(a, dev, rank, world):
             "roofline": {"bound": "hbm", "achieved": round(alg / compute_step / 1e9, 1), "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / compute_step / 1e9 / B.HBM_PEAK_GBS, 4), "traffic": None, "kernel": wl.kernel,
                          "kernel_us": round(compute_step * 1e6, 3), "algorithmic_bytes_per_launch": int(alg),
+                         "per_gpu_frac": round(alg / compute_step / 1e9 / B.HBM_PEAK_GBS, 4),
                          "note": "K1 alone on each GPU (compute-only leg); the exchange is xGMI-bound, not HBM-bound"},
+            # the SAME workload and submission path on ONE GPU (this rank's 64-crop-of-6K step, graph-replayed launches, measured in this
+            # process while the other ranks run theirs): what a scaling curve of this line must be read against -- bench.py --gpus 1 is
+            # cfg #2b on the descriptor queue, a different workload and submission path
+            "n1_same_workload": {"Mpix_per_s": round(n * W.DST[0] * W.DST[1] / compute_step / 1e6, 1), "us_per_step": round(compute_step * 1e6, 3),
+                                 "value_over_n1": round((px_step / step_s) / (n * W.DST[0] * W.DST[1] / compute_step), 3)},
+            "legs": {"compute_only_us": round(compute_step * 1e6, 3), "allgather_us": round(ag_wall / steps * 1e6, 3),
+                     "p2p_write_us": round(p2p["wall"] / steps * 1e6, 3) if p2p_ok else None,
+                     "link_floor_us": round(n * plane * esz / (link * 1e9) * 1e6, 3) if link else None},
             "extra": {
                 "compute_only": {"Mpix_per_s": round(px_step / compute_step / 1e6, 1), "us_per_step": round(compute_step * 1e6, 3),
                                  "note": "graph-replayed K1, no exchange: every rank keeps its shard"},
@@ -209,7 +247,8 @@ def main(a, dev, rank, world):
                 "tensor_element_bytes": esz,
             }}
         result["extra"].update(result_extra)
-        print(json.dumps(result))
+        if "xgmi_probe" in result_extra:
+            result["xgmi_probe"] = result_extra["xgmi_probe"]
     dist.barrier()
     for p in peers:
         try:
@@ -217,3 +256,7 @@ def main(a, dev, rank, world):
         except Exception:
             pass
     dist.destroy_process_group()
+    # the line is the LAST thing rank 0 writes: after the process group is gone (RCCL's banner and teardown messages are behind us;
+    # bench.guard_stdout has routed every other write of every rank to stderr)
+    if result is not None:
+        B.emit(result, a)

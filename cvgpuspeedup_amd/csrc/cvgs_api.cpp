@@ -1351,8 +1351,98 @@ int cvgs_queue_submit_many(cvgs_queue_t h, const cvgs_chain_desc* const* chains,
     return CVGS_OK;
 }
 
+int cvgs_queue_submit_on(cvgs_queue_t h, const cvgs_chain_desc* chain, cvgs_stream_t stream, uint32_t flags, uint64_t* ticket) {
+    if (!h) return fail(CVGS_ERR_INVALID, "null queue");
+    if (flags & ~(uint32_t)(CVGS_QUEUE_SUBMIT_DEFER_WAIT | CVGS_QUEUE_SUBMIT_HYBRID)) return fail(CVGS_ERR_INVALID, "queue: unknown submit flag bits");
+    DeviceGuard guard;
+    if (int rc = guard.enter(h->device)) return rc;
+    Lowered L;
+    int rc = lower(chain, false, L);
+    if (rc) return rc;
+    const bool hybrid = (flags & CVGS_QUEUE_SUBMIT_HYBRID) != 0;
+    std::string err;
+    rc = 1;
+    if (!(L.uses_64f || L.int_arith || L.mirrors.n > 0 || is_warp(L.args.read.kind) || (chain->flags & CVGS_CHAIN_FORCE_GENERIC))) {
+        const cvgs::ChainArgs* ca = &L.args;
+        const cvgs::PlaneParams* pp = L.planes.data();
+        const int np = (int)L.planes.size();
+        int queued = 0;
+        rc = cvgs::queue_submit_on(h->q, &ca, &pp, &np, 1, stream, flags, ticket, &queued, err);
+    } else {
+        err = "queue: not a chain the server takes";
+    }
+    if (rc == 0) return CVGS_OK;
+    if (rc > 0 && hybrid) { // the policy's choice (2) or a chain only cvgs_execute serves (1): ONE launch on the caller's stream, as cvgs_execute
+        if (ticket) *ticket = CVGS_QUEUE_TICKET_DIRECT;
+        return dispatch(chain, L, (hipStream_t)stream, false, nullptr);
+    }
+    if (rc > 0) return fail(CVGS_ERR_UNSUPPORTED, err);
+    return fail(CVGS_ERR_HIP, err);
+}
+
+int cvgs_queue_submit_many_on(cvgs_queue_t h, const cvgs_chain_desc* const* chains, int32_t n, cvgs_stream_t stream, uint32_t flags, uint64_t* last_ticket) {
+    if (!h || !chains || n < 1) return fail(CVGS_ERR_INVALID, "null queue / no chains");
+    if (n > CVGS_QUEUE_MAX_GROUP) return fail(CVGS_ERR_INVALID, "queue: at most CVGS_QUEUE_MAX_GROUP chains behind one gate");
+    if (flags & ~(uint32_t)(CVGS_QUEUE_SUBMIT_DEFER_WAIT | CVGS_QUEUE_SUBMIT_HYBRID)) return fail(CVGS_ERR_INVALID, "queue: unknown submit flag bits");
+    DeviceGuard guard;
+    if (int rc = guard.enter(h->device)) return rc;
+    std::vector<Lowered> L((size_t)n);
+    bool servable = true;
+    for (int32_t i = 0; i < n; ++i) {
+        if (int rc = lower(chains[i], false, L[(size_t)i])) return rc;
+        const Lowered& l = L[(size_t)i];
+        servable = servable && !(l.uses_64f || l.int_arith || l.mirrors.n > 0 || is_warp(l.args.read.kind) || (chains[i]->flags & CVGS_CHAIN_FORCE_GENERIC));
+    }
+    std::string err = "queue: not chains the server takes";
+    int rc = 1, queued = 0;
+    uint64_t tickets[CVGS_QUEUE_MAX_GROUP];
+    if (servable) {
+        const cvgs::ChainArgs* ca[CVGS_QUEUE_MAX_GROUP];
+        const cvgs::PlaneParams* pp[CVGS_QUEUE_MAX_GROUP];
+        int np[CVGS_QUEUE_MAX_GROUP];
+        for (int32_t i = 0; i < n; ++i) {
+            ca[i] = &L[(size_t)i].args;
+            pp[i] = L[(size_t)i].planes.data();
+            np[i] = (int)L[(size_t)i].planes.size();
+        }
+        rc = cvgs::queue_submit_on(h->q, ca, pp, np, n, stream, flags, tickets, &queued, err);
+    }
+    if (rc == 0) {
+        if (last_ticket) *last_ticket = tickets[n - 1];
+        return CVGS_OK;
+    }
+    if (rc > 0 && (flags & CVGS_QUEUE_SUBMIT_HYBRID)) {
+        // chains only cvgs_execute serves, a capturing stream, a group nothing could overlap with, or the closed-batch budget: the rest is one
+        // launch each on the stream, in order, behind what the server took (whose gate kernel holds the stream -- with DEFER_WAIT the caller's
+        // wait on *last_ticket orders the queued part)
+        for (int32_t i = queued; i < n; ++i)
+            if (int rc2 = dispatch(chains[i], L[(size_t)i], (hipStream_t)stream, false, nullptr)) return rc2;
+        if (last_ticket) *last_ticket = queued > 0 ? tickets[queued - 1] : CVGS_QUEUE_TICKET_DIRECT;
+        return CVGS_OK;
+    }
+    if (rc > 0) return fail(CVGS_ERR_UNSUPPORTED, err);
+    return fail(CVGS_ERR_HIP, err);
+}
+
+int cvgs_queue_recover(cvgs_queue_t h, uint64_t* lost) {
+    if (!h) return fail(CVGS_ERR_INVALID, "null queue");
+    DeviceGuard guard;
+    if (int rc = guard.enter(h->device)) return rc;
+    std::string err;
+    if (cvgs::queue_recover(h->q, lost, err)) return fail(CVGS_ERR_HIP, err);
+    return CVGS_OK;
+}
+
+int cvgs_debug_occupy(int32_t blocks, int32_t threads, int32_t lds_bytes, double microseconds, cvgs_stream_t stream) {
+    if (blocks < 1 || threads < 1 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 5e6)
+        return fail(CVGS_ERR_INVALID, "debug_occupy: blocks >= 1, 1..1024 threads, <= 160 KB LDS, <= 5 s");
+    if (cvgs::launch_debug_occupy(blocks, threads, lds_bytes, microseconds, stream)) return fail(CVGS_ERR_HIP, "debug_occupy launch failed");
+    return CVGS_OK;
+}
+
 int cvgs_queue_wait(cvgs_queue_t h, uint64_t ticket, double timeout_s) {
     if (!h) return fail(CVGS_ERR_INVALID, "null queue");
+    if (ticket == CVGS_QUEUE_TICKET_DIRECT) return fail(CVGS_ERR_INVALID, "queue: the batch was launched directly on the caller's stream (hybrid policy): synchronise that stream");
     std::string err;
     const int rc = cvgs::queue_wait(h->q, ticket, timeout_s, err);
     if (rc == 1) return fail(CVGS_ERR_INVALID, err);
@@ -1362,6 +1452,7 @@ int cvgs_queue_wait(cvgs_queue_t h, uint64_t ticket, double timeout_s) {
 
 int cvgs_queue_stream_wait(cvgs_queue_t h, uint64_t ticket, cvgs_stream_t stream) {
     if (!h) return fail(CVGS_ERR_INVALID, "null queue");
+    if (ticket == CVGS_QUEUE_TICKET_DIRECT) return CVGS_OK; // launched on a stream: whoever is ordered behind that stream is ordered behind the batch
     std::string err;
     if (cvgs::queue_stream_wait(h->q, ticket, stream, err)) return fail(CVGS_ERR_HIP, err);
     return CVGS_OK;
@@ -1378,6 +1469,7 @@ cvgs_stream_t cvgs_queue_stream(cvgs_queue_t h) { return h ? cvgs::queue_stream(
 int cvgs_queue_profile(cvgs_queue_t h, uint64_t* out16) {
     if (!h || !out16) return fail(CVGS_ERR_INVALID, "null queue / output");
     cvgs::queue_prof(h->q, out16);
+    out16[15] = (uint64_t)(uintptr_t)cvgs::queue_gate_trace(h->q); // probes only (CVGS_QUEUE_GATE_TRACE=1): host address of the gate trace
     return CVGS_OK;
 }
 

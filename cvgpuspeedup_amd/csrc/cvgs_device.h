@@ -232,6 +232,13 @@ struct Queue;
 int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle_us, std::string& err);
 // 0 = queued (ticket = batch number), 1 = this chain is not one the server takes (use cvgs_execute), < 0 = error
 int queue_submit(Queue* q, const ChainArgs& c, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err);
+// stream-ordered: 0 = queued behind `stream` (gate kernel enqueued), 1 = not a chain / situation the server takes, 2 = hybrid policy:
+// take the direct launch (nothing in flight to overlap with), < 0 = error.  flags: 1 = defer the completion wait, 2 = hybrid policy
+int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams* const* planes, const int* n_planes, int n, void* stream, uint32_t flags,
+                    uint64_t* tickets, int* n_queued, std::string& err);
+int queue_recover(Queue* q, uint64_t* lost, std::string& err);
+const uint64_t* queue_gate_trace(Queue* q); // null unless CVGS_QUEUE_GATE_TRACE was set at create
+int launch_debug_occupy(int blocks, int threads, int lds_bytes, double us, void* stream);
 int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err);
 int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err);
 void queue_stats(Queue* q, uint64_t* out8);

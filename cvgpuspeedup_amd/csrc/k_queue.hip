@@ -36,12 +36,17 @@
 // (k1q_rows: K1's arithmetic -- the headline), of 16UC3 / 16UC4 / 16SC3 / 16SC4 frames (the same worker on 16-byte windows), of
 // NV12 / NV21 decoder surfaces (k4q_rows: K4's arithmetic -- BASELINE cfg #3 and the decode-side 50-crop batch: 8.0 -> 4.9 us and
 // 4.7 -> 2.2 us per frame, tools/bench_more.py) and of P010 decoder surfaces (k4q_rows<S16>: cfg #3's 10-bit sibling 10.7 -> 6.2 us).
+#if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
-#include <setjmp.h>
-#include <signal.h>
+#define CVGS_HOST_X86 1
+#else
+#define CVGS_HOST_X86 0
+#endif
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
@@ -80,13 +85,14 @@ struct QParams {
     uint32_t yuv_range, yuv_primaries, yuv_vu; // QK_NV12: cvgs_yuv_range / cvgs_yuv_primaries, V-before-U (NV21)
     uint32_t src_signed;           // QK_PIXELS16: CV_16S pixels (else CV_16U)
     uint32_t out_half;             // the tensor holds CV_16F elements (the chain's trailing convertTo<CV_32F, CV_16F> is the store's conversion)
-    uint32_t pad[12];
+    uint32_t gated;                // stream-ordered submit: no tap of this batch is loaded before the slot's gate word has reached `stamp`
+    uint32_t pad[11];
 };
 static_assert(sizeof(QParams) == 256, "QParams is one wave-wide dword load");
 enum { QD_STAMP = 0, QD_TASK_BASE = 2, QD_N_TASKS = 4, QD_TPP = 5, QD_COL_TILES = 6, QD_N_PLANES = 7, QD_USED = 8, QD_DST_W = 9, QD_DST_H = 10,
        QD_OUT_W = 11, QD_CN = 12, QD_SWAP = 13, QD_FAST_DIV = 14, QD_ROWS_PER_TASK = 15, QD_MUL = 16, QD_SUB = 20, QD_DIV = 24, QD_RDIV = 28, QD_BG = 32,
        QD_IMG_STRIDE = 36, QD_CH_STRIDE = 38, QD_OUT = 40, QD_OUT_BYTES = 42, QD_ARRIVE_TARGET = 44, QD_KIND = 46, QD_YUV_RANGE = 47,
-       QD_YUV_PRIM = 48, QD_YUV_VU = 49, QD_SRC_SIGNED = 50, QD_OUT_HALF = 51 };
+       QD_YUV_PRIM = 48, QD_YUV_VU = 49, QD_SRC_SIGNED = 50, QD_OUT_HALF = 51, QD_GATED = 52 };
 // What a queue serves -- latched by its first submit; each kind has its own server instantiation (the 8-bit-pixel worker is the
 // tuned headline path and carries nothing of the other's code or registers).
 enum { QK_PIXELS = 0 /* 8UC3 / 8UC4 crops (K1's shape) */, QK_NV12 = 1 /* crops of NV12 / NV21 decoder surfaces (K4's shape) */,
@@ -624,12 +630,12 @@ __device__ __forceinline__ uint64_t q_bcast_u64(uint64_t v, int src_lane) {
 
 
 // ---- workgroup 0's janitor wave: in-order completion count (for retirement / the watchdog only), retirement --------------
-__device__ void k1q_janitor(QDevCtl* dc, QHostCtl* hc, const uint64_t* dflags, uint32_t R, uint64_t gen, uint64_t idle_ticks,
-                            uint64_t stall_ticks, uint64_t done) {
+__device__ void k1q_janitor(QDevCtl* dc, QHostCtl* hc, const uint64_t* dflags, const uint8_t* ring, const uint64_t* gates, uint32_t R, uint64_t gen,
+                            uint64_t idle_ticks, uint64_t stall_ticks, uint64_t gate_ticks, uint64_t done) {
     const int lane = (int)threadIdx.x;
     const uint64_t t_launch = wall_clock64();
-    uint64_t t_last = t_launch, rounds = 0;
-    int why = -1; // 0 = idle retirement, 1 = stall, 3 = destroy
+    uint64_t t_last = t_launch, rounds = 0, gate_since = 0;
+    int why = -1; // 0 = idle retirement, 1 = stall, 3 = destroy, 4 = a stream-ordered batch whose gate never opened
     while (why < 0) {
         ++rounds;
         const uint64_t tail = q_ldu_sys(&dc->tail.v);
@@ -650,8 +656,21 @@ __device__ void k1q_janitor(QDevCtl* dc, QHostCtl* hc, const uint64_t* dflags, u
             if (n > 0) {
                 done += (uint64_t)n;
                 t_last = wall_clock64();
+                gate_since = 0;
             } else if (wall_clock64() - t_last > stall_ticks) {
-                why = 1;
+                // No progress -- but the oldest open batch may be a stream-ordered one whose producer (the work in front of it on the
+                // caller's stream) has not finished: its workers are WAITING at the gate, nothing has stalled.  That wait has its own,
+                // much longer limit (a producer that never finishes -- a destroyed stream, a failed launch -- must not keep the
+                // server alive for ever: hipDeviceSynchronize waits for it).
+                const uint8_t* slot = ring + (size_t)(done % R) * kQSlotBytes;
+                const uint64_t stamp = q_ldu_sys((const uint64_t*)slot);
+                const uint32_t gated = q_uni((uint32_t)__hip_atomic_load((g_u32)((const uint32_t*)slot + QD_GATED), Q_SYSTEM));
+                const bool closed = stamp == done + 1 && gated != 0 && q_ldu_sys(gates + kQCtrStride * (done % R)) < done + 1;
+                const uint64_t now = wall_clock64();
+                if (!closed) why = 1;
+                else if (gate_since == 0) gate_since = t_last, t_last = now;
+                else if (now - gate_since > gate_ticks) why = 4;
+                else t_last = now;
             }
             __builtin_amdgcn_s_sleep(16);
         } else if (wall_clock64() - t_last > idle_ticks || q_ldu_sys(&hc->yield_req.v)) {
@@ -673,6 +692,7 @@ __device__ void k1q_janitor(QDevCtl* dc, QHostCtl* hc, const uint64_t* dflags, u
     if (lane == 0) {
         q_st_sys(&dc->stop_gen.v, gen);
         if (why == 1) q_st_sys(&hc->error.v, 1);
+        if (why == 4) q_st_sys(&hc->error.v, 3);
         q_st_sys(&hc->stat_rounds.v, rounds);
         q_st_sys(&hc->stat_launch_ticks.v, wall_clock64() - t_launch);
         q_drain();
@@ -690,6 +710,7 @@ struct QDevMem { // the server's device-side state, one uncached allocation (hos
     QIndex* index;      // R entries
     uint64_t* arrive;   // ordinary (cached) device memory: per slot 1 top + 16 sub arrival counters, 128 bytes apart; device atomics only
     uint64_t* dflags;   // R completion flags, 128 bytes apart (hipStreamWaitValue64 targets)
+    uint64_t* gates;    // R gate words, 128 bytes apart (uncached): batch b of a stream-ordered submit may be read from once gates[b % R] >= b + 1
     uint64_t* prog;     // 4 G resume words: the ticket (task number) each worker holds
     uint64_t* ticket;   // 16 ticket counters (one per residue class of the task numbering), 128 bytes apart
 };
@@ -700,13 +721,13 @@ struct QDevMem { // the server's device-side state, one uncached allocation (hos
 template <int LD, int ST, int KIND = QK_PIXELS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_PIXELS16 || KIND == QK_P010 ? 3 : 4, 8))) void k1q_server(QDevMem m, QHostCtl* hc, uint64_t* hflags, uint32_t R, uint32_t G,
                                                                                              uint64_t gen, uint64_t done0, uint64_t idle_ticks,
-                                                                                             uint64_t stall_ticks) {
+                                                                                             uint64_t stall_ticks, uint64_t gate_ticks) {
     __shared__ __attribute__((aligned(16))) float q_tiles[kQWaves * kQLdsWave]; // one transpose tile per wave (20 KB per workgroup)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t n_workers = G * kQWaves;
     if (blockIdx.x == 0) {
-        if (wave == 0) k1q_janitor(m.dc, hc, m.dflags, R, gen, idle_ticks, stall_ticks, done0);
+        if (wave == 0) k1q_janitor(m.dc, hc, m.dflags, m.ring, m.gates, R, gen, idle_ticks, stall_ticks, gate_ticks, done0);
         return;
     }
     const uint32_t wid = (blockIdx.x - 1) * kQWaves + (uint32_t)wave;
@@ -810,6 +831,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             v = __hip_atomic_load((g_u32)((const uint32_t*)slot + lane), Q_SYSTEM);
             pv = __hip_atomic_load((g_u32)((const uint32_t*)(slot + kQPlanesOff + (size_t)pz * sizeof(PlaneParams)) + (lane < 12 ? lane : 0)), Q_SYSTEM);
             sub_target = q_ld_sys((const uint64_t*)(slot + kQSubOff) + (T & (kQSubs - 1)));
+            uint64_t gate = q_ld_sys(m.gates + kQCtrStride * (best % R)); // (the same round trip as the parameters)
             q_drain();
             sub_target = q_uni(sub_target);
             QPROF(p_slot += wall_clock64() - p_s0;)
@@ -818,6 +840,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
                 continue;
             }
             b = best;
+            // Stream-ordered batch (cvgs_queue_submit_on): its sources belong to work that is still in front of the gate kernel on the
+            // caller's stream.  No tap is loaded before the gate word says that stream has got there; the gate kernel's store follows a
+            // kernel boundary on that stream (the producer's release), the tap loads below are agent-coherent (sc1).
+            if (q_lane_u32(v, QD_GATED) != 0) {
+                gate = q_uni(gate);
+                // (back-off: a closed gate can have a thousand workers in front of it, all reading ONE uncached word -- at a fixed
+                //  0.25 us interval that traffic slowed every other access to the control block: two alternating streams of 4-frame
+                //  ticks ran at 11.5 us per batch against 5.6 for one stream)
+                int nap = 0;
+                while (gate < best + 1) {
+                    if (q_ldu_sys(&m.dc->stop_gen.v) == gen) return; // (the ticket stays in this worker's resume word)
+                    if (nap == 0) __builtin_amdgcn_s_sleep(8);
+                    else if (nap == 1) __builtin_amdgcn_s_sleep(16);
+                    else if (nap == 2) __builtin_amdgcn_s_sleep(32);
+                    else if (nap < 6) __builtin_amdgcn_s_sleep(64);
+                    else __builtin_amdgcn_s_sleep(127);
+                    ++nap;
+                    gate = q_ldu_sys(m.gates + kQCtrStride * (best % R));
+                }
+            }
             break;
         }
         QPROF(const uint64_t p_t1 = wall_clock64();)
@@ -954,6 +996,72 @@ __global__ void k1q_stage(QDevMem m, const uint8_t* host_ring, const QIndex* hos
     if (lane == 0) q_st_sys(&m.dc->tail.v, new_tail);
 }
 
+// The gate of a stream-ordered batch, enqueued on the CALLER's stream by cvgs_queue_submit_on: everything in front of it on that
+// stream (the decoder / producer kernel that writes the frame) has completed when it runs, and the kernel boundary in front of it
+// has released those writes; it opens the batch's gate and -- unless the caller defers the wait -- holds the stream until the
+// batch's completion word is up, so that whatever follows on the stream sees the tensor.  One launch per submit: the reference's
+// contract "asynchronous on the given stream" (include/cvGPUSpeedup.cuh:464-473) without a host synchronisation anywhere.
+// A server that has reported an error (host word) releases the stream: the failure is reported by the next call, never waited for.
+struct QGateTickets { // the batches behind ONE gate kernel (cvgs_queue_submit_many_on: a tick's frames; tickets need not be consecutive)
+    uint64_t t[64];
+    uint32_t n;
+};
+// `trace` (CVGS_QUEUE_GATE_TRACE=1, tools/probes only; else null): per ticket {gate kernel start, completion seen} in 100 MHz ticks
+__global__ void k1q_gate(uint64_t* gates, uint64_t* hgates, const uint64_t* dflags, uint32_t R, QGateTickets tk, uint32_t wait, const uint64_t* host_error,
+                         uint64_t timeout_ticks, uint64_t* trace) {
+    const uint32_t i = threadIdx.x;
+    if (i >= tk.n) return;
+    const uint64_t t = tk.t[i];
+    const uint64_t t0 = wall_clock64();
+    q_st_sys(gates + kQCtrStride * (t % R), t + 1);
+    q_st_sys(hgates + (t % R), t + 1); // the host's copy: the admission budget of closed batches (queue_submit_on) is kept from it
+    q_drain();
+    if (trace) q_st_sys(trace + 2 * (t & 4095), t0);
+    if (!wait) return;
+    unsigned polls = 0;
+    while (q_ld_sys(dflags + kQCtrStride * (t % R)) < t + 1) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++polls & 63) == 0) {
+            if (q_ld_sys(host_error) != 0) return;
+            if (wall_clock64() - t0 > timeout_ticks) return;
+        }
+    }
+    if (trace) q_st_sys(trace + 2 * (t & 4095) + 1, wall_clock64());
+}
+// cvgs_queue_stream_wait: the stream waits until batches [first, last] are complete (one wave; lane i watches batch first + i, in
+// rounds of 64).  hipStreamWaitValue64 on ordinary device memory proved unusable on a hot path: a wait that is not already satisfied
+// when the stream reaches it costs ~1.6 ms on this runtime (tools/probes/stream_ordered_rate.py, deferred waits trailing by 4 batches).
+__global__ void k1q_wait(const uint64_t* dflags, uint32_t R, uint64_t first, uint64_t last, const uint64_t* host_error, uint64_t timeout_ticks) {
+    const uint64_t t0 = wall_clock64();
+    for (uint64_t base = first; base <= last; base += 64) {
+        const uint64_t b = base + threadIdx.x;
+        unsigned polls = 0;
+        if (b <= last)
+            while (q_ld_sys(dflags + kQCtrStride * (b % R)) < b + 1) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((++polls & 63) == 0 && (q_ld_sys(host_error) != 0 || wall_clock64() - t0 > timeout_ticks)) return;
+            }
+    }
+}
+// host-side gate opening without a writable BAR (a failed gate launch must not leave workers waiting)
+__global__ void k1q_gate_open(uint64_t* gate, uint64_t value) {
+    if (threadIdx.x == 0) q_st_sys(gate, value);
+}
+
+// test / measurement aid (cvgs_debug_occupy): `blocks` workgroups that hold their wave slots (and `lds_bytes` of LDS each) for `us`
+// microseconds -- a stand-in for a foreign kernel that keeps part of the chip busy while the server must stay resident.
+__global__ void k_debug_occupy(uint64_t ticks) {
+    extern __shared__ float occ_lds[];
+    if (threadIdx.x == 0) occ_lds[0] = 0.f;
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int launch_debug_occupy(int blocks, int threads, int lds_bytes, double us, void* stream) {
+    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_debug_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(k_debug_occupy, dim3(blocks), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, (uint64_t)(us * 100.0));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ====================================================================================================================
 // host side
 // ====================================================================================================================
@@ -973,11 +1081,22 @@ struct Queue {
     QIndex* host_index = nullptr;
     QHostCtl* hc = nullptr;             // pinned
     uint64_t* hflags = nullptr;         // pinned: R completion flags
+    uint64_t* gate_trace = nullptr;     // pinned, CVGS_QUEUE_GATE_TRACE=1 only: 4096 x {gate kernel start, completion seen}
+    uint64_t* hgates = nullptr;         // pinned: the gate kernels' host copies of the gate words (R)
+    struct Closed { uint64_t ticket; uint32_t tasks; };
+    std::vector<Closed> closed;         // stream-ordered batches whose gate the host has not yet seen open
+    uint64_t closed_tasks = 0, n_budget_direct = 0, n_budget_waits = 0;
     std::vector<uint64_t> arrive_cum;   // per slot, 1 + 16 words: each arrival counter's value once every batch that used the slot has arrived
     uint64_t next_seq = 0, next_task = 0, done_inorder = 0, gen = 0, launches = 0;
     std::atomic<uint64_t> done_hint{0}; // every batch below is complete: what waiters (which do not take the mutex) have seen so far
-    uint64_t idle_ticks = 0, stall_ticks = 0;
+    uint64_t idle_ticks = 0, stall_ticks = 0, gate_ticks = 0;
+    uint64_t failed_upto = 0;              // every batch below was submitted before the last recovery
+    std::vector<uint64_t> lost_tickets;    // ... and these had not completed then: their tensors may be incomplete (the newest 4096 are remembered)
+    uint64_t n_gated = 0, n_direct = 0; // stream-ordered submits taken by the server / by a direct launch (hybrid policy)
+    struct StreamTail { void* stream; uint64_t ticket; };
+    std::vector<StreamTail> stream_tail; // the newest ticket of every stream that has submitted with an immediate wait (hybrid policy)
     std::mutex mu;
+    std::mutex gate_mu;                  // held across "publish a group closed" + "enqueue its gate kernel" (taken before mu, never inside it)
     uint64_t ns_ring_wait = 0, n_sub = 0; // host side of submit: time spent waiting for a ring slot
     uint64_t n_ring_waits = 0, sum_done_behind_head = 0;               // head-of-line blocking: batches already complete behind an incomplete oldest one
 };
@@ -985,28 +1104,65 @@ struct Queue {
 static inline volatile uint64_t& hv(QLine& l) { return *(volatile uint64_t*)&l.v; }
 static inline uint64_t hflag(Queue* q, uint64_t slot) { return *(volatile uint64_t*)(q->hflags + slot); }
 
-static sigjmp_buf g_probe_jmp;
-static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
-// Is device memory writable from the host (large BAR)?  One guarded 8-byte store + device-side read-back.
-static bool probe_direct(uint64_t* dev_word) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    struct sigaction sa {}, old_segv {}, old_bus {};
-    sa.sa_handler = probe_fault;
-    sigemptyset(&sa.sa_mask);
-    sigaction(SIGSEGV, &sa, &old_segv);
-    sigaction(SIGBUS, &sa, &old_bus);
+// ---- host-side primitives: x86-64 has the real ones, anything else gets portable stand-ins (and the staged path by default) -------
+static inline void cpu_pause() {
+#if CVGS_HOST_X86
+    _mm_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+// orders the write-combined stores to device memory in front of it before the ones behind it
+static inline void wc_fence() {
+#if CVGS_HOST_X86
+    _mm_sfence();
+#else
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
+}
+
+// Is device memory writable from the host (large BAR, the allocation mapped into this process)?  Decided WITHOUT ever faulting: round 3
+// probed with a store guarded by process-wide SIGSEGV / SIGBUS handlers and siglongjmp -- inside a library that races every other
+// thread's faults and every other user of sigaction.  Now: (1) CVGS_QUEUE_DIRECT=0 / CVGS_QUEUE_STAGED=1 /
+// flag bit 0 force the staged path; (2) the device must report a large BAR (hipDeviceAttributeIsLargeBar); (3) the WHOLE block must lie
+// inside read-write mappings of this process (/proc/self/maps: with a large BAR the runtime maps VRAM allocations through the render
+// node at their device address; without one the range is a PROT_NONE reservation) -- only then is the test store issued, and (4) it must
+// read back from the device.  Anything unknown (no /proc, a foreign OS, a non-x86 host without CVGS_QUEUE_DIRECT=1) means "staged".
+static bool range_is_mapped_rw(const void* p, size_t bytes) {
+    FILE* f = std::fopen("/proc/self/maps", "r");
+    if (!f) return false;
+    uintptr_t need = (uintptr_t)p;
+    const uintptr_t end = need + bytes;
+    char line[512];
     bool ok = false;
-    if (sigsetjmp(g_probe_jmp, 1) == 0) {
-        *(volatile uint64_t*)dev_word = 0x5157455545ull;
-        _mm_sfence();
-        ok = true;
+    while (std::fgets(line, sizeof(line), f)) { // (the file is sorted by address)
+        unsigned long long lo = 0, hi = 0;
+        char perms[8] = {0};
+        if (std::sscanf(line, "%llx-%llx %7s", &lo, &hi, perms) != 3) continue;
+        if ((uintptr_t)hi <= need) continue;
+        if ((uintptr_t)lo > need) break;                   // a hole at `need`
+        if (perms[0] != 'r' || perms[1] != 'w') break;     // reserved / read-only
+        need = (uintptr_t)hi;
+        if (need >= end) { ok = true; break; }
     }
-    sigaction(SIGSEGV, &old_segv, nullptr);
-    sigaction(SIGBUS, &old_bus, nullptr);
-    if (!ok) return false;
+    std::fclose(f);
+    return ok;
+}
+static bool decide_direct(int device, uint8_t* block, size_t block_bytes, uint64_t* probe_word, uint32_t flags) {
+    const char* staged_env = getenv("CVGS_QUEUE_STAGED");
+    const char* direct_env = getenv("CVGS_QUEUE_DIRECT");
+    if ((flags & 1u) || (staged_env && staged_env[0] == '1') || (direct_env && direct_env[0] == '0')) return false;
+    const bool asked = direct_env && direct_env[0] == '1';
+    if (!CVGS_HOST_X86 && !asked) return false; // the write-combining path below is tuned and tested on x86-64 only
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) return false;
+    if (!range_is_mapped_rw(block, block_bytes)) return false;
+    *(volatile uint64_t*)probe_word = 0x5157455545ull;
+    wc_fence();
     uint64_t back = 0;
-    if (hipMemcpy(&back, dev_word, 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(&back, probe_word, 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
     return back == 0x5157455545ull;
 }
 
@@ -1042,7 +1198,7 @@ static hipError_t queue_launch(Queue* q) {
             for (;;) {
                 const uint64_t s2 = hv(o->hc->state);
                 if (s2 != QS_RUNNING && s2 != QS_EXITING) break;
-                _mm_pause();
+                cpu_pause();
                 if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                     hv(o->hc->yield_req) = 0;
                     return hipErrorLaunchTimeOut; // the other queue's server never drained
@@ -1058,7 +1214,7 @@ static hipError_t queue_launch(Queue* q) {
     hv(q->hc->state) = QS_RUNNING;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     const dim3 grid(q->G + 1), block(256);
-#define Q_LAUNCH(LD_, ST_, K_) hipLaunchKernelGGL((k1q_server<LD_, ST_, K_>), grid, block, 0, q->stream, q->m, q->hc, q->hflags, q->R, q->G, q->gen, q->done_inorder, q->idle_ticks, q->stall_ticks)
+#define Q_LAUNCH(LD_, ST_, K_) hipLaunchKernelGGL((k1q_server<LD_, ST_, K_>), grid, block, 0, q->stream, q->m, q->hc, q->hflags, q->R, q->G, q->gen, q->done_inorder, q->idle_ticks, q->stall_ticks, q->gate_ticks)
     if (q->kind == QK_NV12) { // the product flavour, and the unsafe upper bound of the A/B tool
         if (q->ld == 0 && q->st == 0) Q_LAUNCH(0, 0, QK_NV12);
         else Q_LAUNCH(1, 2, QK_NV12);
@@ -1083,7 +1239,7 @@ static int queue_ensure_running(Queue* q) {
         const uint64_t s = hv(q->hc->state);
         if (s == QS_RUNNING) return 0;
         if (s == QS_EXITING) { // the janitor is deciding: it re-reads host.tail and either resumes or exits, within microseconds
-            _mm_pause();
+            cpu_pause();
             continue;
         }
         if (hv(q->hc->error)) return -2;
@@ -1124,6 +1280,9 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     }
     const uint32_t g_cap = (uint32_t)prop.multiProcessorCount * 4u - 1u; // every workgroup must be resident (each worker holds a ticket): 4 per CU at most
     if (G > g_cap) G = g_cap;
+    // A task of residue class T % 16 is only ever drawn by the workers of that class (w % 16): fewer than 16 workers -- G < 4 -- would
+    // leave classes nobody serves, and every batch of 5 or more tasks would sit until the watchdog.
+    if (G * kQWaves < (uint32_t)kQSubs) G = (uint32_t)(kQSubs + kQWaves - 1) / kQWaves;
     q->G = G;
     const double tick_hz = 100e6; // s_memrealtime: constant 100 MHz
     q->idle_ticks = (uint64_t)((idle_us <= 0 ? 200.0 : idle_us) * 1e-6 * tick_hz);
@@ -1135,15 +1294,31 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
         if (v >= 1.0 && v <= 600000.0) stall_s = v * 1e-3;
     }
     q->stall_ticks = (uint64_t)(stall_s * tick_hz);
+    // a stream-ordered batch may wait this long at its gate for the work in front of it on the caller's stream (then: error 3)
+    double gate_s = 10.0;
+    if (const char* gm = getenv("CVGS_QUEUE_GATE_TIMEOUT_MS")) {
+        const double v = atof(gm);
+        if (v >= 1.0 && v <= 3600000.0) gate_s = v * 1e-3;
+    }
+    q->gate_ticks = (uint64_t)(gate_s * tick_hz);
     const size_t R = q->R, NW = (size_t)q->G * kQWaves;
-    const size_t off_ring = 4096, off_index = off_ring + R * kQSlotBytes, off_dflags = off_index + R * sizeof(QIndex), total = off_dflags + R * 128;
+    const size_t off_ring = 4096, off_index = off_ring + R * kQSlotBytes, off_dflags = off_index + R * sizeof(QIndex), off_gates = off_dflags + R * 128, total = off_gates + R * 128;
     const size_t ctr_bytes = R * (1 + kQSubs) * kQCtrStride * 8, prog_bytes = (NW * 8 + 127) & ~(size_t)127, total_ctr = ctr_bytes + prog_bytes + kQSubs * kQCtrStride * 8;
-    if ((e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking)) != hipSuccess ||
+    // The server is a LONG-LIVED kernel: whatever shares its hardware queue waits until it retires.  The runtime multiplexes streams
+    // onto a few hardware queues PER PRIORITY LEVEL, so the server's stream is created at the highest priority and the staging stream
+    // at the lowest: neither shares a hardware queue with the caller's (default-priority) streams -- on which the gate kernels of
+    // stream-ordered submits and hipStreamWaitValue64 consumers must be able to run while the server is alive (found by
+    // tools/probes/stream_ordered_rate.py: with four caller streams one of them shared the server's queue, its gate kernel never
+    // started, the server waited at that gate for the 10 s limit) -- nor with each other.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if ((e = hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&q->stage_stream, hipStreamNonBlocking, prio_least)) != hipSuccess ||
         (e = hipExtMallocWithFlags((void**)&q->dev_block, total, hipDeviceMallocUncached)) != hipSuccess ||
         (e = hipMalloc((void**)&q->dev_counters, total_ctr)) != hipSuccess ||
         (e = hipHostMalloc((void**)&q->hc, sizeof(QHostCtl), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&q->hflags, R * 8, hipHostMallocDefault)) != hipSuccess) {
+        (e = hipHostMalloc((void**)&q->hflags, R * 8, hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&q->hgates, R * 8, hipHostMallocDefault)) != hipSuccess) {
         err = std::string("queue allocation: ") + hipGetErrorString(e);
         return -1; // (leaks on this cold path are reclaimed at process exit)
     }
@@ -1151,11 +1326,13 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     q->m.ring = q->dev_block + off_ring;
     q->m.index = (QIndex*)(q->dev_block + off_index);
     q->m.dflags = (uint64_t*)(q->dev_block + off_dflags);
+    q->m.gates = (uint64_t*)(q->dev_block + off_gates);
     q->m.arrive = (uint64_t*)q->dev_counters;
     q->m.prog = (uint64_t*)(q->dev_counters + ctr_bytes);
     q->m.ticket = (uint64_t*)(q->dev_counters + ctr_bytes + prog_bytes);
     std::memset((void*)q->hc, 0, sizeof(QHostCtl));
     std::memset((void*)q->hflags, 0, R * 8);
+    std::memset((void*)q->hgates, 0, R * 8);
     q->arrive_cum.assign(R * (1 + kQSubs), 0);
     std::vector<uint64_t> p0(NW);
     for (size_t i = 0; i < NW; ++i) p0[i] = i; // worker w's first task is w
@@ -1164,8 +1341,8 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
         err = std::string("queue init: ") + hipGetErrorString(e);
         return -1;
     }
-    static const char* staged_env = getenv("CVGS_QUEUE_STAGED"); // debugging / profilers that remap device memory: force the staging path
-    q->direct = !(flags & 1u) && !(staged_env && staged_env[0] == '1') && probe_direct(&q->m.dc->stop_gen.pad[0]);
+    if (getenv("CVGS_QUEUE_GATE_TRACE") && hipHostMalloc((void**)&q->gate_trace, 4096 * 16, hipHostMallocDefault) == hipSuccess) std::memset(q->gate_trace, 0, 4096 * 16);
+    q->direct = decide_direct(device, q->dev_block, total, &q->m.dc->stop_gen.pad[0], flags);
     if (!q->direct) {
         if ((e = hipHostMalloc((void**)&q->host_ring, R * kQSlotBytes, hipHostMallocDefault)) != hipSuccess ||
             (e = hipHostMalloc((void**)&q->host_index, R * sizeof(QIndex), hipHostMallocDefault)) != hipSuccess) {
@@ -1181,16 +1358,30 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
 
 // `bytes` (a multiple of 16) to a 16-byte aligned destination with non-temporal stores
 static inline void wc_copy16(void* dst, const void* src, size_t bytes) {
+#if CVGS_HOST_X86
     __m128i* d = (__m128i*)dst;
     const __m128i* s = (const __m128i*)src;
     for (size_t i = 0; i < bytes / 16; ++i) _mm_stream_si128(d + i, _mm_loadu_si128(s + i));
+#else
+    volatile uint64_t* d = (volatile uint64_t*)dst;
+    const uint64_t* s = (const uint64_t*)src;
+    for (size_t i = 0; i < bytes / 8; ++i) d[i] = s[i];
+#endif
 }
 
 // Can the server take this chain?  K1's hot shape: 8U C3 / C4 crops -> bilinear resize -> [swap R,B] mul sub div -> fp32 planar
 // tensor (NCHW / CNHW), descriptors inline, one target -- or K4's: the same behind crops of an NV12 / NV21 decoder surface
 // (cvtColorNV12 in front of the resize, 3 channels).  A queue serves ONE of the two (its first submit decides); everything else
 // belongs to cvgs_execute.
-static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err) {
+// a stream-ordered batch (published with its gate closed)
+struct GateInfo {
+    void* stream;        // the caller's stream (a key, never dereferenced)
+    bool defer;          // the caller's stream is not held on the batch
+    uint32_t rows;       // rows per task, decided by queue_submit_on (the closed-batch budget is kept in tasks)
+    uint32_t n_tasks;    // out
+};
+static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams* planes, int n_planes, uint64_t* ticket, std::string& err, GateInfo* gate = nullptr) {
+    const bool gated = gate != nullptr;
     const ReadArgs& r = c_in.read;
     const WriteArgs& w = c_in.write;
     const bool planar = w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT;
@@ -1241,7 +1432,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     }
     std::lock_guard<std::mutex> lock(q->mu);
     if (hv(q->hc->error)) {
-        err = "queue: the server reported a stall / protocol error earlier";
+        err = "queue: the server reported a stall / protocol error earlier (cvgs_queue_recover resets the queue)";
         return -2;
     }
     if (hv(q->hc->yield_req)) { // another queue of this device waits to launch its server: this one drains and retires first
@@ -1250,7 +1441,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
         while (hv(q->hc->yield_req)) {
             const uint64_t st = hv(q->hc->state);
             if (st != QS_RUNNING && st != QS_EXITING) break;
-            _mm_pause();
+            cpu_pause();
             if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - ty > std::chrono::seconds(5)) break;
         }
     }
@@ -1292,7 +1483,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
                 const int rc = queue_ensure_running(q);
                 if (rc) { err = "queue: server launch failed / stalled"; return rc; }
             }
-            _mm_pause();
+            cpu_pause();
             if ((++spins & 0xffff) == 0 && ns_since(t0) > 2000000000ull) { err = "queue: ring full for 2 s"; return -2; }
         }
         q->ns_ring_wait += ns_since(t0);
@@ -1316,7 +1507,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     const bool sustained = q->R >= 32 && in_flight * 4 >= q->R * 3;
     const uint32_t deep_rows = deep_env >= 4 && deep_env <= 4096 ? (uint32_t)deep_env
                                : (sustained ? (q->R >= 128 ? (uint32_t)kQRowsPerTaskDeep : 64u) : (uint32_t)kQRowsPerTaskMid);
-    p.rows_per_task = in_flight >= 8 ? deep_rows : (in_flight >= 2 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
+    p.rows_per_task = gated ? gate->rows : (in_flight >= 8 ? deep_rows : (in_flight >= 2 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave));
     p.tiles_per_plane = p.col_tiles * (uint32_t)((r.dst_h + (int)p.rows_per_task - 1) / (int)p.rows_per_task);
     p.n_tasks = p.tiles_per_plane * (uint32_t)r.batch;
     p.n_planes = (uint32_t)n_planes;
@@ -1344,6 +1535,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     p.out = (uint64_t)w.data;
     p.out_bytes = (uint64_t)last * (half ? 2 : 4);
     p.out_half = half ? 1u : 0u;
+    p.gated = gated ? 1u : 0u;
     // cumulative arrival targets of the slot's counters (they are never reset): sub-counter s takes the tasks T = s (mod 16)
     uint64_t sub_targets[kQSubs];
     uint64_t* cum = &q->arrive_cum[k * (1 + kQSubs)];
@@ -1376,7 +1568,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
         const uint64_t st = hv(q->hc->state);
         if (st == QS_RUNNING) break;
         if (st == QS_EXITING) { // the janitor is deciding: it re-reads host.tail and resumes or exits within microseconds
-            _mm_pause();
+            cpu_pause();
             continue;
         }
         if (hv(q->hc->error)) { err = "queue: the server reported a stall / protocol error"; return -2; }
@@ -1403,14 +1595,19 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     }
     for (int i = 0; i < 4; ++i) ((volatile uint64_t*)ixp)[i] = ((const uint64_t*)&ix)[i]; // four atomic 8-byte stores
     if (q->direct) {
-        _mm_sfence(); // the write-combined slot / index stores leave before the tail does
+        wc_fence(); // the write-combined slot / index stores leave before the tail does
         *(volatile uint64_t*)&q->m.dc->tail.v = q->next_seq;
-        _mm_sfence();
+        wc_fence();
     } else {
         hipLaunchKernelGGL(k1q_stage, dim3(1), dim3(64), 0, q->stage_stream, q->m, q->host_ring, q->host_index, q->R, q->next_seq - 1, 1u, q->next_seq);
         if (hipGetLastError() != hipSuccess) { err = "queue: staging kernel launch failed"; return -1; }
     }
     q->n_sub += 1;
+    if (gated) {
+        gate->n_tasks = p.n_tasks;
+        q->closed.push_back({q->next_seq - 1, p.n_tasks});
+        q->closed_tasks += p.n_tasks;
+    }
     // 3. a retired server is replaced AFTER the batch is in place
     if (need_launch && queue_launch(q) != hipSuccess) { err = "queue: server launch failed"; return -1; }
     return 0;
@@ -1479,12 +1676,21 @@ static void queue_debug_dump(Queue* q) {
 // says "batch b is complete" however stale b is.
 int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err) {
     if (ticket >= q->next_seq) { err = "queue: ticket was never issued"; return 1; }
+    if (ticket < q->failed_upto) { // submitted before the last recovery: complete unless it is one of the batches declared lost then
+        std::lock_guard<std::mutex> lock(q->mu);
+        for (const uint64_t t : q->lost_tickets)
+            if (t <= ticket && (ticket < q->R || t + q->R > ticket)) { // (a wait covers the ticket and the batches before it)
+                err = "queue: a batch up to this ticket was in flight when the server stalled; the queue was recovered, its tensor may be incomplete";
+                return -2;
+            }
+        return 0;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     auto wait_flag = [&](uint64_t b) {
         while (hflag(q, b % q->R) < b + 1) {
             if (hv(q->hc->error)) { queue_debug_dump(q); err = "queue: the server reported a stall / protocol error"; return -2; }
-            _mm_pause();
+            cpu_pause();
             if ((++spins & 1023) == 0 && timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
                 err = "queue: wait timed out";
                 return -3;
@@ -1511,20 +1717,244 @@ int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err)
     if (ticket >= q->R && d + q->R <= ticket) d = ticket - q->R + 1;
     while (d <= ticket && hflag(q, d % q->R) >= d + 1) ++d;
     raise_done_hint(q, d < ticket + 1 ? d : ticket + 1);
-    for (uint64_t b = d; b <= ticket; ++b) {
-        if (b != ticket && hflag(q, b % q->R) >= b + 1) continue;
-        const hipError_t e = hipStreamWaitValue64((hipStream_t)stream, q->m.dflags + kQCtrStride * (b % q->R), b + 1, hipStreamWaitValueGte, ~0ull);
-        if (e != hipSuccess) { err = std::string("hipStreamWaitValue64: ") + hipGetErrorString(e); return -1; }
+    if (d > ticket) return 0; // the host has already seen every batch up to the ticket complete: nothing to wait for
+    static const bool use_wait_value = getenv("CVGS_QUEUE_WAITVALUE") != nullptr; // (round 3's spelling, kept for A/B)
+    if (use_wait_value) {
+        for (uint64_t b = d; b <= ticket; ++b) {
+            if (b != ticket && hflag(q, b % q->R) >= b + 1) continue;
+            const hipError_t e = hipStreamWaitValue64((hipStream_t)stream, q->m.dflags + kQCtrStride * (b % q->R), b + 1, hipStreamWaitValueGte, ~0ull);
+            if (e != hipSuccess) { err = std::string("hipStreamWaitValue64: ") + hipGetErrorString(e); return -1; }
+        }
+        return 0;
+    }
+    hipLaunchKernelGGL(k1q_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint64_t*)q->m.dflags, q->R, d, ticket, (const uint64_t*)&q->hc->error.v, q->gate_ticks);
+    if (hipGetLastError() != hipSuccess) { err = "queue: the wait kernel could not be launched on the consumer's stream"; return -1; }
+    return 0;
+}
+
+// ---- stream-ordered submit -------------------------------------------------------------------------------------
+// cvgs_queue_submit's batch is ordered behind NOTHING: a decoder or a previous kernel writing the frame on stream S had to be
+// host-synchronised before the call.  This form keeps the reference's contract -- "asynchronous on the given stream"
+// (include/cvGPUSpeedup.cuh:464-473) -- on the queue: the batch is published with its gate closed, ONE one-wave kernel (k1q_gate) goes
+// onto S behind the producer, opens the gate when S gets there and -- unless QSUB_DEFER_WAIT -- holds S until the batch's completion
+// word is up.  Workers that draw a task of the batch wait at the gate (they poll an uncached word); every other batch in the ring
+// proceeds.  QSUB_HYBRID: when nothing the batch could overlap with is in flight, the caller is told to take the direct launch (2):
+// a lone batch on the server costs a round-trip chain of ~14 us against ~7 us for one launch.
+enum { QSUB_DEFER_WAIT = 1, QSUB_HYBRID = 2 };
+// n chains (1..64) behind ONE gate kernel: the frames of one tick (several cameras' pictures written by the work in front of the call,
+// several crop lists of one picture).  chains[i] / planes[i] / n_planes[i]; tickets[i] out; *n_queued = how many the server took (the
+// rest -- return 2 -- is the caller's to launch directly, in order, behind what was queued).
+//
+// THE BUDGET OF CLOSED BATCHES.  Workers draw task numbers in ring order and WAIT at a closed gate; a host that runs ahead of its
+// streams fills the ring with closed batches, and a later batch whose gate is open only gets the workers the closed ones have not
+// absorbed.  Unbounded, that is a priority inversion and -- where the closed batch's gate kernel sits behind the open batch's wait in a
+// shared hardware queue -- a dead-lock until the 10 s gate limit (tools/probes/gate_trace.py: four strict streams on a default
+// runtime ran at 28 us per batch, 83 us with unlucky queue sharing).  So the tasks of batches whose gate the host has not yet seen open
+// (the gate kernel mirrors every gate into host memory) can be BOUNDED: a batch that does not fit waits for a gate to open (bounded) -- or,
+// with QSUB_HYBRID, is launched directly on the stream: always a correct spelling of the same call.
+// DEAD-LOCK FREEDOM does not need the budget: a group is published and its gate kernel enqueued under ONE lock (gate_mu), so ring order
+// == the order of the gate kernels inside every hardware queue.  The earliest incomplete batch of the ring is then either open -- its
+// tasks were all drawn before any later batch's, by workers that are executing them -- or closed with nothing but completed gate
+// kernels and the caller's own producers in front of its gate kernel: it always makes progress.
+static void prune_closed(Queue* q) { // (under q->mu)
+    size_t w = 0;
+    for (size_t i = 0; i < q->closed.size(); ++i) {
+        const Queue::Closed c = q->closed[i];
+        if (*(volatile uint64_t*)(q->hgates + c.ticket % q->R) >= c.ticket + 1 || c.ticket < q->failed_upto) q->closed_tasks -= c.tasks;
+        else q->closed[w++] = c;
+    }
+    q->closed.resize(w);
+}
+static uint32_t gated_tasks(const ChainArgs& c, uint32_t rows) {
+    return (uint32_t)c.read.batch * (uint32_t)((c.read.dst_w + 63) / 64) * (uint32_t)((c.read.dst_h + (int)rows - 1) / (int)rows);
+}
+int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams* const* planes, const int* n_planes, int n, void* stream, uint32_t flags,
+                    uint64_t* tickets, int* n_queued, std::string& err) {
+    if (n_queued) *n_queued = 0;
+    if (n < 1 || n > 64) { err = "queue: 1..64 chains behind one gate"; return 1; }
+    for (int i = 0; i < n; ++i)
+        if (n_planes[i] > kQMaxPlanes) { err = "queue: a stream-ordered batch holds at most 74 planes"; return 1; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        err = "queue: the stream is capturing (the ring is written at submit time; capture cvgs_execute instead)";
+        return 1;
+    }
+    const bool defer = (flags & QSUB_DEFER_WAIT) != 0, hybrid = (flags & QSUB_HYBRID) != 0;
+    void* const key = stream ? stream : (void*)q; // (the null stream is a stream too)
+    // (off by default: it bounds a batch's latency -- p90 19 us instead of 80-110 us with four strict streams -- but halves the work that
+    //  can sit absorbed behind closed gates, which is exactly what keeps the server fed between two ticks: 16-frame ticks on two
+    //  streams 2.5 -> 8.9 us per batch.  CVGS_QUEUE_CLOSED_BUDGET=<tasks> turns it on; 1 = half the workers.)
+    static const long budget_env = getenv("CVGS_QUEUE_CLOSED_BUDGET") ? atol(getenv("CVGS_QUEUE_CLOSED_BUDGET")) : 0;
+    const uint64_t budget = budget_env <= 0 ? ~0ull : (budget_env == 1 ? (uint64_t)q->G * kQWaves / 2 : (uint64_t)budget_env);
+    int done = 0;
+    while (done < n) {
+        // ---- how many of the remaining chains go behind the next gate kernel, and with which task size ----
+        uint32_t rows = kQRowsPerWave;
+        int take = 0;
+        {
+            std::unique_lock<std::mutex> lock(q->mu);
+            advance_done(q);
+            prune_closed(q);
+            // what can overlap with these batches: a strictly ordered stream has ONE gate open at a time however far its host has run
+            // ahead, so "batches in flight" says nothing (a lone strict stream first got the sustained stream's 128-row tasks: 44 us
+            // per batch); it is the open batches of OTHER strict streams and the rest of this group.  Deferred waits: the caller's
+            // trailing distance, which this call cannot see -- 16-row tasks.
+            uint64_t parallel = (uint64_t)(n - done - 1);
+            bool overlap = parallel > 0;
+            if (defer) {
+                overlap = overlap || q->next_seq > q->done_inorder;
+                parallel += q->next_seq - q->done_inorder > 7 ? 7 : q->next_seq - q->done_inorder;
+            } else {
+                for (const auto& st : q->stream_tail)
+                    if (st.stream != key && st.ticket >= q->done_inorder && hflag(q, st.ticket % q->R) < st.ticket + 1) { ++parallel; overlap = true; }
+            }
+            if (hybrid && !overlap) { ++q->n_direct; return 2; } // a lone batch: ~11 us on the server, ~7 us as one launch
+            rows = parallel >= 8 ? (uint32_t)kQRowsPerTaskMid : (parallel >= 1 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            for (;;) {
+                uint64_t room = budget > q->closed_tasks ? budget - q->closed_tasks : 0;
+                take = 0;
+                uint64_t sum = 0;
+                while (done + take < n && take < 64) {
+                    const uint32_t tt = gated_tasks(*chains[done + take], rows);
+                    if (sum + tt > room) break;
+                    sum += tt;
+                    ++take;
+                }
+                if (take > 0) break;
+                if (q->closed_tasks == 0) { // nothing is closed and ONE batch still exceeds the budget at this task size: larger tasks, else alone
+                    if (rows < (uint32_t)kQRowsPerTaskDeep) { rows *= 2; continue; }
+                    take = 1;
+                    break;
+                }
+                if (hybrid) { ++q->n_budget_direct; if (n_queued) *n_queued = done; return 2; }
+                // wait for a gate to open (the mutex is released: other threads' submits and the gate kernels go on)
+                if (spins == 0) ++q->n_budget_waits;
+                lock.unlock();
+                cpu_pause();
+                if ((++spins & 0x3fff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                    err = "queue: no gate of the closed stream-ordered batches opened for 2 s";
+                    if (n_queued) *n_queued = done;
+                    return -2;
+                }
+                lock.lock();
+                if (hv(q->hc->error)) { err = "queue: the server reported a stall / protocol error"; if (n_queued) *n_queued = done; return -2; }
+                prune_closed(q);
+            }
+        }
+        // ---- publish them closed, then ONE gate kernel on the caller's stream -- under one lock: ring order == gate-kernel order ----
+        std::lock_guard<std::mutex> gate_lock(q->gate_mu);
+        QGateTickets tk;
+        tk.n = 0;
+        int rc = 0;
+        for (int i = 0; i < take; ++i) {
+            uint64_t t = 0;
+            GateInfo g{key, defer, rows, 0};
+            rc = queue_submit_slot(q, *chains[done + i], planes[done + i], n_planes[done + i], &t, err, &g);
+            if (rc) break; // (what has been published still gets its gate opened below)
+            tk.t[tk.n++] = t;
+            if (tickets) tickets[done + i] = t;
+        }
+        if (tk.n > 0) {
+            hipLaunchKernelGGL(k1q_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, q->m.gates, q->hgates, (const uint64_t*)q->m.dflags, q->R, tk, defer ? 0u : 1u,
+                               (const uint64_t*)&q->hc->error.v, q->gate_ticks, q->gate_trace);
+            if (hipGetLastError() != hipSuccess) { // never leave workers at a gate nobody will open
+                for (uint32_t i = 0; i < tk.n; ++i) {
+                    uint64_t* gate = q->m.gates + kQCtrStride * (tk.t[i] % q->R);
+                    if (q->direct) *(volatile uint64_t*)gate = tk.t[i] + 1;
+                    else hipLaunchKernelGGL(k1q_gate_open, dim3(1), dim3(64), 0, q->stage_stream, gate, tk.t[i] + 1);
+                    *(volatile uint64_t*)(q->hgates + tk.t[i] % q->R) = tk.t[i] + 1;
+                }
+                if (q->direct) wc_fence();
+                err = "queue: the gate kernel could not be launched on the caller's stream";
+                if (n_queued) *n_queued = done;
+                return -1;
+            }
+            std::lock_guard<std::mutex> lock(q->mu);
+            q->n_gated += tk.n;
+            if (!defer) {
+                bool found = false;
+                for (auto& st : q->stream_tail)
+                    if (st.stream == key) { st.ticket = tk.t[tk.n - 1]; found = true; break; }
+                if (!found) {
+                    if (q->stream_tail.size() >= 256) q->stream_tail.erase(q->stream_tail.begin());
+                    q->stream_tail.push_back({key, tk.t[tk.n - 1]});
+                }
+            }
+        }
+        done += (int)tk.n;
+        if (n_queued) *n_queued = done;
+        if (rc) return rc;
     }
     return 0;
 }
+
+// After the watchdog has fired (error word set: another kernel held the chip beyond the stall limit, a gate that never opened, ...) the
+// queue used to be dead for good: every later submit failed, nothing reset the error.  Recovery: wait for the failed
+// server to leave, declare the batches that were in flight LOST (waits on their tickets report it; stream waiters are released),
+// renumber from a clean task base -- every counter of the protocol back to its initial state -- and clear the error.  The next
+// submit launches a fresh server.
+int queue_recover(Queue* q, uint64_t* lost, std::string& err) {
+    std::lock_guard<std::mutex> lock(q->mu);
+    if (lost) *lost = 0;
+    if (!hv(q->hc->error)) return 0;
+    (void)hipStreamSynchronize(q->stage_stream);
+    if (hipStreamSynchronize(q->stream) != hipSuccess) { err = "queue: the failed server did not leave"; return -1; }
+    advance_done(q);
+    uint64_t n_lost = 0;
+    for (uint64_t b = q->done_inorder; b < q->next_seq; ++b)
+        if (hflag(q, b % q->R) < b + 1) { // (a batch the late workgroups still finished is complete, not lost)
+            ++n_lost;
+            if (q->lost_tickets.size() >= 4096) q->lost_tickets.erase(q->lost_tickets.begin());
+            q->lost_tickets.push_back(b);
+        }
+    q->failed_upto = q->next_seq;
+    const size_t R = q->R, NW = (size_t)q->G * kQWaves;
+    const uint64_t base = (q->next_task + (kQSubs - 1)) & ~(uint64_t)(kQSubs - 1);
+    q->next_task = base;
+    std::vector<uint64_t> p0(NW), tk((size_t)kQSubs * kQCtrStride, 0), fl(R * kQCtrStride, 0);
+    for (size_t i = 0; i < NW; ++i) p0[i] = base + i;
+    for (int c = 0; c < kQSubs; ++c) tk[(size_t)c * kQCtrStride] = base / kQSubs;
+    // completion words: every batch ever submitted reads as complete (the lost ones are reported through their tickets)
+    for (uint64_t b = q->next_seq >= R ? q->next_seq - R : 0; b < q->next_seq; ++b) {
+        fl[(b % R) * kQCtrStride] = b + 1;
+        *(volatile uint64_t*)(q->hflags + (b % R)) = b + 1;
+    }
+    const size_t ctr_bytes = R * (1 + kQSubs) * kQCtrStride * 8;
+    hipError_t e;
+    if ((e = hipMemset(q->m.arrive, 0, ctr_bytes)) != hipSuccess || (e = hipMemcpy(q->m.prog, p0.data(), NW * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(q->m.ticket, tk.data(), tk.size() * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(q->m.dflags, fl.data(), fl.size() * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(q->m.gates, fl.data(), fl.size() * 8, hipMemcpyHostToDevice)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+        err = std::string("queue recovery: ") + hipGetErrorString(e);
+        return -1;
+    }
+    std::fill(q->arrive_cum.begin(), q->arrive_cum.end(), 0);
+    q->done_inorder = q->next_seq;
+    raise_done_hint(q, q->next_seq);
+    q->stream_tail.clear();
+    q->closed.clear();
+    q->closed_tasks = 0;
+    hv(q->hc->yield_req) = 0;
+    hv(q->hc->error) = 0;
+    hv(q->hc->state) = QS_IDLE;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    if (lost) *lost = n_lost;
+    return 0;
+}
+
+const uint64_t* queue_gate_trace(Queue* q) { return q->gate_trace; }
 
 void queue_prof(Queue* q, uint64_t* out16) {
     for (int i = 0; i < 16; ++i) out16[i] = *(volatile uint64_t*)&q->hc->prof[i];
     out16[6] = q->n_ring_waits;
     out16[7] = q->n_ring_waits ? q->sum_done_behind_head / q->n_ring_waits : 0;
     out16[13] = q->n_sub ? q->ns_ring_wait / q->n_sub : 0; // host side of submit, ns per call (since create)
-    out16[14] = out16[15] = 0;
+    out16[14] = q->n_gated | (q->n_direct << 32); // stream-ordered submits: taken by the server | launched directly by the latency policy
+    out16[15] = 0;
+    out16[2] = q->n_budget_direct;                  // ... launched directly because the closed-batch budget was exhausted
+    out16[3] = q->n_budget_waits;                   // ... that waited for a gate to open
 }
 
 void queue_stats(Queue* q, uint64_t* out8) {
@@ -1544,6 +1974,12 @@ void* queue_stream(Queue* q) { return (void*)q->stream; }
 
 int queue_destroy(Queue* q) {
     if (!q) return 0;
+    // the batches in flight complete first (the janitor retires the grid as soon as it sees the stop word, whatever is in the ring);
+    // bounded: a stalled server or a gate that never opens must not hang the caller
+    if (q->next_seq > q->failed_upto && !hv(q->hc->error)) {
+        std::string ignored;
+        (void)queue_wait(q, q->next_seq - 1, 2.0, ignored);
+    }
     {
         std::lock_guard<std::mutex> lock(q->mu);
         hv(q->hc->stop_req) = 1;
@@ -1561,6 +1997,8 @@ int queue_destroy(Queue* q) {
     (void)hipFree(q->dev_counters);
     (void)hipHostFree((void*)q->hc);
     (void)hipHostFree((void*)q->hflags);
+    (void)hipHostFree((void*)q->hgates);
+    if (q->gate_trace) (void)hipHostFree(q->gate_trace);
     if (q->host_ring) (void)hipHostFree(q->host_ring);
     if (q->host_index) (void)hipHostFree((void*)q->host_index);
     delete q;

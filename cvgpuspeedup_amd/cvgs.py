@@ -612,6 +612,31 @@ class Queue:
         capi.check(self.lib.cvgs_queue_submit(self.handle, C.byref(lowered.desc), C.byref(t)))
         return t.value
 
+    DEFER_WAIT, HYBRID, TICKET_DIRECT = 1, 2, (1 << 64) - 1
+
+    def submit_on(self, stream, *iops, flags=0, submit_flags=0):
+        """cvgs_queue_submit_on: executeOperations(stream, iops...) on the queue -- ordered behind everything already enqueued on
+        `stream`, and (unless DEFER_WAIT) in front of everything enqueued on it afterwards; no host synchronisation.  Returns the
+        ticket (TICKET_DIRECT when the HYBRID policy launched the chain directly on the stream)."""
+        return self.submit_lowered_on(stream, lower(iops, flags), submit_flags)
+
+    def submit_lowered_on(self, stream, lowered, submit_flags=0):
+        t = C.c_uint64()
+        capi.check(self.lib.cvgs_queue_submit_on(self.handle, C.byref(lowered.desc), stream_handle(stream), submit_flags, C.byref(t)))
+        return t.value
+
+    def submit_many_on(self, stream, ptr_array, n, submit_flags=0):
+        """cvgs_queue_submit_many_on: n pre-lowered chains (chain_pointers) behind ONE gate on `stream`; returns the last ticket"""
+        t = C.c_uint64()
+        capi.check(self.lib.cvgs_queue_submit_many_on(self.handle, ptr_array, n, stream_handle(stream), submit_flags, C.byref(t)))
+        return t.value
+
+    def recover(self):
+        """cvgs_queue_recover: after the watchdog has fired; returns the number of batches that were lost"""
+        n = C.c_uint64()
+        capi.check(self.lib.cvgs_queue_recover(self.handle, C.byref(n)))
+        return n.value
+
     def submit_many(self, ptr_array, n):
         """ptr_array: (POINTER(ChainDesc) * n) of pre-lowered chains (see chain_pointers); returns the last ticket"""
         t = C.c_uint64()

@@ -262,6 +262,20 @@ inline fk::WarpingParameters<WT> warp_parameters(const cv::Mat& transform_matrix
     }
     return p;
 }
+// the reference's public spellings (include/cvGPUSpeedup.cuh:269-284): the 6 / 9 doubles of an ALREADY INVERTED transform, row-major,
+// narrowed to float, plus the target size
+inline fk::WarpingParameters<fk::WarpType::Affine> warp_getWarpingAffineParameters(const double* const tm_raw, const cv::Size& dstSize) {
+    fk::WarpingParameters<fk::WarpType::Affine> p;
+    for (int i = 0; i < 6; ++i) p.transformMatrix[i / 3][i % 3] = static_cast<float>(tm_raw[i]);
+    p.dstSize = fk::Size(dstSize.width, dstSize.height);
+    return p;
+}
+inline fk::WarpingParameters<fk::WarpType::Perspective> warp_getWarpingPerspectiveParameters(const double* const tm_raw, const cv::Size& dstSize) {
+    fk::WarpingParameters<fk::WarpType::Perspective> p;
+    for (int i = 0; i < 9; ++i) p.transformMatrix[i / 3][i % 3] = static_cast<float>(tm_raw[i]);
+    p.dstSize = fk::Size(dstSize.width, dstSize.height);
+    return p;
+}
 } // namespace internal
 
 template <fk::WarpType WT, int InputType = CV_8UC3>
@@ -476,9 +490,20 @@ public:
     template <typename... IOps> uint64_t submit(const IOps&... iops) { return q_.submit(iops...); }
     void wait(uint64_t ticket, double timeout_s = 10.0) { q_.wait(ticket, timeout_s); }
     void wait(uint64_t ticket, const cv::cuda::Stream& consumer) { q_.wait(ticket, cv::cuda::StreamAccessor::getStream(consumer)); }
+    uint64_t recover() { return q_.recover(); }
+    fk::Queue& fk() { return q_; }
 private:
     fk::Queue q_;
 };
+// The reference's own call shape on the queue: after attachQueue(stream, queue) every cvGS::executeOperations(stream, iops...) whose
+// chain the server takes is submitted stream-ordered (behind the stream's earlier work, in front of its later work; no host
+// synchronisation -- include/cvGPUSpeedup.cuh:464-473's contract), everything else is the ordinary launch.  deferWait: the stream is not
+// held on each batch; cvGS::fence(stream) orders the consumer (several batches of one stream then overlap on the device).
+inline void attachQueue(const cv::cuda::Stream& stream, Queue& queue, bool deferWait = false) {
+    queue.fk().attach(cv::cuda::StreamAccessor::getStream(stream), deferWait);
+}
+inline void detachQueue(const cv::cuda::Stream& stream) { fk::Queue::detach(cv::cuda::StreamAccessor::getStream(stream)); }
+inline void fence(const cv::cuda::Stream& stream) { fk::Queue::fence(cv::cuda::StreamAccessor::getStream(stream)); }
 // cvGS::executeOperations(queue, iops...): the stream form's IOps, a ticket instead of a stream position
 template <typename... IOpTypes>
 inline uint64_t executeOperations(Queue& queue, const IOpTypes&... iops) {

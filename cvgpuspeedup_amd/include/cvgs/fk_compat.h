@@ -8,6 +8,8 @@
 #pragma once
 
 #include <array>
+#include <atomic>
+#include <mutex>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -727,6 +729,49 @@ template <typename... IOps> inline void lowerChain(ChainBuilder& b, const IOps&.
 }
 
 // fk::executeOperations<TF>(stream, iops...): ONE kernel, asynchronous on `stream`.
+// ---- streams attached to a descriptor queue (engine extension) ----------------------------------------------------
+// The reference's call shape is executeOperations(stream, iops...), asynchronous on that stream (include/cvGPUSpeedup.cuh:464-473).
+// A stream attached to a fk::Queue (cvGS::attachQueue) keeps exactly that contract and routes the chains the server takes through
+// cvgs_queue_submit_on: ordered behind the stream's earlier work and in front of its later work, no host synchronisation; anything
+// else -- and a batch nothing in flight could overlap with (CVGS_QUEUE_SUBMIT_HYBRID) -- is the ordinary launch on the stream.
+namespace detail {
+struct StreamAttachment {
+    hipStream_t stream;
+    cvgs_queue_t queue;
+    uint32_t flags;       // CVGS_QUEUE_SUBMIT_* (HYBRID always set)
+    uint64_t last_ticket; // DEFER_WAIT streams: what fence() orders the stream behind
+    bool has_ticket;
+};
+struct StreamAttachments {
+    std::atomic<bool> any{false};
+    std::mutex mu;
+    std::vector<StreamAttachment> list;
+};
+inline StreamAttachments& stream_attachments() {
+    static StreamAttachments a;
+    return a;
+}
+inline bool submit_attached(hipStream_t stream, const cvgs_chain_desc* d) {
+    StreamAttachments& A = stream_attachments();
+    cvgs_queue_t q = nullptr;
+    uint32_t flags = 0;
+    {
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (const auto& a : A.list)
+            if (a.stream == stream) { q = a.queue; flags = a.flags; break; }
+    }
+    if (!q) return false;
+    uint64_t ticket = 0;
+    check_status(cvgs_queue_submit_on(q, d, stream, flags, &ticket));
+    if ((flags & CVGS_QUEUE_SUBMIT_DEFER_WAIT) && ticket != CVGS_QUEUE_TICKET_DIRECT) {
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (auto& a : A.list)
+            if (a.stream == stream) { a.last_ticket = ticket; a.has_ticket = true; break; }
+    }
+    return true;
+}
+} // namespace detail
+
 template <bool THREAD_FUSION = true, typename... IOps>
 inline void executeOperations(hipStream_t stream, const IOps&... iops) {
     ChainBuilder b;
@@ -738,6 +783,7 @@ inline void executeOperations(hipStream_t stream, const IOps&... iops) {
 #ifdef CVGS_HONOUR_THREAD_FUSION_HINT
     if (!THREAD_FUSION) b.d.flags |= CVGS_CHAIN_NO_THREAD_FUSION;
 #endif
+    if (detail::stream_attachments().any.load(std::memory_order_acquire) && detail::submit_attached(stream, &b.d)) return;
     detail::check_status(cvgs_execute(&b.d, stream));
 }
 
@@ -762,6 +808,32 @@ public:
         if (builders_.empty()) return;
         descs_.resize(builders_.size());
         for (size_t i = 0; i < builders_.size(); ++i) descs_[i] = builders_[i]->d; // POD copy; the builders keep the arrays alive
+        // a stream attached to a queue: the tick's chains go behind ONE gate on the stream (cvgs_queue_submit_many_on), 64 at a time
+        if (detail::stream_attachments().any.load(std::memory_order_acquire)) {
+            cvgs_queue_t q = nullptr;
+            uint32_t flags = 0;
+            detail::StreamAttachments& A = detail::stream_attachments();
+            {
+                std::lock_guard<std::mutex> lock(A.mu);
+                for (const auto& a : A.list)
+                    if (a.stream == stream) { q = a.queue; flags = a.flags; break; }
+            }
+            if (q) {
+                std::vector<const cvgs_chain_desc*> ptrs(descs_.size());
+                for (size_t i = 0; i < descs_.size(); ++i) ptrs[i] = &descs_[i];
+                uint64_t last = CVGS_QUEUE_TICKET_DIRECT;
+                for (size_t base = 0; base < ptrs.size(); base += CVGS_QUEUE_MAX_GROUP) {
+                    const size_t cnt = ptrs.size() - base < (size_t)CVGS_QUEUE_MAX_GROUP ? ptrs.size() - base : (size_t)CVGS_QUEUE_MAX_GROUP;
+                    detail::check_status(cvgs_queue_submit_many_on(q, ptrs.data() + base, (int32_t)cnt, stream, flags, &last));
+                }
+                if ((flags & CVGS_QUEUE_SUBMIT_DEFER_WAIT) && last != CVGS_QUEUE_TICKET_DIRECT) {
+                    std::lock_guard<std::mutex> lock(A.mu);
+                    for (auto& a : A.list)
+                        if (a.stream == stream) { a.last_ticket = last; a.has_ticket = true; break; }
+                }
+                return;
+            }
+        }
         detail::check_status(cvgs_execute_many(descs_.data(), (int32_t)descs_.size(), stream));
     }
 private:
@@ -787,7 +859,17 @@ public:
     explicit Queue(int device = 0, int depth = 0, double idle_us = 0.0) { detail::check_status(cvgs_queue_create(&q_, device, depth, idle_us, 0u)); }
     Queue(const Queue&) = delete;
     Queue& operator=(const Queue&) = delete;
-    ~Queue() { if (q_) (void)cvgs_queue_destroy(q_); }
+    ~Queue() {
+        if (!q_) return;
+        {
+            detail::StreamAttachments& A = detail::stream_attachments();
+            std::lock_guard<std::mutex> lock(A.mu);
+            for (size_t i = A.list.size(); i-- > 0;)
+                if (A.list[i].queue == q_) A.list.erase(A.list.begin() + (long)i);
+            A.any.store(!A.list.empty(), std::memory_order_release);
+        }
+        (void)cvgs_queue_destroy(q_);
+    }
     template <typename... IOps> uint64_t submit(const IOps&... iops) {
         ChainBuilder b;
         lowerChain(b, iops...);
@@ -795,8 +877,51 @@ public:
         detail::check_status(cvgs_queue_submit(q_, &b.d, &ticket));
         return ticket;
     }
+    // the stream-ordered form (cvgs_queue_submit_on): behind everything already on `stream`, in front of everything after it
+    template <typename... IOps> uint64_t submitOn(hipStream_t stream, uint32_t flags, const IOps&... iops) {
+        ChainBuilder b;
+        lowerChain(b, iops...);
+        uint64_t ticket = 0;
+        detail::check_status(cvgs_queue_submit_on(q_, &b.d, stream, flags, &ticket));
+        return ticket;
+    }
     void wait(uint64_t ticket, double timeout_s = 10.0) { detail::check_status(cvgs_queue_wait(q_, ticket, timeout_s)); }
     void wait(uint64_t ticket, hipStream_t consumer) { detail::check_status(cvgs_queue_stream_wait(q_, ticket, consumer)); }
+    // after a wait / submit has thrown because the server's watchdog fired: reset the queue; returns the number of lost batches
+    uint64_t recover() {
+        uint64_t lost = 0;
+        detail::check_status(cvgs_queue_recover(q_, &lost));
+        return lost;
+    }
+    // executeOperations(stream, ...) on `stream` goes through this queue from now on (deferWait: the caller orders consumers with fence())
+    void attach(hipStream_t stream, bool deferWait = false) {
+        detail::StreamAttachments& A = detail::stream_attachments();
+        std::lock_guard<std::mutex> lock(A.mu);
+        const uint32_t f = CVGS_QUEUE_SUBMIT_HYBRID | (deferWait ? CVGS_QUEUE_SUBMIT_DEFER_WAIT : 0u);
+        for (auto& a : A.list)
+            if (a.stream == stream) { a = detail::StreamAttachment{stream, q_, f, 0, false}; return; }
+        A.list.push_back(detail::StreamAttachment{stream, q_, f, 0, false});
+        A.any.store(true, std::memory_order_release);
+    }
+    static void detach(hipStream_t stream) {
+        detail::StreamAttachments& A = detail::stream_attachments();
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (size_t i = 0; i < A.list.size(); ++i)
+            if (A.list[i].stream == stream) { A.list.erase(A.list.begin() + (long)i); break; }
+        A.any.store(!A.list.empty(), std::memory_order_release);
+    }
+    // deferWait streams: order everything enqueued on `stream` from here on behind the batches it has submitted so far
+    static void fence(hipStream_t stream) {
+        detail::StreamAttachments& A = detail::stream_attachments();
+        cvgs_queue_t q = nullptr;
+        uint64_t t = 0;
+        {
+            std::lock_guard<std::mutex> lock(A.mu);
+            for (auto& a : A.list)
+                if (a.stream == stream && a.has_ticket) { q = a.queue; t = a.last_ticket; a.has_ticket = false; break; }
+        }
+        if (q) detail::check_status(cvgs_queue_stream_wait(q, t, stream));
+    }
     cvgs_queue_t handle() const { return q_; }
 private:
     cvgs_queue_t q_ = nullptr;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CVGS_ABI_VERSION 4
+#define CVGS_ABI_VERSION 5
 #define CVGS_MAX_OPS 12        /* pointwise stages between the read and the write            */
 #define CVGS_MAX_CHANNELS 4
 #define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
@@ -175,9 +175,11 @@ typedef enum cvgs_opcode {
     /* fk::Binary<fk::Mul/Add/Sub/Div<T>> (cvGS::multiply/add/subtract/divide,
      * cvGPUSpeedup.cuh:131-149); operand[c] = static_cast<float>(cv::Scalar[c])
      * (cvGPUSpeedupHelpers.cuh:38-54), operand_d[c] = the cv::Scalar value itself for CV_64F
-     * types.  IEEE fp32 (fp64 on CV_64F values), applied in call order, never merged.  On integer-typed values:
-     * CVGS_ERR_UNSUPPORTED here, a static_assert in the C++ facade (cvGS::multiply<CV_8UC3> does not compile; the
-     * reference instantiates fk::Mul<uchar3>, whose semantics live in the un-vendored FKL and no reference test uses).   */
+     * types.  IEEE fp32 (fp64 on CV_64F values), applied in call order, never merged.  On integer-typed values (since ABI 4;
+     * an ENGINE EXTENSION: the reference instantiates fk::Mul<uchar3> etc., whose semantics live in the un-vendored FKL and no
+     * reference test uses): the scalar truncated and saturated to the pixel's own type, 64-bit integer arithmetic, division
+     * truncating toward zero with x / 0 = 0, the result saturated back to the type; interpreted kernels only.  CV_16F values:
+     * CVGS_ERR_UNSUPPORTED.                                                                                              */
     CVGS_OP_MUL = 2,
     CVGS_OP_ADD = 3,
     CVGS_OP_SUB = 4,
@@ -339,8 +341,9 @@ int cvgs_circular_create(cvgs_circular_t* out, int32_t width, int32_t height, in
 #define CVGS_CIRCULAR_MIRRORED 1u
 /* CVGS_CIRCULAR_CAPTURABLE: cvgs_circular_update may be captured into a HIP graph (the reference's update is an ordinary stream
  * launch, include/cvGPUSpeedup.cuh:612-622; a serving loop that replays graphs needs it inside them).  The update count then
- * lives in device memory and every update -- captured or not -- goes through a staging image and a device-indexed shift
- * (one extra pass over ONE image); N captured updates replay as the NEXT N updates.  cvgs_circular_updates() and, for mirrored
+ * lives in device memory; per-pixel pushes (the form the reference tests) stay ONE fused launch that derives its ring slot from
+ * that count, pushes with a resize / NV12 / warp read go through a staging image and a device-indexed shift (one extra pass over
+ * ONE image); N captured updates replay as the NEXT N updates.  cvgs_circular_updates() and, for mirrored
  * handles, cvgs_circular_data() read the device-side count and therefore synchronise the device.                        */
 #define CVGS_CIRCULAR_CAPTURABLE 2u
 int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height, int32_t elem_type,
@@ -352,7 +355,8 @@ int cvgs_circular_create_ex(cvgs_circular_t* out, int32_t width, int32_t height,
  * its slot of the ordered tensor and into the history ring, and the BATCH-1 older frames move from the ring to their
  * new slots.  Per-pixel u8 pushes (the form the reference tests) do all of it in ONE kernel launch; pushes with a
  * resize / NV12 / warp read use the chain's own kernel plus one plane-copy kernel (mirrored handles: no copy at all).
- * Cannot be captured into a HIP graph (the ring index is host state): CVGS_ERR_UNSUPPORTED.                       */
+ * A default handle cannot be captured into a HIP graph (its ring index is host state): CVGS_ERR_UNSUPPORTED on a capturing
+ * stream; handles created with CVGS_CIRCULAR_CAPTURABLE can (above).                                                */
 int cvgs_circular_update(cvgs_circular_t ct, const cvgs_chain_desc* chain, cvgs_stream_t stream);
 /* data() (:624-626): device pointer of the ordered output tensor; stable for the handle's life
  * (mirrored handles: the window of the LAST update -- it moves).                                 */
@@ -368,7 +372,7 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  * waves of ONE launch load, then store, all at the same time.  A queue keeps the call shape -- one submit per
  * frame, same chain descriptor -- and removes the boundary: a resident server grid takes batches from a ring; its
  * workgroups walk from batch to batch without a grid-wide barrier, so batch k+1's loads overlap batch k's stores.
- *   cvgs_queue_create   one queue per device; `depth` ring slots (0 = 64, at most 256); `idle_us`: the server retires
+ *   cvgs_queue_create   one queue per device; `depth` ring slots (0 = 128, at most 256); `idle_us`: the server retires
  *                       itself after this long without work (0 = 200 us) and the next submit starts a new one, so the grid
  *                       never outlives its work; a batch without progress for 250 ms (environment: CVGS_QUEUE_STALL_MS) is reported
  *                       as CVGS_ERR_HIP, not waited for -- every workgroup of the server must be resident, so other kernels of the
@@ -389,13 +393,47 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  * Tuning hooks (environment): CVGS_QUEUE_G = worker workgroups (default 3 per CU - 1; the flags' bits 16..27 say the same per queue),
  * CVGS_QUEUE_DEEP_ROWS = rows per task of a deep queue (default 64 / 128 by depth), CVGS_QUEUE_STALL_MS, CVGS_QUEUE_STAGED=1, CVGS_QUEUE_DEBUG=1.
  * Submits from several host threads are serialised by a mutex (tickets are handed out in submit order).  cvgs_queue_destroy
- * completes the batches in flight first (the workers drain the ring before they see the stop word), then retires the server.
+ * waits (at most 2 s) for the batches in flight, then retires the server.  Whether the host writes the ring straight into device
+ * memory is decided without a fault (large-BAR attribute + /proc/self/maps + a read-back; CVGS_QUEUE_DIRECT=0 / 1 overrides).
  * No reference counterpart.                                                                                           */
 typedef struct cvgs_queue_s* cvgs_queue_t;
 int cvgs_queue_create(cvgs_queue_t* out, int32_t device, int32_t depth, double idle_us, uint32_t flags);
 int cvgs_queue_submit(cvgs_queue_t q, const cvgs_chain_desc* chain, uint64_t* ticket);
 /* n submits in one call (a serving loop's burst); *last_ticket = the ticket of chains[n-1] */
 int cvgs_queue_submit_many(cvgs_queue_t q, const cvgs_chain_desc* const* chains, int32_t n, uint64_t* last_ticket);
+/* Stream-ordered submit (ABI 5) -- the reference's contract on the queue: cvGS::executeOperations(stream, iops...) is "asynchronous on
+ * the given stream" (include/cvGPUSpeedup.cuh:464-473; cv::cuda::StreamAccessor::getStream at :466).  The batch is ordered BEHIND
+ * everything already enqueued on `stream` (the decoder / kernel that writes the frame need not be synchronised with the host) and,
+ * unless CVGS_QUEUE_SUBMIT_DEFER_WAIT, everything enqueued on `stream` AFTER the call is ordered behind the batch's tensor.  Cost: ONE
+ * one-wave kernel on `stream` per call (it opens the batch's gate in the ring when the stream gets there, then holds the stream on the
+ * batch's completion word); no host synchronisation, no event, no second stream operation.  Workers that draw a task of a batch whose
+ * gate is still closed wait there; other batches proceed.  A gate that stays closed for 10 s (CVGS_QUEUE_GATE_TIMEOUT_MS) is reported
+ * as an error (word 3), not waited for.
+ *   CVGS_QUEUE_SUBMIT_DEFER_WAIT  the stream is NOT held: the caller orders the consumer itself with cvgs_queue_stream_wait(q, ticket,
+ *                                 stream) -- several batches of ONE stream can then be in flight at once (a strictly ordered stream has
+ *                                 one, because the next gate sits behind the previous wait).
+ *   CVGS_QUEUE_SUBMIT_HYBRID      latency policy: a batch that nothing in flight could overlap with (an immediate-wait stream whose
+ *                                 queue holds no other stream's open batch; with DEFER_WAIT: an empty queue), and any chain the server
+ *                                 does not take, is launched DIRECTLY on `stream` as cvgs_execute would (*ticket =
+ *                                 CVGS_QUEUE_TICKET_DIRECT): a lone batch costs ~14 us on the server against ~7 us for one launch.
+ * Not capturable (the ring is written at submit time): CVGS_ERR_UNSUPPORTED on a capturing stream (with HYBRID: the direct launch is
+ * captured instead).  At most 74 planes per call.                                                                          */
+#define CVGS_QUEUE_SUBMIT_DEFER_WAIT 1u
+#define CVGS_QUEUE_SUBMIT_HYBRID 2u
+#define CVGS_QUEUE_TICKET_DIRECT (~(uint64_t)0)
+int cvgs_queue_submit_on(cvgs_queue_t q, const cvgs_chain_desc* chain, cvgs_stream_t stream, uint32_t flags, uint64_t* ticket);
+/* n chains (<= CVGS_QUEUE_MAX_GROUP) behind ONE gate kernel: the pictures of one tick -- several cameras' frames written by the work in
+ * front of the call, several crop lists of one frame -- are ordered behind `stream` together, overlap on the server, and (unless
+ * DEFER_WAIT) the stream is held until ALL of them are complete: one launch per tick instead of one per chain.  The stream-ordered
+ * counterpart of cvgs_execute_many / cvgs_queue_submit_many.  A wait on *last_ticket covers the group.  With HYBRID, chains the
+ * server does not take are launched one by one on the stream (the latency policy applies to single submits only).          */
+#define CVGS_QUEUE_MAX_GROUP 64
+int cvgs_queue_submit_many_on(cvgs_queue_t q, const cvgs_chain_desc* const* chains, int32_t n, cvgs_stream_t stream, uint32_t flags, uint64_t* last_ticket);
+/* After a wait / submit has reported CVGS_ERR_HIP because the server's watchdog fired (another kernel held the chip beyond
+ * CVGS_QUEUE_STALL_MS, a gate never opened): waits for the failed server to leave, declares the batches that were in flight lost
+ * (*lost = how many; waits on their tickets return CVGS_ERR_HIP, streams waiting for them are released, their tensors may be
+ * incomplete), resets the protocol state and clears the error -- the next submit starts a fresh server.  A no-op on a healthy queue. */
+int cvgs_queue_recover(cvgs_queue_t q, uint64_t* lost);
 int cvgs_queue_wait(cvgs_queue_t q, uint64_t ticket, double timeout_s);
 int cvgs_queue_stream_wait(cvgs_queue_t q, uint64_t ticket, cvgs_stream_t stream);
 /* out[8]: submitted, completed, server launches, feeder rounds and lifetime (100 MHz ticks) of the last retired server,
@@ -441,6 +479,12 @@ int cvgs_exchange_step(void* const* peer_flag_words, const void* const* own_flag
  * roofline fractions to be quoted against (bench.py), and a utility for callers that re-pack tensors.  The two
  * ranges must not overlap.                                                                                      */
 int cvgs_stream_copy(void* dst, const void* src, size_t bytes, cvgs_stream_t stream);
+
+/* ---- test / measurement aid (ABI 5) --------------------------------------------------------------
+ * `blocks` workgroups of `threads` threads that hold their wave slots and `lds_bytes` of LDS each for `microseconds`, asynchronous on
+ * `stream`: a stand-in for a foreign kernel that occupies part of the chip (the queue's residency / watchdog tests, bench.py's
+ * coexistence leg).  No reference counterpart.                                                                         */
+int cvgs_debug_occupy(int32_t blocks, int32_t threads, int32_t lds_bytes, double microseconds, cvgs_stream_t stream);
 
 /* ---- profiling ranges (reference tests/nvtx.h PUSH_RANGE/POP_RANGE) -------------------------- */
 void cvgs_range_push(const char* name);

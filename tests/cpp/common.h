@@ -24,6 +24,15 @@ inline int g_failures = 0;
         }                                                                           \
     } while (0)
 
+#define HIP_OK(call)                                                                \
+    do {                                                                            \
+        const hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                                     \
+            std::cout << "  FAILED: " #call " -> " << hipGetErrorString(e_) << " (" << __FILE__ << ":" << __LINE__ << ")" << std::endl; \
+            ++g_failures;                                                           \
+        }                                                                           \
+    } while (0)
+
 inline int report(const char* name) {
     std::cout << name << (g_failures ? " failed!!" : " passed!!") << std::endl;
     return g_failures ? 1 : 0;

@@ -7,6 +7,8 @@
 //      benchmarks/benchmark_CPUandGPU_cvGS_vs_fk.cu:191-192).
 #include "common.h"
 
+#include <memory>
+
 struct Params { cv::Scalar init, alpha, sub, div; };
 static const double kAlpha = 0.3;
 static const Params kParams[4] = {
@@ -228,6 +230,24 @@ static void test_chain_batch(cv::cuda::Stream& stream) {
         ok = bit_equal(a.data(), b.data(), n);
     }
     CHECK(ok, "ChainBatch of 4 x 50 crops == 4 executeOperations");
+    // the same batch on a stream attached to a queue: the four chains go behind ONE gate on the stream (cvgs_queue_submit_many_on),
+    // ordered behind the memsets in front of them -- same bits
+    cvGS::Queue queue;
+    cvGS::attachQueue(stream, queue);
+    for (int c = 0; c < CAMS; ++c)
+        HIP_OK(hipMemsetAsync(outs_a[c].data, 0xff, n, cv::cuda::StreamAccessor::getStream(stream)));
+    batch.execute(stream);
+    std::vector<std::vector<uint8_t>> got((size_t)CAMS, std::vector<uint8_t>(n));
+    for (int c = 0; c < CAMS; ++c) // copies ON THE STREAM: ordered behind the batch by the gate kernel's wait
+        HIP_OK(hipMemcpyAsync(got[(size_t)c].data(), outs_a[c].data, n, hipMemcpyDeviceToHost, cv::cuda::StreamAccessor::getStream(stream)));
+    stream.waitForCompletion();
+    cvGS::detachQueue(stream);
+    ok = true;
+    for (int c = 0; c < CAMS && ok; ++c) {
+        const auto b = fetch(outs_b[c].data, n);
+        ok = bit_equal(got[(size_t)c].data(), b.data(), n);
+    }
+    CHECK(ok, "ChainBatch on a stream attached to a queue (one gate for the four chains) == 4 executeOperations");
 }
 
 template <int TI, int TO>
@@ -294,6 +314,87 @@ static void test_queue_vs_oracle(cv::cuda::Stream& stream) {
     CHECK(threw, "queue refuses a chain that is not the batched resize -> normalize -> split shape");
 }
 
+// engine extension (ABI 5): the reference's OWN call shape -- cvGS::executeOperations(stream, iops...), include/cvGPUSpeedup.cuh:464-473 --
+// on streams attached to a queue.  Per iteration and stream: a copy on the stream REWRITES the frame buffer, executeOperations follows
+// with no synchronisation, a copy on the stream reads the tensor back; two streams share the queue so that batches overlap on the server
+// (a lone batch takes the direct launch: the hybrid policy -- both paths must give the oracle's bits).
+template <int TI, int TO, int BATCH>
+static void test_attached_streams_vs_oracle() {
+    constexpr int CN = CV_MAT_CN(TO);
+    const Params& p = kParams[CN - 1];
+    const cv::Size up(64, 128);
+    const int STREAMS = 2, POOL = 4, ITERS = 120, RING = 4;
+    const size_t n = (size_t)BATCH * CN * up.width * up.height;
+    cvGS::Queue queue(0, 0, 5000.0);
+    struct Cam {
+        cv::cuda::Stream stream;
+        std::vector<cv::Mat> h_pool;
+        std::vector<cv::cuda::GpuMat> d_pool;
+        std::vector<cv::Mat> refs;
+        cv::cuda::GpuMat frame, tensor;
+        std::array<cv::Rect, BATCH> rects;
+        float* ring[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev[4];
+    };
+    std::vector<std::unique_ptr<Cam>> cams;
+    for (int c = 0; c < STREAMS; ++c) {
+        cams.emplace_back(new Cam);
+        Cam& cam = *cams.back();
+        cam.frame = cv::cuda::GpuMat(720, 1280, TI);
+        cam.tensor = cv::cuda::GpuMat(BATCH, up.width * up.height * CN, CV_32F);
+        for (int i = 0; i < BATCH; ++i) {
+            const int w = 8 + ((i + c) * 37) % 400, hgt = 16 + ((i + 2 * c) * 53) % 600;
+            cam.rects[i] = cv::Rect(((i + c) * 91) % (1280 - w), (i * 67) % (720 - hgt), w, hgt);
+        }
+        for (int k = 0; k < POOL; ++k) {
+            cam.h_pool.emplace_back(720, 1280, TI);
+            fill_random(cam.h_pool.back(), 0xC0FFEEull + 9000 + 10 * c + k);
+            cam.d_pool.emplace_back(cam.h_pool.back());
+            cv::cuda::GpuMat hv_frame = host_view(cam.h_pool.back());
+            std::array<cv::cuda::GpuMat, BATCH> h_crops;
+            for (int i = 0; i < BATCH; ++i) h_crops[i] = hv_frame(cam.rects[i]);
+            cam.refs.emplace_back(BATCH, up.width * up.height * CN, CV_32F);
+            cv::cuda::GpuMat hv_ref = host_view(cam.refs.back());
+            std::apply([&](const auto&... iops) { run_oracle(iops...); }, build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(h_crops, hv_ref, up, p));
+        }
+        for (int r = 0; r < RING; ++r) {
+            HIP_OK(hipHostMalloc((void**)&cam.ring[r], n * sizeof(float), hipHostMallocDefault));
+            HIP_OK(hipEventCreateWithFlags(&cam.ev[r], hipEventDisableTiming));
+        }
+        cvGS::attachQueue(cam.stream, queue);
+    }
+    HIP_OK(hipDeviceSynchronize());
+    int bad = 0;
+    auto check_slot = [&](Cam& cam, int it) {
+        HIP_OK(hipEventSynchronize(cam.ev[it % RING]));
+        if (!bit_equal(cam.ring[it % RING], cam.refs[(size_t)(it % POOL)].data, n * sizeof(float))) ++bad;
+    };
+    for (int it = 0; it < ITERS; ++it)
+        for (auto& cp : cams) {
+            Cam& cam = *cp;
+            hipStream_t s = cv::cuda::StreamAccessor::getStream(cam.stream);
+            if (it >= RING) check_slot(cam, it - RING); // (the host lags four iterations behind: nothing orders producer -> chain -> consumer but the stream)
+            HIP_OK(hipMemcpy2DAsync(cam.frame.data, cam.frame.step, cam.d_pool[(size_t)(it % POOL)].data, cam.d_pool[(size_t)(it % POOL)].step,
+                                    (size_t)cam.frame.cols * cam.frame.elemSize(), (size_t)cam.frame.rows, hipMemcpyDeviceToDevice, s));
+            std::array<cv::cuda::GpuMat, BATCH> crops;
+            for (int i = 0; i < BATCH; ++i) crops[i] = cam.frame(cam.rects[i]);
+            std::apply([&](const auto&... iops) { cvGS::executeOperations(cam.stream, iops...); },
+                       build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(crops, cam.tensor, up, p));
+            HIP_OK(hipMemcpyAsync(cam.ring[it % RING], cam.tensor.data, n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_OK(hipEventRecord(cam.ev[it % RING], s));
+        }
+    for (auto& cp : cams)
+        for (int it = ITERS - RING; it < ITERS; ++it) check_slot(*cp, it);
+    CHECK(bad == 0, "executeOperations(stream, ...) on streams attached to a queue: " << bad << " of " << STREAMS * ITERS << " tensors differ from the oracle, type " << TI);
+    for (auto& cp : cams) {
+        cvGS::detachQueue(cp->stream);
+        for (int r = 0; r < RING; ++r) {
+            (void)hipHostFree(cp->ring[r]);
+            (void)hipEventDestroy(cp->ev[r]);
+        }
+    }
+}
+
 int main() {
     cv::cuda::Stream stream;
     // the type list of the reference's LAUNCH_TESTS (test_batchresize_x_split3D.cu:427-432)
@@ -313,5 +414,7 @@ int main() {
     test_queue_vs_oracle<CV_16UC3, CV_32FC3, 50>(stream); // the 16-bit kind: a queue of its own (one kind per queue)
     test_queue_vs_oracle<CV_16SC4, CV_32FC4, 11>(stream);
     test_queue_vs_oracle<CV_8UC3, CV_32FC3, 100>(stream); // more crops than a ring slot holds (74): two slots behind one ticket
+    test_attached_streams_vs_oracle<CV_8UC3, CV_32FC3, 40>();
+    test_attached_streams_vs_oracle<CV_8UC4, CV_32FC4, 9>();
     return report("test_batchresize_x_split3D + aspectratio");
 }

@@ -77,6 +77,8 @@ def parse():
                         "duration then comes from its own 100 MHz clock (cvgs_queue_stats)")
     p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
+    p.add_argument("--no-regimes", action="store_true", help="skip the stream-ordered / latency / coexistence legs")
+    p.add_argument("--soak", type=float, default=0.0, help="coexistence: seconds of soak with the consumer running throughout (0 = none)")
     p.add_argument("--print-extra", action="store_true", help="also print the full record (bench_extra.json's content) on stderr")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank (testing)")
@@ -503,6 +505,19 @@ def main():
                                          "submission": "hipGraph replay, one cvgs_execute launch per step"}
     if not a.no_cpu and M == 1:
         result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+    if use_queue and not a.no_regimes:
+        # the queue beside its headline regime: stream-ordered submission with a producer on the stream (the reference's call shape),
+        # batch latency by queue depth, and coexistence with a consumer on the same GPU (tools/bench_queue_regimes.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            import bench_queue_regimes as QR
+            so = QR.stream_ordered(wl)
+            lt = QR.latency_by_depth(wl)
+            co = QR.coexistence(dev, wl, sys.modules[__name__], seconds=1.0, soak_seconds=a.soak)
+            result["stream_ordered_full"], result["queue_latency_by_depth_full"], result["coexistence_full"] = so, lt, co
+            result["stream_ordered"], result["queue_latency_by_depth"], result["coexistence"] = QR.stream_ordered_compact(so), QR.latency_compact(lt), QR.coexistence_compact(co)
+        except Exception as ex:  # never at the cost of the headline
+            result["regimes_error"] = repr(ex)[:300]
     if not a.no_extra:
         result["extra"] = extra_sweeps(dev, a)
     emit(result, a)
@@ -548,7 +563,7 @@ def compact_line(result):
     if "batch_latency_server_alive" in t or "single_launch_latency" in t:
         optional.append(("latency_us", {"queue_batch": t.get("batch_latency_server_alive", {}).get("median_us"),
                                         "one_launch": t.get("single_launch_latency", {}).get("median_us")}))
-    for k in ("stream_ordered", "coexistence", "n1_same_workload", "legs", "xgmi_probe", "queue_latency_by_depth"):
+    for k in ("stream_ordered", "coexistence", "n1_same_workload", "legs", "xgmi_probe", "queue_latency_by_depth", "regimes_error"):
         if k in result:
             optional.append((k, result[k]))
     if "queue" in result:

@@ -1312,6 +1312,10 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     // started, the server waited at that gate for the 10 s limit) -- nor with each other.
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (const char* pe = getenv("CVGS_QUEUE_SERVER_PRIO")) { // A/B hook (tools/probes): "low" swaps the two, "normal" = both at priority 0
+        if (pe[0] == 'l') { const int x = prio_least; prio_least = prio_greatest; prio_greatest = x; }
+        if (pe[0] == 'n') prio_least = prio_greatest = 0;
+    }
     if ((e = hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&q->stage_stream, hipStreamNonBlocking, prio_least)) != hipSuccess ||
         (e = hipExtMallocWithFlags((void**)&q->dev_block, total, hipDeviceMallocUncached)) != hipSuccess ||

@@ -797,7 +797,14 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             const cvgs_chain_desc& c = chains[i];
             if (c.read.batch < 1 || c.read.batch > 65535) fusable = false;
             const size_t esz = (size_t)depth_bytes(CVGS_TYPE_DEPTH(c.write.dst_type));
-            const size_t bytes = (size_t)c.read.batch * CVGS_TYPE_CN(c.write.dst_type) * (size_t)c.write.width * (size_t)c.write.height * esz;
+            const size_t plane = (size_t)c.write.width * (size_t)c.write.height, cn = (size_t)CVGS_TYPE_CN(c.write.dst_type);
+            // NCHW: batch images of cn planes.  CNHW (TensorTSplit): channel k of image z lives at (k * write.planes + z) * plane -- the
+            // chain's writes reach up to channel cn-1 of image batch-1, i.e. ((cn - 1) * planes + batch) planes (batch * cn
+            // planes understated it whenever the tensor holds more images than the chain writes)
+            const size_t n_planes_written = c.write.kind == CVGS_WRITE_TENSOR_T_SPLIT
+                                                ? (cn - 1) * (size_t)(c.write.planes > c.read.batch ? c.write.planes : c.read.batch) + (size_t)c.read.batch
+                                                : (size_t)c.read.batch * cn;
+            const size_t bytes = n_planes_written * plane * esz;
             outs[i] = Range{(const uint8_t*)c.write.data, (const uint8_t*)c.write.data + bytes};
             for (int j = 0; fusable && j < i; ++j)
                 if (outs[i].lo < outs[j].hi && outs[j].lo < outs[i].hi) fusable = false; // two chains write the same bytes
@@ -806,7 +813,15 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             const cvgs_image2d* src = (const cvgs_image2d*)chains[i].read.src;
             for (int k = 0; fusable && src && k < chains[i].read.batch && k < chains[i].read.used_planes; ++k) {
                 const uint8_t* lo = (const uint8_t*)src[k].data;
-                const uint8_t* hi = lo + (size_t)src[k].step * (size_t)(src[k].height > 0 ? src[k].height : 1);
+                size_t rows = (size_t)(src[k].height > 0 ? src[k].height : 1);
+                const uint8_t* hi = lo + (size_t)src[k].step * rows;
+                if (chains[i].read.kind == CVGS_READ_NV12_RESIZE_LINEAR) {
+                    // 4:2:0 surfaces: the chroma rows are read too -- behind the luma rows (whole surfaces: height * 3 / 2 rows) or,
+                    // for a crop view, uv_offset bytes from its first luma byte (+ half the crop's rows)
+                    const size_t chroma_rows = (rows + 1) / 2;
+                    const uint8_t* chi = src[k].uv_offset ? lo + (size_t)src[k].uv_offset + (size_t)src[k].step * chroma_rows : hi + (size_t)src[k].step * chroma_rows;
+                    if (chi > hi) hi = chi;
+                }
                 for (int j = 0; fusable && j < n; ++j)
                     if (lo < outs[j].hi && outs[j].lo < hi) fusable = false;
             }

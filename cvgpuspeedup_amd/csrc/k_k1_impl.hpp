@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(const K1Args<NP
                                 if (out2) st_nt(out2 + (int64_t)k * ch_stride2 + (int64_t)y * W + x, bgp.v[k]);
                                 if constexpr (MIR)
                                     for (int m = 0; m < n_mirror; ++m)
-                                        st_nt((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
+                                        st_sys((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)k * ch_stride + (int64_t)y * W + x, bgp.v[k]);
                             }
                     } else {
                         k1_store_other<WM, OT, CN, (RPW >= 4)>(g, c, z, y, x, bgp.v, bcn);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(const K1Args<NP
                         if (out2) st_row(out2 + (int64_t)y * W + (int64_t)k * ch_stride2, xb, v);
                         if constexpr (MIR)
                             for (int m = 0; m < n_mirror; ++m) // wave-uniform trip count; peers' tensors share the strides
-                                st_row((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)y * W + (int64_t)k * ch_stride, xb, v);
+                                st_row_sys((OT*)g.mirror[m] + (int64_t)z * img_stride + (int64_t)y * W + (int64_t)k * ch_stride, xb, v);
                     }
             } else {
                 float v[4];

@@ -279,6 +279,36 @@ __device__ __forceinline__ void st_row(OT* row_uniform, uint32_t x_bytes, float 
     else __builtin_nontemporal_store((OT)v, (got)(r + x_bytes));
 }
 
+// The same element into a PEER's tensor (cvgs_write_desc.mirrors: P2P-mapped memory of another GPU): a SYSTEM-scope write-through
+// store (sc0 sc1), the flavour the descriptor queue's workers publish their rows with.  The arrival flag that follows
+// (k_exchange.hip) is a relaxed system-scope store behind a kernel boundary; with write-through rows nothing depends on which
+// scope the runtime gives that boundary's release between two back-to-back kernels.
+template <typename OT>
+__device__ __forceinline__ void st_row_sys(OT* row_uniform, uint32_t x_bytes, float v) {
+    typedef __attribute__((address_space(1))) char* gchar;
+    typedef __attribute__((address_space(1))) OT* got;
+    const gchar r = (gchar)(got)pin_uniform(row_uniform);
+    if constexpr (std::is_same_v<OT, float>) {
+        __hip_atomic_store((__attribute__((address_space(1))) uint32_t*)(r + x_bytes), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        const OT h = (OT)v;
+        uint16_t bits;
+        __builtin_memcpy(&bits, &h, 2);
+        __hip_atomic_store((__attribute__((address_space(1))) uint16_t*)(r + x_bytes), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+template <typename OT>
+__device__ __forceinline__ void st_sys(OT* p, float v) {
+    if constexpr (std::is_same_v<OT, float>) {
+        __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        const OT h = (OT)v;
+        uint16_t bits;
+        __builtin_memcpy(&bits, &h, 2);
+        __hip_atomic_store((uint16_t*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 // fp16 output: the chain's trailing CAST(CV_16F) is this one round-to-nearest-even conversion
 __device__ __forceinline__ void st_nt(_Float16* p, float v) { __builtin_nontemporal_store((_Float16)v, p); }

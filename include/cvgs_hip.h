@@ -292,7 +292,8 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * aspect-ratio mode, background, YUV range / primaries / layout, pointwise stages and operands, write kind and type), are
  * fused into ONE launch of the K1 (or K4) kernel: grid z = chain, grid y = crop.  Results are bit-identical to n_chains separate cvgs_execute calls (same
  * kernel code; tests/test_gpu_many.py).  Any other set of chains is executed one by one, in order -- and so is a set whose
- * chains are NOT independent (two chains write overlapping bytes, or a host-described source view of one lies inside another's
+ * chains are NOT independent (two chains write overlapping bytes, or a host-described source view of one -- chroma rows of a 4:2:0
+ * surface included; chains whose plane table lives on the device are NOT checked: the caller vouches for them -- lies inside another's
  * output: fused chains run concurrently), a set with a batch beyond 65535, and host descriptors under stream capture.  Host
  * descriptors of a fused launch are written into a pooled pinned buffer that the kernel reads in place (no copy; the slot is
  * recycled by a HIP event behind the kernel); pass device plane tables to make the fused call capturable; at most
@@ -462,7 +463,8 @@ int cvgs_queue_destroy(cvgs_queue_t q);
  * `step_counter` (device memory, 8 bytes, zero-initialised by the caller; NULL = use `value`): the step number then lives on the
  * device -- signal advances *step_counter and publishes the new count, wait waits for *step_counter - lag (and for nothing while
  * the count is <= lag) -- so that a whole sequence of steps can be captured into ONE HIP graph and replayed (a captured constant
- * would repeat).  With n == 0 and a counter, signal still advances it.
+ * would repeat).  With n == 0 and a counter, cvgs_exchange_signal still advances it; cvgs_exchange_step with n == 0 enqueues NOTHING and
+ * leaves the counter alone (one rank has nobody to tell and nothing to wait for -- the two differ on purpose).
  * No collective and no host round trip per step.  No reference counterpart (the reference is single-GPU).                 */
 int cvgs_exchange_signal(void* const* peer_flag_words, int32_t n, uint64_t value, uint64_t* step_counter, cvgs_stream_t stream);
 int cvgs_exchange_wait(const void* const* own_flag_words, int32_t n, uint64_t value, const uint64_t* step_counter, uint64_t lag, double timeout_ms,

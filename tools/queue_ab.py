@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--crops", type=int, default=50)
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--retire-between", action="store_true", help="sleep 2 ms between replays (the server retires; each replay pays a launch)")
+    ap.add_argument("--sustained", action="store_true",
+                    help="PMC runs in the regime bench.py times: the replays are pipelined one ahead (a 128-deep ring stays full), nothing else is "
+                         "submitted -- ONE server call serves (replays + 1) x batches batches; prints the count to divide the call's counters by")
     ap.add_argument("--variants", default="2,1,0;1,1,0;0,1,0;2,0,0;0,0,0;2,1,1024;2,1,512;2,1,256")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -72,6 +75,28 @@ def main():
             q = cvgs.Queue(depth=a.depth, idle_us=300.0, flags=flags)
         except capi.CvgsError as ex:
             print(json.dumps({"variant": var, "error": str(ex)}), flush=True)
+            continue
+        if a.sustained:
+            try:
+                q.wait(q.submit_many(ptrs, n), 30.0)  # warm-up: its own (short) server call once the server has retired
+                time.sleep(0.01)
+                base = q.stats()
+                t0 = time.perf_counter()
+                prev = q.submit_many(ptrs, n)
+                for r in range(a.replays):
+                    cur = q.submit_many(ptrs, n)
+                    q.wait(prev, 30.0)
+                    prev = cur
+                q.wait(prev, 30.0)
+                dt = time.perf_counter() - t0
+                time.sleep(0.01)
+                st_ = q.stats()
+                ok = all(torch.equal(o, w) for o, w in zip(outs, want))
+                print(json.dumps({"variant": {"st": st, "ld": ld, "G": st_["workgroups"]}, "sustained": True, "batches_in_the_timed_server_calls": st_["submitted"] - base["submitted"],
+                                  "server_calls": st_["server_launches"] - base["server_launches"], "warmup_batches_in_their_own_call": n, "us_per_batch": round(dt / ((a.replays + 1) * n) * 1e6, 3),
+                                  "bit_identical_to_cvgs_execute": bool(ok), "error": st_["error"]}), flush=True)
+            finally:
+                q.destroy()
             continue
         try:
             times = []

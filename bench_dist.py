@@ -127,28 +127,37 @@ def main(a, dev, rank, world):
         # measured): every rank streams 64 MiB (or what the allocation holds) into its right-hand neighbour's allocation with the
         # engine's copy kernel, all ranks at once (each link carries one stream per direction), before any tensor is live
         if world > 1:
-            try:
+            local_gbs, nbytes = -1.0, 0
+            try:  # purely local work; the collectives below are entered by EVERY rank whatever happened here
                 nxt = bases[(rank + 1) % world]
                 nbytes = min(64 << 20, (n_frames * tensor_bytes) & ~0xfff)
                 lib0 = capi.load_library()
                 for _ in range(2):
                     capi.check(lib0.cvgs_stream_copy(nxt, buf.ptr, nbytes, s))
                 torch.cuda.synchronize()
-                dist.barrier()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(8):
-                    capi.check(lib0.cvgs_stream_copy(nxt, buf.ptr, nbytes, s))
-                e1.record()
-                torch.cuda.synchronize()
-                gbs = torch.tensor([8.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9], dtype=torch.float64, device=dev)
-                lo_t, hi_t = gbs.clone(), gbs.clone()
-                dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
-                dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+            except Exception:
+                nbytes = 0
+            dist.barrier()
+            try:
+                if nbytes:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(8):
+                        capi.check(lib0.cvgs_stream_copy(nxt, buf.ptr, nbytes, s))
+                    e1.record()
+                    torch.cuda.synchronize()
+                    local_gbs = 8.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            except Exception:
+                local_gbs = -1.0
+            lo_t = torch.tensor([local_gbs], dtype=torch.float64, device=dev)
+            hi_t = lo_t.clone()
+            dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+            if float(lo_t.item()) > 0:
                 result_extra["xgmi_probe"] = {"GB_per_s_per_link_one_direction_min": round(float(lo_t.item()), 1), "max": round(float(hi_t.item()), 1),
                                               "bytes": int(nbytes), "pattern": "rank r -> rank r+1, all ranks at once, cvgs_stream_copy into the IPC mapping"}
-            except Exception as ex:
-                result_extra["xgmi_probe"] = {"error": repr(ex)[:200]}
+            else:
+                result_extra["xgmi_probe"] = {"error": "the copy into a peer's mapping failed on at least one rank"}
             dist.barrier()
         mirrors = [[bases[r] + f * tensor_bytes for r in range(world) if r != rank] for f in range(n_frames)]
         for o in out_all:

@@ -1368,7 +1368,7 @@ int cvgs_queue_submit_many(cvgs_queue_t h, const cvgs_chain_desc* const* chains,
 
 int cvgs_queue_submit_on(cvgs_queue_t h, const cvgs_chain_desc* chain, cvgs_stream_t stream, uint32_t flags, uint64_t* ticket) {
     if (!h) return fail(CVGS_ERR_INVALID, "null queue");
-    if (flags & ~(uint32_t)(CVGS_QUEUE_SUBMIT_DEFER_WAIT | CVGS_QUEUE_SUBMIT_HYBRID)) return fail(CVGS_ERR_INVALID, "queue: unknown submit flag bits");
+    if (flags & ~(uint32_t)(CVGS_QUEUE_SUBMIT_DEFER_WAIT | CVGS_QUEUE_SUBMIT_HYBRID | CVGS_QUEUE_SUBMIT_MIN_GROUP(0xff))) return fail(CVGS_ERR_INVALID, "queue: unknown submit flag bits");
     DeviceGuard guard;
     if (int rc = guard.enter(h->device)) return rc;
     Lowered L;
@@ -1398,7 +1398,7 @@ int cvgs_queue_submit_on(cvgs_queue_t h, const cvgs_chain_desc* chain, cvgs_stre
 int cvgs_queue_submit_many_on(cvgs_queue_t h, const cvgs_chain_desc* const* chains, int32_t n, cvgs_stream_t stream, uint32_t flags, uint64_t* last_ticket) {
     if (!h || !chains || n < 1) return fail(CVGS_ERR_INVALID, "null queue / no chains");
     if (n > CVGS_QUEUE_MAX_GROUP) return fail(CVGS_ERR_INVALID, "queue: at most CVGS_QUEUE_MAX_GROUP chains behind one gate");
-    if (flags & ~(uint32_t)(CVGS_QUEUE_SUBMIT_DEFER_WAIT | CVGS_QUEUE_SUBMIT_HYBRID)) return fail(CVGS_ERR_INVALID, "queue: unknown submit flag bits");
+    if (flags & ~(uint32_t)(CVGS_QUEUE_SUBMIT_DEFER_WAIT | CVGS_QUEUE_SUBMIT_HYBRID | CVGS_QUEUE_SUBMIT_MIN_GROUP(0xff))) return fail(CVGS_ERR_INVALID, "queue: unknown submit flag bits");
     DeviceGuard guard;
     if (int rc = guard.enter(h->device)) return rc;
     std::vector<Lowered> L((size_t)n);

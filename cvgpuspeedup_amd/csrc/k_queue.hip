@@ -845,17 +845,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == QK_
             // kernel boundary on that stream (the producer's release), the tap loads below are agent-coherent (sc1).
             if (q_lane_u32(v, QD_GATED) != 0) {
                 gate = q_uni(gate);
-                // (back-off: a closed gate can have a thousand workers in front of it, all reading ONE uncached word -- at a fixed
-                //  0.25 us interval that traffic slowed every other access to the control block: two alternating streams of 4-frame
-                //  ticks ran at 11.5 us per batch against 5.6 for one stream)
+                // (back-off: a closed gate can have a thousand workers in front of it, all reading ONE uncached word; A/B'd against a fixed
+                //  0.25 us interval: no measurable difference either way -- kept short of a microsecond)
                 int nap = 0;
                 while (gate < best + 1) {
                     if (q_ldu_sys(&m.dc->stop_gen.v) == gen) return; // (the ticket stays in this worker's resume word)
                     if (nap == 0) __builtin_amdgcn_s_sleep(8);
                     else if (nap == 1) __builtin_amdgcn_s_sleep(16);
-                    else if (nap == 2) __builtin_amdgcn_s_sleep(32);
-                    else if (nap < 6) __builtin_amdgcn_s_sleep(64);
-                    else __builtin_amdgcn_s_sleep(127);
+                    else __builtin_amdgcn_s_sleep(32); // ~1 us: what a gate that opens late adds to its batch's latency at most
                     ++nap;
                     gate = q_ldu_sys(m.gates + kQCtrStride * (best % R));
                 }
@@ -1812,7 +1809,13 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
                 for (const auto& st : q->stream_tail)
                     if (st.stream != key && st.ticket >= q->done_inorder && hflag(q, st.ticket % q->R) < st.ticket + 1) { ++parallel; overlap = true; }
             }
-            if (hybrid && !overlap) { ++q->n_direct; return 2; } // a lone batch: ~11 us on the server, ~7 us as one launch
+            // The latency policy, from the measurements (tools/probes/stream_ordered_rate.py; DESIGN 4 "Round 4"): stream order costs one
+            // launch per gate, so a gate in front of FEWER than `min_group` chains (default 8) never beats launching them directly --
+            // lone strict stream 14-16 us on the server against 8-9 us as launches, single submits on 4-16 streams 10-16 against 8-9,
+            // ticks of 4 frames 3.8-10 (runtime-dependent), ticks of 8 and more 3.1 -> 2.4 us per frame.  And a batch nothing in flight
+            // could overlap with is a launch whatever its size.
+            const int min_group = (int)((flags >> 8) & 0xffu) ? (int)((flags >> 8) & 0xffu) : 8;
+            if (hybrid && (!overlap || n - done < min_group)) { ++q->n_direct; if (n_queued) *n_queued = done; return 2; }
             rows = parallel >= 8 ? (uint32_t)kQRowsPerTaskMid : (parallel >= 1 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
             const auto t0 = std::chrono::steady_clock::now();
             unsigned spins = 0;

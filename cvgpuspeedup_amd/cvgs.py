@@ -459,11 +459,39 @@ def stream_handle(stream):
     return int(stream.cuda_stream)
 
 
+_ATTACHED = {}  # stream handle -> (Queue, submit flags): cvGS::attachQueue
+
+
+def attachQueue(stream, queue, deferWait=False, minGroup=0):
+    """cvGS::attachQueue(stream, queue): executeOperations(stream, ...) on this stream goes through the queue from now on, stream-ordered
+    (cvgs_queue_submit_on, hybrid latency policy: groups below minGroup -- default 8 -- stay launches); deferWait: the stream is not held
+    on each batch, fence(stream) orders the consumer."""
+    _ATTACHED[stream_handle(stream)] = [queue, Queue.HYBRID | (Queue.DEFER_WAIT if deferWait else 0) | ((minGroup & 0xff) << 8), None]
+
+
+def detachQueue(stream):
+    _ATTACHED.pop(stream_handle(stream), None)
+
+
+def fence(stream):
+    a = _ATTACHED.get(stream_handle(stream))
+    if a and a[2] is not None:
+        a[0].stream_wait(a[2], stream)
+        a[2] = None
+
+
 def executeOperations(stream, *iops, flags=0):
     """cvGS::executeOperations(stream, iops...) (reference include/cvGPUSpeedup.cuh:464-473): one kernel,
-    asynchronous on `stream`, never synchronises."""
+    asynchronous on `stream`, never synchronises.  On a stream attached to a queue (attachQueue): the same contract through
+    cvgs_queue_submit_on."""
     lib = capi.load_library()
     lowered = lower(iops, flags)
+    a = _ATTACHED.get(stream_handle(stream)) if _ATTACHED else None
+    if a is not None:
+        t = a[0].submit_lowered_on(stream, lowered, a[1])
+        if (a[1] & Queue.DEFER_WAIT) and t != Queue.TICKET_DIRECT:
+            a[2] = t
+        return lowered
     capi.check(lib.cvgs_execute(C.byref(lowered.desc), stream_handle(stream)))
     return lowered
 
@@ -613,6 +641,10 @@ class Queue:
         return t.value
 
     DEFER_WAIT, HYBRID, TICKET_DIRECT = 1, 2, (1 << 64) - 1
+
+    @staticmethod
+    def MIN_GROUP(n):
+        return (n & 0xff) << 8
 
     def submit_on(self, stream, *iops, flags=0, submit_flags=0):
         """cvgs_queue_submit_on: executeOperations(stream, iops...) on the queue -- ordered behind everything already enqueued on

@@ -497,10 +497,13 @@ private:
 };
 // The reference's own call shape on the queue: after attachQueue(stream, queue) every cvGS::executeOperations(stream, iops...) whose
 // chain the server takes is submitted stream-ordered (behind the stream's earlier work, in front of its later work; no host
-// synchronisation -- include/cvGPUSpeedup.cuh:464-473's contract), everything else is the ordinary launch.  deferWait: the stream is not
-// held on each batch; cvGS::fence(stream) orders the consumer (several batches of one stream then overlap on the device).
-inline void attachQueue(const cv::cuda::Stream& stream, Queue& queue, bool deferWait = false) {
-    queue.fk().attach(cv::cuda::StreamAccessor::getStream(stream), deferWait);
+// synchronisation -- include/cvGPUSpeedup.cuh:464-473's contract), everything else is the ordinary launch.  The latency policy decides per
+// call: one gate kernel per call is the price of stream order, so the server takes ChainBatch::execute(stream) ticks of >= 8 chains (2.5 us
+// per 50-crop frame at 16 frames per tick against 8.9 us as launches) and single calls stay launches -- an attached stream is never slower
+// than an unattached one (minGroup overrides the 8; 1 = always the server).  deferWait: the stream is not held on each batch;
+// cvGS::fence(stream) orders the consumer (several batches of one stream then overlap on the device).
+inline void attachQueue(const cv::cuda::Stream& stream, Queue& queue, bool deferWait = false, int minGroup = 0) {
+    queue.fk().attach(cv::cuda::StreamAccessor::getStream(stream), deferWait, minGroup);
 }
 inline void detachQueue(const cv::cuda::Stream& stream) { fk::Queue::detach(cv::cuda::StreamAccessor::getStream(stream)); }
 inline void fence(const cv::cuda::Stream& stream) { fk::Queue::fence(cv::cuda::StreamAccessor::getStream(stream)); }

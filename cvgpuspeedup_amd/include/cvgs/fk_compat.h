@@ -894,10 +894,11 @@ public:
         return lost;
     }
     // executeOperations(stream, ...) on `stream` goes through this queue from now on (deferWait: the caller orders consumers with fence())
-    void attach(hipStream_t stream, bool deferWait = false) {
+    // minGroup: the smallest number of chains behind one gate the server takes (0 = the engine's default, 8; 1 = always the server)
+    void attach(hipStream_t stream, bool deferWait = false, int minGroup = 0) {
         detail::StreamAttachments& A = detail::stream_attachments();
         std::lock_guard<std::mutex> lock(A.mu);
-        const uint32_t f = CVGS_QUEUE_SUBMIT_HYBRID | (deferWait ? CVGS_QUEUE_SUBMIT_DEFER_WAIT : 0u);
+        const uint32_t f = CVGS_QUEUE_SUBMIT_HYBRID | (deferWait ? CVGS_QUEUE_SUBMIT_DEFER_WAIT : 0u) | CVGS_QUEUE_SUBMIT_MIN_GROUP(minGroup);
         for (auto& a : A.list)
             if (a.stream == stream) { a = detail::StreamAttachment{stream, q_, f, 0, false}; return; }
         A.list.push_back(detail::StreamAttachment{stream, q_, f, 0, false});

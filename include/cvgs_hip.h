@@ -413,21 +413,24 @@ int cvgs_queue_submit_many(cvgs_queue_t q, const cvgs_chain_desc* const* chains,
  *   CVGS_QUEUE_SUBMIT_DEFER_WAIT  the stream is NOT held: the caller orders the consumer itself with cvgs_queue_stream_wait(q, ticket,
  *                                 stream) -- several batches of ONE stream can then be in flight at once (a strictly ordered stream has
  *                                 one, because the next gate sits behind the previous wait).
- *   CVGS_QUEUE_SUBMIT_HYBRID      latency policy: a batch that nothing in flight could overlap with (an immediate-wait stream whose
- *                                 queue holds no other stream's open batch; with DEFER_WAIT: an empty queue), and any chain the server
- *                                 does not take, is launched DIRECTLY on `stream` as cvgs_execute would (*ticket =
- *                                 CVGS_QUEUE_TICKET_DIRECT): a lone batch costs ~14 us on the server against ~7 us for one launch.
+ *   CVGS_QUEUE_SUBMIT_HYBRID      latency policy ("never slower than without a queue"): stream order costs one launch per gate, so a
+ *                                 gate in front of fewer than 8 chains (CVGS_QUEUE_SUBMIT_MIN_GROUP(n) changes the 8) never beats
+ *                                 launching them -- such calls, a batch nothing in flight could overlap with, and any chain the
+ *                                 server does not take are launched DIRECTLY on `stream` as cvgs_execute would (*ticket =
+ *                                 CVGS_QUEUE_TICKET_DIRECT).  Measured: a lone strict stream 14-16 us per batch on the server against
+ *                                 8-9 us as launches; ticks of 16 frames (cvgs_queue_submit_many_on) 2.5 us per frame against 8.9.
  * Not capturable (the ring is written at submit time): CVGS_ERR_UNSUPPORTED on a capturing stream (with HYBRID: the direct launch is
  * captured instead).  At most 74 planes per call.                                                                          */
 #define CVGS_QUEUE_SUBMIT_DEFER_WAIT 1u
 #define CVGS_QUEUE_SUBMIT_HYBRID 2u
+#define CVGS_QUEUE_SUBMIT_MIN_GROUP(n) (((uint32_t)(n) & 0xffu) << 8) /* with HYBRID: the smallest group the server takes (0 = 8) */
 #define CVGS_QUEUE_TICKET_DIRECT (~(uint64_t)0)
 int cvgs_queue_submit_on(cvgs_queue_t q, const cvgs_chain_desc* chain, cvgs_stream_t stream, uint32_t flags, uint64_t* ticket);
 /* n chains (<= CVGS_QUEUE_MAX_GROUP) behind ONE gate kernel: the pictures of one tick -- several cameras' frames written by the work in
  * front of the call, several crop lists of one frame -- are ordered behind `stream` together, overlap on the server, and (unless
  * DEFER_WAIT) the stream is held until ALL of them are complete: one launch per tick instead of one per chain.  The stream-ordered
- * counterpart of cvgs_execute_many / cvgs_queue_submit_many.  A wait on *last_ticket covers the group.  With HYBRID, chains the
- * server does not take are launched one by one on the stream (the latency policy applies to single submits only).          */
+ * counterpart of cvgs_execute_many / cvgs_queue_submit_many.  A wait on *last_ticket covers the group.  With HYBRID, groups below the
+ * minimum and chains the server does not take are launched one by one on the stream, in order.                          */
 #define CVGS_QUEUE_MAX_GROUP 64
 int cvgs_queue_submit_many_on(cvgs_queue_t q, const cvgs_chain_desc* const* chains, int32_t n, cvgs_stream_t stream, uint32_t flags, uint64_t* last_ticket);
 /* After a wait / submit has reported CVGS_ERR_HIP because the server's watchdog fired (another kernel held the chip beyond

@@ -233,7 +233,7 @@ static void test_chain_batch(cv::cuda::Stream& stream) {
     // the same batch on a stream attached to a queue: the four chains go behind ONE gate on the stream (cvgs_queue_submit_many_on),
     // ordered behind the memsets in front of them -- same bits
     cvGS::Queue queue;
-    cvGS::attachQueue(stream, queue);
+    cvGS::attachQueue(stream, queue, /*deferWait=*/false, /*minGroup=*/4); // (the default policy takes ticks of 8 chains and more)
     for (int c = 0; c < CAMS; ++c)
         HIP_OK(hipMemsetAsync(outs_a[c].data, 0xff, n, cv::cuda::StreamAccessor::getStream(stream)));
     batch.execute(stream);
@@ -361,7 +361,7 @@ static void test_attached_streams_vs_oracle() {
             HIP_OK(hipHostMalloc((void**)&cam.ring[r], n * sizeof(float), hipHostMallocDefault));
             HIP_OK(hipEventCreateWithFlags(&cam.ev[r], hipEventDisableTiming));
         }
-        cvGS::attachQueue(cam.stream, queue);
+        cvGS::attachQueue(cam.stream, queue, /*deferWait=*/false, /*minGroup=*/c == 0 ? 1 : 0); // stream 0: every call may go to the server; stream 1: the default policy (launches)
     }
     HIP_OK(hipDeviceSynchronize());
     int bad = 0;

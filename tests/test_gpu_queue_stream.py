@@ -178,7 +178,8 @@ def test_deferred_wait_keeps_several_batches_of_one_stream_in_flight(oracle, tor
 
 def test_hybrid_policy_takes_the_direct_launch_for_a_lone_stream(oracle, torch_dev):
     """A strictly ordered stream alone on its queue has nothing to overlap with: CVGS_QUEUE_SUBMIT_HYBRID launches the chain directly on
-    the stream (the ticket says so) -- same bits, half the latency.  With a second stream's batch open the server takes it."""
+    the stream (the ticket says so) -- same bits, half the latency.  With a second stream's batch open the server takes it -- once the
+    group reaches the policy's minimum (MIN_GROUP(1) here: every call; the default 8 keeps single calls as launches)."""
     torch, dev = torch_dev
     a, b = Camera(torch, dev, oracle, seed=60), Camera(torch, dev, oracle, seed=61)
     warm(torch, a)
@@ -201,9 +202,12 @@ def test_hybrid_policy_takes_the_direct_launch_for_a_lone_stream(oracle, torch_d
             b.consume(3)
         with torch.cuda.stream(a.stream):
             a.produce(5)
-            ta = q.submit_lowered_on(a.stream, a.lowered, cvgs.Queue.HYBRID)
+            td = q.submit_lowered_on(a.stream, a.lowered, cvgs.Queue.HYBRID)                             # default minimum (8): a launch
             a.consume(5)
-        assert tb != cvgs.Queue.TICKET_DIRECT and ta != cvgs.Queue.TICKET_DIRECT
+            a.produce(6)
+            ta = q.submit_lowered_on(a.stream, a.lowered, cvgs.Queue.HYBRID | cvgs.Queue.MIN_GROUP(1))  # every call may go to the server
+            a.consume(6)
+        assert tb != cvgs.Queue.TICKET_DIRECT and ta != cvgs.Queue.TICKET_DIRECT and td == cvgs.Queue.TICKET_DIRECT
         a.stream.synchronize()
         b.stream.synchronize()
         assert int(a.bad.item()) == 0 and int(b.bad.item()) == 0 and q.stats()["error"] == 0
@@ -320,5 +324,31 @@ def test_submit_on_refuses_a_capturing_stream_and_hybrid_captures_the_launch(ora
         g.replay()
         torch.cuda.synchronize()
         assert bool(torch.equal(cam.out.view(torch.int32), cam.refs[1]))
+    finally:
+        q.destroy()
+
+
+def test_attach_queue_keeps_the_call_shape(oracle, torch_dev):
+    """cvgs.attachQueue(stream, queue): the reference's call -- executeOperations(stream, iops...) -- unchanged, two attached streams."""
+    torch, dev = torch_dev
+    cams = [Camera(torch, dev, oracle, seed=130 + k) for k in range(2)]
+    for c in cams:
+        warm(torch, c)
+    q = cvgs.Queue(idle_us=5000.0)
+    try:
+        for c in cams:
+            cvgs.attachQueue(c.stream, q, minGroup=1)  # (the default policy would launch these single calls: same bits, no server)
+        for i in range(200):
+            for c in cams:
+                with torch.cuda.stream(c.stream):
+                    c.produce(i)
+                    ops = H.k1_chain(cvgs.GpuMat.from_tensor(c.frame, cvgs.CV_8UC3), c.crops, cvgs.GpuMat.from_tensor(c.out, cvgs.CV_32FC1), DST, CN)
+                    cvgs.executeOperations(c.stream, *ops)
+                    c.consume(i)
+        for c in cams:
+            c.stream.synchronize()
+            cvgs.detachQueue(c.stream)
+        assert q.stats()["error"] == 0
+        assert [int(c.bad.item()) for c in cams] == [0, 0]
     finally:
         q.destroy()

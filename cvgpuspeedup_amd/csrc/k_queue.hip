@@ -1306,7 +1306,9 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     // at the lowest: neither shares a hardware queue with the caller's (default-priority) streams -- on which the gate kernels of
     // stream-ordered submits and hipStreamWaitValue64 consumers must be able to run while the server is alive (found by
     // tools/probes/stream_ordered_rate.py: with four caller streams one of them shared the server's queue, its gate kernel never
-    // started, the server waited at that gate for the 10 s limit) -- nor with each other.
+    // started, the server waited at that gate for the 10 s limit) -- nor with each other.  Callers' streams of the HIGHEST priority would
+    // meet the server in that level's pool: do not attach those.  (A CU-masked stream -- a hardware queue of its own -- was tried for the
+    // server instead: tests/test_gpu_queue.py::test_queue_nv12_many_batches_in_flight then failed, and the gate trace did not change.)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (const char* pe = getenv("CVGS_QUEUE_SERVER_PRIO")) { // A/B hook (tools/probes): "low" swaps the two, "normal" = both at priority 0

@@ -101,6 +101,26 @@ def stream_ordered(wl, steps=1920, reps=5):
                         capi.check(rc)
             us = timed(ticks, s2, steps // G * G)
             out["ticks_of_%d_on_2_streams" % G] = {"us": round(us, 3), "frac": round(alg / us / 1e3 / HBM, 4)}
+        # (d) the same ticks on ONE stream with the completion wait deferred (cvGS::attachQueue(stream, queue, deferWait) + cvGS::fence): the
+        #     consumer of tick k is ordered behind it two ticks later -- a pipeline of depth 2, no second stream, nothing the runtime's
+        #     stream -> hardware-queue mapping can serialise
+        for G in (8, 16):
+            groups = [cvgs.Queue.chain_pointers([wl.chains[(g * G + j) % nch] for j in range(G)]) for g in range(nch)]
+
+            def ticks_deferred():
+                pend = []
+                for i in range(steps // G):
+                    lib.cvgs_debug_occupy(1, 64, 0, 0.0, h1)
+                    rc = lib.cvgs_queue_submit_many_on(q.handle, groups[i % len(groups)], G, h1, cvgs.Queue.DEFER_WAIT, C.byref(t))
+                    if rc:
+                        capi.check(rc)
+                    pend.append(t.value)
+                    if len(pend) > 2:
+                        lib.cvgs_queue_stream_wait(q.handle, pend.pop(0), h1)
+                for tk in pend:
+                    lib.cvgs_queue_stream_wait(q.handle, tk, h1)
+            us = timed(ticks_deferred, s1, steps // G * G)
+            out["ticks_of_%d_on_1_stream_wait_deferred_2_ticks" % G] = {"us": round(us, 3), "frac": round(alg / us / 1e3 / HBM, 4)}
         st = q.stats()
         out["queue_error"] = st["error"]
     finally:
@@ -120,12 +140,14 @@ def stream_ordered(wl, steps=1920, reps=5):
 
 def stream_ordered_compact(r):
     c = {}
-    for k, short in (("ticks_of_16_on_2_streams", "tick16x2"), ("ticks_of_4_on_2_streams", "tick4x2"), ("lone_stream_hybrid", "lone_hybrid"),
+    for k, short in (("ticks_of_16_on_1_stream_wait_deferred_2_ticks", "tick16_deferred"), ("ticks_of_8_on_1_stream_wait_deferred_2_ticks", "tick8_deferred"),
+                     ("ticks_of_16_on_2_streams", "tick16x2"), ("ticks_of_4_on_2_streams", "tick4x2"), ("lone_stream_hybrid", "lone_hybrid"),
                      ("lone_stream_on_the_server", "lone_server"), ("one_launch_per_step", "launch")):
         if k in r:
             c[short + "_us"] = r[k]["us"]
-    if "ticks_of_16_on_2_streams" in r:
-        c["frac"] = r["ticks_of_16_on_2_streams"]["frac"]
+    best = [r[k]["frac"] for k in ("ticks_of_16_on_1_stream_wait_deferred_2_ticks", "ticks_of_16_on_2_streams") if k in r]
+    if best:
+        c["frac"] = max(best)  # the better of the two 16-frame tick regimes (both: producer on the stream, no host synchronisation)
     c["ok"] = bool(r.get("bit_identical_to_cvgs_execute")) and not r.get("queue_error")
     return c
 

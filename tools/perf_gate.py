@@ -79,7 +79,8 @@ def headline_rows():
 def stream_rows(wl):
     import bench_queue_regimes as QR
     r = QR.stream_ordered(wl, steps=960, reps=3)
-    return [{"name": "stream-ordered: ticks of 16 frames behind one gate, 2 streams, producer on the stream", "us": r["ticks_of_16_on_2_streams"]["us"]},
+    return [{"name": "stream-ordered: ticks of 16 frames behind one gate, 1 stream, wait deferred 2 ticks, producer on the stream", "us": r["ticks_of_16_on_1_stream_wait_deferred_2_ticks"]["us"]},
+            {"name": "stream-ordered: ticks of 16 frames behind one gate, 2 streams, producer on the stream", "us": r["ticks_of_16_on_2_streams"]["us"]},
             {"name": "stream-ordered: lone stream, hybrid policy (direct launch), producer on the stream", "us": r["lone_stream_hybrid"]["us"]}]
 
 

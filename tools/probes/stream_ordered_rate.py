@@ -69,6 +69,36 @@ def run(wl, q, lib, mode, n_streams, steps, producer, lag, threads, hybrid=False
     return ts[len(ts) // 2] * 1e6, direct[0]
 
 
+def run_ticks_deferred(wl, q, lib, group, ticks, producer, lag=2):
+    """ONE stream, `group` frames per tick behind one gate, DEFER_WAIT: the tick's consumer is ordered by cvgs_queue_stream_wait `lag`
+    ticks later (what cvGS::attachQueue(stream, queue, deferWait=true) + cvGS::fence(stream) spell)"""
+    s = torch.cuda.Stream()
+    h = s.cuda_stream
+    nch = len(wl.chains)
+    groups = [cvgs.Queue.chain_pointers([wl.chains[(g * group + j) % nch] for j in range(group)]) for g in range(max(1, nch // group) + 1)]
+    t = C.c_uint64()
+
+    def once():
+        torch.cuda.synchronize()
+        pend = []
+        t0 = time.perf_counter()
+        for i in range(ticks):
+            if producer:
+                lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+            capi.check(lib.cvgs_queue_submit_many_on(q.handle, groups[i % len(groups)], group, h, cvgs.Queue.DEFER_WAIT, C.byref(t)))
+            pend.append(t.value)
+            if len(pend) > lag:
+                lib.cvgs_queue_stream_wait(q.handle, pend.pop(0), h)
+        for tk in pend:
+            lib.cvgs_queue_stream_wait(q.handle, tk, h)
+        s.synchronize()
+        return (time.perf_counter() - t0) / (ticks * group)
+
+    once()
+    ts = sorted(once() for _ in range(5))
+    return ts[len(ts) // 2] * 1e6
+
+
 def run_ticks(wl, q, lib, group, n_streams, ticks, producer):
     """`group` frames per tick behind ONE gate (cvgs_queue_submit_many_on), strict; ticks alternate over n_streams streams."""
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
@@ -128,6 +158,9 @@ def main():
             err = q.stats()["error"]
             if err:
                 print("  !! queue error word %d; recovering: %d batches lost" % (err, q.recover()), flush=True)
+        for group, lag in ((8, 2), (16, 1), (16, 2), (16, 4), (32, 2)):
+            us = run_ticks_deferred(wl, q, lib, group, max(10, a.steps // group), a.producer, lag)
+            print("tick    %2d frames behind one gate, ONE stream, deferred wait trailing %d ticks : %7.3f us per 50-crop batch  frac %.3f" % (group, lag, us, alg / (us * 1e-6) / 8e12), flush=True)
         st = q.stats()
         print("queue error word:", st["error"])
         ok = B.queue_outputs_match_execute(wl)

@@ -508,12 +508,21 @@ def main():
     if use_queue and not a.no_regimes:
         # the queue beside its headline regime: stream-ordered submission with a producer on the stream (the reference's call shape),
         # batch latency by queue depth, and coexistence with a consumer on the same GPU (tools/bench_queue_regimes.py)
+        # In a FRESH process: what these legs measure is paced by the runtime's stream scheduling, and inside this process -- after the
+        # headline's queue, its captured graphs and the CPU leg's thread pool -- the same code read 55 us per batch for the lone strict
+        # stream (14 in a fresh process, 14 in tools/probes) and 5.1 instead of 2.3 for the deferred ticks: history, not the engine.
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
+            import subprocess
             import bench_queue_regimes as QR
-            so = QR.stream_ordered(wl)
-            lt = QR.latency_by_depth(wl)
-            co = QR.coexistence(dev, wl, sys.modules[__name__], seconds=1.0, soak_seconds=a.soak)
+            torch.cuda.synchronize()
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_queue_regimes.py"), "--json", "--seconds", "1.0", "--soak", str(a.soak)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if not line:
+                raise RuntimeError("bench_queue_regimes.py: rc %d, %s" % (p.returncode, p.stderr[-300:]))
+            r = json.loads(line[-1])
+            so, lt, co = r["stream_ordered"], r["queue_latency_by_depth"], r["coexistence"]
             result["stream_ordered_full"], result["queue_latency_by_depth_full"], result["coexistence_full"] = so, lt, co
             result["stream_ordered"], result["queue_latency_by_depth"], result["coexistence"] = QR.stream_ordered_compact(so), QR.latency_compact(lt), QR.coexistence_compact(co)
         except Exception as ex:  # never at the cost of the headline

@@ -365,6 +365,9 @@ if __name__ == "__main__":
     p = argparse.ArgumentParser()
     p.add_argument("--soak", type=float, default=0.0)
     p.add_argument("--g-sweep", action="store_true", help="coexistence only, for several server sizes")
+    p.add_argument("--json", action="store_true", help="ONE JSON object with the three blocks on the last stdout line (bench.py runs this in a fresh process)")
+    p.add_argument("--seconds", type=float, default=2.0, help="coexistence: seconds per leg")
+    p.add_argument("--only-stream", action="store_true", help="--json: the stream-ordered block only (tools/perf_gate.py)")
     a = p.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -378,6 +381,13 @@ if __name__ == "__main__":
                       n, r["gemm_%d" % n]["queue"]["preprocessing_us_per_batch"], r["gemm_%d" % n]["queue"]["consumer_slowdown"],
                       r["gemm_%d" % n]["queue_paced_20k_per_s"]["batch_latency_p50_us"], r["gemm_%d" % n]["queue_paced_20k_per_s"]["consumer_slowdown"],
                       r["gemm_%d" % n]["graph_launches"]["preprocessing_us_per_batch"], r["gemm_%d" % n]["graph_launches"]["consumer_slowdown"]) for n in (4096, 8192)), flush=True)
+        sys.exit(0)
+    if a.json:
+        r = {"stream_ordered": stream_ordered(wl)}
+        if not a.only_stream:
+            r["queue_latency_by_depth"] = latency_by_depth(wl)
+            r["coexistence"] = coexistence(dev, wl, B, seconds=a.seconds, soak_seconds=a.soak)
+        print(json.dumps(r), flush=True)
         sys.exit(0)
     print(json.dumps({"stream_ordered": stream_ordered(wl)}, indent=1), flush=True)
     print(json.dumps({"queue_latency_by_depth": latency_by_depth(wl)}, indent=1), flush=True)

@@ -13,7 +13,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 RP="rocprofv3 --kernel-trace --output-format csv"
 SUM="python tools/prof_summary.py"
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra > $OUT/bench_unprofiled_20_5.json 2>/dev/null
-timeout -k 5 300 $RP --stats -d $RAW/trace -o t -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extra > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+cp bench_extra.json $OUT/bench_unprofiled_20_5_extra.json 2>/dev/null
+timeout -k 5 300 $RP --stats -d $RAW/trace -o t -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extra --no-regimes > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+cp bench_extra.json $OUT/bench_trace_extra.json 2>/dev/null
 $SUM kernels $RAW/trace/t_kernel_trace.csv > $OUT/bench_trace_kernels.txt 2>&1
 $SUM calls $RAW/trace/t_kernel_trace.csv k1q_server > $OUT/bench_trace_server_calls.txt 2>&1
 # HBM counters: rocprofv3 --pmc segfaults inside bench.py on this image (with and without the stream events, staged or direct

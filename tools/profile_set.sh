@@ -10,6 +10,17 @@ mkdir -p $OUT
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu_tail.txt
 bash tools/profile_queue.sh $TAG > /dev/null 2>&1
 python bench.py > $OUT/bench_default.json 2> /dev/null
+cp bench_extra.json $OUT/bench_default_extra.json 2> /dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_20_5.json 2> /dev/null
+cp bench_extra.json $OUT/bench_20_5_extra.json 2> /dev/null
+python bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-extra > $OUT/bench_force_dist.json 2> /dev/null
+bash tools/profile_queue_sustained.sh $TAG > /dev/null 2>&1
+(echo "== default runtime (GPU_MAX_HW_QUEUES unset = 4), producer kernel on the stream =="; python tools/probes/stream_ordered_rate.py --producer 2>&1 | grep -v amdgpu.ids
+ echo; echo "== GPU_MAX_HW_QUEUES=2, producer kernel on the stream =="; GPU_MAX_HW_QUEUES=2 python tools/probes/stream_ordered_rate.py --producer 2>&1 | grep -v amdgpu.ids
+ echo; echo "== default runtime, no producer kernel =="; python tools/probes/stream_ordered_rate.py 2>&1 | grep -v amdgpu.ids) > $OUT/stream_ordered_rate.txt
+(echo "== default runtime =="; python tools/probes/gate_trace.py 2>&1 | grep -v amdgpu.ids; echo "== GPU_MAX_HW_QUEUES=2 =="; GPU_MAX_HW_QUEUES=2 python tools/probes/gate_trace.py 2>&1 | grep -v amdgpu.ids) > $OUT/gate_trace.txt
+python tools/bench_queue_regimes.py --soak 60 2>&1 | grep -v amdgpu.ids > $OUT/queue_regimes_soak60.txt
+python tools/bench_queue_regimes.py --g-sweep 2>&1 | grep -v amdgpu.ids > $OUT/coexistence_g_sweep.txt
 python tools/bench_reference_tests.py > $OUT/reference_test_chains.txt 2> /dev/null
 python tools/bench_more.py > $OUT/bench_more.txt 2> /dev/null
 python tools/bench_upscale.py > $OUT/bench_upscale.txt 2> /dev/null

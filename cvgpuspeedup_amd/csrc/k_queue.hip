@@ -1028,8 +1028,9 @@ __global__ void k1q_gate(uint64_t* gates, uint64_t* hgates, const uint64_t* dfla
 // cvgs_queue_stream_wait: the stream waits until batches [first, last] are complete (one wave; lane i watches batch first + i, in
 // rounds of 64).  hipStreamWaitValue64 on ordinary device memory proved unusable on a hot path: a wait that is not already satisfied
 // when the stream reaches it costs ~1.6 ms on this runtime (tools/probes/stream_ordered_rate.py, deferred waits trailing by 4 batches).
-__global__ void k1q_wait(const uint64_t* dflags, uint32_t R, uint64_t first, uint64_t last, const uint64_t* host_error, uint64_t timeout_ticks) {
+__global__ void k1q_wait(const uint64_t* dflags, uint32_t R, uint64_t first, uint64_t last, const uint64_t* host_error, uint64_t timeout_ticks, uint64_t* trace) {
     const uint64_t t0 = wall_clock64();
+    if (trace && threadIdx.x == 0) q_st_sys(trace + 8192 + 2 * (last & 4095), t0); // (probes: words 8192.. = {wait kernel start, end} per last ticket)
     for (uint64_t base = first; base <= last; base += 64) {
         const uint64_t b = base + threadIdx.x;
         unsigned polls = 0;
@@ -1038,6 +1039,10 @@ __global__ void k1q_wait(const uint64_t* dflags, uint32_t R, uint64_t first, uin
                 __builtin_amdgcn_s_sleep(4);
                 if ((++polls & 63) == 0 && (q_ld_sys(host_error) != 0 || wall_clock64() - t0 > timeout_ticks)) return;
             }
+    }
+    if (trace) {
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0) q_st_sys(trace + 8192 + 2 * (last & 4095) + 1, wall_clock64());
     }
 }
 // host-side gate opening without a writable BAR (a failed gate launch must not leave workers waiting)
@@ -1344,7 +1349,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
         err = std::string("queue init: ") + hipGetErrorString(e);
         return -1;
     }
-    if (getenv("CVGS_QUEUE_GATE_TRACE") && hipHostMalloc((void**)&q->gate_trace, 4096 * 16, hipHostMallocDefault) == hipSuccess) std::memset(q->gate_trace, 0, 4096 * 16);
+    if (getenv("CVGS_QUEUE_GATE_TRACE") && hipHostMalloc((void**)&q->gate_trace, 4096 * 32, hipHostMallocDefault) == hipSuccess) std::memset(q->gate_trace, 0, 4096 * 32);
     q->direct = decide_direct(device, q->dev_block, total, &q->m.dc->stop_gen.pad[0], flags);
     if (!q->direct) {
         if ((e = hipHostMalloc((void**)&q->host_ring, R * kQSlotBytes, hipHostMallocDefault)) != hipSuccess ||
@@ -1730,7 +1735,7 @@ int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err)
         }
         return 0;
     }
-    hipLaunchKernelGGL(k1q_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint64_t*)q->m.dflags, q->R, d, ticket, (const uint64_t*)&q->hc->error.v, q->gate_ticks);
+    hipLaunchKernelGGL(k1q_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint64_t*)q->m.dflags, q->R, d, ticket, (const uint64_t*)&q->hc->error.v, q->gate_ticks, q->gate_trace);
     if (hipGetLastError() != hipSuccess) { err = "queue: the wait kernel could not be launched on the consumer's stream"; return -1; }
     return 0;
 }

@@ -396,6 +396,10 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  * Submits from several host threads are serialised by a mutex (tickets are handed out in submit order).  cvgs_queue_destroy
  * waits (at most 2 s) for the batches in flight, then retires the server.  Whether the host writes the ring straight into device
  * memory is decided without a fault (large-BAR attribute + /proc/self/maps + a read-back; CVGS_QUEUE_DIRECT=0 / 1 overrides).
+ * RUNTIME NOTE: while a server grid is alive, kernels of every stream whose hardware queue shares the server queue's command-processor
+ * pipe dispatch at ~27 us each instead of ~3.4 us (measured: one stream in four on the default runtime's 4 hardware queues, none with
+ * GPU_MAX_HW_QUEUES <= 3; tools/probes/server_vs_streams.py).  Processes that keep a queue alive beside other streams should set
+ * GPU_MAX_HW_QUEUES=3 before the HIP runtime initialises; the server retires idle_us after its last batch.
  * No reference counterpart.                                                                                           */
 typedef struct cvgs_queue_s* cvgs_queue_t;
 int cvgs_queue_create(cvgs_queue_t* out, int32_t device, int32_t depth, double idle_us, uint32_t flags);

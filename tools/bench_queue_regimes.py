@@ -16,6 +16,11 @@
 import ctypes as C
 import os
 import sys
+
+if __name__ == "__main__":
+    # a live server slows kernel dispatch on the hardware queues that share its command-processor pipe (tools/probes/server_vs_streams.py):
+    # with <= 3 queues the caller's and the server's never share one.  Read by the runtime at initialisation; an explicit setting wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +45,8 @@ def stream_ordered(wl, steps=1920, reps=5):
     alg = wl.algorithmic_bytes()
     nch = len(wl.chains)
     t = C.c_uint64()
-    out = {"producer": "a one-wave kernel on the stream in front of every submit (stand-in for the decoder / the kernel that writes the frame)",
+    out = {"runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)")},
+           "producer": "a one-wave kernel on the stream in front of every submit (stand-in for the decoder / the kernel that writes the frame)",
            "clock": "host wall clock over %d batches incl. the final stream synchronise, median of %d" % (steps, reps)}
     q = cvgs.Queue(depth=128, idle_us=2000.0)
 

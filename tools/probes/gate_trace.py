@@ -5,6 +5,11 @@ gap = next gate kernel of the SAME stream's start - this one's completion (kerne
 import ctypes as C
 import os
 import sys
+
+if __name__ == "__main__":
+    # a live server slows kernel dispatch on the hardware queues that share its command-processor pipe (tools/probes/server_vs_streams.py):
+    # with <= 3 queues the caller's and the server's never share one.  Read by the runtime at initialisation; an explicit setting wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 import time
 
 os.environ["CVGS_QUEUE_GATE_TRACE"] = "1"

@@ -9,6 +9,11 @@ import argparse
 import ctypes as C
 import os
 import sys
+
+if __name__ == "__main__":
+    # a live server slows kernel dispatch on the hardware queues that share its command-processor pipe (tools/probes/server_vs_streams.py):
+    # with <= 3 queues the caller's and the server's never share one.  Read by the runtime at initialisation; an explicit setting wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 import threading
 import time
 

@@ -558,7 +558,7 @@ def compact_line(result):
             line["config"][k] = line["config"][k][:257] + "..."
     line["roofline"] = _pick(result.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us",
                                                           "algorithmic_bytes_per_launch", "sector_bound_bytes_per_launch",
-                                                          "frac_of_sector_bound", "copy_ceiling", "per_gpu_frac"))
+                                                          "frac_of_sector_bound", "copy_ceiling", "per_gpu_frac", "per_gpu_frac_on_the_queue"))
     if "cpu_baseline" in result:
         cb = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "single_thread_value", "gpu_matches_oracle_bit_exact"))
         if isinstance(cb.get("sample"), str) and len(cb["sample"]) > 200:

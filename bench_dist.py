@@ -79,6 +79,20 @@ def main(a, dev, rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     compute_step = float(t.item())
     px_step = n * W.DST[0] * W.DST[1] * world
+    # ---- leg 1b: the same shard through the descriptor queue (the headline's kernel and submission path: one cvgs_queue_submit per step,
+    # the rank's rows of the full tensor as the target); no barrier inside -- every rank times its own server, the MAX is taken after
+    compute_queue_step = None
+    try:
+        dist.barrier()
+        mq = B.measure_queue(wl, steps, a.warmup, target_s=0.1, min_replays=20, events=False)
+        tq = torch.tensor([mq["step_s"] if B.queue_outputs_match_execute(wl) and not mq["queue"]["error"] else -1.0], dtype=torch.float64, device=dev)
+    except Exception:
+        tq = torch.tensor([-1.0], dtype=torch.float64, device=dev)
+    tq_min = tq.clone()
+    dist.all_reduce(tq, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tq_min, op=dist.ReduceOp.MIN)
+    if float(tq_min.item()) > 0:
+        compute_queue_step = float(tq.item())
 
     # ---- leg 2: K1 + in-place RCCL all-gather per step -----------------------------------------------------------------
     works = [None] * n_frames
@@ -232,13 +246,17 @@ def main(a, dev, rank, world):
                          "frac": round(alg / compute_step / 1e9 / B.HBM_PEAK_GBS, 4), "traffic": None, "kernel": wl.kernel,
                          "kernel_us": round(compute_step * 1e6, 3), "algorithmic_bytes_per_launch": int(alg),
                          "per_gpu_frac": round(alg / compute_step / 1e9 / B.HBM_PEAK_GBS, 4),
+                         "per_gpu_frac_on_the_queue": round(alg / compute_queue_step / 1e9 / B.HBM_PEAK_GBS, 4) if compute_queue_step else None,
                          "note": "K1 alone on each GPU (compute-only leg); the exchange is xGMI-bound, not HBM-bound"},
             # the SAME workload and submission path on ONE GPU (this rank's 64-crop-of-6K step, graph-replayed launches, measured in this
             # process while the other ranks run theirs): what a scaling curve of this line must be read against -- bench.py --gpus 1 is
             # cfg #2b on the descriptor queue, a different workload and submission path
             "n1_same_workload": {"Mpix_per_s": round(n * W.DST[0] * W.DST[1] / compute_step / 1e6, 1), "us_per_step": round(compute_step * 1e6, 3),
+                                 "on_the_queue_Mpix_per_s": round(n * W.DST[0] * W.DST[1] / compute_queue_step / 1e6, 1) if compute_queue_step else None,
+                                 "on_the_queue_us_per_step": round(compute_queue_step * 1e6, 3) if compute_queue_step else None,
                                  "value_over_n1": round((px_step / step_s) / (n * W.DST[0] * W.DST[1] / compute_step), 3)},
-            "legs": {"compute_only_us": round(compute_step * 1e6, 3), "allgather_us": round(ag_wall / steps * 1e6, 3),
+            "legs": {"compute_only_us": round(compute_step * 1e6, 3), "compute_only_on_the_queue_us": round(compute_queue_step * 1e6, 3) if compute_queue_step else None,
+                     "allgather_us": round(ag_wall / steps * 1e6, 3),
                      "p2p_write_us": round(p2p["wall"] / steps * 1e6, 3) if p2p_ok else None,
                      "link_floor_us": round(n * plane * esz / (link * 1e9) * 1e6, 3) if link else None},
             "extra": {

@@ -118,6 +118,7 @@ SYMBOLS = [
     ("cvgs_queue_submit_many_on", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(ChainDesc)), C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("cvgs_queue_recover", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("cvgs_debug_occupy", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
+    ("cvgs_debug_poll", C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_void_p]),
     ("cvgs_queue_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_double]),
     ("cvgs_queue_stream_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("cvgs_queue_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

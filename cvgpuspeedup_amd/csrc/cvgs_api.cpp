@@ -1455,6 +1455,12 @@ int cvgs_debug_occupy(int32_t blocks, int32_t threads, int32_t lds_bytes, double
     return CVGS_OK;
 }
 
+int cvgs_debug_poll(const void* word, double microseconds, int32_t nap, cvgs_stream_t stream) {
+    if (((uintptr_t)word & 7) || microseconds < 0 || microseconds > 5e6) return fail(CVGS_ERR_INVALID, "debug_poll: an 8-byte aligned word (NULL = an uncached device word of the library's), <= 5 s");
+    if (cvgs::launch_debug_poll(word, microseconds, nap, stream)) return fail(CVGS_ERR_HIP, "debug_poll launch failed");
+    return CVGS_OK;
+}
+
 int cvgs_queue_wait(cvgs_queue_t h, uint64_t ticket, double timeout_s) {
     if (!h) return fail(CVGS_ERR_INVALID, "null queue");
     if (ticket == CVGS_QUEUE_TICKET_DIRECT) return fail(CVGS_ERR_INVALID, "queue: the batch was launched directly on the caller's stream (hybrid policy): synchronise that stream");

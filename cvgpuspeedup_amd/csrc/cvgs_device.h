@@ -239,6 +239,7 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
 int queue_recover(Queue* q, uint64_t* lost, std::string& err);
 const uint64_t* queue_gate_trace(Queue* q); // null unless CVGS_QUEUE_GATE_TRACE was set at create
 int launch_debug_occupy(int blocks, int threads, int lds_bytes, double us, void* stream);
+int launch_debug_poll(const void* word, double us, int nap, void* stream);
 int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err);
 int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err);
 void queue_stats(Queue* q, uint64_t* out8);

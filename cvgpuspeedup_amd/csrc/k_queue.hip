@@ -1058,6 +1058,28 @@ __global__ void k_debug_occupy(uint64_t ticks) {
     const uint64_t t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
+// probe aid (cvgs_debug_poll): one wave that reads `word` with system-scope loads (s_sleep between them) for `us` microseconds -- what a
+// resident server's janitor does to a word in host memory / its workers to a word in uncached device memory
+__global__ void k_debug_poll(const uint64_t* word, uint64_t ticks, uint32_t nap) {
+    const uint64_t t0 = wall_clock64();
+    uint64_t acc = 0;
+    while (wall_clock64() - t0 < ticks) {
+        acc += q_ld_sys(word);
+        if (nap) __builtin_amdgcn_s_sleep(32);
+    }
+    if (acc == 0x123456789abcdefull) __builtin_trap();
+}
+int launch_debug_poll(const void* word, double us, int nap, void* stream) {
+    if (!word) { // the server's own kind of memory: an uncached device word (allocated once, never freed)
+        static void* uc = nullptr;
+        if (!uc && (hipExtMallocWithFlags(&uc, 4096, hipDeviceMallocUncached) != hipSuccess || hipMemset(uc, 0, 4096) != hipSuccess)) return -1;
+        word = uc;
+    }
+    const int blocks = nap >> 8 ? nap >> 8 : 1; // probes: nap bits 8.. = workgroups of 256 threads (all waves poll)
+    nap &= 0xff;
+    hipLaunchKernelGGL(k_debug_poll, dim3(blocks), dim3(blocks > 1 ? 256 : 64), 0, (hipStream_t)stream, (const uint64_t*)word, (uint64_t)(us * 100.0), (uint32_t)nap);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_debug_occupy(int blocks, int threads, int lds_bytes, double us, void* stream) {
     if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_debug_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(k_debug_occupy, dim3(blocks), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, (uint64_t)(us * 100.0));
@@ -1320,7 +1342,15 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
         if (pe[0] == 'l') { const int x = prio_least; prio_least = prio_greatest; prio_greatest = x; }
         if (pe[0] == 'n') prio_least = prio_greatest = 0;
     }
-    if ((e = hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
+    if (const char* pe = getenv("CVGS_QUEUE_SERVER_PRIO")) // A/B hook: "cumask" = a CU-masked stream at the default priority (a hardware queue of its own)
+        if (pe[0] == 'c') {
+            const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
+            std::vector<uint32_t> mask(words, 0xffffffffu);
+            if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+            if (hipExtStreamCreateWithCUMask(&q->stream, words, mask.data()) != hipSuccess) q->stream = nullptr;
+            (void)hipGetLastError();
+        }
+    if ((!q->stream && (e = hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess) ||
         (e = hipStreamCreateWithPriority(&q->stage_stream, hipStreamNonBlocking, prio_least)) != hipSuccess ||
         (e = hipExtMallocWithFlags((void**)&q->dev_block, total, hipDeviceMallocUncached)) != hipSuccess ||
         (e = hipMalloc((void**)&q->dev_counters, total_ctr)) != hipSuccess ||

@@ -494,6 +494,9 @@ int cvgs_stream_copy(void* dst, const void* src, size_t bytes, cvgs_stream_t str
  * `stream`: a stand-in for a foreign kernel that occupies part of the chip (the queue's residency / watchdog tests, bench.py's
  * coexistence leg).  No reference counterpart.                                                                         */
 int cvgs_debug_occupy(int32_t blocks, int32_t threads, int32_t lds_bytes, double microseconds, cvgs_stream_t stream);
+/* one wave that reads `word` (device, uncached-device or pinned host memory, 8-byte aligned) with system-scope loads for `microseconds`
+ * (nap != 0: s_sleep between the loads): the access pattern of a resident server's polling, for tools/probes/ only.               */
+int cvgs_debug_poll(const void* word, double microseconds, int32_t nap, cvgs_stream_t stream);
 
 /* ---- profiling ranges (reference tests/nvtx.h PUSH_RANGE/POP_RANGE) -------------------------- */
 void cvgs_range_push(const char* name);

@@ -31,8 +31,20 @@ def rate(s, n=300):
 
 print("nothing running        :", " ".join("%5.1f" % rate(s) for s in streams), flush=True)
 blocks = 767 if "--grid" in sys.argv else 1
-lib.cvgs_debug_occupy(blocks, 256, 0, 400000.0, hog.cuda_stream)
-time.sleep(0.01)
-print("%4d-block sleeper alive :" % blocks, " ".join("%5.1f" % rate(s) for s in streams), flush=True)
+if "--poll-uncached" in sys.argv:
+    grid = 768 if "--grid" in sys.argv else 1
+    capi.check(lib.cvgs_debug_poll(None, 400000.0, 1 | (grid << 8 if grid > 1 else 0), hog.cuda_stream))
+    time.sleep(0.01)
+    print("%d workgroup(s) polling an UNCACHED device word:" % grid, " ".join("%5.1f" % rate(s) for s in streams), flush=True)
+elif "--poll-host" in sys.argv or "--poll-device" in sys.argv:
+    word = torch.zeros(16, dtype=torch.int64).pin_memory() if "--poll-host" in sys.argv else torch.zeros(16, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    capi.check(lib.cvgs_debug_poll(word.data_ptr(), 400000.0, 1, hog.cuda_stream))
+    time.sleep(0.01)
+    print("one wave polling %s memory:" % ("pinned HOST" if "--poll-host" in sys.argv else "device"), " ".join("%5.1f" % rate(s) for s in streams), flush=True)
+else:
+    lib.cvgs_debug_occupy(blocks, 256, 0, 400000.0, hog.cuda_stream)
+    time.sleep(0.01)
+    print("%4d-block sleeper alive :" % blocks, " ".join("%5.1f" % rate(s) for s in streams), flush=True)
 hog.synchronize()
 print("sleeper gone           :", " ".join("%5.1f" % rate(s) for s in streams), flush=True)

@@ -405,6 +405,8 @@ def main():
     if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
         return self_spawn(a)
     guard_stdout()
+    if os.environ.get("CVGS_BENCH_WORLD_ON_ONE_GPU") == "1":  # test mode: every rank on cuda:0 (bench_dist.py)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or a.force_dist:
@@ -649,6 +651,8 @@ def self_spawn(a):
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("CVGS_BENCH_WORLD_ON_ONE_GPU") == "1" and have >= 1:
+        have = a.gpus
     if have < a.gpus:
         write_line(error_line(a, "--gpus %d but this box has %d visible GPU(s)" % (a.gpus, have)))
         raise SystemExit(2)

@@ -52,7 +52,14 @@ def main(a, dev, rank, world):
     os.environ.setdefault("WORLD_SIZE", "1")
     import datetime
     # a rank that dies must not hold the others in a collective for the default 10 minutes
-    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
+    # CVGS_BENCH_WORLD_ON_ONE_GPU=1 (tests/test_gpu_bench_world2.py): every rank on cuda:0 and gloo for the collectives (RCCL refuses two
+    # ranks on one device) -- the IPC mappings, mirror stores, arrival flags, link probe and the line's assembly run as with N GPUs;
+    # the timings of such a run mean nothing.
+    one_gpu = os.environ.get("CVGS_BENCH_WORLD_ON_ONE_GPU") == "1"
+    if one_gpu:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
+    else:
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
     n = B.CFG5_CROPS
     plane = 3 * W.DST[0] * W.DST[1]
     fw, fh = W.FRAME_6K
@@ -104,6 +111,14 @@ def main(a, dev, rank, world):
                 works[j].wait()  # the launch stream waits for the collective that last read buffer j
             wl.launch(i, s)
             lo, hi = sharding.shard_bounds(world * n, world, rank)
+            if one_gpu:  # gloo: no in-place CUDA all-gather -- through a copy, synchronously (test mode only)
+                torch.cuda.synchronize()
+                parts = [torch.empty_like(out_all[j][lo:hi]) for _ in range(world)]
+                dist.all_gather(parts, out_all[j][lo:hi].clone())
+                for r, part in enumerate(parts):
+                    rlo, rhi = sharding.shard_bounds(world * n, world, r)
+                    out_all[j][rlo:rhi].copy_(part)
+                continue
             works[j] = dist.all_gather_into_tensor(out_all[j], out_all[j][lo:hi], async_op=True)
         for j, w in enumerate(works):
             if w is not None:

@@ -2035,6 +2035,20 @@ int queue_destroy(Queue* q) {
         std::lock_guard<std::mutex> owner_lock(g_server_mu);
         if (g_server_owner[q->device & 63] == q) g_server_owner[q->device & 63] = nullptr;
     }
+    // Gate / wait kernels of stream-ordered submits may still sit on the CALLERS' streams (behind a long producer, or holding a stream on
+    // a batch that will never complete now): they read the gate / completion words and the host error word freed below.  The error word
+    // releases the ones that are waiting (they look at it every 64 polls), and the device is drained before anything is freed.
+    bool gates_pending;
+    {
+        std::lock_guard<std::mutex> lock(q->mu);
+        prune_closed(q);
+        gates_pending = !q->closed.empty() || q->n_gated > 0;
+    }
+    if (gates_pending) {
+        if (!hv(q->hc->error)) hv(q->hc->error) = 4; // "destroyed"
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        (void)hipDeviceSynchronize();
+    }
     (void)hipStreamDestroy(q->stream);
     (void)hipStreamDestroy(q->stage_stream);
     (void)hipFree(q->dev_block);

@@ -352,3 +352,35 @@ def test_attach_queue_keeps_the_call_shape(oracle, torch_dev):
         assert [int(c.bad.item()) for c in cams] == [0, 0]
     finally:
         q.destroy()
+
+
+def test_destroy_with_a_gate_kernel_still_behind_its_producer(oracle, torch_dev):
+    """cvgs_queue_destroy while a stream-ordered batch's gate kernel has not run yet (a 150 ms producer in front of it): the destroy waits
+    its bounded time, releases whatever is waiting and drains the device BEFORE it frees the words those kernels read -- no fault, the
+    stream finishes, and a new queue serves the same stream afterwards."""
+    torch, dev = torch_dev
+    cam = Camera(torch, dev, oracle, seed=150)
+    warm(torch, cam)
+    lib = capi.load_library()
+    q = cvgs.Queue(idle_us=5000.0)
+    with torch.cuda.stream(cam.stream):
+        capi.check(lib.cvgs_debug_occupy(1, 64, 0, 150000.0, cam.stream.cuda_stream))
+        cam.produce(1)
+        q.submit_lowered_on(cam.stream, cam.lowered)
+    t0 = time.perf_counter()
+    q.destroy()
+    assert time.perf_counter() - t0 < 8.0
+    cam.stream.synchronize()
+    torch.cuda.synchronize()
+    q2 = cvgs.Queue(idle_us=5000.0)
+    try:
+        cam.bad.zero_()
+        with torch.cuda.stream(cam.stream):
+            for i in range(20):
+                cam.produce(i)
+                q2.submit_lowered_on(cam.stream, cam.lowered)
+                cam.consume(i)
+        cam.stream.synchronize()
+        assert int(cam.bad.item()) == 0 and q2.stats()["error"] == 0
+    finally:
+        q2.destroy()

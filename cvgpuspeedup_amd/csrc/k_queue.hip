@@ -1860,7 +1860,10 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
                 uint64_t room = budget > q->closed_tasks ? budget - q->closed_tasks : 0;
                 take = 0;
                 uint64_t sum = 0;
-                while (done + take < n && take < 64) {
+                // (at most half the ring behind ONE gate kernel: the chains are published before their gate kernel is enqueued, so a group
+                //  larger than the ring would wait for its own first slot to complete -- behind a gate nobody has launched yet)
+                const int max_take = q->R >= 4 ? (int)(q->R / 2) : 1;
+                while (done + take < n && take < 64 && take < max_take) {
                     const uint32_t tt = gated_tasks(*chains[done + take], rows);
                     if (sum + tt > room) break;
                     sum += tt;

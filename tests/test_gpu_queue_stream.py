@@ -384,3 +384,29 @@ def test_destroy_with_a_gate_kernel_still_behind_its_producer(oracle, torch_dev)
         assert int(cam.bad.item()) == 0 and q2.stats()["error"] == 0
     finally:
         q2.destroy()
+
+
+def test_a_tick_larger_than_the_ring(oracle, torch_dev):
+    """16 chains behind one call on an 8-slot ring: the call splits them over several gate kernels (half a ring each) instead of waiting
+    for its own first slot behind a gate nobody has launched."""
+    torch, dev = torch_dev
+    s = torch.cuda.Stream()
+    cams = [Camera(torch, dev, oracle, seed=160 + k, n_crops=5, pool=2) for k in range(16)]
+    for c in cams:
+        c.stream = s
+        warm(torch, c)
+    ptrs = cvgs.Queue.chain_pointers([c.lowered for c in cams])
+    q = cvgs.Queue(depth=8, idle_us=5000.0)
+    try:
+        with torch.cuda.stream(s):
+            for i in range(12):
+                for c in cams:
+                    c.produce(i)
+                q.submit_many_on(s, ptrs, len(cams))
+                for c in cams:
+                    c.consume(i)
+        s.synchronize()
+        assert q.stats()["error"] == 0 and q.stats()["submitted"] == 12 * 16
+        assert sum(int(c.bad.item()) for c in cams) == 0
+    finally:
+        q.destroy()

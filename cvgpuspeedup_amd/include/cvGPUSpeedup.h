@@ -507,6 +507,7 @@ inline void attachQueue(const cv::cuda::Stream& stream, Queue& queue, bool defer
 }
 inline void detachQueue(const cv::cuda::Stream& stream) { fk::Queue::detach(cv::cuda::StreamAccessor::getStream(stream)); }
 inline void fence(const cv::cuda::Stream& stream) { fk::Queue::fence(cv::cuda::StreamAccessor::getStream(stream)); }
+inline bool lastTicket(const cv::cuda::Stream& stream, uint64_t* ticket) { return fk::Queue::lastTicket(cv::cuda::StreamAccessor::getStream(stream), ticket); }
 // cvGS::executeOperations(queue, iops...): the stream form's IOps, a ticket instead of a stream position
 template <typename... IOpTypes>
 inline uint64_t executeOperations(Queue& queue, const IOpTypes&... iops) {

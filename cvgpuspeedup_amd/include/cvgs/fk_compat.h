@@ -911,6 +911,15 @@ public:
             if (A.list[i].stream == stream) { A.list.erase(A.list.begin() + (long)i); break; }
         A.any.store(!A.list.empty(), std::memory_order_release);
     }
+    // deferWait streams: the ticket of the newest batch the stream has submitted to the server (false: none since the last fence);
+    // wait(ticket, stream) later orders a consumer behind it and everything before it -- a pipeline of any depth
+    static bool lastTicket(hipStream_t stream, uint64_t* ticket) {
+        detail::StreamAttachments& A = detail::stream_attachments();
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (const auto& a : A.list)
+            if (a.stream == stream && a.has_ticket) { *ticket = a.last_ticket; return true; }
+        return false;
+    }
     // deferWait streams: order everything enqueued on `stream` from here on behind the batches it has submitted so far
     static void fence(hipStream_t stream) {
         detail::StreamAttachments& A = detail::stream_attachments();

@@ -410,3 +410,50 @@ def test_a_tick_larger_than_the_ring(oracle, torch_dev):
         assert sum(int(c.bad.item()) for c in cams) == 0
     finally:
         q.destroy()
+
+
+def test_four_host_threads_submit_stream_ordered_batches(oracle, torch_dev):
+    """Four host threads, each with its own camera stream, submit stream-ordered batches to ONE queue concurrently (a fifth submits
+    ticket batches): ring order must stay equal to gate-kernel order under the races (the group lock), every tensor bit-exact."""
+    import threading
+    torch, dev = torch_dev
+    cams = [Camera(torch, dev, oracle, seed=170 + k, n_crops=6 + 2 * k, pool=4) for k in range(4)]
+    extra = Camera(torch, dev, oracle, seed=179, n_crops=9, pool=1)
+    for c in cams + [extra]:
+        warm(torch, c)
+    extra.frame.copy_(extra.pool[0])
+    torch.cuda.synchronize()
+    q = cvgs.Queue(idle_us=5000.0)
+    errors = []
+
+    def camera_thread(c):
+        try:
+            with torch.cuda.stream(c.stream):
+                for i in range(150):
+                    c.produce(i)
+                    q.submit_lowered_on(c.stream, c.lowered)
+                    c.consume(i)
+            c.stream.synchronize()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    def ticket_thread():
+        try:
+            for i in range(100):
+                q.wait(q.submit_lowered(extra.lowered), timeout_s=20.0)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    try:
+        ths = [threading.Thread(target=camera_thread, args=(c,)) for c in cams] + [threading.Thread(target=ticket_thread)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in ths)
+        assert q.stats()["error"] == 0 and q.stats()["submitted"] == 4 * 150 + 100
+        assert [int(c.bad.item()) for c in cams] == [0, 0, 0, 0]
+        assert bool(torch.equal(extra.out.view(torch.int32), extra.refs[0]))
+    finally:
+        q.destroy()

@@ -416,7 +416,9 @@ int cvgs_queue_submit_many(cvgs_queue_t q, const cvgs_chain_desc* const* chains,
  * as an error (word 3), not waited for.
  *   CVGS_QUEUE_SUBMIT_DEFER_WAIT  the stream is NOT held: the caller orders the consumer itself with cvgs_queue_stream_wait(q, ticket,
  *                                 stream) -- several batches of ONE stream can then be in flight at once (a strictly ordered stream has
- *                                 one, because the next gate sits behind the previous wait).
+ *                                 one, because the next gate sits behind the previous wait).  Until that wait the batch's SOURCES are
+ *                                 in flight too: work enqueued on the stream behind the call runs concurrently with the batch and must
+ *                                 not rewrite them (a strictly ordered call protects both sides).
  *   CVGS_QUEUE_SUBMIT_HYBRID      latency policy ("never slower than without a queue"): stream order costs one launch per gate, so a
  *                                 gate in front of fewer than 8 chains (CVGS_QUEUE_SUBMIT_MIN_GROUP(n) changes the 8) never beats
  *                                 launching them -- such calls, a batch nothing in flight could overlap with, and any chain the

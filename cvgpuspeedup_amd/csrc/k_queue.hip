@@ -1098,6 +1098,7 @@ struct Queue {
     int kind = -1;                      // QK_*: latched by the first submit
     int cus = 0;                        // compute units of the device
     bool direct = false;                // the host writes device memory through the BAR
+    bool g_explicit = false;            // G came from the flags / CVGS_QUEUE_G: the per-kind default below does not apply
     uint8_t* dev_block = nullptr;       // ONE uncached device allocation (host-written): ctl | ring | index | dflags
     uint8_t* dev_counters = nullptr;    // ordinary device memory (device-only): arrival counters | resume words
     QDevMem m{};
@@ -1297,10 +1298,15 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     if (use > 3) use = 3;
     uint32_t G = (uint32_t)(prop.multiProcessorCount * use) - 1;
     q->cus = prop.multiProcessorCount;
-    if ((flags >> 16) & 0xfff) G = (flags >> 16) & 0xfff;
-    else if (const char* ge = getenv("CVGS_QUEUE_G")) { // tuning hook: worker workgroups (the flags' bits 16..27 say the same per queue)
+    if ((flags >> 16) & 0xfff) {
+        G = (flags >> 16) & 0xfff;
+        q->g_explicit = true;
+    } else if (const char* ge = getenv("CVGS_QUEUE_G")) { // tuning hook: worker workgroups (the flags' bits 16..27 say the same per queue)
         const int v = atoi(ge);
-        if (v >= 1 && v <= 4095) G = (uint32_t)v;
+        if (v >= 1 && v <= 4095) {
+            G = (uint32_t)v;
+            q->g_explicit = true;
+        }
     }
     const uint32_t g_cap = (uint32_t)prop.multiProcessorCount * 4u - 1u; // every workgroup must be resident (each worker holds a ticket): 4 per CU at most
     if (G > g_cap) G = g_cap;
@@ -1485,6 +1491,11 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     }
     if (q->kind < 0) {
         q->kind = kind;
+        // The 8-bit pixel worker is bound by the memory system, and TWO workgroups per CU feed it slightly better than three (round 4, A/B
+        // on one box: 2.147 against 2.191 us per 50-crop batch, 0.532 against 0.522; 639: 2.161) -- while the surface kinds, bound by their
+        // arithmetic, lose 5-9 % with two (cfg #3 5.27 against 5.02 us, P010 6.89 against 6.29).  The create call sized everything for
+        // three; nothing has been launched yet, so the kind's default is applied here.
+        if (kind == QK_PIXELS && !q->g_explicit && q->G > (uint32_t)q->cus * 2u - 1u) q->G = (uint32_t)q->cus * 2u - 1u;
         if (kind != QK_PIXELS) { // every workgroup must be resident (each worker holds a ticket): these workers' register budget allows 3 per CU
             int per_cu = 0;
             const hipError_t oe = kind == QK_NV12   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1q_server<1, 2, QK_NV12>, 256, 0)

@@ -391,7 +391,7 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  *                       batch up to the ticket that it has not yet seen complete); cvgs_queue_stream_wait makes a HIP stream
  *                       wait for the same set instead (one hipStreamWaitValue64 per batch still open, on the batches' device-side
  *                       completion words), the consumer's kernels enqueued behind it see the tensors.
- * Tuning hooks (environment): CVGS_QUEUE_G = worker workgroups (default 3 per CU - 1; the flags' bits 16..27 say the same per queue),
+ * Tuning hooks (environment): CVGS_QUEUE_G = worker workgroups (default 2 per CU - 1 for 8-bit pixel crops, 3 per CU - 1 for the other kinds; the flags' bits 16..27 say the same per queue),
  * CVGS_QUEUE_DEEP_ROWS = rows per task of a deep queue (default 64 / 128 by depth), CVGS_QUEUE_STALL_MS, CVGS_QUEUE_STAGED=1, CVGS_QUEUE_DEBUG=1.
  * Submits from several host threads are serialised by a mutex (tickets are handed out in submit order).  cvgs_queue_destroy
  * waits (at most 2 s) for the batches in flight, then retires the server.  Whether the host writes the ring straight into device

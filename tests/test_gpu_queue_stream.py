@@ -241,7 +241,7 @@ def test_a_gate_closed_longer_than_the_stall_limit_is_waiting_not_a_stall(oracle
 
 
 def test_the_watchdog_fires_and_the_queue_recovers(oracle, torch_dev, monkeypatch):
-    """A foreign kernel keeps half of the CUs' LDS for 300 ms, so a third of the server's workgroups cannot become resident; with a 50 ms
+    """A foreign kernel keeps half of the CUs' LDS for 300 ms, so a third of a three-per-CU server's workgroups cannot become resident; with a 50 ms
     stall limit the watchdog reports the batch (CVGS_ERR_HIP on the wait -- not a hang).  cvgs_queue_recover then resets the queue:
     the lost batch is reported through its ticket, later submits are served by a fresh server, bit-exact."""
     torch, dev = torch_dev
@@ -256,7 +256,7 @@ def test_the_watchdog_fires_and_the_queue_recovers(oracle, torch_dev, monkeypatc
     lib = capi.load_library()
     torch.cuda.synchronize()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    q = cvgs.Queue()
+    q = cvgs.Queue(flags=(3 * cus - 1) << 16)                   # three workgroups per CU: more than the half-occupied chip can hold (4 per free CU)
     try:
         q.wait(q.submit_lowered(lowered))                      # a healthy round first
         H.assert_bit_exact(out_t.cpu().numpy(), ref, "before the stall")

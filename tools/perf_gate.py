@@ -30,9 +30,17 @@ ABS_SLACK_US = 1.5
 STREAM_SLACK = 1.6  # rows whose pace is the runtime's stream scheduling (stream-ordered submission): wider
 
 
+def eager_row(name):
+    """rows that cannot be replayed from a graph (a default CircularTensor handle's update, host descriptor tables): timed as eager calls,
+    i.e. paced by the host -- the mirrored ring's 4K -> 1080p push read 14.5 ... 19.7 us between runs of one tree"""
+    return (name.startswith("cfg4") and "CAPTURABLE" not in name) or "eager" in name or "host descriptors" in name
+
+
 def ceiling(name, us):
     if name.startswith("stream-ordered"):
         return round(max(us * STREAM_SLACK, us + ABS_SLACK_US), 2)
+    if eager_row(name):
+        return round(max(us * SLACK, us + 6.0), 2)
     return round(max(us * SLACK, us + ABS_SLACK_US), 2)
 
 

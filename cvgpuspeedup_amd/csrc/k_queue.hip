@@ -1344,7 +1344,8 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     // server instead: tests/test_gpu_queue.py::test_queue_nv12_many_batches_in_flight then failed, and the gate trace did not change.)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (const char* pe = getenv("CVGS_QUEUE_SERVER_PRIO")) { // A/B hook (tools/probes): "low" swaps the two, "normal" = both at priority 0
+    if (const char* pe = getenv("CVGS_QUEUE_SERVER_PRIO")) { // A/B hook (tools/probes): "low" swaps the two, "normal" = both at priority 0 (the server may
+                                                             // then SHARE a hardware queue with a caller's stream: gate kernels wait for ever -- probes only, under `timeout`)
         if (pe[0] == 'l') { const int x = prio_least; prio_least = prio_greatest; prio_greatest = x; }
         if (pe[0] == 'n') prio_least = prio_greatest = 0;
     }

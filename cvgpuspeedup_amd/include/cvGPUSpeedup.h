@@ -505,6 +505,13 @@ private:
 inline void attachQueue(const cv::cuda::Stream& stream, Queue& queue, bool deferWait = false, int minGroup = 0) {
     queue.fk().attach(cv::cuda::StreamAccessor::getStream(stream), deferWait, minGroup);
 }
+// Recorded ticks: the reference's loop UNCHANGED -- one cvGS::executeOperations(stream, ...) per camera, one stream.waitForCompletion() (or
+// cvGS::fence(stream)) per tick -- on a stream attached with attachQueueTicks: the calls are recorded (0.14 us each) and go to the queue's
+// server `tick` at a time behind one gate; waitForCompletion / fence submit what is pending first.  Sources and tensors of recorded calls
+// are in flight until then (the deferred-wait contract).
+inline void attachQueueTicks(const cv::cuda::Stream& stream, Queue& queue, int tick = 16) {
+    queue.fk().attachTicks(cv::cuda::StreamAccessor::getStream(stream), tick);
+}
 inline void detachQueue(const cv::cuda::Stream& stream) { fk::Queue::detach(cv::cuda::StreamAccessor::getStream(stream)); }
 inline void fence(const cv::cuda::Stream& stream) { fk::Queue::fence(cv::cuda::StreamAccessor::getStream(stream)); }
 inline bool lastTicket(const cv::cuda::Stream& stream, uint64_t* ticket) { return fk::Queue::lastTicket(cv::cuda::StreamAccessor::getStream(stream), ticket); }

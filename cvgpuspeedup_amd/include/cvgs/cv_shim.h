@@ -287,11 +287,21 @@ inline Mat getPerspectiveTransform(const Point2f src[4], const Point2f dst[4]) {
 
 namespace cuda {
 
+// hook of the facade's attached streams (fk_compat.h: streams attached to a descriptor queue with recorded ticks flush and fence before the
+// host waits) -- null unless a stream has been attached
+inline void (*&cvgs_stream_sync_hook())(hipStream_t) {
+    static void (*hook)(hipStream_t) = nullptr;
+    return hook;
+}
+
 class Stream {
 public:
     Stream() : impl_(std::make_shared<Impl>(true)) {}
     static Stream& Null() { static Stream s{nullptr, 0}; return s; }
-    void waitForCompletion() const { cvgs_hip_check(hipStreamSynchronize(impl_->s), "hipStreamSynchronize"); }
+    void waitForCompletion() const {
+        if (auto hook = cvgs_stream_sync_hook()) hook(impl_->s);
+        cvgs_hip_check(hipStreamSynchronize(impl_->s), "hipStreamSynchronize");
+    }
     hipStream_t raw() const { return impl_->s; }
     static Stream wrap(hipStream_t s) { return Stream(s, 0); }
 

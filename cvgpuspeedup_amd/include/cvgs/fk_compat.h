@@ -741,6 +741,10 @@ struct StreamAttachment {
     uint32_t flags;       // CVGS_QUEUE_SUBMIT_* (HYBRID always set)
     uint64_t last_ticket; // DEFER_WAIT streams: what fence() orders the stream behind
     bool has_ticket;
+    // recorded ticks (attachTicks): executeOperations calls are RECORDED and go behind one gate when `tick` of them are pending, at
+    // fence() / cv::cuda::Stream::waitForCompletion() / detach
+    int tick = 0;
+    std::vector<std::unique_ptr<ChainBuilder>> pending;
 };
 struct StreamAttachments {
     std::atomic<bool> any{false};
@@ -750,6 +754,56 @@ struct StreamAttachments {
 inline StreamAttachments& stream_attachments() {
     static StreamAttachments a;
     return a;
+}
+// submit what a recording stream has pending: ONE cvgs_queue_submit_many_on per <= 64 chains (the pending list is taken under the lock, the
+// submit runs outside it)
+inline void flush_attached(hipStream_t stream) {
+    StreamAttachments& A = stream_attachments();
+    std::vector<std::unique_ptr<ChainBuilder>> take;
+    cvgs_queue_t q = nullptr;
+    uint32_t flags = 0;
+    {
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (auto& a : A.list)
+            if (a.stream == stream) { take.swap(a.pending); q = a.queue; flags = a.flags; break; }
+    }
+    if (!q || take.empty()) return;
+    std::vector<const cvgs_chain_desc*> ptrs(take.size());
+    for (size_t i = 0; i < take.size(); ++i) ptrs[i] = &take[i]->d;
+    uint64_t last = CVGS_QUEUE_TICKET_DIRECT, newest = CVGS_QUEUE_TICKET_DIRECT;
+    for (size_t base = 0; base < ptrs.size(); base += CVGS_QUEUE_MAX_GROUP) {
+        const size_t cnt = ptrs.size() - base < (size_t)CVGS_QUEUE_MAX_GROUP ? ptrs.size() - base : (size_t)CVGS_QUEUE_MAX_GROUP;
+        check_status(cvgs_queue_submit_many_on(q, ptrs.data() + base, (int32_t)cnt, stream, flags, &last));
+        if (last != CVGS_QUEUE_TICKET_DIRECT) newest = last;
+    }
+    if (newest != CVGS_QUEUE_TICKET_DIRECT) {
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (auto& a : A.list)
+            if (a.stream == stream) { a.last_ticket = newest; a.has_ticket = true; break; }
+    }
+}
+// a recording stream takes the chain (true) -- and flushes when the tick is full
+inline bool record_attached(hipStream_t stream, std::unique_ptr<ChainBuilder>& b) {
+    StreamAttachments& A = stream_attachments();
+    bool full = false;
+    {
+        std::lock_guard<std::mutex> lock(A.mu);
+        StreamAttachment* at = nullptr;
+        for (auto& a : A.list)
+            if (a.stream == stream) { at = &a; break; }
+        if (!at || at->tick <= 0) return false;
+        at->pending.push_back(std::move(b));
+        full = (int)at->pending.size() >= at->tick;
+    }
+    if (full) flush_attached(stream);
+    return true;
+}
+inline bool stream_records(hipStream_t stream) {
+    StreamAttachments& A = stream_attachments();
+    std::lock_guard<std::mutex> lock(A.mu);
+    for (const auto& a : A.list)
+        if (a.stream == stream) return a.tick > 0;
+    return false;
 }
 inline bool submit_attached(hipStream_t stream, const cvgs_chain_desc* d) {
     StreamAttachments& A = stream_attachments();
@@ -774,6 +828,13 @@ inline bool submit_attached(hipStream_t stream, const cvgs_chain_desc* d) {
 
 template <bool THREAD_FUSION = true, typename... IOps>
 inline void executeOperations(hipStream_t stream, const IOps&... iops) {
+    if (detail::stream_attachments().any.load(std::memory_order_acquire) && detail::stream_records(stream)) {
+        std::unique_ptr<ChainBuilder> rec(new ChainBuilder); // recorded: the builder outlives this call (it owns the descriptor's arrays)
+        lowerChain(*rec, iops...);
+        if (detail::record_attached(stream, rec)) return;
+        detail::check_status(cvgs_execute(&rec->d, stream)); // (detached in between)
+        return;
+    }
     ChainBuilder b;
     lowerChain(b, iops...);
     // THREAD_FUSION = false is a tuning hint of the reference (its fused-thread path does not cover every type; the reference's
@@ -863,6 +924,15 @@ public:
         if (!q_) return;
         {
             detail::StreamAttachments& A = detail::stream_attachments();
+            std::vector<hipStream_t> mine;
+            {
+                std::lock_guard<std::mutex> lock(A.mu);
+                for (const auto& a : A.list)
+                    if (a.queue == q_ && !a.pending.empty()) mine.push_back(a.stream);
+            }
+            for (hipStream_t s : mine) { // recorded calls are not dropped with the queue
+                try { detail::flush_attached(s); } catch (...) {}
+            }
             std::lock_guard<std::mutex> lock(A.mu);
             for (size_t i = A.list.size(); i-- > 0;)
                 if (A.list[i].queue == q_) A.list.erase(A.list.begin() + (long)i);
@@ -904,7 +974,20 @@ public:
         A.list.push_back(detail::StreamAttachment{stream, q_, f, 0, false});
         A.any.store(true, std::memory_order_release);
     }
+    // RECORDED TICKS: executeOperations(stream, ...) calls on `stream` are recorded and submitted `tick` at a time behind ONE gate (deferred
+    // waits); fence(stream) -- which cv::cuda::Stream::waitForCompletion() calls first -- submits what is pending and orders the stream
+    // behind it.  The reference's multi-camera loop (one call per camera, one synchronisation per tick) gets the queue's speed unchanged.
+    // Contract (as deferWait): sources and tensors of recorded calls are in flight until the fence; do not rewrite / read them before.
+    void attachTicks(hipStream_t stream, int tick = 16) {
+        attach(stream, /*deferWait=*/true, /*minGroup=*/0);
+        detail::StreamAttachments& A = detail::stream_attachments();
+        std::lock_guard<std::mutex> lock(A.mu);
+        for (auto& a : A.list)
+            if (a.stream == stream) a.tick = tick < 1 ? 1 : (tick > 4 * CVGS_QUEUE_MAX_GROUP ? 4 * CVGS_QUEUE_MAX_GROUP : tick);
+        cv::cuda::cvgs_stream_sync_hook() = &Queue::fence;
+    }
     static void detach(hipStream_t stream) {
+        detail::flush_attached(stream);
         detail::StreamAttachments& A = detail::stream_attachments();
         std::lock_guard<std::mutex> lock(A.mu);
         for (size_t i = 0; i < A.list.size(); ++i)
@@ -923,6 +1006,8 @@ public:
     // deferWait streams: order everything enqueued on `stream` from here on behind the batches it has submitted so far
     static void fence(hipStream_t stream) {
         detail::StreamAttachments& A = detail::stream_attachments();
+        if (!A.any.load(std::memory_order_acquire)) return;
+        detail::flush_attached(stream);
         cvgs_queue_t q = nullptr;
         uint64_t t = 0;
         {

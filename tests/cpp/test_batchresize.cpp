@@ -395,6 +395,100 @@ static void test_attached_streams_vs_oracle() {
     }
 }
 
+// engine extension (ABI 5, recorded ticks): the reference's multi-camera loop UNCHANGED -- one executeOperations(stream, ...) per camera,
+// one waitForCompletion() per tick -- on a stream attached with attachQueueTicks.  CAMS cameras and a tick of 16: the calls go behind
+// gates 16 at a time and the rest at the fence (fewer than 8 left: launches, the hybrid policy) -- every tensor must have the oracle's bits,
+// with the frames REWRITTEN on the stream between ticks.
+template <int TI, int TO, int BATCH, int CAMS>
+static void test_recorded_ticks_vs_oracle(bool fence_then_async) {
+    constexpr int CN = CV_MAT_CN(TO);
+    const Params& p = kParams[CN - 1];
+    const cv::Size up(64, 128);
+    const int POOL = 3, TICKS = 12;
+    const size_t n = (size_t)BATCH * CN * up.width * up.height;
+    cvGS::Queue queue(0, 0, 5000.0);
+    cv::cuda::Stream stream;
+    hipStream_t s = cv::cuda::StreamAccessor::getStream(stream);
+    struct Cam {
+        std::vector<cv::cuda::GpuMat> d_pool;
+        std::vector<cv::Mat> refs;
+        cv::cuda::GpuMat frame, tensor;
+        std::array<cv::Rect, BATCH> rects;
+        float* host = nullptr;
+    };
+    std::vector<std::unique_ptr<Cam>> cams;
+    for (int c = 0; c < CAMS; ++c) {
+        cams.emplace_back(new Cam);
+        Cam& cam = *cams.back();
+        cam.frame = cv::cuda::GpuMat(360, 640, TI);
+        cam.tensor = cv::cuda::GpuMat(BATCH, up.width * up.height * CN, CV_32F);
+        for (int i = 0; i < BATCH; ++i) {
+            const int w = 8 + ((i + c) * 37) % 300, hgt = 16 + ((i + 2 * c) * 53) % 300;
+            cam.rects[i] = cv::Rect(((i + c) * 91) % (640 - w), (i * 67 + c) % (360 - hgt), w, hgt);
+        }
+        for (int k = 0; k < POOL; ++k) {
+            cv::Mat h(360, 640, TI);
+            fill_random(h, 0xABCDull + 100 * c + k);
+            cam.d_pool.emplace_back(h);
+            cv::cuda::GpuMat hv_frame = host_view(h);
+            std::array<cv::cuda::GpuMat, BATCH> h_crops;
+            for (int i = 0; i < BATCH; ++i) h_crops[i] = hv_frame(cam.rects[i]);
+            cam.refs.emplace_back(BATCH, up.width * up.height * CN, CV_32F);
+            cv::cuda::GpuMat hv_ref = host_view(cam.refs.back());
+            std::apply([&](const auto&... iops) { run_oracle(iops...); }, build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(h_crops, hv_ref, up, p));
+        }
+        HIP_OK(hipHostMalloc((void**)&cam.host, n * sizeof(float), hipHostMallocDefault));
+    }
+    cvGS::attachQueueTicks(stream, queue, 16);
+    int bad = 0;
+    for (int t = 0; t < TICKS; ++t) {
+        for (auto& cp : cams) { // the producers: the frames of this tick arrive on the stream (the previous tick was fenced)
+            Cam& cam = *cp;
+            const cv::cuda::GpuMat& src = cam.d_pool[(size_t)(t % POOL)];
+            HIP_OK(hipMemcpy2DAsync(cam.frame.data, cam.frame.step, src.data, src.step, (size_t)cam.frame.cols * cam.frame.elemSize(),
+                                    (size_t)cam.frame.rows, hipMemcpyDeviceToDevice, s));
+        }
+        for (auto& cp : cams) {
+            Cam& cam = *cp;
+            std::array<cv::cuda::GpuMat, BATCH> crops;
+            for (int i = 0; i < BATCH; ++i) crops[i] = cam.frame(cam.rects[i]);
+            std::apply([&](const auto&... iops) { cvGS::executeOperations(stream, iops...); },
+                       build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(crops, cam.tensor, up, p));
+        } // (crops -- the GpuMat headers -- die here: the recorded chains own their descriptors)
+        if (fence_then_async) {
+            cvGS::fence(stream); // consumers enqueued from here on follow the tick
+            for (auto& cp : cams) HIP_OK(hipMemcpyAsync(cp->host, cp->tensor.data, n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+        } else {
+            stream.waitForCompletion(); // the reference's synchronisation: submits what is pending, fences, waits
+            for (auto& cp : cams) HIP_OK(hipMemcpy(cp->host, cp->tensor.data, n * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        for (auto& cp : cams)
+            if (!bit_equal(cp->host, cp->refs[(size_t)(t % POOL)].data, n * sizeof(float))) ++bad;
+    }
+    CHECK(bad == 0, "recorded ticks (attachQueueTicks, " << CAMS << " cameras, " << (fence_then_async ? "fence + async consumers" : "waitForCompletion")
+                        << "): " << bad << " of " << CAMS * TICKS << " tensors differ from the oracle, type " << TI);
+    // recorded calls are not lost at detach: record, detach (submits), synchronise, compare
+    for (auto& cp : cams) HIP_OK(hipMemsetAsync(cp->tensor.data, 0, n * sizeof(float), s));
+    for (auto& cp : cams) {
+        Cam& cam = *cp;
+        std::array<cv::cuda::GpuMat, BATCH> crops;
+        for (int i = 0; i < BATCH; ++i) crops[i] = cam.frame(cam.rects[i]);
+        std::apply([&](const auto&... iops) { cvGS::executeOperations(stream, iops...); },
+                   build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(crops, cam.tensor, up, p));
+    }
+    cvGS::fence(stream);
+    cvGS::detachQueue(stream);
+    HIP_OK(hipStreamSynchronize(s));
+    int bad2 = 0;
+    for (auto& cp : cams) {
+        HIP_OK(hipMemcpy(cp->host, cp->tensor.data, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (!bit_equal(cp->host, cp->refs[(size_t)((TICKS - 1) % POOL)].data, n * sizeof(float))) ++bad2;
+        (void)hipHostFree(cp->host);
+    }
+    CHECK(bad2 == 0, "recorded ticks: fence + detach leave " << bad2 << " tensors wrong");
+}
+
 int main() {
     cv::cuda::Stream stream;
     // the type list of the reference's LAUNCH_TESTS (test_batchresize_x_split3D.cu:427-432)
@@ -416,5 +510,7 @@ int main() {
     test_queue_vs_oracle<CV_8UC3, CV_32FC3, 100>(stream); // more crops than a ring slot holds (74): two slots behind one ticket
     test_attached_streams_vs_oracle<CV_8UC3, CV_32FC3, 40>();
     test_attached_streams_vs_oracle<CV_8UC4, CV_32FC4, 9>();
+    test_recorded_ticks_vs_oracle<CV_8UC3, CV_32FC3, 20, 27>(/*fence_then_async=*/false); // 16 behind a gate + 11 at the fence
+    test_recorded_ticks_vs_oracle<CV_8UC4, CV_32FC4, 7, 21>(/*fence_then_async=*/true);   // 16 behind a gate + 5 launches at the fence
     return report("test_batchresize_x_split3D + aspectratio");
 }

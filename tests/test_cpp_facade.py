@@ -52,10 +52,11 @@ def test_readme_example_runs():
 @pytest.mark.gpu
 def test_serving_ticks_example_runs():
     """examples/serving_ticks.cpp: the reference's loop (one executeOperations per frame behind a producer) against ChainBatch ticks on
-    streams ATTACHED to a descriptor queue (deferred waits / strictly ordered): the ticks' tensors must equal the loop's bit for bit."""
+    streams ATTACHED to a descriptor queue (deferred waits / strictly ordered / the loop unchanged with recorded ticks): the ticks' tensors
+    must equal the loop's bit for bit."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(ROOT, "examples", "bin", "serving_ticks")], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.count("bit for bit") == 2, r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.count("bit for bit") == 3, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

@@ -469,12 +469,37 @@ def attachQueue(stream, queue, deferWait=False, minGroup=0):
     _ATTACHED[stream_handle(stream)] = [queue, Queue.HYBRID | (Queue.DEFER_WAIT if deferWait else 0) | ((minGroup & 0xff) << 8), None]
 
 
+def attachQueueTicks(stream, queue, tick=16):
+    """cvGS::attachQueueTicks(stream, queue, tick): executeOperations(stream, ...) calls on this stream are RECORDED and submitted `tick` at
+    a time behind one gate (cvgs_queue_submit_many_on, deferred waits); fence(stream) / detachQueue(stream) submit what is pending.
+    Sources and tensors of recorded calls are in flight until the fence."""
+    attachQueue(stream, queue, deferWait=True)
+    a = _ATTACHED[stream_handle(stream)]
+    a += [max(1, min(int(tick), 4 * 64)), []]
+
+
+def _flush(stream, a):
+    if len(a) < 5 or not a[4]:
+        return
+    pending, a[4] = a[4], []
+    for base in range(0, len(pending), 64):
+        group = pending[base:base + 64]
+        t = a[0].submit_many_on(stream, Queue.chain_pointers(group), len(group), a[1])
+        if t != Queue.TICKET_DIRECT:
+            a[2] = t
+
+
 def detachQueue(stream):
+    a = _ATTACHED.get(stream_handle(stream))
+    if a is not None:
+        _flush(stream, a)
     _ATTACHED.pop(stream_handle(stream), None)
 
 
 def fence(stream):
     a = _ATTACHED.get(stream_handle(stream))
+    if a:
+        _flush(stream, a)
     if a and a[2] is not None:
         a[0].stream_wait(a[2], stream)
         a[2] = None
@@ -487,6 +512,11 @@ def executeOperations(stream, *iops, flags=0):
     lib = capi.load_library()
     lowered = lower(iops, flags)
     a = _ATTACHED.get(stream_handle(stream)) if _ATTACHED else None
+    if a is not None and len(a) >= 5:  # recorded ticks
+        a[4].append(lowered)
+        if len(a[4]) >= a[3]:
+            _flush(stream, a)
+        return lowered
     if a is not None:
         t = a[0].submit_lowered_on(stream, lowered, a[1])
         if (a[1] & Queue.DEFER_WAIT) and t != Queue.TICKET_DIRECT:

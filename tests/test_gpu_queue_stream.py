@@ -354,6 +354,45 @@ def test_attach_queue_keeps_the_call_shape(oracle, torch_dev):
         q.destroy()
 
 
+def test_recorded_ticks_keep_the_loop_unchanged(oracle, torch_dev):
+    """cvgs.attachQueueTicks(stream, queue, 16): the multi-camera loop as the reference's users write it -- one executeOperations(stream, ...)
+    per camera, one fence per tick -- with 21 cameras on ONE stream: 16 calls go behind a gate when the 16th is recorded, the other 5 at the
+    fence (launches: fewer than 8); the frames are rewritten on the stream between ticks; the consumers run on the stream behind the fence."""
+    torch, dev = torch_dev
+    cams = [Camera(torch, dev, oracle, seed=300 + k, n_crops=6, pool=3, wh=(640, 360)) for k in range(21)]
+    stream = cams[0].stream
+    for c in cams:
+        c.stream = stream
+        warm(torch, c)
+    q = cvgs.Queue(idle_us=5000.0)
+    try:
+        cvgs.attachQueueTicks(stream, q, 16)
+        with torch.cuda.stream(stream):
+            for i in range(40):
+                for c in cams:
+                    c.produce(i)
+                for c in cams:
+                    ops = H.k1_chain(cvgs.GpuMat.from_tensor(c.frame, cvgs.CV_8UC3), c.crops, cvgs.GpuMat.from_tensor(c.out, cvgs.CV_32FC1), DST, CN)
+                    cvgs.executeOperations(stream, *ops)
+                cvgs.fence(stream)
+                for c in cams:
+                    c.consume(i)
+            for c in cams:  # recorded calls are submitted at detach as well
+                c.produce(1)
+            for c in cams:
+                cvgs.executeOperations(stream, *H.k1_chain(cvgs.GpuMat.from_tensor(c.frame, cvgs.CV_8UC3), c.crops, cvgs.GpuMat.from_tensor(c.out, cvgs.CV_32FC1), DST, CN))
+            cvgs.fence(stream)
+            cvgs.detachQueue(stream)
+            for c in cams:
+                c.consume(1)
+        stream.synchronize()
+        st = q.stats()
+        assert st["error"] == 0 and st["submitted"] == 41 * 16, st
+        assert sum(int(c.bad.item()) for c in cams) == 0
+    finally:
+        q.destroy()
+
+
 def test_destroy_with_a_gate_kernel_still_behind_its_producer(oracle, torch_dev):
     """cvgs_queue_destroy while a stream-ordered batch's gate kernel has not run yet (a 150 ms producer in front of it): the destroy waits
     its bounded time, releases whatever is waiting and drains the device BEFORE it frees the words those kernels read -- no fault, the

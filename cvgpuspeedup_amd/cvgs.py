@@ -466,6 +466,9 @@ def attachQueue(stream, queue, deferWait=False, minGroup=0):
     """cvGS::attachQueue(stream, queue): executeOperations(stream, ...) on this stream goes through the queue from now on, stream-ordered
     (cvgs_queue_submit_on, hybrid latency policy: groups below minGroup -- default 8 -- stay launches); deferWait: the stream is not held
     on each batch, fence(stream) orders the consumer."""
+    prev = _ATTACHED.get(stream_handle(stream))
+    if prev is not None:
+        _flush(stream, prev)  # (calls a previous attachment recorded)
     _ATTACHED[stream_handle(stream)] = [queue, Queue.HYBRID | (Queue.DEFER_WAIT if deferWait else 0) | ((minGroup & 0xff) << 8), None]
 
 
@@ -478,10 +481,29 @@ def attachQueueTicks(stream, queue, tick=16):
     a += [max(1, min(int(tick), 4 * 64)), []]
 
 
+def recordTicks(stream, tick=16):
+    """cvGS::recordTicks(stream, tick): recorded ticks with NO queue -- the recorded calls are launched `tick` at a time as ONE multi-chain
+    kernel (cvgs_execute_many), strictly stream-ordered; fence(stream) / stopRecording(stream) launch what is pending."""
+    a = _ATTACHED.get(stream_handle(stream))
+    if a is not None:
+        _flush(stream, a)
+    _ATTACHED[stream_handle(stream)] = [None, 0, None, max(1, min(int(tick), 128)), []]
+
+
+def stopRecording(stream):
+    detachQueue(stream)
+
+
 def _flush(stream, a):
     if len(a) < 5 or not a[4]:
         return
     pending, a[4] = a[4], []
+    if a[0] is None:  # no queue: one cvgs_execute_many launch per <= 128 chains
+        lib = capi.load_library()
+        for base in range(0, len(pending), 128):
+            group = pending[base:base + 128]
+            capi.check(lib.cvgs_execute_many(pack_chains(group), len(group), stream_handle(stream)))
+        return
     for base in range(0, len(pending), 64):
         group = pending[base:base + 64]
         t = a[0].submit_many_on(stream, Queue.chain_pointers(group), len(group), a[1])

@@ -276,6 +276,31 @@ inline fk::WarpingParameters<fk::WarpType::Perspective> warp_getWarpingPerspecti
     p.dstSize = fk::Size(dstSize.width, dstSize.height);
     return p;
 }
+// the batch spellings (include/cvGPUSpeedup.cuh:311-377): FORWARD transforms in, the device's (inverted, float) parameters out; entries at
+// and beyond usedPlanes stay value-initialised
+template <size_t BATCH>
+inline auto warp_batchAffineParameters_helper_rt(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize, const size_t& idx) {
+    return warp_parameters<fk::WarpType::Affine>(transform_matrices[idx], dstSize[idx]);
+}
+template <size_t Idx, size_t BATCH>
+inline auto warp_batchAffineParameters_helper(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize) {
+    return warp_batchAffineParameters_helper_rt(transform_matrices, dstSize, Idx);
+}
+template <size_t BATCH>
+inline auto warp_batchPerspectiveParameters_helper_rt(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize, const size_t& idx) {
+    return warp_parameters<fk::WarpType::Perspective>(transform_matrices[idx], dstSize[idx]);
+}
+template <size_t Idx, size_t BATCH>
+inline auto warp_batchPerspectiveParameters_helper(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize) {
+    return warp_batchPerspectiveParameters_helper_rt(transform_matrices, dstSize, Idx);
+}
+template <fk::WarpType WT, size_t BATCH>
+inline std::array<fk::WarpingParameters<WT>, BATCH> warp_batchParameters(const std::array<cv::Mat, BATCH>& transform_matrices,
+                                                                         const std::array<cv::Size, BATCH>& dstSize, const int& usedPlanes = BATCH) {
+    std::array<fk::WarpingParameters<WT>, BATCH> out{};
+    for (int i = 0; i < usedPlanes && i < (int)BATCH; ++i) out[(size_t)i] = warp_parameters<WT>(transform_matrices[(size_t)i], dstSize[(size_t)i]);
+    return out;
+}
 } // namespace internal
 
 template <fk::WarpType WT, int InputType = CV_8UC3>
@@ -512,6 +537,10 @@ inline void attachQueue(const cv::cuda::Stream& stream, Queue& queue, bool defer
 inline void attachQueueTicks(const cv::cuda::Stream& stream, Queue& queue, int tick = 16) {
     queue.fk().attachTicks(cv::cuda::StreamAccessor::getStream(stream), tick);
 }
+// The same with NO queue: the recorded calls are launched `tick` at a time as ONE multi-chain kernel (cvgs_execute_many), strictly
+// stream-ordered, nothing resident on the GPU between ticks.  stopRecording (or detachQueue) launches what is pending and ends it.
+inline void recordTicks(const cv::cuda::Stream& stream, int tick = 16) { fk::recordTicks(cv::cuda::StreamAccessor::getStream(stream), tick); }
+inline void stopRecording(const cv::cuda::Stream& stream) { fk::stopRecording(cv::cuda::StreamAccessor::getStream(stream)); }
 inline void detachQueue(const cv::cuda::Stream& stream) { fk::Queue::detach(cv::cuda::StreamAccessor::getStream(stream)); }
 inline void fence(const cv::cuda::Stream& stream) { fk::Queue::fence(cv::cuda::StreamAccessor::getStream(stream)); }
 inline bool lastTicket(const cv::cuda::Stream& stream, uint64_t* ticket) { return fk::Queue::lastTicket(cv::cuda::StreamAccessor::getStream(stream), ticket); }

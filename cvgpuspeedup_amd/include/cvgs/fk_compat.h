@@ -767,7 +767,16 @@ inline void flush_attached(hipStream_t stream) {
         for (auto& a : A.list)
             if (a.stream == stream) { take.swap(a.pending); q = a.queue; flags = a.flags; break; }
     }
-    if (!q || take.empty()) return;
+    if (take.empty()) return;
+    if (!q) { // recording without a queue (fk::recordTicks): ONE cvgs_execute_many launch per <= CVGS_MAX_CHAINS chains, strictly ordered
+        std::vector<cvgs_chain_desc> flat(take.size());
+        for (size_t i = 0; i < take.size(); ++i) flat[i] = take[i]->d;
+        for (size_t base = 0; base < flat.size(); base += CVGS_MAX_CHAINS) {
+            const size_t cnt = flat.size() - base < (size_t)CVGS_MAX_CHAINS ? flat.size() - base : (size_t)CVGS_MAX_CHAINS;
+            check_status(cvgs_execute_many(flat.data() + base, (int32_t)cnt, stream));
+        }
+        return;
+    }
     std::vector<const cvgs_chain_desc*> ptrs(take.size());
     for (size_t i = 0; i < take.size(); ++i) ptrs[i] = &take[i]->d;
     uint64_t last = CVGS_QUEUE_TICKET_DIRECT, newest = CVGS_QUEUE_TICKET_DIRECT;
@@ -871,6 +880,7 @@ public:
         for (size_t i = 0; i < builders_.size(); ++i) descs_[i] = builders_[i]->d; // POD copy; the builders keep the arrays alive
         // a stream attached to a queue: the tick's chains go behind ONE gate on the stream (cvgs_queue_submit_many_on), 64 at a time
         if (detail::stream_attachments().any.load(std::memory_order_acquire)) {
+            detail::flush_attached(stream); // calls recorded on this stream before the batch go first
             cvgs_queue_t q = nullptr;
             uint32_t flags = 0;
             detail::StreamAttachments& A = detail::stream_attachments();
@@ -967,6 +977,7 @@ public:
     // minGroup: the smallest number of chains behind one gate the server takes (0 = the engine's default, 8; 1 = always the server)
     void attach(hipStream_t stream, bool deferWait = false, int minGroup = 0) {
         detail::StreamAttachments& A = detail::stream_attachments();
+        if (A.any.load(std::memory_order_acquire)) detail::flush_attached(stream); // (calls a previous attachment recorded)
         std::lock_guard<std::mutex> lock(A.mu);
         const uint32_t f = CVGS_QUEUE_SUBMIT_HYBRID | (deferWait ? CVGS_QUEUE_SUBMIT_DEFER_WAIT : 0u) | CVGS_QUEUE_SUBMIT_MIN_GROUP(minGroup);
         for (auto& a : A.list)
@@ -1025,6 +1036,24 @@ template <bool THREAD_FUSION = true, typename... IOps>
 inline uint64_t executeOperations(Queue& queue, const IOps&... iops) {
     return queue.submit(iops...);
 }
+// RECORDED TICKS WITHOUT A QUEUE: executeOperations(stream, ...) calls on `stream` are recorded and launched `tick` at a time as ONE
+// multi-chain kernel (cvgs_execute_many) -- strictly stream-ordered, no resident server; Queue::fence(stream) /
+// cv::cuda::Stream::waitForCompletion() / stopRecording launch what is pending.  Recorded calls are in flight until then (a consumer
+// enqueued on the stream before the fence is not ordered behind them).
+inline void recordTicks(hipStream_t stream, int tick = 16) {
+    detail::StreamAttachments& A = detail::stream_attachments();
+    detail::flush_attached(stream);
+    std::lock_guard<std::mutex> lock(A.mu);
+    detail::StreamAttachment at{stream, nullptr, 0u, 0, false};
+    at.tick = tick < 1 ? 1 : (tick > CVGS_MAX_CHAINS ? CVGS_MAX_CHAINS : tick);
+    bool found = false;
+    for (auto& a : A.list)
+        if (a.stream == stream) { a = std::move(at); found = true; break; }
+    if (!found) A.list.push_back(std::move(at));
+    A.any.store(true, std::memory_order_release);
+    cv::cuda::cvgs_stream_sync_hook() = &Queue::fence;
+}
+inline void stopRecording(hipStream_t stream) { Queue::detach(stream); }
 
 // ---- CircularTensor ------------------------------------------------------------------------------------------------
 // MIRRORED (engine extension, default off = the reference's behaviour): the opt-in mirrored-ring layout of

@@ -1,11 +1,13 @@
-// serving_ticks.cpp -- the reference's call shape in a serving loop, four ways (engine extension of round 4; DESIGN.md 4 "Round 4"):
+// serving_ticks.cpp -- the reference's call shape in a serving loop, six ways (engine extension of round 4; DESIGN.md 4 "Round 4"):
 //   A. cvGS::executeOperations(stream, iops...) per frame, a producer on the stream in front of each call -- the reference's loop
 //      (include/cvGPUSpeedup.cuh:464-473), one kernel launch per frame;
 //   B. the same frames recorded 16 at a time in a cvGS::ChainBatch and executed on a stream ATTACHED to a descriptor queue with deferred
 //      waits: one gate kernel per tick behind the producer, the tick's consumer ordered two ticks later (queue.wait(ticket, stream));
 //   C. the same ticks, strictly ordered (the stream is held on every tick), alternating over two attached streams;
 //   D. loop A UNCHANGED on a stream attached with cvGS::attachQueueTicks(stream, queue, 16): the calls are recorded and go to the server 16
-//      at a time; stream.waitForCompletion() submits what is pending and fences.
+//      at a time; stream.waitForCompletion() submits what is pending and fences;
+//   E. B's ticks on a PLAIN stream: ChainBatch::execute = ONE cvgs_execute_many launch per tick, strictly ordered, no queue;
+//   F. loop A unchanged with cvGS::recordTicks(stream, 16): as D with no queue -- one multi-chain launch per 16 recorded calls.
 // Host wall clock per frame, including the final synchronise; B's and C's tensors are compared with A's bit for bit.
 //   make -C examples && GPU_MAX_HW_QUEUES=3 ./examples/bin/serving_ticks
 #include <cvGPUSpeedup.cuh>
@@ -142,6 +144,31 @@ int main() {
     const auto got_d = snapshot();
     cvGS::detachQueue(sd);
 
+    // ---- E: the same ticks with NO queue: ChainBatch::execute on a plain stream = ONE cvgs_execute_many launch per tick, strictly ordered ---
+    cv::cuda::Stream se;
+    const double us_e = timed_us([&]() {
+        cvGS::ChainBatch tick;
+        for (int i = 0; i < TOTAL; i += TICK) {
+            (void)hipMemsetAsync(scratch, i & 255, 64, cv::cuda::StreamAccessor::getStream(se));
+            tick.clear();
+            for (int k = 0; k < TICK; ++k) chain(*fr[(i + k) % FRAMES], [&](const auto&... iops) { tick.add(iops...); });
+            tick.execute(se);
+        }
+    }, [&]() { se.waitForCompletion(); });
+    const auto got_e = snapshot();
+
+    // ---- F: loop A unchanged on a stream that records ticks with NO queue (one cvgs_execute_many launch per 16 calls) ------------------------
+    cv::cuda::Stream sf;
+    cvGS::recordTicks(sf, TICK);
+    const double us_f = timed_us([&]() {
+        for (int i = 0; i < TOTAL; ++i) {
+            (void)hipMemsetAsync(scratch, i & 255, 64, cv::cuda::StreamAccessor::getStream(sf));
+            chain(*fr[i % FRAMES], [&](const auto&... iops) { cvGS::executeOperations(sf, iops...); });
+        }
+    }, [&]() { sf.waitForCompletion(); });
+    const auto got_f = snapshot();
+    cvGS::stopRecording(sf);
+
     // what the HOST pays per frame in B: recording the frame's chain (IOps -> descriptor) and the queue's submit (geometry in double, slot)
     double us_record = 0;
     {
@@ -153,18 +180,22 @@ int main() {
         }
         us_record = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / TOTAL;
     }
-    bool same_b = true, same_c = true, same_d = true;
+    bool same_b = true, same_c = true, same_d = true, same_e = true, same_f = true;
     for (int f = 0; f < FRAMES; ++f) {
         same_b = same_b && std::memcmp(ref[f].data(), got_b[f].data(), tbytes) == 0;
         same_c = same_c && std::memcmp(ref[f].data(), got_c[f].data(), tbytes) == 0;
         same_d = same_d && std::memcmp(ref[f].data(), got_d[f].data(), tbytes) == 0;
+        same_e = same_e && std::memcmp(ref[f].data(), got_e[f].data(), tbytes) == 0;
+        same_f = same_f && std::memcmp(ref[f].data(), got_f[f].data(), tbytes) == 0;
     }
     const double px = (double)N * up.width * up.height;
     std::printf("A  executeOperations(stream, ...) per frame, producer on the stream          : %6.2f us per frame  %6.1f Gpix/s\n", us_a, px / us_a / 1e3);
     std::printf("B  ChainBatch of %d frames on an attached stream, waits deferred two ticks   : %6.2f us per frame  %6.1f Gpix/s  (== A: %s)\n", TICK, us_b, px / us_b / 1e3, same_b ? "bit for bit" : "DIFFERENT");
     std::printf("C  ChainBatch of %d frames, strictly ordered, two attached streams           : %6.2f us per frame  %6.1f Gpix/s  (== A: %s)\n", TICK, us_c, px / us_c / 1e3, same_c ? "bit for bit" : "DIFFERENT");
     std::printf("D  loop A unchanged on a stream attached with attachQueueTicks(.., %d)        : %6.2f us per frame  %6.1f Gpix/s  (== A: %s)\n", TICK, us_d, px / us_d / 1e3, same_d ? "bit for bit" : "DIFFERENT");
+    std::printf("E  ChainBatch of %d frames on a PLAIN stream (one cvgs_execute_many launch)   : %6.2f us per frame  %6.1f Gpix/s  (== A: %s)\n", TICK, us_e, px / us_e / 1e3, same_e ? "bit for bit" : "DIFFERENT");
+    std::printf("F  loop A unchanged on a stream with recordTicks(.., %d), no queue             : %6.2f us per frame  %6.1f Gpix/s  (== A: %s)\n", TICK, us_f, px / us_f / 1e3, same_f ? "bit for bit" : "DIFFERENT");
     std::printf("   host: recording one frame's chain in the ChainBatch (IOps -> descriptor)   : %6.2f us per frame\n", us_record);
     (void)hipFree(scratch);
-    return same_b && same_c && same_d ? 0 : 1;
+    return same_b && same_c && same_d && same_e && same_f ? 0 : 1;
 }

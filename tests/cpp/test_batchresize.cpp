@@ -400,13 +400,13 @@ static void test_attached_streams_vs_oracle() {
 // gates 16 at a time and the rest at the fence (fewer than 8 left: launches, the hybrid policy) -- every tensor must have the oracle's bits,
 // with the frames REWRITTEN on the stream between ticks.
 template <int TI, int TO, int BATCH, int CAMS>
-static void test_recorded_ticks_vs_oracle(bool fence_then_async) {
+static void test_recorded_ticks_vs_oracle(bool fence_then_async, bool with_queue = true) {
     constexpr int CN = CV_MAT_CN(TO);
     const Params& p = kParams[CN - 1];
     const cv::Size up(64, 128);
     const int POOL = 3, TICKS = 12;
     const size_t n = (size_t)BATCH * CN * up.width * up.height;
-    cvGS::Queue queue(0, 0, 5000.0);
+    std::unique_ptr<cvGS::Queue> queue(with_queue ? new cvGS::Queue(0, 0, 5000.0) : nullptr); // (without: cvGS::recordTicks, one cvgs_execute_many launch per tick)
     cv::cuda::Stream stream;
     hipStream_t s = cv::cuda::StreamAccessor::getStream(stream);
     struct Cam {
@@ -439,7 +439,8 @@ static void test_recorded_ticks_vs_oracle(bool fence_then_async) {
         }
         HIP_OK(hipHostMalloc((void**)&cam.host, n * sizeof(float), hipHostMallocDefault));
     }
-    cvGS::attachQueueTicks(stream, queue, 16);
+    if (with_queue) cvGS::attachQueueTicks(stream, *queue, 16);
+    else cvGS::recordTicks(stream, 16);
     int bad = 0;
     for (int t = 0; t < TICKS; ++t) {
         for (auto& cp : cams) { // the producers: the frames of this tick arrive on the stream (the previous tick was fenced)
@@ -466,7 +467,7 @@ static void test_recorded_ticks_vs_oracle(bool fence_then_async) {
         for (auto& cp : cams)
             if (!bit_equal(cp->host, cp->refs[(size_t)(t % POOL)].data, n * sizeof(float))) ++bad;
     }
-    CHECK(bad == 0, "recorded ticks (attachQueueTicks, " << CAMS << " cameras, " << (fence_then_async ? "fence + async consumers" : "waitForCompletion")
+    CHECK(bad == 0, "recorded ticks (" << (with_queue ? "attachQueueTicks, " : "recordTicks with no queue, ") << CAMS << " cameras, " << (fence_then_async ? "fence + async consumers" : "waitForCompletion")
                         << "): " << bad << " of " << CAMS * TICKS << " tensors differ from the oracle, type " << TI);
     // recorded calls are not lost at detach: record, detach (submits), synchronise, compare
     for (auto& cp : cams) HIP_OK(hipMemsetAsync(cp->tensor.data, 0, n * sizeof(float), s));
@@ -512,5 +513,7 @@ int main() {
     test_attached_streams_vs_oracle<CV_8UC4, CV_32FC4, 9>();
     test_recorded_ticks_vs_oracle<CV_8UC3, CV_32FC3, 20, 27>(/*fence_then_async=*/false); // 16 behind a gate + 11 at the fence
     test_recorded_ticks_vs_oracle<CV_8UC4, CV_32FC4, 7, 21>(/*fence_then_async=*/true);   // 16 behind a gate + 5 launches at the fence
+    test_recorded_ticks_vs_oracle<CV_8UC3, CV_32FC3, 20, 27>(/*fence_then_async=*/false, /*with_queue=*/false); // one launch per 16 + one for 11
+    test_recorded_ticks_vs_oracle<CV_8UC4, CV_32FC4, 7, 21>(/*fence_then_async=*/true, /*with_queue=*/false);
     return report("test_batchresize_x_split3D + aspectratio");
 }

@@ -123,7 +123,49 @@ static bool testPerspectiveBatch(int usedPlanes) {
     return same;
 }
 
+// the reference's parameter helpers under their own names (include/cvGPUSpeedup.cuh:269-284, 311-377): host arithmetic only
+static void testParameterHelpers() {
+    const cv::Size sz(300, 200);
+    const double inv_a[6] = {1, 0, -50, 0, 1, -100};
+    const auto pa = cvGS::internal::warp_getWarpingAffineParameters(inv_a, sz);
+    bool ok = pa.dstSize.width == 300 && pa.dstSize.height == 200;
+    for (int i = 0; i < 6; ++i) ok = ok && pa.transformMatrix[i / 3][i % 3] == (float)inv_a[i];
+    const double inv_p[9] = {1.25, 0.5, -3, 0.125, 2, 7, 0.001, 0.002, 1};
+    const auto pp = cvGS::internal::warp_getWarpingPerspectiveParameters(inv_p, sz);
+    for (int i = 0; i < 9; ++i) ok = ok && pp.transformMatrix[i / 3][i % 3] == (float)inv_p[i];
+    CHECK(ok, "warp_getWarping{Affine,Perspective}Parameters narrow the inverted transform to float, row-major");
+    // the batch helpers take FORWARD transforms and must agree with the single-image path (inversion in double, then float)
+    std::array<cv::Mat, 3> fwd;
+    std::array<cv::Size, 3> sizes;
+    for (size_t i = 0; i < 3; ++i) {
+        fwd[i] = cv::getPerspectiveTransform(kSrc[i], kDst[i]);
+        sizes[i] = cv::Size(100 + 10 * (int)i, 90);
+    }
+    const auto all = cvGS::internal::warp_batchParameters<fk::WarpType::Perspective>(fwd, sizes);
+    const auto two = cvGS::internal::warp_batchParameters<fk::WarpType::Perspective>(fwd, sizes, 2);
+    bool same = true;
+    for (size_t i = 0; i < 3; ++i) {
+        const cv::Mat inv(fwd[i].inv());
+        const auto one = cvGS::internal::warp_getWarpingPerspectiveParameters(inv.ptr<double>(), sizes[i]);
+        const auto rt = cvGS::internal::warp_batchPerspectiveParameters_helper_rt(fwd, sizes, i);
+        for (int k = 0; k < 9; ++k) {
+            same = same && all[i].transformMatrix[k / 3][k % 3] == one.transformMatrix[k / 3][k % 3] && rt.transformMatrix[k / 3][k % 3] == one.transformMatrix[k / 3][k % 3];
+            if (i < 2) same = same && two[i].transformMatrix[k / 3][k % 3] == one.transformMatrix[k / 3][k % 3];
+        }
+        same = same && all[i].dstSize.width == (uint)sizes[i].width;
+    }
+    CHECK(same, "warp_batchParameters == the single-image parameters, plane by plane");
+    std::array<cv::Mat, 2> aff = {(cv::Mat_<double>(2, 3) << 1, 0, 50, 0, 1, 100), (cv::Mat_<double>(2, 3) << 2, 0, 0, 0, 4, 8)};
+    std::array<cv::Size, 2> asz = {sz, sz};
+    const auto ab = cvGS::internal::warp_batchParameters<fk::WarpType::Affine>(aff, asz);
+    const auto a1 = cvGS::internal::warp_batchAffineParameters_helper<1>(aff, asz);
+    CHECK(ab[0].transformMatrix[0][2] == -50.f && ab[0].transformMatrix[1][2] == -100.f && ab[1].transformMatrix[0][0] == 0.5f &&
+              ab[1].transformMatrix[1][1] == 0.25f && ab[1].transformMatrix[1][2] == -2.f && a1.transformMatrix[1][2] == -2.f,
+          "warp_batchParameters<Affine> inverts the forward transforms");
+}
+
 int main() {
+    testParameterHelpers();
     testPerspective();
     testAffine();
     testPerspectiveBatch<5>(5);

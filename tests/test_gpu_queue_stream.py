@@ -354,7 +354,8 @@ def test_attach_queue_keeps_the_call_shape(oracle, torch_dev):
         q.destroy()
 
 
-def test_recorded_ticks_keep_the_loop_unchanged(oracle, torch_dev):
+@pytest.mark.parametrize("with_queue", [True, False])
+def test_recorded_ticks_keep_the_loop_unchanged(oracle, torch_dev, with_queue):
     """cvgs.attachQueueTicks(stream, queue, 16): the multi-camera loop as the reference's users write it -- one executeOperations(stream, ...)
     per camera, one fence per tick -- with 21 cameras on ONE stream: 16 calls go behind a gate when the 16th is recorded, the other 5 at the
     fence (launches: fewer than 8); the frames are rewritten on the stream between ticks; the consumers run on the stream behind the fence."""
@@ -366,7 +367,10 @@ def test_recorded_ticks_keep_the_loop_unchanged(oracle, torch_dev):
         warm(torch, c)
     q = cvgs.Queue(idle_us=5000.0)
     try:
-        cvgs.attachQueueTicks(stream, q, 16)
+        if with_queue:
+            cvgs.attachQueueTicks(stream, q, 16)
+        else:
+            cvgs.recordTicks(stream, 16)  # no queue: one cvgs_execute_many launch per 16 recorded calls
         with torch.cuda.stream(stream):
             for i in range(40):
                 for c in cams:
@@ -387,7 +391,7 @@ def test_recorded_ticks_keep_the_loop_unchanged(oracle, torch_dev):
                 c.consume(1)
         stream.synchronize()
         st = q.stats()
-        assert st["error"] == 0 and st["submitted"] == 41 * 16, st
+        assert st["error"] == 0 and st["submitted"] == (41 * 16 if with_queue else 0), st
         assert sum(int(c.bad.item()) for c in cams) == 0
     finally:
         q.destroy()

@@ -131,6 +131,22 @@ def stream_ordered(wl, steps=1920, reps=5):
         out["queue_error"] = st["error"]
     finally:
         q.destroy()
+    torch.cuda.synchronize()
+    # (e) the same strict ticks with NO queue: ONE cvgs_execute_many launch per tick on a plain stream (ChainBatch::execute on a stream that
+    #     is not attached; what the hybrid policy gives strictly ordered groups on attached streams) -- nothing resident between ticks
+    for G, S in ((16, 1), (16, 2)):
+        packs = [cvgs.pack_chains([wl.chains[(g * G + j) % nch] for j in range(G)]) for g in range(nch)]
+        ss = s1 if S == 1 else s2
+
+        def many():
+            for i in range(steps // G):
+                h = ss[i % S].cuda_stream
+                lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+                rc = lib.cvgs_execute_many(packs[i % len(packs)], G, h)
+                if rc:
+                    capi.check(rc)
+        us = timed(many, ss, steps // G * G)
+        out["ticks_of_%d_one_launch_%d_stream%s" % (G, S, "s" if S > 1 else "")] = {"us": round(us, 3), "frac": round(alg / us / 1e3 / HBM, 4)}
     # every resident frame's tensor against ONE cvgs_execute launch of the same chain
     s = torch.cuda.current_stream().cuda_stream
     ok = True
@@ -148,12 +164,14 @@ def stream_ordered_compact(r):
     c = {}
     for k, short in (("ticks_of_16_on_1_stream_wait_deferred_2_ticks", "tick16_deferred"), ("ticks_of_8_on_1_stream_wait_deferred_2_ticks", "tick8_deferred"),
                      ("ticks_of_16_on_2_streams", "tick16x2"), ("ticks_of_4_on_2_streams", "tick4x2"), ("lone_stream_hybrid", "lone_hybrid"),
-                     ("lone_stream_on_the_server", "lone_server"), ("one_launch_per_step", "launch")):
+                     ("lone_stream_on_the_server", "lone_server"), ("one_launch_per_step", "launch"),
+                     ("ticks_of_16_one_launch_1_stream", "tick16_many"), ("ticks_of_16_one_launch_2_streams", "tick16_manyx2")):
         if k in r:
             c[short + "_us"] = r[k]["us"]
-    best = [r[k]["frac"] for k in ("ticks_of_16_on_1_stream_wait_deferred_2_ticks", "ticks_of_16_on_2_streams") if k in r]
+    best = [r[k]["frac"] for k in ("ticks_of_16_on_1_stream_wait_deferred_2_ticks", "ticks_of_16_on_2_streams", "ticks_of_16_one_launch_2_streams",
+                                   "ticks_of_16_one_launch_1_stream") if k in r]
     if best:
-        c["frac"] = max(best)  # the better of the two 16-frame tick regimes (both: producer on the stream, no host synchronisation)
+        c["frac"] = max(best)  # the best of the 16-frame tick regimes (all: producer on the stream, no host synchronisation)
     c["ok"] = bool(r.get("bit_identical_to_cvgs_execute")) and not r.get("queue_error")
     return c
 

@@ -128,18 +128,47 @@ def run_ticks(wl, q, lib, group, n_streams, ticks, producer):
     return ts[len(ts) // 2] * 1e6
 
 
+def run_ticks_many(wl, lib, group, n_streams, ticks, producer):
+    """`group` frames per tick as ONE cvgs_execute_many launch on a plain stream (no queue, no server, strictly stream-ordered); ticks
+    alternate over n_streams streams."""
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    nch = len(wl.chains)
+    groups = [cvgs.pack_chains([wl.chains[(g * group + j) % nch] for j in range(group)]) for g in range(max(1, nch // group) + 1)]
+
+    def once():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(ticks):
+            s = streams[i % n_streams].cuda_stream
+            if producer:
+                lib.cvgs_debug_occupy(1, 64, 0, 0.0, s)
+            capi.check(lib.cvgs_execute_many(groups[i % len(groups)], group, s))
+        for st in streams:
+            st.synchronize()
+        return (time.perf_counter() - t0) / (ticks * group)
+
+    once()
+    ts = sorted(once() for _ in range(5))
+    return ts[len(ts) // 2] * 1e6
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--steps", type=int, default=400)
     p.add_argument("--producer", action="store_true")
     p.add_argument("--depth", type=int, default=128, help="ring slots")
     p.add_argument("--quick", action="store_true", help="the diagnostic subset only")
+    p.add_argument("--only-many", action="store_true", help="the cvgs_execute_many ticks only (no queue is created)")
+    p.add_argument("--frames", type=int, default=20, help="resident frames (a tick's chains must be distinct frames: >= the largest tick)")
     a = p.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    wl = B.Workload(dev, 20, 50, 0, 1, False)
+    wl = B.Workload(dev, a.frames, 50, 0, 1, False)
     lib = capi.load_library()
     alg = wl.algorithmic_bytes()
+    if a.only_many:
+        many_ticks(a, wl, lib, alg)
+        return
     q = cvgs.Queue(depth=a.depth, idle_us=2000.0)
     rows = []
     try:
@@ -172,6 +201,17 @@ def main():
         print("every frame bit-identical to cvgs_execute:", ok)
     finally:
         q.destroy()
+    torch.cuda.synchronize()
+    many_ticks(a, wl, lib, alg)
+
+
+def many_ticks(a, wl, lib, alg):
+    # the same ticks with no queue at all: one cvgs_execute_many launch per tick (what ChainBatch::execute does on a stream that is not attached)
+    for group, S in ((4, 1), (8, 1), (8, 2), (16, 1), (16, 2), (16, 4), (32, 1), (32, 2), (64, 1), (64, 2)):
+        if group > len(wl.chains):
+            continue  # (chains of one launch must be independent: distinct frames)
+        us = run_ticks_many(wl, lib, group, S, max(10, a.steps // group), a.producer)
+        print("tick    %2d frames in ONE cvgs_execute_many launch, %d plain stream(s), no queue : %7.3f us per 50-crop batch  frac %.3f" % (group, S, us, alg / (us * 1e-6) / 8e12), flush=True)
 
 
 if __name__ == "__main__":

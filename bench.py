@@ -428,7 +428,17 @@ def main():
     use_queue = a.submission == "queue" and M == 1 and not a.eager and not a.table and n <= 74
     m_graph = None
     if use_queue:
-        m = measure_queue(wl, a.steps, a.warmup, events=not a.no_queue_events)
+        # The server grid must live across the WHOLE timed region (one launch: its event-timed duration / batches is roofline.achieved).
+        # A host stall longer than idle_us (an OS scheduling blip on a shared box: seen once in round 4, 16 ms) retires it mid-region; the
+        # events then span the stall and the relaunches (230 ms instead of 210: frac 0.48 instead of 0.53 with the same per-step clock).
+        # Such a region is measured again -- at most twice -- and the line says how many attempts it took.
+        attempts = []
+        for _ in range(3):
+            m = measure_queue(wl, a.steps, a.warmup, events=not a.no_queue_events)
+            attempts.append(m["server_launches_in_timed_region"])
+            if m["server_launches_in_timed_region"] == 1:
+                break
+        m["attempts_server_launches"] = attempts
         queue_ok = queue_outputs_match_execute(wl)
     else:
         m = measure(wl, a.steps, a.warmup, eager=a.eager)
@@ -479,8 +489,8 @@ def main():
     if use_queue:
         # the dominant kernel is the server grid: ONE launch served every batch of the timed region; its duration between two
         # HIP events on its own stream (minus the idle tail it waits before retiring) / the batches it served
-        kernel_us = (m["server_kernel_ms"] - m["idle_tail_ms"]) * 1e3 / m["batches_served"]
-        result["timing"]["server_kernel"] = {"launches_in_timed_region": m["server_launches_in_timed_region"], "duration_ms": round(m["server_kernel_ms"], 3),
+        kernel_us = (m["server_kernel_ms"] - m["idle_tail_ms"] * max(1, m["server_launches_in_timed_region"])) * 1e3 / m["batches_served"]
+        result["timing"]["server_kernel"] = {"launches_in_timed_region": m["server_launches_in_timed_region"], "attempts_launches": m["attempts_server_launches"], "duration_ms": round(m["server_kernel_ms"], 3),
                                              "idle_tail_ms": m["idle_tail_ms"], "batches_served": m["batches_served"], "us_per_batch": round(kernel_us, 4), "clock": m["server_kernel_clock"],
                                              "kernel": "k1q_server<1, 2> (rocprofv3: ONE call per timed region; avg duration / batches_served agrees)"}
         result["timing"]["batch_latency_server_alive"] = m["latency"]

@@ -290,6 +290,22 @@ def coexistence(dev, wl, bench_mod, seconds=2.0, soak_seconds=0.0, queue_flags=0
             dt = time.perf_counter() - t0
         return dt / launches * 1e6, 0, 0
 
+    lib = capi.load_library()
+    packs = [cvgs.pack_chains([wl.chains[(g * 16 + j) % nch] for j in range(16)]) for g in range(nch)]
+
+    def prep_many(duration):
+        """ticks of 16 frames as ONE cvgs_execute_many launch each, eager, 8 ticks between stream synchronisations (no queue, nothing resident)"""
+        h = side.cuda_stream
+        t0 = time.perf_counter()
+        ticks = 0
+        while time.perf_counter() - t0 < duration:
+            for k in range(8):
+                capi.check(lib.cvgs_execute_many(packs[(ticks + k) % len(packs)], 16, h))
+            side.synchronize()
+            ticks += 8
+        dt = time.perf_counter() - t0
+        return dt / (ticks * 16) * 1e6, 0, 0
+
     def prep_paced(duration, period_us=50.0):
         """one batch every 50 us (20,000 batches/s: what 16 cameras at 1250 fps would ask for -- far above any real pipeline, far below the
         server's 450,000/s): the server is alive and mostly idle; returns the batch latency p50 (submit -> host sees it complete)"""
@@ -311,14 +327,15 @@ def coexistence(dev, wl, bench_mod, seconds=2.0, soak_seconds=0.0, queue_flags=0
         st = q.stats()
         return _pct(lat, 0.5), st["error"], len(lat)
 
-    alone = {"queue": prep_queue(min(seconds, 1.0))[0], "graph_launches": prep_graph(min(seconds, 1.0))[0]}
+    prep_many(0.1)
+    alone = {"queue": prep_queue(min(seconds, 1.0))[0], "graph_launches": prep_graph(min(seconds, 1.0))[0], "ticks_of_16_one_launch": prep_many(min(seconds, 1.0))[0]}
     out["paced_latency_alone_p50_us"] = round(prep_paced(0.5)[0], 2)
     out["preprocessing_alone_us_per_batch"] = {k: round(v, 3) for k, v in alone.items()}
     for n in (4096, 8192):
         a, b, c = _gemm_setup(dev, n)
         flop, one, count = _gemm_rate(a, b, c, gs, seconds + 0.5)
         row = {"consumer_alone_TFLOPs": round(flop / one / 1e12, 1), "consumer_ms_per_gemm": round(one * 1e3, 3)}
-        for name, fn in (("queue", prep_queue), ("graph_launches", prep_graph)):
+        for name, fn in (("queue", prep_queue), ("graph_launches", prep_graph), ("ticks_of_16_one_launch", prep_many)):
             torch.cuda.synchronize()
             with torch.cuda.stream(gs):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -372,7 +389,9 @@ def coexistence_compact(r):
         g = r.get("gemm_%d" % n)
         if g:
             c["gemm%d" % n] = {"queue_us": g["queue"]["preprocessing_us_per_batch"], "graph_us": g["graph_launches"]["preprocessing_us_per_batch"],
-                               "consumer_slowdown": [g["queue"]["consumer_slowdown"], g["graph_launches"]["consumer_slowdown"]],
+                               "tick16_us": g.get("ticks_of_16_one_launch", {}).get("preprocessing_us_per_batch"),
+                               "consumer_slowdown": [g["queue"]["consumer_slowdown"], g["graph_launches"]["consumer_slowdown"]] +
+                                                    ([g["ticks_of_16_one_launch"]["consumer_slowdown"]] if "ticks_of_16_one_launch" in g else []),
                                "paced_consumer_slowdown": g.get("queue_paced_20k_per_s", {}).get("consumer_slowdown"),
                                "paced_latency_us": g.get("queue_paced_20k_per_s", {}).get("batch_latency_p50_us"),
                                "watchdog": g["queue"]["watchdog_error"]}
@@ -401,10 +420,11 @@ if __name__ == "__main__":
         for g in (127, 255, 383, 511, 767):
             r = coexistence(dev, wl, B, seconds=1.0, queue_flags=g << 16)
             print("G %4d | alone: queue %.3f us/batch, paced latency p50 %.1f us |" % (r["server_workgroups"], r["preprocessing_alone_us_per_batch"]["queue"], r["paced_latency_alone_p50_us"]),
-                  " | ".join("gemm%d: queue %.3f us (consumer x%.2f), paced lat %.1f us (consumer x%.2f), graph launches %.2f us (consumer x%.2f)" % (
+                  " | ".join("gemm%d: queue %.3f us (consumer x%.2f), paced lat %.1f us (consumer x%.2f), graph launches %.2f us (consumer x%.2f), ticks of 16 in one launch %.2f us (consumer x%.2f)" % (
                       n, r["gemm_%d" % n]["queue"]["preprocessing_us_per_batch"], r["gemm_%d" % n]["queue"]["consumer_slowdown"],
                       r["gemm_%d" % n]["queue_paced_20k_per_s"]["batch_latency_p50_us"], r["gemm_%d" % n]["queue_paced_20k_per_s"]["consumer_slowdown"],
-                      r["gemm_%d" % n]["graph_launches"]["preprocessing_us_per_batch"], r["gemm_%d" % n]["graph_launches"]["consumer_slowdown"]) for n in (4096, 8192)), flush=True)
+                      r["gemm_%d" % n]["graph_launches"]["preprocessing_us_per_batch"], r["gemm_%d" % n]["graph_launches"]["consumer_slowdown"],
+                      r["gemm_%d" % n]["ticks_of_16_one_launch"]["preprocessing_us_per_batch"], r["gemm_%d" % n]["ticks_of_16_one_launch"]["consumer_slowdown"]) for n in (4096, 8192)), flush=True)
         sys.exit(0)
     if a.json:
         r = {"stream_ordered": stream_ordered(wl)}

@@ -232,3 +232,65 @@ def test_recycled_zero_copy_descriptor_slots_never_serve_a_stale_table(oracle):
         ref = np.zeros((n, plane), np.float32)
         oracle.execute(cvgs.lower(H.k1_chain(h_src, lists[i], cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, 3)))
         H.assert_bit_exact(outs[i].cpu().numpy(), ref, "launch %d through a recycled descriptor slot" % i)
+
+
+def test_descriptor_slots_behind_a_blocked_stream_are_not_recycled(oracle):
+    """Round 4: the scratch pool records ONE event per four launches of a hot stream (a hipEventRecord behind every launch kept the next
+    kernel of the stream ~4 us behind), so the last launches of a stream may be covered by no event yet.  Such slots are reclaimed only
+    when their stream has nothing left to do (hipStreamQuery, 20 ms after the commit).  Stream S: a 300 ms blocker, then THREE 330-crop
+    launches (uncovered); stream T meanwhile: 60 launches with other tables, which need slots for 100+ ms.  S's kernels run last and must
+    still read THEIR tables."""
+    import time
+    import torch
+    dev = torch.device("cuda:0")
+    frame = H.random_u8((540, 960, 3), seed=78)
+    frame_t = torch.from_numpy(frame).to(dev)
+    g_src = cvgs.GpuMat.from_tensor(frame_t, cvgs.CV_8UC3)
+    h_src = cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)
+    n, dst = 330, (16, 8)
+    plane = 3 * dst[0] * dst[1]
+    lib = capi.load_library()
+    S, T = torch.cuda.Stream(), torch.cuda.Stream()
+    s_lists = [H.random_crops(n, 960, 540, seed=7000 + i, wmin=8, wmax=200, hmin=8, hmax=200) for i in range(3)]
+    t_lists = [H.random_crops(n, 960, 540, seed=7100 + i, wmin=8, wmax=200, hmin=8, hmax=200) for i in range(60)]
+    s_outs = [torch.zeros((n, plane), dtype=torch.float32, device=dev) for _ in s_lists]
+    t_outs = [torch.zeros((n, plane), dtype=torch.float32, device=dev) for _ in t_lists]
+    torch.cuda.synchronize()
+    # the pool grows to a dozen slots first (12 launches queued behind a 20 ms blocker): adding a slot later would allocate pinned memory,
+    # which waits for the device -- i.e. for S's blocker
+    capi.check(lib.cvgs_debug_occupy(1, 64, 0, 20000.0, T.cuda_stream))
+    for i in range(12):
+        cvgs.executeOperations(T, *H.k1_chain(g_src, t_lists[i], cvgs.GpuMat.from_tensor(t_outs[i], cvgs.CV_32FC1), dst, 3))
+    torch.cuda.synchronize()
+    for o in t_outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    # (lowered up front: building a 330-crop chain in Python takes milliseconds)
+    s_low = [cvgs.lower(H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst, 3)) for crops, out in zip(s_lists, s_outs)]
+    t_low = [cvgs.lower(H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst, 3)) for crops, out in zip(t_lists, t_outs)]
+    capi.check(lib.cvgs_debug_occupy(1, 64, 0, 300000.0, S.cuda_stream))
+    for lc in s_low:
+        capi.check(lib.cvgs_execute(C.byref(lc.desc), S.cuda_stream))
+    # T must not share S's hardware queue (the runtime spreads streams over a few): take the first stream a tiny kernel gets through on
+    for cand in [T] + [torch.cuda.Stream() for _ in range(6)]:
+        p0 = time.perf_counter()
+        capi.check(lib.cvgs_debug_occupy(1, 64, 0, 0.0, cand.cuda_stream))
+        cand.synchronize()
+        if time.perf_counter() - p0 < 0.02:
+            T = cand
+            break
+    else:
+        pytest.skip("every stream of this process queues behind the blocked one")
+    t0 = time.perf_counter()
+    for i, lc in enumerate(t_low):
+        capi.check(lib.cvgs_execute(C.byref(lc.desc), T.cuda_stream))
+        if i % 10 == 9:
+            T.synchronize()
+            time.sleep(0.012)  # (past the 20 ms age at which a quiet stream's slots are looked at -- S is not quiet, it is blocked)
+    assert time.perf_counter() - t0 < 0.28, "T's launches must have been issued while S was still blocked"
+    torch.cuda.synchronize()
+    for lists, outs, name in ((s_lists, s_outs, "blocked stream"), (t_lists, t_outs, "busy stream")):
+        for i, (crops, out) in enumerate(zip(lists, outs)):
+            ref = np.zeros((n, plane), np.float32)
+            oracle.execute(cvgs.lower(H.k1_chain(h_src, crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), dst, 3)))
+            H.assert_bit_exact(out.cpu().numpy(), ref, "%s, launch %d" % (name, i))

@@ -95,7 +95,9 @@ def stream_rows():
     r = json.loads(line[-1])["stream_ordered"]
     return [{"name": "stream-ordered: ticks of 16 frames behind one gate, 1 stream, wait deferred 2 ticks, producer on the stream", "us": r["ticks_of_16_on_1_stream_wait_deferred_2_ticks"]["us"]},
             {"name": "stream-ordered: ticks of 16 frames behind one gate, 2 streams, producer on the stream", "us": r["ticks_of_16_on_2_streams"]["us"]},
-            {"name": "stream-ordered: lone stream, hybrid policy (direct launch), producer on the stream", "us": r["lone_stream_hybrid"]["us"]}]
+            {"name": "stream-ordered: lone stream, hybrid policy (direct launch), producer on the stream", "us": r["lone_stream_hybrid"]["us"]}] + [
+            {"name": "stream-ordered: ticks of 16 frames as ONE cvgs_execute_many launch, %s, no queue, producer on the stream" % lab, "us": r[k]["us"]}
+            for k, lab in (("ticks_of_16_one_launch_1_stream", "1 stream"), ("ticks_of_16_one_launch_2_streams", "2 streams")) if k in r]
 
 
 def quick_rows():

@@ -1088,6 +1088,7 @@ public:
         constexpr bool tsplit_needed = MODE == ColorPlanes::Transposed;
         if (tsplit_needed != (b.d.write.kind == CVGS_WRITE_TENSOR_T_SPLIT))
             throw std::runtime_error("Need to use TensorTSplit as write function exactly when CP_MODE = Transposed");
+        if (detail::stream_attachments().any.load(std::memory_order_acquire)) detail::flush_attached(stream); // recorded calls of this stream go first
         detail::check_status(cvgs_circular_update(handle_, &b.d, stream));
         if constexpr (MIRRORED && !CAPTURABLE) ptr_a.data = (T*)cvgs_circular_data(handle_); // the window moved
     }

@@ -1866,6 +1866,8 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
             const int min_group = (int)((flags >> 8) & 0xffu) ? (int)((flags >> 8) & 0xffu) : 8;
             if (hybrid && (!overlap || n - done < min_group)) { ++q->n_direct; if (n_queued) *n_queued = done; return 2; }
             rows = parallel >= 8 ? (uint32_t)kQRowsPerTaskMid : (parallel >= 1 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
+            static const int gated_rows_env = getenv("CVGS_QUEUE_GATED_ROWS") ? atoi(getenv("CVGS_QUEUE_GATED_ROWS")) & ~3 : 0; // tuning: the size used from 8 overlappable batches
+            if (gated_rows_env >= 4 && gated_rows_env <= 4096 && parallel >= 8) rows = (uint32_t)gated_rows_env;
             const auto t0 = std::chrono::steady_clock::now();
             unsigned spins = 0;
             for (;;) {

@@ -232,7 +232,7 @@ def measure_queue(wl, steps, warmup, barrier=lambda: None, target_s=0.25, min_re
     events on ITS stream / the batches it served is reported beside it and feeds roofline.achieved."""
     m_rep = 1 if steps >= 256 else -(-256 // steps)
     n = steps * m_rep
-    q = cvgs.Queue(depth=128, idle_us=2000.0)
+    q = cvgs.Queue(device=torch.cuda.current_device(), depth=128, idle_us=2000.0)  # (rank r of a multi-GPU run: ITS GPU, not device 0)
     order = [wl.chains[i % len(wl.chains)] for i in range(n)]
     ptrs = cvgs.Queue.chain_pointers(order)
     try:

@@ -141,9 +141,11 @@ def main(a, dev, rank, world):
             bases.append(buf.ptr if r == rank else rccl.open_peer(handles[r]))
             if r != rank:
                 peers.append(bases[-1])
-        # probe: a plain store into every peer's allocation (its last float: nothing reads it) before any kernel is pointed at it
+        # probe: a plain store into every peer's allocation (its last 64 bytes: nothing reads them) before any kernel is pointed at it --
+        # with the engine's own copy kernel (a torch view of a peer's pointer would be created on the PEER's device and copied over)
+        lib_p = capi.load_library()
         for b in peers:
-            rccl.view(b + flag_off + world * 128 + 128, (1,)).fill_(1.0)
+            capi.check(lib_p.cvgs_stream_copy(b + flag_off + world * 128 + 128, buf.ptr + flag_off + world * 128 + 128, 64, s))
         torch.cuda.synchronize()
     except Exception as ex:  # no peer access on this box, IPC refused, ...
         map_error = repr(ex)

@@ -1376,6 +1376,12 @@ struct cvgs_queue_s {
 int cvgs_queue_create(cvgs_queue_t* out, int32_t device, int32_t depth, double idle_us, uint32_t flags) {
     if (!out) return fail(CVGS_ERR_INVALID, "null queue handle");
     if (depth < 0 || depth > 256) return fail(CVGS_ERR_INVALID, "queue depth must be in [0, 256]");
+    if (device < 0) { // the calling thread's current device (a rank of a multi-GPU job creates its queue where its frames live)
+        int cur = 0;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+        device = cur;
+    }
     DeviceGuard guard;
     if (int rc = guard.enter(device)) return rc;
     cvgs::Queue* q = nullptr;

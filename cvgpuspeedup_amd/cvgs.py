@@ -677,7 +677,7 @@ class Queue:
     the same behind crops of NV12 / NV21 decoder surfaces (read_nv12(..., dsize), 3 channels); a queue serves the kind of its
     first submit.  capi.CvgsError(CVGS_ERR_UNSUPPORTED) otherwise."""
 
-    def __init__(self, device=0, depth=0, idle_us=0.0, flags=0):
+    def __init__(self, device=-1, depth=0, idle_us=0.0, flags=0):  # device -1: the calling thread's current device
         self.lib = capi.load_library()
         self.handle = C.c_void_p()
         capi.check(self.lib.cvgs_queue_create(C.byref(self.handle), device, depth, float(idle_us), flags))

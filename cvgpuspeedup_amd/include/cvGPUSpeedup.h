@@ -511,7 +511,7 @@ private:
 // ---- device-side descriptor queue (engine extension, see fk::Queue): executeOperations without a launch per call -------
 class Queue {
 public:
-    explicit Queue(int device = 0, int depth = 0, double idle_us = 0.0) : q_(device, depth, idle_us) {}
+    explicit Queue(int device = -1 /* the current device */, int depth = 0, double idle_us = 0.0) : q_(device, depth, idle_us) {}
     template <typename... IOps> uint64_t submit(const IOps&... iops) { return q_.submit(iops...); }
     void wait(uint64_t ticket, double timeout_s = 10.0) { q_.wait(ticket, timeout_s); }
     void wait(uint64_t ticket, const cv::cuda::Stream& consumer) { q_.wait(ticket, cv::cuda::StreamAccessor::getStream(consumer)); }

@@ -927,7 +927,7 @@ private:
 // The sources must be complete when the call is made (the server is not ordered behind any stream).
 class Queue {
 public:
-    explicit Queue(int device = 0, int depth = 0, double idle_us = 0.0) { detail::check_status(cvgs_queue_create(&q_, device, depth, idle_us, 0u)); }
+    explicit Queue(int device = -1 /* the current device */, int depth = 0, double idle_us = 0.0) { detail::check_status(cvgs_queue_create(&q_, device, depth, idle_us, 0u)); }
     Queue(const Queue&) = delete;
     Queue& operator=(const Queue&) = delete;
     ~Queue() {

@@ -373,7 +373,7 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  * waves of ONE launch load, then store, all at the same time.  A queue keeps the call shape -- one submit per
  * frame, same chain descriptor -- and removes the boundary: a resident server grid takes batches from a ring; its
  * workgroups walk from batch to batch without a grid-wide barrier, so batch k+1's loads overlap batch k's stores.
- *   cvgs_queue_create   one queue per device; `depth` ring slots (0 = 128, at most 256); `idle_us`: the server retires
+ *   cvgs_queue_create   one queue per device (`device` < 0: the calling thread's current device); `depth` ring slots (0 = 128, at most 256); `idle_us`: the server retires
  *                       itself after this long without work (0 = 200 us) and the next submit starts a new one, so the grid
  *                       never outlives its work; a batch without progress for 250 ms (environment: CVGS_QUEUE_STALL_MS) is reported
  *                       as CVGS_ERR_HIP, not waited for -- every workgroup of the server must be resident, so other kernels of the

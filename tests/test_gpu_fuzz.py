@@ -225,7 +225,10 @@ def _run(seed, big, flags, tiers=False):
     H.assert_bit_exact(g, r, what)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_N", "600"))))  # CVGS_FUZZ_N=20000 for a long hunt
+_BASE = int(os.environ.get("CVGS_FUZZ_BASE", "0"))  # a long hunt in several runs: CVGS_FUZZ_BASE=1000000, 2000000, ... with CVGS_FUZZ_N=200000 each
+
+
+@pytest.mark.parametrize("seed", range(_BASE, _BASE + int(os.environ.get("CVGS_FUZZ_N", "600"))))  # CVGS_FUZZ_N=20000 for a long hunt
 def test_random_chain_matches_oracle(seed):
     _run(seed, False, [0, capi.CHAIN_FORCE_GENERIC, 0, capi.CHAIN_NO_THREAD_FUSION][seed % 4])
 

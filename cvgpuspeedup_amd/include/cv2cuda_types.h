@@ -20,7 +20,7 @@ template <> struct depth_base<CV_16S> { using type = short; };
 template <> struct depth_base<CV_32S> { using type = int; };
 template <> struct depth_base<CV_32F> { using type = float; };
 template <> struct depth_base<CV_64F> { using type = double; };
-template <> struct depth_base<CV_16F> { using type = _Float16; }; // engine extension: half-precision hand-off
+template <> struct depth_base<CV_16F> { using type = cvgs::half_t; }; // engine extension: half-precision hand-off
 
 // scalar for one channel, HIP_vector_type<base, N> otherwise (uchar3, float4, ...)
 template <typename B, int CN> struct vec_of { using type = HIP_vector_type<B, CN>; };
@@ -55,7 +55,7 @@ template <> struct base_depth<int> { static constexpr int value = CV_32S; };
 template <> struct base_depth<uint> { static constexpr int value = CV_32S; };
 template <> struct base_depth<float> { static constexpr int value = CV_32F; };
 template <> struct base_depth<double> { static constexpr int value = CV_64F; };
-template <> struct base_depth<_Float16> { static constexpr int value = CV_16F; };
+template <> struct base_depth<cvgs::half_t> { static constexpr int value = CV_16F; };
 
 template <typename T>
 constexpr int cv_type_of = CV_MAKETYPE(base_depth<typename vector_traits<T>::base>::value, vector_traits<T>::cn);

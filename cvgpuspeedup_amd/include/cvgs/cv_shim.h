@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "half.h"
+
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -189,7 +191,7 @@ private:
         case CV_16S: ((short*)row)[e] = (short)std::nearbyint(clampd(v, -32768, 32767)); break;
         case CV_32S: ((int*)row)[e] = (int)std::nearbyint(clampd(v, -2147483648.0, 2147483647.0)); break;
         case CV_32F: ((float*)row)[e] = (float)v; break;
-        case CV_16F: ((_Float16*)row)[e] = (_Float16)v; break;
+        case CV_16F: ((cvgs::half_t*)row)[e] = (cvgs::half_t)v; break;
         default: ((double*)row)[e] = v; break;
         }
     }

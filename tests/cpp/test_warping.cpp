@@ -152,7 +152,7 @@ static void testParameterHelpers() {
             same = same && all[i].transformMatrix[k / 3][k % 3] == one.transformMatrix[k / 3][k % 3] && rt.transformMatrix[k / 3][k % 3] == one.transformMatrix[k / 3][k % 3];
             if (i < 2) same = same && two[i].transformMatrix[k / 3][k % 3] == one.transformMatrix[k / 3][k % 3];
         }
-        same = same && all[i].dstSize.width == (uint)sizes[i].width;
+        same = same && (int)all[i].dstSize.width == sizes[i].width;
     }
     CHECK(same, "warp_batchParameters == the single-image parameters, plane by plane");
     std::array<cv::Mat, 2> aff = {(cv::Mat_<double>(2, 3) << 1, 0, 50, 0, 1, 100), (cv::Mat_<double>(2, 3) << 2, 0, 0, 0, 4, 8)};

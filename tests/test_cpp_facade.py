@@ -134,3 +134,69 @@ int main() {
                     "-Wl,-rpath," + os.path.join(ROOT, "cvgpuspeedup_amd", "lib")], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_soft_half_matches_the_compilers_float16(tmp_path):
+    """cvgs/half.h: on compilers without _Float16 (g++ 11 in C++ mode) CV_16F elements are 16 bits of storage with software conversions.
+    Built here with a compiler that HAS _Float16, the stand-in forced: every one of the 65,536 bit patterns widens to the same float, and
+    doubles -- every exponent of interest, ties, subnormals, overflow, 2,000,000 random ones -- narrow to the same bits (round to nearest
+    even straight from double).  Host-only."""
+    inc = os.path.join(ROOT, "cvgpuspeedup_amd", "include")
+    src = tmp_path / "half.cpp"
+    src.write_text(r'''
+#define CVGS_HALF_FORCE_SOFT
+#include <cvgs/half.h>
+#include <cmath>
+#include <cstdio>
+static uint16_t native(double v) { _Float16 h = (_Float16)v; uint16_t b; std::memcpy(&b, &h, 2); return b; }
+static uint64_t s = 0x1234567ull;
+static uint64_t rnd() { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+int main() {
+    long bad = 0;
+    for (uint32_t b = 0; b < 65536; ++b) {
+        _Float16 h; uint16_t bb = (uint16_t)b; std::memcpy(&h, &bb, 2);
+        const float a = (float)h, c = cvgs::half_t::to_float(bb);
+        if (std::isnan(a) ? !std::isnan(c) : std::memcmp(&a, &c, 4) != 0) ++bad;
+        // and back: a half value narrows to itself
+        if (!std::isnan(a) && cvgs::half_t::from_double((double)a) != bb) ++bad;
+    }
+    auto check = [&](double v) {
+        const uint16_t a = native(v), c = cvgs::half_t::from_double(v);
+        if (std::isnan(v) ? ((c & 0x7c00u) != 0x7c00u || !(c & 0x3ffu)) : a != c) { if (bad < 5) std::printf("%.17g: native %04x soft %04x\n", v, a, c); ++bad; }
+    };
+    for (uint32_t b = 0; b < 65536; ++b) { // every half value, its neighbours' midpoints and a hair to either side of them
+        uint16_t bb = (uint16_t)b;
+        const float f = cvgs::half_t::to_float(bb);
+        if (std::isnan(f) || std::isinf(f)) continue;
+        const float g = cvgs::half_t::to_float((uint16_t)(bb + 1));
+        if (std::isnan(g) || std::isinf(g) || ((bb + 1) & 0x8000u) != (bb & 0x8000u)) continue;
+        const double mid = ((double)f + (double)g) / 2;
+        check(mid); check(std::nextafter(mid, 1e300)); check(std::nextafter(mid, -1e300)); check((double)f); check(std::nextafter((double)f, 1e300));
+    }
+    const double special[] = {0.0, -0.0, 65504.0, 65519.999, 65520.0, 65520.001, 1e300, -1e300, 5.9604644775390625e-8, 2.98023223876953125e-8,
+                              2.9802322387695316e-8, 2.9802322387695309e-8, 1e-30, -1e-30, 6.103515625e-5, 6.0975551605224609375e-5, INFINITY, -INFINITY, NAN};
+    for (double v : special) check(v);
+    for (int i = 0; i < 2000000; ++i) {
+        const uint64_t r = rnd();
+        double v;
+        const uint64_t bits = (r & 0x800fffffffffffffull) | ((uint64_t)(1023 - 30 + (r >> 52) % 50) << 52); // exponents -30 .. +19
+        std::memcpy(&v, &bits, 8);
+        check(v);
+    }
+    std::printf("%ld mismatches\n", bad);
+    return bad ? 1 : 0;
+}
+''')
+    exe = tmp_path / "half"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "c++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-command-line-argument", "-I" + inc, str(src), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-1000:]
+
+
+def test_facade_headers_compile_with_plain_gcc():
+    """The facade is host C++17: the five reference-test programs must get through g++ (this image's 11.4, no _Float16 in C++ mode) as well as
+    through hipcc -x c++ -- a maintainer's host compiler need not be clang.  Syntax + semantics only (no link: the box decides)."""
+    inc = os.path.join(ROOT, "cvgpuspeedup_amd", "include")
+    for prog in PROGRAMS:
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-I" + inc,
+                        os.path.join(CPP, prog + ".cpp")], check=True, cwd=CPP)

@@ -200,3 +200,11 @@ def test_facade_headers_compile_with_plain_gcc():
     for prog in PROGRAMS:
         subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-I" + inc,
                         os.path.join(CPP, prog + ".cpp")], check=True, cwd=CPP)
+
+
+def test_c_abi_headers_are_plain_c99(tmp_path):
+    """include/cvgs_hip.h and include/cvgs_rccl.h are what a cgo / JNI / ctypes binding includes: they must be C, not C++ (gcc -std=c99
+    -pedantic, no warnings)."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include "include/cvgs_hip.h"\n#include "include/cvgs_rccl.h"\nint main(void) { return (int)sizeof(cvgs_chain_desc) == 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + ROOT, str(src)], check=True)

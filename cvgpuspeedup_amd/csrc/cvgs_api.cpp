@@ -334,10 +334,21 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
     // ---- pointwise stages ----
     ProgArgs& Pg = L.args.prog;
     int n = 0;
+    int cn_run = R.out_cn; // channels of the value at this stage: the channel selectors below are canonicalised to them
     for (int k = 0; k < ch->n_ops; ++k) {
         if (ch->ops[k].opcode == CVGS_OP_NOP) continue;
         Pg.opcode[n] = ch->ops[k].opcode;
         Pg.aux[n] = ch->ops[k].aux;
+        // 2 bits per output channel: bits beyond the stage's channels mean nothing (walk_program checks the ones that do), but the
+        // kernels' program matching compares the whole word -- a binding that fills all four selectors ("3,2,1,0 | 3 << 6" on a
+        // 3-channel value) must get the same specialised kernel as the facade's spelling
+        switch (ch->ops[k].opcode) {
+        case CVGS_OP_REORDER: if (cn_run >= 1 && cn_run <= 4) Pg.aux[n] &= (1 << (2 * cn_run)) - 1; break;
+        case CVGS_OP_ADD_ALPHA: Pg.aux[n] &= 0x3f; cn_run = 4; break;
+        case CVGS_OP_DROP_ALPHA: Pg.aux[n] &= 0x3f; cn_run = 3; break;
+        case CVGS_OP_GRAY: Pg.aux[n] &= 0x3f; cn_run = 1; break;
+        default: break;
+        }
         for (int c = 0; c < 4; ++c) {
             Pg.operand[n][c] = ch->ops[k].operand[c];
             L.p64.operand[n][c] = ch->ops[k].operand_d[c];

@@ -208,3 +208,12 @@ def test_c_abi_headers_are_plain_c99(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text('#include "include/cvgs_hip.h"\n#include "include/cvgs_rccl.h"\nint main(void) { return (int)sizeof(cvgs_chain_desc) == 0; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + ROOT, str(src)], check=True)
+
+
+@pytest.mark.gpu
+def test_the_boundary_from_plain_c():
+    """tests/cpp/c_abi_k1.c: the headline chain described as ONE cvgs_chain_desc in C99 (gcc, no C++), run with cvgs_execute on a HIP
+    stream, against the oracle running the same descriptor on host memory -- what a cgo / JNI / N-API binding of the C-ABI does."""
+    subprocess.run(["make", "-C", CPP, "bin/c_abi_k1"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "bin", "c_abi_k1")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "bit-identical" in r.stdout and "k1_u8c3_swap_mul_sub_div" in r.stdout, r.stdout + r.stderr

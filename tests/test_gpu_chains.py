@@ -658,3 +658,61 @@ def test_read_convert_split_into_separate_planes(depth, cn, normalize):
     H.assert_bit_exact(interp[0], ref[0], "%sC%d -> planes (interpreted kernel) vs oracle" % (depth, cn))
     ops = build(lambda a, t: cvgs.GpuMat.from_array(a, t), lambda a, t: cvgs.GpuMat.from_array(a, t), np.zeros((cn * h, w + pad), np.float32))
     assert cvgs.kernel_name(*ops).startswith("pointwise4_"), cvgs.kernel_name(*ops)
+
+
+def test_fields_a_stage_does_not_use_do_not_change_the_kernel_or_the_bits(oracle):
+    """A binding written against include/cvgs_hip.h fills a descriptor its own way: junk in fields the chain's stages do not use (the
+    background of an IGNORE_AR resize, the YUV fields of a pixel read, the step of a dense tensor, the aux word of an arithmetic stage, the
+    fourth operand of a 3-channel value, selector bits beyond the value's channels, NOP stages in between) must neither change the kernel
+    the dispatcher picks nor a bit of the result."""
+    import ctypes as C
+    import torch
+    from cvgpuspeedup_amd import capi
+    dev = torch.device("cuda:0")
+    frame = H.random_u8((540, 960, 3), seed=4242)
+    ft = torch.from_numpy(frame).to(dev)
+    crops = H.random_crops(9, 960, 540, seed=4243, wmin=8, wmax=400, hmin=8, hmax=400)
+    out_a = torch.zeros((9, 3 * 64 * 128), dtype=torch.float32, device=dev)
+    out_b = torch.zeros_like(out_a)
+    lib = capi.load_library()
+    s = torch.cuda.current_stream().cuda_stream
+
+    def build(out):
+        return cvgs.lower(H.k1_chain(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)))
+
+    a, b = build(out_a), build(out_b)
+    d = b.desc
+    for c in range(4):
+        d.read.background[c] = 1e30
+    d.read.yuv_range, d.read.yuv_primaries, d.read.yuv_alpha = 1, 2, 1
+    d.write.step = 12345
+    n = d.n_ops
+    assert n == 4 and d.ops[0].opcode == capi.OP_REORDER
+    d.ops[0].aux |= 3 << 6            # a selector for a fourth channel the value does not have
+    for k in (1, 2, 3):
+        d.ops[k].aux = 77             # arithmetic stages have no aux
+        d.ops[k].operand[3] = -5.0    # nor a fourth channel
+        d.ops[k].operand_d[3] = -5.0
+    # NOP stages in between: REORDER, NOP, MUL, NOP, SUB, DIV
+    ops = [d.ops[k] for k in range(4)]
+    saved = [(o.opcode, o.aux, list(o.operand), list(o.operand_d)) for o in ops]
+    order = [0, None, 1, None, 2, 3]
+    for i, src in enumerate(order):
+        o = d.ops[i]
+        if src is None:
+            o.opcode, o.aux = capi.OP_NOP, 99
+        else:
+            o.opcode, o.aux = saved[src][0], saved[src][1]
+            for c in range(4):
+                o.operand[c] = saved[src][2][c]
+                o.operand_d[c] = saved[src][3][c]
+    d.n_ops = len(order)
+    name_a, name_b = C.create_string_buffer(128), C.create_string_buffer(128)
+    capi.check(lib.cvgs_kernel_name(C.byref(a.desc), name_a, 128))
+    capi.check(lib.cvgs_kernel_name(C.byref(d), name_b, 128))
+    assert name_a.value == name_b.value == b"k1_u8c3_swap_mul_sub_div", (name_a.value, name_b.value)
+    capi.check(lib.cvgs_execute(C.byref(a.desc), s))
+    capi.check(lib.cvgs_execute(C.byref(d), s))
+    torch.cuda.synchronize()
+    assert bool(torch.equal(out_a.view(torch.int32), out_b.view(torch.int32)))
+    assert bool(out_a.abs().sum() > 0)

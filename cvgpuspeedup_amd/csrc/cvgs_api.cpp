@@ -491,17 +491,20 @@ struct ScratchSlot {
     int device = -1;
     bool leased = false;  // handed to a call that has not committed yet
     bool pending = false; // committed: reusable once the event that covers it completes
-    // Lazy events (zero-copy mode): a hipEventRecord costs the stream ~4 us of device time behind the kernel (a marker packet between
-    // the launch and whatever follows: 5.8 us from the end of a 16-chain cvgs_execute_many launch to the next kernel against ~1.5 without
-    // it, rocprofv3 kernel trace), so a hot stream records ONE event per kLazyEvery commits -- on the committing call's own stream, alive
-    // by construction -- and the earlier uncovered slots of that stream share it (they precede it in stream order).
+    // Completion tracking.  Default: the launch that reads the slot signals `ev` itself (hipExtLaunchKernelGGL's stopEvent, K1's planar
+    // kernels: cvgs_device.h StopEventSlot) or, at the other launch sites, a hipEventRecord behind the launch.  Either way the stream pays
+    // ~4 us of device time between this kernel and the next (rocprofv3 kernel trace: 5.8 us from the end of a 16-chain cvgs_execute_many
+    // launch to the next kernel against ~1.5 without an event).  CVGS_SCRATCH_LAZY_EVENTS=n (opt-in) records ONE event per n commits of a
+    // hot stream instead -- on the committing call's own stream, alive by construction; the earlier uncovered slots of that stream share
+    // it -- which takes ticks of 16 frames on one stream from 3.05 to 2.83 us per frame.  It is opt-in because the last n - 1 slots of a
+    // stream that stops calling stay uncovered (a bounded leak per stream), and a DESTROYED stream cannot be asked anything: round 4 first
+    // reclaimed such slots with hipStreamQuery, which faults on a dead handle (found by tests/cpp/test_batchresize under ASan).
     hipStream_t stream = nullptr; // the stream whose kernel reads the slot
     int owner = -1;               // the slot whose `ev` covers this one (-1: not covered yet)
     uint32_t owner_gen = 0;       // ... and which recording of it (a later recording implies the earlier one completed)
     uint32_t gen = 0;             // recordings of `ev`
     std::chrono::steady_clock::time_point committed;
 };
-static constexpr int kLazyEvery = 4;
 
 class ScratchPool {
 public:
@@ -514,18 +517,6 @@ public:
                 if (!complete(sl)) continue;
                 sl.pending = false;
             }
-            sl.leased = true;
-            *slot_out = (int)i;
-            return 0;
-        }
-        // slots no event covers yet whose stream has gone quiet (fewer than kLazyEvery commits since): a stream that has nothing left to do
-        // has run the kernel that read them
-        const auto now = std::chrono::steady_clock::now();
-        for (size_t i = 0; i < slots_.size(); ++i) {
-            ScratchSlot& sl = slots_[i];
-            if (sl.device != device || sl.leased || sl.cap < bytes || !sl.pending || sl.owner >= 0) continue;
-            if (now - sl.committed < std::chrono::milliseconds(20) || hipStreamQuery(sl.stream) != hipSuccess) continue;
-            sl.pending = false;
             sl.leased = true;
             *slot_out = (int)i;
             return 0;
@@ -573,17 +564,18 @@ public:
         return 0;
     }
     void* host(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].host; }
+    hipEvent_t event(int slot) { std::lock_guard<std::mutex> lk(m_); return slots_[(size_t)slot].ev; }
     void* dev(int slot) {
         std::lock_guard<std::mutex> lk(m_);
         return scratch_zero_copy() ? slots_[(size_t)slot].host_dev : slots_[(size_t)slot].dev;
     }
     // the kernel that reads the slot has been enqueued on `stream`: recycle after it
-    void commit(int slot, hipStream_t stream) {
+    void commit(int slot, hipStream_t stream, bool signalled_by_launch = false) {
         std::lock_guard<std::mutex> lk(m_);
         ScratchSlot& sl = slots_[(size_t)slot];
         static const int lazy_every = [] {
             const char* e = getenv("CVGS_SCRATCH_LAZY_EVENTS"); // 1 = an event behind every launch (round 3's behaviour)
-            const int v = e ? atoi(e) : kLazyEvery;
+            const int v = e ? atoi(e) : 1; // (opt-in: slots of a stream that stops calling stay uncovered -- up to n - 1 per stream)
             return v < 1 ? 1 : (v > 64 ? 64 : v);
         }();
         sl.stream = stream;
@@ -591,6 +583,12 @@ public:
         sl.pending = true;
         sl.leased = false;
         sl.committed = std::chrono::steady_clock::now();
+        if (signalled_by_launch) { // the kernel's own completion signals sl.ev (hipExtLaunchKernelGGL stopEvent): nothing to record
+            ++sl.gen;
+            sl.owner = slot;
+            sl.owner_gen = sl.gen;
+            return;
+        }
         int uncovered = 0;
         for (const ScratchSlot& o : slots_)
             uncovered += o.pending && o.owner < 0 && o.stream == stream && o.device == sl.device;
@@ -678,6 +676,10 @@ struct Upload {
         rc = scratch_pool().acquire(device, bytes, &slot);
         if (rc) return rc;
         dev = scratch_pool().dev(slot);
+        static const bool stop_events = [] { const char* e = getenv("CVGS_SCRATCH_STOP_EVENTS"); return e ? e[0] != '0' : true; }();
+        cvgs::StopEventSlot& st = cvgs::tls_stop_event();
+        st.event = (stop_events && scratch_zero_copy()) ? (void*)scratch_pool().event(slot) : nullptr;
+        st.used = false;
         return 0;
     }
     // appends `bytes` to the staging buffer; returns the device address they will have (16-byte aligned pieces)
@@ -700,7 +702,11 @@ struct Upload {
     }
     void done(bool launched) {
         if (slot < 0) return;
-        if (launched || flushed) scratch_pool().commit(slot, stream); // an enqueued copy still reads the staging bytes
+        cvgs::StopEventSlot& st = cvgs::tls_stop_event();
+        const bool by_launch = launched && st.event && st.used;
+        st.event = nullptr;
+        st.used = false;
+        if (launched || flushed) scratch_pool().commit(slot, stream, by_launch); // an enqueued copy still reads the staging bytes
         else scratch_pool().abandon(slot);
         slot = -1;
     }

@@ -104,6 +104,18 @@ static_assert(sizeof(KernArgs<kKernargPlanesBig>) <= 16384, "large kernel-argume
 
 // Extra write targets (cvgs_write_desc.mirrors): the same values at the same element offsets in up to 7 more tensors
 // (the peers' copies of the sharded [N,C,H,W] tensor).  Travels as its own kernel argument to the kernels that
+// The launch that reads a pooled descriptor table signals the slot's event ITSELF (hipExtLaunchKernelGGL's stopEvent: the kernel packet's own
+// completion signal) instead of a hipEventRecord behind it -- a marker packet that kept the NEXT kernel of the stream ~4 us behind.  Armed by
+// the table upload of the call (thread-local: the launch happens on the same thread, inside the same C-ABI call), consumed by the launch site.
+struct StopEventSlot {
+    void* event = nullptr; // hipEvent_t
+    bool used = false;     // a launch site attached it
+};
+inline StopEventSlot& tls_stop_event() {
+    static thread_local StopEventSlot x{};
+    return x;
+}
+
 // implement it (K1 planar inside K1Geom, the interpreted kernel).
 struct MirrorArgs {          // 64 bytes
     uint8_t* p[CVGS_MAX_MIRRORS];

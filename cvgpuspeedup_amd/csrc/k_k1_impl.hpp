@@ -8,6 +8,8 @@
 #include <initializer_list>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "k_taps.hpp"
 
 namespace cvgs {
@@ -344,7 +346,13 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
     }
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
-    hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, a, g);
+    StopEventSlot& stop = tls_stop_event();
+    if (stop.event && !stop.used) {
+        stop.used = true;
+        hipExtLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, nullptr, (hipEvent_t)stop.event, 0u, a, g);
+    } else {
+        hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, a, g);
+    }
     return hipGetLastError();
 }
 

@@ -295,6 +295,11 @@ inline void (*&cvgs_stream_sync_hook())(hipStream_t) {
     static void (*hook)(hipStream_t) = nullptr;
     return hook;
 }
+// ... and the one a stream's destruction calls first: an attachment must not outlive its stream (a later stream may get the same handle)
+inline void (*&cvgs_stream_destroy_hook())(hipStream_t) {
+    static void (*hook)(hipStream_t) = nullptr;
+    return hook;
+}
 
 class Stream {
 public:
@@ -313,7 +318,13 @@ private:
         bool own = false;
         explicit Impl(bool create) : own(create) { if (create) cvgs_hip_check(hipStreamCreate(&s), "hipStreamCreate"); }
         Impl(hipStream_t user) : s(user), own(false) {}
-        ~Impl() { if (own && s) (void)hipStreamDestroy(s); }
+        ~Impl() {
+            if (!own || !s) return;
+            if (auto hook = cvgs_stream_destroy_hook()) {
+                try { hook(s); } catch (...) {} // (recorded calls are submitted, the attachment goes)
+            }
+            (void)hipStreamDestroy(s);
+        }
     };
     Stream(hipStream_t s, int) : impl_(std::make_shared<Impl>(s)) {}
     std::shared_ptr<Impl> impl_;

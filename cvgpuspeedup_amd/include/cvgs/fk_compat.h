@@ -978,6 +978,7 @@ public:
     void attach(hipStream_t stream, bool deferWait = false, int minGroup = 0) {
         detail::StreamAttachments& A = detail::stream_attachments();
         if (A.any.load(std::memory_order_acquire)) detail::flush_attached(stream); // (calls a previous attachment recorded)
+        cv::cuda::cvgs_stream_destroy_hook() = &Queue::detach; // a cv::cuda::Stream that dies takes its attachment with it
         std::lock_guard<std::mutex> lock(A.mu);
         const uint32_t f = CVGS_QUEUE_SUBMIT_HYBRID | (deferWait ? CVGS_QUEUE_SUBMIT_DEFER_WAIT : 0u) | CVGS_QUEUE_SUBMIT_MIN_GROUP(minGroup);
         for (auto& a : A.list)
@@ -996,6 +997,7 @@ public:
         for (auto& a : A.list)
             if (a.stream == stream) a.tick = tick < 1 ? 1 : (tick > 4 * CVGS_QUEUE_MAX_GROUP ? 4 * CVGS_QUEUE_MAX_GROUP : tick);
         cv::cuda::cvgs_stream_sync_hook() = &Queue::fence;
+        cv::cuda::cvgs_stream_destroy_hook() = &Queue::detach;
     }
     static void detach(hipStream_t stream) {
         detail::flush_attached(stream);
@@ -1052,6 +1054,7 @@ inline void recordTicks(hipStream_t stream, int tick = 16) {
     if (!found) A.list.push_back(std::move(at));
     A.any.store(true, std::memory_order_release);
     cv::cuda::cvgs_stream_sync_hook() = &Queue::fence;
+    cv::cuda::cvgs_stream_destroy_hook() = &Queue::detach;
 }
 inline void stopRecording(hipStream_t stream) { Queue::detach(stream); }
 

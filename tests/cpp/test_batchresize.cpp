@@ -488,6 +488,31 @@ static void test_recorded_ticks_vs_oracle(bool fence_then_async, bool with_queue
         (void)hipHostFree(cp->host);
     }
     CHECK(bad2 == 0, "recorded ticks: fence + detach leave " << bad2 << " tensors wrong");
+    // a stream that dies takes its attachment (and submits what it recorded): record on a scoped stream, let it go, then the tensors must be there
+    {
+        for (auto& cp : cams) HIP_OK(hipMemset(cp->tensor.data, 0, n * sizeof(float)));
+        cv::cuda::Stream scoped;
+        if (with_queue) cvGS::attachQueueTicks(scoped, *queue, 64);
+        else cvGS::recordTicks(scoped, 64);
+        for (auto& cp : cams) {
+            Cam& cam = *cp;
+            std::array<cv::cuda::GpuMat, BATCH> crops;
+            for (int i = 0; i < BATCH; ++i) crops[i] = cam.frame(cam.rects[i]);
+            std::apply([&](const auto&... iops) { cvGS::executeOperations(scoped, iops...); },
+                       build_chain<TI, TO, BATCH, cvGS::IGNORE_AR>(crops, cam.tensor, up, p));
+        }
+    } // ~Stream: flush + detach + hipStreamDestroy (which completes the stream's work)
+    HIP_OK(hipDeviceSynchronize());
+    int bad3 = 0;
+    std::vector<float> back(n);
+    for (auto& cp : cams) {
+        HIP_OK(hipMemcpy(back.data(), cp->tensor.data, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (!bit_equal(back.data(), cp->refs[(size_t)((TICKS - 1) % POOL)].data, n * sizeof(float))) ++bad3;
+    }
+    CHECK(bad3 == 0, "recorded calls of a stream that was destroyed: " << bad3 << " tensors wrong");
+    uint64_t tk = 0;
+    cv::cuda::Stream fresh; // (may get the dead stream's handle: it must not inherit an attachment)
+    CHECK(!cvGS::lastTicket(fresh, &tk), "a new stream starts unattached");
 }
 
 int main() {

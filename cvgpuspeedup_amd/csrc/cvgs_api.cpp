@@ -473,6 +473,15 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
 // recycled by the event behind the kernel that read it.  Measured (MI355X, eager, host descriptors): 16 x 50 crops through
 // cvgs_execute_many 47.3 -> 43.9 us, one chain of 400 crops 28.0 -> 23.7 us (host enqueue 19.4 -> 14.0 us); 300 back-to-back
 // launches with a different crop list each through recycled slots verified plane by plane against the oracle.
+// CVGS_SCRATCH_LAZY_EVENTS=n (opt-in, default 1 = every launch tracked on its own): see ScratchSlot
+static int scratch_lazy_every() {
+    static const int n = [] {
+        const char* e = getenv("CVGS_SCRATCH_LAZY_EVENTS");
+        const int v = e ? atoi(e) : 1;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
+}
 static bool scratch_zero_copy() {
     static const bool on = [] {
         const char* e = getenv("CVGS_SCRATCH_ZEROCOPY");
@@ -573,11 +582,7 @@ public:
     void commit(int slot, hipStream_t stream, bool signalled_by_launch = false) {
         std::lock_guard<std::mutex> lk(m_);
         ScratchSlot& sl = slots_[(size_t)slot];
-        static const int lazy_every = [] {
-            const char* e = getenv("CVGS_SCRATCH_LAZY_EVENTS"); // 1 = an event behind every launch (round 3's behaviour)
-            const int v = e ? atoi(e) : 1; // (opt-in: slots of a stream that stops calling stay uncovered -- up to n - 1 per stream)
-            return v < 1 ? 1 : (v > 64 ? 64 : v);
-        }();
+        const int lazy_every = scratch_lazy_every();
         sl.stream = stream;
         sl.owner = -1;
         sl.pending = true;
@@ -678,7 +683,7 @@ struct Upload {
         dev = scratch_pool().dev(slot);
         static const bool stop_events = [] { const char* e = getenv("CVGS_SCRATCH_STOP_EVENTS"); return e ? e[0] != '0' : true; }();
         cvgs::StopEventSlot& st = cvgs::tls_stop_event();
-        st.event = (stop_events && scratch_zero_copy()) ? (void*)scratch_pool().event(slot) : nullptr;
+        st.event = (stop_events && scratch_zero_copy() && scratch_lazy_every() == 1) ? (void*)scratch_pool().event(slot) : nullptr;
         st.used = false;
         return 0;
     }
@@ -1476,7 +1481,7 @@ int cvgs_queue_submit_many_on(cvgs_queue_t h, const cvgs_chain_desc* const* chai
     if (int rc = guard.enter(h->device)) return rc;
     // The latency policy for STRICTLY ordered groups, from the measurements (tools/probes/stream_ordered_rate.py, DESIGN 4 "Round 4"): the
     // stream is held until the group is complete either way, and ONE multi-chain launch (cvgs_execute_many) serves a tick of 16 frames at
-    // 2.5-2.8 us per frame where the gate + server reach 2.7-3.4 -- with no resident grid beside the consumer.  An explicit
+    // 2.4-3.0 us per frame where the gate + server reach 2.7-3.4 -- with no resident grid beside the consumer.  An explicit
     // CVGS_QUEUE_SUBMIT_MIN_GROUP(n) keeps groups of >= n chains on the server.
     if ((flags & CVGS_QUEUE_SUBMIT_HYBRID) && !(flags & CVGS_QUEUE_SUBMIT_DEFER_WAIT) && !(flags & CVGS_QUEUE_SUBMIT_MIN_GROUP(0xff)) && n >= 2) {
         std::vector<cvgs_chain_desc> flat((size_t)n);

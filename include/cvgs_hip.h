@@ -439,7 +439,7 @@ int cvgs_queue_submit_on(cvgs_queue_t q, const cvgs_chain_desc* chain, cvgs_stre
  * minimum and chains the server does not take are launched one by one on the stream, in order -- and a STRICTLY ordered group (no
  * DEFER_WAIT, no explicit MIN_GROUP) is ONE multi-chain launch on the stream (cvgs_execute_many; *last_ticket = CVGS_QUEUE_TICKET_DIRECT):
  * the stream is held until the group is complete either way, and measured (ticks of 16 frames, a producer on the stream) the launch
- * serves a frame in 2.5-2.8 us where gate + server take 2.7-3.4, with nothing resident beside the consumer.  The server keeps what it is
+ * serves a frame in 2.4-3.0 us where gate + server take 2.7-3.4, with nothing resident beside the consumer.  The server keeps what it is
  * better at: deferred waits (2.4-2.5 us per frame on ONE stream) and host tickets (cvgs_queue_submit, 2.15).               */
 #define CVGS_QUEUE_MAX_GROUP 64
 int cvgs_queue_submit_many_on(cvgs_queue_t q, const cvgs_chain_desc* const* chains, int32_t n, cvgs_stream_t stream, uint32_t flags, uint64_t* last_ticket);

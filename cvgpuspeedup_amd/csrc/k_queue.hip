@@ -1148,6 +1148,12 @@ static inline void wc_fence() {
 #endif
 }
 
+// one look at the environment per knob (a second getenv between the test and the use could return null)
+static long env_long(const char* name, long fallback) {
+    const char* e = getenv(name);
+    return e ? atol(e) : fallback;
+}
+
 // Is device memory writable from the host (large BAR, the allocation mapped into this process)?  Decided WITHOUT ever faulting: round 3
 // probed with a store guarded by process-wide SIGSEGV / SIGBUS handlers and siglongjmp -- inside a library that races every other
 // thread's faults and every other user of sigaction.  Now: (1) CVGS_QUEUE_DIRECT=0 / CVGS_QUEUE_STAGED=1 /
@@ -1553,7 +1559,7 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     // CVGS_QUEUE_DEEP_ROWS pins the size used from 8 batches in flight (tuning).
     advance_done(q);
     const uint64_t in_flight = q->next_seq - q->done_inorder;
-    static const int deep_env = getenv("CVGS_QUEUE_DEEP_ROWS") ? atoi(getenv("CVGS_QUEUE_DEEP_ROWS")) & ~3 : 0;
+    static const int deep_env = (int)env_long("CVGS_QUEUE_DEEP_ROWS", 0) & ~3;
     const bool sustained = q->R >= 32 && in_flight * 4 >= q->R * 3;
     const uint32_t deep_rows = deep_env >= 4 && deep_env <= 4096 ? (uint32_t)deep_env
                                : (sustained ? (q->R >= 128 ? (uint32_t)kQRowsPerTaskDeep : 64u) : (uint32_t)kQRowsPerTaskMid);
@@ -1834,7 +1840,7 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
     // (off by default: it bounds a batch's latency -- p90 19 us instead of 80-110 us with four strict streams -- but halves the work that
     //  can sit absorbed behind closed gates, which is exactly what keeps the server fed between two ticks: 16-frame ticks on two
     //  streams 2.5 -> 8.9 us per batch.  CVGS_QUEUE_CLOSED_BUDGET=<tasks> turns it on; 1 = half the workers.)
-    static const long budget_env = getenv("CVGS_QUEUE_CLOSED_BUDGET") ? atol(getenv("CVGS_QUEUE_CLOSED_BUDGET")) : 0;
+    static const long budget_env = env_long("CVGS_QUEUE_CLOSED_BUDGET", 0);
     const uint64_t budget = budget_env <= 0 ? ~0ull : (budget_env == 1 ? (uint64_t)q->G * kQWaves / 2 : (uint64_t)budget_env);
     int done = 0;
     while (done < n) {
@@ -1866,7 +1872,7 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
             const int min_group = (int)((flags >> 8) & 0xffu) ? (int)((flags >> 8) & 0xffu) : 8;
             if (hybrid && (!overlap || n - done < min_group)) { ++q->n_direct; if (n_queued) *n_queued = done; return 2; }
             rows = parallel >= 8 ? (uint32_t)kQRowsPerTaskMid : (parallel >= 1 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
-            static const int gated_rows_env = getenv("CVGS_QUEUE_GATED_ROWS") ? atoi(getenv("CVGS_QUEUE_GATED_ROWS")) & ~3 : 0; // tuning: the size used from 8 overlappable batches
+            static const int gated_rows_env = (int)env_long("CVGS_QUEUE_GATED_ROWS", 0) & ~3; // tuning: the size used from 8 overlappable batches
             if (gated_rows_env >= 4 && gated_rows_env <= 4096 && parallel >= 8) rows = (uint32_t)gated_rows_env;
             const auto t0 = std::chrono::steady_clock::now();
             unsigned spins = 0;

@@ -516,22 +516,46 @@ struct ScratchSlot {
 };
 
 class ScratchPool {
+    static constexpr int kMaxSlotsInFlight = 16;
 public:
-    int acquire(int device, size_t bytes, int* slot_out) {
-        std::lock_guard<std::mutex> lk(m_);
-        for (size_t i = 0; i < slots_.size(); ++i) {
-            ScratchSlot& sl = slots_[i];
-            if (sl.device != device || sl.leased || sl.cap < bytes) continue;
-            if (sl.pending) {
-                if (!complete(sl)) continue;
-                sl.pending = false;
+    int acquire(int device, size_t bytes, int* slot_out, hipStream_t stream) {
+        std::unique_lock<std::mutex> lk(m_);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int in_flight = 0, oldest = -1; // tables of THIS stream still in flight (another stream's blocked kernel is not this one's problem)
+            for (size_t i = 0; i < slots_.size(); ++i) {
+                ScratchSlot& sl = slots_[i];
+                if (sl.device != device || sl.cap < bytes) continue;
+                if (sl.leased) continue;
+                if (sl.pending) {
+                    if (!complete(sl)) {
+                        if (sl.stream == stream) {
+                            ++in_flight;
+                            if (sl.owner >= 0 && (oldest < 0 || sl.committed < slots_[(size_t)oldest].committed)) oldest = (int)i;
+                        }
+                        continue;
+                    }
+                    sl.pending = false;
+                }
+                sl.leased = true;
+                *slot_out = (int)i;
+                return 0;
             }
-            sl.leased = true;
-            *slot_out = (int)i;
-            return 0;
+            // Back-pressure instead of growth: a host that enqueues faster than the device executes (14 us per 16-chain launch against
+            // 50) would otherwise take a fresh pinned slot per launch -- an allocation of hundreds of microseconds each, in the middle of a
+            // serving loop (one eager row of bench.py read 87 us for 53 that way).  With kMaxSlotsInFlight tables of this size in flight ON THE
+            // CALLER'S STREAM the call waits for the oldest one's kernel (its own event: no stream is touched): the host runs at most that far ahead.
+            if (attempt == 0 && in_flight >= kMaxSlotsInFlight && oldest >= 0) {
+                const ScratchSlot& o = slots_[(size_t)slots_[(size_t)oldest].owner];
+                hipEvent_t ev = o.ev;
+                lk.unlock();
+                (void)hipEventSynchronize(ev);
+                lk.lock();
+                continue;
+            }
+            break;
         }
         // nothing free and large enough: add a slot (slots are never freed -- hipFree would synchronise the device; the
-        // pool is bounded by the number of tables in flight at once times the largest table)
+        // pool is bounded by kMaxSlotsInFlight tables per size class in flight at once, plus what lazy events leave uncovered)
         ScratchSlot sl;
         size_t cap = 64 << 10;
         while (cap < bytes) cap <<= 1;
@@ -678,7 +702,7 @@ struct Upload {
         DeviceGuard guard;
         int rc = guard.enter(device);
         if (rc) return rc;
-        rc = scratch_pool().acquire(device, bytes, &slot);
+        rc = scratch_pool().acquire(device, bytes, &slot, s);
         if (rc) return rc;
         dev = scratch_pool().dev(slot);
         static const bool stop_events = [] { const char* e = getenv("CVGS_SCRATCH_STOP_EVENTS"); return e ? e[0] != '0' : true; }();

@@ -296,7 +296,7 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * surface included; chains whose plane table lives on the device are NOT checked: the caller vouches for them -- lies inside another's
  * output: fused chains run concurrently), a set with a batch beyond 65535, and host descriptors under stream capture.  Host
  * descriptors of a fused launch are written into a pooled pinned buffer that the kernel reads in place (no copy; the slot is
- * recycled by a HIP event behind the kernel); pass device plane tables to make the fused call capturable; at most
+ * recycled once its kernel has run; a host more than 16 such launches ahead of ONE stream waits for the oldest of them); pass device plane tables to make the fused call capturable; at most
  * CVGS_MAX_CHAINS chains per call.  The reference's closest spelling is the batch sweep of
  * tests/batchresize/test_batchresize_x_split3D.cu:384-392 (one launch per BATCH value).                          */
 int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stream_t stream);

@@ -49,6 +49,7 @@ CFG5_CROPS = 64        # BASELINE cfg #5: 64 crops of a 6K frame per GPU
 INFINITY_CACHE = 256 << 20
 PREROLL_S = 0.05       # >= 50 ms of K1 before any timing (clock ramp)
 MIN_REPLAYS = 50
+RESIDENCY_SWEEP = (20, 48, 96)  # frames in rotation: round 4's 20 (touched set ~ 0.96 x the Infinity Cache), 48 (2.3 x), 96 (4.6 x)
 
 
 def baseline_metric():
@@ -78,6 +79,7 @@ def parse():
     p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
     p.add_argument("--no-regimes", action="store_true", help="skip the stream-ordered / latency / coexistence legs")
+    p.add_argument("--no-sweep", action="store_true", help="skip the 20 / 48 / 96-frame residency sweep of the headline step")
     p.add_argument("--soak", type=float, default=0.0, help="coexistence: seconds of soak with the consumer running throughout (0 = none)")
     p.add_argument("--print-extra", action="store_true", help="also print the full record (bench_extra.json's content) on stderr")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -150,6 +152,14 @@ class Workload:
         sample = self.crops[:min(len(self.crops), 8)]
         rd = float(np.mean([W.k1_sector_read_bytes(c, fw, fh, sector=sector) for c in sample]))
         return (wr + rd) * self.per_launch
+
+
+class RotationView:
+    """The first k frames of a Workload as a rotation of their own (the residency sweep): only what measure_queue reads."""
+
+    def __init__(self, wl, k):
+        self.chains = wl.chains[:k]
+        self.n = wl.n
 
 
 def capture(wl, n, base=0):
@@ -387,6 +397,47 @@ def cpu_baseline(wl, seconds):
             "gpu_matches_oracle_bit_exact": checked}
 
 
+def cfg1_cpu(seconds=1.5):
+    """BASELINE cfg #1 (the reference's own CPU-runnable case, README.md:91-97): 1 x 1080p u8c3 -> resize 64x128 -> subtract (1,4,6) ->
+    divide (2,8,1) -> split to 3 x fp32 planes, on the host through the oracle's interpreter (one thread): ms per frame."""
+    from oracle import oracle_binding as ob
+    frame = W.random_u8((1080, 1920, 3), W.SEED + 77)
+    out = np.zeros((1, 3 * W.DST[0] * W.DST[1]), np.float32)
+    f = cvgs.CV_32FC3
+    src = cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)
+    chain = cvgs.lower([cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [src], W.DST, 1), cvgs.subtract(f, [1.0, 4.0, 6.0]), cvgs.divide(f, [2.0, 8.0, 1.0]),
+                        cvgs.split(f, cvgs.GpuMat.from_array(out, cvgs.CV_32FC1), W.DST)])
+    lib = ob.load_oracle()
+    lib.oracle_set_threads(1)
+    ob.execute(chain)
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and reps < 200000:
+        ob.execute(chain)
+        reps += 1
+    dt = (time.perf_counter() - t0) / max(1, reps)
+    return {"ms": round(dt * 1e3, 4), "out_Mpix_s": round(W.DST[0] * W.DST[1] / dt / 1e6, 2), "src_Mpix_s": round(1920 * 1080 / dt / 1e6, 1), "threads": 1}
+
+
+def configs_block(extra):
+    """BASELINE.json's other single-GPU configs for the driver's line: cfg #3 (NV12 6K -> BGR float -> 1280x720 -> normalize,
+    one launch per frame and one queue submit per frame) and cfg #4 (CircularTensor depth 16 of 1080p fp32 x 3) from tools/bench_more.py's rows."""
+    rows = extra.get("other_configs") if isinstance(extra, dict) else None
+    out = {}
+    for r in rows or []:
+        c = r.get("config", "")
+        if c.startswith("cfg3 NV12"):
+            d = out.setdefault("cfg3", {})
+            if "cvgs_queue_submit" in c:
+                d["queue_us"] = r.get("us_per_launch")
+                d["queue_frac"] = r.get("frac_of_8TBs")
+            else:
+                d["launch_us"], d["frac"], d["surfaces"] = r.get("us_per_launch"), r.get("frac_of_8TBs"), r.get("surfaces_in_rotation")
+                d["out_Mpix_s"] = r.get("output_Mpix_per_s")
+        elif c.startswith("cfg4 CircularTensor depth 16, 1080p fp32 x3, push 1080p"):
+            out["cfg4"] = {"us": r.get("us_per_update"), "frac": r.get("frac_of_8TBs"), "GBs": r.get("GB_per_s"), "copy_GBs": r.get("copy_same_footprint_GB_per_s")}
+    return out
+
+
 def summary(wl, m, out_elem=4):
     """The figures every sweep line carries, all from the one per-step clock."""
     alg = wl.algorithmic_bytes(out_elem)
@@ -417,10 +468,16 @@ def main():
     M = a.frames_per_launch
     plane = 3 * W.DST[0] * W.DST[1]
     per_frame_bytes = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + n * plane * 4
-    n_frames = a.frames or max(8, (2 * INFINITY_CACHE + per_frame_bytes - 1) // per_frame_bytes + 1)
+    # The rotation is sized from the bytes a launch TOUCHES (distinct 64-byte sectors holding a tapped byte), not from whole frames:
+    # its READ-touched set alone must be >= 2 x the 256 MiB Infinity Cache (W.rotation_units; VERDICT r4 "What's weak" #2 -- round 4's
+    # 20 whole frames were 596 MB but 257 MB of touched sectors, 0.96 x the cache).  The headline rotates over the largest point of the
+    # residency sweep (96 frames: 763 MB read-touched + 472 MB written), which is beyond the rule's 68.
+    rd_frame, wr_frame = W.k1_touched_per_frame(n, W.FRAME_4K, rank)
+    n_frames = a.frames or max(W.rotation_units(rd_frame), RESIDENCY_SWEEP[-1])
     if M > 1:
         n_frames = ((n_frames + M - 1) // M) * M
     wl = Workload(dev, n_frames, n, rank, world, a.table or M > 1, per_launch=M)
+    resid = W.residency(n_frames, rd_frame, wr_frame, per_frame_bytes)
 
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
@@ -458,8 +515,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "cfg2b: %d variable-size crops (w~U[32,512], h~U[64,1024]) of a 4K u8c3 frame -> "
-                               "[%d,3,128,64] fp32 per launch; %d resident frames cycled (working set %.0f MB)" % (
-                                   n, n, n_frames, n_frames * per_frame_bytes / 1e6),
+                               "[%d,3,128,64] fp32 per launch; %d resident frames cycled (touched set %.0f MB = %.0f MB of tapped 64-B sectors + "
+                               "%.0f MB written, %.1f x the 268 MB Infinity Cache; the whole frames + tensors are %.0f MB)" % (
+                                   n, n, n_frames, resid["touched_MB"], resid["read_touched_MB"], resid["touched_MB"] - resid["read_touched_MB"],
+                                   resid["touched_MB"] / resid["llc_MB"], n_frames * per_frame_bytes / 1e6),
                    "chain": "resize(bilinear) -> RGB2BGR -> x0.3 -> -(1,4,3.2) -> /(3.2,0.6,11.8) -> TensorSplit",
                    "crops_per_launch": n, "frames_per_launch": M, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
                    "descriptors": "device table" if (a.table or M > 1) else "kernel arguments",
@@ -508,7 +567,21 @@ def main():
                           "sector_bound_bytes_per_launch": int(sector),
                           "frac_of_sector_bound": round(sector / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                           # the on-box device-to-device copy ceiling (read + write bytes / time), measured now
-                          "copy_ceiling": ceiling, "frac_of_copy_ceiling": round(achieved / ceiling, 4) if ceiling else None}
+                          "copy_ceiling": ceiling, "frac_of_copy_ceiling": round(achieved / ceiling, 4) if ceiling else None,
+                          "residency": resid,
+                          "traffic_src": "committed PMC passes of this kernel and workload (profiles/pmc_headline.json), not counters of this run"}
+    if use_queue and not a.frames and not a.no_sweep:
+        # the same step on rotations of 20 / 48 / 96 frames: does the figure depend on what the Infinity Cache can hold?
+        sweep = {}
+        for k in RESIDENCY_SWEEP:
+            if k == n_frames:
+                sweep[str(k)] = round(step_s * 1e6, 4)
+            elif k < n_frames:
+                sub = RotationView(wl, k)
+                ms = measure_queue(sub, a.steps, 0, target_s=0.08, min_replays=12, events=False)
+                sweep[str(k)] = round(ms["step_s"] * 1e6, 4)
+        result["roofline"]["sweep_us"] = sweep
+        result["roofline"]["sweep_touched_MB"] = {str(k): W.residency(k, rd_frame, wr_frame)["touched_MB"] for k in RESIDENCY_SWEEP if str(k) in sweep}
     result["timing"]["single_launch_latency"] = single_launch_latency(wl)
     if use_queue:  # the same workload with one graph-replayed launch per step: the round-1/2 headline, for comparison
         mg = measure(wl, a.steps, a.warmup)
@@ -541,6 +614,14 @@ def main():
             result["regimes_error"] = repr(ex)[:300]
     if not a.no_extra:
         result["extra"] = extra_sweeps(dev, a)
+    cfgs = configs_block(result.get("extra", {}))
+    if not a.no_cpu:
+        try:
+            cfgs["cfg1_cpu"] = cfg1_cpu()
+        except Exception as ex:
+            cfgs["cfg1_cpu"] = {"error": repr(ex)[:120]}
+    if cfgs:
+        result["configs"] = cfgs
     emit(result, a)
 
 
@@ -570,7 +651,10 @@ def compact_line(result):
             line["config"][k] = line["config"][k][:257] + "..."
     line["roofline"] = _pick(result.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us",
                                                           "algorithmic_bytes_per_launch", "sector_bound_bytes_per_launch",
-                                                          "frac_of_sector_bound", "copy_ceiling", "per_gpu_frac", "per_gpu_frac_on_the_queue"))
+                                                          "frac_of_sector_bound", "copy_ceiling", "per_gpu_frac", "per_gpu_frac_on_the_queue",
+                                                          "residency", "sweep_us", "traffic_src"))
+    if isinstance(line["roofline"].get("traffic_src"), str):
+        line["roofline"]["traffic_src"] = "profiles/pmc_headline.json (committed PMC passes, not this run)"
     if "cpu_baseline" in result:
         cb = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "single_thread_value", "gpu_matches_oracle_bit_exact"))
         if isinstance(cb.get("sample"), str) and len(cb["sample"]) > 200:
@@ -584,7 +668,7 @@ def compact_line(result):
     if "batch_latency_server_alive" in t or "single_launch_latency" in t:
         optional.append(("latency_us", {"queue_batch": t.get("batch_latency_server_alive", {}).get("median_us"),
                                         "one_launch": t.get("single_launch_latency", {}).get("median_us")}))
-    for k in ("stream_ordered", "coexistence", "n1_same_workload", "legs", "xgmi_probe", "queue_latency_by_depth", "regimes_error"):
+    for k in ("configs", "stream_ordered", "coexistence", "n1_same_workload", "rccl_ranks_seen", "gpus_seen", "legs", "xgmi_probe", "queue_latency_by_depth", "regimes_error"):
         if k in result:
             optional.append((k, result[k]))
     if "queue" in result:
@@ -747,7 +831,7 @@ def multi_stream(dev, n_streams=4, per_stream=64, rounds=16):
     """Independent batches submitted on several streams (one HIP graph with parallel branches): consecutive launches
     of ONE stream are serialised by the queue's barrier bit, so a single stream pays the full launch/drain latency per
     batch; independent streams overlap it.  Throughput only -- per-kernel durations stretch when kernels overlap."""
-    wl = Workload(dev, 24, CROPS, 0, 1, use_table=False)
+    wl = Workload(dev, W.rotation_units(W.k1_touched_per_frame(CROPS, W.FRAME_4K, 0, sample=4)[0]), CROPS, 0, 1, use_table=False)
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     for i in range(64):
         wl.launch(i, torch.cuda.current_stream().cuda_stream)
@@ -777,8 +861,8 @@ def multi_stream(dev, n_streams=4, per_stream=64, rounds=16):
 
 def sweep_line(dev, crops, frame_wh=W.FRAME_4K, per_launch=1, half=False, table=None, steps=None):
     out_elem = 2 if half else 4
-    per_frame = frame_wh[0] * frame_wh[1] * 3 + crops * 3 * 64 * 128 * out_elem
-    nf = max(4, min(48, (2 * INFINITY_CACHE) // per_frame + 1))
+    # (the rotation rule of the headline: the read-touched set alone >= 2 x the Infinity Cache; capped at 128 frames)
+    nf = max(4, min(128, W.rotation_units(W.k1_touched_per_frame(crops, frame_wh, 0, out_elem, sample=4)[0])))
     if per_launch > 1:
         nf = max(per_launch, ((nf + per_launch - 1) // per_launch) * per_launch)
     use_table = table if table is not None else (crops > 64 or per_launch > 1)
@@ -831,8 +915,7 @@ def extra_sweeps(dev, a):
         for crops in (50, 3200):
             out["fp16_output_%d" % crops] = sweep_line(dev, crops, half=True)
         # the fp16 tensor through the descriptor queue (one submit per frame, as the headline)
-        per_frame = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + 50 * 3 * 64 * 128 * 2
-        wlq = Workload(dev, max(4, min(48, (2 * INFINITY_CACHE) // per_frame + 1)), 50, 0, 1, False, half=True)
+        wlq = Workload(dev, max(4, min(128, W.rotation_units(W.k1_touched_per_frame(50, W.FRAME_4K, 0, 2, sample=4)[0]))), 50, 0, 1, False, half=True)
         mq = measure_queue(wlq, 256, 64, target_s=0.08, min_replays=10, events=False)
         out["fp16_output_50_queue"] = {"us_per_step": round(mq["step_s"] * 1e6, 3), "Mpix_per_s": round(50 * 8192 / mq["step_s"] / 1e6, 1),
                                        "every_frame_bit_identical_to_cvgs_execute": queue_outputs_match_execute(wlq), "queue_error": mq["queue"]["error"]}

@@ -67,7 +67,14 @@ def main(a, dev, rank, world):
     esz = 2 if half else 4
     tensor_bytes = world * n * plane * esz
     per_frame_bytes = fw * fh * 3 + tensor_bytes
-    n_frames = a.frames or max(6, (2 * B.INFINITY_CACHE + per_frame_bytes - 1) // per_frame_bytes + 1)
+    # rotation sized from TOUCHED bytes (W.rotation_units: the read-touched set alone >= 2 x the Infinity Cache), as the N = 1 headline
+    rd_frame, wr_frame = W.k1_touched_per_frame(n, W.FRAME_6K, rank, esz)
+    n_frames = a.frames or max(6, W.rotation_units(rd_frame))
+    # how many ranks / distinct GPUs this run really spans (RCCL has only ever seen one rank on this pool)
+    seen = [None] * world
+    dist.all_gather_object(seen, (str(getattr(torch.cuda.get_device_properties(dev), "uuid", None) or dev), dist.get_backend()))
+    rccl_ranks_seen = world if dist.get_backend() == "nccl" else 0
+    gpus_seen = len({u for u, _ in seen})
     steps, reps = a.steps, 9
 
     # the step's full tensors live in ONE dedicated allocation per rank, so that peers can map it with one IPC handle
@@ -264,6 +271,7 @@ def main(a, dev, rank, world):
                          "kernel_us": round(compute_step * 1e6, 3), "algorithmic_bytes_per_launch": int(alg),
                          "per_gpu_frac": round(alg / compute_step / 1e9 / B.HBM_PEAK_GBS, 4),
                          "per_gpu_frac_on_the_queue": round(alg / compute_queue_step / 1e9 / B.HBM_PEAK_GBS, 4) if compute_queue_step else None,
+                         "residency": W.residency(n_frames, rd_frame, wr_frame, per_frame_bytes),
                          "note": "K1 alone on each GPU (compute-only leg); the exchange is xGMI-bound, not HBM-bound"},
             # the SAME workload and submission path on ONE GPU (this rank's 64-crop-of-6K step, graph-replayed launches, measured in this
             # process while the other ranks run theirs): what a scaling curve of this line must be read against -- bench.py --gpus 1 is
@@ -272,6 +280,7 @@ def main(a, dev, rank, world):
                                  "on_the_queue_Mpix_per_s": round(n * W.DST[0] * W.DST[1] / compute_queue_step / 1e6, 1) if compute_queue_step else None,
                                  "on_the_queue_us_per_step": round(compute_queue_step * 1e6, 3) if compute_queue_step else None,
                                  "value_over_n1": round((px_step / step_s) / (n * W.DST[0] * W.DST[1] / compute_step), 3)},
+            "rccl_ranks_seen": rccl_ranks_seen, "gpus_seen": gpus_seen,
             "legs": {"compute_only_us": round(compute_step * 1e6, 3), "compute_only_on_the_queue_us": round(compute_queue_step * 1e6, 3) if compute_queue_step else None,
                      "allgather_us": round(ag_wall / steps * 1e6, 3),
                      "p2p_write_us": round(p2p["wall"] / steps * 1e6, 3) if p2p_ok else None,

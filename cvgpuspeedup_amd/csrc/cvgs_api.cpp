@@ -13,6 +13,7 @@
 #include <new>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "cvgs_device.h"
@@ -548,7 +549,13 @@ public:
                 const ScratchSlot& o = slots_[(size_t)slots_[(size_t)oldest].owner];
                 hipEvent_t ev = o.ev;
                 lk.unlock();
-                (void)hipEventSynchronize(ev);
+                // BOUNDED: the stream may be held by something only THIS host thread will release (a hipStreamWaitValue on a
+                // host-written word, a polling kernel the host feeds, an event this thread records later) -- an unbounded wait here would
+                // dead-lock the caller.  Poll the oldest table's event for a few milliseconds (a 16-chain launch takes 40 us), then grow
+                // the pool as before round 4.
+                const auto t0 = std::chrono::steady_clock::now();
+                while (hipEventQuery(ev) != hipSuccess && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(4)) std::this_thread::yield();
+                (void)hipGetLastError(); // (hipErrorNotReady is sticky in hipGetLastError)
                 lk.lock();
                 continue;
             }
@@ -867,6 +874,57 @@ bool same_shape(const cvgs_chain_desc& a, const cvgs_chain_desc& b) {
            (wa.kind != CVGS_WRITE_TENSOR_T_SPLIT || wa.planes == wb.planes); // CNHW: the channel stride is the tensor's N
 }
 
+// Are n chains INDEPENDENT -- no chain writes where another writes, and no chain reads (host-described sources) where another writes?
+// Anything that runs a group's chains concurrently (the fused launch of cvgs_execute_many, a group behind ONE gate on the queue's server)
+// needs that; n sequential cvgs_execute calls do not, and the callers fall back to them.  Only tensor targets have an
+// extent this function can state: any other write kind answers "not independent" (nothing concurrent serves those anyway).  Sources that
+// live in a caller-owned DEVICE table (CVGS_READ_FLAG_TABLE_ON_DEVICE) cannot be seen from the host: only the targets are compared then.
+struct ByteRange { const uint8_t* lo; const uint8_t* hi; };
+bool tensor_out_range(const cvgs_chain_desc& c, ByteRange* out) {
+    if (c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return false;
+    if (c.read.batch < 1 || !c.write.data) return false;
+    const size_t esz = (size_t)depth_bytes(CVGS_TYPE_DEPTH(c.write.dst_type));
+    const size_t plane = (size_t)c.write.width * (size_t)c.write.height, cn = (size_t)CVGS_TYPE_CN(c.write.dst_type);
+    // NCHW: batch images of cn planes.  CNHW (TensorTSplit): channel k of image z lives at (k * write.planes + z) * plane -- the
+    // chain's writes reach up to channel cn-1 of image batch-1, i.e. ((cn - 1) * planes + batch) planes (batch * cn
+    // planes understated it whenever the tensor holds more images than the chain writes)
+    const size_t n_planes_written = c.write.kind == CVGS_WRITE_TENSOR_T_SPLIT
+                                        ? (cn - 1) * (size_t)(c.write.planes > c.read.batch ? c.write.planes : c.read.batch) + (size_t)c.read.batch
+                                        : (size_t)c.read.batch * cn;
+    *out = ByteRange{(const uint8_t*)c.write.data, (const uint8_t*)c.write.data + n_planes_written * plane * esz};
+    return true;
+}
+bool chains_independent(const cvgs_chain_desc* const* chains, int n) {
+    if (n > CVGS_MAX_CHAINS) return false;
+    ByteRange outs[CVGS_MAX_CHAINS];
+    for (int i = 0; i < n; ++i) {
+        if (!chains[i] || !tensor_out_range(*chains[i], &outs[i])) return false;
+        for (int j = 0; j < i; ++j)
+            if (outs[i].lo < outs[j].hi && outs[j].lo < outs[i].hi) return false; // two chains write the same bytes
+    }
+    for (int i = 0; i < n; ++i) { // a source view of one chain inside another chain's output
+        const cvgs_chain_desc& c = *chains[i];
+        if (c.read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) continue;
+        const cvgs_image2d* src = (const cvgs_image2d*)c.read.src;
+        const bool yuv = c.read.kind == CVGS_READ_NV12_RESIZE_LINEAR || c.read.kind == CVGS_READ_NV12;
+        for (int k = 0; src && k < c.read.batch && k < c.read.used_planes; ++k) {
+            const uint8_t* lo = (const uint8_t*)src[k].data;
+            size_t rows = (size_t)(src[k].height > 0 ? src[k].height : 1);
+            const uint8_t* hi = lo + (size_t)src[k].step * rows;
+            if (yuv) {
+                // 4:2:0 surfaces: the chroma rows are read too -- behind the luma rows (whole surfaces: height * 3 / 2 rows) or,
+                // for a crop view, uv_offset bytes from its first luma byte (+ half the crop's rows)
+                const size_t chroma_rows = (rows + 1) / 2;
+                const uint8_t* chi = src[k].uv_offset ? lo + (size_t)src[k].uv_offset + (size_t)src[k].step * chroma_rows : hi + (size_t)src[k].step * chroma_rows;
+                if (chi > hi) hi = chi;
+            }
+            for (int j = 0; j < n; ++j)
+                if (lo < outs[j].hi && outs[j].lo < hi) return false;
+        }
+    }
+    return true;
+}
+
 int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
     // try the fused launch: every chain a resize of pixels (K1) or of 4:2:0 surfaces (K4) into a planar tensor, all of one shape
     bool fusable = n >= 2;
@@ -887,40 +945,12 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         const bool tables0 = (chains[0].read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (!tables0 && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) fusable = false;
-        struct Range { const uint8_t* lo; const uint8_t* hi; };
-        Range outs[CVGS_MAX_CHAINS];
-        for (int i = 0; fusable && i < n; ++i) {
-            const cvgs_chain_desc& c = chains[i];
-            if (c.read.batch < 1 || c.read.batch > 65535) fusable = false;
-            const size_t esz = (size_t)depth_bytes(CVGS_TYPE_DEPTH(c.write.dst_type));
-            const size_t plane = (size_t)c.write.width * (size_t)c.write.height, cn = (size_t)CVGS_TYPE_CN(c.write.dst_type);
-            // NCHW: batch images of cn planes.  CNHW (TensorTSplit): channel k of image z lives at (k * write.planes + z) * plane -- the
-            // chain's writes reach up to channel cn-1 of image batch-1, i.e. ((cn - 1) * planes + batch) planes (batch * cn
-            // planes understated it whenever the tensor holds more images than the chain writes)
-            const size_t n_planes_written = c.write.kind == CVGS_WRITE_TENSOR_T_SPLIT
-                                                ? (cn - 1) * (size_t)(c.write.planes > c.read.batch ? c.write.planes : c.read.batch) + (size_t)c.read.batch
-                                                : (size_t)c.read.batch * cn;
-            const size_t bytes = n_planes_written * plane * esz;
-            outs[i] = Range{(const uint8_t*)c.write.data, (const uint8_t*)c.write.data + bytes};
-            for (int j = 0; fusable && j < i; ++j)
-                if (outs[i].lo < outs[j].hi && outs[j].lo < outs[i].hi) fusable = false; // two chains write the same bytes
-        }
-        for (int i = 0; fusable && !tables0 && i < n; ++i) { // a source view of one chain inside another chain's output
-            const cvgs_image2d* src = (const cvgs_image2d*)chains[i].read.src;
-            for (int k = 0; fusable && src && k < chains[i].read.batch && k < chains[i].read.used_planes; ++k) {
-                const uint8_t* lo = (const uint8_t*)src[k].data;
-                size_t rows = (size_t)(src[k].height > 0 ? src[k].height : 1);
-                const uint8_t* hi = lo + (size_t)src[k].step * rows;
-                if (chains[i].read.kind == CVGS_READ_NV12_RESIZE_LINEAR) {
-                    // 4:2:0 surfaces: the chroma rows are read too -- behind the luma rows (whole surfaces: height * 3 / 2 rows) or,
-                    // for a crop view, uv_offset bytes from its first luma byte (+ half the crop's rows)
-                    const size_t chroma_rows = (rows + 1) / 2;
-                    const uint8_t* chi = src[k].uv_offset ? lo + (size_t)src[k].uv_offset + (size_t)src[k].step * chroma_rows : hi + (size_t)src[k].step * chroma_rows;
-                    if (chi > hi) hi = chi;
-                }
-                for (int j = 0; fusable && j < n; ++j)
-                    if (lo < outs[j].hi && outs[j].lo < hi) fusable = false;
-            }
+        for (int i = 0; fusable && i < n; ++i)
+            if (chains[i].read.batch < 1 || chains[i].read.batch > 65535) fusable = false;
+        if (fusable) {
+            const cvgs_chain_desc* ptrs[CVGS_MAX_CHAINS];
+            for (int i = 0; i < n; ++i) ptrs[i] = &chains[i];
+            fusable = chains_independent(ptrs, n);
         }
     }
     if (fusable) {
@@ -1527,6 +1557,12 @@ int cvgs_queue_submit_many_on(cvgs_queue_t h, const cvgs_chain_desc* const* chai
     std::string err = "queue: not chains the server takes";
     int rc = 1, queued = 0;
     uint64_t tickets[CVGS_QUEUE_MAX_GROUP];
+    // The server runs the batches of a group CONCURRENTLY: a group in which one chain writes what another reads or writes keeps
+    // the meaning of n ordered calls only as n ordered launches -- the hybrid policy does that below, without it the group is refused.
+    if (servable && n >= 2 && !chains_independent(chains, n)) {
+        servable = false;
+        err = "queue: the chains of one group must be independent (a chain writes what another chain reads or writes); submit them one by one";
+    }
     if (servable) {
         const cvgs::ChainArgs* ca[CVGS_QUEUE_MAX_GROUP];
         const cvgs::PlaneParams* pp[CVGS_QUEUE_MAX_GROUP];

@@ -1118,6 +1118,10 @@ struct Queue {
     uint64_t failed_upto = 0;              // every batch below was submitted before the last recovery
     std::vector<uint64_t> lost_tickets;    // ... and these had not completed then: their tensors may be incomplete (the newest 4096 are remembered)
     uint64_t n_gated = 0, n_direct = 0; // stream-ordered submits taken by the server / by a direct launch (hybrid policy)
+    struct StreamPrio { void* stream; bool same_as_server; };
+    std::vector<StreamPrio> stream_prio; // caller streams whose priority has been looked at (queue_submit_on)
+    int server_prio = 0;
+    bool server_prio_known = false, prio_range_nonempty = false;
     struct StreamTail { void* stream; uint64_t ticket; };
     std::vector<StreamTail> stream_tail; // the newest ticket of every stream that has submitted with an immediate wait (hybrid policy)
     std::mutex mu;
@@ -1392,6 +1396,10 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
         err = std::string("queue init: ") + hipGetErrorString(e);
         return -1;
     }
+    // (the server's priority, for queue_submit_on's guard against caller streams that may share its hardware queue)
+    q->prio_range_nonempty = prio_least != prio_greatest;
+    q->server_prio_known = hipStreamGetPriority(q->stream, &q->server_prio) == hipSuccess;
+    (void)hipGetLastError();
     if (getenv("CVGS_QUEUE_GATE_TRACE") && hipHostMalloc((void**)&q->gate_trace, 4096 * 32, hipHostMallocDefault) == hipSuccess) std::memset(q->gate_trace, 0, 4096 * 32);
     q->direct = decide_direct(device, q->dev_block, total, &q->m.dc->stop_gen.pad[0], flags);
     if (!q->direct) {
@@ -1837,6 +1845,30 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
     }
     const bool defer = (flags & QSUB_DEFER_WAIT) != 0, hybrid = (flags & QSUB_HYBRID) != 0;
     void* const key = stream ? stream : (void*)q; // (the null stream is a stream too)
+    // A caller stream at the SERVER's own priority (the greatest: torch.cuda.Stream(priority=-1) is exactly that on ROCm) may be multiplexed
+    // onto the server's hardware queue, where its gate kernel would sit behind the long-lived server grid and never start -- the batch
+    // would wait the 10 s gate limit and end in error 3.  Not a stream the server takes: the hybrid policy launches directly.
+    // One hipStreamGetPriority per stream key, cached.
+    if (stream && q->server_prio_known) {
+        bool same = false, found = false;
+        {
+            std::lock_guard<std::mutex> lock(q->mu);
+            for (const auto& sp : q->stream_prio)
+                if (sp.stream == stream) { found = true; same = sp.same_as_server; break; }
+        }
+        if (!found) {
+            int prio = 0;
+            same = hipStreamGetPriority((hipStream_t)stream, &prio) == hipSuccess && prio == q->server_prio && q->prio_range_nonempty;
+            std::lock_guard<std::mutex> lock(q->mu);
+            if (q->stream_prio.size() >= 256) q->stream_prio.erase(q->stream_prio.begin()); // (handles are reused: bounded, oldest out)
+            q->stream_prio.push_back({stream, same});
+        }
+        if (same) {
+            err = "queue: the stream has the server's own (highest) priority and may share its hardware queue -- its gate kernel could never start; "
+                  "use a default-priority stream, or the hybrid policy's direct launches";
+            return 1;
+        }
+    }
     // (off by default: it bounds a batch's latency -- p90 19 us instead of 80-110 us with four strict streams -- but halves the work that
     //  can sit absorbed behind closed gates, which is exactly what keeps the server fed between two ticks: 16-frame ticks on two
     //  streams 2.5 -> 8.9 us per batch.  CVGS_QUEUE_CLOSED_BUDGET=<tasks> turns it on; 1 = half the workers.)

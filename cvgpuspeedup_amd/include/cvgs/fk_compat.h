@@ -752,8 +752,10 @@ struct StreamAttachments {
     std::vector<StreamAttachment> list;
 };
 inline StreamAttachments& stream_attachments() {
-    static StreamAttachments a;
-    return a;
+    // leaked on purpose: a namespace-scope cv::cuda::Stream is destroyed AFTER function-local statics of other translation
+    // units may be gone, and its destroy hook looks in here
+    static StreamAttachments* a = new StreamAttachments;
+    return *a;
 }
 // submit what a recording stream has pending: ONE cvgs_queue_submit_many_on per <= 64 chains (the pending list is taken under the lock, the
 // submit runs outside it)
@@ -768,13 +770,23 @@ inline void flush_attached(hipStream_t stream) {
             if (a.stream == stream) { take.swap(a.pending); q = a.queue; flags = a.flags; break; }
     }
     if (take.empty()) return;
+    // A chunk that fails as a whole (one chain the lowering rejects fails the group) is retried chain by chain, in order, as plain launches:
+    // the other recorded calls are NOT dropped and the error names the offending chain.  Every chunk is attempted; the first
+    // error is thrown once all of them have been.
+    std::string first_error;
+    auto one_by_one = [&](size_t base, size_t cnt) {
+        for (size_t i = base; i < base + cnt; ++i)
+            if (cvgs_execute(&take[i]->d, stream) != CVGS_OK && first_error.empty())
+                first_error = std::string("cvGS (recorded call ") + std::to_string(i) + " of the tick): " + cvgs_last_error();
+    };
     if (!q) { // recording without a queue (fk::recordTicks): ONE cvgs_execute_many launch per <= CVGS_MAX_CHAINS chains, strictly ordered
         std::vector<cvgs_chain_desc> flat(take.size());
         for (size_t i = 0; i < take.size(); ++i) flat[i] = take[i]->d;
         for (size_t base = 0; base < flat.size(); base += CVGS_MAX_CHAINS) {
             const size_t cnt = flat.size() - base < (size_t)CVGS_MAX_CHAINS ? flat.size() - base : (size_t)CVGS_MAX_CHAINS;
-            check_status(cvgs_execute_many(flat.data() + base, (int32_t)cnt, stream));
+            if (cvgs_execute_many(flat.data() + base, (int32_t)cnt, stream) != CVGS_OK) one_by_one(base, cnt);
         }
+        if (!first_error.empty()) throw std::runtime_error(first_error);
         return;
     }
     std::vector<const cvgs_chain_desc*> ptrs(take.size());
@@ -782,7 +794,12 @@ inline void flush_attached(hipStream_t stream) {
     uint64_t last = CVGS_QUEUE_TICKET_DIRECT, newest = CVGS_QUEUE_TICKET_DIRECT;
     for (size_t base = 0; base < ptrs.size(); base += CVGS_QUEUE_MAX_GROUP) {
         const size_t cnt = ptrs.size() - base < (size_t)CVGS_QUEUE_MAX_GROUP ? ptrs.size() - base : (size_t)CVGS_QUEUE_MAX_GROUP;
-        check_status(cvgs_queue_submit_many_on(q, ptrs.data() + base, (int32_t)cnt, stream, flags, &last));
+        if (cvgs_queue_submit_many_on(q, ptrs.data() + base, (int32_t)cnt, stream, flags, &last) != CVGS_OK) {
+            // (with DEFER_WAIT the launches are ordered behind the stream, not behind earlier groups still on the server: order them first)
+            if (newest != CVGS_QUEUE_TICKET_DIRECT) (void)cvgs_queue_stream_wait(q, newest, stream);
+            one_by_one(base, cnt);
+            continue;
+        }
         if (last != CVGS_QUEUE_TICKET_DIRECT) newest = last;
     }
     if (newest != CVGS_QUEUE_TICKET_DIRECT) {
@@ -790,6 +807,7 @@ inline void flush_attached(hipStream_t stream) {
         for (auto& a : A.list)
             if (a.stream == stream) { a.last_ticket = newest; a.has_ticket = true; break; }
     }
+    if (!first_error.empty()) throw std::runtime_error(first_error);
 }
 // a recording stream takes the chain (true) -- and flushes when the tick is full
 inline bool record_attached(hipStream_t stream, std::unique_ptr<ChainBuilder>& b) {

@@ -12,6 +12,7 @@ FRAME_1080P = (1920, 1080)
 FRAME_4K = (3840, 2160)
 FRAME_6K = (6144, 3456)
 DST = (64, 128)  # crop target, width x height (reference tests/batchresize/test_batchresize_x_split3D.cu:265)
+LLC_BYTES = 256 << 20  # MI355X Infinity Cache (MI355X_MICROARCH.md)
 
 # the per-channel tables of the reference's K1 tests (test_batchresize_x_split3D.cu:56-67,241-252)
 K1_ALPHA = 0.3
@@ -180,3 +181,49 @@ def k1_sector_read_bytes(crops, frame_w, frame_h, dst=DST, px_bytes=3, sector=64
         secs = np.unique(np.concatenate([first, last]))
         mark[np.ix_(rows, secs)] = True
     return int(mark.sum()) * sector
+
+
+def nv12_crops_sector_read_bytes(crops, surf_w, surf_h, dst=DST, sample_bytes=1, sector=64):
+    """Sector-granular READ bound of one K4 launch over crops of ONE NV12 / P010 surface (the decode-side cfg #2b): distinct sectors of
+    the luma plane and of the interleaved chroma plane holding a tapped sample, union over the crops (rows dense: step = w * sample_bytes)."""
+    step = surf_w * sample_bytes
+    ns = (step + sector - 1) // sector
+    luma = np.zeros((surf_h, ns), dtype=bool)
+    chroma = np.zeros((surf_h // 2 + 1, ns), dtype=bool)
+    for (x0, y0, w, h) in crops:
+        cols = _tap_indices(w, dst[0]) + x0
+        rows = _tap_indices(h, dst[1]) + y0
+        lb = cols * sample_bytes
+        luma[np.ix_(rows, np.unique(np.concatenate([lb // sector, (lb + sample_bytes - 1) // sector])))] = True
+        pb = (cols // 2) * 2 * sample_bytes
+        chroma[np.ix_(np.unique(rows // 2), np.unique(np.concatenate([pb // sector, (pb + 2 * sample_bytes - 1) // sector])))] = True
+    return int(luma.sum() + chroma.sum()) * sector
+
+
+def rotation_units(read_touched_bytes_per_unit, factor=2.0, minimum=8, requested=0):
+    """How many distinct frames / surfaces a benchmark must rotate through so that NONE of what a launch reads can still be in
+    the 256 MiB Infinity Cache on its next turn: the rule is on the bytes a launch actually TOUCHES on the read side (the distinct
+    64-byte sectors that hold a tapped byte), not on whole-frame sizes -- the READ-touched set of the rotation alone is >= `factor`
+    x the cache, so the rule holds even if streaming (nt) stores never allocate there ("working sets that defeat the
+    256 MB Infinity Cache"; VERDICT r4 "What's weak" #2: 20 whole 4K frames are 596 MB but only 257 MB of touched sectors)."""
+    if requested:
+        return int(requested)
+    return int(max(minimum, -(-int(factor * LLC_BYTES) // max(1, int(read_touched_bytes_per_unit)))))
+
+
+def k1_touched_per_frame(n_crops, frame_wh, rank=0, out_elem=4, cn=3, sample=8):
+    """(read-touched, written) bytes of ONE K1 launch over `n_crops` cfg #2b crops of one frame: mean over `sample` of the crop
+    lists bench.py's Workload generates (seed rule below), the sector census of k1_sector_read_bytes."""
+    fw, fh = frame_wh
+    rd = float(np.mean([k1_sector_read_bytes(random_crops(n_crops, fw, fh, seed=SEED + 1000 * rank + f + 500000), fw, fh, px_bytes=cn)
+                        for f in range(sample)]))
+    return rd, float(n_crops * cn * out_elem * DST[0] * DST[1])
+
+
+def residency(units, read_touched_per_unit, written_per_unit, whole_unit_bytes=None):
+    """The block bench.py prints beside a roofline figure: how large the rotation's touched set is against the Infinity Cache."""
+    r = {"frames": int(units), "touched_MB": round(units * (read_touched_per_unit + written_per_unit) / 1e6, 1),
+         "read_touched_MB": round(units * read_touched_per_unit / 1e6, 1), "llc_MB": round(LLC_BYTES / 1e6, 1)}
+    if whole_unit_bytes:
+        r["whole_frames_MB"] = round(units * whole_unit_bytes / 1e6, 1)
+    return r

@@ -389,8 +389,13 @@ int cvgs_circular_destroy(cvgs_circular_t ct);
  *   cvgs_queue_wait     host waits for a ticket AND every batch submitted before it (tickets are handed out in submit order; the
  *                       server completes batches in any order -- their tasks are spread over its workers -- so the wait looks at every
  *                       batch up to the ticket that it has not yet seen complete); cvgs_queue_stream_wait makes a HIP stream
- *                       wait for the same set instead (one hipStreamWaitValue64 per batch still open, on the batches' device-side
- *                       completion words), the consumer's kernels enqueued behind it see the tensors.
+ *                       wait for the same set instead: ONE one-wave polling kernel on that stream (k1q_wait; an unsatisfied
+ *                       hipStreamWaitValue64 on device memory costs ~1.6 ms here -- CVGS_QUEUE_WAITVALUE=1 keeps that spelling), the
+ *                       consumer's kernels enqueued behind it see the tensors.  RELEASE ON FAILURE: the gate kernel of a stream-ordered
+ *                       submit and the wait kernel return -- and so release the stream -- when the queue's error word is set or their
+ *                       time limit expires (the 10 s gate limit / the stall limit); the tensor may then be incomplete and NOTHING on the
+ *                       stream says so.  The failure is reported by the next cvgs_queue_wait / submit / stats call (error word != 0):
+ *                       a consumer that must not run on an incomplete tensor checks cvgs_queue_wait(ticket) == CVGS_OK first.
  * Tuning hooks (environment): CVGS_QUEUE_G = worker workgroups (default 2 per CU - 1 for 8-bit pixel crops, 3 per CU - 1 for the other kinds; the flags' bits 16..27 say the same per queue),
  * CVGS_QUEUE_DEEP_ROWS = rows per task of a deep queue (default 64 / 128 by depth), CVGS_QUEUE_STALL_MS, CVGS_QUEUE_STAGED=1, CVGS_QUEUE_DEBUG=1.
  * Submits from several host threads are serialised by a mutex (tickets are handed out in submit order).  cvgs_queue_destroy
@@ -435,7 +440,12 @@ int cvgs_queue_submit_on(cvgs_queue_t q, const cvgs_chain_desc* chain, cvgs_stre
 /* n chains (<= CVGS_QUEUE_MAX_GROUP) behind ONE gate kernel: the pictures of one tick -- several cameras' frames written by the work in
  * front of the call, several crop lists of one frame -- are ordered behind `stream` together, overlap on the server, and (unless
  * DEFER_WAIT) the stream is held until ALL of them are complete: one launch per tick instead of one per chain.  The stream-ordered
- * counterpart of cvgs_execute_many / cvgs_queue_submit_many.  A wait on *last_ticket covers the group.  With HYBRID, groups below the
+ * counterpart of cvgs_execute_many / cvgs_queue_submit_many.  A wait on *last_ticket covers the group.  The chains of a group run
+ * CONCURRENTLY on the server, so they must be independent -- no chain may write what another chain of the group reads or writes (checked
+ * for tensor targets against each other and against host-described sources, as cvgs_execute_many does; sources in caller-owned device
+ * tables cannot be checked): a dependent group is launched one by one, in order, under HYBRID and is CVGS_ERR_UNSUPPORTED without it.
+ * A caller stream created at the HIGHEST stream priority (the server's own) may share the server's hardware queue, where its gate kernel
+ * could never start: such streams are not taken by the server (HYBRID: direct launches; otherwise CVGS_ERR_UNSUPPORTED).  With HYBRID, groups below the
  * minimum and chains the server does not take are launched one by one on the stream, in order -- and a STRICTLY ordered group (no
  * DEFER_WAIT, no explicit MIN_GROUP) is ONE multi-chain launch on the stream (cvgs_execute_many; *last_ticket = CVGS_QUEUE_TICKET_DIRECT):
  * the stream is held until the group is complete either way, and measured (ticks of 16 frames, a producer on the stream) the launch

@@ -500,3 +500,65 @@ def test_four_host_threads_submit_stream_ordered_batches(oracle, torch_dev):
         assert bool(torch.equal(extra.out.view(torch.int32), extra.refs[0]))
     finally:
         q.destroy()
+
+
+def test_a_dependent_group_is_not_run_concurrently(oracle, torch_dev):
+    """the server runs the batches of one group concurrently, so a group in which one chain writes what another chain writes (or
+    reads) must not go behind ONE gate.  Two chains with the SAME output tensor: refused without the hybrid policy (CVGS_ERR_UNSUPPORTED,
+    nothing queued); with it they are launched one by one, in order -- the tensor then holds the LAST chain's result, as two ordered
+    cvgs_execute calls would leave it.  An independent group of the same shape still goes to the server."""
+    torch, dev = torch_dev
+    a, b = Camera(torch, dev, oracle, seed=71, n_crops=9), Camera(torch, dev, oracle, seed=72, n_crops=9)
+    warm(torch, a)
+    warm(torch, b)
+    # chain `b2`: camera b's picture and crops INTO camera a's tensor
+    ops = H.k1_chain(cvgs.GpuMat.from_tensor(b.frame, cvgs.CV_8UC3), b.crops, cvgs.GpuMat.from_tensor(a.out, cvgs.CV_32FC1), DST, CN)
+    b2 = cvgs.lower(ops)
+    dep = cvgs.Queue.chain_pointers([a.lowered, b2])
+    ind = cvgs.Queue.chain_pointers([a.lowered, b.lowered])
+    q = cvgs.Queue(idle_us=5000.0)
+    s = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(s):
+            a.frame.copy_(a.pool[1])
+            b.frame.copy_(b.pool[2])
+        s.synchronize()
+        with pytest.raises(Exception):   # strict group on the server (explicit MIN_GROUP keeps it there): refused
+            q.submit_many_on(s, dep, 2, cvgs.Queue.MIN_GROUP(2))
+        assert q.stats()["submitted"] == 0
+        t = q.submit_many_on(s, dep, 2, cvgs.Queue.HYBRID | cvgs.Queue.DEFER_WAIT | cvgs.Queue.MIN_GROUP(2))
+        assert t == cvgs.Queue.TICKET_DIRECT and q.stats()["submitted"] == 0
+        s.synchronize()
+        assert torch.equal(a.out.view(torch.int32), b.refs[2])   # the second chain's bits: the launches ran in order
+        t = q.submit_many_on(s, ind, 2, cvgs.Queue.MIN_GROUP(2))
+        s.synchronize()
+        assert t != cvgs.Queue.TICKET_DIRECT and q.stats()["submitted"] == 2 and q.stats()["error"] == 0
+        assert torch.equal(a.out.view(torch.int32), a.refs[1]) and torch.equal(b.out.view(torch.int32), b.refs[2])
+    finally:
+        q.destroy()
+
+
+def test_a_stream_at_the_servers_priority_is_not_taken_by_the_server(oracle, torch_dev):
+    """the server's stream has the highest stream priority; a caller stream of that priority (torch.cuda.Stream(priority=-1)) may share
+    its hardware queue, where the gate kernel would never start (10 s, error 3).  Such a stream is refused at once (hybrid: direct launch)."""
+    torch, dev = torch_dev
+    lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+    if lo == hi:
+        pytest.skip("one stream priority level only")
+    cam = Camera(torch, dev, oracle, seed=81)
+    warm(torch, cam)
+    cam.stream = torch.cuda.Stream(priority=hi)
+    q = cvgs.Queue(idle_us=5000.0)
+    try:
+        with torch.cuda.stream(cam.stream):
+            cam.produce(1)
+            t0 = time.perf_counter()
+            with pytest.raises(Exception):
+                q.submit_lowered_on(cam.stream, cam.lowered)
+            assert time.perf_counter() - t0 < 1.0
+            assert q.submit_lowered_on(cam.stream, cam.lowered, cvgs.Queue.HYBRID | cvgs.Queue.MIN_GROUP(1)) == cvgs.Queue.TICKET_DIRECT
+            cam.consume(1)
+        cam.stream.synchronize()
+        assert int(cam.bad.item()) == 0 and q.stats()["submitted"] == 0 and q.stats()["error"] == 0
+    finally:
+        q.destroy()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Three measurements bench.py carries in its compact line beside the headline, all on the headline's workload
-(50 variable crops of a 4K frame -> [50,3,128,64] fp32, 20 resident frames in rotation):
+(50 variable crops of a 4K frame -> [50,3,128,64] fp32, 96 resident frames in rotation: touched set 4.6 x the Infinity Cache):
 
   stream_ordered()   the reference's contract -- executeOperations(stream, ...) ordered behind a PRODUCER kernel on the stream and in
                      front of whatever follows (include/cvGPUSpeedup.cuh:464-473) -- on the queue (cvgs_queue_submit_on /
@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from cvgpuspeedup_amd import workloads as W  # noqa: E402
 
 HBM = 8000.0
 
@@ -414,7 +415,8 @@ if __name__ == "__main__":
     a = p.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    wl = B.Workload(dev, 20, 50, 0, 1, False)
+    # rotation sized from TOUCHED bytes like bench.py's headline (96 frames: read-touched set 2.8 x the Infinity Cache)
+    wl = B.Workload(dev, max(W.rotation_units(W.k1_touched_per_frame(50, W.FRAME_4K)[0]), 96), 50, 0, 1, False)
     import json
     if a.g_sweep:
         for g in (127, 255, 383, 511, 767):

@@ -26,7 +26,11 @@ from cvgpuspeedup_amd import workloads as W  # noqa: E402
 
 
 def load_exp():
-    lib = C.CDLL(os.path.join(ROOT, "cvgpuspeedup_amd", "lib", "libcvgs_exp.so"))
+    path = os.path.join(ROOT, "cvgpuspeedup_amd", "lib", "libcvgs_exp.so")
+    if not os.path.exists(path):  # built on demand (`make exp`): not part of the product build
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "cvgpuspeedup_amd", "csrc"), "-j8", "exp"], check=True)
+    lib = C.CDLL(path)
     lib.cvgs_exp_execute.restype = C.c_int
     lib.cvgs_exp_execute.argtypes = [C.POINTER(capi.ChainDesc), C.c_int32, C.c_void_p]
     lib.cvgs_exp_name.restype = C.c_char_p

@@ -689,6 +689,167 @@ struct DeviceGuard {
     }
 };
 
+// ---- per-stream state of the tick kernel (k_tick.hip) ------------------------------------------------------------------------------
+// cvgs_execute_many's tick launch needs (a) 33 device counters that are zero between launches -- the kernel's last worker resets them,
+// and kernels of ONE stream never overlap, so a stream's launches share one block --, and (b) for host descriptors a device-visible
+// table that lives until the kernel has read it.  Both belong to a TickStream keyed by the stream handle.  Tables live in pinned,
+// non-coherent, mapped host slots (the kernel reads them in place); a slot is free again when the pinned `done` word -- written by the
+// launch's last worker -- has reached the slot's sequence number: a plain host read, no HIP event, no stream handle touched after the
+// call that used it.  Captured launches (device tables only) cannot share a block with whatever else runs beside the replay: each gets
+// a block of its own from a grow-only pool.
+struct TickSlot {
+    void* host = nullptr;
+    void* host_dev = nullptr;
+    size_t cap = 0;
+    uint64_t seq = 0; // the launch that reads it (0: never used / released)
+};
+struct TickStream {
+    hipStream_t stream = nullptr;
+    int device = -1;
+    uint64_t* counters = nullptr;   // device
+    volatile uint64_t* done_host = nullptr; // pinned
+    uint64_t* done_dev = nullptr;
+    uint64_t next_seq = 1;
+    std::vector<TickSlot> slots;
+    uint64_t last_use = 0;
+    std::mutex mu;                  // held from the slot's acquisition to the launch: sequence numbers are enqueued in order
+    bool idle() const { return !done_host || *done_host + 1 >= next_seq; }
+};
+class TickPool {
+    static constexpr size_t kMaxStreams = 64, kMaxSlots = 8, kCaptureChunk = 256, kMaxCaptureBlocks = 16384;
+public:
+    // the stream's block (created on first use; nullptr on failure).  NOT under stream capture (it allocates).
+    TickStream* get(hipStream_t stream, int device) {
+        std::lock_guard<std::mutex> lk(m_);
+        ++clock_;
+        for (TickStream* t : streams_)
+            if (t->stream == stream && t->device == device) { t->last_use = clock_; return t; }
+        if (streams_.size() >= kMaxStreams) { // a finished stream's block serves the new key (nothing is freed: hipFree synchronises the device)
+            TickStream* victim = nullptr;
+            for (TickStream* t : streams_)
+                if (t->device == device && t->idle() && t->mu.try_lock()) {
+                    if (!victim || t->last_use < victim->last_use) { if (victim) victim->mu.unlock(); victim = t; }
+                    else t->mu.unlock();
+                }
+            if (!victim) return nullptr;
+            victim->stream = stream;
+            victim->last_use = clock_;
+            victim->mu.unlock();
+            return victim;
+        }
+        DeviceGuard guard;
+        if (guard.enter(device)) return nullptr;
+        TickStream* t = new TickStream;
+        void* done = nullptr;
+        const size_t bytes = (size_t)cvgs::tick_counter_words() * 8;
+        hipError_t e = hipMalloc((void**)&t->counters, bytes);
+        if (e == hipSuccess) e = hipMemset(t->counters, 0, bytes);
+        if (e == hipSuccess) e = hipHostMalloc(&done, 128, hipHostMallocMapped | hipHostMallocPortable);
+        if (e == hipSuccess) { std::memset(done, 0, 128); e = hipHostGetDevicePointer((void**)&t->done_dev, done, 0); }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (t->counters) (void)hipFree(t->counters);
+            if (done) (void)hipHostFree(done);
+            delete t;
+            return nullptr;
+        }
+        t->done_host = (volatile uint64_t*)done;
+        t->stream = stream;
+        t->device = device;
+        t->last_use = clock_;
+        streams_.push_back(t);
+        return t;
+    }
+    // (t->mu held) a free table slot of >= bytes, or nullptr: every slot's kernel is still in flight after a bounded wait -- the caller
+    // takes the event-tracked path of the descriptor scratch instead
+    TickSlot* acquire(TickStream* t, size_t bytes) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const uint64_t done = *t->done_host;
+            for (TickSlot& sl : t->slots)
+                if (sl.cap >= bytes && sl.seq <= done) return &sl;
+            if (t->slots.size() < kMaxSlots) {
+                DeviceGuard guard;
+                if (guard.enter(t->device)) return nullptr;
+                TickSlot sl;
+                size_t cap = 64 << 10;
+                while (cap < bytes) cap <<= 1;
+                hipError_t e = hipHostMalloc(&sl.host, cap, hipHostMallocNonCoherent | hipHostMallocMapped | hipHostMallocPortable);
+                if (e == hipSuccess) e = hipHostGetDevicePointer(&sl.host_dev, sl.host, 0);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (sl.host) (void)hipHostFree(sl.host);
+                    return nullptr;
+                }
+                sl.cap = cap;
+                t->slots.push_back(sl);
+                return &t->slots.back();
+            }
+            if (attempt == 0) { // the host is kMaxSlots ticks ahead of the device: wait for the oldest one (bounded: ADVICE r4)
+                uint64_t oldest = ~0ull;
+                for (const TickSlot& sl : t->slots)
+                    if (sl.cap >= bytes && sl.seq < oldest) oldest = sl.seq;
+                if (oldest == ~0ull) return nullptr; // only smaller slots: the descriptor scratch serves this one
+                const auto t0 = std::chrono::steady_clock::now();
+                while (*t->done_host < oldest && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(4)) std::this_thread::yield();
+            }
+        }
+        return nullptr;
+    }
+    // a counter block that NO other launch will ever use (captured launches), or nullptr
+    uint64_t* capture_block(int device) {
+        std::lock_guard<std::mutex> lk(m_);
+        for (CaptureChunk& c : chunks_)
+            if (c.device == device && c.used < kCaptureChunk) return c.base + (size_t)(c.used++) * (size_t)cvgs::tick_counter_words();
+        if (chunks_.size() * kCaptureChunk >= kMaxCaptureBlocks) return nullptr;
+        DeviceGuard guard;
+        if (guard.enter(device)) return nullptr;
+        // (allocation under stream capture: allowed for this thread in the relaxed capture mode only)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+        CaptureChunk c;
+        const size_t bytes = kCaptureChunk * (size_t)cvgs::tick_counter_words() * 8;
+        hipError_t e = hipMalloc((void**)&c.base, bytes);
+        if (e == hipSuccess) e = hipMemset(c.base, 0, bytes);
+        if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        c.device = device;
+        c.used = 1;
+        chunks_.push_back(c);
+        return c.base;
+    }
+    // called where a caller prepares device tables (cvgs_plane_table_build): the first chunk exists before anything is captured
+    void prepare_capture_blocks() {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return; }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (const CaptureChunk& c : chunks_)
+                if (c.device == device) return;
+        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(nullptr, &cap) != hipSuccess) (void)hipGetLastError();
+        uint64_t* b = capture_block(device);
+        if (b) { // hand it back: nothing was launched on it
+            std::lock_guard<std::mutex> lk(m_);
+            for (CaptureChunk& c : chunks_)
+                if (c.device == device && c.base == b && c.used == 1) c.used = 0;
+        }
+    }
+private:
+    struct CaptureChunk { uint64_t* base = nullptr; int device = -1; size_t used = 0; };
+    std::mutex m_;
+    std::vector<TickStream*> streams_;
+    std::vector<CaptureChunk> chunks_;
+    uint64_t clock_ = 0;
+};
+TickPool& tick_pool() {
+    static TickPool* pool = new TickPool; // leaked on purpose, as the descriptor scratch
+    return *pool;
+}
+
 // One stream-ordered upload of host descriptors; committed after the launch that reads it.
 struct Upload {
     int slot = -1;
@@ -894,6 +1055,28 @@ bool tensor_out_range(const cvgs_chain_desc& c, ByteRange* out) {
     *out = ByteRange{(const uint8_t*)c.write.data, (const uint8_t*)c.write.data + n_planes_written * plane * esz};
     return true;
 }
+// extent of source view k of chain c: [lo, hi)
+static void source_range(const cvgs_chain_desc& c, const cvgs_image2d& im, size_t px_bytes, bool yuv, ByteRange* out) {
+    // bytes of one source row that belong to the view (a crop's LAST row ends width pixels in, not a whole step further: a bottom crop of
+    // a frame must not appear to reach into the allocation behind the frame -- round 4's test counted `step` bytes per row and silently
+    // un-fused such launches)
+    const uint8_t* lo = (const uint8_t*)im.data;
+    const size_t rows = (size_t)(im.height > 0 ? im.height : 1);
+    const size_t last_row = (size_t)(im.width > 0 ? im.width : 1) * px_bytes;
+    const uint8_t* hi = lo + (size_t)im.step * (rows - 1) + last_row;
+    if (yuv) {
+        // 4:2:0 surfaces: the chroma rows are read too -- behind the luma rows (whole surfaces: height * 3 / 2 rows) or,
+        // for a crop view, uv_offset bytes from its first luma byte (+ half the crop's rows).  Planar chroma (I420 / YV12: two
+        // quarter planes behind the luma plane) stays inside the same height * 3 / 2 rows.
+        const size_t chroma_rows = (rows + 1) / 2;
+        const uint8_t* cbase = im.uv_offset ? lo + (size_t)im.uv_offset : lo + (size_t)im.step * rows;
+        const bool planar_chroma = c.read.yuv_layout == CVGS_YUV_I420 || c.read.yuv_layout == CVGS_YUV_YV12;
+        const uint8_t* chi = planar_chroma ? cbase + (size_t)im.step * chroma_rows // (two half-width planes: the upper bound)
+                                           : cbase + (size_t)im.step * (chroma_rows - 1) + last_row;
+        if (chi > hi) hi = chi;
+    }
+    *out = ByteRange{lo, hi};
+}
 bool chains_independent(const cvgs_chain_desc* const* chains, int n) {
     if (n > CVGS_MAX_CHAINS) return false;
     ByteRange outs[CVGS_MAX_CHAINS];
@@ -906,23 +1089,91 @@ bool chains_independent(const cvgs_chain_desc* const* chains, int n) {
         const cvgs_chain_desc& c = *chains[i];
         if (c.read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) continue;
         const cvgs_image2d* src = (const cvgs_image2d*)c.read.src;
+        if (!src) continue;
         const bool yuv = c.read.kind == CVGS_READ_NV12_RESIZE_LINEAR || c.read.kind == CVGS_READ_NV12;
-        for (int k = 0; src && k < c.read.batch && k < c.read.used_planes; ++k) {
-            const uint8_t* lo = (const uint8_t*)src[k].data;
-            size_t rows = (size_t)(src[k].height > 0 ? src[k].height : 1);
-            const uint8_t* hi = lo + (size_t)src[k].step * rows;
-            if (yuv) {
-                // 4:2:0 surfaces: the chroma rows are read too -- behind the luma rows (whole surfaces: height * 3 / 2 rows) or,
-                // for a crop view, uv_offset bytes from its first luma byte (+ half the crop's rows)
-                const size_t chroma_rows = (rows + 1) / 2;
-                const uint8_t* chi = src[k].uv_offset ? lo + (size_t)src[k].uv_offset + (size_t)src[k].step * chroma_rows : hi + (size_t)src[k].step * chroma_rows;
-                if (chi > hi) hi = chi;
+        const size_t px_bytes = (size_t)depth_bytes(CVGS_TYPE_DEPTH(c.read.src_type)) * (size_t)CVGS_TYPE_CN(c.read.src_type);
+        const int n_src = c.read.batch < c.read.used_planes ? c.read.batch : c.read.used_planes;
+        // the hull of the chain's views first (a tick's crops all lie inside one frame): only a target that meets the hull is compared view by view
+        ByteRange hull{nullptr, nullptr};
+        for (int k = 0; k < n_src; ++k) {
+            ByteRange r;
+            source_range(c, src[k], px_bytes, yuv, &r);
+            if (!hull.lo || r.lo < hull.lo) hull.lo = r.lo;
+            if (!hull.hi || r.hi > hull.hi) hull.hi = r.hi;
+        }
+        if (!hull.lo) continue;
+        for (int j = 0; j < n; ++j) {
+            if (!(hull.lo < outs[j].hi && outs[j].lo < hull.hi)) continue;
+            for (int k = 0; k < n_src; ++k) {
+                ByteRange r;
+                source_range(c, src[k], px_bytes, yuv, &r);
+                if (r.lo < outs[j].hi && outs[j].lo < r.hi) return false;
             }
-            for (int j = 0; j < n; ++j)
-                if (lo < outs[j].hi && outs[j].lo < hi) return false;
         }
     }
     return true;
+}
+
+// cvgs_execute_many as ONE tick launch (k_tick.hip).  1 = launched, 0 = not a tick this path takes (the caller continues with the grid
+// kernel), else a CVGS_ERR_* code (nothing enqueued).  `L0` = chains[0] lowered.
+int execute_tick(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream, bool tables, Lowered& L0) {
+    {   // the shape first (dry run: nothing allocated, nothing enqueued)
+        ChainArgs probe = L0.args;
+        const cvgs::TickSeg one{(const PlaneParams*)(uintptr_t)16, probe.write.data, probe.read.batch, probe.read.used, 0, 0};
+        if (cvgs::launch_k1_tick(probe, &one, 1, cvgs::TickLaunch{nullptr, nullptr, 0}, stream, true, nullptr) != 1) return 0;
+    }
+    const int device = stream_device(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (capturing && !tables) return 0;
+    cvgs::TickSeg segs[CVGS_MAX_CHAINS];
+    if (capturing) {
+        for (int i = 0; i < n; ++i) {
+            Lowered Li;
+            Lowered& L = i == 0 ? L0 : Li;
+            if (i > 0) { if (int rc = lower(&chains[i], false, L)) return rc; }
+            segs[i] = cvgs::TickSeg{L.args.read.table, L.args.write.data, L.args.read.batch, L.args.read.used, 0, 0};
+        }
+        uint64_t* block = tick_pool().capture_block(device);
+        if (!block) return 0;
+        const int rc = cvgs::launch_k1_tick(L0.args, segs, n, cvgs::TickLaunch{block, nullptr, 0}, stream, false, nullptr);
+        return rc == 1 ? 1 : (rc == 0 ? 0 : fail(CVGS_ERR_HIP, "tick kernel launch failed"));
+    }
+    TickStream* ts = tick_pool().get(stream, device);
+    if (!ts) return 0;
+    std::lock_guard<std::mutex> lock(ts->mu);
+    if (ts->stream != stream) return 0; // (the block was handed to another stream between get() and here)
+    TickSlot* slot = nullptr;
+    size_t used = 0;
+    if (!tables) {
+        size_t bytes = 0;
+        for (int i = 0; i < n; ++i) bytes += (size_t)(chains[i].read.batch > 0 ? chains[i].read.batch : 0) * sizeof(PlaneParams) + 16;
+        slot = tick_pool().acquire(ts, bytes);
+        if (!slot) return 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        Lowered Li;
+        Lowered& L = i == 0 ? L0 : Li;
+        if (i > 0) { if (int rc = lower(&chains[i], false, L)) return rc; } // nothing enqueued yet, the slot was not marked
+        const PlaneParams* table = L.args.read.table;
+        if (!tables) {
+            // the row worker addresses a crop's rows with 32-bit byte offsets from its first pixel (device tables: cvgs_plane_table_build
+            // refuses larger sources)
+            for (size_t z = 0; z < L.planes.size() && (int)z < L.args.read.used; ++z)
+                if ((uint64_t)L.planes[z].h * (uint64_t)L.planes[z].step >= (1ull << 32)) return 0;
+            const size_t b = L.planes.size() * sizeof(PlaneParams);
+            std::memcpy((uint8_t*)slot->host + used, L.planes.data(), b);
+            table = (const PlaneParams*)((uint8_t*)slot->host_dev + used);
+            used += (b + 15) & ~(size_t)15;
+        }
+        segs[i] = cvgs::TickSeg{table, L.args.write.data, L.args.read.batch, L.args.read.used, 0, 0};
+    }
+    const uint64_t seq = ts->next_seq;
+    const int rc = cvgs::launch_k1_tick(L0.args, segs, n, cvgs::TickLaunch{ts->counters, ts->done_dev, seq}, stream, false, nullptr);
+    if (rc != 1) return rc == 0 ? 0 : fail(CVGS_ERR_HIP, "tick kernel launch failed");
+    ts->next_seq = seq + 1;
+    if (slot) slot->seq = seq;
+    return 1;
 }
 
 int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
@@ -968,6 +1219,11 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         int rc = lower(&chains[0], false, L0);
         if (rc) return rc;
         if (L0.int_arith) fusable = false; // integer-typed arithmetic: the interpreted kernel, chain by chain
+        if (fusable && !k4) { // crops of 8-bit frames behind [swap] mul sub div: the tick kernel
+            const int trc = execute_tick(chains, n, stream, tables, L0);
+            if (trc == 1) return CVGS_OK;
+            if (trc != 0) return trc;
+        }
         if (fusable) {
             // would the fast kernel take this shape?  (dry run: nothing is enqueued, nothing uploaded)
             ChainArgs probe = L0.args;
@@ -1112,7 +1368,14 @@ int cvgs_plane_table_build(const cvgs_read_desc* read, void* host_out) {
     }
     int rc = lower(&ch, false, L);
     if (rc) return rc;
+    // the tick kernel of cvgs_execute_many addresses a crop's rows with 32-bit byte offsets and cannot see a device table's planes from
+    // the host: tables never hold sources of 4 GiB and more (host descriptors of such sources keep the 64-bit kernels)
+    if (read->kind == CVGS_READ_RESIZE_LINEAR)
+        for (size_t z = 0; z < L.planes.size() && (int)z < read->used_planes; ++z)
+            if ((uint64_t)L.planes[z].h * (uint64_t)L.planes[z].step >= (1ull << 32))
+                return fail(CVGS_ERR_UNSUPPORTED, "device plane tables: a source view of 4 GiB or more (use host descriptors)");
     std::memcpy(host_out, L.planes.data(), L.planes.size() * sizeof(PlaneParams));
+    tick_pool().prepare_capture_blocks(); // (a caller that builds device tables may capture their launches: the counter blocks of captured tick launches exist before any capture starts)
     return CVGS_OK;
 }
 
@@ -1606,6 +1869,8 @@ int cvgs_debug_occupy(int32_t blocks, int32_t threads, int32_t lds_bytes, double
     if (cvgs::launch_debug_occupy(blocks, threads, lds_bytes, microseconds, stream)) return fail(CVGS_ERR_HIP, "debug_occupy launch failed");
     return CVGS_OK;
 }
+
+uint64_t cvgs_debug_tick_launches(void) { return cvgs::tick_launches(); }
 
 int cvgs_debug_poll(const void* word, double microseconds, int32_t nap, cvgs_stream_t stream) {
     if (((uintptr_t)word & 7) || microseconds < 0 || microseconds > 5e6) return fail(CVGS_ERR_INVALID, "debug_poll: an 8-byte aligned word (NULL = an uncached device word of the library's), <= 5 s");

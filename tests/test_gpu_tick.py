@@ -1,0 +1,303 @@
+"""cvgs_execute_many served by the TICK kernel (csrc/k_tick.hip): one launch whose worker waves draw the tick's tasks from ticket
+counters -- bit-exact against the CPU oracle, against one cvgs_execute per chain and against the grid kernel it replaces (CVGS_TICK=0 is
+read once per process, so that comparison runs in a subprocess).  Reference call shape: one executeOperations per frame,
+include/cvGPUSpeedup.cuh:464-473; a tick = the calls of several cameras (tests/batchresize/test_batchresize_x_split3D.cu:384-392 sweeps
+the batch the same way).  Also: the table slots' recycling through the launch's completion word (hundreds of ticks with a different
+crop list each, nothing synchronised in between), two streams at once, captured launches with device tables, and the shapes the tick
+kernel hands back to the grid kernel."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _chain(torch, dev, frame_t, crops, dst, cn, half=False, table=False, out=None, **kw):
+    n = len(crops)
+    if out is None:
+        out = torch.full((n, cn * dst[0] * dst[1]), -777.0, dtype=torch.float16 if half else torch.float32, device=dev)
+    g_src = cvgs.GpuMat.from_tensor(frame_t, cvgs.make_type(cvgs.CV_8U, cn))
+    g_out = cvgs.GpuMat.from_tensor(out, cvgs.CV_16FC1 if half else cvgs.CV_32FC1)
+    ops = H.k1_chain(g_src, crops, g_out, dst, cn, half=half, **kw)
+    keep = None
+    if table:
+        keep = torch.frombuffer(bytearray(cvgs.build_plane_table(ops[0])), dtype=torch.uint8).to(dev)
+        ops = H.k1_chain(g_src, crops, g_out, dst, cn, half=half, table=keep.data_ptr(), **kw)
+    return ops, out, keep
+
+
+def _oracle(oracle, frame, crops, dst, cn, half=False, **kw):
+    ref = np.full((len(crops), cn * dst[0] * dst[1]), -777.0, dtype=np.float16 if half else np.float32)
+    oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frame, cvgs.make_type(cvgs.CV_8U, cn)), crops,
+                                         cvgs.GpuMat.from_array(ref, cvgs.CV_16FC1 if half else cvgs.CV_32FC1), dst, cn, half=half, **kw)))
+    return ref
+
+
+def _tick(torch, dev, oracle, lib, n_chains, cn=3, dst=(64, 128), half=False, table=False, seed=1, frame_hw=(540, 960), crops_lo=1, crops_hi=40,
+          stream=None, **kw):
+    rng = np.random.default_rng(seed)
+    chains, outs, keeps, refs = [], [], [], []
+    fh, fw = frame_hw
+    for m in range(n_chains):
+        frame = H.random_u8((fh, fw, cn), seed=seed * 1000 + m)
+        n = int(rng.integers(crops_lo, crops_hi + 1))
+        crops = H.random_crops(n, fw, fh, seed=seed * 77 + m, wmax=min(400, fw), hmax=min(500, fh))
+        ft = torch.from_numpy(frame).to(dev)
+        ops, out, keep = _chain(torch, dev, ft, crops, dst, cn, half=half, table=table, **kw)
+        chains.append(ops)
+        outs.append(out)
+        keeps += [ft, keep]
+        refs.append(_oracle(oracle, frame, crops, dst, cn, half=half, **kw))
+    before = lib.cvgs_debug_tick_launches()
+    lowered, arr = cvgs.executeMany(stream or torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    took = lib.cvgs_debug_tick_launches() - before
+    for m in range(n_chains):
+        H.assert_bit_exact(outs[m].cpu().numpy(), refs[m], "tick of %d chains, chain %d" % (n_chains, m))
+    return took, chains, outs, refs, keeps
+
+
+@pytest.mark.parametrize("n_chains", [2, 3, 16, 17, 64, 65, 128])
+def test_tick_matches_the_oracle_for_every_segment_table_size(oracle, device, lib, n_chains):
+    import torch
+    took, *_ = _tick(torch, device, oracle, lib, n_chains, seed=10 + n_chains, crops_hi=12 if n_chains > 16 else 40)
+    assert took == 1, "the tick kernel must serve the hot shape (CVGS_TICK unset)"
+
+
+@pytest.mark.parametrize("cn,swap,half", [(3, True, False), (3, False, False), (4, True, False), (4, False, True), (3, True, True)])
+def test_tick_channels_programs_and_fp16(oracle, device, lib, cn, swap, half):
+    import torch
+    took, *_ = _tick(torch, device, oracle, lib, 6, cn=cn, half=half, swap=swap, seed=40 + cn + 2 * swap + 4 * half)
+    assert took == 1
+
+
+@pytest.mark.parametrize("kw", [{"ar": cvgs.PRESERVE_AR, "background": [128.0, 64.0, 32.0, 0.0]},
+                                {"ar": cvgs.PRESERVE_AR_RN_EVEN, "background": [1.0, 2.0, 3.0, 0.0]},
+                                {"used": 2, "background": [7.0, 8.0, 9.0, 0.0]}])
+def test_tick_aspect_ratio_windows_and_default_planes(oracle, device, lib, kw):
+    import torch
+    took, *_ = _tick(torch, device, oracle, lib, 5, seed=70, crops_lo=3, crops_hi=9, **kw)
+    assert took == 1
+
+
+@pytest.mark.parametrize("dst", [(100, 37), (64, 4), (1, 1), (200, 130), (63, 129)])
+def test_tick_ragged_targets(oracle, device, lib, dst):
+    """targets that are not multiples of the 4 x 64 tile: ragged column tiles, row groups that end inside a task"""
+    import torch
+    took, *_ = _tick(torch, device, oracle, lib, 4, dst=dst, seed=90 + dst[0], crops_hi=10)
+    assert took == 1
+
+
+@pytest.mark.parametrize("table", [False, True])
+def test_tick_sources_narrower_than_a_tap_window(oracle, device, lib, table):
+    """crops 1-2 pixels wide / 1 row high: the byte-by-byte gather (the server refuses such crops on the host; a device table cannot be looked at)"""
+    import torch
+    fh, fw = 64, 96
+    chains, outs, refs, keep = [], [], [], []
+    for m in range(3):
+        frame = H.random_u8((fh, fw, 3), seed=500 + m)
+        crops = [(5, 3, 1, 1), (7, 9, 2, 30), (0, 0, 1, 64), (94, 10, 2, 2), (10, 10, 3, 1), (20, 5, 40, 50)]
+        ft = torch.from_numpy(frame).to(device)
+        ops, out, kp = _chain(torch, device, ft, crops, (64, 128), 3, table=table)
+        chains.append(ops)
+        outs.append(out)
+        keep += [ft, kp]
+        refs.append(_oracle(oracle, frame, crops, (64, 128), 3))
+    before = lib.cvgs_debug_tick_launches()
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    assert lib.cvgs_debug_tick_launches() - before == 1
+    for m in range(3):
+        H.assert_bit_exact(outs[m].cpu().numpy(), refs[m], "tiny sources, chain %d" % m)
+
+
+def test_tick_cnhw_tensor(oracle, device, lib):
+    """TensorTSplit (CNHW): the channel stride is the tensor's N"""
+    import torch
+    fh, fw = 300, 400
+    chains, outs, refs, keep = [], [], [], []
+    for m in range(3):
+        frame = H.random_u8((fh, fw, 3), seed=600 + m)
+        crops = H.random_crops(5 + m, fw, fh, seed=610 + m, wmax=200, hmax=200)
+        n = len(crops)
+        ft = torch.from_numpy(frame).to(device)
+        out = torch.full((3, n, 128 * 64), -777.0, dtype=torch.float32, device=device)
+        ref = np.full((3, n, 128 * 64), -777.0, dtype=np.float32)
+        f = cvgs.CV_32FC3
+
+        def ops_for(src_mat, data_ptr, owner):
+            return [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [src_mat.roi(*c) for c in crops], (64, 128), n),
+                    cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, [1.0, 4.0, 3.2]), cvgs.divide(f, [3.2, 0.6, 11.8]),
+                    cvgs.splitT(f, data_ptr, 64, 128, n, keep=owner)]
+        chains.append(ops_for(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), out.data_ptr(), out))
+        oracle.execute(cvgs.lower(ops_for(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), ref.ctypes.data, ref)))
+        outs.append(out)
+        refs.append(ref)
+        keep.append(ft)
+    before = lib.cvgs_debug_tick_launches()
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    assert lib.cvgs_debug_tick_launches() - before == 1
+    for m in range(3):
+        H.assert_bit_exact(outs[m].cpu().numpy(), refs[m], "CNHW tick, chain %d" % m)
+
+
+def test_hundreds_of_ticks_recycle_their_table_slots(oracle, device, lib):
+    """300 ticks back to back on one stream, a DIFFERENT crop list in every tick, no synchronisation in between: the pinned table slots
+    are recycled by the launches' completion word while the host runs ahead; every tick's tensors are checked at the end (a slot
+    rewritten while its kernel still reads it would show up as another tick's crops)."""
+    import torch
+    fh, fw = 360, 640
+    frames = [H.random_u8((fh, fw, 3), seed=700 + k) for k in range(3)]
+    fts = [torch.from_numpy(f).to(device) for f in frames]
+    ticks, n_ticks = [], 300
+    s = torch.cuda.Stream()
+    before = lib.cvgs_debug_tick_launches()
+    for i in range(n_ticks):
+        chains, outs, meta = [], [], []
+        for k in range(3):
+            crops = H.random_crops(4 + (i + k) % 5, fw, fh, seed=7000 + 10 * i + k, wmax=300, hmax=300)
+            ops, out, _ = _chain(torch, device, fts[k], crops, (64, 128), 3)
+            chains.append(ops)
+            outs.append(out)
+            meta.append((k, crops))
+        ticks.append((outs, meta, cvgs.executeMany(s, chains)))
+    s.synchronize()
+    assert lib.cvgs_debug_tick_launches() - before == n_ticks
+    for i in (list(range(0, n_ticks, 7)) + [n_ticks - 1]):
+        outs, meta, _ = ticks[i]
+        for out, (k, crops) in zip(outs, meta):
+            H.assert_bit_exact(out.cpu().numpy(), _oracle(oracle, frames[k], crops, (64, 128), 3), "tick %d, camera %d" % (i, k))
+
+
+def test_two_streams_tick_at_once(oracle, device, lib):
+    """every stream has its own counter block: ticks of two streams overlap on the device"""
+    import torch
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    jobs = []
+    for i in range(40):
+        st = s1 if i % 2 == 0 else s2
+        rng_seed = 800 + i
+        fh, fw = 540, 960
+        chains, outs, refs = [], [], []
+        for m in range(4):
+            frame = H.random_u8((fh, fw, 3), seed=rng_seed * 10 + m)
+            crops = H.random_crops(20, fw, fh, seed=rng_seed * 13 + m, wmax=400, hmax=500)
+            ft = torch.from_numpy(frame).to(device)
+            ops, out, _ = _chain(torch, device, ft, crops, (64, 128), 3)
+            chains.append(ops)
+            outs.append(out)
+            refs.append((frame, crops, ft))
+        jobs.append((st, chains, outs, refs))
+    torch.cuda.synchronize()
+    held = [cvgs.executeMany(st, chains) for st, chains, _, _ in jobs]
+    s1.synchronize()
+    s2.synchronize()
+    for i in (0, 1, 17, 38, 39):
+        _, _, outs, refs = jobs[i]
+        for out, (frame, crops, _) in zip(outs, refs):
+            H.assert_bit_exact(out.cpu().numpy(), _oracle(oracle, frame, crops, (64, 128), 3), "two streams, job %d" % i)
+    assert held
+
+
+def test_captured_tick_with_device_tables_replays(oracle, device, lib):
+    """device plane tables: the tick launch is capturable (a counter block of its own per captured launch) and replays"""
+    import torch
+    took, chains, outs, refs, keeps = _tick(torch, device, oracle, lib, 8, table=True, seed=900)
+    assert took == 1
+    lowered = [cvgs.lower(ops) for ops in chains]
+    arr = cvgs.pack_chains(lowered)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        before = lib.cvgs_debug_tick_launches()
+        with torch.cuda.graph(g):
+            for _ in range(3):  # three tick launches in one graph: each has its own counter block
+                capi.check(lib.cvgs_execute_many(arr, len(lowered), torch.cuda.current_stream().cuda_stream))
+        assert lib.cvgs_debug_tick_launches() - before == 3
+        for rep in range(3):
+            for o in outs:
+                o.fill_(-5.0)
+            g.replay()
+            torch.cuda.synchronize()
+            for m in range(len(outs)):
+                H.assert_bit_exact(outs[m].cpu().numpy(), refs[m], "captured tick, replay %d, chain %d" % (rep, m))
+
+
+def test_other_shapes_keep_the_grid_kernel(oracle, device, lib):
+    """16-bit sources and interpreted programs are not the tick kernel's: same call, same bits, the grid kernel (blockIdx.z = chain)"""
+    import torch
+    fh, fw = 300, 400
+    chains, outs, refs, keep = [], [], [], []
+    f = cvgs.CV_32FC3
+    for m in range(3):
+        frame = H.random_u8((fh, fw, 3), seed=950 + m)
+        crops = H.random_crops(6, fw, fh, seed=960 + m, wmax=200, hmax=200)
+        ft = torch.from_numpy(frame).to(device)
+        out = torch.full((6, 3 * 128 * 64), -777.0, dtype=torch.float32, device=device)
+        ref = np.full((6, 3 * 128 * 64), -777.0, dtype=np.float32)
+
+        def ops_for(src_mat, out_mat):  # an ADD stage: not [swap] mul sub div
+            return [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [src_mat.roi(*c) for c in crops], (64, 128), 6),
+                    cvgs.multiply(f, [0.5] * 3), cvgs.add(f, [1.0, 2.0, 3.0]), cvgs.split(f, out_mat, (64, 128))]
+        chains.append(ops_for(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)))
+        oracle.execute(cvgs.lower(ops_for(cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3), cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+        outs.append(out)
+        refs.append(ref)
+        keep.append(ft)
+    before = lib.cvgs_debug_tick_launches()
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    assert lib.cvgs_debug_tick_launches() == before
+    for m in range(3):
+        H.assert_bit_exact(outs[m].cpu().numpy(), refs[m], "interpreted program, chain %d" % m)
+
+
+_GRID_VS_TICK = r"""
+import os, sys, hashlib
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from cvgpuspeedup_amd import capi, cvgs
+from tests import helpers as H
+dev = torch.device("cuda:0")
+lib = capi.load_library()
+h = hashlib.sha256()
+for seed in (1, 2, 3):
+    chains, outs, keep = [], [], []
+    for m in range(9):
+        frame = H.random_u8((540, 960, 3), seed=seed * 100 + m)
+        crops = H.random_crops(3 + 4 * m, 960, 540, seed=seed * 31 + m, wmax=400, hmax=500)
+        ft = torch.from_numpy(frame).to(dev)
+        out = torch.full((len(crops), 3 * 64 * 128), -777.0, dtype=torch.float32, device=dev)
+        chains.append(H.k1_chain(cvgs.GpuMat.from_tensor(ft, cvgs.CV_8UC3), crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1)))
+        outs.append(out); keep.append(ft)
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    for o in outs:
+        h.update(o.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest(), lib.cvgs_debug_tick_launches())
+"""
+
+
+def test_tick_and_grid_kernel_write_the_same_bytes():
+    """the same three ticks in two fresh processes: CVGS_TICK unset (tick kernel) and CVGS_TICK=0 (the grid kernel): one digest"""
+    res = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ)
+        env["CVGS_TICK"] = mode
+        p = subprocess.run([sys.executable, "-c", _GRID_VS_TICK % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("DIGEST")]
+        assert line, p.stderr[-2000:]
+        _, digest, launches = line[-1].split()
+        res[mode] = (digest, int(launches))
+    assert res["1"][1] == 3 and res["0"][1] == 0, res
+    assert res["1"][0] == res["0"][0]

@@ -119,7 +119,6 @@ SYMBOLS = [
     ("cvgs_queue_recover", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("cvgs_debug_occupy", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
     ("cvgs_debug_poll", C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_void_p]),
-    ("cvgs_debug_tick_launches", C.c_uint64, []),
     ("cvgs_queue_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_double]),
     ("cvgs_queue_stream_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("cvgs_queue_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -167,7 +166,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.cvgs_abi_version() != 6:
+    if lib.cvgs_abi_version() != 5:
         raise ImportError("libcvgs_hip.so ABI version mismatch")
     _lib = lib
     return lib

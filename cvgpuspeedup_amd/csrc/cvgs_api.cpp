@@ -689,88 +689,72 @@ struct DeviceGuard {
     }
 };
 
-// ---- per-stream state of the tick kernel (k_tick.hip) ------------------------------------------------------------------------------
-// cvgs_execute_many's tick launch needs (a) 33 device counters that are zero between launches -- the kernel's last worker resets them,
-// and kernels of ONE stream never overlap, so a stream's launches share one block --, and (b) for host descriptors a device-visible
-// table that lives until the kernel has read it.  Both belong to a TickStream keyed by the stream handle.  Tables live in pinned,
-// non-coherent, mapped host slots (the kernel reads them in place); a slot is free again when the pinned `done` word -- written by the
-// launch's last worker -- has reached the slot's sequence number: a plain host read, no HIP event, no stream handle touched after the
-// call that used it.  Captured launches (device tables only) cannot share a block with whatever else runs beside the replay: each gets
-// a block of its own from a grow-only pool.
-struct TickSlot {
+// ---- per-stream descriptor tables of cvgs_execute_many's fused K1 launch ---------------------------------------------------------------
+// Round 4 recycled the pooled table of a fused launch through a HIP event: the kernel trace showed the stream's NEXT kernel ~4 us behind
+// such a launch (a marker packet / a completion signal the runtime waits on), and a host that runs ahead paid one hipEventQuery per pending
+// slot and call.  Here the fused launch itself reports progress: the kernel carries a sequence number, and its first work-item stores
+// (sequence - 1) into a pinned host word when the kernel STARTS -- kernels of one stream run in order, so every earlier launch of the
+// stream has finished by then.  A table slot is free again once that word has reached the slot's sequence number: a plain host read, no
+// HIP event, no marker behind the launch, no stream handle touched after the call that used it.  The newest launch's slot is released
+// by the stream's next fused launch (a stream that stops calling keeps ONE slot).  Slots are pinned, non-coherent, mapped host memory
+// the kernel reads in place, as the descriptor scratch's.
+struct ManySlot {
     void* host = nullptr;
     void* host_dev = nullptr;
     size_t cap = 0;
-    uint64_t seq = 0; // the launch that reads it (0: never used / released)
+    uint64_t seq = 0; // the launch that reads it (0: never used)
 };
-struct TickStream {
+struct ManyStream {
     hipStream_t stream = nullptr;
     int device = -1;
-    uint64_t* counters = nullptr;   // device
-    volatile uint64_t* done_host = nullptr; // pinned
+    volatile uint64_t* done_host = nullptr; // pinned: every launch of this stream with a sequence number <= *done_host has finished
     uint64_t* done_dev = nullptr;
     uint64_t next_seq = 1;
-    std::vector<TickSlot> slots;
-    uint64_t last_use = 0;
-    std::mutex mu;                  // held from the slot's acquisition to the launch: sequence numbers are enqueued in order
-    bool idle() const { return !done_host || *done_host + 1 >= next_seq; }
+    std::vector<ManySlot> slots;
+    std::mutex mu; // held from the slot's acquisition to the launch: sequence numbers are enqueued in order
 };
-class TickPool {
-    static constexpr size_t kMaxStreams = 64, kMaxSlots = 8, kCaptureChunk = 256, kMaxCaptureBlocks = 16384;
+class ManyPool {
+    static constexpr size_t kMaxStreams = 256, kMaxSlots = 8;
 public:
-    // the stream's block (created on first use; nullptr on failure).  NOT under stream capture (it allocates).
-    TickStream* get(hipStream_t stream, int device) {
+    // the stream's state (created on first use); nullptr: no room or no memory -- the caller takes the event-tracked descriptor scratch.
+    // Keyed by the stream HANDLE: a handle the runtime hands out again after hipStreamDestroy continues the old entry, which is sound as
+    // long as the destroyed stream's last fused launch has finished by the time the new stream's SECOND fused launch is prepared.
+    ManyStream* get(hipStream_t stream, int device) {
         std::lock_guard<std::mutex> lk(m_);
-        ++clock_;
-        for (TickStream* t : streams_)
-            if (t->stream == stream && t->device == device) { t->last_use = clock_; return t; }
-        if (streams_.size() >= kMaxStreams) { // a finished stream's block serves the new key (nothing is freed: hipFree synchronises the device)
-            TickStream* victim = nullptr;
-            for (TickStream* t : streams_)
-                if (t->device == device && t->idle() && t->mu.try_lock()) {
-                    if (!victim || t->last_use < victim->last_use) { if (victim) victim->mu.unlock(); victim = t; }
-                    else t->mu.unlock();
-                }
-            if (!victim) return nullptr;
-            victim->stream = stream;
-            victim->last_use = clock_;
-            victim->mu.unlock();
-            return victim;
-        }
+        for (ManyStream* t : streams_)
+            if (t->stream == stream && t->device == device) return t;
+        if (streams_.size() >= kMaxStreams) return nullptr;
         DeviceGuard guard;
         if (guard.enter(device)) return nullptr;
-        TickStream* t = new TickStream;
         void* done = nullptr;
-        const size_t bytes = (size_t)cvgs::tick_counter_words() * 8;
-        hipError_t e = hipMalloc((void**)&t->counters, bytes);
-        if (e == hipSuccess) e = hipMemset(t->counters, 0, bytes);
-        if (e == hipSuccess) e = hipHostMalloc(&done, 128, hipHostMallocMapped | hipHostMallocPortable);
-        if (e == hipSuccess) { std::memset(done, 0, 128); e = hipHostGetDevicePointer((void**)&t->done_dev, done, 0); }
+        uint64_t* done_dev = nullptr;
+        hipError_t e = hipHostMalloc(&done, 128, hipHostMallocMapped | hipHostMallocPortable);
+        if (e == hipSuccess) { std::memset(done, 0, 128); e = hipHostGetDevicePointer((void**)&done_dev, done, 0); }
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            if (t->counters) (void)hipFree(t->counters);
             if (done) (void)hipHostFree(done);
-            delete t;
             return nullptr;
         }
+        ManyStream* t = new ManyStream;
         t->done_host = (volatile uint64_t*)done;
+        t->done_dev = done_dev;
         t->stream = stream;
         t->device = device;
-        t->last_use = clock_;
         streams_.push_back(t);
         return t;
     }
-    // (t->mu held) a free table slot of >= bytes, or nullptr: every slot's kernel is still in flight after a bounded wait -- the caller
-    // takes the event-tracked path of the descriptor scratch instead
-    TickSlot* acquire(TickStream* t, size_t bytes) {
+    // (t->mu held) a free table slot of >= bytes, or nullptr (every slot's kernel still pending after a bounded wait / out of memory)
+    ManySlot* acquire(ManyStream* t, size_t bytes) {
         for (int attempt = 0; attempt < 2; ++attempt) {
             const uint64_t done = *t->done_host;
-            for (TickSlot& sl : t->slots)
+            for (ManySlot& sl : t->slots)
                 if (sl.cap >= bytes && sl.seq <= done) return &sl;
-            if (t->slots.size() < kMaxSlots) {
+            size_t fitting = 0;
+            for (const ManySlot& sl : t->slots) fitting += sl.cap >= bytes;
+            if (fitting < kMaxSlots && t->slots.size() < 4 * kMaxSlots) {
                 DeviceGuard guard;
                 if (guard.enter(t->device)) return nullptr;
-                TickSlot sl;
+                ManySlot sl;
                 size_t cap = 64 << 10;
                 while (cap < bytes) cap <<= 1;
                 hipError_t e = hipHostMalloc(&sl.host, cap, hipHostMallocNonCoherent | hipHostMallocMapped | hipHostMallocPortable);
@@ -784,69 +768,24 @@ public:
                 t->slots.push_back(sl);
                 return &t->slots.back();
             }
-            if (attempt == 0) { // the host is kMaxSlots ticks ahead of the device: wait for the oldest one (bounded: ADVICE r4)
+            if (attempt == 0) { // the host is kMaxSlots launches ahead of the device: wait for the oldest one -- bounded (the stream
+                                // may be held by something only this thread will release), then the event-tracked scratch takes the call
                 uint64_t oldest = ~0ull;
-                for (const TickSlot& sl : t->slots)
+                for (const ManySlot& sl : t->slots)
                     if (sl.cap >= bytes && sl.seq < oldest) oldest = sl.seq;
-                if (oldest == ~0ull) return nullptr; // only smaller slots: the descriptor scratch serves this one
+                if (oldest == ~0ull) return nullptr;
                 const auto t0 = std::chrono::steady_clock::now();
                 while (*t->done_host < oldest && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(4)) std::this_thread::yield();
             }
         }
         return nullptr;
     }
-    // a counter block that NO other launch will ever use (captured launches), or nullptr
-    uint64_t* capture_block(int device) {
-        std::lock_guard<std::mutex> lk(m_);
-        for (CaptureChunk& c : chunks_)
-            if (c.device == device && c.used < kCaptureChunk) return c.base + (size_t)(c.used++) * (size_t)cvgs::tick_counter_words();
-        if (chunks_.size() * kCaptureChunk >= kMaxCaptureBlocks) return nullptr;
-        DeviceGuard guard;
-        if (guard.enter(device)) return nullptr;
-        // (allocation under stream capture: allowed for this thread in the relaxed capture mode only)
-        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
-        const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
-        CaptureChunk c;
-        const size_t bytes = kCaptureChunk * (size_t)cvgs::tick_counter_words() * 8;
-        hipError_t e = hipMalloc((void**)&c.base, bytes);
-        if (e == hipSuccess) e = hipMemset(c.base, 0, bytes);
-        if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        c.device = device;
-        c.used = 1;
-        chunks_.push_back(c);
-        return c.base;
-    }
-    // called where a caller prepares device tables (cvgs_plane_table_build): the first chunk exists before anything is captured
-    void prepare_capture_blocks() {
-        int device = 0;
-        if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return; }
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            for (const CaptureChunk& c : chunks_)
-                if (c.device == device) return;
-        }
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(nullptr, &cap) != hipSuccess) (void)hipGetLastError();
-        uint64_t* b = capture_block(device);
-        if (b) { // hand it back: nothing was launched on it
-            std::lock_guard<std::mutex> lk(m_);
-            for (CaptureChunk& c : chunks_)
-                if (c.device == device && c.base == b && c.used == 1) c.used = 0;
-        }
-    }
 private:
-    struct CaptureChunk { uint64_t* base = nullptr; int device = -1; size_t used = 0; };
     std::mutex m_;
-    std::vector<TickStream*> streams_;
-    std::vector<CaptureChunk> chunks_;
-    uint64_t clock_ = 0;
+    std::vector<ManyStream*> streams_;
 };
-TickPool& tick_pool() {
-    static TickPool* pool = new TickPool; // leaked on purpose, as the descriptor scratch
+ManyPool& many_pool() {
+    static ManyPool* pool = new ManyPool; // leaked on purpose, as the descriptor scratch
     return *pool;
 }
 
@@ -1114,68 +1053,6 @@ bool chains_independent(const cvgs_chain_desc* const* chains, int n) {
     return true;
 }
 
-// cvgs_execute_many as ONE tick launch (k_tick.hip).  1 = launched, 0 = not a tick this path takes (the caller continues with the grid
-// kernel), else a CVGS_ERR_* code (nothing enqueued).  `L0` = chains[0] lowered.
-int execute_tick(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream, bool tables, Lowered& L0) {
-    {   // the shape first (dry run: nothing allocated, nothing enqueued)
-        ChainArgs probe = L0.args;
-        const cvgs::TickSeg one{(const PlaneParams*)(uintptr_t)16, probe.write.data, probe.read.batch, probe.read.used, 0, 0};
-        if (cvgs::launch_k1_tick(probe, &one, 1, cvgs::TickLaunch{nullptr, nullptr, 0}, stream, true, nullptr) != 1) return 0;
-    }
-    const int device = stream_device(stream);
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    if (capturing && !tables) return 0;
-    cvgs::TickSeg segs[CVGS_MAX_CHAINS];
-    if (capturing) {
-        for (int i = 0; i < n; ++i) {
-            Lowered Li;
-            Lowered& L = i == 0 ? L0 : Li;
-            if (i > 0) { if (int rc = lower(&chains[i], false, L)) return rc; }
-            segs[i] = cvgs::TickSeg{L.args.read.table, L.args.write.data, L.args.read.batch, L.args.read.used, 0, 0};
-        }
-        uint64_t* block = tick_pool().capture_block(device);
-        if (!block) return 0;
-        const int rc = cvgs::launch_k1_tick(L0.args, segs, n, cvgs::TickLaunch{block, nullptr, 0}, stream, false, nullptr);
-        return rc == 1 ? 1 : (rc == 0 ? 0 : fail(CVGS_ERR_HIP, "tick kernel launch failed"));
-    }
-    TickStream* ts = tick_pool().get(stream, device);
-    if (!ts) return 0;
-    std::lock_guard<std::mutex> lock(ts->mu);
-    if (ts->stream != stream) return 0; // (the block was handed to another stream between get() and here)
-    TickSlot* slot = nullptr;
-    size_t used = 0;
-    if (!tables) {
-        size_t bytes = 0;
-        for (int i = 0; i < n; ++i) bytes += (size_t)(chains[i].read.batch > 0 ? chains[i].read.batch : 0) * sizeof(PlaneParams) + 16;
-        slot = tick_pool().acquire(ts, bytes);
-        if (!slot) return 0;
-    }
-    for (int i = 0; i < n; ++i) {
-        Lowered Li;
-        Lowered& L = i == 0 ? L0 : Li;
-        if (i > 0) { if (int rc = lower(&chains[i], false, L)) return rc; } // nothing enqueued yet, the slot was not marked
-        const PlaneParams* table = L.args.read.table;
-        if (!tables) {
-            // the row worker addresses a crop's rows with 32-bit byte offsets from its first pixel (device tables: cvgs_plane_table_build
-            // refuses larger sources)
-            for (size_t z = 0; z < L.planes.size() && (int)z < L.args.read.used; ++z)
-                if ((uint64_t)L.planes[z].h * (uint64_t)L.planes[z].step >= (1ull << 32)) return 0;
-            const size_t b = L.planes.size() * sizeof(PlaneParams);
-            std::memcpy((uint8_t*)slot->host + used, L.planes.data(), b);
-            table = (const PlaneParams*)((uint8_t*)slot->host_dev + used);
-            used += (b + 15) & ~(size_t)15;
-        }
-        segs[i] = cvgs::TickSeg{table, L.args.write.data, L.args.read.batch, L.args.read.used, 0, 0};
-    }
-    const uint64_t seq = ts->next_seq;
-    const int rc = cvgs::launch_k1_tick(L0.args, segs, n, cvgs::TickLaunch{ts->counters, ts->done_dev, seq}, stream, false, nullptr);
-    if (rc != 1) return rc == 0 ? 0 : fail(CVGS_ERR_HIP, "tick kernel launch failed");
-    ts->next_seq = seq + 1;
-    if (slot) slot->seq = seq;
-    return 1;
-}
-
 int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
     // try the fused launch: every chain a resize of pixels (K1) or of 4:2:0 surfaces (K4) into a planar tensor, all of one shape
     bool fusable = n >= 2;
@@ -1219,11 +1096,6 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         int rc = lower(&chains[0], false, L0);
         if (rc) return rc;
         if (L0.int_arith) fusable = false; // integer-typed arithmetic: the interpreted kernel, chain by chain
-        if (fusable && !k4) { // crops of 8-bit frames behind [swap] mul sub div: the tick kernel
-            const int trc = execute_tick(chains, n, stream, tables, L0);
-            if (trc == 1) return CVGS_OK;
-            if (trc != 0) return trc;
-        }
         if (fusable) {
             // would the fast kernel take this shape?  (dry run: nothing is enqueued, nothing uploaded)
             ChainArgs probe = L0.args;
@@ -1232,9 +1104,24 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             if (k4) fusable = !tables && launch_nv12(probe, nullptr, 0, 1 << 30, &one, 1, stream, true, nullptr) == 1; // K4 checks its planes on the host
             else fusable = launch_k1(probe, nullptr, 0, MirrorArgs{}, &one, 1, stream, true, nullptr) == 1;
         }
+        // host descriptors: K1's table goes into a slot of the stream's own ring, recycled through the launch's progress word (ManyPool);
+        // K4's -- and K1's when that ring has no room -- into the event-tracked descriptor scratch
+        ManyStream* ms = nullptr;
+        ManySlot* mslot = nullptr;
+        std::unique_lock<std::mutex> ms_lock;
+        size_t ms_used = 0;
         if (fusable && !tables) {
-            rc = up.begin(total_planes * sizeof(PlaneParams) + 16 * (size_t)n, stream);
-            if (rc) return rc;
+            const size_t bytes = total_planes * sizeof(PlaneParams) + 16 * (size_t)n;
+            static const bool progress_word = [] { const char* e = getenv("CVGS_MANY_PROGRESS_WORD"); return e ? e[0] != '0' : true; }();
+            if (!k4 && progress_word && (ms = many_pool().get(stream, stream_device(stream))) != nullptr) {
+                ms_lock = std::unique_lock<std::mutex>(ms->mu);
+                mslot = many_pool().acquire(ms, bytes);
+                if (!mslot) { ms_lock.unlock(); ms = nullptr; }
+            }
+            if (!mslot) {
+                rc = up.begin(bytes, stream);
+                if (rc) return rc;
+            }
         }
         for (int i = 0; fusable && i < n; ++i) {
             Lowered Li;
@@ -1249,20 +1136,40 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             segs[i].batch = L.args.read.batch;
             segs[i].used = L.args.read.used;
             segs[i].out = L.args.write.data;
-            segs[i].table = tables ? L.args.read.table
-                                   : (const PlaneParams*)up.put(L.planes.data(), L.planes.size() * sizeof(PlaneParams));
+            if (tables) segs[i].table = L.args.read.table;
+            else if (mslot) {
+                const size_t b = L.planes.size() * sizeof(PlaneParams);
+                std::memcpy((uint8_t*)mslot->host + ms_used, L.planes.data(), b);
+                segs[i].table = (const PlaneParams*)((uint8_t*)mslot->host_dev + ms_used);
+                ms_used += (b + 15) & ~(size_t)15;
+            } else segs[i].table = (const PlaneParams*)up.put(L.planes.data(), L.planes.size() * sizeof(PlaneParams));
         }
         if (fusable) {
-            if (!tables) {
+            if (!tables && !mslot) {
                 rc = up.flush();
                 if (rc) return rc;
             }
             ChainArgs c = L0.args;
             c.read.batch = max_batch;
             c.read.table = segs[0].table; // non-null: the table variants
+            cvgs::DoneWordSlot& dw = cvgs::tls_done_word();
+            dw = cvgs::DoneWordSlot{};
+            if (mslot) { // this launch is number next_seq of its stream: when it starts, number next_seq - 1 has finished
+                dw.word = ms->done_dev;
+                dw.value = ms->next_seq - 1;
+            }
             rc = k4 ? launch_nv12(c, nullptr, 0, 1 << 30, segs, n, stream, false, nullptr)
                     : launch_k1(c, nullptr, 0, MirrorArgs{}, segs, n, stream, false, nullptr);
+            const bool reported = dw.used;
+            dw = cvgs::DoneWordSlot{};
             if (rc != 1) return fail(CVGS_ERR_HIP, "fused kernel launch failed");
+            if (mslot) {
+                if (reported) mslot->seq = ms->next_seq++;
+                else { // (a launch site that does not carry the word: make the slot safe the slow way -- not expected)
+                    (void)hipStreamSynchronize(stream);
+                    mslot->seq = 0;
+                }
+            }
             up.done(true);
             return CVGS_OK;
         }
@@ -1368,14 +1275,7 @@ int cvgs_plane_table_build(const cvgs_read_desc* read, void* host_out) {
     }
     int rc = lower(&ch, false, L);
     if (rc) return rc;
-    // the tick kernel of cvgs_execute_many addresses a crop's rows with 32-bit byte offsets and cannot see a device table's planes from
-    // the host: tables never hold sources of 4 GiB and more (host descriptors of such sources keep the 64-bit kernels)
-    if (read->kind == CVGS_READ_RESIZE_LINEAR)
-        for (size_t z = 0; z < L.planes.size() && (int)z < read->used_planes; ++z)
-            if ((uint64_t)L.planes[z].h * (uint64_t)L.planes[z].step >= (1ull << 32))
-                return fail(CVGS_ERR_UNSUPPORTED, "device plane tables: a source view of 4 GiB or more (use host descriptors)");
     std::memcpy(host_out, L.planes.data(), L.planes.size() * sizeof(PlaneParams));
-    tick_pool().prepare_capture_blocks(); // (a caller that builds device tables may capture their launches: the counter blocks of captured tick launches exist before any capture starts)
     return CVGS_OK;
 }
 
@@ -1869,8 +1769,6 @@ int cvgs_debug_occupy(int32_t blocks, int32_t threads, int32_t lds_bytes, double
     if (cvgs::launch_debug_occupy(blocks, threads, lds_bytes, microseconds, stream)) return fail(CVGS_ERR_HIP, "debug_occupy launch failed");
     return CVGS_OK;
 }
-
-uint64_t cvgs_debug_tick_launches(void) { return cvgs::tick_launches(); }
 
 int cvgs_debug_poll(const void* word, double microseconds, int32_t nap, cvgs_stream_t stream) {
     if (((uintptr_t)word & 7) || microseconds < 0 || microseconds > 5e6) return fail(CVGS_ERR_INVALID, "debug_poll: an 8-byte aligned word (NULL = an uncached device word of the library's), <= 5 s");

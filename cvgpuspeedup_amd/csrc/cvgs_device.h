@@ -116,6 +116,19 @@ inline StopEventSlot& tls_stop_event() {
     return x;
 }
 
+// The fused K1 launch of cvgs_execute_many reports the stream's progress itself: its first work-item stores `value` (the sequence number
+// of the stream's PREVIOUS fused launch, which has finished once this kernel runs) into the pinned word `word` (cvgs_api.cpp: ManyPool).
+// Armed by the call that prepared the table, consumed by the launch site (thread-local, as the stop event above).
+struct DoneWordSlot {
+    uint64_t* word = nullptr;
+    uint64_t value = 0;
+    bool used = false;
+};
+inline DoneWordSlot& tls_done_word() {
+    static thread_local DoneWordSlot x{};
+    return x;
+}
+
 // implement it (K1 planar inside K1Geom, the interpreted kernel).
 struct MirrorArgs {          // 64 bytes
     uint8_t* p[CVGS_MAX_MIRRORS];
@@ -135,25 +148,6 @@ struct KernArgsMany {
     ManySeg seg[CVGS_MAX_CHAINS];
 };
 static_assert(sizeof(KernArgsMany) <= 4096 - 256, "segment block + K1Geom must fit the kernel-argument block");
-
-// cvgs_execute_many as a TICK (k_tick.hip): the chains of one call walked by a grid of persistent-for-one-launch worker waves.
-struct TickSeg {             // 32 bytes
-    const PlaneParams* table; // device-visible: PlaneParams[batch] of this chain
-    uint8_t* out;             // this chain's output tensor
-    int32_t batch, used;
-    uint32_t plane0;          // planes of the segments in front of this one (filled by launch_k1_tick)
-    uint32_t out_bytes;       // extent of the chain's tensor (filled by launch_k1_tick)
-};
-struct TickLaunch {
-    uint64_t* counters;  // device memory, tick_counter_words() words, all zero between launches (the kernel's last worker resets them)
-    uint64_t* done_word; // device-visible pinned host word that receives `seq` when the launch has finished, or null
-    uint64_t seq;
-};
-struct LaunchInfo;
-int tick_counter_words();
-uint64_t tick_launches();
-// 1 = launched (dry_run: would launch), 0 = not a shape the tick kernel takes, < 0 = error
-int launch_k1_tick(const ChainArgs& c, const TickSeg* segs, int n_segs, const TickLaunch& tl, void* stream, bool dry_run, LaunchInfo* info);
 
 // CV_64F chains: the double operands travel next to the float ones, with a small inline plane block.
 struct Prog64Args {

@@ -46,6 +46,10 @@ struct K1Geom {
     uint8_t* mirror[CVGS_MAX_MIRRORS];
     int32_t n_mirror;
     int32_t pad2;
+    // fused launches with host descriptors (NPL == 0; cvgs_api.cpp: ManyPool): the first work-item stores done_value into *done_word
+    // (pinned host memory) when the kernel starts -- every earlier launch of the stream has finished by then
+    uint64_t* done_word;
+    uint64_t done_value;
 };
 
 // NPL > 0: the planes travel in the kernel arguments.  NPL == 0: they live in device tables, one segment per fused
@@ -122,6 +126,11 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(const K1Args<NP
     asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(used), "s"(W), "s"(col_tiles), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.x1),
                  "s"(P.y1), "s"(P.x2), "s"(P.y2), "s"(P.fx), "s"(P.fy), "s"(P.data), "s"(img_stride), "s"(ch_stride),
                  "s"(out_base), "s"(out2_base), "s"(img_stride2), "s"(ch_stride2), "s"(op0), "s"(op1), "s"(op2), "s"(op3), "s"(n_mirror));
+    // (behind the scalar loads: a store in front of them would make the compiler fetch the descriptors with vector loads)
+    if constexpr (NPL == 0) {
+        if (g.done_word && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0)
+            __hip_atomic_store(g.done_word, g.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 
     int col_tile = 0, row_tile = (int)blockIdx.x;
     if (col_tiles > 1) {
@@ -346,6 +355,16 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
     }
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
+    g.done_word = nullptr;
+    g.done_value = 0;
+    if constexpr (NPL == 0) {
+        DoneWordSlot& dw = tls_done_word();
+        if (dw.word && !dw.used) {
+            dw.used = true;
+            g.done_word = dw.word;
+            g.done_value = dw.value;
+        }
+    }
     StopEventSlot& stop = tls_stop_event();
     if (stop.event && !stop.used) {
         stop.used = true;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CVGS_ABI_VERSION 6
+#define CVGS_ABI_VERSION 5
 #define CVGS_MAX_OPS 12        /* pointwise stages between the read and the write            */
 #define CVGS_MAX_CHANNELS 4
 #define CVGS_KERNARG_PLANES 64 /* planes whose descriptors travel inside the kernel arguments */
@@ -296,12 +296,7 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * surface included; chains whose plane table lives on the device are NOT checked: the caller vouches for them -- lies inside another's
  * output: fused chains run concurrently), a set with a batch beyond 65535, and host descriptors under stream capture.  Host
  * descriptors of a fused launch are written into a pooled pinned buffer that the kernel reads in place (no copy; the slot is
- * recycled once its kernel has run; a host more than 8 (tick kernel) / 16 such launches ahead of ONE stream waits -- a few milliseconds at most -- for the oldest of them).
- * Crops of 8-bit 3- / 4-channel frames behind [RGB<->BGR] mul, sub, div into fp32 / fp16 planar tensors -- the hot shape -- are served by the
- * TICK kernel (ABI 6; csrc/k_tick.hip): one launch of a few workgroups per CU whose waves draw the tick's tasks (rows of crops, all chains in
- * one numbering) from ticket counters, 16-byte row stores, and a completion word instead of a HIP event behind the launch; other shapes keep
- * the grid kernel (blockIdx.z = chain).  Pass device plane tables to make the fused call capturable (a captured tick launch must not be
- * replayed concurrently with itself); at most
+ * recycled once its kernel has run; a host more than 16 such launches ahead of ONE stream waits for the oldest of them); pass device plane tables to make the fused call capturable; at most
  * CVGS_MAX_CHAINS chains per call.  The reference's closest spelling is the batch sweep of
  * tests/batchresize/test_batchresize_x_split3D.cu:384-392 (one launch per BATCH value).                          */
 int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stream_t stream);
@@ -518,9 +513,6 @@ int cvgs_debug_occupy(int32_t blocks, int32_t threads, int32_t lds_bytes, double
 /* one wave that reads `word` (device, uncached-device or pinned host memory, 8-byte aligned) with system-scope loads for `microseconds`
  * (nap != 0: s_sleep between the loads): the access pattern of a resident server's polling, for tools/probes/ only.               */
 int cvgs_debug_poll(const void* word, double microseconds, int32_t nap, cvgs_stream_t stream);
-/* (ABI 6) how many cvgs_execute_many calls of this process were served by the tick kernel (k1_tick: one launch whose worker waves walk
- * the tick's tasks) -- introspection for tests and benchmarks, as cvgs_kernel_name is for cvgs_execute.                          */
-uint64_t cvgs_debug_tick_launches(void);
 
 /* ---- profiling ranges (reference tests/nvtx.h PUSH_RANGE/POP_RANGE) -------------------------- */
 void cvgs_range_push(const char* name);

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Ticks of M frames (50 crops each, cfg #2b) through cvgs_execute_many -- the tick kernel (csrc/k_tick.hip) or, with CVGS_TICK=0, the grid
-kernel it replaced -- on a rotation whose read-touched set is >= 2 x the Infinity Cache:
+"""Ticks of M frames (50 crops each, cfg #2b) through cvgs_execute_many (ONE launch per tick, grid z = chain) on a rotation whose read-touched
+set is >= 2 x the Infinity Cache:
   graph   device plane tables, the K ticks captured into HIP graphs and replayed: device time per tick (HIP events around replays)
   eager   host descriptors (a fresh table every call), a one-wave producer kernel on the stream in front of every tick, ONE stream, host wall
           clock incl. the final synchronise + the host's enqueue time per call (what a serving loop pays)
-The environment knobs are read once per process: --sweep runs this file once per setting in a subprocess.
-usage: bench_tick.py [--m 16] [--frames 96] [--sweep]"""
+  host    the same call on 16 x 1-crop chains (a kernel of a few microseconds): what the HOST needs per call
+usage: bench_tick.py [--m 16] [--frames 96]"""
 import argparse
 import ctypes as C
 import json
@@ -29,17 +29,16 @@ def run(a):
     lib = capi.load_library()
     M = a.m
     nf = ((a.frames + M - 1) // M) * M
-    out = {"env": {k: os.environ[k] for k in os.environ if k.startswith("CVGS_TICK")}, "m": M, "frames": nf}
+    out = {"env": {k: os.environ[k] for k in os.environ if k.startswith("CVGS_")}, "m": M, "frames": nf}
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
     s = side.cuda_stream
     # ---- graph-replayed, device tables ----
     wl = B.Workload(dev, nf, 50, 0, 1, True, per_launch=M)
     alg = wl.algorithmic_bytes()  # per launch (M frames)
-    before = lib.cvgs_debug_tick_launches()
     m = B.measure(wl, max(16, 256 // M), 4, target_s=0.15, min_replays=20, est_step_s=2.5e-6 * M)
     out["graph"] = {"us_per_tick": round(m["step_s"] * 1e6, 3), "us_per_frame": round(m["step_s"] * 1e6 / M, 4), "frac": round(alg / m["step_s"] / 1e9 / 8000.0, 4),
-                    "p10_us": round(m["p10_s"] * 1e6, 3), "p90_us": round(m["p90_s"] * 1e6, 3), "tick_kernel_launches_captured": lib.cvgs_debug_tick_launches() - before}
+                    "p10_us": round(m["p10_s"] * 1e6, 3), "p90_us": round(m["p90_s"] * 1e6, 3)}
     del wl
     torch.cuda.empty_cache()
     # ---- eager, host descriptors, producer on the stream ----
@@ -84,7 +83,18 @@ def run(a):
             torch.cuda.synchronize()
             ok = ok and bool(torch.equal(got.view(torch.int32), wlh.outs[i].view(torch.int32)))
     out["bit_identical_to_cvgs_execute"] = ok
-    out["tick_kernel_launches"] = lib.cvgs_debug_tick_launches()
+    # ---- the host's share: the same call on M one-crop chains (the kernel is a few microseconds) ----
+    wl1 = B.Workload(dev, M * 4, 1, 0, 1, False)
+    p1 = [cvgs.pack_chains(wl1.chains[g * M:(g + 1) * M]) for g in range(4)]
+    for i in range(64):
+        capi.check(lib.cvgs_execute_many(p1[i % 4], M, s))
+    side.synchronize()
+    t0 = time.perf_counter()
+    for i in range(512):
+        capi.check(lib.cvgs_execute_many(p1[i % 4], M, s))
+    t1 = time.perf_counter()
+    side.synchronize()
+    out["host_us_per_call_1_crop_chains"] = round((t1 - t0) / 512 * 1e6, 3)
     print(json.dumps(out), flush=True)
 
 
@@ -92,21 +102,8 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--m", type=int, default=16)
     p.add_argument("--frames", type=int, default=96)
-    p.add_argument("--sweep", action="store_true")
     a = p.parse_args()
-    if not a.sweep:
-        return run(a)
-    settings = [{"CVGS_TICK": "0"}, {}]
-    for rows in (4, 8, 16, 32):
-        for wgs in (2, 3, 4):
-            settings.append({"CVGS_TICK_ROWS": str(rows), "CVGS_TICK_WGS_PER_CU": str(wgs)})
-    settings += [{"CVGS_TICK_ST": "0"}, {"CVGS_TICK_ST": "0", "CVGS_TICK_ROWS": "8", "CVGS_TICK_WGS_PER_CU": "4"}]
-    for st in settings:
-        env = dict(os.environ)
-        env.update(st)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--m", str(a.m), "--frames", str(a.frames)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        print(line[-1] if line else json.dumps({"env": st, "error": r.stderr[-400:]}), flush=True)
+    return run(a)
 
 
 if __name__ == "__main__":

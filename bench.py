@@ -5,25 +5,31 @@ Metric: Mpixels/s of the fused crop+resize+normalize+split kernel (K1), 50 varia
 frame -> [50,3,128,64] fp32 NCHW (BASELINE.md cfg #2b), plus the fraction of the HBM roofline the kernel
 reaches and the CPU restatement timed beside it.
 
-A "step" = one pass of the hot path over one batch = ONE cvgs_execute() = one K1 launch over the 50 crops
-of one frame.  Steps cycle over enough distinct resident frames / outputs to exceed 2x the 256 MB Infinity
-Cache, so reads and writes really go to HBM.  Inputs (frames, crop descriptors) are resident in HBM before
-the timed region; the K timed steps are replayed from a HIP graph so the host's launch rate is not what is
-measured (eager numbers are reported next to it under "extra").
+A "step" = one pass of the hot path over one batch = the 50 crops of ONE frame -> one tensor.  Round 5's headline regime is the one a
+drop-in runs: STRICTLY STREAM-ORDERED TICKS -- the frames of 16 cameras (16 steps) per cvgs_execute_many call =
+ONE kernel launch on one plain stream, nothing resident between two ticks (`--submission ticks`, the default).  The descriptor queue
+(`--submission queue`: one cvgs_queue_submit per step, a resident server grid -- rounds 3 / 4's headline) and one launch per step
+(`--submission graph`) are measured beside it in every line.  Steps cycle over a rotation of resident frames whose TOUCHED set (the
+distinct 64-byte sectors holding a tapped byte + the written tensors) is several times the 256 MiB Infinity Cache -- sized from touched
+bytes, not whole frames: round 4's 20 whole frames were 0.96 x the cache and its 0.53 turned out to be cache-assisted (the 20 / 48 / 96
+frame sweep in the line: 2.15 / 2.58 / 2.64 us per step on the queue).  Inputs (frames, crop descriptors) are resident in HBM before the
+timed region; the timed launches are replayed from HIP graphs so the host's launch rate is not what is measured (the eager call path,
+host lowering included, is reported in `stream_ordered`).
 
 Timing protocol (one clock for `value`, `ms_per_step` and `roofline.frac`; mirrors the warm-up + ITERS
 mean/min/max protocol of the reference's tests/testsCommon.cuh:122-195):
   1. pre-roll: >= 50 ms of K1 launches regardless of --warmup (clock ramp), then the W warm-up steps;
-  2. the K-step graph is replayed R >= 50 times back to back, each replay bracketed by a pair of HIP events ON THE
-     LAUNCH STREAM; the whole sequence sits between barrier + torch.cuda.synchronize() on both sides;
-  3. per-step time = MEDIAN over the R replays of (event time / K) (p10 / p90 / single-launch latency beside it);
-     value = pixels per step / that time, ms_per_step = that time, roofline.frac = algorithmic bytes per launch /
-     that time / 8 TB/s.  The wall clock of the bracketed region is reported too (`wall_ms_per_step`).
+  2. the K steps (repeated m times: m x K a multiple of the tick and >= 256) are captured as m x K / 16 tick launches and replayed
+     R >= 50 times back to back, each replay bracketed by a pair of HIP events ON THE LAUNCH STREAM; the whole sequence sits between
+     barrier + torch.cuda.synchronize() on both sides;
+  3. per-step time = MEDIAN over the R replays of (event time / (m x K)) (p10 / p90 beside it); value = pixels per step / that time,
+     ms_per_step = that time, roofline.frac = algorithmic bytes per step / that time / 8 TB/s.  The wall clock of the bracketed region
+     is reported too (`wall_ms_per_step`).
 
 N > 1 (one process per GPU, torch.distributed/RCCL) runs BASELINE cfg #5: each rank owns one resident 6K frame stream
 and 64 crops per step (weak scaling), K1 writes the rank's rows of the [N*64,3,128,64] tensor, and the tensor is
 assembled on every GPU either by an in-place RCCL all-gather over xGMI or by the P2P fused write (the kernel stores
-its rows into every peer's tensor through IPC-mapped pointers; one tiny all-reduce per step as the barrier).
+its rows into every peer's tensor through IPC-mapped pointers; device-side arrival flags as the barrier).
 """
 import argparse
 import ctypes as C
@@ -50,6 +56,8 @@ INFINITY_CACHE = 256 << 20
 PREROLL_S = 0.05       # >= 50 ms of K1 before any timing (clock ramp)
 MIN_REPLAYS = 50
 RESIDENCY_SWEEP = (20, 48, 96)  # frames in rotation: round 4's 20 (touched set ~ 0.96 x the Infinity Cache), 48 (2.3 x), 96 (4.6 x)
+TICK = 16                       # frames (steps) per cvgs_execute_many launch in the headline regime
+TICK_SWEEP = (32, 48, 96)       # the same sweep for ticks (rotations are whole ticks)
 
 
 def baseline_metric():
@@ -70,16 +78,17 @@ def parse():
     p.add_argument("--frames-per-launch", type=int, default=1, help="independent 50-crop chains fused per launch (cvgs_execute_many)")
     p.add_argument("--table", action="store_true", help="descriptors in a resident device table, not kernel args")
     p.add_argument("--eager", action="store_true", help="time eager launches instead of graph replay (PMC runs)")
-    p.add_argument("--submission", choices=("queue", "graph"), default="queue",
-                   help="headline submission path: the device-side descriptor queue (one cvgs_queue_submit per step) or one "
-                        "graph-replayed cvgs_execute launch per step")
+    p.add_argument("--submission", choices=("ticks", "queue", "graph"), default="ticks",
+                   help="headline submission path: strictly stream-ordered ticks (16 steps per cvgs_execute_many launch, the default), the "
+                        "device-side descriptor queue (one cvgs_queue_submit per step, rounds 3 / 4) or one graph-replayed cvgs_execute launch per step")
     p.add_argument("--no-queue-events", action="store_true",
                    help="queue submission: no HIP events on the server's stream (rocprofv3 --pmc crashes on them); the server's "
                         "duration then comes from its own 100 MHz clock (cvgs_queue_stats)")
     p.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     p.add_argument("--no-extra", action="store_true", help="skip the extra sweeps")
     p.add_argument("--no-regimes", action="store_true", help="skip the stream-ordered / latency / coexistence legs")
-    p.add_argument("--no-sweep", action="store_true", help="skip the 20 / 48 / 96-frame residency sweep of the headline step")
+    p.add_argument("--no-sweep", action="store_true", help="skip the residency sweep of the headline step (rotations of 32 / 48 / 96 frames; the queue: 20 / 48 / 96)")
+    p.add_argument("--no-queue-leg", action="store_true", help="ticks: skip the descriptor-queue leg (queue_opt_in)")
     p.add_argument("--soak", type=float, default=0.0, help="coexistence: seconds of soak with the consumer running throughout (0 = none)")
     p.add_argument("--print-extra", action="store_true", help="also print the full record (bench_extra.json's content) on stderr")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -155,11 +164,22 @@ class Workload:
 
 
 class RotationView:
-    """The first k frames of a Workload as a rotation of their own (the residency sweep): only what measure_queue reads."""
+    """The first k frames of a Workload as a rotation of their own (the residency sweep): what measure_queue / measure_ticks read."""
 
     def __init__(self, wl, k):
         self.chains = wl.chains[:k]
         self.n = wl.n
+        self.per_launch = wl.per_launch
+        self.lib = wl.lib
+        self.groups = wl.groups[:max(1, k // wl.per_launch)] if wl.per_launch > 1 else []
+
+    def launch(self, i, stream):
+        if self.per_launch > 1:
+            rc = self.lib.cvgs_execute_many(self.groups[i % len(self.groups)], self.per_launch, stream)
+        else:
+            rc = self.lib.cvgs_execute(C.byref(self.chains[i % len(self.chains)].desc), stream)
+        if rc:
+            capi.check(rc)
 
 
 def capture(wl, n, base=0):
@@ -175,7 +195,7 @@ def percentile(sorted_vals, q):
     return float(sorted_vals[min(len(sorted_vals) - 1, int(len(sorted_vals) * q))])
 
 
-def measure(wl, steps, warmup, barrier=lambda: None, eager=False, target_s=0.25, min_replays=MIN_REPLAYS, est_step_s=5e-6):
+def measure(wl, steps, warmup, barrier=lambda: None, eager=False, target_s=0.25, min_replays=MIN_REPLAYS, est_step_s=5e-6, exact_steps=False):
     """The timing protocol of the module docstring.  Returns per-step seconds (median / p10 / p90 over the replays),
     the wall clock of the whole bracketed region, and the number of replays."""
     s = torch.cuda.current_stream().cuda_stream
@@ -183,7 +203,7 @@ def measure(wl, steps, warmup, barrier=lambda: None, eager=False, target_s=0.25,
     # A graph replay has a fixed device-side cost of its own (~10 us between two replays, measured: K = 20 reads 4.98 us
     # per step against 4.44 us at K = 256) that belongs to no step.  Short step counts are therefore captured as the
     # K-step sequence repeated m times inside ONE graph (m*K >= 256 launches); one timed replay = m passes over the K steps.
-    m_rep = 1 if (eager or steps >= 256) else -(-256 // steps)
+    m_rep = 1 if (eager or steps >= 256 or exact_steps) else -(-256 // steps)
     if not eager:
         # long step counts: graphs of <= 256 launches (graph nodes are cheap to build, very long graphs are not)
         graphs, base = [], 0
@@ -448,6 +468,37 @@ def summary(wl, m, out_elem=4):
             "frac_of_sector_bound": round(wl.sector_bound_bytes(out_elem) / t / 1e9 / HBM_PEAK_GBS, 4), "kernel": wl.kernel}
 
 
+def measure_ticks(wl, steps, warmup, barrier=lambda: None, eager=False, target_s=0.25, min_replays=MIN_REPLAYS):
+    """The protocol of the module docstring for TICKS: `wl` launches wl.per_launch steps (frames) per call (cvgs_execute_many, device
+    tables).  The K steps are repeated m times so that m x K is a whole number of ticks and >= 256 steps; one timed replay = m x K / tick
+    launches.  Returns measure()'s dict with every time PER STEP, plus `launch_s` (per tick launch) and the launches per replay."""
+    tick = wl.per_launch
+    m_rep = 1
+    while (m_rep * steps) % tick or m_rep * steps < 256:
+        m_rep += 1
+    launches = m_rep * steps // tick
+    m = measure(wl, launches, max(1, -(-warmup // tick)), barrier=barrier, eager=eager, target_s=target_s, min_replays=min_replays, est_step_s=2.5e-6 * tick,
+                exact_steps=True)
+    out = {k: (v / tick if k.endswith("_s") and k != "wall_s" else v) for k, v in m.items()}
+    out.update({"launch_s": m["step_s"], "launches_per_replay": launches, "passes_per_replay": m_rep, "tick": tick})
+    return out
+
+
+def ticks_match_single_launches(wl, single):
+    """Every resident frame's tensor as the tick launches left it against what ONE cvgs_execute launch writes for the same chain (`single`:
+    a Workload over the same frames and crop lists with its own tensors, one chain per launch)."""
+    s = torch.cuda.current_stream().cuda_stream
+    ok = True
+    for g in range(len(wl.groups)):
+        wl.launch(g, s)
+    for i in range(len(single.chains)):
+        single.launch(i, s)
+    torch.cuda.synchronize()
+    for i in range(len(single.chains)):
+        ok = ok and bool(torch.equal(wl.outs[i].view(torch.int32), single.outs[i].view(torch.int32)))
+    return ok
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -465,9 +516,13 @@ def main():
         return bench_dist.main(a, dev, rank, world)
 
     n = a.crops
-    M = a.frames_per_launch
     plane = 3 * W.DST[0] * W.DST[1]
     per_frame_bytes = W.FRAME_4K[0] * W.FRAME_4K[1] * 3 + n * plane * 4
+    # which regime is the headline?  ticks (default): TICK steps per cvgs_execute_many launch; --frames-per-launch M: the same with M
+    use_ticks = a.submission == "ticks" and not a.table
+    M = a.frames_per_launch if a.frames_per_launch > 1 else (TICK if use_ticks else 1)
+    use_ticks = use_ticks or M > 1
+    use_queue = a.submission == "queue" and M == 1 and not a.eager and not a.table and n <= 74
     # The rotation is sized from the bytes a launch TOUCHES (distinct 64-byte sectors holding a tapped byte), not from whole frames:
     # its READ-touched set alone must be >= 2 x the 256 MiB Infinity Cache (W.rotation_units; VERDICT r4 "What's weak" #2 -- round 4's
     # 20 whole frames were 596 MB but 257 MB of touched sectors, 0.96 x the cache).  The headline rotates over the largest point of the
@@ -482,8 +537,7 @@ def main():
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
 
-    use_queue = a.submission == "queue" and M == 1 and not a.eager and not a.table and n <= 74
-    m_graph = None
+    queue_ok = None
     if use_queue:
         # The server grid must live across the WHOLE timed region (one launch: its event-timed duration / batches is roofline.achieved).
         # A host stall longer than idle_us (an OS scheduling blip on a shared box: seen once in round 4, 16 ms) retires it mid-region; the
@@ -497,10 +551,30 @@ def main():
                 break
         m["attempts_server_launches"] = attempts
         queue_ok = queue_outputs_match_execute(wl)
+    elif use_ticks:
+        m = measure_ticks(wl, a.steps, a.warmup, eager=a.eager)
     else:
         m = measure(wl, a.steps, a.warmup, eager=a.eager)
     step_s = m["step_s"]
-    px_per_step = wl.pixels_per_launch()
+    px_per_step = n * W.DST[0] * W.DST[1]
+    if use_ticks:
+        submission = ("strictly stream-ordered TICKS: %d steps (frames, one 50-crop chain each) per cvgs_execute_many call = ONE kernel launch (grid z = chain) on "
+                      "one plain stream, nothing resident between ticks; device plane tables, %s" % (M, "eager" if a.eager else "HIP-graph replay"))
+        regime = "%d independent 50-crop chains per launch: a tick of %d cameras' frames" % (M, M)
+        protocol = ("pre-roll >= %d ms; the K steps repeated m times (m x K a whole number of ticks, >= 256 steps) = m x K / %d tick launches per graph replay, "
+                    "R replays back to back, HIP events on the launch stream around each; per-step time = median over replays of event time / (m x K)" % (int(PREROLL_S * 1e3), M))
+    elif use_queue:
+        submission = "device-side descriptor queue: one cvgs_queue_submit per step, a resident server grid, no launch per step"
+        regime = "one frame (50 crops) per step; consecutive steps overlap on the device (batch k+1 loads while batch k stores)"
+        protocol = ("pre-roll >= %d ms; the K steps (repeated m times when K < 256) handed to cvgs_queue_submit_many per replay, replays "
+                    "pipelined one ahead, host wall clock stamped at every awaited last ticket; per-step time = median over "
+                    "replays of stamp difference / (m x K) -- end to end, host side included" % int(PREROLL_S * 1e3))
+    else:
+        submission = "eager" if a.eager else "hipGraph replay (%d-launch graphs)" % (256 if a.steps >= 256 else a.steps * -(-256 // a.steps))
+        regime = ("one launch per step, steps serialised on one stream (launch-latency regime: a 50-crop launch moves ~9 MB = 1.1 us at 8 TB/s "
+                  "behind a ~1.8 us launch/drain floor)")
+        protocol = ("pre-roll >= %d ms; graph of the K steps (repeated m times when K < 256, so that a graph holds >= 256 launches) replayed R times back to "
+                    "back, HIP events on the launch stream around each replay; per-step time = median over replays of event time / (m x K)" % int(PREROLL_S * 1e3))
     result = {
         "metric": baseline_metric(),
         "value": round(px_per_step / step_s / 1e6, 1),
@@ -515,27 +589,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "cfg2b: %d variable-size crops (w~U[32,512], h~U[64,1024]) of a 4K u8c3 frame -> "
-                               "[%d,3,128,64] fp32 per launch; %d resident frames cycled (touched set %.0f MB = %.0f MB of tapped 64-B sectors + "
+                               "[%d,3,128,64] fp32 per step; %d resident frames cycled (touched set %.0f MB = %.0f MB of tapped 64-B sectors + "
                                "%.0f MB written, %.1f x the 268 MB Infinity Cache; the whole frames + tensors are %.0f MB)" % (
                                    n, n, n_frames, resid["touched_MB"], resid["read_touched_MB"], resid["touched_MB"] - resid["read_touched_MB"],
                                    resid["touched_MB"] / resid["llc_MB"], n_frames * per_frame_bytes / 1e6),
                    "chain": "resize(bilinear) -> RGB2BGR -> x0.3 -> -(1,4,3.2) -> /(3.2,0.6,11.8) -> TensorSplit",
-                   "crops_per_launch": n, "frames_per_launch": M, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
+                   "crops_per_launch": n * M, "frames_per_launch": M, "frame": "3840x2160 u8c3", "kernel": wl.kernel,
                    "descriptors": "device table" if (a.table or M > 1) else "kernel arguments",
-                   "submission": ("device-side descriptor queue: one cvgs_queue_submit per step, a resident server grid, no launch per step"
-                                  if use_queue else ("eager" if a.eager else "hipGraph replay (%d-launch graphs)" % (256 if a.steps >= 256 else a.steps * -(-256 // a.steps)))),
-                   "regime": ("one frame (50 crops) per step; consecutive steps overlap on the device (batch k+1 loads while batch k stores)"
-                              if use_queue else
-                              "one launch per step, steps serialised on one stream (launch-latency regime: a 50-crop launch "
-                              "moves ~9 MB = 1.1 us at 8 TB/s behind a ~1.8 us launch/drain floor)") if M == 1 else
-                             "%d independent 50-crop chains fused per launch (cvgs_execute_many)" % M,
+                   "submission": submission, "regime": regime,
                    "parallelism": "1 process per GPU, crop lists sharded, no collective"},
-        "timing": {"protocol": ("pre-roll >= %d ms; the K steps (repeated m times when K < 256) handed to cvgs_queue_submit_many per replay, replays "
-                                "pipelined one ahead, host wall clock stamped at every awaited last ticket; per-step time = median over "
-                                "replays of stamp difference / (m x K) -- end to end, host side included" % int(PREROLL_S * 1e3)) if use_queue else
-                               "pre-roll >= %d ms; graph of the K steps (repeated m times when K < 256, so that a graph holds >= 256 "
-                               "launches) replayed R times back to back, HIP events on the launch stream around each replay; "
-                               "per-step time = median over replays of event time / (m x K)" % int(PREROLL_S * 1e3),
+        "timing": {"protocol": protocol,
                    "replays": m["replays"], "passes_over_the_K_steps_per_replay": m["passes_per_replay"], "step_us_median": round(step_s * 1e6, 4), "step_us_p10": round(m["p10_s"] * 1e6, 4),
                    "step_us_p90": round(m["p90_s"] * 1e6, 4), "step_us_min": round(m["min_s"] * 1e6, 4),
                    "wall_ms_per_step": round(m["wall_step_s"] * 1e3, 6),
@@ -543,8 +606,13 @@ def main():
                                 "submissions and event records"},
     }
 
-    alg = wl.algorithmic_bytes()
-    kernel_us = step_s * 1e6
+    alg = float(np.mean([W.k1_algorithmic_bytes(c) for c in wl.crops]))  # per step (one frame's 50 crops)
+    sector = float(wr_frame + rd_frame)
+    kernel_us = step_s * 1e6 * M  # per launch
+    if use_ticks:
+        result["timing"]["tick_launch"] = {"us_per_launch": round(m["launch_s"] * 1e6, 3), "launches_per_replay": m["launches_per_replay"], "steps_per_launch": M,
+                                           "clock": "HIP events on the launch stream around each replay / launches per replay (includes the ~1.5 us boundary between two launches)",
+                                           "kernel": wl.kernel + " (K1's fused form: k1_resize_split<3, 0, 2, ...>, planes in device tables, blockIdx.z = chain)"}
     if use_queue:
         # the dominant kernel is the server grid: ONE launch served every batch of the timed region; its duration between two
         # HIP events on its own stream (minus the idle tail it waits before retiring) / the batches it served
@@ -555,46 +623,75 @@ def main():
         result["timing"]["batch_latency_server_alive"] = m["latency"]
         result["queue"] = m["queue"]
         result["queue"]["every_frame_bit_identical_to_cvgs_execute"] = queue_ok
-    achieved = alg / (kernel_us * 1e-6) / 1e9
+    units = 1 if use_queue else M  # steps one "launch" of the dominant kernel serves (the queue: one batch of its ONE server call)
+    achieved = alg * units / (kernel_us * 1e-6) / 1e9
     ceiling = copy_ceiling(dev)
-    sector = wl.sector_bound_bytes()
     result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, a.table, M, use_queue),
-                          "kernel": "k1q_server (queue) / " + wl.kernel if use_queue else wl.kernel, "kernel_us": round(kernel_us, 3),
+                          "kernel": "k1q_server (queue) / " + wl.kernel if use_queue else wl.kernel, "kernel_us": round(kernel_us, 3), "steps_per_launch": units,
                           "frac_end_to_end": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 4),
-                          "algorithmic_bytes_per_launch": int(alg),
+                          "algorithmic_bytes_per_launch": int(alg * units),
                           # distinct 64-byte sectors holding a tapped byte + the writes: what no kernel can go below
-                          "sector_bound_bytes_per_launch": int(sector),
-                          "frac_of_sector_bound": round(sector / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "sector_bound_bytes_per_launch": int(sector * units),
+                          "frac_of_sector_bound": round(sector * units / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                           # the on-box device-to-device copy ceiling (read + write bytes / time), measured now
                           "copy_ceiling": ceiling, "frac_of_copy_ceiling": round(achieved / ceiling, 4) if ceiling else None,
                           "residency": resid,
                           "traffic_src": "committed PMC passes of this kernel and workload (profiles/pmc_headline.json), not counters of this run"}
-    if use_queue and not a.frames and not a.no_sweep:
-        # the same step on rotations of 20 / 48 / 96 frames: does the figure depend on what the Infinity Cache can hold?
+    if not a.frames and not a.no_sweep and not a.eager and (use_queue or (use_ticks and M == TICK)):
+        # the same step on smaller rotations: does the figure depend on what the Infinity Cache can hold?
         sweep = {}
-        for k in RESIDENCY_SWEEP:
+        for k in (RESIDENCY_SWEEP if use_queue else TICK_SWEEP):
             if k == n_frames:
                 sweep[str(k)] = round(step_s * 1e6, 4)
+            elif k < n_frames and use_queue:
+                sweep[str(k)] = round(measure_queue(RotationView(wl, k), a.steps, 0, target_s=0.08, min_replays=12, events=False)["step_s"] * 1e6, 4)
             elif k < n_frames:
-                sub = RotationView(wl, k)
-                ms = measure_queue(sub, a.steps, 0, target_s=0.08, min_replays=12, events=False)
-                sweep[str(k)] = round(ms["step_s"] * 1e6, 4)
+                sweep[str(k)] = round(measure_ticks(RotationView(wl, k), a.steps, 0, target_s=0.08, min_replays=12)["step_s"] * 1e6, 4)
         result["roofline"]["sweep_us"] = sweep
-        result["roofline"]["sweep_touched_MB"] = {str(k): W.residency(k, rd_frame, wr_frame)["touched_MB"] for k in RESIDENCY_SWEEP if str(k) in sweep}
-    result["timing"]["single_launch_latency"] = single_launch_latency(wl)
-    if use_queue:  # the same workload with one graph-replayed launch per step: the round-1/2 headline, for comparison
+    single = None
+    if use_ticks and M == TICK and not a.eager:
+        # the same frames and crop lists, one chain per launch / per queue submit (their own tensors): the other two regimes, and the check
+        single = Workload(dev, n_frames, n, rank, world, False, share=wl)
+        result["ticks_ok"] = ticks_match_single_launches(wl, single)
+        mg = measure(single, a.steps, a.warmup, target_s=0.12)
+        result["one_launch_per_step"] = {"us_per_step": round(mg["step_s"] * 1e6, 4), "Mpix_per_s": round(px_per_step / mg["step_s"] / 1e6, 1),
+                                         "frac": round(alg / mg["step_s"] / 1e9 / HBM_PEAK_GBS, 4), "kernel": single.kernel,
+                                         "submission": "hipGraph replay, one cvgs_execute launch per step"}
+        result["timing"]["single_launch_latency"] = single_launch_latency(single)
+        if not a.no_queue_leg and n <= 74:
+            # the descriptor queue (rounds 3 / 4's headline; an OPT-IN since round 5: a resident server costs a co-resident GEMM x1.6, `coexistence`):
+            # one cvgs_queue_submit per step on the same rotation, and on the rotations round 4 used
+            mq = measure_queue(single, a.steps, a.warmup, target_s=0.12, events=False)
+            qk = {"us_per_step": round(mq["step_s"] * 1e6, 4), "frac": round(alg / mq["step_s"] / 1e9 / HBM_PEAK_GBS, 4),
+                  "latency_us": mq["latency"]["median_us"], "ok": bool(queue_outputs_match_execute(single)) and not mq["queue"]["error"]}
+            if not a.frames and not a.no_sweep:
+                qk["sweep_us"] = {str(k): (qk["us_per_step"] if k == n_frames else
+                                           round(measure_queue(RotationView(single, k), a.steps, 0, target_s=0.08, min_replays=12, events=False)["step_s"] * 1e6, 4))
+                                  for k in RESIDENCY_SWEEP if k <= n_frames}
+            result["queue_opt_in"] = qk
+        for big in (64,):  # larger ticks on the same rotation (needs a multiple of the tick: 128 frames)
+            try:
+                wlb = Workload(dev, 128, n, rank, world, True, per_launch=big)
+                mb = measure_ticks(wlb, 256, 0, target_s=0.1, min_replays=12)
+                result["tick%d_us_per_step" % big] = round(mb["step_s"] * 1e6, 4)
+                del wlb
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                result["tick%d_error" % big] = repr(ex)[:120]
+    elif use_queue:
+        result["timing"]["single_launch_latency"] = single_launch_latency(wl)
         mg = measure(wl, a.steps, a.warmup)
         result["one_launch_per_step"] = {"us_per_step": round(mg["step_s"] * 1e6, 4), "Mpix_per_s": round(px_per_step / mg["step_s"] / 1e6, 1),
                                          "frac": round(alg / mg["step_s"] / 1e9 / HBM_PEAK_GBS, 4), "kernel": wl.kernel,
                                          "submission": "hipGraph replay, one cvgs_execute launch per step"}
-    if not a.no_cpu and M == 1:
-        result["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
-    if use_queue and not a.no_regimes:
-        # the queue beside its headline regime: stream-ordered submission with a producer on the stream (the reference's call shape),
-        # batch latency by queue depth, and coexistence with a consumer on the same GPU (tools/bench_queue_regimes.py)
+    if not a.no_cpu and (M == 1 or M == TICK):
+        result["cpu_baseline"] = cpu_baseline(single if single is not None else wl, a.cpu_seconds)
+    if (use_queue or (use_ticks and M == TICK)) and not a.no_regimes and not a.eager:
+        # the regimes beside the headline: stream-ordered submission EAGER with a producer on the stream (the reference's call shape; ticks as one
+        # launch, the queue's gates), batch latency by queue depth, and coexistence with a consumer on the same GPU (tools/bench_queue_regimes.py)
         # In a FRESH process: what these legs measure is paced by the runtime's stream scheduling, and inside this process -- after the
-        # headline's queue, its captured graphs and the CPU leg's thread pool -- the same code read 55 us per batch for the lone strict
+        # headline's captured graphs and the CPU leg's thread pool -- the same code read 55 us per batch for the lone strict
         # stream (14 in a fresh process, 14 in tools/probes) and 5.1 instead of 2.3 for the deferred ticks: history, not the engine.
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
@@ -612,6 +709,9 @@ def main():
             result["stream_ordered"], result["queue_latency_by_depth"], result["coexistence"] = QR.stream_ordered_compact(so), QR.latency_compact(lt), QR.coexistence_compact(co)
         except Exception as ex:  # never at the cost of the headline
             result["regimes_error"] = repr(ex)[:300]
+    if single is not None:
+        del single
+        torch.cuda.empty_cache()
     if not a.no_extra:
         result["extra"] = extra_sweeps(dev, a)
     cfgs = configs_block(result.get("extra", {}))
@@ -652,7 +752,7 @@ def compact_line(result):
     line["roofline"] = _pick(result.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us",
                                                           "algorithmic_bytes_per_launch", "sector_bound_bytes_per_launch",
                                                           "frac_of_sector_bound", "copy_ceiling", "per_gpu_frac", "per_gpu_frac_on_the_queue",
-                                                          "residency", "sweep_us", "traffic_src"))
+                                                          "steps_per_launch", "residency", "sweep_us", "traffic_src"))
     if isinstance(line["roofline"].get("traffic_src"), str):
         line["roofline"]["traffic_src"] = "profiles/pmc_headline.json (committed PMC passes, not this run)"
     if "cpu_baseline" in result:
@@ -668,7 +768,7 @@ def compact_line(result):
     if "batch_latency_server_alive" in t or "single_launch_latency" in t:
         optional.append(("latency_us", {"queue_batch": t.get("batch_latency_server_alive", {}).get("median_us"),
                                         "one_launch": t.get("single_launch_latency", {}).get("median_us")}))
-    for k in ("configs", "stream_ordered", "coexistence", "n1_same_workload", "rccl_ranks_seen", "gpus_seen", "legs", "xgmi_probe", "queue_latency_by_depth", "regimes_error"):
+    for k in ("ticks_ok", "tick64_us_per_step", "queue_opt_in", "configs", "stream_ordered", "coexistence", "n1_same_workload", "rccl_ranks_seen", "gpus_seen", "legs", "xgmi_probe", "queue_latency_by_depth", "regimes_error"):
         if k in result:
             optional.append((k, result[k]))
     if "queue" in result:
@@ -818,10 +918,11 @@ def pmc_traffic(crops, table, per_launch=1, queue=False):
     WRITE_SIZE, separate --pmc runs, corrected as calibrated in profiles/).  Counters cannot be read from inside this process, so
     the value is the one measured for exactly this workload/kernel; null for any other configuration."""
     path = os.path.join(ROOT, "profiles", "pmc_headline.json")
-    if crops != CROPS or table or per_launch != 1 or not os.path.exists(path):
+    key = "queue" if queue else ("launch" if per_launch == 1 else "ticks%d" % per_launch)
+    if crops != CROPS or (table and per_launch == 1) or not os.path.exists(path):
         return None
     try:
-        j = json.load(open(path))["queue" if queue else "launch"]
+        j = json.load(open(path))[key]
         return int(j["fetch_size_kb"] * 1024 * j["fetch_correction"] + j["write_size_kb"] * 1024)
     except Exception:
         return None

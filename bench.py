@@ -89,6 +89,7 @@ def parse():
     p.add_argument("--no-regimes", action="store_true", help="skip the stream-ordered / latency / coexistence legs")
     p.add_argument("--no-sweep", action="store_true", help="skip the residency sweep of the headline step (rotations of 32 / 48 / 96 frames; the queue: 20 / 48 / 96)")
     p.add_argument("--no-queue-leg", action="store_true", help="ticks: skip the descriptor-queue leg (queue_opt_in)")
+    p.add_argument("--headline-only", action="store_true", help="ticks: nothing but the headline's launches (kernel traces: the fused launch's average is then the headline's)")
     p.add_argument("--soak", type=float, default=0.0, help="coexistence: seconds of soak with the consumer running throughout (0 = none)")
     p.add_argument("--print-extra", action="store_true", help="also print the full record (bench_extra.json's content) on stderr")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -650,7 +651,7 @@ def main():
                 sweep[str(k)] = round(measure_ticks(RotationView(wl, k), a.steps, 0, target_s=0.08, min_replays=12)["step_s"] * 1e6, 4)
         result["roofline"]["sweep_us"] = sweep
     single = None
-    if use_ticks and M == TICK and not a.eager:
+    if use_ticks and M == TICK and not a.eager and not a.headline_only:
         # the same frames and crop lists, one chain per launch / per queue submit (their own tensors): the other two regimes, and the check
         single = Workload(dev, n_frames, n, rank, world, False, share=wl)
         result["ticks_ok"] = ticks_match_single_launches(wl, single)

@@ -95,6 +95,25 @@ def run(a):
     t1 = time.perf_counter()
     side.synchronize()
     out["host_us_per_call_1_crop_chains"] = round((t1 - t0) / 512 * 1e6, 3)
+    # ... and on M x 50-crop chains with an 8 x 8 target (the full lowering / table work of the headline's call, a kernel of a few microseconds)
+    small, keep = [], []
+    for f in range(M * 4):
+        crops = W.random_crops(50, W.FRAME_4K[0], W.FRAME_4K[1], seed=W.SEED + 77 + f)
+        o = torch.zeros((50, 3 * 8 * 8), dtype=torch.float32, device=dev)
+        keep.append(o)
+        small.append(cvgs.lower(W.k1_chain(cvgs.GpuMat.from_tensor(wlh.frames[f % len(wlh.frames)], cvgs.CV_8UC3), crops, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), dst=(8, 8))))
+    p8 = [cvgs.pack_chains(small[g * M:(g + 1) * M]) for g in range(4)]
+    for i in range(64):
+        capi.check(lib.cvgs_execute_many(p8[i % 4], M, s))
+    side.synchronize()
+    t0 = time.perf_counter()
+    for i in range(512):
+        capi.check(lib.cvgs_execute_many(p8[i % 4], M, s))
+    t1 = time.perf_counter()
+    side.synchronize()
+    t2 = time.perf_counter()
+    out["host_us_per_call_50_crop_chains_8x8_target"] = round((t1 - t0) / 512 * 1e6, 3)
+    out["wall_us_per_call_50_crop_chains_8x8_target"] = round((t2 - t0) / 512 * 1e6, 3)
     print(json.dumps(out), flush=True)
 
 

@@ -14,7 +14,7 @@ cp bench_extra.json $OUT/bench_20_5_extra.json 2> /dev/null
 tail -c 3000 $OUT/bench_20_5.err > $OUT/bench_20_5.err.tail; rm -f $OUT/bench_20_5.err
 python bench.py --no-extra > $OUT/bench_default_no_extra.json 2> /dev/null
 # kernel trace of the headline command (no side legs): the fused K1 launch's average duration must agree with timing.tick_launch.us_per_launch
-timeout -k 5 300 $RP --stats -d $RAW/bench_trace -o t -- python bench.py --no-cpu --no-extra --no-regimes --no-sweep --no-queue-leg > $OUT/bench_trace.json 2> /dev/null
+timeout -k 5 300 $RP --stats -d $RAW/bench_trace -o t -- python bench.py --no-cpu --no-extra --no-regimes --no-sweep --headline-only > $OUT/bench_trace.json 2> /dev/null
 $SUM kernels $RAW/bench_trace/t_kernel_trace.csv > $OUT/bench_trace_kernels.txt 2>&1
 # HBM counters of the same kernel, eager (counters serialise the kernels), separate passes
 for C in FETCH_SIZE WRITE_SIZE; do

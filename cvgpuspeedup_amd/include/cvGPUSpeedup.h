@@ -86,6 +86,8 @@ template <int I, int O> inline auto convertTo(float alpha, float beta) { return 
 
 template <int I> inline auto multiply(const cv::Scalar& s) { return fk::Binary<fk::Mul<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
 template <int I> inline auto subtract(const cv::Scalar& s) { return fk::Binary<fk::Sub<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
+// (the reference README's example spells it `substract`, README.md:127: the snippet users copy compiles)
+template <int I> inline auto substract(const cv::Scalar& s) { return subtract<I>(s); }
 template <int I> inline auto divide(const cv::Scalar& s) { return fk::Binary<fk::Div<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
 template <int I> inline auto add(const cv::Scalar& s) { return fk::Binary<fk::Add<CUDA_T(I)>>{cvScalar2CUDAV<I>::get(s)}; }
 

@@ -23,6 +23,27 @@
 #include "../../../include/cvgs_hip.h"
 #include "../cv2cuda_types.h"
 
+// The reference's sequence selectors are spelled with CUDA function qualifiers (tests/batchread/test_circularbatchread_x_write3D.cu:89-93:
+// `constexpr static __device__ __forceinline__ uint at(...)`; tests/resize/test_fused_resize.cu:22-26: FK_HOST_DEVICE_FUSE).  This facade is
+// host C++: the selector is evaluated on the HOST (fk::executeDivergentBatch), so in a translation unit the HIP compiler's language mode
+// has not defined them the qualifiers mean nothing.
+#if !defined(__HIP__) && !defined(__CUDACC__)
+#ifndef __device__
+#define __device__
+#endif
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __forceinline__
+#define __forceinline__ inline
+#endif
+#endif
+#ifndef FK_HOST_DEVICE_FUSE
+#define FK_HOST_DEVICE_FUSE static constexpr inline
+#define FK_DEVICE_FUSE static constexpr inline
+#define FK_HOST_FUSE static inline
+#endif
+
 namespace fk {
 
 // ---- small vocabulary types ---------------------------------------------------------------------------
@@ -98,9 +119,22 @@ struct Dims2D { uint width = 0, height = 0, pitch = 0; };
 struct Dims3D { uint width = 0, height = 0, planes = 0, color_planes = 1, pitch = 0, plane_pitch = 0; };
 
 template <ND D, typename T> struct RawPtr;
+template <ND D, typename T> class TensorBase;
 template <typename T> struct RawPtr<_2D, T> { T* data = nullptr; Dims2D dims; using type = T; };
-template <typename T> struct RawPtr<_3D, T> { T* data = nullptr; Dims3D dims; using type = T; };
-template <typename T> struct RawPtr<T3D, T> { T* data = nullptr; Dims3D dims; using type = T; };
+// (3D: also constructible from the owning tensor, so that the reference's `Write<PerThreadWrite<_3D, T>> w{ {tensor} }` compiles:
+//  tests/batchread/test_circularbatchread_x_write3D.cu:64)
+template <typename T> struct RawPtr<_3D, T> {
+    T* data = nullptr; Dims3D dims; using type = T;
+    RawPtr() = default;
+    RawPtr(T* d, const Dims3D& dm) : data(d), dims(dm) {}
+    RawPtr(const TensorBase<_3D, T>& t);
+};
+template <typename T> struct RawPtr<T3D, T> {
+    T* data = nullptr; Dims3D dims; using type = T;
+    RawPtr() = default;
+    RawPtr(T* d, const Dims3D& dm) : data(d), dims(dm) {}
+    RawPtr(const TensorBase<T3D, T>& t);
+};
 
 inline void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -151,6 +185,8 @@ protected:
 };
 template <typename T> using Tensor = TensorBase<_3D, T>;
 template <typename T> using TensorT = TensorBase<T3D, T>;
+template <typename T> inline RawPtr<_3D, T>::RawPtr(const TensorBase<_3D, T>& t) : data(t.ptr().data), dims(t.ptr().dims) {}
+template <typename T> inline RawPtr<T3D, T>::RawPtr(const TensorBase<T3D, T>& t) : data(t.ptr().data), dims(t.ptr().dims) {}
 
 // ---- small-buffer array for the builders --------------------------------------------------------------------------
 // The chain builders hold plane tables / matrices / op lists of at most a few dozen entries; a std::vector there costs
@@ -626,6 +662,35 @@ template <typename T> struct BatchPixelRead {
     }
 };
 
+// ---- fk::CircularBatchRead (reference tests/batchread/test_circularbatchread_x_write3D.cu:59-66, 72-83) -----------------------------
+//     fk::Read<fk::CircularBatchRead<fk::Ascendent, fk::PerThreadRead<fk::_2D, uchar3>, BATCH>> r;
+//     r.params.first = FIRST;  r.params.opData[i].params = input[i];
+// Plane z of the read is input plane (z + first) mod BATCH (Ascendent; the reference's check: out[z] == in[z + FIRST wrapped]) or
+// (first - z) mod BATCH (Descendent, [FKL-mem]: the direction CircularTensor's NewestFirst order reads its ring in).  The rotation
+// happens where the descriptor is built: the kernel reads an ordinary batch of planes.
+enum CircularDirection { Ascendent = 0, Descendent = 1 };
+template <CircularDirection DIR, typename ReadOp, int BATCH> struct CircularBatchRead;
+template <CircularDirection DIR, typename T, int BATCH> struct CircularBatchRead<DIR, PerThreadRead<_2D, T>, BATCH> {
+    static_assert(BATCH >= 1, "CircularBatchRead needs at least one plane");
+    struct OpData { RawPtr<_2D, T> params; };
+    struct ParamsType {
+        uint first = 0;
+        OpData opData[BATCH];
+    };
+    using OutputType = T;
+    static void lower(const ParamsType& p, ChainBuilder& b) {
+        cvgs_read_desc& r = b.d.read;
+        r.kind = CVGS_READ_PIXEL; r.src_type = cvGS::cv_type_of<T>;
+        r.batch = BATCH; r.used_planes = BATCH;
+        b.src.clear();
+        const uint first = p.first % (uint)BATCH;
+        for (uint z = 0; z < (uint)BATCH; ++z) {
+            const uint from = DIR == Ascendent ? (z + first) % (uint)BATCH : (first + (uint)BATCH - z) % (uint)BATCH;
+            b.src.push_back(image2d(p.opData[from].params));
+        }
+    }
+};
+
 // ---- Warping (cvGS::warp) ------------------------------------------------------------------------------------
 enum class WarpType { Affine = 0, Perspective = 1 };
 // the INVERSE (destination -> source) transform narrowed to float, plus the target size (reference
@@ -700,7 +765,18 @@ template <InterpolationType IT, AspectRatio AR = IGNORE_AR> struct Resize {
 
 // ---- execution ------------------------------------------------------------------------------------------------
 namespace detail {
-template <typename A, typename B> constexpr bool chains = std::is_same_v<typename A::OutputType, typename B::InputType>;
+// The reference README's own example (README.md:123-130) spells `cvGS::convertTo<CV_8UC3, CV_32FC3>()` directly behind the batched
+// resize, whose output is ALREADY float3 (include/cvGPUSpeedup.cuh:227) -- the snippet users copy.  That one spelling is accepted: a
+// SaturateCast<T, floatN> directly behind a resize read of T sources is the identity and is not lowered at all (the chain keeps its
+// compile-time program and its kernel).  Every other type mismatch is still a compile-time error.
+template <typename R> struct resize_source { using type = void; };
+template <typename T> struct resize_source<ResizeRead<T>> { using type = T; };
+template <typename T> struct resize_source<BatchResizeRead<T>> { using type = T; };
+template <typename A, typename B> struct redundant_cast : std::false_type {};
+template <typename A, typename I, typename O> struct redundant_cast<A, Unary<SaturateCast<I, O>>>
+    : std::bool_constant<!std::is_void_v<typename resize_source<A>::type> && std::is_same_v<typename resize_source<A>::type, I> &&
+                         std::is_same_v<typename A::OutputType, O>> {};
+template <typename A, typename B> constexpr bool chains = std::is_same_v<typename A::OutputType, typename B::InputType> || redundant_cast<A, B>::value;
 
 template <typename Tuple, size_t... I> constexpr bool types_chain(std::index_sequence<I...>) {
     return (chains<std::tuple_element_t<I, Tuple>, std::tuple_element_t<I + 1, Tuple>> && ...);
@@ -724,7 +800,10 @@ template <typename... IOps> inline void lowerChain(ChainBuilder& b, const IOps&.
                   "only Unary/Binary operations may sit between the read and the write");
     static_assert(detail::types_chain<Tuple>(std::make_index_sequence<N - 1>{}),
                   "the output type of each operation must be the input type of the next one");
-    (iops.lower(b), ...);
+    using First = std::tuple_element_t<0, Tuple>;
+    const auto lower_one = [&b](const auto& iop, bool skip) { if (!skip) iop.lower(b); };
+    size_t k = 0;
+    (lower_one(iops, k++ == 1 && detail::redundant_cast<First, std::decay_t<decltype(iops)>>::value), ...);
     b.finish();
 }
 
@@ -929,6 +1008,89 @@ private:
     std::vector<std::unique_ptr<ChainBuilder>> builders_;
     std::vector<cvgs_chain_desc> descs_;
 };
+
+// ---- fk::buildOperationSequence + the divergent-batch launch (reference tests/batchread/test_circularbatchread_x_write3D.cu:147-156,
+// tests/resize/test_fused_resize.cu:73-92) --------------------------------------------------------------------------------------------
+// The reference runs DIFFERENT operation sequences on the planes of one launch: grid z = plane, plane z executes sequence
+// SequenceSelector::at(z) (1-based) with z as its thread's z index,
+//     fk::launchDivergentBatchTransformDPP_Kernel<fk::ParArch::GPU_NVIDIA, Selector><<<grid(.., .., BATCH), block, 0, stream>>>(seq1, seq2);
+// A raw kernel launch has no host-C++ spelling; its counterpart here is
+//     fk::executeDivergentBatch<Selector>(stream, BATCH, seq1, seq2);
+// Each plane's sequence is lowered to its own chain with "z as the thread's z index" resolved on the host -- a batched read keeps its
+// plane z, a tensor write starts at its plane z, 2D reads / writes ignore z -- and all planes go to ONE cvgs_execute_many call: chains of
+// one hot shape (crops -> resize -> ... -> tensor) are ONE launch with grid z = plane, anything else is launched plane by plane in z
+// order on the stream (same results: the planes are independent by construction).
+template <typename... IOps> struct OperationSequence {
+    std::tuple<IOps...> iops;
+};
+template <typename... IOps> inline OperationSequence<IOps...> buildOperationSequence(const IOps&... iops) {
+    using Tuple = std::tuple<IOps...>;
+    constexpr size_t N = sizeof...(IOps);
+    static_assert(N >= 2, "an operation sequence needs at least a read and a write operation");
+    static_assert(std::tuple_element_t<0, Tuple>::stage == Stage::Read, "the first operation must be a Read/ReadBack");
+    static_assert(std::tuple_element_t<N - 1, Tuple>::stage == Stage::Write, "the last operation must be a Write");
+    return OperationSequence<IOps...>{Tuple(iops...)};
+}
+enum class ParArch { GPU_NVIDIA = 0, GPU_AMD = 1 };
+namespace detail {
+// "z is the thread's z index" for one lowered chain
+inline void select_plane(ChainBuilder& b, uint z) {
+    cvgs_read_desc& r = b.d.read;
+    if (r.kind == CVGS_READ_WARP_AFFINE || r.kind == CVGS_READ_WARP_PERSPECTIVE || (r.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE))
+        throw std::runtime_error("cvGS: executeDivergentBatch takes pixel / resize / 4:2:0 reads with host descriptors");
+    if (r.batch > 1) { // a batched read: plane z of it
+        if (z >= (uint)r.batch) throw std::runtime_error("cvGS: executeDivergentBatch: plane index beyond the sequence's batched read");
+        if (z != 0) b.src[0] = b.src[z];
+        b.src.resize(1);
+        r.used_planes = (int)z < r.used_planes ? 1 : 0;
+        r.batch = 1;
+    }
+    cvgs_write_desc& w = b.d.write;
+    static const size_t kDepthBytes[8] = {1, 1, 2, 2, 4, 4, 8, 2}; // CV_8U .. CV_64F, CV_16F
+    const size_t base = kDepthBytes[CVGS_TYPE_DEPTH(w.dst_type) & 7]; // bytes of one channel element
+    const size_t plane = (size_t)w.width * (size_t)w.height;
+    switch (w.kind) {
+    case CVGS_WRITE_PIXEL_3D: w.data = (uint8_t*)w.data + (size_t)z * plane * base * (size_t)CVGS_TYPE_CN(w.dst_type); break;
+    case CVGS_WRITE_TENSOR_SPLIT: w.data = (uint8_t*)w.data + (size_t)z * plane * base * (size_t)CVGS_TYPE_CN(w.dst_type); break;
+    case CVGS_WRITE_TENSOR_T_SPLIT: w.data = (uint8_t*)w.data + (size_t)z * plane * base; break; // (the channel stride stays the tensor's N)
+    case CVGS_WRITE_PIXEL_2D: break; // a 2D write ignores z
+    default: throw std::runtime_error("cvGS: executeDivergentBatch takes tensor / image writes");
+    }
+    if ((w.kind == CVGS_WRITE_PIXEL_3D || w.kind == CVGS_WRITE_TENSOR_SPLIT || w.kind == CVGS_WRITE_TENSOR_T_SPLIT) && z >= (uint)w.planes)
+        throw std::runtime_error("cvGS: executeDivergentBatch: plane index beyond the tensor");
+}
+template <typename Seq, size_t... I> inline void lower_sequence(ChainBuilder& b, const Seq& seq, std::index_sequence<I...>) {
+    lowerChain(b, std::get<I>(seq.iops)...);
+}
+template <size_t K, typename... Seqs> inline void lower_selected(ChainBuilder& b, uint which, const std::tuple<const Seqs&...>& seqs) {
+    if constexpr (K < sizeof...(Seqs)) {
+        if (which == K + 1) {
+            const auto& seq = std::get<K>(seqs);
+            lower_sequence(b, seq, std::make_index_sequence<std::tuple_size_v<decltype(seq.iops)>>{});
+        } else lower_selected<K + 1>(b, which, seqs);
+    }
+}
+} // namespace detail
+template <typename SequenceSelector, typename... Seqs>
+inline void executeDivergentBatch(hipStream_t stream, uint batch, const Seqs&... seqs) {
+    static_assert(sizeof...(Seqs) >= 1, "executeDivergentBatch needs at least one operation sequence");
+    if (batch > (uint)CVGS_MAX_CHAINS) throw std::runtime_error("cvGS: more than CVGS_MAX_CHAINS planes in one divergent batch");
+    std::vector<std::unique_ptr<ChainBuilder>> builders;
+    std::vector<cvgs_chain_desc> descs;
+    const std::tuple<const Seqs&...> all(seqs...);
+    for (uint z = 0; z < batch; ++z) {
+        const uint which = (uint)SequenceSelector::at(z); // 1-based; 0 or beyond the list: the plane runs nothing (the reference's divergent_operate falls through)
+        if (which < 1 || which > sizeof...(Seqs)) continue;
+        builders.emplace_back(new ChainBuilder);
+        detail::lower_selected<0>(*builders.back(), which, all);
+        detail::select_plane(*builders.back(), z);
+        builders.back()->finish();
+        descs.push_back(builders.back()->d); // POD copy; the builder keeps the arrays alive
+    }
+    if (descs.empty()) return;
+    if (detail::stream_attachments().any.load(std::memory_order_acquire)) detail::flush_attached(stream); // recorded calls of this stream go first
+    detail::check_status(cvgs_execute_many(descs.data(), (int32_t)descs.size(), stream));
+}
 
 // ---- device-side descriptor queue (engine extension: cvgs_queue_*) ---------------------------------------------------
 // executeOperations' call shape -- one call per frame, the same IOps -- without a kernel launch per call: a resident server

@@ -33,11 +33,13 @@ int main() {
     std::vector<float> us;
     for (int it = -1; it < ITERS; ++it) { // it == -1: warm-up
         (void)hipEventRecord(e0, stream.raw());
-        // single kernel (resize already yields CV_32FC3, so the README's convertTo<CV_8UC3,CV_32FC3>() is dropped)
+        // single kernel -- the README's call verbatim (README.md:123-130), its convertTo<CV_8UC3, CV_32FC3>() behind the resize and its
+        // `substract` included: the resize already yields CV_32FC3, the facade drops that one redundant cast at compile time
         cvGS::executeOperations(stream,
                                 cvGS::resize<CV_8UC3, cv::INTER_LINEAR, MAX_DETECTIONS>(crops, resDims, activeDetections),
+                                cvGS::convertTo<CV_8UC3, CV_32FC3>(),
                                 cvGS::multiply<CV_32FC3>(cv::Scalar(alpha, alpha, alpha)),
-                                cvGS::subtract<CV_32FC3>(subtract_val),
+                                cvGS::substract<CV_32FC3>(subtract_val),
                                 cvGS::divide<CV_32FC3>(divide_val),
                                 cvGS::split<CV_32FC3>(output, resDims));
         (void)hipEventRecord(e1, stream.raw());

@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
-PROGRAMS = ["test_batchresize", "test_resize", "test_pointwise", "test_circulartensor", "test_warping"]
+PROGRAMS = ["test_batchresize", "test_resize", "test_pointwise", "test_circulartensor", "test_warping", "test_divergent"]
 
 
 def _build():
@@ -217,3 +217,78 @@ def test_the_boundary_from_plain_c():
     subprocess.run(["make", "-C", CPP, "bin/c_abi_k1"], check=True, stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(CPP, "bin", "c_abi_k1")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "bit-identical" in r.stdout and "k1_u8c3_swap_mul_sub_div" in r.stdout, r.stdout + r.stderr
+
+
+def test_readme_spelling_and_the_new_fk_slice_lower_as_specified(tmp_path):
+    """Host-only lowering checks (no GPU): (1) the reference README's call verbatim -- convertTo<CV_8UC3, CV_32FC3>() behind the batched
+    resize, `substract` -- lowers to the SAME descriptor as the chain without the redundant cast (README.md:123-130);
+    (2) fk::CircularBatchRead<Ascendent / Descendent> rotates its planes where the descriptor is built
+    (tests/batchread/test_circularbatchread_x_write3D.cu:59-66); (3) fk::executeDivergentBatch's plane selection: a tensor write of plane z
+    starts z planes in, a batched read keeps its plane z."""
+    _build()
+    inc = os.path.join(ROOT, "cvgpuspeedup_amd", "include")
+    src = tmp_path / "lowering.cpp"
+    src.write_text(r'''
+#include <cvGPUSpeedup.cuh>
+#include <cstdio>
+#include <cstring>
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+int main() {
+    constexpr int N = 50;
+    static unsigned char frame[480 * 640 * 3];
+    static float out[N * 64 * 128 * 3];
+    cv::cuda::GpuMat f(480, 640, CV_8UC3, frame, 640 * 3), o(N, 64 * 128 * 3, CV_32FC1, out, 64 * 128 * 3 * 4);
+    std::array<cv::cuda::GpuMat, N> crops;
+    for (int i = 0; i < N; ++i) crops[i] = f(cv::Rect(i, i, 60, 120));
+    const cv::Size resDims(64, 128);
+    const cv::Scalar substract_val(1, 4, 6), divide_val(255, 255, 255);
+    const double alpha = 0.5;
+    fk::ChainBuilder a, b;
+    fk::lowerChain(a, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, N>(crops, resDims, 50), cvGS::convertTo<CV_8UC3, CV_32FC3>(),
+                   cvGS::multiply<CV_32FC3>(cv::Scalar(alpha, alpha, alpha)), cvGS::substract<CV_32FC3>(substract_val), cvGS::divide<CV_32FC3>(divide_val),
+                   cvGS::split<CV_32FC3>(o, resDims));
+    fk::lowerChain(b, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, N>(crops, resDims, 50),
+                   cvGS::multiply<CV_32FC3>(cv::Scalar(alpha, alpha, alpha)), cvGS::subtract<CV_32FC3>(substract_val), cvGS::divide<CV_32FC3>(divide_val),
+                   cvGS::split<CV_32FC3>(o, resDims));
+    CHECK(a.d.n_ops == 3 && b.d.n_ops == 3);
+    CHECK(std::memcmp(a.d.ops, b.d.ops, sizeof(a.d.ops)) == 0);
+    CHECK(a.d.read.batch == N && a.d.read.kind == CVGS_READ_RESIZE_LINEAR && a.d.write.kind == CVGS_WRITE_TENSOR_SPLIT);
+    CHECK(cvgs_validate(&a.d) == CVGS_OK);
+    // ---- CircularBatchRead ----
+    constexpr int B = 5;
+    static uchar3 planes[B][4 * 4];
+    fk::Read<fk::CircularBatchRead<fk::Ascendent, fk::PerThreadRead<fk::_2D, uchar3>, B>> asc;
+    fk::Read<fk::CircularBatchRead<fk::Descendent, fk::PerThreadRead<fk::_2D, uchar3>, B>> desc;
+    asc.params.first = desc.params.first = 2;
+    for (int i = 0; i < B; ++i) asc.params.opData[i].params = desc.params.opData[i].params = fk::RawPtr<fk::_2D, uchar3>{planes[i], {4, 4, 12}};
+    static uchar3 tensor[B * 16];
+    fk::Write<fk::PerThreadWrite<fk::_3D, uchar3>> w{fk::RawPtr<fk::_3D, uchar3>{tensor, {4, 4, B, 1, 12, 48}}};
+    fk::ChainBuilder ca, cd;
+    fk::lowerChain(ca, asc, w);
+    fk::lowerChain(cd, desc, w);
+    const cvgs_image2d* sa = (const cvgs_image2d*)ca.d.read.src;
+    const cvgs_image2d* sd = (const cvgs_image2d*)cd.d.read.src;
+    for (int z = 0; z < B; ++z) {
+        CHECK(sa[z].data == planes[(z + 2) % B]);
+        CHECK(sd[z].data == planes[(2 + B - z) % B]);
+    }
+    CHECK(ca.d.read.batch == B && cvgs_validate(&ca.d) == CVGS_OK && cvgs_validate(&cd.d) == CVGS_OK);
+    // ---- plane selection of the divergent batch ----
+    fk::ChainBuilder p3;
+    fk::lowerChain(p3, asc, w);
+    fk::detail::select_plane(p3, 3);
+    p3.finish();
+    CHECK(p3.d.read.batch == 1 && ((const cvgs_image2d*)p3.d.read.src)[0].data == planes[(3 + 2) % B]);
+    CHECK((unsigned char*)p3.d.write.data == (unsigned char*)tensor + 3 * 16 * 3);
+    CHECK(cvgs_validate(&p3.d) == CVGS_OK);
+    std::printf("ok\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "lowering"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "c++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-command-line-argument", "-Wno-unused-variable",
+                    "-I" + inc, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", str(src), "-o", str(exe),
+                    "-L" + os.path.join(ROOT, "cvgpuspeedup_amd", "lib"), "-lcvgs_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + os.path.join(ROOT, "cvgpuspeedup_amd", "lib")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

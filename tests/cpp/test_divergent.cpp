@@ -5,7 +5,7 @@
 //                                                                 plane 0 = input[0] + 3, plane 1 = input[1]
 //   * tests/resize/test_fused_resize.cu:73-92                      the tensor variant of the fused NV12 resize: one sequence for every plane
 //                                                                 (PerPlaneSequenceSelector::at == 1), written into a Tensor<uchar4>
-// plus what the reference does not test: Descendent order, a sequence per camera of the K1 shape (ONE fused launch), and the oracle as checker.
+// plus what the reference does not test: Descendent order, K1-shaped planes through one / two sequences (one sequence: ONE fused launch), a selector that skips planes, and the oracle as checker.
 // The raw kernel launch `launchDivergentBatchTransformDPP_Kernel<PA, Selector><<<grid(.., .., BATCH), block, 0, stream>>>(seqs...)` is spelled
 // fk::executeDivergentBatch<Selector>(stream, BATCH, seqs...) here.
 #include "common.h"
@@ -120,37 +120,43 @@ static void testFusedResizeIntoTensor(hipStream_t stream) {
     CHECK(same, "fused NV12 resize as ONE operation sequence over a " << OUTPUTS << "-plane Tensor<uchar4>: every plane bit-exact vs the oracle");
 }
 
-// one sequence PER CAMERA of the K1 shape (crops of a frame -> resize -> normalize -> its own tensor): the planes share a hot shape, so the
-// divergent batch is ONE fused launch (grid z = plane); checked against one executeOperations per camera
-static void testOneSequencePerCamera(cv::cuda::Stream& cv_stream) {
-    constexpr int CAMS = 3, CROPS = 5;
+struct EvenOdd { // even planes run sequence 1, odd planes sequence 2
+    FK_HOST_DEVICE_FUSE uint at(const uint& z) { return 1 + z % 2; }
+};
+
+// K1-shaped planes: the crops of a frame -> resize -> normalize -> the planes of ONE tensor.  With one sequence for every plane the
+// divergent batch is the batched chain itself (every plane = one crop: ONE fused launch, grid z = plane); with two sequences (different
+// multipliers) even planes must carry sequence 1's values and odd planes sequence 2's.  Checked against cvGS::executeOperations.
+static void testK1PlanesThroughSequences(cv::cuda::Stream& cv_stream) {
+    constexpr int CROPS = 6;
     const cv::Size up(64, 128);
-    std::vector<cv::cuda::GpuMat> frames, tensors, refs;
-    using Seq = decltype(fk::buildOperationSequence(cvGS::resize<CV_8UC3, cv::INTER_LINEAR, CROPS>(std::array<cv::cuda::GpuMat, CROPS>{}, up, CROPS),
-                                                    cvGS::multiply<CV_32FC3>(cv::Scalar()), cvGS::split<CV_32FC3>(cv::cuda::GpuMat(), up)));
-    std::vector<Seq> seqs;
-    for (int k = 0; k < CAMS; ++k) {
-        cv::Mat h(480, 640, CV_8UC3);
-        fill_random(h, 100 + k);
-        frames.emplace_back(h);
-        tensors.emplace_back(CROPS, up.width * up.height * 3, CV_32FC1);
-        refs.emplace_back(CROPS, up.width * up.height * 3, CV_32FC1);
-        std::array<cv::cuda::GpuMat, CROPS> crops;
-        for (int i = 0; i < CROPS; ++i) crops[i] = frames[k](cv::Rect(10 * i + k, 7 * i, 60 + 20 * i, 120 + 10 * k));
-        const cv::Scalar a(0.5, 0.25, 2.0);
-        seqs.push_back(fk::buildOperationSequence(cvGS::resize<CV_8UC3, cv::INTER_LINEAR, CROPS>(crops, up, CROPS), cvGS::multiply<CV_32FC3>(a),
-                                                  cvGS::split<CV_32FC3>(tensors[k], up)));
-        cvGS::executeOperations(cv_stream, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, CROPS>(crops, up, CROPS), cvGS::multiply<CV_32FC3>(a),
-                                cvGS::split<CV_32FC3>(refs[k], up));
-    }
-    fk::executeDivergentBatch<OneToOne>(cv_stream.raw(), CAMS, seqs[0], seqs[1], seqs[2]);
+    cv::Mat h(480, 640, CV_8UC3);
+    fill_random(h, 4711);
+    cv::cuda::GpuMat frame(h);
+    std::array<cv::cuda::GpuMat, CROPS> crops;
+    for (int i = 0; i < CROPS; ++i) crops[i] = frame(cv::Rect(10 * i + 3, 7 * i, 60 + 20 * i, 120 + 10 * i));
+    const size_t plane_bytes = (size_t)up.width * up.height * 3 * 4, bytes = CROPS * plane_bytes;
+    cv::cuda::GpuMat tensor(CROPS, up.width * up.height * 3, CV_32FC1), refA(CROPS, up.width * up.height * 3, CV_32FC1), refB(CROPS, up.width * up.height * 3, CV_32FC1);
+    const cv::Scalar a(0.5, 0.25, 2.0), b(3.0, 1.5, 0.125), sub(1, 4, 3.2), div(3.2, 0.6, 11.8);
+    auto chain = [&](const cv::Scalar& mul, cv::cuda::GpuMat& out) {
+        return fk::buildOperationSequence(cvGS::resize<CV_8UC3, cv::INTER_LINEAR, CROPS>(crops, up, CROPS), cvGS::multiply<CV_32FC3>(mul),
+                                          cvGS::subtract<CV_32FC3>(sub), cvGS::divide<CV_32FC3>(div), cvGS::split<CV_32FC3>(out, up));
+    };
+    cvGS::executeOperations(cv_stream, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, CROPS>(crops, up, CROPS), cvGS::multiply<CV_32FC3>(a),
+                            cvGS::subtract<CV_32FC3>(sub), cvGS::divide<CV_32FC3>(div), cvGS::split<CV_32FC3>(refA, up));
+    cvGS::executeOperations(cv_stream, cvGS::resize<CV_8UC3, cv::INTER_LINEAR, CROPS>(crops, up, CROPS), cvGS::multiply<CV_32FC3>(b),
+                            cvGS::subtract<CV_32FC3>(sub), cvGS::divide<CV_32FC3>(div), cvGS::split<CV_32FC3>(refB, up));
+    const auto seqA = chain(a, tensor), seqB = chain(b, tensor);
+    fk::executeDivergentBatch<PerPlaneSequenceSelector>(cv_stream.raw(), CROPS, seqA);
     cv_stream.waitForCompletion();
+    CHECK(fetch(tensor.data, bytes) == fetch(refA.data, bytes), "one K1 sequence for every plane == the batched chain, bit for bit");
+    tensor.setTo(cv::Scalar(-1));
+    fk::executeDivergentBatch<EvenOdd>(cv_stream.raw(), CROPS, seqA, seqB);
+    cv_stream.waitForCompletion();
+    const auto t = fetch(tensor.data, bytes), ra = fetch(refA.data, bytes), rb = fetch(refB.data, bytes);
     bool same = true;
-    for (int k = 0; k < CAMS; ++k) {
-        const size_t bytes = (size_t)CROPS * up.width * up.height * 3 * 4;
-        same = same && fetch(tensors[k].data, bytes) == fetch(refs[k].data, bytes);
-    }
-    CHECK(same, "one K1 sequence per camera in a divergent batch == one executeOperations per camera, bit for bit");
+    for (int z = 0; z < CROPS; ++z) same = same && bit_equal(t.data() + z * plane_bytes, (z % 2 ? rb : ra).data() + z * plane_bytes, plane_bytes);
+    CHECK(same, "two K1 sequences: even planes carry sequence 1's values, odd planes sequence 2's");
 }
 
 int main() {
@@ -163,7 +169,7 @@ int main() {
     HIP_OK(hipStreamDestroy(stream));
     {
         cv::cuda::Stream cv_stream;
-        testOneSequencePerCamera(cv_stream);
+        testK1PlanesThroughSequences(cv_stream);
     }
     return report("test_divergent");
 }

@@ -2,8 +2,10 @@
 """Out-of-bounds READ probe: every source image is placed so that its last byte is the last byte of a hipMalloc'ed
 region whose size is a multiple of 2 MiB (so that, unless the driver happens to map another allocation right behind it,
 the next page is not mapped), then the fast kernels run on crops that touch the
-last row / column.  A read past the image faults the process; finishing = no over-read.  (A tool, not a test: a fault
-aborts the interpreter.)"""
+last row / column.  A read past the image faults the process; finishing = no over-read.  A fault aborts the interpreter, so
+the GPU suite runs this file in a SUBPROCESS (tests/test_gpu_oob_probe.py: SURVEY.md 5 "GPU-side bounds checking").
+Covered: K1 / the interpreted kernel (every depth and channel count), per-pixel chains, warps, K4 on NV12 / NV21 / I420 / YV12 / P010
+surfaces, the u8 colour conversions, the fused multi-chain launch (cvgs_execute_many) and every kind of the descriptor queue."""
 import ctypes as C
 import os
 import sys
@@ -106,6 +108,52 @@ def main():
             cvgs.executeOperations(s, cvgs.read_nv12(views, (64, 48), capi.YUV_LIMITED, capi.BT2020, False, layout=capi.YUV_P010), cvgs.multiply(f, [0.5] * 3),
                                    cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 48)), flags=flags)
         torch.cuda.synchronize()
+        n_run += 1
+    # the fused multi-chain launch (cvgs_execute_many, grid z = chain) and the descriptor queue's four kinds: K1-shaped chains whose
+    # crops touch the last row / column of a frame that ends with its allocation
+    f3 = cvgs.CV_32FC3
+
+    def k1_ops(src_mat, st, crops, out, cn=3):
+        ft = cvgs.make_type(cvgs.CV_32F, cn)
+        return [cvgs.resize(st, cvgs.INTER_LINEAR, crops, (64, 128), len(crops)), cvgs.cvtColor(cvgs.COLOR_RGB2BGR if cn == 3 else cvgs.COLOR_RGBA2BGRA, ft),
+                cvgs.multiply(ft, [0.3] * cn), cvgs.subtract(ft, [1.0, 4.0, 3.2, 0.5][:cn]), cvgs.divide(ft, [3.2, 0.6, 11.8, 33.0][:cn]),
+                cvgs.split(ft, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 128))]
+
+    for depth, dt, cn in ((cvgs.CV_8U, np.uint8, 3), (cvgs.CV_8U, np.uint8, 4), (cvgs.CV_16U, np.uint16, 3), (cvgs.CV_16S, np.int16, 4)):
+        w, h = 333, 77
+        a = (rng.integers(0, 200, (h, w, cn))).astype(dt)
+        st = cvgs.make_type(depth, cn)
+        m = cvgs.GpuMat(h, w, st, at_end(a), w * cn * a.itemsize)
+        crops = [m, m.roi(w - 3, h - 2, 3, 2), m.roi(0, h - 1, w, 1), m.roi(w - 9, 0, 9, h), m.roi(w - 40, h - 50, 40, 50)]
+        outs = [torch.zeros((len(crops), cn * 64 * 128), dtype=torch.float32, device="cuda") for _ in range(4)]
+        cvgs.executeMany(s, [k1_ops(m, st, crops, o, cn) for o in outs[:3]])
+        torch.cuda.synchronize()
+        q = cvgs.Queue()
+        try:
+            q.wait(q.submit(*k1_ops(m, st, crops, outs[3], cn)))
+        finally:
+            q.destroy()
+        assert torch.equal(outs[0], outs[3]), "queue and fused launch disagree"
+        n_run += 1
+    for layout, dt, st, sb in ((capi.YUV_NV12, np.uint8, cvgs.CV_8UC1, 1), (capi.YUV_NV21, np.uint8, cvgs.CV_8UC1, 1), (capi.YUV_P010, np.uint16, cvgs.CV_16UC1, 2)):
+        w, h = 642, 362
+        a = rng.integers(0, 255 if sb == 1 else 65535, (h + h // 2, w)).astype(dt)
+        luma = cvgs.GpuMat(h, w, st, at_end(a), w * sb)
+        views = [luma.nv12_roi(0, 0, w, h), luma.nv12_roi(w - 4, h - 2, 4, 2), luma.nv12_roi(0, h - 2, w, 2), luma.nv12_roi(w - 8, 0, 8, h)]
+        outs = [torch.zeros((len(views), 3 * 64 * 128), dtype=torch.float32, device="cuda") for _ in range(3)]
+
+        def nv_ops(out):
+            return [cvgs.read_nv12(views, (64, 128), capi.YUV_LIMITED, capi.BT709, False, layout=layout), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f3),
+                    cvgs.multiply(f3, [0.3] * 3), cvgs.subtract(f3, [1.0, 4.0, 3.2]), cvgs.divide(f3, [3.2, 0.6, 11.8]),
+                    cvgs.split(f3, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 128))]
+        cvgs.executeMany(s, [nv_ops(o) for o in outs[:2]])
+        torch.cuda.synchronize()
+        q = cvgs.Queue()
+        try:
+            q.wait(q.submit(*nv_ops(outs[2])))
+        finally:
+            q.destroy()
+        assert torch.equal(outs[0], outs[2]), "queue and fused launch disagree (4:2:0 surfaces)"
         n_run += 1
     print("no read past the end of any source image: %d configurations ran to completion" % n_run)
 

@@ -474,15 +474,6 @@ int lower(const cvgs_chain_desc* ch, bool circular, Lowered& L) {
 // recycled by the event behind the kernel that read it.  Measured (MI355X, eager, host descriptors): 16 x 50 crops through
 // cvgs_execute_many 47.3 -> 43.9 us, one chain of 400 crops 28.0 -> 23.7 us (host enqueue 19.4 -> 14.0 us); 300 back-to-back
 // launches with a different crop list each through recycled slots verified plane by plane against the oracle.
-// CVGS_SCRATCH_LAZY_EVENTS=n (opt-in, default 1 = every launch tracked on its own): see ScratchSlot
-static int scratch_lazy_every() {
-    static const int n = [] {
-        const char* e = getenv("CVGS_SCRATCH_LAZY_EVENTS");
-        const int v = e ? atoi(e) : 1;
-        return v < 1 ? 1 : (v > 64 ? 64 : v);
-    }();
-    return n;
-}
 static bool scratch_zero_copy() {
     static const bool on = [] {
         const char* e = getenv("CVGS_SCRATCH_ZEROCOPY");
@@ -496,23 +487,18 @@ struct ScratchSlot {
     void* host_dev = nullptr; // the device-side address of `host` (zero-copy mode)
     void* dev = nullptr;
     size_t cap = 0;
-    hipEvent_t ev = nullptr;      // recorded behind the kernel that read the slot: the slot is reusable once it completes
-    hipEvent_t copy_ev = nullptr; // recorded behind the host -> device copy on the pool's own copy stream
+    // Completion tracking: the slot is reusable once `ev` has completed.  The launch that reads the slot signals it ITSELF
+    // (hipExtLaunchKernelGGL's stopEvent, K1's planar kernels: cvgs_device.h StopEventSlot) or, at the other launch sites, a hipEventRecord
+    // follows the launch.  Either way the stream pays ~4 us of device time between this kernel and the next (rocprofv3 kernel trace) -- which
+    // is why the hot multi-chain launch does not come through here any more (ManyPool below: a progress word the kernel writes).  No stream
+    // handle is touched after the call that used it (round 4 reclaimed quiet streams' slots with hipStreamQuery, which faults on a destroyed
+    // stream: found by tests/cpp/test_batchresize under ASan).
+    hipEvent_t ev = nullptr;
+    hipEvent_t copy_ev = nullptr; // recorded behind the host -> device copy on the pool's own copy stream (staged mode)
     int device = -1;
     bool leased = false;  // handed to a call that has not committed yet
-    bool pending = false; // committed: reusable once the event that covers it completes
-    // Completion tracking.  Default: the launch that reads the slot signals `ev` itself (hipExtLaunchKernelGGL's stopEvent, K1's planar
-    // kernels: cvgs_device.h StopEventSlot) or, at the other launch sites, a hipEventRecord behind the launch.  Either way the stream pays
-    // ~4 us of device time between this kernel and the next (rocprofv3 kernel trace: 5.8 us from the end of a 16-chain cvgs_execute_many
-    // launch to the next kernel against ~1.5 without an event).  CVGS_SCRATCH_LAZY_EVENTS=n (opt-in) records ONE event per n commits of a
-    // hot stream instead -- on the committing call's own stream, alive by construction; the earlier uncovered slots of that stream share
-    // it -- which takes ticks of 16 frames on one stream from 3.05 to 2.83 us per frame.  It is opt-in because the last n - 1 slots of a
-    // stream that stops calling stay uncovered (a bounded leak per stream), and a DESTROYED stream cannot be asked anything: round 4 first
-    // reclaimed such slots with hipStreamQuery, which faults on a dead handle (found by tests/cpp/test_batchresize under ASan).
-    hipStream_t stream = nullptr; // the stream whose kernel reads the slot
-    int owner = -1;               // the slot whose `ev` covers this one (-1: not covered yet)
-    uint32_t owner_gen = 0;       // ... and which recording of it (a later recording implies the earlier one completed)
-    uint32_t gen = 0;             // recordings of `ev`
+    bool pending = false; // committed: reusable once `ev` completes
+    hipStream_t stream = nullptr; // the stream whose kernel reads the slot (compared, never dereferenced)
     std::chrono::steady_clock::time_point committed;
 };
 
@@ -531,7 +517,7 @@ public:
                     if (!complete(sl)) {
                         if (sl.stream == stream) {
                             ++in_flight;
-                            if (sl.owner >= 0 && (oldest < 0 || sl.committed < slots_[(size_t)oldest].committed)) oldest = (int)i;
+                            if (oldest < 0 || sl.committed < slots_[(size_t)oldest].committed) oldest = (int)i;
                         }
                         continue;
                     }
@@ -546,8 +532,7 @@ public:
             // serving loop (one eager row of bench.py read 87 us for 53 that way).  With kMaxSlotsInFlight tables of this size in flight ON THE
             // CALLER'S STREAM the call waits for the oldest one's kernel (its own event: no stream is touched): the host runs at most that far ahead.
             if (attempt == 0 && in_flight >= kMaxSlotsInFlight && oldest >= 0) {
-                const ScratchSlot& o = slots_[(size_t)slots_[(size_t)oldest].owner];
-                hipEvent_t ev = o.ev;
+                hipEvent_t ev = slots_[(size_t)oldest].ev;
                 lk.unlock();
                 // BOUNDED: the stream may be held by something only THIS host thread will release (a hipStreamWaitValue on a
                 // host-written word, a polling kernel the host feeds, an event this thread records later) -- an unbounded wait here would
@@ -562,7 +547,7 @@ public:
             break;
         }
         // nothing free and large enough: add a slot (slots are never freed -- hipFree would synchronise the device; the
-        // pool is bounded by kMaxSlotsInFlight tables per size class in flight at once, plus what lazy events leave uncovered)
+        // pool is bounded by kMaxSlotsInFlight tables per size class in flight at once)
         ScratchSlot sl;
         size_t cap = 64 << 10;
         while (cap < bytes) cap <<= 1;
@@ -613,30 +598,14 @@ public:
     void commit(int slot, hipStream_t stream, bool signalled_by_launch = false) {
         std::lock_guard<std::mutex> lk(m_);
         ScratchSlot& sl = slots_[(size_t)slot];
-        const int lazy_every = scratch_lazy_every();
         sl.stream = stream;
-        sl.owner = -1;
         sl.pending = true;
         sl.leased = false;
         sl.committed = std::chrono::steady_clock::now();
-        if (signalled_by_launch) { // the kernel's own completion signals sl.ev (hipExtLaunchKernelGGL stopEvent): nothing to record
-            ++sl.gen;
-            sl.owner = slot;
-            sl.owner_gen = sl.gen;
-            return;
-        }
-        int uncovered = 0;
-        for (const ScratchSlot& o : slots_)
-            uncovered += o.pending && o.owner < 0 && o.stream == stream && o.device == sl.device;
-        if (scratch_zero_copy() && uncovered < lazy_every) return;
-        if (hipEventRecord(sl.ev, stream) == hipSuccess) {
-            ++sl.gen;
-            for (ScratchSlot& o : slots_)
-                if (o.pending && o.owner < 0 && o.stream == stream && o.device == sl.device) { o.owner = slot; o.owner_gen = sl.gen; }
-        } else {
+        if (signalled_by_launch) return; // the kernel's own completion signals sl.ev (hipExtLaunchKernelGGL stopEvent): nothing to record
+        if (hipEventRecord(sl.ev, stream) != hipSuccess) {
             (void)hipStreamSynchronize(stream); // cannot track it: make it safe the slow way
-            for (ScratchSlot& o : slots_)
-                if (o.pending && o.owner < 0 && o.stream == stream && o.device == sl.device) o.pending = false;
+            sl.pending = false;
         }
     }
     void abandon(int slot) { // nothing was enqueued
@@ -644,12 +613,11 @@ public:
         slots_[(size_t)slot].leased = false;
     }
 private:
-    // (m_ held) has the kernel that read the slot finished?  Covered by slot `owner`'s event: complete when that recording has completed --
-    // or when the owner's event has been recorded AGAIN since (the owner was recycled, which its earlier recording had to complete for)
+    // (m_ held) has the kernel that read the slot finished?
     bool complete(const ScratchSlot& sl) const {
-        if (sl.owner < 0) return false;
-        const ScratchSlot& o = slots_[(size_t)sl.owner];
-        return o.gen != sl.owner_gen || hipEventQuery(o.ev) == hipSuccess;
+        const bool done = hipEventQuery(sl.ev) == hipSuccess;
+        if (!done) (void)hipGetLastError(); // (hipErrorNotReady would otherwise stick)
+        return done;
     }
     std::mutex m_;
     std::vector<ScratchSlot> slots_;
@@ -812,9 +780,8 @@ struct Upload {
         rc = scratch_pool().acquire(device, bytes, &slot, s);
         if (rc) return rc;
         dev = scratch_pool().dev(slot);
-        static const bool stop_events = [] { const char* e = getenv("CVGS_SCRATCH_STOP_EVENTS"); return e ? e[0] != '0' : true; }();
         cvgs::StopEventSlot& st = cvgs::tls_stop_event();
-        st.event = (stop_events && scratch_zero_copy() && scratch_lazy_every() == 1) ? (void*)scratch_pool().event(slot) : nullptr;
+        st.event = scratch_zero_copy() ? (void*)scratch_pool().event(slot) : nullptr;
         st.used = false;
         return 0;
     }

@@ -263,7 +263,7 @@ int launch_plane_copies(const CopyJob* jobs, int n_jobs, size_t bytes, void* str
     }
     hipStream_t s = (hipStream_t)stream;
     // ~8192 workgroups in total, 8 x 16-byte loads in flight per lane (measured best on cfg #4: 124 us vs 136 us
-    // at 4096 workgroups x 4 loads; tools/bench_more.py with CVGS_COPY_TUNE)
+    // at 4096 workgroups x 4 loads; round 1 sweep)
     auto blocks_for = [&](size_t n_vec, int unroll) {
         size_t want = (n_vec + 256 * (size_t)unroll - 1) / (256 * (size_t)unroll);
         size_t cap = (size_t)(8192 / n_jobs > 1 ? 8192 / n_jobs : 1);
@@ -272,25 +272,6 @@ int launch_plane_copies(const CopyJob* jobs, int n_jobs, size_t bytes, void* str
     };
     if (al16) {
         const size_t n = bytes / 16;
-        // tuning hook (benchmarks only): CVGS_COPY_TUNE=<variant>,<total workgroups>
-        static const char* tune = getenv("CVGS_COPY_TUNE");
-        if (tune) {
-            int variant = 0, total = 4096;
-            sscanf(tune, "%d,%d", &variant, &total);
-            auto blocks = [&](int unroll) {
-                size_t want = (n + 256 * (size_t)unroll - 1) / (256 * (size_t)unroll);
-                size_t cap = (size_t)(total / n_jobs > 1 ? total / n_jobs : 1);
-                return (unsigned)(want < cap ? want : cap);
-            };
-            switch (variant) {
-            case 1: hipLaunchKernelGGL((k_plane_copy<vec4f, 8>), dim3(blocks(8), n_jobs), dim3(256), 0, s, a, n); break;
-            case 2: hipLaunchKernelGGL((k_plane_copy<vec4f, 4, false>), dim3(blocks(4), n_jobs), dim3(256), 0, s, a, n); break;
-            case 3: hipLaunchKernelGGL((k_plane_copy<vec4f, 2>), dim3(blocks(2), n_jobs), dim3(256), 0, s, a, n); break;
-            case 4: hipLaunchKernelGGL((k_plane_copy<vec4f, 1>), dim3(blocks(1), n_jobs), dim3(256), 0, s, a, n); break;
-            default: hipLaunchKernelGGL((k_plane_copy<vec4f, 4>), dim3(blocks(4), n_jobs), dim3(256), 0, s, a, n); break;
-            }
-            return hipGetLastError() == hipSuccess ? 0 : -1;
-        }
         hipLaunchKernelGGL((k_plane_copy<vec4f, 8>), dim3(blocks_for(n, 8), n_jobs), dim3(256), 0, s, a, n);
     } else if (al4) {
         const size_t n = bytes / 4;

@@ -255,7 +255,7 @@ int launch_nv12_x2(const ChainArgs& c, const PlaneParams* planes, int n_planes, 
     const bool pipe = !(rows_env && rows_env[0] == '1') && (r.dst_w & 1) == 0 && total_bytes > 0 && total_bytes < ((int64_t)1 << 32) - 65536 &&
                       (int64_t)r.batch * r.dst_h * ((r.dst_w + 127) / 128) >= 4096;
     a.out_bytes = pipe ? (uint32_t)total_bytes : 0u;
-    const int rpw = pipe ? kN2Rows : 1;
+    const int rpw = pipe ? kN2Rows : 1; // (round 5 A/B of 4 / 2 / 1 rows per wave at cfg #3: 8.19 / 7.93 / 8.03 us -- flat: profiles/r05_f_k4_rows_ab.txt)
     const unsigned col_tiles = (unsigned)((r.dst_w + 127) / 128), row_groups = (unsigned)((r.dst_h + kN2Waves * rpw - 1) / (kN2Waves * rpw));
     const dim3 grid(col_tiles, row_groups, (unsigned)r.batch), block(64 * kN2Waves);
     hipStream_t s = (hipStream_t)stream;

@@ -1110,7 +1110,7 @@ struct Queue {
     uint64_t* hgates = nullptr;         // pinned: the gate kernels' host copies of the gate words (R)
     struct Closed { uint64_t ticket; uint32_t tasks; };
     std::vector<Closed> closed;         // stream-ordered batches whose gate the host has not yet seen open
-    uint64_t closed_tasks = 0, n_budget_direct = 0, n_budget_waits = 0;
+    uint64_t closed_tasks = 0;
     std::vector<uint64_t> arrive_cum;   // per slot, 1 + 16 words: each arrival counter's value once every batch that used the slot has arrived
     uint64_t next_seq = 0, next_task = 0, done_inorder = 0, gen = 0, launches = 0;
     std::atomic<uint64_t> done_hint{0}; // every batch below is complete: what waiters (which do not take the mutex) have seen so far
@@ -1354,20 +1354,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     // server instead: tests/test_gpu_queue.py::test_queue_nv12_many_batches_in_flight then failed, and the gate trace did not change.)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (const char* pe = getenv("CVGS_QUEUE_SERVER_PRIO")) { // A/B hook (tools/probes): "low" swaps the two, "normal" = both at priority 0 (the server may
-                                                             // then SHARE a hardware queue with a caller's stream: gate kernels wait for ever -- probes only, under `timeout`)
-        if (pe[0] == 'l') { const int x = prio_least; prio_least = prio_greatest; prio_greatest = x; }
-        if (pe[0] == 'n') prio_least = prio_greatest = 0;
-    }
-    if (const char* pe = getenv("CVGS_QUEUE_SERVER_PRIO")) // A/B hook: "cumask" = a CU-masked stream at the default priority (a hardware queue of its own)
-        if (pe[0] == 'c') {
-            const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
-            std::vector<uint32_t> mask(words, 0xffffffffu);
-            if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
-            if (hipExtStreamCreateWithCUMask(&q->stream, words, mask.data()) != hipSuccess) q->stream = nullptr;
-            (void)hipGetLastError();
-        }
-    if ((!q->stream && (e = hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess) ||
+    if ((e = hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&q->stage_stream, hipStreamNonBlocking, prio_least)) != hipSuccess ||
         (e = hipExtMallocWithFlags((void**)&q->dev_block, total, hipDeviceMallocUncached)) != hipSuccess ||
         (e = hipMalloc((void**)&q->dev_counters, total_ctr)) != hipSuccess ||
@@ -1782,15 +1769,7 @@ int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err)
     while (d <= ticket && hflag(q, d % q->R) >= d + 1) ++d;
     raise_done_hint(q, d < ticket + 1 ? d : ticket + 1);
     if (d > ticket) return 0; // the host has already seen every batch up to the ticket complete: nothing to wait for
-    static const bool use_wait_value = getenv("CVGS_QUEUE_WAITVALUE") != nullptr; // (round 3's spelling, kept for A/B)
-    if (use_wait_value) {
-        for (uint64_t b = d; b <= ticket; ++b) {
-            if (b != ticket && hflag(q, b % q->R) >= b + 1) continue;
-            const hipError_t e = hipStreamWaitValue64((hipStream_t)stream, q->m.dflags + kQCtrStride * (b % q->R), b + 1, hipStreamWaitValueGte, ~0ull);
-            if (e != hipSuccess) { err = std::string("hipStreamWaitValue64: ") + hipGetErrorString(e); return -1; }
-        }
-        return 0;
-    }
+    // (ONE one-wave polling kernel: an unsatisfied hipStreamWaitValue64 on device memory costs ~1.6 ms on this runtime -- round 3's spelling)
     hipLaunchKernelGGL(k1q_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint64_t*)q->m.dflags, q->R, d, ticket, (const uint64_t*)&q->hc->error.v, q->gate_ticks, q->gate_trace);
     if (hipGetLastError() != hipSuccess) { err = "queue: the wait kernel could not be launched on the consumer's stream"; return -1; }
     return 0;
@@ -1809,14 +1788,9 @@ enum { QSUB_DEFER_WAIT = 1, QSUB_HYBRID = 2 };
 // several crop lists of one picture).  chains[i] / planes[i] / n_planes[i]; tickets[i] out; *n_queued = how many the server took (the
 // rest -- return 2 -- is the caller's to launch directly, in order, behind what was queued).
 //
-// THE BUDGET OF CLOSED BATCHES.  Workers draw task numbers in ring order and WAIT at a closed gate; a host that runs ahead of its
-// streams fills the ring with closed batches, and a later batch whose gate is open only gets the workers the closed ones have not
-// absorbed.  Unbounded, that is a priority inversion and -- where the closed batch's gate kernel sits behind the open batch's wait in a
-// shared hardware queue -- a dead-lock until the 10 s gate limit (tools/probes/gate_trace.py: four strict streams on a default
-// runtime ran at 28 us per batch, 83 us with unlucky queue sharing).  So the tasks of batches whose gate the host has not yet seen open
-// (the gate kernel mirrors every gate into host memory) can be BOUNDED: a batch that does not fit waits for a gate to open (bounded) -- or,
-// with QSUB_HYBRID, is launched directly on the stream: always a correct spelling of the same call.
-// DEAD-LOCK FREEDOM does not need the budget: a group is published and its gate kernel enqueued under ONE lock (gate_mu), so ring order
+// (A budget on the tasks that may sit behind closed gates was implemented in round 4 and removed in round 5: it bounded a batch's p90
+// latency with four strict streams but halved what ticks absorb -- 2.5 -> 8.9 us per batch -- and was never on by default: HISTORY.md.)
+// DEAD-LOCK FREEDOM needs no such bound: a group is published and its gate kernel enqueued under ONE lock (gate_mu), so ring order
 // == the order of the gate kernels inside every hardware queue.  The earliest incomplete batch of the ring is then either open -- its
 // tasks were all drawn before any later batch's, by workers that are executing them -- or closed with nothing but completed gate
 // kernels and the caller's own producers in front of its gate kernel: it always makes progress.
@@ -1828,9 +1802,6 @@ static void prune_closed(Queue* q) { // (under q->mu)
         else q->closed[w++] = c;
     }
     q->closed.resize(w);
-}
-static uint32_t gated_tasks(const ChainArgs& c, uint32_t rows) {
-    return (uint32_t)c.read.batch * (uint32_t)((c.read.dst_w + 63) / 64) * (uint32_t)((c.read.dst_h + (int)rows - 1) / (int)rows);
 }
 int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams* const* planes, const int* n_planes, int n, void* stream, uint32_t flags,
                     uint64_t* tickets, int* n_queued, std::string& err) {
@@ -1869,11 +1840,6 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
             return 1;
         }
     }
-    // (off by default: it bounds a batch's latency -- p90 19 us instead of 80-110 us with four strict streams -- but halves the work that
-    //  can sit absorbed behind closed gates, which is exactly what keeps the server fed between two ticks: 16-frame ticks on two
-    //  streams 2.5 -> 8.9 us per batch.  CVGS_QUEUE_CLOSED_BUDGET=<tasks> turns it on; 1 = half the workers.)
-    static const long budget_env = env_long("CVGS_QUEUE_CLOSED_BUDGET", 0);
-    const uint64_t budget = budget_env <= 0 ? ~0ull : (budget_env == 1 ? (uint64_t)q->G * kQWaves / 2 : (uint64_t)budget_env);
     int done = 0;
     while (done < n) {
         // ---- how many of the remaining chains go behind the next gate kernel, and with which task size ----
@@ -1904,43 +1870,12 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
             const int min_group = (int)((flags >> 8) & 0xffu) ? (int)((flags >> 8) & 0xffu) : 8;
             if (hybrid && (!overlap || n - done < min_group)) { ++q->n_direct; if (n_queued) *n_queued = done; return 2; }
             rows = parallel >= 8 ? (uint32_t)kQRowsPerTaskMid : (parallel >= 1 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave);
-            static const int gated_rows_env = (int)env_long("CVGS_QUEUE_GATED_ROWS", 0) & ~3; // tuning: the size used from 8 overlappable batches
-            if (gated_rows_env >= 4 && gated_rows_env <= 4096 && parallel >= 8) rows = (uint32_t)gated_rows_env;
-            const auto t0 = std::chrono::steady_clock::now();
-            unsigned spins = 0;
-            for (;;) {
-                uint64_t room = budget > q->closed_tasks ? budget - q->closed_tasks : 0;
-                take = 0;
-                uint64_t sum = 0;
-                // (at most half the ring behind ONE gate kernel: the chains are published before their gate kernel is enqueued, so a group
-                //  larger than the ring would wait for its own first slot to complete -- behind a gate nobody has launched yet)
-                const int max_take = q->R >= 4 ? (int)(q->R / 2) : 1;
-                while (done + take < n && take < 64 && take < max_take) {
-                    const uint32_t tt = gated_tasks(*chains[done + take], rows);
-                    if (sum + tt > room) break;
-                    sum += tt;
-                    ++take;
-                }
-                if (take > 0) break;
-                if (q->closed_tasks == 0) { // nothing is closed and ONE batch still exceeds the budget at this task size: larger tasks, else alone
-                    if (rows < (uint32_t)kQRowsPerTaskDeep) { rows *= 2; continue; }
-                    take = 1;
-                    break;
-                }
-                if (hybrid) { ++q->n_budget_direct; if (n_queued) *n_queued = done; return 2; }
-                // wait for a gate to open (the mutex is released: other threads' submits and the gate kernels go on)
-                if (spins == 0) ++q->n_budget_waits;
-                lock.unlock();
-                cpu_pause();
-                if ((++spins & 0x3fff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-                    err = "queue: no gate of the closed stream-ordered batches opened for 2 s";
-                    if (n_queued) *n_queued = done;
-                    return -2;
-                }
-                lock.lock();
-                if (hv(q->hc->error)) { err = "queue: the server reported a stall / protocol error"; if (n_queued) *n_queued = done; return -2; }
-                prune_closed(q);
-            }
+            // (at most half the ring behind ONE gate kernel: the chains are published before their gate kernel is enqueued, so a group
+            //  larger than the ring would wait for its own first slot to complete -- behind a gate nobody has launched yet)
+            const int max_take = q->R >= 4 ? (int)(q->R / 2) : 1;
+            take = n - done;
+            if (take > 64) take = 64;
+            if (take > max_take) take = max_take;
         }
         // ---- publish them closed, then ONE gate kernel on the caller's stream -- under one lock: ring order == gate-kernel order ----
         std::lock_guard<std::mutex> gate_lock(q->gate_mu);
@@ -2052,8 +1987,8 @@ void queue_prof(Queue* q, uint64_t* out16) {
     out16[13] = q->n_sub ? q->ns_ring_wait / q->n_sub : 0; // host side of submit, ns per call (since create)
     out16[14] = q->n_gated | (q->n_direct << 32); // stream-ordered submits: taken by the server | launched directly by the latency policy
     out16[15] = 0;
-    out16[2] = q->n_budget_direct;                  // ... launched directly because the closed-batch budget was exhausted
-    out16[3] = q->n_budget_waits;                   // ... that waited for a gate to open
+    out16[2] = 0;                  // ... launched directly because the closed-batch budget was exhausted
+    out16[3] = 0;                   // ... that waited for a gate to open
 }
 
 void queue_stats(Queue* q, uint64_t* out8) {

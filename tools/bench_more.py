@@ -125,8 +125,9 @@ def cfg4(dev, iters, resize_from_4k=False, mirrored=False, half=False, graph=Fal
             "copy_same_footprint_GB_per_s": copy_gbs}
 
 
-def cfg3(dev, iters, p010=False, queue=False):
-    """p010: the same frame as a 10-bit decoder surface (16-bit samples, BT.2020 limited range, x 1/1023 in the chain)."""
+def cfg3(dev, iters, p010=False, queue=False, per_launch=1):
+    """p010: the same frame as a 10-bit decoder surface (16-bit samples, BT.2020 limited range, x 1/1023 in the chain).
+    per_launch > 1: a TICK of that many cameras' surfaces in ONE chain (batch = per_launch -> [per_launch,3,720,1280]) = one launch."""
     w, h = W.FRAME_6K
     dst = (1280, 720)
     sb = 2 if p010 else 1
@@ -140,8 +141,13 @@ def cfg3(dev, iters, p010=False, queue=False):
     f = cvgs.CV_32FC3
     s = torch.cuda.current_stream()
     chains, ops = [], None
-    for b, o in zip(bufs, outs):
-        luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1 if p010 else cvgs.CV_8UC1, b.data_ptr(), w * sb, owner=b)
+    if per_launch > 1:
+        nbuf = (nbuf // per_launch) * per_launch
+        outs = [torch.zeros((per_launch, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev) for _ in range(nbuf // per_launch)]
+    for k, o in enumerate(outs):
+        group = bufs[k * per_launch:(k + 1) * per_launch]
+        lumas = [cvgs.GpuMat(h, w, cvgs.CV_16UC1 if p010 else cvgs.CV_8UC1, b.data_ptr(), w * sb, owner=b) for b in group]
+        luma = lumas[0] if per_launch == 1 else lumas
         rd = (cvgs.read_nv12(luma, dst, capi.YUV_LIMITED, capi.BT2020, False, layout=capi.YUV_P010) if p010 else
               cvgs.read_nv12(luma, dst, capi.YUV_FULL, capi.BT709, False))
         ops = [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
@@ -169,12 +175,16 @@ def cfg3(dev, iters, p010=False, queue=False):
     t = events_time(g.replay, max(3, iters // 8), warm=2) / per
     if queue:  # the same frames through the descriptor queue (NV12 / NV21 surfaces are its second kind, P010 surfaces its fourth)
         t = queue_time(chains)
+    t = t / per_launch  # per FRAME
     write = dst[0] * dst[1] * 3 * 4
     # scale 4.8: every output pixel taps 4 distinct luma bytes and up to 4 distinct UV pairs (SURVEY.md 8d bound)
     read = (dst[0] * dst[1] * 4 + dst[0] * dst[1] * 2 * 4) * sb
     alg = write + read
     sector = W.nv12_sector_read_bytes(w, h, dst[0], dst[1], sb) + write
-    return {"config": "cfg3 %s 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, %s" % ("P010 (10-bit, BT.2020 limited)" if p010 else "NV12", "one cvgs_queue_submit per frame (descriptor queue, no launch per frame)" if queue else "one kernel per frame (graph-replayed launches)"),
+    how = ("one cvgs_queue_submit per frame (descriptor queue, no launch per frame)" if queue else
+           ("one kernel per frame (graph-replayed launches)" if per_launch == 1 else
+            "a TICK of %d cameras' surfaces per launch (one chain, batch %d; graph-replayed), time per frame" % (per_launch, per_launch)))
+    return {"config": "cfg3 %s 6144x3456 -> BGR float -> 1280x720 -> normalize -> split, %s" % ("P010 (10-bit, BT.2020 limited)" if p010 else "NV12", how),
             "kernel": ("k1q_server<1, 2, P010> (k4q_rows<S16>)" if p010 else "k1q_server<1, 2, NV12> (k4q_rows)") if queue else cvgs.kernel_name(*ops), "us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": alg,
             "GB_per_s": round(alg / t / 1e9, 1), "frac_of_8TBs": round(alg / t / 1e9 / PEAK, 4),
             "sector_bound_bytes": sector, "frac_of_sector_bound": round(sector / t / 1e9 / PEAK, 4), "surfaces_in_rotation": nbuf,
@@ -285,6 +295,7 @@ def run_all(dev, iters=100, only=""):
     if only in ("", "cfg3"):
         res.append(cfg3(dev, iters))
         res.append(cfg3(dev, iters, p010=True))
+        res.append(cfg3(dev, iters, per_launch=4))
         res.append(cfg3(dev, iters, queue=True))
         res.append(cfg3(dev, iters, p010=True, queue=True))
     if only in ("", "nv12many"):

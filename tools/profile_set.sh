@@ -19,8 +19,7 @@ bash tools/profile_queue_sustained.sh $TAG > /dev/null 2>&1
  echo; echo "== the runtime's default (GPU_MAX_HW_QUEUES=4), producer kernel on the stream =="; GPU_MAX_HW_QUEUES=4 python tools/probes/stream_ordered_rate.py --producer 2>&1 | grep -v amdgpu.ids
  echo; echo "== GPU_MAX_HW_QUEUES=3, no producer kernel =="; GPU_MAX_HW_QUEUES=3 python tools/probes/stream_ordered_rate.py 2>&1 | grep -v amdgpu.ids) > $OUT/stream_ordered_rate.txt
 (echo "== GPU_MAX_HW_QUEUES=3 =="; GPU_MAX_HW_QUEUES=3 python tools/probes/gate_trace.py 2>&1 | grep -v amdgpu.ids; echo "== the runtime's default (4) =="; GPU_MAX_HW_QUEUES=4 python tools/probes/gate_trace.py 2>&1 | grep -v amdgpu.ids) > $OUT/gate_trace.txt
-(for Q in 4 8 3 2; do echo "== GPU_MAX_HW_QUEUES=$Q: 24 fresh streams, us per empty one-wave kernel =="; GPU_MAX_HW_QUEUES=$Q python tools/probes/server_vs_streams.py --many 2>&1 | grep -v amdgpu.ids; done
- echo "== GPU_MAX_HW_QUEUES=4, server stream at the LOWEST priority =="; GPU_MAX_HW_QUEUES=4 CVGS_QUEUE_SERVER_PRIO=low python tools/probes/server_vs_streams.py --many 2>&1 | grep -v amdgpu.ids) > $OUT/server_vs_streams.txt
+(for Q in 4 8 3 2; do echo "== GPU_MAX_HW_QUEUES=$Q: 24 fresh streams, us per empty one-wave kernel =="; GPU_MAX_HW_QUEUES=$Q python tools/probes/server_vs_streams.py --many 2>&1 | grep -v amdgpu.ids; done) > $OUT/server_vs_streams.txt
 python tools/bench_queue_regimes.py --soak 60 2>&1 | grep -v amdgpu.ids > $OUT/queue_regimes_soak60.txt
 python tools/bench_queue_regimes.py --g-sweep 2>&1 | grep -v amdgpu.ids > $OUT/coexistence_g_sweep.txt
 python tools/bench_reference_tests.py > $OUT/reference_test_chains.txt 2> /dev/null

@@ -1071,8 +1071,8 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             if (k4) fusable = !tables && launch_nv12(probe, nullptr, 0, 1 << 30, &one, 1, stream, true, nullptr) == 1; // K4 checks its planes on the host
             else fusable = launch_k1(probe, nullptr, 0, MirrorArgs{}, &one, 1, stream, true, nullptr) == 1;
         }
-        // host descriptors: K1's table goes into a slot of the stream's own ring, recycled through the launch's progress word (ManyPool);
-        // K4's -- and K1's when that ring has no room -- into the event-tracked descriptor scratch
+        // host descriptors: the table goes into a slot of the stream's own ring, recycled through the launch's progress word (ManyPool) --
+        // or, when that ring has no room, into the event-tracked descriptor scratch
         ManyStream* ms = nullptr;
         ManySlot* mslot = nullptr;
         std::unique_lock<std::mutex> ms_lock;
@@ -1080,7 +1080,7 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         if (fusable && !tables) {
             const size_t bytes = total_planes * sizeof(PlaneParams) + 16 * (size_t)n;
             static const bool progress_word = [] { const char* e = getenv("CVGS_MANY_PROGRESS_WORD"); return e ? e[0] != '0' : true; }();
-            if (!k4 && progress_word && (ms = many_pool().get(stream, stream_device(stream))) != nullptr) {
+            if (progress_word && (ms = many_pool().get(stream, stream_device(stream))) != nullptr) {
                 ms_lock = std::unique_lock<std::mutex>(ms->mu);
                 mslot = many_pool().acquire(ms, bytes);
                 if (!mslot) { ms_lock.unlock(); ms = nullptr; }

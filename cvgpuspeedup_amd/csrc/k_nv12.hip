@@ -33,6 +33,10 @@ struct N12Geom {
     int64_t img_stride2, ch_stride2;
     uint32_t col_tiles; // NPL == 0 (fused chains): blockIdx.x = row group * col_tiles + column tile
     uint32_t pad;
+    // fused launches with host descriptors (NPL == 0; cvgs_api.cpp: ManyPool): the first work-item stores done_value into *done_word
+    // (pinned host memory) when the kernel starts -- every earlier launch of the stream has finished by then (as K1: k_k1_impl.hpp)
+    uint64_t* done_word;
+    uint64_t done_value;
 };
 
 // NPL > 0: the planes travel in the kernel arguments, grid = (column tiles, row groups, planes).  NPL == 0: the chains of a
@@ -97,6 +101,11 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     asm volatile("" ::"s"(dst_w), "s"(dst_h), "s"(W), "s"(CN), "s"(P.w), "s"(P.h), "s"(P.step), "s"(P.fx), "s"(P.fy), "s"(P.data), "s"(P.uv_off),
                  "s"(yuv_range), "s"(yuv_prim), "s"(packed), "s"(img_stride), "s"(ch_stride), "s"(out_base), "s"(op0), "s"(op1),
                  "s"(op2), "s"(op3));
+    // (behind the scalar loads: a store in front of them would make the compiler fetch the descriptors with vector loads)
+    if constexpr (NPL == 0) {
+        if (g.done_word && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0)
+            __hip_atomic_store(g.done_word, g.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const YuvK yk = yuv_matrix(yuv_range, yuv_prim, S16 ? CVGS_YUV_P010 : CVGS_YUV_NV12);
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -357,12 +366,20 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
     const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + kK4Waves * RPW - 1) / (kK4Waves * RPW));
     g.col_tiles = col_tiles;
     g.pad = 0;
+    g.done_word = nullptr;
+    g.done_value = 0;
     const N12Many& many = tls_many();
     constexpr bool kImage = std::is_same_v<OT, uint8_t>; // packed u8 images: never fused chains, never the 16 KB argument block
     if constexpr (!kImage) if (many.segs) {
         KernArgsMany a;
         a.c = c;
         for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
+        DoneWordSlot& dw = tls_done_word();
+        if (dw.word && !dw.used) {
+            dw.used = true;
+            g.done_word = dw.word;
+            g.done_value = dw.value;
+        }
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
         hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
         return hipGetLastError();

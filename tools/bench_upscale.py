@@ -13,7 +13,8 @@ from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
 from tools.bench_resize import events_time  # noqa: E402
 
 CASES = [((1920, 1080), (3840, 2160)), ((960, 540), (1920, 1080)), ((1280, 720), (2560, 1440)), ((1280, 720), (3840, 2160)),
-         ((1920, 1080), (2560, 1440)), ((3840, 2160), (1920, 1080)), ((640, 360), (1280, 720)), ((2560, 1440), (3840, 2160))]
+         ((1920, 1080), (2560, 1440)), ((3840, 2160), (1920, 1080)), ((640, 360), (1280, 720)), ((2560, 1440), (3840, 2160)),
+         ((3840, 2160), (3870, 2260))]  # the last one: the reference's own resize_write size (tests/resize/test_resize_write.cu:55-56)
 
 
 def case(dev, cn, src, dst, iters, nbuf=0):

@@ -25,12 +25,17 @@
 //    oracle (p00*w00 + p10*w10 + p01*w01 + p11*w11, left to right, no FMA), two pixels per instruction.
 // Measured (tools/bench_upscale.py, profiles/r03_*): 1080p -> 4K packed u8c3 23.0 -> 10.8 us, u8c4 23.9 -> 11.0, u8c1 17.5 -> 8.3;
 // 720p -> 1440p 13.8 -> 6.8; the reference's 4K -> 3870 x 2260: 8UC3 30.1 -> 19.8, 8UC1 23.6 -> 15.8, 8UC4 25.7 -> 19.4.
+// Round 5: ONE shared 8-byte tap window per lane and source row for u8 images of 1-2 channels and one-channel 16-bit images (x4_load<SH>):
+// the counters of the one-channel case (profiles/r05_h_c1_pmc_sq*.txt) showed 62 % of the wave cycles stalled on instruction issue with the
+// pipes used one after the other (all resident waves are in the same phase) -- 20 window loads per wave were a third of the launch.  4K ->
+// 3870 x 2260: 8UC1 15.7 -> 9.4 us, 16SC1 21.8 -> 14.4 us; 1080p -> 4K 8UC1 8.4 -> 6.0 us (profiles/r05_k_*, r05_l_*).
 // What bounds it now: issue (tools/probes/pk_rate_probe.cpp: v_pk_mul_f32 / v_pk_add_f32 retire at 5.7 cycles per
 // instruction per SIMD, conversions at 4.4 - 4.8; 3.4 M VALU + 1.4 M SALU instructions per 4K launch = ~7 us of issue at
 // 4 waves per SIMD) -- a launch without its stores runs 10.3 us against 11.3 with them (profiles/r03_d_*).
 // Vertical DOWN-scaling stays with k1_resize_split: no source row is shared, and it ties or wins there (4K -> 1080p 10.3 us).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -75,7 +80,7 @@ template <int CN, int SRC>
 struct X4Col {
     static constexpr int PX = x4_px<SRC>;
     f32x2 wxa[PX / 2], wxb[PX / 2];
-    uint32_t ol[PX];
+    uint32_t ol[PX]; // SH (shared window): ol[0] only
     // u8: the v_perm_b32 selectors of the window's two dwords; 16-bit: the window's shift in bits, fp32: "the window was
     // clamped back by one pixel" (fix_a), and the right-edge flag (fix_b)
     uint32_t fix_a[PX], fix_b[PX];
@@ -97,9 +102,23 @@ template <int SRC> struct X4Raw { uint64_t w[x4_px<SRC>]; };
 template <> struct X4Raw<SRC_U16> { u32x4 w[2]; };
 template <> struct X4Raw<SRC_S16> { u32x4 w[2]; };
 
-template <int CN, int SRC>
+// SH: ONE 8-byte window per lane and source row holds the taps of ALL the lane's pixels (u8 images of 1-2 channels when the lane's
+// pixels lie close enough: launch_k1_packed_x4) -- a quarter of the load instructions of one window per pixel.
+template <int CN, int SRC, bool SH = false>
 __device__ __forceinline__ X4Raw<SRC> x4_load(const X4Col<CN, SRC>& col, gptr_u8 row) {
     X4Raw<SRC> r;
+    if constexpr (SH) {
+        static_assert(SRC == SRC_U8 || ((SRC == SRC_U16 || SRC == SRC_S16) && CN == 1), "shared windows: u8 images, one-channel 16-bit images");
+        const uint64_t w = *(gptr_u64)(row + col.ol[0]);
+        if constexpr (SRC == SRC_U8) {
+#pragma unroll
+            for (int i = 0; i < x4_px<SRC>; ++i) r.w[i] = w;
+        } else { // the 8 bytes (4 elements) in the first half of the first window slot
+            r.w[0] = u32x4{(uint32_t)w, (uint32_t)(w >> 32), 0u, 0u};
+            r.w[1] = r.w[0];
+        }
+        return r;
+    }
 #pragma unroll
     for (int i = 0; i < x4_px<SRC>; ++i) {
         if constexpr (x4_winb<SRC> == 16) r.w[i] = *(gptr_u32x4)(row + col.ol[i]);
@@ -108,11 +127,17 @@ __device__ __forceinline__ X4Raw<SRC> x4_load(const X4Col<CN, SRC>& col, gptr_u8
     return r;
 }
 
-template <int CN, int SRC>
+template <int CN, int SRC, bool SH = false>
 __device__ __forceinline__ void x4_unpack(X4Slot<CN, x4_px<SRC>>& s, const X4Col<CN, SRC>& col, const X4Raw<SRC>& r) {
 #pragma unroll
     for (int i = 0; i < x4_px<SRC>; ++i) {
-        if constexpr (SRC == SRC_U8) {
+        if constexpr (SH && SRC != SRC_U8) { // one-channel 16-bit image, shared 8-byte window: the pixel's two elements sit fix_a[i] bits in
+            const uint64_t w64 = ((uint64_t)r.w[0].y << 32) | r.w[0].x;
+            const uint32_t v = (uint32_t)(w64 >> col.fix_a[i]);
+            const float a = elem_to_float<SRC>(v & 0xffffu);
+            s.t0[i >> 1][0][i & 1] = a;
+            s.t1[i >> 1][0][i & 1] = col.fix_b[i] ? a : elem_to_float<SRC>(v >> 16);
+        } else if constexpr (SRC == SRC_U8) {
             const uint32_t wl = (uint32_t)r.w[i], wh = (uint32_t)(r.w[i] >> 32);
             const uint32_t lo = __builtin_amdgcn_perm(wh, wl, col.fix_a[i]);
             [[maybe_unused]] uint32_t hi = 0;
@@ -223,7 +248,7 @@ __device__ __forceinline__ void x4_row(const X4Slot<CN, x4_px<SRC>>& A, const X4
     }
 }
 
-template <int CN, int SRC, int PRE>
+template <int CN, int SRC, int PRE, bool SH = false>
 __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
     constexpr int PX = x4_px<SRC>;
     constexpr int EB = elem_bytes<SRC>;
@@ -258,9 +283,13 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
         col.wxb[i >> 1][i & 1] = sx - (float)x1;
         const bool edge = x2 > P.w - 1;
         const int o = x1 * CN * EB;
-        const int ol = min(o, row_bytes - WINB);
+        int ol = min(o, row_bytes - (SH ? 8 : WINB)); // (shared windows are 8 bytes for every type)
+        if constexpr (SH) { // the lane's one window starts at its FIRST pixel's tap (clamped into the row): o >= that start for every pixel
+            if (i == 0) col.ol[0] = (uint32_t)ol;
+            ol = (int)col.ol[0];
+        }
         const uint32_t sh = (uint32_t)(o - ol);
-        col.ol[i] = (uint32_t)ol;
+        if constexpr (!SH) col.ol[i] = (uint32_t)ol;
         if constexpr (SRC == SRC_U8) {
             col.fix_a[i] = 0x03020100u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(0) : 0u);
             col.fix_b[i] = 0x07060504u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(1) : 0u);
@@ -309,18 +338,18 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
         const int s0 = y1_of(0);
         X4Raw<SRC> raw[PRE + 1];
 #pragma unroll
-        for (int k = 0; k <= PRE; ++k) raw[k] = x4_load<CN, SRC>(col, row_of(min(s0 + k, h1)));
-        x4_unpack<CN, SRC>(S0, col, raw[0]);
+        for (int k = 0; k <= PRE; ++k) raw[k] = x4_load<CN, SRC, SH>(col, row_of(min(s0 + k, h1)));
+        x4_unpack<CN, SRC, SH>(S0, col, raw[0]);
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
             if (j < nrows) { // wave-uniform
                 const int jn = j + rows_on(s0 + k);
                 if ((k & 1) == 0) {
-                    x4_unpack<CN, SRC>(S1, col, raw[k + 1]);
+                    x4_unpack<CN, SRC, SH>(S1, col, raw[k + 1]);
 #pragma unroll 1
                     for (; j < jn; ++j) emit(S0, S1, j);
                 } else {
-                    x4_unpack<CN, SRC>(S0, col, raw[k + 1]);
+                    x4_unpack<CN, SRC, SH>(S0, col, raw[k + 1]);
 #pragma unroll 1
                     for (; j < jn; ++j) emit(S1, S0, j);
                 }
@@ -334,23 +363,23 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
 #pragma unroll 1
     while (j < nrows) {
         int s = y1_of(j);
-        const X4Raw<SRC> first = x4_load<CN, SRC>(col, row_of(s));
-        X4Raw<SRC> next = x4_load<CN, SRC>(col, row_of(min(s + 1, h1)));
-        x4_unpack<CN, SRC>(S0, col, first);
+        const X4Raw<SRC> first = x4_load<CN, SRC, SH>(col, row_of(s));
+        X4Raw<SRC> next = x4_load<CN, SRC, SH>(col, row_of(min(s + 1, h1)));
+        x4_unpack<CN, SRC, SH>(S0, col, first);
 #pragma unroll 1
         for (;;) {
-            x4_unpack<CN, SRC>(S1, col, next);
+            x4_unpack<CN, SRC, SH>(S1, col, next);
             int jn = j + rows_on(s);
             bool more = jn < nrows && y1_of(jn) == s + 1;
-            if (more) next = x4_load<CN, SRC>(col, row_of(min(s + 2, h1)));
+            if (more) next = x4_load<CN, SRC, SH>(col, row_of(min(s + 2, h1)));
 #pragma unroll 1
             for (; j < jn; ++j) emit(S0, S1, j);
             if (!more) break;
             ++s;
-            x4_unpack<CN, SRC>(S0, col, next);
+            x4_unpack<CN, SRC, SH>(S0, col, next);
             jn = j + rows_on(s);
             more = jn < nrows && y1_of(jn) == s + 1;
-            if (more) next = x4_load<CN, SRC>(col, row_of(min(s + 2, h1)));
+            if (more) next = x4_load<CN, SRC, SH>(col, row_of(min(s + 2, h1)));
 #pragma unroll 1
             for (; j < jn; ++j) emit(S1, S0, j);
             if (!more) break;
@@ -427,8 +456,24 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     // source intervals requested up front: what the wave's rows span (a wave that needs 2 source rows must not fetch 5)
     const float spanned = (float)a.rows_per_wave * (fy_max > 0.f ? fy_max : 1.f);
     const int pre = spanned <= 1.0f ? 1 : (spanned <= 2.0f ? 2 : kX4Pre);
+    // shared tap windows (u8, 1-2 channels): the lane's 4 pixels tap at most (floor(3 fx) + 1) source pixels apart, + the second tap:
+    // everything inside ONE 8-byte window
+    const bool sh16 = (src == SRC_U16 || src == SRC_S16) && r.cn == 1; // 2 pixels per lane, 2-byte elements: 4 elements per window
+    bool shared = ((src == SRC_U8 && r.cn <= 2) || sh16) && fy_max > 0.f;
+    for (int i = 0; i < n_planes && shared; ++i)
+        shared = ((int)std::floor((double)(px - 1) * (double)planes[i].fx * 1.0001) + 1) * r.cn * eb + 2 * r.cn * eb <= 8;
+    static const char* shared_env = getenv("CVGS_K1_X4_SHARED"); // benchmark-only: 0 = one window per pixel
+    if (shared_env && shared_env[0] == '0') shared = false;
     auto go = [&](auto cn_tag, auto src_tag) {
         constexpr int CN = decltype(cn_tag)::value, SRC = decltype(src_tag)::value;
+        if constexpr ((SRC == SRC_U8 && CN <= 2) || ((SRC == SRC_U16 || SRC == SRC_S16) && CN == 1)) {
+            if (shared) {
+                if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 1, true>), grid, block, 0, s, a);
+                else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 2, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((k1_packed_x4<CN, SRC, kX4Pre, true>), grid, block, 0, s, a);
+                return;
+            }
+        }
         if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 1>), grid, block, 0, s, a);
         else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k1_packed_x4<CN, SRC, kX4Pre>), grid, block, 0, s, a);

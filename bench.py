@@ -472,15 +472,20 @@ def summary(wl, m, out_elem=4):
             "frac_of_sector_bound": round(wl.sector_bound_bytes(out_elem) / t / 1e9 / HBM_PEAK_GBS, 4), "kernel": wl.kernel}
 
 
+def tick_passes(steps, tick, at_least=256):
+    """(m, launches): the K steps are repeated m times so that m x K is a whole number of ticks and >= `at_least` steps; m x K / tick launches."""
+    m = 1
+    while (m * steps) % tick or m * steps < at_least:
+        m += 1
+    return m, m * steps // tick
+
+
 def measure_ticks(wl, steps, warmup, barrier=lambda: None, eager=False, target_s=0.25, min_replays=MIN_REPLAYS):
     """The protocol of the module docstring for TICKS: `wl` launches wl.per_launch steps (frames) per call (cvgs_execute_many, device
     tables).  The K steps are repeated m times so that m x K is a whole number of ticks and >= 256 steps; one timed replay = m x K / tick
     launches.  Returns measure()'s dict with every time PER STEP, plus `launch_s` (per tick launch) and the launches per replay."""
     tick = wl.per_launch
-    m_rep = 1
-    while (m_rep * steps) % tick or m_rep * steps < 256:
-        m_rep += 1
-    launches = m_rep * steps // tick
+    m_rep, launches = tick_passes(steps, tick)
     m = measure(wl, launches, max(1, -(-warmup // tick)), barrier=barrier, eager=eager, target_s=target_s, min_replays=min_replays, est_step_s=2.5e-6 * tick,
                 exact_steps=True)
     out = {k: (v / tick if k.endswith("_s") and k != "wall_s" else v) for k, v in m.items()}

@@ -937,6 +937,7 @@ inline void executeOperations(hipStream_t stream, const IOps&... iops) {
     if (detail::stream_attachments().any.load(std::memory_order_acquire) && detail::stream_records(stream)) {
         std::unique_ptr<ChainBuilder> rec(new ChainBuilder); // recorded: the builder outlives this call (it owns the descriptor's arrays)
         lowerChain(*rec, iops...);
+        detail::check_status(cvgs_validate(&rec->d)); // an invalid chain throws HERE, from the call that spelled it, not from a later flush
         if (detail::record_attached(stream, rec)) return;
         detail::check_status(cvgs_execute(&rec->d, stream)); // (detached in between)
         return;

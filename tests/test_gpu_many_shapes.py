@@ -290,3 +290,43 @@ def test_progress_word_and_event_tracked_tables_write_the_same_bytes():
         assert line, p.stderr[-2000:]
         res[mode] = line[-1].split()[1]
     assert res["1"] == res["0"]
+
+
+def test_ticks_on_streams_that_come_and_go(oracle, device, lib):
+    """The per-stream table rings of the fused launch are keyed by the stream HANDLE and never touch a stream after the call that used it:
+    400 raw HIP streams are created, run three ticks each (a different crop list per tick) and are destroyed -- the runtime hands handles
+    out again, the ring bookkeeping must neither fault nor mix tables up (round 4's event-based reclaim faulted on destroyed streams)."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    fh, fw = 270, 480
+    frames = [H.random_u8((fh, fw, 3), seed=1200 + k) for k in range(2)]
+    fts = [torch.from_numpy(f).to(device) for f in frames]
+    torch.cuda.synchronize()
+    checked = 0
+    for i in range(400):
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        held = []
+        for t in range(3):
+            chains, outs, meta = [], [], []
+            for k in range(2):
+                crops = H.random_crops(3 + (i + t + k) % 4, fw, fh, seed=12000 + 31 * i + 7 * t + k, wmax=200, hmax=200)
+                ops, out, _ = _chain(torch, device, fts[k], crops, (64, 128), 3)
+                chains.append(ops)
+                outs.append(out)
+                meta.append((k, crops))
+            lowered = [cvgs.lower(ops) for ops in chains]
+            arr = cvgs.pack_chains(lowered)
+            capi.check(lib.cvgs_execute_many(arr, len(lowered), s))
+            held.append((outs, meta, lowered, arr))
+        assert hip.hipStreamSynchronize(s) == 0
+        if i % 40 == 0:
+            for outs, meta, _, _ in held:
+                for out, (k, crops) in zip(outs, meta):
+                    H.assert_bit_exact(out.cpu().numpy(), _oracle(oracle, frames[k], crops, (64, 128), 3), "stream %d" % i)
+                    checked += 1
+        assert hip.hipStreamDestroy(s) == 0
+    assert checked == 60

@@ -20,13 +20,6 @@
 
 using namespace cvgs;
 
-#ifdef CVGS_WITH_EXPERIMENTS
-namespace cvgs {
-// experimental K1 variants (k_k1_exp.hip); A/B benchmarking only, never part of libcvgs_hip.so
-int launch_k1_exp(int variant, const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, void* stream);
-const char* k1_exp_name(int variant);
-} // namespace cvgs
-#endif
 
 namespace {
 
@@ -1185,24 +1178,6 @@ int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stre
     return execute_many(chains, n_chains, (hipStream_t)stream);
 }
 
-#ifdef CVGS_WITH_EXPERIMENTS
-// libcvgs_exp.so only (tools/k1_ab.py): run an experimental K1 variant of csrc/k_k1_exp.hip on a headline-shaped chain.
-// The product library is built without this block and without k_k1_exp.hip.
-int cvgs_exp_execute(const cvgs_chain_desc* chain, int32_t variant, cvgs_stream_t stream) {
-    Lowered L;
-    int rc = lower(chain, false, L);
-    if (rc) return rc;
-    const ChainArgs& a = L.args;
-    if (!k1_exp_name(variant) || a.read.kind != CVGS_READ_RESIZE_LINEAR || a.read.depth != CVGS_DEPTH_8U || a.read.cn != 3 ||
-        a.prog.n != 4 || a.write.depth != CVGS_DEPTH_32F || a.write.data2 || L.mirrors.n ||
-        (a.write.kind != CVGS_WRITE_TENSOR_SPLIT && a.write.kind != CVGS_WRITE_TENSOR_T_SPLIT))
-        return fail(CVGS_ERR_UNSUPPORTED, "experimental variants take the headline chain only");
-    if (!a.read.table && L.planes.size() > (size_t)CVGS_KERNARG_PLANES) return fail(CVGS_ERR_UNSUPPORTED, "pass a device plane table");
-    rc = launch_k1_exp(variant, a, L.planes.data(), a.read.table ? 0 : (int)L.planes.size(), stream);
-    return rc < 0 ? fail(CVGS_ERR_HIP, "experimental K1 launch failed") : CVGS_OK;
-}
-const char* cvgs_exp_name(int32_t variant) { return k1_exp_name(variant); }
-#endif
 
 int cvgs_kernel_name(const cvgs_chain_desc* chain, char* buf, size_t buf_size) {
     if (!buf || !buf_size) return fail(CVGS_ERR_INVALID, "null buffer");

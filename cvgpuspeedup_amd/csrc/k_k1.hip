@@ -6,7 +6,7 @@
 //     -> ColorConversion -> Mul -> Sub -> Div -> Write<TensorSplit<float3>>
 // launched at reference tests/batchresize/test_batchresize_x_split3D.cu:311-314.
 //
-// CDNA4 mapping.  Measured (profiles/, tools/k1_ab.py): a 50-crop launch is latency bound (an EMPTY 1600-workgroup
+// CDNA4 mapping.  Measured (profiles/r02_a_*: round 2's A/B of experimental variants, since removed): a 50-crop launch is latency bound (an EMPTY 1600-workgroup
 // launch already costs 1.76 us of the ~5 us), a 3200-crop launch is HBM bound (mixed read/write traffic at ~4.9 TB/s
 // real); the VALU work hides under both.  Hence:
 //  * lane = output column, wave = RPW consecutive output rows of one crop, workgroup = kK1Waves such waves, blockIdx.y = crop
@@ -80,7 +80,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     const ChainArgs& c = c_mut;
 
     // rows per wave: small launches are latency bound -> maximum parallelism (1 row per wave);
-    // large ones amortise the column geometry over more rows (measured: tools/k1_ab.py).
+    // large ones amortise the column geometry over more rows (measured: profiles/r02_*).
     int64_t planes_total = r.batch;
     if (segs) {
         planes_total = 0;

@@ -44,6 +44,16 @@ def _median_wall(fn, reps, dist, dev):
     return float(t.item())
 
 
+def rotation_length(frames_arg, n_crops, esz, one_gpu=False):
+    """(frames in rotation, read-touched bytes per frame, written bytes per frame) -- the SAME on every rank by construction: no argument
+    depends on the rank (the per-rank crop lists would give lengths that differ by one or two)."""
+    rd_frame, wr_frame = W.k1_touched_per_frame(n_crops, W.FRAME_6K, 0, esz)
+    n_frames = frames_arg or max(6, W.rotation_units(rd_frame))
+    if one_gpu and not frames_arg:
+        n_frames = 8  # (test mode: N ranks share one GPU and gloo moves the tensors through the host -- the timings mean nothing, keep it short)
+    return int(n_frames), rd_frame, wr_frame
+
+
 def main(a, dev, rank, world):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -68,8 +78,12 @@ def main(a, dev, rank, world):
     tensor_bytes = world * n * plane * esz
     per_frame_bytes = fw * fh * 3 + tensor_bytes
     # rotation sized from TOUCHED bytes (W.rotation_units: the read-touched set alone >= 2 x the Infinity Cache), as the N = 1 headline
-    rd_frame, wr_frame = W.k1_touched_per_frame(n, W.FRAME_6K, rank, esz)
-    n_frames = a.frames or max(6, W.rotation_units(rd_frame))
+    # (from RANK 0's crop lists on every rank: the rotation's length fixes the layout of the shared allocation -- tensors, then the flag
+    #  words -- that the peers map, so every rank must arrive at the same number; per-rank crop lists gave 46 / 47 / 48 and a memory fault)
+    n_frames, rd_frame, wr_frame = rotation_length(a.frames, n, esz, one_gpu)
+    agree = [None] * world
+    dist.all_gather_object(agree, int(n_frames))
+    assert len(set(agree)) == 1, "ranks disagree on the rotation's length: %r" % (agree,)
     # how many ranks / distinct GPUs this run really spans (RCCL has only ever seen one rank on this pool)
     seen = [None] * world
     dist.all_gather_object(seen, (str(getattr(torch.cuda.get_device_properties(dev), "uuid", None) or dev), dist.get_backend()))

@@ -78,3 +78,17 @@ def test_configs_block_and_compact_line():
     assert line["roofline"]["residency"]["frames"] == 96 and line["roofline"]["sweep_us"]["96"] == 2.49 and line["roofline"]["steps_per_launch"] == 16
     assert line["queue_opt_in"]["sweep_us"]["20"] == 2.15 and line["configs"]["cfg3"]["tick4_us"] == 5.9 and line["ticks_ok"] is True
     assert "not this run" in line["roofline"]["traffic_src"]
+
+
+def test_every_rank_rotates_over_the_same_number_of_frames():
+    """bench_dist.py: the rotation's length fixes the layout of the IPC-shared allocation the peers map (tensors, then flag words).  Sized
+    from each rank's OWN crop lists it differed between ranks (round 5: a memory fault at 4 ranks) -- the rule takes no rank."""
+    import inspect
+
+    import bench_dist
+    assert "rank" not in inspect.signature(bench_dist.rotation_length).parameters
+    n, rd, wr = bench_dist.rotation_length(0, 64, 4)
+    assert n == W.rotation_units(W.k1_touched_per_frame(64, W.FRAME_6K, 0, 4)[0]) and n * rd >= 2 * W.LLC_BYTES and wr == 64 * 3 * 4 * 64 * 128
+    per_rank = {W.rotation_units(W.k1_touched_per_frame(64, W.FRAME_6K, r, 4)[0]) for r in range(8)}
+    assert len(per_rank) > 1          # ... which is exactly why: the per-rank figures do differ
+    assert bench_dist.rotation_length(5, 64, 4)[0] == 5 and bench_dist.rotation_length(0, 64, 4, one_gpu=True)[0] == 8

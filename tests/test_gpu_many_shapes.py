@@ -330,3 +330,95 @@ def test_ticks_on_streams_that_come_and_go(oracle, device, lib):
                     checked += 1
         assert hip.hipStreamDestroy(s) == 0
     assert checked == 60
+
+
+def test_ticks_from_several_host_threads(oracle, device, lib):
+    """Four host threads tick at once: two of them share ONE stream (the stream's ring is handed out under its mutex: sequence numbers reach
+    the stream in order), the other two own a stream each; a different crop list per tick, nothing synchronised until the end."""
+    import threading
+
+    import torch
+    fh, fw = 360, 640
+    frames = [H.random_u8((fh, fw, 3), seed=1300 + k) for k in range(2)]
+    fts = [torch.from_numpy(f).to(device) for f in frames]
+    shared, own_a, own_b = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    plan = [(shared, 0), (shared, 1), (own_a, 2), (own_b, 3)]
+    n_ticks = 120
+    jobs = []  # per thread: [(chains, outs, meta)]
+    for _, tid in plan:
+        mine = []
+        for i in range(n_ticks):
+            chains, outs, meta = [], [], []
+            for k in range(2):
+                crops = H.random_crops(3 + (i + k + tid) % 6, fw, fh, seed=13000 + 1000 * tid + 10 * i + k, wmax=300, hmax=300)
+                ops, out, _ = _chain(torch, device, fts[k], crops, (64, 128), 3)
+                chains.append(ops)
+                outs.append(out)
+                meta.append((k, crops))
+            lowered = [cvgs.lower(ops) for ops in chains]
+            mine.append((lowered, cvgs.pack_chains(lowered), outs, meta))
+        jobs.append(mine)
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(len(plan))
+
+    def worker(stream, tid):
+        try:
+            start.wait()
+            for lowered, arr, _, _ in jobs[tid]:
+                capi.check(lib.cvgs_execute_many(arr, len(lowered), stream.cuda_stream))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=p) for p in plan]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for tid in range(len(plan)):
+        for i in (0, 1, 2, 9, 10, 11, 57, 118, 119):
+            _, _, outs, meta = jobs[tid][i]
+            for out, (k, crops) in zip(outs, meta):
+                H.assert_bit_exact(out.cpu().numpy(), _oracle(oracle, frames[k], crops, (64, 128), 3), "thread %d, tick %d" % (tid, i))
+
+
+def test_a_stream_destroyed_with_its_tick_still_pending(oracle, device, lib):
+    """hipStreamDestroy right behind a tick that has not started yet (a 3 ms occupancy kernel in front of it), then a NEW stream -- the runtime
+    may hand the handle out again -- ticks three times at once.  The ring is keyed by the handle: the old stream's table must not be
+    rewritten before its kernel has read it (every tick of every stream is checked)."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    fh, fw = 270, 480
+    frames = [H.random_u8((fh, fw, 3), seed=1400 + k) for k in range(2)]
+    fts = [torch.from_numpy(f).to(device) for f in frames]
+    torch.cuda.synchronize()
+    held, handles = [], set()
+    for i in range(30):
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        handles.add(s.value)
+        n_ticks = 1 if i % 2 == 0 else 3
+        if i % 2 == 0:  # the tick waits behind 3 ms of someone else's work on its stream
+            capi.check(lib.cvgs_debug_occupy(8, 64, 0, 3000.0, s))
+        for t in range(n_ticks):
+            chains, outs, meta = [], [], []
+            for k in range(2):
+                crops = H.random_crops(3 + (i + t + k) % 4, fw, fh, seed=14000 + 31 * i + 7 * t + k, wmax=200, hmax=200)
+                ops, out, _ = _chain(torch, device, fts[k], crops, (64, 128), 3)
+                chains.append(ops)
+                outs.append(out)
+                meta.append((k, crops))
+            lowered = [cvgs.lower(ops) for ops in chains]
+            arr = cvgs.pack_chains(lowered)
+            capi.check(lib.cvgs_execute_many(arr, len(lowered), s))
+            held.append((i, outs, meta, lowered, arr))
+        assert hip.hipStreamDestroy(s) == 0  # pending work completes; the handle may come back with the next create
+    torch.cuda.synchronize()
+    for i, outs, meta, _, _ in held:
+        for out, (k, crops) in zip(outs, meta):
+            H.assert_bit_exact(out.cpu().numpy(), _oracle(oracle, frames[k], crops, (64, 128), 3), "stream %d" % i)
+    assert len(handles) >= 1

@@ -707,7 +707,7 @@ public:
     // (t->mu held) a free table slot of >= bytes, or nullptr (every slot's kernel still pending after a bounded wait / out of memory)
     ManySlot* acquire(ManyStream* t, size_t bytes) {
         for (int attempt = 0; attempt < 2; ++attempt) {
-            const uint64_t done = *t->done_host;
+            const uint64_t done = __atomic_load_n((const uint64_t*)t->done_host, __ATOMIC_ACQUIRE); // the slot is rewritten AFTER this read
             for (ManySlot& sl : t->slots)
                 if (sl.cap >= bytes && sl.seq <= done) return &sl;
             size_t fitting = 0;
@@ -736,7 +736,7 @@ public:
                     if (sl.cap >= bytes && sl.seq < oldest) oldest = sl.seq;
                 if (oldest == ~0ull) return nullptr;
                 const auto t0 = std::chrono::steady_clock::now();
-                while (*t->done_host < oldest && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(4)) std::this_thread::yield();
+                while (__atomic_load_n((const uint64_t*)t->done_host, __ATOMIC_ACQUIRE) < oldest && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(4)) std::this_thread::yield();
             }
         }
         return nullptr;

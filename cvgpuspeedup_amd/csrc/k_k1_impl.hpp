@@ -90,29 +90,46 @@ __device__ __forceinline__ void k1_store_other(const K1Geom& g, const ChainArgs&
     }
 }
 
+// The kernel's leading SCALAR parameters: 14 dwords, the most the hardware preloads into user SGPRs with the dispatch
+// (-mllvm -amdgpu-kernarg-preload-count=14 in the Makefile; aggregates are never preloaded).  They repeat what the wave needs FIRST --
+// segment 0 (a single chain IS segment 0) and the target's extent -- so that the crop's descriptor can be requested without waiting for
+// a load of the argument block: one memory round trip less in front of the taps.  Firmware without the feature runs the compiler's
+// compatibility prologue (plain loads of the same values).
+#define K1_PRELOADED_PARAMS                                                                                                               \
+    const PlaneParams *pre_table, uint8_t *pre_out, int64_t pre_img_stride, int64_t pre_ch_stride, int32_t pre_batch, int32_t pre_used,  \
+        uint32_t pre_col_tiles, int32_t pre_dst_w, int32_t pre_dst_h, int32_t pre_out_w
 // MIR: the instantiations that also write cvgs_write_desc.mirrors (kept out of the others' code)
 template <int CN, int NPL, int RPW, class Prog, int SRC = SRC_U8, typename OT = float, int WM = WM_PLANAR, bool MIR = false>
-__global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(const K1Args<NPL> a, const K1Geom g) {
+__global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PARAMS, const K1Args<NPL> a, const K1Geom g) {
     constexpr int EB = elem_bytes<SRC>;
     constexpr int WINB = SRC == SRC_F32 ? 2 * CN * 4 : 8 * EB; // bytes per tap window (fp32: exactly the pixel pair)
     const ChainArgs& c = a.c;
     const int z = (int)blockIdx.y;
-    // ---- one batch of scalar loads: geometry, the crop's parameters, the program operands come in together ----
-    const int dst_w = g.dst_w, dst_h = g.dst_h, W = g.out_w;
-    const uint32_t col_tiles = g.col_tiles;
-    const int64_t img_stride = g.img_stride, ch_stride = g.ch_stride;
+    // ---- one batch of scalar loads: the crop's parameters, the program operands come in together; what the wave needs to ask for its
+    // crop's descriptor (segment 0's table, the target's extent) arrives in SGPRs with the dispatch (kernel-argument preload) ----
+    const int dst_w = pre_dst_w, dst_h = pre_dst_h, W = pre_out_w;
+    const uint32_t col_tiles = pre_col_tiles;
+    const int64_t img_stride = pre_img_stride, ch_stride = pre_ch_stride;
     int used;
     OT* out_base;
     PlaneParams P;
     if constexpr (NPL == 0) {
-        const ManySeg sg = a.seg[blockIdx.z];
-        if (z >= sg.batch) return; // a shorter chain of the fused launch
-        used = sg.used;
-        out_base = (OT*)sg.out;
-        P = sg.table[z < used ? z : 0];
+        const PlaneParams* table = pre_table;
+        int batch = pre_batch;
+        used = pre_used;
+        out_base = (OT*)pre_out;
+        if (blockIdx.z != 0) { // the other chains of a fused launch: their segment comes from the argument block
+            const ManySeg sg = a.seg[blockIdx.z];
+            table = sg.table;
+            batch = sg.batch;
+            used = sg.used;
+            out_base = (OT*)sg.out;
+        }
+        if (z >= batch) return; // a shorter chain of the fused launch
+        P = table[z < used ? z : 0];
     } else {
-        used = g.used;
-        out_base = (OT*)g.out;
+        used = pre_used;
+        out_base = (OT*)pre_out;
         P = a.planes[z];
     }
     OT* const out2_base = (OT*)g.out2;
@@ -365,12 +382,24 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
             g.done_value = dw.value;
         }
     }
+    // segment 0 / the single chain, repeated in front of the argument block (K1_PRELOADED_PARAMS)
+    const PlaneParams* pre_table = nullptr;
+    uint8_t* pre_out = (uint8_t*)g.out;
+    int32_t pre_batch = c.read.batch, pre_used = g.used;
+    if constexpr (NPL == 0) {
+        pre_table = a.seg[0].table;
+        pre_out = a.seg[0].out;
+        pre_batch = a.seg[0].batch;
+        pre_used = a.seg[0].used;
+    }
     StopEventSlot& stop = tls_stop_event();
     if (stop.event && !stop.used) {
         stop.used = true;
-        hipExtLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, nullptr, (hipEvent_t)stop.event, 0u, a, g);
+        hipExtLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, nullptr, (hipEvent_t)stop.event, 0u,
+                              pre_table, pre_out, g.img_stride, g.ch_stride, pre_batch, pre_used, g.col_tiles, g.dst_w, g.dst_h, g.out_w, a, g);
     } else {
-        hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, a, g);
+        hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream,
+                           pre_table, pre_out, g.img_stride, g.ch_stride, pre_batch, pre_used, g.col_tiles, g.dst_w, g.dst_h, g.out_w, a, g);
     }
     return hipGetLastError();
 }

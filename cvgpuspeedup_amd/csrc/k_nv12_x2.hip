@@ -68,13 +68,19 @@ __device__ __forceinline__ N2Rgb n2_tap(f32x2 Y, f32x2 U, f32x2 V, const YuvK& k
     return t;
 }
 
+// The kernel's leading SCALAR parameters (14 dwords: what the hardware preloads into user SGPRs with the dispatch; Makefile: PRELOAD):
+// surface 0 and the target's extent -- a one-surface launch (cfg #3) asks for its taps without waiting for any load of the argument block.
+#define N2_PRELOADED_PARAMS                                                                                                          \
+    const uint8_t *p0_data, int32_t p0_w, int32_t p0_h, int32_t p0_step, int32_t p0_uv_off, float p0_fx, float p0_fy, int32_t pre_dst_w, \
+        int32_t pre_dst_h, int32_t pre_out_w, int32_t pre_yuv_range, int32_t pre_yuv_primaries, int32_t pre_yuv_vu
 template <class Prog, int RPW>
-__global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(const N2Args a) {
+__global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS, const N2Args a) {
     const int z = (int)blockIdx.z;
-    const N2Plane P = a.plane[z];
-    const int dst_w = a.dst_w, dst_h = a.dst_h, W = a.out_w;
-    const int yuv_range = a.yuv_range, vu = a.yuv_vu;
-    const YuvK yk = yuv_matrix(yuv_range, a.yuv_primaries, CVGS_YUV_NV12);
+    N2Plane P = N2Plane{p0_data, p0_w, p0_h, p0_step, p0_uv_off, p0_fx, p0_fy};
+    if (z != 0) P = a.plane[z];
+    const int dst_w = pre_dst_w, dst_h = pre_dst_h, W = pre_out_w;
+    const int yuv_range = pre_yuv_range, vu = pre_yuv_vu;
+    const YuvK yk = yuv_matrix(yuv_range, pre_yuv_primaries, CVGS_YUV_NV12);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
     const int col_tile = (int)blockIdx.x;
@@ -259,12 +265,14 @@ int launch_nv12_x2(const ChainArgs& c, const PlaneParams* planes, int n_planes, 
     const unsigned col_tiles = (unsigned)((r.dst_w + 127) / 128), row_groups = (unsigned)((r.dst_h + kN2Waves * rpw - 1) / (kN2Waves * rpw));
     const dim3 grid(col_tiles, row_groups, (unsigned)r.batch), block(64 * kN2Waves);
     hipStream_t s = (hipStream_t)stream;
+    const N2Plane& p0 = a.plane[0];
+#define N2_PRELOADED_VALUES p0.data, p0.w, p0.h, p0.step, p0.uv_off, p0.fx, p0.fy, a.dst_w, a.dst_h, a.out_w, a.yuv_range, a.yuv_primaries, a.yuv_vu
     if (prog_swap) {
-        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, kN2Rows>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, 1>), grid, block, 0, s, a);
+        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, kN2Rows>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
+        else hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, 1>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
     } else {
-        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, kN2Rows>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, 1>), grid, block, 0, s, a);
+        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, kN2Rows>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
+        else hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, 1>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : -(int)e - 1000;

@@ -67,3 +67,16 @@ def test_hot_kernels_keep_full_occupancy(kernels):
         assert found, "hot kernel not in the library any more: " + frag
         for k in found:
             assert k["vgpr"] <= 64 and k["lds"] <= 20480, (KR.demangle([k["name"]])[0][:160], k["vgpr"], k["lds"])
+
+
+def test_k1_and_frame_size_k4_kernels_get_their_leading_scalars_preloaded(kernels):
+    """k1_resize_split / k4_nv12_x2 take 14 leading scalar parameters that the hardware delivers in user SGPRs with the dispatch
+    (csrc/Makefile: PRELOAD; DESIGN 9: tick of 16 39.58 -> 38.97 us).  A build that loses the flag is still correct and 1.5 % slower:
+    the kernel descriptor says which one this is."""
+    hot = [k for k in kernels if "k1_resize_split" in k["name"] or "k4_nv12_x2" in k["name"]]
+    assert len(hot) > 100
+    wrong = [k["name"] for k in hot if k["preload"] != 14]
+    assert not wrong, KR.demangle(wrong[:5])
+    # ... and nothing else asks for it (the flag is scoped to those translation units)
+    others = [k["name"] for k in kernels if k["preload"] and k not in hot]
+    assert not others, KR.demangle(others[:5])

@@ -128,6 +128,7 @@ def kernels_of(lib_path):
             kd = co[file_off(kd_va):file_off(kd_va) + 64]
             # kernel descriptor: compute_pgm_rsrc2 at byte 52, kernel_code_properties (u16) at byte 56
             props, = struct.unpack_from("<H", kd, 56)
+            preload, = struct.unpack_from("<H", kd, 58)  # kernarg_preload: length in dwords (bits 0-6), offset (bits 7-15)
             out.append({
                 "name": k[".name"],
                 "lds": k[".group_segment_fixed_size"],
@@ -140,6 +141,7 @@ def kernels_of(lib_path):
                 "dispatch_ptr": bool(props & 0x2),   # ENABLE_SGPR_DISPATCH_PTR
                 "queue_ptr": bool(props & 0x4),      # ENABLE_SGPR_QUEUE_PTR
                 "kernarg": k[".kernarg_segment_size"],
+                "preload": preload & 0x7f,           # leading kernel-argument dwords delivered in user SGPRs with the dispatch
             })
     return out
 

@@ -28,7 +28,7 @@ static void testCircularBatchRead(hipStream_t stream) {
     circularBatchRead.params.first = FIRST;
     for (uint i = 0; i < BATCH; ++i) {
         fk::Ptr2D<uchar3> temp(WIDTH, HEIGHT);
-        std::vector<uchar3> h((size_t)temp.dims().pitch / sizeof(uchar3) * HEIGHT, fk::make_<uchar3>(i, i, i));
+        std::vector<uchar3> h(((size_t)temp.dims().pitch * HEIGHT + sizeof(uchar3) - 1) / sizeof(uchar3), fk::make_<uchar3>(i, i, i)); // (a 256-byte pitch is not a whole number of 3-byte pixels)
         HIP_OK(hipMemcpy(temp.ptr().data, h.data(), (size_t)temp.dims().pitch * HEIGHT, hipMemcpyHostToDevice));
         inputs.push_back(temp);
         circularBatchRead.params.opData[i].params = temp;

@@ -39,6 +39,21 @@ def run(a):
     m = B.measure(wl, max(16, 256 // M), 4, target_s=0.15, min_replays=20, est_step_s=2.5e-6 * M)
     out["graph"] = {"us_per_tick": round(m["step_s"] * 1e6, 3), "us_per_frame": round(m["step_s"] * 1e6 / M, 4), "frac": round(alg / m["step_s"] / 1e9 / 8000.0, 4),
                     "p10_us": round(m["p10_s"] * 1e6, 3), "p90_us": round(m["p90_s"] * 1e6, 3)}
+    # ---- eager, the SAME device tables (what eager launches cost by themselves: the difference to the next leg is the host-descriptor path --
+    # table build, the kernel reading its descriptors from pinned host memory) ----
+    n_ticks_d = max(64, 2048 // M)
+    for i in range(n_ticks_d):
+        wl.launch(i, s)
+    side.synchronize()
+    walls = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_ticks_d):
+            wl.launch(i, s)
+        side.synchronize()
+        walls.append((time.perf_counter() - t0) / n_ticks_d)
+    out["eager_device_tables"] = {"us_per_tick_wall": round(float(np.median(walls)) * 1e6, 3), "us_per_frame_wall": round(float(np.median(walls)) * 1e6 / M, 4)}
     del wl
     torch.cuda.empty_cache()
     # ---- eager, host descriptors, producer on the stream ----

@@ -1029,10 +1029,20 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
     //  * a batch beyond the grid's y range;
     //  * chains that are not independent (one writes where another writes or reads): the fused launch runs them concurrently,
     //    n sequential cvgs_execute calls would not -- keep the sequential meaning.
+    // host-described K1 chains of u8 pixels with 3 / 4 channels, at most kManyInlineLarge planes in all: segments AND planes travel in the
+    // kernel arguments (cvgs_device.h: KernArgsManyInline) -- no table slot, nothing to recycle, capturable
+    bool inline_many = false;
     if (fusable) {
         const bool tables0 = (chains[0].read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
+        static const bool inline_ok = [] { const char* e = getenv("CVGS_MANY_INLINE"); return e ? e[0] != '0' : true; }();
+        if (!tables0 && inline_ok && chains[0].read.kind == CVGS_READ_RESIZE_LINEAR && CVGS_TYPE_CN(chains[0].read.src_type) >= 3 &&
+            CVGS_TYPE_DEPTH(chains[0].read.src_type) == CVGS_DEPTH_8U) {
+            size_t planes = 0;
+            for (int i = 0; i < n; ++i) planes += (size_t)(chains[i].read.batch > 0 ? chains[i].read.batch : 0);
+            inline_many = planes <= (size_t)cvgs::kManyInlineLarge;
+        }
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (!tables0 && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) fusable = false;
+        if (!tables0 && !inline_many && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) fusable = false;
         for (int i = 0; fusable && i < n; ++i)
             if (chains[i].read.batch < 1 || chains[i].read.batch > 65535) fusable = false;
         if (fusable) {
@@ -1070,7 +1080,9 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         ManySlot* mslot = nullptr;
         std::unique_lock<std::mutex> ms_lock;
         size_t ms_used = 0;
-        if (fusable && !tables) {
+        static thread_local std::vector<PlaneParams> inline_planes; // inline_many: every chain's planes, in chain order
+        inline_planes.clear();
+        if (fusable && !tables && !inline_many) {
             const size_t bytes = total_planes * sizeof(PlaneParams) + 16 * (size_t)n;
             static const bool progress_word = [] { const char* e = getenv("CVGS_MANY_PROGRESS_WORD"); return e ? e[0] != '0' : true; }();
             if (progress_word && (ms = many_pool().get(stream, stream_device(stream))) != nullptr) {
@@ -1097,7 +1109,10 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             segs[i].used = L.args.read.used;
             segs[i].out = L.args.write.data;
             if (tables) segs[i].table = L.args.read.table;
-            else if (mslot) {
+            else if (inline_many) {
+                segs[i].table = (const PlaneParams*)(uintptr_t)inline_planes.size(); // the chain's first index into the argument block's planes
+                inline_planes.insert(inline_planes.end(), L.planes.data(), L.planes.data() + L.planes.size());
+            } else if (mslot) {
                 const size_t b = L.planes.size() * sizeof(PlaneParams);
                 std::memcpy((uint8_t*)mslot->host + ms_used, L.planes.data(), b);
                 segs[i].table = (const PlaneParams*)((uint8_t*)mslot->host_dev + ms_used);
@@ -1105,13 +1120,14 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             } else segs[i].table = (const PlaneParams*)up.put(L.planes.data(), L.planes.size() * sizeof(PlaneParams));
         }
         if (fusable) {
-            if (!tables && !mslot) {
+            if (!tables && !mslot && !inline_many) {
                 rc = up.flush();
                 if (rc) return rc;
             }
+            if (inline_many && inline_planes.size() > (size_t)cvgs::kManyInlineLarge) return fail(CVGS_ERR_INVALID, "inline tick: more planes than counted");
             ChainArgs c = L0.args;
             c.read.batch = max_batch;
-            c.read.table = segs[0].table; // non-null: the table variants
+            c.read.table = inline_many ? nullptr : segs[0].table; // non-null: the table variants; null + segments: planes in the arguments
             cvgs::DoneWordSlot& dw = cvgs::tls_done_word();
             dw = cvgs::DoneWordSlot{};
             if (mslot) { // this launch is number next_seq of its stream: when it starts, number next_seq - 1 has finished
@@ -1119,7 +1135,7 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
                 dw.value = ms->next_seq - 1;
             }
             rc = k4 ? launch_nv12(c, nullptr, 0, 1 << 30, segs, n, stream, false, nullptr)
-                    : launch_k1(c, nullptr, 0, MirrorArgs{}, segs, n, stream, false, nullptr);
+                    : launch_k1(c, inline_many ? inline_planes.data() : nullptr, inline_many ? (int)inline_planes.size() : 0, MirrorArgs{}, segs, n, stream, false, nullptr);
             const bool reported = dw.used;
             dw = cvgs::DoneWordSlot{};
             if (rc != 1) return fail(CVGS_ERR_HIP, "fused kernel launch failed");

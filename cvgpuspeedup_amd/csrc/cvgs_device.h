@@ -148,6 +148,20 @@ struct KernArgsMany {
     ManySeg seg[CVGS_MAX_CHAINS];
 };
 static_assert(sizeof(KernArgsMany) <= 4096 - 256, "segment block + K1Geom must fit the kernel-argument block");
+// Fused chains described on the HOST (fresh crop lists every tick): the planes of ALL chains travel in the kernel arguments behind the
+// segment block (ManySeg::table then holds the chain's first index into `planes`, not an address).  The runtime places kernel arguments
+// in device memory, so the kernel reads its descriptors as it reads a device table -- a pinned host table costs every XCD a PCIe round
+// trip per crop and 1.75 us per 16 x 50-crop tick (tools/bench_tick.py) -- and the launch can be captured.  Two block sizes: the host
+// pays for the bytes of the DECLARED block (tools/probes/big_kernarg_probe.cpp: 16 KB + 1.1 us, 52 KB + 5 us per launch; a launch may
+// not supply less than the kernel declares: tools/probes/partial_kernarg_probe.cpp).
+static constexpr int kManyInlineSmall = 256, kManyInlineLarge = 1024;
+template <int N>
+struct KernArgsManyInline {
+    ChainArgs c;
+    ManySeg seg[CVGS_MAX_CHAINS];
+    PlaneParams planes[N];
+};
+static_assert(sizeof(KernArgsManyInline<kManyInlineSmall>) <= 16384 && sizeof(KernArgsManyInline<kManyInlineLarge>) <= 53248, "inline tick blocks: 16 KB / 52 KB");
 
 // CV_64F chains: the double operands travel next to the float ones, with a small inline plane block.
 struct Prog64Args {

@@ -51,9 +51,12 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     // the interpreted kernel's business
     if (mirrors.n > 0 && (r.depth != CVGS_DEPTH_8U || r.cn < 3 || r.table || segs || (c_in.write.depth != CVGS_DEPTH_32F && c_in.write.depth != CVGS_DEPTH_16F)))
         return 0;
-    if (segs && (!r.table || n_segs < 1 || n_segs > CVGS_MAX_CHAINS)) return 0;
+    if (segs && (n_segs < 1 || n_segs > CVGS_MAX_CHAINS)) return 0;
+    // fused chains without a table: segments AND planes in the kernel arguments (KernArgsManyInline; u8 sources, 3 / 4 channels)
+    const bool inline_many = segs && !r.table;
+    if (inline_many && (!inline_planes || n_inline < 1 || n_inline > kManyInlineLarge || r.depth != CVGS_DEPTH_8U || few)) return 0;
     // more than CVGS_KERNARG_PLANES descriptors in the kernel arguments: the 3- / 4-channel planar-tensor kernels only
-    if (!r.table && n_inline > CVGS_KERNARG_PLANES && (n_inline > kKernargPlanesBig || !planar || few || segs)) return 0;
+    if (!r.table && !inline_many && n_inline > CVGS_KERNARG_PLANES && (n_inline > kKernargPlanesBig || !planar || few)) return 0;
     const bool f16 = c_in.write.depth == CVGS_DEPTH_16F;
     const bool u8out = c_in.write.depth == CVGS_DEPTH_8U;
     const bool i16out = c_in.write.depth == CVGS_DEPTH_16U || c_in.write.depth == CVGS_DEPTH_16S;

@@ -54,7 +54,8 @@ struct K1Geom {
 
 // NPL > 0: the planes travel in the kernel arguments.  NPL == 0: they live in device tables, one segment per fused
 // chain (cvgs_execute_many; a single chain with a resident table is one segment), blockIdx.z = segment.
-template <int NPL> using K1Args = std::conditional_t<NPL == 0, KernArgsMany, KernArgs<NPL>>;
+// NPL < 0: the same segments with the planes of all chains INSIDE the kernel arguments (KernArgsManyInline<-NPL>: fused chains described on the host).
+template <int NPL> using K1Args = std::conditional_t<NPL == 0, KernArgsMany, std::conditional_t<(NPL < 0), KernArgsManyInline<(NPL < 0 ? -NPL : 1)>, KernArgs<(NPL > 0 ? NPL : 1)>>>;
 
 // packed pixels / separate pitched planes: one output pixel of row y, column x, plane z
 // WIDE: the throughput regime (4 rows per wave, whole-frame outputs), where the store instruction count matters; small
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
     int used;
     OT* out_base;
     PlaneParams P;
-    if constexpr (NPL == 0) {
-        const PlaneParams* table = pre_table;
+    if constexpr (NPL <= 0) {
+        const PlaneParams* table = pre_table; // NPL < 0: the chain's first index into a.planes
         int batch = pre_batch;
         used = pre_used;
         out_base = (OT*)pre_out;
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
             out_base = (OT*)sg.out;
         }
         if (z >= batch) return; // a shorter chain of the fused launch
-        P = table[z < used ? z : 0];
+        if constexpr (NPL == 0) P = table[z < used ? z : 0];
+        else P = a.planes[(uint32_t)(uintptr_t)table + (uint32_t)(z < used ? z : 0)];
     } else {
         used = pre_used;
         out_base = (OT*)pre_out;
@@ -334,6 +336,9 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         for (int i = n_inline; i < NPL; ++i) a.planes[i] = PlaneParams{};
     } else {
         const LaunchExtra& x = tls_extra();
+        if constexpr (NPL < 0) { // fused chains with host descriptors: every chain's planes behind the segments (segs[i].table = first index)
+            for (int i = 0; i < n_inline && i < -NPL; ++i) a.planes[i] = inline_planes[i];
+        }
         if (x.segs) {
             grid_z = (unsigned)x.n_segs;
             for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < x.n_segs ? x.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
@@ -386,7 +391,7 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     const PlaneParams* pre_table = nullptr;
     uint8_t* pre_out = (uint8_t*)g.out;
     int32_t pre_batch = c.read.batch, pre_used = g.used;
-    if constexpr (NPL == 0) {
+    if constexpr (NPL <= 0) {
         pre_table = a.seg[0].table;
         pre_out = a.seg[0].out;
         pre_batch = a.seg[0].batch;
@@ -462,6 +467,12 @@ template <int CN, class Prog, int SRC, typename OT>
 static hipError_t launch_npl(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
                              hipStream_t s) {
     if (table) return launch_rpw<CN, 0, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
+    if constexpr (SRC == SRC_U8) { // cvgs_execute_many on host descriptors (u8 sources, 3 / 4 channels): segments + ALL planes in the arguments
+        if (tls_extra().segs) {
+            if (ni <= kManyInlineSmall) return launch_rpw<CN, -kManyInlineSmall, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
+            return launch_rpw<CN, -kManyInlineLarge, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
+        }
+    }
     if (ni > CVGS_KERNARG_PLANES) return launch_rpw<CN, kKernargPlanesBig, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s); // 16 KB argument block
     return launch_rpw<CN, CVGS_KERNARG_PLANES, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
 }

@@ -294,13 +294,18 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * kernel code; tests/test_gpu_many.py).  Any other set of chains is executed one by one, in order -- and so is a set whose
  * chains are NOT independent (two chains write overlapping bytes, or a host-described source view of one -- chroma rows of a 4:2:0
  * surface included; chains whose plane table lives on the device are NOT checked: the caller vouches for them -- lies inside another's
- * output: fused chains run concurrently), a set with a batch beyond 65535, and host descriptors under stream capture.  Host
- * descriptors of a fused launch are written into a pinned buffer of the stream's own ring that the kernel reads in place (no copy; round 5:
+ * output: fused chains run concurrently), a set with a batch beyond 65535, and staged host descriptors under stream capture.  Host
+ * descriptors of fused 8-bit pixel chains with 3 / 4 channels and at most 1024 planes in all (a tick of 16 cameras x 50 crops is 800) travel
+ * INSIDE the fused launch's kernel arguments (a 16 KB block up to 256 planes, 52 KB beyond): nothing is staged, nothing is recycled, the
+ * call allocates nothing and can be captured as it is; the kernel reads them from device memory (the runtime's argument pool) instead of
+ * fetching a pinned table over PCIe (eager tick of 16 x 50 crops: 40.9 -> 39.9 us; the host pays 1-5 us more per call for the larger
+ * argument block).  Every other fused launch with host
+ * descriptors writes them into a pinned buffer of the stream's own ring that the kernel reads in place (no copy; round 5:
  * the fused kernel itself stores the stream's progress into a pinned word when it starts, and a slot is recycled once that word has reached
  * its launch -- no HIP event behind the launch; a host 8 such launches ahead of ONE stream waits for the oldest of them, at most a few
  * milliseconds, then falls back to the event-tracked descriptor scratch; a stream handle the runtime hands out again after
  * hipStreamDestroy continues the old ring: destroy a stream only once its fused launches have finished); pass device plane tables to
- * make the fused call capturable; at most
+ * make such a fused call capturable; at most
  * CVGS_MAX_CHAINS chains per call.  The reference's closest spelling is the batch sweep of
  * tests/batchresize/test_batchresize_x_split3D.cu:384-392 (one launch per BATCH value).                          */
 int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stream_t stream);

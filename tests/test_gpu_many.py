@@ -96,17 +96,34 @@ def test_execute_many_is_one_launch_and_capturable_with_tables(device, lib):
         torch.cuda.synchronize()
     for m in range(len(outs)):
         H.assert_bit_exact(outs[m].cpu().numpy(), want[m], "captured execute_many, chain %d" % m)
-    # host descriptors that do not fit the kernel arguments (> 320 planes per chain for this shape) need a staged table: refused
-    # under capture, loudly -- chain by chain (chains whose planes travel in the kernel arguments ARE capturable one by one:
-    # test_execute_many_with_host_descriptors_is_capturable_chain_by_chain)
+    # host descriptors: up to 1024 planes in all travel in the kernel arguments of the fused launch (round 5) -- capturable as it is
     chains2, outs2, _, keep2 = _make(device, 2, 330, seed=600)
     low2 = [cvgs.lower(ops) for ops in chains2]
     arr2 = cvgs.pack_chains(low2)
     with torch.cuda.stream(side):
+        capi.check(lib.cvgs_execute_many(arr2, 2, side.cuda_stream))
+        torch.cuda.synchronize()
+        want2 = [o.cpu().numpy() for o in outs2]
+        for o in outs2:
+            o.fill_(0.0)
         g2 = torch.cuda.CUDAGraph()
-        rc = 0
         with torch.cuda.graph(g2):
-            rc = lib.cvgs_execute_many(arr2, 2, torch.cuda.current_stream().cuda_stream)
+            capi.check(lib.cvgs_execute_many(arr2, 2, torch.cuda.current_stream().cuda_stream))
+        g2.replay()
+        torch.cuda.synchronize()
+    for m in range(2):
+        H.assert_bit_exact(outs2[m].cpu().numpy(), want2[m], "captured host-described execute_many, chain %d" % m)
+    # beyond that (4 x 330 planes) the table would be staged, and a chain of 330 planes does not fit the kernel arguments on its own either:
+    # refused under capture, loudly (chains of <= 320 planes ARE capturable one by one:
+    # test_execute_many_with_host_descriptors_is_capturable_chain_by_chain)
+    chains3, outs3, _, keep3 = _make(device, 4, 330, seed=610)
+    low3 = [cvgs.lower(ops) for ops in chains3]
+    arr3 = cvgs.pack_chains(low3)
+    with torch.cuda.stream(side):
+        g3 = torch.cuda.CUDAGraph()
+        rc = 0
+        with torch.cuda.graph(g3):
+            rc = lib.cvgs_execute_many(arr3, 4, torch.cuda.current_stream().cuda_stream)
         assert rc == capi.ERR_UNSUPPORTED, lib.cvgs_last_error()
 
 

@@ -278,18 +278,74 @@ print("DIGEST", h.hexdigest())
 """
 
 
-def test_progress_word_and_event_tracked_tables_write_the_same_bytes():
-    """the same three ticks in two fresh processes: tables recycled through the launch's progress word (the default) and through the
-    descriptor scratch's HIP events (CVGS_MANY_PROGRESS_WORD=0): one digest"""
+def test_inline_ring_and_event_tracked_tables_write_the_same_bytes():
+    """the same ticks in three fresh processes: descriptors inside the kernel arguments (the default for <= 1024 planes), in the stream's
+    table ring recycled through the launch's progress word (CVGS_MANY_INLINE=0), and in the event-tracked descriptor scratch
+    (+ CVGS_MANY_PROGRESS_WORD=0): one digest"""
     res = {}
-    for mode in ("1", "0"):
+    for mode, extra in (("inline", {}), ("ring", {"CVGS_MANY_INLINE": "0"}), ("events", {"CVGS_MANY_INLINE": "0", "CVGS_MANY_PROGRESS_WORD": "0"})):
         env = dict(os.environ)
-        env["CVGS_MANY_PROGRESS_WORD"] = mode
+        env.update(extra)
         p = subprocess.run([sys.executable, "-c", _GRID_VS_TICK % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("DIGEST")]
         assert line, p.stderr[-2000:]
         res[mode] = line[-1].split()[1]
-    assert res["1"] == res["0"]
+    assert res["inline"] == res["ring"] == res["events"]
+
+
+def test_the_table_ring_still_serves_this_file():
+    """Ticks of up to 1024 host-described planes travel in the kernel arguments since round 5; larger ones, K4 ticks and 1-2 channel sources
+    keep the per-stream table ring.  The tests of this file that were written for the ring (slot recycling over hundreds of ticks, two
+    streams, four host threads, streams that come and go or are destroyed with work pending) run again with CVGS_MANY_INLINE=0."""
+    env = dict(os.environ)
+    env["CVGS_MANY_INLINE"] = "0"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "recycle or two_streams or host_threads or come_and_go or destroyed or segment_table_size"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-1000:]
+
+
+@pytest.mark.parametrize("planes_per_chain,n_chains", [(16, 16), (16, 17), (64, 16), (60, 17), (64, 17)])
+def test_ticks_around_the_inline_block_sizes(oracle, device, lib, planes_per_chain, n_chains):
+    """256 / 272 / 1024 / 1020 / 1088 planes in all: the small block's last fit, the large block's first, its last fits, the ring's first"""
+    import torch
+    took, *_ = _tick(torch, device, oracle, lib, n_chains, seed=300 + n_chains + planes_per_chain, crops_lo=planes_per_chain, crops_hi=planes_per_chain,
+                     frame_hw=(360, 640), dst=(32, 48))
+    assert took == 1
+
+
+def test_a_host_described_tick_is_capturable(oracle, device, lib):
+    """descriptors in the kernel arguments: the fused launch of host-described chains is captured into a graph as it is (round 4: refused)
+    and replays; a tick beyond 1024 planes under capture runs chain by chain (<= 64 planes each in kernel arguments) -- same bits"""
+    import torch
+    for n_chains, per in ((6, 20), (20, 60)):  # 120 planes: one fused launch; 1200 planes: chain by chain under capture
+        fh, fw = 360, 640
+        chains, outs, refs, keep = [], [], [], []
+        for m in range(n_chains):
+            frame = H.random_u8((fh, fw, 3), seed=1500 + m)
+            crops = H.random_crops(per, fw, fh, seed=1510 + m, wmax=300, hmax=300)
+            ft = torch.from_numpy(frame).to(device)
+            ops, out, _ = _chain(torch, device, ft, crops, (32, 48), 3)
+            chains.append(ops)
+            outs.append(out)
+            keep.append(ft)
+            refs.append(_oracle(oracle, frame, crops, (32, 48), 3))
+        lowered = [cvgs.lower(ops) for ops in chains]
+        arr = cvgs.pack_chains(lowered)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                capi.check(lib.cvgs_execute_many(arr, len(lowered), torch.cuda.current_stream().cuda_stream))
+            for rep in range(2):
+                for o in outs:
+                    o.fill_(-5.0)
+                g.replay()
+                torch.cuda.synchronize()
+                for m in range(n_chains):
+                    H.assert_bit_exact(outs[m].cpu().numpy(), refs[m], "captured host-described tick of %d chains, replay %d, chain %d" % (n_chains, rep, m))
 
 
 def test_ticks_on_streams_that_come_and_go(oracle, device, lib):

@@ -48,6 +48,7 @@ template <int NPL> using K4Args = std::conditional_t<NPL == 0, KernArgsMany, Ker
 #define CVGS_K4_WPB 4
 #endif
 constexpr int kK4Waves = CVGS_K4_WPB;
+constexpr int kK4TileRow = 80; // floats between the rows of a wave's LDS tile (64 + padding: the 16-byte reads of a row group do not collide)
 
 using N12SwapMulSubDiv = ProgSwapMulSubDiv; // the compile-time program of k_taps.hpp (incl. the division by the uniform divisor)
 
@@ -210,6 +211,20 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     const uint32_t uo = PL ? (uint32_t)min(c1, ((P.w - 1) >> 1) - 1) : (uint32_t)min(2 * c1, P.w - 4) * kSB;
     const int ush = PL ? (c1 - (int)uo) * 8 : (2 * c1 * kSB - (int)uo) * 8;
     const bool same_pair = c2 == c1;
+    // 8-bit interleaved chroma: v_perm_b32 selectors that pick the pixel's four tap samples {a0, a1, b0, b1} (row a / b, tap 0 / 1) out of its two
+    // 2-byte luma windows / its two 4-byte chroma windows -- what was a shift, a mask and a select per sample: the luma window clamped back at
+    // the right edge (then both taps are its second byte), the chroma window clamped back at the last pair, taps sharing a chroma pair, NV21's
+    // byte order (k_nv12_x2.hip and the queue's k4q_rows pick their samples the same way)
+    [[maybe_unused]] uint32_t sel_y = 0, sel_u = 0, sel_v = 0;
+    if constexpr (!S16 && !PL) {
+        sel_y = edge ? 0x05050101u : 0x05040100u;
+        const uint32_t pr0 = 2 * c1 != (int)uo ? 2u : 0u; // byte of tap 0's pair inside the chroma window
+        const uint32_t pr1 = same_pair ? pr0 : 2u;        // ... of tap 1's
+        const uint32_t sel_c = pr0 | (pr1 << 8) | ((4u + pr0) << 16) | ((4u + pr1) << 24);
+        const bool vu_first = c.read.yuv_layout == CVGS_YUV_NV21;
+        sel_u = sel_c + (vu_first ? 0x01010101u : 0u);
+        sel_v = sel_c + (vu_first ? 0u : 0x01010101u);
+    }
     const gptr_u8 base = (gptr_u8)P.data;
     const size_t step = (size_t)P.step;
     const gptr_u8 uvp = base + (size_t)P.uv_off; // crops of a surface carry their own luma -> chroma offset
@@ -222,6 +237,10 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     uint32_t vva[RPW], vvb[RPW]; // planar chroma: the windows of the second plane
     float wya[RPW], wyb[RPW];
     bool in_y[RPW];
+    // four rows per wave into a planar fp32 tensor: a full 64-column tile with all four rows inside the target leaves through the LDS transpose
+    constexpr bool kRowsTile = RPW == 4 && std::is_same_v<OT, float> && !WIN;
+    [[maybe_unused]] const bool tile_rows = kRowsTile && !packed && !g.out2 && col_tile * 64 + 63 < dst_w && row0 + RPW <= dst_h;
+    [[maybe_unused]] float tv[RPW][4];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         // row geometry (wave-uniform)
@@ -291,6 +310,12 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
             fu[0] = (float)((pa0 & 0xffffu) >> 6); fu[1] = (float)((pa1 & 0xffffu) >> 6);
             fu[2] = (float)((pb0 & 0xffffu) >> 6); fu[3] = (float)((pb1 & 0xffffu) >> 6);
             fv[0] = (float)(pa0 >> 22); fv[1] = (float)(pa1 >> 22); fv[2] = (float)(pb0 >> 22); fv[3] = (float)(pb1 >> 22);
+        } else if constexpr (!PL) {
+            const uint32_t ly = __builtin_amdgcn_perm(vyb[j], vya[j], sel_y);
+            const uint32_t lu = __builtin_amdgcn_perm((uint32_t)vub[j], (uint32_t)vua[j], sel_u), lv = __builtin_amdgcn_perm((uint32_t)vub[j], (uint32_t)vua[j], sel_v);
+            fy[0] = (float)(ly & 0xffu); fy[1] = (float)((ly >> 8) & 0xffu); fy[2] = (float)((ly >> 16) & 0xffu); fy[3] = (float)(ly >> 24);
+            fu[0] = (float)(lu & 0xffu); fu[1] = (float)((lu >> 8) & 0xffu); fu[2] = (float)((lu >> 16) & 0xffu); fu[3] = (float)(lu >> 24);
+            fv[0] = (float)(lv & 0xffu); fv[1] = (float)((lv >> 8) & 0xffu); fv[2] = (float)((lv >> 16) & 0xffu); fv[3] = (float)(lv >> 24);
         } else {
             const uint32_t ya0 = (vya[j] >> ysh) & 0xffu, ya1 = edge ? ya0 : (vya[j] >> 8) & 0xffu;
             const uint32_t yb0 = (vyb[j] >> ysh) & 0xffu, yb1 = edge ? yb0 : (vyb[j] >> 8) & 0xffu;
@@ -346,7 +371,39 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
             }
         }
 
+        if constexpr (kRowsTile) {
+            if (tile_rows) { // wave-uniform: the wave's four rows leave together below
+#pragma unroll
+                for (int k = 0; k < CN; ++k) tv[j][k] = p.v[k];
+                continue;
+            }
+        }
         store_px(p, depth, cn, y);
+    }
+    if constexpr (kRowsTile) {
+        if (tile_rows) {
+            // the lane = column register layout transposed through a wave-private LDS tile: lane l then owns 4 consecutive columns of row
+            // l / 16 -- 16 bytes per lane and store instruction, three stores for the wave's four rows instead of twelve (the descriptor
+            // queue's row workers publish their rows this way, k_queue.hip: q_lds_put / q_lds_get; fused launches of 4:2:0 crops are bound by
+            // the number of memory instructions: four tap loads per row and lane)
+            __shared__ __attribute__((aligned(16))) float tiles[kK4Waves][CN * RPW * kK4TileRow];
+            float* const tile = tiles[wave];
+#pragma unroll
+            for (int k = 0; k < CN; ++k)
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) tile[(k * RPW + j) * kK4TileRow + lane] = tv[j][k];
+            __builtin_amdgcn_wave_barrier(); // (compiler ordering only: one wave's LDS operations run in order)
+            typedef float f32x4t __attribute__((ext_vector_type(4)));
+            typedef f32x4t f32x4t_a4 __attribute__((aligned(4)));
+            typedef __attribute__((address_space(1))) f32x4t_a4* gf4;
+            const int i = lane >> 4, q = lane & 15;
+            float* const orow = (float*)out_base + (int64_t)z * img_stride + (int64_t)(row0 + i) * W + col_tile * 64 + q * 4;
+#pragma unroll
+            for (int k = 0; k < CN; ++k) {
+                const f32x4t o = *(const f32x4t*)(tile + (k * RPW + i) * kK4TileRow + q * 4);
+                __builtin_nontemporal_store(o, (gf4)(orow + (int64_t)k * ch_stride));
+            }
+        }
     }
 }
 
@@ -423,6 +480,18 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     // One output row per wave.  Two rows per wave were measured for whole-frame outputs (cfg #3: 14400 one-row waves need two
     // rounds of the chip's 8192 wave slots) and lost: 8.27 vs 8.08 us, and 5.29 vs 4.52 us on 50 crops -- the launch is
     // bound by the VALU work per row (~100 instructions x 14 waves per SIMD) plus the launch floor, not by residency.
+    // fused launches (cvgs_execute_many: the crops of several surfaces) in the throughput regime: four rows per wave, the rows leaving as
+    // 16-byte stores through a wave-private LDS tile -- the launch is bound by its memory INSTRUCTIONS (four tap loads per row and lane):
+    // 16 x 50 crops of NV12 surfaces 52 -> see profiles/r05_x_k4_tick_rows4.txt
+    if constexpr (std::is_same_v<OT, float>) {
+        const N12Many& many = tls_many();
+        static const char* rows_env = getenv("CVGS_K4_TICK_ROWS"); // benchmark-only: 1 = one row per wave as single launches
+        if (many.segs && g.cn == 3 && !s16 && !pl && !(rows_env && rows_env[0] == '1')) {
+            int64_t planes = 0;
+            for (int i = 0; i < many.n_segs; ++i) planes += many.segs[i].batch;
+            if (planes * g.dst_h * ((g.dst_w + 63) / 64) >= 32768) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
+        }
+    }
 #ifdef CVGS_K4_AB_RPW
     static const char* rpw_env = getenv("CVGS_K4_RPW");
     if (rpw_env && rpw_env[0] == '2' && g.cn == 3 && !s16 && !pl) return launch_n12_r<Prog, OT, 2, 3, false>(c, ip, ni, g, s);

@@ -185,13 +185,16 @@ def test_mirrors_receive_the_same_rows(oracle, device, n_mirrors, flags, n):
 
 # ---- fused NV12 chains (K4) --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_P010])
-@pytest.mark.parametrize("n_cams,crops_per,ragged", [(4, 12, False), (6, 50, True), (16, 5, False)])
-def test_execute_many_nv12_crop_chains(oracle, device, layout, n_cams, crops_per, ragged):
+@pytest.mark.parametrize("n_cams,crops_per,ragged,dst", [(4, 12, False, (64, 128)), (6, 50, True, (64, 128)), (16, 5, False, (64, 128)),
+                                                         (8, 40, False, (64, 128)), (6, 40, False, (100, 126)), (9, 50, True, (64, 128))])
+def test_execute_many_nv12_crop_chains(oracle, device, layout, n_cams, crops_per, ragged, dst):
     """The decode-side form of the batched-crop path: every camera hands over an NV12 (or NV21) decoder surface and a crop
     list; cvgs_execute_many turns them into ONE launch of the K4 kernel -- bit-identical to one launch per camera and to
-    the oracle."""
+    the oracle.  From 32 Ki wave-rows on (the last three cases) the 8-bit layouts run four rows per wave with 16-byte stores through an
+    LDS transpose (round 5); a 100 x 126 target has a ragged second column tile and a last row group of two rows: the row-by-row stores."""
     import torch
     w, h = 640, 360
+    dw, dh = dst
     f = cvgs.CV_32FC3
     chains, outs, refs, keep = [], [], [], []
     for cam in range(n_cams):
@@ -201,15 +204,15 @@ def test_execute_many_nv12_crop_chains(oracle, device, layout, n_cams, crops_per
         surf = (H.random_u16 if p010 else H.random_u8)((h + h // 2, w), seed=800 + cam)
         st = torch.from_numpy(surf.view(np.int16) if p010 else surf).to(device)
         rects = [(x & ~1, y & ~1, max(4, cw & ~1), max(2, ch & ~1)) for (x, y, cw, ch) in H.random_crops(n, w, h, seed=850 + cam, wmin=4, wmax=300, hmin=4, hmax=300)]
-        ot = torch.full((n, 3 * 64 * 128), -3.0, dtype=torch.float32, device=device)
-        ref = np.full((n, 3 * 64 * 128), -3.0, np.float32)
+        ot = torch.full((n, 3 * dw * dh), -3.0, dtype=torch.float32, device=device)
+        ref = np.full((n, 3 * dw * dh), -3.0, np.float32)
 
         def chain(wrap_s, wrap_o, out):
             m = wrap_s(surf)
             luma = cvgs.GpuMat(h, w, s_t, m.data, m.step, owner=m.owner)
-            return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], (64, 128), capi.YUV_LIMITED, capi.BT709, False, layout=layout),
+            return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], (dw, dh), capi.YUV_LIMITED, capi.BT709, False, layout=layout),
                     cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]),
-                    cvgs.split(f, wrap_o(out), (64, 128))]
+                    cvgs.split(f, wrap_o(out), (dw, dh))]
 
         chains.append(chain(lambda a: cvgs.GpuMat.from_tensor(st, s_t), lambda o: cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), ot))
         oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, s_t), lambda o: cvgs.GpuMat.from_array(o, cvgs.CV_32FC1), ref)))

@@ -454,6 +454,9 @@ def configs_block(extra):
             elif "a TICK of 4" in c:
                 d["tick4_us"] = r.get("us_per_launch")
                 d["tick4_frac"] = r.get("frac_of_8TBs")
+            elif "a TICK of 8" in c:
+                d["tick8_us"] = r.get("us_per_launch")
+                d["tick8_frac"] = r.get("frac_of_8TBs")
             else:
                 d["launch_us"], d["frac"], d["surfaces"] = r.get("us_per_launch"), r.get("frac_of_8TBs"), r.get("surfaces_in_rotation")
                 d["out_Mpix_s"] = r.get("output_Mpix_per_s")

@@ -296,6 +296,7 @@ def run_all(dev, iters=100, only=""):
         res.append(cfg3(dev, iters))
         res.append(cfg3(dev, iters, p010=True))
         res.append(cfg3(dev, iters, per_launch=4))
+        res.append(cfg3(dev, iters, per_launch=8))
         res.append(cfg3(dev, iters, queue=True))
         res.append(cfg3(dev, iters, p010=True, queue=True))
     if only in ("", "nv12many"):

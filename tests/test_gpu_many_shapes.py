@@ -319,7 +319,7 @@ def test_a_host_described_tick_is_capturable(oracle, device, lib):
     """descriptors in the kernel arguments: the fused launch of host-described chains is captured into a graph as it is (round 4: refused)
     and replays; a tick beyond 1024 planes under capture runs chain by chain (<= 64 planes each in kernel arguments) -- same bits"""
     import torch
-    for n_chains, per in ((6, 20), (20, 60)):  # 120 planes: one fused launch; 1200 planes: chain by chain under capture
+    for n_chains, per in ((6, 20), (16, 50), (20, 60)):  # 120 / 800 planes: one fused launch (16 KB / 52 KB argument block); 1200 planes: chain by chain under capture
         fh, fw = 360, 640
         chains, outs, refs, keep = [], [], [], []
         for m in range(n_chains):

@@ -480,15 +480,15 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     // One output row per wave.  Two rows per wave were measured for whole-frame outputs (cfg #3: 14400 one-row waves need two
     // rounds of the chip's 8192 wave slots) and lost: 8.27 vs 8.08 us, and 5.29 vs 4.52 us on 50 crops -- the launch is
     // bound by the VALU work per row (~100 instructions x 14 waves per SIMD) plus the launch floor, not by residency.
-    // fused launches (cvgs_execute_many: the crops of several surfaces) in the throughput regime: four rows per wave, the rows leaving as
+    // launches in the throughput regime (cvgs_execute_many: the crops of several surfaces; one chain of hundreds of crops): four rows per wave, the rows leaving as
     // 16-byte stores through a wave-private LDS tile -- the launch is bound by its memory INSTRUCTIONS (four tap loads per row and lane):
     // 16 x 50 crops of NV12 surfaces 52 -> see profiles/r05_x_k4_tick_rows4.txt
     if constexpr (std::is_same_v<OT, float>) {
         const N12Many& many = tls_many();
         static const char* rows_env = getenv("CVGS_K4_TICK_ROWS"); // benchmark-only: 1 = one row per wave as single launches
-        if (many.segs && g.cn == 3 && !s16 && !pl && !(rows_env && rows_env[0] == '1')) {
-            int64_t planes = 0;
-            for (int i = 0; i < many.n_segs; ++i) planes += many.segs[i].batch;
+        if (g.cn == 3 && !s16 && !pl && !(rows_env && rows_env[0] == '1')) { // (a single chain of 256+ crops is in the same regime)
+            int64_t planes = many.segs ? 0 : c.read.batch;
+            for (int i = 0; many.segs && i < many.n_segs; ++i) planes += many.segs[i].batch;
             if (planes * g.dst_h * ((g.dst_w + 63) / 64) >= 32768) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
         }
     }

@@ -302,7 +302,7 @@ def test_descriptor_scratch_is_thread_safe(oracle, device, lib):
 
 
 @pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_P010])
-@pytest.mark.parametrize("n", [65, 130, 400])
+@pytest.mark.parametrize("n", [65, 130, 300, 400])
 def test_more_than_64_crops_of_a_decoder_surface_stay_on_k4(oracle, device, layout, n):
     """65+ detections of one NV12 / NV21 / P010 surface in one chain: the crop table no longer fits the kernel arguments; K4
     reads it as one segment of its fused-chain form instead of leaving the chain to the interpreted kernel."""

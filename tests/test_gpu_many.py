@@ -83,6 +83,7 @@ def test_execute_many_is_one_launch_and_capturable_with_tables(device, lib):
     lowered = [cvgs.lower(ops) for ops in chains]
     arr = cvgs.pack_chains(lowered)
     side = torch.cuda.Stream()
+    torch.cuda.synchronize()  # frames and tensors were written on torch's stream; `side` does not wait for it by itself
     with torch.cuda.stream(side):
         capi.check(lib.cvgs_execute_many(arr, len(lowered), side.cuda_stream))
         torch.cuda.synchronize()
@@ -100,6 +101,7 @@ def test_execute_many_is_one_launch_and_capturable_with_tables(device, lib):
     chains2, outs2, _, keep2 = _make(device, 2, 330, seed=600)
     low2 = [cvgs.lower(ops) for ops in chains2]
     arr2 = cvgs.pack_chains(low2)
+    torch.cuda.synchronize()
     with torch.cuda.stream(side):
         capi.check(lib.cvgs_execute_many(arr2, 2, side.cuda_stream))
         torch.cuda.synchronize()

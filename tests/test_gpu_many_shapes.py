@@ -165,6 +165,7 @@ def test_hundreds_of_ticks_recycle_their_table_slots(oracle, device, lib):
             chains.append(ops)
             outs.append(out)
             meta.append((k, crops))
+        torch.cuda.current_stream().synchronize()  # the tensors' fills ran on torch's stream: they must have landed before a tick on `s` writes them (`s` itself is never waited for)
         ticks.append((outs, meta, cvgs.executeMany(s, chains)))
     s.synchronize()
     for i in (list(range(0, n_ticks, 7)) + [n_ticks - 1]):
@@ -376,6 +377,7 @@ def test_ticks_on_streams_that_come_and_go(oracle, device, lib):
                 meta.append((k, crops))
             lowered = [cvgs.lower(ops) for ops in chains]
             arr = cvgs.pack_chains(lowered)
+            torch.cuda.current_stream().synchronize()  # (the tensors' fills, on torch's stream, before the tick on the raw stream)
             capi.check(lib.cvgs_execute_many(arr, len(lowered), s))
             held.append((outs, meta, lowered, arr))
         assert hip.hipStreamSynchronize(s) == 0
@@ -470,6 +472,7 @@ def test_a_stream_destroyed_with_its_tick_still_pending(oracle, device, lib):
                 meta.append((k, crops))
             lowered = [cvgs.lower(ops) for ops in chains]
             arr = cvgs.pack_chains(lowered)
+            torch.cuda.current_stream().synchronize()  # (the tensors' fills, on torch's stream, before the tick on the raw stream)
             capi.check(lib.cvgs_execute_many(arr, len(lowered), s))
             held.append((i, outs, meta, lowered, arr))
         assert hip.hipStreamDestroy(s) == 0  # pending work completes; the handle may come back with the next create

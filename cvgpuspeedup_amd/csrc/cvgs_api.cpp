@@ -1035,8 +1035,11 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
     if (fusable) {
         const bool tables0 = (chains[0].read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) != 0;
         static const bool inline_ok = [] { const char* e = getenv("CVGS_MANY_INLINE"); return e ? e[0] != '0' : true; }();
-        if (!tables0 && inline_ok && chains[0].read.kind == CVGS_READ_RESIZE_LINEAR && CVGS_TYPE_CN(chains[0].read.src_type) >= 3 &&
-            CVGS_TYPE_DEPTH(chains[0].read.src_type) == CVGS_DEPTH_8U) {
+        const bool k1_u8 = chains[0].read.kind == CVGS_READ_RESIZE_LINEAR && CVGS_TYPE_CN(chains[0].read.src_type) >= 3 &&
+                           CVGS_TYPE_DEPTH(chains[0].read.src_type) == CVGS_DEPTH_8U;
+        const bool k4_u8 = chains[0].read.kind == CVGS_READ_NV12_RESIZE_LINEAR &&
+                           (chains[0].read.yuv_layout == CVGS_YUV_NV12 || chains[0].read.yuv_layout == CVGS_YUV_NV21); // 8-bit samples, interleaved chroma
+        if (!tables0 && inline_ok && (k1_u8 || k4_u8)) {
             size_t planes = 0;
             for (int i = 0; i < n; ++i) planes += (size_t)(chains[i].read.batch > 0 ? chains[i].read.batch : 0);
             inline_many = planes <= (size_t)cvgs::kManyInlineLarge;
@@ -1134,7 +1137,7 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
                 dw.word = ms->done_dev;
                 dw.value = ms->next_seq - 1;
             }
-            rc = k4 ? launch_nv12(c, nullptr, 0, 1 << 30, segs, n, stream, false, nullptr)
+            rc = k4 ? launch_nv12(c, inline_many ? inline_planes.data() : nullptr, inline_many ? (int)inline_planes.size() : 0, 1 << 30, segs, n, stream, false, nullptr)
                     : launch_k1(c, inline_many ? inline_planes.data() : nullptr, inline_many ? (int)inline_planes.size() : 0, MirrorArgs{}, segs, n, stream, false, nullptr);
             const bool reported = dw.used;
             dw = cvgs::DoneWordSlot{};

@@ -41,7 +41,8 @@ struct N12Geom {
 
 // NPL > 0: the planes travel in the kernel arguments, grid = (column tiles, row groups, planes).  NPL == 0: the chains of a
 // cvgs_execute_many launch, planes in per-chain device tables, grid = (column tiles x row groups, planes, chains).
-template <int NPL> using K4Args = std::conditional_t<NPL == 0, KernArgsMany, KernArgs<NPL>>;
+// NPL < 0: the segments with the planes of ALL chains inside the kernel arguments (KernArgsManyInline<-NPL>: fused chains described on the host, as K1).
+template <int NPL> using K4Args = std::conditional_t<NPL == 0, KernArgsMany, std::conditional_t<(NPL < 0), KernArgsManyInline<(NPL < 0 ? -NPL : 1)>, KernArgs<(NPL > 0 ? NPL : 1)>>>;
 
 // waves per workgroup (see k_k1.hip): an A/B build may override it
 #ifndef CVGS_K4_WPB
@@ -70,12 +71,13 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     PlaneParams P;
     int z, col_tile, row_group, used;
     uint8_t* out_base;
-    if constexpr (NPL == 0) {
+    if constexpr (NPL <= 0) {
         z = (int)blockIdx.y;
         const ManySeg sg = a.seg[blockIdx.z];
         if (z >= sg.batch) return; // a shorter chain of the fused launch
         used = sg.used;
-        P = sg.table[z < used ? z : 0];
+        if constexpr (NPL == 0) P = sg.table[z < used ? z : 0];
+        else P = a.planes[(uint32_t)(uintptr_t)sg.table + (uint32_t)(z < used ? z : 0)]; // (sg.table: the chain's first index into a.planes)
         out_base = sg.out;
         col_tile = 0;
         row_group = (int)blockIdx.x;
@@ -411,9 +413,11 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
 struct N12Many {
     const ManySeg* segs;
     int n_segs;
+    const PlaneParams* planes; // host-described fused chains whose planes travel in the kernel arguments (segs[i].table = first index), or null
+    int n_planes;
 };
 static N12Many& tls_many() {
-    static thread_local N12Many m{nullptr, 0};
+    static thread_local N12Many m{nullptr, 0, nullptr, 0};
     return m;
 }
 
@@ -427,6 +431,21 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
     g.done_value = 0;
     const N12Many& many = tls_many();
     constexpr bool kImage = std::is_same_v<OT, uint8_t>; // packed u8 images: never fused chains, never the 16 KB argument block
+    if constexpr (!kImage && !S16 && !PL && !WIN) if (many.segs && many.planes) {
+        // host descriptors of at most kManyInlineLarge planes: segments + planes in the arguments (16 KB / 52 KB blocks), capturable
+        const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
+        auto go = [&](auto cap_tag) {
+            constexpr int CAP = decltype(cap_tag)::value;
+            KernArgsManyInline<CAP> a;
+            a.c = c;
+            for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
+            for (int i = 0; i < many.n_planes && i < CAP; ++i) a.planes[i] = many.planes[i];
+            hipLaunchKernelGGL((k4_nv12_resize<-CAP, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+        };
+        if (many.n_planes <= kManyInlineSmall) go(std::integral_constant<int, kManyInlineSmall>{});
+        else go(std::integral_constant<int, kManyInlineLarge>{});
+        return hipGetLastError();
+    }
     if constexpr (!kImage) if (many.segs) {
         KernArgsMany a;
         a.c = c;
@@ -538,6 +557,8 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
     if (segs) {
         if (n_segs < 1 || n_segs > CVGS_MAX_CHAINS || c_in.write.data2) return 0;
+        // segments without a table: the planes travel in the kernel arguments -- 8-bit samples with interleaved chroma only (launch_n12_r)
+        if (!r.table && (!inline_planes || n_inline < 1 || n_inline > kManyInlineLarge || (r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21))) return 0;
     } else {
         if (r.table || n_inline > kKernargPlanesBig || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
         if (n_inline > CVGS_KERNARG_PLANES && !(planar_kind && (c_in.write.depth == CVGS_DEPTH_32F || f16))) return 0; // the large block: tensors only
@@ -586,7 +607,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
             info->kernel = r.out_cn == 3 ? (u8_prog == 0 ? "k4_nv12_resize_u8c3" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c3" : "k4_nv12_resize_interp_u8c3"))
                                          : (u8_prog == 0 ? "k4_nv12_resize_u8c4" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c4" : "k4_nv12_resize_interp_u8c4"));
         if (dry_run) return 1;
-        tls_many() = N12Many{nullptr, 0};
+        tls_many() = N12Many{nullptr, 0, nullptr, 0};
         const bool win8 = r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h);
         hipStream_t s8 = (hipStream_t)stream;
         const hipError_t e8 = u8_prog == 0   ? launch_n12<ProgNone, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
@@ -629,7 +650,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
         info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
                            : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : (fast_rgb ? "k4_nv12_resize_mul_sub_div" : "k4_nv12_resize_interp"));
     if (dry_run) return 1;
-    tls_many() = N12Many{segs, n_segs};
+    tls_many() = N12Many{segs, n_segs, segs && !r.table ? inline_planes : nullptr, segs && !r.table ? n_inline : 0};
     // the windowed instantiations: an aspect-ratio window or default-value planes (never for fused chains / staged tables, whose
     // callers admit stretch geometry only)
     const bool win = !segs && (r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h));

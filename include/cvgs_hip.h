@@ -295,7 +295,8 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * chains are NOT independent (two chains write overlapping bytes, or a host-described source view of one -- chroma rows of a 4:2:0
  * surface included; chains whose plane table lives on the device are NOT checked: the caller vouches for them -- lies inside another's
  * output: fused chains run concurrently), a set with a batch beyond 65535, and staged host descriptors under stream capture.  Host
- * descriptors of fused 8-bit pixel chains with 3 / 4 channels and at most 1024 planes in all (a tick of 16 cameras x 50 crops is 800) travel
+ * descriptors of fused 8-bit chains -- pixels with 3 / 4 channels, or crops of NV12 / NV21 surfaces -- with at most 1024 planes in all (a tick of
+ * 16 cameras x 50 crops is 800) travel
  * INSIDE the fused launch's kernel arguments (a 16 KB block up to 256 planes, 52 KB beyond): nothing is staged, nothing is recycled, the
  * call allocates nothing and can be captured as it is; the kernel reads them from device memory (the runtime's argument pool) instead of
  * fetching a pinned table over PCIe (eager tick of 16 x 50 crops: 40.9 -> 39.9 us; the host pays 1-5 us more per call for the larger

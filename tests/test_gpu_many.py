@@ -234,6 +234,49 @@ def test_execute_many_nv12_crop_chains(oracle, device, layout, n_cams, crops_per
         H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "one launch per camera, camera %d" % cam)
 
 
+def test_a_host_described_nv12_tick_is_capturable(oracle, device, lib):
+    """The decode-side tick (crops of several NV12 surfaces, host descriptors) carries its planes in the kernel arguments since round 5: the
+    fused K4 launch is captured as it is and replays (it used to be refused: K4 chains have no device-table form)."""
+    import torch
+    w, h = 640, 360
+    f = cvgs.CV_32FC3
+    chains, outs, refs, keep = [], [], [], []
+    for cam in range(7):
+        surf = H.random_u8((h + h // 2, w), seed=1800 + cam)
+        st = torch.from_numpy(surf).to(device)
+        rects = [(x & ~1, y & ~1, max(4, cw & ~1), max(2, ch & ~1)) for (x, y, cw, ch) in H.random_crops(40, w, h, seed=1850 + cam, wmin=4, wmax=300, hmin=4, hmax=300)]
+        ot = torch.full((40, 3 * 64 * 128), -3.0, dtype=torch.float32, device=device)
+        ref = np.full((40, 3 * 64 * 128), -3.0, np.float32)
+
+        def chain(wrap_s, wrap_o, out):
+            m = wrap_s(surf)
+            luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, m.data, m.step, owner=m.owner)
+            return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], (64, 128), capi.YUV_LIMITED, capi.BT709, False),
+                    cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]),
+                    cvgs.split(f, wrap_o(out), (64, 128))]
+
+        chains.append(chain(lambda a: cvgs.GpuMat.from_tensor(st, cvgs.CV_8UC1), lambda o: cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), ot))
+        oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_8UC1), lambda o: cvgs.GpuMat.from_array(o, cvgs.CV_32FC1), ref)))
+        outs.append(ot)
+        refs.append(ref)
+        keep.append(st)
+    lowered = [cvgs.lower(ops) for ops in chains]
+    arr = cvgs.pack_chains(lowered)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            capi.check(lib.cvgs_execute_many(arr, len(lowered), torch.cuda.current_stream().cuda_stream))
+        for rep in range(2):
+            for o in outs:
+                o.fill_(-5.0)
+            g.replay()
+            torch.cuda.synchronize()
+            for cam in range(7):
+                H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "captured NV12 tick, replay %d, camera %d" % (rep, cam))
+
+
 def test_execute_many_nv12_with_a_narrow_crop_falls_back(oracle, device):
     """A 2-pixel-wide crop is not K4's (its chroma window needs 4 bytes): the set is executed one by one, same results."""
     import torch

@@ -1037,9 +1037,9 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
         static const bool inline_ok = [] { const char* e = getenv("CVGS_MANY_INLINE"); return e ? e[0] != '0' : true; }();
         const bool k1_u8 = chains[0].read.kind == CVGS_READ_RESIZE_LINEAR && CVGS_TYPE_CN(chains[0].read.src_type) >= 3 &&
                            CVGS_TYPE_DEPTH(chains[0].read.src_type) == CVGS_DEPTH_8U;
-        const bool k4_u8 = chains[0].read.kind == CVGS_READ_NV12_RESIZE_LINEAR &&
-                           (chains[0].read.yuv_layout == CVGS_YUV_NV12 || chains[0].read.yuv_layout == CVGS_YUV_NV21); // 8-bit samples, interleaved chroma
-        if (!tables0 && inline_ok && (k1_u8 || k4_u8)) {
+        const bool k4_il = chains[0].read.kind == CVGS_READ_NV12_RESIZE_LINEAR &&
+                           (chains[0].read.yuv_layout == CVGS_YUV_NV12 || chains[0].read.yuv_layout == CVGS_YUV_NV21 || chains[0].read.yuv_layout == CVGS_YUV_P010); // interleaved chroma
+        if (!tables0 && inline_ok && (k1_u8 || k4_il)) {
             size_t planes = 0;
             for (int i = 0; i < n; ++i) planes += (size_t)(chains[i].read.batch > 0 ? chains[i].read.batch : 0);
             inline_many = planes <= (size_t)cvgs::kManyInlineLarge;

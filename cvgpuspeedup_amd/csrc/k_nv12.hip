@@ -431,7 +431,7 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
     g.done_value = 0;
     const N12Many& many = tls_many();
     constexpr bool kImage = std::is_same_v<OT, uint8_t>; // packed u8 images: never fused chains, never the 16 KB argument block
-    if constexpr (!kImage && !S16 && !PL && !WIN) if (many.segs && many.planes) {
+    if constexpr (!kImage && !PL && !WIN) if (many.segs && many.planes) {
         // host descriptors of at most kManyInlineLarge planes: segments + planes in the arguments (16 KB / 52 KB blocks), capturable
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
         auto go = [&](auto cap_tag) {
@@ -505,10 +505,11 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     if constexpr (std::is_same_v<OT, float>) {
         const N12Many& many = tls_many();
         static const char* rows_env = getenv("CVGS_K4_TICK_ROWS"); // benchmark-only: 1 = one row per wave as single launches
-        if (g.cn == 3 && !s16 && !pl && !(rows_env && rows_env[0] == '1')) { // (a single chain of 256+ crops is in the same regime)
+        if (g.cn == 3 && !pl && !(rows_env && rows_env[0] == '1')) { // (a single chain of 256+ crops is in the same regime; P010 surfaces too)
             int64_t planes = many.segs ? 0 : c.read.batch;
             for (int i = 0; many.segs && i < many.n_segs; ++i) planes += many.segs[i].batch;
-            if (planes * g.dst_h * ((g.dst_w + 63) / 64) >= 32768) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
+            if (planes * g.dst_h * ((g.dst_w + 63) / 64) >= 32768)
+                return s16 ? launch_n12_r<Prog, OT, 4, 3, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
         }
     }
 #ifdef CVGS_K4_AB_RPW
@@ -557,8 +558,8 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     if (r.kind != CVGS_READ_NV12_RESIZE_LINEAR) return 0;
     if (segs) {
         if (n_segs < 1 || n_segs > CVGS_MAX_CHAINS || c_in.write.data2) return 0;
-        // segments without a table: the planes travel in the kernel arguments -- 8-bit samples with interleaved chroma only (launch_n12_r)
-        if (!r.table && (!inline_planes || n_inline < 1 || n_inline > kManyInlineLarge || (r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21))) return 0;
+        // segments without a table: the planes travel in the kernel arguments -- interleaved chroma only (launch_n12_r)
+        if (!r.table && (!inline_planes || n_inline < 1 || n_inline > kManyInlineLarge || (r.yuv_layout != CVGS_YUV_NV12 && r.yuv_layout != CVGS_YUV_NV21 && r.yuv_layout != CVGS_YUV_P010))) return 0;
     } else {
         if (r.table || n_inline > kKernargPlanesBig || min_width < 4) return 0; // tiny frames / resident tables: generic kernel
         if (n_inline > CVGS_KERNARG_PLANES && !(planar_kind && (c_in.write.depth == CVGS_DEPTH_32F || f16))) return 0; // the large block: tensors only

@@ -244,7 +244,7 @@ def nv12_crops(dev, iters, n=50, queue=False):
             "output_Mpix_per_s": round(n * dst[0] * dst[1] / t / 1e6, 1)}
 
 
-def nv12_many(dev, iters, cams=16, n=50):
+def nv12_many(dev, iters, cams=16, n=50, p010=False):
     """16 cameras' NV12 surfaces x 50 crops each -> 16 NCHW tensors in ONE launch (cvgs_execute_many over K4), eager with
     host descriptors (the crop lists are per frame), next to 16 separate launches."""
     w, h = W.FRAME_4K
@@ -255,12 +255,14 @@ def nv12_many(dev, iters, cams=16, n=50):
     lowered, keep = [], []
     sets = 8  # 8 x 16 surfaces in rotation: ~4 MB of tapped sectors each -> 2 x the Infinity Cache of READ-touched bytes (round 4: 3 sets)
     for i in range(cams * sets):
-        buf = W.random_u8_torch((h + h // 2, w), 1800 + i, dev)
+        sb = 2 if p010 else 1  # P010: 16-bit samples
+        buf = W.random_u8_torch((h + h // 2, w * sb), 1800 + i, dev)
         out = torch.zeros((n, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
-        luma = cvgs.GpuMat(h, w, cvgs.CV_8UC1, buf.data_ptr(), w, owner=buf)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1 if p010 else cvgs.CV_8UC1, buf.data_ptr(), w * sb, owner=buf)
         rects = [(x & ~1, y & ~1, max(4, cw & ~1), max(2, ch & ~1)) for (x, y, cw, ch) in W.random_crops(n, w, h, seed=W.SEED + 1900 + i)]
-        ops = [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], dst, capi.YUV_LIMITED, capi.BT709, False),
-               cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]),
+        rd = (cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], dst, capi.YUV_LIMITED, capi.BT2020, False, layout=capi.YUV_P010) if p010 else
+              cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], dst, capi.YUV_LIMITED, capi.BT709, False))
+        ops = [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [1 / 1023.0 if p010 else W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]),
                cvgs.divide(f, W.K1_DIV[3]), cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst)]
         keep += [buf, out]
         lowered.append(cvgs.lower(ops))
@@ -277,7 +279,7 @@ def nv12_many(dev, iters, cams=16, n=50):
         for lc in lowered[(state["i"] % sets) * cams:(state["i"] % sets + 1) * cams]:
             capi.check(lib.cvgs_execute(C.byref(lc.desc), s.cuda_stream))
     t_sep = events_time(separate, max(4, iters // 4))
-    return {"config": "decode-side: %d NV12 4K surfaces x %d crops -> %d NCHW tensors, ONE launch (cvgs_execute_many, host descriptors, eager)" % (cams, n, cams),
+    return {"config": "decode-side: %d %s 4K surfaces x %d crops -> %d NCHW tensors, ONE launch (cvgs_execute_many, host descriptors, eager)" % (cams, "P010" if p010 else "NV12", n, cams),
             "us_per_launch": round(t_many * 1e6, 2), "us_as_%d_launches" % cams: round(t_sep * 1e6, 2),
             "output_Mpix_per_s": round(cams * n * dst[0] * dst[1] / t_many / 1e6, 1)}
 
@@ -301,6 +303,7 @@ def run_all(dev, iters=100, only=""):
         res.append(cfg3(dev, iters, p010=True, queue=True))
     if only in ("", "nv12many"):
         res.append(nv12_many(dev, iters))
+        res.append(nv12_many(dev, iters, p010=True))
     if only in ("", "nv12crops"):
         res.append(nv12_crops(dev, iters))
         res.append(nv12_crops(dev, iters, queue=True))

@@ -7,6 +7,7 @@ batch sweep of tests/batchresize/test_batchresize_x_split3D.cu:384-392.
 mirrors: the exchange step of the sharded batched-crop path (SURVEY.md 8e option 2): the kernel stores its rows into
 its own tensor and into every "peer" tensor; here the peers are further tensors on the same device."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -407,3 +408,43 @@ def test_execute_many_with_host_descriptors_is_capturable_chain_by_chain(oracle,
     torch.cuda.synchronize()
     for o, (frame, crops) in zip(outs, refs_in):
         H.assert_bit_exact(o.cpu().numpy(), _oracle(oracle, frame, crops), "captured execute_many, host descriptors")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CVGS_FUZZ_K4_TICKS_N", "8"))))
+def test_random_nv12_ticks(oracle, device, seed):
+    """Random decode-side ticks: 2-14 surfaces of a random 4:2:0 layout (NV12 / NV21 / P010), 1-60 crops each, a random target size (ragged column
+    tiles, row counts that are not multiples of four): one-row and four-row waves, inline descriptors and the table ring, bit-exact against the
+    oracle.  CVGS_FUZZ_K4_TICKS_N=300 for a long hunt."""
+    import torch
+    rng = np.random.default_rng(77000 + seed)
+    layout = [capi.YUV_NV12, capi.YUV_NV21, capi.YUV_P010][int(rng.integers(3))]
+    p010 = layout == capi.YUV_P010
+    dw, dh = int(rng.choice([16, 48, 64, 100, 128, 200])), int(rng.choice([8, 30, 64, 126, 128, 131]))
+    w, h = 640, 360
+    f = cvgs.CV_32FC3
+    s_t = cvgs.CV_16UC1 if p010 else cvgs.CV_8UC1
+    chains, outs, refs, keep = [], [], [], []
+    for cam in range(int(rng.integers(2, 15))):
+        n = int(rng.integers(1, 61))
+        surf = (H.random_u16 if p010 else H.random_u8)((h + h // 2, w), seed=int(rng.integers(1 << 30)))
+        st = torch.from_numpy(surf.view(np.int16) if p010 else surf).to(device)
+        rects = [(x & ~1, y & ~1, max(4, cw & ~1), max(2, ch & ~1)) for (x, y, cw, ch) in H.random_crops(n, w, h, seed=int(rng.integers(1 << 30)), wmin=4, wmax=300, hmin=4, hmax=300)]
+        ot = torch.full((n, 3 * dw * dh), -3.0, dtype=torch.float32, device=device)
+        ref = np.full((n, 3 * dw * dh), -3.0, np.float32)
+
+        def chain(wrap_s, wrap_o, out):
+            m = wrap_s(surf)
+            luma = cvgs.GpuMat(h, w, s_t, m.data, m.step, owner=m.owner)
+            return [cvgs.read_nv12([luma.nv12_roi(*r) for r in rects], (dw, dh), capi.YUV_LIMITED, capi.BT709, False, layout=layout),
+                    cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, H.K1_SUB[3]), cvgs.divide(f, H.K1_DIV[3]),
+                    cvgs.split(f, wrap_o(out), (dw, dh))]
+
+        chains.append(chain(lambda a: cvgs.GpuMat.from_tensor(st, s_t), lambda o: cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), ot))
+        oracle.execute(cvgs.lower(chain(lambda a: cvgs.GpuMat.from_array(a, s_t), lambda o: cvgs.GpuMat.from_array(o, cvgs.CV_32FC1), ref)))
+        outs.append(ot)
+        refs.append(ref)
+        keep.append(st)
+    cvgs.executeMany(torch.cuda.current_stream(), chains)
+    torch.cuda.synchronize()
+    for cam in range(len(outs)):
+        H.assert_bit_exact(outs[cam].cpu().numpy(), refs[cam], "random NV12 tick %d (layout %d, %dx%d), camera %d" % (seed, layout, dw, dh, cam))

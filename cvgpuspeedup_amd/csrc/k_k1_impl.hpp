@@ -27,6 +27,19 @@ enum { WM_PLANAR = 0, WM_PACKED = 1, WM_SPLIT2D = 2 };
 #endif
 constexpr int kK1Waves = CVGS_K1_WPB;
 
+// Ablation hooks of tools/probes/tick_ablation.py (round 6): the product build never defines CVGS_K1_ABLATE -- every hook below is an
+// `if constexpr` on 0 there, the generated code is unchanged (tests/test_kernel_resources.py holds the kernels' register / code-size
+// census).  The probe builds k_k1_c3.hip again with -DCVGS_K1_ABLATE=<bits> into build/ablate/ (NOT into libcvgs_hip.so), so that the
+// skeletons run the production kernel's own grid, scalar loads and tap addresses:
+//   1 no tap loads (the windows are synthesised from the lane id)     2 no arithmetic (the windows' dwords are stored as they are)
+//   4 no stores (kept behind a data-dependent test that never holds, so the loads stay)
+//   8 the linear workgroup index is re-read chain-fastest (consecutive workgroups belong to different chains of the tick)
+//  16 the wave ends behind its batch of scalar loads (descriptor fetch only)
+#ifndef CVGS_K1_ABLATE
+#define CVGS_K1_ABLATE 0
+#endif
+constexpr int kAblate = CVGS_K1_ABLATE;
+
 struct K1Geom {
     uint32_t col_tiles;  // ceil(dst_w / 64)
     int32_t dst_w, dst_h;
@@ -105,7 +118,15 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
     constexpr int EB = elem_bytes<SRC>;
     constexpr int WINB = SRC == SRC_F32 ? 2 * CN * 4 : 8 * EB; // bytes per tap window (fp32: exactly the pixel pair)
     const ChainArgs& c = a.c;
-    const int z = (int)blockIdx.y;
+    uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if constexpr ((kAblate & 8) != 0) { // chain-fastest order of the same grid (probe only)
+        const uint32_t lin = bx + gridDim.x * (by + gridDim.y * bz);
+        bz = lin % gridDim.z;
+        const uint32_t rest = lin / gridDim.z;
+        bx = rest % gridDim.x;
+        by = rest / gridDim.x;
+    }
+    const int z = (int)by;
     // ---- one batch of scalar loads: the crop's parameters, the program operands come in together; what the wave needs to ask for its
     // crop's descriptor (segment 0's table, the target's extent) arrives in SGPRs with the dispatch (kernel-argument preload) ----
     const int dst_w = pre_dst_w, dst_h = pre_dst_h, W = pre_out_w;
@@ -119,8 +140,8 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
         int batch = pre_batch;
         used = pre_used;
         out_base = (OT*)pre_out;
-        if (blockIdx.z != 0) { // the other chains of a fused launch: their segment comes from the argument block
-            const ManySeg sg = a.seg[blockIdx.z];
+        if (bz != 0) { // the other chains of a fused launch: their segment comes from the argument block
+            const ManySeg sg = a.seg[bz];
             table = sg.table;
             batch = sg.batch;
             used = sg.used;
@@ -151,10 +172,11 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
             __hip_atomic_store(g.done_word, g.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
-    int col_tile = 0, row_tile = (int)blockIdx.x;
+    if constexpr ((kAblate & 16) != 0) return;
+    int col_tile = 0, row_tile = (int)bx;
     if (col_tiles > 1) {
-        col_tile = (int)(blockIdx.x % col_tiles);
-        row_tile = (int)(blockIdx.x / col_tiles);
+        col_tile = (int)(bx % col_tiles);
+        row_tile = (int)(bx / col_tiles);
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
@@ -233,7 +255,12 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
         wyb[j] = sy - (float)y1;
         const gptr_u8 ra = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y1) * (size_t)P.step);
         const gptr_u8 rb = pin_uniform(src + (size_t)__builtin_amdgcn_readfirstlane(y2r) * (size_t)P.step);
-        if constexpr (SRC == SRC_F32) {
+        if constexpr ((kAblate & 1) != 0 && SRC == SRC_U8) { // probe: no tap loads
+            va[j].lo = (uint64_t)(uint32_t)(lane * 0x01010101 + y1) * 0x100000001ull;
+            vb[j].lo = (uint64_t)(uint32_t)(lane * 0x01010101 + y2r) * 0x100000001ull;
+            (void)ra;
+            (void)rb;
+        } else if constexpr (SRC == SRC_F32) {
             if (!tiny) {
                 va[j] = load_win_f32<CN>(ra + ol);
                 vb[j] = load_win_f32<CN>(rb + ol);
@@ -255,7 +282,10 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
         const int y = row0 + j;
         if (y < dst_h) { // wave-uniform
             float p00[4], p10[4], p01[4], p11[4];
-            if constexpr (SRC == SRC_F32) {
+            if constexpr ((kAblate & 2) != 0 && SRC == SRC_U8) { // probe: no arithmetic -- the four dwords of the two windows, as they are
+                p00[0] = __uint_as_float((uint32_t)va[j].lo), p00[1] = __uint_as_float((uint32_t)(va[j].lo >> 32) ^ (uint32_t)vb[j].lo);
+                p00[2] = __uint_as_float((uint32_t)(vb[j].lo >> 32)), p00[3] = 0.f;
+            } else if constexpr (SRC == SRC_F32) {
                 unpack_pair_f32<CN>(va[j], sh != 0, edge, p00, p10);
                 unpack_pair_f32<CN>(vb[j], sh != 0, edge, p01, p11);
             } else {
@@ -268,17 +298,25 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
             const float w11 = wxb * wyb[j];
             Px p;
             p.v[0] = p.v[1] = p.v[2] = p.v[3] = 0.f;
-#pragma unroll
-            for (int k = 0; k < CN; ++k) {
-                float acc = p00[k] * w00;
-                acc = acc + p10[k] * w10;
-                acc = acc + p01[k] * w01;
-                acc = acc + p11[k] * w11;
-                p.v[k] = acc;
-            }
             int depth = CVGS_DEPTH_32F, cn = CN;
-            Prog::run(c.prog, p, depth, cn);
+            if constexpr ((kAblate & 2) != 0 && SRC == SRC_U8) {
+#pragma unroll
+                for (int k = 0; k < CN; ++k) p.v[k] = p00[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < CN; ++k) {
+                    float acc = p00[k] * w00;
+                    acc = acc + p10[k] * w10;
+                    acc = acc + p01[k] * w01;
+                    acc = acc + p11[k] * w11;
+                    p.v[k] = acc;
+                }
+                Prog::run(c.prog, p, depth, cn);
+            }
             out_cn = cn;
+            if constexpr ((kAblate & 4) != 0) { // probe: no stores (the test never holds on pixel data; the loads stay alive)
+                if (!(__float_as_uint(p.v[0]) == 0x7fc12345u && __float_as_uint(p.v[1]) == 0x7fc54321u && __float_as_uint(p.v[2]) == 0x7fc00001u)) continue;
+            }
             const bool take = whole || (in_x && in_y[j]);
             if constexpr (WM == WM_PLANAR) {
                 OT* const orow = out + (int64_t)y * W; // wave-uniform

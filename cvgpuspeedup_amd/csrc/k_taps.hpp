@@ -275,6 +275,13 @@ __device__ __forceinline__ void st_row(OT* row_uniform, uint32_t x_bytes, float 
     typedef __attribute__((address_space(1))) char* gchar;
     typedef __attribute__((address_space(1))) OT* got;
     const gchar r = (gchar)(got)pin_uniform(row_uniform);
+#if defined(CVGS_K1_STORE) && CVGS_K1_STORE != 0 // tools/probes/tick_ablation.py only: 1 plain, 2 agent-scope (sc1), 3 system-scope write-through (sc0 sc1)
+    if constexpr (std::is_same_v<OT, float>) {
+        if constexpr (CVGS_K1_STORE == 1) *(got)(r + x_bytes) = v;
+        else __hip_atomic_store((__attribute__((address_space(1))) uint32_t*)(r + x_bytes), __float_as_uint(v), __ATOMIC_RELAXED, CVGS_K1_STORE == 2 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+#endif
     if constexpr (std::is_same_v<OT, float>) __builtin_nontemporal_store(v, (got)(r + x_bytes));
     else __builtin_nontemporal_store((OT)v, (got)(r + x_bytes));
 }

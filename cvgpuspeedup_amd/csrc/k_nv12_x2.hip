@@ -14,11 +14,13 @@
 //    compiler's s_waitcnt counts stay exact and no row ever waits for the previous row's stores); small ones keep one row per wave;
 //  * the scalar side (row geometry, row pointers, program operands) is paid once per 128 columns instead of once per 64;
 //  * planar stores are 8 bytes per lane and channel: 512-byte rows per wave, non-temporal.
-// Measured (tools/bench_more.py, tools/bench_nv12_letterbox.py): cfg #3 8.4 -> 8.0 us, 1080p / 4K surface -> 640 x 640 detector
-// input 4.3 / 4.6 -> 3.9 / 4.4 us.  Less than the instruction counts promised, and the reason is measured too: with its loads
-// AND stores disabled the launch still takes 7.2 us of the 8.0-9.0 (the same box) -- the chain is bound by its arithmetic at the
-// issue rates this chip gives it (tools/probes/pk_rate_probe.cpp: a packed fp32 instruction costs 5.7 cycles, worth 1.2 plain
-// ones, not 2), not by memory: 230 VALU instructions per 128 pixels here against 280 on k4_nv12_resize.
+// Measured (tools/bench_more.py, tools/bench_nv12_letterbox.py): cfg #3 8.4 -> 8.0 us (round 3), 1080p / 4K surface -> 640 x 640 detector
+// input 4.3 / 4.6 -> 3.9 / 4.4 us.  What bounds one cfg #3 launch, decomposed on the final tree (round 6: the kernel's own skeletons,
+// tools/probes/tick_ablation.py --workload cfg3, profiles/r06_c_cfg3_rows2_m1.txt): an empty launch of the grid 1.82 us; the arithmetic alone
+// (no loads, no stores) 4.27; the tap loads alone 5.54; the stores alone 3.02; loads + stores without arithmetic 7.36; the product kernel
+// 7.36-7.50 -- it runs AT its memory skeleton (round 3's "7.2 us with loads and stores disabled" described the kernel before its VALU
+// diet; the arithmetic now hides under the load phase).  The skeleton itself is a launch floor + 26 MB that every wave reads, then
+// writes, in the same phase: a single frame-size launch has no second launch to overlap with (ticks of several surfaces do: 5.2 us per frame).
 // Stretch geometry only (every surface covers its whole target), NV12 / NV21 8-bit, three channels, the two compile-time
 // programs; everything else stays on k4_nv12_resize.  Bit-identical to it and to the oracle (tests/test_gpu_k4_x2.py).
 #include <hip/hip_runtime.h>
@@ -31,8 +33,27 @@
 namespace cvgs {
 
 constexpr int kN2Planes = 8; // surfaces per launch (blockIdx.z)
-constexpr int kN2Waves = 4;  // waves per workgroup (independent)
-constexpr int kN2Rows = 4;   // rows per wave of the pipelined form (even)
+// Launch shapes (round 6, tools/probes/tick_ablation.py --workload cfg3, round-robin on one box; profiles/r06_c_cfg3_*): the pipelined form walks
+// kN2Rows rows per wave in workgroups of kN2PipeWaves waves -- 2 rows x 1 wave: 7.36 us at cfg #3 and 5.24 us per frame in a tick of 4 surfaces, against
+// 7.97 / 5.95 for round 5's 4 rows x 4 waves (8 rows: 9.7; every row's loads up front: 7.85; an XCD-banded tile order: 8.16).  Both are macros only so
+// that tools/probes/build_ablate.sh can build the other shapes.
+#ifndef CVGS_K4_WAVES
+#define CVGS_K4_WAVES 1
+#endif
+#ifndef CVGS_K4_ROWS
+#define CVGS_K4_ROWS 2
+#endif
+constexpr int kN2Waves = 4;                 // waves per workgroup of the one-row form (independent)
+constexpr int kN2PipeWaves = CVGS_K4_WAVES; // ... of the pipelined form
+constexpr int kN2Rows = CVGS_K4_ROWS;       // rows per wave of the pipelined form (even)
+
+// Ablation hooks of tools/probes/tick_ablation.py --workload cfg3 (round 6; never defined in the product build, see k_k1_impl.hpp):
+//   1 no tap loads (words synthesised from the lane id)   2 no arithmetic (the tap words are stored as they are)
+//   4 no stores (behind a test that never holds)          16 the wave ends behind its geometry
+#ifndef CVGS_K4_ABLATE
+#define CVGS_K4_ABLATE 0
+#endif
+constexpr int kN2Ablate = CVGS_K4_ABLATE;
 
 typedef uint16_t n2_u16_unaligned __attribute__((aligned(1)));
 typedef uint32_t n2_u32_unaligned __attribute__((aligned(1)));
@@ -73,8 +94,8 @@ __device__ __forceinline__ N2Rgb n2_tap(f32x2 Y, f32x2 U, f32x2 V, const YuvK& k
 #define N2_PRELOADED_PARAMS                                                                                                          \
     const uint8_t *p0_data, int32_t p0_w, int32_t p0_h, int32_t p0_step, int32_t p0_uv_off, float p0_fx, float p0_fy, int32_t pre_dst_w, \
         int32_t pre_dst_h, int32_t pre_out_w, int32_t pre_yuv_range, int32_t pre_yuv_primaries, int32_t pre_yuv_vu
-template <class Prog, int RPW>
-__global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS, const N2Args a) {
+template <class Prog, int RPW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k4_nv12_x2(N2_PRELOADED_PARAMS, const N2Args a) {
     const int z = (int)blockIdx.z;
     N2Plane P = N2Plane{p0_data, p0_w, p0_h, p0_step, p0_uv_off, p0_fx, p0_fy};
     if (z != 0) P = a.plane[z];
@@ -83,10 +104,20 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS,
     const YuvK yk = yuv_matrix(yuv_range, pre_yuv_primaries, CVGS_YUV_NV12);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
-    const int col_tile = (int)blockIdx.x;
-    const int row0 = ((int)blockIdx.y * kN2Waves + wave) * RPW;
+    int col_tile = (int)blockIdx.x, row_group = (int)blockIdx.y;
+#if defined(CVGS_K4_XCD) && CVGS_K4_XCD // probe: workgroup i runs on XCD i % 8 -- give every XCD one contiguous band of the target's row groups
+    {
+        const uint32_t total = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const uint32_t k = lin % 8u, base = total / 8u, rem = total % 8u;
+        const uint32_t tile = k * base + (k < rem ? k : rem) + lin / 8u; // XCD k: tiles [start_k, start_k + base + (k < rem))
+        col_tile = (int)(tile % gridDim.x);
+        row_group = (int)(tile / gridDim.x);
+    }
+#endif
+    const int row0 = (row_group * WAVES + wave) * RPW;
     const int x0 = (col_tile * 64 + lane) * 2;
     if (row0 >= dst_h || x0 >= dst_w) return;
+    if constexpr ((kN2Ablate & 16) != 0) return;
 
     // ---- column geometry of the lane's two pixels (k4_nv12_resize's, per pixel) ----
     f32x2 wxa, wxb;
@@ -138,10 +169,17 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS,
         const gptr_u8 ua = pin_uniform(uvp + (size_t)(r1 >> 1) * step), ub = pin_uniform(uvp + (size_t)(r2 >> 1) * step);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            r.vya[i] = *(n2_gptr_u16)(ya + yo[i]);
-            r.vyb[i] = *(n2_gptr_u16)(yb + yo[i]);
-            r.vua[i] = *(n2_gptr_u32)(ua + uo[i]);
-            r.vub[i] = *(n2_gptr_u32)(ub + uo[i]);
+            if constexpr ((kN2Ablate & 1) != 0) { // probe: no tap loads
+                r.vya[i] = (uint32_t)(lane * 3 + r1 + i) & 0xffffu;
+                r.vyb[i] = (uint32_t)(lane * 5 + r2 + i) & 0xffffu;
+                r.vua[i] = (uint32_t)(lane * 0x01010101 + r1);
+                r.vub[i] = (uint32_t)(lane * 0x01010101 + r2);
+            } else {
+                r.vya[i] = *(n2_gptr_u16)(ya + yo[i]);
+                r.vyb[i] = *(n2_gptr_u16)(yb + yo[i]);
+                r.vua[i] = *(n2_gptr_u32)(ua + uo[i]);
+                r.vub[i] = *(n2_gptr_u32)(ub + uo[i]);
+            }
         }
         return r;
     };
@@ -152,6 +190,12 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS,
     // so rows past the target and the control flow around them disappear and every row issues the same 8 loads + 3 stores
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
     auto finish_row = [&](const Raw& raw, int y) {
+        Px p0, p1;
+        p0.v[3] = p1.v[3] = 0.f;
+        if constexpr ((kN2Ablate & 2) != 0) { // probe: no arithmetic -- the tap words as they are
+            p0.v[0] = __uint_as_float(raw.vya[0] | (raw.vyb[0] << 16)); p0.v[1] = __uint_as_float(raw.vua[0]); p0.v[2] = __uint_as_float(raw.vub[0]);
+            p1.v[0] = __uint_as_float(raw.vya[1] | (raw.vyb[1] << 16)); p1.v[1] = __uint_as_float(raw.vua[1]); p1.v[2] = __uint_as_float(raw.vub[1]);
+        } else {
         f32x2 fy[4], fu[4], fv[4]; // taps 00, 10, 01, 11 of the pixel pair
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -177,13 +221,16 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS,
             v = t[0].b * w00; v = v + t[1].b * w10; v = v + t[2].b * w01; v = v + t[3].b * w11; acc[2] = v;
         }
         // the program, per pixel: the compile-time stages of k_taps.hpp (incl. the division by the uniform divisor)
-        Px p0, p1;
-        p0.v[0] = acc[0].x; p0.v[1] = acc[1].x; p0.v[2] = acc[2].x; p0.v[3] = 0.f;
-        p1.v[0] = acc[0].y; p1.v[1] = acc[1].y; p1.v[2] = acc[2].y; p1.v[3] = 0.f;
+        p0.v[0] = acc[0].x; p0.v[1] = acc[1].x; p0.v[2] = acc[2].x;
+        p1.v[0] = acc[0].y; p1.v[1] = acc[1].y; p1.v[2] = acc[2].y;
         int depth = CVGS_DEPTH_32F, cn = 3;
         Prog::run(a.prog, p0, depth, cn);
         depth = CVGS_DEPTH_32F; cn = 3;
         Prog::run(a.prog, p1, depth, cn);
+        }
+        if constexpr ((kN2Ablate & 4) != 0) { // probe: no stores (the test never holds on pixel data)
+            if (!(__float_as_uint(p0.v[0]) == 0x7fc12345u && __float_as_uint(p0.v[1]) == 0x7fc54321u && __float_as_uint(p1.v[2]) == 0x7fc00001u)) return;
+        }
         if constexpr (RPW > 1) {
             // (even target widths only: the launcher checks) offsets in bytes from the tensor's start fit 32 bits (checked on the host)
             const uint32_t row_off = (uint32_t)(((int64_t)z * a.img_stride + (int64_t)y * W) * 4);
@@ -218,6 +265,13 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS,
     } else {
         // the wave's rows one after the other, the NEXT row's tap words requested before this row is computed: across the chip the
         // rows' loads and stores interleave in time (a launch of one-row waves reads everything, then writes everything)
+#if defined(CVGS_K4_UPFRONT) && CVGS_K4_UPFRONT // probe (tools/probes/build_ablate.sh): every row's tap words requested before the first row is computed
+        Raw r[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) r[j] = load_row(row0 + j);
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) finish_row(r[j], row0 + j);
+#else
         Raw r0 = load_row(row0), r1;
 #pragma unroll
         for (int j = 0; j < RPW; j += 2) {
@@ -226,6 +280,7 @@ __global__ __launch_bounds__(64 * kN2Waves) void k4_nv12_x2(N2_PRELOADED_PARAMS,
             if (j + 2 < RPW) r0 = load_row(row0 + j + 2);
             finish_row(r1, row0 + j + 1);
         }
+#endif
     }
 }
 
@@ -261,18 +316,18 @@ int launch_nv12_x2(const ChainArgs& c, const PlaneParams* planes, int n_planes, 
     const bool pipe = !(rows_env && rows_env[0] == '1') && (r.dst_w & 1) == 0 && total_bytes > 0 && total_bytes < ((int64_t)1 << 32) - 65536 &&
                       (int64_t)r.batch * r.dst_h * ((r.dst_w + 127) / 128) >= 4096;
     a.out_bytes = pipe ? (uint32_t)total_bytes : 0u;
-    const int rpw = pipe ? kN2Rows : 1; // (round 5 A/B of 4 / 2 / 1 rows per wave at cfg #3: 8.19 / 7.93 / 8.03 us -- flat: profiles/r05_f_k4_rows_ab.txt)
-    const unsigned col_tiles = (unsigned)((r.dst_w + 127) / 128), row_groups = (unsigned)((r.dst_h + kN2Waves * rpw - 1) / (kN2Waves * rpw));
-    const dim3 grid(col_tiles, row_groups, (unsigned)r.batch), block(64 * kN2Waves);
+    const int rpw = pipe ? kN2Rows : 1, waves = pipe ? kN2PipeWaves : kN2Waves;
+    const unsigned col_tiles = (unsigned)((r.dst_w + 127) / 128), row_groups = (unsigned)((r.dst_h + waves * rpw - 1) / (waves * rpw));
+    const dim3 grid(col_tiles, row_groups, (unsigned)r.batch), block(64 * waves);
     hipStream_t s = (hipStream_t)stream;
     const N2Plane& p0 = a.plane[0];
 #define N2_PRELOADED_VALUES p0.data, p0.w, p0.h, p0.step, p0.uv_off, p0.fx, p0.fy, a.dst_w, a.dst_h, a.out_w, a.yuv_range, a.yuv_primaries, a.yuv_vu
     if (prog_swap) {
-        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, kN2Rows>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
-        else hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, 1>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
+        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, kN2Rows, kN2PipeWaves>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
+        else hipLaunchKernelGGL((k4_nv12_x2<ProgSwapMulSubDiv, 1, kN2Waves>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
     } else {
-        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, kN2Rows>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
-        else hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, 1>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
+        if (pipe) hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, kN2Rows, kN2PipeWaves>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
+        else hipLaunchKernelGGL((k4_nv12_x2<ProgMulSubDiv, 1, kN2Waves>), grid, block, 0, s, N2_PRELOADED_VALUES, a);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : -(int)e - 1000;

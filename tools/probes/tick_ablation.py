@@ -15,6 +15,10 @@ k_k1_c3.hip again with -DCVGS_K1_ABLATE / -DCVGS_K1_STORE into build/ablate/libc
   zfast_ldst  the skeleton in that order
   plain / sc1 / sys   product kernel with plain / agent-scope (sc1) / system-scope write-through stores instead of non-temporal ones
 
+--workload cfg3 does the same for k4_nv12_x2 (BASELINE cfg #3, NV12 6K -> 1280x720, --m surfaces per launch), variants k4_full / k4_ldst / k4_ld / k4_st /
+k4_math (no loads, no stores: the arithmetic alone) / k4_empty (the wave ends behind its first bounds test) from -DCVGS_K4_ABLATE builds of k_nv12_x2.hip.
+--frame 8k draws the headline's 50 crops from 7680x4320 frames, where crops of the same sizes barely overlap (what the eight L2s fetch = what HBM delivers).
+
 Variants are measured round-robin (ABAB...), R rounds, the median over rounds is reported (A-then-B orderings drift by ~3 % on this pool).
 usage (GPU box): python tools/probes/tick_ablation.py [--m 16] [--frames 96] [--rounds 4] [--variants full,ldst,...]"""
 import argparse
@@ -26,7 +30,57 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-BITWISE = ("full", "zfast", "plain", "sc1", "sys")  # variants whose output must equal the product's bit for bit
+ABLATED = ("ldst", "ld", "st", "math", "empty", "desc")  # name tokens of variants that do NOT compute the product's values; every other variant must match it bit for bit
+
+
+def bitwise(v):
+    return not any(t in ABLATED for t in v.split("_"))
+
+
+class Cfg3Workload:
+    """BASELINE cfg #3 as tools/bench_more.py: cfg3() builds it: NV12 6144x3456 surfaces -> BGR float -> 1280x720 -> normalize -> split, one
+    cvgs_execute per launch (`cams` surfaces per chain: 1 = one launch per frame), a rotation sized from the touched sectors."""
+
+    def __init__(self, dev, cams=1):
+        import ctypes as C
+        import torch
+        from cvgpuspeedup_amd import capi, cvgs
+        from cvgpuspeedup_amd import workloads as W
+        w, h = W.FRAME_6K
+        dst = (1280, 720)
+        nbuf = W.rotation_units(W.nv12_sector_read_bytes(w, h, dst[0], dst[1], 1), minimum=6)
+        nbuf = (nbuf // cams) * cams
+        self.bufs = [W.random_u8_torch((h + h // 2, w), 500 + i, dev) for i in range(nbuf)]
+        self.outs = [torch.zeros((cams, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev) for _ in range(nbuf // cams)]
+        f = cvgs.CV_32FC3
+        self.chains = []
+        for k, o in enumerate(self.outs):
+            lumas = [cvgs.GpuMat(h, w, cvgs.CV_8UC1, b.data_ptr(), w, owner=b) for b in self.bufs[k * cams:(k + 1) * cams]]
+            rd = cvgs.read_nv12(lumas[0] if cams == 1 else lumas, dst, capi.YUV_FULL, capi.BT709, False)
+            ops = [rd, cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [W.K1_ALPHA] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3]),
+                   cvgs.split(f, cvgs.GpuMat.from_tensor(o, cvgs.CV_32FC1), dst)]
+            self.chains.append(cvgs.lower(ops))
+        self.kernel = cvgs.kernel_name(*ops)
+        self.lib = capi.load_library()
+        self.per_launch = 1
+        self.n = cams
+        self.groups = []
+        self._C = C
+        self._check = capi.check
+        write = dst[0] * dst[1] * 3 * 4
+        self._alg = cams * (write + dst[0] * dst[1] * 4 + dst[0] * dst[1] * 2 * 4)
+        self._sector = cams * (W.nv12_sector_read_bytes(w, h, dst[0], dst[1], 1) + write)
+
+    def launch(self, i, stream):
+        rc = self.lib.cvgs_execute(self._C.byref(self.chains[i % len(self.chains)].desc), stream)
+        if rc:
+            self._check(rc)
+
+    def algorithmic_bytes(self):
+        return float(self._alg)
+
+    def sector_bound_bytes(self):
+        return float(self._sector)
 
 
 def load_variant(path):
@@ -45,21 +99,30 @@ def main():
     p.add_argument("--m", type=int, default=16, help="frames per launch (1 = one cvgs_execute per frame)")
     p.add_argument("--frames", type=int, default=96)
     p.add_argument("--rounds", type=int, default=4)
-    p.add_argument("--variants", default="full,ldst,ld,st,desc,zfast,zfast_ldst,plain,sc1,sys")
+    p.add_argument("--variants", default=None)
+    p.add_argument("--workload", default="k1", choices=["k1", "cfg3"], help="k1: the headline ticks (cfg #2b); cfg3: NV12 6K -> 1280x720, --m = cameras per launch")
+    p.add_argument("--frame", default="4k", choices=["4k", "8k"], help="k1 only: frame size the 50 crops are drawn from (8k: the same crop sizes barely overlap)")
     p.add_argument("--out", default=None)
     a = p.parse_args()
     import numpy as np
     import torch
     import bench as B
     from cvgpuspeedup_amd import capi
+    from cvgpuspeedup_amd import workloads as W
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
     s = side.cuda_stream
     M = a.m
-    nf = ((a.frames + M - 1) // M) * M
-    wl = B.Workload(dev, nf, 50, 0, 1, True, per_launch=M)
+    if a.variants is None:
+        a.variants = "full,ldst,ld,st,desc,zfast,zfast_ldst,plain,sc1,sys" if a.workload == "k1" else "k4_full,k4_ldst,k4_ld,k4_st,k4_math,k4_empty"
+    if a.workload == "cfg3":
+        wl = Cfg3Workload(dev, cams=M)
+        nf, M = len(wl.chains), 1  # one cvgs_execute per launch
+    else:
+        nf = ((a.frames + M - 1) // M) * M
+        wl = B.Workload(dev, nf, 50, 0, 1, True, per_launch=M, frame_wh=(7680, 4320) if a.frame == "8k" else W.FRAME_4K)
     installed = wl.lib
     names = [v for v in a.variants.split(",") if v]
     libs = {"installed": installed}
@@ -71,6 +134,8 @@ def main():
         libs[v] = load_variant(path)
     order = ["installed"] + names
     launches = max(16, 256 // M)
+    if a.workload == "cfg3":
+        launches = 2 * nf
 
     def run_all(lib):
         wl.lib = lib
@@ -86,7 +151,7 @@ def main():
     ref = [o.clone() for o in wl.outs]
     bit = {}
     for v in names:
-        if v in BITWISE:
+        if bitwise(v):
             for o in wl.outs:
                 o.zero_()
             run_all(libs[v])
@@ -96,7 +161,7 @@ def main():
     for r in range(a.rounds):
         for v in order:
             wl.lib = libs[v]
-            m = B.measure(wl, launches, 4, target_s=0.12, min_replays=20, est_step_s=2.5e-6 * M, exact_steps=True)
+            m = B.measure(wl, launches, 4, target_s=0.12, min_replays=20, est_step_s=(8e-6 * a.m if a.workload == "cfg3" else 2.5e-6 * M), exact_steps=True)
             times[v].append(m["step_s"] * 1e6)
             print("round %d %-12s %8.3f us per launch" % (r, v, times[v][-1]), file=sys.stderr, flush=True)
     wl.lib = installed
@@ -106,15 +171,18 @@ def main():
     for v in order:
         t = float(np.median(times[v]))
         rows[v] = {"us_per_launch": round(t, 3), "us_per_frame": round(t / M, 4), "min_us": round(min(times[v]), 3), "max_us": round(max(times[v]), 3),
-                   "frac_alg_of_8TBs": round(alg / t / 1e6 / 8000.0, 4), "sector_TBs": round(sect / t / 1e6, 3)}
+                   "frac_alg_of_8TBs": round(alg / t / 1e6 / 8.0, 4), "sector_TBs": round(sect / t / 1e6, 3)}
         if v in bit:
             rows[v]["bit_identical_to_installed"] = bit[v]
     out = {"m": M, "frames": nf, "rounds": a.rounds, "launches_per_replay": launches, "algorithmic_bytes_per_launch": alg, "sector_floor_bytes_per_launch": sect,
            "copy_ceiling_TBs": copy, "rows": rows}
-    full = rows.get("full", rows["installed"])["us_per_launch"]
-    if "ldst" in rows:
-        out["full_over_skeleton"] = round(full / rows["ldst"]["us_per_launch"], 4)
-    text = ["# tick ablation: M = %d frames x 50 crops per launch, %d-frame rotation, %d rounds round-robin, median (min-max) us per launch" % (M, nf, a.rounds),
+    full = rows.get("full", rows.get("k4_full", rows["installed"]))["us_per_launch"]
+    skel = "ldst" if "ldst" in rows else ("k4_ldst" if "k4_ldst" in rows else None)
+    if skel:
+        out["full_over_skeleton"] = round(full / rows[skel]["us_per_launch"], 4)
+    what = ("cfg #3 (NV12 6K -> 1280x720 normalized NCHW), %d surface(s) per launch, %d launches in rotation" % (a.m, nf) if a.workload == "cfg3" else
+            "M = %d frames (%s) x 50 crops per launch, %d-frame rotation" % (M, a.frame, nf))
+    text = ["# ablation of %s [%s]: %d rounds round-robin, median (min-max) us per launch" % (wl.kernel, what, a.rounds),
             "# algorithmic bytes per launch %.0f, 64-B sector floor %.0f, copy ceiling of this run %s TB/s" % (alg, sect, json.dumps(copy)),
             "%-12s %10s %10s %18s %10s %12s %s" % ("variant", "us/launch", "us/frame", "min-max", "frac(alg)", "sector TB/s", "bits")]
     for v in order:
@@ -122,7 +190,7 @@ def main():
         text.append("%-12s %10.3f %10.4f %8.3f-%-9.3f %10.4f %12.3f %s" % (v, r["us_per_launch"], r["us_per_frame"], r["min_us"], r["max_us"], r["frac_alg_of_8TBs"], r["sector_TBs"],
                                                                           r.get("bit_identical_to_installed", "")))
     if "full_over_skeleton" in out:
-        text.append("# product kernel / its own memory skeleton (ldst) = %.4f" % out["full_over_skeleton"])
+        text.append("# product kernel / its own memory skeleton (%s) = %.4f" % (skel, out["full_over_skeleton"]))
     print("\n".join(text))
     print(json.dumps(out))
     if a.out:

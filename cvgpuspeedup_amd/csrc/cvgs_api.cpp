@@ -481,7 +481,7 @@ struct ScratchSlot {
     void* dev = nullptr;
     size_t cap = 0;
     // Completion tracking: the slot is reusable once `ev` has completed.  The launch that reads the slot signals it ITSELF
-    // (hipExtLaunchKernelGGL's stopEvent, K1's planar kernels: cvgs_device.h StopEventSlot) or, at the other launch sites, a hipEventRecord
+    // (hipExtLaunchKernelGGL's stopEvent, K1's planar kernels: cvgs_device.h LaunchCtx::stop_event) or, at the other launch sites, a hipEventRecord
     // follows the launch.  Either way the stream pays ~4 us of device time between this kernel and the next (rocprofv3 kernel trace) -- which
     // is why the hot multi-chain launch does not come through here any more (ManyPool below: a progress word the kernel writes).  No stream
     // handle is touched after the call that used it (round 4 reclaimed quiet streams' slots with hipStreamQuery, which faults on a destroyed
@@ -757,6 +757,7 @@ struct Upload {
     void* dev = nullptr;
     size_t used = 0;
     bool flushed = false;
+    void* stop_event = nullptr; // the slot's event when the kernel reads the pinned table in place: a K1 launch site signals it itself (LaunchCtx)
     int begin(size_t bytes, hipStream_t s) {
         stream = s;
         // Under stream capture the copy node would keep a pointer to staging memory this library recycles: refuse
@@ -773,9 +774,7 @@ struct Upload {
         rc = scratch_pool().acquire(device, bytes, &slot, s);
         if (rc) return rc;
         dev = scratch_pool().dev(slot);
-        cvgs::StopEventSlot& st = cvgs::tls_stop_event();
-        st.event = scratch_zero_copy() ? (void*)scratch_pool().event(slot) : nullptr;
-        st.used = false;
+        stop_event = scratch_zero_copy() ? (void*)scratch_pool().event(slot) : nullptr;
         return 0;
     }
     // appends `bytes` to the staging buffer; returns the device address they will have (16-byte aligned pieces)
@@ -796,12 +795,11 @@ struct Upload {
         flushed = true;
         return 0;
     }
-    void done(bool launched) {
+    // signalled_by_launch: the launch site attached stop_event to its kernel (LaunchCtx::stop_event_taken)
+    void done(bool launched, bool signalled_by_launch = false) {
         if (slot < 0) return;
-        cvgs::StopEventSlot& st = cvgs::tls_stop_event();
-        const bool by_launch = launched && st.event && st.used;
-        st.event = nullptr;
-        st.used = false;
+        const bool by_launch = launched && stop_event && signalled_by_launch;
+        stop_event = nullptr;
         if (launched || flushed) scratch_pool().commit(slot, stream, by_launch); // an enqueued copy still reads the staging bytes
         else scratch_pool().abandon(slot);
         slot = -1;
@@ -821,11 +819,13 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
     if (!warp && !L.uses_64f && !L.int_arith && !L.args.read.table && !(ch->flags & CVGS_CHAIN_FORCE_GENERIC) &&
         (int)L.planes.size() > CVGS_KERNARG_PLANES && (int)L.planes.size() <= kKernargPlanesBig)
     {
-        big_inline = launch_k1(L.args, L.planes.data(), (int)L.planes.size(), L.mirrors, nullptr, 0, stream, true, nullptr) == 1;
+        LaunchCtx probe(stream);
+        probe.mirrors = L.mirrors;
+        big_inline = launch_k1(L.args, L.planes.data(), (int)L.planes.size(), probe, true, nullptr) == 1;
         if (!big_inline && !has_mirrors && is_nv12(L.args.read.kind)) { // K4: crops of a decoder surface into a planar tensor
             int min_w = 1 << 30;
             for (size_t i = 0; i < L.planes.size() && (int)i < L.args.read.used; ++i) min_w = L.planes[i].w < min_w ? L.planes[i].w : min_w;
-            big_inline = launch_nv12(L.args, L.planes.data(), (int)L.planes.size(), min_w, nullptr, 0, stream, true, nullptr) == 1;
+            big_inline = launch_nv12(L.args, L.planes.data(), (int)L.planes.size(), min_w, probe, true, nullptr) == 1;
         }
     }
     const bool up_src = warp ? (int)L.warp_planes.size() > (L.uses_64f ? kInlineWarp64 : kInlineWarp)
@@ -884,9 +884,12 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
         return CVGS_OK;
     }
     if (!(ch->flags & CVGS_CHAIN_FORCE_GENERIC) && !L.int_arith) { // integer-typed arithmetic: the interpreted kernel's business
-        rc = launch_k1(L.args, inline_planes, n_inline, L.mirrors, nullptr, 0, stream, dry_run, info, ch->flags);
+        LaunchCtx ctx(stream);
+        ctx.mirrors = L.mirrors;
+        ctx.stop_event = up.stop_event;
+        rc = launch_k1(L.args, inline_planes, n_inline, ctx, dry_run, info, ch->flags);
         if (rc < 0) return fail(CVGS_ERR_HIP, "K1 kernel launch failed");
-        if (rc == 1) { up.done(true); return CVGS_OK; }
+        if (rc == 1) { up.done(true, ctx.stop_event_taken); return CVGS_OK; }
         if (big_inline && (has_mirrors || !is_nv12(L.args.read.kind)))
             return fail(CVGS_ERR_HIP, "internal: K1 refused a chain its dry run accepted"); // only K1 / K4 take > 64 inline planes
         if (!has_mirrors) { // only K1 and the interpreted kernel write mirrors
@@ -897,9 +900,13 @@ int dispatch(const cvgs_chain_desc* ch, Lowered& L, hipStream_t stream, bool dry
                 // more than 64 crops of a decoder surface: K4 reads the staged table as ONE segment of its fused-chain form
                 // (the planes are known on the host here, so its per-plane preconditions can be checked)
                 const ManySeg seg{L.args.read.table, L.args.write.data, L.args.read.batch, L.args.read.used};
-                rc = launch_nv12(L.args, nullptr, 0, 4, &seg, 1, stream, dry_run, info);
+                LaunchCtx one(stream);
+                one.segs = &seg;
+                one.n_segs = 1;
+                rc = launch_nv12(L.args, nullptr, 0, 4, one, dry_run, info);
             } else {
-                rc = launch_nv12(L.args, inline_planes, n_inline, min_w, nullptr, 0, stream, dry_run, info, ch->flags);
+                LaunchCtx plain(stream);
+                rc = launch_nv12(L.args, inline_planes, n_inline, min_w, plain, dry_run, info, ch->flags);
             }
             if (rc < 0) return fail(CVGS_ERR_HIP, "NV12 kernel launch failed");
             if (rc == 1) { up.done(true); return CVGS_OK; }
@@ -1074,8 +1081,11 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             ChainArgs probe = L0.args;
             probe.read.table = (const PlaneParams*)(uintptr_t)16;
             const ManySeg one{probe.read.table, probe.write.data, probe.read.batch, probe.read.used};
-            if (k4) fusable = !tables && launch_nv12(probe, nullptr, 0, 1 << 30, &one, 1, stream, true, nullptr) == 1; // K4 checks its planes on the host
-            else fusable = launch_k1(probe, nullptr, 0, MirrorArgs{}, &one, 1, stream, true, nullptr) == 1;
+            LaunchCtx pctx(stream);
+            pctx.segs = &one;
+            pctx.n_segs = 1;
+            if (k4) fusable = !tables && launch_nv12(probe, nullptr, 0, 1 << 30, pctx, true, nullptr) == 1; // K4 checks its planes on the host
+            else fusable = launch_k1(probe, nullptr, 0, pctx, true, nullptr) == 1;
         }
         // host descriptors: the table goes into a slot of the stream's own ring, recycled through the launch's progress word (ManyPool) --
         // or, when that ring has no room, into the event-tracked descriptor scratch
@@ -1131,16 +1141,17 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
             ChainArgs c = L0.args;
             c.read.batch = max_batch;
             c.read.table = inline_many ? nullptr : segs[0].table; // non-null: the table variants; null + segments: planes in the arguments
-            cvgs::DoneWordSlot& dw = cvgs::tls_done_word();
-            dw = cvgs::DoneWordSlot{};
+            LaunchCtx ctx(stream);
+            ctx.segs = segs;
+            ctx.n_segs = n;
+            ctx.stop_event = up.stop_event;
             if (mslot) { // this launch is number next_seq of its stream: when it starts, number next_seq - 1 has finished
-                dw.word = ms->done_dev;
-                dw.value = ms->next_seq - 1;
+                ctx.done_word = ms->done_dev;
+                ctx.done_value = ms->next_seq - 1;
             }
-            rc = k4 ? launch_nv12(c, inline_many ? inline_planes.data() : nullptr, inline_many ? (int)inline_planes.size() : 0, 1 << 30, segs, n, stream, false, nullptr)
-                    : launch_k1(c, inline_many ? inline_planes.data() : nullptr, inline_many ? (int)inline_planes.size() : 0, MirrorArgs{}, segs, n, stream, false, nullptr);
-            const bool reported = dw.used;
-            dw = cvgs::DoneWordSlot{};
+            rc = k4 ? launch_nv12(c, inline_many ? inline_planes.data() : nullptr, inline_many ? (int)inline_planes.size() : 0, 1 << 30, ctx, false, nullptr)
+                    : launch_k1(c, inline_many ? inline_planes.data() : nullptr, inline_many ? (int)inline_planes.size() : 0, ctx, false, nullptr);
+            const bool reported = ctx.done_word_taken;
             if (rc != 1) return fail(CVGS_ERR_HIP, "fused kernel launch failed");
             if (mslot) {
                 if (reported) mslot->seq = ms->next_seq++;
@@ -1149,7 +1160,7 @@ int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
                     mslot->seq = 0;
                 }
             }
-            up.done(true);
+            up.done(true, ctx.stop_event_taken);
             return CVGS_OK;
         }
         // not a fast-kernel shape after all (e.g. an integer-typed program): one by one below; nothing was enqueued

@@ -104,36 +104,33 @@ static_assert(sizeof(KernArgs<kKernargPlanesBig>) <= 16384, "large kernel-argume
 
 // Extra write targets (cvgs_write_desc.mirrors): the same values at the same element offsets in up to 7 more tensors
 // (the peers' copies of the sharded [N,C,H,W] tensor).  Travels as its own kernel argument to the kernels that
-// The launch that reads a pooled descriptor table signals the slot's event ITSELF (hipExtLaunchKernelGGL's stopEvent: the kernel packet's own
-// completion signal) instead of a hipEventRecord behind it -- a marker packet that kept the NEXT kernel of the stream ~4 us behind.  Armed by
-// the table upload of the call (thread-local: the launch happens on the same thread, inside the same C-ABI call), consumed by the launch site.
-struct StopEventSlot {
-    void* event = nullptr; // hipEvent_t
-    bool used = false;     // a launch site attached it
-};
-inline StopEventSlot& tls_stop_event() {
-    static thread_local StopEventSlot x{};
-    return x;
-}
-
-// The fused K1 launch of cvgs_execute_many reports the stream's progress itself: its first work-item stores `value` (the sequence number
-// of the stream's PREVIOUS fused launch, which has finished once this kernel runs) into the pinned word `word` (cvgs_api.cpp: ManyPool).
-// Armed by the call that prepared the table, consumed by the launch site (thread-local, as the stop event above).
-struct DoneWordSlot {
-    uint64_t* word = nullptr;
-    uint64_t value = 0;
-    bool used = false;
-};
-inline DoneWordSlot& tls_done_word() {
-    static thread_local DoneWordSlot x{};
-    return x;
-}
-
 // implement it (K1 planar inside K1Geom, the interpreted kernel).
 struct MirrorArgs {          // 64 bytes
     uint8_t* p[CVGS_MAX_MIRRORS];
     int32_t n;
     int32_t pad;
+};
+
+struct ManySeg;
+// What a K1 / K4 launch takes beside its chain: ONE explicit argument from the C-ABI call down to the launch site (round 6; rounds 4-5 passed
+// these through three thread-local slots, and a launch site that forgot to consume one fell back to a stream synchronise).
+struct LaunchCtx {
+    void* stream = nullptr;        // hipStream_t
+    MirrorArgs mirrors{};          // extra write targets (K1's planar kernels)
+    const ManySeg* segs = nullptr; // the chains of a cvgs_execute_many launch (nullptr: one chain)
+    int n_segs = 0;
+    // The launch that reads a pooled descriptor table signals the slot's event ITSELF (hipExtLaunchKernelGGL's stopEvent: the kernel packet's own
+    // completion signal) instead of a hipEventRecord behind it -- a marker packet that kept the NEXT kernel of the stream ~4 us behind.  Set by
+    // the call that uploaded the table; a launch site that attaches it says so in stop_event_taken (the others get an event recorded behind them).
+    void* stop_event = nullptr;    // hipEvent_t
+    bool stop_event_taken = false;
+    // The fused launch of cvgs_execute_many reports its stream's progress itself: its first work-item stores done_value (the sequence number
+    // of the stream's PREVIOUS fused launch, which has finished once this kernel runs) into the pinned word done_word (cvgs_api.cpp: ManyPool).
+    uint64_t* done_word = nullptr;
+    uint64_t done_value = 0;
+    bool done_word_taken = false;
+    LaunchCtx() = default;
+    explicit LaunchCtx(void* s) : stream(s) {}
 };
 
 // cvgs_execute_many: one segment per fused chain.  The K1 kernel's table variants ALWAYS read their planes through a
@@ -192,10 +189,9 @@ int launch_generic(const ChainArgs& c, const PlaneParams* inline_planes, int n_i
 
 // K1 fast path: u8 C3/C4 -> resize linear -> program -> fp32 TensorSplit / TensorTSplit.
 // Returns 1 if it took the chain, 0 if not eligible, <0 on error.
-// `segs` (n_segs >= 1): the chains of a cvgs_execute_many launch (their planes live in device tables; c.read.batch is
+// ctx.segs (n_segs >= 1): the chains of a cvgs_execute_many launch (their planes live in device tables; c.read.batch is
 // the largest batch); nullptr: one chain described by c / inline_planes.
-int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors,
-              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags = 0);
+int launch_k1(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, LaunchCtx& ctx, bool dry_run, LaunchInfo* info, uint32_t chain_flags = 0);
 // K1's whole-frame form for packed targets, four output pixels per lane (k_k1_x4.hip); 1 launched / 0 not eligible / < 0 error
 int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_planes, void* stream, bool dry_run, bool force);
 static constexpr int64_t kX4MinWaveRows = 12288; // output rows x 64-column tiles x images from which launch_k1 prefers it
@@ -205,8 +201,8 @@ int launch_generic64(const ChainArgs& c, const Prog64Args& p64, const PlaneParam
                      bool dry_run, LaunchInfo* info);
 
 // K4 fast path: NV12 read-back fused into the bilinear resize -> program -> planar fp32 tensor or packed pixels.
-int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, const ManySeg* segs, int n_segs,
-                void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags = 0);
+int launch_nv12(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int min_width, LaunchCtx& ctx, bool dry_run, LaunchInfo* info,
+                uint32_t chain_flags = 0);
 // K4 at frame size, two output pixels per lane (k_nv12_x2.hip); 1 launched / 0 not eligible / < 0 error
 int launch_nv12_x2(const ChainArgs& c, const PlaneParams* planes, int n_planes, bool prog_swap, void* stream, bool dry_run);
 static constexpr int64_t kK4X2MinWaveRows = 4096; // output rows x 64-column tiles x surfaces from which launch_nv12 prefers it

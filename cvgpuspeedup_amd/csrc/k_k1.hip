@@ -28,11 +28,14 @@
 namespace cvgs {
 
 // the planar-tensor variants of 3- / 4-channel sources live in k_k1_c3.hip / k_k1_c4.hip (parallel compilation)
-hipError_t k1_launch_planar_c3(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s);
-hipError_t k1_launch_planar_c4(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s);
+hipError_t k1_launch_planar_c3(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, LaunchCtx& s);
+hipError_t k1_launch_planar_c4(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, LaunchCtx& s);
 
-int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, const MirrorArgs& mirrors,
-              const ManySeg* segs, int n_segs, void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags) {
+int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, LaunchCtx& ctx, bool dry_run, LaunchInfo* info, uint32_t chain_flags) {
+    const MirrorArgs& mirrors = ctx.mirrors;
+    const ManySeg* const segs = ctx.segs;
+    const int n_segs = ctx.n_segs;
+    void* const stream = ctx.stream;
     const ReadArgs& r = c_in.read;
     // eligibility: 8U / 16U / 16S C3/C4 resize read, fp32 planar tensor write -- or, for 8U sources, an fp16 planar
     // tensor whose conversion is the chain's LAST stage (the half-precision hand-off option)
@@ -157,12 +160,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
     }
     if (dry_run) return 1;
-    LaunchExtra& extra = tls_extra();
-    extra.mirrors = mirrors;
-    extra.segs = segs;
-    extra.n_segs = n_segs;
-
-    hipStream_t s = (hipStream_t)stream;
+    LaunchCtx& s = ctx;
     const int out_cn = c.write.cn;
     hipError_t e;
     if (mirrors.n > 0) {

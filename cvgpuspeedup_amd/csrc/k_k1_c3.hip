@@ -3,7 +3,7 @@
 
 namespace cvgs {
 
-hipError_t k1_launch_planar_c3(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s) {
+hipError_t k1_launch_planar_c3(int src, bool f16, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, LaunchCtx& s) {
     if (f16) return launch_prog<3, SRC_U8, _Float16>(prog_id, table, rpw, c, ip, ni, out_cn, s);
     return src == SRC_U8    ? launch_prog<3, SRC_U8>(prog_id, table, rpw, c, ip, ni, out_cn, s)
            : src == SRC_U16 ? launch_prog<3, SRC_U16>(prog_id, table, rpw, c, ip, ni, out_cn, s)

@@ -352,20 +352,9 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
 }
 
 // ------------------------------------------------------------------------------------------------
-// what launch_k1 hands to the instantiation it picks, without threading two more parameters through every selector
-struct LaunchExtra {
-    MirrorArgs mirrors;
-    const ManySeg* segs;
-    int n_segs;
-};
-inline LaunchExtra& tls_extra() { // inline: ONE thread-local instance across the translation units
-    static thread_local LaunchExtra x{};
-    return x;
-}
-
 template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT, int WM = WM_PLANAR, bool MIR = false>
-static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn,
-                           hipStream_t stream) {
+static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn, LaunchCtx& x) {
+    hipStream_t stream = (hipStream_t)x.stream;
     K1Args<NPL> a;
     a.c = c;
     unsigned grid_z = 1;
@@ -373,7 +362,6 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         for (int i = 0; i < n_inline; ++i) a.planes[i] = inline_planes[i];
         for (int i = n_inline; i < NPL; ++i) a.planes[i] = PlaneParams{};
     } else {
-        const LaunchExtra& x = tls_extra();
         if constexpr (NPL < 0) { // fused chains with host descriptors: every chain's planes behind the segments (segs[i].table = first index)
             for (int i = 0; i < n_inline && i < -NPL; ++i) a.planes[i] = inline_planes[i];
         }
@@ -408,21 +396,17 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     g.row_pitch2 = c.write.width * px_bytes;
     g.img_pitch2 = c.write.img_stride2 * px_bytes;
     g.planes2d = c.write.table;
-    {
-        const LaunchExtra& x = tls_extra();
-        g.n_mirror = MIR ? x.mirrors.n : 0;
-        g.pad2 = 0;
-        for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
-    }
+    g.n_mirror = MIR ? x.mirrors.n : 0;
+    g.pad2 = 0;
+    for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
     const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
     g.done_word = nullptr;
     g.done_value = 0;
     if constexpr (NPL == 0) {
-        DoneWordSlot& dw = tls_done_word();
-        if (dw.word && !dw.used) {
-            dw.used = true;
-            g.done_word = dw.word;
-            g.done_value = dw.value;
+        if (x.done_word && !x.done_word_taken) {
+            x.done_word_taken = true;
+            g.done_word = x.done_word;
+            g.done_value = x.done_value;
         }
     }
     // segment 0 / the single chain, repeated in front of the argument block (K1_PRELOADED_PARAMS)
@@ -435,10 +419,9 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         pre_batch = a.seg[0].batch;
         pre_used = a.seg[0].used;
     }
-    StopEventSlot& stop = tls_stop_event();
-    if (stop.event && !stop.used) {
-        stop.used = true;
-        hipExtLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, nullptr, (hipEvent_t)stop.event, 0u,
+    if (x.stop_event && !x.stop_event_taken) {
+        x.stop_event_taken = true;
+        hipExtLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, nullptr, (hipEvent_t)x.stop_event, 0u,
                               pre_table, pre_out, g.img_stride, g.ch_stride, pre_batch, pre_used, g.col_tiles, g.dst_w, g.dst_h, g.out_w, a, g);
     } else {
         hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream,
@@ -449,7 +432,7 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
 
 // packed / separate-plane targets; one row per wave, four for whole-frame sizes
 template <int CN, typename OT, int WM, class Prog = InterpProg, int SRC = SRC_U8>
-static hipError_t launch_other(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+static hipError_t launch_other(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
     if (rpw >= 4) {
         if (table) return launch_t<CN, 0, 4, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
         return launch_t<CN, CVGS_KERNARG_PLANES, 4, Prog, SRC, OT, WM>(c, ip, ni, c.write.cn, s);
@@ -459,7 +442,7 @@ static hipError_t launch_other(bool table, int rpw, const ChainArgs& c, const Pl
 }
 // the same with the program picked at run time: empty (nothing between the resize and the folded cast / the write) or interpreted
 template <int CN, typename OT, int WM, int SRC = SRC_U8>
-static hipError_t launch_other_np(bool none, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+static hipError_t launch_other_np(bool none, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
     if (none) return launch_other<CN, OT, WM, ProgNone, SRC>(table, rpw, c, ip, ni, s);
     return launch_other<CN, OT, WM, InterpProg, SRC>(table, rpw, c, ip, ni, s);
 }
@@ -467,27 +450,27 @@ static hipError_t launch_other_np(bool none, bool table, int rpw, const ChainArg
 // CV_16U / CV_16S C1, C3, C4 and CV_32FC1: resize -> convertTo<CV_32F, I> -> write<I>, tests/resize/test_resize_write.cu:55-56,
 // 110-123), and 16-bit sources into separate fp32 planes (tests/resize/test_resize_x_split.cu)
 template <int CN>
-static hipError_t launch_same_type_packed(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+static hipError_t launch_same_type_packed(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
     const bool none = c.prog.n == 0;
     if (src == SRC_U16) return launch_other_np<CN, uint16_t, WM_PACKED, SRC_U16>(none, table, rpw, c, ip, ni, s);
     if (src == SRC_S16) return launch_other_np<CN, int16_t, WM_PACKED, SRC_S16>(none, table, rpw, c, ip, ni, s);
     return launch_other_np<CN, float, WM_PACKED, SRC_F32>(none, table, rpw, c, ip, ni, s);
 }
 template <int CN>
-static hipError_t launch_split2d_16(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+static hipError_t launch_split2d_16(int src, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
     if (src == SRC_U16) return launch_other<CN, float, WM_SPLIT2D, InterpProg, SRC_U16>(table, rpw, c, ip, ni, s);
     return launch_other<CN, float, WM_SPLIT2D, InterpProg, SRC_S16>(table, rpw, c, ip, ni, s);
 }
 // separate planes: the reference's K2 chain (mul, sub, div; with or without the R<->B swap) gets its compile-time program
 template <int CN>
-static hipError_t launch_split2d(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+static hipError_t launch_split2d(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
     if (prog_id == 0) return launch_other<CN, float, WM_SPLIT2D, ProgSwapMulSubDiv>(table, rpw, c, ip, ni, s);
     if (prog_id == 1) return launch_other<CN, float, WM_SPLIT2D, ProgMulSubDiv>(table, rpw, c, ip, ni, s);
     return launch_other<CN, float, WM_SPLIT2D>(table, rpw, c, ip, ni, s);
 }
 
 template <int CN, int NPL, class Prog, int SRC, typename OT>
-static hipError_t launch_rpw(int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, hipStream_t s) {
+static hipError_t launch_rpw(int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn, LaunchCtx& s) {
     // the interpreted program keeps its opcode loop rolled; more than one row per wave only bloats it
     if constexpr (std::is_same_v<Prog, InterpProg>) return launch_t<CN, NPL, 1, Prog, SRC, OT>(c, ip, ni, out_cn, s);
     else if constexpr (SRC != SRC_U8) { // 16-bit sources: two row counts are enough
@@ -503,10 +486,10 @@ static hipError_t launch_rpw(int rpw, const ChainArgs& c, const PlaneParams* ip,
 
 template <int CN, class Prog, int SRC, typename OT>
 static hipError_t launch_npl(bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
-                             hipStream_t s) {
+                             LaunchCtx& s) {
     if (table) return launch_rpw<CN, 0, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
     if constexpr (SRC == SRC_U8) { // cvgs_execute_many on host descriptors (u8 sources, 3 / 4 channels): segments + ALL planes in the arguments
-        if (tls_extra().segs) {
+        if (s.segs) {
             if (ni <= kManyInlineSmall) return launch_rpw<CN, -kManyInlineSmall, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
             return launch_rpw<CN, -kManyInlineLarge, Prog, SRC, OT>(rpw, c, ip, ni, out_cn, s);
         }
@@ -517,7 +500,7 @@ static hipError_t launch_npl(bool table, int rpw, const ChainArgs& c, const Plan
 
 template <int CN, int SRC, typename OT = float>
 static hipError_t launch_prog(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, int out_cn,
-                              hipStream_t s) {
+                              LaunchCtx& s) {
     if (prog_id == 0) return launch_npl<CN, ProgSwapMulSubDiv, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
     if (prog_id == 1) return launch_npl<CN, ProgMulSubDiv, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
     return launch_npl<CN, InterpProg, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
@@ -526,7 +509,7 @@ static hipError_t launch_prog(int prog_id, bool table, int rpw, const ChainArgs&
 // 1- and 2-channel sources (grayscale / two-plane images; the reference's single-image resize tests sweep C1 types,
 // tests/resize/test_resize_write.cu:120-123): planar fp32 for every source kind, packed fp32 / u8 for 8U sources
 template <int CN, int SRC>
-static hipError_t launch_few_planar(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, hipStream_t s) {
+static hipError_t launch_few_planar(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
     const int r = rpw >= 4 ? 4 : 1;
     if (prog_id == 1) {
         if (table) return r == 4 ? launch_t<CN, 0, 4, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s) : launch_t<CN, 0, 1, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s);
@@ -538,7 +521,7 @@ static hipError_t launch_few_planar(int prog_id, bool table, int rpw, const Chai
 }
 template <int CN>
 static hipError_t launch_few(int src, bool planar, bool u8out, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip,
-                             int ni, hipStream_t s) {
+                             int ni, LaunchCtx& s) {
     if (planar) {
         return src == SRC_U8    ? launch_few_planar<CN, SRC_U8>(prog_id, table, rpw, c, ip, ni, s)
                : src == SRC_U16 ? launch_few_planar<CN, SRC_U16>(prog_id, table, rpw, c, ip, ni, s)

@@ -409,27 +409,24 @@ __global__ __launch_bounds__(64 * kK4Waves) void k4_nv12_resize(const K4Args<NPL
     }
 }
 
-// the chains of a cvgs_execute_many launch (set by launch_nv12 for the instantiation it picks)
+// what launch_nv12 hands to the instantiation it picks: the call's LaunchCtx and the chains of a cvgs_execute_many launch
 struct N12Many {
+    LaunchCtx* ctx;
     const ManySeg* segs;
     int n_segs;
     const PlaneParams* planes; // host-described fused chains whose planes travel in the kernel arguments (segs[i].table = first index), or null
     int n_planes;
 };
-static N12Many& tls_many() {
-    static thread_local N12Many m{nullptr, 0, nullptr, 0};
-    return m;
-}
 
 template <class Prog, typename OT, int RPW, int CN, bool S16, bool WIN = false, bool PL = false>
-static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g_in, hipStream_t s) {
+static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g_in, const N12Many& many) {
+    hipStream_t s = (hipStream_t)many.ctx->stream;
     N12Geom g = g_in;
     const uint32_t col_tiles = (uint32_t)((g.dst_w + 63) / 64), row_groups = (uint32_t)((g.dst_h + kK4Waves * RPW - 1) / (kK4Waves * RPW));
     g.col_tiles = col_tiles;
     g.pad = 0;
     g.done_word = nullptr;
     g.done_value = 0;
-    const N12Many& many = tls_many();
     constexpr bool kImage = std::is_same_v<OT, uint8_t>; // packed u8 images: never fused chains, never the 16 KB argument block
     if constexpr (!kImage && !PL && !WIN) if (many.segs && many.planes) {
         // host descriptors of at most kManyInlineLarge planes: segments + planes in the arguments (16 KB / 52 KB blocks), capturable
@@ -450,11 +447,11 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         KernArgsMany a;
         a.c = c;
         for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
-        DoneWordSlot& dw = tls_done_word();
-        if (dw.word && !dw.used) {
-            dw.used = true;
-            g.done_word = dw.word;
-            g.done_value = dw.value;
+        LaunchCtx& x = *many.ctx;
+        if (x.done_word && !x.done_word_taken) {
+            x.done_word_taken = true;
+            g.done_word = x.done_word;
+            g.done_value = x.done_value;
         }
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
         hipLaunchKernelGGL((k4_nv12_resize<0, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
@@ -482,13 +479,13 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
 
 // the channel count (3, or 4 with alpha) becomes a template argument
 template <class Prog, typename OT, bool S16, bool WIN, bool PL>
-static hipError_t launch_n12_cn(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s) {
+static hipError_t launch_n12_cn(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, const N12Many& s) {
     if (g.cn == 4) return launch_n12_r<Prog, OT, 1, 4, S16, WIN, PL>(c, ip, ni, g, s);
     return launch_n12_r<Prog, OT, 1, 3, S16, WIN, PL>(c, ip, ni, g, s);
 }
 
 template <class Prog, typename OT = float>
-static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, hipStream_t s, bool win = false) {
+static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, const N12Geom& g, const N12Many& s, bool win = false) {
     const bool pl = c.read.yuv_layout == CVGS_YUV_I420 || c.read.yuv_layout == CVGS_YUV_YV12;
     const bool s16 = c.read.yuv_layout == CVGS_YUV_P010;
     if (win) { // aspect-ratio windows / default-value planes: their own instantiations (see k4_nv12_resize)
@@ -503,7 +500,7 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     // 16-byte stores through a wave-private LDS tile -- the launch is bound by its memory INSTRUCTIONS (four tap loads per row and lane):
     // 16 x 50 crops of NV12 surfaces 52 -> see profiles/r05_x_k4_tick_rows4.txt
     if constexpr (std::is_same_v<OT, float>) {
-        const N12Many& many = tls_many();
+        const N12Many& many = s;
         static const char* rows_env = getenv("CVGS_K4_TICK_ROWS"); // benchmark-only: 1 = one row per wave as single launches
         if (g.cn == 3 && !pl && !(rows_env && rows_env[0] == '1')) { // (a single chain of 256+ crops is in the same regime; P010 surfaces too)
             int64_t planes = many.segs ? 0 : c.read.batch;
@@ -538,10 +535,13 @@ static bool k4_planes_wide_enough(const PlaneParams* planes, int n) {
     return true;
 }
 
-// `segs` (n_segs >= 1): the chains of a cvgs_execute_many launch -- their planes live in device tables that the caller
+// ctx.segs (n_segs >= 1): the chains of a cvgs_execute_many launch -- their planes live in device tables that the caller
 // has checked with k4_planes_eligible; c_in.read.batch is the largest batch.  nullptr: one chain (inline_planes).
-int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, int min_width, const ManySeg* segs, int n_segs,
-                void* stream, bool dry_run, LaunchInfo* info, uint32_t chain_flags) {
+int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inline, int min_width, LaunchCtx& ctx, bool dry_run, LaunchInfo* info,
+                uint32_t chain_flags) {
+    const ManySeg* const segs = ctx.segs;
+    const int n_segs = ctx.n_segs;
+    void* const stream = ctx.stream;
     const ReadArgs& r = c_in.read;
     // fp16 planar tensors: the trailing CAST(CV_16F) moves into the store
     const bool planar_kind = c_in.write.kind == CVGS_WRITE_TENSOR_SPLIT || c_in.write.kind == CVGS_WRITE_TENSOR_T_SPLIT;
@@ -608,9 +608,8 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
             info->kernel = r.out_cn == 3 ? (u8_prog == 0 ? "k4_nv12_resize_u8c3" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c3" : "k4_nv12_resize_interp_u8c3"))
                                          : (u8_prog == 0 ? "k4_nv12_resize_u8c4" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c4" : "k4_nv12_resize_interp_u8c4"));
         if (dry_run) return 1;
-        tls_many() = N12Many{nullptr, 0, nullptr, 0};
+        const N12Many s8{&ctx, nullptr, 0, nullptr, 0};
         const bool win8 = r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h);
-        hipStream_t s8 = (hipStream_t)stream;
         const hipError_t e8 = u8_prog == 0   ? launch_n12<ProgNone, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
                               : u8_prog == 1 ? launch_n12<K1Prog<kOpSwapRB>, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
                                              : launch_n12<InterpProg, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8);
@@ -651,11 +650,10 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
         info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
                            : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : (fast_rgb ? "k4_nv12_resize_mul_sub_div" : "k4_nv12_resize_interp"));
     if (dry_run) return 1;
-    tls_many() = N12Many{segs, n_segs, segs && !r.table ? inline_planes : nullptr, segs && !r.table ? n_inline : 0};
+    const N12Many s{&ctx, segs, n_segs, segs && !r.table ? inline_planes : nullptr, segs && !r.table ? n_inline : 0};
     // the windowed instantiations: an aspect-ratio window or default-value planes (never for fused chains / staged tables, whose
     // callers admit stretch geometry only)
     const bool win = !segs && (r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h));
-    hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c_fd, inline_planes, n_inline, g, s, win)
                            : launch_n12<InterpProg, _Float16>(c_fd, inline_planes, n_inline, g, s, win);

@@ -46,6 +46,7 @@ YUV_FULL, YUV_LIMITED = 0, 1
 YUV_NV12, YUV_NV21, YUV_I420, YUV_YV12, YUV_P010 = 0, 1, 2, 3, 4
 BT601, BT709, BT2020 = 0, 1, 2
 READ_FLAG_TABLE_ON_DEVICE = 1
+READ_FLAG_TABLE_SOURCES_VOUCHED = 2
 # opcodes
 (OP_NOP, OP_CAST, OP_MUL, OP_ADD, OP_SUB, OP_DIV, OP_REORDER, OP_ADD_ALPHA, OP_DROP_ALPHA, OP_GRAY,
  OP_CAST_TRUNC) = range(11)
@@ -70,7 +71,7 @@ class ReadDesc(C.Structure):
                 ("aspect_ratio", C.c_int32), ("flags", C.c_uint32), ("background", C.c_float * 4),
                 ("yuv_range", C.c_int32), ("yuv_primaries", C.c_int32), ("yuv_alpha", C.c_int32),
                 ("yuv_layout", C.c_int32), ("warp_matrices", C.POINTER(C.c_float)),
-                ("warp_dst_sizes", C.POINTER(C.c_int32))]
+                ("warp_dst_sizes", C.POINTER(C.c_int32)), ("table_src_lo", C.c_void_p), ("table_src_hi", C.c_void_p)]
 
 
 class Op(C.Structure):
@@ -100,6 +101,7 @@ SYMBOLS = [
     ("cvgs_kernel_name", C.c_int, [C.POINTER(ChainDesc), C.c_char_p, C.c_size_t]),
     ("cvgs_plane_table_bytes", C.c_size_t, [C.c_int32]),
     ("cvgs_plane_table_build", C.c_int, [C.POINTER(ReadDesc), C.c_void_p]),
+    ("cvgs_plane_table_hull", C.c_int, [C.POINTER(ReadDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("cvgs_circular_create", C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int32] * 8),
     ("cvgs_circular_create_ex", C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int32] * 8 + [C.c_uint32]),
     ("cvgs_circular_update", C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
@@ -117,8 +119,6 @@ SYMBOLS = [
     ("cvgs_queue_submit_on", C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("cvgs_queue_submit_many_on", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(ChainDesc)), C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("cvgs_queue_recover", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
-    ("cvgs_debug_occupy", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
-    ("cvgs_debug_poll", C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_void_p]),
     ("cvgs_queue_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_double]),
     ("cvgs_queue_stream_wait", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("cvgs_queue_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -166,7 +166,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.cvgs_abi_version() != 5:
+    if lib.cvgs_abi_version() != 6:
         raise ImportError("libcvgs_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -8,7 +8,7 @@
 
 #include <string>
 
-#include "../../include/cvgs_hip.h"
+#include "../../include/cvgs_hip_ext.h" // (includes cvgs_hip.h; the engine also implements the queue / exchange extensions)
 
 namespace cvgs {
 
@@ -272,9 +272,7 @@ int queue_submit(Queue* q, const ChainArgs& c, const PlaneParams* planes, int n_
 int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams* const* planes, const int* n_planes, int n, void* stream, uint32_t flags,
                     uint64_t* tickets, int* n_queued, std::string& err);
 int queue_recover(Queue* q, uint64_t* lost, std::string& err);
-const uint64_t* queue_gate_trace(Queue* q); // null unless CVGS_QUEUE_GATE_TRACE was set at create
-int launch_debug_occupy(int blocks, int threads, int lds_bytes, double us, void* stream);
-int launch_debug_poll(const void* word, double us, int nap, void* stream);
+const uint64_t* queue_gate_trace(Queue* q); // null unless CVGS_QUEUE_DEBUG=2 was set at create
 int queue_wait(Queue* q, uint64_t ticket, double timeout_s, std::string& err);
 int queue_stream_wait(Queue* q, uint64_t ticket, void* stream, std::string& err);
 void queue_stats(Queue* q, uint64_t* out8);

@@ -446,8 +446,6 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     for (int i = 0; i < n_planes; ++i) fy_max = planes[i].fy > fy_max ? planes[i].fy : fy_max;
     const int rows_fed = fy_max > 0.f ? (int)((float)kX4Pre / fy_max) : 8;
     if (rows_fed < rows_per_wave) rows_per_wave = rows_fed < 1 ? 1 : rows_fed;
-    static const char* rows_env = getenv("CVGS_K1_X4_ROWS"); // tuning hook (benchmarks only)
-    if (rows_env && atoi(rows_env) > 0) rows_per_wave = atoi(rows_env);
     a.rows_per_wave = rows_per_wave > 64 ? 64 : rows_per_wave;
     const int rows_per_wg = kX4Waves * a.rows_per_wave;
     const uint32_t row_blks = (uint32_t)((r.dst_h + rows_per_wg - 1) / rows_per_wg);
@@ -462,8 +460,6 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     bool shared = ((src == SRC_U8 && r.cn <= 2) || sh16) && fy_max > 0.f;
     for (int i = 0; i < n_planes && shared; ++i)
         shared = ((int)std::floor((double)(px - 1) * (double)planes[i].fx * 1.0001) + 1) * r.cn * eb + 2 * r.cn * eb <= 8;
-    static const char* shared_env = getenv("CVGS_K1_X4_SHARED"); // benchmark-only: 0 = one window per pixel
-    if (shared_env && shared_env[0] == '0') shared = false;
     auto go = [&](auto cn_tag, auto src_tag) {
         constexpr int CN = decltype(cn_tag)::value, SRC = decltype(src_tag)::value;
         if constexpr ((SRC == SRC_U8 && CN <= 2) || ((SRC == SRC_U16 || SRC == SRC_S16) && CN == 1)) {

@@ -501,19 +501,13 @@ static hipError_t launch_n12(const ChainArgs& c, const PlaneParams* ip, int ni, 
     // 16 x 50 crops of NV12 surfaces 52 -> see profiles/r05_x_k4_tick_rows4.txt
     if constexpr (std::is_same_v<OT, float>) {
         const N12Many& many = s;
-        static const char* rows_env = getenv("CVGS_K4_TICK_ROWS"); // benchmark-only: 1 = one row per wave as single launches
-        if (g.cn == 3 && !pl && !(rows_env && rows_env[0] == '1')) { // (a single chain of 256+ crops is in the same regime; P010 surfaces too)
+        if (g.cn == 3 && !pl) { // (a single chain of 256+ crops is in the same regime; P010 surfaces too)
             int64_t planes = many.segs ? 0 : c.read.batch;
             for (int i = 0; many.segs && i < many.n_segs; ++i) planes += many.segs[i].batch;
             if (planes * g.dst_h * ((g.dst_w + 63) / 64) >= 32768)
                 return s16 ? launch_n12_r<Prog, OT, 4, 3, true>(c, ip, ni, g, s) : launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
         }
     }
-#ifdef CVGS_K4_AB_RPW
-    static const char* rpw_env = getenv("CVGS_K4_RPW");
-    if (rpw_env && rpw_env[0] == '2' && g.cn == 3 && !s16 && !pl) return launch_n12_r<Prog, OT, 2, 3, false>(c, ip, ni, g, s);
-    if (rpw_env && rpw_env[0] == '4' && g.cn == 3 && !s16 && !pl) return launch_n12_r<Prog, OT, 4, 3, false>(c, ip, ni, g, s);
-#endif
     if (pl) return launch_n12_cn<Prog, OT, false, false, true>(c, ip, ni, g, s);
     if (s16) return launch_n12_cn<Prog, OT, true, false, false>(c, ip, ni, g, s);
     return launch_n12_cn<Prog, OT, false, false, false>(c, ip, ni, g, s);

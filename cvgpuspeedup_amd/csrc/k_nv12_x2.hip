@@ -312,8 +312,7 @@ int launch_nv12_x2(const ChainArgs& c, const PlaneParams* planes, int n_planes, 
     // rows per wave: 1 (small / odd-width targets: maximum parallelism, the last lane may store ONE pixel) or kN2Rows, walked with the
     // next row's loads in flight (even widths, tensors below 4 GB: the stores go through one buffer descriptor)
     const int64_t total_bytes = ((int64_t)(r.batch - 1) * w.img_stride + 2 * w.ch_stride + (int64_t)r.dst_h * w.width) * 4;
-    static const char* rows_env = getenv("CVGS_K4_X2_ROWS"); // tuning hook (benchmarks only): 1 = one row per wave always
-    const bool pipe = !(rows_env && rows_env[0] == '1') && (r.dst_w & 1) == 0 && total_bytes > 0 && total_bytes < ((int64_t)1 << 32) - 65536 &&
+    const bool pipe = (r.dst_w & 1) == 0 && total_bytes > 0 && total_bytes < ((int64_t)1 << 32) - 65536 &&
                       (int64_t)r.batch * r.dst_h * ((r.dst_w + 127) / 128) >= 4096;
     a.out_bytes = pipe ? (uint32_t)total_bytes : 0u;
     const int rpw = pipe ? kN2Rows : 1, waves = pipe ? kN2PipeWaves : kN2Waves;

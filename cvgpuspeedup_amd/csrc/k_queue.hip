@@ -1003,7 +1003,7 @@ struct QGateTickets { // the batches behind ONE gate kernel (cvgs_queue_submit_m
     uint64_t t[64];
     uint32_t n;
 };
-// `trace` (CVGS_QUEUE_GATE_TRACE=1, tools/probes only; else null): per ticket {gate kernel start, completion seen} in 100 MHz ticks
+// `trace` (CVGS_QUEUE_DEBUG=2, tools/probes only; else null): per ticket {gate kernel start, completion seen} in 100 MHz ticks
 __global__ void k1q_gate(uint64_t* gates, uint64_t* hgates, const uint64_t* dflags, uint32_t R, QGateTickets tk, uint32_t wait, const uint64_t* host_error,
                          uint64_t timeout_ticks, uint64_t* trace) {
     const uint32_t i = threadIdx.x;
@@ -1050,42 +1050,6 @@ __global__ void k1q_gate_open(uint64_t* gate, uint64_t value) {
     if (threadIdx.x == 0) q_st_sys(gate, value);
 }
 
-// test / measurement aid (cvgs_debug_occupy): `blocks` workgroups that hold their wave slots (and `lds_bytes` of LDS each) for `us`
-// microseconds -- a stand-in for a foreign kernel that keeps part of the chip busy while the server must stay resident.
-__global__ void k_debug_occupy(uint64_t ticks) {
-    extern __shared__ float occ_lds[];
-    if (threadIdx.x == 0) occ_lds[0] = 0.f;
-    const uint64_t t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-}
-// probe aid (cvgs_debug_poll): one wave that reads `word` with system-scope loads (s_sleep between them) for `us` microseconds -- what a
-// resident server's janitor does to a word in host memory / its workers to a word in uncached device memory
-__global__ void k_debug_poll(const uint64_t* word, uint64_t ticks, uint32_t nap) {
-    const uint64_t t0 = wall_clock64();
-    uint64_t acc = 0;
-    while (wall_clock64() - t0 < ticks) {
-        acc += q_ld_sys(word);
-        if (nap) __builtin_amdgcn_s_sleep(32);
-    }
-    if (acc == 0x123456789abcdefull) __builtin_trap();
-}
-int launch_debug_poll(const void* word, double us, int nap, void* stream) {
-    if (!word) { // the server's own kind of memory: an uncached device word (allocated once, never freed)
-        static void* uc = nullptr;
-        if (!uc && (hipExtMallocWithFlags(&uc, 4096, hipDeviceMallocUncached) != hipSuccess || hipMemset(uc, 0, 4096) != hipSuccess)) return -1;
-        word = uc;
-    }
-    const int blocks = nap >> 8 ? nap >> 8 : 1; // probes: nap bits 8.. = workgroups of 256 threads (all waves poll)
-    nap &= 0xff;
-    hipLaunchKernelGGL(k_debug_poll, dim3(blocks), dim3(blocks > 1 ? 256 : 64), 0, (hipStream_t)stream, (const uint64_t*)word, (uint64_t)(us * 100.0), (uint32_t)nap);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-int launch_debug_occupy(int blocks, int threads, int lds_bytes, double us, void* stream) {
-    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_debug_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(k_debug_occupy, dim3(blocks), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, (uint64_t)(us * 100.0));
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
 // ====================================================================================================================
 // host side
 // ====================================================================================================================
@@ -1106,7 +1070,7 @@ struct Queue {
     QIndex* host_index = nullptr;
     QHostCtl* hc = nullptr;             // pinned
     uint64_t* hflags = nullptr;         // pinned: R completion flags
-    uint64_t* gate_trace = nullptr;     // pinned, CVGS_QUEUE_GATE_TRACE=1 only: 4096 x {gate kernel start, completion seen}
+    uint64_t* gate_trace = nullptr;     // pinned, CVGS_QUEUE_DEBUG=2 only: 4096 x {gate kernel start, completion seen}
     uint64_t* hgates = nullptr;         // pinned: the gate kernels' host copies of the gate words (R)
     struct Closed { uint64_t ticket; uint32_t tasks; };
     std::vector<Closed> closed;         // stream-ordered batches whose gate the host has not yet seen open
@@ -1152,19 +1116,12 @@ static inline void wc_fence() {
 #endif
 }
 
-// one look at the environment per knob (a second getenv between the test and the use could return null)
-static long env_long(const char* name, long fallback) {
-    const char* e = getenv(name);
-    return e ? atol(e) : fallback;
-}
-
 // Is device memory writable from the host (large BAR, the allocation mapped into this process)?  Decided WITHOUT ever faulting: round 3
 // probed with a store guarded by process-wide SIGSEGV / SIGBUS handlers and siglongjmp -- inside a library that races every other
-// thread's faults and every other user of sigaction.  Now: (1) CVGS_QUEUE_DIRECT=0 / CVGS_QUEUE_STAGED=1 /
-// flag bit 0 force the staged path; (2) the device must report a large BAR (hipDeviceAttributeIsLargeBar); (3) the WHOLE block must lie
+// thread's faults and every other user of sigaction.  Now: (1) flag bit 0 forces the staged path; (2) the device must report a large BAR (hipDeviceAttributeIsLargeBar); (3) the WHOLE block must lie
 // inside read-write mappings of this process (/proc/self/maps: with a large BAR the runtime maps VRAM allocations through the render
 // node at their device address; without one the range is a PROT_NONE reservation) -- only then is the test store issued, and (4) it must
-// read back from the device.  Anything unknown (no /proc, a foreign OS, a non-x86 host without CVGS_QUEUE_DIRECT=1) means "staged".
+// read back from the device.  Anything unknown (no /proc, a foreign OS, a non-x86 host) means "staged".
 static bool range_is_mapped_rw(const void* p, size_t bytes) {
     FILE* f = std::fopen("/proc/self/maps", "r");
     if (!f) return false;
@@ -1186,11 +1143,8 @@ static bool range_is_mapped_rw(const void* p, size_t bytes) {
     return ok;
 }
 static bool decide_direct(int device, uint8_t* block, size_t block_bytes, uint64_t* probe_word, uint32_t flags) {
-    const char* staged_env = getenv("CVGS_QUEUE_STAGED");
-    const char* direct_env = getenv("CVGS_QUEUE_DIRECT");
-    if ((flags & 1u) || (staged_env && staged_env[0] == '1') || (direct_env && direct_env[0] == '0')) return false;
-    const bool asked = direct_env && direct_env[0] == '1';
-    if (!CVGS_HOST_X86 && !asked) return false; // the write-combining path below is tuned and tested on x86-64 only
+    if (flags & 1u) return false; // the caller asked for the staged ring
+    if (!CVGS_HOST_X86) return false; // the write-combining path below is tuned and tested on x86-64 only
     int large_bar = 0;
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) return false;
     if (!range_is_mapped_rw(block, block_bytes)) return false;
@@ -1335,11 +1289,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     }
     q->stall_ticks = (uint64_t)(stall_s * tick_hz);
     // a stream-ordered batch may wait this long at its gate for the work in front of it on the caller's stream (then: error 3)
-    double gate_s = 10.0;
-    if (const char* gm = getenv("CVGS_QUEUE_GATE_TIMEOUT_MS")) {
-        const double v = atof(gm);
-        if (v >= 1.0 && v <= 3600000.0) gate_s = v * 1e-3;
-    }
+    const double gate_s = 10.0;
     q->gate_ticks = (uint64_t)(gate_s * tick_hz);
     const size_t R = q->R, NW = (size_t)q->G * kQWaves;
     const size_t off_ring = 4096, off_index = off_ring + R * kQSlotBytes, off_dflags = off_index + R * sizeof(QIndex), off_gates = off_dflags + R * 128, total = off_gates + R * 128;
@@ -1387,7 +1337,7 @@ int queue_create(Queue** out, int device, int depth, uint32_t flags, double idle
     q->prio_range_nonempty = prio_least != prio_greatest;
     q->server_prio_known = hipStreamGetPriority(q->stream, &q->server_prio) == hipSuccess;
     (void)hipGetLastError();
-    if (getenv("CVGS_QUEUE_GATE_TRACE") && hipHostMalloc((void**)&q->gate_trace, 4096 * 32, hipHostMallocDefault) == hipSuccess) std::memset(q->gate_trace, 0, 4096 * 32);
+    if (const char* dbg = getenv("CVGS_QUEUE_DEBUG"); dbg && dbg[0] == '2' && hipHostMalloc((void**)&q->gate_trace, 4096 * 32, hipHostMallocDefault) == hipSuccess) std::memset(q->gate_trace, 0, 4096 * 32);
     q->direct = decide_direct(device, q->dev_block, total, &q->m.dc->stop_gen.pad[0], flags);
     if (!q->direct) {
         if ((e = hipHostMalloc((void**)&q->host_ring, R * kQSlotBytes, hipHostMallocDefault)) != hipSuccess ||
@@ -1551,13 +1501,10 @@ static int queue_submit_slot(Queue* q, const ChainArgs& c_in, const PlaneParams*
     // of 16 batches takes 71 us with 64-row tasks from 8 batches in flight, 53 us with 16-row tasks (tools/probes/queue_burst_tail.py).
     // So: 16 rows with 2..7 batches in flight, 32 from 8, and the large size (128 rows; 64 on rings shallower than 128 slots, whose
     // batches would not hold two tasks per worker) only when the ring is three quarters full, i.e. the stream is sustained.
-    // CVGS_QUEUE_DEEP_ROWS pins the size used from 8 batches in flight (tuning).
     advance_done(q);
     const uint64_t in_flight = q->next_seq - q->done_inorder;
-    static const int deep_env = (int)env_long("CVGS_QUEUE_DEEP_ROWS", 0) & ~3;
     const bool sustained = q->R >= 32 && in_flight * 4 >= q->R * 3;
-    const uint32_t deep_rows = deep_env >= 4 && deep_env <= 4096 ? (uint32_t)deep_env
-                               : (sustained ? (q->R >= 128 ? (uint32_t)kQRowsPerTaskDeep : 64u) : (uint32_t)kQRowsPerTaskMid);
+    const uint32_t deep_rows = sustained ? (q->R >= 128 ? (uint32_t)kQRowsPerTaskDeep : 64u) : (uint32_t)kQRowsPerTaskMid;
     p.rows_per_task = gated ? gate->rows : (in_flight >= 8 ? deep_rows : (in_flight >= 2 ? (uint32_t)kQRowsPerTask : (uint32_t)kQRowsPerWave));
     p.tiles_per_plane = p.col_tiles * (uint32_t)((r.dst_h + (int)p.rows_per_task - 1) / (int)p.rows_per_task);
     p.n_tasks = p.tiles_per_plane * (uint32_t)r.batch;
@@ -1687,7 +1634,7 @@ int queue_submit(Queue* q, const ChainArgs& c, const PlaneParams* planes, int n_
     return 0;
 }
 
-// debugging aid (CVGS_QUEUE_DEBUG=1): what the device-side state of the oldest incomplete batch looks like when the server reports a stall
+// debugging aid (CVGS_QUEUE_DEBUG=1; =2 also records the gate kernels' timestamps for tools/probes/gate_trace.py): what the device-side state of the oldest incomplete batch looks like when the server reports a stall
 static void queue_debug_dump(Queue* q) {
     static const bool on = getenv("CVGS_QUEUE_DEBUG") != nullptr;
     if (!on) return;

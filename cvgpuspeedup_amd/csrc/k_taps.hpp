@@ -45,8 +45,6 @@ __device__ __forceinline__ float div_by_uniform(float x, float d, float r) {
 // all ones is left to the real division (the one case where RN(1/d) is not good enough for Markstein's theorem), and so
 // is a background value outside [2^-20, 2^20] (it is pushed through the same program).
 inline void fast_div_setup(ProgArgs& p, int div_at, int mul_at, int cn, const float* bg) {
-    static const char* off = getenv("CVGS_K1_FASTDIV"); // tuning / test hook: CVGS_K1_FASTDIV=0 keeps the IEEE division
-    if (off && off[0] == '0') return;
     auto in_range = [](float v, int lo_exp, int hi_exp) {
         const float a = std::fabs(v);
         return std::isfinite(v) && a >= std::ldexp(1.0f, lo_exp) && a <= std::ldexp(1.0f, hi_exp);

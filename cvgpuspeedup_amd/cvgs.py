@@ -395,6 +395,16 @@ def lower(iops, flags=0):
     if rd.table is not None:
         r.src = int(rd.table)
         r.flags = capi.READ_FLAG_TABLE_ON_DEVICE
+        # ABI 6: a device-table chain states the byte range its table's planes read, so that cvgs_execute_many can check the chains of a tick
+        # for independence (the host cannot see into the table).  rd.table_hull = (lo, hi) states it; rd.table_vouched = True vouches instead
+        # (tables rewritten in place); otherwise it is computed from the host views the table was built from (cvgs_plane_table_hull).
+        hull = getattr(rd, "table_hull", None)
+        if getattr(rd, "table_vouched", False):
+            r.flags |= capi.READ_FLAG_TABLE_SOURCES_VOUCHED
+        elif hull is None and rd.mats and all(m is not None for m in rd.mats):
+            hull = table_hull(rd)
+        if hull is not None:
+            r.table_src_lo, r.table_src_hi = int(hull[0]), int(hull[1])
     else:
         arr = (capi.Image2D * rd.batch)()
         for i, m in enumerate(rd.mats):
@@ -597,6 +607,21 @@ def kernel_name(*iops, flags=0):
     buf = C.create_string_buffer(128)
     capi.check(lib.cvgs_kernel_name(C.byref(lowered.desc), buf, 128))
     return buf.value.decode()
+
+
+def table_hull(read_iop):
+    """(lo, hi): the byte range that holds everything the planes of a read stage read (cvgs_plane_table_hull) -- what a chain that passes
+    the built device table states in read.table_src_lo / table_src_hi."""
+    lib = capi.load_library()
+    keep_table = read_iop.table
+    read_iop.table = None
+    try:
+        lowered = lower([read_iop, WriteIOp(capi.WRITE_PIXEL_3D, read_iop.out_type(), 16, 1, 1, 0, read_iop.batch)])
+    finally:
+        read_iop.table = keep_table
+    lo, hi = C.c_void_p(), C.c_void_p()
+    capi.check(lib.cvgs_plane_table_hull(C.byref(lowered.desc.read), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
 
 
 def build_plane_table(read_iop):

@@ -20,7 +20,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../../include/cvgs_hip.h"
+#include "../../../include/cvgs_hip_ext.h" // cvgs_hip.h + the descriptor queue behind cvGS::Queue / attachQueue
 #include "../cv2cuda_types.h"
 
 // The reference's sequence selectors are spelled with CUDA function qualifiers (tests/batchread/test_circularbatchread_x_write3D.cu:89-93:

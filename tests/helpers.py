@@ -36,3 +36,31 @@ def assert_bit_exact(gpu, ref, what=""):
         raise AssertionError("%s: %d elements differ (first at %s: gpu=%r ref=%r)%s" % (
             what, int((~same).reshape(gpu.size, -1).any(axis=1).sum()), first,
             gpu[first] if first else None, ref[first] if first else None, extra))
+
+
+_testaid = None
+
+
+def testaid():
+    """tests/aids/libcvgs_testaid.so: cvgs_debug_occupy / cvgs_debug_poll -- test and measurement aids (a stand-in for a foreign kernel, a
+    producer kernel on a stream), NOT part of the product library (round 6).  Built by `make -C tests/aids` (__graft_entry__.build())."""
+    global _testaid
+    if _testaid is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "aids", "libcvgs_testaid.so")
+        if not os.path.exists(path):
+            raise ImportError("tests/aids/libcvgs_testaid.so is missing: run `make -C tests/aids` (or __graft_entry__.build())")
+        import torch  # noqa: F401  (the same HIP runtime as the product library: see capi.load_library)
+        lib = C.CDLL(path)
+        lib.cvgs_debug_occupy.restype = C.c_int
+        lib.cvgs_debug_occupy.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]
+        lib.cvgs_debug_poll.restype = C.c_int
+        lib.cvgs_debug_poll.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_void_p]
+        _testaid = lib
+    return _testaid
+
+
+def aid_check(rc):
+    if rc != 0:
+        raise RuntimeError("test aid call failed: %d" % rc)

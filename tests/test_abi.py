@@ -13,10 +13,21 @@ from tests import helpers as H
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "cvgs_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(cvgs_[a-z0-9_]+)\s*\(", src)))
+def header_functions(*headers):
+    names = set()
+    for h in headers or ("cvgs_hip.h", "cvgs_hip_ext.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"^\s*#\s*define[^\n]*(\\\n[^\n]*)*", "", src, flags=re.M)  # (function-like macros are not entry points)
+        names |= set(re.findall(r"\b(cvgs_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def exported_symbols(path):
+    """The dynamic symbol table of a shared library (defined symbols only)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -26,8 +37,26 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), "libcvgs_hip.so does not export %s" % n
         assert n in declared_in_binding, "capi.SYMBOLS lacks %s" % n
-    assert lib.cvgs_abi_version() == 5
+    assert lib.cvgs_abi_version() == 6
     assert b"gfx950" in lib.cvgs_version_string()
+
+
+def test_exported_symbol_list_is_exactly_the_c_abi():
+    """the product library's dynamic symbol table IS the C-ABI -- what include/cvgs_hip.h (the drop-in boundary: what
+    replaces fk::executeOperations / fk::CircularTensor, reference include/cvGPUSpeedup.cuh:464-627) and include/cvgs_hip_ext.h (engine
+    extensions: queue, exchange) declare, nothing more (no C++ internals, no kernel stubs, no test aids), nothing less."""
+    core = header_functions("cvgs_hip.h")
+    ext = header_functions("cvgs_hip_ext.h")
+    assert not [n for n in core if n.startswith(("cvgs_queue_", "cvgs_exchange_", "cvgs_debug_"))], "queue / exchange / debug entry points belong to cvgs_hip_ext.h / the test aid"
+    assert not [n for n in ext if n.startswith("cvgs_debug_")]
+    assert exported_symbols(capi.LIB_PATH) == sorted(set(core) | set(ext))
+    # the boundary itself stays small: what replaces executeOperations + CircularTensor, plane tables, the tick launch, introspection
+    assert core == sorted(["cvgs_abi_version", "cvgs_version_string", "cvgs_last_error", "cvgs_device_count", "cvgs_execute", "cvgs_execute_many",
+                           "cvgs_validate", "cvgs_kernel_name", "cvgs_plane_table_bytes", "cvgs_plane_table_build", "cvgs_plane_table_hull",
+                           "cvgs_circular_create", "cvgs_circular_create_ex", "cvgs_circular_update", "cvgs_circular_data", "cvgs_circular_bytes",
+                           "cvgs_circular_updates", "cvgs_circular_destroy", "cvgs_stream_copy", "cvgs_range_push", "cvgs_range_pop"])
+    rccl = os.path.join(os.path.dirname(capi.LIB_PATH), "libcvgs_rccl.so")
+    assert exported_symbols(rccl) == header_functions("cvgs_rccl.h")
 
 
 def test_struct_layout_matches_c(lib):
@@ -253,3 +282,36 @@ def test_device_plane_tables_are_refused_for_layouts_they_cannot_vouch_for(lib):
         lowered.desc.read.yuv_layout = layout
         rc = lib.cvgs_validate(C.byref(lowered.desc))
         assert (rc == 0) == ok, (layout, rc, lib.cvgs_last_error())
+
+
+def test_plane_table_hull_and_the_fields_that_state_it(lib):
+    """ABI 6: cvgs_plane_table_hull gives the byte range a table's planes read; a chain states it for a DEVICE table only."""
+    frame = np.zeros((480, 640, 3), np.uint8)
+    out = np.zeros((3, 3 * 64 * 128), np.float32)
+    g = cvgs.GpuMat.from_array(frame, cvgs.CV_8UC3)
+    crops = [(10, 20, 100, 50), (300, 400, 64, 80), (5, 470, 30, 10)]
+    ops = H.k1_chain(g, crops, cvgs.GpuMat.from_array(out, cvgs.CV_32FC1))
+    lo, hi = cvgs.table_hull(ops[0])
+    base, step = frame.ctypes.data, 640 * 3
+    assert lo == base + 20 * step + 10 * 3                      # first byte of the top-most crop
+    assert hi == base + 479 * step + (300 + 64) * 3             # one past the last tapped byte: row 479 is the last row of crops 1 and 2, crop 1 ends further right
+    # NV12 surfaces: the chroma rows behind the luma plane belong to the range
+    surf = np.zeros((480 * 3 // 2, 640), np.uint8)
+    rd = cvgs.read_nv12(cvgs.GpuMat(480, 640, cvgs.CV_8UC1, surf.ctypes.data, 640, owner=surf), (64, 64), capi.YUV_FULL, capi.BT709, False)
+    lo, hi = cvgs.table_hull(rd)
+    assert lo == surf.ctypes.data and hi == surf.ctypes.data + 640 * 720
+    # the fields describe device tables only, come in pairs, lo <= hi; unknown read flags are refused
+    low = cvgs.lower(ops)
+    for lo_v, hi_v, flags, msg in ((base, base + 100, 0, b"DEVICE table"), (0, 0, capi.READ_FLAG_TABLE_SOURCES_VOUCHED, b"DEVICE table"),
+                                   (0, 0, 4, b"unknown read flags")):
+        low.desc.read.table_src_lo, low.desc.read.table_src_hi, low.desc.read.flags = lo_v, hi_v, flags
+        assert lib.cvgs_validate(C.byref(low.desc)) == capi.ERR_INVALID
+        assert msg in lib.cvgs_last_error(), lib.cvgs_last_error()
+    low.desc.read.flags = capi.READ_FLAG_TABLE_ON_DEVICE
+    low.desc.read.src = 4096  # (a pretend device table: validation does not read it)
+    for lo_v, hi_v in ((base, 0), (0, base), (base + 8, base)):
+        low.desc.read.table_src_lo, low.desc.read.table_src_hi = lo_v, hi_v
+        assert lib.cvgs_validate(C.byref(low.desc)) == capi.ERR_INVALID
+        assert b"table_src_lo" in lib.cvgs_last_error()
+    low.desc.read.table_src_lo, low.desc.read.table_src_hi = base, base + frame.nbytes
+    assert lib.cvgs_validate(C.byref(low.desc)) == capi.OK, lib.cvgs_last_error()

@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
-PROGRAMS = ["test_batchresize", "test_resize", "test_pointwise", "test_circulartensor", "test_warping", "test_divergent"]
+PROGRAMS = ["test_batchresize", "test_resize", "test_pointwise", "test_circulartensor", "test_warping", "test_divergent", "test_sharded"]
 
 
 def _build():
@@ -47,6 +47,16 @@ def test_readme_example_runs():
     subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(ROOT, "examples", "bin", "readme_example")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_sharded_crops_example_runs():
+    """examples/sharded_crops.cpp: BASELINE cfg #5 from ONE C++ process through the C-ABI -- cvgs_comm_init_all, one fused
+    K1 launch per GPU into its rows, cvgs_allgather_inplace inside cvgs_group_start / _end, then the P2P mirror variant; every GPU's copy must be
+    the tensor one GPU computes alone, bit for bit.  N = cvgs_device_count() (1 on the test boxes; tests/cpp/test_sharded.cpp adds the oracle)."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(ROOT, "examples", "bin", "sharded_crops"), "--iters", "10"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("bit for bit") == 2 and "rccl_ranks_seen" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

@@ -258,7 +258,7 @@ def test_descriptor_slots_behind_a_blocked_stream_are_not_recycled(oracle):
     torch.cuda.synchronize()
     # the pool grows to a dozen slots first (12 launches queued behind a 20 ms blocker): adding a slot later would allocate pinned memory,
     # which waits for the device -- i.e. for S's blocker
-    capi.check(lib.cvgs_debug_occupy(1, 64, 0, 20000.0, T.cuda_stream))
+    H.aid_check(H.testaid().cvgs_debug_occupy(1, 64, 0, 20000.0, T.cuda_stream))
     for i in range(12):
         cvgs.executeOperations(T, *H.k1_chain(g_src, t_lists[i], cvgs.GpuMat.from_tensor(t_outs[i], cvgs.CV_32FC1), dst, 3))
     torch.cuda.synchronize()
@@ -268,13 +268,13 @@ def test_descriptor_slots_behind_a_blocked_stream_are_not_recycled(oracle):
     # (lowered up front: building a 330-crop chain in Python takes milliseconds)
     s_low = [cvgs.lower(H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst, 3)) for crops, out in zip(s_lists, s_outs)]
     t_low = [cvgs.lower(H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), dst, 3)) for crops, out in zip(t_lists, t_outs)]
-    capi.check(lib.cvgs_debug_occupy(1, 64, 0, 300000.0, S.cuda_stream))
+    H.aid_check(H.testaid().cvgs_debug_occupy(1, 64, 0, 300000.0, S.cuda_stream))
     for lc in s_low:
         capi.check(lib.cvgs_execute(C.byref(lc.desc), S.cuda_stream))
     # T must not share S's hardware queue (the runtime spreads streams over a few): take the first stream a tiny kernel gets through on
     for cand in [T] + [torch.cuda.Stream() for _ in range(6)]:
         p0 = time.perf_counter()
-        capi.check(lib.cvgs_debug_occupy(1, 64, 0, 0.0, cand.cuda_stream))
+        H.aid_check(H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, cand.cuda_stream))
         cand.synchronize()
         if time.perf_counter() - p0 < 0.02:
             T = cand

@@ -461,7 +461,7 @@ def test_a_stream_destroyed_with_its_tick_still_pending(oracle, device, lib):
         handles.add(s.value)
         n_ticks = 1 if i % 2 == 0 else 3
         if i % 2 == 0:  # the tick waits behind 3 ms of someone else's work on its stream
-            capi.check(lib.cvgs_debug_occupy(8, 64, 0, 3000.0, s))
+            H.aid_check(H.testaid().cvgs_debug_occupy(8, 64, 0, 3000.0, s))
         for t in range(n_ticks):
             chains, outs, meta = [], [], []
             for k in range(2):

@@ -196,7 +196,7 @@ def test_hybrid_policy_takes_the_direct_launch_for_a_lone_stream(oracle, torch_d
         assert int(a.bad.item()) == 0 and q.stats()["submitted"] == 0
         # stream b's batch is held open by a slow producer (20 ms); stream a's submit now has something to overlap with
         with torch.cuda.stream(b.stream):
-            capi.check(lib.cvgs_debug_occupy(1, 64, 0, 20000.0, b.stream.cuda_stream))
+            H.aid_check(H.testaid().cvgs_debug_occupy(1, 64, 0, 20000.0, b.stream.cuda_stream))
             b.produce(3)
             tb = q.submit_lowered_on(b.stream, b.lowered)
             b.consume(3)
@@ -225,7 +225,7 @@ def test_a_gate_closed_longer_than_the_stall_limit_is_waiting_not_a_stall(oracle
     lib = capi.load_library()
     try:
         with torch.cuda.stream(cam.stream):
-            capi.check(lib.cvgs_debug_occupy(1, 64, 0, 400000.0, cam.stream.cuda_stream))
+            H.aid_check(H.testaid().cvgs_debug_occupy(1, 64, 0, 400000.0, cam.stream.cuda_stream))
             cam.produce(2)
             q.submit_lowered_on(cam.stream, cam.lowered)
             cam.consume(2)
@@ -261,7 +261,7 @@ def test_the_watchdog_fires_and_the_queue_recovers(oracle, torch_dev, monkeypatc
         q.wait(q.submit_lowered(lowered))                      # a healthy round first
         H.assert_bit_exact(out_t.cpu().numpy(), ref, "before the stall")
         torch.cuda.synchronize()                                # the server has retired
-        capi.check(lib.cvgs_debug_occupy(cus // 2, 64, 150 * 1024, 300000.0, hog.cuda_stream))
+        H.aid_check(H.testaid().cvgs_debug_occupy(cus // 2, 64, 150 * 1024, 300000.0, hog.cuda_stream))
         time.sleep(0.01)
         t = q.submit_lowered(lowered)
         with pytest.raises(capi.CvgsError):
@@ -407,7 +407,7 @@ def test_destroy_with_a_gate_kernel_still_behind_its_producer(oracle, torch_dev)
     lib = capi.load_library()
     q = cvgs.Queue(idle_us=5000.0)
     with torch.cuda.stream(cam.stream):
-        capi.check(lib.cvgs_debug_occupy(1, 64, 0, 150000.0, cam.stream.cuda_stream))
+        H.aid_check(H.testaid().cvgs_debug_occupy(1, 64, 0, 150000.0, cam.stream.cuda_stream))
         cam.produce(1)
         q.submit_lowered_on(cam.stream, cam.lowered)
     t0 = time.perf_counter()

@@ -30,6 +30,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+
+from tests import helpers as H  # noqa: E402
 from cvgpuspeedup_amd import workloads as W  # noqa: E402
 
 HBM = 8000.0
@@ -72,7 +74,7 @@ def stream_ordered(wl, steps=1920, reps=5):
 
         def launches():
             for i in range(steps):
-                lib.cvgs_debug_occupy(1, 64, 0, 0.0, h1)
+                H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h1)
                 rc = lib.cvgs_execute(C.byref(wl.chains[i % nch].desc), h1)
                 if rc:
                     capi.check(rc)
@@ -86,7 +88,7 @@ def stream_ordered(wl, steps=1920, reps=5):
             def lone():
                 direct[0] = 0
                 for i in range(steps // 4):
-                    lib.cvgs_debug_occupy(1, 64, 0, 0.0, h1)
+                    H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h1)
                     rc = lib.cvgs_queue_submit_on(q.handle, C.byref(wl.chains[i % nch].desc), h1, flags, C.byref(t))
                     if rc:
                         capi.check(rc)
@@ -102,7 +104,7 @@ def stream_ordered(wl, steps=1920, reps=5):
             def ticks():
                 for i in range(steps // G):
                     h = s2[i & 1].cuda_stream
-                    lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+                    H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
                     rc = lib.cvgs_queue_submit_many_on(q.handle, groups[i % len(groups)], G, h, 0, C.byref(t))
                     if rc:
                         capi.check(rc)
@@ -117,7 +119,7 @@ def stream_ordered(wl, steps=1920, reps=5):
             def ticks_deferred():
                 pend = []
                 for i in range(steps // G):
-                    lib.cvgs_debug_occupy(1, 64, 0, 0.0, h1)
+                    H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h1)
                     rc = lib.cvgs_queue_submit_many_on(q.handle, groups[i % len(groups)], G, h1, cvgs.Queue.DEFER_WAIT, C.byref(t))
                     if rc:
                         capi.check(rc)
@@ -142,7 +144,7 @@ def stream_ordered(wl, steps=1920, reps=5):
         def many():
             for i in range(steps // G):
                 h = ss[i % S].cuda_stream
-                lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+                H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
                 rc = lib.cvgs_execute_many(packs[i % len(packs)], G, h)
                 if rc:
                     capi.check(rc)

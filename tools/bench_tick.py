@@ -23,6 +23,7 @@ def run(a):
     import torch
     import bench as B
     from cvgpuspeedup_amd import capi, cvgs
+    from tests import helpers as H  # noqa: E402
     from cvgpuspeedup_amd import workloads as W
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -64,7 +65,7 @@ def run(a):
     def loop(producer):
         for i in range(n_ticks):
             if producer:
-                lib.cvgs_debug_occupy(1, 64, 0, 0.0, s)
+                H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, s)
             rc = lib.cvgs_execute_many(packs[i % len(packs)], M, s)
             if rc:
                 capi.check(rc)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One stream, deferred waits trailing by `lag` batches (CVGS_QUEUE_GATE_TRACE=1): gate-kernel starts and wait-kernel spans per ticket.
+"""One stream, deferred waits trailing by `lag` batches (CVGS_QUEUE_DEBUG=2): gate-kernel starts and wait-kernel spans per ticket.
 Prints the spacing of consecutive gate kernels, the wait kernels' durations, and the time from a gate's opening to the end of the wait
 that covers it."""
 import ctypes as C
@@ -7,7 +7,7 @@ import os
 import sys
 import time
 
-os.environ["CVGS_QUEUE_GATE_TRACE"] = "1"
+os.environ["CVGS_QUEUE_DEBUG"] = "2"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
@@ -15,6 +15,7 @@ import torch  # noqa: E402
 
 import bench as B  # noqa: E402
 from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from tests import helpers as H  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
@@ -37,7 +38,7 @@ for lag in (4, 16):
             t0 = time.perf_counter()
             for i in range(600):
                 if producer:
-                    lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+                    H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
                 capi.check(lib.cvgs_queue_submit_on(q.handle, C.byref(wl.chains[i % 20].desc), h, cvgs.Queue.DEFER_WAIT, C.byref(t)))
                 pend.append(t.value)
                 if len(pend) > lag:

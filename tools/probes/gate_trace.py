@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a stream-ordered batch spends its time (CVGS_QUEUE_GATE_TRACE=1): per ticket the gate kernel's start and the moment it saw
+"""Where a stream-ordered batch spends its time (CVGS_QUEUE_DEBUG=2): per ticket the gate kernel's start and the moment it saw
 the batch complete, 100 MHz ticks.  latency = complete - start (gate store -> workers -> rows -> flag -> seen by the gate kernel);
 gap = next gate kernel of the SAME stream's start - this one's completion (kernel exit -> producer -> next gate kernel start)."""
 import ctypes as C
@@ -12,7 +12,7 @@ if __name__ == "__main__":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 import time
 
-os.environ["CVGS_QUEUE_GATE_TRACE"] = "1"
+os.environ["CVGS_QUEUE_DEBUG"] = "2"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
@@ -20,6 +20,7 @@ import torch  # noqa: E402
 
 import bench as B  # noqa: E402
 from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from tests import helpers as H  # noqa: E402
 
 
 def main():
@@ -43,7 +44,7 @@ def main():
             for i in range(600 // group):
                 s = streams[i % n_streams].cuda_stream
                 if producer:
-                    lib.cvgs_debug_occupy(1, 64, 0, 0.0, s)
+                    H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, s)
                 capi.check(lib.cvgs_queue_submit_many_on(q.handle, ptrs[i % 20], group, s, 0, C.byref(t)))
                 owner[t.value] = i % n_streams
             for st in streams:

@@ -11,6 +11,8 @@ import torch  # noqa: E402
 
 from cvgpuspeedup_amd import capi  # noqa: E402
 
+from tests import helpers as H  # noqa: E402
+
 torch.cuda.set_device(0)
 lib = capi.load_library()
 hog = torch.cuda.Stream(priority=-1) if "--high" in sys.argv else torch.cuda.Stream()
@@ -20,11 +22,11 @@ streams = [torch.cuda.Stream() for _ in range(16)]
 def rate(s, n=300):
     h = s.cuda_stream
     for _ in range(20):
-        lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+        H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
     s.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
-        lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+        H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
     s.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
 
@@ -33,17 +35,17 @@ print("nothing running        :", " ".join("%5.1f" % rate(s) for s in streams), 
 blocks = 767 if "--grid" in sys.argv else 1
 if "--poll-uncached" in sys.argv:
     grid = 768 if "--grid" in sys.argv else 1
-    capi.check(lib.cvgs_debug_poll(None, 400000.0, 1 | (grid << 8 if grid > 1 else 0), hog.cuda_stream))
+    H.aid_check(H.testaid().cvgs_debug_poll(None, 400000.0, 1 | (grid << 8 if grid > 1 else 0), hog.cuda_stream))
     time.sleep(0.01)
     print("%d workgroup(s) polling an UNCACHED device word:" % grid, " ".join("%5.1f" % rate(s) for s in streams), flush=True)
 elif "--poll-host" in sys.argv or "--poll-device" in sys.argv:
     word = torch.zeros(16, dtype=torch.int64).pin_memory() if "--poll-host" in sys.argv else torch.zeros(16, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
-    capi.check(lib.cvgs_debug_poll(word.data_ptr(), 400000.0, 1, hog.cuda_stream))
+    H.aid_check(H.testaid().cvgs_debug_poll(word.data_ptr(), 400000.0, 1, hog.cuda_stream))
     time.sleep(0.01)
     print("one wave polling %s memory:" % ("pinned HOST" if "--poll-host" in sys.argv else "device"), " ".join("%5.1f" % rate(s) for s in streams), flush=True)
 else:
-    lib.cvgs_debug_occupy(blocks, 256, 0, 400000.0, hog.cuda_stream)
+    H.testaid().cvgs_debug_occupy(blocks, 256, 0, 400000.0, hog.cuda_stream)
     time.sleep(0.01)
     print("%4d-block sleeper alive :" % blocks, " ".join("%5.1f" % rate(s) for s in streams), flush=True)
 hog.synchronize()

@@ -13,6 +13,7 @@ import torch  # noqa: E402
 
 import bench as B  # noqa: E402
 from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from tests import helpers as H  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
@@ -27,11 +28,11 @@ streams = [torch.cuda.Stream() for _ in range(N)]
 def rate(s, n=300):
     h = s.cuda_stream
     for _ in range(20):
-        lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+        H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
     s.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
-        lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+        H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
     s.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
 

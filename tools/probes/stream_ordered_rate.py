@@ -23,6 +23,7 @@ import torch  # noqa: E402
 
 import bench as B  # noqa: E402
 from cvgpuspeedup_amd import capi, cvgs  # noqa: E402
+from tests import helpers as H  # noqa: E402
 
 
 def run(wl, q, lib, mode, n_streams, steps, producer, lag, threads, hybrid=False):
@@ -41,7 +42,7 @@ def run(wl, q, lib, mode, n_streams, steps, producer, lag, threads, hybrid=False
                 s = handles[k]
                 ch = wl.chains[(i * n_streams + k) % nch]
                 if producer:
-                    lib.cvgs_debug_occupy(1, 64, 0, 0.0, s)
+                    H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, s)
                 if mode == "launch":
                     rc = lib.cvgs_execute(C.byref(ch.desc), s)
                 else:
@@ -89,7 +90,7 @@ def run_ticks_deferred(wl, q, lib, group, ticks, producer, lag=2):
         t0 = time.perf_counter()
         for i in range(ticks):
             if producer:
-                lib.cvgs_debug_occupy(1, 64, 0, 0.0, h)
+                H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, h)
             capi.check(lib.cvgs_queue_submit_many_on(q.handle, groups[i % len(groups)], group, h, cvgs.Queue.DEFER_WAIT, C.byref(t)))
             pend.append(t.value)
             if len(pend) > lag:
@@ -117,7 +118,7 @@ def run_ticks(wl, q, lib, group, n_streams, ticks, producer):
         for i in range(ticks):
             s = streams[i % n_streams].cuda_stream
             if producer:
-                lib.cvgs_debug_occupy(1, 64, 0, 0.0, s)
+                H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, s)
             capi.check(lib.cvgs_queue_submit_many_on(q.handle, groups[i % len(groups)], group, s, 0, C.byref(t)))
         for st in streams:
             st.synchronize()
@@ -141,7 +142,7 @@ def run_ticks_many(wl, lib, group, n_streams, ticks, producer):
         for i in range(ticks):
             s = streams[i % n_streams].cuda_stream
             if producer:
-                lib.cvgs_debug_occupy(1, 64, 0, 0.0, s)
+                H.testaid().cvgs_debug_occupy(1, 64, 0, 0.0, s)
             capi.check(lib.cvgs_execute_many(groups[i % len(groups)], group, s))
         for st in streams:
             st.synchronize()

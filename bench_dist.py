@@ -123,13 +123,27 @@ def main(a, dev, rank, world):
         compute_queue_step = float(tq.item())
 
     # ---- leg 2: K1 + in-place RCCL all-gather per step -----------------------------------------------------------------
-    works = [None] * n_frames
+    # The collective goes through the C-ABI (libcvgs_rccl.so: cvgs_comm_init_rank + cvgs_allgather_inplace = ncclAllGather in place), the
+    # spelling a C++ host uses (examples/sharded_crops.cpp) -- torch.distributed only carries the 128-byte unique id to the
+    # ranks.  It runs on a second stream behind an event of the step's K1, so the K1 of later steps overlaps it; a buffer's next K1 waits
+    # for the collective that last read it.
+    native = None
+    if not one_gpu:
+        uid = [rccl.Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        native = rccl.Communicator(world, rank, uid[0])
+        rccl_ranks_seen = int(native.lib.cvgs_comm_size(native.handle))
+    coll = torch.cuda.Stream()
+    k1_done = [torch.cuda.Event() for _ in range(n_frames)]
+    gathered = [None] * n_frames
+    slice_bytes = n * plane * esz
 
     def ag_steps():
+        launch_stream = torch.cuda.current_stream()
         for i in range(steps):
             j = i % n_frames
-            if works[j] is not None:
-                works[j].wait()  # the launch stream waits for the collective that last read buffer j
+            if gathered[j] is not None:
+                launch_stream.wait_event(gathered[j])  # the collective that last read buffer j
             wl.launch(i, s)
             lo, hi = sharding.shard_bounds(world * n, world, rank)
             if one_gpu:  # gloo: no in-place CUDA all-gather -- through a copy, synchronously (test mode only)
@@ -140,11 +154,13 @@ def main(a, dev, rank, world):
                     rlo, rhi = sharding.shard_bounds(world * n, world, r)
                     out_all[j][rlo:rhi].copy_(part)
                 continue
-            works[j] = dist.all_gather_into_tensor(out_all[j], out_all[j][lo:hi], async_op=True)
-        for j, w in enumerate(works):
-            if w is not None:
-                w.wait()
-                works[j] = None
+            k1_done[j].record(launch_stream)
+            coll.wait_event(k1_done[j])
+            native.allgather_inplace(out_all[j].data_ptr(), slice_bytes, coll.cuda_stream)
+            if gathered[j] is None:
+                gathered[j] = torch.cuda.Event()
+            gathered[j].record(coll)
+        coll.synchronize()
 
     ag_steps()
     ag_wall = _median_wall(ag_steps, reps, dist, dev)
@@ -263,7 +279,7 @@ def main(a, dev, rank, world):
     dist.all_reduce(okall, op=dist.ReduceOp.MIN)
     p2p_ok = bool(okall.item() == 1)
 
-    best_wall, exchange = ag_wall, "RCCL in-place all_gather_into_tensor per step (overlapped with later steps' K1)"
+    best_wall, exchange = ag_wall, "RCCL in-place all-gather per step through libcvgs_rccl.so (cvgs_allgather_inplace on a second stream, overlapped with later steps' K1)"
     if p2p_ok and p2p["wall"] < ag_wall:
         best_wall, exchange = p2p["wall"], "P2P fused write (K1 stores into every peer's tensor) + device-side arrival flags (no collective per step)"
     step_s = best_wall / steps
@@ -317,6 +333,8 @@ def main(a, dev, rank, world):
         if "xgmi_probe" in result_extra:
             result["xgmi_probe"] = result_extra["xgmi_probe"]
     dist.barrier()
+    if native is not None:
+        native.destroy()
     for p in peers:
         try:
             rccl.close_peer(p)

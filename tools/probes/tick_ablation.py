@@ -102,6 +102,7 @@ def main():
     p.add_argument("--variants", default=None)
     p.add_argument("--workload", default="k1", choices=["k1", "cfg3"], help="k1: the headline ticks (cfg #2b); cfg3: NV12 6K -> 1280x720, --m = cameras per launch")
     p.add_argument("--frame", default="4k", choices=["4k", "8k"], help="k1 only: frame size the 50 crops are drawn from (8k: the same crop sizes barely overlap)")
+    p.add_argument("--fixed", action="store_true", help="k1 only: cfg #2a's crops (60 x 120 at (i, i), the reference's own test layout) instead of cfg #2b's")
     p.add_argument("--out", default=None)
     a = p.parse_args()
     import numpy as np
@@ -122,7 +123,7 @@ def main():
         nf, M = len(wl.chains), 1  # one cvgs_execute per launch
     else:
         nf = ((a.frames + M - 1) // M) * M
-        wl = B.Workload(dev, nf, 50, 0, 1, True, per_launch=M, frame_wh=(7680, 4320) if a.frame == "8k" else W.FRAME_4K)
+        wl = B.Workload(dev, nf, 50, 0, 1, True, per_launch=M, frame_wh=(7680, 4320) if a.frame == "8k" else W.FRAME_4K, fixed=a.fixed)
     installed = wl.lib
     names = [v for v in a.variants.split(",") if v]
     libs = {"installed": installed}
@@ -181,7 +182,7 @@ def main():
     if skel:
         out["full_over_skeleton"] = round(full / rows[skel]["us_per_launch"], 4)
     what = ("cfg #3 (NV12 6K -> 1280x720 normalized NCHW), %d surface(s) per launch, %d launches in rotation" % (a.m, nf) if a.workload == "cfg3" else
-            "M = %d frames (%s) x 50 crops per launch, %d-frame rotation" % (M, a.frame, nf))
+            "M = %d frames (%s) x 50 %s crops per launch, %d-frame rotation" % (M, a.frame, "fixed 60x120 (cfg #2a)" if a.fixed else "variable (cfg #2b)", nf))
     text = ["# ablation of %s [%s]: %d rounds round-robin, median (min-max) us per launch" % (wl.kernel, what, a.rounds),
             "# algorithmic bytes per launch %.0f, 64-B sector floor %.0f, copy ceiling of this run %s TB/s" % (alg, sect, json.dumps(copy)),
             "%-12s %10s %10s %18s %10s %12s %s" % ("variant", "us/launch", "us/frame", "min-max", "frac(alg)", "sector TB/s", "bits")]

@@ -97,6 +97,7 @@ SYMBOLS = [
     ("cvgs_device_count", C.c_int, []),
     ("cvgs_execute", C.c_int, [C.POINTER(ChainDesc), C.c_void_p]),
     ("cvgs_execute_many", C.c_int, [C.POINTER(ChainDesc), C.c_int32, C.c_void_p]),
+    ("cvgs_stream_release", C.c_int, [C.c_void_p]),
     ("cvgs_validate", C.c_int, [C.POINTER(ChainDesc)]),
     ("cvgs_kernel_name", C.c_int, [C.POINTER(ChainDesc), C.c_char_p, C.c_size_t]),
     ("cvgs_plane_table_bytes", C.c_size_t, [C.c_int32]),

@@ -709,6 +709,26 @@ public:
         streams_.push_back(t);
         return t;
     }
+    // cvgs_stream_release: the caller has synchronised the stream -- free the entry's pinned memory and forget the handle
+    void release(hipStream_t stream) {
+        ManyStream* gone = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (size_t i = 0; i < streams_.size(); ++i)
+                if (streams_[i]->stream == stream) { gone = streams_[i]; streams_.erase(streams_.begin() + (long)i); break; }
+        }
+        if (!gone) return;
+        {
+            std::lock_guard<std::mutex> lk(gone->mu); // (a call of another thread still inside its launch on this stream finishes first)
+            DeviceGuard guard;
+            (void)guard.enter(gone->device);
+            for (ManySlot& sl : gone->slots)
+                if (sl.host) (void)hipHostFree(sl.host);
+            gone->slots.clear();
+            if (gone->done_host) (void)hipHostFree((void*)gone->done_host);
+        }
+        delete gone;
+    }
     // (t->mu held) a free table slot of >= bytes, or nullptr (every slot's kernel still pending after a bounded wait / out of memory)
     ManySlot* acquire(ManyStream* t, size_t bytes) {
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1205,6 +1225,16 @@ int cvgs_device_count(void) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) return fail(CVGS_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     return n;
+}
+
+int cvgs_stream_release(cvgs_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return fail(CVGS_ERR_INVALID, "stream_release on a capturing stream");
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    many_pool().release(s);
+    return CVGS_OK;
 }
 
 int cvgs_validate(const cvgs_chain_desc* chain) {

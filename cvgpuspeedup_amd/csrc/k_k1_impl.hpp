@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <memory>
 #include <type_traits>
 
 #include <hip/hip_ext.h>
@@ -355,7 +356,19 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
 template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT, int WM = WM_PLANAR, bool MIR = false>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn, LaunchCtx& x) {
     hipStream_t stream = (hipStream_t)x.stream;
-    K1Args<NPL> a;
+    // Argument blocks beyond 8 KB (the 16 KB / 52 KB blocks of large batches and host-described ticks) are staged in a per-thread heap buffer and
+    // handed to the launch BY ADDRESS (hipLaunchKernel's argument-pointer form): nothing that size lives on the caller's stack or is copied
+    // through it by value (a tick call used 100-150 KB of stack -- more than some worker threads have).  The buffer starts
+    // zeroed and keeps the previous call's descriptors beyond this call's: no uninitialised byte reaches the argument block.
+    constexpr bool kBig = sizeof(K1Args<NPL>) > 8192;
+    K1Args<NPL> small_block;
+    K1Args<NPL>* block = &small_block;
+    if constexpr (kBig) {
+        static thread_local std::unique_ptr<K1Args<NPL>> staged;
+        if (!staged) staged.reset(new K1Args<NPL>());
+        block = staged.get();
+    }
+    K1Args<NPL>& a = *block;
     a.c = c;
     unsigned grid_z = 1;
     if constexpr (NPL > 0) {
@@ -419,15 +432,18 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
         pre_batch = a.seg[0].batch;
         pre_used = a.seg[0].used;
     }
+    // every argument by address, in the kernel's parameter order (K1_PRELOADED_PARAMS, the argument block, the geometry)
+    void* args[] = {(void*)&pre_table, (void*)&pre_out, (void*)&g.img_stride, (void*)&g.ch_stride, (void*)&pre_batch, (void*)&pre_used, (void*)&g.col_tiles,
+                    (void*)&g.dst_w, (void*)&g.dst_h, (void*)&g.out_w, (void*)&a, (void*)&g};
+    const void* fn = (const void*)&k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>;
+    hipError_t e;
     if (x.stop_event && !x.stop_event_taken) {
         x.stop_event_taken = true;
-        hipExtLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream, nullptr, (hipEvent_t)x.stop_event, 0u,
-                              pre_table, pre_out, g.img_stride, g.ch_stride, pre_batch, pre_used, g.col_tiles, g.dst_w, g.dst_h, g.out_w, a, g);
+        e = hipExtLaunchKernel(fn, grid, dim3(64 * kK1Waves), args, 0, stream, nullptr, (hipEvent_t)x.stop_event, 0);
     } else {
-        hipLaunchKernelGGL((k1_resize_split<CN, NPL, RPW, Prog, SRC, OT, WM, MIR>), grid, dim3(64 * kK1Waves), 0, stream,
-                           pre_table, pre_out, g.img_stride, g.ch_stride, pre_batch, pre_used, g.col_tiles, g.dst_w, g.dst_h, g.out_w, a, g);
+        e = hipLaunchKernel(fn, grid, dim3(64 * kK1Waves), args, 0, stream);
     }
-    return hipGetLastError();
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 // packed / separate-plane targets; one row per wave, four for whole-frame sizes

@@ -9,6 +9,7 @@
 // pairs (4 loads per pixel instead of 12 byte loads); windows are clamped into the row.  Planar stores are
 // full-wave 256-byte rows, non-temporal.
 #include <cstdlib>
+#include <memory>
 #include <type_traits>
 
 #include "k_taps.hpp"
@@ -433,11 +434,15 @@ static hipError_t launch_n12_r(const ChainArgs& c, const PlaneParams* ip, int ni
         const dim3 grid(col_tiles * row_groups, (unsigned)c.read.batch, (unsigned)many.n_segs);
         auto go = [&](auto cap_tag) {
             constexpr int CAP = decltype(cap_tag)::value;
-            KernArgsManyInline<CAP> a;
+            // the 16 KB / 52 KB argument block: staged in a per-thread heap buffer, handed over by address (as K1's: k_k1_impl.hpp launch_t)
+            static thread_local std::unique_ptr<KernArgsManyInline<CAP>> staged;
+            if (!staged) staged.reset(new KernArgsManyInline<CAP>());
+            KernArgsManyInline<CAP>& a = *staged;
             a.c = c;
             for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < many.n_segs ? many.segs[i] : ManySeg{nullptr, nullptr, 0, 0};
             for (int i = 0; i < many.n_planes && i < CAP; ++i) a.planes[i] = many.planes[i];
-            hipLaunchKernelGGL((k4_nv12_resize<-CAP, Prog, OT, RPW, CN, S16, WIN, PL>), grid, dim3(64 * kK4Waves), 0, s, a, g);
+            void* args[] = {(void*)&a, (void*)&g};
+            (void)hipLaunchKernel((const void*)&k4_nv12_resize<-CAP, Prog, OT, RPW, CN, S16, WIN, PL>, grid, dim3(64 * kK4Waves), args, 0, s);
         };
         if (many.n_planes <= kManyInlineSmall) go(std::integral_constant<int, kManyInlineSmall>{});
         else go(std::integral_constant<int, kManyInlineLarge>{});

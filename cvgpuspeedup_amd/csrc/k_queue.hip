@@ -1082,8 +1082,6 @@ struct Queue {
     uint64_t failed_upto = 0;              // every batch below was submitted before the last recovery
     std::vector<uint64_t> lost_tickets;    // ... and these had not completed then: their tensors may be incomplete (the newest 4096 are remembered)
     uint64_t n_gated = 0, n_direct = 0; // stream-ordered submits taken by the server / by a direct launch (hybrid policy)
-    struct StreamPrio { void* stream; bool same_as_server; };
-    std::vector<StreamPrio> stream_prio; // caller streams whose priority has been looked at (queue_submit_on)
     int server_prio = 0;
     bool server_prio_known = false, prio_range_nonempty = false;
     struct StreamTail { void* stream; uint64_t ticket; };
@@ -1768,19 +1766,10 @@ int queue_submit_on(Queue* q, const ChainArgs* const* chains, const PlaneParams*
     // would wait the 10 s gate limit and end in error 3.  Not a stream the server takes: the hybrid policy launches directly.
     // One hipStreamGetPriority per stream key, cached.
     if (stream && q->server_prio_known) {
-        bool same = false, found = false;
-        {
-            std::lock_guard<std::mutex> lock(q->mu);
-            for (const auto& sp : q->stream_prio)
-                if (sp.stream == stream) { found = true; same = sp.same_as_server; break; }
-        }
-        if (!found) {
-            int prio = 0;
-            same = hipStreamGetPriority((hipStream_t)stream, &prio) == hipSuccess && prio == q->server_prio && q->prio_range_nonempty;
-            std::lock_guard<std::mutex> lock(q->mu);
-            if (q->stream_prio.size() >= 256) q->stream_prio.erase(q->stream_prio.begin()); // (handles are reused: bounded, oldest out)
-            q->stream_prio.push_back({stream, same});
-        }
+        // asked anew on every call (a cache keyed by the stream handle could answer for a destroyed stream whose handle the runtime
+        // has handed out again at another priority; the query is cheap beside the gate kernel's launch)
+        int prio = 0;
+        const bool same = hipStreamGetPriority((hipStream_t)stream, &prio) == hipSuccess && prio == q->server_prio && q->prio_range_nonempty;
         if (same) {
             err = "queue: the stream has the server's own (highest) priority and may share its hardware queue -- its gate kernel could never start; "
                   "use a default-priority stream, or the hybrid policy's direct launches";

@@ -873,10 +873,15 @@ inline void flush_attached(hipStream_t stream) {
     uint64_t last = CVGS_QUEUE_TICKET_DIRECT, newest = CVGS_QUEUE_TICKET_DIRECT;
     for (size_t base = 0; base < ptrs.size(); base += CVGS_QUEUE_MAX_GROUP) {
         const size_t cnt = ptrs.size() - base < (size_t)CVGS_QUEUE_MAX_GROUP ? ptrs.size() - base : (size_t)CVGS_QUEUE_MAX_GROUP;
-        if (cvgs_queue_submit_many_on(q, ptrs.data() + base, (int32_t)cnt, stream, flags, &last) != CVGS_OK) {
+        const int rc = cvgs_queue_submit_many_on(q, ptrs.data() + base, (int32_t)cnt, stream, flags, &last);
+        if (rc == CVGS_ERR_UNSUPPORTED || rc == CVGS_ERR_INVALID) { // refused BEFORE anything was published: the chunk runs as plain launches
             // (with DEFER_WAIT the launches are ordered behind the stream, not behind earlier groups still on the server: order them first)
             if (newest != CVGS_QUEUE_TICKET_DIRECT) (void)cvgs_queue_stream_wait(q, newest, stream);
             one_by_one(base, cnt);
+            continue;
+        }
+        if (rc != CVGS_OK) { // a HIP / server error: part of the group may already be on the server -- running it again would run chains twice
+            if (first_error.empty()) first_error = std::string("cvGS (recorded tick, chunk at call ") + std::to_string(base) + "): " + cvgs_last_error();
             continue;
         }
         if (last != CVGS_QUEUE_TICKET_DIRECT) newest = last;
@@ -1159,7 +1164,7 @@ public:
     void attach(hipStream_t stream, bool deferWait = false, int minGroup = 0) {
         detail::StreamAttachments& A = detail::stream_attachments();
         if (A.any.load(std::memory_order_acquire)) detail::flush_attached(stream); // (calls a previous attachment recorded)
-        cv::cuda::cvgs_stream_destroy_hook() = &Queue::detach; // a cv::cuda::Stream that dies takes its attachment with it
+        cv::cuda::cvgs_stream_destroy_hook() = &Queue::stream_dying; // a cv::cuda::Stream that dies takes its attachment with it
         std::lock_guard<std::mutex> lock(A.mu);
         const uint32_t f = CVGS_QUEUE_SUBMIT_HYBRID | (deferWait ? CVGS_QUEUE_SUBMIT_DEFER_WAIT : 0u) | CVGS_QUEUE_SUBMIT_MIN_GROUP(minGroup);
         for (auto& a : A.list)
@@ -1178,7 +1183,14 @@ public:
         for (auto& a : A.list)
             if (a.stream == stream) a.tick = tick < 1 ? 1 : (tick > 4 * CVGS_QUEUE_MAX_GROUP ? 4 * CVGS_QUEUE_MAX_GROUP : tick);
         cv::cuda::cvgs_stream_sync_hook() = &Queue::fence;
-        cv::cuda::cvgs_stream_destroy_hook() = &Queue::detach;
+        cv::cuda::cvgs_stream_destroy_hook() = &Queue::stream_dying;
+    }
+    // what a dying cv::cuda::Stream calls (cv_shim.h: cvgs_stream_destroy_hook, installed when this header is loaded): recorded calls are
+    // submitted and the attachment goes, then the engine retires what it keeps for the stream HANDLE (cvgs_stream_release: the table ring of
+    // cvgs_execute_many -- a handle the runtime hands out again must not continue it)
+    static void stream_dying(hipStream_t stream) {
+        detach(stream);
+        (void)cvgs_stream_release(stream);
     }
     static void detach(hipStream_t stream) {
         detail::flush_attached(stream);
@@ -1235,9 +1247,13 @@ inline void recordTicks(hipStream_t stream, int tick = 16) {
     if (!found) A.list.push_back(std::move(at));
     A.any.store(true, std::memory_order_release);
     cv::cuda::cvgs_stream_sync_hook() = &Queue::fence;
-    cv::cuda::cvgs_stream_destroy_hook() = &Queue::detach;
+    cv::cuda::cvgs_stream_destroy_hook() = &Queue::stream_dying;
 }
 inline void stopRecording(hipStream_t stream) { Queue::detach(stream); }
+// installed when this header is loaded: every owning cv::cuda::Stream that dies releases what the engine keeps for its handle
+namespace detail {
+inline const bool stream_hook_installed = (cv::cuda::cvgs_stream_destroy_hook() = &Queue::stream_dying, true);
+}
 
 // ---- CircularTensor ------------------------------------------------------------------------------------------------
 // MIRRORED (engine extension, default off = the reference's behaviour): the opt-in mirrored-ring layout of

@@ -322,6 +322,13 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * tests/batchresize/test_batchresize_x_split3D.cu:384-392 (one launch per BATCH value).                          */
 int cvgs_execute_many(const cvgs_chain_desc* chains, int32_t n_chains, cvgs_stream_t stream);
 
+/* Call before destroying a stream that has carried cvgs_execute_many calls with host descriptors: waits for the stream's work
+ * (hipStreamSynchronize -- the stream is about to go anyway) and retires the table ring and progress word the library keeps for that stream
+ * HANDLE, so that a later stream the runtime creates with the same handle starts from a clean state and the pinned tables are freed
+ * (hipStreamDestroy does not wait for pending work, and the ring is keyed by the handle).  A no-op (CVGS_OK) for streams the
+ * library holds nothing for; the C++ facade's cv::cuda::Stream calls it from its destructor.  No reference counterpart.               */
+int cvgs_stream_release(cvgs_stream_t stream);
+
 /* Validation only (what the reference checks with static_assert / assert / runtime_error).    */
 int cvgs_validate(const cvgs_chain_desc* chain);
 

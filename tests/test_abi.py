@@ -52,7 +52,7 @@ def test_exported_symbol_list_is_exactly_the_c_abi():
     assert exported_symbols(capi.LIB_PATH) == sorted(set(core) | set(ext))
     # the boundary itself stays small: what replaces executeOperations + CircularTensor, plane tables, the tick launch, introspection
     assert core == sorted(["cvgs_abi_version", "cvgs_version_string", "cvgs_last_error", "cvgs_device_count", "cvgs_execute", "cvgs_execute_many",
-                           "cvgs_validate", "cvgs_kernel_name", "cvgs_plane_table_bytes", "cvgs_plane_table_build", "cvgs_plane_table_hull",
+                           "cvgs_stream_release", "cvgs_validate", "cvgs_kernel_name", "cvgs_plane_table_bytes", "cvgs_plane_table_build", "cvgs_plane_table_hull",
                            "cvgs_circular_create", "cvgs_circular_create_ex", "cvgs_circular_update", "cvgs_circular_data", "cvgs_circular_bytes",
                            "cvgs_circular_updates", "cvgs_circular_destroy", "cvgs_stream_copy", "cvgs_range_push", "cvgs_range_pop"])
     rccl = os.path.join(os.path.dirname(capi.LIB_PATH), "libcvgs_rccl.so")

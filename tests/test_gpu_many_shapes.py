@@ -481,3 +481,48 @@ def test_a_stream_destroyed_with_its_tick_still_pending(oracle, device, lib):
         for out, (k, crops) in zip(outs, meta):
             H.assert_bit_exact(out.cpu().numpy(), _oracle(oracle, frames[k], crops, (64, 128), 3), "stream %d" % i)
     assert len(handles) >= 1
+
+
+def test_stream_release_retires_the_table_ring(oracle, device, lib):
+    """cvgs_stream_release (round 6): the call a host makes before hipStreamDestroy.  Ticks with 16-bit sources take the stream's
+    pinned table ring (their descriptors do not travel in the kernel arguments); release waits for them, frees the ring and forgets the handle --
+    a stream created afterwards (the runtime likes to hand the same handle out again) ticks from a clean state.  A stream the library holds
+    nothing for, and a second release, are no-ops."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    fh, fw = 270, 480
+    rng = np.random.default_rng(77)
+    frames = [rng.integers(0, 65536, size=(fh, fw, 3), dtype=np.uint16) for _ in range(2)]
+    fts = [torch.from_numpy(f.view(np.int16)).to(device) for f in frames]  # (torch has no uint16 arithmetic; the bytes are what matters)
+    torch.cuda.synchronize()
+    handles = set()
+    for i in range(24):
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        handles.add(s.value)
+        chains, outs, meta = [], [], []
+        for k in range(2):
+            crops = H.random_crops(4 + (i + k) % 3, fw, fh, seed=13000 + 17 * i + k, wmax=200, hmax=200)
+            out = torch.full((len(crops), 3 * 64 * 128), -777.0, dtype=torch.float32, device=device)
+            g_src = cvgs.GpuMat(fh, fw, cvgs.CV_16UC3, fts[k].data_ptr(), fw * 6, owner=fts[k])
+            ops = H.k1_chain(g_src, crops, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 128), 3, src_depth=cvgs.CV_16U)
+            chains.append(ops)
+            outs.append(out)
+            meta.append((k, crops))
+        lowered = [cvgs.lower(ops) for ops in chains]
+        arr = cvgs.pack_chains(lowered)
+        torch.cuda.current_stream().synchronize()
+        for _ in range(3):
+            capi.check(lib.cvgs_execute_many(arr, len(lowered), s))
+        capi.check(lib.cvgs_stream_release(s))  # waits for the three ticks, retires the ring
+        for out, (k, crops) in zip(outs, meta):
+            ref = np.full((len(crops), 3 * 64 * 128), -777.0, np.float32)
+            oracle.execute(cvgs.lower(H.k1_chain(cvgs.GpuMat.from_array(frames[k], cvgs.CV_16UC3), crops, cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1), (64, 128), 3,
+                                                 src_depth=cvgs.CV_16U)))
+            H.assert_bit_exact(out.cpu().numpy(), ref, "16-bit tick on stream %d" % i)
+        capi.check(lib.cvgs_stream_release(s))  # nothing left: a no-op
+        assert hip.hipStreamDestroy(s) == 0
+    assert len(handles) < 24, "the runtime never reused a handle: the scenario this test is about did not occur"
+    capi.check(lib.cvgs_stream_release(torch.cuda.current_stream().cuda_stream))  # a stream the library holds nothing for

@@ -12,3 +12,11 @@ hipError_t k1_launch_planar_c3(int src, bool f16, int prog_id, bool table, int r
 }
 
 } // namespace cvgs
+
+#if (CVGS_K1_ABLATE & 32)
+// probe only (tools/probes/xcd_worklist_probe.py; never in the product build): the work lists of the NEXT launch
+extern "C" void cvgs_probe_set_worklist(const uint32_t* base, uint32_t slots) {
+    cvgs::probe_worklist().base = base;
+    cvgs::probe_worklist().slots = slots;
+}
+#endif

@@ -36,6 +36,8 @@ constexpr int kK1Waves = CVGS_K1_WPB;
 //   4 no stores (kept behind a data-dependent test that never holds, so the loads stay)
 //   8 the linear workgroup index is re-read chain-fastest (consecutive workgroups belong to different chains of the tick)
 //  16 the wave ends behind its batch of scalar loads (descriptor fetch only)
+//  32 XCD-banded work lists (tools/probes/xcd_worklist_probe.py): workgroup (slot, chain) looks its (crop, row tile) up in a per-chain list in
+//     which slot s belongs to XCD s % 8 and every XCD's items tap one band of source rows -- overlapping crops of a frame then share an L2
 #ifndef CVGS_K1_ABLATE
 #define CVGS_K1_ABLATE 0
 #endif
@@ -126,6 +128,12 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
         const uint32_t rest = lin / gridDim.z;
         bx = rest % gridDim.x;
         by = rest / gridDim.x;
+    }
+    if constexpr ((kAblate & 32) != 0) { // probe: (crop, row tile) from the chain's XCD-banded work list (g.planes2d / g.row_pitch carry base / slots)
+        const uint32_t item = ((const uint32_t*)g.planes2d)[(size_t)bz * (size_t)g.row_pitch + bx];
+        if (item == 0xffffffffu) return;
+        by = item >> 8;
+        bx = item & 0xffu;
     }
     const int z = (int)by;
     // ---- one batch of scalar loads: the crop's parameters, the program operands come in together; what the wave needs to ask for its
@@ -353,6 +361,11 @@ __global__ __launch_bounds__(64 * kK1Waves) void k1_resize_split(K1_PRELOADED_PA
 }
 
 // ------------------------------------------------------------------------------------------------
+#if (CVGS_K1_ABLATE & 32)
+struct ProbeWorklist { const uint32_t* base = nullptr; uint32_t slots = 0; };
+inline ProbeWorklist& probe_worklist() { static ProbeWorklist w; return w; }
+#endif
+
 template <int CN, int NPL, int RPW, class Prog, int SRC, typename OT, int WM = WM_PLANAR, bool MIR = false>
 static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, int out_cn, LaunchCtx& x) {
     hipStream_t stream = (hipStream_t)x.stream;
@@ -412,7 +425,14 @@ static hipError_t launch_t(const ChainArgs& c, const PlaneParams* inline_planes,
     g.n_mirror = MIR ? x.mirrors.n : 0;
     g.pad2 = 0;
     for (int i = 0; i < CVGS_MAX_MIRRORS; ++i) g.mirror[i] = i < g.n_mirror ? x.mirrors.p[i] : nullptr;
-    const dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
+    dim3 grid(g.col_tiles * row_tiles, (unsigned)c.read.batch, grid_z);
+#if (CVGS_K1_ABLATE & 32)
+    if (probe_worklist().base) {
+        grid = dim3(probe_worklist().slots, 1, grid_z);
+        g.planes2d = (const DstPlane*)probe_worklist().base;
+        g.row_pitch = (int64_t)probe_worklist().slots;
+    }
+#endif
     g.done_word = nullptr;
     g.done_value = 0;
     if constexpr (NPL == 0) {

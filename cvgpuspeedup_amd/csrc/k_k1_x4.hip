@@ -43,6 +43,13 @@
 
 namespace cvgs {
 
+// Ablation hooks of tools/probes/tick_ablation.py --workload resize_write (round 6; never defined in the product build, see k_k1_impl.hpp):
+//   1 no tap loads (windows synthesised from the lane id)   2 no arithmetic (the windows' bytes are stored as they are)   4 no stores
+#ifndef CVGS_X4_ABLATE
+#define CVGS_X4_ABLATE 0
+#endif
+constexpr int kX4Ablate = CVGS_X4_ABLATE;
+
 constexpr int kX4Planes = 8;   // images per launch (blockIdx.y)
 constexpr int kX4Waves = 4;    // waves per workgroup (independent)
 constexpr int kX4Pre = 4;      // most source intervals whose rows a wave requests up front (PRE + 1 source rows; PRE = 1, 2, 4)
@@ -107,6 +114,11 @@ template <> struct X4Raw<SRC_S16> { u32x4 w[2]; };
 template <int CN, int SRC, bool SH = false>
 __device__ __forceinline__ X4Raw<SRC> x4_load(const X4Col<CN, SRC>& col, gptr_u8 row) {
     X4Raw<SRC> r;
+    if constexpr ((kX4Ablate & 1) != 0 && x4_winb<SRC> == 8) { // probe: no tap loads
+#pragma unroll
+        for (int i = 0; i < x4_px<SRC>; ++i) r.w[i] = (uint64_t)(threadIdx.x * 0x01010101u + (uint32_t)(uintptr_t)row + i) * 0x100000001ull;
+        return r;
+    }
     if constexpr (SH) {
         static_assert(SRC == SRC_U8 || ((SRC == SRC_U16 || SRC == SRC_S16) && CN == 1), "shared windows: u8 images, one-channel 16-bit images");
         const uint64_t w = *(gptr_u64)(row + col.ol[0]);
@@ -178,6 +190,15 @@ __device__ __forceinline__ void x4_row(const X4Slot<CN, x4_px<SRC>>& A, const X4
     constexpr int PX = x4_px<SRC>;
     using OT = x4_elem_t<SRC>;
     float v[PX * CN];
+    if constexpr ((kX4Ablate & 2) != 0) { // probe: no arithmetic -- one unpacked tap of each source row, as it is
+#pragma unroll
+        for (int q = 0; q < PX / 2; ++q)
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                v[(2 * q) * CN + c] = A.t0[q][c].x + B.t1[q][c].y;
+                v[(2 * q + 1) * CN + c] = A.t1[q][c].y + B.t0[q][c].x;
+            }
+    } else
 #pragma unroll
     for (int q = 0; q < PX / 2; ++q) {
         const f32x2 w00 = col.wxa[q] * wya;
@@ -216,6 +237,9 @@ __device__ __forceinline__ void x4_row(const X4Slot<CN, x4_px<SRC>>& A, const X4
         }
     }
     const gout p = (gout)pin_uniform(orow) + x0 * (uint32_t)(CN * sizeof(OT));
+    if constexpr ((kX4Ablate & 4) != 0) { // probe: no stores (the test never holds on pixel data; the loads and the arithmetic stay alive)
+        if (!(word[0] == 0x9e3779b9u && word[NW - 1] == 0x7f4a7c15u && v[0] == 1234.5f)) return;
+    }
     auto store_all = [&]() {
         // byte-aligned types: rows of a 3870-pixel u8c3 image (the reference's tests/resize/test_resize_write.cu size) start on
         // any byte; the hardware takes the unaligned multi-dword store

@@ -83,6 +83,43 @@ class Cfg3Workload:
         return float(self._sector)
 
 
+class ResizeWriteWorkload:
+    """The reference's tests/resize/test_resize_write.cu chain at its own size (tools/bench_reference_tests.py: resize_write): a 4K image of
+    `cn` u8 channels -> resize 3870 x 2260 -> convertTo back to u8 -> write (packed), one cvgs_execute per launch, 12 image pairs in rotation."""
+
+    def __init__(self, dev, cn=3, dst=(3870, 2260), pairs=12):
+        import ctypes as C
+        import torch
+        from cvgpuspeedup_amd import capi, cvgs
+        from cvgpuspeedup_amd import workloads as W
+        fw, fh = W.FRAME_4K
+        st, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+        self.chains, self.outs, self.keep = [], [], []
+        for i in range(pairs):
+            src = W.random_u8_torch((fh, fw, cn), 7000 + i, dev)
+            out = torch.zeros((dst[1], dst[0], cn), dtype=torch.uint8, device=dev)
+            ops = [cvgs.resize(st, cvgs.INTER_LINEAR, cvgs.GpuMat.from_tensor(src, st), dst), cvgs.convertTo(f, st), cvgs.write(st, cvgs.GpuMat.from_tensor(out, st))]
+            self.chains.append(cvgs.lower(ops))
+            self.outs.append(out)
+            self.keep.append(src)
+        self.kernel = cvgs.kernel_name(*ops)
+        self.lib = capi.load_library()
+        self.per_launch, self.n, self.groups = 1, 1, []
+        self._C, self._check = C, capi.check
+        self._alg = (fw * fh + dst[0] * dst[1]) * cn
+
+    def launch(self, i, stream):
+        rc = self.lib.cvgs_execute(self._C.byref(self.chains[i % len(self.chains)].desc), stream)
+        if rc:
+            self._check(rc)
+
+    def algorithmic_bytes(self):
+        return float(self._alg)
+
+    def sector_bound_bytes(self):
+        return float(self._alg)
+
+
 def load_variant(path):
     from cvgpuspeedup_amd import capi
     lib = C.CDLL(path)
@@ -100,7 +137,8 @@ def main():
     p.add_argument("--frames", type=int, default=96)
     p.add_argument("--rounds", type=int, default=4)
     p.add_argument("--variants", default=None)
-    p.add_argument("--workload", default="k1", choices=["k1", "cfg3"], help="k1: the headline ticks (cfg #2b); cfg3: NV12 6K -> 1280x720, --m = cameras per launch")
+    p.add_argument("--workload", default="k1", choices=["k1", "cfg3", "resize_write"],
+                   help="k1: the headline ticks (cfg #2b); cfg3: NV12 6K -> 1280x720, --m = cameras per launch; resize_write: 4K u8 (--m channels) -> 3870x2260 -> u8 (k1_packed_x4)")
     p.add_argument("--frame", default="4k", choices=["4k", "8k"], help="k1 only: frame size the 50 crops are drawn from (8k: the same crop sizes barely overlap)")
     p.add_argument("--fixed", action="store_true", help="k1 only: cfg #2a's crops (60 x 120 at (i, i), the reference's own test layout) instead of cfg #2b's")
     p.add_argument("--out", default=None)
@@ -118,7 +156,12 @@ def main():
     M = a.m
     if a.variants is None:
         a.variants = "full,ldst,ld,st,desc,zfast,zfast_ldst,plain,sc1,sys" if a.workload == "k1" else "k4_full,k4_ldst,k4_ld,k4_st,k4_math,k4_empty"
-    if a.workload == "cfg3":
+    if a.workload == "resize_write":
+        wl = ResizeWriteWorkload(dev, cn=M if M in (1, 2, 3, 4) else 3)
+        nf, M = len(wl.chains), 1
+        if a.variants is None or a.variants.startswith("k4_"):
+            a.variants = "x4_full,x4_ldst,x4_ld,x4_st,x4_math"
+    elif a.workload == "cfg3":
         wl = Cfg3Workload(dev, cams=M)
         nf, M = len(wl.chains), 1  # one cvgs_execute per launch
     else:
@@ -135,7 +178,7 @@ def main():
         libs[v] = load_variant(path)
     order = ["installed"] + names
     launches = max(16, 256 // M)
-    if a.workload == "cfg3":
+    if a.workload in ("cfg3", "resize_write"):
         launches = 2 * nf
 
     def run_all(lib):
@@ -156,13 +199,13 @@ def main():
             for o in wl.outs:
                 o.zero_()
             run_all(libs[v])
-            bit[v] = all(bool(torch.equal(o.view(torch.int32), r.view(torch.int32))) for o, r in zip(wl.outs, ref))
+            bit[v] = all(bool(torch.equal(o.reshape(-1).view(torch.uint8), r.reshape(-1).view(torch.uint8))) for o, r in zip(wl.outs, ref))
     copy = B.copy_ceiling(dev)
     times = {v: [] for v in order}
     for r in range(a.rounds):
         for v in order:
             wl.lib = libs[v]
-            m = B.measure(wl, launches, 4, target_s=0.12, min_replays=20, est_step_s=(8e-6 * a.m if a.workload == "cfg3" else 2.5e-6 * M), exact_steps=True)
+            m = B.measure(wl, launches, 4, target_s=0.12, min_replays=20, est_step_s=(8e-6 * a.m if a.workload == "cfg3" else (2e-5 if a.workload == "resize_write" else 2.5e-6 * M)), exact_steps=True)
             times[v].append(m["step_s"] * 1e6)
             print("round %d %-12s %8.3f us per launch" % (r, v, times[v][-1]), file=sys.stderr, flush=True)
     wl.lib = installed
@@ -177,11 +220,12 @@ def main():
             rows[v]["bit_identical_to_installed"] = bit[v]
     out = {"m": M, "frames": nf, "rounds": a.rounds, "launches_per_replay": launches, "algorithmic_bytes_per_launch": alg, "sector_floor_bytes_per_launch": sect,
            "copy_ceiling_TBs": copy, "rows": rows}
-    full = rows.get("full", rows.get("k4_full", rows["installed"]))["us_per_launch"]
-    skel = "ldst" if "ldst" in rows else ("k4_ldst" if "k4_ldst" in rows else None)
+    full = rows.get("full", rows.get("k4_full", rows.get("x4_full", rows["installed"])))["us_per_launch"]
+    skel = next((k for k in ("ldst", "k4_ldst", "k4_rows2_ldst", "x4_ldst") if k in rows), None)
     if skel:
         out["full_over_skeleton"] = round(full / rows[skel]["us_per_launch"], 4)
-    what = ("cfg #3 (NV12 6K -> 1280x720 normalized NCHW), %d surface(s) per launch, %d launches in rotation" % (a.m, nf) if a.workload == "cfg3" else
+    what = ("resize_write 4K u8c%d -> 3870x2260 u8, %d image pairs in rotation" % (a.m, nf) if a.workload == "resize_write" else
+            "cfg #3 (NV12 6K -> 1280x720 normalized NCHW), %d surface(s) per launch, %d launches in rotation" % (a.m, nf) if a.workload == "cfg3" else
             "M = %d frames (%s) x 50 %s crops per launch, %d-frame rotation" % (M, a.frame, "fixed 60x120 (cfg #2a)" if a.fixed else "variable (cfg #2b)", nf))
     text = ["# ablation of %s [%s]: %d rounds round-robin, median (min-max) us per launch" % (wl.kernel, what, a.rounds),
             "# algorithmic bytes per launch %.0f, 64-B sector floor %.0f, copy ceiling of this run %s TB/s" % (alg, sect, json.dumps(copy)),

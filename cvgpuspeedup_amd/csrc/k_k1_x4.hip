@@ -52,7 +52,10 @@ constexpr int kX4Ablate = CVGS_X4_ABLATE;
 
 constexpr int kX4Planes = 8;   // images per launch (blockIdx.y)
 constexpr int kX4Waves = 4;    // waves per workgroup (independent)
-constexpr int kX4Pre = 4;      // most source intervals whose rows a wave requests up front (PRE + 1 source rows; PRE = 1, 2, 4)
+#ifndef CVGS_X4_PRE
+#define CVGS_X4_PRE 4
+#endif
+constexpr int kX4Pre = CVGS_X4_PRE; // most source intervals whose rows a wave requests up front (PRE + 1 source rows; PRE = 1, 2, 4)
 
 struct X4Plane { // 32 bytes
     const uint8_t* data;
@@ -88,6 +91,9 @@ struct X4Col {
     static constexpr int PX = x4_px<SRC>;
     f32x2 wxa[PX / 2], wxb[PX / 2];
     uint32_t ol[PX]; // SH (shared window): ol[0] only
+    // W16 (u8c3, no horizontal down-scaling): ONE unaligned 16-byte load per lane and source row at `ob` holds the taps of all four pixels
+    // (they span at most 5 source pixels = 15 bytes); pixel i's window starts rel[i] = ol[i] - ob bytes in (0..9)
+    uint32_t ob, rel[PX];
     // u8: the v_perm_b32 selectors of the window's two dwords; 16-bit: the window's shift in bits, fp32: "the window was
     // clamped back by one pixel" (fix_a), and the right-edge flag (fix_b)
     uint32_t fix_a[PX], fix_b[PX];
@@ -111,9 +117,27 @@ template <> struct X4Raw<SRC_S16> { u32x4 w[2]; };
 
 // SH: ONE 8-byte window per lane and source row holds the taps of ALL the lane's pixels (u8 images of 1-2 channels when the lane's
 // pixels lie close enough: launch_k1_packed_x4) -- a quarter of the load instructions of one window per pixel.
-template <int CN, int SRC, bool SH = false>
+template <int CN, int SRC, bool SH = false, bool W16 = false>
 __device__ __forceinline__ X4Raw<SRC> x4_load(const X4Col<CN, SRC>& col, gptr_u8 row) {
     X4Raw<SRC> r;
+    if constexpr (W16 && (kX4Ablate & 1) == 0) {
+        static_assert(SRC == SRC_U8 && CN == 3 && !SH, "one 16-byte window per lane: u8c3");
+        // Round 6 (profiles/r06_f_resize_write_c3.txt): four overlapping unaligned 8-byte loads per lane and source row made the launch
+        // LOAD-INSTRUCTION bound (tap loads alone 13.3 us for 25 MB; an unaligned vector load costs the address unit ~40 cycles whatever its
+        // width).  One 16-byte load brings the same bytes; each pixel's 8-byte window is cut out of it with two v_alignbyte_b32 on the dwords
+        // its offset selects (5 selects: the offset is 0..9 bytes, so the window starts in dword 0, 1 or 2).
+        const u32x4 q = *(gptr_u32x4)(row + col.ob);
+#pragma unroll
+        for (int i = 0; i < x4_px<SRC>; ++i) {
+            const uint32_t k = col.rel[i] >> 2, m = col.rel[i] & 3u;
+            const uint32_t a = k == 0 ? q.x : (k == 1 ? q.y : q.z);
+            const uint32_t b = k == 0 ? q.y : (k == 1 ? q.z : q.w);
+            const uint32_t c = k == 0 ? q.z : q.w;
+            const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, m), hi = __builtin_amdgcn_alignbyte(c, b, m);
+            r.w[i] = ((uint64_t)hi << 32) | lo;
+        }
+        return r;
+    }
     if constexpr ((kX4Ablate & 1) != 0 && x4_winb<SRC> == 8) { // probe: no tap loads
 #pragma unroll
         for (int i = 0; i < x4_px<SRC>; ++i) r.w[i] = (uint64_t)(threadIdx.x * 0x01010101u + (uint32_t)(uintptr_t)row + i) * 0x100000001ull;
@@ -272,7 +296,7 @@ __device__ __forceinline__ void x4_row(const X4Slot<CN, x4_px<SRC>>& A, const X4
     }
 }
 
-template <int CN, int SRC, int PRE, bool SH = false>
+template <int CN, int SRC, int PRE, bool SH = false, bool W16 = false>
 __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
     constexpr int PX = x4_px<SRC>;
     constexpr int EB = elem_bytes<SRC>;
@@ -314,6 +338,10 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
         }
         const uint32_t sh = (uint32_t)(o - ol);
         if constexpr (!SH) col.ol[i] = (uint32_t)ol;
+        if constexpr (W16) { // (row_bytes >= 16: the launcher checks)
+            if (i == 0) col.ob = (uint32_t)min(o, row_bytes - 16);
+            col.rel[i] = (uint32_t)ol - col.ob;
+        }
         if constexpr (SRC == SRC_U8) {
             col.fix_a[i] = 0x03020100u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(0) : 0u);
             col.fix_b[i] = 0x07060504u + sh * 0x01010101u - (edge ? x4_edge_sub<CN>(1) : 0u);
@@ -362,7 +390,7 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
         const int s0 = y1_of(0);
         X4Raw<SRC> raw[PRE + 1];
 #pragma unroll
-        for (int k = 0; k <= PRE; ++k) raw[k] = x4_load<CN, SRC, SH>(col, row_of(min(s0 + k, h1)));
+        for (int k = 0; k <= PRE; ++k) raw[k] = x4_load<CN, SRC, SH, W16>(col, row_of(min(s0 + k, h1)));
         x4_unpack<CN, SRC, SH>(S0, col, raw[0]);
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
@@ -387,15 +415,15 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
 #pragma unroll 1
     while (j < nrows) {
         int s = y1_of(j);
-        const X4Raw<SRC> first = x4_load<CN, SRC, SH>(col, row_of(s));
-        X4Raw<SRC> next = x4_load<CN, SRC, SH>(col, row_of(min(s + 1, h1)));
+        const X4Raw<SRC> first = x4_load<CN, SRC, SH, W16>(col, row_of(s));
+        X4Raw<SRC> next = x4_load<CN, SRC, SH, W16>(col, row_of(min(s + 1, h1)));
         x4_unpack<CN, SRC, SH>(S0, col, first);
 #pragma unroll 1
         for (;;) {
             x4_unpack<CN, SRC, SH>(S1, col, next);
             int jn = j + rows_on(s);
             bool more = jn < nrows && y1_of(jn) == s + 1;
-            if (more) next = x4_load<CN, SRC, SH>(col, row_of(min(s + 2, h1)));
+            if (more) next = x4_load<CN, SRC, SH, W16>(col, row_of(min(s + 2, h1)));
 #pragma unroll 1
             for (; j < jn; ++j) emit(S0, S1, j);
             if (!more) break;
@@ -403,7 +431,7 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
             x4_unpack<CN, SRC, SH>(S0, col, next);
             jn = j + rows_on(s);
             more = jn < nrows && y1_of(jn) == s + 1;
-            if (more) next = x4_load<CN, SRC, SH>(col, row_of(min(s + 2, h1)));
+            if (more) next = x4_load<CN, SRC, SH, W16>(col, row_of(min(s + 2, h1)));
 #pragma unroll 1
             for (; j < jn; ++j) emit(S1, S0, j);
             if (!more) break;
@@ -470,6 +498,9 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     for (int i = 0; i < n_planes; ++i) fy_max = planes[i].fy > fy_max ? planes[i].fy : fy_max;
     const int rows_fed = fy_max > 0.f ? (int)((float)kX4Pre / fy_max) : 8;
     if (rows_fed < rows_per_wave) rows_per_wave = rows_fed < 1 ? 1 : rows_fed;
+#ifdef CVGS_X4_ROWS // (tools/probes/build_ablate.sh: other rows per wave for A/B)
+    rows_per_wave = CVGS_X4_ROWS;
+#endif
     a.rows_per_wave = rows_per_wave > 64 ? 64 : rows_per_wave;
     const int rows_per_wg = kX4Waves * a.rows_per_wave;
     const uint32_t row_blks = (uint32_t)((r.dst_h + rows_per_wg - 1) / rows_per_wg);
@@ -484,6 +515,12 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     bool shared = ((src == SRC_U8 && r.cn <= 2) || sh16) && fy_max > 0.f;
     for (int i = 0; i < n_planes && shared; ++i)
         shared = ((int)std::floor((double)(px - 1) * (double)planes[i].fx * 1.0001) + 1) * r.cn * eb + 2 * r.cn * eb <= 8;
+    // u8c3 without horizontal down-scaling: the lane's four pixels tap at most 5 source pixels (15 bytes) -- one 16-byte window per lane
+    bool wide16 = src == SRC_U8 && r.cn == 3;
+    for (int i = 0; i < n_planes && wide16; ++i) wide16 = planes[i].fx <= 1.0f && (int64_t)planes[i].w * 3 >= 16;
+#ifdef CVGS_X4_NO_W16 // (tools/probes/build_ablate.sh builds the four-window form for A/B)
+    wide16 = false;
+#endif
     auto go = [&](auto cn_tag, auto src_tag) {
         constexpr int CN = decltype(cn_tag)::value, SRC = decltype(src_tag)::value;
         if constexpr ((SRC == SRC_U8 && CN <= 2) || ((SRC == SRC_U16 || SRC == SRC_S16) && CN == 1)) {
@@ -491,6 +528,14 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
                 if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 1, true>), grid, block, 0, s, a);
                 else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 2, true>), grid, block, 0, s, a);
                 else hipLaunchKernelGGL((k1_packed_x4<CN, SRC, kX4Pre, true>), grid, block, 0, s, a);
+                return;
+            }
+        }
+        if constexpr (SRC == SRC_U8 && CN == 3) {
+            if (wide16) { // one 16-byte window per lane and source row (see x4_load)
+                if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 1, false, true>), grid, block, 0, s, a);
+                else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 2, false, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((k1_packed_x4<CN, SRC, kX4Pre, false, true>), grid, block, 0, s, a);
                 return;
             }
         }

@@ -120,8 +120,25 @@ template <> struct X4Raw<SRC_S16> { u32x4 w[2]; };
 template <int CN, int SRC, bool SH = false, bool W16 = false>
 __device__ __forceinline__ X4Raw<SRC> x4_load(const X4Col<CN, SRC>& col, gptr_u8 row) {
     X4Raw<SRC> r;
-    if constexpr (W16 && (kX4Ablate & 1) == 0) {
-        static_assert(SRC == SRC_U8 && CN == 3 && !SH, "one 16-byte window per lane: u8c3");
+    if constexpr (W16 && CN == 4 && (kX4Ablate & 1) == 0) {
+        // u8c4: the four pixels tap at most 5 source pixels = 20 bytes, dword aligned: one 16-byte + one 4-byte load, every window = two of the
+        // five dwords, picked by the pixel's dword offset (0..3)
+        static_assert(SRC == SRC_U8 && !SH, "wide windows: u8 images");
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        typedef const __attribute__((address_space(1))) u32_unaligned* gptr_u32u;
+        const u32x4 q = *(gptr_u32x4)(row + col.ob);
+        const uint32_t e = *(gptr_u32u)(row + col.ob + 16);
+#pragma unroll
+        for (int i = 0; i < x4_px<SRC>; ++i) {
+            const uint32_t k = col.rel[i] >> 2;
+            const uint32_t lo = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
+            const uint32_t hi = k == 0 ? q.y : (k == 1 ? q.z : (k == 2 ? q.w : e));
+            r.w[i] = ((uint64_t)hi << 32) | lo;
+        }
+        return r;
+    }
+    if constexpr (W16 && CN == 3 && (kX4Ablate & 1) == 0) {
+        static_assert(SRC == SRC_U8 && !SH, "wide windows: u8 images");
         // Round 6 (profiles/r06_f_resize_write_c3.txt): four overlapping unaligned 8-byte loads per lane and source row made the launch
         // LOAD-INSTRUCTION bound (tap loads alone 13.3 us for 25 MB; an unaligned vector load costs the address unit ~40 cycles whatever its
         // width).  One 16-byte load brings the same bytes; each pixel's 8-byte window is cut out of it with two v_alignbyte_b32 on the dwords
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(64 * kX4Waves) void k1_packed_x4(const X4Args a) {
         const uint32_t sh = (uint32_t)(o - ol);
         if constexpr (!SH) col.ol[i] = (uint32_t)ol;
         if constexpr (W16) { // (row_bytes >= 16: the launcher checks)
-            if (i == 0) col.ob = (uint32_t)min(o, row_bytes - 16);
+            if (i == 0) col.ob = (uint32_t)min(o, row_bytes - (CN == 4 ? 20 : 16));
             col.rel[i] = (uint32_t)ol - col.ob;
         }
         if constexpr (SRC == SRC_U8) {
@@ -516,8 +533,9 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
     for (int i = 0; i < n_planes && shared; ++i)
         shared = ((int)std::floor((double)(px - 1) * (double)planes[i].fx * 1.0001) + 1) * r.cn * eb + 2 * r.cn * eb <= 8;
     // u8c3 without horizontal down-scaling: the lane's four pixels tap at most 5 source pixels (15 bytes) -- one 16-byte window per lane
-    bool wide16 = src == SRC_U8 && r.cn == 3;
-    for (int i = 0; i < n_planes && wide16; ++i) wide16 = planes[i].fx <= 1.0f && (int64_t)planes[i].w * 3 >= 16;
+    // (u8c4: 20 bytes = a 16-byte and a 4-byte load instead of four 8-byte ones)
+    bool wide16 = src == SRC_U8 && r.cn >= 3;
+    for (int i = 0; i < n_planes && wide16; ++i) wide16 = planes[i].fx <= 1.0f && (int64_t)planes[i].w * r.cn >= (r.cn == 4 ? 20 : 16);
 #ifdef CVGS_X4_NO_W16 // (tools/probes/build_ablate.sh builds the four-window form for A/B)
     wide16 = false;
 #endif
@@ -531,7 +549,7 @@ int launch_k1_packed_x4(const ChainArgs& c, const PlaneParams* planes, int n_pla
                 return;
             }
         }
-        if constexpr (SRC == SRC_U8 && CN == 3) {
+        if constexpr (SRC == SRC_U8 && CN >= 3) {
             if (wide16) { // one 16-byte window per lane and source row (see x4_load)
                 if (pre == 1) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 1, false, true>), grid, block, 0, s, a);
                 else if (pre == 2) hipLaunchKernelGGL((k1_packed_x4<CN, SRC, 2, false, true>), grid, block, 0, s, a);

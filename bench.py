@@ -1042,9 +1042,11 @@ def pmc_traffic(crops, table, per_launch=1, queue=False):
 
 
 def skeleton_evidence(per_launch):
-    """The committed ablation of the headline launch (tools/probes/tick_ablation.py, profiles/r06_a_tick_ablation_m16.txt): the product kernel
+    """The committed ablation of the headline launch (tools/probes/tick_ablation.py, profiles/r06_z_tick_ablation_m16.txt): the product kernel
     against its own memory skeleton (tap loads + stores, no arithmetic) on this exact grid and rotation -- measured in its own run, not in this one."""
-    path = os.path.join(ROOT, "profiles", "r06_a_tick_ablation_m%d.txt" % per_launch)
+    path = os.path.join(ROOT, "profiles", "r06_z_tick_ablation_m%d.txt" % per_launch)  # the final tree's set; r06_a: the round's first
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r06_a_tick_ablation_m%d.txt" % per_launch)
     try:
         rows = json.loads(open(path).read().strip().splitlines()[-1])["rows"]
         return {"full_us": rows["full"]["us_per_launch"], "loads_stores_only_us": rows["ldst"]["us_per_launch"], "loads_only_us": rows["ld"]["us_per_launch"],

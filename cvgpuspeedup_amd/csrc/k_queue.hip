@@ -1923,8 +1923,7 @@ void queue_prof(Queue* q, uint64_t* out16) {
     out16[13] = q->n_sub ? q->ns_ring_wait / q->n_sub : 0; // host side of submit, ns per call (since create)
     out16[14] = q->n_gated | (q->n_direct << 32); // stream-ordered submits: taken by the server | launched directly by the latency policy
     out16[15] = 0;
-    out16[2] = 0;                  // ... launched directly because the closed-batch budget was exhausted
-    out16[3] = 0;                   // ... that waited for a gate to open
+    out16[2] = out16[3] = 0; // (reserved: the closed-batch budget these two slots reported was removed in round 5 -- ADVICE r5)
 }
 
 void queue_stats(Queue* q, uint64_t* out8) {

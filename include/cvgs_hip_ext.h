@@ -112,8 +112,9 @@ int cvgs_queue_stream_wait(cvgs_queue_t q, uint64_t ticket, cvgs_stream_t stream
 int cvgs_queue_stats(cvgs_queue_t q, uint64_t* out8);
 /* the hipStream_t the server grid is launched on (for HIP events / profilers; do not enqueue work behind a live server) */
 cvgs_stream_t cvgs_queue_stream(cvgs_queue_t q);
-/* out[16], of the last RETIRED server, 100 MHz ticks / counts: feeder {rounds with copies, slots, load ticks, copy ticks},
- * monitor {scans, scan ticks, completions published, -}, worker 0 {tasks, find ticks, rows ticks, drain ticks, idle polls} */
+/* out[16], of the last RETIRED server, 100 MHz ticks / counts: feeder {rounds with copies, slots, 0, 0 (reserved)},
+ * monitor {scans, scan ticks, ring waits of the host, batches complete behind an incomplete oldest one (mean)}, worker 0 {tasks, find ticks, rows ticks, drain
+ * ticks, idle polls}, host ns per submit spent waiting for a ring slot, stream-ordered submits taken by the server | launched directly << 32, gate trace address (probes) */
 int cvgs_queue_profile(cvgs_queue_t q, uint64_t* out16);
 int cvgs_queue_destroy(cvgs_queue_t q);
 

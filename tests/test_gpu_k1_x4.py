@@ -213,3 +213,26 @@ def test_x4_reference_resize_write_size(cn):
     gpu, ref = _both(build, oshape, odt)
     H.assert_bit_exact(gpu[0], ref[0], "4K -> 3870x2260 packed u8c%d" % cn)
     assert _name(build) == "k1_u8c%d_packed_u8_x4" % cn
+
+
+# round 6: u8c3 / u8c4 without horizontal down-scaling take ONE 16-byte (+ 4-byte) tap window per lane and source row; the window is clamped
+# back at the row's end, and a lane's pixels may start anywhere inside it: narrow sources (barely one window), identity scale (every lane's
+# window offset is a multiple of 12 / 16), ragged last column tiles, fractional up-scaling, sources that END at the end of their allocation
+WIDE_SHAPES = [((40, 6), (18, 80)), ((40, 7), (7, 40)), ((33, 17), (50, 70)), ((64, 256), (256, 64)), ((64, 257), (257, 64)), ((30, 300), (1023, 41)),
+               ((50, 86), (258, 100)), ((25, 1000), (1000, 25)), ((19, 341), (999, 57)), ((12, 5), (12, 24))]
+
+
+@pytest.mark.parametrize("cn", [3, 4])
+@pytest.mark.parametrize("shape", WIDE_SHAPES)
+def test_x4_wide_tap_window(forced, shape, cn):
+    (sh, sw), dst = shape
+    if sw * cn < (20 if cn == 4 else 16):
+        # (narrower than one wide window: the four-window form serves it -- still bit-exact, still this kernel)
+        assert sw * cn >= 8
+    src = H.random_u8((sh, sw, cn), 4200 + cn + sw)
+    build, oshape, odt = _chain(src, cn, dst, True, x_off=1, pad=3)
+    gpu, ref = _both(build, oshape, odt)
+    H.assert_bit_exact(gpu[0], ref[0], "resize -> packed u8, wide tap window, %dx%d -> %dx%d c%d" % (sw, sh, dst[0], dst[1], cn))
+    assert _name(build) == "k1_u8c%d_packed_u8_x4" % cn
+    one, _ = _both(build, oshape, odt, flags=capi.CHAIN_NO_THREAD_FUSION)
+    H.assert_bit_exact(one[0], gpu[0], "the one-pixel-per-lane kernel agrees")

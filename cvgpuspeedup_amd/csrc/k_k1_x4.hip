@@ -32,6 +32,9 @@
 // What bounds it now: issue (tools/probes/pk_rate_probe.cpp: v_pk_mul_f32 / v_pk_add_f32 retire at 5.7 cycles per
 // instruction per SIMD, conversions at 4.4 - 4.8; 3.4 M VALU + 1.4 M SALU instructions per 4K launch = ~7 us of issue at
 // 4 waves per SIMD) -- a launch without its stores runs 10.3 us against 11.3 with them (profiles/r03_d_*).
+// Round 6: the kernel's own skeletons at the reference's 4K -> 3870 x 2260 size (tools/probes/tick_ablation.py --workload resize_write;
+// profiles/r06_f_resize_write_c*.txt) showed u8c3 bound by its tap-load INSTRUCTIONS (loads alone 13.3 us for 25 MB): u8c3 / u8c4 images without
+// horizontal down-scaling now take ONE 16-byte (+ 4-byte) window per lane and source row (x4_load<W16>): 19.6 -> 17.2 us, u8c4 19.2 -> 18.9.
 // Vertical DOWN-scaling stays with k1_resize_split: no source row is shared, and it ties or wins there (4K -> 1080p 10.3 us).
 #include <hip/hip_runtime.h>
 

@@ -1,5 +1,5 @@
 """Up-scaling sweep for K1's packed-u8 whole-frame kernels (k_k1_x4.hip against k1_resize_split): src -> dst packed u8c3 / u8c4,
-HIP-event time per launch.  Environment hooks (CVGS_K1_X4, CVGS_K1_X4_ROWS) pick the variant; run once per setting."""
+HIP-event time per launch.  The environment hook CVGS_K1_X4 (0 = never, 1 = whenever eligible) picks the kernel; other rows-per-wave shapes: tools/probes/build_ablate.sh (-DCVGS_X4_ROWS)."""
 import argparse
 import ctypes as C
 import json

@@ -976,8 +976,13 @@ bool same_shape(const cvgs_chain_desc& a, const cvgs_chain_desc& b) {
 // headline's own submission path (device tables, graph replay) was the one path nothing checked (VERDICT r5 "what's weak" #6).
 struct ByteRange { const uint8_t* lo; const uint8_t* hi; };
 bool tensor_out_range(const cvgs_chain_desc& c, ByteRange* out) {
-    if (c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT) return false;
+    if (c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT && c.write.kind != CVGS_WRITE_PIXEL_3D) return false;
     if (c.read.batch < 1 || !c.write.data) return false;
+    if (c.write.kind == CVGS_WRITE_PIXEL_3D) { // dense [plane][y][x] packed pixels: batch planes of width x height pixels
+        const size_t px = (size_t)depth_bytes(CVGS_TYPE_DEPTH(c.write.dst_type)) * (size_t)CVGS_TYPE_CN(c.write.dst_type);
+        *out = ByteRange{(const uint8_t*)c.write.data, (const uint8_t*)c.write.data + (size_t)c.read.batch * (size_t)c.write.width * (size_t)c.write.height * px};
+        return true;
+    }
     const size_t esz = (size_t)depth_bytes(CVGS_TYPE_DEPTH(c.write.dst_type));
     const size_t plane = (size_t)c.write.width * (size_t)c.write.height, cn = (size_t)CVGS_TYPE_CN(c.write.dst_type);
     // NCHW: batch images of cn planes.  CNHW (TensorTSplit): channel k of image z lives at (k * write.planes + z) * plane -- the
@@ -1057,7 +1062,57 @@ bool chains_independent(const cvgs_chain_desc* const* chains, int n) {
     return true;
 }
 
+// n chains of the thread-fused POINTWISE shape in one launch (round 6; the reference's batched per-pixel chains, tests/batchread/
+// test_batchread_x_write3D.cu:92-96: BATCH crops -> convertTo -> subtract -> divide -> tensor, launch-bound at 4 us for 50 crops of 60 x 120):
+// per-pixel reads of u8 planes of ONE size, host descriptors, a dense fp32 target per chain.  1 launched / 0 not this shape / < 0 error.
+int pointwise_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
+    if (n < 2 || n > CVGS_MAX_CHAINS) return 0;
+    size_t total_planes = 0;
+    int max_batch = 0;
+    const cvgs_chain_desc* ptrs[CVGS_MAX_CHAINS];
+    for (int i = 0; i < n; ++i) {
+        const cvgs_chain_desc& c = chains[i];
+        if (c.read.kind != CVGS_READ_PIXEL || (c.flags & (CVGS_CHAIN_FORCE_GENERIC | CVGS_CHAIN_NO_THREAD_FUSION)) || (c.read.flags & CVGS_READ_FLAG_TABLE_ON_DEVICE) ||
+            (c.write.kind != CVGS_WRITE_TENSOR_SPLIT && c.write.kind != CVGS_WRITE_TENSOR_T_SPLIT && c.write.kind != CVGS_WRITE_PIXEL_3D) ||
+            c.read.batch < 1 || c.read.batch > 65535 || !same_shape(chains[0], c))
+            return 0;
+        total_planes += (size_t)c.read.batch;
+        max_batch = std::max(max_batch, (int)c.read.batch);
+        ptrs[i] = &c;
+    }
+    if (total_planes > (size_t)cvgs::kManyInlineLarge || (int64_t)n * max_batch > 65535) return 0;
+    if (!chains_independent(ptrs, n)) return 0; // fused chains run concurrently: keep the sequential meaning of dependent ones
+    ManySeg segs[CVGS_MAX_CHAINS];
+    static thread_local std::vector<PlaneParams> planes;
+    planes.clear();
+    Lowered L0;
+    for (int i = 0; i < n; ++i) {
+        Lowered Li;
+        Lowered& L = i == 0 ? L0 : Li;
+        const int rc = lower(&chains[i], false, L);
+        if (rc) return rc; // nothing enqueued yet
+        if (L.int_arith || L.uses_64f || L.mirrors.n > 0 || !L.dst_planes.empty() || (int)L.planes.size() != L.args.read.batch) return 0;
+        // one plane size for the whole tick (the grid's x / y extent), and it is the target's
+        if (L.args.read.dst_w != L0.args.read.dst_w || L.args.read.dst_h != L0.args.read.dst_h) return 0;
+        for (size_t k = 0; k < L.planes.size() && (int)k < L.args.read.used; ++k)
+            if (L.planes[k].w != L0.args.read.dst_w || L.planes[k].h != L0.args.read.dst_h) return 0;
+        segs[i] = ManySeg{(const PlaneParams*)(uintptr_t)planes.size(), L.args.write.data, L.args.read.batch, L.args.read.used};
+        planes.insert(planes.end(), L.planes.data(), L.planes.data() + L.planes.size());
+    }
+    ChainArgs c = L0.args;
+    c.read.batch = max_batch;
+    if (launch_pointwise_many(c, planes.data(), (int)planes.size(), segs, n, max_batch, chains[0].flags, stream, true) != 1) return 0;
+    const int rc = launch_pointwise_many(c, planes.data(), (int)planes.size(), segs, n, max_batch, chains[0].flags, stream, false);
+    if (rc < 0) return fail(CVGS_ERR_HIP, "fused pointwise kernel launch failed");
+    return rc;
+}
+
 int execute_many(const cvgs_chain_desc* chains, int32_t n, hipStream_t stream) {
+    if (n >= 2 && chains[0].read.kind == CVGS_READ_PIXEL) {
+        const int rc = pointwise_many(chains, n, stream);
+        if (rc == 1) return CVGS_OK;
+        if (rc < 0) return rc;
+    }
     // try the fused launch: every chain a resize of pixels (K1) or of 4:2:0 surfaces (K4) into a planar tensor, all of one shape
     bool fusable = n >= 2;
     for (int i = 0; fusable && i < n; ++i) {

@@ -209,6 +209,11 @@ static constexpr int64_t kK4X2MinWaveRows = 4096; // output rows x 64-column til
 bool k4_planes_eligible(const PlaneParams* planes, int n, int dst_w, int dst_h);
 
 // Thread-fused pointwise chains on u8 sources (4 pixels per thread) -> fp32 planar / packed.
+// n_segs chains of ONE thread-fused pointwise shape (per-pixel reads of u8 planes -> fp32 tensor / packed fp32 pixels) in one launch: the
+// chains' planes travel in the kernel arguments (segs[i].table = the chain's first index into `planes`), grid z = chain x max_batch + plane.
+// 1 launched / 0 not this shape (the caller runs the chains one by one) / < 0 error.
+int launch_pointwise_many(const ChainArgs& c, const PlaneParams* planes, int n_planes, const ManySeg* segs, int n_segs, int max_batch,
+                          uint32_t chain_flags, void* stream, bool dry_run);
 int launch_pointwise(const ChainArgs& c, const PlaneParams* inline_planes, int n_inline, uint32_t chain_flags, void* stream,
                      bool dry_run, LaunchInfo* info);
 

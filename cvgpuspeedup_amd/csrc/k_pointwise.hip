@@ -7,6 +7,7 @@
 // does not cover (integer outputs, CV_64F) stay on k_generic.  SplitWrite<_2D> targets (separate pitched planes) are the
 // planar stores with one base and pitch per plane.  Used by K5/K6/K7 and by the
 // CircularTensor push of an un-resized frame (cfg #4).
+#include <memory>
 #include <type_traits>
 
 #include "k_pointwise_body.hpp"
@@ -22,6 +23,44 @@ __global__ __launch_bounds__(256) void k_pointwise4(const KernArgs<NPL> a, const
     else P = a.planes[z];
     asm volatile("" ::"s"(g.w), "s"(g.h), "s"(g.used), "s"(P.step));
     pw4_body<CN, Prog, OT, SD>(c, P, g, (int)blockIdx.x, (int)blockIdx.y, z);
+}
+
+// cvgs_execute_many on the pointwise shape (round 6): the planes of ALL chains in the kernel arguments, blockIdx.z = chain x max_batch + plane;
+// every chain writes its own tensor (the segment's), reads its own planes, shares the geometry, the program and its operands
+template <int CN, int CAP, class Prog, typename OT>
+__global__ __launch_bounds__(256) void k_pointwise4_many(const KernArgsManyInline<CAP> a, const PwGeom g, const uint32_t max_batch) {
+    const ChainArgs& c = a.c;
+    const uint32_t chain = blockIdx.z / max_batch, zl = blockIdx.z - chain * max_batch;
+    const ManySeg sg = a.seg[chain];
+    if ((int)zl >= sg.batch) return; // a shorter chain of the tick
+    const PlaneParams P = a.planes[(uint32_t)(uintptr_t)sg.table + (zl < (uint32_t)sg.used ? zl : 0u)];
+    PwGeom gl = g;
+    gl.out = sg.out;
+    gl.used = sg.used;
+    asm volatile("" ::"s"(gl.w), "s"(gl.h), "s"(gl.used), "s"(P.step));
+    pw4_body<CN, Prog, OT, CVGS_DEPTH_8U>(c, P, gl, (int)blockIdx.x, (int)blockIdx.y, (int)zl);
+}
+
+template <int CN, class Prog, typename OT>
+static hipError_t launch_pw_many(const ChainArgs& c, const PlaneParams* planes, int n_planes, const ManySeg* segs, int n_segs, int max_batch, const PwGeom& g,
+                                 hipStream_t s) {
+    const int px_per_wave_row = 256 >> g.narrow, rows_per_block = 4 << g.narrow;
+    const dim3 grid((g.w + px_per_wave_row - 1) / px_per_wave_row, (g.h + rows_per_block - 1) / rows_per_block, (unsigned)(n_segs * max_batch));
+    const uint32_t mb = (uint32_t)max_batch;
+    auto go = [&](auto cap_tag) {
+        constexpr int CAP = decltype(cap_tag)::value;
+        // the 16 KB / 52 KB argument block: staged in a per-thread heap buffer, handed over by address (as K1's: k_k1_impl.hpp launch_t)
+        static thread_local std::unique_ptr<KernArgsManyInline<CAP>> staged;
+        if (!staged) staged.reset(new KernArgsManyInline<CAP>());
+        KernArgsManyInline<CAP>& a = *staged;
+        a.c = c;
+        for (int i = 0; i < CVGS_MAX_CHAINS; ++i) a.seg[i] = i < n_segs ? segs[i] : ManySeg{nullptr, nullptr, 0, 0};
+        for (int i = 0; i < n_planes && i < CAP; ++i) a.planes[i] = planes[i];
+        void* args[] = {(void*)&a, (void*)&g, (void*)&mb};
+        return hipLaunchKernel((const void*)&k_pointwise4_many<CN, CAP, Prog, OT>, grid, dim3(256), args, 0, s);
+    };
+    const hipError_t e = n_planes <= kManyInlineSmall ? go(std::integral_constant<int, kManyInlineSmall>{}) : go(std::integral_constant<int, kManyInlineLarge>{});
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 template <int CN, class Prog, typename OT, int SD = CVGS_DEPTH_8U>
@@ -336,6 +375,38 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
         g.img_stride2 = w.img_stride2; g.ch_stride2 = w.ch_stride2;
     }
     return true;
+}
+
+int launch_pointwise_many(const ChainArgs& c_in, const PlaneParams* planes, int n_planes, const ManySeg* segs, int n_segs, int max_batch,
+                          uint32_t chain_flags, void* stream, bool dry_run) {
+    const ReadArgs& r = c_in.read;
+    const WriteArgs& w = c_in.write;
+    // the hot pointwise shape only: u8 planes read per pixel, an fp32 program, a dense fp32 target (planar tensor or packed pixels)
+    if (r.kind != CVGS_READ_PIXEL || r.depth != CVGS_DEPTH_8U || r.table || w.data2 || w.depth != CVGS_DEPTH_32F) return 0;
+    if (w.kind != CVGS_WRITE_TENSOR_SPLIT && w.kind != CVGS_WRITE_TENSOR_T_SPLIT && w.kind != CVGS_WRITE_PIXEL_3D) return 0;
+    if (n_segs < 2 || n_segs > CVGS_MAX_CHAINS || max_batch < 1 || (int64_t)n_segs * max_batch > 65535 || n_planes < 1 || n_planes > kManyInlineLarge) return 0;
+    ChainArgs c;
+    PwGeom g;
+    int prog_id = 0;
+    bool f16 = false;
+    if (!pointwise4_plan(c_in, 1, chain_flags, c, g, prog_id, f16, nullptr) || prog_id == 3 || f16 || g.packed == 2) return 0;
+    if (dry_run) return 1;
+    g.narrow = g.w <= 64 ? 2 : (g.w <= 128 ? 1 : 0);
+    hipStream_t s = (hipStream_t)stream;
+    auto by_prog = [&](auto cn_tag) {
+        constexpr int CN = decltype(cn_tag)::value;
+        if (prog_id == 0) return launch_pw_many<CN, ProgCastMulSubDiv, float>(c, planes, n_planes, segs, n_segs, max_batch, g, s);
+        if (prog_id == 1) return launch_pw_many<CN, ProgCast, float>(c, planes, n_planes, segs, n_segs, max_batch, g, s);
+        return launch_pw_many<CN, ArithProg<CN, CVGS_DEPTH_8U>, float>(c, planes, n_planes, segs, n_segs, max_batch, g, s);
+    };
+    hipError_t e;
+    switch (c.read.cn) {
+    case 1: e = by_prog(std::integral_constant<int, 1>{}); break;
+    case 2: e = by_prog(std::integral_constant<int, 2>{}); break;
+    case 3: e = by_prog(std::integral_constant<int, 3>{}); break;
+    default: e = by_prog(std::integral_constant<int, 4>{}); break;
+    }
+    return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 
 // Measured and NOT adopted (round 2): running C1 / C2 chains as C4 images of a quarter / half the width (4 / 2 x-adjacent

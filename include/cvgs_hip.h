@@ -296,7 +296,8 @@ int cvgs_execute(const cvgs_chain_desc* chain, cvgs_stream_t stream);
  * possible.  A 50-crop chain moves ~9 MB, about 1 us of HBM time behind a ~1.8 us launch/drain floor;
  * a serving loop with several cameras amortises that floor by submitting its frames together.  Chains whose read is
  * a bilinear resize of 8U/16U/16S/32F pixels, or of NV12 / NV21 surfaces or crops of them (host descriptors), into a planar
- * fp32 / fp16 tensor (the K1 / K4 shapes), and that agree in
+ * fp32 / fp16 tensor (the K1 / K4 shapes) -- or, since round 6, a per-pixel read of 8U planes of ONE size (host descriptors) through an fp32 program into a
+ * dense fp32 tensor / packed pixels (the reference's batched pointwise chains, tests/batchread/test_batchread_x_write3D.cu:92-96) --, and that agree in
  * everything except read.src / batch / used_planes and write.data / planes (same source type, target size,
  * aspect-ratio mode, background, YUV range / primaries / layout, pointwise stages and operands, write kind and type), are
  * fused into ONE launch of the K1 (or K4) kernel: grid z = chain, grid y = crop.  Results are bit-identical to n_chains separate cvgs_execute calls (same

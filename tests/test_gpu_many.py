@@ -552,3 +552,98 @@ def test_device_table_chains_are_checked_for_independence(oracle, device, lib):
         for m, (fr, crops) in enumerate(refs2):
             H.assert_bit_exact(outs2[m].cpu().numpy(), _oracle(oracle, fr, crops), "independent device-table chains (%s), chain %d" % (mode, m))
         assert _captured_kernel_nodes(lib, arr, 3, device) == want_nodes, mode
+
+
+# ---- round 6: ticks of POINTWISE chains (the reference's batched per-pixel chains, tests/batchread/test_batchread_x_write3D.cu:92-96) ------------------
+def _pointwise_tick(device, n_chains, batch, cn, size=(60, 120), kind="write3d", seed=2000, ragged=False, used=None, prog="norm"):
+    import torch
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    w, h = size
+    chains, outs, meta, keep = [], [], [], []
+    for m in range(n_chains):
+        b = batch if not ragged else max(1, batch - 3 * m)
+        frame = H.random_u8((400, 600, cn), seed=seed + m)
+        ft = torch.from_numpy(frame).to(device)
+        rects = [((7 * i + 3 * m) % (600 - w), (5 * i + m) % (400 - h), w, h) for i in range(b)]
+        out = torch.full((b, w * h * cn), -777.0, dtype=torch.float32, device=device)
+
+        def build(mat, o, rects=rects, b=b):
+            ops = [cvgs.ReadIOp(capi.READ_PIXEL, u, [mat.roi(*r) for r in rects], b if used is None else min(used, b))]
+            if prog == "norm":
+                ops += [cvgs.convertTo(u, f, 0.3), cvgs.subtract(f, H.K1_SUB[cn]), cvgs.divide(f, H.K1_DIV[cn])]
+            elif prog == "cast":
+                ops += [cvgs.convertTo(u, f)]
+            else:  # an interpreted arithmetic program
+                ops += [cvgs.convertTo(u, f), cvgs.add(f, [1.5, 2.5, 3.5, 4.5][:cn]), cvgs.multiply(f, [0.5] * cn)]
+            ops.append(cvgs.write(f, o, (w, h)) if kind == "write3d" else cvgs.split(f, o, (w, h)))
+            return ops
+        chains.append(build(cvgs.GpuMat.from_tensor(ft, u), cvgs.GpuMat.from_tensor(out, f if kind == "write3d" else cvgs.CV_32FC1)))
+        outs.append(out)
+        meta.append((frame, build, b))
+        keep.append(ft)
+    return chains, outs, meta, keep
+
+
+@pytest.mark.parametrize("cn,kind,prog,ragged,used", [(3, "write3d", "norm", False, None), (4, "write3d", "norm", True, None), (1, "split", "cast", False, None),
+                                                        (2, "write3d", "interp", True, None), (3, "split", "norm", False, 5), (4, "split", "interp", False, None)])
+def test_pointwise_chains_fuse_into_one_launch(oracle, device, lib, cn, kind, prog, ragged, used):
+    """16 batched per-pixel chains of one shape in ONE launch (k_pointwise4_many: the planes of all chains in the kernel arguments, grid z =
+    chain x max_batch + plane): bit-identical to one cvgs_execute per chain and to the oracle; ONE captured kernel node."""
+    import torch
+    chains, outs, meta, keep = _pointwise_tick(device, 16, 12, cn, kind=kind, prog=prog, ragged=ragged, used=used)
+    lowered = [cvgs.lower(ops) for ops in chains]
+    arr = cvgs.pack_chains(lowered)
+    torch.cuda.synchronize()
+    capi.check(lib.cvgs_execute_many(arr, len(lowered), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    many = [o.cpu().numpy() for o in outs]
+    for o in outs:
+        o.fill_(-777.0)
+    for ops in chains:
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    f = cvgs.make_type(cvgs.CV_32F, cn)
+    for m, (frame, build, b) in enumerate(meta):
+        H.assert_bit_exact(many[m], outs[m].cpu().numpy(), "pointwise tick vs separate launches, chain %d" % m)
+        ref = np.full((b, 60 * 120 * cn), -777.0, np.float32)
+        oracle.execute(cvgs.lower(build(cvgs.GpuMat.from_array(frame, cvgs.make_type(cvgs.CV_8U, cn)), cvgs.GpuMat.from_array(ref, f if kind == "write3d" else cvgs.CV_32FC1))))
+        H.assert_bit_exact(many[m], ref, "pointwise tick vs oracle, chain %d" % m)
+    assert _captured_kernel_nodes(lib, arr, len(lowered), device) == 1
+
+
+def test_pointwise_ticks_that_do_not_fuse_keep_their_meaning(oracle, device, lib):
+    """Chains of different plane sizes, and chains that alias (B reads what A writes), run one by one -- same results as separate calls."""
+    import torch
+    a_chains, a_outs, a_meta, keep_a = _pointwise_tick(device, 2, 6, 3, size=(60, 120), seed=2100)
+    b_chains, b_outs, b_meta, keep_b = _pointwise_tick(device, 1, 6, 3, size=(40, 80), seed=2200)
+    # (the write extents differ, so same_shape already says no; the call must still be right)
+    chains = a_chains + b_chains
+    outs = a_outs + b_outs
+    lowered = [cvgs.lower(ops) for ops in chains]
+    arr = cvgs.pack_chains(lowered)
+    torch.cuda.synchronize()
+    capi.check(lib.cvgs_execute_many(arr, 3, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy() for o in outs]
+    for o in outs:
+        o.fill_(-777.0)
+    for ops in chains:
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    for m in range(3):
+        H.assert_bit_exact(got[m], outs[m].cpu().numpy(), "mixed plane sizes, chain %d" % m)
+    assert _captured_kernel_nodes(lib, arr, 3, device) == 3
+    # two chains writing the SAME tensor: the later one's result stands
+    c2, o2, m2, k2 = _pointwise_tick(device, 2, 6, 3, seed=2300)
+    frame1, build1, b1 = m2[1]
+    ft1 = k2[1]
+    ops1 = build1(cvgs.GpuMat.from_tensor(ft1, cvgs.CV_8UC3), cvgs.GpuMat.from_tensor(o2[0], cvgs.CV_32FC3))
+    low = [cvgs.lower(c2[0]), cvgs.lower(ops1)]
+    arr2 = cvgs.pack_chains(low)
+    torch.cuda.synchronize()
+    capi.check(lib.cvgs_execute_many(arr2, 2, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref = np.full((b1, 60 * 120 * 3), -777.0, np.float32)
+    oracle.execute(cvgs.lower(build1(cvgs.GpuMat.from_array(frame1, cvgs.CV_8UC3), cvgs.GpuMat.from_array(ref, cvgs.CV_32FC3))))
+    H.assert_bit_exact(o2[0].cpu().numpy(), ref, "aliased pointwise chains: the later chain's result stands")
+    assert _captured_kernel_nodes(lib, arr2, 2, device) == 2

@@ -150,6 +150,53 @@ def batchread_write3d(depth, cn, batch=50):
     report("batchread_x_write3D %sC%d x%d crops" % (depth, cn, batch), make, b, W4K * H4K * cn * esz, flags=0)  # the facade does not forward executeOperations<false>
 
 
+def batchread_write3d_ticks(cn, batch=50, tick=16):
+    """the same 50-crop chain as a TICK: `tick` chains (own frames, own tensors) per cvgs_execute_many call = ONE k_pointwise4_many launch (round 6);
+    time per CHAIN"""
+    st, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    n_sets = 3
+    sets, keep, ops = [], [], None
+    for _ in range(n_sets):
+        low = []
+        for _ in range(tick):
+            frame = rand(H4K, W4K, cn, "8U")
+            m = cvgs.GpuMat.from_tensor(frame, st)
+            crops = [m.roi(i, i, 60, 120) for i in range(batch)]
+            out = torch.zeros((batch, 60 * 120, cn), dtype=torch.float32, device=dev)
+            ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, crops, batch), cvgs.convertTo(st, f, 0.3), cvgs.subtract(f, W.K1_SUB[cn]), cvgs.divide(f, W.K1_DIV[cn]),
+                   cvgs.write(f, cvgs.GpuMat.from_tensor(out, f), (60, 120))]
+            low.append(cvgs.lower(ops))
+            keep.append((frame, out))
+        sets.append((low, cvgs.pack_chains(low)))
+    side = torch.cuda.Stream()
+    reps = 8
+    for low, arr in sets:
+        capi.check(lib.cvgs_execute_many(arr, tick, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(reps):
+            for low, arr in sets:
+                capi.check(lib.cvgs_execute_many(arr, tick, torch.cuda.current_stream().cuda_stream))
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / (reps * n_sets * tick))
+    t = sorted(ts)[1]
+    b = batch * 60 * 120 * cn * 5
+    row = {"test": "batchread_x_write3D 8UC%d x%d crops, ticks of %d chains per launch (per chain)" % (cn, batch, tick), "kernel": "pointwise4_many_u8_cast_mul_sub_div",
+           "us": round(t * 1e6, 2), "GB_per_s": round(b / t / 1e9, 1), "frac_of_8TBs": round(b / t / 8e12, 4)}
+    ROWS.append(row)
+    if VERBOSE:
+        print(json.dumps(row), flush=True)
+
+
 def resize_write(depth, cn, dst):
     st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
     esz = torch.empty(0, dtype=TORCH[depth]).element_size()
@@ -206,6 +253,8 @@ def run_all(verbose=True):
         cvt_color(name, code, depth, icn, ocn)
     for depth, cn in (("8U", 3), ("8U", 4), ("16U", 3), ("16S", 1), ("32S", 2), ("32F", 3)):
         batchread_write3d(depth, cn)
+    for cn in (3, 4):
+        batchread_write3d_ticks(cn)
     for depth, cn in (("8U", 1), ("8U", 3), ("8U", 4), ("16U", 3), ("16S", 1), ("32F", 1)):
         resize_write(depth, cn, (3870, 2260))
         resize_write(depth, cn, (300, 500))

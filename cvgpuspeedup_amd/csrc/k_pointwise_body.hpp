@@ -300,15 +300,15 @@ __device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, c
         // cn floats per pixel, contiguous: 4 pixels = cn float4
         uint8_t* rows[2] = {g.out + (size_t)z * g.img_stride + (size_t)y * g.row_pitch,
                             g.out2 ? g.out2 + (size_t)z * g.img_stride2 + (size_t)y * g.row_pitch2 : nullptr};
+        constexpr int EPW = 256 * CN; // elements per wave
+        __shared__ __attribute__((aligned(16))) OT stage[4][EPW]; // wave-private quarters, wave-synchronous use (no workgroup barrier)
         if (sh == 0 && bx * 256 + 255 < W) { // wave-uniform: the whole 256-pixel group exists, every lane is alive
             // Each lane owns 4*CN consecutive output elements (48 / 64 bytes for fp32): stored directly, every 16-byte
             // store instruction would scatter the wave over a 3-4 KB span.  Transpose through LDS instead: lanes write
             // their elements, then lane l stores the wave's l-th, (64+l)-th, ... 16-byte chunk -> 1 KB contiguous per
             // instruction.  Wave-private LDS region, wave-synchronous (no workgroup barrier).
-            constexpr int EPW = 256 * CN;                  // elements per wave
             constexpr int EPC = 16 / (int)sizeof(OT);      // elements per 16-byte chunk
             constexpr int CHUNKS = EPW / EPC;
-            __shared__ __attribute__((aligned(16))) OT stage[4][EPW];
             OT* mine = &stage[wave][lane * 4 * CN];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -333,6 +333,39 @@ __device__ __forceinline__ void pw4_write(const ChainArgs& c, const PwGeom& g, c
                 }
             }
             return;
+        }
+        // NARROW planes (round 6; the reference's batched 60 x 120 crops: 16 lanes x 4 rows per wave): a lane's direct stores are 16 bytes at a
+        // stride of 16 * CN -- every store instruction touches every line of the wave's rows, CN times over (ticks of 16 x 50 such planes ran at
+        // 1.5 TB/s with 4 channels).  When the plane's rows are DENSE the wave's 2 / 4 rows are one contiguous span: the same LDS transpose, the
+        // span cut into 16-byte chunks that the wave's ALIVE lanes store in order (lanes past the row's end have left: chunk = round x alive + rank).
+        if constexpr (sizeof(OT) == 4) {
+            const int nrows = 1 << sh;
+            const int y0 = y - (lane >> (6 - sh)); // the wave's first row (wave-uniform)
+            const bool dense = sh > 0 && !rows[1] && g.row_pitch == W * CN * (int)sizeof(OT) && (W & 3) == 0 && y0 + nrows <= g.h &&
+                               ((nrows * W * CN * (int)sizeof(OT)) & 15) == 0;
+            if (dense) { // wave-uniform
+                OT* mine = &stage[wave][(((lane >> (6 - sh)) * W) + x0) * CN];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch)
+                        if (ch < CN) mine[i * CN + ch] = cvt_out<OT>(px[i].v[ch]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+                typedef u32x4n u32x4n_a4 __attribute__((aligned(4)));
+                const uint64_t alive = __builtin_amdgcn_ballot_w64(true);
+                const int n_alive = (int)__builtin_popcountll(alive);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
+                const int chunks = nrows * W * CN * (int)sizeof(OT) / 16;
+                uint8_t* const span = g.out + (size_t)z * g.img_stride + (size_t)y0 * g.row_pitch;
+                for (int cidx = rank; cidx < chunks; cidx += n_alive) {
+                    const u32x4n q = *(const u32x4n*)((const uint8_t*)&stage[wave][0] + (size_t)cidx * 16);
+                    __builtin_nontemporal_store(q, (u32x4n_a4*)(span + (size_t)cidx * 16));
+                }
+                return;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {

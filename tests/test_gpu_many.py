@@ -611,6 +611,34 @@ def test_pointwise_chains_fuse_into_one_launch(oracle, device, lib, cn, kind, pr
     assert _captured_kernel_nodes(lib, arr, len(lowered), device) == 1
 
 
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+@pytest.mark.parametrize("size", [(4, 4), (8, 3), (12, 5), (16, 7), (32, 9), (60, 17), (64, 6), (62, 9), (68, 5), (100, 3), (124, 2), (128, 7), (132, 5)])
+def test_narrow_dense_planes_of_every_width(oracle, device, lib, cn, size):
+    """Planes at most 64 / 128 pixels wide put 4 / 2 rows on a wave; with dense rows (the tensor of cvGS::write / fk::TensorWrite) the wave's rows leave
+    as ONE span of 16-byte chunks through LDS (k_pointwise_body.hpp, round 6).  Widths around both limits, heights that are not a multiple of the
+    rows per wave (the last wave stores directly), a width that is not a multiple of 4: as a tick AND one by one, against the oracle."""
+    import torch
+    w, h = size
+    chains, outs, meta, keep = _pointwise_tick(device, 3, 7, cn, size=size, seed=2400 + w, ragged=True)
+    lowered = [cvgs.lower(ops) for ops in chains]
+    arr = cvgs.pack_chains(lowered)
+    torch.cuda.synchronize()
+    capi.check(lib.cvgs_execute_many(arr, len(lowered), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    many = [o.cpu().numpy() for o in outs]
+    for o in outs:
+        o.fill_(-777.0)
+    for ops in chains:
+        cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    f = cvgs.make_type(cvgs.CV_32F, cn)
+    for m, (frame, build, b) in enumerate(meta):
+        ref = np.full((b, w * h * cn), -777.0, np.float32)
+        oracle.execute(cvgs.lower(build(cvgs.GpuMat.from_array(frame, cvgs.make_type(cvgs.CV_8U, cn)), cvgs.GpuMat.from_array(ref, f))))
+        H.assert_bit_exact(outs[m].cpu().numpy(), ref, "narrow plane %dx%d C%d one by one, chain %d" % (w, h, cn, m))
+        H.assert_bit_exact(many[m], ref, "narrow plane %dx%d C%d as a tick, chain %d" % (w, h, cn, m))
+
+
 def test_pointwise_ticks_that_do_not_fuse_keep_their_meaning(oracle, device, lib):
     """Chains of different plane sizes, and chains that alias (B reads what A writes), run one by one -- same results as separate calls."""
     import torch

@@ -166,7 +166,11 @@ template <int EB>
 __device__ __forceinline__ Win<EB> load_win(gptr_u8 p) {
     Win<EB> w;
     if constexpr (EB == 1) {
+#if defined(CVGS_K1_LDSCOPE) && CVGS_K1_LDSCOPE // probe (tools/probes/build_ablate.sh): sc0 / sc1 / sc0 sc1 on the tap loads -- does the L2 then fetch less than 128-byte lines?
+        w.lo = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, CVGS_K1_LDSCOPE == 1 ? __HIP_MEMORY_SCOPE_WORKGROUP : (CVGS_K1_LDSCOPE == 2 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM));
+#else
         w.lo = *(gptr_u64)p; // plain, cached: neighbouring lanes and rows share lines (non-temporal loads measured 8 % slower at 16 x 50 crops, 24 % at 3200)
+#endif
     } else {
         const u32x4 v = *(gptr_u32x4)p;
         w.lo = ((uint64_t)v.y << 32) | v.x;

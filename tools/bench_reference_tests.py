@@ -197,19 +197,29 @@ def batchread_write3d_ticks(cn, batch=50, tick=16):
         print(json.dumps(row), flush=True)
 
 
-def resize_write(depth, cn, dst):
+def resize_write(depth, cn, dst, pitched=False):
+    """pitched: the output's rows start on 512-byte boundaries, as cv::cuda::GpuMat / fk::Ptr2D allocate them (cudaMallocPitch) -- what the reference's own
+    test writes into; the default (dense rows: 3870 * 3 bytes is not even a multiple of 4) is the harder case."""
     st, f = cvgs.make_type(DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
     esz = torch.empty(0, dtype=TORCH[depth]).element_size()
 
     def make():
-        src, out = rand(H4K, W4K, cn, depth), torch.zeros((dst[1], dst[0], cn), dtype=TORCH[depth], device=dev)
+        src = rand(H4K, W4K, cn, depth)
+        if pitched:
+            step = (dst[0] * cn * esz + 511) // 512 * 512
+            out = torch.zeros((dst[1], step), dtype=torch.uint8, device=dev)
+            omat = cvgs.GpuMat(dst[1], dst[0], st, out.data_ptr(), step, owner=out)
+        else:
+            out = torch.zeros((dst[1], dst[0], cn), dtype=TORCH[depth], device=dev)
+            omat = cvgs.GpuMat.from_tensor(out, st)
         ops = [cvgs.resize(st, cvgs.INTER_LINEAR, cvgs.GpuMat.from_tensor(src, st), dst)]
         if depth != "32F":
             ops.append(cvgs.convertTo(f, st))
-        return ops + [cvgs.write(st, cvgs.GpuMat.from_tensor(out, st))], (src, out)
+        return ops + [cvgs.write(st, omat)], (src, out)
     tapped = min(W4K, 2 * dst[0]) * min(H4K, 2 * dst[1])  # distinct source pixels a stretch can tap (upper bound)
     b = (tapped + dst[0] * dst[1]) * cn * esz
-    report("resize_write %sC%d 4K -> %dx%d" % (depth, cn, dst[0], dst[1]), make, b, W4K * H4K * cn * esz + dst[0] * dst[1] * cn * esz)
+    report("resize_write %sC%d 4K -> %dx%d%s" % (depth, cn, dst[0], dst[1], " (512-byte pitched output rows)" if pitched else ""), make, b,
+           W4K * H4K * cn * esz + dst[0] * dst[1] * cn * esz)
 
 
 def resize_x_split(depth, cn):
@@ -258,6 +268,8 @@ def run_all(verbose=True):
     for depth, cn in (("8U", 1), ("8U", 3), ("8U", 4), ("16U", 3), ("16S", 1), ("32F", 1)):
         resize_write(depth, cn, (3870, 2260))
         resize_write(depth, cn, (300, 500))
+    for depth, cn in (("8U", 1), ("8U", 3), ("8U", 4)):
+        resize_write(depth, cn, (3870, 2260), pitched=True)
     for depth, cn in (("8U", 3), ("8U", 4), ("16U", 3), ("16S", 4)):
         resize_x_split(depth, cn)
     warp()

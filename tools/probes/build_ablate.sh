@@ -17,7 +17,7 @@ K1=k_k1_c3.hip
 K4=k_nv12_x2.hip
 X4=k_k1_x4.hip
 # the default set is what tools/profile_r06_final.sh measures; other shapes on request, e.g.
-#   VARIANTS="zfast:$K1:-DCVGS_K1_ABLATE=8 sc1:$K1:-DCVGS_K1_STORE=2 wpb4:$K1:-DCVGS_K1_WPB=4 xcdwl:$K1:-DCVGS_K1_ABLATE=32 k4_rows4w4:$K4:-DCVGS_K4_ROWS=4,-DCVGS_K4_WAVES=4 x4_now16:$X4:-DCVGS_X4_NO_W16=1"
+#   VARIANTS="zfast:$K1:-DCVGS_K1_ABLATE=8 sc1:$K1:-DCVGS_K1_STORE=2 wpb4:$K1:-DCVGS_K1_WPB=4 xcdwl:$K1:-DCVGS_K1_ABLATE=32 k4_rows4w4:$K4:-DCVGS_K4_ROWS=4,-DCVGS_K4_WAVES=4 x4_now16:$X4:-DCVGS_X4_NO_W16=1 ldsys:$K1:-DCVGS_K1_LDSCOPE=3"
 VARIANTS=${VARIANTS:-"full:$K1:-DCVGS_K1_ABLATE=0 ldst:$K1:-DCVGS_K1_ABLATE=2 ld:$K1:-DCVGS_K1_ABLATE=6 st:$K1:-DCVGS_K1_ABLATE=3 desc:$K1:-DCVGS_K1_ABLATE=16 \
 k4_full:$K4:-DCVGS_K4_ABLATE=0 k4_ldst:$K4:-DCVGS_K4_ABLATE=2 k4_ld:$K4:-DCVGS_K4_ABLATE=6 k4_st:$K4:-DCVGS_K4_ABLATE=3 k4_math:$K4:-DCVGS_K4_ABLATE=5 k4_empty:$K4:-DCVGS_K4_ABLATE=16 \
 x4_full:$X4:-DCVGS_X4_ABLATE=0 x4_ldst:$X4:-DCVGS_X4_ABLATE=2 x4_ld:$X4:-DCVGS_X4_ABLATE=6 x4_st:$X4:-DCVGS_X4_ABLATE=3 x4_math:$X4:-DCVGS_X4_ABLATE=5"}

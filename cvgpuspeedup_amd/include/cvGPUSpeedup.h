@@ -280,22 +280,6 @@ inline fk::WarpingParameters<fk::WarpType::Perspective> warp_getWarpingPerspecti
 }
 // the batch spellings (include/cvGPUSpeedup.cuh:311-377): FORWARD transforms in, the device's (inverted, float) parameters out; entries at
 // and beyond usedPlanes stay value-initialised
-template <size_t BATCH>
-inline auto warp_batchAffineParameters_helper_rt(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize, const size_t& idx) {
-    return warp_parameters<fk::WarpType::Affine>(transform_matrices[idx], dstSize[idx]);
-}
-template <size_t Idx, size_t BATCH>
-inline auto warp_batchAffineParameters_helper(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize) {
-    return warp_batchAffineParameters_helper_rt(transform_matrices, dstSize, Idx);
-}
-template <size_t BATCH>
-inline auto warp_batchPerspectiveParameters_helper_rt(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize, const size_t& idx) {
-    return warp_parameters<fk::WarpType::Perspective>(transform_matrices[idx], dstSize[idx]);
-}
-template <size_t Idx, size_t BATCH>
-inline auto warp_batchPerspectiveParameters_helper(const std::array<cv::Mat, BATCH>& transform_matrices, const std::array<cv::Size, BATCH>& dstSize) {
-    return warp_batchPerspectiveParameters_helper_rt(transform_matrices, dstSize, Idx);
-}
 template <fk::WarpType WT, size_t BATCH>
 inline std::array<fk::WarpingParameters<WT>, BATCH> warp_batchParameters(const std::array<cv::Mat, BATCH>& transform_matrices,
                                                                          const std::array<cv::Size, BATCH>& dstSize, const int& usedPlanes = BATCH) {

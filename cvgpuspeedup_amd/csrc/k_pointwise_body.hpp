@@ -97,7 +97,7 @@ struct PwGeom {
     int32_t packed;    // 1: packed pixels (PIXEL_2D / PIXEL_3D), 0: planar tensor, 2: separate pitched planes (SPLIT_2D)
     int32_t row_pitch; // packed: bytes between output rows
     int32_t row_pitch2;
-    int32_t narrow;    // log2(rows per wave): 0 = a wave is 64 lanes x 4 pixels of ONE row; 1 / 2 = 32 / 16 lanes per row, 2 / 4 rows per
+    int32_t narrow;    // log2(rows per wave): 0 = a wave is 64 lanes x 4 pixels of ONE row (-1: and of the row 4 below, pw4_body_rows2); 1 / 2 = 32 / 16 lanes per row, 2 / 4 rows per
                        // wave, for planes at most 128 / 64 pixels wide (a 60-pixel crop would leave 49 of 64 lanes idle)
     int64_t img_stride, ch_stride, img_stride2, ch_stride2; // planar: elements; packed: img_stride in BYTES
     uint8_t* out;
@@ -141,6 +141,50 @@ __device__ __forceinline__ Px4 px4_of(const Px (&px)[4]) {
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) q.p[i].v[ch] = px[i].v[ch];
     return q;
+}
+
+// ---- the read stage of a per-pixel source: 4 pixels = 4*CN elements = NDW dwords, one wide load ----
+template <int CN, int SD> struct PwRaw { uint32_t w[CN * src_elem_bytes<SD>]; };
+template <int CN, int SD>
+__device__ __forceinline__ void pw4_load(PwRaw<CN, SD>& raw, const PlaneParams& P, int x0, int y, int npx, bool live) {
+    constexpr int EB = src_elem_bytes<SD>;
+    constexpr int NDW = CN * EB;
+    if (live) {
+        const gp_u8 row = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * CN * EB;
+        if (npx == 4) {
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) raw.w[k] = *(gp_u32)(row + 4 * k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) raw.w[k] = 0;
+#pragma unroll
+            for (int b = 0; b < 4 * CN * EB; ++b)
+                if (b < npx * CN * EB) raw.w[b >> 2] |= (uint32_t)row[b] << (8 * (b & 3));
+        }
+    }
+}
+// ---- the rest of the thread's work on those 4 pixels: source elements -> work pixels, the program, the write stage ----
+template <int CN, class Prog, typename OT, int SD>
+__device__ __forceinline__ void pw4_finish(const ChainArgs& c, const PwGeom& g, const PwRaw<CN, SD>& raw, int bx, int x0, int y, int z, int npx, int wave,
+                                           int lane, int sh) {
+    const int used = g.used;
+    Px px[4];
+    int depth = SD, cn = CN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < CN) {
+                // default-value planes carry the background in the source type (CV_32S: as an integer)
+                const float bgv = SD == CVGS_DEPTH_32S ? from_int((int)c.read.bg[ch]) : c.read.bg[ch];
+                px[i].v[ch] = z < used ? elem_value<SD>(raw.w, i * CN + ch) : bgv;
+            } else {
+                px[i].v[ch] = 0.f;
+            }
+        }
+    }
+    Prog::run4(c.prog, px, depth, cn);
+    pw4_write<CN, OT>(c, g, px4_of(px), cn, bx, x0, y, z, npx, wave, lane, sh);
 }
 
 // One thread's work: pixels x0..x0+3 of row y of plane z.  (bx, by) = the 256-pixel column group and the 4-row group.
@@ -236,40 +280,28 @@ __device__ __forceinline__ void pw4_body(const ChainArgs& c, const PlaneParams& 
         pw4_write<CN, OT>(c, g, px4_of(px), cn, bx, x0, y, z, npx, wave, lane, sh);
         return;
     }
-    // ---- read 4 pixels: 4*CN elements = NDW dwords, one wide load ----
-    constexpr int EB = src_elem_bytes<SD>;
-    constexpr int NDW = CN * EB;
-    uint32_t raw[NDW];
-    if (z < used) {
-        const gp_u8 row = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * CN * EB;
-        if (npx == 4) {
-#pragma unroll
-            for (int k = 0; k < NDW; ++k) raw[k] = *(gp_u32)(row + 4 * k);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NDW; ++k) raw[k] = 0;
-#pragma unroll
-            for (int b = 0; b < 4 * CN * EB; ++b)
-                if (b < npx * CN * EB) raw[b >> 2] |= (uint32_t)row[b] << (8 * (b & 3));
-        }
-    }
-    Px px[4];
-    int depth = SD, cn = CN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            if (ch < CN) {
-                // default-value planes carry the background in the source type (CV_32S: as an integer)
-                const float bgv = SD == CVGS_DEPTH_32S ? from_int((int)c.read.bg[ch]) : c.read.bg[ch];
-                px[i].v[ch] = z < used ? elem_value<SD>(raw, i * CN + ch) : bgv;
-            } else {
-                px[i].v[ch] = 0.f;
-            }
-        }
-    }
-    Prog::run4(c.prog, px, depth, cn);
-    pw4_write<CN, OT>(c, g, px4_of(px), cn, bx, x0, y, z, npx, wave, lane, sh);
+    PwRaw<CN, SD> raw;
+    pw4_load<CN, SD>(raw, P, x0, y, npx, z < used);
+    pw4_finish<CN, Prog, OT, SD>(c, g, raw, bx, x0, y, z, npx, wave, lane, sh);
+}
+
+// Two rows per thread (round 6; whole ONE-CHANNEL frames: g.narrow == -1, launch_pw): rows y and y + 4 of an 8-row block, both rows' loads in flight
+// before either is converted and stored (a one-channel thread moves 20 bytes per row).
+template <int CN, class Prog, typename OT, int SD>
+__device__ __forceinline__ void pw4_body_rows2(const ChainArgs& c, const PlaneParams& P, const PwGeom& g, int bx, int by, int z) {
+    static_assert(!is_yuv_sd<SD>, "per-pixel reads only");
+    const int W = g.w, H = g.h, used = g.used;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int x0 = (bx * 64 + lane) * 4;
+    const int ya = by * 8 + wave, yb = ya + 4; // wave-uniform
+    if (ya >= H || x0 >= W) return;
+    const int npx = min(4, W - x0);
+    PwRaw<CN, SD> ra, rb;
+    pw4_load<CN, SD>(ra, P, x0, ya, npx, z < used);
+    if (yb < H) pw4_load<CN, SD>(rb, P, x0, yb, npx, z < used);
+    pw4_finish<CN, Prog, OT, SD>(c, g, ra, bx, x0, ya, z, npx, wave, lane, 0);
+    if (yb < H) pw4_finish<CN, Prog, OT, SD>(c, g, rb, bx, x0, yb, z, npx, wave, lane, 0);
 }
 
 // ---- the write stage of pw4_body: 4 pixels of row y, plane z ----

@@ -357,6 +357,29 @@ def test_thread_fused_pointwise_other_depths(depth, cn, out, w):
     assert cvgs.kernel_name(*chain) == "pointwise4_%s" % want
 
 
+@pytest.mark.parametrize("depth", ["8U", "8S", "16U", "16S", "32S", "32F"])
+@pytest.mark.parametrize("size,n,used", [((1283, 821), 1, 1), ((1024, 1031), 1, 1), ((700, 509), 3, 2)])
+def test_one_channel_whole_frames_two_rows_per_thread(depth, size, n, used):
+    """Launches of >= 1 Mpixel of ONE-channel planes put two rows (y, y + 4 of an 8-row block) on a thread (k_pointwise_body.hpp: pw4_body_rows2):
+    heights that leave a partial 8-row block with and without its lower rows, a ragged last pixel group, pitched views, a default-value plane;
+    packed and planar targets, vs the oracle and vs the interpreted kernel."""
+    w, h = size
+    srcs = [_random_src((h + 2, w + 5, 1), depth, 3100 + i) for i in range(n)]
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], 1), cvgs.CV_32FC1
+
+    def build(wrap, wrap_out, out_buf):
+        mats = [wrap(s, st).roi(2, 1, w, h) for s in srcs]
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, mats, used, None, cvgs.IGNORE_AR, [9.0])]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(st, f))
+        return ops + [cvgs.multiply(f, [0.3]), cvgs.subtract(f, H.K1_SUB[1]), cvgs.divide(f, H.K1_DIV[1]), cvgs.write(f, wrap_out(out_buf, f), (w, h))]
+
+    gpu, ref = _both(build, (n, w * h), np.float32)
+    H.assert_bit_exact(gpu[0], ref[0], "one-channel whole frame %sC1 %dx%d x%d" % (depth, w, h, n))
+    gen, _ = _both(build, (n, w * h), np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gpu[0], gen[0], "fused vs interpreted")
+
+
 U8_CODES = [("BGR2RGB", 3, 3), ("RGBA2BGRA", 4, 4), ("BGR2BGRA", 3, 4), ("RGB2BGRA", 3, 4), ("BGRA2BGR", 4, 3), ("RGBA2BGR", 4, 3),
             ("BGR2GRAY", 3, 1), ("RGB2GRAY", 3, 1), ("BGRA2GRAY", 4, 1), ("RGBA2GRAY", 4, 1)]
 

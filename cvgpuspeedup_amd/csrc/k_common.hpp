@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
+#include <cstring>
+
 #include "cvgs_device.h"
 
 namespace cvgs {
@@ -254,6 +257,70 @@ struct InterpProg {
     }
 };
 
+// Division by a WAVE-UNIFORM divisor d with r = RN(1/d) from the host: q0 = x*r and two FMA correction steps give RN(x/d) bit for bit
+// (Markstein) when d's significand is not all ones and no intermediate leaves the normal range -- guaranteed by bounds on the
+// operands (launch_k1: k1_fast_div_ok) and by construction for x: everything finite and far from the exponent range's
+// ends; x == 0 is excluded by the caller (the sign of a zero quotient needs the real
+// division).  tests/test_fast_division.py checks the identity against IEEE division for EVERY divisor significand.
+__device__ __forceinline__ float div_by_uniform(float x, float d, float r) {
+    const float q0 = x * r;
+    const float e0 = __builtin_fmaf(-d, q0, x);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-d, q1, x);
+    return __builtin_fmaf(e1, r, q1);
+}
+
+// The DIV stage of a pointwise program on a thread's four pixels, RUN-TIME GUARDED (round 6): prog.fast_div == 2 + k says the host found stage
+// k's divisors fit (k_taps.hpp: guarded_div_setup) and left their reciprocals in prog.rdiv.  The dividends are checked here: the largest and
+// the smallest magnitude of the thread's values as integers (NaN and infinity compare above every finite float, zero below every normal one),
+// one ballot over the wave -- inside [2^-90, 2^38] the five-instruction form is the IEEE quotient, otherwise the wave divides for real.
+// An IEEE fp32 division costs ~10 instructions + a quarter-rate reciprocal per value; the reference's test_read_x_write chain on a 4K u8c3 frame
+// spent 8 of its 23 us dividing.
+__device__ __forceinline__ bool div4_guarded(const ProgArgs& prog, int k, Px (&px)[4], int cn) {
+    if (prog.fast_div != 2 + k) return false; // wave-uniform
+    uint32_t mx = 0u, mn = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < cn) {
+                const uint32_t u = __float_as_uint(px[i].v[c]) & 0x7fffffffu;
+                mx = u > mx ? u : mx;
+                mn = u < mn ? u : mn;
+            }
+    const bool outside = mn < 0x12800000u || mx > 0x52800000u; // 2^-90, 2^38
+    if (__builtin_amdgcn_ballot_w64(outside) != 0) return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < cn) px[i].v[c] = div_by_uniform(px[i].v[c], prog.operand[k][c], prog.rdiv[c]);
+    return true;
+}
+
+// HOST side of the RUN-TIME GUARDED division of the pointwise programs (k_common.hpp: div4_guarded): the first DIV stage whose divisors qualify
+// (finite, 2^-20 <= |d| <= 2^20, significand not all ones) gets its correctly rounded reciprocals and p.fast_div = 2 + its index.  Nothing is
+// assumed about the dividends: the kernel checks them (every value of the wave inside [2^-90, 2^38], which also says "finite" and "not zero")
+// and takes the real division otherwise -- the range tests/test_fast_division.py sweeps.
+inline void guarded_div_setup(ProgArgs& p, int cn) {
+    p.fast_div = 0;
+    for (int k = 0; k < p.n; ++k) {
+        if (p.opcode[k] != CVGS_OP_DIV) continue;
+        for (int c = 0; c < cn; ++c) {
+            const float d = p.operand[k][c], a = std::fabs(d);
+            uint32_t bits;
+            std::memcpy(&bits, &d, 4);
+            if (!std::isfinite(d) || !(a >= std::ldexp(1.0f, -20) && a <= std::ldexp(1.0f, 20)) || (bits & 0x7fffffu) == 0x7fffffu) return;
+        }
+        for (int c = 0; c < 4; ++c) {
+            volatile float r = c < cn ? 1.0f / p.operand[k][c] : 0.0f; // IEEE single division on the host: the correctly rounded reciprocal
+            p.rdiv[c] = r;
+        }
+        p.fast_div = 2 + k;
+        return;
+    }
+}
+
 // Compile-time program: the opcode list is a template pack (operands stay run-time), so the chain
 // is straight-line code the compiler can schedule against the loads and stores.
 template <int... OPS>
@@ -262,13 +329,22 @@ struct StaticProg {
         int k = 0;
         ((apply_op(OPS, prog.aux[k], prog.operand[k], p, depth, cn), ++k), ...);
     }
+    // four pixels, stage by stage (the stages are per-pixel: the same operations on the same values as pixel by pixel)
     static __device__ __forceinline__ void run4(const ProgArgs& prog, Px (&px)[4], int& depth, int& cn) {
+        [[maybe_unused]] int k = 0;
+        ((step4<OPS>(prog, k, px, depth, cn), ++k), ...);
+    }
+    template <int OP>
+    static __device__ __forceinline__ void step4(const ProgArgs& prog, int k, Px (&px)[4], int& depth, int& cn) {
+        if constexpr (OP == CVGS_OP_DIV) {
+            if (depth == CVGS_DEPTH_32F && div4_guarded(prog, k, px, cn)) return;
+        }
         int d = depth, c = cn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             d = depth;
             c = cn;
-            run(prog, px[i], d, c);
+            apply_op(OP, prog.aux[k], prog.operand[k], px[i], d, c);
         }
         depth = d;
         cn = c;

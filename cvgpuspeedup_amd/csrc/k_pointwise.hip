@@ -365,6 +365,7 @@ bool pointwise4_plan(const ChainArgs& c_in, int n_inline, uint32_t chain_flags, 
     else if (starts_with_cast && p.n == 4 && p.opcode[1] == CVGS_OP_MUL && p.opcode[2] == CVGS_OP_SUB && p.opcode[3] == CVGS_OP_DIV) prog_id = 0;
     else if (starts_with_cast && p.n == 1) prog_id = 1;
 
+    guarded_div_setup(c.prog, scn); // the first DIV stage with fitting divisors divides by reciprocal, checked per wave (k_common.hpp: div4_guarded)
     g.w = r.dst_w; g.h = r.dst_h; g.used = r.used; g.cn = scn;
     g.packed = packed ? 1 : (split2d ? 2 : 0);
     g.out = w.data; g.out2 = w.data2; g.narrow = 0;

@@ -71,6 +71,7 @@ struct ArithProg {
 #pragma unroll
                     for (int ch = 0; ch < CN; ++ch) px[i].v[ch] = px[i].v[ch] - o[ch];
             } else if (op == CVGS_OP_DIV) {
+                if (div4_guarded(prog, k, px, CN)) continue; // (k_common.hpp: the divisors fit and every dividend of the wave does)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -149,6 +150,14 @@ template <int CN, int SD>
 __device__ __forceinline__ void pw4_load(PwRaw<CN, SD>& raw, const PlaneParams& P, int x0, int y, int npx, bool live) {
     constexpr int EB = src_elem_bytes<SD>;
     constexpr int NDW = CN * EB;
+#ifndef CVGS_PW_ABLATE
+#define CVGS_PW_ABLATE 0
+#endif
+    if constexpr ((CVGS_PW_ABLATE & 1) != 0) {
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) raw.w[k] = (uint32_t)(x0 + y + k);
+        return;
+    }
     if (live) {
         const gp_u8 row = (gp_u8)P.data + (size_t)y * (size_t)P.step + (size_t)x0 * CN * EB;
         if (npx == 4) {
@@ -184,6 +193,9 @@ __device__ __forceinline__ void pw4_finish(const ChainArgs& c, const PwGeom& g, 
         }
     }
     Prog::run4(c.prog, px, depth, cn);
+    if constexpr ((CVGS_PW_ABLATE & 4) != 0) {
+        if (!(px[0].v[0] == 1234.5f && px[3].v[0] == 77.25f)) return;
+    }
     pw4_write<CN, OT>(c, g, px4_of(px), cn, bx, x0, y, z, npx, wave, lane, sh);
 }
 

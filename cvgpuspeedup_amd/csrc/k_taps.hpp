@@ -26,13 +26,7 @@ constexpr int kOpSwapRB = 100;
 // operands (launch_k1: k1_fast_div_ok) and by construction for x: everything finite and far from the exponent range's
 // ends, d's significand not all ones; x == 0 is excluded by the caller (the sign of a zero quotient needs the real
 // division).  tests/test_fast_division.py checks the identity against IEEE division for EVERY divisor significand.
-__device__ __forceinline__ float div_by_uniform(float x, float d, float r) {
-    const float q0 = x * r;
-    const float e0 = __builtin_fmaf(-d, q0, x);
-    const float q1 = __builtin_fmaf(e0, r, q0);
-    const float e1 = __builtin_fmaf(-d, q1, x);
-    return __builtin_fmaf(e1, r, q1);
-}
+// (div_by_uniform itself lives in k_common.hpp: the pointwise programs use it too)
 
 // HOST side of div_by_uniform: can the DIV stage of a [swap] MUL SUB DIV program use it?  Integer-valued sources only
 // (8U / 16U / 16S pixels, NV12 bytes through the YCbCr matrix): the interpolated value v is finite and bounded

@@ -125,6 +125,58 @@ def test_pointwise_chain_random(depth, cn):
     H.assert_bit_exact(gpu[0], ref[0], "pointwise %sC%d" % (depth, cn))
 
 
+GUARDED_DIV_CASES = {
+    # name: (multiplier before the division, subtrahend, divisors) -- what the thread-fused kernels' run-time guarded division (k_common.hpp:
+    # div4_guarded) must get right: dividends inside the guarded range, zeros (black pixels: +0 and -0), dividends below 2^-90 / above 2^38,
+    # overflow to infinity, NaN (inf * 0, inf - inf), divisors the host must refuse (significand all ones, outside [2^-20, 2^20]), negative ones
+    "plain": ([0.3, 0.3, 0.3, 0.3], [1.0, 4.0, 3.2, 0.5], [3.2, 0.6, 11.8, 33.0]),
+    "zeros_plus": ([1.0, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0], [3.2, 0.6, 11.8, 33.0]),
+    "zeros_minus": ([-1.0, -1.0, -1.0, -1.0], [0.0, 0.0, 0.0, 0.0], [3.2, -0.6, 11.8, -33.0]),
+    "tiny": ([1e-29, 3e-30, 1e-28, 1e-30], [0.0, 0.0, 0.0, 0.0], [3.2, 0.6, 11.8, 33.0]),
+    "huge": ([1e10, 3e11, 1e9, 1e12], [0.0, 0.0, 0.0, 0.0], [3.2, 0.6, 11.8, 33.0]),
+    "overflow": ([3e38, 3e38, 3e38, 3e38], [0.0, 0.0, 0.0, 0.0], [0.5, 0.6, 0.8, 0.25]),
+    "inf_minus_inf": ([3e38, 3e38, 3e38, 3e38], [float("inf")] * 4, [3.2, 0.6, 11.8, 33.0]),
+    "all_ones_divisor": ([0.3, 0.3, 0.3, 0.3], [1.0, 4.0, 3.2, 0.5], [float(np.float32(2.0) - np.float32(2.0 ** -23)), 0.6, 11.8, 33.0]),
+    "divisor_out_of_range": ([0.3, 0.3, 0.3, 0.3], [1.0, 4.0, 3.2, 0.5], [3.2, 2.0 ** 24, 11.8, 33.0]),
+    "negative_divisors": ([0.3, -0.3, 0.3, -0.3], [1.0, 4.0, 3.2, 0.5], [-3.2, 0.6, -11.8, 33.0]),
+    "power_of_two_divisors": ([0.3, 0.3, 0.3, 0.3], [1.0, 4.0, 3.2, 0.5], [2.0, 0.5, 1024.0, 2.0 ** -20]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(GUARDED_DIV_CASES))
+@pytest.mark.parametrize("depth,cn,interpreted", [("8U", 3, False), ("8U", 4, True), ("8U", 1, True), ("16S", 3, True), ("16U", 2, False), ("32F", 3, True)])
+def test_run_time_guarded_division(depth, cn, interpreted, case):
+    """The pointwise programs divide by reciprocal + two FMA corrections when the host finds the divisors fit AND every dividend of the WAVE is
+    inside [2^-90, 2^38] (else the wave divides for real): a frame whose upper part is non-zero pixels and whose lower part holds zeros, so some
+    waves take each side; compile-time program (cast, mul, sub, div) and interpreted one (cast, mul, sub, div, add); vs the oracle's IEEE division
+    and vs the interpreted per-pixel kernel."""
+    mul, sub, div = GUARDED_DIV_CASES[case]
+    w, h = 517, 23
+    src = _random_src((h, w, cn), depth, 4000 + cn)
+    flat = src.reshape(h, w * cn)
+    if depth != "32F":
+        flat[: h // 2] |= 1  # the upper rows: no zero anywhere
+        flat[h // 2 + 2:, 100 * cn:300 * cn] = 0  # a black block further down
+    else:
+        flat[h // 2 + 2:, 100 * cn:300 * cn] = np.array([0.0, -0.0, np.inf, 1e-40], np.float32)[np.arange(200 * cn) % 4]
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+
+    def build(wrap, wrap_out, out_buf):
+        ops = [cvgs.ReadIOp(capi.READ_PIXEL, st, [wrap(src, st)], 1)]
+        if depth != "32F":
+            ops.append(cvgs.convertTo(st, f))
+        ops += [cvgs.multiply(f, mul[:cn]), cvgs.subtract(f, sub[:cn]), cvgs.divide(f, div[:cn])]
+        if interpreted:
+            ops.append(cvgs.add(f, [0.25] * cn))
+        return ops + [cvgs.write(f, wrap_out(out_buf, f))]
+
+    with np.errstate(all="ignore"):
+        gpu, ref = _both(build, (h, w, cn), np.float32)
+        gen, _ = _both(build, (h, w, cn), np.float32, flags=capi.CHAIN_FORCE_GENERIC)
+    H.assert_bit_exact(gpu[0], ref[0], "guarded division %s, %sC%d" % (case, depth, cn))
+    H.assert_bit_exact(gpu[0], gen[0], "fused vs interpreted per-pixel kernel")
+
+
 @pytest.mark.parametrize("dst_depth", ["8U", "8S", "16U", "16S", "32S"])
 def test_saturate_cast_rounding(dst_depth):
     """fk::SaturateCast float -> integer: nearest-even, clamped, NaN -> 0; via convertTo(alpha, beta)."""

@@ -276,8 +276,8 @@ __device__ __forceinline__ float div_by_uniform(float x, float d, float r) {
 // one ballot over the wave -- inside [2^-90, 2^38] the five-instruction form is the IEEE quotient, otherwise the wave divides for real.
 // An IEEE fp32 division costs ~10 instructions + a quarter-rate reciprocal per value; the reference's test_read_x_write chain on a 4K u8c3 frame
 // spent 8 of its 23 us dividing.
-__device__ __forceinline__ bool div4_guarded(const ProgArgs& prog, int k, Px (&px)[4], int cn) {
-    if (prog.fast_div != 2 + k) return false; // wave-uniform
+__device__ __forceinline__ bool div4_guarded(bool stage_fits, const float (&d)[4], const float (&r)[4], Px (&px)[4], int cn) {
+    if (!stage_fits) return false; // wave-uniform
     uint32_t mx = 0u, mn = 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -294,8 +294,13 @@ __device__ __forceinline__ bool div4_guarded(const ProgArgs& prog, int k, Px (&p
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (c < cn) px[i].v[c] = div_by_uniform(px[i].v[c], prog.operand[k][c], prog.rdiv[c]);
+            if (c < cn) px[i].v[c] = div_by_uniform(px[i].v[c], d[c], r[c]);
     return true;
+}
+__device__ __forceinline__ bool div4_guarded(const ProgArgs& prog, int k, Px (&px)[4], int cn) {
+    const float d[4] = {prog.operand[k][0], prog.operand[k][1], prog.operand[k][2], prog.operand[k][3]};
+    const float r[4] = {prog.rdiv[0], prog.rdiv[1], prog.rdiv[2], prog.rdiv[3]};
+    return div4_guarded(prog.fast_div == 2 + k, d, r, px, cn);
 }
 
 // HOST side of the RUN-TIME GUARDED division of the pointwise programs (k_common.hpp: div4_guarded): the first DIV stage whose divisors qualify

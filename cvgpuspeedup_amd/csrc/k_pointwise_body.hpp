@@ -51,10 +51,44 @@ using ProgCast = StaticProg<CVGS_OP_CAST>;
 // frame: 45 -> 21 us).
 template <int CN, int SD>
 struct ArithProg {
+    // The first kUnrolled stages are unrolled AND their opcodes, operands and the division's reciprocals are read before the first stage: scalar
+    // loads at fixed kernel-argument offsets, requested together, one wait.  A loop over k fetched each stage's opcode and operands when it got
+    // there -- one scalar-memory round trip per stage and wave (a one-channel thread has 4 values to spend it on: 4K 8UC1 -> 32FC1 ran 8 of its
+    // 12 us with its loads and stores removed).
+    static constexpr int kUnrolled = 6;
     static __device__ __forceinline__ void run4(const ProgArgs& prog, Px (&px)[4], int& depth, int& cn) {
-        for (int k = 0; k < prog.n; ++k) {
-            const int op = prog.opcode[k]; // wave-uniform
-            const float o[4] = {prog.operand[k][0], prog.operand[k][1], prog.operand[k][2], prog.operand[k][3]};
+        int op[kUnrolled], aux[kUnrolled];
+        float o[kUnrolled][4];
+        const int n = prog.n, fast_div = prog.fast_div;
+        float r[4] = {prog.rdiv[0], prog.rdiv[1], prog.rdiv[2], prog.rdiv[3]};
+#pragma unroll
+        for (int k = 0; k < kUnrolled; ++k) {
+            op[k] = prog.opcode[k];
+            aux[k] = prog.aux[k];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) o[k][ch] = ch < CN ? prog.operand[k][ch] : 0.f;
+        }
+        // (the values are pinned in scalar registers HERE: left alone, the compiler sinks each load into the stage that uses it)
+#pragma unroll
+        for (int k = 0; k < kUnrolled; ++k) {
+            asm volatile("" : "+s"(op[k]), "+s"(aux[k]));
+#pragma unroll
+            for (int ch = 0; ch < CN; ++ch) asm volatile("" : "+s"(o[k][ch]));
+        }
+#pragma unroll
+        for (int ch = 0; ch < CN; ++ch) asm volatile("" : "+s"(r[ch]));
+#pragma unroll
+        for (int k = 0; k < kUnrolled; ++k)
+            if (k < n) stage4(op[k], aux[k], o[k], fast_div == 2 + k, r, px);
+        for (int k = kUnrolled; k < n; ++k) {
+            const float ok[4] = {prog.operand[k][0], prog.operand[k][1], prog.operand[k][2], prog.operand[k][3]};
+            stage4(prog.opcode[k], prog.aux[k], ok, fast_div == 2 + k, r, px);
+        }
+        depth = CVGS_DEPTH_32F;
+        cn = CN;
+    }
+    static __device__ __forceinline__ void stage4(const int op, const int aux, const float (&o)[4], const bool div_fits, const float (&r)[4], Px (&px)[4]) {
+        {
             if (op == CVGS_OP_MUL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -71,7 +105,7 @@ struct ArithProg {
 #pragma unroll
                     for (int ch = 0; ch < CN; ++ch) px[i].v[ch] = px[i].v[ch] - o[ch];
             } else if (op == CVGS_OP_DIV) {
-                if (div4_guarded(prog, k, px, CN)) continue; // (k_common.hpp: the divisors fit and every dividend of the wave does)
+                if (div4_guarded(div_fits, o, r, px, CN)) return; // (k_common.hpp: the divisors fit and every dividend of the wave does)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -85,11 +119,9 @@ struct ArithProg {
                 }
             } else { // CVGS_OP_REORDER
 #pragma unroll
-                for (int i = 0; i < 4; ++i) reorder_px(px[i], prog.aux[k], CN);
+                for (int i = 0; i < 4; ++i) reorder_px(px[i], aux, CN);
             }
         }
-        depth = CVGS_DEPTH_32F;
-        cn = CN;
     }
 };
 

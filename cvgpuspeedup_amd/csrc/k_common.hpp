@@ -236,27 +236,6 @@ struct InterpProgInt {
     }
 };
 
-// Interpreted program: any valid op list whose arithmetic meets float values.
-struct InterpProg {
-    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
-        for (int k = 0; k < prog.n; ++k) apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], p, depth, cn);
-    }
-    // four pixels at once: the opcode loop stays outermost so the pixel array is only indexed by constants
-    static __device__ __forceinline__ void run4(const ProgArgs& prog, Px (&px)[4], int& depth, int& cn) {
-        for (int k = 0; k < prog.n; ++k) {
-            int d = depth, c = cn;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d = depth;
-                c = cn;
-                apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], px[i], d, c);
-            }
-            depth = d;
-            cn = c;
-        }
-    }
-};
-
 // Division by a WAVE-UNIFORM divisor d with r = RN(1/d) from the host: q0 = x*r and two FMA correction steps give RN(x/d) bit for bit
 // (Markstein) when d's significand is not all ones and no intermediate leaves the normal range -- guaranteed by bounds on the
 // operands (launch_k1: k1_fast_div_ok) and by construction for x: everything finite and far from the exponent range's
@@ -303,13 +282,158 @@ __device__ __forceinline__ bool div4_guarded(const ProgArgs& prog, int k, Px (&p
     return div4_guarded(prog.fast_div == 2 + k, d, r, px, cn);
 }
 
+// The DIV stage on ONE pixel (the one-pixel-per-lane kernels: K1 / K4 / warp with an interpreted program), guarded like div4_guarded.
+__device__ __forceinline__ bool div1_guarded(bool stage_fits, const float (&d)[4], const float (&r)[4], Px& p, int cn) {
+    if (!stage_fits) return false; // wave-uniform
+    uint32_t mx = 0u, mn = 0xffffffffu;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < cn) {
+            const uint32_t u = __float_as_uint(p.v[c]) & 0x7fffffffu;
+            mx = u > mx ? u : mx;
+            mn = u < mn ? u : mn;
+        }
+    const bool outside = mn < 0x12800000u || mx > 0x52800000u; // 2^-90, 2^38
+    if (__builtin_amdgcn_ballot_w64(outside) != 0) return false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < cn) p.v[c] = div_by_uniform(p.v[c], d[c], r[c]);
+    return true;
+}
+
+// Interpreted program: any valid op list whose arithmetic meets float values.
+// Round 6: programs made of MUL / ADD / SUB / DIV / REORDER stages on CV_32F values only (the host says so: prog.fast_div & 0x100,
+// interp_arith_setup) -- every resize chain that normalises in another order or with one more stage than the compile-time programs -- take
+// run_arith: the opcodes, aux words and operands of the first kUnrolled stages are fetched BEFORE the first stage (scalar loads at fixed
+// kernel-argument offsets, one wait; the rolled loop pays a scalar-memory round trip per stage and wave: + ~5 us per stage on a K1 tick of 16 x 50
+// crops, 60 us against the compile-time program's 39 for one more `add`), the stages are a few instructions each, and the DIV stage the host vetted
+// divides by reciprocal when every dividend of the wave fits (div1_guarded).  Everything else keeps the rolled loop over the full stage switch
+// (inlining that switch six times into ~300 kernels would add 18 MB of code).  ARITH = false: the rolled loop only.
+template <bool ARITH>
+struct InterpProgT {
+    static constexpr int kUnrolled = 6;
+    // MUL, ADD and SUB are ONE fused multiply-add with scalar-selected operands -- p * o = fma(p, o, -0), p + o = fma(p, 1, o), p - o = fma(p, 1, -o),
+    // each the same single rounding as the plain operation (adding -0 changes no value and no zero's sign) -- so the common stages cost one compare
+    // and one branch instead of a compare-and-branch chain per opcode (a wave pays ~20 cycles per taken branch; five stages of four tests each
+    // were most of the 18 us a K1 tick lost to its interpreted program).
+    static __device__ __forceinline__ void arith_stage(int op, int aux, const float (&o)[4], bool div_fits, const float (&r)[4], Px& p, int cn) {
+        if (op == CVGS_OP_MUL || op == CVGS_OP_ADD || op == CVGS_OP_SUB) { // wave-uniform
+            const bool mul = op == CVGS_OP_MUL, sub = op == CVGS_OP_SUB;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { // (channels at and beyond cn hold nothing anybody stores)
+                const float m = mul ? o[c] : 1.0f;
+                const float a = mul ? -0.0f : (sub ? -o[c] : o[c]);
+                p.v[c] = __builtin_fmaf(p.v[c], m, a);
+            }
+        } else if (op == CVGS_OP_DIV) {
+            if (div1_guarded(div_fits, o, r, p, cn)) return;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < cn) p.v[c] = p.v[c] / o[c];
+        } else { // CVGS_OP_REORDER
+            reorder_px(p, aux, cn);
+        }
+    }
+    // The arithmetic path's scalar state: requested by the kernel BEFORE its tap loads (prefetch: plain loads), pinned in registers AFTER they are
+    // issued (settle) -- the program's words arrive in the shadow of the taps instead of after them.
+    struct State {
+        int op[ARITH ? kUnrolled : 1], aux[ARITH ? kUnrolled : 1];
+        float o[ARITH ? kUnrolled : 1][4];
+        float r[4];
+        int n, div_at;
+        bool arith;
+    };
+    static __device__ __forceinline__ State prefetch(const ProgArgs& prog) {
+        State st;
+        st.arith = false;
+        if constexpr (ARITH) {
+            st.arith = (prog.fast_div & 0x100) != 0;
+            st.n = prog.n;
+            st.div_at = (prog.fast_div & 0xff) - 2;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) st.r[ch] = prog.rdiv[ch];
+#pragma unroll
+            for (int k = 0; k < kUnrolled; ++k) {
+                st.op[k] = prog.opcode[k];
+                st.aux[k] = prog.aux[k];
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) st.o[k][ch] = prog.operand[k][ch];
+            }
+        }
+        return st;
+    }
+    static __device__ __forceinline__ void settle(State& st) {
+        if constexpr (ARITH) {
+            // (pinned in scalar registers HERE: left alone, the compiler sinks each load into the stage that uses it)
+#pragma unroll
+            for (int k = 0; k < kUnrolled; ++k) {
+                asm volatile("" : "+s"(st.op[k]), "+s"(st.aux[k]));
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) asm volatile("" : "+s"(st.o[k][ch]));
+            }
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) asm volatile("" : "+s"(st.r[ch]));
+        }
+    }
+    static __device__ __forceinline__ void run_arith(const ProgArgs& prog, const State& st, Px& p, int cn) {
+        if constexpr (ARITH) {
+#pragma unroll
+            for (int k = 0; k < kUnrolled; ++k)
+                if (k < st.n) arith_stage(st.op[k], st.aux[k], st.o[k], st.div_at == k, st.r, p, cn);
+            for (int k = kUnrolled; k < st.n; ++k) {
+                const float ok[4] = {prog.operand[k][0], prog.operand[k][1], prog.operand[k][2], prog.operand[k][3]};
+                arith_stage(prog.opcode[k], prog.aux[k], ok, st.div_at == k, st.r, p, cn);
+            }
+        }
+    }
+    static __device__ __forceinline__ void run(const ProgArgs& prog, const State& st, Px& p, int& depth, int& cn) {
+        if constexpr (ARITH) {
+            if (st.arith && depth == CVGS_DEPTH_32F) { // wave-uniform
+                run_arith(prog, st, p, cn);
+                return;
+            }
+        }
+        for (int k = 0; k < prog.n; ++k) apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], p, depth, cn);
+    }
+    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
+        for (int k = 0; k < prog.n; ++k) apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], p, depth, cn);
+    }
+    // four pixels at once: the opcode loop stays outermost so the pixel array is only indexed by constants
+    static __device__ __forceinline__ void run4(const ProgArgs& prog, Px (&px)[4], int& depth, int& cn) {
+        for (int k = 0; k < prog.n; ++k) {
+            int d = depth, c = cn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d = depth;
+                c = cn;
+                apply_op(prog.opcode[k], prog.aux[k], prog.operand[k], px[i], d, c);
+            }
+            depth = d;
+            cn = c;
+        }
+    }
+};
+using InterpProg = InterpProgT<false>;      // the rolled loop only (K4, warps, the CircularTensor push, K1's packed / 4-rows-per-wave modes)
+using InterpProgArith = InterpProgT<true>;  // + run_arith (K1's planar-tensor kernels: ~36 more scalar registers, which the others do not have)
+
 // HOST side of the RUN-TIME GUARDED division of the pointwise programs (k_common.hpp: div4_guarded): the first DIV stage whose divisors qualify
 // (finite, 2^-20 <= |d| <= 2^20, significand not all ones) gets its correctly rounded reciprocals and p.fast_div = 2 + its index.  Nothing is
 // assumed about the dividends: the kernel checks them (every value of the wave inside [2^-90, 2^38], which also says "finite" and "not zero")
 // and takes the real division otherwise -- the range tests/test_fast_division.py sweeps.
+inline void guarded_div_setup(ProgArgs& p, int cn);
+// HOST side of InterpProg::run_arith: an arithmetic-only program (MUL / ADD / SUB / DIV / REORDER: the value stays CV_32F with cn channels)
+inline void interp_arith_setup(ProgArgs& p, int cn) {
+    guarded_div_setup(p, cn);
+    for (int k = 0; k < p.n; ++k)
+        if (p.opcode[k] != CVGS_OP_MUL && p.opcode[k] != CVGS_OP_ADD && p.opcode[k] != CVGS_OP_SUB && p.opcode[k] != CVGS_OP_DIV && p.opcode[k] != CVGS_OP_REORDER) return;
+    p.fast_div |= 0x100;
+}
 inline void guarded_div_setup(ProgArgs& p, int cn) {
     p.fast_div = 0;
     for (int k = 0; k < p.n; ++k) {
+        if (p.opcode[k] == CVGS_OP_ADD_ALPHA) cn = 4; // (the interpreted one-pixel kernels: the channel count the DIV stage meets)
+        else if (p.opcode[k] == CVGS_OP_DROP_ALPHA) cn = 3;
+        else if (p.opcode[k] == CVGS_OP_GRAY) cn = 1;
         if (p.opcode[k] != CVGS_OP_DIV) continue;
         for (int c = 0; c < cn; ++c) {
             const float d = p.operand[k][c], a = std::fabs(d);
@@ -330,6 +454,10 @@ inline void guarded_div_setup(ProgArgs& p, int cn) {
 // is straight-line code the compiler can schedule against the loads and stores.
 template <int... OPS>
 struct StaticProg {
+    struct State {};
+    static __device__ __forceinline__ State prefetch(const ProgArgs&) { return {}; }
+    static __device__ __forceinline__ void settle(State&) {}
+    static __device__ __forceinline__ void run(const ProgArgs& prog, const State&, Px& p, int& depth, int& cn) { run(prog, p, depth, cn); }
     static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
         int k = 0;
         ((apply_op(OPS, prog.aux[k], prog.operand[k], p, depth, cn), ++k), ...);

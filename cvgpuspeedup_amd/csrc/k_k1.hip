@@ -107,6 +107,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     const bool table = r.table != nullptr;
     const int prog_id = k1_classify_program(c.prog, r.cn);
     if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
+    if (prog_id == 2) interp_arith_setup(c_mut.prog, r.cn); // interpreted: arithmetic-only programs take InterpProg::run_arith (k_common.hpp)
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
     // whole-frame resize -> cast -> packed pixels of the SOURCE's type with nothing in between (the reference's

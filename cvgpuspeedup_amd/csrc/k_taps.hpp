@@ -61,6 +61,10 @@ inline void fast_div_setup(ProgArgs& p, int div_at, int mul_at, int cn, const fl
 
 template <int... OPS>
 struct K1Prog {
+    struct State {};
+    static __device__ __forceinline__ State prefetch(const ProgArgs&) { return {}; }
+    static __device__ __forceinline__ void settle(State&) {}
+    static __device__ __forceinline__ void run(const ProgArgs& prog, const State&, Px& p, int& depth, int& cn) { run(prog, p, depth, cn); }
     static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
         [[maybe_unused]] int k = 0;
         ((step<OPS>(prog, k, p, depth, cn), ++k), ...);

@@ -4,7 +4,7 @@ test_batchresize_aspectratio_x_split3D.cu, but on NON-constant images (the refer
 import numpy as np
 import pytest
 
-from cvgpuspeedup_amd import cvgs
+from cvgpuspeedup_amd import capi, cvgs
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -268,3 +268,61 @@ def test_k1_division_paths_match_the_oracle(oracle, name, mul, sub, div, swap):
     H.assert_bit_exact(out.cpu().numpy(), ref, name)
     if "zero" in name:
         assert (ref.view(np.uint32) == 0x80000000).any(), "the case must really produce negative zeros"
+
+
+# ---- round 6: K1's interpreted ARITHMETIC programs (k_common.hpp: InterpProgT<true>::run_arith) ---------------------------------------------------
+def _arith_programs(f, cn):
+    sw = cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f) if cn == 3 else None
+    k = lambda v: list(v)[:cn]  # noqa: E731
+    progs = {
+        "norm_then_add": [sw, cvgs.multiply(f, k([0.3] * 4)), cvgs.subtract(f, k([1.0, 4.0, 3.2, 0.5])), cvgs.divide(f, k([3.2, 0.6, 11.8, 33.0])), cvgs.add(f, k([0.5, 0.25, 0.125, 1.0]))],
+        "sub_div_only": [cvgs.subtract(f, k([127.5] * 4)), cvgs.divide(f, k([58.4, 57.1, 57.4, 60.0]))],
+        "div_first": [cvgs.divide(f, k([255.0] * 4)), cvgs.subtract(f, k([0.485, 0.456, 0.406, 0.5])), cvgs.divide(f, k([0.229, 0.224, 0.225, 0.25]))],  # two DIVs: one guarded, one real
+        "eight_stages": [cvgs.add(f, k([1.0] * 4)), cvgs.multiply(f, k([0.5, 0.25, 2.0, 3.0])), sw, cvgs.subtract(f, k([0.1, 0.2, 0.3, 0.4])), cvgs.divide(f, k([3.0, 7.0, 9.0, 11.0])),
+                         cvgs.add(f, k([5.0] * 4)), cvgs.multiply(f, k([-1.0, 1.0, -1.0, 1.0])), cvgs.subtract(f, k([2.0] * 4))],  # more than the unrolled stages
+        "zeros_through_div": [cvgs.multiply(f, k([0.0, -0.0, 1.0, 0.0])), cvgs.divide(f, k([3.2, 0.6, 11.8, 33.0])), cvgs.add(f, k([1.0] * 4))],  # +0 / -0 dividends: the wave divides for real
+        "tiny_and_huge": [cvgs.multiply(f, k([1e-30, 1e12, 3e38, 1.0])), cvgs.divide(f, k([3.2, 0.6, 0.5, 33.0])), cvgs.subtract(f, k([1.0] * 4))],
+        "refused_divisor": [cvgs.multiply(f, k([0.3] * 4)), cvgs.divide(f, k([float(np.float32(2.0) - np.float32(2.0 ** -23)), 2.0 ** 24, 11.8, 33.0]))],
+        "minus_zero_products": [cvgs.subtract(f, k([5.0] * 4)), cvgs.multiply(f, k([-0.0, 0.0, -0.0, 0.0])), cvgs.add(f, k([-0.0] * 4))],  # p * o with zero products: the fma form keeps their signs
+    }
+    return {n: [s for s in p if s is not None] for n, p in progs.items()}
+
+
+@pytest.mark.parametrize("name", ["norm_then_add", "sub_div_only", "div_first", "eight_stages", "zeros_through_div", "tiny_and_huge", "refused_divisor", "minus_zero_products"])
+@pytest.mark.parametrize("cn,ar,half", [(3, cvgs.IGNORE_AR, False), (4, cvgs.IGNORE_AR, False), (3, cvgs.PRESERVE_AR, False), (3, cvgs.IGNORE_AR, True)])
+def test_interpreted_arithmetic_programs(oracle, device, name, cn, ar, half):
+    """Resize chains whose program is NOT [swap,] mul, sub, div run K1's interpreted kernel; programs of MUL / ADD / SUB / DIV / REORDER stages take its
+    arithmetic path: the program's words fetched before the taps, MUL / ADD / SUB as one fma with selected operands (bit-identical to the plain operation,
+    zero signs included), the vetted DIV stage by reciprocal when every dividend of the wave fits.  Against the oracle AND the forced generic kernel;
+    aspect-ratio padding pushes the background value through the same program; the fp16 tensor takes the cast in the store."""
+    import torch
+    fh, fw = 240, 320
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    frame = H.random_u8((fh, fw, cn), seed=7100 + cn)
+    frame[40:80, 60:200] = 0  # a black block: zero dividends for some waves only
+    crops = H.random_crops(7, fw, fh, seed=7200 + cn, wmin=3, wmax=250, hmin=3, hmax=200)
+    prog = _arith_programs(f, cn)[name]
+    ot, od = (torch.float16, np.float16) if half else (torch.float32, np.float32)
+    o1 = cvgs.CV_16FC1 if half else cvgs.CV_32FC1
+
+    def build(src_mat, out_mat):
+        ops = [cvgs.resize(u, cvgs.INTER_LINEAR, [src_mat.roi(*c) for c in crops], (64, 128), 6, [10.0, 20.0, 30.0, 40.0][:cn], ar)] + list(prog)
+        if half:
+            ops.append(cvgs.convertTo(f, cvgs.make_type(cvgs.CV_16F, cn)))
+        return ops + [cvgs.split(cvgs.make_type(cvgs.CV_16F, cn) if half else f, out_mat, (64, 128))]
+
+    ft = torch.from_numpy(frame).to(device)
+    out = torch.full((7, cn * 128 * 64), -777.0, dtype=ot, device=device)
+    ref = np.full((7, cn * 128 * 64), -777.0, dtype=od)
+    ops = build(cvgs.GpuMat.from_tensor(ft, u), cvgs.GpuMat.from_tensor(out, o1))
+    assert cvgs.kernel_name(*ops).endswith("_interp" + ("_f16" if half else "")), cvgs.kernel_name(*ops)
+    with np.errstate(all="ignore"):
+        oracle.execute(cvgs.lower(build(cvgs.GpuMat.from_array(frame, u), cvgs.GpuMat.from_array(ref, o1))))
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    H.assert_bit_exact(got, ref, "K1 interpreted arithmetic program %s C%d" % (name, cn))
+    out.fill_(-777.0)
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(got, out.cpu().numpy(), "K1 interpreted vs the generic kernel")

@@ -107,7 +107,17 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     const bool table = r.table != nullptr;
     const int prog_id = k1_classify_program(c.prog, r.cn);
     if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
-    if (prog_id == 2) interp_arith_setup(c_mut.prog, r.cn); // interpreted: arithmetic-only programs take InterpProg::run_arith (k_common.hpp)
+    // u8 C3 / C4 into a planar tensor: a chain of the canonical arithmetic shape ([swap] {mul|add|sub} x 0..2 [div] {mul|add|sub} x 0..2) is rewritten
+    // into the straight-line K1CanonProg (k_taps.hpp); other programs run interpreted (arithmetic-only ones: InterpProgT<true>::run_arith, k_common.hpp)
+    int planar_prog = prog_id;
+    if (prog_id == 2 && planar && !few && r.depth == CVGS_DEPTH_8U && mirrors.n == 0) {
+        ProgArgs canon;
+        if (k1_canonicalise(c_mut.prog, r.cn, canon)) {
+            c_mut.prog = canon;
+            planar_prog = 3;
+        }
+    }
+    if (prog_id == 2 && planar_prog == 2) interp_arith_setup(c_mut.prog, r.cn);
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
     // whole-frame resize -> cast -> packed pixels of the SOURCE's type with nothing in between (the reference's
@@ -157,6 +167,7 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         if (same_type_packed) info->kernel = names_same[src][r.cn - 1];
         else if (planes_16) info->kernel = names_planes16[src == SRC_S16][r.cn == 4];
         else if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : names_few_packed[r.cn - 1][u8out];
+        else if (planar && planar_prog == 3) info->kernel = f16 ? (r.cn == 4 ? "k1_u8c4_arith_f16" : "k1_u8c3_arith_f16") : (r.cn == 4 ? "k1_u8c4_arith" : "k1_u8c3_arith");
         else if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
         else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
     }
@@ -198,9 +209,9 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         else e = r.cn == 3 ? launch_other_np<3, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s)
                            : launch_other_np<4, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s);
     } else if (r.cn == 3) {
-        e = k1_launch_planar_c3(src, f16, prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
+        e = k1_launch_planar_c3(src, f16, planar_prog, table, rpw, c, inline_planes, n_inline, out_cn, s);
     } else {
-        e = k1_launch_planar_c4(src, f16, prog_id, table, rpw, c, inline_planes, n_inline, out_cn, s);
+        e = k1_launch_planar_c4(src, f16, planar_prog, table, rpw, c, inline_planes, n_inline, out_cn, s);
     }
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }

@@ -645,9 +645,19 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
             }
         }
     }
+    // any other chain of the canonical arithmetic shape ([swap] {mul|add|sub} x 0..2 [div] {mul|add|sub} x 0..2): the straight-line K1CanonProg
+    // (k_taps.hpp; round 6 -- a tick of 16 surfaces x 50 crops with one more `add` ran 58 us interpreted against 37 for the compile-time program)
+    bool canon_prog = false;
+    if (!fast_prog && !(fast_rgb && !f16) && planar) {
+        ProgArgs canon;
+        if (k1_canonicalise(c_fd.prog, r.out_cn, canon)) {
+            c_fd.prog = canon;
+            canon_prog = true;
+        }
+    }
     if (info)
-        info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : "k4_nv12_resize_interp_f16")
-                           : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : (fast_rgb ? "k4_nv12_resize_mul_sub_div" : "k4_nv12_resize_interp"));
+        info->kernel = f16 ? (fast_prog ? "k4_nv12_resize_swap_mul_sub_div_f16" : (canon_prog ? "k4_nv12_resize_arith_f16" : "k4_nv12_resize_interp_f16"))
+                           : (fast_prog ? "k4_nv12_resize_swap_mul_sub_div" : (fast_rgb ? "k4_nv12_resize_mul_sub_div" : (canon_prog ? "k4_nv12_resize_arith" : "k4_nv12_resize_interp")));
     if (dry_run) return 1;
     const N12Many s{&ctx, segs, n_segs, segs && !r.table ? inline_planes : nullptr, segs && !r.table ? n_inline : 0};
     // the windowed instantiations: an aspect-ratio window or default-value planes (never for fused chains / staged tables, whose
@@ -655,9 +665,11 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     const bool win = !segs && (r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h));
     hipError_t e;
     if (f16) e = fast_prog ? launch_n12<N12SwapMulSubDiv, _Float16>(c_fd, inline_planes, n_inline, g, s, win)
-                           : launch_n12<InterpProg, _Float16>(c_fd, inline_planes, n_inline, g, s, win);
-    else e = fast_prog ? launch_n12<N12SwapMulSubDiv>(c_fd, inline_planes, n_inline, g, s, win)
-                       : (fast_rgb ? launch_n12<ProgMulSubDiv>(c_fd, inline_planes, n_inline, g, s, win) : launch_n12<InterpProg>(c_fd, inline_planes, n_inline, g, s, win));
+                           : (canon_prog ? launch_n12<K1CanonProg, _Float16>(c_fd, inline_planes, n_inline, g, s, win)
+                                         : launch_n12<InterpProg, _Float16>(c_fd, inline_planes, n_inline, g, s, win));
+    else if (fast_prog) e = launch_n12<N12SwapMulSubDiv>(c_fd, inline_planes, n_inline, g, s, win);
+    else if (fast_rgb) e = launch_n12<ProgMulSubDiv>(c_fd, inline_planes, n_inline, g, s, win);
+    else e = canon_prog ? launch_n12<K1CanonProg>(c_fd, inline_planes, n_inline, g, s, win) : launch_n12<InterpProg>(c_fd, inline_planes, n_inline, g, s, win);
     return e == hipSuccess ? 1 : -(int)e - 1000;
 }
 

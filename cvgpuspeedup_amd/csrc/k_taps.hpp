@@ -102,6 +102,105 @@ using ProgMulSubDiv = K1Prog<CVGS_OP_MUL, CVGS_OP_SUB, CVGS_OP_DIV>;
 // constants, so the whole-frame kernels carry no interpreter at all.
 using ProgNone = K1Prog<>;
 
+// ---- the CANONICAL arithmetic program (round 6): [swap R,B] -> two fma stages -> [DIV] -> two fma stages, straight-line --------------------------
+// Every chain of the shape  [cvtColor(R<->B)]  {mul | add | sub} x 0..2  [div]  {mul | add | sub} x 0..2  -- "subtract the mean, divide by the
+// deviation", "scale and shift", "divide by 255", one more stage behind the reference's normalisation ... -- is rewritten ON THE HOST
+// (k1_canonicalise) into this fixed pipeline: a MUL / ADD / SUB stage is ONE fma with the operands (o, -0) / (1, o) / (1, -o) -- the same single
+// rounding as the plain operation, zero signs included -- and a missing stage is the identity (1, -0).  Nothing is decoded at run time: the
+// interpreted kernel's tick of 16 x 50 crops cost 60 us (51 with its arithmetic path) for such a chain against 39 for the reference's own.
+//   prog.aux[0] = swap R,B first; prog.aux[1] = a DIV stage sits between the two fma pairs (divisors in operand[8], reciprocals in rdiv when
+//   prog.fast_div says the divisors fit: then the dividends are checked per wave, k_common.hpp div1_guarded);
+//   fma stage s (0..3): multipliers operand[s], addends operand[4 + s].
+struct K1CanonProg {
+    struct State {};
+    static __device__ __forceinline__ State prefetch(const ProgArgs&) { return {}; }
+    static __device__ __forceinline__ void settle(State&) {}
+    static __device__ __forceinline__ void run(const ProgArgs& prog, const State&, Px& p, int& depth, int& cn) { run(prog, p, depth, cn); }
+    static __device__ __forceinline__ void fma_stage(const ProgArgs& prog, int s, Px& p) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p.v[c] = __builtin_fmaf(p.v[c], prog.operand[s][c], prog.operand[4 + s][c]); // (channels at and beyond cn hold nothing anybody stores)
+    }
+    static __device__ __forceinline__ void run(const ProgArgs& prog, Px& p, int& depth, int& cn) {
+        if (prog.aux[0]) { // wave-uniform
+            const float t = p.v[0];
+            p.v[0] = p.v[2];
+            p.v[2] = t;
+        }
+        fma_stage(prog, 0, p);
+        fma_stage(prog, 1, p);
+        if (prog.aux[1]) { // wave-uniform
+            const float d[4] = {prog.operand[8][0], prog.operand[8][1], prog.operand[8][2], prog.operand[8][3]};
+            const float r[4] = {prog.rdiv[0], prog.rdiv[1], prog.rdiv[2], prog.rdiv[3]};
+            if (!div1_guarded(prog.fast_div != 0, d, r, p, cn)) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < cn) p.v[c] = p.v[c] / d[c];
+            }
+        }
+        fma_stage(prog, 2, p);
+        fma_stage(prog, 3, p);
+    }
+};
+// HOST: rewrite `in` into the canonical pipeline if it has that shape (false: it does not)
+inline bool k1_canonicalise(const ProgArgs& in, int cn, ProgArgs& out) {
+    const int swap = cn == 3 ? (2 | (1 << 2) | (0 << 4)) : (2 | (1 << 2) | (0 << 4) | (3 << 6));
+    int k = 0;
+    bool has_swap = false;
+    if (cn >= 3 && k < in.n && in.opcode[k] == CVGS_OP_REORDER && in.aux[k] == swap) {
+        has_swap = true;
+        ++k;
+    }
+    auto is_lin = [](int op) { return op == CVGS_OP_MUL || op == CVGS_OP_ADD || op == CVGS_OP_SUB; };
+    int lin[4] = {-1, -1, -1, -1}, div_at = -1;
+    for (int s = 0; s < 2 && k < in.n && is_lin(in.opcode[k]); ++s) lin[s] = k++;
+    if (k < in.n && in.opcode[k] == CVGS_OP_DIV) div_at = k++;
+    for (int s = 2; s < 4 && k < in.n && is_lin(in.opcode[k]); ++s) lin[s] = k++;
+    if (k != in.n) return false;
+    out = in;
+    out.n = 0; // (nothing is interpreted)
+    for (int i = 0; i < CVGS_MAX_OPS; ++i) {
+        out.opcode[i] = 0;
+        out.aux[i] = 0;
+        for (int c = 0; c < 4; ++c) out.operand[i][c] = 0.f;
+    }
+    out.aux[0] = has_swap ? 1 : 0;
+    out.aux[1] = div_at >= 0 ? 1 : 0;
+    for (int s = 0; s < 4; ++s)
+        for (int c = 0; c < 4; ++c) {
+            float m = 1.0f, a = -0.0f;
+            if (lin[s] >= 0) {
+                const float o = in.operand[lin[s]][c];
+                if (in.opcode[lin[s]] == CVGS_OP_MUL) m = o;
+                else a = in.opcode[lin[s]] == CVGS_OP_ADD ? o : -o;
+            }
+            out.operand[s][c] = m;
+            out.operand[4 + s][c] = a;
+        }
+    out.fast_div = 0;
+    for (int c = 0; c < 4; ++c) out.rdiv[c] = 0.f;
+    if (div_at >= 0) {
+        bool fits = true;
+        for (int c = 0; c < 4; ++c) {
+            const float d = in.operand[div_at][c];
+            out.operand[8][c] = d;
+            if (c < cn) {
+                uint32_t bits;
+                std::memcpy(&bits, &d, 4);
+                const float a = std::fabs(d);
+                fits = fits && std::isfinite(d) && a >= std::ldexp(1.0f, -20) && a <= std::ldexp(1.0f, 20) && (bits & 0x7fffffu) != 0x7fffffu;
+            }
+        }
+        if (fits) {
+            for (int c = 0; c < cn; ++c) {
+                volatile float r = 1.0f / in.operand[div_at][c]; // IEEE single division on the host: the correctly rounded reciprocal
+                out.rdiv[c] = r;
+            }
+            out.fast_div = 1;
+        }
+    }
+    return true;
+}
+
 // program shape: [REORDER(swap R,B)] MUL SUB DIV, with the swap's permutation checked on the host
 inline int k1_classify_program(const ProgArgs& p, int cn) {
     if (cn < 3) return (p.n == 3 && p.opcode[0] == CVGS_OP_MUL && p.opcode[1] == CVGS_OP_SUB && p.opcode[2] == CVGS_OP_DIV) ? 1 : 2;

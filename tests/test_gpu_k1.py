@@ -283,15 +283,23 @@ def _arith_programs(f, cn):
         "zeros_through_div": [cvgs.multiply(f, k([0.0, -0.0, 1.0, 0.0])), cvgs.divide(f, k([3.2, 0.6, 11.8, 33.0])), cvgs.add(f, k([1.0] * 4))],  # +0 / -0 dividends: the wave divides for real
         "tiny_and_huge": [cvgs.multiply(f, k([1e-30, 1e12, 3e38, 1.0])), cvgs.divide(f, k([3.2, 0.6, 0.5, 33.0])), cvgs.subtract(f, k([1.0] * 4))],
         "refused_divisor": [cvgs.multiply(f, k([0.3] * 4)), cvgs.divide(f, k([float(np.float32(2.0) - np.float32(2.0 ** -23)), 2.0 ** 24, 11.8, 33.0]))],
+        "swap_only": [sw],
+        "div_only": [cvgs.divide(f, k([255.0, 127.5, 63.75, 2.0]))],
+        "scale_shift": [cvgs.multiply(f, k([1 / 255.0] * 4)), cvgs.add(f, k([-0.5, -0.25, 0.0, 0.5]))],
+        "full_shape": [sw, cvgs.subtract(f, k([104.0, 117.0, 123.0, 0.0])), cvgs.multiply(f, k([0.017, 0.0175, 0.0171, 1.0])), cvgs.divide(f, k([0.9, 1.1, 1.3, 2.0])),
+                       cvgs.add(f, k([0.1, 0.2, 0.3, 0.4])), cvgs.multiply(f, k([2.0, 0.5, -1.0, 1.0]))],
         "minus_zero_products": [cvgs.subtract(f, k([5.0] * 4)), cvgs.multiply(f, k([-0.0, 0.0, -0.0, 0.0])), cvgs.add(f, k([-0.0] * 4))],  # p * o with zero products: the fma form keeps their signs
     }
     return {n: [s for s in p if s is not None] for n, p in progs.items()}
 
 
-@pytest.mark.parametrize("name", ["norm_then_add", "sub_div_only", "div_first", "eight_stages", "zeros_through_div", "tiny_and_huge", "refused_divisor", "minus_zero_products"])
+@pytest.mark.parametrize("name", ["norm_then_add", "sub_div_only", "div_first", "eight_stages", "zeros_through_div", "tiny_and_huge", "refused_divisor", "minus_zero_products",
+                                  "swap_only", "div_only", "scale_shift", "full_shape"])
 @pytest.mark.parametrize("cn,ar,half", [(3, cvgs.IGNORE_AR, False), (4, cvgs.IGNORE_AR, False), (3, cvgs.PRESERVE_AR, False), (3, cvgs.IGNORE_AR, True)])
 def test_interpreted_arithmetic_programs(oracle, device, name, cn, ar, half):
-    """Resize chains whose program is NOT [swap,] mul, sub, div run K1's interpreted kernel; programs of MUL / ADD / SUB / DIV / REORDER stages take its
+    """Resize chains whose program is NOT [swap,] mul, sub, div: the canonical arithmetic shape ([swap] <= 2 linear stages [div] <= 2 linear stages) is
+    rewritten on the host into the straight-line K1CanonProg (every linear stage one fma with (o, -0) / (1, o) / (1, -o); the division by reciprocal
+    under the per-wave dividend check); anything else runs K1's interpreted kernel, programs of MUL / ADD / SUB / DIV / REORDER stages on its
     arithmetic path: the program's words fetched before the taps, MUL / ADD / SUB as one fma with selected operands (bit-identical to the plain operation,
     zero signs included), the vetted DIV stage by reciprocal when every dividend of the wave fits.  Against the oracle AND the forced generic kernel;
     aspect-ratio padding pushes the background value through the same program; the fp16 tensor takes the cast in the store."""
@@ -315,7 +323,9 @@ def test_interpreted_arithmetic_programs(oracle, device, name, cn, ar, half):
     out = torch.full((7, cn * 128 * 64), -777.0, dtype=ot, device=device)
     ref = np.full((7, cn * 128 * 64), -777.0, dtype=od)
     ops = build(cvgs.GpuMat.from_tensor(ft, u), cvgs.GpuMat.from_tensor(out, o1))
-    assert cvgs.kernel_name(*ops).endswith("_interp" + ("_f16" if half else "")), cvgs.kernel_name(*ops)
+    # chains of the canonical shape ([swap] <= 2 linear stages [div] <= 2 linear stages) run K1CanonProg, the others K1's interpreted program
+    want = "_interp" if name in ("eight_stages", "div_first") else "_arith"
+    assert cvgs.kernel_name(*ops).endswith(want + ("_f16" if half else "")), (name, cvgs.kernel_name(*ops))
     with np.errstate(all="ignore"):
         oracle.execute(cvgs.lower(build(cvgs.GpuMat.from_array(frame, u), cvgs.GpuMat.from_array(ref, o1))))
     cvgs.executeOperations(torch.cuda.current_stream(), *ops)

@@ -86,7 +86,7 @@ def test_planar_stretch(oracle, layout, shape, prog):
         shp, dt, ot = (dst[1], dst[0], 3), np.uint8, u
     else:
         shp, dt, ot = (1, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1
-    want = {"bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "rgb_norm": "k4_nv12_resize_mul_sub_div", "plain": "k4_nv12_resize_interp",
+    want = {"bgr_norm": "k4_nv12_resize_swap_mul_sub_div", "rgb_norm": "k4_nv12_resize_mul_sub_div", "plain": "k4_nv12_resize_arith",
             "u8": "k4_nv12_resize_u8c3"}[prog]
     ref, _ = run_both(oracle, mk(layout, surf), [surf], shp, dt, ot, want)
     # the same picture as NV12 (the reference's own format) gives the same output
@@ -305,3 +305,39 @@ def test_packed_float_image_outputs(oracle, layout, shape, cn, batch):
 
     shp = (n, dst[0] * dst[1], cn) if batch else (dst[1], dst[0], cn)
     run_both(oracle, build, [surf], shp, np.float32, f, "k4_nv12_resize_interp")
+
+
+# ---- round 6: the canonical arithmetic program on decoder surfaces (k_taps.hpp: K1CanonProg through launch_n12) ---------------------------------
+K4_ARITH = {
+    # name: (stages after the read, the kernel it must take)
+    "norm_then_add": (lambda f: [cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f), cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, [1.0, 4.0, 3.2]), cvgs.divide(f, [3.2, 0.6, 11.8]),
+                                 cvgs.add(f, [0.5, 0.25, 0.125])], "k4_nv12_resize_arith"),
+    "sub_div": (lambda f: [cvgs.subtract(f, [127.5] * 3), cvgs.divide(f, [58.4, 57.1, 57.4])], "k4_nv12_resize_arith"),
+    "div_only": (lambda f: [cvgs.divide(f, [255.0, 127.5, 2.0])], "k4_nv12_resize_arith"),
+    "swap_only": (lambda f: [cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f)], "k4_nv12_resize_arith"),
+    "nothing": (lambda f: [], "k4_nv12_resize_arith"),
+    "zero_products": (lambda f: [cvgs.multiply(f, [0.0, -0.0, 1.0]), cvgs.divide(f, [3.2, 0.6, 11.8]), cvgs.add(f, [-0.0] * 3)], "k4_nv12_resize_arith"),
+    "refused_divisor": (lambda f: [cvgs.divide(f, [2.0 ** 24, 0.6, float(np.float32(2.0) - np.float32(2.0 ** -23))])], "k4_nv12_resize_arith"),
+    "three_linear_before_div": (lambda f: [cvgs.add(f, [1.0] * 3), cvgs.multiply(f, [0.5] * 3), cvgs.subtract(f, [0.25] * 3), cvgs.divide(f, [3.0, 7.0, 9.0])], "k4_nv12_resize_interp"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(K4_ARITH))
+@pytest.mark.parametrize("layout,shape", [(capi.YUV_NV12, ((640, 360), (213, 120))), (capi.YUV_NV21, ((322, 198), (70, 66))), (capi.YUV_I420, ((640, 360), (64, 128))),
+                                          (capi.YUV_NV12, ((64, 36), (200, 150)))])
+def test_canonical_arithmetic_programs_on_decoder_surfaces(oracle, name, layout, shape):
+    """Decoder surface -> resize -> a program that is not one of K4's compile-time ones -> planar tensor: chains of the canonical arithmetic shape take the
+    straight-line K1CanonProg (one fma per linear stage, the division by reciprocal under the per-wave dividend check), others the interpreted
+    kernel; both against the oracle and the forced generic kernel, down- and up-scaling, limited-range BT.601 (black surfaces give zero dividends)."""
+    (w, h), dst = shape
+    stages, want = K4_ARITH[name]
+    surf = planar_surface(w, h, 8100 + w, layout)[0] if layout in PLANAR else H.random_u8((h * 3 // 2, w), 8100 + w)
+    surf[: h // 3] = 16  # a black band: Y = 16, with the limited-range matrix R = G = B = 0 for neutral chroma rows
+    f = cvgs.CV_32FC3
+
+    def build(wrap, out):
+        return [cvgs.read_nv12(luma_of(wrap, surf, w, h), dst, capi.YUV_LIMITED, capi.BT601, False, layout=layout)] + stages(f) + [cvgs.split(f, out, dst)]
+
+    with np.errstate(all="ignore"):
+        ref, got = run_both(oracle, build, [surf], (1, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1, want)
+    assert got == want

@@ -109,15 +109,24 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     if (prog_id < 2 && r.depth != CVGS_DEPTH_32F) fast_div_setup(c_mut.prog, prog_id == 0 ? 3 : 2, prog_id == 0 ? 1 : 0, r.cn, r.bg);
     // u8 C3 / C4 into a planar tensor: a chain of the canonical arithmetic shape ([swap] {mul|add|sub} x 0..2 [div] {mul|add|sub} x 0..2) is rewritten
     // into the straight-line K1CanonProg (k_taps.hpp); other programs run interpreted (arithmetic-only ones: InterpProgT<true>::run_arith, k_common.hpp)
+    // (planar tensors of 1-4 channels and packed fp32 / fp16 / u8 pixels; not the separate-plane mode, not the mirrored launches)
     int planar_prog = prog_id;
-    if (prog_id == 2 && planar && !few && r.depth == CVGS_DEPTH_8U && mirrors.n == 0) {
+    bool canon_packed = false;
+    if (prog_id == 2 && n_prog > 0 && r.depth == CVGS_DEPTH_8U && mirrors.n == 0 && (planar || packed) && !same_type_packed) {
         ProgArgs canon;
+        if (k1_canonicalise(c_mut.prog, r.cn, canon)) {
+            c_mut.prog = canon;
+            if (planar) planar_prog = 3;
+            else canon_packed = true;
+        }
+    } else if (prog_id == 2 && n_prog == 0 && planar && !few && r.depth == CVGS_DEPTH_8U && mirrors.n == 0) {
+        ProgArgs canon; // the EMPTY program into a planar tensor (resize -> split): the canonical pipeline of four identities beats the interpreted kernel's one row per wave
         if (k1_canonicalise(c_mut.prog, r.cn, canon)) {
             c_mut.prog = canon;
             planar_prog = 3;
         }
     }
-    if (prog_id == 2 && planar_prog == 2) interp_arith_setup(c_mut.prog, r.cn);
+    if (prog_id == 2 && planar_prog == 2 && !canon_packed) interp_arith_setup(c_mut.prog, r.cn);
 
     const int src = r.depth == CVGS_DEPTH_8U ? SRC_U8 : (r.depth == CVGS_DEPTH_16U ? SRC_U16 : (r.depth == CVGS_DEPTH_16S ? SRC_S16 : SRC_F32));
     // whole-frame resize -> cast -> packed pixels of the SOURCE's type with nothing in between (the reference's
@@ -166,10 +175,15 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         static const char* names_planes16[2][2] = {{"k1_u16c3_planes2d_f32", "k1_u16c4_planes2d_f32"}, {"k1_s16c3_planes2d_f32", "k1_s16c4_planes2d_f32"}};
         if (same_type_packed) info->kernel = names_same[src][r.cn - 1];
         else if (planes_16) info->kernel = names_planes16[src == SRC_S16][r.cn == 4];
-        else if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : names_few_packed[r.cn - 1][u8out];
+        else if (few && planar && planar_prog == 3) info->kernel = r.cn == 1 ? "k1_u8c1_arith" : "k1_u8c2_arith";
+        else if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : (canon_packed ? (u8out ? (r.cn == 1 ? "k1_u8c1_packed_u8_arith" : "k1_u8c2_packed_u8_arith") : (r.cn == 1 ? "k1_u8c1_packed_f32_arith" : "k1_u8c2_packed_f32_arith")) : names_few_packed[r.cn - 1][u8out]);
         else if (planar && planar_prog == 3) info->kernel = f16 ? (r.cn == 4 ? "k1_u8c4_arith_f16" : "k1_u8c3_arith_f16") : (r.cn == 4 ? "k1_u8c4_arith" : "k1_u8c3_arith");
         else if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
-        else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
+        else if (canon_packed) {
+            static const char* names_canon[2][3] = {{"k1_u8c3_packed_f32_arith", "k1_u8c3_packed_f16_arith", "k1_u8c3_packed_u8_arith"},
+                                                    {"k1_u8c4_packed_f32_arith", "k1_u8c4_packed_f16_arith", "k1_u8c4_packed_u8_arith"}};
+            info->kernel = names_canon[r.cn == 4][u8out ? 2 : (f16 ? 1 : 0)];
+        } else info->kernel = names_other[r.cn == 4][split2d ? 3 : (u8out ? 2 : (f16 ? 1 : 0))];
     }
     if (dry_run) return 1;
     LaunchCtx& s = ctx;
@@ -197,17 +211,17 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         e = r.cn == 3 ? launch_split2d_16<3>(src, table, rpw, c, inline_planes, n_inline, s)
                       : launch_split2d_16<4>(src, table, rpw, c, inline_planes, n_inline, s);
     } else if (few) {
-        e = r.cn == 1 ? launch_few<1>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s)
-                      : launch_few<2>(src, planar, u8out, prog_id, table, rpw, c, inline_planes, n_inline, s);
+        e = r.cn == 1 ? launch_few<1>(src, planar, u8out, planar_prog, table, rpw, c, inline_planes, n_inline, s, canon_packed)
+                      : launch_few<2>(src, planar, u8out, planar_prog, table, rpw, c, inline_planes, n_inline, s, canon_packed);
     } else if (!planar) {
         if (split2d) e = r.cn == 3 ? launch_split2d<3>(prog_id, table, rpw, c, inline_planes, n_inline, s)
                                    : launch_split2d<4>(prog_id, table, rpw, c, inline_planes, n_inline, s);
-        else if (u8out) e = r.cn == 3 ? launch_other_np<3, uint8_t, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s)
-                                      : launch_other_np<4, uint8_t, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s);
-        else if (f16) e = r.cn == 3 ? launch_other<3, _Float16, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s)
-                                    : launch_other<4, _Float16, WM_PACKED>(table, rpw, c, inline_planes, n_inline, s);
-        else e = r.cn == 3 ? launch_other_np<3, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s)
-                           : launch_other_np<4, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s);
+        else if (u8out) e = r.cn == 3 ? launch_other_np<3, uint8_t, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s, canon_packed)
+                                      : launch_other_np<4, uint8_t, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s, canon_packed);
+        else if (f16) e = r.cn == 3 ? launch_other_np<3, _Float16, WM_PACKED>(false, table, rpw, c, inline_planes, n_inline, s, canon_packed)
+                                    : launch_other_np<4, _Float16, WM_PACKED>(false, table, rpw, c, inline_planes, n_inline, s, canon_packed);
+        else e = r.cn == 3 ? launch_other_np<3, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s, canon_packed)
+                           : launch_other_np<4, float, WM_PACKED>(n_prog == 0, table, rpw, c, inline_planes, n_inline, s, canon_packed);
     } else if (r.cn == 3) {
         e = k1_launch_planar_c3(src, f16, planar_prog, table, rpw, c, inline_planes, n_inline, out_cn, s);
     } else {

@@ -480,8 +480,11 @@ static hipError_t launch_other(bool table, int rpw, const ChainArgs& c, const Pl
 }
 // the same with the program picked at run time: empty (nothing between the resize and the folded cast / the write) or interpreted
 template <int CN, typename OT, int WM, int SRC = SRC_U8>
-static hipError_t launch_other_np(bool none, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
+static hipError_t launch_other_np(bool none, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s, bool canon = false) {
     if (none) return launch_other<CN, OT, WM, ProgNone, SRC>(table, rpw, c, ip, ni, s);
+    if constexpr (SRC == SRC_U8 && WM == WM_PACKED) { // (k_taps.hpp: the chain was rewritten into the canonical arithmetic pipeline)
+        if (canon) return launch_other<CN, OT, WM, K1CanonProg, SRC>(table, rpw, c, ip, ni, s);
+    }
     return launch_other<CN, OT, WM, InterpProg, SRC>(table, rpw, c, ip, ni, s);
 }
 // 16-bit and CV_32F sources into packed pixels of the SOURCE's own type (the reference's single-image resize tests sweep
@@ -553,6 +556,13 @@ static hipError_t launch_prog(int prog_id, bool table, int rpw, const ChainArgs&
 template <int CN, int SRC>
 static hipError_t launch_few_planar(int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip, int ni, LaunchCtx& s) {
     const int r = rpw >= 4 ? 4 : 1;
+    if constexpr (SRC == SRC_U8) {
+        if (prog_id == 3) { // the canonical arithmetic pipeline (k_taps.hpp)
+            if (table) return r == 4 ? launch_t<CN, 0, 4, K1CanonProg, SRC, float>(c, ip, ni, CN, s) : launch_t<CN, 0, 1, K1CanonProg, SRC, float>(c, ip, ni, CN, s);
+            return r == 4 ? launch_t<CN, CVGS_KERNARG_PLANES, 4, K1CanonProg, SRC, float>(c, ip, ni, CN, s)
+                          : launch_t<CN, CVGS_KERNARG_PLANES, 1, K1CanonProg, SRC, float>(c, ip, ni, CN, s);
+        }
+    }
     if (prog_id == 1) {
         if (table) return r == 4 ? launch_t<CN, 0, 4, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s) : launch_t<CN, 0, 1, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s);
         return r == 4 ? launch_t<CN, CVGS_KERNARG_PLANES, 4, ProgMulSubDiv, SRC, float>(c, ip, ni, CN, s)
@@ -563,15 +573,15 @@ static hipError_t launch_few_planar(int prog_id, bool table, int rpw, const Chai
 }
 template <int CN>
 static hipError_t launch_few(int src, bool planar, bool u8out, int prog_id, bool table, int rpw, const ChainArgs& c, const PlaneParams* ip,
-                             int ni, LaunchCtx& s) {
+                             int ni, LaunchCtx& s, bool canon = false) {
     if (planar) {
         return src == SRC_U8    ? launch_few_planar<CN, SRC_U8>(prog_id, table, rpw, c, ip, ni, s)
                : src == SRC_U16 ? launch_few_planar<CN, SRC_U16>(prog_id, table, rpw, c, ip, ni, s)
                : src == SRC_S16 ? launch_few_planar<CN, SRC_S16>(prog_id, table, rpw, c, ip, ni, s)
                                 : launch_few_planar<CN, SRC_F32>(prog_id, table, rpw, c, ip, ni, s);
     }
-    if (u8out) return launch_other_np<CN, uint8_t, WM_PACKED>(c.prog.n == 0, table, rpw, c, ip, ni, s);
-    return launch_other_np<CN, float, WM_PACKED>(c.prog.n == 0, table, rpw, c, ip, ni, s);
+    if (u8out) return launch_other_np<CN, uint8_t, WM_PACKED>(c.prog.n == 0, table, rpw, c, ip, ni, s, canon);
+    return launch_other_np<CN, float, WM_PACKED>(c.prog.n == 0, table, rpw, c, ip, ni, s, canon);
 }
 
 

@@ -156,8 +156,7 @@ inline bool k1_canonicalise(const ProgArgs& in, int cn, ProgArgs& out) {
     if (k < in.n && in.opcode[k] == CVGS_OP_DIV) div_at = k++;
     for (int s = 2; s < 4 && k < in.n && is_lin(in.opcode[k]); ++s) lin[s] = k++;
     if (k != in.n) return false;
-    out = in;
-    out.n = 0; // (nothing is interpreted)
+    out = in; // (n stays: "is there a program at all" is still asked of it; nothing is interpreted)
     for (int i = 0; i < CVGS_MAX_OPS; ++i) {
         out.opcode[i] = 0;
         out.aux[i] = 0;

@@ -336,3 +336,50 @@ def test_interpreted_arithmetic_programs(oracle, device, name, cn, ar, half):
     cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
     torch.cuda.synchronize()
     H.assert_bit_exact(got, out.cpu().numpy(), "K1 interpreted vs the generic kernel")
+
+
+@pytest.mark.parametrize("name", ["sub_div_only", "scale_shift", "zeros_through_div", "full_shape"])
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+@pytest.mark.parametrize("target", ["planar", "packed_f32", "packed_u8"])
+def test_canonical_program_on_every_u8_target(oracle, device, name, cn, target):
+    """The canonical arithmetic program also serves 1- / 2-channel planar tensors and packed fp32 / u8 pixel targets of u8 sources (k_k1.hip: canon_packed):
+    grayscale "(x - mean) / std", brightness / contrast into a u8 image, ... -- against the oracle and the forced generic kernel."""
+    import torch
+    fh, fw = 200, 260
+    u, f = cvgs.make_type(cvgs.CV_8U, cn), cvgs.make_type(cvgs.CV_32F, cn)
+    frame = H.random_u8((fh, fw, cn), seed=7300 + cn)
+    frame[30:60, 40:160] = 0
+    crops = H.random_crops(5, fw, fh, seed=7400 + cn, wmin=3, wmax=200, hmin=3, hmax=150)
+    prog = [s for s in _arith_programs(f, cn)[name]]
+    dst = (64, 48)
+    if target == "planar":
+        shape, odt, tdt, ot = (5, cn * dst[0] * dst[1]), np.float32, torch.float32, cvgs.CV_32FC1
+    elif target == "packed_f32":
+        shape, odt, tdt, ot = (5, dst[0] * dst[1], cn), np.float32, torch.float32, f
+    else:
+        shape, odt, tdt, ot = (5, dst[0] * dst[1], cn), np.uint8, torch.uint8, u
+
+    def build(src_mat, out_mat):
+        ops = [cvgs.resize(u, cvgs.INTER_LINEAR, [src_mat.roi(*c) for c in crops], dst, 4, [10.0, 20.0, 30.0, 40.0][:cn], cvgs.PRESERVE_AR)] + list(prog)
+        if target == "planar":
+            return ops + [cvgs.split(f, out_mat, dst) if cn > 1 else cvgs.write(f, out_mat, dst)]
+        if target == "packed_u8":
+            ops.append(cvgs.convertTo(f, u))
+        return ops + [cvgs.write(ot, out_mat, dst)]
+
+    ft = torch.from_numpy(frame).to(device)
+    out = torch.zeros(shape, dtype=tdt, device=device)
+    ref = np.zeros(shape, dtype=odt)
+    ops = build(cvgs.GpuMat.from_tensor(ft, u), cvgs.GpuMat.from_tensor(out, ot))
+    kname = cvgs.kernel_name(*ops)
+    assert kname.startswith("k1_u8c%d" % cn) and kname.endswith("_arith"), kname
+    with np.errstate(all="ignore"):
+        oracle.execute(cvgs.lower(build(cvgs.GpuMat.from_array(frame, u), cvgs.GpuMat.from_array(ref, ot))))
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    H.assert_bit_exact(got, ref, "canonical program %s C%d -> %s" % (name, cn, target))
+    out.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(got, out.cpu().numpy(), "canonical vs the generic kernel")

@@ -66,7 +66,7 @@ def test_batch_resize_to_packed_float(cn, half):
 
     gpu, ref = _both(build, (n, dst[0] * dst[1], cn), np.float16 if half else np.float32)
     H.assert_bit_exact(gpu[0], ref[0], "batch resize -> packed float")
-    assert _name(build) == "k1_u8c%d_packed_%s" % (cn, "f16" if half else "f32")
+    assert _name(build) == "k1_u8c%d_packed_%s_arith" % (cn, "f16" if half else "f32")  # (multiply, add: the canonical arithmetic program, round 6)
 
 
 @pytest.mark.parametrize("cn,batch", [(3, 1), (4, 2), (3, 9)])

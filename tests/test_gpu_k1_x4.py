@@ -183,7 +183,7 @@ def test_x4_leaves_what_it_does_not_cover(forced):
 
     gpu, ref = _both(with_program, (200, 320, cn), np.float32)
     H.assert_bit_exact(gpu[0], ref[0], "program between resize and write")
-    assert _name(with_program) == "k1_u8c3_packed_f32"
+    assert _name(with_program) == "k1_u8c3_packed_f32_arith"  # (the canonical arithmetic program, round 6)
     build, oshape, odt = _chain(src, cn, (320, 200), False)
     gpu, ref = _both(build, oshape, odt)
     H.assert_bit_exact(gpu[0], ref[0], "packed fp32 target")

@@ -288,13 +288,14 @@ def _arith_programs(f, cn):
         "scale_shift": [cvgs.multiply(f, k([1 / 255.0] * 4)), cvgs.add(f, k([-0.5, -0.25, 0.0, 0.5]))],
         "full_shape": [sw, cvgs.subtract(f, k([104.0, 117.0, 123.0, 0.0])), cvgs.multiply(f, k([0.017, 0.0175, 0.0171, 1.0])), cvgs.divide(f, k([0.9, 1.1, 1.3, 2.0])),
                        cvgs.add(f, k([0.1, 0.2, 0.3, 0.4])), cvgs.multiply(f, k([2.0, 0.5, -1.0, 1.0]))],
+        "denormals": [cvgs.multiply(f, k([1e-40, 3e-41, 1e-39, 1e-42])), cvgs.add(f, k([1e-39, -1e-40, 0.0, 1e-41])), cvgs.multiply(f, k([0.5, 0.25, 1.5, 0.75]))],  # subnormal operands, products and sums
         "minus_zero_products": [cvgs.subtract(f, k([5.0] * 4)), cvgs.multiply(f, k([-0.0, 0.0, -0.0, 0.0])), cvgs.add(f, k([-0.0] * 4))],  # p * o with zero products: the fma form keeps their signs
     }
     return {n: [s for s in p if s is not None] for n, p in progs.items()}
 
 
 @pytest.mark.parametrize("name", ["norm_then_add", "sub_div_only", "div_first", "eight_stages", "zeros_through_div", "tiny_and_huge", "refused_divisor", "minus_zero_products",
-                                  "swap_only", "div_only", "scale_shift", "full_shape"])
+                                  "swap_only", "div_only", "scale_shift", "full_shape", "denormals"])
 @pytest.mark.parametrize("cn,ar,half", [(3, cvgs.IGNORE_AR, False), (4, cvgs.IGNORE_AR, False), (3, cvgs.PRESERVE_AR, False), (3, cvgs.IGNORE_AR, True)])
 def test_interpreted_arithmetic_programs(oracle, device, name, cn, ar, half):
     """Resize chains whose program is NOT [swap,] mul, sub, div: the canonical arithmetic shape ([swap] <= 2 linear stages [div] <= 2 linear stages) is

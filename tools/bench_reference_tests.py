@@ -197,6 +197,53 @@ def batchread_write3d_ticks(cn, batch=50, tick=16):
         print(json.dumps(row), flush=True)
 
 
+def k1_tick_other_spelling(tick=16, n_frames=32):
+    """the headline's tick (16 frames x 50 variable crops per cvgs_execute_many launch, graph-replayed, 32 frames in rotation) with a chain that is NOT
+    the reference's own spelling -- one more `add` behind the normalisation: the canonical arithmetic program (round 6; the interpreted kernel: 60 us)"""
+    f = cvgs.CV_32FC3
+    sets, keep, ops = [], [], None
+    for t in range(n_frames // tick):
+        low = []
+        for m in range(tick):
+            k = t * tick + m
+            frame = W.random_u8_torch((H4K, W4K, 3), 1000 + k, dev)
+            crops = W.random_crops(50, W4K, H4K, seed=500000 + k)
+            out = torch.zeros((50, 3 * 128 * 64), dtype=torch.float32, device=dev)
+            src = cvgs.GpuMat.from_tensor(frame, cvgs.CV_8UC3)
+            ops = [cvgs.resize(cvgs.CV_8UC3, cvgs.INTER_LINEAR, [src.roi(*c) for c in crops], (64, 128), 50), cvgs.cvtColor(cvgs.COLOR_RGB2BGR, f),
+                   cvgs.multiply(f, [0.3] * 3), cvgs.subtract(f, W.K1_SUB[3]), cvgs.divide(f, W.K1_DIV[3]), cvgs.add(f, [0.5, 0.25, 0.125]),
+                   cvgs.split(f, cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1), (64, 128))]
+            low.append(cvgs.lower(ops))
+            keep.append((frame, out))
+        sets.append((low, cvgs.pack_chains(low)))
+    side = torch.cuda.Stream()
+    reps = 8
+    for low, arr in sets:
+        capi.check(lib.cvgs_execute_many(arr, tick, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(reps):
+            for low, arr in sets:
+                capi.check(lib.cvgs_execute_many(arr, tick, torch.cuda.current_stream().cuda_stream))
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / (reps * len(sets)))
+    t = sorted(ts)[1]
+    row = {"test": "headline tick (16 x 50 crops) with one more stage behind the normalisation (canonical arithmetic program), per tick", "kernel": cvgs.kernel_name(*ops),
+           "us": round(t * 1e6, 2)}
+    ROWS.append(row)
+    if VERBOSE:
+        print(json.dumps(row), flush=True)
+
+
 def resize_write(depth, cn, dst, pitched=False):
     """pitched: the output's rows start on 512-byte boundaries, as cv::cuda::GpuMat / fk::Ptr2D allocate them (cudaMallocPitch) -- what the reference's own
     test writes into; the default (dense rows: 3870 * 3 bytes is not even a multiple of 4) is the harder case."""
@@ -265,6 +312,7 @@ def run_all(verbose=True):
         batchread_write3d(depth, cn)
     for cn in (3, 4):
         batchread_write3d_ticks(cn)
+    k1_tick_other_spelling()
     for depth, cn in (("8U", 1), ("8U", 3), ("8U", 4), ("16U", 3), ("16S", 1), ("32F", 1)):
         resize_write(depth, cn, (3870, 2260))
         resize_write(depth, cn, (300, 500))

@@ -237,8 +237,9 @@ def k1_tick_other_spelling(tick=16, n_frames=32):
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e-3 / (reps * len(sets)))
     t = sorted(ts)[1]
+    b = sum(W.k1_algorithmic_bytes(W.random_crops(50, W4K, H4K, seed=500000 + k)) for k in range(tick))  # SURVEY 8d's bytes of the first tick's crops
     row = {"test": "headline tick (16 x 50 crops) with one more stage behind the normalisation (canonical arithmetic program), per tick", "kernel": cvgs.kernel_name(*ops),
-           "us": round(t * 1e6, 2)}
+           "us": round(t * 1e6, 2), "GB_per_s": round(b / t / 1e9, 1), "frac_of_8TBs": round(b / t / 8e12, 4)}
     ROWS.append(row)
     if VERBOSE:
         print(json.dumps(row), flush=True)

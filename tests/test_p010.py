@@ -227,3 +227,36 @@ def test_gpu_p010_crops_of_a_surface_in_one_launch(oracle):
     torch.cuda.synchronize()
     oracle.execute(cvgs.lower(ops(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_16UC1), cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
     H.assert_bit_exact(gt.cpu().numpy(), ref, "P010 crops via %s" % cvgs.kernel_name(*chain_gpu))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dst", [(213, 120), (800, 450)])
+def test_gpu_p010_canonical_arithmetic_program(oracle, dst):
+    """10-bit surface -> resize -> a chain that is not K4's compile-time program (scale, subtract, divide, add) -> planar tensor: the canonical
+    arithmetic program (k_taps.hpp: K1CanonProg) on 16-bit taps, bit for bit against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h = 640, 360
+    surf, _ = p010_surface(w, h, 95, low_bits=True)
+    f = cvgs.CV_32FC3
+
+    def build(wrap, out):
+        m = wrap(surf)
+        luma = cvgs.GpuMat(h, w, cvgs.CV_16UC1, m.data, m.step, owner=m.owner)
+        return [cvgs.read_nv12(luma, dst, capi.YUV_LIMITED, capi.BT2020, False, layout=capi.YUV_P010), cvgs.multiply(f, [1 / 1023.0] * 3),
+                cvgs.subtract(f, [0.485, 0.456, 0.406]), cvgs.divide(f, [0.229, 0.224, 0.225]), cvgs.add(f, [0.5, 0.25, 0.125]), cvgs.split(f, out, dst)]
+
+    st = torch.from_numpy(surf.view(np.int16)).to(dev)
+    gt = torch.zeros((1, 3 * dst[0] * dst[1]), dtype=torch.float32, device=dev)
+    ref = np.zeros((1, 3 * dst[0] * dst[1]), np.float32)
+    ops = build(lambda a: cvgs.GpuMat.from_tensor(st, cvgs.CV_16UC1), cvgs.GpuMat.from_tensor(gt, cvgs.CV_32FC1))
+    assert cvgs.kernel_name(*ops) == "k4_nv12_resize_arith", cvgs.kernel_name(*ops)
+    oracle.execute(cvgs.lower(build(lambda a: cvgs.GpuMat.from_array(a, cvgs.CV_16UC1), cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    got = gt.cpu().numpy()
+    H.assert_bit_exact(got, ref, "P010 canonical arithmetic program")
+    gt.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(got, gt.cpu().numpy(), "canonical vs the generic kernel")

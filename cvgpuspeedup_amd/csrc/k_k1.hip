@@ -112,14 +112,15 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
     // (planar tensors of 1-4 channels and packed fp32 / fp16 / u8 pixels; not the separate-plane mode, not the mirrored launches)
     int planar_prog = prog_id;
     bool canon_packed = false;
-    if (prog_id == 2 && n_prog > 0 && r.depth == CVGS_DEPTH_8U && mirrors.n == 0 && (planar || packed) && !same_type_packed) {
+    const bool canon_src = r.depth == CVGS_DEPTH_8U || (planar && !few); // (16-bit and fp32 sources: the 3- / 4-channel planar-tensor kernels)
+    if (prog_id == 2 && n_prog > 0 && canon_src && mirrors.n == 0 && (planar || packed) && !same_type_packed) {
         ProgArgs canon;
         if (k1_canonicalise(c_mut.prog, r.cn, canon)) {
             c_mut.prog = canon;
             if (planar) planar_prog = 3;
             else canon_packed = true;
         }
-    } else if (prog_id == 2 && n_prog == 0 && planar && !few && r.depth == CVGS_DEPTH_8U && mirrors.n == 0) {
+    } else if (prog_id == 2 && n_prog == 0 && planar && !few && mirrors.n == 0) {
         ProgArgs canon; // the EMPTY program into a planar tensor (resize -> split): the canonical pipeline of four identities beats the interpreted kernel's one row per wave
         if (k1_canonicalise(c_mut.prog, r.cn, canon)) {
             c_mut.prog = canon;
@@ -177,7 +178,10 @@ int launch_k1(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_inl
         else if (planes_16) info->kernel = names_planes16[src == SRC_S16][r.cn == 4];
         else if (few && planar && planar_prog == 3) info->kernel = r.cn == 1 ? "k1_u8c1_arith" : "k1_u8c2_arith";
         else if (few) info->kernel = planar ? names_few[src][r.cn - 1][prog_id - 1] : (canon_packed ? (u8out ? (r.cn == 1 ? "k1_u8c1_packed_u8_arith" : "k1_u8c2_packed_u8_arith") : (r.cn == 1 ? "k1_u8c1_packed_f32_arith" : "k1_u8c2_packed_f32_arith")) : names_few_packed[r.cn - 1][u8out]);
-        else if (planar && planar_prog == 3) info->kernel = f16 ? (r.cn == 4 ? "k1_u8c4_arith_f16" : "k1_u8c3_arith_f16") : (r.cn == 4 ? "k1_u8c4_arith" : "k1_u8c3_arith");
+        else if (planar && planar_prog == 3) {
+            static const char* names_arith[4][2] = {{"k1_u8c3_arith", "k1_u8c4_arith"}, {"k1_u16c3_arith", "k1_u16c4_arith"}, {"k1_s16c3_arith", "k1_s16c4_arith"}, {"k1_f32c3_arith", "k1_f32c4_arith"}};
+            info->kernel = f16 ? (r.cn == 4 ? "k1_u8c4_arith_f16" : "k1_u8c3_arith_f16") : names_arith[src][r.cn == 4];
+        }
         else if (planar) info->kernel = f16 ? names16[r.cn == 4][prog_id] : names[src][r.cn == 4][prog_id];
         else if (canon_packed) {
             static const char* names_canon[2][3] = {{"k1_u8c3_packed_f32_arith", "k1_u8c3_packed_f16_arith", "k1_u8c3_packed_u8_arith"},

@@ -545,9 +545,7 @@ static hipError_t launch_prog(int prog_id, bool table, int rpw, const ChainArgs&
                               LaunchCtx& s) {
     if (prog_id == 0) return launch_npl<CN, ProgSwapMulSubDiv, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
     if (prog_id == 1) return launch_npl<CN, ProgMulSubDiv, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
-    if constexpr (SRC == SRC_U8) {
-        if (prog_id == 3) return launch_npl<CN, K1CanonProg, SRC, OT>(table, rpw, c, ip, ni, out_cn, s); // (k_taps.hpp: the canonical arithmetic pipeline)
-    }
+    if (prog_id == 3) return launch_npl<CN, K1CanonProg, SRC, OT>(table, rpw, c, ip, ni, out_cn, s); // (k_taps.hpp: the canonical arithmetic pipeline)
     return launch_npl<CN, InterpProgArith, SRC, OT>(table, rpw, c, ip, ni, out_cn, s);
 }
 

@@ -384,3 +384,43 @@ def test_canonical_program_on_every_u8_target(oracle, device, name, cn, target):
     cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
     torch.cuda.synchronize()
     H.assert_bit_exact(got, out.cpu().numpy(), "canonical vs the generic kernel")
+
+
+@pytest.mark.parametrize("name", ["sub_div_only", "norm_then_add", "zeros_through_div", "full_shape", "eight_stages"])
+@pytest.mark.parametrize("depth,cn", [("16U", 3), ("16U", 4), ("16S", 3), ("32F", 3), ("32F", 4)])
+def test_canonical_program_on_other_source_depths(oracle, device, name, depth, cn):
+    """16-bit and fp32 sources into planar tensors take the canonical arithmetic program too (fp32 frames with infinities among the pixels: the
+    per-wave dividend check sends those waves to the real division)."""
+    import torch
+    from tests import kat_runner as K
+    fh, fw = 180, 240
+    st, f = cvgs.make_type(K.CV_DEPTH[depth], cn), cvgs.make_type(cvgs.CV_32F, cn)
+    if depth == "32F":
+        frame = (H.random_u16((fh, fw, cn), 7500 + cn).astype(np.float32) / 64.0 - 300.0).astype(np.float32)
+        frame[100:110, 50:90] = np.inf
+    else:
+        frame = H.random_u16((fh, fw, cn), 7500 + cn).view(K.NP_DEPTH[depth]).copy()
+    frame[20:50, 30:150] = 0
+    crops = H.random_crops(5, fw, fh, seed=7600 + cn, wmin=3, wmax=200, hmin=3, hmax=150)
+    prog = _arith_programs(f, cn)[name]
+    dst = (64, 48)
+
+    def build(src_mat, out_mat):
+        return [cvgs.resize(st, cvgs.INTER_LINEAR, [src_mat.roi(*c) for c in crops], dst, 4, [10.0, 20.0, 30.0, 40.0][:cn], cvgs.PRESERVE_AR)] + list(prog) + [cvgs.split(f, out_mat, dst)]
+
+    ft = torch.from_numpy(frame.view(np.int16) if depth == "16U" else frame).to(device)
+    out = torch.zeros((5, cn * dst[0] * dst[1]), dtype=torch.float32, device=device)
+    ref = np.zeros((5, cn * dst[0] * dst[1]), np.float32)
+    ops = build(cvgs.GpuMat.from_tensor(ft, st), cvgs.GpuMat.from_tensor(out, cvgs.CV_32FC1))
+    want = "_interp" if name == "eight_stages" else "_arith"
+    assert cvgs.kernel_name(*ops).endswith(want), cvgs.kernel_name(*ops)
+    with np.errstate(all="ignore"):
+        oracle.execute(cvgs.lower(build(cvgs.GpuMat.from_array(frame, st), cvgs.GpuMat.from_array(ref, cvgs.CV_32FC1))))
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    H.assert_bit_exact(got, ref, "canonical program %s on %sC%d" % (name, depth, cn))
+    out.zero_()
+    cvgs.executeOperations(torch.cuda.current_stream(), *ops, flags=capi.CHAIN_FORCE_GENERIC)
+    torch.cuda.synchronize()
+    H.assert_bit_exact(got, out.cpu().numpy(), "canonical vs the generic kernel")

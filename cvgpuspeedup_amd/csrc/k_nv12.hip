@@ -600,17 +600,26 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     if (u8img) {
         c8.prog.n -= 1;
         c8.prog.fast_div = 0;
+        bool canon8 = false; // brightness / contrast on the way to a u8 image, ...: the canonical arithmetic program (k_taps.hpp)
+        if (u8_prog == 2) {
+            ProgArgs canon;
+            if (k1_canonicalise(c8.prog, r.out_cn, canon)) {
+                c8.prog = canon;
+                canon8 = true;
+            }
+        }
         N12Geom g8{};
         g8.dst_w = r.dst_w; g8.dst_h = r.dst_h; g8.out_w = w.width; g8.cn = r.out_cn;
         g8.out = w.data; g8.out_step = w.step; g8.packed = 1;
         if (info)
-            info->kernel = r.out_cn == 3 ? (u8_prog == 0 ? "k4_nv12_resize_u8c3" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c3" : "k4_nv12_resize_interp_u8c3"))
-                                         : (u8_prog == 0 ? "k4_nv12_resize_u8c4" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c4" : "k4_nv12_resize_interp_u8c4"));
+            info->kernel = r.out_cn == 3 ? (u8_prog == 0 ? "k4_nv12_resize_u8c3" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c3" : (canon8 ? "k4_nv12_resize_arith_u8c3" : "k4_nv12_resize_interp_u8c3")))
+                                         : (u8_prog == 0 ? "k4_nv12_resize_u8c4" : (u8_prog == 1 ? "k4_nv12_resize_swap_u8c4" : (canon8 ? "k4_nv12_resize_arith_u8c4" : "k4_nv12_resize_interp_u8c4")));
         if (dry_run) return 1;
         const N12Many s8{&ctx, nullptr, 0, nullptr, 0};
         const bool win8 = r.used != r.batch || !k4_planes_eligible(inline_planes, n_inline, r.dst_w, r.dst_h);
         const hipError_t e8 = u8_prog == 0   ? launch_n12<ProgNone, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
                               : u8_prog == 1 ? launch_n12<K1Prog<kOpSwapRB>, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
+                              : canon8       ? launch_n12<K1CanonProg, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8)
                                              : launch_n12<InterpProg, uint8_t>(c8, inline_planes, n_inline, g8, s8, win8);
         return e8 == hipSuccess ? 1 : -(int)e8 - 1000;
     }
@@ -648,7 +657,7 @@ int launch_nv12(const ChainArgs& c_in, const PlaneParams* inline_planes, int n_i
     // any other chain of the canonical arithmetic shape ([swap] {mul|add|sub} x 0..2 [div] {mul|add|sub} x 0..2): the straight-line K1CanonProg
     // (k_taps.hpp; round 6 -- a tick of 16 surfaces x 50 crops with one more `add` ran 58 us interpreted against 37 for the compile-time program)
     bool canon_prog = false;
-    if (!fast_prog && !(fast_rgb && !f16) && planar) {
+    if (!fast_prog && !(fast_rgb && !f16)) { // (planar tensors and packed fp32 / fp16 pixels alike)
         ProgArgs canon;
         if (k1_canonicalise(c_fd.prog, r.out_cn, canon)) {
             c_fd.prog = canon;

@@ -304,7 +304,7 @@ def test_packed_float_image_outputs(oracle, layout, shape, cn, batch):
         return [rd, cvgs.multiply(f, [0.5, 0.25, 2.0, 1.5][:cn]), cvgs.write(f, out, dst) if batch else cvgs.write(f, out)]
 
     shp = (n, dst[0] * dst[1], cn) if batch else (dst[1], dst[0], cn)
-    run_both(oracle, build, [surf], shp, np.float32, f, "k4_nv12_resize_interp")
+    run_both(oracle, build, [surf], shp, np.float32, f, "k4_nv12_resize_arith")  # (multiply: the canonical arithmetic program, round 6)
 
 
 # ---- round 6: the canonical arithmetic program on decoder surfaces (k_taps.hpp: K1CanonProg through launch_n12) ---------------------------------
@@ -341,3 +341,21 @@ def test_canonical_arithmetic_programs_on_decoder_surfaces(oracle, name, layout,
     with np.errstate(all="ignore"):
         ref, got = run_both(oracle, build, [surf], (1, 3 * dst[0] * dst[1]), np.float32, cvgs.CV_32FC1, want)
     assert got == want
+
+
+@pytest.mark.parametrize("layout", [capi.YUV_NV12, capi.YUV_I420])
+@pytest.mark.parametrize("cn", [3, 4])
+def test_canonical_program_into_a_u8_image(oracle, layout, cn):
+    """Decoder surface -> resize -> swap, multiply, add (brightness / contrast) -> SaturateCast -> packed u8 image: the canonical arithmetic program in front
+    of the store's conversion (kernel k4_nv12_resize_arith_u8cN), against the oracle and the forced generic kernel."""
+    (w, h), dst = (640, 360), (213, 120)
+    surf = planar_surface(w, h, 8300 + cn, layout)[0] if layout in PLANAR else H.random_u8((h * 3 // 2, w), 8300 + cn)
+    f, u = cvgs.make_type(cvgs.DEPTH_32F, cn), cvgs.make_type(cvgs.DEPTH_8U, cn)
+    swap = cvgs.COLOR_RGB2BGR if cn == 3 else cvgs.COLOR_RGBA2BGRA
+
+    def build(wrap, out):
+        return [cvgs.read_nv12(luma_of(wrap, surf, w, h), dst, capi.YUV_FULL, capi.BT709, cn == 4, layout=layout), cvgs.cvtColor(swap, f),
+                cvgs.multiply(f, [1.25, 0.75, 1.1, 1.0][:cn]), cvgs.add(f, [-12.5, 20.0, 0.25, 0.0][:cn]), cvgs.convertTo(f, u), cvgs.write(u, out)]
+
+    ref, name = run_both(oracle, build, [surf], (dst[1], dst[0], cn), np.uint8, u, "k4_nv12_resize_arith_u8c%d" % cn)
+    assert name == "k4_nv12_resize_arith_u8c%d" % cn
